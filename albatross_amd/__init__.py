@@ -1,0 +1,13 @@
+"""MI355X-native dense Gaussian-process fit/predict engine (albatross hot path).
+
+Host-side mirror of albatross's GaussianProcessRegression / CovarianceFunction
+call surface over the C-ABI in include/albatross_amd.h.  All Gram / factor /
+solve / predict arithmetic runs in the HIP library; there is no CPU fallback.
+"""
+from .covariance import (AngularDistance, Constant, CovarianceFunction, EuclideanDistance, Exponential,
+                         FeatureSet, IndependentNoise, Matern32, Matern52, Measurement, MeasurementOnly,
+                         Nugget, Polynomial, ProductOfCovarianceFunctions, RadialDistance, ScalingFunction,
+                         ScalingTerm, SquaredExponential, SumOfCovarianceFunctions, as_measurements,
+                         measurement_only)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

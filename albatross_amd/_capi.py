@@ -1,0 +1,126 @@
+"""ctypes declarations of the C-ABI in include/albatross_amd.h.
+
+Only the struct layouts and the loader live here; they are shared by the
+product wrapper (which loads libalbatross_amd.so and nothing else) and by the
+test-side oracle wrapper (oracle/oracle_py.py, which reuses the struct types).
+"""
+import ctypes as C
+import os
+
+AGP_OK = 0
+AGP_ERR_INVALID_ARGUMENT = 1
+AGP_ERR_NAN_INPUT = 2
+AGP_ERR_NOT_POSITIVE_DEFINITE = 3
+AGP_ERR_HIP = 4
+AGP_ERR_COMM = 5
+AGP_ERR_UNSUPPORTED = 6
+AGP_ERR_NO_DEVICE = 7
+
+OP_SQUARED_EXPONENTIAL = 1
+OP_EXPONENTIAL = 2
+OP_MATERN32 = 3
+OP_MATERN52 = 4
+OP_CONSTANT = 5
+OP_INDEPENDENT_NOISE = 6
+OP_NUGGET = 7
+OP_POLYNOMIAL = 8
+OP_SCALING = 9
+OP_SUM = 10
+OP_PRODUCT = 11
+OP_MEASUREMENT_ONLY = 12
+
+METRIC_EUCLIDEAN = 0
+METRIC_RADIAL = 1
+METRIC_ANGULAR = 2
+
+HOST = 0
+DEVICE = 1
+
+MAX_KERNEL_NODES = 32
+MAX_STACK = 8
+MAX_DIM = 8
+MAX_SCALE_COLUMNS = 4
+
+
+class KernelNode(C.Structure):
+    _fields_ = [
+        ("op", C.c_int32),
+        ("metric", C.c_int32),
+        ("column", C.c_int32),
+        ("order", C.c_int32),
+        ("params", C.c_double * 4),
+    ]
+
+
+class Features(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("dim", C.c_int32),
+        ("n_scale_columns", C.c_int32),
+        ("coords", C.c_void_p),
+        ("eq_id", C.c_void_p),
+        ("scales", C.c_void_p),
+        ("is_measurement", C.c_int32),
+        ("location", C.c_int32),
+    ]
+
+
+# every symbol include/albatross_amd.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_D = C.POINTER(C.c_double)
+EXPORTS = [
+    ("agp_context_create", C.c_int, [C.c_int, _PP]),
+    ("agp_context_destroy", None, [_P]),
+    ("agp_context_synchronize", C.c_int, [_P]),
+    ("agp_last_error", C.c_char_p, [_P]),
+    ("agp_status_string", C.c_char_p, [C.c_int]),
+    ("agp_device_count", C.c_int, []),
+    ("agp_kernel_create", C.c_int, [C.POINTER(KernelNode), C.c_int, _PP]),
+    ("agp_kernel_destroy", None, [_P]),
+    ("agp_gram", C.c_int, [_P, _P, C.POINTER(Features), C.POINTER(Features), _P, C.c_int64, C.c_int]),
+    ("agp_fit_create", C.c_int, [_P, _P, C.POINTER(Features), _P, _P, _PP, _P, _P]),
+    ("agp_fit_destroy", None, [_P]),
+    ("agp_fit_size", C.c_int64, [_P]),
+    ("agp_fit_failed_pivot", C.c_int64, [_P]),
+    ("agp_fit_log_determinant", C.c_int, [_P, _D]),
+    ("agp_fit_download_factor", C.c_int, [_P, _P, _P, C.c_int64]),
+    ("agp_fit_download_information", C.c_int, [_P, _P, _P]),
+    ("agp_nll", C.c_int, [_P, _P, C.POINTER(Features), _P, _P, _D]),
+    ("agp_solve", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int]),
+    ("agp_predict_mean", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, C.c_int]),
+    ("agp_predict_marginal", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
+    ("agp_predict_joint", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
+    ("agp_last_stage_ms", C.c_int, [_P, C.c_int, _D]),
+    ("agp_set_profiling", C.c_int, [_P, C.c_int]),
+    ("agp_mfma_f64_peak", C.c_int, [_P, C.c_int, _D]),
+]
+
+LIB_NAME = "libalbatross_amd.so"
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library.  There is no CPU fallback: a missing or
+    unloadable library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). albatross_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, restype, argtypes in EXPORTS:
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is absent
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

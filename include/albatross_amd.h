@@ -1,0 +1,210 @@
+/*
+ * albatross_amd.h — C-ABI of the MI355X-native dense Gaussian-process engine.
+ *
+ * This is the drop-in boundary for the dense GP hot path of swift-nav/albatross
+ * (Gram build -> LL^T factor -> solve -> log-marginal-likelihood -> predict).
+ * The reference is a header-only C++ template library with no FFI of its own;
+ * each entry point below names the reference function (file:line, relative to
+ * the albatross checkout) whose work it replaces.  Plain pointers and sizes
+ * only; opaque handles; int status returns; no exceptions cross this boundary.
+ *
+ * Matrix layout: column-major fp64, exactly like Eigen::MatrixXd.
+ * Feature layout: row-major n x dim fp64 (array-of-structs, like
+ * std::vector<Eigen::Vector3d> / std::vector<double>).
+ */
+#ifndef ALBATROSS_AMD_H
+#define ALBATROSS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+typedef enum {
+  AGP_OK = 0,
+  AGP_ERR_INVALID_ARGUMENT = 1,
+  /* the assembled covariance holds a NaN: ALBATROSS_ASSERT(!cov.hasNaN()),
+   * include/albatross/src/models/gp.hpp:66 */
+  AGP_ERR_NAN_INPUT = 2,
+  /* un-pivoted LL^T met a pivot <= 0 (the reference's pivoted LDL^T tolerates
+   * semi-definite input; callers fall back to their CPU path on this code) */
+  AGP_ERR_NOT_POSITIVE_DEFINITE = 3,
+  AGP_ERR_HIP = 4,
+  AGP_ERR_COMM = 5,
+  AGP_ERR_UNSUPPORTED = 6,
+  AGP_ERR_NO_DEVICE = 7
+} agp_status;
+
+/* ---- covariance-function descriptor ------------------------------------- */
+/* One node of a postfix (reverse-Polish) program describing a composed
+ * CovarianceFunction.  Leaves push one value, SUM / PRODUCT pop two and push
+ * one, MEASUREMENT_ONLY pops one and pushes one. */
+typedef enum {
+  /* sigma^2 exp(-(d/l)^2); params = {length_scale, sigma}
+   * src/covariance_functions/radial.hpp:25-33,131-189 */
+  AGP_OP_SQUARED_EXPONENTIAL = 1,
+  /* sigma^2 exp(-|d/l|);   radial.hpp:191-198,239-287 */
+  AGP_OP_EXPONENTIAL = 2,
+  /* sigma^2 (1+q) exp(-q), q = sqrt(3) d/l; radial.hpp:289-297,421-459 */
+  AGP_OP_MATERN32 = 3,
+  /* sigma^2 (1+q+q^2/3) exp(-q), q = sqrt(5) d/l; radial.hpp:461-470,491-529 */
+  AGP_OP_MATERN52 = 4,
+  /* sigma^2; params = {sigma}; polynomials.hpp:31-61 */
+  AGP_OP_CONSTANT = 5,
+  /* sigma^2 iff x == y (by value / eq_id); params = {sigma}; noise.hpp:20-44 */
+  AGP_OP_INDEPENDENT_NOISE = 6,
+  /* sigma^2 iff x == y; params = {sigma}; nugget.hpp:32-49 */
+  AGP_OP_NUGGET = 7,
+  /* sum_p sigma_p^2 x^p y^p on 1-D features, p = 0..order (order <= 3);
+   * params = {sigma_0..sigma_order}; polynomials.hpp:63-90 */
+  AGP_OP_POLYNOMIAL = 8,
+  /* f(x) f(y) with f precomputed per point in scale column `column`;
+   * scaling_function.hpp:58-112 */
+  AGP_OP_SCALING = 9,
+  /* lhs + rhs; covariance_function.hpp:266-272 */
+  AGP_OP_SUM = 10,
+  /* lhs * rhs, rhs skipped when lhs == 0; covariance_function.hpp:357-367 */
+  AGP_OP_PRODUCT = 11,
+  /* sub-covariance iff BOTH arguments are Measurement<>, else 0;
+   * measurement.hpp:70-106 */
+  AGP_OP_MEASUREMENT_ONLY = 12
+} agp_op;
+
+typedef enum {
+  AGP_METRIC_EUCLIDEAN = 0, /* distance_metrics.hpp:30-45 */
+  AGP_METRIC_RADIAL = 1,    /* distance_metrics.hpp:47-62 */
+  AGP_METRIC_ANGULAR = 2    /* distance_metrics.hpp:64-90 */
+} agp_metric;
+
+#define AGP_MAX_KERNEL_NODES 32
+#define AGP_MAX_STACK 8
+#define AGP_MAX_DIM 8
+#define AGP_MAX_SCALE_COLUMNS 4
+
+typedef struct {
+  int32_t op;     /* agp_op */
+  int32_t metric; /* agp_metric, radial leaves only */
+  int32_t column; /* AGP_OP_SCALING: which scale column */
+  int32_t order;  /* AGP_OP_POLYNOMIAL: polynomial order */
+  double params[4];
+} agp_kernel_node;
+
+typedef enum { AGP_HOST = 0, AGP_DEVICE = 1 } agp_location;
+
+/* A vector of features, flattened to plain-old-data. */
+typedef struct {
+  int64_t n;
+  int32_t dim;             /* 1..AGP_MAX_DIM */
+  int32_t n_scale_columns; /* 0..AGP_MAX_SCALE_COLUMNS */
+  const double *coords;    /* n x dim row-major */
+  /* optional equality ids for IndependentNoise / Nugget (`x == y`,
+   * noise.hpp:37-43): equal id <=> equal feature.  NULL: features are equal
+   * iff all coords compare equal. */
+  const int64_t *eq_id;
+  const double *scales;    /* n x n_scale_columns column-major, or NULL */
+  int32_t is_measurement;  /* 1: every feature is wrapped in Measurement<> */
+  int32_t location;        /* agp_location of coords / eq_id / scales */
+} agp_features;
+
+typedef struct agp_context agp_context;
+typedef struct agp_kernel agp_kernel;
+typedef struct agp_fit agp_fit;
+
+/* ---- context ------------------------------------------------------------- */
+/* One context per host thread (or externally locked).  Owns the HIP streams
+ * and scratch workspaces.  The reference's equivalent state is the model's
+ * ThreadPool (src/core/model.hpp:30-36,133-135). */
+int agp_context_create(int device_id, agp_context **out);
+void agp_context_destroy(agp_context *ctx);
+int agp_context_synchronize(agp_context *ctx);
+/* last HIP error text for AGP_ERR_HIP, "" otherwise */
+const char *agp_last_error(const agp_context *ctx);
+const char *agp_status_string(int status);
+/* number of visible HIP devices (0 when no GPU / no driver) */
+int agp_device_count(void);
+
+/* ---- covariance function ------------------------------------------------- */
+/* Flattened get_params() of a composed covariance function
+ * (covariance_function.hpp:222-420). Immutable after creation. */
+int agp_kernel_create(const agp_kernel_node *postfix, int n_nodes,
+                      agp_kernel **out);
+void agp_kernel_destroy(agp_kernel *k);
+
+/* ---- Gram ---------------------------------------------------------------- */
+/* compute_covariance_matrix (src/covariance_functions/callers.hpp:38-166).
+ * y == NULL: symmetric n x n Gram of x (callers.hpp:107-166), full matrix
+ * written. Else the n_x x n_y cross Gram (callers.hpp:38-102).
+ * `out` is column-major with leading dimension ld, at out_location. */
+int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x,
+             const agp_features *y, double *out, int64_t ld, int out_location);
+
+/* ---- fit ----------------------------------------------------------------- */
+/* Fit<GPFit<...>>::Fit(features, train_cov, targets) (src/models/gp.hpp:61-69)
+ * preceded by the Gram of GaussianProcessBase::_fit_impl (gp.hpp:281-294):
+ *   K = k(x, x) + diag(y_var);  K = L L^T;  information = K^-1 y.
+ * y, y_var (may be NULL = zeros) live at x->location; the factor stays on the
+ * device inside *out.  information (n doubles, host) and log_det (host) may be
+ * NULL.  The training features are copied into the fit (gp.hpp:63). */
+int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x,
+                   const double *y, const double *y_var, agp_fit **out,
+                   double *information, double *log_det);
+void agp_fit_destroy(agp_fit *fit);
+int64_t agp_fit_size(const agp_fit *fit);
+/* 0-based index of the first non-positive pivot of the last failed factor */
+int64_t agp_fit_failed_pivot(const agp_fit *fit);
+/* sum(log D) of the reference's LDLT == 2 sum(log L_ii)
+ * (src/eigen/serializable_ldlt.hpp:128-135) */
+int agp_fit_log_determinant(const agp_fit *fit, double *out);
+/* lower-triangular factor, column-major n x n, strictly-upper part zeroed */
+int agp_fit_download_factor(agp_context *ctx, const agp_fit *fit, double *L,
+                            int64_t ld);
+int agp_fit_download_information(agp_context *ctx, const agp_fit *fit,
+                                 double *information);
+
+/* negative_log_likelihood(deviation, covariance)
+ * (src/evaluation/likelihood.hpp:38-66) on K = k(x,x) + diag(y_var):
+ *   0.5 (log|K| + y^T K^-1 y + n log 2 pi).
+ * Factor is not kept (GaussianProcessBase::log_likelihood, gp.hpp:442-451). */
+int agp_nll(agp_context *ctx, const agp_kernel *k, const agp_features *x,
+            const double *y, const double *y_var, double *out);
+
+/* ---- solve (CovarianceRepresentation::solve, gp.hpp:42-45,68,96,111) ----- */
+/* out = K^-1 rhs; rhs/out column-major n x nrhs (ld = n), at `location`. */
+int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs,
+              int64_t nrhs, double *out, int location);
+
+/* ---- predict ------------------------------------------------------------- */
+/* gp_mean_prediction (gp.hpp:82-85) via _predict_impl (gp.hpp:350-366):
+ *   mean = k(train, xs)^T information.  mean: m doubles at out_location. */
+int agp_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
+                     const agp_features *xs, double *mean, int out_location);
+/* gp_marginal_prediction (gp.hpp:87-101) via _predict_impl (gp.hpp:326-348):
+ *   var_j = k(xs_j, xs_j) - sum_i (K^-1 K*)_ij K*_ij. */
+int agp_predict_marginal(agp_context *ctx, const agp_kernel *k,
+                         const agp_fit *fit, const agp_features *xs,
+                         double *mean, double *variance, int out_location);
+/* gp_joint_prediction (gp.hpp:103-113) via _predict_impl (gp.hpp:305-324):
+ *   cov = k(xs, xs) - K*^T K^-1 K*.  cov: m x m column-major, ld = m. */
+int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
+                      const agp_features *xs, double *mean, double *cov,
+                      int out_location);
+
+/* ---- instrumentation (bench.py) ----------------------------------------- */
+/* Per-stage device time of the LAST fit / nll on this context, measured with
+ * HIP events on the stream the kernels were launched on.  Stages:
+ * 0 gram, 1 factor (total), 2 solve, 3 trailing-update kernels only (sum),
+ * 4 number of trailing-update launches.  Returns ms (or a count for 4). */
+int agp_last_stage_ms(const agp_context *ctx, int stage, double *ms);
+/* enable (1) / disable (0) per-stage event timing (default off: events add
+ * host overhead to the launch chain). */
+int agp_set_profiling(agp_context *ctx, int enabled);
+/* Bare v_mfma_f64_16x16x4_f64 issue loop: measured fp64 MFMA TFLOP/s of this
+ * device (used as a cross-check of the roofline denominator). */
+int agp_mfma_f64_peak(agp_context *ctx, int iters, double *tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALBATROSS_AMD_H */

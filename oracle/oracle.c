@@ -1,0 +1,682 @@
+/*
+ * oracle.c — CPU restatement of albatross's dense-GP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under albatross_amd/ may include, link or
+ * call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, as the checker / the timed CPU baseline.
+ *
+ * Parity status: PINNED against the reference's own golden vectors
+ * (tests/golden/*.json, taken from /root/reference/tests: Matern 15x15 oracle
+ * matrices, MVN NLL known answer, radial edge cases, distance-metric values,
+ * toy-linear-data GP).  The pivoted LDL^T below restates the PUBLISHED
+ * algorithm of Eigen 3.3 `LDLT<MatrixXd, Lower>` (third-party dependency
+ * `eigen` 3.3.swiftnav.1, MODULE.bazel:38-42 — its source is NOT in the
+ * reference checkout); the factor itself (L, D, P) is parity-unpinned, results
+ * are pinned at the solve / log-det / prediction level where every reference
+ * test checks them.  The reference itself cannot be compiled here (every
+ * header needs Eigen), so there is no oracle/_ref.
+ *
+ * All file:line citations are relative to the albatross checkout,
+ * include/albatross/src/...
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/albatross_amd.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------------- */
+/* distance metrics: covariance_functions/distance_metrics.hpp:30-90       */
+/* ---------------------------------------------------------------------- */
+static double norm_of(const double *x, int dim) {
+  double s = 0.;
+  for (int d = 0; d < dim; ++d) s += x[d] * x[d];
+  return sqrt(s);
+}
+
+static double dist_euclidean(const double *x, const double *y, int dim) {
+  if (dim == 1) return fabs(x[0] - y[0]); /* :34-36 */
+  double s = 0.;                          /* (x - y).norm()  :38-42 */
+  for (int d = 0; d < dim; ++d) {
+    const double t = x[d] - y[d];
+    s += t * t;
+  }
+  return sqrt(s);
+}
+
+static double dist_radial(const double *x, const double *y, int dim) {
+  return fabs(norm_of(x, dim) - norm_of(y, dim)); /* :47-51 */
+}
+
+static double dist_angular(const double *x, const double *y, int dim) {
+  const double eps = 1e-16; /* EPSILON, :18 */
+  double dot = 0.;
+  for (int d = 0; d < dim; ++d) dot += x[d] * y[d];
+  const double c = dot / (norm_of(x, dim) * norm_of(y, dim)); /* :70 */
+  if (c > 1. - eps) return 0.;                               /* :71-72 */
+  if (c < -1. + eps) return M_PI;                            /* :73-74 */
+  return acos(c);
+}
+
+static double distance(int metric, const double *x, const double *y, int dim) {
+  switch (metric) {
+  case AGP_METRIC_RADIAL: return dist_radial(x, y, dim);
+  case AGP_METRIC_ANGULAR: return dist_angular(x, y, dim);
+  default: return dist_euclidean(x, y, dim);
+  }
+}
+
+/* ---------------------------------------------------------------------- */
+/* radial kernels: covariance_functions/radial.hpp                         */
+/* ---------------------------------------------------------------------- */
+static double squared_exponential(double d, double l, double sigma) { /* :25-33 */
+  if (l <= 0.) return 0.;
+  return sigma * sigma * exp(-pow(d / l, 2));
+}
+static double exponential(double d, double l, double sigma) { /* :191-198 */
+  if (l <= 0.) return 0.;
+  return sigma * sigma * exp(-fabs(d / l));
+}
+static double matern32(double d, double l, double sigma) { /* :289-297 */
+  if (l <= 0.) return 0.;
+  const double q = sqrt(3.) * d / l;
+  return sigma * sigma * (1 + q) * exp(-q);
+}
+static double matern52(double d, double l, double sigma) { /* :461-470 */
+  if (l <= 0.) return 0.;
+  const double q = sqrt(5.) * d / l;
+  return sigma * sigma * (1 + q + q * q / 3.) * exp(-q);
+}
+
+/* ---------------------------------------------------------------------- */
+/* one k(x, y): postfix walk of the composed covariance function           */
+/* ---------------------------------------------------------------------- */
+typedef struct {
+  const double *coords;
+  const int64_t *eq_id;
+  const double *scales;
+  int64_t n;
+  int dim;
+  int is_measurement;
+} orc_set;
+
+static int features_equal(const orc_set *X, int64_t i, const orc_set *Y,
+                          int64_t j) {
+  if (X->eq_id && Y->eq_id) return X->eq_id[i] == Y->eq_id[j];
+  for (int d = 0; d < X->dim; ++d)
+    if (!(X->coords[i * X->dim + d] == Y->coords[j * Y->dim + d])) return 0;
+  return 1;
+}
+
+static double eval_pair(const agp_kernel_node *prog, int n_nodes,
+                        const orc_set *X, int64_t i, const orc_set *Y,
+                        int64_t j) {
+  double st[AGP_MAX_STACK];
+  int sp = 0;
+  const double *x = X->coords + i * X->dim;
+  const double *y = Y->coords + j * Y->dim;
+  const int dim = X->dim;
+  for (int t = 0; t < n_nodes; ++t) {
+    const agp_kernel_node *nd = &prog[t];
+    const double *p = nd->params;
+    switch (nd->op) {
+    case AGP_OP_SQUARED_EXPONENTIAL:
+      st[sp++] = squared_exponential(distance(nd->metric, x, y, dim), p[0], p[1]);
+      break;
+    case AGP_OP_EXPONENTIAL:
+      st[sp++] = exponential(distance(nd->metric, x, y, dim), p[0], p[1]);
+      break;
+    case AGP_OP_MATERN32:
+      st[sp++] = matern32(distance(nd->metric, x, y, dim), p[0], p[1]);
+      break;
+    case AGP_OP_MATERN52:
+      st[sp++] = matern52(distance(nd->metric, x, y, dim), p[0], p[1]);
+      break;
+    case AGP_OP_CONSTANT: /* polynomials.hpp:56-60 */
+      st[sp++] = p[0] * p[0];
+      break;
+    case AGP_OP_INDEPENDENT_NOISE: /* noise.hpp:37-43 */
+    case AGP_OP_NUGGET:            /* nugget.hpp:40-48 */
+      st[sp++] = features_equal(X, i, Y, j) ? p[0] * p[0] : 0.;
+      break;
+    case AGP_OP_POLYNOMIAL: { /* polynomials.hpp:78-86 */
+      double cov = 0.;
+      for (int q = 0; q < nd->order + 1; ++q) {
+        const double s = p[q];
+        cov += s * s * pow(x[0], (double)q) * pow(y[0], (double)q);
+      }
+      st[sp++] = cov;
+    } break;
+    case AGP_OP_SCALING: /* scaling_function.hpp:79-83: f(x) * f(y) */
+      st[sp++] = X->scales[nd->column * X->n + i] * Y->scales[nd->column * Y->n + j];
+      break;
+    case AGP_OP_SUM: /* covariance_function.hpp:266-272 */
+      st[sp - 2] = st[sp - 2] + st[sp - 1];
+      --sp;
+      break;
+    case AGP_OP_PRODUCT: { /* covariance_function.hpp:357-367 */
+      double out = st[sp - 2];
+      if (out != 0.) out *= st[sp - 1];
+      st[sp - 2] = out;
+      --sp;
+    } break;
+    case AGP_OP_MEASUREMENT_ONLY: /* measurement.hpp:87-102 */
+      if (!(X->is_measurement && Y->is_measurement)) st[sp - 1] = 0.;
+      break;
+    default:
+      st[sp++] = NAN;
+    }
+  }
+  return st[0];
+}
+
+static orc_set as_set(const agp_features *f) {
+  orc_set s;
+  s.coords = f->coords;
+  s.eq_id = f->eq_id;
+  s.scales = f->scales;
+  s.n = f->n;
+  s.dim = f->dim;
+  s.is_measurement = f->is_measurement;
+  return s;
+}
+
+ORC_API double orc_eval(const agp_kernel_node *prog, int n_nodes,
+                        const agp_features *x, int64_t i,
+                        const agp_features *y, int64_t j) {
+  orc_set X = as_set(x), Y = as_set(y);
+  return eval_pair(prog, n_nodes, &X, i, &Y, j);
+}
+
+/* ---------------------------------------------------------------------- */
+/* Gram: covariance_functions/callers.hpp                                  */
+/* ---------------------------------------------------------------------- */
+/* cross, serial: callers.hpp:38-60 (row-major walk of a col-major matrix) */
+ORC_API void orc_gram_cross(const agp_kernel_node *prog, int n_nodes,
+                            const agp_features *x, const agp_features *y,
+                            double *C, int64_t ld) {
+  orc_set X = as_set(x), Y = as_set(y);
+  for (int64_t i = 0; i < X.n; ++i)
+    for (int64_t j = 0; j < Y.n; ++j)
+      C[i + j * ld] = eval_pair(prog, n_nodes, &X, i, &Y, j);
+}
+
+/* symmetric, serial: callers.hpp:107-129 (lower triangle, mirrored) */
+ORC_API void orc_gram_sym(const agp_kernel_node *prog, int n_nodes,
+                          const agp_features *x, double *C, int64_t ld) {
+  orc_set X = as_set(x);
+  for (int64_t i = 0; i < X.n; ++i)
+    for (int64_t j = 0; j <= i; ++j) {
+      C[i + j * ld] = eval_pair(prog, n_nodes, &X, i, &X, j);
+      C[j + i * ld] = C[i + j * ld];
+    }
+}
+
+/* partition_triangular: indexing/block.hpp:25-44 — column blocks of
+ * approximately equal triangle area: end_fraction_{b+1} = sqrt(1/k + area_b),
+ * end index = rint(size * end_fraction), last block clamped to size. */
+static int partition_triangular(int64_t size, int64_t block_count,
+                                int64_t *starts, int64_t *ends) {
+  double area = 0.;
+  int64_t start = 0;
+  for (int64_t b = 0; b < block_count; ++b) {
+    const double end_fraction = sqrt(1. / (double)block_count + area);
+    area = end_fraction * end_fraction;
+    const int64_t end = (int64_t)rint((double)size * end_fraction);
+    starts[b] = start;
+    ends[b] = end;
+    start = end;
+  }
+  if (ends[block_count - 1] > size) ends[block_count - 1] = size;
+  return (int)block_count;
+}
+
+typedef struct {
+  const agp_kernel_node *prog;
+  int n_nodes;
+  const orc_set *X;
+  const orc_set *Y;
+  double *C;
+  int64_t ld;
+  int64_t c0, c1;
+  int symmetric;
+} gram_job;
+
+static void *gram_worker(void *arg) {
+  gram_job *jb = (gram_job *)arg;
+  for (int64_t col = jb->c0; col < jb->c1; ++col) {
+    /* symmetric: rows 0..col of column col (upper triangle, callers.hpp:149-157)
+     * cross:     every row of column col (callers.hpp:86-96) */
+    const int64_t rows = jb->symmetric ? col + 1 : jb->X->n;
+    for (int64_t row = 0; row < rows; ++row)
+      jb->C[row + col * jb->ld] =
+          eval_pair(jb->prog, jb->n_nodes, jb->X, row, jb->Y, col);
+  }
+  return NULL;
+}
+
+/* symmetric, pooled: callers.hpp:134-166 */
+ORC_API void orc_gram_sym_pooled(const agp_kernel_node *prog, int n_nodes,
+                                 const agp_features *x, double *C, int64_t ld,
+                                 int threads) {
+  orc_set X = as_set(x);
+  if (threads <= 1) { /* should_serial_apply */
+    orc_gram_sym(prog, n_nodes, x, C, ld);
+    return;
+  }
+  int64_t *starts = malloc(sizeof(int64_t) * (size_t)threads);
+  int64_t *ends = malloc(sizeof(int64_t) * (size_t)threads);
+  const int nb = partition_triangular(X.n, threads, starts, ends);
+  pthread_t *tid = malloc(sizeof(pthread_t) * (size_t)nb);
+  gram_job *jobs = malloc(sizeof(gram_job) * (size_t)nb);
+  for (int b = 0; b < nb; ++b) {
+    gram_job jb = {prog, n_nodes, &X, &X, C, ld, starts[b], ends[b], 1};
+    jobs[b] = jb;
+    pthread_create(&tid[b], NULL, gram_worker, &jobs[b]);
+  }
+  for (int b = 0; b < nb; ++b) pthread_join(tid[b], NULL);
+  /* output.triangularView<Lower>() = output.transpose()  (:163-164) */
+  for (int64_t j = 0; j < X.n; ++j)
+    for (int64_t i = j + 1; i < X.n; ++i) C[i + j * ld] = C[j + i * ld];
+  free(starts); free(ends); free(tid); free(jobs);
+}
+
+/* cross, pooled: callers.hpp:66-102 (ceil(n_cols / threads) column blocks) */
+ORC_API void orc_gram_cross_pooled(const agp_kernel_node *prog, int n_nodes,
+                                   const agp_features *x, const agp_features *y,
+                                   double *C, int64_t ld, int threads) {
+  orc_set X = as_set(x), Y = as_set(y);
+  if (threads <= 1) {
+    orc_gram_cross(prog, n_nodes, x, y, C, ld);
+    return;
+  }
+  const int64_t block = (int64_t)ceil((double)Y.n / (double)threads);
+  pthread_t *tid = malloc(sizeof(pthread_t) * (size_t)threads);
+  gram_job *jobs = malloc(sizeof(gram_job) * (size_t)threads);
+  int nb = 0;
+  for (int b = 0; b < threads; ++b) {
+    const int64_t c0 = b * block;
+    const int64_t c1 = (b + 1) * block < Y.n ? (b + 1) * block : Y.n;
+    if (c0 >= c1) continue;
+    gram_job jb = {prog, n_nodes, &X, &Y, C, ld, c0, c1, 0};
+    jobs[nb] = jb;
+    pthread_create(&tid[nb], NULL, gram_worker, &jobs[nb]);
+    ++nb;
+  }
+  for (int b = 0; b < nb; ++b) pthread_join(tid[b], NULL);
+  free(tid); free(jobs);
+}
+
+/* ---------------------------------------------------------------------- */
+/* Eigen 3.3 LDLT<MatrixXd, Lower>, unblocked, in place (published         */
+/* algorithm; call sites eigen/serializable_ldlt.hpp:27, likelihood.hpp:63)*/
+/*   P A P^T = L D L^T ; L unit lower in the strict lower triangle of A,   */
+/*   D on the diagonal, transpositions in tr[].                            */
+/* ---------------------------------------------------------------------- */
+ORC_API int orc_ldlt(double *A, int64_t n, int64_t ld, int64_t *tr) {
+  int ok = 1, found_zero_pivot = 0;
+  if (n <= 1) {
+    if (n == 1) tr[0] = 0;
+    return 1;
+  }
+  double *temp = malloc(sizeof(double) * (size_t)n);
+  for (int64_t k = 0; k < n; ++k) {
+    /* largest |diagonal| of the trailing block */
+    int64_t big = k;
+    double best = fabs(A[k + k * ld]);
+    for (int64_t i = k + 1; i < n; ++i) {
+      const double v = fabs(A[i + i * ld]);
+      if (v > best) { best = v; big = i; }
+    }
+    tr[k] = big;
+    if (big != k) {
+      /* symmetric row/column swap touching only the lower triangle */
+      for (int64_t c = 0; c < k; ++c) {
+        const double t = A[k + c * ld];
+        A[k + c * ld] = A[big + c * ld];
+        A[big + c * ld] = t;
+      }
+      for (int64_t r = big + 1; r < n; ++r) {
+        const double t = A[r + k * ld];
+        A[r + k * ld] = A[r + big * ld];
+        A[r + big * ld] = t;
+      }
+      {
+        const double t = A[k + k * ld];
+        A[k + k * ld] = A[big + big * ld];
+        A[big + big * ld] = t;
+      }
+      for (int64_t i = k + 1; i < big; ++i) {
+        const double t = A[i + k * ld];
+        A[i + k * ld] = A[big + i * ld];
+        A[big + i * ld] = t;
+      }
+    }
+    const int64_t rs = n - k - 1;
+    if (k > 0) {
+      /* temp = D[:k] .* A10^T ; A_kk -= A10 temp ; A21 -= A20 temp */
+      double dot = 0.;
+      for (int64_t c = 0; c < k; ++c) {
+        temp[c] = A[c + c * ld] * A[k + c * ld];
+        dot += A[k + c * ld] * temp[c];
+      }
+      A[k + k * ld] -= dot;
+      for (int64_t c = 0; c < k; ++c) {
+        const double t = temp[c];
+        const double *col = A + c * ld;
+        double *dst = A + k * ld;
+        for (int64_t r = k + 1; r < n; ++r) dst[r] -= col[r] * t;
+      }
+    }
+    const double akk = A[k + k * ld];
+    const int pivot_is_valid = fabs(akk) > 0.;
+    if (k == 0 && !pivot_is_valid) {
+      for (int64_t j = 0; j < n; ++j) {
+        tr[j] = j;
+        for (int64_t r = j + 1; r < n; ++r) ok = ok && (A[r + j * ld] == 0.);
+      }
+      free(temp);
+      return ok;
+    }
+    if (rs > 0 && pivot_is_valid) {
+      for (int64_t r = k + 1; r < n; ++r) A[r + k * ld] /= akk;
+    } else if (rs > 0) {
+      for (int64_t r = k + 1; r < n; ++r) ok = ok && (A[r + k * ld] == 0.);
+    }
+    if (found_zero_pivot && pivot_is_valid) ok = 0;
+    else if (!pivot_is_valid) found_zero_pivot = 1;
+  }
+  free(temp);
+  return ok;
+}
+
+/* LDLT::solve: P^T L^-T D^+ L^-1 P rhs, D^+ zeroes rows whose |D| is not
+ * above numeric_limits<double>::min().  In place on B (n x nrhs, ld ldb). */
+ORC_API void orc_ldlt_solve(const double *A, int64_t n, int64_t ld,
+                            const int64_t *tr, double *B, int64_t nrhs,
+                            int64_t ldb) {
+  const double tol = 2.2250738585072014e-308;
+  for (int64_t c = 0; c < nrhs; ++c) {
+    double *b = B + c * ldb;
+    for (int64_t k = 0; k < n; ++k)
+      if (tr[k] != k) { const double t = b[k]; b[k] = b[tr[k]]; b[tr[k]] = t; }
+    for (int64_t j = 0; j < n; ++j) { /* unit-lower forward substitution */
+      const double bj = b[j];
+      const double *col = A + j * ld;
+      for (int64_t i = j + 1; i < n; ++i) b[i] -= col[i] * bj;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+      const double d = A[i + i * ld];
+      if (fabs(d) > tol) b[i] /= d; else b[i] = 0.;
+    }
+    for (int64_t j = n - 1; j >= 0; --j) { /* unit-upper (L^T) back substitution */
+      const double *col = A + j * ld;
+      double s = b[j];
+      for (int64_t i = j + 1; i < n; ++i) s -= col[i] * b[i];
+      b[j] = s;
+    }
+    for (int64_t k = n - 1; k >= 0; --k)
+      if (tr[k] != k) { const double t = b[k]; b[k] = b[tr[k]]; b[tr[k]] = t; }
+  }
+}
+
+/* log_sum(vectorD): likelihood.hpp:26-32 / serializable_ldlt.hpp:128-135 */
+ORC_API double orc_ldlt_logdet(const double *A, int64_t n, int64_t ld) {
+  double s = 0.;
+  for (int64_t i = 0; i < n; ++i) s += log(A[i + i * ld]);
+  return s;
+}
+
+/* ---------------------------------------------------------------------- */
+/* un-pivoted LL^T (what the device computes) — left-looking, column form  */
+/* returns 0 on success, k+1 if pivot k is not positive                    */
+/* ---------------------------------------------------------------------- */
+ORC_API int64_t orc_llt(double *A, int64_t n, int64_t ld) {
+  for (int64_t j = 0; j < n; ++j) {
+    double *cj = A + j * ld;
+    for (int64_t c = 0; c < j; ++c) {
+      const double *cc = A + c * ld;
+      const double t = cc[j];
+      for (int64_t r = j; r < n; ++r) cj[r] -= cc[r] * t;
+    }
+    const double d = cj[j];
+    if (!(d > 0.)) return j + 1;
+    const double s = sqrt(d);
+    cj[j] = s;
+    for (int64_t r = j + 1; r < n; ++r) cj[r] /= s;
+  }
+  return 0;
+}
+
+ORC_API void orc_llt_solve(const double *L, int64_t n, int64_t ld, double *B,
+                           int64_t nrhs, int64_t ldb) {
+  for (int64_t c = 0; c < nrhs; ++c) {
+    double *b = B + c * ldb;
+    for (int64_t j = 0; j < n; ++j) {
+      const double *col = L + j * ld;
+      b[j] /= col[j];
+      const double bj = b[j];
+      for (int64_t i = j + 1; i < n; ++i) b[i] -= col[i] * bj;
+    }
+    for (int64_t j = n - 1; j >= 0; --j) {
+      const double *col = L + j * ld;
+      double s = b[j];
+      for (int64_t i = j + 1; i < n; ++i) s -= col[i] * b[i];
+      b[j] = s / col[j];
+    }
+  }
+}
+
+ORC_API double orc_llt_logdet(const double *L, int64_t n, int64_t ld) {
+  double s = 0.;
+  for (int64_t i = 0; i < n; ++i) s += log(L[i + i * ld]);
+  return 2. * s;
+}
+
+/* ---------------------------------------------------------------------- */
+/* fit / nll / predict: models/gp.hpp, evaluation/likelihood.hpp           */
+/* ---------------------------------------------------------------------- */
+typedef struct {
+  int64_t n;
+  double *ldlt;   /* n x n packed factor */
+  int64_t *tr;
+  double *information;
+  agp_features train; /* un-wrapped training features (gp.hpp:293) */
+  double *coords_copy;
+  int64_t *eq_copy;
+  double *scales_copy;
+  int use_llt;
+} orc_fit;
+
+static int has_nan(const double *A, int64_t n, int64_t ld) {
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < n; ++i)
+      if (isnan(A[i + j * ld])) return 1;
+  return 0;
+}
+
+/* gp.hpp:281-294 (_fit_impl) + gp.hpp:61-69 (Fit ctor).
+ * threads <= 1: serial Gram (the reference default, core/model.hpp:20).
+ * use_llt: factor with un-pivoted LL^T instead of Eigen's pivoted LDL^T.
+ * Returns NULL with *status = AGP_ERR_NAN_INPUT when the covariance has NaN. */
+ORC_API orc_fit *orc_fit_create(const agp_kernel_node *prog, int n_nodes,
+                                const agp_features *x, const double *y,
+                                const double *y_var, int threads, int use_llt,
+                                int *status) {
+  const int64_t n = x->n;
+  agp_features meas = *x;
+  meas.is_measurement = 1; /* as_measurements(features), gp.hpp:288 */
+  double *K = malloc(sizeof(double) * (size_t)(n * n));
+  orc_gram_sym_pooled(prog, n_nodes, &meas, K, n, threads);
+  if (y_var)
+    for (int64_t i = 0; i < n; ++i) K[i + i * n] += y_var[i]; /* gp.hpp:65 */
+  if (has_nan(K, n, n)) { /* gp.hpp:66 */
+    free(K);
+    if (status) *status = AGP_ERR_NAN_INPUT;
+    return NULL;
+  }
+  orc_fit *f = calloc(1, sizeof(orc_fit));
+  f->n = n;
+  f->ldlt = K;
+  f->tr = malloc(sizeof(int64_t) * (size_t)n);
+  f->use_llt = use_llt;
+  f->information = malloc(sizeof(double) * (size_t)n);
+  memcpy(f->information, y, sizeof(double) * (size_t)n);
+  if (use_llt) {
+    const int64_t bad = orc_llt(K, n, n);
+    if (bad) {
+      if (status) *status = AGP_ERR_NOT_POSITIVE_DEFINITE;
+      free(K); free(f->tr); free(f->information); free(f);
+      return NULL;
+    }
+    orc_llt_solve(K, n, n, f->information, 1, n);
+  } else {
+    orc_ldlt(K, n, n, f->tr);                                 /* gp.hpp:67 */
+    orc_ldlt_solve(K, n, n, f->tr, f->information, 1, n);     /* gp.hpp:68 */
+  }
+  /* train_features = features (un-wrapped), gp.hpp:63 */
+  f->train = *x;
+  f->train.is_measurement = 0;
+  f->coords_copy = malloc(sizeof(double) * (size_t)(n * x->dim));
+  memcpy(f->coords_copy, x->coords, sizeof(double) * (size_t)(n * x->dim));
+  f->train.coords = f->coords_copy;
+  if (x->eq_id) {
+    f->eq_copy = malloc(sizeof(int64_t) * (size_t)n);
+    memcpy(f->eq_copy, x->eq_id, sizeof(int64_t) * (size_t)n);
+    f->train.eq_id = f->eq_copy;
+  }
+  if (x->scales && x->n_scale_columns > 0) {
+    const size_t cnt = (size_t)(n * x->n_scale_columns);
+    f->scales_copy = malloc(sizeof(double) * cnt);
+    memcpy(f->scales_copy, x->scales, sizeof(double) * cnt);
+    f->train.scales = f->scales_copy;
+  }
+  if (status) *status = AGP_OK;
+  return f;
+}
+
+ORC_API void orc_fit_destroy(orc_fit *f) {
+  if (!f) return;
+  free(f->ldlt); free(f->tr); free(f->information);
+  free(f->coords_copy); free(f->eq_copy); free(f->scales_copy);
+  free(f);
+}
+
+ORC_API void orc_fit_information(const orc_fit *f, double *out) {
+  memcpy(out, f->information, sizeof(double) * (size_t)f->n);
+}
+
+ORC_API double orc_fit_logdet(const orc_fit *f) {
+  return f->use_llt ? orc_llt_logdet(f->ldlt, f->n, f->n)
+                    : orc_ldlt_logdet(f->ldlt, f->n, f->n);
+}
+
+ORC_API void orc_fit_solve(const orc_fit *f, double *B, int64_t nrhs) {
+  if (f->use_llt) orc_llt_solve(f->ldlt, f->n, f->n, B, nrhs, f->n);
+  else orc_ldlt_solve(f->ldlt, f->n, f->n, f->tr, B, nrhs, f->n);
+}
+
+/* negative_log_likelihood(deviation, covariance): likelihood.hpp:38-66 */
+ORC_API double orc_nll_dense(const double *dev, const double *cov, int64_t n,
+                             int64_t ld) {
+  if (n == 1) { /* univariate shortcut, likelihood.hpp:57-60 */
+    const double v = cov[0];
+    return 0.5 * (log(2 * M_PI * v) + dev[0] * dev[0] / v);
+  }
+  double *A = malloc(sizeof(double) * (size_t)(n * n));
+  for (int64_t j = 0; j < n; ++j)
+    memcpy(A + j * n, cov + j * ld, sizeof(double) * (size_t)n);
+  int64_t *tr = malloc(sizeof(int64_t) * (size_t)n);
+  double *s = malloc(sizeof(double) * (size_t)n);
+  memcpy(s, dev, sizeof(double) * (size_t)n);
+  orc_ldlt(A, n, n, tr);
+  orc_ldlt_solve(A, n, n, tr, s, 1, n);
+  double maha = 0.;
+  for (int64_t i = 0; i < n; ++i) maha += dev[i] * s[i];
+  const double log_det = orc_ldlt_logdet(A, n, n);
+  free(A); free(tr); free(s);
+  return 0.5 * (log_det + maha + (double)n * log(2 * M_PI));
+}
+
+/* -log_likelihood without the prior term: gp.hpp:442-451 */
+ORC_API double orc_nll(const agp_kernel_node *prog, int n_nodes,
+                       const agp_features *x, const double *y,
+                       const double *y_var) {
+  const int64_t n = x->n;
+  agp_features meas = *x;
+  meas.is_measurement = 1;
+  double *K = malloc(sizeof(double) * (size_t)(n * n));
+  orc_gram_sym(prog, n_nodes, &meas, K, n);
+  if (y_var)
+    for (int64_t i = 0; i < n; ++i) K[i + i * n] += y_var[i];
+  const double out = orc_nll_dense(y, K, n, n);
+  free(K);
+  return out;
+}
+
+/* gp.hpp:350-366 + 82-85 */
+ORC_API void orc_predict_mean(const orc_fit *f, const agp_kernel_node *prog,
+                              int n_nodes, const agp_features *xs,
+                              double *mean) {
+  const int64_t n = f->n, m = xs->n;
+  double *Ks = malloc(sizeof(double) * (size_t)(n * m));
+  orc_gram_cross(prog, n_nodes, &f->train, xs, Ks, n);
+  for (int64_t j = 0; j < m; ++j) {
+    double s = 0.;
+    for (int64_t i = 0; i < n; ++i) s += Ks[i + j * n] * f->information[i];
+    mean[j] = s;
+  }
+  free(Ks);
+}
+
+/* gp.hpp:326-348 + 87-101 */
+ORC_API void orc_predict_marginal(const orc_fit *f, const agp_kernel_node *prog,
+                                  int n_nodes, const agp_features *xs,
+                                  double *mean, double *variance) {
+  const int64_t n = f->n, m = xs->n;
+  double *Ks = malloc(sizeof(double) * (size_t)(n * m));
+  double *E = malloc(sizeof(double) * (size_t)(n * m));
+  orc_gram_cross(prog, n_nodes, &f->train, xs, Ks, n);
+  memcpy(E, Ks, sizeof(double) * (size_t)(n * m));
+  orc_fit_solve(f, E, m); /* explained = train_covariance.solve(cross_cov) */
+  orc_set XS = as_set(xs);
+  for (int64_t j = 0; j < m; ++j) {
+    double mu = 0., ex = 0.;
+    for (int64_t i = 0; i < n; ++i) {
+      mu += Ks[i + j * n] * f->information[i];
+      ex += E[i + j * n] * Ks[i + j * n];
+    }
+    mean[j] = mu;
+    variance[j] = eval_pair(prog, n_nodes, &XS, j, &XS, j) - ex; /* :339-343,99 */
+  }
+  free(Ks); free(E);
+}
+
+/* gp.hpp:305-324 + 103-113 */
+ORC_API void orc_predict_joint(const orc_fit *f, const agp_kernel_node *prog,
+                               int n_nodes, const agp_features *xs,
+                               double *mean, double *cov) {
+  const int64_t n = f->n, m = xs->n;
+  double *Ks = malloc(sizeof(double) * (size_t)(n * m));
+  double *E = malloc(sizeof(double) * (size_t)(n * m));
+  orc_gram_cross(prog, n_nodes, &f->train, xs, Ks, n);
+  memcpy(E, Ks, sizeof(double) * (size_t)(n * m));
+  orc_fit_solve(f, E, m);
+  orc_gram_sym(prog, n_nodes, xs, cov, m); /* prior_cov */
+  for (int64_t j = 0; j < m; ++j) {
+    double mu = 0.;
+    for (int64_t i = 0; i < n; ++i) mu += Ks[i + j * n] * f->information[i];
+    mean[j] = mu;
+  }
+  for (int64_t b = 0; b < m; ++b)
+    for (int64_t a = 0; a < m; ++a) {
+      double s = 0.;
+      for (int64_t i = 0; i < n; ++i) s += Ks[i + a * n] * E[i + b * n];
+      cov[a + b * m] -= s;
+    }
+  free(Ks); free(E);
+}

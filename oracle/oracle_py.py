@@ -1,0 +1,218 @@
+"""ctypes wrapper of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
+never by anything under albatross_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from albatross_amd._capi import Features, KernelNode
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        PF = C.POINTER(Features)
+        PN = C.POINTER(KernelNode)
+        V = C.c_void_p
+        I64 = C.c_int64
+        L.orc_eval.restype = C.c_double
+        L.orc_eval.argtypes = [PN, C.c_int, PF, I64, PF, I64]
+        L.orc_gram_cross.argtypes = [PN, C.c_int, PF, PF, V, I64]
+        L.orc_gram_sym.argtypes = [PN, C.c_int, PF, V, I64]
+        L.orc_gram_sym_pooled.argtypes = [PN, C.c_int, PF, V, I64, C.c_int]
+        L.orc_gram_cross_pooled.argtypes = [PN, C.c_int, PF, PF, V, I64, C.c_int]
+        L.orc_ldlt.restype = C.c_int
+        L.orc_ldlt.argtypes = [V, I64, I64, V]
+        L.orc_ldlt_solve.argtypes = [V, I64, I64, V, V, I64, I64]
+        L.orc_ldlt_logdet.restype = C.c_double
+        L.orc_ldlt_logdet.argtypes = [V, I64, I64]
+        L.orc_llt.restype = I64
+        L.orc_llt.argtypes = [V, I64, I64]
+        L.orc_llt_solve.argtypes = [V, I64, I64, V, I64, I64]
+        L.orc_llt_logdet.restype = C.c_double
+        L.orc_llt_logdet.argtypes = [V, I64, I64]
+        L.orc_fit_create.restype = V
+        L.orc_fit_create.argtypes = [PN, C.c_int, PF, V, V, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.orc_fit_destroy.argtypes = [V]
+        L.orc_fit_information.argtypes = [V, V]
+        L.orc_fit_logdet.restype = C.c_double
+        L.orc_fit_logdet.argtypes = [V]
+        L.orc_fit_solve.argtypes = [V, V, I64]
+        L.orc_nll_dense.restype = C.c_double
+        L.orc_nll_dense.argtypes = [V, V, I64, I64]
+        L.orc_nll.restype = C.c_double
+        L.orc_nll.argtypes = [PN, C.c_int, PF, V, V]
+        L.orc_predict_mean.argtypes = [V, PN, C.c_int, PF, V]
+        L.orc_predict_marginal.argtypes = [V, PN, C.c_int, PF, V, V]
+        L.orc_predict_joint.argtypes = [V, PN, C.c_int, PF, V, V]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _prog(cov):
+    nodes = cov.program_nodes()
+    arr = (KernelNode * len(nodes))(*nodes)
+    return arr, len(nodes)
+
+
+def _feat(cov, x, is_measurement=False):
+    """host FeatureSet -> (Features struct, keepalive)"""
+    fs = cov.features(x, is_measurement=is_measurement)
+    return fs.as_struct(), fs
+
+
+def eval_pair(cov, x, i, y, j, x_meas=False, y_meas=False):
+    p, n = _prog(cov)
+    fx, kx = _feat(cov, x, x_meas)
+    fy, ky = _feat(cov, y, y_meas)
+    return lib().orc_eval(p, n, C.byref(fx), i, C.byref(fy), j)
+
+
+def gram(cov, x, y=None, x_meas=False, y_meas=False, threads=0):
+    p, n = _prog(cov)
+    fx, kx = _feat(cov, x, x_meas)
+    if y is None:
+        out = np.zeros((fx.n, fx.n), order="F")
+        if threads > 1:
+            lib().orc_gram_sym_pooled(p, n, C.byref(fx), _ptr(out), fx.n, threads)
+        else:
+            lib().orc_gram_sym(p, n, C.byref(fx), _ptr(out), fx.n)
+        return out
+    fy, ky = _feat(cov, y, y_meas)
+    out = np.zeros((fx.n, fy.n), order="F")
+    if threads > 1:
+        lib().orc_gram_cross_pooled(p, n, C.byref(fx), C.byref(fy), _ptr(out), fx.n, threads)
+    else:
+        lib().orc_gram_cross(p, n, C.byref(fx), C.byref(fy), _ptr(out), fx.n)
+    return out
+
+
+def ldlt(A):
+    A = np.array(A, dtype=np.float64, order="F")
+    n = A.shape[0]
+    tr = np.zeros(n, dtype=np.int64)
+    ok = lib().orc_ldlt(_ptr(A), n, n, _ptr(tr))
+    return A, tr, bool(ok)
+
+
+def ldlt_solve(packed, tr, B):
+    B = np.array(B, dtype=np.float64, order="F")
+    B2 = np.asfortranarray(B.reshape(B.shape[0], -1, order="F"))
+    n = packed.shape[0]
+    lib().orc_ldlt_solve(_ptr(packed), n, n, _ptr(tr), _ptr(B2), B2.shape[1], n)
+    return B2.reshape(B.shape, order="F")
+
+
+def ldlt_logdet(packed):
+    return lib().orc_ldlt_logdet(_ptr(packed), packed.shape[0], packed.shape[0])
+
+
+def llt(A):
+    A = np.array(A, dtype=np.float64, order="F")
+    n = A.shape[0]
+    info = lib().orc_llt(_ptr(A), n, n)
+    return A, int(info)
+
+
+def llt_solve(L, B):
+    B = np.array(B, dtype=np.float64, order="F")
+    B2 = np.asfortranarray(B.reshape(B.shape[0], -1, order="F"))
+    n = L.shape[0]
+    lib().orc_llt_solve(_ptr(L), n, n, _ptr(B2), B2.shape[1], n)
+    return B2.reshape(B.shape, order="F")
+
+
+def llt_logdet(L):
+    return lib().orc_llt_logdet(_ptr(L), L.shape[0], L.shape[0])
+
+
+def nll_dense(dev, cov):
+    dev = np.ascontiguousarray(dev, dtype=np.float64)
+    cov = np.array(cov, dtype=np.float64, order="F")
+    return lib().orc_nll_dense(_ptr(dev), _ptr(cov), dev.shape[0], cov.shape[0])
+
+
+class OracleFit:
+    """Fit<GPFit<SerializableLDLT, F>> restated on the CPU (gp.hpp:43-77)."""
+
+    def __init__(self, cov, x, y, y_var=None, threads=0, use_llt=False):
+        self.cov = cov
+        self._p, self._n = _prog(cov)
+        fx, self._keep = _feat(cov, x, False)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        yv = None if y_var is None else np.ascontiguousarray(y_var, dtype=np.float64)
+        st = C.c_int(0)
+        self.h = lib().orc_fit_create(self._p, self._n, C.byref(fx), _ptr(y), _ptr(yv), threads,
+                                      1 if use_llt else 0, C.byref(st))
+        self.status = st.value
+        self.n = int(fx.n)
+        if not self.h:
+            raise FloatingPointError(f"oracle fit failed with status {self.status}")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_fit_destroy(self.h)
+            self.h = None
+
+    @property
+    def information(self):
+        out = np.zeros(self.n)
+        lib().orc_fit_information(self.h, _ptr(out))
+        return out
+
+    @property
+    def log_determinant(self):
+        return lib().orc_fit_logdet(self.h)
+
+    def solve(self, B):
+        B = np.array(B, dtype=np.float64, order="F")
+        B2 = np.asfortranarray(B.reshape(B.shape[0], -1, order="F"))
+        lib().orc_fit_solve(self.h, _ptr(B2), B2.shape[1])
+        return B2.reshape(B.shape, order="F")
+
+    def predict_mean(self, xs, xs_meas=False):
+        f, keep = _feat(self.cov, xs, xs_meas)
+        mean = np.zeros(f.n)
+        lib().orc_predict_mean(self.h, self._p, self._n, C.byref(f), _ptr(mean))
+        return mean
+
+    def predict_marginal(self, xs, xs_meas=False):
+        f, keep = _feat(self.cov, xs, xs_meas)
+        mean = np.zeros(f.n)
+        var = np.zeros(f.n)
+        lib().orc_predict_marginal(self.h, self._p, self._n, C.byref(f), _ptr(mean), _ptr(var))
+        return mean, var
+
+    def predict_joint(self, xs, xs_meas=False):
+        f, keep = _feat(self.cov, xs, xs_meas)
+        mean = np.zeros(f.n)
+        cov = np.zeros((f.n, f.n), order="F")
+        lib().orc_predict_joint(self.h, self._p, self._n, C.byref(f), _ptr(mean), _ptr(cov))
+        return mean, cov
+
+
+def nll(cov, x, y, y_var=None):
+    p, n = _prog(cov)
+    fx, keep = _feat(cov, x, False)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    yv = None if y_var is None else np.ascontiguousarray(y_var, dtype=np.float64)
+    return lib().orc_nll(p, n, C.byref(fx), _ptr(y), _ptr(yv))
