@@ -10,4 +10,8 @@ from .covariance import (AngularDistance, Constant, CovarianceFunction, Euclidea
                          ScalingTerm, SquaredExponential, SumOfCovarianceFunctions, as_measurements,
                          measurement_only)
 
+from .gp import (AlbatrossAmdError, Context, FitModel, GaussianProcessRegression, GPFit, JointDistribution,
+                 LinearMean, MarginalDistribution, NanInputError, NotPositiveDefiniteError, Prediction,
+                 RegressionDataset, ZeroMean, default_context, gp_from_covariance, gp_from_covariance_and_mean)
+
 __all__ = [n for n in dir() if not n.startswith("_")]

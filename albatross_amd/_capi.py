@@ -1,8 +1,8 @@
 """ctypes declarations of the C-ABI in include/albatross_amd.h.
 
-Only the struct layouts and the loader live here; they are shared by the
-product wrapper (which loads libalbatross_amd.so and nothing else) and by the
-test-side oracle wrapper (oracle/oracle_py.py, which reuses the struct types).
+Only the struct layouts and the loader live here.  The product wrapper loads
+libalbatross_amd.so and nothing else; the struct types are also reused by the
+test-side CPU checker's wrapper.
 """
 import ctypes as C
 import os

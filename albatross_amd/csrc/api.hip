@@ -1,0 +1,688 @@
+// api.hip — the C-ABI of include/albatross_amd.h.
+//
+// Host-side orchestration only: uploads POD feature vectors, enqueues the HIP
+// kernels of gram.hip / chol.hip / gemm.hip / reduce.hip on the context's
+// stream, reads back the small results.  No CPU arithmetic fallback exists.
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "common.h"
+
+namespace agp {
+void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n);
+void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n);
+
+void DeviceFeatures::release() {
+  for (void *&p : owned) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+  v = FeatView{};
+}
+
+static long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
+
+// leading dimension of the factor: even (16-B aligned columns) and not a
+// multiple of 256 doubles, so that consecutive columns do not alias the same
+// HBM channel / L2 set pattern
+static long long factor_ld(long long n) {
+  long long ld = round_up(n, 8);
+  if (ld % 256 == 0) ld += 8;
+  return ld;
+}
+
+}  // namespace agp
+
+using namespace agp;
+
+struct ProgSlot {
+  unsigned long long uid = 0;
+  DevProgram *dev = nullptr;
+};
+
+struct agp_context_ext {
+  ProgSlot slots[8];
+  int next = 0;
+};
+
+static std::atomic<unsigned long long> g_kernel_uid{1};
+
+struct agp_kernel_full : agp_kernel {
+  unsigned long long uid;
+};
+
+// context extension kept out of common.h (host-only bookkeeping)
+static agp_context_ext *ext_of(agp_context *ctx);
+
+struct agp_context_impl : agp_context {
+  agp_context_ext ext;
+  std::vector<hipEvent_t> gemm_events;
+  std::vector<double> gemm_flops;
+  hipEvent_t stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double *partial_ws = nullptr;
+  size_t partial_bytes = 0;
+  double gemm_ms_sum = 0., gemm_flop_sum = 0.;
+  int gemm_launches = 0;
+};
+
+static agp_context_ext *ext_of(agp_context *ctx) { return &static_cast<agp_context_impl *>(ctx)->ext; }
+
+extern "C" {
+
+const char *agp_status_string(int status) {
+  switch (status) {
+  case AGP_OK: return "ok";
+  case AGP_ERR_INVALID_ARGUMENT: return "invalid argument";
+  case AGP_ERR_NAN_INPUT: return "covariance matrix contains NaN";
+  case AGP_ERR_NOT_POSITIVE_DEFINITE: return "covariance matrix is not positive definite";
+  case AGP_ERR_HIP: return "HIP runtime error";
+  case AGP_ERR_COMM: return "communication error";
+  case AGP_ERR_UNSUPPORTED: return "unsupported";
+  case AGP_ERR_NO_DEVICE: return "no HIP device";
+  default: return "unknown status";
+  }
+}
+
+int agp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int agp_context_create(int device_id, agp_context **out) {
+  if (!out) return AGP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return AGP_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= n) return AGP_ERR_INVALID_ARGUMENT;
+  agp_context_impl *ctx = new (std::nothrow) agp_context_impl();
+  if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
+  ctx->device = device_id;
+  AGP_HIP_CHECK(ctx, hipSetDevice(device_id));
+  AGP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  AGP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+  AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+  AGP_HIP_CHECK(ctx, hipMalloc(&ctx->d_flags, 4 * sizeof(int)));
+  AGP_HIP_CHECK(ctx, hipMalloc(&ctx->d_scalars, 4 * sizeof(double)));
+  AGP_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_flags, 4 * sizeof(int)));
+  AGP_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_scalars, 4 * sizeof(double)));
+  for (auto &e : ctx->stage_ev) AGP_HIP_CHECK(ctx, hipEventCreate(&e));
+  for (auto &sl : ctx->ext.slots) AGP_HIP_CHECK(ctx, hipMalloc(&sl.dev, sizeof(DevProgram)));
+  *out = ctx;
+  return AGP_OK;
+}
+
+void agp_context_destroy(agp_context *c) {
+  if (!c) return;
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto &sl : ctx->ext.slots)
+    if (sl.dev) (void)hipFree(sl.dev);
+  for (auto e : ctx->gemm_events) (void)hipEventDestroy(e);
+  for (auto e : ctx->stage_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->partial_ws) (void)hipFree(ctx->partial_ws);
+  if (ctx->ws_A) (void)hipFree(ctx->ws_A);
+  if (ctx->ws_aux) (void)hipFree(ctx->ws_aux);
+  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+  if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+  if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+  if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+  if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  delete ctx;
+}
+
+int agp_context_synchronize(agp_context *ctx) {
+  if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return AGP_OK;
+}
+
+const char *agp_last_error(const agp_context *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int agp_set_profiling(agp_context *ctx, int enabled) {
+  if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
+  ctx->profiling = enabled != 0;
+  return AGP_OK;
+}
+
+int agp_last_stage_ms(const agp_context *c, int stage, double *ms) {
+  if (!c || !ms || stage < 0 || stage > 7) return AGP_ERR_INVALID_ARGUMENT;
+  *ms = c->stage_ms[stage];
+  return AGP_OK;
+}
+
+int agp_mfma_f64_peak(agp_context *ctx, int iters, double *tflops) {
+  if (!ctx || !tflops || iters <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return mfma_f64_peak(ctx->stream, iters, tflops);
+}
+
+// ---- covariance function ---------------------------------------------------
+int agp_kernel_create(const agp_kernel_node *postfix, int n_nodes, agp_kernel **out) {
+  if (!postfix || !out || n_nodes <= 0 || n_nodes > AGP_MAX_KERNEL_NODES) return AGP_ERR_INVALID_ARGUMENT;
+  int depth = 0, mask = 0, uses_eq = 0;
+  for (int t = 0; t < n_nodes; ++t) {
+    const agp_kernel_node &nd = postfix[t];
+    switch (nd.op) {
+    case AGP_OP_SQUARED_EXPONENTIAL:
+    case AGP_OP_EXPONENTIAL:
+    case AGP_OP_MATERN32:
+    case AGP_OP_MATERN52:
+      if (nd.metric < 0 || nd.metric > AGP_METRIC_ANGULAR) return AGP_ERR_INVALID_ARGUMENT;
+      mask |= 1 << nd.metric;
+      ++depth;
+      break;
+    case AGP_OP_CONSTANT: ++depth; break;
+    case AGP_OP_INDEPENDENT_NOISE:
+    case AGP_OP_NUGGET: uses_eq = 1; ++depth; break;
+    case AGP_OP_POLYNOMIAL:
+      if (nd.order < 0 || nd.order > 3) return AGP_ERR_UNSUPPORTED;
+      ++depth;
+      break;
+    case AGP_OP_SCALING:
+      if (nd.column < 0 || nd.column >= AGP_MAX_SCALE_COLUMNS) return AGP_ERR_INVALID_ARGUMENT;
+      ++depth;
+      break;
+    case AGP_OP_SUM:
+    case AGP_OP_PRODUCT:
+      if (depth < 2) return AGP_ERR_INVALID_ARGUMENT;
+      --depth;
+      break;
+    case AGP_OP_MEASUREMENT_ONLY:
+      if (depth < 1) return AGP_ERR_INVALID_ARGUMENT;
+      break;
+    default: return AGP_ERR_INVALID_ARGUMENT;
+    }
+    if (depth > AGP_MAX_STACK) return AGP_ERR_UNSUPPORTED;
+  }
+  if (depth != 1) return AGP_ERR_INVALID_ARGUMENT;
+  agp_kernel_full *k = new (std::nothrow) agp_kernel_full();
+  if (!k) return AGP_ERR_INVALID_ARGUMENT;
+  std::memset(&k->prog, 0, sizeof(k->prog));
+  k->prog.n_nodes = n_nodes;
+  k->prog.metric_mask = mask;
+  k->prog.uses_equality = uses_eq;
+  std::memcpy(k->prog.nodes, postfix, sizeof(agp_kernel_node) * (size_t)n_nodes);
+  k->uid = g_kernel_uid.fetch_add(1);
+  *out = k;
+  return AGP_OK;
+}
+
+void agp_kernel_destroy(agp_kernel *k) { delete static_cast<agp_kernel_full *>(k); }
+
+}  // extern "C"
+
+// device copy of a kernel program (small LRU ring per context)
+static int device_program(agp_context *ctx, const agp_kernel *k, const DevProgram **out) {
+  agp_context_ext *x = ext_of(ctx);
+  const unsigned long long uid = static_cast<const agp_kernel_full *>(k)->uid;
+  for (auto &sl : x->slots)
+    if (sl.uid == uid) {
+      *out = sl.dev;
+      return AGP_OK;
+    }
+  ProgSlot &sl = x->slots[x->next];
+  x->next = (x->next + 1) % 8;
+  // the slot may still be read by kernels in flight on the stream
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  AGP_HIP_CHECK(ctx, hipMemcpy(sl.dev, &k->prog, sizeof(DevProgram), hipMemcpyHostToDevice));
+  sl.uid = uid;
+  *out = sl.dev;
+  return AGP_OK;
+}
+
+static int validate_features(const agp_features *f) {
+  if (!f || f->n < 0 || f->dim < 1 || f->dim > AGP_MAX_DIM) return AGP_ERR_INVALID_ARGUMENT;
+  if (f->n_scale_columns < 0 || f->n_scale_columns > AGP_MAX_SCALE_COLUMNS) return AGP_ERR_INVALID_ARGUMENT;
+  if (f->n > 0 && !f->coords) return AGP_ERR_INVALID_ARGUMENT;
+  if (f->n_scale_columns > 0 && f->n > 0 && !f->scales) return AGP_ERR_INVALID_ARGUMENT;
+  return AGP_OK;
+}
+
+// Make a device view of a feature vector (uploads host data; `copy` forces an
+// owned device copy of device-resident data as well).
+static int to_device(agp_context *ctx, const agp_features *f, bool copy, DeviceFeatures *out) {
+  const int st = validate_features(f);
+  if (st != AGP_OK) return st;
+  out->release();
+  FeatView v;
+  v.n = f->n; v.dim = f->dim; v.nsc = f->n_scale_columns; v.meas = f->is_measurement;
+  v.coords = nullptr; v.ids = nullptr; v.scales = nullptr;
+  const bool on_host = f->location == AGP_HOST;
+  const hipMemcpyKind kind = on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  if (f->n > 0) {
+    if (on_host || copy) {
+      const size_t cb = sizeof(double) * (size_t)f->n * (size_t)f->dim;
+      AGP_HIP_CHECK(ctx, hipMalloc(&out->owned[0], cb));
+      AGP_HIP_CHECK(ctx, hipMemcpyAsync(out->owned[0], f->coords, cb, kind, ctx->stream));
+      v.coords = static_cast<const double *>(out->owned[0]);
+      if (f->eq_id) {
+        const size_t ib = sizeof(long long) * (size_t)f->n;
+        AGP_HIP_CHECK(ctx, hipMalloc(&out->owned[1], ib));
+        AGP_HIP_CHECK(ctx, hipMemcpyAsync(out->owned[1], f->eq_id, ib, kind, ctx->stream));
+        v.ids = static_cast<const long long *>(out->owned[1]);
+      }
+      if (f->n_scale_columns > 0) {
+        const size_t sb = sizeof(double) * (size_t)f->n * (size_t)f->n_scale_columns;
+        AGP_HIP_CHECK(ctx, hipMalloc(&out->owned[2], sb));
+        AGP_HIP_CHECK(ctx, hipMemcpyAsync(out->owned[2], f->scales, sb, kind, ctx->stream));
+        v.scales = static_cast<const double *>(out->owned[2]);
+      }
+      if (on_host) AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // pageable source
+    } else {
+      v.coords = f->coords;
+      v.ids = reinterpret_cast<const long long *>(f->eq_id);
+      v.scales = f->n_scale_columns > 0 ? f->scales : nullptr;
+    }
+  }
+  out->v = v;
+  return AGP_OK;
+}
+
+static int ensure_ws(agp_context *ctx, double **ws, size_t *have, size_t need) {
+  if (*have >= need) return AGP_OK;
+  if (*ws) {
+    AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    AGP_HIP_CHECK(ctx, hipFree(*ws));
+    *ws = nullptr;
+    *have = 0;
+  }
+  AGP_HIP_CHECK(ctx, hipMalloc(ws, need));
+  *have = need;
+  return AGP_OK;
+}
+
+// a device staging copy of an n-vector living at `location`
+static int vector_to_device(agp_context *ctx, const double *src, long long n, int location, double *dst) {
+  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  AGP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, kind, ctx->stream));
+  if (location == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return AGP_OK;
+}
+
+static int copy_out(agp_context *ctx, const double *dev, long long count, double *dst, int location) {
+  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  AGP_HIP_CHECK(ctx, hipMemcpyAsync(dst, dev, sizeof(double) * (size_t)count, kind, ctx->stream));
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return AGP_OK;
+}
+
+static int copy_out_2d(agp_context *ctx, const double *dev, long long ld_dev, long long rows, long long cols,
+                       double *dst, long long ld_dst, int location) {
+  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, sizeof(double) * (size_t)ld_dst, dev, sizeof(double) * (size_t)ld_dev,
+                                      sizeof(double) * (size_t)rows, (size_t)cols, kind, ctx->stream));
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return AGP_OK;
+}
+
+// Gram + diag add + LL^T (+ fused forward substitution) on A / y.  On return
+// the stream has been synchronised and ctx->h_flags / h_scalars are valid.
+static int build_and_factor(agp_context *c, const DevProgram *dprog, const FeatView &xm, double *A, long long lda,
+                            double *invd, double *y, const double *yvar) {
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  const long long n = xm.n;
+  hipStream_t s = ctx->stream;
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 4 * sizeof(double), s));
+  const bool prof = ctx->profiling;
+  if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[0], s));
+  // as_measurements(features) -> covariance_function_(measurement_features)   gp.hpp:288-290
+  launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, A, lda, yvar, ctx->d_flags);
+  if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[1], s));
+  FactorTimers timers;
+  if (prof) {
+    const size_t want = (size_t)(2 * (2 * ((n + NB - 1) / NB) + 4));
+    while (ctx->gemm_events.size() < want) {
+      hipEvent_t e;
+      AGP_HIP_CHECK(ctx, hipEventCreate(&e));
+      ctx->gemm_events.push_back(e);
+    }
+    ctx->gemm_flops.assign(want / 2, 0.);
+    timers.ev = ctx->gemm_events.data();
+    timers.flops = ctx->gemm_flops.data();
+    timers.n_ev = (int)want;
+  }
+  factor_lower(ctx, A, n, lda, invd, y, prof ? &timers : nullptr);
+  if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[2], s));
+  AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  AGP_HIP_CHECK(ctx, hipGetLastError());
+  if (prof) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->stage_ev[0], ctx->stage_ev[1]);
+    ctx->stage_ms[0] = ms;
+    (void)hipEventElapsedTime(&ms, ctx->stage_ev[1], ctx->stage_ev[2]);
+    ctx->stage_ms[1] = ms;
+    double sum = 0., flop = 0.;
+    for (int i = 0; i + 1 < timers.used; i += 2) {
+      (void)hipEventElapsedTime(&ms, timers.ev[i], timers.ev[i + 1]);
+      sum += ms;
+      flop += timers.flops[i / 2];
+    }
+    ctx->stage_ms[3] = sum;
+    ctx->stage_ms[4] = timers.used / 2;
+    ctx->stage_ms[5] = flop;  // flop of the trailing updates (not ms)
+  }
+  return AGP_OK;
+}
+
+static int status_from_flags(const agp_context *ctx) {
+  if (ctx->h_flags[0]) return AGP_ERR_NAN_INPUT;
+  if (ctx->h_flags[1]) return AGP_ERR_NOT_POSITIVE_DEFINITE;
+  return AGP_OK;
+}
+
+extern "C" {
+
+// ---- Gram ------------------------------------------------------------------
+int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x, const agp_features *y, double *out,
+             int64_t ld, int out_location) {
+  if (!ctx || !k || !x || !out) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(x);
+  if (st != AGP_OK) return st;
+  if (y && (st = validate_features(y)) != AGP_OK) return st;
+  if (y && y->dim != x->dim) return AGP_ERR_INVALID_ARGUMENT;
+  const long long rows = x->n, cols = y ? y->n : x->n;
+  if (rows == 0 || cols == 0) return AGP_OK;
+  if (ld < rows) return AGP_ERR_INVALID_ARGUMENT;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  DeviceFeatures dx, dy;
+  if ((st = to_device(ctx, x, false, &dx)) != AGP_OK) return st;
+  if (y && (st = to_device(ctx, y, false, &dy)) != AGP_OK) { dx.release(); return st; }
+  const FeatView &vy = y ? dy.v : dx.v;
+  if (out_location == AGP_DEVICE) {
+    launch_gram(ctx->stream, dprog, dx.v, vy, y == nullptr, false, out, ld, nullptr, nullptr);
+    st = AGP_OK;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); st = AGP_ERR_HIP; }
+  } else {
+    const long long ldd = round_up(rows, 2);
+    st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)ldd * (size_t)cols);
+    if (st == AGP_OK) {
+      launch_gram(ctx->stream, dprog, dx.v, vy, y == nullptr, false, ctx->ws_aux, ldd, nullptr, nullptr);
+      st = copy_out_2d(ctx, ctx->ws_aux, ldd, rows, cols, out, ld, AGP_HOST);
+    }
+  }
+  dx.release();
+  dy.release();
+  return st;
+}
+
+// ---- fit -------------------------------------------------------------------
+void agp_fit_destroy(agp_fit *fit) {
+  if (!fit) return;
+  (void)hipSetDevice(fit->device);
+  if (fit->A) (void)hipFree(fit->A);
+  if (fit->invd) (void)hipFree(fit->invd);
+  if (fit->alpha) (void)hipFree(fit->alpha);
+  if (fit->z) (void)hipFree(fit->z);
+  fit->train.release();
+  delete fit;
+}
+
+int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y,
+                   const double *y_var, agp_fit **out, double *information, double *log_det) {
+  if (!c || !k || !x || !y || !out) return AGP_ERR_INVALID_ARGUMENT;
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  *out = nullptr;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(x);
+  if (st != AGP_OK) return st;
+  const long long n = x->n;
+  if (n <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+
+  agp_fit *fit = new (std::nothrow) agp_fit();
+  if (!fit) return AGP_ERR_INVALID_ARGUMENT;
+  fit->device = ctx->device;
+  fit->n = n;
+  fit->lda = factor_ld(n);
+  const long long nblk = (n + NB - 1) / NB;
+  hipStream_t s = ctx->stream;
+  double *yvar_d = nullptr;
+#define FIT_CHECK(expr)                                                                  \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+      if (yvar_d) (void)hipFree(yvar_d);                                                 \
+      agp_fit_destroy(fit);                                                              \
+      return AGP_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+  // train_features = features (un-wrapped; gp.hpp:63,293): always an owned copy
+  if ((st = to_device(ctx, x, true, &fit->train)) != AGP_OK) { agp_fit_destroy(fit); return st; }
+  fit->train.v.meas = 0;
+  FIT_CHECK(hipMalloc(&fit->A, sizeof(double) * (size_t)fit->lda * (size_t)n));
+  FIT_CHECK(hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * NMB * MB * MB));
+  FIT_CHECK(hipMalloc(&fit->alpha, sizeof(double) * (size_t)n));
+  FIT_CHECK(hipMalloc(&fit->z, sizeof(double) * (size_t)n));
+  const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  FIT_CHECK(hipMemcpyAsync(fit->z, y, sizeof(double) * (size_t)n, kind, s));
+  if (y_var) {
+    FIT_CHECK(hipMalloc(&yvar_d, sizeof(double) * (size_t)n));
+    FIT_CHECK(hipMemcpyAsync(yvar_d, y_var, sizeof(double) * (size_t)n, kind, s));
+  }
+  if (x->location == AGP_HOST) FIT_CHECK(hipStreamSynchronize(s));
+  {
+    const size_t need = sizeof(double) * (size_t)((n + 255) / 256 + 1) * NB;
+    if (ctx->partial_bytes < need) {
+      if (ctx->partial_ws) FIT_CHECK(hipFree(ctx->partial_ws));
+      ctx->partial_ws = nullptr;
+      FIT_CHECK(hipMalloc(&ctx->partial_ws, need));
+      ctx->partial_bytes = need;
+    }
+  }
+
+  FeatView xm = fit->train.v;
+  xm.meas = 1;  // as_measurements(features), gp.hpp:288
+  st = build_and_factor(ctx, dprog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d);
+  if (yvar_d) { (void)hipFree(yvar_d); yvar_d = nullptr; }
+  if (st != AGP_OK) { agp_fit_destroy(fit); return st; }
+  st = status_from_flags(ctx);
+  fit->failed_pivot = ctx->h_flags[1] ? (int64_t)ctx->h_flags[1] - 1 : -1;
+  fit->log_det = 2. * ctx->h_scalars[0];
+  if (st != AGP_OK) {
+    // keep a handle so the caller can query the failed pivot, but no factor
+    *out = fit;
+    return st;
+  }
+  // information = L^-T (L^-1 y)
+  if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[3], s));
+  FIT_CHECK(hipMemcpyAsync(fit->alpha, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+  backward_solve_vec(s, fit->A, n, fit->lda, fit->invd, fit->alpha, ctx->partial_ws);
+  if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[4], s));
+  if (information) FIT_CHECK(hipMemcpyAsync(information, fit->alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+  FIT_CHECK(hipStreamSynchronize(s));
+  FIT_CHECK(hipGetLastError());
+  if (ctx->profiling) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->stage_ev[3], ctx->stage_ev[4]);
+    ctx->stage_ms[2] = ms;
+  }
+  if (log_det) *log_det = fit->log_det;
+  *out = fit;
+#undef FIT_CHECK
+  return AGP_OK;
+}
+
+int64_t agp_fit_size(const agp_fit *fit) { return fit ? fit->n : 0; }
+int64_t agp_fit_failed_pivot(const agp_fit *fit) { return fit ? fit->failed_pivot : -1; }
+
+int agp_fit_log_determinant(const agp_fit *fit, double *out) {
+  if (!fit || !out) return AGP_ERR_INVALID_ARGUMENT;
+  *out = fit->log_det;
+  return AGP_OK;
+}
+
+int agp_fit_download_information(agp_context *ctx, const agp_fit *fit, double *information) {
+  if (!ctx || !fit || !information) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return copy_out(ctx, fit->alpha, fit->n, information, AGP_HOST);
+}
+
+int agp_fit_download_factor(agp_context *ctx, const agp_fit *fit, double *L, int64_t ld) {
+  if (!ctx || !fit || !L || ld < fit->n) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const long long n = fit->n;
+  int st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)fit->lda * (size_t)n);
+  if (st != AGP_OK) return st;
+  AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws_aux, fit->A, sizeof(double) * (size_t)fit->lda * (size_t)n,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+  launch_zero_upper(ctx->stream, ctx->ws_aux, fit->lda, n);
+  return copy_out_2d(ctx, ctx->ws_aux, fit->lda, n, n, L, ld, AGP_HOST);
+}
+
+// ---- nll -------------------------------------------------------------------
+int agp_nll(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y, const double *y_var,
+            double *out) {
+  if (!c || !k || !x || !y || !out) return AGP_ERR_INVALID_ARGUMENT;
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(x);
+  if (st != AGP_OK) return st;
+  const long long n = x->n;
+  if (n <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  const long long lda = factor_ld(n);
+  const long long nblk = (n + NB - 1) / NB;
+  // workspace: [A | invd | z | yvar]
+  const size_t a_bytes = sizeof(double) * (size_t)lda * (size_t)n;
+  const size_t aux = sizeof(double) * ((size_t)nblk * NMB * MB * MB + 2 * (size_t)round_up(n, 2));
+  if ((st = ensure_ws(ctx, &ctx->ws_A, &ctx->ws_A_bytes, a_bytes + aux)) != AGP_OK) return st;
+  double *A = ctx->ws_A;
+  double *invd = A + (size_t)lda * (size_t)n;
+  double *z = invd + (size_t)nblk * NMB * MB * MB;
+  double *yvar_d = y_var ? z + round_up(n, 2) : nullptr;
+  DeviceFeatures dx;
+  if ((st = to_device(ctx, x, false, &dx)) != AGP_OK) return st;
+  if ((st = vector_to_device(ctx, y, n, x->location, z)) != AGP_OK) { dx.release(); return st; }
+  if (y_var && (st = vector_to_device(ctx, y_var, n, x->location, yvar_d)) != AGP_OK) { dx.release(); return st; }
+  FeatView xm = dx.v;
+  xm.meas = 1;
+  st = build_and_factor(ctx, dprog, xm, A, lda, invd, z, yvar_d);
+  if (st == AGP_OK) st = status_from_flags(ctx);
+  if (st == AGP_OK) {
+    // mahalanobis = y^T K^-1 y = z^T z with z = L^-1 y   (likelihood.hpp:44)
+    launch_dot(ctx->stream, z, z, n, ctx->d_scalars + 1);
+    hipError_t e = hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); st = AGP_ERR_HIP; }
+    else {
+      const double log_det = 2. * ctx->h_scalars[0];
+      *out = 0.5 * (log_det + ctx->h_scalars[1] + (double)n * std::log(2 * M_PI));  // likelihood.hpp:46
+    }
+  }
+  dx.release();
+  return st;
+}
+
+// ---- solve -----------------------------------------------------------------
+int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs, int64_t nrhs, double *out, int location) {
+  if (!ctx || !fit || !rhs || !out || nrhs < 0) return AGP_ERR_INVALID_ARGUMENT;
+  if (nrhs == 0) return AGP_OK;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const long long n = fit->n, ldb = round_up(n, 2);
+  int st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)ldb * (size_t)nrhs);
+  if (st != AGP_OK) return st;
+  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->ws_aux, sizeof(double) * (size_t)ldb, rhs, sizeof(double) * (size_t)n,
+                                      sizeof(double) * (size_t)n, (size_t)nrhs, kind, ctx->stream));
+  if (location == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  forward_solve_mat(ctx->stream, fit->A, n, fit->lda, fit->invd, ctx->ws_aux, nrhs, ldb);
+  backward_solve_mat(ctx->stream, fit->A, n, fit->lda, fit->invd, ctx->ws_aux, nrhs, ldb);
+  return copy_out_2d(ctx, ctx->ws_aux, ldb, n, nrhs, out, n, location);
+}
+
+// ---- predict ---------------------------------------------------------------
+int agp_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, const agp_features *xs,
+                     double *mean, int out_location) {
+  if (!ctx || !k || !fit || !xs || !mean) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(xs);
+  if (st != AGP_OK) return st;
+  if (xs->dim != fit->train.v.dim) return AGP_ERR_INVALID_ARGUMENT;
+  const long long m = xs->n;
+  if (m == 0) return AGP_OK;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  DeviceFeatures dxs;
+  if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
+  st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)m);
+  if (st == AGP_OK) {
+    // cross_cov = cov(train_features, features); mean = cross_cov^T information  (gp.hpp:361-363)
+    launch_predict_mean(ctx->stream, dprog, fit->train.v, dxs.v, fit->alpha, ctx->ws_aux);
+    st = copy_out(ctx, ctx->ws_aux, m, mean, out_location);
+  }
+  dxs.release();
+  return st;
+}
+
+static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, const agp_features *xs,
+                          double *mean, double *var_or_cov, bool joint, int out_location) {
+  if (!ctx || !k || !fit || !xs || !mean || !var_or_cov) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(xs);
+  if (st != AGP_OK) return st;
+  if (xs->dim != fit->train.v.dim) return AGP_ERR_INVALID_ARGUMENT;
+  const long long m = xs->n, n = fit->n;
+  if (m == 0) return AGP_OK;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  DeviceFeatures dxs;
+  if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
+  const long long ldv = round_up(n, 2), ldc = round_up(m, 2);
+  // workspace: V (n x m) | mean (m) | prior (m or m x m)
+  const size_t v_elems = (size_t)ldv * (size_t)m;
+  const size_t p_elems = joint ? (size_t)ldc * (size_t)m : (size_t)round_up(m, 2);
+  st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (v_elems + (size_t)round_up(m, 2) + p_elems));
+  if (st != AGP_OK) { dxs.release(); return st; }
+  double *V = ctx->ws_aux, *mean_d = V + v_elems, *prior = mean_d + round_up(m, 2);
+  hipStream_t s = ctx->stream;
+  // mean (gp.hpp:82-85)
+  launch_predict_mean(s, dprog, fit->train.v, dxs.v, fit->alpha, mean_d);
+  // cross_cov = cov(train_features, features)   (gp.hpp:316,337)
+  launch_gram(s, dprog, fit->train.v, dxs.v, false, false, V, ldv, nullptr, nullptr);
+  // V = L^-1 K*  ;  explained = V^T V  (== K*^T K^-1 K*, gp.hpp:96,111)
+  forward_solve_mat(s, fit->A, n, fit->lda, fit->invd, V, m, ldv);
+  if (!joint) {
+    launch_gram_diagonal(s, dprog, dxs.v, prior);                   // gp.hpp:339-343
+    launch_coldot(s, V, ldv, V, ldv, n, m, prior, 1.0, prior);      // gp.hpp:97-99
+    st = copy_out(ctx, mean_d, m, mean, out_location);
+    if (st == AGP_OK) st = copy_out(ctx, prior, m, var_or_cov, out_location);
+  } else {
+    launch_gram(s, dprog, dxs.v, dxs.v, true, false, prior, ldc, nullptr, nullptr);  // prior_cov, gp.hpp:317
+    launch_gemm_nt_sub(s, prior, ldc, V, ldv, true, V, ldv, true, m, m, n, true);   // lower tiles
+    launch_symmetrize(s, prior, ldc, m);
+    st = copy_out(ctx, mean_d, m, mean, out_location);
+    if (st == AGP_OK) st = copy_out_2d(ctx, prior, ldc, m, m, var_or_cov, m, out_location);
+  }
+  dxs.release();
+  return st;
+}
+
+int agp_predict_marginal(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, const agp_features *xs,
+                         double *mean, double *variance, int out_location) {
+  return predict_common(ctx, k, fit, xs, mean, variance, false, out_location);
+}
+
+int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, const agp_features *xs,
+                      double *mean, double *cov, int out_location) {
+  return predict_common(ctx, k, fit, xs, mean, cov, true, out_location);
+}
+
+}  // extern "C"

@@ -1,0 +1,509 @@
+// chol.hip — K3: blocked right-looking LL^T on fp64 MFMA, with the forward
+// substitution z = L^-1 y fused into the panel kernels.
+//
+// Replaces Eigen::SerializableLDLT(cov) + .solve(y)
+// (include/albatross/src/eigen/serializable_ldlt.hpp:27, models/gp.hpp:67-68).
+// The reference factor is a pivoted L D L^T; this one is un-pivoted L L^T —
+// parity is defined on K^-1 y, log|K| and predictions.
+//
+// Structure (NB = 128, NBO = 512, micro block MB = 16):
+//   for every outer block of NBO columns:
+//     for every NB-wide diagonal block inside it:
+//       potrf_diag_kernel   one workgroup: 128x128 block in LDS, 8 micro steps
+//                           {register POTRF16 + INV16 | MFMA TRSM | MFMA SYRK}
+//       trsm_panel_kernel   rows below: X <- X L11^-T by substitution over the
+//                           micro blocks, all on MFMA; accumulators of finished
+//                           micro columns are reused directly as MFMA operands
+//       gemm_nt_sub (K=128) update of the rest of the outer block column
+//     gemm_nt_sub (K=512)   trailing update  (the MFMA-bound bulk, gemm.hip)
+#include "common.h"
+#include "mfma_f64.h"
+
+namespace agp {
+
+constexpr int PLD = NB + 8;  // LDS pitch of the diagonal block image
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+struct PotrfArgs {
+  double *A;        // matrix base
+  long long lda;
+  long long k0;     // first row/col of the diagonal block
+  int nbk;          // valid size of the block (<= NB)
+  double *invd;     // NMB inverted micro blocks for this diagonal block
+  double *y;        // y + k0 or nullptr
+  int *flags;
+  double *scalars;
+};
+
+__global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
+  __shared__ double S[NB * PLD];       // S[c * PLD + r], lower triangle live
+  __shared__ double Wl[NMB][MB * MB];  // inverted micro blocks, column-major
+  __shared__ double ys[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, lg = lane >> 4;
+  const int nbk = p.nbk;
+
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int c = idx >> 7, r = idx & (NB - 1);
+    double v;
+    if (r < nbk && c < nbk) v = (r >= c) ? p.A[(p.k0 + c) * p.lda + p.k0 + r] : 0.;
+    else v = (r == c) ? 1. : 0.;  // identity padding of a partial last block
+    S[c * PLD + r] = v;
+  }
+  if (tid < NB) ys[tid] = (p.y && tid < nbk) ? p.y[tid] : 0.;
+  __syncthreads();
+
+  double logsum = 0.;
+  int bad_pivot = 0;
+
+#pragma unroll 1
+  for (int jb = 0; jb < NMB; ++jb) {
+    const int o = jb * MB;
+    // ---- stage 1: POTRF16 + INV16 of the diagonal micro block, wave 0, in registers ----
+    if (wave == 0) {
+      double a[MB], dinv[MB], w[MB];
+#pragma unroll
+      for (int c = 0; c < MB; ++c) a[c] = S[(o + c) * PLD + o + ln];  // lane ln holds row ln
+#pragma unroll
+      for (int c = 0; c < MB; ++c) {
+        const double piv = readlane_f64(a[c], c);
+        if (!(piv > 0.) && bad_pivot == 0) bad_pivot = o + c + 1;
+        const double s = sqrt(piv);
+        const double inv = 1. / s;
+        dinv[c] = inv;
+        logsum += log(s);
+        a[c] = (ln == c) ? s : a[c] * inv;
+#pragma unroll
+        for (int j = c + 1; j < MB; ++j) {
+          const double ljc = readlane_f64(a[c], j);
+          a[j] -= a[c] * ljc;
+        }
+      }
+      // W = L16^-1 : lane ln computes column ln by forward substitution on e_ln
+#pragma unroll
+      for (int r = 0; r < MB; ++r) {
+        double acc = (ln == r) ? 1. : 0.;
+#pragma unroll
+        for (int k = 0; k < r; ++k) acc -= readlane_f64(a[k], r) * w[k];
+        w[r] = acc * dinv[r];
+      }
+      if (lane < MB) {
+#pragma unroll
+        for (int c = 0; c < MB; ++c) S[(o + c) * PLD + o + ln] = (c <= ln) ? a[c] : 0.;
+#pragma unroll
+        for (int r = 0; r < MB; ++r) {
+          Wl[jb][ln * MB + r] = w[r];
+          p.invd[jb * MB * MB + ln * MB + r] = w[r];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- stage 2: micro TRSM of the tiles below, X <- X W^T, one tile per wave ----
+    for (int ib = jb + 1 + wave; ib < NMB; ib += 4) {
+      v4d acc = v4zero();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double wa = Wl[jb][(4 * s + lg) * MB + ln];            // W[m=ln][k]
+        const double xb = S[(o + 4 * s + lg) * PLD + ib * MB + ln];  // Xold[n=ln][k]
+        acc = mfma16(wa, xb, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(o + lg + 4 * r) * PLD + ib * MB + ln] = acc[r];
+    }
+    // z_jb = W y_jb  (wave 3, 16 lanes; reads precede the write in program order)
+    if (wave == 3) {
+      double zz = 0.;
+#pragma unroll
+      for (int c = 0; c < MB; ++c) zz += Wl[jb][c * MB + ln] * ys[o + c];
+      if (lane < MB) ys[o + ln] = zz;
+    }
+    __syncthreads();
+
+    // ---- stage 3: micro SYRK of the trailing tiles + y update ----
+    {
+      const int rem = NMB - 1 - jb;          // trailing micro blocks
+      const int ntile = rem * (rem + 1) / 2;  // lower tiles (ib >= kb)
+      for (int tix = wave; tix < ntile; tix += 4) {
+        int kb = 0, left = tix;
+        while (left >= rem - kb) { left -= rem - kb; ++kb; }
+        const int ib = kb + left;
+        const int cb = (jb + 1 + kb) * MB, rb = (jb + 1 + ib) * MB;
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = S[(cb + lg + 4 * r) * PLD + rb + ln];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double xa = -S[(o + 4 * s + lg) * PLD + cb + ln];  // X_kb[m=ln][k]
+          const double xb = S[(o + 4 * s + lg) * PLD + rb + ln];   // X_ib[n=ln][k]
+          acc = mfma16(xa, xb, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(cb + lg + 4 * r) * PLD + rb + ln] = acc[r];
+      }
+      const int row = o + MB + tid;
+      if (row < NB) {
+        double s = ys[row];
+#pragma unroll
+        for (int k = 0; k < MB; ++k) s -= S[(o + k) * PLD + row] * ys[o + k];
+        ys[row] = s;
+      }
+    }
+    __syncthreads();
+  }
+
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int c = idx >> 7, r = idx & (NB - 1);
+    if (r < nbk && c < nbk && r >= c) p.A[(p.k0 + c) * p.lda + p.k0 + r] = S[c * PLD + r];
+  }
+  if (p.y && tid < nbk) p.y[tid] = ys[tid];
+  if (tid == 0) {
+    p.scalars[0] += logsum;
+    if (bad_pivot && p.flags[1] == 0) p.flags[1] = (int)(p.k0 + bad_pivot);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Substitution against one NB x NB diagonal block over its micro blocks.
+//   Y (NB x 16 per wave, held as 8 C/D tiles) <- L11^-1 Y        (TRANS = false)
+//   Y                                         <- L11^-T Y        (TRANS = true)
+// Element (m, n) of Y lives at base[m * stride_m + n * stride_n]:
+//   panel TRSM  X <- X L11^-T : Y = X^T, stride_m = lda, stride_n = 1
+//   left  TRSM  V <- L11^-1 V : Y = V,   stride_m = 1,   stride_n = ldv
+// LDS holds the 36 lower 16x16 tiles of L11 as ready-made MFMA A-operand
+// fragments (negated off-diagonal tiles, inverted diagonal tiles).
+// ---------------------------------------------------------------------------
+constexpr int NFRAG_TILES = NMB * (NMB + 1) / 2;  // 36
+
+struct TrsmArgs {
+  const double *L;  // diagonal block origin: L11(0,0)
+  long long ldl;
+  const double *invd;  // NMB inverted micro blocks of this diagonal block
+  int nbk;
+  double *Y;  // element (0, 0) of the block to be solved
+  long long stride_m, stride_n;
+  long long ncols;  // number of n (panel rows / V columns)
+  const double *z;  // z_b (nbk) or nullptr          (FUSE_Y only)
+  double *yrest;    // y entries matching n = 0..ncols (FUSE_Y only)
+};
+
+template <bool TRANS, bool FUSE_Y>
+__global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
+  __shared__ double F[NFRAG_TILES * 4 * 64 + NB];
+  double *zs = F + NFRAG_TILES * 4 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, lg = lane >> 4;
+
+  // ---- stage the fragment image of L11 ----
+  for (int e = tid; e < NFRAG_TILES * 4 * 64; e += 256) {
+    const int l = e & 63, s = (e >> 6) & 3, t = e >> 8;
+    int jb = 0;
+    while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;  // t = jb(jb+1)/2 + ib, ib <= jb
+    const int ib = t - jb * (jb + 1) / 2;
+    const int m = l & 15, k = (l >> 4) + 4 * s;
+    double v;
+    if (ib == jb) {
+      // W = inv(L_jj) column-major: W[m][k] at k*16+m ; transposed solve uses W^T
+      v = TRANS ? p.invd[jb * MB * MB + m * MB + k] : p.invd[jb * MB * MB + k * MB + m];
+    } else {
+      // !TRANS: tile T[m][k] = -L[jb*16+m][ib*16+k]
+      //  TRANS: the pair (row block ib' = jb, col block jb' = ib) needs
+      //         T[m][k] = -L[jb*16+k][ib*16+m]
+      const int lr = TRANS ? (jb * MB + k) : (jb * MB + m);
+      const int lc = TRANS ? (ib * MB + m) : (ib * MB + k);
+      v = (lr < p.nbk && lc < p.nbk) ? -p.L[(long long)lc * p.ldl + lr] : 0.;
+    }
+    F[e] = v;
+  }
+  if (FUSE_Y && tid < NB) zs[tid] = (tid < p.nbk) ? p.z[tid] : 0.;
+  __syncthreads();
+
+  const long long n0 = ((long long)blockIdx.x * 4 + wave) * 16;
+  if (n0 >= p.ncols) return;
+  const bool nok = n0 + ln < p.ncols;
+  double *base = p.Y + (n0 + ln) * p.stride_n;
+
+  v4d Y[NMB];
+  if (!TRANS) {
+#pragma unroll
+    for (int jb = 0; jb < NMB; ++jb) {
+      v4d acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = jb * MB + lg + 4 * r;
+        acc[r] = (nok && m < p.nbk) ? base[m * p.stride_m] : 0.;
+      }
+#pragma unroll
+      for (int ib = 0; ib < jb; ++ib) {
+        const double *f = F + (jb * (jb + 1) / 2 + ib) * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma16(f[s * 64], Y[ib][s], acc);
+      }
+      v4d out = v4zero();
+      const double *f = F + (jb * (jb + 1) / 2 + jb) * 256 + lane;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) out = mfma16(f[s * 64], acc[s], out);
+      Y[jb] = out;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = jb * MB + lg + 4 * r;
+        if (nok && m < p.nbk) base[m * p.stride_m] = out[r];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int jb = NMB - 1; jb >= 0; --jb) {
+      v4d acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = jb * MB + lg + 4 * r;
+        acc[r] = (nok && m < p.nbk) ? base[m * p.stride_m] : 0.;
+      }
+#pragma unroll
+      for (int ib = NMB - 1; ib > jb; --ib) {
+        // image tile index of the stored pair (row block ib, col block jb)
+        const double *f = F + (ib * (ib + 1) / 2 + jb) * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma16(f[s * 64], Y[ib][s], acc);
+      }
+      v4d out = v4zero();
+      const double *f = F + (jb * (jb + 1) / 2 + jb) * 256 + lane;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) out = mfma16(f[s * 64], acc[s], out);
+      Y[jb] = out;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = jb * MB + lg + 4 * r;
+        if (nok && m < p.nbk) base[m * p.stride_m] = out[r];
+      }
+    }
+  }
+
+  if (FUSE_Y) {
+    // y[n] -= sum_m X[n][m] z[m]   (forward substitution carried by the panel)
+    double part = 0.;
+#pragma unroll
+    for (int jb = 0; jb < NMB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part += Y[jb][r] * zs[jb * MB + lg + 4 * r];
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (lg == 0 && nok) p.yrest[n0 + ln] -= part;
+  }
+}
+
+// In the TRANS staging above the image is indexed t = jb(jb+1)/2 + ib with
+// ib <= jb; for the transposed solve the "row block" of the stored pair is jb
+// and the "column block" ib, i.e. tile (jb, ib) of L, used when solving micro
+// block ib with the already-solved block jb > ib.
+
+static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, int nbk, double *invd,
+                         double *y, int *flags, double *scalars) {
+  PotrfArgs p;
+  p.A = A; p.lda = lda; p.k0 = k0; p.nbk = nbk;
+  p.invd = invd + (k0 / NB) * (long long)(NMB * MB * MB);
+  p.y = y ? y + k0 : nullptr;
+  p.flags = flags; p.scalars = scalars;
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, s, p);
+}
+
+// trailing update C -= P P^T (lower tiles) bracketed by a HIP-event pair when
+// the caller collects per-launch timings (bench.py's roofline block)
+static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long lda, const double *P,
+                       long long M, long long N, long long K) {
+  const bool timed = timers && timers->ev && timers->used + 2 <= timers->n_ev;
+  if (timed) (void)hipEventRecord(timers->ev[timers->used], s);
+  launch_gemm_nt_sub(s, C, lda, P, lda, false, P, lda, false, M, N, K, true);
+  if (timed) {
+    (void)hipEventRecord(timers->ev[timers->used + 1], s);
+    // algorithmic flop: 2 K per C entry on or below the diagonal
+    timers->flops[timers->used / 2] = 2. * (double)K * ((double)M * (double)N - 0.5 * (double)N * (double)(N - 1));
+    timers->used += 2;
+  }
+}
+
+void factor_lower(agp_context *ctx, double *A, long long n, long long lda, double *invd, double *y,
+                  FactorTimers *timers) {
+  hipStream_t s = ctx->stream;
+  for (long long K0 = 0; K0 < n; K0 += NBO) {
+    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
+    for (long long k = K0; k < kend; k += NB) {
+      const int nbk = (int)((n - k < NB) ? n - k : NB);
+      launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars);
+      const long long below = n - (k + nbk);
+      if (below <= 0) continue;
+      TrsmArgs t;
+      t.L = A + k * lda + k; t.ldl = lda;
+      t.invd = invd + (k / NB) * (long long)(NMB * MB * MB);
+      t.nbk = nbk;
+      t.Y = A + k * lda + (k + nbk);
+      t.stride_m = lda; t.stride_n = 1;
+      t.ncols = below;
+      t.z = y ? y + k : nullptr;
+      t.yrest = y ? y + k + nbk : nullptr;
+      const unsigned grid = (unsigned)((below + 63) / 64);
+      if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
+      else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
+      const long long width = kend - (k + nbk);
+      if (width > 0) {
+        const double *P = A + k * lda + (k + nbk);
+        timed_gemm(s, timers, A + (k + nbk) * lda + (k + nbk), lda, P, below, width, nbk);
+      }
+    }
+    if (kend < n) {
+      const double *P = A + K0 * lda + kend;
+      timed_gemm(s, timers, A + kend * lda + kend, lda, P, n - kend, n - kend, kend - K0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// multi-RHS triangular solves (K4): B <- L^-1 B and B <- L^-T B
+// ---------------------------------------------------------------------------
+void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                       double *B, long long m, long long ldb) {
+  if (m <= 0) return;
+  for (long long K0 = 0; K0 < n; K0 += NBO) {
+    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
+    for (long long k = K0; k < kend; k += NB) {
+      const int nbk = (int)((n - k < NB) ? n - k : NB);
+      TrsmArgs t;
+      t.L = A + k * lda + k; t.ldl = lda;
+      t.invd = invd + (k / NB) * (long long)(NMB * MB * MB);
+      t.nbk = nbk;
+      t.Y = B + k;
+      t.stride_m = 1; t.stride_n = ldb;
+      t.ncols = m;
+      t.z = nullptr; t.yrest = nullptr;
+      hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, t);
+      const long long rows = kend - (k + nbk);
+      if (rows > 0)  // B[k+nbk : kend] -= L[k+nbk : kend, k : k+nbk] B[k : k+nbk]
+        launch_gemm_nt_sub(s, B + k + nbk, ldb, A + k * lda + (k + nbk), lda, false, B + k, ldb, true, rows, m,
+                           nbk, false);
+    }
+    if (kend < n)  // B[kend :] -= L[kend :, K0 : kend] B[K0 : kend]
+      launch_gemm_nt_sub(s, B + kend, ldb, A + K0 * lda + kend, lda, false, B + K0, ldb, true, n - kend, m,
+                         kend - K0, false);
+  }
+}
+
+void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                        double *B, long long m, long long ldb) {
+  if (m <= 0 || n <= 0) return;
+  const long long nblk = (n + NB - 1) / NB;
+  for (long long b = nblk - 1; b >= 0; --b) {
+    const long long k = b * NB;
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    TrsmArgs t;
+    t.L = A + k * lda + k; t.ldl = lda;
+    t.invd = invd + b * (long long)(NMB * MB * MB);
+    t.nbk = nbk;
+    t.Y = B + k;
+    t.stride_m = 1; t.stride_n = ldb;
+    t.ncols = m;
+    t.z = nullptr; t.yrest = nullptr;
+    hipLaunchKernelGGL((trsm_micro_kernel<true, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, t);
+    if (k > 0)  // B[0 : k] -= L[k : k+nbk, 0 : k]^T B[k : k+nbk]
+      launch_gemm_nt_sub(s, B, ldb, A + k, lda, true, B + k, ldb, true, k, m, nbk, false);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// one right-hand side: x = L^-T z  (second half of K^-1 y, gp.hpp:68)
+// ---------------------------------------------------------------------------
+constexpr int BV_ROWS = 256;  // rows per partial-sum workgroup
+
+// partial[chunk][c] = sum_{rows of chunk} L[row][k0 + c] x[row]
+__global__ __launch_bounds__(256) void gemvt_partial_kernel(const double *__restrict__ A, long long lda,
+                                                            long long k0, int nbk, long long row_begin,
+                                                            long long n, const double *__restrict__ x,
+                                                            double *__restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r0 = row_begin + (long long)blockIdx.x * BV_ROWS;
+  double xv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long long r = r0 + lane + 64 * q;
+    xv[q] = r < n ? x[r] : 0.;
+  }
+  for (int c = wave; c < nbk; c += 4) {
+    const double *col = A + (k0 + c) * lda;
+    double acc = 0.;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long r = r0 + lane + 64 * q;
+      if (r < n) acc += col[r] * xv[q];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) partial[(long long)blockIdx.x * NB + c] = acc;
+  }
+}
+
+// x_b = L_bb^-T (z_b - sum_chunks partial)
+__global__ __launch_bounds__(128) void diag_back_kernel(const double *__restrict__ A, long long lda,
+                                                        long long k0, int nbk, const double *__restrict__ invd,
+                                                        const double *__restrict__ partial, int nchunks,
+                                                        double *__restrict__ z) {
+  __shared__ double S[NB * (NB + 1)];
+  __shared__ double t[NB];
+  __shared__ double xs[MB];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < NB * NB; idx += 128) {
+    const int c = idx >> 7, r = idx & (NB - 1);
+    S[c * (NB + 1) + r] = (r < nbk && c < nbk && r >= c) ? A[(k0 + c) * lda + k0 + r] : 0.;
+  }
+  {
+    double v = tid < nbk ? z[k0 + tid] : 0.;
+    for (int ch = 0; ch < nchunks; ++ch) v -= (tid < nbk) ? partial[(long long)ch * NB + tid] : 0.;
+    t[tid] = v;
+  }
+  __syncthreads();
+  for (int jb = NMB - 1; jb >= 0; --jb) {
+    const int o = jb * MB;
+    if (tid < MB) {
+      // x = W^T t_jb : x[c] = sum_r W[r][c] t[r], W column-major
+      const double *W = invd + jb * MB * MB;
+      double v = 0.;
+#pragma unroll
+      for (int r = 0; r < MB; ++r) v += W[tid * MB + r] * t[o + r];
+      xs[tid] = (o + tid < nbk) ? v : 0.;
+    }
+    __syncthreads();
+    if (tid < o) {
+      double v = t[tid];
+#pragma unroll
+      for (int r = 0; r < MB; ++r) v -= S[tid * (NB + 1) + o + r] * xs[r];
+      t[tid] = v;
+    } else if (tid < o + MB) {
+      t[tid] = xs[tid - o];
+    }
+    __syncthreads();
+  }
+  if (tid < nbk) z[k0 + tid] = t[tid];
+}
+
+void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                        double *z, double *partial_ws) {
+  // partial_ws: ceil(n / BV_ROWS) * NB doubles
+  const long long nblk = (n + NB - 1) / NB;
+  for (long long b = nblk - 1; b >= 0; --b) {
+    const long long k = b * NB;
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    const long long below = n - (k + nbk);
+    const int nchunks = (int)((below + BV_ROWS - 1) / BV_ROWS);
+    if (nchunks > 0)
+      hipLaunchKernelGGL(gemvt_partial_kernel, dim3(nchunks), dim3(256), 0, s, A, lda, k, nbk, k + nbk, n, z,
+                         partial_ws);
+    hipLaunchKernelGGL(diag_back_kernel, dim3(1), dim3(128), 0, s, A, lda, k, nbk,
+                       invd + b * (long long)(NMB * MB * MB), partial_ws, nchunks, z);
+  }
+}
+
+}  // namespace agp

@@ -1,0 +1,144 @@
+// common.h — internal types shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/albatross_amd.h"
+#include "cov_eval.h"
+
+namespace agp {
+
+// Blocking factors of the LL^T factorisation:
+//   NB    diagonal-block / panel width handled by one potrf + one trsm launch
+//   NBO   outer block: trailing updates accumulate NBO columns of panel (K=NBO)
+//   MB    micro-block inside a diagonal block (one f64 MFMA tile)
+constexpr int NB = 128;
+constexpr int NBO = 512;
+constexpr int MB = 16;
+constexpr int NMB = NB / MB;  // 8 micro blocks per diagonal block
+
+struct FeatView {
+  const double *coords;  // n x dim row-major (device)
+  const long long *ids;  // n or nullptr
+  const double *scales;  // n x nsc column-major or nullptr
+  long long n;
+  int dim;
+  int nsc;
+  int meas;
+};
+
+struct DeviceFeatures {
+  FeatView v{};
+  void *owned[3] = {nullptr, nullptr, nullptr};
+  void release();
+};
+
+}  // namespace agp
+
+struct agp_kernel {
+  agp::DevProgram prog;
+};
+
+struct agp_context {
+  int device = 0;
+  hipStream_t stream = nullptr;   // main chain
+  hipStream_t stream2 = nullptr;  // look-ahead / side chain
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  std::string last_error;
+  int *d_flags = nullptr;  // [0] nan flag, [1] first bad pivot + 1
+  int *h_flags = nullptr;  // pinned mirror
+  double *d_scalars = nullptr;  // [0] sum log L_ii, [1] z^T z
+  double *h_scalars = nullptr;  // pinned mirror
+  bool profiling = false;
+  double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // reusable factor workspace (agp_nll re-uses it between tuner steps)
+  double *ws_A = nullptr;
+  size_t ws_A_bytes = 0;
+  double *ws_aux = nullptr;
+  size_t ws_aux_bytes = 0;
+};
+
+struct agp_fit {
+  int device = 0;
+  int64_t n = 0;
+  int64_t lda = 0;
+  double *A = nullptr;      // n x n lower factor, column-major, ld = lda
+  double *invd = nullptr;   // (n/MB) inverted 16x16 diagonal micro blocks
+  double *alpha = nullptr;  // information vector K^-1 y
+  double *z = nullptr;      // L^-1 y
+  agp::DeviceFeatures train;
+  double log_det = 0.;
+  int64_t failed_pivot = -1;
+};
+
+#define AGP_HIP_CHECK(ctx, expr)                                              \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      if (ctx) {                                                              \
+        (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); \
+      }                                                                       \
+      return AGP_ERR_HIP;                                                     \
+    }                                                                         \
+  } while (0)
+
+namespace agp {
+
+// ---- launchers implemented in the .hip files ----
+void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y,
+                 bool symmetric, bool lower_only, double *out, long long ld,
+                 const double *diag_add, int *nan_flag);
+void launch_gram_diagonal(hipStream_t s, const DevProgram *P, const FeatView &X, double *out);
+// mean_j = sum_i k(x_i, xs_j) alpha_i without materialising the cross Gram
+void launch_predict_mean(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &XS,
+                         const double *alpha, double *mean);
+
+// LL^T of the n x n lower triangle of A (ld = lda), in place.  y (n) is
+// overwritten with z = L^-1 y when non-null.  invd receives the inverted
+// diagonal micro blocks.  flags[1] = first non-positive pivot + 1.
+// scalars[0] += sum log L_ii.
+struct FactorTimers {
+  hipEvent_t *ev = nullptr;  // optional pool: one (start, stop) pair per trailing-update launch
+  double *flops = nullptr;   // per pair: flop of that launch
+  int n_ev = 0;
+  int used = 0;
+};
+void factor_lower(agp_context *ctx, double *A, long long n, long long lda, double *invd, double *y,
+                  FactorTimers *timers);
+
+// x = L^-T z (one right-hand side), z overwritten.
+void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                        double *z, double *partial_ws);
+// B (n x m, ldb) <- L^-1 B
+void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                       double *B, long long m, long long ldb);
+// B (n x m, ldb) <- L^-T B
+void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                        double *B, long long m, long long ldb);
+
+// out[j] = sum_i A[i,j] * B[i,j]   (column-wise dot of two n x m matrices)
+void launch_coldot(hipStream_t s, const double *A, long long lda, const double *B, long long ldb,
+                   long long n, long long m, double *out, double scale, const double *base);
+// C (m x m, ldc) = base - V^T W  with V, W n x m
+void launch_gemm_tn_sub(hipStream_t s, const double *V, long long ldv, const double *W, long long ldw,
+                        long long n, long long m, double *C, long long ldc);
+// y = A^T x for A n x m
+void launch_gemv_t(hipStream_t s, const double *A, long long lda, long long n, long long m,
+                   const double *x, double *y);
+void launch_dot(hipStream_t s, const double *a, const double *b, long long n, double *out);
+
+int mfma_f64_peak(hipStream_t s, int iters, double *tflops);
+
+}  // namespace agp
+
+namespace agp {
+// C(M x N) -= A(M x K) * B(N x K)^T  (fp64 MFMA).  a_kmajor / b_kmajor select
+// transposed operand storage; tri keeps only tiles on/below C's diagonal.
+void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
+                        bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
+                        long long N, long long K, bool tri);
+}  // namespace agp

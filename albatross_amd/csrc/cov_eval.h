@@ -1,0 +1,155 @@
+// cov_eval.h — device-side evaluation of one k(x, y) for a composed
+// covariance function given as a postfix agp_kernel_node program.
+//
+// Follows, term by term, include/albatross/src/covariance_functions/
+//   radial.hpp:25-33,191-198,289-297,461-470   (radial kernels)
+//   distance_metrics.hpp:30-90                  (metrics)
+//   noise.hpp:37-43, nugget.hpp:40-48, polynomials.hpp:56-60,78-86
+//   scaling_function.hpp:79-83, measurement.hpp:87-102
+//   covariance_function.hpp:266-272,357-367     (sum, product short-circuit)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/albatross_amd.h"
+
+namespace agp {
+
+// The program lives in device memory and is passed by pointer: every index
+// into it is wave-uniform, so the nodes are fetched with scalar loads through
+// the constant cache (a by-value copy would be demoted to a per-thread LDS
+// array by the compiler because of the dynamic node index).
+struct DevProgram {
+  int n_nodes;
+  int metric_mask;   // bit m set: some radial leaf uses metric m
+  int uses_equality; // any INDEPENDENT_NOISE / NUGGET leaf
+  int pad;
+  agp_kernel_node nodes[AGP_MAX_KERNEL_NODES];
+};
+
+// One point as the pair evaluator sees it.  DIMP = padded dimension
+// (1, 2, 3, 4 or 8); unused trailing coordinates are zero, which leaves every
+// distance / dot product bit-identical.
+template <int DIMP>
+struct Point {
+  double c[DIMP];
+  double norm;                       // ||x||, only valid if metric_mask needs it
+  double s[AGP_MAX_SCALE_COLUMNS];   // ScalingTerm values f(x)
+  long long id;                      // equality id (only when ids are supplied)
+};
+
+// The evaluation stack is an 8-wide fp64 vector indexed by the wave-uniform
+// stack pointer: the backend lowers that to VGPR-indexed moves (no scratch,
+// no LDS), which a plain `double st[8]` does not get.
+typedef double stack_t __attribute__((ext_vector_type(AGP_MAX_STACK)));
+
+__device__ __forceinline__ double stack_get(const stack_t &st, int i) { return st[i]; }
+__device__ __forceinline__ void stack_set(stack_t &st, int i, double v) { st[i] = v; }
+
+template <int DIMP>
+__device__ __forceinline__ double eval_pair(const DevProgram *__restrict__ Pp, const Point<DIMP> &x,
+                                            const Point<DIMP> &y, bool swapped, bool have_ids,
+                                            bool both_measurement) {
+  // `swapped`: evaluate k(y, x) instead of k(x, y).  Every term except the
+  // polynomial's left-to-right product is bitwise symmetric in its arguments.
+  const DevProgram &P = *Pp;
+  // ---- distances, once per pair per metric in use ----
+  double d_euclid = 0., d_radial = 0., d_angular = 0.;
+  if (P.metric_mask & (1 << AGP_METRIC_EUCLIDEAN)) {
+    if (DIMP == 1) {
+      d_euclid = fabs(x.c[0] - y.c[0]);  // distance_metrics.hpp:34-36
+    } else {
+      double s = 0.;
+#pragma unroll
+      for (int d = 0; d < DIMP; ++d) {
+        const double t = x.c[d] - y.c[d];
+        s += t * t;
+      }
+      d_euclid = sqrt(s);  // (x - y).norm()
+    }
+  }
+  if (P.metric_mask & (1 << AGP_METRIC_RADIAL)) d_radial = fabs(x.norm - y.norm);
+  if (P.metric_mask & (1 << AGP_METRIC_ANGULAR)) {
+    double dot = 0.;
+#pragma unroll
+    for (int d = 0; d < DIMP; ++d) dot += x.c[d] * y.c[d];
+    const double c = dot / (x.norm * y.norm);
+    const double eps = 1e-16;  // EPSILON, distance_metrics.hpp:18
+    d_angular = (c > 1. - eps) ? 0. : ((c < -1. + eps) ? M_PI : acos(c));
+  }
+  bool equal = false;
+  if (P.uses_equality) {
+    if (have_ids) {
+      equal = (x.id == y.id);
+    } else {
+      equal = true;
+#pragma unroll
+      for (int d = 0; d < DIMP; ++d) equal = equal && (x.c[d] == y.c[d]);
+    }
+  }
+
+  stack_t st = (stack_t)(0.);
+  int sp = 0;
+  for (int t = 0; t < P.n_nodes; ++t) {
+    const agp_kernel_node &nd = P.nodes[t];
+    const int op = nd.op;
+    if (op <= AGP_OP_MATERN52) {
+      const double dist = nd.metric == AGP_METRIC_EUCLIDEAN ? d_euclid
+                          : (nd.metric == AGP_METRIC_RADIAL ? d_radial : d_angular);
+      const double l = nd.params[0], sigma = nd.params[1];
+      double v;
+      if (l <= 0.) {
+        v = 0.;
+      } else if (op == AGP_OP_SQUARED_EXPONENTIAL) {
+        const double q = dist / l;
+        v = sigma * sigma * exp(-(q * q));  // exp(-pow(d/l, 2))
+      } else if (op == AGP_OP_EXPONENTIAL) {
+        v = sigma * sigma * exp(-fabs(dist / l));
+      } else if (op == AGP_OP_MATERN32) {
+        const double q = sqrt(3.) * dist / l;
+        v = sigma * sigma * (1 + q) * exp(-q);
+      } else {
+        const double q = sqrt(5.) * dist / l;
+        v = sigma * sigma * (1 + q + q * q / 3.) * exp(-q);
+      }
+      stack_set(st, sp, v);
+      ++sp;
+    } else if (op == AGP_OP_CONSTANT) {
+      stack_set(st, sp, nd.params[0] * nd.params[0]);
+      ++sp;
+    } else if (op == AGP_OP_INDEPENDENT_NOISE || op == AGP_OP_NUGGET) {
+      stack_set(st, sp, equal ? nd.params[0] * nd.params[0] : 0.);
+      ++sp;
+    } else if (op == AGP_OP_POLYNOMIAL) {
+      double cov = 0., xp = 1., yp = 1.;
+      for (int q = 0; q <= nd.order; ++q) {
+        const double s = nd.params[q];
+        cov += swapped ? s * s * yp * xp : s * s * xp * yp;  // sigma^2 pow(x,q) pow(y,q)
+        xp *= x.c[0];
+        yp *= y.c[0];
+      }
+      stack_set(st, sp, cov);
+      ++sp;
+    } else if (op == AGP_OP_SCALING) {
+      double fx = x.s[0], fy = y.s[0];
+#pragma unroll
+      for (int k = 1; k < AGP_MAX_SCALE_COLUMNS; ++k) {
+        fx = (nd.column == k) ? x.s[k] : fx;
+        fy = (nd.column == k) ? y.s[k] : fy;
+      }
+      stack_set(st, sp, fx * fy);
+      ++sp;
+    } else if (op == AGP_OP_SUM) {
+      const double r = stack_get(st, sp - 1), l = stack_get(st, sp - 2);
+      stack_set(st, sp - 2, l + r);
+      --sp;
+    } else if (op == AGP_OP_PRODUCT) {
+      const double r = stack_get(st, sp - 1), l = stack_get(st, sp - 2);
+      stack_set(st, sp - 2, (l != 0.) ? l * r : l);  // rhs skipped when lhs == 0
+      --sp;
+    } else if (op == AGP_OP_MEASUREMENT_ONLY) {
+      if (!both_measurement) stack_set(st, sp - 1, 0.);
+    }
+  }
+  return st[0];
+}
+
+}  // namespace agp

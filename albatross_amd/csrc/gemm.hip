@@ -1,0 +1,259 @@
+// gemm.hip — fp64 MFMA update kernel  C <- C - A * B^T  (K3 trailing update,
+// K4/K6 multi-RHS solves and joint covariance).
+//
+// This is where the N^3/3 flop of the factorisation go (the work Eigen's
+// LDLT::compute does at eigen/serializable_ldlt.hpp:27 in the reference).
+//
+// One workgroup = 4 waves = one 128 x 128 tile of C; each wave owns a 64 x 64
+// quadrant = 4 x 4 tiles of v_mfma_f64_16x16x4_f64 (128 accumulator VGPRs).
+// The K loop streams 16-deep chunks of both operand panels global -> registers
+// -> LDS (double buffered, one barrier per chunk); fragments are one
+// ds_read_b64 per lane from a [k][row] image padded to 144 doubles per k so
+// the two 16-lane halves of a 32-lane LDS group fall on disjoint banks.
+// The MFMA "A" operand carries the C-column panel (pre-negated while staging)
+// and the MFMA "B" operand the C-row panel, so that a C/D register holds 16
+// CONSECUTIVE ROWS of one C column: epilogue accesses are 128-B segments of
+// the column-major matrix.
+//
+// Roofline: MFMA-bound.  Per tile 2*128*128*K flop against (2*128*K + 2*128*128)
+// * 8 B of operand + C traffic (K = 512: 64 flop/B).
+#include "common.h"
+#include "mfma_f64.h"
+
+namespace agp {
+
+constexpr int GT = 128;        // C tile edge
+constexpr int GK = 16;         // K chunk
+constexpr int GLD = GT + 16;   // LDS row pitch in doubles
+constexpr int GEMM_THREADS = 256;
+
+struct GemmArgs {
+  double *C;
+  long long ldc;
+  const double *A;  // operand indexed by C row i
+  long long lda;
+  const double *B;  // operand indexed by C col j
+  long long ldb;
+  long long M, N, K;
+  int tri;  // skip tiles strictly above the diagonal of C
+  int ntr, ntc;
+};
+
+// Load this thread's 8 doubles of a 128 x 16 operand chunk.
+//   !KMAJOR: element (row, k) at P[row + k * ld]   (panel stored like the matrix)
+//    KMAJOR: element (row, k) at P[k + row * ld]   (transposed access)
+template <bool KMAJOR>
+__device__ __forceinline__ void load_chunk(const double *__restrict__ P, long long ld, long long row0,
+                                           long long nrows, long long k0, long long K, bool vec_ok,
+                                           double (&r)[8]) {
+  const int t = threadIdx.x;
+  // wave-uniform: interior tile and full chunk -> unguarded 16-B loads
+  const bool fast = vec_ok && (row0 + GT <= nrows) && (k0 + GK <= K);
+  if (!KMAJOR) {
+    const int kk = t >> 4, seg = (t & 15) * 8;
+    const long long row = row0 + seg, k = k0 + kk;
+    const double *p = P + row + k * ld;
+    if (fast) {
+      const double2 a = *reinterpret_cast<const double2 *>(p);
+      const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+      const double2 c = *reinterpret_cast<const double2 *>(p + 4);
+      const double2 d = *reinterpret_cast<const double2 *>(p + 6);
+      r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+      r[4] = c.x; r[5] = c.y; r[6] = d.x; r[7] = d.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r[q] = (k < K && row + q < nrows) ? p[q] : 0.;
+    }
+  } else {
+    const int j = t >> 1, kh = (t & 1) * 8;
+    const long long row = row0 + j, k = k0 + kh;
+    const double *p = P + k + row * ld;
+    if (fast) {
+      const double2 a = *reinterpret_cast<const double2 *>(p);
+      const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+      const double2 c = *reinterpret_cast<const double2 *>(p + 4);
+      const double2 d = *reinterpret_cast<const double2 *>(p + 6);
+      r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+      r[4] = c.x; r[5] = c.y; r[6] = d.x; r[7] = d.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r[q] = (row < nrows && k + q < K) ? p[q] : 0.;
+    }
+  }
+}
+
+template <bool KMAJOR, bool NEGATE>
+__device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const double (&r)[8]) {
+  const int t = threadIdx.x;
+  if (!KMAJOR) {
+    const int kk = t >> 4, seg = (t & 15) * 8;
+    double2 *dst = reinterpret_cast<double2 *>(Ls + kk * GLD + seg);
+    if (NEGATE) {
+      dst[0] = make_double2(-r[0], -r[1]);
+      dst[1] = make_double2(-r[2], -r[3]);
+      dst[2] = make_double2(-r[4], -r[5]);
+      dst[3] = make_double2(-r[6], -r[7]);
+    } else {
+      dst[0] = make_double2(r[0], r[1]);
+      dst[1] = make_double2(r[2], r[3]);
+      dst[2] = make_double2(r[4], r[5]);
+      dst[3] = make_double2(r[6], r[7]);
+    }
+  } else {
+    const int j = t >> 1, kh = (t & 1) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Ls[(kh + q) * GLD + j] = NEGATE ? -r[q] : r[q];
+  }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g) {
+  // one LDS array: [buffer][operand][k][row]
+  __shared__ double lds[2 * 2 * GK * GLD];
+
+  // ---- which tile ----
+  int bj = 0;
+  long long id = blockIdx.x;
+  while (true) {
+    const int cnt = g.tri ? (g.ntr - bj) : g.ntr;
+    if (id < cnt) break;
+    id -= cnt;
+    ++bj;
+  }
+  const int bi = (g.tri ? bj : 0) + (int)id;
+  const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ln = lane & 15, lg = lane >> 4;
+
+  const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
+
+  v4d acc[4][4];  // [tj][ti]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = v4zero();
+
+  double ra[8], rb[8];
+  const long long nk = (g.K + GK - 1) / GK;
+  load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
+  load_chunk<B_KMAJOR>(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb);
+  store_chunk<A_KMAJOR, false>(lds, ra);
+  store_chunk<B_KMAJOR, true>(lds + GK * GLD, rb);
+  __syncthreads();
+
+  for (long long kc = 0; kc < nk; ++kc) {
+    const int cur = (int)(kc & 1);
+    const double *As = lds + cur * (2 * GK * GLD);
+    const double *Bs = As + GK * GLD;
+    const bool more = kc + 1 < nk;
+    if (more) {
+      load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, (kc + 1) * GK, g.K, a_vec, ra);
+      load_chunk<B_KMAJOR>(g.B, g.ldb, j0, g.N, (kc + 1) * GK, g.K, b_vec, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < GK / 4; ++s) {
+      double fa[4], fb[4];
+      const int krow = (4 * s + lg) * GLD;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = Bs[krow + 64 * wc + 16 * t + ln];  // MFMA A operand: C-column panel (negated)
+        fb[t] = As[krow + 64 * wr + 16 * t + ln];  // MFMA B operand: C-row panel
+      }
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
+    }
+    if (more) {
+      double *An = lds + (cur ^ 1) * (2 * GK * GLD);
+      store_chunk<A_KMAJOR, false>(An, ra);
+      store_chunk<B_KMAJOR, true>(An + GK * GLD, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C += acc (acc already holds -A B^T) ----
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const long long row = i0 + 64 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 64 * wc + 16 * tj + lg + 4 * r;
+        if (row < g.M && col < g.N) {
+          double *c = g.C + row + col * g.ldc;
+          *c = *c + acc[tj][ti][r];
+        }
+      }
+    }
+}
+
+static long long count_tiles(int ntr, int ntc, int tri) {
+  long long total = 0;
+  for (int bj = 0; bj < ntc; ++bj) total += tri ? (ntr - bj > 0 ? ntr - bj : 0) : ntr;
+  return total;
+}
+
+// C(M x N) -= A(M x K) * B(N x K)^T ; tri != 0 keeps only tiles on/below the diagonal.
+void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
+                        bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
+                        long long N, long long K, bool tri) {
+  if (M <= 0 || N <= 0 || K <= 0) return;
+  GemmArgs g;
+  g.C = C; g.ldc = ldc; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
+  g.M = M; g.N = N; g.K = K; g.tri = tri ? 1 : 0;
+  g.ntr = (int)((M + GT - 1) / GT);
+  g.ntc = (int)((N + GT - 1) / GT);
+  if (tri && g.ntc > g.ntr) g.ntc = g.ntr;
+  const long long tiles = count_tiles(g.ntr, g.ntc, g.tri);
+  if (tiles <= 0) return;
+  dim3 grid((unsigned)tiles), block(GEMM_THREADS);
+  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<false, false>), grid, block, 0, s, g);
+  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<false, true>), grid, block, 0, s, g);
+  else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<true, false>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm_nt_sub_kernel<true, true>), grid, block, 0, s, g);
+}
+
+// ---- bare MFMA issue loop: measured fp64 matrix peak of this device ----------
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double *sink, int iters, double a0, double b0) {
+  v4d acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = v4zero();
+  double a = a0 + threadIdx.x * 1e-9, b = b0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = mfma16(a, b, acc[i]);
+  }
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456) sink[0] = s;  // keep the loop live
+}
+
+int mfma_f64_peak(hipStream_t s, int iters, double *tflops) {
+  double *sink = nullptr;
+  if (hipMalloc(&sink, 8) != hipSuccess) return AGP_ERR_HIP;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int blocks = 256 * 2;  // 2 workgroups of 4 waves per CU: 2 waves per SIMD
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, sink, 16, 1.0, 2.0);
+  (void)hipEventRecord(e0, s);
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, sink, iters, 1.0, 2.0);
+  (void)hipEventRecord(e1, s);
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double flop = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+  *tflops = flop / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  return e == hipSuccess ? AGP_OK : AGP_ERR_HIP;
+}
+
+}  // namespace agp

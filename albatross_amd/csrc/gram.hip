@@ -1,0 +1,220 @@
+// gram.hip — K1/K2: pairwise covariance evaluation.
+//
+// Replaces compute_covariance_matrix (include/albatross/src/covariance_functions/
+// callers.hpp:38-166): one workgroup produces a 128 x 32 tile of the
+// column-major output.  The two coordinate panels (128 + 32 points) are staged
+// once through LDS as structure-of-arrays; every lane owns two consecutive
+// rows, so each wave store is 64 lanes x 16 B = 1 KiB of one output column
+// (fully coalesced), and the y-point of a column is an LDS broadcast read.
+// HBM-write bound: 8 B per entry out, 8*dim B per point in.
+#include "common.h"
+
+namespace agp {
+
+constexpr int TM = 128;  // tile rows
+constexpr int TN = 32;   // tile cols
+constexpr int GRAM_THREADS = 256;
+
+template <int DIMP>
+struct TileLds {
+  double c[DIMP][TM + TN];
+  double norm[TM + TN];
+  double s[AGP_MAX_SCALE_COLUMNS][TM + TN];
+  long long id[TM + TN];
+};
+
+template <int DIMP>
+__device__ __forceinline__ void stage_points(TileLds<DIMP> &L, int slot0, int count, const FeatView &F,
+                                             long long first, bool need_norm) {
+  for (int t = threadIdx.x; t < count; t += GRAM_THREADS) {
+    const long long g = first + t;
+    const bool ok = g < F.n;
+    double nn = 0.;
+#pragma unroll
+    for (int d = 0; d < DIMP; ++d) {
+      const double v = (ok && d < F.dim) ? F.coords[g * F.dim + d] : 0.;
+      L.c[d][slot0 + t] = v;
+      nn += v * v;
+    }
+    L.norm[slot0 + t] = need_norm ? sqrt(nn) : 0.;
+#pragma unroll
+    for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k)
+      L.s[k][slot0 + t] = (ok && k < F.nsc) ? F.scales[(long long)k * F.n + g] : 0.;
+    L.id[slot0 + t] = (ok && F.ids) ? F.ids[g] : -1;
+  }
+}
+
+template <int DIMP>
+__device__ __forceinline__ Point<DIMP> read_point(const TileLds<DIMP> &L, int slot) {
+  Point<DIMP> p;
+#pragma unroll
+  for (int d = 0; d < DIMP; ++d) p.c[d] = L.c[d][slot];
+  p.norm = L.norm[slot];
+#pragma unroll
+  for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) p.s[k] = L.s[k][slot];
+  p.id = L.id[slot];
+  return p;
+}
+
+template <int DIMP>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const DevProgram *__restrict__ P, FeatView X, FeatView Y,
+                                                            int symmetric, int lower_only, double *out,
+                                                            long long ld, const double *diag_add,
+                                                            int *nan_flag) {
+  __shared__ TileLds<DIMP> L;
+  const long long row0 = (long long)blockIdx.x * TM;
+  const long long col0 = (long long)blockIdx.y * TN;
+  if (lower_only && col0 > row0 + TM - 1) return;  // tile strictly above the diagonal
+  const bool need_norm = (P->metric_mask & ((1 << AGP_METRIC_RADIAL) | (1 << AGP_METRIC_ANGULAR))) != 0;
+  stage_points<DIMP>(L, 0, TM, X, row0, need_norm);
+  stage_points<DIMP>(L, TM, TN, Y, col0, need_norm);
+  __syncthreads();
+
+  const int lane_row = 2 * (threadIdx.x & 63);
+  const int cgrp = threadIdx.x >> 6;
+  const Point<DIMP> xa = read_point<DIMP>(L, lane_row);
+  const Point<DIMP> xb = read_point<DIMP>(L, lane_row + 1);
+  const long long ra = row0 + lane_row, rb = ra + 1;
+  const bool have_ids = X.ids != nullptr && Y.ids != nullptr;
+  const bool both_meas = X.meas && Y.meas;
+  const bool wide = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  bool saw_nan = false;
+#pragma unroll 1
+  for (int jj = 0; jj < TN / 4; ++jj) {
+    const int cslot = cgrp * (TN / 4) + jj;
+    const long long col = col0 + cslot;
+    if (col >= Y.n) break;
+    const Point<DIMP> y = read_point<DIMP>(L, TM + cslot);
+    // symmetric Gram: the reference evaluates caller(xs[i], xs[j]) with i >= j
+    // and mirrors (callers.hpp:119-127); keep the same argument order.
+    double va = eval_pair<DIMP>(P, xa, y, symmetric && ra < col, have_ids, both_meas);
+    double vb = eval_pair<DIMP>(P, xb, y, symmetric && rb < col, have_ids, both_meas);
+    if (diag_add) {
+      if (ra == col) va += diag_add[col];
+      if (rb == col) vb += diag_add[col];
+    }
+    saw_nan = saw_nan || (va != va) || (vb != vb);
+    double *dst = out + col * ld + ra;
+    if (rb < X.n) {
+      if (wide) {
+        *reinterpret_cast<double2 *>(dst) = make_double2(va, vb);
+      } else {
+        dst[0] = va;
+        dst[1] = vb;
+      }
+    } else if (ra < X.n) {
+      dst[0] = va;
+    }
+  }
+  if (saw_nan && nan_flag) atomicOr(nan_flag, 1);
+}
+
+template <int DIMP>
+static void launch_gram_t(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y,
+                          bool symmetric, bool lower_only, double *out, long long ld,
+                          const double *diag_add, int *nan_flag) {
+  dim3 grid((unsigned)((X.n + TM - 1) / TM), (unsigned)((Y.n + TN - 1) / TN));
+  hipLaunchKernelGGL(gram_kernel<DIMP>, grid, dim3(GRAM_THREADS), 0, s, P, X, Y, symmetric ? 1 : 0,
+                     lower_only ? 1 : 0, out, ld, diag_add, nan_flag);
+}
+
+void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y, bool symmetric,
+                 bool lower_only, double *out, long long ld, const double *diag_add, int *nan_flag) {
+  if (X.n == 0 || Y.n == 0) return;
+  const int dim = X.dim;
+  if (dim == 1) launch_gram_t<1>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
+  else if (dim == 2) launch_gram_t<2>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
+  else if (dim == 3) launch_gram_t<3>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
+  else if (dim == 4) launch_gram_t<4>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
+  else launch_gram_t<8>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
+}
+
+// ---- diagonal: prior_variance[i] = cov(f_i, f_i)  (gp.hpp:339-343) -----------
+template <int DIMP>
+__global__ __launch_bounds__(256) void gram_diag_kernel(const DevProgram *__restrict__ P, FeatView X, double *out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= X.n) return;
+  Point<DIMP> p;
+  double nn = 0.;
+#pragma unroll
+  for (int d = 0; d < DIMP; ++d) {
+    p.c[d] = d < X.dim ? X.coords[i * X.dim + d] : 0.;
+    nn += p.c[d] * p.c[d];
+  }
+  p.norm = sqrt(nn);
+#pragma unroll
+  for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) p.s[k] = k < X.nsc ? X.scales[(long long)k * X.n + i] : 0.;
+  p.id = X.ids ? X.ids[i] : -1;
+  out[i] = eval_pair<DIMP>(P, p, p, false, X.ids != nullptr, X.meas != 0);
+}
+
+void launch_gram_diagonal(hipStream_t s, const DevProgram *P, const FeatView &X, double *out) {
+  if (X.n == 0) return;
+  dim3 grid((unsigned)((X.n + 255) / 256));
+  const int dim = X.dim;
+  if (dim == 1) hipLaunchKernelGGL(gram_diag_kernel<1>, grid, dim3(256), 0, s, P, X, out);
+  else if (dim == 2) hipLaunchKernelGGL(gram_diag_kernel<2>, grid, dim3(256), 0, s, P, X, out);
+  else if (dim == 3) hipLaunchKernelGGL(gram_diag_kernel<3>, grid, dim3(256), 0, s, P, X, out);
+  else if (dim == 4) hipLaunchKernelGGL(gram_diag_kernel<4>, grid, dim3(256), 0, s, P, X, out);
+  else hipLaunchKernelGGL(gram_diag_kernel<8>, grid, dim3(256), 0, s, P, X, out);
+}
+
+// ---- fused predictive mean: mean_j = sum_i k(x_i, xs_j) alpha_i ----------------
+// gp_mean_prediction (gp.hpp:82-85) without materialising the N x M cross
+// Gram: one workgroup per 4 test points... each wave owns one test point and
+// strides over the training points; wave reduction at the end.
+constexpr int PM_WAVES = 4;
+
+template <int DIMP>
+__global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_kernel(const DevProgram *__restrict__ P, FeatView X, FeatView XS,
+                                                                      const double *alpha, double *mean) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long j = (long long)blockIdx.x * PM_WAVES + wave;
+  if (j >= XS.n) return;
+  const bool need_norm = (P->metric_mask & ((1 << AGP_METRIC_RADIAL) | (1 << AGP_METRIC_ANGULAR))) != 0;
+  Point<DIMP> y;
+  double nn = 0.;
+#pragma unroll
+  for (int d = 0; d < DIMP; ++d) {
+    y.c[d] = d < XS.dim ? XS.coords[j * XS.dim + d] : 0.;
+    nn += y.c[d] * y.c[d];
+  }
+  y.norm = need_norm ? sqrt(nn) : 0.;
+#pragma unroll
+  for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) y.s[k] = k < XS.nsc ? XS.scales[(long long)k * XS.n + j] : 0.;
+  y.id = XS.ids ? XS.ids[j] : -1;
+  const bool have_ids = X.ids != nullptr && XS.ids != nullptr;
+  const bool both_meas = X.meas && XS.meas;
+  double acc = 0.;
+  for (long long i = lane; i < X.n; i += 64) {
+    Point<DIMP> x;
+    double xn = 0.;
+#pragma unroll
+    for (int d = 0; d < DIMP; ++d) {
+      x.c[d] = d < X.dim ? X.coords[i * X.dim + d] : 0.;
+      xn += x.c[d] * x.c[d];
+    }
+    x.norm = need_norm ? sqrt(xn) : 0.;
+#pragma unroll
+    for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) x.s[k] = k < X.nsc ? X.scales[(long long)k * X.n + i] : 0.;
+    x.id = X.ids ? X.ids[i] : -1;
+    acc += eval_pair<DIMP>(P, x, y, false, have_ids, both_meas) * alpha[i];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) mean[j] = acc;
+}
+
+void launch_predict_mean(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &XS,
+                         const double *alpha, double *mean) {
+  if (XS.n == 0) return;
+  dim3 grid((unsigned)((XS.n + PM_WAVES - 1) / PM_WAVES)), block(64 * PM_WAVES);
+  const int dim = X.dim;
+  if (dim == 1) hipLaunchKernelGGL(predict_mean_kernel<1>, grid, block, 0, s, P, X, XS, alpha, mean);
+  else if (dim == 2) hipLaunchKernelGGL(predict_mean_kernel<2>, grid, block, 0, s, P, X, XS, alpha, mean);
+  else if (dim == 3) hipLaunchKernelGGL(predict_mean_kernel<3>, grid, block, 0, s, P, X, XS, alpha, mean);
+  else if (dim == 4) hipLaunchKernelGGL(predict_mean_kernel<4>, grid, block, 0, s, P, X, XS, alpha, mean);
+  else hipLaunchKernelGGL(predict_mean_kernel<8>, grid, block, 0, s, P, X, XS, alpha, mean);
+}
+
+}  // namespace agp

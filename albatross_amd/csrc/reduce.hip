@@ -1,0 +1,90 @@
+// reduce.hip — K5: small bandwidth-bound reductions of the predict / NLL path.
+#include "common.h"
+
+namespace agp {
+
+// out[j] = base[j] - scale * sum_i A[i,j] * B[i,j]
+// gp_marginal_prediction's explained variance (models/gp.hpp:96-99); with
+// A = B = V = L^-1 K* it is k** - colsum(V o V).
+__global__ __launch_bounds__(256) void coldot_kernel(const double *__restrict__ A, long long lda,
+                                                     const double *__restrict__ B, long long ldb, long long n,
+                                                     double *__restrict__ out, double scale,
+                                                     const double *__restrict__ base) {
+  __shared__ double red[4];
+  const long long j = blockIdx.x;
+  const double *a = A + j * lda, *b = B + j * ldb;
+  double acc = 0.;
+  for (long long i = threadIdx.x; i < n; i += 256) acc += a[i] * b[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double s = (red[0] + red[1]) + (red[2] + red[3]);
+    out[j] = (base ? base[j] : 0.) - scale * s;
+  }
+}
+
+void launch_coldot(hipStream_t s, const double *A, long long lda, const double *B, long long ldb, long long n,
+                   long long m, double *out, double scale, const double *base) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m), dim3(256), 0, s, A, lda, B, ldb, n, out, scale, base);
+}
+
+// out[0] = sum_i a_i b_i   (single workgroup, deterministic order)
+__global__ __launch_bounds__(1024) void dot_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                                   long long n, double *__restrict__ out) {
+  __shared__ double red[16];
+  double acc = 0.;
+  for (long long i = threadIdx.x; i < n; i += 1024) acc += a[i] * b[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    out[0] = s;
+  }
+}
+
+void launch_dot(hipStream_t s, const double *a, const double *b, long long n, double *out) {
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, s, a, b, n, out);
+}
+
+// Mirror the lower triangle of a column-major n x n matrix into the upper one.
+__global__ __launch_bounds__(256) void symmetrize_kernel(double *A, long long ld, long long n) {
+  __shared__ double tile[32][33];
+  const long long bi = blockIdx.x, bj = blockIdx.y;
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const long long row = bi * 32 + tx, col = bj * 32 + r;
+    tile[r][tx] = (row < n && col < n) ? A[col * ld + row] : 0.;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    // write A[bj*32 + tx, bi*32 + r] = tile element (row = bi*32 + r, col = bj*32 + tx)
+    const long long row = bj * 32 + tx, col = bi * 32 + r;
+    if (row < n && col < n && row < col) A[col * ld + row] = tile[tx][r];
+  }
+}
+
+void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n) {
+  if (n <= 0) return;
+  const unsigned nb = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, s, A, ld, n);
+}
+
+// zero the strictly-upper triangle (factor download)
+__global__ __launch_bounds__(256) void zero_upper_kernel(double *A, long long ld, long long n) {
+  const long long col = blockIdx.x;
+  for (long long r = threadIdx.x; r < col && r < n; r += 256) A[col * ld + r] = 0.;
+}
+
+void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)n), dim3(256), 0, s, A, ld, n);
+}
+
+}  // namespace agp

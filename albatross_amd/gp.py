@@ -1,0 +1,426 @@
+"""Host-side mirror of albatross's GaussianProcessRegression call surface.
+
+Mirrors include/albatross/src/models/gp.hpp (GaussianProcessBase :170-463,
+GaussianProcessRegression :487-505, factories :507-537), core/model.hpp,
+core/fit_model.hpp and core/prediction.hpp: `gp_from_covariance(cov).fit(dataset)
+.predict(features).mean()/.marginal()/.joint()`, `model.log_likelihood(dataset)`.
+Every Gram / factor / solve / predict goes through the C-ABI in
+include/albatross_amd.h (HIP kernels); nothing is computed on the CPU here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from .covariance import CovarianceFunction, FeatureSet, Measurement, nodes_to_array
+
+
+class AlbatrossAmdError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        name = capi.load().agp_status_string(status).decode()
+        super().__init__(f"albatross_amd: {name}" + (f" ({detail})" if detail else ""))
+
+
+class NotPositiveDefiniteError(AlbatrossAmdError):
+    pass
+
+
+class NanInputError(AlbatrossAmdError):
+    pass
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """agp_context: HIP streams + workspaces of one GPU."""
+
+    def __init__(self, device_id=0):
+        self._lib = capi.load()
+        h = C.c_void_p()
+        st = self._lib.agp_context_create(device_id, C.byref(h))
+        if st != capi.AGP_OK:
+            raise AlbatrossAmdError(st, "agp_context_create")
+        self._h = h
+        self.device_id = device_id
+        self._kernels = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for kh in self._kernels.values():
+                self._lib.agp_kernel_destroy(kh)
+            self._kernels = {}
+            self._lib.agp_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- helpers ---------------------------------------------------------------
+    def _check(self, st, what):
+        if st == capi.AGP_OK:
+            return
+        detail = what
+        if st == capi.AGP_ERR_HIP:
+            detail += ": " + self._lib.agp_last_error(self._h).decode()
+        if st == capi.AGP_ERR_NOT_POSITIVE_DEFINITE:
+            raise NotPositiveDefiniteError(st, detail)
+        if st == capi.AGP_ERR_NAN_INPUT:
+            raise NanInputError(st, detail)
+        raise AlbatrossAmdError(st, detail)
+
+    def kernel(self, cov):
+        """agp_kernel for the CURRENT parameter values of `cov` (cached by the
+        flattened program bytes, so a tuner revisiting parameters re-uses it)."""
+        nodes = cov.program_nodes()
+        arr = nodes_to_array(nodes)
+        key = bytes(arr)
+        kh = self._kernels.get(key)
+        if kh is None:
+            kh = C.c_void_p()
+            self._check(self._lib.agp_kernel_create(arr, len(nodes), C.byref(kh)), "agp_kernel_create")
+            if len(self._kernels) > 64:
+                for old in self._kernels.values():
+                    self._lib.agp_kernel_destroy(old)
+                self._kernels = {}
+            self._kernels[key] = kh
+        return kh
+
+    def synchronize(self):
+        self._check(self._lib.agp_context_synchronize(self._h), "synchronize")
+
+    def set_profiling(self, enabled):
+        self._check(self._lib.agp_set_profiling(self._h, 1 if enabled else 0), "set_profiling")
+
+    def stage_ms(self, stage):
+        v = C.c_double()
+        self._check(self._lib.agp_last_stage_ms(self._h, stage, C.byref(v)), "last_stage_ms")
+        return v.value
+
+    def mfma_f64_peak(self, iters=20000):
+        v = C.c_double()
+        self._check(self._lib.agp_mfma_f64_peak(self._h, iters, C.byref(v)), "mfma_f64_peak")
+        return v.value
+
+    # --- Gram ------------------------------------------------------------------
+    def gram(self, cov, xs, ys=None):
+        """compute_covariance_matrix (callers.hpp:38-166) on the device."""
+        fx = cov.features(xs)
+        sx = fx.as_struct()
+        kh = self.kernel(cov)
+        if ys is None:
+            out = np.empty((fx.n, fx.n), order="F")
+            st = self._lib.agp_gram(self._h, kh, C.byref(sx), None, _ptr(out), max(fx.n, 1), capi.HOST)
+        else:
+            fy = cov.features(ys)
+            sy = fy.as_struct()
+            out = np.empty((fx.n, fy.n), order="F")
+            st = self._lib.agp_gram(self._h, kh, C.byref(sx), C.byref(sy), _ptr(out), max(fx.n, 1), capi.HOST)
+        self._check(st, "agp_gram")
+        return out
+
+    def gram_diagonal(self, cov, xs):
+        f = cov.features(xs)
+        return np.array([self.gram(cov, FeatureSet(f.coords[i:i + 1],
+                                                   None if f.scales is None else list(f.scales[i:i + 1].T),
+                                                   None if f.eq_id is None else f.eq_id[i:i + 1],
+                                                   f.is_measurement))[0, 0] for i in range(f.n)])
+
+
+_default_context = None
+
+
+def default_context():
+    global _default_context
+    if _default_context is None:
+        _default_context = Context(0)
+    return _default_context
+
+
+# ---------------------------------------------------------------------------
+# core containers (core/dataset.hpp, core/distribution.hpp)
+# ---------------------------------------------------------------------------
+class MarginalDistribution:
+    """mean + diagonal covariance (core/distribution.hpp)."""
+
+    def __init__(self, mean, covariance=None):
+        self.mean = np.asarray(mean, dtype=np.float64)
+        self.covariance = None if covariance is None else np.asarray(covariance, dtype=np.float64)
+
+    def size(self):
+        return self.mean.shape[0]
+
+
+class JointDistribution:
+    def __init__(self, mean, covariance):
+        self.mean = np.asarray(mean, dtype=np.float64)
+        self.covariance = np.asarray(covariance, dtype=np.float64)
+
+    def size(self):
+        return self.mean.shape[0]
+
+    def marginal(self):
+        return MarginalDistribution(self.mean, np.diag(self.covariance).copy())
+
+
+class RegressionDataset:
+    """RegressionDataset<Feature>{features, targets} (core/dataset.hpp)."""
+
+    def __init__(self, features, targets):
+        self.features = features
+        if not isinstance(targets, MarginalDistribution):
+            targets = MarginalDistribution(targets)
+        self.targets = targets
+
+    def size(self):
+        return self.targets.size()
+
+
+class ZeroMean:
+    """mean_function.hpp:274-276"""
+
+    def get_params(self):
+        return {}
+
+    def __call__(self, coords):
+        return np.zeros(len(coords))
+
+
+class LinearMean:
+    """slope * x + offset on 1-D features (polynomials.hpp:92-106)."""
+
+    def __init__(self, slope=0., offset=0.):
+        self._params = {"slope": float(slope), "offset": float(offset)}
+
+    def get_params(self):
+        return dict(self._params)
+
+    def set_param(self, name, value):
+        self._params[name] = float(value)
+
+    def __call__(self, coords):
+        x = np.asarray(coords, dtype=np.float64).reshape(len(coords), -1)[:, 0]
+        return self._params["slope"] * x + self._params["offset"]
+
+
+def _values_of(features):
+    return features.values if isinstance(features, Measurement) else features
+
+
+# ---------------------------------------------------------------------------
+# Fit<GPFit<...>> (gp.hpp:43-77): device factor + information vector
+# ---------------------------------------------------------------------------
+class GPFit:
+    def __init__(self, ctx, handle, n, train_features):
+        self._ctx = ctx
+        self._h = handle
+        self.n = n
+        self.train_features = train_features
+        self._information = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._ctx._h:
+                self._ctx._lib.agp_fit_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    @property
+    def information(self):
+        if self._information is None:
+            out = np.empty(self.n)
+            self._ctx._check(self._ctx._lib.agp_fit_download_information(self._ctx._h, self._h, _ptr(out)),
+                             "download_information")
+            self._information = out
+        return self._information
+
+    @property
+    def log_determinant(self):
+        v = C.c_double()
+        self._ctx._check(self._ctx._lib.agp_fit_log_determinant(self._h, C.byref(v)), "log_determinant")
+        return v.value
+
+    def solve(self, rhs):
+        """train_covariance.solve(rhs) (CovarianceRepresentation, gp.hpp:42-45)."""
+        rhs = np.asarray(rhs, dtype=np.float64)
+        b = np.asfortranarray(rhs.reshape(self.n, -1, order="F"))
+        out = np.empty_like(b, order="F")
+        self._ctx._check(self._ctx._lib.agp_solve(self._ctx._h, self._h, _ptr(b), b.shape[1], _ptr(out), capi.HOST),
+                         "agp_solve")
+        return out.reshape(rhs.shape, order="F")
+
+    def factor(self):
+        L = np.empty((self.n, self.n), order="F")
+        self._ctx._check(self._ctx._lib.agp_fit_download_factor(self._ctx._h, self._h, _ptr(L), self.n),
+                         "download_factor")
+        return L
+
+
+class Prediction:
+    """Lazy prediction object (core/prediction.hpp:115-224)."""
+
+    def __init__(self, fit_model, features):
+        self._fm = fit_model
+        self._features = features
+
+    def mean(self):
+        return self._fm._predict_mean(self._features)
+
+    def marginal(self):
+        return self._fm._predict_marginal(self._features)
+
+    def joint(self):
+        return self._fm._predict_joint(self._features)
+
+
+class FitModel:
+    """FitModel<Model, Fit> (core/fit_model.hpp:18-114)."""
+
+    def __init__(self, model, fit):
+        self._model = model
+        self._fit = fit
+
+    def get_fit(self):
+        return self._fit
+
+    def get_model(self):
+        return self._model
+
+    def predict(self, features):
+        return Prediction(self, features)
+
+    def predict_with_measurement_noise(self, features):
+        """fit_model.hpp:54-62: wraps the test features in Measurement<>."""
+        return Prediction(self, features if isinstance(features, Measurement) else Measurement(features))
+
+    # --- _predict_impl (gp.hpp:305-366) ------------------------------------------
+    def _xs(self, features):
+        fs = self._model.covariance_function_.features(features)
+        return fs, fs.as_struct()
+
+    def _predict_mean(self, features):
+        m, ctx = self._model, self._model._ctx()
+        fs, s = self._xs(features)
+        mean = np.empty(fs.n)
+        ctx._check(ctx._lib.agp_predict_mean(ctx._h, ctx.kernel(m.covariance_function_), self._fit._h, C.byref(s),
+                                             _ptr(mean), capi.HOST), "agp_predict_mean")
+        return mean + m.mean_function_(fs.coords)  # mean_function_.add_to, gp.hpp:364
+
+    def _predict_marginal(self, features):
+        m, ctx = self._model, self._model._ctx()
+        fs, s = self._xs(features)
+        mean, var = np.empty(fs.n), np.empty(fs.n)
+        ctx._check(ctx._lib.agp_predict_marginal(ctx._h, ctx.kernel(m.covariance_function_), self._fit._h,
+                                                 C.byref(s), _ptr(mean), _ptr(var), capi.HOST),
+                   "agp_predict_marginal")
+        return MarginalDistribution(mean + m.mean_function_(fs.coords), var)
+
+    def _predict_joint(self, features):
+        m, ctx = self._model, self._model._ctx()
+        fs, s = self._xs(features)
+        mean, cov = np.empty(fs.n), np.empty((fs.n, fs.n), order="F")
+        ctx._check(ctx._lib.agp_predict_joint(ctx._h, ctx.kernel(m.covariance_function_), self._fit._h, C.byref(s),
+                                              _ptr(mean), _ptr(cov), capi.HOST), "agp_predict_joint")
+        return JointDistribution(mean + m.mean_function_(fs.coords), cov)
+
+
+class GaussianProcessRegression:
+    """GaussianProcessRegression<CovFunc, MeanFunc> (gp.hpp:487-505)."""
+
+    def __init__(self, covariance_function, mean_function=None, model_name="gaussian_process_regression",
+                 context=None):
+        if not isinstance(covariance_function, CovarianceFunction):
+            raise TypeError("covariance_function must be an albatross_amd CovarianceFunction")
+        self.covariance_function_ = covariance_function
+        self.mean_function_ = mean_function or ZeroMean()
+        self.model_name_ = model_name
+        self._context = context
+
+    def _ctx(self):
+        return self._context or default_context()
+
+    def get_name(self):
+        return self.model_name_
+
+    def get_covariance(self):
+        return self.covariance_function_
+
+    def get_mean(self):
+        return self.mean_function_
+
+    # ParameterHandlingMixin subset (gp.hpp:255-268)
+    def get_params(self):
+        out = dict(self.covariance_function_.get_params())
+        out.update(self.mean_function_.get_params())
+        return out
+
+    def set_param(self, name, value):
+        if name in self.covariance_function_.get_params():
+            self.covariance_function_.set_param(name, value)
+        elif name in self.mean_function_.get_params():
+            self.mean_function_.set_param(name, value)
+        else:
+            raise KeyError(name)
+
+    def set_param_values(self, values):
+        for k, v in values.items():
+            self.set_param(k, v)
+
+    set_params = set_param_values
+
+    def _targets(self, fs, targets):
+        y = np.ascontiguousarray(targets.mean - self.mean_function_(fs.coords), dtype=np.float64)  # remove_from
+        yv = None
+        if targets.covariance is not None:
+            yv = np.ascontiguousarray(targets.covariance, dtype=np.float64)
+            if yv.ndim != 1 or yv.shape[0] != y.shape[0]:
+                raise ValueError("target covariance must be the diagonal (one variance per target)")
+        if y.shape[0] != fs.n:
+            raise ValueError("features and targets differ in size")
+        return y, yv
+
+    def fit(self, dataset, targets=None):
+        """ModelBase::fit (core/model.hpp:137-152) -> _fit_impl (gp.hpp:281-294)."""
+        if targets is not None:
+            dataset = RegressionDataset(dataset, targets)
+        ctx = self._ctx()
+        fs = self.covariance_function_.features(_values_of(dataset.features))
+        y, yv = self._targets(fs, dataset.targets)
+        s = fs.as_struct()
+        h = C.c_void_p()
+        st = ctx._lib.agp_fit_create(ctx._h, ctx.kernel(self.covariance_function_), C.byref(s), _ptr(y), _ptr(yv),
+                                     C.byref(h), None, None)
+        if st != capi.AGP_OK:
+            pivot = ctx._lib.agp_fit_failed_pivot(h) if h else -1
+            if h:
+                ctx._lib.agp_fit_destroy(h)
+            ctx._check(st, f"agp_fit_create (pivot {pivot})")
+        return FitModel(self, GPFit(ctx, h, fs.n, dataset.features))
+
+    def log_likelihood(self, dataset):
+        """gp.hpp:442-451 (without priors: the parameter-prior subsystem is out of scope)."""
+        ctx = self._ctx()
+        fs = self.covariance_function_.features(_values_of(dataset.features))
+        y, yv = self._targets(fs, dataset.targets)
+        s = fs.as_struct()
+        out = C.c_double()
+        ctx._check(ctx._lib.agp_nll(ctx._h, ctx.kernel(self.covariance_function_), C.byref(s), _ptr(y), _ptr(yv),
+                                    C.byref(out)), "agp_nll")
+        return -out.value
+
+
+def gp_from_covariance(covariance_function, model_name="gaussian_process_regression", context=None):
+    """gp.hpp:507-521"""
+    return GaussianProcessRegression(covariance_function, None, model_name, context)
+
+
+def gp_from_covariance_and_mean(covariance_function, mean_function, model_name="gaussian_process_regression",
+                                context=None):
+    """gp.hpp:523-537"""
+    return GaussianProcessRegression(covariance_function, mean_function, model_name, context)

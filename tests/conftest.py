@@ -1,0 +1,39 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One agp_context on cuda:0 for the whole GPU session.  Fails loudly when
+    the HIP library is missing or no device is visible: there is no fallback."""
+    import albatross_amd as ab
+    c = ab.Context(0)
+    yield c
+    c.close()
+
+
+def synthetic_3d(n, seed):
+    """X ~ U[0,10]^3, y = sum_k sin x_k + 0.1 cos(10 x_0)."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0., 10., size=(n, 3))
+    y = np.sin(x).sum(axis=1) + 0.1 * np.cos(10. * x[:, 0])
+    return x, y

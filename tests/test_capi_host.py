@@ -1,0 +1,92 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports every symbol
+include/albatross_amd.h declares; the host mirror flattens covariance
+functions correctly.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import albatross_amd as ab
+from albatross_amd import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "albatross_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(agp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/albatross_amd.h but not exported"
+    assert sorted(n for n, _, _ in capi.EXPORTS) == names
+
+
+def test_status_strings_and_device_count_without_gpu():
+    lib = capi.load()
+    assert lib.agp_status_string(capi.AGP_OK) == b"ok"
+    assert b"positive definite" in lib.agp_status_string(capi.AGP_ERR_NOT_POSITIVE_DEFINITE)
+    assert lib.agp_device_count() >= 0
+
+
+def test_kernel_create_validates_programs():
+    lib = capi.load()
+    cov = ab.SquaredExponential(1., 1.) + ab.IndependentNoise(0.1)
+    nodes = cov.program_nodes()
+    arr = (capi.KernelNode * len(nodes))(*nodes)
+    h = C.c_void_p()
+    assert lib.agp_kernel_create(arr, len(nodes), C.byref(h)) == capi.AGP_OK
+    lib.agp_kernel_destroy(h)
+    # a SUM with one operand is malformed
+    bad = (capi.KernelNode * 2)(nodes[0], nodes[2])
+    assert lib.agp_kernel_create(bad, 2, C.byref(h)) == capi.AGP_ERR_INVALID_ARGUMENT
+    # two leaves and no operator leave two values on the stack
+    bad = (capi.KernelNode * 2)(nodes[0], nodes[1])
+    assert lib.agp_kernel_create(bad, 2, C.byref(h)) == capi.AGP_ERR_INVALID_ARGUMENT
+
+
+def test_postfix_program_of_composed_covariance():
+    cov = ab.ScalingTerm(type("F", (ab.ScalingFunction,), {"_call_impl": lambda self, c: np.ones(len(c))})()) \
+        * ab.Constant(5.) + ab.measurement_only(ab.IndependentNoise(1.75)) \
+        + ab.Exponential(1.1, 1., ab.AngularDistance()) * ab.SquaredExponential(5835., 13.9, ab.RadialDistance())
+    ops = [n.op for n in cov.program_nodes()]
+    assert ops == [capi.OP_SCALING, capi.OP_CONSTANT, capi.OP_PRODUCT, capi.OP_INDEPENDENT_NOISE,
+                   capi.OP_MEASUREMENT_ONLY, capi.OP_SUM, capi.OP_EXPONENTIAL, capi.OP_SQUARED_EXPONENTIAL,
+                   capi.OP_PRODUCT, capi.OP_SUM]
+    assert cov.get_name().startswith("(((F*constant)+measurement[independent_noise])+")
+
+
+def test_parameter_handling_mirrors_reference_names():
+    cov = ab.SquaredExponential(3.5, 5.7) + ab.measurement_only(ab.IndependentNoise(1.0))
+    assert cov.get_params() == {"squared_exponential_length_scale": 3.5, "sigma_squared_exponential": 5.7,
+                                "sigma_independent_noise": 1.0}
+    cov.set_param_values({"sigma_independent_noise": 0.25})
+    assert cov.get_params()["sigma_independent_noise"] == 0.25
+    assert cov.program_nodes()[1].params[0] == 0.25
+    with pytest.raises(KeyError):
+        cov.set_param("no_such_param", 1.)
+    with pytest.raises(TypeError):
+        ab.SquaredExponential(1., 1., ab.AngularDistance())  # static_assert radial.hpp:138-141
+
+
+def test_no_fallback_when_library_missing(monkeypatch, tmp_path):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "lib_path", lambda: str(tmp_path / "libalbatross_amd.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.load()
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, "albatross_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), f"{f} mentions the oracle"

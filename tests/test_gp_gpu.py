@@ -1,0 +1,172 @@
+"""GPU parity of the full path: gp.fit(dataset) / fit.predict(x) /
+model.log_likelihood(dataset) through the C-ABI vs the oracle (pivoted LDL^T,
+the reference's algorithm) and vs the golden fixtures.
+
+Stated fp64 tolerances: information / predictive mean /
+variance relative error <= 1e-8 (ill-conditioned toy case: its fixture's own
+1e-7), log-likelihood absolute error <= 1e-6 * N."""
+import numpy as np
+import pytest
+
+import albatross_amd as ab
+from conftest import golden, synthetic_3d
+from oracle import oracle_py as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+def simple_cov(c):
+    return ab.SquaredExponential(c["squared_exponential_length_scale"], c["sigma_squared_exponential"])
+
+
+def test_toy_linear_golden(ctx):
+    g = golden("toy_linear.json")
+    cov = simple_cov(g["cov"]) + ab.measurement_only(ab.IndependentNoise(g["cov"]["sigma_independent_noise"]))
+    model = ab.gp_from_covariance(cov, context=ctx)
+    ds = ab.RegressionDataset(np.array(g["x"]), np.array(g["y"]))
+    fm = model.fit(ds)
+    tol = g["tolerance_rel"]
+    assert rel(fm.get_fit().information, g["information"]) <= tol
+    assert abs(fm.get_fit().log_determinant - g["log_det"]) <= 1e-8 * abs(g["log_det"])
+    assert abs(-model.log_likelihood(ds) - g["nll"]) <= 1e-7 * abs(g["nll"])
+    for p in g["predictions"]:
+        pred = fm.predict(np.array(p["xs"]))
+        joint = pred.joint()
+        assert rel(joint.mean, p["mean"]) <= tol
+        assert np.abs(joint.covariance - np.array(p["cov"])).max() <= 1e-5
+        assert rel(pred.mean(), p["mean"]) <= tol
+        marg = pred.marginal()
+        assert np.abs(marg.covariance - np.diag(np.array(p["cov"]))).max() <= 1e-5
+    # expect_predict_variants_consistent (test_models.h:324-432): 1e-8 between variants
+    pred = fm.predict(np.array([0.1, 1.1, 2.2]))
+    assert np.abs(pred.mean() - pred.joint().mean).max() < 1e-8
+    assert np.abs(pred.marginal().covariance - np.diag(pred.joint().covariance)).max() < 1e-8 * 1e4
+
+
+def test_bench512_golden(ctx):
+    g = golden("bench512.json")
+    cov = simple_cov(g["cov"]) + ab.IndependentNoise(g["cov"]["sigma_independent_noise"])
+    model = ab.gp_from_covariance(cov, context=ctx)
+    ds = ab.RegressionDataset(np.array(g["x"]), np.array(g["y"]))
+    fm = model.fit(ds)
+    tol = 1e-8
+    assert rel(fm.get_fit().information, g["information"]) <= tol
+    assert abs(fm.get_fit().log_determinant - g["log_det"]) <= 1e-9 * abs(g["log_det"])
+    assert abs(-model.log_likelihood(ds) - g["nll"]) <= 1e-6 * 512
+    marg = fm.predict(np.array(g["xs"])).marginal()
+    assert np.abs(marg.mean - np.array(g["mean"])).max() <= tol
+    assert np.abs(marg.covariance - np.array(g["variance"])).max() <= tol
+
+
+CASES = [
+    ("matern52+noise 3-D", lambda: ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1), 3),
+    ("se+noise 3-D", lambda: ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1), 3),
+    ("exp*se + meas-noise 2-D", lambda: ab.Exponential(4.0, 1.3) * ab.SquaredExponential(6.0, 1.1)
+     + ab.measurement_only(ab.IndependentNoise(0.2)), 2),
+]
+
+
+@pytest.mark.parametrize("label,make,dim", CASES)
+@pytest.mark.parametrize("n,m", [(1, 3), (17, 5), (128, 64), (129, 65), (640, 200), (1500, 333)])
+def test_fit_predict_matches_oracle(ctx, label, make, dim, n, m):
+    rng = np.random.default_rng(n + 13 * m)
+    x = rng.uniform(0., 10., (n, dim))
+    y = np.sin(x).sum(axis=1) + 0.1 * np.cos(10. * x[:, 0])
+    yvar = rng.uniform(0.0, 0.05, n)
+    xs = rng.uniform(0., 10., (m, dim))
+    cov = make()
+    model = ab.gp_from_covariance(cov, context=ctx)
+    ds = ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar))
+    fm = model.fit(ds)
+    ofit = orc.OracleFit(cov, x, y, yvar)  # pivoted LDL^T, as the reference
+    assert rel(fm.get_fit().information, ofit.information) <= 1e-8
+    assert abs(fm.get_fit().log_determinant - ofit.log_determinant) <= 1e-6 * n
+    assert abs(-model.log_likelihood(ds) - orc.nll(cov, x, y, yvar)) <= 1e-6 * n
+    pred = fm.predict(xs)
+    om, ov = ofit.predict_marginal(xs)
+    marg = pred.marginal()
+    assert rel(marg.mean, om) <= 1e-8 and rel(pred.mean(), om) <= 1e-8
+    assert np.abs(marg.covariance - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-9
+    jm, jc = ofit.predict_joint(xs)
+    joint = pred.joint()
+    assert rel(joint.mean, jm) <= 1e-8
+    assert np.abs(joint.covariance - jc).max() <= 1e-8 * np.abs(jc).max() + 1e-9
+    assert np.array_equal(joint.covariance, joint.covariance.T)
+    # predict_with_measurement_noise wraps the test features (fit_model.hpp:54-62)
+    om2, ov2 = ofit.predict_marginal(xs, xs_meas=True)
+    marg2 = fm.predict_with_measurement_noise(xs).marginal()
+    assert np.abs(marg2.covariance - ov2).max() <= 1e-8 * np.abs(ov2).max() + 1e-9
+    # CovarianceRepresentation::solve
+    B = rng.standard_normal((n, 4))
+    assert rel(fm.get_fit().solve(B), ofit.solve(B)) <= 1e-8
+
+
+def test_mean_function_is_removed_and_added(ctx):
+    # tests/test_gp.cc:344-371,464-506
+    rng = np.random.default_rng(2)
+    x = np.linspace(0., 10., 60)
+    y = 3. * x + 1. + 0.01 * rng.standard_normal(60)
+    cov = ab.SquaredExponential(2., 1.) + ab.measurement_only(ab.IndependentNoise(0.1))
+    with_mean = ab.gp_from_covariance_and_mean(cov, ab.LinearMean(3., 1.), context=ctx).fit(ab.RegressionDataset(x, y))
+    without = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
+    far = np.array([-20., 40.])
+    assert np.abs(with_mean.predict(far).mean() - (3. * far + 1.)).max() < 1e-3
+    assert np.linalg.norm(with_mean.predict(far).mean() - without.predict(far).mean()) > 1.
+
+
+def test_not_positive_definite_and_nan_are_reported(ctx):
+    x = np.array([0., 0., 1.])  # duplicate point, no noise: singular Gram
+    model = ab.gp_from_covariance(ab.SquaredExponential(1., 1.), context=ctx)
+    with pytest.raises(ab.NotPositiveDefiniteError, match="pivot 1"):
+        model.fit(ab.RegressionDataset(x, np.zeros(3)))
+    with pytest.raises(ab.NanInputError):
+        model.fit(ab.RegressionDataset(np.array([0., np.nan, 2.]), np.zeros(3)))
+    with pytest.raises(ab.NanInputError):
+        model.log_likelihood(ab.RegressionDataset(np.array([0., np.nan, 2.]), np.zeros(3)))
+
+
+def test_config2_n4096_matern(ctx):
+    """BASELINE config 2: 3-D Matern-5/2 + noise, N = 4096, dense fit + predict.
+    Checked against the oracle's un-pivoted LL^T (the pivoted LDL^T takes
+    minutes at this size) plus residual properties."""
+    x, y = synthetic_3d(4096, 42)
+    xs, _ = synthetic_3d(512, 43)
+    cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+    model = ab.gp_from_covariance(cov, context=ctx)
+    fm = model.fit(ab.RegressionDataset(x, y))
+    ofit = orc.OracleFit(cov, x, y, threads=8, use_llt=True)
+    assert rel(fm.get_fit().information, ofit.information) <= 1e-8
+    assert abs(fm.get_fit().log_determinant - ofit.log_determinant) <= 1e-6 * 4096
+    om, ov = ofit.predict_marginal(xs)
+    marg = fm.predict(xs).marginal()
+    assert rel(marg.mean, om) <= 1e-8
+    assert np.abs(marg.covariance - ov).max() <= 1e-8
+
+
+def test_config3_n16384_properties(ctx):
+    """BASELINE config 3 (N = 16384, SE + noise) through size-independent
+    properties: K alpha = y residual, L L^T = K on sampled rows, solve round
+    trip, NLL consistent with the fit's log-det and information."""
+    n = 16384
+    x, y = synthetic_3d(n, 44)
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+    model = ab.gp_from_covariance(cov, context=ctx)
+    ds = ab.RegressionDataset(x, y)
+    fm = model.fit(ds)
+    alpha = fm.get_fit().information
+    K = ctx.gram(cov, ab.Measurement(x))
+    resid = np.abs(K @ alpha - y).max()
+    assert resid <= 1e-9 * (np.abs(K).sum(axis=1).max() * np.abs(alpha).max())
+    nll = -model.log_likelihood(ds)
+    expect = 0.5 * (fm.get_fit().log_determinant + y @ alpha + n * np.log(2 * np.pi))
+    assert abs(nll - expect) <= 1e-6 * n
+    rows = np.random.default_rng(1).choice(n, 64, replace=False)
+    L = fm.get_fit().factor()
+    assert np.abs(L[rows] @ L.T - K[rows]).max() <= 1e-11
+    B = np.random.default_rng(2).standard_normal((n, 2))
+    X = fm.get_fit().solve(B)
+    assert np.abs(K @ X - B).max() <= 1e-8 * np.abs(B).max() * 10

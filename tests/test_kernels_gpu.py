@@ -1,0 +1,114 @@
+"""GPU tests of the building blocks, through the debug entry points of the
+C-ABI library: MFMA lane map, the fp64 MFMA update kernel, the blocked LL^T."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from albatross_amd import _capi as capi
+from oracle import oracle_py as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+@pytest.fixture(scope="module")
+def dbg(ctx):
+    lib = capi.load()
+    lib.agp_debug_mfma_tile.restype = C.c_int
+    lib.agp_debug_mfma_tile.argtypes = [C.c_void_p] * 4
+    lib.agp_debug_gemm.restype = C.c_int
+    lib.agp_debug_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                   C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int]
+    lib.agp_debug_factor.restype = C.c_int
+    lib.agp_debug_factor.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                     C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    return lib
+
+
+def test_mfma_f64_lane_map(ctx, dbg):
+    """v_mfma_f64_16x16x4_f64 operand / result lane maps assumed in mfma_f64.h,
+    checked with exact integer data and an asymmetric B."""
+    rng = np.random.default_rng(0)
+    A = rng.integers(-8, 9, (16, 4)).astype(np.float64)
+    B = rng.integers(-8, 9, (4, 16)).astype(np.float64)
+    D = np.zeros((16, 16))
+    assert dbg.agp_debug_mfma_tile(ctx._h, _p(A), _p(B), _p(D)) == 0
+    assert np.array_equal(D, A @ B)
+
+
+def test_mfma_peak_is_sane(ctx):
+    tf = ctx.mfma_f64_peak(4000)
+    print(f"measured fp64 MFMA issue-loop rate: {tf:.1f} TFLOP/s")
+    assert 20. < tf < 400.
+
+
+@pytest.mark.parametrize("M,N,K,tri,akm,bkm", [
+    (128, 128, 16, 0, 0, 0), (256, 128, 128, 0, 0, 0), (384, 384, 512, 1, 0, 0),
+    (200, 130, 70, 0, 0, 0), (333, 333, 129, 1, 0, 0), (257, 100, 128, 0, 0, 1),
+    (140, 90, 50, 0, 1, 1), (300, 64, 128, 0, 1, 0), (130, 130, 1000, 1, 1, 1),
+])
+def test_gemm_nt_sub(ctx, dbg, M, N, K, tri, akm, bkm):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((N, K))
+    C0 = rng.standard_normal((M, N))
+    ldc = M + 3
+    Cd = np.zeros((ldc, N), order="F")
+    Cd[:M] = C0
+    Ah = np.asfortranarray(A.T if akm else A)   # kmajor: K x M column-major
+    Bh = np.asfortranarray(B.T if bkm else B)
+    st = dbg.agp_debug_gemm(ctx._h, _p(Cd), ldc, _p(Ah), Ah.shape[0], akm, _p(Bh), Bh.shape[0], bkm, M, N, K, tri)
+    assert st == 0
+    want = C0 - A @ B.T
+    got = Cd[:M]
+    scale = np.abs(A) @ np.abs(B.T) + np.abs(C0)
+    if tri:
+        # tiles strictly above the diagonal are skipped: compare the lower triangle only
+        mask = np.tril(np.ones((M, N), dtype=bool))
+        err = (np.abs(got - want) / scale)[mask].max()
+    else:
+        err = (np.abs(got - want) / scale).max()
+    assert err < 8 * np.finfo(float).eps * np.sqrt(K)
+    assert np.array_equal(Cd[M:], np.zeros((ldc - M, N)))  # padding rows untouched
+
+
+@pytest.mark.parametrize("n", [16, 100, 128, 129, 300, 512, 640, 1000, 1537])
+def test_factor_matches_oracle_llt(ctx, dbg, n):
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n + 5))
+    A = G @ G.T / n + np.eye(n)
+    y = rng.standard_normal(n)
+    lda = n + (n % 2) + 2
+    Ad = np.full((lda, n), np.nan, order="F")
+    Ad[:n] = np.tril(A) + np.triu(np.full((n, n), 7.5), 1)  # upper triangle must be ignored
+    yd = y.copy()
+    logdet = C.c_double()
+    bad = C.c_int64()
+    assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, lda, _p(yd), C.byref(logdet), C.byref(bad)) == 0
+    assert bad.value == -1
+    L = np.tril(Ad[:n])
+    Lo, info = orc.llt(A)
+    assert info == 0
+    Lo = np.tril(Lo)
+    assert np.abs(L - Lo).max() <= 1e-12 * np.abs(Lo).max()
+    assert np.abs(L @ L.T - A).max() <= 1e-13 * np.abs(A).max() * n
+    z = np.linalg.solve(Lo, y)
+    assert np.abs(yd - z).max() <= 1e-11 * np.abs(z).max()
+    assert abs(logdet.value - orc.llt_logdet(Lo)) <= 1e-11 * max(1., abs(orc.llt_logdet(Lo)))
+
+
+def test_factor_reports_first_bad_pivot(ctx, dbg):
+    n = 300
+    rng = np.random.default_rng(3)
+    G = rng.standard_normal((n, n))
+    A = G @ G.T / n + np.eye(n)
+    A[200, 200] = -1.0  # leading 200x200 block stays PD; pivot 200 goes non-positive
+    Ad = np.asfortranarray(A.copy())
+    bad = C.c_int64()
+    logdet = C.c_double()
+    assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, None, C.byref(logdet), C.byref(bad)) == 0
+    assert bad.value == 200

@@ -1,0 +1,174 @@
+"""CPU tests (-m "not gpu"): pin the oracle against the reference's own golden
+vectors (tests/golden/*.json, sources cited there) and check its internal
+consistency.  The oracle is the checker of the GPU parity tests."""
+import numpy as np
+import pytest
+
+import albatross_amd as ab
+from conftest import golden
+from oracle import oracle_py as orc
+
+
+@pytest.mark.parametrize("name,cls", [("matern52.json", ab.Matern52), ("matern32.json", ab.Matern32)])
+def test_matern_gpytorch_oracle(name, cls):
+    g = golden(name)  # tests/test_radial.cc:212-353,355-489, tolerance 1e-15
+    K = orc.gram(cls(g["length_scale"], g["sigma"]), np.array(g["x"]))
+    assert np.abs(K - np.array(g["K"])).max() < g["tolerance_abs"]
+
+
+def test_mvn_negative_log_likelihood():
+    g = golden("mvn_nll.json")  # tests/test_evaluate.cc:20-44
+    nll = orc.nll_dense(np.array(g["x"]), np.array(g["cov"]))
+    assert abs(nll - g["nll"]) < g["tolerance_build"]
+
+
+@pytest.mark.parametrize("cls", [ab.Exponential, ab.SquaredExponential, ab.Matern32, ab.Matern52])
+def test_radial_edge_cases(cls):
+    g = golden("radial_edges.json")  # tests/test_radial.cc:52-66
+    cov = cls(g["length_scale"], g["sigma"])
+    s2 = g["sigma"] ** 2
+    assert orc.eval_pair(cov, [np.pi], 0, [np.pi], 0) == s2
+    assert abs(orc.eval_pair(cov, [np.pi], 0, [np.pi + 1e-16], 0) - s2) < 1e-8
+    assert orc.eval_pair(cov, [0.], 0, [1e32], 0) == 0.
+
+
+def test_distance_metrics():
+    g = golden("distances.json")  # tests/test_distance_metrics.cc:20-75 (EXPECT_DOUBLE_EQ)
+    for key, metric in (("euclidean", ab.EuclideanDistance), ("radial", ab.RadialDistance),
+                        ("angular", ab.AngularDistance)):
+        # Exponential(l=1, sigma=1) = exp(-d): recover d = -log k
+        cov = ab.Exponential(1., 1., metric())
+        for x, y, d in g[key]:
+            k = orc.eval_pair(cov, np.array([x], dtype=float), 0, np.array([y], dtype=float), 0)
+            assert abs(-np.log(k) - d) <= 4 * np.finfo(float).eps * max(1., d)
+
+
+def test_measurement_noise_algebra():
+    # tests/test_covariance_functions.cc:33-93
+    radial = ab.SquaredExponential()
+    noise = ab.IndependentNoise()
+    meas_noise = ab.measurement_only(noise)
+    total = radial + meas_noise
+    prod = meas_noise * radial
+    prod_of_sum = noise * total
+    x = np.array([0., 1., 2.])
+
+    def call(cov, a_meas, b_meas, i=0, j=0):
+        return orc.eval_pair(cov, x, i, x, j, a_meas, b_meas)
+
+    assert call(meas_noise, False, False) == 0.
+    assert call(meas_noise, False, True) == 0.
+    assert call(meas_noise, True, False) == 0.
+    assert call(meas_noise, True, True) > 0.
+    assert call(radial, False, False) > 0.
+    for am, bm in ((True, True), (True, False), (False, True)):
+        assert call(radial, am, bm) == call(radial, False, False)
+    assert call(total, True, True) > call(total, False, False) > 0.
+    for am, bm in ((True, True), (True, False), (False, True)):
+        assert call(total, am, bm) == call(radial, am, bm) + call(meas_noise, am, bm)
+    assert call(prod, False, False) == 0.
+    assert call(prod, True, True) == call(radial, True, True) * call(meas_noise, True, True) > 0.
+    assert call(prod, True, False) == 0. and call(prod, False, True) == 0.
+    assert call(prod_of_sum, False, False) == call(noise, False, False) * call(total, False, False) > 0.
+    assert call(prod_of_sum, True, True) == call(noise, True, True) * call(total, True, True)
+    assert call(prod_of_sum, True, False) == call(prod_of_sum, False, False)
+    assert call(prod_of_sum, False, True) == call(prod_of_sum, True, False)
+
+
+def test_product_short_circuit():
+    # covariance_function.hpp:362-366: rhs is skipped when lhs == 0, so 0 * inf stays 0
+    x = np.array([0., 1.])
+    huge = ab.Constant(1e200) * ab.Constant(1e200)  # overflows to inf
+    cov = ab.IndependentNoise(1.) * huge
+    assert orc.eval_pair(cov, x, 0, x, 1) == 0.
+    assert np.isinf(orc.eval_pair(cov, x, 0, x, 0))
+
+
+def test_toy_linear_gp():
+    g = golden("toy_linear.json")
+    c = g["cov"]
+    cov = ab.SquaredExponential(c["squared_exponential_length_scale"], c["sigma_squared_exponential"]) \
+        + ab.measurement_only(ab.IndependentNoise(c["sigma_independent_noise"]))
+    x, y = np.array(g["x"]), np.array(g["y"])
+    K = orc.gram(cov, x, x_meas=True)
+    assert np.abs(K - np.array(g["K_train"])).max() <= 1e-12 * np.abs(K).max()
+    tol = g["tolerance_rel"]
+    for use_llt in (False, True):
+        fit = orc.OracleFit(cov, x, y, use_llt=use_llt)
+        info = np.array(g["information"])
+        assert np.abs(fit.information - info).max() <= tol * np.abs(info).max()
+        assert abs(fit.log_determinant - g["log_det"]) <= 1e-8 * abs(g["log_det"])
+        for p in g["predictions"]:
+            mean, covm = fit.predict_joint(np.array(p["xs"]))
+            assert np.abs(mean - np.array(p["mean"])).max() <= tol * np.abs(np.array(p["mean"])).max()
+            assert np.abs(covm - np.array(p["cov"])).max() <= 1e-5  # kappa ~ 1e8 on sigma^2 = 1e4
+            m2, var = fit.predict_marginal(np.array(p["xs"]))
+            assert np.allclose(m2, mean, rtol=0, atol=1e-9 * np.abs(mean).max())
+            assert np.abs(var - np.diag(covm)).max() <= 1e-8 * 1e4
+    assert abs(orc.nll(cov, x, y) - g["nll"]) <= 1e-7 * abs(g["nll"])
+
+
+def test_bench512_gp():
+    g = golden("bench512.json")
+    c = g["cov"]
+    cov = ab.SquaredExponential(c["squared_exponential_length_scale"], c["sigma_squared_exponential"]) \
+        + ab.IndependentNoise(c["sigma_independent_noise"])
+    x, y, xs = np.array(g["x"]), np.array(g["y"]), np.array(g["xs"])
+    tol = g["tolerance_rel"]
+    for use_llt in (False, True):
+        fit = orc.OracleFit(cov, x, y, use_llt=use_llt)
+        info = np.array(g["information"])
+        assert np.abs(fit.information - info).max() <= tol * np.abs(info).max()
+        assert abs(fit.log_determinant - g["log_det"]) <= tol * abs(g["log_det"])
+        mean, var = fit.predict_marginal(xs)
+        assert np.abs(mean - np.array(g["mean"])).max() <= tol
+        assert np.abs(var - np.array(g["variance"])).max() <= tol
+    assert abs(orc.nll(cov, x, y) - g["nll"]) <= tol * abs(g["nll"])
+
+
+def test_serial_equals_pooled_gram():
+    # tests/test_callers.cc:225-266: bitwise equality for pool sizes 1..32
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0., 10., (600, 3))
+    cov = ab.Matern52(2., 1.) + ab.IndependentNoise(0.1)
+    serial = orc.gram(cov, x)
+    cross = orc.gram(cov, x, x[:77])
+    for threads in (2, 3, 8, 32):
+        assert np.array_equal(serial, orc.gram(cov, x, threads=threads))
+        assert np.array_equal(cross, orc.gram(cov, x, x[:77], threads=threads))
+
+
+def test_ldlt_matches_llt_and_numpy():
+    # tests/test_serializable_ldlt.cc:34-85 property checks, restated
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 17, 130):
+        A = rng.standard_normal((n, n))
+        A = A @ A.T + n * np.eye(n)
+        B = rng.standard_normal((n, 3))
+        packed, tr, ok = orc.ldlt(A)
+        assert ok
+        X = orc.ldlt_solve(packed, tr, B)
+        assert np.abs(A @ X - B).max() < 1e-10
+        L, info = orc.llt(A)
+        assert info == 0
+        assert np.abs(orc.llt_solve(L, B) - X).max() < 1e-11
+        sign, logdet = np.linalg.slogdet(A)
+        assert abs(orc.ldlt_logdet(packed) - logdet) < 1e-8 and abs(orc.llt_logdet(L) - logdet) < 1e-8
+
+
+def test_ldlt_pivoting_handles_semidefinite():
+    # the reference's pivoted LDLT tolerates rank deficiency (tests/test_gp.cc:20-33)
+    v = np.array([[1.], [2.], [3.]])
+    A = v @ v.T
+    packed, tr, ok = orc.ldlt(A)
+    x = orc.ldlt_solve(packed, tr, A @ np.array([1., 1., 1.]))
+    assert np.all(np.isfinite(x))
+    L, info = orc.llt(A)
+    assert info != 0  # un-pivoted LL^T reports the failed pivot instead
+
+
+def test_oracle_nan_input_is_reported():
+    cov = ab.SquaredExponential(1., 1.)
+    x = np.array([0., np.nan, 2.])
+    with pytest.raises(FloatingPointError):
+        orc.OracleFit(cov, x, np.zeros(3))
