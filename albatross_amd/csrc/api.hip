@@ -426,6 +426,7 @@ void agp_fit_destroy(agp_fit *fit) {
   (void)hipSetDevice(fit->device);
   if (fit->A) (void)hipFree(fit->A);
   if (fit->invd) (void)hipFree(fit->invd);
+  if (fit->winv) (void)hipFree(fit->winv);
   if (fit->alpha) (void)hipFree(fit->alpha);
   if (fit->z) (void)hipFree(fit->z);
   fit->train.release();
@@ -468,6 +469,7 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   fit->train.v.meas = 0;
   FIT_CHECK(hipMalloc(&fit->A, sizeof(double) * (size_t)fit->lda * (size_t)n));
   FIT_CHECK(hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * NMB * MB * MB));
+  FIT_CHECK(hipMalloc(&fit->winv, sizeof(double) * (size_t)nblk * NB * NB));
   FIT_CHECK(hipMalloc(&fit->alpha, sizeof(double) * (size_t)n));
   FIT_CHECK(hipMalloc(&fit->z, sizeof(double) * (size_t)n));
   const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
@@ -477,16 +479,6 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
     FIT_CHECK(hipMemcpyAsync(yvar_d, y_var, sizeof(double) * (size_t)n, kind, s));
   }
   if (x->location == AGP_HOST) FIT_CHECK(hipStreamSynchronize(s));
-  {
-    const size_t need = sizeof(double) * (size_t)((n + 255) / 256 + 1) * NB;
-    if (ctx->partial_bytes < need) {
-      if (ctx->partial_ws) FIT_CHECK(hipFree(ctx->partial_ws));
-      ctx->partial_ws = nullptr;
-      FIT_CHECK(hipMalloc(&ctx->partial_ws, need));
-      ctx->partial_bytes = need;
-    }
-  }
-
   FeatView xm = fit->train.v;
   xm.meas = 1;  // as_measurements(features), gp.hpp:288
   st = build_and_factor(ctx, dprog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d);
@@ -503,7 +495,8 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   // information = L^-T (L^-1 y)
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[3], s));
   FIT_CHECK(hipMemcpyAsync(fit->alpha, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-  backward_solve_vec(s, fit->A, n, fit->lda, fit->invd, fit->alpha, ctx->partial_ws);
+  invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);
+  backward_solve_vec(s, fit->A, n, fit->lda, fit->winv, fit->alpha);
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[4], s));
   if (information) FIT_CHECK(hipMemcpyAsync(information, fit->alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   FIT_CHECK(hipStreamSynchronize(s));

@@ -77,7 +77,6 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
         const double s = sqrt(piv);
         const double inv = 1. / s;
         dinv[c] = inv;
-        logsum += log(s);
         a[c] = (ln == c) ? s : a[c] * inv;
 #pragma unroll
         for (int j = c + 1; j < MB; ++j) {
@@ -163,8 +162,16 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
     if (r < nbk && c < nbk && r >= c) p.A[(p.k0 + c) * p.lda + p.k0 + r] = S[c * PLD + r];
   }
   if (p.y && tid < nbk) p.y[tid] = ys[tid];
+  // sum log L_ii of this block (log_determinant, serializable_ldlt.hpp:128-135):
+  // 128 logs in parallel, fixed-order reduction
+  logsum = (tid < nbk) ? log(S[tid * PLD + tid]) : 0.;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) logsum += __shfl_down(logsum, off, 64);
+  __syncthreads();
+  if (lane == 0) ys[wave] = logsum;
+  __syncthreads();
   if (tid == 0) {
-    p.scalars[0] += logsum;
+    p.scalars[0] += (ys[0] + ys[1]) + (ys[2] + ys[3]);
     if (bad_pivot && p.flags[1] == 0) p.flags[1] = (int)(p.k0 + bad_pivot);
   }
 }
@@ -191,6 +198,9 @@ struct TrsmArgs {
   long long ncols;  // number of n (panel rows / V columns)
   const double *z;  // z_b (nbk) or nullptr          (FUSE_Y only)
   double *yrest;    // y entries matching n = 0..ncols (FUSE_Y only)
+  // batched launches (blockIdx.y = diagonal block index): element strides
+  long long batch_L, batch_invd, batch_Y;
+  long long n_total;  // matrix size, to derive nbk per batch entry (0: use nbk)
 };
 
 template <bool TRANS, bool FUSE_Y>
@@ -199,8 +209,19 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
   double *zs = F + NFRAG_TILES * 4 * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 15, lg = lane >> 4;
+  if (blockIdx.y > 0 || p.n_total > 0) {
+    const long long b = blockIdx.y;
+    p.L += b * p.batch_L;
+    p.invd += b * p.batch_invd;
+    p.Y += b * p.batch_Y;
+    if (p.n_total > 0) {
+      const long long left = p.n_total - b * NB;
+      p.nbk = (int)(left < NB ? left : NB);
+    }
+  }
 
   // ---- stage the fragment image of L11 ----
+#pragma unroll 4
   for (int e = tid; e < NFRAG_TILES * 4 * 64; e += 256) {
     const int l = e & 63, s = (e >> 6) & 3, t = e >> 8;
     int jb = 0;
@@ -230,15 +251,18 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
   double *base = p.Y + (n0 + ln) * p.stride_n;
 
   v4d Y[NMB];
+  // all 8 input tiles are requested up front: one HBM round trip, not eight
+#pragma unroll
+  for (int jb = 0; jb < NMB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = jb * MB + lg + 4 * r;
+      Y[jb][r] = (nok && m < p.nbk) ? base[m * p.stride_m] : 0.;
+    }
   if (!TRANS) {
 #pragma unroll
     for (int jb = 0; jb < NMB; ++jb) {
-      v4d acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = jb * MB + lg + 4 * r;
-        acc[r] = (nok && m < p.nbk) ? base[m * p.stride_m] : 0.;
-      }
+      v4d acc = Y[jb];
 #pragma unroll
       for (int ib = 0; ib < jb; ++ib) {
         const double *f = F + (jb * (jb + 1) / 2 + ib) * 256 + lane;
@@ -259,12 +283,7 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
   } else {
 #pragma unroll
     for (int jb = NMB - 1; jb >= 0; --jb) {
-      v4d acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = jb * MB + lg + 4 * r;
-        acc[r] = (nok && m < p.nbk) ? base[m * p.stride_m] : 0.;
-      }
+      v4d acc = Y[jb];
 #pragma unroll
       for (int ib = NMB - 1; ib > jb; --ib) {
         // image tile index of the stored pair (row block ib, col block jb)
@@ -347,6 +366,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
       t.ncols = below;
       t.z = y ? y + k : nullptr;
       t.yrest = y ? y + k + nbk : nullptr;
+      t.batch_L = t.batch_invd = t.batch_Y = 0; t.n_total = 0;
       const unsigned grid = (unsigned)((below + 63) / 64);
       if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
       else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
@@ -381,6 +401,7 @@ void forward_solve_mat(hipStream_t s, const double *A, long long n, long long ld
       t.stride_m = 1; t.stride_n = ldb;
       t.ncols = m;
       t.z = nullptr; t.yrest = nullptr;
+      t.batch_L = t.batch_invd = t.batch_Y = 0; t.n_total = 0;
       hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, t);
       const long long rows = kend - (k + nbk);
       if (rows > 0)  // B[k+nbk : kend] -= L[k+nbk : kend, k : k+nbk] B[k : k+nbk]
@@ -408,6 +429,7 @@ void backward_solve_mat(hipStream_t s, const double *A, long long n, long long l
     t.stride_m = 1; t.stride_n = ldb;
     t.ncols = m;
     t.z = nullptr; t.yrest = nullptr;
+    t.batch_L = t.batch_invd = t.batch_Y = 0; t.n_total = 0;
     hipLaunchKernelGGL((trsm_micro_kernel<true, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, t);
     if (k > 0)  // B[0 : k] -= L[k : k+nbk, 0 : k]^T B[k : k+nbk]
       launch_gemm_nt_sub(s, B, ldb, A + k, lda, true, B + k, ldb, true, k, m, nbk, false);
@@ -416,93 +438,110 @@ void backward_solve_mat(hipStream_t s, const double *A, long long n, long long l
 
 // ---------------------------------------------------------------------------
 // one right-hand side: x = L^-T z  (second half of K^-1 y, gp.hpp:68)
+//
+// Right-looking over NB blocks from the bottom.  The diagonal blocks are
+// inverted beforehand by ONE batched launch (all blocks in parallel, off the
+// serial chain), so a step is two short kernels:
+//   x_b = inv(L_bb)^T z_b                      (128 x 128 mat-vec, one workgroup)
+//   z[0:k] -= L[k:k+nb, 0:k]^T x_b             (one wave per 8 columns, coalesced
+//                                               1-KiB column segments)
+// Bandwidth: L is read exactly once (8 N^2 / 2 bytes).
 // ---------------------------------------------------------------------------
-constexpr int BV_ROWS = 256;  // rows per partial-sum workgroup
-
-// partial[chunk][c] = sum_{rows of chunk} L[row][k0 + c] x[row]
-__global__ __launch_bounds__(256) void gemvt_partial_kernel(const double *__restrict__ A, long long lda,
-                                                            long long k0, int nbk, long long row_begin,
-                                                            long long n, const double *__restrict__ x,
-                                                            double *__restrict__ partial) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long r0 = row_begin + (long long)blockIdx.x * BV_ROWS;
-  double xv[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const long long r = r0 + lane + 64 * q;
-    xv[q] = r < n ? x[r] : 0.;
-  }
-  for (int c = wave; c < nbk; c += 4) {
-    const double *col = A + (k0 + c) * lda;
-    double acc = 0.;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const long long r = r0 + lane + 64 * q;
-      if (r < n) acc += col[r] * xv[q];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) partial[(long long)blockIdx.x * NB + c] = acc;
-  }
+__global__ __launch_bounds__(256) void set_identity_blocks_kernel(double *W, long long count) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const int within = (int)(i & (NB * NB - 1));
+  W[i] = ((within >> 7) == (within & (NB - 1))) ? 1. : 0.;
 }
 
-// x_b = L_bb^-T (z_b - sum_chunks partial)
-__global__ __launch_bounds__(128) void diag_back_kernel(const double *__restrict__ A, long long lda,
-                                                        long long k0, int nbk, const double *__restrict__ invd,
-                                                        const double *__restrict__ partial, int nchunks,
-                                                        double *__restrict__ z) {
-  __shared__ double S[NB * (NB + 1)];
-  __shared__ double t[NB];
-  __shared__ double xs[MB];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < NB * NB; idx += 128) {
-    const int c = idx >> 7, r = idx & (NB - 1);
-    S[c * (NB + 1) + r] = (r < nbk && c < nbk && r >= c) ? A[(k0 + c) * lda + k0 + r] : 0.;
-  }
-  {
-    double v = tid < nbk ? z[k0 + tid] : 0.;
-    for (int ch = 0; ch < nchunks; ++ch) v -= (tid < nbk) ? partial[(long long)ch * NB + tid] : 0.;
-    t[tid] = v;
+// Winv[b] = inv(L_bb), column-major NB x NB (lower), for every diagonal block.
+void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                        double *Winv) {
+  const long long nblk = (n + NB - 1) / NB;
+  const long long count = nblk * NB * NB;
+  hipLaunchKernelGGL(set_identity_blocks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, Winv, count);
+  TrsmArgs t;
+  t.L = A; t.ldl = lda; t.invd = invd; t.nbk = NB;
+  t.Y = Winv; t.stride_m = 1; t.stride_n = NB; t.ncols = NB;
+  t.z = nullptr; t.yrest = nullptr;
+  t.batch_L = NB * (lda + 1); t.batch_invd = NMB * MB * MB; t.batch_Y = NB * NB; t.n_total = n;
+  hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
+}
+
+// x_b = Winv_b^T z_b ; one wave per column, columns strided over 4 waves
+__global__ __launch_bounds__(256) void diag_back_kernel(const double *__restrict__ Winv, int nbk,
+                                                        double *__restrict__ zb) {
+  __shared__ double out[NB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double2 zv = (2 * lane + 1 < nbk) ? *reinterpret_cast<const double2 *>(zb + 2 * lane)
+                                          : make_double2(2 * lane < nbk ? zb[2 * lane] : 0., 0.);
+  for (int c0 = wave * 32; c0 < wave * 32 + 32; c0 += 8) {
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double2 w = *reinterpret_cast<const double2 *>(Winv + (c0 + q) * NB + 2 * lane);
+      acc[q] = w.x * zv.x + w.y * zv.y;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
+      if (lane == 0) out[c0 + q] = acc[q];
+    }
   }
   __syncthreads();
-  for (int jb = NMB - 1; jb >= 0; --jb) {
-    const int o = jb * MB;
-    if (tid < MB) {
-      // x = W^T t_jb : x[c] = sum_r W[r][c] t[r], W column-major
-      const double *W = invd + jb * MB * MB;
-      double v = 0.;
-#pragma unroll
-      for (int r = 0; r < MB; ++r) v += W[tid * MB + r] * t[o + r];
-      xs[tid] = (o + tid < nbk) ? v : 0.;
-    }
-    __syncthreads();
-    if (tid < o) {
-      double v = t[tid];
-#pragma unroll
-      for (int r = 0; r < MB; ++r) v -= S[tid * (NB + 1) + o + r] * xs[r];
-      t[tid] = v;
-    } else if (tid < o + MB) {
-      t[tid] = xs[tid - o];
-    }
-    __syncthreads();
-  }
-  if (tid < nbk) z[k0 + tid] = t[tid];
+  if (threadIdx.x < nbk) zb[threadIdx.x] = out[threadIdx.x];
 }
 
-void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
-                        double *z, double *partial_ws) {
-  // partial_ws: ceil(n / BV_ROWS) * NB doubles
+// z[c] -= sum_r L[k0 + r][c] x[r]  for c < k0 ; r < nbk.   8 columns per wave.
+__global__ __launch_bounds__(256) void back_update_kernel(const double *__restrict__ A, long long lda,
+                                                          long long k0, int nbk, const double *__restrict__ x,
+                                                          double *__restrict__ z) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long c0 = ((long long)blockIdx.x * 4 + wave) * 8;
+  if (c0 >= k0) return;
+  const int r = 2 * lane;
+  const double x0 = r < nbk ? x[r] : 0., x1 = r + 1 < nbk ? x[r + 1] : 0.;
+  const bool vec = ((lda & 1) == 0) && ((k0 & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  double acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const long long c = c0 + q;
+    double a0 = 0., a1 = 0.;
+    if (c < k0) {
+      const double *p = A + c * lda + k0 + r;
+      if (vec && r + 1 < nbk) {
+        const double2 v = *reinterpret_cast<const double2 *>(p);
+        a0 = v.x; a1 = v.y;
+      } else {
+        a0 = r < nbk ? p[0] : 0.;
+        a1 = r + 1 < nbk ? p[1] : 0.;
+      }
+    }
+    acc[q] = a0 * x0 + a1 * x1;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (c0 + q < k0) z[c0 + q] -= acc[q];
+  }
+}
+
+void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Winv,
+                        double *z) {
   const long long nblk = (n + NB - 1) / NB;
   for (long long b = nblk - 1; b >= 0; --b) {
     const long long k = b * NB;
     const int nbk = (int)((n - k < NB) ? n - k : NB);
-    const long long below = n - (k + nbk);
-    const int nchunks = (int)((below + BV_ROWS - 1) / BV_ROWS);
-    if (nchunks > 0)
-      hipLaunchKernelGGL(gemvt_partial_kernel, dim3(nchunks), dim3(256), 0, s, A, lda, k, nbk, k + nbk, n, z,
-                         partial_ws);
-    hipLaunchKernelGGL(diag_back_kernel, dim3(1), dim3(128), 0, s, A, lda, k, nbk,
-                       invd + b * (long long)(NMB * MB * MB), partial_ws, nchunks, z);
+    hipLaunchKernelGGL(diag_back_kernel, dim3(1), dim3(256), 0, s, Winv + b * (long long)(NB * NB), nbk, z + k);
+    if (k > 0)
+      hipLaunchKernelGGL(back_update_kernel, dim3((unsigned)((k + 31) / 32)), dim3(256), 0, s, A, lda, k, nbk,
+                         z + k, z);
   }
 }
 

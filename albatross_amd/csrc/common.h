@@ -68,6 +68,7 @@ struct agp_fit {
   int64_t lda = 0;
   double *A = nullptr;      // n x n lower factor, column-major, ld = lda
   double *invd = nullptr;   // (n/MB) inverted 16x16 diagonal micro blocks
+  double *winv = nullptr;   // (n/NB) inverted NB x NB diagonal blocks
   double *alpha = nullptr;  // information vector K^-1 y
   double *z = nullptr;      // L^-1 y
   agp::DeviceFeatures train;
@@ -110,9 +111,12 @@ struct FactorTimers {
 void factor_lower(agp_context *ctx, double *A, long long n, long long lda, double *invd, double *y,
                   FactorTimers *timers);
 
+// Winv[b] = inv(L_bb) for every NB x NB diagonal block (batched, one launch)
+void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                        double *Winv);
 // x = L^-T z (one right-hand side), z overwritten.
-void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
-                        double *z, double *partial_ws);
+void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Winv,
+                        double *z);
 // B (n x m, ldb) <- L^-1 B
 void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                        double *B, long long m, long long ldb);
