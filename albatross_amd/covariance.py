@@ -157,6 +157,8 @@ class CovarianceFunction:
             return FeatureSet(x.coords, None if x.scales is None else list(x.scales.T), x.eq_id, is_measurement)
         _, scalers = self.program()
         coords = np.asarray(x, dtype=np.float64)
+        if coords.ndim == 1:
+            coords = coords.reshape(-1, 1)  # scaling functions always see n x dim
         cols = [np.asarray(s(coords), dtype=np.float64).reshape(-1) for s in scalers]
         return FeatureSet(coords, cols, None, is_measurement)
 

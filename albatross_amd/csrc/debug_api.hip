@@ -1,6 +1,7 @@
 // debug_api.hip — kernel-level entry points used only by tests/ to check the
 // building blocks (MFMA lane map, update kernel, factorisation) in isolation.
 // Not part of include/albatross_amd.h.
+#include <algorithm>
 #include "common.h"
 #include "mfma_f64.h"
 
@@ -12,6 +13,64 @@ __global__ void mfma_tile_kernel(const double *A, const double *B, double *D) {
   v4d acc = v4zero();
   acc = mfma16(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], acc);
   for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+// cycles (s_memtime) and 100 MHz ticks (s_memrealtime) around a loop of
+// `iters` x NACC independent v_mfma_f64_16x16x4_f64 per wave
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_clock_kernel(unsigned long long *out, int iters, double a0, double b0) {
+  v4d acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = v4zero();
+  const double a = a0 * (1.0 + (threadIdx.x % 7) * 0.125), b = b0 * (1.0 - (threadIdx.x % 5) * 0.0625);
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = mfma16(a, b, acc[i]);
+  }
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][3];
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
+  if (s == 1.2345e300) out[0] = 0;
+}
+
+// NM MFMA + NV independent v_fma_f64 per loop iteration, per wave
+template <int NM, int NV>
+__global__ __launch_bounds__(256) void mix_clock_kernel(unsigned long long *out, int iters, double a0, double b0) {
+  v4d acc[NM > 0 ? NM : 1];
+  double v[NV > 0 ? NV : 1];
+#pragma unroll
+  for (int i = 0; i < (NM > 0 ? NM : 1); ++i) acc[i] = v4zero();
+#pragma unroll
+  for (int i = 0; i < (NV > 0 ? NV : 1); ++i) v[i] = 0.001 * (i + 1) + threadIdx.x * 1e-6;
+  const double a = a0 * (1.0 + (threadIdx.x % 7) * 0.125), b = b0 * (1.0 - (threadIdx.x % 5) * 0.0625);
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NM; ++i) acc[i] = mfma16(a, b, acc[i]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = __builtin_fma(v[i], 0.999999, b);
+  }
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < (NM > 0 ? NM : 1); ++i) s += acc[i][0] + acc[i][3];
+#pragma unroll
+  for (int i = 0; i < (NV > 0 ? NV : 1); ++i) s += v[i];
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
+  if (s == 1.2345e300) out[0] = 0;
 }
 
 }  // namespace agp
@@ -31,6 +90,93 @@ int agp_debug_mfma_tile(agp_context *ctx, const double *A, const double *B, doub
   AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   AGP_HIP_CHECK(ctx, hipMemcpy(D, d + 128, sizeof(double) * 256, hipMemcpyDeviceToHost));
   AGP_HIP_CHECK(ctx, hipFree(d));
+  return AGP_OK;
+}
+
+// out[0] = median cycles per MFMA per wave, out[1] = effective clock (GHz),
+// out[2] = chip TFLOP/s.  waves_per_simd in {1, 2}; nacc in {1, 4, 8}.
+int agp_debug_mfma_clock(agp_context *ctx, int blocks, int waves_per_simd, int nacc, int iters, double a0,
+                         double b0, double *out) {
+  if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int nblk = blocks * waves_per_simd;
+  unsigned long long *d = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&d, sizeof(unsigned long long) * 2 * nblk));
+  hipEvent_t e0, e1;
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    AGP_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+    if (nacc == 1) hipLaunchKernelGGL(mfma_clock_kernel<1>, dim3(nblk), dim3(256), 0, ctx->stream, d, iters, a0, b0);
+    else if (nacc == 4) hipLaunchKernelGGL(mfma_clock_kernel<4>, dim3(nblk), dim3(256), 0, ctx->stream, d, iters, a0, b0);
+    else hipLaunchKernelGGL(mfma_clock_kernel<8>, dim3(nblk), dim3(256), 0, ctx->stream, d, iters, a0, b0);
+    AGP_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+    AGP_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  }
+  float ms = 0.f;
+  AGP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h(2 * nblk);
+  AGP_HIP_CHECK(ctx, hipMemcpy(h.data(), d, sizeof(unsigned long long) * 2 * nblk, hipMemcpyDeviceToHost));
+  std::vector<double> cyc(nblk), clk(nblk);
+  const int na = nacc == 1 ? 1 : (nacc == 4 ? 4 : 8);
+  for (int i = 0; i < nblk; ++i) {
+    cyc[i] = (double)h[2 * i] / ((double)iters * na);
+    clk[i] = (double)h[2 * i] / ((double)h[2 * i + 1] * 10.0) ;  // cycles per 10 ns tick -> GHz
+  }
+  std::sort(cyc.begin(), cyc.end());
+  std::sort(clk.begin(), clk.end());
+  out[0] = cyc[nblk / 2];
+  out[1] = clk[nblk / 2];
+  out[2] = (double)nblk * 4.0 * iters * na * 2048.0 / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
+  return AGP_OK;
+}
+
+// out[0] = cycles per loop iteration per wave, out[1] = clock GHz, out[2] = chip TFLOP/s (MFMA + VALU flops)
+int agp_debug_mix_clock(agp_context *ctx, int waves_per_simd, int variant, int iters, double *out) {
+  if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int nblk = 256 * waves_per_simd;
+  unsigned long long *d = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&d, sizeof(unsigned long long) * 2 * nblk));
+  hipEvent_t e0, e1;
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e1));
+  int nm = 0, nv = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    AGP_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+#define MIX(NM_, NV_) { nm = NM_; nv = NV_; hipLaunchKernelGGL((mix_clock_kernel<NM_, NV_>), dim3(nblk), dim3(256), 0, ctx->stream, d, iters, 1.1, 0.9); }
+    switch (variant) {
+    case 0: MIX(0, 16) break;
+    case 1: MIX(0, 32) break;
+    case 2: MIX(4, 0) break;
+    case 3: MIX(4, 16) break;
+    case 4: MIX(4, 32) break;
+    case 5: MIX(4, 64) break;
+    case 6: MIX(4, 96) break;
+    case 7: MIX(2, 48) break;
+    default: MIX(4, 48) break;
+    }
+#undef MIX
+    AGP_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+    AGP_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  }
+  float ms = 0.f;
+  AGP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h(2 * nblk);
+  AGP_HIP_CHECK(ctx, hipMemcpy(h.data(), d, sizeof(unsigned long long) * 2 * nblk, hipMemcpyDeviceToHost));
+  std::vector<double> cyc(nblk), clk(nblk);
+  for (int i = 0; i < nblk; ++i) {
+    cyc[i] = (double)h[2 * i] / (double)iters;
+    clk[i] = (double)h[2 * i] / ((double)h[2 * i + 1] * 10.0);
+  }
+  std::sort(cyc.begin(), cyc.end());
+  std::sort(clk.begin(), clk.end());
+  out[0] = cyc[nblk / 2];
+  out[1] = clk[nblk / 2];
+  out[2] = (double)nblk * 4.0 * iters * (nm * 2048.0 + nv * 128.0) / (ms * 1e-3) / 1e12;
+  out[3] = nm; out[4] = nv;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
   return AGP_OK;
 }
 

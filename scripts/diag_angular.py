@@ -17,3 +17,11 @@ for nm, cov in [("exp_ang", ab.Exponential(1.1, 1.0, ab.AngularDistance())),
     print("   theta", theta_g, theta_w, "x_i", x[i], "x_j", x[j])
     bad = np.argwhere(d > 4e-16 + 2e-14 * np.abs(want))
     print("   n bad", len(bad), bad[:10].tolist())
+cov = ab.Exponential(1.1, 1.0, ab.AngularDistance()) * ab.SquaredExponential(6.0, 3.7, ab.RadialDistance()) + ab.measurement_only(ab.IndependentNoise(1.75))
+for meas in (False, True):
+    got = ctx.gram(cov, ab.Measurement(x) if meas else x); want = orc.gram(cov, x, x_meas=meas)
+    d = np.abs(got - want)
+    bad = np.argwhere(d > 4e-16 * np.abs(want).max() + 2e-14 * np.abs(want))
+    print("composite meas", meas, "max abs", d.max(), "n bad", len(bad), bad[:6].tolist())
+    for i, j in bad[:4]:
+        print("    ", i, j, got[i, j], want[i, j])
