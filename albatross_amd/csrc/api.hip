@@ -101,8 +101,14 @@ int agp_context_create(int device_id, agp_context **out) {
   if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
   ctx->device = device_id;
   AGP_HIP_CHECK(ctx, hipSetDevice(device_id));
-  AGP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  AGP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  {
+    // main / panel stream at the highest priority: its short kernels must not
+    // queue behind the bulk update running on stream2
+    int lo = 0, hi = 0;
+    AGP_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi));
+    AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo));
+  }
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
   AGP_HIP_CHECK(ctx, hipMalloc(&ctx->d_flags, 4 * sizeof(int)));

@@ -21,13 +21,21 @@
 
 namespace agp {
 
-constexpr int PLD = NB + 8;  // LDS pitch of the diagonal block image
-
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const long long b = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
   const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// 1/sqrt(x) to full fp64 accuracy: hardware estimate + two Newton steps
+// (a short dependent chain: this sits on the serial pivot path)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
 }
 
 struct PotrfArgs {
@@ -41,41 +49,58 @@ struct PotrfArgs {
   double *scalars;
 };
 
+constexpr int NTILE = NMB * (NMB + 1) / 2;  // 36 lower 16x16 tiles
+
+// LDS image: only the 36 lower micro tiles, each column-major 16x16
+// (tile (ib, kb), ib >= kb, at index ib(ib+1)/2 + kb).  An MFMA operand
+// fragment of a tile is 64 consecutive doubles per k-step: conflict-free.
+__device__ __forceinline__ int tile_off(int ib, int kb) { return (ib * (ib + 1) / 2 + kb) * (MB * MB); }
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
-  __shared__ double S[NB * PLD];       // S[c * PLD + r], lower triangle live
-  __shared__ double Wl[NMB][MB * MB];  // inverted micro blocks, column-major
-  __shared__ double ys[NB];
+  __shared__ double T[NTILE * MB * MB + MB * MB + NB];  // tiles | current inverse | y
+  double *Wc = T + NTILE * MB * MB;
+  double *ys = Wc + MB * MB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 15, lg = lane >> 4;
   const int nbk = p.nbk;
 
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int c = idx >> 7, r = idx & (NB - 1);
-    double v;
-    if (r < nbk && c < nbk) v = (r >= c) ? p.A[(p.k0 + c) * p.lda + p.k0 + r] : 0.;
-    else v = (r == c) ? 1. : 0.;  // identity padding of a partial last block
-    S[c * PLD + r] = v;
+  {  // thread (r, c) of every tile; all 36 loads in flight
+    const int r = tid & 15, c = tid >> 4;
+    double v[NTILE];
+#pragma unroll
+    for (int ib = 0; ib < NMB; ++ib)
+#pragma unroll
+      for (int kb = 0; kb <= ib; ++kb) {
+        const int gr = ib * MB + r, gc = kb * MB + c;
+        double x;
+        if (gr < nbk && gc < nbk) x = (gr >= gc) ? p.A[(p.k0 + gc) * p.lda + p.k0 + gr] : 0.;
+        else x = (gr == gc) ? 1. : 0.;  // identity padding of a partial last block
+        v[ib * (ib + 1) / 2 + kb] = x;
+      }
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) T[t * (MB * MB) + c * MB + r] = v[t];
   }
   if (tid < NB) ys[tid] = (p.y && tid < nbk) ? p.y[tid] : 0.;
   __syncthreads();
 
-  double logsum = 0.;
   int bad_pivot = 0;
 
 #pragma unroll 1
   for (int jb = 0; jb < NMB; ++jb) {
     const int o = jb * MB;
-    // ---- stage 1: POTRF16 + INV16 of the diagonal micro block, wave 0, in registers ----
+    double *D = T + tile_off(jb, jb);
+    // ---- stage 1: POTRF16 + INV16 of the diagonal micro tile, wave 0, in registers ----
     if (wave == 0) {
       double a[MB], dinv[MB], w[MB];
 #pragma unroll
-      for (int c = 0; c < MB; ++c) a[c] = S[(o + c) * PLD + o + ln];  // lane ln holds row ln
+      for (int c = 0; c < MB; ++c) a[c] = D[c * MB + ln];  // lane ln holds row ln
 #pragma unroll
       for (int c = 0; c < MB; ++c) {
         const double piv = readlane_f64(a[c], c);
         if (!(piv > 0.) && bad_pivot == 0) bad_pivot = o + c + 1;
-        const double s = sqrt(piv);
-        const double inv = 1. / s;
+        const double inv = rsqrt_nr(piv);
+        double s = piv * inv;
+        s = s + 0.5 * inv * (piv - s * s);  // Heron correction: s = sqrt(piv) to the last bit or two
         dinv[c] = inv;
         a[c] = (ln == c) ? s : a[c] * inv;
 #pragma unroll
@@ -84,20 +109,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
           a[j] -= a[c] * ljc;
         }
       }
-      // W = L16^-1 : lane ln computes column ln by forward substitution on e_ln
+      // W = L16^-1, lane ln owns column ln; column sweep (short dependent chain)
 #pragma unroll
-      for (int r = 0; r < MB; ++r) {
-        double acc = (ln == r) ? 1. : 0.;
+      for (int r = 0; r < MB; ++r) w[r] = (ln == r) ? 1. : 0.;
 #pragma unroll
-        for (int k = 0; k < r; ++k) acc -= readlane_f64(a[k], r) * w[k];
-        w[r] = acc * dinv[r];
+      for (int k = 0; k < MB; ++k) {
+        w[k] *= dinv[k];
+#pragma unroll
+        for (int r = k + 1; r < MB; ++r) w[r] -= readlane_f64(a[k], r) * w[k];
       }
       if (lane < MB) {
 #pragma unroll
-        for (int c = 0; c < MB; ++c) S[(o + c) * PLD + o + ln] = (c <= ln) ? a[c] : 0.;
+        for (int c = 0; c < MB; ++c) D[c * MB + ln] = (c <= ln) ? a[c] : 0.;
 #pragma unroll
         for (int r = 0; r < MB; ++r) {
-          Wl[jb][ln * MB + r] = w[r];
+          Wc[ln * MB + r] = w[r];
           p.invd[jb * MB * MB + ln * MB + r] = w[r];
         }
       }
@@ -106,65 +132,72 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
 
     // ---- stage 2: micro TRSM of the tiles below, X <- X W^T, one tile per wave ----
     for (int ib = jb + 1 + wave; ib < NMB; ib += 4) {
-      v4d acc = v4zero();
+      double *X = T + tile_off(ib, jb);
+      v4d acc0 = v4zero(), acc1 = v4zero();
+      acc0 = mfma16(Wc[(0 + lg) * MB + ln], X[(0 + lg) * MB + ln], acc0);
+      acc1 = mfma16(Wc[(4 + lg) * MB + ln], X[(4 + lg) * MB + ln], acc1);
+      acc0 = mfma16(Wc[(8 + lg) * MB + ln], X[(8 + lg) * MB + ln], acc0);
+      acc1 = mfma16(Wc[(12 + lg) * MB + ln], X[(12 + lg) * MB + ln], acc1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double wa = Wl[jb][(4 * s + lg) * MB + ln];            // W[m=ln][k]
-        const double xb = S[(o + 4 * s + lg) * PLD + ib * MB + ln];  // Xold[n=ln][k]
-        acc = mfma16(wa, xb, acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) S[(o + lg + 4 * r) * PLD + ib * MB + ln] = acc[r];
+      for (int r = 0; r < 4; ++r) X[(lg + 4 * r) * MB + ln] = acc0[r] + acc1[r];
     }
-    // z_jb = W y_jb  (wave 3, 16 lanes; reads precede the write in program order)
+    // z_jb = W y_jb  (wave 3; reads precede the write in program order)
     if (wave == 3) {
       double zz = 0.;
 #pragma unroll
-      for (int c = 0; c < MB; ++c) zz += Wl[jb][c * MB + ln] * ys[o + c];
+      for (int c = 0; c < MB; ++c) zz += Wc[c * MB + ln] * ys[o + c];
       if (lane < MB) ys[o + ln] = zz;
     }
     __syncthreads();
 
     // ---- stage 3: micro SYRK of the trailing tiles + y update ----
     {
-      const int rem = NMB - 1 - jb;          // trailing micro blocks
-      const int ntile = rem * (rem + 1) / 2;  // lower tiles (ib >= kb)
+      const int rem = NMB - 1 - jb;
+      const int ntile = rem * (rem + 1) / 2;
       for (int tix = wave; tix < ntile; tix += 4) {
         int kb = 0, left = tix;
         while (left >= rem - kb) { left -= rem - kb; ++kb; }
-        const int ib = kb + left;
-        const int cb = (jb + 1 + kb) * MB, rb = (jb + 1 + ib) * MB;
-        v4d acc;
+        const int ib = jb + 1 + kb + left;
+        kb += jb + 1;
+        double *Cc = T + tile_off(ib, kb);
+        const double *Xk = T + tile_off(kb, jb), *Xi = T + tile_off(ib, jb);
+        v4d acc0, acc1 = v4zero();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = S[(cb + lg + 4 * r) * PLD + rb + ln];
+        for (int r = 0; r < 4; ++r) acc0[r] = Cc[(lg + 4 * r) * MB + ln];
+        acc0 = mfma16(-Xk[(0 + lg) * MB + ln], Xi[(0 + lg) * MB + ln], acc0);
+        acc1 = mfma16(-Xk[(4 + lg) * MB + ln], Xi[(4 + lg) * MB + ln], acc1);
+        acc0 = mfma16(-Xk[(8 + lg) * MB + ln], Xi[(8 + lg) * MB + ln], acc0);
+        acc1 = mfma16(-Xk[(12 + lg) * MB + ln], Xi[(12 + lg) * MB + ln], acc1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double xa = -S[(o + 4 * s + lg) * PLD + cb + ln];  // X_kb[m=ln][k]
-          const double xb = S[(o + 4 * s + lg) * PLD + rb + ln];   // X_ib[n=ln][k]
-          acc = mfma16(xa, xb, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(cb + lg + 4 * r) * PLD + rb + ln] = acc[r];
+        for (int r = 0; r < 4; ++r) Cc[(lg + 4 * r) * MB + ln] = acc0[r] + acc1[r];
       }
       const int row = o + MB + tid;
       if (row < NB) {
+        const double *Xr = T + tile_off(row >> 4, jb) + (row & 15);
         double s = ys[row];
 #pragma unroll
-        for (int k = 0; k < MB; ++k) s -= S[(o + k) * PLD + row] * ys[o + k];
+        for (int k = 0; k < MB; ++k) s -= Xr[k * MB] * ys[o + k];
         ys[row] = s;
       }
     }
     __syncthreads();
   }
 
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int c = idx >> 7, r = idx & (NB - 1);
-    if (r < nbk && c < nbk && r >= c) p.A[(p.k0 + c) * p.lda + p.k0 + r] = S[c * PLD + r];
+  {
+    const int r = tid & 15, c = tid >> 4;
+#pragma unroll
+    for (int ib = 0; ib < NMB; ++ib)
+#pragma unroll
+      for (int kb = 0; kb <= ib; ++kb) {
+        const int gr = ib * MB + r, gc = kb * MB + c;
+        if (gr < nbk && gc < nbk && gr >= gc)
+          p.A[(p.k0 + gc) * p.lda + p.k0 + gr] = T[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r];
+      }
   }
   if (p.y && tid < nbk) p.y[tid] = ys[tid];
   // sum log L_ii of this block (log_determinant, serializable_ldlt.hpp:128-135):
   // 128 logs in parallel, fixed-order reduction
-  logsum = (tid < nbk) ? log(S[tid * PLD + tid]) : 0.;
+  double logsum = (tid < nbk) ? log(T[tile_off(tid >> 4, tid >> 4) + (tid & 15) * (MB + 1)]) : 0.;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) logsum += __shfl_down(logsum, off, 64);
   __syncthreads();
@@ -221,26 +254,56 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
   }
 
   // ---- stage the fragment image of L11 ----
-#pragma unroll 4
-  for (int e = tid; e < NFRAG_TILES * 4 * 64; e += 256) {
-    const int l = e & 63, s = (e >> 6) & 3, t = e >> 8;
-    int jb = 0;
-    while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;  // t = jb(jb+1)/2 + ib, ib <= jb
-    const int ib = t - jb * (jb + 1) / 2;
-    const int m = l & 15, k = (l >> 4) + 4 * s;
-    double v;
-    if (ib == jb) {
-      // W = inv(L_jj) column-major: W[m][k] at k*16+m ; transposed solve uses W^T
-      v = TRANS ? p.invd[jb * MB * MB + m * MB + k] : p.invd[jb * MB * MB + k * MB + m];
-    } else {
-      // !TRANS: tile T[m][k] = -L[jb*16+m][ib*16+k]
-      //  TRANS: the pair (row block ib' = jb, col block jb' = ib) needs
-      //         T[m][k] = -L[jb*16+k][ib*16+m]
-      const int lr = TRANS ? (jb * MB + k) : (jb * MB + m);
-      const int lc = TRANS ? (ib * MB + m) : (ib * MB + k);
-      v = (lr < p.nbk && lc < p.nbk) ? -p.L[(long long)lc * p.ldl + lr] : 0.;
+  // image element e = tile * 256 + s * 64 + l holds T[m = l & 15][k = (l >> 4) + 4 s];
+  // for the non-transposed solve m runs down a matrix column, so two
+  // consecutive image elements are two consecutive matrix rows: 16-B loads.
+  const bool vec_stage = !TRANS && ((p.ldl & 1) == 0) && ((reinterpret_cast<uintptr_t>(p.L) & 15) == 0);
+  if (vec_stage) {
+#pragma unroll
+    for (int it = 0; it < NFRAG_TILES * 4 * 64 / 2 / 256; ++it) {
+      const int e = 2 * (tid + 256 * it);
+      const int l = e & 63, s = (e >> 6) & 3, t = e >> 8;
+      int jb = 0;
+      while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;
+      const int ib = t - jb * (jb + 1) / 2;
+      const int m = l & 15, k = (l >> 4) + 4 * s;
+      double2 v;
+      if (ib == jb) {
+        v = *reinterpret_cast<const double2 *>(p.invd + jb * MB * MB + k * MB + m);
+      } else {
+        const int lr = jb * MB + m, lc = ib * MB + k;
+        if (lr + 1 < p.nbk && lc < p.nbk) {
+          v = *reinterpret_cast<const double2 *>(p.L + (long long)lc * p.ldl + lr);
+          v.x = -v.x; v.y = -v.y;
+        } else {
+          v.x = (lr < p.nbk && lc < p.nbk) ? -p.L[(long long)lc * p.ldl + lr] : 0.;
+          v.y = 0.;
+        }
+      }
+      *reinterpret_cast<double2 *>(F + e) = v;
     }
-    F[e] = v;
+  } else {
+#pragma unroll 4
+    for (int e = tid; e < NFRAG_TILES * 4 * 64; e += 256) {
+      const int l = e & 63, s = (e >> 6) & 3, t = e >> 8;
+      int jb = 0;
+      while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;  // t = jb(jb+1)/2 + ib, ib <= jb
+      const int ib = t - jb * (jb + 1) / 2;
+      const int m = l & 15, k = (l >> 4) + 4 * s;
+      double v;
+      if (ib == jb) {
+        // W = inv(L_jj) column-major: W[m][k] at k*16+m ; transposed solve uses W^T
+        v = TRANS ? p.invd[jb * MB * MB + m * MB + k] : p.invd[jb * MB * MB + k * MB + m];
+      } else {
+        // !TRANS: tile T[m][k] = -L[jb*16+m][ib*16+k]
+        //  TRANS: the pair (row block jb, col block ib) of L is used transposed:
+        //         T[m][k] = -L[jb*16+k][ib*16+m]
+        const int lr = TRANS ? (jb * MB + k) : (jb * MB + m);
+        const int lc = TRANS ? (ib * MB + m) : (ib * MB + k);
+        v = (lr < p.nbk && lc < p.nbk) ? -p.L[(long long)lc * p.ldl + lr] : 0.;
+      }
+      F[e] = v;
+    }
   }
   if (FUSE_Y && tid < NB) zs[tid] = (tid < p.nbk) ? p.z[tid] : 0.;
   __syncthreads();
@@ -262,17 +325,22 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
   if (!TRANS) {
 #pragma unroll
     for (int jb = 0; jb < NMB; ++jb) {
-      v4d acc = Y[jb];
+      // four independent accumulation chains (one per k-step) instead of one
+      // chain of 4 jb dependent MFMAs: the dependent-issue latency of the f64
+      // MFMA (~190 cycles) is what this kernel is bound by
+      v4d pa[4] = {Y[jb], v4zero(), v4zero(), v4zero()};
 #pragma unroll
       for (int ib = 0; ib < jb; ++ib) {
         const double *f = F + (jb * (jb + 1) / 2 + ib) * 256 + lane;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma16(f[s * 64], Y[ib][s], acc);
+        for (int s = 0; s < 4; ++s) pa[s] = mfma16(f[s * 64], Y[ib][s], pa[s]);
       }
-      v4d out = v4zero();
+      const v4d acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+      v4d po[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
       const double *f = F + (jb * (jb + 1) / 2 + jb) * 256 + lane;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) out = mfma16(f[s * 64], acc[s], out);
+      for (int s = 0; s < 4; ++s) po[s] = mfma16(f[s * 64], acc[s], po[s]);
+      const v4d out = (po[0] + po[1]) + (po[2] + po[3]);
       Y[jb] = out;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -283,18 +351,20 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
   } else {
 #pragma unroll
     for (int jb = NMB - 1; jb >= 0; --jb) {
-      v4d acc = Y[jb];
+      v4d pa[4] = {Y[jb], v4zero(), v4zero(), v4zero()};
 #pragma unroll
       for (int ib = NMB - 1; ib > jb; --ib) {
         // image tile index of the stored pair (row block ib, col block jb)
         const double *f = F + (ib * (ib + 1) / 2 + jb) * 256 + lane;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma16(f[s * 64], Y[ib][s], acc);
+        for (int s = 0; s < 4; ++s) pa[s] = mfma16(f[s * 64], Y[ib][s], pa[s]);
       }
-      v4d out = v4zero();
+      const v4d acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+      v4d po[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
       const double *f = F + (jb * (jb + 1) / 2 + jb) * 256 + lane;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) out = mfma16(f[s * 64], acc[s], out);
+      for (int s = 0; s < 4; ++s) po[s] = mfma16(f[s * 64], acc[s], po[s]);
+      const v4d out = (po[0] + po[1]) + (po[2] + po[3]);
       Y[jb] = out;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -335,10 +405,10 @@ static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, 
 // trailing update C -= P P^T (lower tiles) bracketed by a HIP-event pair when
 // the caller collects per-launch timings (bench.py's roofline block)
 static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long lda, const double *P,
-                       long long M, long long N, long long K) {
+                       const double *Q, long long M, long long N, long long K) {
   const bool timed = timers && timers->ev && timers->used + 2 <= timers->n_ev;
   if (timed) (void)hipEventRecord(timers->ev[timers->used], s);
-  launch_gemm_nt_sub(s, C, lda, P, lda, false, P, lda, false, M, N, K, true);
+  launch_gemm_nt_sub(s, C, lda, P, lda, false, Q, lda, false, M, N, K, true);
   if (timed) {
     (void)hipEventRecord(timers->ev[timers->used + 1], s);
     // algorithmic flop: 2 K per C entry on or below the diagonal
@@ -347,40 +417,70 @@ static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long
   }
 }
 
-void factor_lower(agp_context *ctx, double *A, long long n, long long lda, double *invd, double *y,
-                  FactorTimers *timers) {
-  hipStream_t s = ctx->stream;
-  for (long long K0 = 0; K0 < n; K0 += NBO) {
-    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
-    for (long long k = K0; k < kend; k += NB) {
-      const int nbk = (int)((n - k < NB) ? n - k : NB);
-      launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars);
-      const long long below = n - (k + nbk);
-      if (below <= 0) continue;
-      TrsmArgs t;
-      t.L = A + k * lda + k; t.ldl = lda;
-      t.invd = invd + (k / NB) * (long long)(NMB * MB * MB);
-      t.nbk = nbk;
-      t.Y = A + k * lda + (k + nbk);
-      t.stride_m = lda; t.stride_n = 1;
-      t.ncols = below;
-      t.z = y ? y + k : nullptr;
-      t.yrest = y ? y + k + nbk : nullptr;
-      t.batch_L = t.batch_invd = t.batch_Y = 0; t.n_total = 0;
-      const unsigned grid = (unsigned)((below + 63) / 64);
-      if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
-      else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
-      const long long width = kend - (k + nbk);
-      if (width > 0) {
-        const double *P = A + k * lda + (k + nbk);
-        timed_gemm(s, timers, A + (k + nbk) * lda + (k + nbk), lda, P, below, width, nbk);
-      }
-    }
-    if (kend < n) {
-      const double *P = A + K0 * lda + kend;
-      timed_gemm(s, timers, A + kend * lda + kend, lda, P, n - kend, n - kend, kend - K0);
+// Panel phase of one outer block [K0, kend): for every NB-wide diagonal block
+// POTRF, panel TRSM (with the fused forward substitution on y) and the update
+// of the remaining columns of the outer block.  Everything on stream s.
+static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *invd,
+                        double *y, long long K0, long long kend, FactorTimers *timers) {
+  for (long long k = K0; k < kend; k += NB) {
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars);
+    const long long below = n - (k + nbk);
+    if (below <= 0) continue;
+    TrsmArgs t;
+    t.L = A + k * lda + k; t.ldl = lda;
+    t.invd = invd + (k / NB) * (long long)(NMB * MB * MB);
+    t.nbk = nbk;
+    t.Y = A + k * lda + (k + nbk);
+    t.stride_m = lda; t.stride_n = 1;
+    t.ncols = below;
+    t.z = y ? y + k : nullptr;
+    t.yrest = y ? y + k + nbk : nullptr;
+    t.batch_L = t.batch_invd = t.batch_Y = 0; t.n_total = 0;
+    const unsigned grid = (unsigned)((below + 63) / 64);
+    if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
+    else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
+    const long long width = kend - (k + nbk);
+    if (width > 0) {
+      const double *P = A + k * lda + (k + nbk);
+      timed_gemm(s, timers, A + (k + nbk) * lda + (k + nbk), lda, P, P, below, width, nbk);
     }
   }
+}
+
+// Right-looking LL^T with one outer block of look-ahead on two streams:
+//   stream  (high priority): panel phase P(K0), then U1(K0) = update of the
+//            NEXT outer block column, then P(K0 + NBO) ...
+//   stream2: U2(K0) = update of everything right of the next block column
+//            (the MFMA-bound bulk), overlapping P(K0 + NBO).
+// Dependencies: U1(K0), U2(K0) after P(K0) and after U2(K0 - NBO).
+void factor_lower(agp_context *ctx, double *A, long long n, long long lda, double *invd, double *y,
+                  FactorTimers *timers) {
+  hipStream_t sa = ctx->stream, sb = ctx->stream2;
+  bool have_u2 = false;
+  panel_phase(ctx, sa, A, n, lda, invd, y, 0, (NBO < n) ? NBO : n, timers);
+  for (long long K0 = 0; K0 < n; K0 += NBO) {
+    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
+    if (kend >= n) break;
+    const long long next_end = (kend + NBO < n) ? kend + NBO : n;
+    const long long K = kend - K0;
+    const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
+    (void)hipEventRecord(ctx->ev_a, sa);            // P(K0) done
+    if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);  // U2(K0 - NBO) done
+    // U1: block column [kend, next_end), all rows below its diagonal
+    timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K);
+    if (next_end < n) {
+      (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
+      const double *Q = A + K0 * lda + next_end;
+      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K);
+      (void)hipEventRecord(ctx->ev_b, sb);
+      have_u2 = true;
+    } else {
+      have_u2 = false;
+    }
+    panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers);
+  }
+  // the panel stream ran last (its final panel depends on every update)
 }
 
 // ---------------------------------------------------------------------------
