@@ -474,7 +474,7 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   if ((st = to_device(ctx, x, true, &fit->train)) != AGP_OK) { agp_fit_destroy(fit); return st; }
   fit->train.v.meas = 0;
   FIT_CHECK(hipMalloc(&fit->A, sizeof(double) * (size_t)fit->lda * (size_t)n));
-  FIT_CHECK(hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * NMB * MB * MB));
+  FIT_CHECK(hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * (36 * MB * MB)));
   FIT_CHECK(hipMalloc(&fit->winv, sizeof(double) * (size_t)nblk * NB * NB));
   FIT_CHECK(hipMalloc(&fit->alpha, sizeof(double) * (size_t)n));
   FIT_CHECK(hipMalloc(&fit->z, sizeof(double) * (size_t)n));
@@ -561,11 +561,11 @@ int agp_nll(agp_context *c, const agp_kernel *k, const agp_features *x, const do
   const long long nblk = (n + NB - 1) / NB;
   // workspace: [A | invd | z | yvar]
   const size_t a_bytes = sizeof(double) * (size_t)lda * (size_t)n;
-  const size_t aux = sizeof(double) * ((size_t)nblk * NMB * MB * MB + 2 * (size_t)round_up(n, 2));
+  const size_t aux = sizeof(double) * ((size_t)nblk * (36 * MB * MB) + 2 * (size_t)round_up(n, 2));
   if ((st = ensure_ws(ctx, &ctx->ws_A, &ctx->ws_A_bytes, a_bytes + aux)) != AGP_OK) return st;
   double *A = ctx->ws_A;
   double *invd = A + (size_t)lda * (size_t)n;
-  double *z = invd + (size_t)nblk * NMB * MB * MB;
+  double *z = invd + (size_t)nblk * (36 * MB * MB);
   double *yvar_d = y_var ? z + round_up(n, 2) : nullptr;
   DeviceFeatures dx;
   if ((st = to_device(ctx, x, false, &dx)) != AGP_OK) return st;

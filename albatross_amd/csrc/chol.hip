@@ -43,23 +43,87 @@ struct PotrfArgs {
   long long lda;
   long long k0;     // first row/col of the diagonal block
   int nbk;          // valid size of the block (<= NB)
-  double *invd;     // NMB inverted micro blocks for this diagonal block
+  double *img;      // tile image of this diagonal block (IMG_DOUBLES doubles, see below)
   double *y;        // y + k0 or nullptr
   int *flags;
   double *scalars;
 };
 
-constexpr int NTILE = NMB * (NMB + 1) / 2;  // 36 lower 16x16 tiles
+constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
+constexpr int IMG_DOUBLES = NTILE * MB * MB;  // 9216 doubles = 72 KiB per diagonal block
 
 // LDS image: only the 36 lower micro tiles, each column-major 16x16
 // (tile (ib, kb), ib >= kb, at index ib(ib+1)/2 + kb).  An MFMA operand
-// fragment of a tile is 64 consecutive doubles per k-step: conflict-free.
+// fragment of a tile (element [k*16 + m], k = (lane >> 4) + 4 s, m = lane & 15)
+// is 64 consecutive doubles per k-step: conflict-free ds_read_b64.
+//
+// The kernel also emits the "tile image" of the factored block to global
+// memory: the same 36 tiles with the off-diagonal ones NEGATED and the diagonal
+// ones replaced by their INVERSES.  That image is exactly the set of MFMA
+// A-operand fragments the substitution kernels need, so they stage it with a
+// straight coalesced copy.
 __device__ __forceinline__ int tile_off(int ib, int kb) { return (ib * (ib + 1) / 2 + kb) * (MB * MB); }
 
+// POTRF16 + INV16 of one diagonal micro tile by one wave, in registers.
+// Lane ln (= lane & 15) owns row ln of the tile / column ln of the inverse.
+__device__ __forceinline__ void micro_potrf_inv(double *D, double *Wout, double *img_diag, int lane, int ln,
+                                                int pivot_base, int &bad_pivot) {
+  double a[MB], dinv[MB], w[MB];
+#pragma unroll
+  for (int c = 0; c < MB; ++c) a[c] = D[c * MB + ln];
+#pragma unroll
+  for (int c = 0; c < MB; ++c) {
+    const double piv = readlane_f64(a[c], c);
+    if (!(piv > 0.) && bad_pivot == 0) bad_pivot = pivot_base + c + 1;
+    const double inv = rsqrt_nr(piv);
+    double s = piv * inv;
+    s = s + 0.5 * inv * (piv - s * s);  // Heron correction of sqrt(piv)
+    dinv[c] = inv;
+    a[c] = (ln == c) ? s : a[c] * inv;
+#pragma unroll
+    for (int j = c + 1; j < MB; ++j) {
+      const double ljc = readlane_f64(a[c], j);
+      a[j] -= a[c] * ljc;
+    }
+  }
+  // W = L16^-1 by column sweep (short dependent chain)
+#pragma unroll
+  for (int r = 0; r < MB; ++r) w[r] = (ln == r) ? 1. : 0.;
+#pragma unroll
+  for (int k = 0; k < MB; ++k) {
+    w[k] *= dinv[k];
+#pragma unroll
+    for (int r = k + 1; r < MB; ++r) w[r] -= readlane_f64(a[k], r) * w[k];
+  }
+  if (lane < MB) {
+#pragma unroll
+    for (int c = 0; c < MB; ++c) D[c * MB + ln] = (c <= ln) ? a[c] : 0.;
+#pragma unroll
+    for (int r = 0; r < MB; ++r) {
+      Wout[ln * MB + r] = w[r];
+      img_diag[ln * MB + r] = w[r];
+    }
+  }
+}
+
+__device__ __forceinline__ void micro_syrk_tile(double *T, int ib, int kb, int jb, int ln, int lg) {
+  double *Cc = T + tile_off(ib, kb);
+  const double *Xk = T + tile_off(kb, jb), *Xi = T + tile_off(ib, jb);
+  v4d acc0, acc1 = v4zero();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc0[r] = Cc[(lg + 4 * r) * MB + ln];
+  acc0 = mfma16(-Xk[(0 + lg) * MB + ln], Xi[(0 + lg) * MB + ln], acc0);
+  acc1 = mfma16(-Xk[(4 + lg) * MB + ln], Xi[(4 + lg) * MB + ln], acc1);
+  acc0 = mfma16(-Xk[(8 + lg) * MB + ln], Xi[(8 + lg) * MB + ln], acc0);
+  acc1 = mfma16(-Xk[(12 + lg) * MB + ln], Xi[(12 + lg) * MB + ln], acc1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Cc[(lg + 4 * r) * MB + ln] = acc0[r] + acc1[r];
+}
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
-  __shared__ double T[NTILE * MB * MB + MB * MB + NB];  // tiles | current inverse | y
-  double *Wc = T + NTILE * MB * MB;
-  double *ys = Wc + MB * MB;
+  __shared__ double T[IMG_DOUBLES + 2 * MB * MB + NB];  // tiles | two inverse buffers | y
+  double *Wc = T + IMG_DOUBLES;
+  double *ys = Wc + 2 * MB * MB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 15, lg = lane >> 4;
   const int nbk = p.nbk;
@@ -84,60 +148,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
   __syncthreads();
 
   int bad_pivot = 0;
+  if (wave == 0) micro_potrf_inv(T + tile_off(0, 0), Wc, p.img + tile_off(0, 0), lane, ln, 0, bad_pivot);
+  __syncthreads();
 
 #pragma unroll 1
   for (int jb = 0; jb < NMB; ++jb) {
     const int o = jb * MB;
-    double *D = T + tile_off(jb, jb);
-    // ---- stage 1: POTRF16 + INV16 of the diagonal micro tile, wave 0, in registers ----
-    if (wave == 0) {
-      double a[MB], dinv[MB], w[MB];
-#pragma unroll
-      for (int c = 0; c < MB; ++c) a[c] = D[c * MB + ln];  // lane ln holds row ln
-#pragma unroll
-      for (int c = 0; c < MB; ++c) {
-        const double piv = readlane_f64(a[c], c);
-        if (!(piv > 0.) && bad_pivot == 0) bad_pivot = o + c + 1;
-        const double inv = rsqrt_nr(piv);
-        double s = piv * inv;
-        s = s + 0.5 * inv * (piv - s * s);  // Heron correction: s = sqrt(piv) to the last bit or two
-        dinv[c] = inv;
-        a[c] = (ln == c) ? s : a[c] * inv;
-#pragma unroll
-        for (int j = c + 1; j < MB; ++j) {
-          const double ljc = readlane_f64(a[c], j);
-          a[j] -= a[c] * ljc;
-        }
-      }
-      // W = L16^-1, lane ln owns column ln; column sweep (short dependent chain)
-#pragma unroll
-      for (int r = 0; r < MB; ++r) w[r] = (ln == r) ? 1. : 0.;
-#pragma unroll
-      for (int k = 0; k < MB; ++k) {
-        w[k] *= dinv[k];
-#pragma unroll
-        for (int r = k + 1; r < MB; ++r) w[r] -= readlane_f64(a[k], r) * w[k];
-      }
-      if (lane < MB) {
-#pragma unroll
-        for (int c = 0; c < MB; ++c) D[c * MB + ln] = (c <= ln) ? a[c] : 0.;
-#pragma unroll
-        for (int r = 0; r < MB; ++r) {
-          Wc[ln * MB + r] = w[r];
-          p.invd[jb * MB * MB + ln * MB + r] = w[r];
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- stage 2: micro TRSM of the tiles below, X <- X W^T, one tile per wave ----
+    const double *W = Wc + (jb & 1) * (MB * MB);
+    // ---- stage A: micro TRSM of the tiles below, X <- X W^T, one tile per wave ----
     for (int ib = jb + 1 + wave; ib < NMB; ib += 4) {
       double *X = T + tile_off(ib, jb);
       v4d acc0 = v4zero(), acc1 = v4zero();
-      acc0 = mfma16(Wc[(0 + lg) * MB + ln], X[(0 + lg) * MB + ln], acc0);
-      acc1 = mfma16(Wc[(4 + lg) * MB + ln], X[(4 + lg) * MB + ln], acc1);
-      acc0 = mfma16(Wc[(8 + lg) * MB + ln], X[(8 + lg) * MB + ln], acc0);
-      acc1 = mfma16(Wc[(12 + lg) * MB + ln], X[(12 + lg) * MB + ln], acc1);
+      acc0 = mfma16(W[(0 + lg) * MB + ln], X[(0 + lg) * MB + ln], acc0);
+      acc1 = mfma16(W[(4 + lg) * MB + ln], X[(4 + lg) * MB + ln], acc1);
+      acc0 = mfma16(W[(8 + lg) * MB + ln], X[(8 + lg) * MB + ln], acc0);
+      acc1 = mfma16(W[(12 + lg) * MB + ln], X[(12 + lg) * MB + ln], acc1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) X[(lg + 4 * r) * MB + ln] = acc0[r] + acc1[r];
     }
@@ -145,33 +170,27 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
     if (wave == 3) {
       double zz = 0.;
 #pragma unroll
-      for (int c = 0; c < MB; ++c) zz += Wc[c * MB + ln] * ys[o + c];
+      for (int c = 0; c < MB; ++c) zz += W[c * MB + ln] * ys[o + c];
       if (lane < MB) ys[o + ln] = zz;
     }
     __syncthreads();
+    if (jb == NMB - 1) break;
 
-    // ---- stage 3: micro SYRK of the trailing tiles + y update ----
-    {
+    // ---- stage B: wave 0 updates the NEXT diagonal tile and factors it right
+    // away (look-ahead) while waves 1-3 run the remaining SYRK tiles + y update
+    if (wave == 0) {
+      micro_syrk_tile(T, jb + 1, jb + 1, jb, ln, lg);
+      micro_potrf_inv(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB),
+                      p.img + tile_off(jb + 1, jb + 1), lane, ln, o + MB, bad_pivot);
+    } else {
       const int rem = NMB - 1 - jb;
       const int ntile = rem * (rem + 1) / 2;
-      for (int tix = wave; tix < ntile; tix += 4) {
+      for (int tix = wave; tix < ntile; tix += 3) {  // tix 0 is the diagonal tile done by wave 0
         int kb = 0, left = tix;
         while (left >= rem - kb) { left -= rem - kb; ++kb; }
-        const int ib = jb + 1 + kb + left;
-        kb += jb + 1;
-        double *Cc = T + tile_off(ib, kb);
-        const double *Xk = T + tile_off(kb, jb), *Xi = T + tile_off(ib, jb);
-        v4d acc0, acc1 = v4zero();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc0[r] = Cc[(lg + 4 * r) * MB + ln];
-        acc0 = mfma16(-Xk[(0 + lg) * MB + ln], Xi[(0 + lg) * MB + ln], acc0);
-        acc1 = mfma16(-Xk[(4 + lg) * MB + ln], Xi[(4 + lg) * MB + ln], acc1);
-        acc0 = mfma16(-Xk[(8 + lg) * MB + ln], Xi[(8 + lg) * MB + ln], acc0);
-        acc1 = mfma16(-Xk[(12 + lg) * MB + ln], Xi[(12 + lg) * MB + ln], acc1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Cc[(lg + 4 * r) * MB + ln] = acc0[r] + acc1[r];
+        micro_syrk_tile(T, jb + 1 + kb + left, jb + 1 + kb, jb, ln, lg);
       }
-      const int row = o + MB + tid;
+      const int row = o + MB + (tid - 64);
       if (row < NB) {
         const double *Xr = T + tile_off(row >> 4, jb) + (row & 15);
         double s = ys[row];
@@ -190,8 +209,9 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
 #pragma unroll
       for (int kb = 0; kb <= ib; ++kb) {
         const int gr = ib * MB + r, gc = kb * MB + c;
-        if (gr < nbk && gc < nbk && gr >= gc)
-          p.A[(p.k0 + gc) * p.lda + p.k0 + gr] = T[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r];
+        const double v = T[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r];
+        if (gr < nbk && gc < nbk && gr >= gc) p.A[(p.k0 + gc) * p.lda + p.k0 + gr] = v;
+        if (ib != kb) p.img[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r] = -v;
       }
   }
   if (p.y && tid < nbk) p.y[tid] = ys[tid];
@@ -219,12 +239,10 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
 // LDS holds the 36 lower 16x16 tiles of L11 as ready-made MFMA A-operand
 // fragments (negated off-diagonal tiles, inverted diagonal tiles).
 // ---------------------------------------------------------------------------
-constexpr int NFRAG_TILES = NMB * (NMB + 1) / 2;  // 36
+constexpr int NFRAG_TILES = NTILE;
 
 struct TrsmArgs {
-  const double *L;  // diagonal block origin: L11(0,0)
-  long long ldl;
-  const double *invd;  // NMB inverted micro blocks of this diagonal block
+  const double *img;  // tile image of the diagonal block (written by potrf_diag_kernel)
   int nbk;
   double *Y;  // element (0, 0) of the block to be solved
   long long stride_m, stride_n;
@@ -232,7 +250,7 @@ struct TrsmArgs {
   const double *z;  // z_b (nbk) or nullptr          (FUSE_Y only)
   double *yrest;    // y entries matching n = 0..ncols (FUSE_Y only)
   // batched launches (blockIdx.y = diagonal block index): element strides
-  long long batch_L, batch_invd, batch_Y;
+  long long batch_img, batch_Y;
   long long n_total;  // matrix size, to derive nbk per batch entry (0: use nbk)
 };
 
@@ -244,8 +262,7 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
   const int ln = lane & 15, lg = lane >> 4;
   if (blockIdx.y > 0 || p.n_total > 0) {
     const long long b = blockIdx.y;
-    p.L += b * p.batch_L;
-    p.invd += b * p.batch_invd;
+    p.img += b * p.batch_img;
     p.Y += b * p.batch_Y;
     if (p.n_total > 0) {
       const long long left = p.n_total - b * NB;
@@ -254,55 +271,19 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
   }
 
   // ---- stage the fragment image of L11 ----
-  // image element e = tile * 256 + s * 64 + l holds T[m = l & 15][k = (l >> 4) + 4 s];
-  // for the non-transposed solve m runs down a matrix column, so two
-  // consecutive image elements are two consecutive matrix rows: 16-B loads.
-  const bool vec_stage = !TRANS && ((p.ldl & 1) == 0) && ((reinterpret_cast<uintptr_t>(p.L) & 15) == 0);
-  if (vec_stage) {
+  // Image element [tile * 256 + k * 16 + m] is the A-operand value T[m][k] of
+  // the forward solve; the transposed solve needs T^T of every tile.
+  if (!TRANS) {
 #pragma unroll
-    for (int it = 0; it < NFRAG_TILES * 4 * 64 / 2 / 256; ++it) {
+    for (int it = 0; it < IMG_DOUBLES / 2 / 256; ++it) {
       const int e = 2 * (tid + 256 * it);
-      const int l = e & 63, s = (e >> 6) & 3, t = e >> 8;
-      int jb = 0;
-      while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;
-      const int ib = t - jb * (jb + 1) / 2;
-      const int m = l & 15, k = (l >> 4) + 4 * s;
-      double2 v;
-      if (ib == jb) {
-        v = *reinterpret_cast<const double2 *>(p.invd + jb * MB * MB + k * MB + m);
-      } else {
-        const int lr = jb * MB + m, lc = ib * MB + k;
-        if (lr + 1 < p.nbk && lc < p.nbk) {
-          v = *reinterpret_cast<const double2 *>(p.L + (long long)lc * p.ldl + lr);
-          v.x = -v.x; v.y = -v.y;
-        } else {
-          v.x = (lr < p.nbk && lc < p.nbk) ? -p.L[(long long)lc * p.ldl + lr] : 0.;
-          v.y = 0.;
-        }
-      }
-      *reinterpret_cast<double2 *>(F + e) = v;
+      *reinterpret_cast<double2 *>(F + e) = *reinterpret_cast<const double2 *>(p.img + e);
     }
   } else {
 #pragma unroll 4
-    for (int e = tid; e < NFRAG_TILES * 4 * 64; e += 256) {
-      const int l = e & 63, s = (e >> 6) & 3, t = e >> 8;
-      int jb = 0;
-      while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;  // t = jb(jb+1)/2 + ib, ib <= jb
-      const int ib = t - jb * (jb + 1) / 2;
-      const int m = l & 15, k = (l >> 4) + 4 * s;
-      double v;
-      if (ib == jb) {
-        // W = inv(L_jj) column-major: W[m][k] at k*16+m ; transposed solve uses W^T
-        v = TRANS ? p.invd[jb * MB * MB + m * MB + k] : p.invd[jb * MB * MB + k * MB + m];
-      } else {
-        // !TRANS: tile T[m][k] = -L[jb*16+m][ib*16+k]
-        //  TRANS: the pair (row block jb, col block ib) of L is used transposed:
-        //         T[m][k] = -L[jb*16+k][ib*16+m]
-        const int lr = TRANS ? (jb * MB + k) : (jb * MB + m);
-        const int lc = TRANS ? (ib * MB + m) : (ib * MB + k);
-        v = (lr < p.nbk && lc < p.nbk) ? -p.L[(long long)lc * p.ldl + lr] : 0.;
-      }
-      F[e] = v;
+    for (int e = tid; e < IMG_DOUBLES; e += 256) {
+      const int m = e & 15, k = (e >> 4) & 15, t = e >> 8;
+      F[e] = p.img[t * 256 + m * 16 + k];
     }
   }
   if (FUSE_Y && tid < NB) zs[tid] = (tid < p.nbk) ? p.z[tid] : 0.;
@@ -392,11 +373,11 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
 // and the "column block" ib, i.e. tile (jb, ib) of L, used when solving micro
 // block ib with the already-solved block jb > ib.
 
-static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, int nbk, double *invd,
+static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, int nbk, double *img,
                          double *y, int *flags, double *scalars) {
   PotrfArgs p;
   p.A = A; p.lda = lda; p.k0 = k0; p.nbk = nbk;
-  p.invd = invd + (k0 / NB) * (long long)(NMB * MB * MB);
+  p.img = img + (k0 / NB) * (long long)IMG_DOUBLES;
   p.y = y ? y + k0 : nullptr;
   p.flags = flags; p.scalars = scalars;
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, s, p);
@@ -405,10 +386,13 @@ static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, 
 // trailing update C -= P P^T (lower tiles) bracketed by a HIP-event pair when
 // the caller collects per-launch timings (bench.py's roofline block)
 static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long lda, const double *P,
-                       const double *Q, long long M, long long N, long long K) {
-  const bool timed = timers && timers->ev && timers->used + 2 <= timers->n_ev;
+                       const double *Q, long long M, long long N, long long K, bool bulk) {
+  // only the bulk trailing updates (their own kernel symbol) are event-timed:
+  // they run on the second stream, where an event gap is off the critical path
+  const bool timed = bulk && timers && timers->ev && timers->used + 2 <= timers->n_ev;
   if (timed) (void)hipEventRecord(timers->ev[timers->used], s);
-  launch_gemm_nt_sub(s, C, lda, P, lda, false, Q, lda, false, M, N, K, true);
+  if (bulk) launch_trailing_update(s, C, lda, P, Q, lda, M, K);
+  else launch_gemm_nt_sub(s, C, lda, P, lda, false, Q, lda, false, M, N, K, true);
   if (timed) {
     (void)hipEventRecord(timers->ev[timers->used + 1], s);
     // algorithmic flop: 2 K per C entry on or below the diagonal
@@ -428,22 +412,21 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
     const long long below = n - (k + nbk);
     if (below <= 0) continue;
     TrsmArgs t;
-    t.L = A + k * lda + k; t.ldl = lda;
-    t.invd = invd + (k / NB) * (long long)(NMB * MB * MB);
+    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
     t.nbk = nbk;
     t.Y = A + k * lda + (k + nbk);
     t.stride_m = lda; t.stride_n = 1;
     t.ncols = below;
     t.z = y ? y + k : nullptr;
     t.yrest = y ? y + k + nbk : nullptr;
-    t.batch_L = t.batch_invd = t.batch_Y = 0; t.n_total = 0;
+    t.batch_img = t.batch_Y = 0; t.n_total = 0;
     const unsigned grid = (unsigned)((below + 63) / 64);
     if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
     else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
     const long long width = kend - (k + nbk);
     if (width > 0) {
       const double *P = A + k * lda + (k + nbk);
-      timed_gemm(s, timers, A + (k + nbk) * lda + (k + nbk), lda, P, P, below, width, nbk);
+      timed_gemm(s, timers, A + (k + nbk) * lda + (k + nbk), lda, P, P, below, width, nbk, false);
     }
   }
 }
@@ -468,11 +451,11 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     (void)hipEventRecord(ctx->ev_a, sa);            // P(K0) done
     if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);  // U2(K0 - NBO) done
     // U1: block column [kend, next_end), all rows below its diagonal
-    timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K);
+    timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
     if (next_end < n) {
       (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       const double *Q = A + K0 * lda + next_end;
-      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K);
+      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true);
       (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;
     } else {
@@ -494,14 +477,13 @@ void forward_solve_mat(hipStream_t s, const double *A, long long n, long long ld
     for (long long k = K0; k < kend; k += NB) {
       const int nbk = (int)((n - k < NB) ? n - k : NB);
       TrsmArgs t;
-      t.L = A + k * lda + k; t.ldl = lda;
-      t.invd = invd + (k / NB) * (long long)(NMB * MB * MB);
+      t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
       t.nbk = nbk;
       t.Y = B + k;
       t.stride_m = 1; t.stride_n = ldb;
       t.ncols = m;
       t.z = nullptr; t.yrest = nullptr;
-      t.batch_L = t.batch_invd = t.batch_Y = 0; t.n_total = 0;
+      t.batch_img = t.batch_Y = 0; t.n_total = 0;
       hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, t);
       const long long rows = kend - (k + nbk);
       if (rows > 0)  // B[k+nbk : kend] -= L[k+nbk : kend, k : k+nbk] B[k : k+nbk]
@@ -522,14 +504,13 @@ void backward_solve_mat(hipStream_t s, const double *A, long long n, long long l
     const long long k = b * NB;
     const int nbk = (int)((n - k < NB) ? n - k : NB);
     TrsmArgs t;
-    t.L = A + k * lda + k; t.ldl = lda;
-    t.invd = invd + b * (long long)(NMB * MB * MB);
+    t.img = invd + b * (long long)IMG_DOUBLES;
     t.nbk = nbk;
     t.Y = B + k;
     t.stride_m = 1; t.stride_n = ldb;
     t.ncols = m;
     t.z = nullptr; t.yrest = nullptr;
-    t.batch_L = t.batch_invd = t.batch_Y = 0; t.n_total = 0;
+    t.batch_img = t.batch_Y = 0; t.n_total = 0;
     hipLaunchKernelGGL((trsm_micro_kernel<true, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, t);
     if (k > 0)  // B[0 : k] -= L[k : k+nbk, 0 : k]^T B[k : k+nbk]
       launch_gemm_nt_sub(s, B, ldb, A + k, lda, true, B + k, ldb, true, k, m, nbk, false);
@@ -561,10 +542,11 @@ void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long l
   const long long count = nblk * NB * NB;
   hipLaunchKernelGGL(set_identity_blocks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, Winv, count);
   TrsmArgs t;
-  t.L = A; t.ldl = lda; t.invd = invd; t.nbk = NB;
+  (void)A; (void)lda;
+  t.img = invd; t.nbk = NB;
   t.Y = Winv; t.stride_m = 1; t.stride_n = NB; t.ncols = NB;
   t.z = nullptr; t.yrest = nullptr;
-  t.batch_L = NB * (lda + 1); t.batch_invd = NMB * MB * MB; t.batch_Y = NB * NB; t.n_total = n;
+  t.batch_img = IMG_DOUBLES; t.batch_Y = NB * NB; t.n_total = n;
   hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
 }
 

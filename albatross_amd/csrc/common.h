@@ -67,7 +67,8 @@ struct agp_fit {
   int64_t n = 0;
   int64_t lda = 0;
   double *A = nullptr;      // n x n lower factor, column-major, ld = lda
-  double *invd = nullptr;   // (n/MB) inverted 16x16 diagonal micro blocks
+  double *invd = nullptr;   // tile image of every NB x NB diagonal block (72 KiB each):
+                            // negated off-diagonal micro tiles + inverted diagonal micro tiles
   double *winv = nullptr;   // (n/NB) inverted NB x NB diagonal blocks
   double *alpha = nullptr;  // information vector K^-1 y
   double *z = nullptr;      // L^-1 y
@@ -145,4 +146,7 @@ namespace agp {
 void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
                         bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
                         long long N, long long K, bool tri);
+// bulk trailing update of the factorisation: C(M x M, lower tiles) -= P Q^T
+void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
+                            long long ldp, long long M, long long K);
 }  // namespace agp

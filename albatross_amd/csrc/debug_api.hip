@@ -214,7 +214,7 @@ int agp_debug_factor(agp_context *ctx, double *A, int64_t n, int64_t lda, double
   const long long nblk = (n + NB - 1) / NB;
   double *dA = nullptr, *dI = nullptr, *dy = nullptr;
   AGP_HIP_CHECK(ctx, hipMalloc(&dA, ab));
-  AGP_HIP_CHECK(ctx, hipMalloc(&dI, sizeof(double) * (size_t)nblk * NMB * MB * MB));
+  AGP_HIP_CHECK(ctx, hipMalloc(&dI, sizeof(double) * (size_t)nblk * (36 * MB * MB)));
   AGP_HIP_CHECK(ctx, hipMemcpy(dA, A, ab, hipMemcpyHostToDevice));
   if (y) {
     AGP_HIP_CHECK(ctx, hipMalloc(&dy, sizeof(double) * (size_t)n));

@@ -107,9 +107,7 @@ __device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const doubl
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g) {
-  // one LDS array: [buffer][operand][k][row]
-  __shared__ double lds[2 * 2 * GK * GLD];
+__device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds) {
 
   // ---- which tile ----
   int bj = 0;
@@ -192,6 +190,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g
     }
 }
 
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g) {
+  // one LDS array: [buffer][operand][k][row]
+  __shared__ double lds[2 * 2 * GK * GLD];
+  gemm_nt_sub_body<A_KMAJOR, B_KMAJOR>(g, lds);
+}
+
+// The bulk trailing update of the factorisation (C -= P P^T, lower tiles, K =
+// NBO) under its own kernel symbol, so that profiles and bench.py's roofline
+// block isolate exactly these launches.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmArgs g) {
+  __shared__ double lds[2 * 2 * GK * GLD];
+  gemm_nt_sub_body<false, false>(g, lds);
+}
+
 static long long count_tiles(int ntr, int ntc, int tri) {
   long long total = 0;
   for (int bj = 0; bj < ntc; ++bj) total += tri ? (ntr - bj > 0 ? ntr - bj : 0) : ntr;
@@ -216,6 +229,18 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
   else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<false, true>), grid, block, 0, s, g);
   else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<true, false>), grid, block, 0, s, g);
   else hipLaunchKernelGGL((gemm_nt_sub_kernel<true, true>), grid, block, 0, s, g);
+}
+
+void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
+                            long long ldp, long long M, long long K) {
+  if (M <= 0 || K <= 0) return;
+  GemmArgs g;
+  g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = Q; g.ldb = ldp;
+  g.M = M; g.N = M; g.K = K; g.tri = 1;
+  g.ntr = (int)((M + GT - 1) / GT);
+  g.ntc = g.ntr;
+  const long long tiles = count_tiles(g.ntr, g.ntc, 1);
+  hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
 }
 
 // ---- bare MFMA issue loop: measured fp64 matrix peak of this device ----------

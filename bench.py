@@ -170,7 +170,7 @@ def main():
                                    "inputs resident in HBM (BASELINE config 3 problem)",
                        "parallelism": "1 fit per GPU" if world > 1 else "1 GPU"},
             "roofline": {
-                "bound": "mfma", "kernel": "gemm_nt_sub_kernel<false,false> (fp64 MFMA trailing update)",
+                "bound": "mfma", "kernel": "agp::trailing_update_kernel (fp64 MFMA bulk trailing update C -= P P^T, K=512)",
                 "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F64_PEAK_TFLOPS,
                 "traffic": None,
