@@ -133,6 +133,7 @@ void agp_context_destroy(agp_context *c) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->partial_ws) (void)hipFree(ctx->partial_ws);
   if (ctx->ws_A) (void)hipFree(ctx->ws_A);
+  if (ctx->pool_A) (void)hipFree(ctx->pool_A);
   if (ctx->ws_aux) (void)hipFree(ctx->ws_aux);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -430,7 +431,17 @@ int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x, const
 void agp_fit_destroy(agp_fit *fit) {
   if (!fit) return;
   (void)hipSetDevice(fit->device);
-  if (fit->A) (void)hipFree(fit->A);
+  if (fit->A) {
+    agp_context *ctx = fit->ctx;
+    if (ctx && !ctx->pool_A) {
+      // kernels reading the factor were enqueued on the context's streams; the
+      // next user of the buffer is enqueued on the same streams, after them
+      ctx->pool_A = fit->A;
+      ctx->pool_A_bytes = fit->A_bytes;
+    } else {
+      (void)hipFree(fit->A);
+    }
+  }
   if (fit->invd) (void)hipFree(fit->invd);
   if (fit->winv) (void)hipFree(fit->winv);
   if (fit->alpha) (void)hipFree(fit->alpha);
@@ -473,7 +484,15 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   // train_features = features (un-wrapped; gp.hpp:63,293): always an owned copy
   if ((st = to_device(ctx, x, true, &fit->train)) != AGP_OK) { agp_fit_destroy(fit); return st; }
   fit->train.v.meas = 0;
-  FIT_CHECK(hipMalloc(&fit->A, sizeof(double) * (size_t)fit->lda * (size_t)n));
+  fit->ctx = ctx;
+  fit->A_bytes = sizeof(double) * (size_t)fit->lda * (size_t)n;
+  if (ctx->pool_A && ctx->pool_A_bytes == fit->A_bytes) {
+    fit->A = ctx->pool_A;
+    ctx->pool_A = nullptr;
+    ctx->pool_A_bytes = 0;
+  } else {
+    FIT_CHECK(hipMalloc(&fit->A, fit->A_bytes));
+  }
   FIT_CHECK(hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * (36 * MB * MB)));
   FIT_CHECK(hipMalloc(&fit->winv, sizeof(double) * (size_t)nblk * NB * NB));
   FIT_CHECK(hipMalloc(&fit->alpha, sizeof(double) * (size_t)n));

@@ -16,6 +16,7 @@
 //                           micro columns are reused directly as MFMA operands
 //       gemm_nt_sub (K=128) update of the rest of the outer block column
 //     gemm_nt_sub (K=512)   trailing update  (the MFMA-bound bulk, gemm.hip)
+#include <cstdlib>
 #include "common.h"
 #include "mfma_f64.h"
 
@@ -431,25 +432,53 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
   }
 }
 
+// Outer block width as a function of the remaining (trailing) size.  Wide
+// blocks (K = 512) keep the bulk update's C traffic off the HBM roofline while
+// the trailing matrix is far larger than the 256 MiB Infinity Cache; once it is
+// not, narrow blocks take the inner-update launches out of the serial panel
+// chain, which is what bounds the late phase.  Tunable for experiments through
+// AGP_NBO_SWITCH="m512,m256" (remaining size above which 512 / 256 is used).
+static void nbo_thresholds(long long *m512, long long *m256) {
+  static long long t512 = -1, t256 = -1;
+  if (t512 < 0) {
+    t512 = 10240; t256 = 6144;
+    if (const char *e = getenv("AGP_NBO_SWITCH")) {
+      long long a = 0, b = 0;
+      if (sscanf(e, "%lld,%lld", &a, &b) == 2) { t512 = a; t256 = b; }
+    }
+  }
+  *m512 = t512; *m256 = t256;
+}
+
+static long long pick_nbo(long long remaining) {
+  long long m512, m256;
+  nbo_thresholds(&m512, &m256);
+  if (remaining > m512) return 512;
+  if (remaining > m256) return 256;
+  return NB;
+}
+
 // Right-looking LL^T with one outer block of look-ahead on two streams:
-//   stream  (high priority): panel phase P(K0), then U1(K0) = update of the
-//            NEXT outer block column, then P(K0 + NBO) ...
-//   stream2: U2(K0) = update of everything right of the next block column
-//            (the MFMA-bound bulk), overlapping P(K0 + NBO).
-// Dependencies: U1(K0), U2(K0) after P(K0) and after U2(K0 - NBO).
+//   stream  (high priority): panel phase P(j), then U1(j) = update of the
+//            NEXT outer block column, then P(j + 1) ...
+//   stream2: U2(j) = update of everything right of the next block column
+//            (the MFMA-bound bulk), overlapping P(j + 1).
+// Dependencies: U1(j), U2(j) after P(j) and after U2(j - 1).
 void factor_lower(agp_context *ctx, double *A, long long n, long long lda, double *invd, double *y,
                   FactorTimers *timers) {
   hipStream_t sa = ctx->stream, sb = ctx->stream2;
   bool have_u2 = false;
-  panel_phase(ctx, sa, A, n, lda, invd, y, 0, (NBO < n) ? NBO : n, timers);
-  for (long long K0 = 0; K0 < n; K0 += NBO) {
-    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
-    if (kend >= n) break;
-    const long long next_end = (kend + NBO < n) ? kend + NBO : n;
+  long long K0 = 0;
+  long long kend = K0 + pick_nbo(n);
+  if (kend > n) kend = n;
+  panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers);
+  while (kend < n) {
+    long long next_end = kend + pick_nbo(n - kend);
+    if (next_end > n) next_end = n;
     const long long K = kend - K0;
     const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
-    (void)hipEventRecord(ctx->ev_a, sa);            // P(K0) done
-    if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);  // U2(K0 - NBO) done
+    (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
+    if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);   // U2(j - 1) done
     // U1: block column [kend, next_end), all rows below its diagonal
     timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
     if (next_end < n) {
@@ -462,6 +491,8 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
       have_u2 = false;
     }
     panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers);
+    K0 = kend;
+    kend = next_end;
   }
   // the panel stream ran last (its final panel depends on every update)
 }

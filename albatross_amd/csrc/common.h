@@ -60,9 +60,15 @@ struct agp_context {
   size_t ws_A_bytes = 0;
   double *ws_aux = nullptr;
   size_t ws_aux_bytes = 0;
+  // one cached factor allocation (agp_fit_destroy parks its N x N buffer here;
+  // the next agp_fit_create of the same size takes it instead of hipMalloc)
+  double *pool_A = nullptr;
+  size_t pool_A_bytes = 0;
 };
 
 struct agp_fit {
+  agp_context *ctx = nullptr;  // owner; a fit must not outlive its context
+  size_t A_bytes = 0;
   int device = 0;
   int64_t n = 0;
   int64_t lda = 0;

@@ -147,6 +147,8 @@ int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x,
  * y, y_var (may be NULL = zeros) live at x->location; the factor stays on the
  * device inside *out.  information (n doubles, host) and log_det (host) may be
  * NULL.  The training features are copied into the fit (gp.hpp:63). */
+/* A fit belongs to the context that created it and must be destroyed before
+ * that context. */
 int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x,
                    const double *y, const double *y_var, agp_fit **out,
                    double *information, double *log_det);
