@@ -441,7 +441,7 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
 static void nbo_thresholds(long long *m512, long long *m256) {
   static long long t512 = -1, t256 = -1;
   if (t512 < 0) {
-    t512 = 10240; t256 = 6144;
+    t512 = 8192; t256 = 4096;
     if (const char *e = getenv("AGP_NBO_SWITCH")) {
       long long a = 0, b = 0;
       if (sscanf(e, "%lld,%lld", &a, &b) == 2) { t512 = a; t256 = b; }

@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=N_TRAIN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-predict", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -150,6 +151,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- secondary: predict points/sec at M = 4096 against one resident fit ----
+    predict = None
+    if rank == 0 and not args.no_predict:
+        m = 4096
+        xs_h, _ = make_dataset(m, 43)
+        xs_d = torch.from_numpy(xs_h).to(f"cuda:{local_rank}")
+        out_d = torch.empty(2 * m, dtype=torch.float64, device=f"cuda:{local_rank}")
+        fx = capi.Features()
+        fx.n, fx.dim, fx.n_scale_columns = m, DIM, 0
+        fx.coords = xs_d.data_ptr()
+        fx.eq_id = None
+        fx.scales = None
+        fx.is_measurement = 0
+        fx.location = capi.DEVICE
+        h = C.c_void_p()
+        st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+        assert st == capi.AGP_OK
+        mean_p, var_p = C.c_void_p(out_d.data_ptr()), C.c_void_p(out_d.data_ptr() + 8 * m)
+
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps
+
+        t_mean = timed(lambda: lib.agp_predict_mean(ctx._h, kh, h, C.byref(fx), mean_p, capi.DEVICE), 5)
+        t_marg = timed(lambda: lib.agp_predict_marginal(ctx._h, kh, h, C.byref(fx), mean_p, var_p, capi.DEVICE), 3)
+        lib.agp_fit_destroy(h)
+        predict = {"m": m, "mean_pts_per_sec": m / t_mean, "marginal_pts_per_sec": m / t_marg,
+                   "mean_ms": 1e3 * t_mean, "marginal_ms": 1e3 * t_marg}
+
     if rank == 0:
         fits = args.steps * world  # every rank fits its own dataset (replicas; DESIGN.md "multi-GPU")
         achieved = (gemm_flop / 1e12) / (gemm_ms * 1e-3) if gemm_ms > 0 else 0.0
@@ -182,6 +217,8 @@ def main():
                                   "backward_solve": solve_ms / args.steps,
                                   "trailing_update_kernels": gemm_ms / args.steps},
         }
+        if predict is not None:
+            out["predict"] = predict
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
