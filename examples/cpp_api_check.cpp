@@ -1,0 +1,94 @@
+// cpp_api_check.cpp — exercises the C++ drop-in surface the way the reference's
+// tests do (tests/test_covariance_functions.cc:33-93, tests/test_gp.cc,
+// tests/lib/albatross/test/test_models.h): 3-D features, scaling terms,
+// parameter get/set, fit / predict variants / solve.  Prints "key,value" lines
+// that tests/test_cpp_host_gpu.py checks against the oracle.
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include <albatross_amd/albatross.hpp>
+
+using namespace albatross;
+using P3 = std::array<double, 3>;
+
+struct Elevation {  // a ScalingFunction, cf. examples/temperature_example/temperature_example_utils.h:60-90
+  double center = 4.0, factor = 0.3;
+  std::string get_name() const { return "elevation_scaling"; }
+  ParameterStore get_params() const { return {{"elevation_scaling_center", center}, {"elevation_scaling_factor", factor}}; }
+  void set_param(const std::string &n, double v) { (n == "elevation_scaling_center" ? center : factor) = v; }
+  double _call_impl(const P3 &x) const { return 1. + factor * std::fmax(center - x[2], 0.); }
+};
+
+int main() {
+  // --- measurement / noise algebra (exact) ---
+  SquaredExponential<EuclideanDistance> radial;
+  IndependentNoise<double> noise;
+  auto meas_noise = measurement_only(noise);
+  auto sum = radial + meas_noise;
+  auto prod = meas_noise * radial;
+  const double f = 0.;
+  const Measurement<double> m(f);
+  std::printf("algebra_meas_ff,%.17g\n", meas_noise.call(f, f));
+  std::printf("algebra_meas_mm,%.17g\n", meas_noise.call(m, m));
+  std::printf("algebra_meas_mf,%.17g\n", meas_noise.call(m, f));
+  std::printf("algebra_sum_mm_minus_parts,%.17g\n", sum.call(m, m) - (radial.call(m, m) + meas_noise.call(m, m)));
+  std::printf("algebra_prod_ff,%.17g\n", prod.call(f, f));
+  std::printf("algebra_prod_mm_minus_parts,%.17g\n", prod.call(m, m) - radial.call(m, m) * meas_noise.call(m, m));
+
+  // --- 3-D Matern + scaling term model, seeded data ---
+  std::mt19937 gen(42);
+  std::uniform_real_distribution<double> u(0., 10.);
+  const int n = 400, ms = 50;
+  std::vector<P3> x(n), xs(ms);
+  Vector y(n);
+  for (int i = 0; i < n; ++i) {
+    x[i] = {u(gen), u(gen), u(gen)};
+    y[i] = std::sin(x[i][0]) + std::sin(x[i][1]) + std::sin(x[i][2]) + 0.1 * std::cos(10. * x[i][0]);
+  }
+  for (int i = 0; i < ms; ++i) xs[i] = {u(gen), u(gen), u(gen)};
+  auto cov = ScalingTerm<Elevation>() * Constant(0.5) + Matern52<EuclideanDistance>(2.0, 1.0) + IndependentNoise<P3>(0.1);
+  auto model = gp_from_covariance(cov, "cpp_check");
+  std::printf("name,%s\n", cov.get_name().c_str());
+  model.set_param("sigma_constant", 0.7);
+  for (const auto &kv : model.get_params()) std::printf("param_%s,%.17g\n", kv.first.c_str(), kv.second);
+  RegressionDataset<P3> data(x, y);
+  const auto fm = model.fit(data);
+  std::printf("loglik,%.17g\n", model.log_likelihood(data));
+  std::printf("logdet,%.17g\n", fm.get_fit().log_determinant);
+  for (int i = 0; i < n; ++i) std::printf("x,%d,%.17g,%.17g,%.17g,%.17g\n", i, x[i][0], x[i][1], x[i][2], y[i]);
+  for (int i = 0; i < ms; ++i) std::printf("xs,%d,%.17g,%.17g,%.17g\n", i, xs[i][0], xs[i][1], xs[i][2]);
+  for (int i = 0; i < n; ++i) std::printf("info,%d,%.17g\n", i, fm.get_fit().information[i]);
+  const auto pred = fm.predict(xs);
+  const auto mean = pred.mean();
+  const auto marg = pred.marginal();
+  const auto joint = pred.joint();
+  for (int i = 0; i < ms; ++i)
+    std::printf("pred,%d,%.17g,%.17g,%.17g,%.17g\n", i, mean[i], marg.mean[i], marg.covariance[i], joint.covariance(i, i));
+  double asym = 0.;
+  for (int i = 0; i < ms; ++i)
+    for (int j = 0; j < ms; ++j) asym = std::fmax(asym, std::fabs(joint.covariance(i, j) - joint.covariance(j, i)));
+  std::printf("joint_asymmetry,%.17g\n", asym);
+  // CovarianceRepresentation::solve round trip: K (K^-1 e_0) = e_0
+  Matrix rhs(n, 1);
+  rhs(0, 0) = 1.;
+  const Matrix sol = fm.get_fit().solve(rhs);
+  const Matrix K = cov(as_measurements(x));
+  double resid = 0.;
+  for (int i = 0; i < n; ++i) {
+    double s = 0.;
+    for (int j = 0; j < n; ++j) s += K(i, j) * sol(j, 0);
+    resid = std::fmax(resid, std::fabs(s - (i == 0 ? 1. : 0.)));
+  }
+  std::printf("solve_residual,%.17g\n", resid);
+  // a singular covariance is reported, not silently factored
+  try {
+    std::vector<double> dup = {0., 0., 1.};
+    gp_from_covariance(SquaredExponential<EuclideanDistance>(1., 1.)).fit(RegressionDataset<double>(dup, Vector{0., 0., 0.}));
+    std::printf("singular,not_reported\n");
+  } catch (const std::runtime_error &e) {
+    std::printf("singular,%s\n", e.what());
+  }
+  return 0;
+}

@@ -1,0 +1,761 @@
+// albatross.hpp — C++ host-side mirror of albatross's dense-GP call surface
+// over the C-ABI of the MI355X engine (include/albatross_amd.h).
+//
+//   #include <albatross_amd/albatross.hpp>     // instead of <albatross/GP>
+//   using namespace albatross;
+//   auto cov = SquaredExponential<EuclideanDistance>(3.5, 5.7) +
+//              measurement_only(IndependentNoise<double>(1.0));
+//   auto model = gp_from_covariance(cov);
+//   auto fit_model = model.fit(dataset);                 // RegressionDataset<double>
+//   auto pred = fit_model.predict(xs).marginal();        // .mean() / .joint()
+//   double ll = model.log_likelihood(dataset);
+//
+// Same names, argument meaning and composition rules as the reference
+// (include/albatross/src/...): covariance_functions/*.hpp, models/gp.hpp:170-537,
+// core/model.hpp, core/fit_model.hpp, core/prediction.hpp, core/dataset.hpp,
+// core/distribution.hpp.  Every Gram / factor / solve / predict is executed by
+// the HIP library; nothing here computes on the CPU.  The reference's Eigen
+// containers are replaced by the minimal column-major `Vector` / `Matrix`
+// below (Eigen is not a dependency of this engine).
+#ifndef ALBATROSS_AMD_ALBATROSS_HPP
+#define ALBATROSS_AMD_ALBATROSS_HPP
+
+#include <array>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../albatross_amd.h"
+
+namespace albatross {
+
+// ---------------------------------------------------------------------------
+// containers
+// ---------------------------------------------------------------------------
+using Vector = std::vector<double>;
+
+struct Matrix {  // column-major, like Eigen::MatrixXd
+  std::int64_t rows_ = 0, cols_ = 0;
+  std::vector<double> data;
+  Matrix() = default;
+  Matrix(std::int64_t r, std::int64_t c) : rows_(r), cols_(c), data(static_cast<std::size_t>(r * c), 0.) {}
+  std::int64_t rows() const { return rows_; }
+  std::int64_t cols() const { return cols_; }
+  double &operator()(std::int64_t i, std::int64_t j) { return data[static_cast<std::size_t>(i + j * rows_)]; }
+  double operator()(std::int64_t i, std::int64_t j) const { return data[static_cast<std::size_t>(i + j * rows_)]; }
+  Vector diagonal() const {
+    Vector d(static_cast<std::size_t>(rows_ < cols_ ? rows_ : cols_));
+    for (std::size_t i = 0; i < d.size(); ++i) d[i] = (*this)(static_cast<std::int64_t>(i), static_cast<std::int64_t>(i));
+    return d;
+  }
+};
+
+// core/distribution.hpp
+struct MarginalDistribution {
+  Vector mean;
+  Vector covariance;  // diagonal; empty = no target variance
+  MarginalDistribution() = default;
+  explicit MarginalDistribution(Vector mean_) : mean(std::move(mean_)) {}
+  MarginalDistribution(Vector mean_, Vector diag) : mean(std::move(mean_)), covariance(std::move(diag)) {}
+  std::size_t size() const { return mean.size(); }
+};
+
+struct JointDistribution {
+  Vector mean;
+  Matrix covariance;
+  std::size_t size() const { return mean.size(); }
+  MarginalDistribution marginal() const { return MarginalDistribution(mean, covariance.diagonal()); }
+};
+
+// core/dataset.hpp
+template <typename FeatureType>
+struct RegressionDataset {
+  std::vector<FeatureType> features;
+  MarginalDistribution targets;
+  RegressionDataset() = default;
+  RegressionDataset(std::vector<FeatureType> f, MarginalDistribution t) : features(std::move(f)), targets(std::move(t)) {}
+  RegressionDataset(std::vector<FeatureType> f, Vector t) : features(std::move(f)), targets(std::move(t)) {}
+  std::size_t size() const { return features.size(); }
+};
+
+// measurement.hpp:18-53
+template <typename X>
+struct Measurement {
+  X value;
+  Measurement() : value() {}
+  Measurement(const X &x) : value(x) {}
+};
+
+template <typename X>
+std::vector<Measurement<X>> as_measurements(const std::vector<X> &features) {
+  return std::vector<Measurement<X>>(features.begin(), features.end());
+}
+
+// ---------------------------------------------------------------------------
+// feature flattening: how a feature type becomes the POD record of the C-ABI.
+// Specialise FeatureTraits<X> for user types (coords, optional equality id).
+// ---------------------------------------------------------------------------
+template <typename X, typename Enable = void>
+struct FeatureTraits;
+
+template <>
+struct FeatureTraits<double> {
+  static constexpr int dim = 1;
+  static constexpr bool has_eq_id = false;
+  static void coords(const double &x, double *out) { out[0] = x; }
+  static std::int64_t eq_id(const double &) { return 0; }
+};
+
+template <std::size_t N>
+struct FeatureTraits<std::array<double, N>> {
+  static_assert(N >= 1 && N <= AGP_MAX_DIM, "feature dimension must be 1..AGP_MAX_DIM");
+  static constexpr int dim = static_cast<int>(N);
+  static constexpr bool has_eq_id = false;
+  static void coords(const std::array<double, N> &x, double *out) {
+    for (std::size_t d = 0; d < N; ++d) out[d] = x[d];
+  }
+  static std::int64_t eq_id(const std::array<double, N> &) { return 0; }
+};
+
+namespace detail {
+
+inline void check(int status, agp_context *ctx, const char *what) {
+  if (status == AGP_OK) return;
+  std::string msg = std::string("albatross_amd: ") + what + ": " + agp_status_string(status);
+  if (status == AGP_ERR_HIP && ctx) msg += std::string(" (") + agp_last_error(ctx) + ")";
+  throw std::runtime_error(msg);
+}
+
+struct ContextHolder {
+  agp_context *ctx = nullptr;
+  explicit ContextHolder(int device) { check(agp_context_create(device, &ctx), nullptr, "agp_context_create"); }
+  ~ContextHolder() { agp_context_destroy(ctx); }
+  ContextHolder(const ContextHolder &) = delete;
+  ContextHolder &operator=(const ContextHolder &) = delete;
+};
+
+inline std::shared_ptr<ContextHolder> default_context() {
+  static std::shared_ptr<ContextHolder> c = std::make_shared<ContextHolder>(0);
+  return c;
+}
+
+struct KernelHolder {
+  agp_kernel *k = nullptr;
+  explicit KernelHolder(const std::vector<agp_kernel_node> &nodes) {
+    check(agp_kernel_create(nodes.data(), static_cast<int>(nodes.size()), &k), nullptr, "agp_kernel_create");
+  }
+  ~KernelHolder() { agp_kernel_destroy(k); }
+  KernelHolder(const KernelHolder &) = delete;
+  KernelHolder &operator=(const KernelHolder &) = delete;
+};
+
+template <typename X>
+struct unwrap {
+  using type = X;
+  static constexpr bool is_measurement = false;
+  static const X &get(const X &x) { return x; }
+};
+template <typename X>
+struct unwrap<Measurement<X>> {
+  using type = X;
+  static constexpr bool is_measurement = true;
+  static const X &get(const Measurement<X> &m) { return m.value; }
+};
+
+// flattened feature vector + the agp_features view over it
+struct Flat {
+  std::vector<double> coords, scales;
+  std::vector<std::int64_t> ids;
+  agp_features view{};
+};
+
+template <typename Cov, typename F>
+Flat flatten(const Cov &cov, const std::vector<F> &features, bool force_measurement = false) {
+  using U = unwrap<F>;
+  using X = typename U::type;
+  using T = FeatureTraits<X>;
+  Flat f;
+  const std::size_t n = features.size();
+  f.coords.resize(n * T::dim);
+  const int ncol = cov.n_scale_columns();
+  f.scales.resize(n * static_cast<std::size_t>(ncol));
+  if (T::has_eq_id) f.ids.resize(n);
+  std::vector<double> tmp(static_cast<std::size_t>(ncol));
+  for (std::size_t i = 0; i < n; ++i) {
+    const X &x = U::get(features[i]);
+    T::coords(x, f.coords.data() + i * T::dim);
+    if (T::has_eq_id) f.ids[i] = T::eq_id(x);
+    if (ncol > 0) {
+      int col = 0;
+      cov.template fill_scales<X>(x, tmp.data(), col);
+      for (int c = 0; c < ncol; ++c) f.scales[static_cast<std::size_t>(c) * n + i] = tmp[static_cast<std::size_t>(c)];
+    }
+  }
+  f.view.n = static_cast<std::int64_t>(n);
+  f.view.dim = T::dim;
+  f.view.n_scale_columns = ncol;
+  f.view.coords = f.coords.data();
+  f.view.eq_id = T::has_eq_id ? f.ids.data() : nullptr;
+  f.view.scales = ncol > 0 ? f.scales.data() : nullptr;
+  f.view.is_measurement = (U::is_measurement || force_measurement) ? 1 : 0;
+  f.view.location = AGP_HOST;
+  return f;
+}
+
+inline agp_kernel_node node(int op, int metric = 0, int column = 0, int order = 0, double p0 = 0., double p1 = 0.,
+                            double p2 = 0., double p3 = 0.) {
+  agp_kernel_node nd{};
+  nd.op = op; nd.metric = metric; nd.column = column; nd.order = order;
+  nd.params[0] = p0; nd.params[1] = p1; nd.params[2] = p2; nd.params[3] = p3;
+  return nd;
+}
+
+}  // namespace detail
+
+using ParameterStore = std::map<std::string, double>;
+
+// ---------------------------------------------------------------------------
+// distance metrics (distance_metrics.hpp:30-90): tags; the math runs on device
+// ---------------------------------------------------------------------------
+struct EuclideanDistance {
+  static constexpr int metric = AGP_METRIC_EUCLIDEAN;
+  std::string get_name() const { return "euclidean_distance"; }
+};
+struct RadialDistance {
+  static constexpr int metric = AGP_METRIC_RADIAL;
+  std::string get_name() const { return "radial_distance"; }
+};
+struct AngularDistance {
+  static constexpr int metric = AGP_METRIC_ANGULAR;
+  std::string get_name() const { return "angular_distance"; }
+};
+
+template <class LHS, class RHS> class SumOfCovarianceFunctions;
+template <class LHS, class RHS> class ProductOfCovarianceFunctions;
+
+// ---------------------------------------------------------------------------
+// CovarianceFunction CRTP base (covariance_function.hpp:63-217)
+// ---------------------------------------------------------------------------
+template <typename Derived>
+class CovarianceFunction {
+ public:
+  const Derived &derived() const { return *static_cast<const Derived *>(this); }
+  Derived &derived() { return *static_cast<Derived *>(this); }
+
+  std::string get_name() const { return derived().name(); }
+
+  std::vector<agp_kernel_node> program() const {
+    std::vector<agp_kernel_node> nodes;
+    int column = 0;
+    derived().emit(nodes, column);
+    return nodes;
+  }
+
+  int n_scale_columns() const {
+    std::vector<agp_kernel_node> nodes;
+    int column = 0;
+    derived().emit(nodes, column);
+    return column;
+  }
+
+  void set_param_values(const ParameterStore &values) {
+    for (const auto &kv : values) derived().set_param(kv.first, kv.second);
+  }
+  double get_param_value(const std::string &name) const { return derived().get_params().at(name); }
+
+  // cov(xs): symmetric Gram, callers.hpp:107-166
+  template <typename F>
+  Matrix operator()(const std::vector<F> &xs) const {
+    auto ctx = detail::default_context();
+    detail::KernelHolder k(program());
+    detail::Flat fx = detail::flatten(derived(), xs);
+    Matrix out(fx.view.n, fx.view.n);
+    if (fx.view.n > 0)
+      detail::check(agp_gram(ctx->ctx, k.k, &fx.view, nullptr, out.data.data(), fx.view.n, AGP_HOST), ctx->ctx, "agp_gram");
+    return out;
+  }
+
+  // cov(xs, ys): cross Gram, callers.hpp:38-102
+  template <typename F, typename G>
+  Matrix operator()(const std::vector<F> &xs, const std::vector<G> &ys) const {
+    auto ctx = detail::default_context();
+    detail::KernelHolder k(program());
+    detail::Flat fx = detail::flatten(derived(), xs), fy = detail::flatten(derived(), ys);
+    Matrix out(fx.view.n, fy.view.n);
+    if (fx.view.n > 0 && fy.view.n > 0)
+      detail::check(agp_gram(ctx->ctx, k.k, &fx.view, &fy.view, out.data.data(), fx.view.n, AGP_HOST), ctx->ctx, "agp_gram");
+    return out;
+  }
+
+  // cov(x, y) for two single features (CovarianceFunction::call)
+  template <typename F, typename G>
+  double call(const F &x, const G &y) const {
+    return (*this)(std::vector<F>{x}, std::vector<G>{y})(0, 0);
+  }
+
+  template <typename Other>
+  SumOfCovarianceFunctions<Derived, Other> operator+(const CovarianceFunction<Other> &other) const {
+    return SumOfCovarianceFunctions<Derived, Other>(derived(), other.derived());
+  }
+  template <typename Other>
+  ProductOfCovarianceFunctions<Derived, Other> operator*(const CovarianceFunction<Other> &other) const {
+    return ProductOfCovarianceFunctions<Derived, Other>(derived(), other.derived());
+  }
+};
+
+constexpr double default_length_scale = 100000.;  // radial.hpp:16
+constexpr double default_radial_sigma = 10.;      // radial.hpp:17
+
+#define ALBATROSS_AMD_RADIAL(ClassName, OP, LS_NAME, SIGMA_NAME, PRETTY)                                   \
+  template <class DistanceMetricType>                                                                      \
+  class ClassName : public CovarianceFunction<ClassName<DistanceMetricType>> {                             \
+   public:                                                                                                 \
+    ClassName(double length_scale_ = default_length_scale, double sigma_ = default_radial_sigma)           \
+        : length_scale(length_scale_), sigma(sigma_) {}                                                    \
+    std::string name() const { return std::string(PRETTY "[") + distance_metric_.get_name() + "]"; }        \
+    ParameterStore get_params() const { return {{LS_NAME, length_scale}, {SIGMA_NAME, sigma}}; }            \
+    bool has_param(const std::string &n) const { return n == LS_NAME || n == SIGMA_NAME; }                  \
+    void set_param(const std::string &n, double v) {                                                       \
+      if (n == LS_NAME) length_scale = v;                                                                  \
+      else if (n == SIGMA_NAME) sigma = v;                                                                 \
+      else throw std::out_of_range("unknown parameter " + n);                                              \
+    }                                                                                                      \
+    void emit(std::vector<agp_kernel_node> &nodes, int &) const {                                          \
+      nodes.push_back(detail::node(OP, DistanceMetricType::metric, 0, 0, length_scale, sigma));            \
+    }                                                                                                      \
+    template <typename X> void fill_scales(const X &, double *, int &) const {}                           \
+    double length_scale, sigma;                                                                            \
+    DistanceMetricType distance_metric_;                                                                   \
+  };
+
+// radial.hpp:131-189, 239-287, 421-459, 491-529
+ALBATROSS_AMD_RADIAL(SquaredExponential, AGP_OP_SQUARED_EXPONENTIAL, "squared_exponential_length_scale",
+                     "sigma_squared_exponential", "squared_exponential")
+ALBATROSS_AMD_RADIAL(Exponential, AGP_OP_EXPONENTIAL, "exponential_length_scale", "sigma_exponential", "exponential")
+ALBATROSS_AMD_RADIAL(Matern32, AGP_OP_MATERN32, "matern_32_length_scale", "sigma_matern_32", "matern_32")
+ALBATROSS_AMD_RADIAL(Matern52, AGP_OP_MATERN52, "matern_52_length_scale", "sigma_matern_52", "matern_52")
+#undef ALBATROSS_AMD_RADIAL
+
+// The SquaredExponential is not PSD under a great-circle distance (radial.hpp:138-141)
+template <>
+class SquaredExponential<AngularDistance>;
+
+#define ALBATROSS_AMD_ONE_PARAM(ClassDecl, ClassName, OP, PNAME, DEFAULT, PRETTY)                         \
+  ClassDecl class ClassName : public CovarianceFunction<ClassName> {                                      \
+   public:                                                                                                \
+    explicit ClassName(double v = DEFAULT) : value(v) {}                                                  \
+    std::string name() const { return PRETTY; }                                                           \
+    ParameterStore get_params() const { return {{PNAME, value}}; }                                        \
+    bool has_param(const std::string &n) const { return n == PNAME; }                                     \
+    void set_param(const std::string &n, double v) {                                                      \
+      if (n != PNAME) throw std::out_of_range("unknown parameter " + n);                                  \
+      value = v;                                                                                          \
+    }                                                                                                     \
+    void emit(std::vector<agp_kernel_node> &nodes, int &) const { nodes.push_back(detail::node(OP, 0, 0, 0, value)); } \
+    template <typename X> void fill_scales(const X &, double *, int &) const {}                          \
+    double value;                                                                                         \
+  };
+
+// polynomials.hpp:31-61, nugget.hpp:32-49
+ALBATROSS_AMD_ONE_PARAM(, Constant, AGP_OP_CONSTANT, "sigma_constant", 10., "constant")
+ALBATROSS_AMD_ONE_PARAM(, Nugget, AGP_OP_NUGGET, "nugget_sigma", 1e-8, "nugget")
+#undef ALBATROSS_AMD_ONE_PARAM
+
+// noise.hpp:20-44
+template <typename Observed>
+class IndependentNoise : public CovarianceFunction<IndependentNoise<Observed>> {
+ public:
+  explicit IndependentNoise(double sigma_noise = 0.1) : sigma_independent_noise(sigma_noise) {}
+  std::string name() const { return "independent_noise"; }
+  ParameterStore get_params() const { return {{"sigma_independent_noise", sigma_independent_noise}}; }
+  bool has_param(const std::string &n) const { return n == "sigma_independent_noise"; }
+  void set_param(const std::string &n, double v) {
+    if (!has_param(n)) throw std::out_of_range("unknown parameter " + n);
+    sigma_independent_noise = v;
+  }
+  void emit(std::vector<agp_kernel_node> &nodes, int &) const {
+    nodes.push_back(detail::node(AGP_OP_INDEPENDENT_NOISE, 0, 0, 0, sigma_independent_noise));
+  }
+  template <typename X> void fill_scales(const X &, double *, int &) const {}
+  double sigma_independent_noise;
+};
+
+// polynomials.hpp:63-90 (1-D features)
+template <int order>
+class Polynomial : public CovarianceFunction<Polynomial<order>> {
+  static_assert(order >= 0 && order <= 3, "device path supports Polynomial<order> for order <= 3");
+
+ public:
+  explicit Polynomial(double sigma = 10.) { sigmas.fill(sigma); }
+  std::string name() const { return "polynomial_" + std::to_string(order); }
+  ParameterStore get_params() const {
+    ParameterStore p;
+    for (int i = 0; i <= order; ++i) p["sigma_polynomial_" + std::to_string(i)] = sigmas[static_cast<std::size_t>(i)];
+    return p;
+  }
+  bool has_param(const std::string &n) const { return get_params().count(n) > 0; }
+  void set_param(const std::string &n, double v) {
+    for (int i = 0; i <= order; ++i)
+      if (n == "sigma_polynomial_" + std::to_string(i)) { sigmas[static_cast<std::size_t>(i)] = v; return; }
+    throw std::out_of_range("unknown parameter " + n);
+  }
+  void emit(std::vector<agp_kernel_node> &nodes, int &) const {
+    nodes.push_back(detail::node(AGP_OP_POLYNOMIAL, 0, 0, order, sigmas[0], sigmas[1], sigmas[2], sigmas[3]));
+  }
+  template <typename X> void fill_scales(const X &, double *, int &) const {}
+  std::array<double, 4> sigmas{};
+};
+
+// scaling_function.hpp:58-112: cov(x, y) = f(x) f(y).  ScalingFunction needs
+//   double _call_impl(const X &) const;  std::string get_name() const;
+//   ParameterStore get_params() const;   void set_param(name, value);
+template <typename ScalingFunction>
+class ScalingTerm : public CovarianceFunction<ScalingTerm<ScalingFunction>> {
+ public:
+  ScalingTerm() = default;
+  explicit ScalingTerm(const ScalingFunction &f) : scaling_function_(f) {}
+  std::string name() const { return scaling_function_.get_name(); }
+  ParameterStore get_params() const { return scaling_function_.get_params(); }
+  bool has_param(const std::string &n) const { return get_params().count(n) > 0; }
+  void set_param(const std::string &n, double v) { scaling_function_.set_param(n, v); }
+  void emit(std::vector<agp_kernel_node> &nodes, int &column) const {
+    nodes.push_back(detail::node(AGP_OP_SCALING, 0, column, 0));
+    ++column;
+  }
+  template <typename X>
+  void fill_scales(const X &x, double *out, int &column) const {
+    out[column++] = scaling_function_._call_impl(x);  // evaluated once per point, not per pair
+  }
+
+ private:
+  ScalingFunction scaling_function_;
+};
+
+namespace detail {
+template <class LHS, class RHS, int OP, char SYM, typename Self>
+class Binary : public CovarianceFunction<Self> {
+ public:
+  Binary() = default;
+  Binary(const LHS &l, const RHS &r) : lhs_(l), rhs_(r) {}
+  std::string name() const { return "(" + lhs_.get_name() + std::string(1, SYM) + rhs_.get_name() + ")"; }
+  ParameterStore get_params() const {  // map_join, covariance_function.hpp:235-237
+    ParameterStore p = lhs_.get_params();
+    for (const auto &kv : rhs_.get_params()) p[kv.first] = kv.second;
+    return p;
+  }
+  bool has_param(const std::string &n) const { return lhs_.has_param(n) || rhs_.has_param(n); }
+  void set_param(const std::string &n, double v) {  // set_param_if_exists_in_any, :239-242
+    bool done = false;
+    if (lhs_.has_param(n)) { lhs_.set_param(n, v); done = true; }
+    if (rhs_.has_param(n)) { rhs_.set_param(n, v); done = true; }
+    if (!done) throw std::out_of_range("unknown parameter " + n);
+  }
+  void emit(std::vector<agp_kernel_node> &nodes, int &column) const {
+    lhs_.emit(nodes, column);
+    rhs_.emit(nodes, column);
+    nodes.push_back(detail::node(OP));
+  }
+  template <typename X>
+  void fill_scales(const X &x, double *out, int &column) const {
+    lhs_.template fill_scales<X>(x, out, column);
+    rhs_.template fill_scales<X>(x, out, column);
+  }
+
+ protected:
+  LHS lhs_;
+  RHS rhs_;
+};
+}  // namespace detail
+
+// covariance_function.hpp:222-325
+template <class LHS, class RHS>
+class SumOfCovarianceFunctions
+    : public detail::Binary<LHS, RHS, AGP_OP_SUM, '+', SumOfCovarianceFunctions<LHS, RHS>> {
+  using Base = detail::Binary<LHS, RHS, AGP_OP_SUM, '+', SumOfCovarianceFunctions<LHS, RHS>>;
+ public:
+  using Base::Base;
+};
+
+// covariance_function.hpp:330-420 (rhs skipped when lhs == 0, :362-366 — on device)
+template <class LHS, class RHS>
+class ProductOfCovarianceFunctions
+    : public detail::Binary<LHS, RHS, AGP_OP_PRODUCT, '*', ProductOfCovarianceFunctions<LHS, RHS>> {
+  using Base = detail::Binary<LHS, RHS, AGP_OP_PRODUCT, '*', ProductOfCovarianceFunctions<LHS, RHS>>;
+ public:
+  using Base::Base;
+};
+
+// measurement.hpp:70-106
+template <typename SubCovariance>
+class MeasurementOnly : public CovarianceFunction<MeasurementOnly<SubCovariance>> {
+ public:
+  MeasurementOnly() = default;
+  explicit MeasurementOnly(const SubCovariance &sub) : sub_cov_(sub) {}
+  std::string name() const { return "measurement[" + sub_cov_.get_name() + "]"; }
+  ParameterStore get_params() const { return sub_cov_.get_params(); }
+  bool has_param(const std::string &n) const { return sub_cov_.has_param(n); }
+  void set_param(const std::string &n, double v) { sub_cov_.set_param(n, v); }
+  void emit(std::vector<agp_kernel_node> &nodes, int &column) const {
+    sub_cov_.emit(nodes, column);
+    nodes.push_back(detail::node(AGP_OP_MEASUREMENT_ONLY));
+  }
+  template <typename X>
+  void fill_scales(const X &x, double *out, int &column) const { sub_cov_.template fill_scales<X>(x, out, column); }
+
+ private:
+  SubCovariance sub_cov_;
+};
+
+template <typename SubCovariance>
+MeasurementOnly<SubCovariance> measurement_only(const SubCovariance &cov) {
+  return MeasurementOnly<SubCovariance>(cov);
+}
+
+// ---------------------------------------------------------------------------
+// mean functions (mean_function.hpp:86-107,274-276; polynomials.hpp:92-106)
+// ---------------------------------------------------------------------------
+struct ZeroMean {
+  std::string get_name() const { return "zero_mean"; }
+  ParameterStore get_params() const { return {}; }
+  bool has_param(const std::string &) const { return false; }
+  void set_param(const std::string &n, double) { throw std::out_of_range("unknown parameter " + n); }
+  template <typename X> double _call_impl(const X &) const { return 0.; }
+};
+
+struct LinearMean {
+  double slope = 0., offset = 0.;
+  std::string get_name() const { return "linear"; }
+  ParameterStore get_params() const { return {{"slope", slope}, {"offset", offset}}; }
+  bool has_param(const std::string &n) const { return n == "slope" || n == "offset"; }
+  void set_param(const std::string &n, double v) {
+    if (n == "slope") slope = v;
+    else if (n == "offset") offset = v;
+    else throw std::out_of_range("unknown parameter " + n);
+  }
+  double _call_impl(const double &x) const { return slope * x + offset; }
+};
+
+// ---------------------------------------------------------------------------
+// Fit<GPFit<...>> (gp.hpp:43-77): the factor lives on the device
+// ---------------------------------------------------------------------------
+template <typename FeatureType>
+struct GPFit {
+  std::vector<FeatureType> train_features;
+  Vector information;
+  double log_determinant = 0.;
+  std::shared_ptr<detail::ContextHolder> context;
+  std::shared_ptr<agp_fit> handle;  // train_covariance (CovarianceRepresentation)
+
+  // train_covariance.solve(rhs), gp.hpp:42-45
+  Matrix solve(const Matrix &rhs) const {
+    Matrix out(rhs.rows(), rhs.cols());
+    detail::check(agp_solve(context->ctx, handle.get(), rhs.data.data(), rhs.cols(), out.data.data(), AGP_HOST),
+                  context->ctx, "agp_solve");
+    return out;
+  }
+};
+
+template <typename ModelType, typename FeatureType> class FitModel;
+
+// core/prediction.hpp:115-224 — lazy prediction
+template <typename ModelType, typename FitFeature, typename PredictFeature>
+class Prediction {
+ public:
+  Prediction(const FitModel<ModelType, FitFeature> *fm, std::vector<PredictFeature> features)
+      : fm_(fm), features_(std::move(features)) {}
+  Vector mean() const { return fm_->predict_mean_(features_); }
+  MarginalDistribution marginal() const { return fm_->predict_marginal_(features_); }
+  JointDistribution joint() const { return fm_->predict_joint_(features_); }
+
+ private:
+  const FitModel<ModelType, FitFeature> *fm_;
+  std::vector<PredictFeature> features_;
+};
+
+// core/fit_model.hpp:18-114
+template <typename ModelType, typename FeatureType>
+class FitModel {
+ public:
+  FitModel(const ModelType &model, GPFit<FeatureType> fit) : model_(model), fit_(std::move(fit)) {}
+  const GPFit<FeatureType> &get_fit() const { return fit_; }
+  const ModelType &get_model() const { return model_; }
+
+  template <typename P>
+  Prediction<ModelType, FeatureType, P> predict(const std::vector<P> &features) const {
+    return Prediction<ModelType, FeatureType, P>(this, features);
+  }
+  // fit_model.hpp:54-62
+  template <typename P>
+  Prediction<ModelType, FeatureType, Measurement<P>> predict_with_measurement_noise(const std::vector<P> &features) const {
+    return Prediction<ModelType, FeatureType, Measurement<P>>(this, as_measurements(features));
+  }
+
+  // _predict_impl, gp.hpp:305-366
+  template <typename P>
+  Vector predict_mean_(const std::vector<P> &xs) const {
+    detail::KernelHolder k(model_.get_covariance().program());
+    detail::Flat f = detail::flatten(model_.get_covariance(), xs);
+    Vector mean(xs.size());
+    if (!xs.empty())
+      detail::check(agp_predict_mean(fit_.context->ctx, k.k, fit_.handle.get(), &f.view, mean.data(), AGP_HOST),
+                    fit_.context->ctx, "agp_predict_mean");
+    model_.add_mean(xs, &mean);
+    return mean;
+  }
+  template <typename P>
+  MarginalDistribution predict_marginal_(const std::vector<P> &xs) const {
+    detail::KernelHolder k(model_.get_covariance().program());
+    detail::Flat f = detail::flatten(model_.get_covariance(), xs);
+    MarginalDistribution out(Vector(xs.size()), Vector(xs.size()));
+    if (!xs.empty())
+      detail::check(agp_predict_marginal(fit_.context->ctx, k.k, fit_.handle.get(), &f.view, out.mean.data(),
+                                         out.covariance.data(), AGP_HOST),
+                    fit_.context->ctx, "agp_predict_marginal");
+    model_.add_mean(xs, &out.mean);
+    return out;
+  }
+  template <typename P>
+  JointDistribution predict_joint_(const std::vector<P> &xs) const {
+    detail::KernelHolder k(model_.get_covariance().program());
+    detail::Flat f = detail::flatten(model_.get_covariance(), xs);
+    JointDistribution out;
+    out.mean.resize(xs.size());
+    out.covariance = Matrix(static_cast<std::int64_t>(xs.size()), static_cast<std::int64_t>(xs.size()));
+    if (!xs.empty())
+      detail::check(agp_predict_joint(fit_.context->ctx, k.k, fit_.handle.get(), &f.view, out.mean.data(),
+                                      out.covariance.data.data(), AGP_HOST),
+                    fit_.context->ctx, "agp_predict_joint");
+    model_.add_mean(xs, &out.mean);
+    return out;
+  }
+
+ private:
+  ModelType model_;
+  GPFit<FeatureType> fit_;
+};
+
+// ---------------------------------------------------------------------------
+// GaussianProcessRegression (gp.hpp:170-505)
+// ---------------------------------------------------------------------------
+template <typename CovFunc, typename MeanFunc = ZeroMean>
+class GaussianProcessRegression {
+ public:
+  GaussianProcessRegression() = default;
+  explicit GaussianProcessRegression(const CovFunc &cov, const std::string &name = "gaussian_process_regression")
+      : covariance_function_(cov), model_name_(name) {}
+  GaussianProcessRegression(const CovFunc &cov, const MeanFunc &mean, const std::string &name = "gaussian_process_regression")
+      : covariance_function_(cov), mean_function_(mean), model_name_(name) {}
+
+  std::string get_name() const { return model_name_; }
+  const CovFunc &get_covariance() const { return covariance_function_; }
+  const MeanFunc &get_mean() const { return mean_function_; }
+
+  ParameterStore get_params() const {  // gp.hpp:255-258
+    ParameterStore p = covariance_function_.get_params();
+    for (const auto &kv : mean_function_.get_params()) p[kv.first] = kv.second;
+    return p;
+  }
+  void set_param(const std::string &n, double v) {  // gp.hpp:260-268
+    if (covariance_function_.has_param(n)) covariance_function_.set_param(n, v);
+    else if (mean_function_.has_param(n)) mean_function_.set_param(n, v);
+    else throw std::out_of_range("unknown parameter " + n);
+  }
+  void set_param_values(const ParameterStore &values) {
+    for (const auto &kv : values) set_param(kv.first, kv.second);
+  }
+
+  template <typename P>
+  void add_mean(const std::vector<P> &xs, Vector *mean) const {  // mean_function_.add_to, mean_function.hpp:86-95
+    if (std::is_same<MeanFunc, ZeroMean>::value) return;
+    for (std::size_t i = 0; i < xs.size(); ++i) (*mean)[i] += mean_function_._call_impl(detail::unwrap<P>::get(xs[i]));
+  }
+
+  // ModelBase::fit (core/model.hpp:137-152) -> _fit_impl (gp.hpp:281-294)
+  template <typename FeatureType>
+  FitModel<GaussianProcessRegression, FeatureType> fit(const RegressionDataset<FeatureType> &dataset) const {
+    return fit(dataset.features, dataset.targets);
+  }
+
+  template <typename FeatureType>
+  FitModel<GaussianProcessRegression, FeatureType> fit(const std::vector<FeatureType> &features,
+                                                       const MarginalDistribution &targets) const {
+    if (features.size() != targets.size()) throw std::invalid_argument("features and targets differ in size");
+    if (!targets.covariance.empty() && targets.covariance.size() != targets.size())
+      throw std::invalid_argument("target covariance must be diagonal (one variance per target)");
+    auto ctx = detail::default_context();
+    detail::KernelHolder k(covariance_function_.program());
+    detail::Flat f = detail::flatten(covariance_function_, features);  // as_measurements happens inside agp_fit_create
+    Vector y = targets.mean;                                            // mean_function_.remove_from, gp.hpp:291-292
+    if (!std::is_same<MeanFunc, ZeroMean>::value)
+      for (std::size_t i = 0; i < y.size(); ++i) y[i] -= mean_function_._call_impl(detail::unwrap<FeatureType>::get(features[i]));
+    GPFit<FeatureType> fit;
+    fit.train_features = features;
+    fit.information.resize(features.size());
+    fit.context = ctx;
+    agp_fit *h = nullptr;
+    const int st = agp_fit_create(ctx->ctx, k.k, &f.view, y.data(), targets.covariance.empty() ? nullptr : targets.covariance.data(),
+                                  &h, fit.information.data(), &fit.log_determinant);
+    if (st != AGP_OK) {
+      const long long pivot = h ? static_cast<long long>(agp_fit_failed_pivot(h)) : -1;
+      agp_fit_destroy(h);
+      std::string what = "agp_fit_create";
+      if (st == AGP_ERR_NOT_POSITIVE_DEFINITE) what += " (pivot " + std::to_string(pivot) + ")";
+      detail::check(st, ctx->ctx, what.c_str());
+    }
+    fit.handle = std::shared_ptr<agp_fit>(h, [ctx](agp_fit *p) { agp_fit_destroy(p); });
+    return FitModel<GaussianProcessRegression, FeatureType>(*this, std::move(fit));
+  }
+
+  // gp.hpp:442-451 (prior_log_likelihood() is outside the hot path and not included)
+  template <typename FeatureType>
+  double log_likelihood(const RegressionDataset<FeatureType> &dataset) const {
+    auto ctx = detail::default_context();
+    detail::KernelHolder k(covariance_function_.program());
+    detail::Flat f = detail::flatten(covariance_function_, dataset.features);
+    Vector y = dataset.targets.mean;
+    if (!std::is_same<MeanFunc, ZeroMean>::value)
+      for (std::size_t i = 0; i < y.size(); ++i)
+        y[i] -= mean_function_._call_impl(detail::unwrap<FeatureType>::get(dataset.features[i]));
+    double nll = 0.;
+    detail::check(agp_nll(ctx->ctx, k.k, &f.view, y.data(),
+                          dataset.targets.covariance.empty() ? nullptr : dataset.targets.covariance.data(), &nll),
+                  ctx->ctx, "agp_nll");
+    return -nll;
+  }
+
+ private:
+  CovFunc covariance_function_;
+  MeanFunc mean_function_;
+  std::string model_name_ = "gaussian_process_regression";
+};
+
+// factories, gp.hpp:507-537
+template <typename CovFunc>
+GaussianProcessRegression<CovFunc, ZeroMean> gp_from_covariance(const CovFunc &cov,
+                                                                const std::string &name = "gaussian_process_regression") {
+  return GaussianProcessRegression<CovFunc, ZeroMean>(cov, name);
+}
+
+template <typename CovFunc, typename MeanFunc>
+GaussianProcessRegression<CovFunc, MeanFunc> gp_from_covariance_and_mean(
+    const CovFunc &cov, const MeanFunc &mean, const std::string &name = "gaussian_process_regression") {
+  return GaussianProcessRegression<CovFunc, MeanFunc>(cov, mean, name);
+}
+
+// GaussianProcessNegativeLogLikelihood, gp.hpp:542-550: the tuner's objective
+struct GaussianProcessNegativeLogLikelihood {
+  template <typename FeatureType, typename CovFunc, typename MeanFunc>
+  double operator()(const RegressionDataset<FeatureType> &dataset,
+                    const GaussianProcessRegression<CovFunc, MeanFunc> &model) const {
+    return -model.log_likelihood(dataset);
+  }
+};
+
+}  // namespace albatross
+
+#endif  // ALBATROSS_AMD_ALBATROSS_HPP

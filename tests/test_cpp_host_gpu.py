@@ -1,0 +1,96 @@
+"""GPU tests of the C++ drop-in surface (include/albatross_amd/albatross.hpp):
+build the examples with g++ against the C-ABI library, run them, and check
+their output against the oracle on the same data."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import albatross_amd as ab
+from oracle import oracle_py as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, "examples")
+
+
+def run(binary, *args):
+    subprocess.check_call(["make", "-s", "-C", EX])
+    out = subprocess.check_output([os.path.join(EX, binary), *args], text=True)
+    rows = {}
+    for line in out.strip().splitlines():
+        key, *vals = line.split(",")
+        rows.setdefault(key, []).append(vals)
+    return rows
+
+
+def test_headers_compile_without_gpu():
+    """not a gpu test: the C++ surface builds with plain g++ and links the C-ABI"""
+    subprocess.check_call(["make", "-s", "-C", EX, "clean"])
+    subprocess.check_call(["make", "-s", "-C", EX])
+    assert os.path.exists(os.path.join(EX, "sinc_example"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["radial", "radial_only"])
+def test_sinc_example_config1(mode):
+    """BASELINE config 1: sinc_example, 1-D SquaredExponential GP, N = 256."""
+    rows = run("sinc_example", mode, "256")
+    train = np.array(rows["train"], dtype=float)
+    pred = np.array(rows["pred"], dtype=float)
+    assert train.shape == (256, 2) and pred.shape == (161, 4)
+    x, y = train[:, 0], train[:, 1]
+    if mode == "radial":
+        cov = ab.Polynomial(1, 100.) + ab.SquaredExponential(3.5, 5.7) + ab.measurement_only(ab.IndependentNoise(1.0))
+    else:
+        cov = ab.SquaredExponential(3.5, 100.) + ab.measurement_only(ab.IndependentNoise(1.0))
+    params = {k: float(v) for k, v in rows["params"]}
+    assert params == cov.get_params()
+    ofit = orc.OracleFit(cov, x, y)
+    om, ov = ofit.predict_marginal(pred[:, 0], xs_meas=True)  # predict_with_measurement_noise
+    assert np.abs(pred[:, 1] - om).max() <= 1e-7 * np.abs(om).max()
+    assert np.abs(pred[:, 2] - ov).max() <= 1e-7 * np.abs(ov).max()
+    assert abs(float(rows["loglik"][0][0]) + orc.nll(cov, x, y)) <= 1e-6 * 256
+    # the GP should recover the truth inside the data range (the example's purpose)
+    inside = (pred[:, 0] > -8) & (pred[:, 0] < 21)
+    assert np.abs(pred[inside, 1] - pred[inside, 3]).max() < 3.0
+
+
+@pytest.mark.gpu
+def test_cpp_api_matches_oracle():
+    rows = run("cpp_api_check")
+    one = {k: v[0][0] for k, v in rows.items() if len(v) == 1 and len(v[0]) == 1}
+    # measurement / noise algebra is exact (tests/test_covariance_functions.cc:33-93)
+    assert float(one["algebra_meas_ff"]) == 0. and float(one["algebra_meas_mf"]) == 0.
+    assert float(one["algebra_meas_mm"]) == 0.1 * 0.1
+    assert float(one["algebra_sum_mm_minus_parts"]) == 0. and float(one["algebra_prod_mm_minus_parts"]) == 0.
+    assert float(one["algebra_prod_ff"]) == 0.
+    assert one["name"] == "(((elevation_scaling*constant)+matern_52[euclidean_distance])+independent_noise)"
+    assert float(one["param_sigma_constant"]) == 0.7 and float(one["param_matern_52_length_scale"]) == 2.0
+
+    class Elevation(ab.ScalingFunction):
+        _params = {"elevation_scaling_center": 4.0, "elevation_scaling_factor": 0.3}
+
+        def get_name(self):
+            return "elevation_scaling"
+
+        def _call_impl(self, c):
+            return 1. + 0.3 * np.maximum(4.0 - np.asarray(c)[:, 2], 0.)
+
+    cov = ab.ScalingTerm(Elevation()) * ab.Constant(0.7) + ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+    xr = np.array(rows["x"], dtype=float)
+    x, y = xr[:, 1:4], xr[:, 4]
+    xs = np.array(rows["xs"], dtype=float)[:, 1:4]
+    ofit = orc.OracleFit(cov, x, y)
+    info = np.array(rows["info"], dtype=float)[:, 1]
+    assert np.abs(info - ofit.information).max() <= 1e-8 * np.abs(ofit.information).max()
+    assert abs(float(one["logdet"]) - ofit.log_determinant) <= 1e-6 * 400
+    assert abs(float(one["loglik"]) + orc.nll(cov, x, y)) <= 1e-6 * 400
+    pred = np.array(rows["pred"], dtype=float)
+    om, ov = ofit.predict_marginal(xs)
+    assert np.abs(pred[:, 1] - om).max() <= 1e-8 * np.abs(om).max()
+    assert np.abs(pred[:, 2] - om).max() <= 1e-8 * np.abs(om).max()
+    assert np.abs(pred[:, 3] - ov).max() <= 1e-8 and np.abs(pred[:, 4] - ov).max() <= 1e-8
+    assert float(one["joint_asymmetry"]) == 0.
+    assert float(one["solve_residual"]) < 1e-10
+    assert "not positive definite" in one["singular"] and "pivot 1" in one["singular"]
