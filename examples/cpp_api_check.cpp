@@ -74,7 +74,7 @@ int main() {
   Matrix rhs(n, 1);
   rhs(0, 0) = 1.;
   const Matrix sol = fm.get_fit().solve(rhs);
-  const Matrix K = cov(as_measurements(x));
+  const Matrix K = model.get_covariance()(as_measurements(x));  // the model holds its own copy of cov
   double resid = 0.;
   for (int i = 0; i < n; ++i) {
     double s = 0.;
