@@ -91,6 +91,11 @@ EXPORTS = [
     ("agp_predict_mean", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, C.c_int]),
     ("agp_predict_marginal", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
     ("agp_predict_joint", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
+    ("agp_blk_gram", C.c_int, [_P, _P, C.POINTER(Features), C.POINTER(Features), _P, C.c_int64, _P, C.POINTER(C.c_int)]),
+    ("agp_blk_panel_factor", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, C.POINTER(C.c_int64), _D]),
+    ("agp_blk_update", C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+    ("agp_blk_back_diag", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
+    ("agp_blk_back_update", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     ("agp_last_stage_ms", C.c_int, [_P, C.c_int, _D]),
     ("agp_set_profiling", C.c_int, [_P, C.c_int]),
     ("agp_mfma_f64_peak", C.c_int, [_P, C.c_int, _D]),

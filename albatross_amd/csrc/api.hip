@@ -246,6 +246,12 @@ static int device_program(agp_context *ctx, const agp_kernel *k, const DevProgra
   return AGP_OK;
 }
 
+namespace agp {
+int device_program_for(agp_context *ctx, const agp_kernel *k, const DevProgram **out) {
+  return device_program(ctx, k, out);
+}
+}  // namespace agp
+
 static int validate_features(const agp_features *f) {
   if (!f || f->n < 0 || f->dim < 1 || f->dim > AGP_MAX_DIM) return AGP_ERR_INVALID_ARGUMENT;
   if (f->n_scale_columns < 0 || f->n_scale_columns > AGP_MAX_SCALE_COLUMNS) return AGP_ERR_INVALID_ARGUMENT;
@@ -293,6 +299,12 @@ static int to_device(agp_context *ctx, const agp_features *f, bool copy, DeviceF
   out->v = v;
   return AGP_OK;
 }
+
+namespace agp {
+int features_to_device(agp_context *ctx, const agp_features *f, bool copy, DeviceFeatures *out) {
+  return to_device(ctx, f, copy, out);
+}
+}  // namespace agp
 
 static int ensure_ws(agp_context *ctx, double **ws, size_t *have, size_t need) {
   if (*have >= need) return AGP_OK;

@@ -432,6 +432,11 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
   }
 }
 
+void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *img,
+                        double *y, long long K0, long long kend) {
+  panel_phase(ctx, s, A, n, lda, img, y, K0, kend, nullptr);
+}
+
 // Outer block width as a function of the remaining (trailing) size.  Wide
 // blocks (K = 512) keep the bulk update's C traffic off the HBM roofline while
 // the trailing matrix is far larger than the 256 MiB Infinity Cache; once it is
@@ -608,11 +613,12 @@ __global__ __launch_bounds__(256) void diag_back_kernel(const double *__restrict
 
 // z[c] -= sum_r L[k0 + r][c] x[r]  for c < k0 ; r < nbk.   8 columns per wave.
 __global__ __launch_bounds__(256) void back_update_kernel(const double *__restrict__ A, long long lda,
-                                                          long long k0, int nbk, const double *__restrict__ x,
-                                                          double *__restrict__ z) {
+                                                          long long k0, int nbk, long long ncols,
+                                                          const double *__restrict__ x, double *__restrict__ z) {
+  // rows k0 .. k0 + nbk of A, columns 0 .. ncols
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long c0 = ((long long)blockIdx.x * 4 + wave) * 8;
-  if (c0 >= k0) return;
+  if (c0 >= ncols) return;
   const int r = 2 * lane;
   const double x0 = r < nbk ? x[r] : 0., x1 = r + 1 < nbk ? x[r + 1] : 0.;
   const bool vec = ((lda & 1) == 0) && ((k0 & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(256) void back_update_kernel(const double *__restri
   for (int q = 0; q < 8; ++q) {
     const long long c = c0 + q;
     double a0 = 0., a1 = 0.;
-    if (c < k0) {
+    if (c < ncols) {
       const double *p = A + c * lda + k0 + r;
       if (vec && r + 1 < nbk) {
         const double2 v = *reinterpret_cast<const double2 *>(p);
@@ -641,8 +647,15 @@ __global__ __launch_bounds__(256) void back_update_kernel(const double *__restri
   if (lane == 0) {
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      if (c0 + q < k0) z[c0 + q] -= acc[q];
+      if (c0 + q < ncols) z[c0 + q] -= acc[q];
   }
+}
+
+void launch_back_update(hipStream_t s, const double *A, long long lda, long long k0, int nbk, long long ncols,
+                        const double *x, double *z) {
+  if (ncols <= 0 || nbk <= 0) return;
+  hipLaunchKernelGGL(back_update_kernel, dim3((unsigned)((ncols + 31) / 32)), dim3(256), 0, s, A, lda, k0, nbk,
+                     ncols, x, z);
 }
 
 void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Winv,
@@ -652,9 +665,7 @@ void backward_solve_vec(hipStream_t s, const double *A, long long n, long long l
     const long long k = b * NB;
     const int nbk = (int)((n - k < NB) ? n - k : NB);
     hipLaunchKernelGGL(diag_back_kernel, dim3(1), dim3(256), 0, s, Winv + b * (long long)(NB * NB), nbk, z + k);
-    if (k > 0)
-      hipLaunchKernelGGL(back_update_kernel, dim3((unsigned)((k + 31) / 32)), dim3(256), 0, s, A, lda, k, nbk,
-                         z + k, z);
+    if (k > 0) launch_back_update(s, A, lda, k, nbk, k, z + k, z);
   }
 }
 

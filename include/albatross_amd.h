@@ -193,6 +193,47 @@ int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
                       const agp_features *xs, double *mean, double *cov,
                       int out_location);
 
+/* ---- block-level building blocks of the multi-GPU sharded fit ------------ */
+/* One fit sharded block-column-cyclically over the GPUs of a node
+ * (albatross_amd/distributed.py): every rank owns whole block columns of the
+ * lower triangle of K; per outer block the owner factors the panel and the
+ * panel is broadcast (RCCL) so that every rank updates its own block columns.
+ * These entry points are the per-rank arithmetic; all pointers are DEVICE
+ * pointers unless stated, matrices column-major.  Reference work replaced:
+ * the same Fit<GPFit> constructor (models/gp.hpp:61-69) as agp_fit_create. */
+
+/* Lower part of one block column of the training Gram: out(i, j) =
+ * k(rows_i, cols_j) for i >= j (tiles strictly above the diagonal are
+ * skipped), both feature vectors measurement-wrapped by the caller, rows and
+ * cols starting at the same training index.  diag_add (device, one value per
+ * column, or NULL) is added where i == j.  *nan_flag (host) is set to 1 if any
+ * written entry is NaN. */
+int agp_blk_gram(agp_context *ctx, const agp_kernel *k, const agp_features *rows,
+                 const agp_features *cols, double *out, int64_t ld,
+                 const double *diag_add, int *nan_flag);
+/* LL^T panel factorisation of an m x width block column whose diagonal block
+ * is at its top (POTRF + TRSM + inner updates over its 128-wide sub-blocks).
+ * y (m entries aligned with the rows, or NULL) receives the fused forward
+ * substitution.  img: ceil(width / 128) tile images (9216 doubles each).
+ * Host outputs: *bad_pivot = first non-positive pivot (0-based, -1 if none),
+ * *log_sum = sum of log L_ii of these columns. */
+int agp_blk_panel_factor(agp_context *ctx, double *A, int64_t m, int64_t lda,
+                         int64_t width, double *img, double *y,
+                         int64_t *bad_pivot, double *log_sum);
+/* C (M x N, ldc) -= P (M x K, ldp) * Q (N x K, ldq)^T; tri != 0: only the
+ * tiles on / below the diagonal of C. */
+int agp_blk_update(agp_context *ctx, double *C, int64_t ldc, const double *P,
+                   int64_t ldp, const double *Q, int64_t ldq, int64_t M,
+                   int64_t N, int64_t K, int tri);
+/* x = L_BB^-T z for the width x width lower-triangular diagonal block at the
+ * top of a factored block column (z overwritten by x). */
+int agp_blk_back_diag(agp_context *ctx, const double *A, int64_t lda,
+                      int64_t width, const double *img, double *z);
+/* z[c] -= sum_r L[r][c] x[r] for c < ncols, r < nrows, L = Arows(r, c). */
+int agp_blk_back_update(agp_context *ctx, const double *Arows, int64_t lda,
+                        int64_t nrows, int64_t ncols, const double *x,
+                        double *z);
+
 /* ---- instrumentation (bench.py) ----------------------------------------- */
 /* Per-stage device time of the LAST fit / nll on this context, measured with
  * HIP events on the stream the kernels were launched on.  Stages:
