@@ -29,8 +29,22 @@ tensors over gloo with a numpy implementation of the same block interface.
 import ctypes as C
 
 import numpy as np
+import torch  # noqa: F401  (imported BEFORE the HIP library is loaded, see _init_torch_first)
 
 from . import _capi as capi
+
+
+def _init_torch_first():
+    """The torch wheel carries its own HIP runtime (ROCm 7.0, soname
+    libamdhip64.so) next to the system one this library links (ROCm 7.2,
+    libamdhip64.so.7).  Both can live in one process, but only if torch's is
+    initialised first; so any process that shares buffers between torch and
+    this library initialises torch's CUDA context before the first agp_* call."""
+    if torch.cuda.is_available():
+        torch.cuda.init()
+
+
+_init_torch_first()
 
 IMG_DOUBLES = 36 * 16 * 16  # tile image of one 128 x 128 diagonal block
 NB = 128

@@ -4,6 +4,12 @@ import sys
 
 import numpy as np
 import pytest
+import torch
+
+if torch.cuda.is_available():
+    # torch's bundled HIP runtime must be initialised before libalbatross_amd.so
+    # (system ROCm) makes its first HIP call — see albatross_amd/distributed.py
+    torch.cuda.init()
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
