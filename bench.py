@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--n", type=int, default=N_TRAIN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predict", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="use the sharded-fit code path even on 1 GPU")
     ap.add_argument("--multi-gpu", choices=["sharded", "replicas"], default="sharded",
                     help="N > 1: 'sharded' = ONE fit block-column-sharded over all ranks with a panel broadcast "
                          "per outer block (strong scaling, north_star); 'replicas' = one independent fit per rank")
@@ -120,7 +121,7 @@ def main():
     feats.is_measurement = 0
     feats.location = capi.DEVICE
 
-    sharded = world > 1 and args.multi_gpu == "sharded"
+    sharded = (world > 1 and args.multi_gpu == "sharded") or args.force_sharded
     if sharded:
         from albatross_amd.distributed import HipBlockOps, ShardedGaussianProcessFit
         x_h, y_h = make_dataset(n, 44)  # every rank holds the same dataset: ONE fit over all ranks
