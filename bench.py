@@ -165,6 +165,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- auxiliary (N > 1, sharded): throughput of independent fits, one per GPU ----
+    replicas = None
+    if sharded and world > 1:
+        def replica_step():
+            h = C.c_void_p()
+            st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+            if st != capi.AGP_OK:
+                raise RuntimeError("agp_fit_create failed")
+            lib.agp_fit_destroy(h)
+        replica_step()
+        barrier()
+        tr = time.perf_counter()
+        for _ in range(3):
+            replica_step()
+        barrier()
+        tr = time.perf_counter() - tr
+        t = torch.tensor([tr], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        replicas = {"fits_per_sec": 3 * world / float(t.item()), "note": "one independent fit per GPU, no collective"}
+
     # ---- secondary: predict points/sec at M = 4096 against one resident fit ----
     predict = None
     if rank == 0 and not args.no_predict and not sharded:
@@ -236,6 +256,8 @@ def main():
         }
         if predict is not None:
             out["predict"] = predict
+        if replicas is not None:
+            out["replicas"] = replicas
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
