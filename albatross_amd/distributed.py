@@ -171,7 +171,10 @@ class ShardedGaussianProcessFit:
     a process group.  Every rank passes the same (full) features and targets and
     receives the full information vector and log-determinant."""
 
-    def __init__(self, ops, cov, block=512, group=None):
+    def __init__(self, ops, cov, block=512, group=None, force_collectives=False):
+        # force_collectives: issue the broadcasts / all-reduce even on a single
+        # rank (used by the GPU test to exercise RCCL on buffers the HIP library wrote)
+        self.force_collectives = force_collectives
         self.ops = ops
         self.cov = cov
         self.block = block
@@ -188,13 +191,13 @@ class ShardedGaussianProcessFit:
         return self.dist.get_global_rank(self.group, owner) if (self.active and self.group is not None) else owner
 
     def _broadcast(self, tensor, owner):
-        if self.active and self.world > 1:
+        if self.active and (self.world > 1 or self.force_collectives):
             self.ops.sync()
             self.dist.broadcast(tensor, src=self._src(owner), group=self.group)
             self.ops.sync()
 
     def _all_max(self, value):
-        if not (self.active and self.world > 1):
+        if not (self.active and (self.world > 1 or self.force_collectives)):
             return value
         t = self.ops.from_host(np.array([float(value)]))
         self.ops.sync()

@@ -56,7 +56,9 @@ def test_sharded_fit_with_rccl_group_of_one(ctx):
     try:
         x, y, yvar = problem(900)
         cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
-        fit = ShardedGaussianProcessFit(HipBlockOps(ctx, "cuda:0"), cov, block=256)
+        # force_collectives: every panel / solution broadcast and the NaN all-reduce really go
+        # through RCCL (self-broadcast) on buffers written by the HIP library's kernels
+        fit = ShardedGaussianProcessFit(HipBlockOps(ctx, "cuda:0"), cov, block=256, force_collectives=True)
         assert fit.active and fit.world == 1
         res = fit.fit(x, y, yvar)
         ofit = orc.OracleFit(cov, x, y, yvar)
