@@ -219,6 +219,16 @@ def main():
         predict = {"m": m, "mean_pts_per_sec": m / t_mean, "marginal_pts_per_sec": m / t_marg,
                    "mean_ms": 1e3 * t_mean, "marginal_ms": 1e3 * t_marg}
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
+    # the per-launch figure comes from the committed rocprofv3 --pmc passes (profiles/r01/pmc_traffic.json,
+    # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction applied); null if absent.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+            traffic = json.load(fh)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     if rank == 0:
         # sharded: one fit per step over all ranks; replicas: every rank fits its own dataset
         fits = args.steps if (sharded or world == 1) else args.steps * world
@@ -245,7 +255,8 @@ def main():
                 "bound": "mfma", "kernel": "agp::trailing_update_kernel (fp64 MFMA bulk trailing update C -= P P^T, K=512)",
                 "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F64_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (rocprofv3 PMC passes, profiles/r01/pmc_traffic.json)",
                 "launches_per_fit": gemm_launches / args.steps,
                 "avg_launch_ms": gemm_ms / max(gemm_launches, 1.0),
                 "flop_per_fit": gemm_flop / args.steps,
