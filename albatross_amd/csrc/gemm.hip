@@ -17,6 +17,7 @@
 //
 // Roofline: MFMA-bound.  Per tile 2*128*128*K flop against (2*128*K + 2*128*128)
 // * 8 B of operand + C traffic (K = 512: 64 flop/B).
+#include <cstdlib>
 #include "common.h"
 #include "mfma_f64.h"
 
@@ -197,6 +198,108 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g
   gemm_nt_sub_body<A_KMAJOR, B_KMAJOR>(g, lds);
 }
 
+// ---------------------------------------------------------------------------
+// fp64 VALU variant of the same update.  On gfx950 the fp64 MFMA pipe saturates
+// at ~48 TFLOP/s while plain v_fma_f64 reaches ~69 TFLOP/s (profiles/r01/
+// microbench_fp64.txt), so the bulk update can also run as a register-tiled
+// FMA kernel: 16 x 16 threads, 8 x 8 accumulators per lane, both operand strips
+// read from the same [k][row] LDS image (a: 16 lanes share an address ->
+// broadcast; b: 16 distinct 64-B segments = one contiguous 1 KiB row).
+// ---------------------------------------------------------------------------
+template <bool A_KMAJOR, bool B_KMAJOR>
+__device__ __forceinline__ void gemm_valu_body(const GemmArgs &g, double *lds) {
+  int bj = 0;
+  long long id = blockIdx.x;
+  while (true) {
+    const int cnt = g.tri ? (g.ntr - bj) : g.ntr;
+    if (id < cnt) break;
+    id -= cnt;
+    ++bj;
+  }
+  const int bi = (g.tri ? bj : 0) + (int)id;
+  const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // tx: column group, ty: row group
+
+  const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
+
+  double acc[8][8];  // [col][row]
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[c][r] = 0.;
+
+  double ra[8], rb[8];
+  const long long nk = (g.K + GK - 1) / GK;
+  load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
+  load_chunk<B_KMAJOR>(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb);
+  store_chunk<A_KMAJOR, false>(lds, ra);
+  store_chunk<B_KMAJOR, true>(lds + GK * GLD, rb);
+  __syncthreads();
+
+  for (long long kc = 0; kc < nk; ++kc) {
+    const int cur = (int)(kc & 1);
+    const double *As = lds + cur * (2 * GK * GLD) + 8 * ty;
+    const double *Bs = lds + cur * (2 * GK * GLD) + GK * GLD + 8 * tx;
+    const bool more = kc + 1 < nk;
+    if (more) {
+      load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, (kc + 1) * GK, g.K, a_vec, ra);
+      load_chunk<B_KMAJOR>(g.B, g.ldb, j0, g.N, (kc + 1) * GK, g.K, b_vec, rb);
+    }
+#pragma unroll 2
+    for (int k = 0; k < GK; ++k) {
+      double a[8], b[8];
+      const double2 *ap = reinterpret_cast<const double2 *>(As + k * GLD);
+      const double2 *bp = reinterpret_cast<const double2 *>(Bs + k * GLD);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double2 av = ap[q], bv = bp[q];
+        a[2 * q] = av.x; a[2 * q + 1] = av.y;
+        b[2 * q] = bv.x; b[2 * q + 1] = bv.y;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[c][r] = __builtin_fma(a[r], b[c], acc[c][r]);
+    }
+    if (more) {
+      double *An = lds + (cur ^ 1) * (2 * GK * GLD);
+      store_chunk<A_KMAJOR, false>(An, ra);
+      store_chunk<B_KMAJOR, true>(An + GK * GLD, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C += acc; a lane owns 8 consecutive rows (64 B) of 8 columns
+  const bool c_vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const long long col = j0 + 8 * tx + c;
+    const long long row = i0 + 8 * ty;
+    if (col >= g.N) continue;
+    double *cp = g.C + row + col * g.ldc;
+    if (c_vec && row + 8 <= g.M) {
+      double2 *cv = reinterpret_cast<double2 *>(cp);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double2 v = cv[q];
+        v.x += acc[c][2 * q];
+        v.y += acc[c][2 * q + 1];
+        cv[q] = v;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (row + r < g.M) cp[r] += acc[c][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_valu_kernel(GemmArgs g) {
+  __shared__ double lds[2 * 2 * GK * GLD];
+  gemm_valu_body<false, false>(g, lds);
+}
+
 // The bulk trailing update of the factorisation (C -= P P^T, lower tiles, K =
 // NBO) under its own kernel symbol, so that profiles and bench.py's roofline
 // block isolate exactly these launches.
@@ -240,7 +343,13 @@ void launch_trailing_update(hipStream_t s, double *C, long long ldc, const doubl
   g.ntr = (int)((M + GT - 1) / GT);
   g.ntc = g.ntr;
   const long long tiles = count_tiles(g.ntr, g.ntc, 1);
-  hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+  static int use_valu = -1;
+  if (use_valu < 0) {
+    const char *e = getenv("AGP_UPDATE_VALU");
+    use_valu = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (use_valu) hipLaunchKernelGGL(trailing_update_valu_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+  else hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
 }
 
 // ---- bare MFMA issue loop: measured fp64 matrix peak of this device ----------
