@@ -223,7 +223,10 @@ __device__ __forceinline__ void gemm_valu_body(const GemmArgs &g, double *lds) {
   const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
   const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
 
-  double acc[8][8];  // [col][row]
+  // Ownership is interleaved so that every ds_read_b128 of a wave is one
+  // contiguous run: lane (tx, ty) owns rows 32 q + 2 ty + {0,1} and columns
+  // 32 q + 2 tx + {0,1}, q = 0..3 (8 x 8 accumulators as 4 x 4 blocks of 2 x 2).
+  double acc[8][8];  // [col index c = 2 qc + e][row index r = 2 qr + f]
 #pragma unroll
   for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -239,8 +242,8 @@ __device__ __forceinline__ void gemm_valu_body(const GemmArgs &g, double *lds) {
 
   for (long long kc = 0; kc < nk; ++kc) {
     const int cur = (int)(kc & 1);
-    const double *As = lds + cur * (2 * GK * GLD) + 8 * ty;
-    const double *Bs = lds + cur * (2 * GK * GLD) + GK * GLD + 8 * tx;
+    const double *As = lds + cur * (2 * GK * GLD) + 2 * ty;
+    const double *Bs = lds + cur * (2 * GK * GLD) + GK * GLD + 2 * tx;
     const bool more = kc + 1 < nk;
     if (more) {
       load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, (kc + 1) * GK, g.K, a_vec, ra);
@@ -249,11 +252,10 @@ __device__ __forceinline__ void gemm_valu_body(const GemmArgs &g, double *lds) {
 #pragma unroll 2
     for (int k = 0; k < GK; ++k) {
       double a[8], b[8];
-      const double2 *ap = reinterpret_cast<const double2 *>(As + k * GLD);
-      const double2 *bp = reinterpret_cast<const double2 *>(Bs + k * GLD);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double2 av = ap[q], bv = bp[q];
+        const double2 av = *reinterpret_cast<const double2 *>(As + k * GLD + 32 * q);
+        const double2 bv = *reinterpret_cast<const double2 *>(Bs + k * GLD + 32 * q);
         a[2 * q] = av.x; a[2 * q + 1] = av.y;
         b[2 * q] = bv.x; b[2 * q + 1] = bv.y;
       }
@@ -270,27 +272,26 @@ __device__ __forceinline__ void gemm_valu_body(const GemmArgs &g, double *lds) {
     __syncthreads();
   }
 
-  // epilogue: C += acc; a lane owns 8 consecutive rows (64 B) of 8 columns
+  // epilogue: C += acc; per (column, qr) a lane updates 2 consecutive rows (16 B),
+  // the 16 ty-lanes together 256 contiguous bytes
   const bool c_vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    const long long col = j0 + 8 * tx + c;
-    const long long row = i0 + 8 * ty;
+    const long long col = j0 + 32 * (c >> 1) + 2 * tx + (c & 1);
     if (col >= g.N) continue;
-    double *cp = g.C + row + col * g.ldc;
-    if (c_vec && row + 8 <= g.M) {
-      double2 *cv = reinterpret_cast<double2 *>(cp);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        double2 v = cv[q];
-        v.x += acc[c][2 * q];
-        v.y += acc[c][2 * q + 1];
-        cv[q] = v;
+    for (int qr = 0; qr < 4; ++qr) {
+      const long long row = i0 + 32 * qr + 2 * ty;
+      double *cp = g.C + row + col * g.ldc;
+      if (c_vec && row + 2 <= g.M) {
+        double2 v = *reinterpret_cast<double2 *>(cp);
+        v.x += acc[c][2 * qr];
+        v.y += acc[c][2 * qr + 1];
+        *reinterpret_cast<double2 *>(cp) = v;
+      } else {
+        if (row < g.M) cp[0] += acc[c][2 * qr];
+        if (row + 1 < g.M) cp[1] += acc[c][2 * qr + 1];
       }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (row + r < g.M) cp[r] += acc[c][r];
     }
   }
 }
