@@ -4,7 +4,6 @@
 // kernels of gram.hip / chol.hip / gemm.hip / reduce.hip on the context's
 // stream, reads back the small results.  No CPU arithmetic fallback exists.
 #include <atomic>
-#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -109,25 +108,6 @@ int agp_context_create(int device_id, agp_context **out) {
     AGP_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi));
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo));
-    // optional: a third stream whose kernels may not use the last AGP_FREE_CUS compute
-    // units, so that late-phase panel kernels find idle CUs (experiment, default off)
-    int free_cus = 0;
-    if (const char *e = getenv("AGP_FREE_CUS")) free_cus = atoi(e);
-    if (free_cus > 0 && free_cus < 128) {
-      hipDeviceProp_t prop;
-      AGP_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, device_id));
-      const int ncu = prop.multiProcessorCount;
-      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
-      // clear free_cus bits spread evenly over the mask
-      for (int i = 0; i < free_cus; ++i) {
-        const int cu = (int)(((long long)i * ncu) / free_cus) + ncu / (2 * free_cus);
-        mask[(size_t)cu / 32] &= ~(1u << (cu % 32));
-      }
-      if (hipExtStreamCreateWithCUMask(&ctx->stream3, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        ctx->stream3 = nullptr;
-      }
-    }
   }
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
@@ -163,7 +143,6 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
   delete ctx;
 }
 

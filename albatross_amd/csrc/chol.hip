@@ -487,18 +487,10 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     // U1: block column [kend, next_end), all rows below its diagonal
     timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
     if (next_end < n) {
-      // late phase: the masked stream (if any) leaves some CUs to the panel chain
-      static long long mask_below = -1;
-      if (mask_below < 0) {
-        const char *e = getenv("AGP_MASK_BELOW");
-        mask_below = e ? atoll(e) : 8192;
-      }
-      hipStream_t su = (ctx->stream3 && n - next_end <= mask_below) ? ctx->stream3 : sb;
-      if (su != sb && have_u2) (void)hipStreamWaitEvent(su, ctx->ev_b, 0);  // order after the previous bulk update
-      (void)hipStreamWaitEvent(su, ctx->ev_a, 0);
+      (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       const double *Q = A + K0 * lda + next_end;
-      timed_gemm(su, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true);
-      (void)hipEventRecord(ctx->ev_b, su);
+      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true);
+      (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;
     } else {
       have_u2 = false;

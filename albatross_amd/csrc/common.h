@@ -46,7 +46,6 @@ struct agp_context {
   int device = 0;
   hipStream_t stream = nullptr;   // main chain
   hipStream_t stream2 = nullptr;  // look-ahead / side chain
-  hipStream_t stream3 = nullptr;  // as stream2, but restricted by a CU mask (late-phase bulk updates)
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   std::vector<hipEvent_t> ev_pool;
   std::string last_error;
