@@ -38,6 +38,11 @@ struct GemmArgs {
   long long M, N, K;
   int tri;  // skip tiles strictly above the diagonal of C
   int ntr, ntc;
+  // XCD-aware order (bulk update only): workgroups b, b+8, b+16, ... share an
+  // XCD (round-robin dispatch); the 64 that run there together are dealt one
+  // 8 x 8 super-tile of C, so they share 8 row strips and 8 column strips of
+  // the panel in that XCD's L2.  nsuper = number of lower super-tiles.
+  int remap, nsuper, nb8;
 };
 
 // Load this thread's 8 doubles of a 128 x 16 operand chunk.
@@ -107,11 +112,21 @@ __device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const doubl
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
-__device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds) {
-
-  // ---- which tile ----
-  int bj = 0;
+// Which C tile a workgroup computes.  Returns false for padding workgroups.
+__device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int &bi, int &bj) {
+  if (g.remap) {
+    const unsigned b = blockIdx.x;
+    const int xcd = (int)(b & 7), l = (int)(b >> 3);
+    const int s = (l >> 6) * 8 + xcd, within = l & 63;
+    if (s >= g.nsuper) return false;
+    int sj = 0, left = s;
+    while (left >= g.nb8 - sj) { left -= g.nb8 - sj; ++sj; }
+    const int si = sj + left;
+    bi = 8 * si + (within & 7);
+    bj = 8 * sj + (within >> 3);
+    return bi < g.ntr && bj < g.ntc && bi >= bj;
+  }
+  bj = 0;
   long long id = blockIdx.x;
   while (true) {
     const int cnt = g.tri ? (g.ntr - bj) : g.ntr;
@@ -119,7 +134,14 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
     id -= cnt;
     ++bj;
   }
-  const int bi = (g.tri ? bj : 0) + (int)id;
+  bi = (g.tri ? bj : 0) + (int)id;
+  return true;
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds) {
+  int bi, bj;
+  if (!tile_of_block(g, bi, bj)) return;
   const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -208,15 +230,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g
 // ---------------------------------------------------------------------------
 template <bool A_KMAJOR, bool B_KMAJOR>
 __device__ __forceinline__ void gemm_valu_body(const GemmArgs &g, double *lds) {
-  int bj = 0;
-  long long id = blockIdx.x;
-  while (true) {
-    const int cnt = g.tri ? (g.ntr - bj) : g.ntr;
-    if (id < cnt) break;
-    id -= cnt;
-    ++bj;
-  }
-  const int bi = (g.tri ? bj : 0) + (int)id;
+  int bi, bj;
+  if (!tile_of_block(g, bi, bj)) return;
   const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // tx: column group, ty: row group
 
@@ -323,6 +338,7 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
   GemmArgs g;
   g.C = C; g.ldc = ldc; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
   g.M = M; g.N = N; g.K = K; g.tri = tri ? 1 : 0;
+  g.remap = 0; g.nsuper = 0; g.nb8 = 0;
   g.ntr = (int)((M + GT - 1) / GT);
   g.ntc = (int)((N + GT - 1) / GT);
   if (tri && g.ntc > g.ntr) g.ntc = g.ntr;
@@ -343,7 +359,19 @@ void launch_trailing_update(hipStream_t s, double *C, long long ldc, const doubl
   g.M = M; g.N = M; g.K = K; g.tri = 1;
   g.ntr = (int)((M + GT - 1) / GT);
   g.ntc = g.ntr;
-  const long long tiles = count_tiles(g.ntr, g.ntc, 1);
+  g.remap = 0; g.nsuper = 0; g.nb8 = 0;
+  long long tiles = count_tiles(g.ntr, g.ntc, 1);
+  static int use_remap = -1;
+  if (use_remap < 0) {
+    const char *e = getenv("AGP_XCD_REMAP");
+    use_remap = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (use_remap && g.ntr >= 16) {
+    g.remap = 1;
+    g.nb8 = (g.ntr + 7) / 8;
+    g.nsuper = g.nb8 * (g.nb8 + 1) / 2;
+    tiles = (long long)((g.nsuper + 7) / 8) * 8 * 64;
+  }
   static int use_valu = -1;
   if (use_valu < 0) {
     const char *e = getenv("AGP_UPDATE_VALU");
