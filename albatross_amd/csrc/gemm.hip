@@ -324,6 +324,119 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmAr
   gemm_nt_sub_body<false, false>(g, lds);
 }
 
+// ---------------------------------------------------------------------------
+// 64 x 64-tile variant for launches too small to fill the chip with 128 x 128
+// tiles (the next-panel and inner updates of the serial panel chain): four
+// times as many, four times shorter workgroups, 3-4 of them per CU.
+// Panel-major operands only.
+// ---------------------------------------------------------------------------
+constexpr int ST = 64;         // small tile edge
+constexpr int SLD = ST + 16;   // LDS pitch (pitch mod 32 == 16: conflict-free fragment reads)
+
+__device__ __forceinline__ void load_chunk64(const double *__restrict__ P, long long ld, long long row0,
+                                             long long nrows, long long k0, long long K, bool vec_ok,
+                                             double (&r)[4]) {
+  const int t = threadIdx.x;
+  const int kk = t >> 4, seg = (t & 15) * 4;
+  const long long row = row0 + seg, k = k0 + kk;
+  const double *p = P + row + k * ld;
+  const bool fast = vec_ok && (row0 + ST <= nrows) && (k0 + GK <= K);
+  if (fast) {
+    const double2 a = *reinterpret_cast<const double2 *>(p);
+    const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+    r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (k < K && row + q < nrows) ? p[q] : 0.;
+  }
+}
+
+template <bool NEGATE>
+__device__ __forceinline__ void store_chunk64(double *__restrict__ Ls, const double (&r)[4]) {
+  const int t = threadIdx.x;
+  const int kk = t >> 4, seg = (t & 15) * 4;
+  double2 *dst = reinterpret_cast<double2 *>(Ls + kk * SLD + seg);
+  dst[0] = NEGATE ? make_double2(-r[0], -r[1]) : make_double2(r[0], r[1]);
+  dst[1] = NEGATE ? make_double2(-r[2], -r[3]) : make_double2(r[2], r[3]);
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs g) {
+  __shared__ double lds[2 * 2 * GK * SLD];
+  int bj = 0;
+  long long id = blockIdx.x;
+  while (true) {
+    // tri: column bj of 64-tiles holds the row tiles bi >= bj
+    const int cnt = g.tri ? (g.ntr - bj) : g.ntr;
+    if (id < cnt) break;
+    id -= cnt;
+    ++bj;
+  }
+  const int bi = (g.tri ? bj : 0) + (int)id;
+  const long long i0 = (long long)bi * ST, j0 = (long long)bj * ST;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ln = lane & 15, lg = lane >> 4;
+  const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
+
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = v4zero();
+  double ra[4], rb[4];
+  const long long nk = (g.K + GK - 1) / GK;
+  load_chunk64(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
+  load_chunk64(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb);
+  store_chunk64<false>(lds, ra);
+  store_chunk64<true>(lds + GK * SLD, rb);
+  __syncthreads();
+  for (long long kc = 0; kc < nk; ++kc) {
+    const int cur = (int)(kc & 1);
+    const double *As = lds + cur * (2 * GK * SLD);
+    const double *Bs = As + GK * SLD;
+    const bool more = kc + 1 < nk;
+    if (more) {
+      load_chunk64(g.A, g.lda, i0, g.M, (kc + 1) * GK, g.K, a_vec, ra);
+      load_chunk64(g.B, g.ldb, j0, g.N, (kc + 1) * GK, g.K, b_vec, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < GK / 4; ++s) {
+      const int krow = (4 * s + lg) * SLD;
+      double fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = Bs[krow + 32 * wc + 16 * t + ln];
+        fb[t] = As[krow + 32 * wr + 16 * t + ln];
+      }
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
+    }
+    if (more) {
+      double *An = lds + (cur ^ 1) * (2 * GK * SLD);
+      store_chunk64<false>(An, ra);
+      store_chunk64<true>(An + GK * SLD, rb);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const long long row = i0 + 32 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
+        if (row < g.M && col < g.N) {
+          double *c = g.C + row + col * g.ldc;
+          *c = *c + acc[tj][ti][r];
+        }
+      }
+    }
+}
+
 static long long count_tiles(int ntr, int ntc, int tri) {
   long long total = 0;
   for (int bj = 0; bj < ntc; ++bj) total += tri ? (ntr - bj > 0 ? ntr - bj : 0) : ntr;
@@ -344,6 +457,21 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
   if (tri && g.ntc > g.ntr) g.ntc = g.ntr;
   const long long tiles = count_tiles(g.ntr, g.ntc, g.tri);
   if (tiles <= 0) return;
+  // fewer 128-tiles than workgroup slots (2 per CU): use 64 x 64 tiles instead
+  static int small_limit = -1;
+  if (small_limit < 0) {
+    const char *e = getenv("AGP_SMALL_TILE_LIMIT");
+    small_limit = e ? atoi(e) : 512;
+  }
+  if (!a_kmajor && !b_kmajor && tiles < small_limit) {
+    GemmArgs h = g;
+    h.ntr = (int)((M + ST - 1) / ST);
+    h.ntc = (int)((N + ST - 1) / ST);
+    if (tri && h.ntc > h.ntr) h.ntc = h.ntr;
+    const long long t64 = count_tiles(h.ntr, h.ntc, h.tri);
+    hipLaunchKernelGGL(gemm64_nt_sub_kernel, dim3((unsigned)t64), dim3(GEMM_THREADS), 0, s, h);
+    return;
+  }
   dim3 grid((unsigned)tiles), block(GEMM_THREADS);
   if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<false, false>), grid, block, 0, s, g);
   else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<false, true>), grid, block, 0, s, g);

@@ -50,6 +50,8 @@ def test_mfma_peak_is_sane(ctx):
     (128, 128, 16, 0, 0, 0), (256, 128, 128, 0, 0, 0), (384, 384, 512, 1, 0, 0),
     (200, 130, 70, 0, 0, 0), (333, 333, 129, 1, 0, 0), (257, 100, 128, 0, 0, 1),
     (140, 90, 50, 0, 1, 1), (300, 64, 128, 0, 1, 0), (130, 130, 1000, 1, 1, 1),
+    # >= 512 tiles of 128 x 128: the large-tile kernel (smaller launches use 64 x 64 tiles)
+    (4500, 4500, 48, 1, 0, 0), (3000, 2900, 40, 0, 0, 0), (70, 70, 300, 1, 0, 0),
 ])
 def test_gemm_nt_sub(ctx, dbg, M, N, K, tri, akm, bkm):
     rng = np.random.default_rng(M * 7 + N * 3 + K)
