@@ -345,8 +345,8 @@ static int copy_out_2d(agp_context *ctx, const double *dev, long long ld_dev, lo
 
 // Gram + diag add + LL^T (+ fused forward substitution) on A / y.  On return
 // the stream has been synchronised and ctx->h_flags / h_scalars are valid.
-static int build_and_factor(agp_context *c, const DevProgram *dprog, const FeatView &xm, double *A, long long lda,
-                            double *invd, double *y, const double *yvar) {
+static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevProgram *hprog, const FeatView &xm,
+                            double *A, long long lda, double *invd, double *y, const double *yvar) {
   agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
   const long long n = xm.n;
   hipStream_t s = ctx->stream;
@@ -355,7 +355,7 @@ static int build_and_factor(agp_context *c, const DevProgram *dprog, const FeatV
   const bool prof = ctx->profiling;
   if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[0], s));
   // as_measurements(features) -> covariance_function_(measurement_features)   gp.hpp:288-290
-  launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, A, lda, yvar, ctx->d_flags);
+  launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, A, lda, yvar, ctx->d_flags, hprog);
   if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[1], s));
   FactorTimers timers;
   if (prof) {
@@ -422,7 +422,7 @@ int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x, const
   if (y && (st = to_device(ctx, y, false, &dy)) != AGP_OK) { dx.release(); return st; }
   const FeatView &vy = y ? dy.v : dx.v;
   if (out_location == AGP_DEVICE) {
-    launch_gram(ctx->stream, dprog, dx.v, vy, y == nullptr, false, out, ld, nullptr, nullptr);
+    launch_gram(ctx->stream, dprog, dx.v, vy, y == nullptr, false, out, ld, nullptr, nullptr, &k->prog);
     st = AGP_OK;
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); st = AGP_ERR_HIP; }
@@ -430,7 +430,7 @@ int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x, const
     const long long ldd = round_up(rows, 2);
     st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)ldd * (size_t)cols);
     if (st == AGP_OK) {
-      launch_gram(ctx->stream, dprog, dx.v, vy, y == nullptr, false, ctx->ws_aux, ldd, nullptr, nullptr);
+      launch_gram(ctx->stream, dprog, dx.v, vy, y == nullptr, false, ctx->ws_aux, ldd, nullptr, nullptr, &k->prog);
       st = copy_out_2d(ctx, ctx->ws_aux, ldd, rows, cols, out, ld, AGP_HOST);
     }
   }
@@ -518,7 +518,7 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   if (x->location == AGP_HOST) FIT_CHECK(hipStreamSynchronize(s));
   FeatView xm = fit->train.v;
   xm.meas = 1;  // as_measurements(features), gp.hpp:288
-  st = build_and_factor(ctx, dprog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d);
+  st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d);
   if (yvar_d) { (void)hipFree(yvar_d); yvar_d = nullptr; }
   if (st != AGP_OK) { agp_fit_destroy(fit); return st; }
   st = status_from_flags(ctx);
@@ -604,7 +604,7 @@ int agp_nll(agp_context *c, const agp_kernel *k, const agp_features *x, const do
   if (y_var && (st = vector_to_device(ctx, y_var, n, x->location, yvar_d)) != AGP_OK) { dx.release(); return st; }
   FeatView xm = dx.v;
   xm.meas = 1;
-  st = build_and_factor(ctx, dprog, xm, A, lda, invd, z, yvar_d);
+  st = build_and_factor(ctx, dprog, &k->prog, xm, A, lda, invd, z, yvar_d);
   if (st == AGP_OK) st = status_from_flags(ctx);
   if (st == AGP_OK) {
     // mahalanobis = y^T K^-1 y = z^T z with z = L^-1 y   (likelihood.hpp:44)
@@ -686,7 +686,7 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
   // mean (gp.hpp:82-85)
   launch_predict_mean(s, dprog, fit->train.v, dxs.v, fit->alpha, mean_d);
   // cross_cov = cov(train_features, features)   (gp.hpp:316,337)
-  launch_gram(s, dprog, fit->train.v, dxs.v, false, false, V, ldv, nullptr, nullptr);
+  launch_gram(s, dprog, fit->train.v, dxs.v, false, false, V, ldv, nullptr, nullptr, &k->prog);
   // V = L^-1 K*  ;  explained = V^T V  (== K*^T K^-1 K*, gp.hpp:96,111)
   forward_solve_mat(s, fit->A, n, fit->lda, fit->invd, V, m, ldv);
   if (!joint) {
@@ -695,7 +695,7 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
     st = copy_out(ctx, mean_d, m, mean, out_location);
     if (st == AGP_OK) st = copy_out(ctx, prior, m, var_or_cov, out_location);
   } else {
-    launch_gram(s, dprog, dxs.v, dxs.v, true, false, prior, ldc, nullptr, nullptr);  // prior_cov, gp.hpp:317
+    launch_gram(s, dprog, dxs.v, dxs.v, true, false, prior, ldc, nullptr, nullptr, &k->prog);  // prior_cov, gp.hpp:317
     launch_gemm_nt_sub(s, prior, ldc, V, ldv, true, V, ldv, true, m, m, n, true);   // lower tiles
     launch_symmetrize(s, prior, ldc, m);
     st = copy_out(ctx, mean_d, m, mean, out_location);

@@ -30,7 +30,7 @@ int agp_blk_gram(agp_context *ctx, const agp_kernel *k, const agp_features *rows
   if ((st = features_to_device(ctx, cols, false, &dc)) != AGP_OK) { dr.release(); return st; }
   hipError_t e = hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), ctx->stream);
   launch_gram(ctx->stream, dprog, dr.v, dc.v, /*symmetric=*/true, /*lower_only=*/true, out, ld, diag_add,
-              ctx->d_flags);
+              ctx->d_flags, &k->prog);
   if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   dr.release();

@@ -586,26 +586,31 @@ void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long l
   hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
 }
 
-// x_b = Winv_b^T z_b ; one wave per column, columns strided over 4 waves
-__global__ __launch_bounds__(256) void diag_back_kernel(const double *__restrict__ Winv, int nbk,
+// x_b = Winv_b^T z_b : 8 waves, 16 columns each, all 16 column segments of a
+// wave requested before the first is consumed (one L2 round trip per step —
+// this kernel sits on the serial chain of the back substitution)
+__global__ __launch_bounds__(512) void diag_back_kernel(const double *__restrict__ Winv, int nbk,
                                                         double *__restrict__ zb) {
   __shared__ double out[NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double2 zv = (2 * lane + 1 < nbk) ? *reinterpret_cast<const double2 *>(zb + 2 * lane)
                                           : make_double2(2 * lane < nbk ? zb[2 * lane] : 0., 0.);
-  for (int c0 = wave * 32; c0 < wave * 32 + 32; c0 += 8) {
-    double acc[8];
+  const int c0 = wave * 16;
+  double2 w[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const double2 w = *reinterpret_cast<const double2 *>(Winv + (c0 + q) * NB + 2 * lane);
-      acc[q] = w.x * zv.x + w.y * zv.y;
-    }
+  for (int q = 0; q < 16; ++q) w[q] = *reinterpret_cast<const double2 *>(Winv + (c0 + q) * NB + 2 * lane);
+  double acc[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < 16; ++q) acc[q] = w[q].x * zv.x + w[q].y * zv.y;
+  // 16 values per lane -> 16 column sums: fold halves (transpose-reduce), 6 steps
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
-      if (lane == 0) out[c0 + q] = acc[q];
-    }
+  for (int q = 0; q < 16; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[c0 + q] = acc[q];
   }
   __syncthreads();
   if (threadIdx.x < nbk) zb[threadIdx.x] = out[threadIdx.x];
@@ -664,7 +669,7 @@ void backward_solve_vec(hipStream_t s, const double *A, long long n, long long l
   for (long long b = nblk - 1; b >= 0; --b) {
     const long long k = b * NB;
     const int nbk = (int)((n - k < NB) ? n - k : NB);
-    hipLaunchKernelGGL(diag_back_kernel, dim3(1), dim3(256), 0, s, Winv + b * (long long)(NB * NB), nbk, z + k);
+    hipLaunchKernelGGL(diag_back_kernel, dim3(1), dim3(512), 0, s, Winv + b * (long long)(NB * NB), nbk, z + k);
     if (k > 0) launch_back_update(s, A, lda, k, nbk, k, z + k, z);
   }
 }

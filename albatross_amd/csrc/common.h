@@ -99,7 +99,7 @@ namespace agp {
 // ---- launchers implemented in the .hip files ----
 void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y,
                  bool symmetric, bool lower_only, double *out, long long ld,
-                 const double *diag_add, int *nan_flag);
+                 const double *diag_add, int *nan_flag, const DevProgram *host_program = nullptr);
 void launch_gram_diagonal(hipStream_t s, const DevProgram *P, const FeatView &X, double *out);
 // mean_j = sum_i k(x_i, xs_j) alpha_i without materialising the cross Gram
 void launch_predict_mean(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &XS,

@@ -7,6 +7,7 @@
 // rows, so each wave store is 64 lanes x 16 B = 1 KiB of one output column
 // (fully coalesced), and the y-point of a column is an LDS broadcast read.
 // HBM-write bound: 8 B per entry out, 8*dim B per point in.
+#include <cstdlib>
 #include "common.h"
 
 namespace agp {
@@ -109,6 +110,168 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const DevProgram *__
   if (saw_nan && nan_flag) atomicOr(nan_flag, 1);
 }
 
+// ---------------------------------------------------------------------------
+// Fast path for the commonest trees:  radial<Euclidean>  and
+// radial<Euclidean> + [measurement_only](IndependentNoise | Nugget).
+// Same tile shape and the same IEEE operation sequence per pair as the generic
+// evaluator (distance -> q -> exp), but the tree is fixed at compile time: no
+// program walk, no evaluation stack.  ~2.5x fewer VALU instructions per pair.
+// ---------------------------------------------------------------------------
+struct FastParams {
+  double length_scale, sigma;
+  double noise_var;   // sigma_noise^2 (0 when there is no noise term)
+  int has_noise;      // tree is radial + noise
+  int noise_meas_only;  // the noise term is wrapped in MeasurementOnly
+};
+
+template <int OP>
+__device__ __forceinline__ double radial_value(double dist, double l, double sigma) {
+  if (l <= 0.) return 0.;
+  if (OP == AGP_OP_SQUARED_EXPONENTIAL) {
+    const double q = dist / l;
+    return sigma * sigma * exp(-(q * q));
+  } else if (OP == AGP_OP_EXPONENTIAL) {
+    return sigma * sigma * exp(-fabs(dist / l));
+  } else if (OP == AGP_OP_MATERN32) {
+    const double q = sqrt(3.) * dist / l;
+    return sigma * sigma * (1 + q) * exp(-q);
+  } else {
+    const double q = sqrt(5.) * dist / l;
+    return sigma * sigma * (1 + q + q * q / 3.) * exp(-q);
+  }
+}
+
+template <int DIMP, int OP>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_fast_kernel(FastParams fp, FeatView X, FeatView Y, int lower_only,
+                                                                 double *out, long long ld, const double *diag_add,
+                                                                 int *nan_flag) {
+  __shared__ double xs[DIMP][TM], ys[DIMP][TN];
+  __shared__ long long xid[TM], yid[TN];
+  const long long row0 = (long long)blockIdx.x * TM;
+  const long long col0 = (long long)blockIdx.y * TN;
+  if (lower_only && col0 > row0 + TM - 1) return;
+  const bool have_ids = X.ids != nullptr && Y.ids != nullptr;
+  for (int t = threadIdx.x; t < TM + TN; t += GRAM_THREADS) {
+    const bool isx = t < TM;
+    const FeatView &F = isx ? X : Y;
+    const long long g = isx ? row0 + t : col0 + (t - TM);
+    const bool ok = g < F.n;
+#pragma unroll
+    for (int d = 0; d < DIMP; ++d) {
+      const double v = (ok && d < F.dim) ? F.coords[g * F.dim + d] : 0.;
+      if (isx) xs[d][t] = v; else ys[d][t - TM] = v;
+    }
+    const long long id = (ok && F.ids) ? F.ids[g] : -1;
+    if (isx) xid[t] = id; else yid[t - TM] = id;
+  }
+  __syncthreads();
+  const int lane_row = 2 * (threadIdx.x & 63);
+  const int cgrp = threadIdx.x >> 6;
+  double xa[DIMP], xb[DIMP];
+#pragma unroll
+  for (int d = 0; d < DIMP; ++d) { xa[d] = xs[d][lane_row]; xb[d] = xs[d][lane_row + 1]; }
+  const long long ida = xid[lane_row], idb = xid[lane_row + 1];
+  const long long ra = row0 + lane_row, rb = ra + 1;
+  const bool wide = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const bool noise_on = fp.has_noise && (!fp.noise_meas_only || (X.meas && Y.meas));
+  bool saw_nan = false;
+#pragma unroll 2
+  for (int jj = 0; jj < TN / 4; ++jj) {
+    const int cslot = cgrp * (TN / 4) + jj;
+    const long long col = col0 + cslot;
+    if (col >= Y.n) break;
+    double da, db;
+    bool ea = true, eb = true;
+    if (DIMP == 1) {
+      const double y0 = ys[0][cslot];
+      da = fabs(xa[0] - y0);
+      db = fabs(xb[0] - y0);
+      ea = xa[0] == y0;
+      eb = xb[0] == y0;
+    } else {
+      double sa = 0., sb = 0.;
+#pragma unroll
+      for (int d = 0; d < DIMP; ++d) {
+        const double yd = ys[d][cslot];
+        const double ta = xa[d] - yd, tb = xb[d] - yd;
+        sa += ta * ta;
+        sb += tb * tb;
+        ea = ea && (xa[d] == yd);
+        eb = eb && (xb[d] == yd);
+      }
+      da = sqrt(sa);
+      db = sqrt(sb);
+    }
+    if (have_ids) {
+      ea = ida == yid[cslot];
+      eb = idb == yid[cslot];
+    }
+    double va = radial_value<OP>(da, fp.length_scale, fp.sigma);
+    double vb = radial_value<OP>(db, fp.length_scale, fp.sigma);
+    if (fp.has_noise) {  // lhs + rhs with rhs = noise (0 when not measurements / not equal)
+      va = va + ((noise_on && ea) ? fp.noise_var : 0.);
+      vb = vb + ((noise_on && eb) ? fp.noise_var : 0.);
+    }
+    if (diag_add) {
+      if (ra == col) va += diag_add[col];
+      if (rb == col) vb += diag_add[col];
+    }
+    saw_nan = saw_nan || (va != va) || (vb != vb);
+    double *dst = out + col * ld + ra;
+    if (rb < X.n) {
+      if (wide) *reinterpret_cast<double2 *>(dst) = make_double2(va, vb);
+      else { dst[0] = va; dst[1] = vb; }
+    } else if (ra < X.n) {
+      dst[0] = va;
+    }
+  }
+  if (saw_nan && nan_flag) atomicOr(nan_flag, 1);
+}
+
+// Does the program have one of the fast-path shapes?
+static bool match_fast(const DevProgram &H, FastParams *fp, int *op) {
+  const agp_kernel_node *n = H.nodes;
+  if (H.n_nodes < 1 || n[0].op > AGP_OP_MATERN52 || n[0].metric != AGP_METRIC_EUCLIDEAN) return false;
+  *op = n[0].op;
+  fp->length_scale = n[0].params[0];
+  fp->sigma = n[0].params[1];
+  fp->noise_var = 0.; fp->has_noise = 0; fp->noise_meas_only = 0;
+  if (H.n_nodes == 1) return true;
+  const bool is_noise = n[1].op == AGP_OP_INDEPENDENT_NOISE || n[1].op == AGP_OP_NUGGET;
+  if (!is_noise) return false;
+  if (H.n_nodes == 3 && n[2].op == AGP_OP_SUM) {
+    fp->has_noise = 1; fp->noise_var = n[1].params[0] * n[1].params[0];
+    return true;
+  }
+  if (H.n_nodes == 4 && n[2].op == AGP_OP_MEASUREMENT_ONLY && n[3].op == AGP_OP_SUM) {
+    fp->has_noise = 1; fp->noise_meas_only = 1; fp->noise_var = n[1].params[0] * n[1].params[0];
+    return true;
+  }
+  return false;
+}
+
+template <int DIMP>
+static bool launch_gram_fast_t(hipStream_t s, const FastParams &fp, int op, const FeatView &X, const FeatView &Y,
+                               bool lower_only, double *out, long long ld, const double *diag_add, int *nan_flag) {
+  dim3 grid((unsigned)((X.n + TM - 1) / TM), (unsigned)((Y.n + TN - 1) / TN)), block(GRAM_THREADS);
+  const int lo = lower_only ? 1 : 0;
+  switch (op) {
+  case AGP_OP_SQUARED_EXPONENTIAL:
+    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_SQUARED_EXPONENTIAL>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag);
+    return true;
+  case AGP_OP_EXPONENTIAL:
+    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_EXPONENTIAL>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag);
+    return true;
+  case AGP_OP_MATERN32:
+    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_MATERN32>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag);
+    return true;
+  case AGP_OP_MATERN52:
+    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_MATERN52>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag);
+    return true;
+  default: return false;
+  }
+}
+
 template <int DIMP>
 static void launch_gram_t(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y,
                           bool symmetric, bool lower_only, double *out, long long ld,
@@ -119,9 +282,28 @@ static void launch_gram_t(hipStream_t s, const DevProgram *P, const FeatView &X,
 }
 
 void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y, bool symmetric,
-                 bool lower_only, double *out, long long ld, const double *diag_add, int *nan_flag) {
+                 bool lower_only, double *out, long long ld, const double *diag_add, int *nan_flag,
+                 const DevProgram *host_program) {
   if (X.n == 0 || Y.n == 0) return;
   const int dim = X.dim;
+  if (host_program && dim <= 3) {
+    // (the fast shapes are bitwise symmetric in their arguments, so `symmetric`
+    // needs no special handling)
+    FastParams fp;
+    int op = 0;
+    static int fast_on = -1;
+    if (fast_on < 0) {
+      const char *e = getenv("AGP_GRAM_FAST");
+      fast_on = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (fast_on && match_fast(*host_program, &fp, &op)) {
+      bool done = false;
+      if (dim == 1) done = launch_gram_fast_t<1>(s, fp, op, X, Y, lower_only, out, ld, diag_add, nan_flag);
+      else if (dim == 2) done = launch_gram_fast_t<2>(s, fp, op, X, Y, lower_only, out, ld, diag_add, nan_flag);
+      else done = launch_gram_fast_t<3>(s, fp, op, X, Y, lower_only, out, ld, diag_add, nan_flag);
+      if (done) return;
+    }
+  }
   if (dim == 1) launch_gram_t<1>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
   else if (dim == 2) launch_gram_t<2>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
   else if (dim == 3) launch_gram_t<3>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
