@@ -13,6 +13,9 @@
 namespace agp {
 void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n);
 void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n);
+void launch_set_identity(hipStream_t s, double *B, long long ld, long long n);
+void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const double *information, long long n,
+                double *mean, double *variance);
 
 void DeviceFeatures::release() {
   for (void *&p : owned) {
@@ -636,6 +639,50 @@ int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs, int64_t n
   forward_solve_mat(ctx->stream, fit->A, n, fit->lda, fit->invd, ctx->ws_aux, nrhs, ldb);
   backward_solve_mat(ctx->stream, fit->A, n, fit->lda, fit->invd, ctx->ws_aux, nrhs, ldb);
   return copy_out_2d(ctx, ctx->ws_aux, ldb, n, nrhs, out, n, location);
+}
+
+// ---- leave-one-out fast path ---------------------------------------------------
+// diag(K^-1) into ws_aux[ldr * n ...]; returns the device pointer of the n results
+static int inverse_diagonal_device(agp_context *ctx, const agp_fit *fit, double **diag_out) {
+  const long long n = fit->n, ldr = factor_ld(n);
+  const size_t r_elems = (size_t)ldr * (size_t)n;
+  int st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (r_elems + 3 * (size_t)round_up(n, 2)));
+  if (st != AGP_OK) return st;
+  double *R = ctx->ws_aux, *diag = R + r_elems;
+  hipStream_t s = ctx->stream;
+  launch_set_identity(s, R, ldr, n);
+  // R = L^-1 (serializable_ldlt.hpp:154-160), exploiting the triangular right-hand side
+  forward_solve_mat(s, fit->A, n, fit->lda, fit->invd, R, n, ldr, /*rhs_lower=*/true);
+  // (K^-1)_ii = || R[:, i] ||^2   (sub_matrix^T * sub_matrix, :171-172)
+  launch_coldot(s, R, ldr, R, ldr, n, n, diag, -1.0, nullptr);
+  AGP_HIP_CHECK(ctx, hipGetLastError());
+  *diag_out = diag;
+  return AGP_OK;
+}
+
+int agp_fit_inverse_diagonal(agp_context *ctx, const agp_fit *fit, double *out, int out_location) {
+  if (!ctx || !fit || !out || !fit->A) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  double *diag = nullptr;
+  int st = inverse_diagonal_device(ctx, fit, &diag);
+  if (st != AGP_OK) return st;
+  return copy_out(ctx, diag, fit->n, out, out_location);
+}
+
+int agp_loo_marginal(agp_context *ctx, const agp_fit *fit, const double *y, double *mean, double *variance,
+                     int location) {
+  if (!ctx || !fit || !y || !mean || !variance || !fit->A) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const long long n = fit->n;
+  double *diag = nullptr;
+  int st = inverse_diagonal_device(ctx, fit, &diag);
+  if (st != AGP_OK) return st;
+  double *yd = diag + round_up(n, 2), *md = yd + round_up(n, 2);  // mean overwrites... separate slots below
+  if ((st = vector_to_device(ctx, y, n, location, yd)) != AGP_OK) return st;
+  // variance is written over the diag slot's successor: reuse `diag` for the variance after reading it
+  launch_loo(ctx->stream, diag, yd, fit->alpha, n, md, diag);
+  if ((st = copy_out(ctx, md, n, mean, location)) != AGP_OK) return st;
+  return copy_out(ctx, diag, n, variance, location);
 }
 
 // ---- predict ---------------------------------------------------------------

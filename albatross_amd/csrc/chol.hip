@@ -506,7 +506,9 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
 // multi-RHS triangular solves (K4): B <- L^-1 B and B <- L^-T B
 // ---------------------------------------------------------------------------
 void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
-                       double *B, long long m, long long ldb) {
+                       double *B, long long m, long long ldb, bool rhs_lower) {
+  // rhs_lower: column j of B is zero above row j (e.g. the identity): block row
+  // k then only has work in its first k + nbk columns (N^3/3 instead of N^3 flop)
   if (m <= 0) return;
   for (long long K0 = 0; K0 < n; K0 += NBO) {
     const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
@@ -517,18 +519,21 @@ void forward_solve_mat(hipStream_t s, const double *A, long long n, long long ld
       t.nbk = nbk;
       t.Y = B + k;
       t.stride_m = 1; t.stride_n = ldb;
-      t.ncols = m;
+      const long long m_act = (rhs_lower && k + nbk < m) ? k + nbk : m;
+      t.ncols = m_act;
       t.z = nullptr; t.yrest = nullptr;
       t.batch_img = t.batch_Y = 0; t.n_total = 0;
-      hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, t);
+      hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m_act + 63) / 64)), dim3(256), 0, s, t);
       const long long rows = kend - (k + nbk);
       if (rows > 0)  // B[k+nbk : kend] -= L[k+nbk : kend, k : k+nbk] B[k : k+nbk]
-        launch_gemm_nt_sub(s, B + k + nbk, ldb, A + k * lda + (k + nbk), lda, false, B + k, ldb, true, rows, m,
+        launch_gemm_nt_sub(s, B + k + nbk, ldb, A + k * lda + (k + nbk), lda, false, B + k, ldb, true, rows, m_act,
                            nbk, false);
     }
-    if (kend < n)  // B[kend :] -= L[kend :, K0 : kend] B[K0 : kend]
-      launch_gemm_nt_sub(s, B + kend, ldb, A + K0 * lda + kend, lda, false, B + K0, ldb, true, n - kend, m,
+    if (kend < n) {  // B[kend :] -= L[kend :, K0 : kend] B[K0 : kend]
+      const long long m_act = (rhs_lower && kend < m) ? kend : m;
+      launch_gemm_nt_sub(s, B + kend, ldb, A + K0 * lda + kend, lda, false, B + K0, ldb, true, n - kend, m_act,
                          kend - K0, false);
+    }
   }
 }
 

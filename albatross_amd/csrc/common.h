@@ -126,7 +126,7 @@ void backward_solve_vec(hipStream_t s, const double *A, long long n, long long l
                         double *z);
 // B (n x m, ldb) <- L^-1 B
 void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
-                       double *B, long long m, long long ldb);
+                       double *B, long long m, long long ldb, bool rhs_lower = false);
 // B (n x m, ldb) <- L^-T B
 void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                         double *B, long long m, long long ldb);

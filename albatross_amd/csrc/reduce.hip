@@ -87,4 +87,34 @@ void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n) {
   hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)n), dim3(256), 0, s, A, ld, n);
 }
 
+// B (n x n, ld) <- identity
+__global__ __launch_bounds__(256) void set_identity_kernel(double *B, long long ld, long long n) {
+  const long long col = blockIdx.x;
+  for (long long r = threadIdx.x; r < n; r += 256) B[col * ld + r] = (r == col) ? 1. : 0.;
+}
+
+void launch_set_identity(hipStream_t s, double *B, long long ld, long long n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)n), dim3(256), 0, s, B, ld, n);
+}
+
+// leave-one-out marginals from diag(K^-1): cross_validation_utils.hpp:138-163,171-186
+// (variance may alias kinv_diag: every thread reads its element before writing it)
+__global__ __launch_bounds__(256) void loo_kernel(const double *kinv_diag, const double *__restrict__ y,
+                                                  const double *__restrict__ information, long long n,
+                                                  double *__restrict__ mean, double *variance) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double d = kinv_diag[i];
+  mean[i] = y[i] - information[i] / d;  // y - A_ldlt.solve(v) for a 1 x 1 block
+  variance[i] = 1. / d;                 // leave_one_out_conditional_variance
+}
+
+void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const double *information, long long n,
+                double *mean, double *variance) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(loo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kinv_diag, y, information, n, mean,
+                     variance);
+}
+
 }  // namespace agp

@@ -255,6 +255,22 @@ class GPFit:
                          "agp_solve")
         return out.reshape(rhs.shape, order="F")
 
+    def inverse_diagonal(self):
+        """SerializableLDLT::inverse_diagonal (serializable_ldlt.hpp:181-199)."""
+        out = np.empty(self.n)
+        self._ctx._check(self._ctx._lib.agp_fit_inverse_diagonal(self._ctx._h, self._h, _ptr(out), capi.HOST),
+                         "agp_fit_inverse_diagonal")
+        return out
+
+    def leave_one_out(self, target_mean):
+        """Leave-one-out predictive marginals of every training point
+        (held_out_predictions with singleton groups, cross_validation_utils.hpp:165-232)."""
+        y = np.ascontiguousarray(target_mean, dtype=np.float64)
+        mean, var = np.empty(self.n), np.empty(self.n)
+        self._ctx._check(self._ctx._lib.agp_loo_marginal(self._ctx._h, self._h, _ptr(y), _ptr(mean), _ptr(var),
+                                                         capi.HOST), "agp_loo_marginal")
+        return MarginalDistribution(mean, var)
+
     def factor(self):
         L = np.empty((self.n, self.n), order="F")
         self._ctx._check(self._ctx._lib.agp_fit_download_factor(self._ctx._h, self._h, _ptr(L), self.n),

@@ -82,6 +82,10 @@ int main() {
     resid = std::fmax(resid, std::fabs(s - (i == 0 ? 1. : 0.)));
   }
   std::printf("solve_residual,%.17g\n", resid);
+  // leave-one-out fast path
+  const auto loo = fm.get_fit().leave_one_out(y);
+  const auto kinv = fm.get_fit().inverse_diagonal();
+  for (int i = 0; i < n; ++i) std::printf("loo,%d,%.17g,%.17g,%.17g\n", i, loo.mean[i], loo.covariance[i], kinv[i]);
   // a singular covariance is reported, not silently factored
   try {
     std::vector<double> dup = {0., 0., 1.};

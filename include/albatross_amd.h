@@ -177,6 +177,20 @@ int agp_nll(agp_context *ctx, const agp_kernel *k, const agp_features *x,
 int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs,
               int64_t nrhs, double *out, int location);
 
+/* ---- leave-one-out fast path (the tuner's LeaveOneOutLikelihood objective) --- */
+/* diag(K^-1): SerializableLDLT::inverse_diagonal (src/eigen/serializable_ldlt.hpp:
+ * 137-199: R = L^-1, then the squared column norms of R).  out: n doubles. */
+int agp_fit_inverse_diagonal(agp_context *ctx, const agp_fit *fit, double *out,
+                             int out_location);
+/* Leave-one-out predictive marginals, all n at once: held_out_predictions with
+ * singleton groups (src/evaluation/cross_validation_utils.hpp:165-232) ==
+ * leave_one_out_conditional (:138-163, GPML eq. 5.12):
+ *   variance_i = 1 / (K^-1)_ii ,  mean_i = y_i - information_i / (K^-1)_ii.
+ * y = the target means as passed to the fit's dataset (n doubles at `location`);
+ * mean / variance: n doubles each at `location`. */
+int agp_loo_marginal(agp_context *ctx, const agp_fit *fit, const double *y,
+                     double *mean, double *variance, int location);
+
 /* ---- predict ------------------------------------------------------------- */
 /* gp_mean_prediction (gp.hpp:82-85) via _predict_impl (gp.hpp:350-366):
  *   mean = k(train, xs)^T information.  mean: m doubles at out_location. */

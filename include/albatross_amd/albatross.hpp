@@ -551,6 +551,24 @@ struct GPFit {
   std::shared_ptr<detail::ContextHolder> context;
   std::shared_ptr<agp_fit> handle;  // train_covariance (CovarianceRepresentation)
 
+  // SerializableLDLT::inverse_diagonal, eigen/serializable_ldlt.hpp:181-199
+  Vector inverse_diagonal() const {
+    Vector out(train_features.size());
+    detail::check(agp_fit_inverse_diagonal(context->ctx, handle.get(), out.data(), AGP_HOST), context->ctx,
+                  "agp_fit_inverse_diagonal");
+    return out;
+  }
+
+  // leave-one-out predictive marginals of every training point
+  // (held_out_predictions with singleton groups, evaluation/cross_validation_utils.hpp:165-232)
+  MarginalDistribution leave_one_out(const Vector &target_mean) const {
+    MarginalDistribution out(Vector(train_features.size()), Vector(train_features.size()));
+    detail::check(agp_loo_marginal(context->ctx, handle.get(), target_mean.data(), out.mean.data(),
+                                   out.covariance.data(), AGP_HOST),
+                  context->ctx, "agp_loo_marginal");
+    return out;
+  }
+
   // train_covariance.solve(rhs), gp.hpp:42-45
   Matrix solve(const Matrix &rhs) const {
     Matrix out(rhs.rows(), rhs.cols());

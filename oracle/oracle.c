@@ -680,3 +680,77 @@ ORC_API void orc_predict_joint(const orc_fit *f, const agp_kernel_node *prog,
     }
   free(Ks); free(E);
 }
+
+/* ---------------------------------------------------------------------- */
+/* leave-one-out fast path: eigen/serializable_ldlt.hpp:137-199,           */
+/* evaluation/cross_validation_utils.hpp:132-163,165-232                   */
+/* ---------------------------------------------------------------------- */
+/* inverse_cholesky = D^-1/2 L^-1 P  (serializable_ldlt.hpp:154-163), column-major n x n into R */
+static void ldlt_inverse_cholesky(const double *A, int64_t n, int64_t ld, const int64_t *tr, double *R) {
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < n; ++i) R[i + j * n] = (i == j) ? 1. : 0.;
+  /* P * I : apply the transpositions to the rows */
+  for (int64_t k = 0; k < n; ++k)
+    if (tr[k] != k)
+      for (int64_t c = 0; c < n; ++c) {
+        const double t = R[k + c * n];
+        R[k + c * n] = R[tr[k] + c * n];
+        R[tr[k] + c * n] = t;
+      }
+  for (int64_t c = 0; c < n; ++c) { /* unit-lower solve, column by column */
+    double *b = R + c * n;
+    for (int64_t j = 0; j < n; ++j) {
+      const double bj = b[j];
+      if (bj == 0.) continue;
+      const double *col = A + j * ld;
+      for (int64_t i = j + 1; i < n; ++i) b[i] -= col[i] * bj;
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) { /* diagonal_sqrt_inverse, :50-68 */
+    const double d = A[i + i * ld];
+    const double sc = d > 0. ? 1. / sqrt(d) : 0.;
+    for (int64_t c = 0; c < n; ++c) R[i + c * n] *= sc;
+  }
+}
+
+/* SerializableLDLT::inverse_diagonal (:181-199): blocks of one index each */
+ORC_API void orc_fit_inverse_diagonal(const orc_fit *f, double *out) {
+  const int64_t n = f->n;
+  double *R = malloc(sizeof(double) * (size_t)(n * n));
+  if (f->use_llt) {
+    /* R = L^-1 */
+    for (int64_t j = 0; j < n; ++j)
+      for (int64_t i = 0; i < n; ++i) R[i + j * n] = (i == j) ? 1. : 0.;
+    for (int64_t c = 0; c < n; ++c) {
+      double *b = R + c * n;
+      for (int64_t j = c; j < n; ++j) {
+        b[j] /= f->ldlt[j + j * n];
+        const double bj = b[j];
+        const double *col = f->ldlt + j * n;
+        for (int64_t i = j + 1; i < n; ++i) b[i] -= col[i] * bj;
+      }
+    }
+  } else {
+    ldlt_inverse_cholesky(f->ldlt, n, n, f->tr, R);
+  }
+  for (int64_t c = 0; c < n; ++c) { /* sub_matrix^T * sub_matrix for a single column */
+    double s = 0.;
+    for (int64_t i = 0; i < n; ++i) s += R[i + c * n] * R[i + c * n];
+    out[c] = s;
+  }
+  free(R);
+}
+
+/* held_out_predictions with singleton groups (cross_validation_utils.hpp:199-232,
+ * held_out_prediction :171-186): mean_i = y_i - v_i / Ainv_ii, var_i = 1 / Ainv_ii,
+ * == leave_one_out_conditional (:138-163, GPML eq. 5.12) */
+ORC_API void orc_fit_loo_marginal(const orc_fit *f, const double *y, double *mean, double *variance) {
+  const int64_t n = f->n;
+  double *d = malloc(sizeof(double) * (size_t)n);
+  orc_fit_inverse_diagonal(f, d);
+  for (int64_t i = 0; i < n; ++i) {
+    variance[i] = 1. / d[i];
+    mean[i] = y[i] - f->information[i] / d[i];
+  }
+  free(d);
+}

@@ -53,6 +53,8 @@ def lib():
         L.orc_fit_logdet.restype = C.c_double
         L.orc_fit_logdet.argtypes = [V]
         L.orc_fit_solve.argtypes = [V, V, I64]
+        L.orc_fit_inverse_diagonal.argtypes = [V, V]
+        L.orc_fit_loo_marginal.argtypes = [V, V, V, V]
         L.orc_nll_dense.restype = C.c_double
         L.orc_nll_dense.argtypes = [V, V, I64, I64]
         L.orc_nll.restype = C.c_double
@@ -188,6 +190,17 @@ class OracleFit:
         B2 = np.asfortranarray(B.reshape(B.shape[0], -1, order="F"))
         lib().orc_fit_solve(self.h, _ptr(B2), B2.shape[1])
         return B2.reshape(B.shape, order="F")
+
+    def inverse_diagonal(self):
+        out = np.zeros(self.n)
+        lib().orc_fit_inverse_diagonal(self.h, _ptr(out))
+        return out
+
+    def loo_marginal(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        mean, var = np.zeros(self.n), np.zeros(self.n)
+        lib().orc_fit_loo_marginal(self.h, _ptr(y), _ptr(mean), _ptr(var))
+        return mean, var
 
     def predict_mean(self, xs, xs_meas=False):
         f, keep = _feat(self.cov, xs, xs_meas)

@@ -91,6 +91,10 @@ def test_cpp_api_matches_oracle():
     assert np.abs(pred[:, 1] - om).max() <= 1e-8 * np.abs(om).max()
     assert np.abs(pred[:, 2] - om).max() <= 1e-8 * np.abs(om).max()
     assert np.abs(pred[:, 3] - ov).max() <= 1e-8 and np.abs(pred[:, 4] - ov).max() <= 1e-8
+    loo = np.array(rows["loo"], dtype=float)
+    lm, lv = ofit.loo_marginal(y)
+    assert np.abs(loo[:, 1] - lm).max() <= 1e-8 * np.abs(lm).max() and np.abs(loo[:, 2] - lv).max() <= 1e-8 * lv.max()
+    assert np.abs(loo[:, 3] - ofit.inverse_diagonal()).max() <= 1e-8 * ofit.inverse_diagonal().max()
     assert float(one["joint_asymmetry"]) == 0.
     assert float(one["solve_residual"]) < 1e-10
     assert "not positive definite" in one["singular"] and "pivot 1" in one["singular"]

@@ -170,3 +170,40 @@ def test_config3_n16384_properties(ctx):
     B = np.random.default_rng(2).standard_normal((n, 2))
     X = fm.get_fit().solve(B)
     assert np.abs(K @ X - B).max() <= 1e-8 * np.abs(B).max() * 10
+
+
+@pytest.mark.parametrize("n", [1, 50, 128, 300, 1000, 1700])
+def test_leave_one_out_fast_path(ctx, n):
+    """tests/test_cross_validation.cc:419-446 / test_serializable_ldlt.cc:52-66 restated:
+    the LOO fast path equals the oracle's (which equals brute-force refits, see
+    tests/test_oracle_golden.py) at 1e-8."""
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0., 10., (n, 2))
+    y = np.sin(x).sum(axis=1) + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.05, n)
+    cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+    fm = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar)))
+    ofit = orc.OracleFit(cov, x, y, yvar)
+    d = fm.get_fit().inverse_diagonal()
+    od = ofit.inverse_diagonal()
+    assert np.abs(d - od).max() <= 1e-8 * od.max()
+    loo = fm.get_fit().leave_one_out(y)
+    om, ov = ofit.loo_marginal(y)
+    assert np.abs(loo.mean - om).max() <= 1e-8 * max(np.abs(om).max(), 1.)
+    assert np.abs(loo.covariance - ov).max() <= 1e-8 * ov.max()
+
+
+def test_leave_one_out_n16384_property(ctx):
+    """At the bench size: (K^-1)_ii from the fast path vs a direct solve of K x = e_i on sampled i."""
+    n = 16384
+    x, y = synthetic_3d(n, 44)
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+    fm = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
+    d = fm.get_fit().inverse_diagonal()
+    idx = np.random.default_rng(0).choice(n, 6, replace=False)
+    E = np.zeros((n, 6))
+    E[idx, np.arange(6)] = 1.
+    X = fm.get_fit().solve(E)
+    assert np.abs(X[idx, np.arange(6)] - d[idx]).max() <= 1e-9 * d.max()
+    loo = fm.get_fit().leave_one_out(y)
+    assert np.all(loo.covariance > 0) and np.abs(loo.mean - y).max() < 1.0

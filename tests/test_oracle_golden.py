@@ -172,3 +172,22 @@ def test_oracle_nan_input_is_reported():
     x = np.array([0., np.nan, 2.])
     with pytest.raises(FloatingPointError):
         orc.OracleFit(cov, x, np.zeros(3))
+
+
+def test_loo_fast_path_equals_brute_force():
+    # tests/test_cross_validation.cc:419-446: fast path == brute-force refits (1e-8)
+    rng = np.random.default_rng(1)
+    n = 60
+    x = rng.uniform(0, 10, (n, 2))
+    y = np.sin(x).sum(1) + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.05, n)
+    cov = ab.Matern52(2., 1.) + ab.IndependentNoise(0.1)
+    K = orc.gram(cov, x, x_meas=True) + np.diag(yvar)
+    for use_llt in (False, True):
+        f = orc.OracleFit(cov, x, y, yvar, use_llt=use_llt)
+        assert np.abs(f.inverse_diagonal() - np.diag(np.linalg.inv(K))).max() < 1e-8  # test_serializable_ldlt.cc:52-59
+        m, v = f.loo_marginal(y)
+        for i in range(n):
+            idx = np.r_[0:i, i + 1:n]
+            sol = np.linalg.solve(K[np.ix_(idx, idx)], K[idx, i])
+            assert abs(m[i] - sol @ y[idx]) < 1e-8 and abs(v[i] - (K[i, i] - K[idx, i] @ sol)) < 1e-8
