@@ -14,6 +14,7 @@ namespace agp {
 void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n);
 void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n);
 void launch_set_identity(hipStream_t s, double *B, long long ld, long long n);
+void launch_nan_scan_lower(hipStream_t s, const double *A, long long ld, long long n, int *flag);
 void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const double *information, long long n,
                 double *mean, double *variance);
 
@@ -562,7 +563,7 @@ int agp_fit_log_determinant(const agp_fit *fit, double *out) {
 }
 
 int agp_fit_download_information(agp_context *ctx, const agp_fit *fit, double *information) {
-  if (!ctx || !fit || !information) return AGP_ERR_INVALID_ARGUMENT;
+  if (!ctx || !fit || !information || !fit->alpha) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return copy_out(ctx, fit->alpha, fit->n, information, AGP_HOST);
 }
@@ -641,6 +642,86 @@ int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs, int64_t n
   return copy_out_2d(ctx, ctx->ws_aux, ldb, n, nrhs, out, n, location);
 }
 
+// ---- dense-matrix factor ---------------------------------------------------------
+// copies the lower triangle of K into a fresh factor buffer and runs the LL^T;
+// y (device, optional) receives the fused forward substitution
+static int factor_dense(agp_context *c, const double *K, long long n, long long ld, int location, agp_fit *fit,
+                        double *y) {
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  hipStream_t s = ctx->stream;
+  const long long nblk = (n + NB - 1) / NB;
+  fit->ctx = ctx;
+  fit->device = ctx->device;
+  fit->n = n;
+  fit->lda = factor_ld(n);
+  fit->A_bytes = sizeof(double) * (size_t)fit->lda * (size_t)n;
+  if (ctx->pool_A && ctx->pool_A_bytes == fit->A_bytes) {
+    fit->A = ctx->pool_A;
+    ctx->pool_A = nullptr;
+    ctx->pool_A_bytes = 0;
+  } else {
+    AGP_HIP_CHECK(ctx, hipMalloc(&fit->A, fit->A_bytes));
+  }
+  AGP_HIP_CHECK(ctx, hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * (36 * MB * MB)));
+  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(fit->A, sizeof(double) * (size_t)fit->lda, K, sizeof(double) * (size_t)ld,
+                                      sizeof(double) * (size_t)n, (size_t)n, kind, s));
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 4 * sizeof(double), s));
+  launch_nan_scan_lower(s, fit->A, fit->lda, n, ctx->d_flags);
+  factor_lower(ctx, fit->A, n, fit->lda, fit->invd, y, nullptr);
+  AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  AGP_HIP_CHECK(ctx, hipGetLastError());
+  fit->failed_pivot = ctx->h_flags[1] ? (int64_t)ctx->h_flags[1] - 1 : -1;
+  fit->log_det = 2. * ctx->h_scalars[0];
+  return status_from_flags(ctx);
+}
+
+int agp_factor_create(agp_context *ctx, const double *K, int64_t n, int64_t ld, int location, agp_fit **out) {
+  if (!ctx || !K || !out || n <= 0 || ld < n) return AGP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  agp_fit *fit = new (std::nothrow) agp_fit();
+  if (!fit) return AGP_ERR_INVALID_ARGUMENT;
+  const int st = factor_dense(ctx, K, n, ld, location, fit, nullptr);
+  if (st == AGP_ERR_HIP) { agp_fit_destroy(fit); return st; }
+  *out = fit;  // on NOT_POSITIVE_DEFINITE / NAN the handle only carries the failed pivot
+  return st;
+}
+
+int agp_nll_dense(agp_context *ctx, const double *deviation, const double *K, int64_t n, int64_t ld, int location,
+                  double *out) {
+  if (!ctx || !deviation || !K || !out || n <= 0 || ld < n) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (n == 1) {  // univariate shortcut, likelihood.hpp:57-60 -> -gaussian::log_pdf(deviation, variance)
+    double d = 0., v = 0.;
+    const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
+    AGP_HIP_CHECK(ctx, hipMemcpy(&d, deviation, sizeof(double), kind));
+    AGP_HIP_CHECK(ctx, hipMemcpy(&v, K, sizeof(double), kind));
+    *out = 0.5 * (std::log(2 * M_PI * v) + d * d / v);
+    return AGP_OK;
+  }
+  agp_fit *fit = new (std::nothrow) agp_fit();
+  if (!fit) return AGP_ERR_INVALID_ARGUMENT;
+  double *z = nullptr;
+  hipError_t e = hipMalloc(&z, sizeof(double) * (size_t)n);
+  if (e != hipSuccess) { delete fit; ctx->last_error = hipGetErrorString(e); return AGP_ERR_HIP; }
+  int st = vector_to_device(ctx, deviation, n, location, z);
+  if (st == AGP_OK) st = factor_dense(ctx, K, n, ld, location, fit, z);
+  if (st == AGP_OK) {
+    launch_dot(ctx->stream, z, z, n, ctx->d_scalars + 1);  // dev^T K^-1 dev = z^T z
+    e = hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); st = AGP_ERR_HIP; }
+    else *out = 0.5 * (fit->log_det + ctx->h_scalars[1] + (double)n * std::log(2 * M_PI));
+  }
+  (void)hipFree(z);
+  agp_fit_destroy(fit);
+  return st;
+}
+
 // ---- leave-one-out fast path ---------------------------------------------------
 // diag(K^-1) into ws_aux[ldr * n ...]; returns the device pointer of the n results
 static int inverse_diagonal_device(agp_context *ctx, const agp_fit *fit, double **diag_out) {
@@ -671,7 +752,7 @@ int agp_fit_inverse_diagonal(agp_context *ctx, const agp_fit *fit, double *out, 
 
 int agp_loo_marginal(agp_context *ctx, const agp_fit *fit, const double *y, double *mean, double *variance,
                      int location) {
-  if (!ctx || !fit || !y || !mean || !variance || !fit->A) return AGP_ERR_INVALID_ARGUMENT;
+  if (!ctx || !fit || !y || !mean || !variance || !fit->A || !fit->alpha) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long n = fit->n;
   double *diag = nullptr;
@@ -692,7 +773,7 @@ int agp_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, 
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   int st = validate_features(xs);
   if (st != AGP_OK) return st;
-  if (xs->dim != fit->train.v.dim) return AGP_ERR_INVALID_ARGUMENT;
+  if (!fit->alpha || xs->dim != fit->train.v.dim) return AGP_ERR_INVALID_ARGUMENT;
   const long long m = xs->n;
   if (m == 0) return AGP_OK;
   const DevProgram *dprog = nullptr;
@@ -702,7 +783,7 @@ int agp_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, 
   st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)m);
   if (st == AGP_OK) {
     // cross_cov = cov(train_features, features); mean = cross_cov^T information  (gp.hpp:361-363)
-    launch_predict_mean(ctx->stream, dprog, fit->train.v, dxs.v, fit->alpha, ctx->ws_aux);
+    launch_predict_mean(ctx->stream, dprog, fit->train.v, dxs.v, fit->alpha, ctx->ws_aux, &k->prog);
     st = copy_out(ctx, ctx->ws_aux, m, mean, out_location);
   }
   dxs.release();
@@ -715,7 +796,7 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   int st = validate_features(xs);
   if (st != AGP_OK) return st;
-  if (xs->dim != fit->train.v.dim) return AGP_ERR_INVALID_ARGUMENT;
+  if (!fit->alpha || xs->dim != fit->train.v.dim) return AGP_ERR_INVALID_ARGUMENT;
   const long long m = xs->n, n = fit->n;
   if (m == 0) return AGP_OK;
   const DevProgram *dprog = nullptr;
@@ -731,7 +812,7 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
   double *V = ctx->ws_aux, *mean_d = V + v_elems, *prior = mean_d + round_up(m, 2);
   hipStream_t s = ctx->stream;
   // mean (gp.hpp:82-85)
-  launch_predict_mean(s, dprog, fit->train.v, dxs.v, fit->alpha, mean_d);
+  launch_predict_mean(s, dprog, fit->train.v, dxs.v, fit->alpha, mean_d, &k->prog);
   // cross_cov = cov(train_features, features)   (gp.hpp:316,337)
   launch_gram(s, dprog, fit->train.v, dxs.v, false, false, V, ldv, nullptr, nullptr, &k->prog);
   // V = L^-1 K*  ;  explained = V^T V  (== K*^T K^-1 K*, gp.hpp:96,111)

@@ -103,7 +103,7 @@ void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const Fe
 void launch_gram_diagonal(hipStream_t s, const DevProgram *P, const FeatView &X, double *out);
 // mean_j = sum_i k(x_i, xs_j) alpha_i without materialising the cross Gram
 void launch_predict_mean(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &XS,
-                         const double *alpha, double *mean);
+                         const double *alpha, double *mean, const DevProgram *host_program = nullptr);
 
 // LL^T of the n x n lower triangle of A (ld = lda), in place.  y (n) is
 // overwritten with z = L^-1 y when non-null.  invd receives the inverted

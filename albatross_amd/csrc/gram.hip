@@ -387,9 +387,87 @@ __global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_kernel(const DevPr
   if (lane == 0) mean[j] = acc;
 }
 
+// fast-path twin of predict_mean_kernel for radial<Euclidean> [+ noise] trees:
+// 8 test points per workgroup... one wave per test point, training points
+// strided over the lanes, coordinates read as row-major triples.
+template <int DIMP, int OP>
+__global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_fast_kernel(FastParams fp, FeatView X, FeatView XS,
+                                                                           const double *alpha, double *mean) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long j = (long long)blockIdx.x * PM_WAVES + wave;
+  if (j >= XS.n) return;
+  double y[DIMP];
+#pragma unroll
+  for (int d = 0; d < DIMP; ++d) y[d] = XS.coords[j * XS.dim + d];
+  const bool have_ids = X.ids != nullptr && XS.ids != nullptr;
+  const long long yid = have_ids ? XS.ids[j] : -1;
+  const bool noise_on = fp.has_noise && (!fp.noise_meas_only || (X.meas && XS.meas));
+  double acc = 0.;
+#pragma unroll 2
+  for (long long i = lane; i < X.n; i += 64) {
+    double dist;
+    bool eq = true;
+    if (DIMP == 1) {
+      const double x0 = X.coords[i];
+      dist = fabs(x0 - y[0]);
+      eq = x0 == y[0];
+    } else {
+      double s = 0.;
+#pragma unroll
+      for (int d = 0; d < DIMP; ++d) {
+        const double xd = X.coords[i * DIMP + d];
+        const double t = xd - y[d];
+        s += t * t;
+        eq = eq && (xd == y[d]);
+      }
+      dist = sqrt(s);
+    }
+    if (have_ids) eq = X.ids[i] == yid;
+    double v = radial_value<OP>(dist, fp.length_scale, fp.sigma);
+    if (fp.has_noise) v = v + ((noise_on && eq) ? fp.noise_var : 0.);
+    acc += v * alpha[i];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) mean[j] = acc;
+}
+
+template <int DIMP>
+static bool launch_predict_mean_fast_t(hipStream_t s, const FastParams &fp, int op, const FeatView &X,
+                                       const FeatView &XS, const double *alpha, double *mean) {
+  dim3 grid((unsigned)((XS.n + PM_WAVES - 1) / PM_WAVES)), block(64 * PM_WAVES);
+  switch (op) {
+  case AGP_OP_SQUARED_EXPONENTIAL:
+    hipLaunchKernelGGL((predict_mean_fast_kernel<DIMP, AGP_OP_SQUARED_EXPONENTIAL>), grid, block, 0, s, fp, X, XS, alpha, mean);
+    return true;
+  case AGP_OP_EXPONENTIAL:
+    hipLaunchKernelGGL((predict_mean_fast_kernel<DIMP, AGP_OP_EXPONENTIAL>), grid, block, 0, s, fp, X, XS, alpha, mean);
+    return true;
+  case AGP_OP_MATERN32:
+    hipLaunchKernelGGL((predict_mean_fast_kernel<DIMP, AGP_OP_MATERN32>), grid, block, 0, s, fp, X, XS, alpha, mean);
+    return true;
+  case AGP_OP_MATERN52:
+    hipLaunchKernelGGL((predict_mean_fast_kernel<DIMP, AGP_OP_MATERN52>), grid, block, 0, s, fp, X, XS, alpha, mean);
+    return true;
+  default: return false;
+  }
+}
+
 void launch_predict_mean(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &XS,
-                         const double *alpha, double *mean) {
+                         const double *alpha, double *mean, const DevProgram *host_program) {
   if (XS.n == 0) return;
+  if (host_program && X.dim <= 3 && X.dim == XS.dim) {
+    FastParams fp;
+    int op = 0;
+    const char *e = getenv("AGP_GRAM_FAST");
+    if (!(e && e[0] == '0') && match_fast(*host_program, &fp, &op)) {
+      bool done = false;
+      if (X.dim == 1) done = launch_predict_mean_fast_t<1>(s, fp, op, X, XS, alpha, mean);
+      else if (X.dim == 2) done = launch_predict_mean_fast_t<2>(s, fp, op, X, XS, alpha, mean);
+      else done = launch_predict_mean_fast_t<3>(s, fp, op, X, XS, alpha, mean);
+      if (done) return;
+    }
+  }
   dim3 grid((unsigned)((XS.n + PM_WAVES - 1) / PM_WAVES)), block(64 * PM_WAVES);
   const int dim = X.dim;
   if (dim == 1) hipLaunchKernelGGL(predict_mean_kernel<1>, grid, block, 0, s, P, X, XS, alpha, mean);

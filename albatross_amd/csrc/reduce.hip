@@ -87,6 +87,22 @@ void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n) {
   hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)n), dim3(256), 0, s, A, ld, n);
 }
 
+// NaN scan of the lower triangle (ALBATROSS_ASSERT(!cov.hasNaN()), gp.hpp:66)
+__global__ __launch_bounds__(256) void nan_scan_lower_kernel(const double *A, long long ld, long long n, int *flag) {
+  const long long col = blockIdx.x;
+  bool bad = false;
+  for (long long r = col + threadIdx.x; r < n; r += 256) {
+    const double v = A[col * ld + r];
+    bad = bad || (v != v);
+  }
+  if (bad) atomicOr(flag, 1);
+}
+
+void launch_nan_scan_lower(hipStream_t s, const double *A, long long ld, long long n, int *flag) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(nan_scan_lower_kernel, dim3((unsigned)n), dim3(256), 0, s, A, ld, n, flag);
+}
+
 // B (n x n, ld) <- identity
 __global__ __launch_bounds__(256) void set_identity_kernel(double *B, long long ld, long long n) {
   const long long col = blockIdx.x;

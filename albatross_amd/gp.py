@@ -246,6 +246,9 @@ class GPFit:
         self._ctx._check(self._ctx._lib.agp_fit_log_determinant(self._h, C.byref(v)), "log_determinant")
         return v.value
 
+    def rows(self):
+        return self.n
+
     def solve(self, rhs):
         """train_covariance.solve(rhs) (CovarianceRepresentation, gp.hpp:42-45)."""
         rhs = np.asarray(rhs, dtype=np.float64)
@@ -276,6 +279,95 @@ class GPFit:
         self._ctx._check(self._ctx._lib.agp_fit_download_factor(self._ctx._h, self._h, _ptr(L), self.n),
                          "download_factor")
         return L
+
+
+class DenseFactor:
+    """`Eigen::SerializableLDLT(const MatrixXd &)` (eigen/serializable_ldlt.hpp:27): the
+    device LL^T of a dense symmetric positive-definite matrix (lower triangle read)."""
+
+    def __init__(self, matrix, context=None):
+        self._ctx = context or default_context()
+        K = np.asfortranarray(matrix, dtype=np.float64)
+        if K.ndim != 2 or K.shape[0] != K.shape[1]:
+            raise ValueError("square matrix expected")
+        self.n = K.shape[0]
+        h = C.c_void_p()
+        st = self._ctx._lib.agp_factor_create(self._ctx._h, _ptr(K), self.n, self.n, capi.HOST, C.byref(h))
+        if st != capi.AGP_OK:
+            pivot = self._ctx._lib.agp_fit_failed_pivot(h) if h else -1
+            if h:
+                self._ctx._lib.agp_fit_destroy(h)
+            self._ctx._check(st, f"agp_factor_create (pivot {pivot})")
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._ctx._h:
+                self._ctx._lib.agp_fit_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    def rows(self):
+        return self.n
+
+    solve = GPFit.solve
+    inverse_diagonal = GPFit.inverse_diagonal
+    factor = GPFit.factor
+    log_determinant = GPFit.log_determinant
+
+
+def negative_log_likelihood(deviation, covariance, context=None):
+    """negative_log_likelihood(deviation, covariance) (evaluation/likelihood.hpp:53-66)."""
+    ctx = context or default_context()
+    d = np.ascontiguousarray(deviation, dtype=np.float64)
+    K = np.asfortranarray(covariance, dtype=np.float64)
+    out = C.c_double()
+    ctx._check(ctx._lib.agp_nll_dense(ctx._h, _ptr(d), _ptr(K), d.shape[0], K.shape[0], capi.HOST, C.byref(out)),
+               "agp_nll_dense")
+    return out.value
+
+
+class BlockSymmetric:
+    """linalg/block_symmetric.hpp:46-115: solver of [[A, B], [B^T, C]] from a solver of A,
+    Ai_B = A^-1 B and the factor of the Schur complement S = C - B^T A^-1 B."""
+
+    def __init__(self, A, B, S):
+        self.A = A
+        self.Ai_B = A.solve(np.asfortranarray(B, dtype=np.float64))  # block_symmetric.hpp:51
+        self.S = S
+
+    def rows(self):
+        return self.A.rows() + self.S.rows()
+
+    def solve(self, rhs):  # block_symmetric.hpp:75-98
+        rhs = np.asarray(rhs, dtype=np.float64)
+        r2 = rhs.reshape(rhs.shape[0], -1)
+        na = self.A.rows()
+        rhs_a, rhs_b = r2[:na], r2[na:]
+        Bt_Ai_rhs = self.Ai_B.T @ rhs_a
+        Si_Bt_Ai_rhs = self.S.solve(Bt_Ai_rhs)
+        Si_rhs_b = self.S.solve(np.ascontiguousarray(rhs_b))
+        out = np.empty_like(r2)
+        out[:na] = self.A.solve(np.ascontiguousarray(rhs_a)) + self.Ai_B @ (Si_Bt_Ai_rhs - Si_rhs_b)
+        out[na:] = Si_rhs_b - Si_Bt_Ai_rhs
+        return out.reshape(rhs.shape)
+
+
+class UpdatedGPFit:
+    """Fit<GPFit<BlockSymmetric<Solver>, F>> produced by update() (gp.hpp:384-414)."""
+
+    def __init__(self, train_features, train_covariance, information):
+        self.train_features = train_features
+        self.train_covariance = train_covariance
+        self.information = information
+        self.n = information.shape[0]
+
+    def rows(self):
+        return self.n
+
+    def solve(self, rhs):
+        return self.train_covariance.solve(rhs)
 
 
 class Prediction:
@@ -315,12 +407,54 @@ class FitModel:
         """fit_model.hpp:54-62: wraps the test features in Measurement<>."""
         return Prediction(self, features if isinstance(features, Measurement) else Measurement(features))
 
+    def update(self, dataset, targets=None):
+        """FitModel::update (core/fit_model.hpp:68-81) -> _update_impl (gp.hpp:384-414):
+        condition the fit on further observations through the Schur complement instead of
+        re-factoring; returns a new FitModel whose fit holds a BlockSymmetric solver."""
+        if targets is not None:
+            dataset = RegressionDataset(dataset, targets)
+        m, ctx = self._model, self._model._ctx()
+        feats = _values_of(dataset.features)
+        pred = self.predict(feats).joint()                                   # gp.hpp:388-389
+        delta = np.asarray(dataset.targets.mean, dtype=np.float64) - pred.mean
+        S = np.array(pred.covariance)
+        if dataset.targets.covariance is not None:
+            S[np.diag_indices_from(S)] += dataset.targets.covariance         # pred.covariance += targets.covariance
+        S_ldlt = DenseFactor(S, ctx)                                          # gp.hpp:393
+        old_feats = _values_of(self._fit.train_features)
+        cross = ctx.gram(m.covariance_function_, old_feats, feats)            # gp.hpp:395-396
+        new_cov = BlockSymmetric(self._fit, cross, S_ldlt)                    # gp.hpp:398-399
+        Si_delta = S_ldlt.solve(delta)
+        info = np.concatenate([self._fit.information - new_cov.Ai_B @ Si_delta, Si_delta])  # gp.hpp:403-407
+        new_feats = np.concatenate([np.asarray(old_feats, dtype=np.float64).reshape(self._fit.rows(), -1),
+                                    np.asarray(feats, dtype=np.float64).reshape(len(delta), -1)])
+        return FitModel(m, UpdatedGPFit(new_feats, new_cov, info))
+
     # --- _predict_impl (gp.hpp:305-366) ------------------------------------------
+    def _host_predict(self, features, want):
+        """_predict_impl written against a generic CovarianceRepresentation (gp.hpp:305-366):
+        used for fits whose solver is a BlockSymmetric; Gram and solves still run on the device."""
+        m, ctx = self._model, self._model._ctx()
+        cov = m.covariance_function_
+        fs = cov.features(features)
+        cross = ctx.gram(cov, self._fit.train_features, fs)
+        mean = cross.T @ self._fit.information + m.mean_function_(fs.coords)
+        if want == "mean":
+            return mean
+        explained = self._fit.solve(cross)
+        if want == "marginal":
+            prior = np.array([ctx.gram(cov, FeatureSet(fs.coords[i:i + 1], None if fs.scales is None else list(fs.scales[i:i + 1].T),
+                                                       None, fs.is_measurement))[0, 0] for i in range(fs.n)])
+            return MarginalDistribution(mean, prior - np.einsum("ij,ij->j", explained, cross))
+        return JointDistribution(mean, ctx.gram(cov, fs) - cross.T @ explained)
+
     def _xs(self, features):
         fs = self._model.covariance_function_.features(features)
         return fs, fs.as_struct()
 
     def _predict_mean(self, features):
+        if isinstance(self._fit, UpdatedGPFit):
+            return self._host_predict(features, "mean")
         m, ctx = self._model, self._model._ctx()
         fs, s = self._xs(features)
         mean = np.empty(fs.n)
@@ -329,6 +463,8 @@ class FitModel:
         return mean + m.mean_function_(fs.coords)  # mean_function_.add_to, gp.hpp:364
 
     def _predict_marginal(self, features):
+        if isinstance(self._fit, UpdatedGPFit):
+            return self._host_predict(features, "marginal")
         m, ctx = self._model, self._model._ctx()
         fs, s = self._xs(features)
         mean, var = np.empty(fs.n), np.empty(fs.n)
@@ -338,6 +474,8 @@ class FitModel:
         return MarginalDistribution(mean + m.mean_function_(fs.coords), var)
 
     def _predict_joint(self, features):
+        if isinstance(self._fit, UpdatedGPFit):
+            return self._host_predict(features, "joint")
         m, ctx = self._model, self._model._ctx()
         fs, s = self._xs(features)
         mean, cov = np.empty(fs.n), np.empty((fs.n, fs.n), order="F")
