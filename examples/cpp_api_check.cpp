@@ -86,6 +86,31 @@ int main() {
   const auto loo = fm.get_fit().leave_one_out(y);
   const auto kinv = fm.get_fit().inverse_diagonal();
   for (int i = 0; i < n; ++i) std::printf("loo,%d,%.17g,%.17g,%.17g\n", i, loo.mean[i], loo.covariance[i], kinv[i]);
+  // dense-matrix factor, dense NLL (tests/test_evaluate.cc:20-44) and update == full fit (tests/test_gp.cc:182-219)
+  {
+    Matrix c3(3, 3);
+    const double vals[9] = {1., .9, .8, .9, 1., .9, .8, .9, 1.};
+    for (int i = 0; i < 9; ++i) c3.data[i] = vals[i];
+    std::printf("mvn_nll,%.17g\n", negative_log_likelihood(Vector{-1., 0., 1.}, c3));
+    std::printf("mvn_logdet,%.17g\n", SerializableLDLT(c3).log_determinant());
+    auto ucov = SquaredExponential<EuclideanDistance>(1.5, 1.0) + Constant(2.0);
+    auto umodel = gp_from_covariance(ucov);
+    std::vector<P3> xa(x.begin(), x.begin() + 250), xb(x.begin() + 250, x.begin() + 330), xc(x.begin() + 330, x.end());
+    Vector ya(y.begin(), y.begin() + 250), yb(y.begin() + 250, y.begin() + 330), yc(y.begin() + 330, y.end());
+    const auto full = umodel.fit(RegressionDataset<P3>(x, MarginalDistribution(y, Vector(n, 0.1))));
+    const auto part = umodel.fit(RegressionDataset<P3>(xa, MarginalDistribution(ya, Vector(250, 0.1))));
+    const auto up1 = update(part, RegressionDataset<P3>(xb, MarginalDistribution(yb, Vector(80, 0.1))));
+    const auto up2 = up1.update(RegressionDataset<P3>(xc, MarginalDistribution(yc, Vector(yc.size(), 0.1))));
+    const auto fj = full.predict(xs).joint();
+    const auto uj = up2.predict_joint(xs);
+    double dm = 0., dc = 0.;
+    for (int i = 0; i < ms; ++i) {
+      dm = std::fmax(dm, std::fabs(fj.mean[i] - uj.mean[i]));
+      for (int j = 0; j < ms; ++j) dc = std::fmax(dc, std::fabs(fj.covariance(i, j) - uj.covariance(i, j)));
+    }
+    std::printf("update_mean_diff,%.17g\n", dm);
+    std::printf("update_cov_diff,%.17g\n", dc);
+  }
   // a singular covariance is reported, not silently factored
   try {
     std::vector<double> dup = {0., 0., 1.};

@@ -551,6 +551,8 @@ struct GPFit {
   std::shared_ptr<detail::ContextHolder> context;
   std::shared_ptr<agp_fit> handle;  // train_covariance (CovarianceRepresentation)
 
+  std::int64_t rows() const { return static_cast<std::int64_t>(train_features.size()); }
+
   // SerializableLDLT::inverse_diagonal, eigen/serializable_ldlt.hpp:181-199
   Vector inverse_diagonal() const {
     Vector out(train_features.size());
@@ -576,6 +578,100 @@ struct GPFit {
                   context->ctx, "agp_solve");
     return out;
   }
+};
+
+// ---------------------------------------------------------------------------
+// Eigen::SerializableLDLT(const MatrixXd &) (eigen/serializable_ldlt.hpp:27):
+// device LL^T of a dense symmetric positive-definite matrix (lower triangle read)
+// ---------------------------------------------------------------------------
+class SerializableLDLT {
+ public:
+  SerializableLDLT() = default;
+  explicit SerializableLDLT(const Matrix &x) : context_(detail::default_context()), n_(x.rows()) {
+    agp_fit *h = nullptr;
+    const int st = agp_factor_create(context_->ctx, x.data.data(), x.rows(), x.rows(), AGP_HOST, &h);
+    if (st != AGP_OK) {
+      const long long pivot = h ? static_cast<long long>(agp_fit_failed_pivot(h)) : -1;
+      agp_fit_destroy(h);
+      const std::string what = "agp_factor_create (pivot " + std::to_string(pivot) + ")";
+      detail::check(st, context_->ctx, what.c_str());
+    }
+    auto ctx = context_;
+    handle_ = std::shared_ptr<agp_fit>(h, [ctx](agp_fit *p) { agp_fit_destroy(p); });
+  }
+  std::int64_t rows() const { return n_; }
+  Matrix solve(const Matrix &rhs) const {
+    Matrix out(rhs.rows(), rhs.cols());
+    detail::check(agp_solve(context_->ctx, handle_.get(), rhs.data.data(), rhs.cols(), out.data.data(), AGP_HOST),
+                  context_->ctx, "agp_solve");
+    return out;
+  }
+  Vector solve(const Vector &rhs) const {
+    Vector out(rhs.size());
+    detail::check(agp_solve(context_->ctx, handle_.get(), rhs.data(), 1, out.data(), AGP_HOST), context_->ctx, "agp_solve");
+    return out;
+  }
+  double log_determinant() const {  // serializable_ldlt.hpp:128-135
+    double v = 0.;
+    detail::check(agp_fit_log_determinant(handle_.get(), &v), context_->ctx, "agp_fit_log_determinant");
+    return v;
+  }
+  Vector inverse_diagonal() const {  // serializable_ldlt.hpp:181-199
+    Vector out(static_cast<std::size_t>(n_));
+    detail::check(agp_fit_inverse_diagonal(context_->ctx, handle_.get(), out.data(), AGP_HOST), context_->ctx,
+                  "agp_fit_inverse_diagonal");
+    return out;
+  }
+
+ private:
+  std::shared_ptr<detail::ContextHolder> context_;
+  std::shared_ptr<agp_fit> handle_;
+  std::int64_t n_ = 0;
+};
+
+// negative_log_likelihood(deviation, covariance), evaluation/likelihood.hpp:53-66
+inline double negative_log_likelihood(const Vector &deviation, const Matrix &covariance) {
+  auto ctx = detail::default_context();
+  double out = 0.;
+  detail::check(agp_nll_dense(ctx->ctx, deviation.data(), covariance.data.data(), covariance.rows(), covariance.rows(),
+                              AGP_HOST, &out),
+                ctx->ctx, "agp_nll_dense");
+  return out;
+}
+
+// linalg/block_symmetric.hpp:46-115
+template <typename Solver>
+struct BlockSymmetric {
+  BlockSymmetric() = default;
+  BlockSymmetric(const Solver &A_, const Matrix &B_, const SerializableLDLT &S_) : A(A_), Ai_B(A_.solve(B_)), S(S_) {}
+  std::int64_t rows() const { return A.rows() + S.rows(); }
+  Matrix solve(const Matrix &rhs) const {  // block_symmetric.hpp:75-98
+    const std::int64_t na = A.rows(), ns = S.rows(), k = rhs.cols();
+    Matrix rhs_a(na, k), rhs_b(ns, k), Bt_Ai_rhs(ns, k);
+    for (std::int64_t c = 0; c < k; ++c) {
+      for (std::int64_t i = 0; i < na; ++i) rhs_a(i, c) = rhs(i, c);
+      for (std::int64_t i = 0; i < ns; ++i) rhs_b(i, c) = rhs(na + i, c);
+      for (std::int64_t j = 0; j < ns; ++j) {
+        double s = 0.;
+        for (std::int64_t i = 0; i < na; ++i) s += Ai_B(i, j) * rhs(i, c);
+        Bt_Ai_rhs(j, c) = s;
+      }
+    }
+    const Matrix Si_Bt_Ai_rhs = S.solve(Bt_Ai_rhs), Si_rhs_b = S.solve(rhs_b), Ai_rhs_a = A.solve(rhs_a);
+    Matrix out(na + ns, k);
+    for (std::int64_t c = 0; c < k; ++c) {
+      for (std::int64_t i = 0; i < na; ++i) {
+        double s = Ai_rhs_a(i, c);
+        for (std::int64_t j = 0; j < ns; ++j) s += Ai_B(i, j) * (Si_Bt_Ai_rhs(j, c) - Si_rhs_b(j, c));
+        out(i, c) = s;
+      }
+      for (std::int64_t j = 0; j < ns; ++j) out(na + j, c) = Si_rhs_b(j, c) - Si_Bt_Ai_rhs(j, c);
+    }
+    return out;
+  }
+  Solver A;
+  Matrix Ai_B;
+  SerializableLDLT S;
 };
 
 template <typename ModelType, typename FeatureType> class FitModel;
@@ -656,6 +752,101 @@ class FitModel {
   ModelType model_;
   GPFit<FeatureType> fit_;
 };
+
+// ---------------------------------------------------------------------------
+// update(): Fit<GPFit<BlockSymmetric<Solver>, F>> (gp.hpp:384-414).  The updated
+// fit predicts through the generic CovarianceRepresentation form of _predict_impl
+// (gp.hpp:305-366): device Gram + solver.solve().
+// ---------------------------------------------------------------------------
+template <typename ModelType, typename FeatureType, typename Solver>
+class UpdatedFitModel {
+ public:
+  UpdatedFitModel(const ModelType &model, std::vector<FeatureType> features, BlockSymmetric<Solver> cov, Vector info)
+      : train_features(std::move(features)), train_covariance(std::move(cov)), information(std::move(info)), model_(model) {}
+
+  std::int64_t rows() const { return train_covariance.rows(); }
+  Matrix solve(const Matrix &rhs) const { return train_covariance.solve(rhs); }
+
+  JointDistribution predict_joint(const std::vector<FeatureType> &xs) const {
+    const Matrix cross = model_.get_covariance()(train_features, xs);
+    const Matrix explained = train_covariance.solve(cross);
+    JointDistribution out;
+    out.mean = mean_of(cross, xs);
+    out.covariance = model_.get_covariance()(xs);
+    const std::int64_t n = cross.rows(), m = cross.cols();
+    for (std::int64_t a = 0; a < m; ++a)
+      for (std::int64_t b = 0; b < m; ++b) {
+        double s = 0.;
+        for (std::int64_t i = 0; i < n; ++i) s += cross(i, a) * explained(i, b);
+        out.covariance(a, b) -= s;
+      }
+    return out;
+  }
+  Vector predict_mean(const std::vector<FeatureType> &xs) const {
+    return mean_of(model_.get_covariance()(train_features, xs), xs);
+  }
+
+  // a further update nests the solvers, exactly like the reference's types do
+  UpdatedFitModel<ModelType, FeatureType, BlockSymmetric<Solver>> update(const RegressionDataset<FeatureType> &d) const {
+    return update_impl<ModelType, FeatureType, BlockSymmetric<Solver>>(model_, *this, train_covariance, train_features,
+                                                                        information, d);
+  }
+
+  template <typename M2, typename F2, typename S2, typename Self>
+  static UpdatedFitModel<M2, F2, S2> update_impl(const M2 &model, const Self &self, const S2 &solver,
+                                                 const std::vector<F2> &old_features, const Vector &old_information,
+                                                 const RegressionDataset<F2> &d) {
+    JointDistribution pred = self.predict_joint(d.features);                       // gp.hpp:388-389
+    const std::size_t m = d.features.size(), n = old_features.size();
+    Vector delta(m);
+    for (std::size_t i = 0; i < m; ++i) delta[i] = d.targets.mean[i] - pred.mean[i];
+    if (!d.targets.covariance.empty())
+      for (std::size_t i = 0; i < m; ++i) pred.covariance(static_cast<std::int64_t>(i), static_cast<std::int64_t>(i)) += d.targets.covariance[i];
+    const SerializableLDLT S_ldlt(pred.covariance);                                 // gp.hpp:393
+    const Matrix cross = model.get_covariance()(old_features, d.features);          // gp.hpp:395-396
+    BlockSymmetric<S2> new_cov(solver, cross, S_ldlt);                              // gp.hpp:398-399
+    const Vector Si_delta = S_ldlt.solve(delta);
+    Vector info(n + m);
+    for (std::size_t i = 0; i < n; ++i) {                                           // gp.hpp:403-407
+      double s = old_information[i];
+      for (std::size_t j = 0; j < m; ++j) s -= new_cov.Ai_B(static_cast<std::int64_t>(i), static_cast<std::int64_t>(j)) * Si_delta[j];
+      info[i] = s;
+    }
+    for (std::size_t j = 0; j < m; ++j) info[n + j] = Si_delta[j];
+    std::vector<F2> feats = old_features;
+    feats.insert(feats.end(), d.features.begin(), d.features.end());
+    return UpdatedFitModel<M2, F2, S2>(model, std::move(feats), std::move(new_cov), std::move(info));
+  }
+
+  std::vector<FeatureType> train_features;
+  BlockSymmetric<Solver> train_covariance;
+  Vector information;
+
+ private:
+  Vector mean_of(const Matrix &cross, const std::vector<FeatureType> &xs) const {
+    Vector mean(xs.size(), 0.);
+    for (std::int64_t j = 0; j < cross.cols(); ++j) {
+      double s = 0.;
+      for (std::int64_t i = 0; i < cross.rows(); ++i) s += cross(i, j) * information[static_cast<std::size_t>(i)];
+      mean[static_cast<std::size_t>(j)] = s;
+    }
+    model_.add_mean(xs, &mean);
+    return mean;
+  }
+  ModelType model_;
+};
+
+// update(fit_model, dataset), core/fit_model.hpp:117-120
+template <typename ModelType, typename FeatureType>
+UpdatedFitModel<ModelType, FeatureType, GPFit<FeatureType>> update(const FitModel<ModelType, FeatureType> &fm,
+                                                                    const RegressionDataset<FeatureType> &d) {
+  struct Adapter {  // FitModel seen through the interface update_impl needs
+    const FitModel<ModelType, FeatureType> *fm;
+    JointDistribution predict_joint(const std::vector<FeatureType> &xs) const { return fm->predict(xs).joint(); }
+  } self{&fm};
+  return UpdatedFitModel<ModelType, FeatureType, GPFit<FeatureType>>::template update_impl<ModelType, FeatureType, GPFit<FeatureType>>(
+      fm.get_model(), self, fm.get_fit(), fm.get_fit().train_features, fm.get_fit().information, d);
+}
 
 // ---------------------------------------------------------------------------
 // GaussianProcessRegression (gp.hpp:170-505)

@@ -95,6 +95,9 @@ def test_cpp_api_matches_oracle():
     lm, lv = ofit.loo_marginal(y)
     assert np.abs(loo[:, 1] - lm).max() <= 1e-8 * np.abs(lm).max() and np.abs(loo[:, 2] - lv).max() <= 1e-8 * lv.max()
     assert np.abs(loo[:, 3] - ofit.inverse_diagonal()).max() <= 1e-8 * ofit.inverse_diagonal().max()
+    assert abs(float(one["mvn_nll"]) - 6.0946974293510134) < 1e-12  # tests/test_evaluate.cc:26,41
+    assert abs(float(one["mvn_logdet"]) - np.linalg.slogdet(np.array([[1, .9, .8], [.9, 1, .9], [.8, .9, 1.]]))[1]) < 1e-13
+    assert float(one["update_mean_diff"]) < 1e-8 and float(one["update_cov_diff"]) < 1e-6  # tests/test_gp.cc:213
     assert float(one["joint_asymmetry"]) == 0.
     assert float(one["solve_residual"]) < 1e-10
     assert "not positive definite" in one["singular"] and "pivot 1" in one["singular"]
