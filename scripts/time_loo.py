@@ -1,0 +1,18 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import albatross_amd as ab
+ctx = ab.Context(0)
+n = 16384
+rng = np.random.default_rng(44)
+x = rng.uniform(0., 10., (n, 3)); y = np.sin(x).sum(axis=1) + 0.1 * np.cos(10. * x[:, 0])
+cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+fm = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
+fit = fm.get_fit()
+fit.leave_one_out(y)
+t = time.perf_counter(); loo = fit.leave_one_out(y); dt = time.perf_counter() - t
+print(f"LOO marginals of all {n} points: {dt*1e3:.1f} ms ({n**3/3/dt/1e12:.1f} TFLOP/s on N^3/3)")
+K = rng.standard_normal((4096, 4100)); K = K @ K.T / 4096 + np.eye(4096)
+ab.DenseFactor(K, ctx)
+t = time.perf_counter(); f = ab.DenseFactor(K, ctx); dt = time.perf_counter() - t
+print(f"DenseFactor n=4096 (host matrix, incl. 134 MB upload): {dt*1e3:.1f} ms")
