@@ -340,6 +340,25 @@ static int copy_out(agp_context *ctx, const double *dev, long long count, double
 
 static int copy_out_2d(agp_context *ctx, const double *dev, long long ld_dev, long long rows, long long cols,
                        double *dst, long long ld_dst, int location) {
+  if (location == AGP_HOST && ld_dev == ld_dst) {  // one contiguous transfer instead of one per column
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(dst, dev, sizeof(double) * ((size_t)ld_dev * (size_t)(cols - 1) + (size_t)rows),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return AGP_OK;
+  }
+  if (location == AGP_HOST && (size_t)rows * (size_t)cols >= (1u << 16)) {
+    // re-pitch on the device, then one contiguous transfer
+    double *tmp = nullptr;
+    const size_t elems = (size_t)ld_dst * (size_t)(cols - 1) + (size_t)rows;
+    AGP_HIP_CHECK(ctx, hipMalloc(&tmp, sizeof(double) * elems));
+    hipError_t e = hipMemcpy2DAsync(tmp, sizeof(double) * (size_t)ld_dst, dev, sizeof(double) * (size_t)ld_dev,
+                                    sizeof(double) * (size_t)rows, (size_t)cols, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, sizeof(double) * elems, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return AGP_ERR_HIP; }
+    return AGP_OK;
+  }
   const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, sizeof(double) * (size_t)ld_dst, dev, sizeof(double) * (size_t)ld_dev,
                                       sizeof(double) * (size_t)rows, (size_t)cols, kind, ctx->stream));
@@ -663,9 +682,19 @@ static int factor_dense(agp_context *c, const double *K, long long n, long long 
     AGP_HIP_CHECK(ctx, hipMalloc(&fit->A, fit->A_bytes));
   }
   AGP_HIP_CHECK(ctx, hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * (36 * MB * MB)));
-  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-  AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(fit->A, sizeof(double) * (size_t)fit->lda, K, sizeof(double) * (size_t)ld,
-                                      sizeof(double) * (size_t)n, (size_t)n, kind, s));
+  if (location == AGP_HOST) {
+    // a pitched copy from pageable host memory degenerates into one small copy per
+    // column; upload the matrix in one piece and re-pitch it on the device
+    const size_t bytes = sizeof(double) * (size_t)ld * (size_t)n;
+    int st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, bytes);
+    if (st != AGP_OK) return st;
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws_aux, K, bytes - sizeof(double) * (size_t)(ld - n), hipMemcpyHostToDevice, s));
+    AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(fit->A, sizeof(double) * (size_t)fit->lda, ctx->ws_aux, sizeof(double) * (size_t)ld,
+                                        sizeof(double) * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, s));
+  } else {
+    AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(fit->A, sizeof(double) * (size_t)fit->lda, K, sizeof(double) * (size_t)ld,
+                                        sizeof(double) * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, s));
+  }
   AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
   AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 4 * sizeof(double), s));
   launch_nan_scan_lower(s, fit->A, fit->lda, n, ctx->d_flags);
