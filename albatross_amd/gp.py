@@ -287,9 +287,12 @@ class DenseFactor:
 
     def __init__(self, matrix, context=None):
         self._ctx = context or default_context()
-        K = np.asfortranarray(matrix, dtype=np.float64)
+        K = np.asarray(matrix, dtype=np.float64)
         if K.ndim != 2 or K.shape[0] != K.shape[1]:
             raise ValueError("square matrix expected")
+        if not (K.flags.f_contiguous or K.flags.c_contiguous):
+            K = np.asfortranarray(K)
+        # a C-ordered symmetric matrix read column-major is its own transpose: no copy needed
         self.n = K.shape[0]
         h = C.c_void_p()
         st = self._ctx._lib.agp_factor_create(self._ctx._h, _ptr(K), self.n, self.n, capi.HOST, C.byref(h))

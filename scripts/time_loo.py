@@ -16,3 +16,14 @@ K = rng.standard_normal((4096, 4100)); K = K @ K.T / 4096 + np.eye(4096)
 ab.DenseFactor(K, ctx)
 t = time.perf_counter(); f = ab.DenseFactor(K, ctx); dt = time.perf_counter() - t
 print(f"DenseFactor n=4096 (host matrix, incl. 134 MB upload): {dt*1e3:.1f} ms")
+import ctypes as C
+from albatross_amd import _capi as capi
+Kf = np.asfortranarray(K)
+h = C.c_void_p()
+t = time.perf_counter()
+st = ctx._lib.agp_factor_create(ctx._h, C.c_void_p(Kf.ctypes.data), 4096, 4096, capi.HOST, C.byref(h)); dt = time.perf_counter() - t
+print(f"agp_factor_create n=4096 from a host matrix: {dt*1e3:.1f} ms (status {st})")
+ctx._lib.agp_fit_destroy(h)
+t = time.perf_counter()
+st = ctx._lib.agp_factor_create(ctx._h, C.c_void_p(Kf.ctypes.data), 4096, 4096, capi.HOST, C.byref(h)); dt = time.perf_counter() - t
+print(f"  second call: {dt*1e3:.1f} ms")
