@@ -1,0 +1,96 @@
+// temperature_example.cpp — the covariance function and feature type of the reference's
+// examples/temperature_example (BASELINE config 4's spatial kernel) on the drop-in C++ surface,
+// in fp64, on synthetic stations (lat ~ U[25,50] deg, lon ~ U[-125,-65] deg,
+// h ~ U[0,3000] m -> WGS-84 ECEF; temp = 60 - 0.0065 h 1.8 + smooth field + N(0, 1.75)).
+// `Station` is an arbitrary user feature type: ECEF coordinates for the radial / angular
+// metrics, equality by ECEF (temperature_example_utils.h:34), elevation for the ScalingTerm.
+// Output (CSV on stdout): station,<x>,<y>,<z>,<height>,<temp> / pred,<x>,<y>,<z>,<height>,<mean>,<var>
+// Usage: temperature_example [n_train] [n_predict]
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include <albatross_amd/albatross.hpp>
+
+struct Station {
+  int id;
+  double lat, lon, height;
+  std::array<double, 3> ecef;
+};
+
+namespace albatross {
+template <>
+struct FeatureTraits<Station> {
+  static constexpr int dim = 3;
+  static constexpr bool has_eq_id = false;  // equality == equality of the ECEF coordinates
+  static void coords(const Station &s, double *out) { out[0] = s.ecef[0]; out[1] = s.ecef[1]; out[2] = s.ecef[2]; }
+  static std::int64_t eq_id(const Station &) { return 0; }
+};
+}  // namespace albatross
+
+using namespace albatross;
+
+// temperature_example_utils.h:68-90
+class ElevationScalingFunction {
+ public:
+  explicit ElevationScalingFunction(double center_ = 1000., double factor_ = 3.5 / 300) : center(center_), factor(factor_) {}
+  std::string get_name() const { return "elevation_scaled"; }
+  ParameterStore get_params() const { return {{"elevation_scaling_center", center}, {"elevation_scaling_factor", factor}}; }
+  void set_param(const std::string &n, double v) { (n == "elevation_scaling_center" ? center : factor) = v; }
+  double _call_impl(const Station &x) const { return 1. + factor * std::fmax(0., (center - x.height)); }
+
+ private:
+  double center, factor;
+};
+
+static Station make_station(int id, double lat_deg, double lon_deg, double h) {
+  const double a = 6378137.0, e2 = 6.69437999014e-3;
+  const double lat = lat_deg * M_PI / 180., lon = lon_deg * M_PI / 180.;
+  const double N = a / std::sqrt(1. - e2 * std::sin(lat) * std::sin(lat));
+  Station s;
+  s.id = id; s.lat = lat_deg; s.lon = lon_deg; s.height = h;
+  s.ecef = {(N + h) * std::cos(lat) * std::cos(lon), (N + h) * std::cos(lat) * std::sin(lon), (N * (1. - e2) + h) * std::sin(lat)};
+  return s;
+}
+
+int main(int argc, char *argv[]) {
+  const int n = argc > 1 ? std::stoi(argv[1]) : 1500, m = argc > 2 ? std::stoi(argv[2]) : 100;
+  std::mt19937 gen(7);
+  std::uniform_real_distribution<double> ulat(25., 50.), ulon(-125., -65.), uh(0., 3000.);
+  std::normal_distribution<double> noise(0., 1.75);
+  std::vector<Station> stations, grid;
+  Vector temps;
+  for (int i = 0; i < n; ++i) {
+    Station s = make_station(i, ulat(gen), ulon(gen), uh(gen));
+    temps.push_back(60. - 0.0065 * s.height * 1.8 + 8. * std::sin(s.lat / 7.) * std::cos(s.lon / 11.) + noise(gen));
+    stations.push_back(s);
+  }
+  for (int i = 0; i < m; ++i) grid.push_back(make_station(n + i, ulat(gen), ulon(gen), uh(gen)));
+  grid[0] = stations[3];  // one prediction location coincides with a station
+
+  // temperature_example.cc:34-85
+  IndependentNoise<Station> noise_cov(2.0);
+  Constant mean(1.5);
+  ScalingTerm<ElevationScalingFunction> elevation_scalar;
+  auto elevation_scaled_mean = elevation_scalar * mean;
+  SquaredExponential<RadialDistance> radial_sqr_exp(15000., 2.5);
+  Exponential<AngularDistance> angular_exp(9e-2, 3.5);
+  auto spatial_cov = angular_exp * radial_sqr_exp;
+  auto covariance = elevation_scaled_mean + noise_cov + spatial_cov;
+  auto model = gp_from_covariance(covariance);
+  model.set_param_values({{"elevation_scaling_center", 4446.5}, {"elevation_scaling_factor", 0.000153439},
+                          {"exponential_length_scale", 1.10298}, {"sigma_constant", 5.07288}, {"sigma_exponential", 1},
+                          {"sigma_independent_noise", 1.75027}, {"sigma_squared_exponential", 13.913},
+                          {"squared_exponential_length_scale", 5835.56}});
+  std::printf("name,%s\n", model.get_covariance().get_name().c_str());
+  const auto fit_model = model.fit(RegressionDataset<Station>(stations, temps));
+  std::printf("loglik,%.17g\n", model.log_likelihood(RegressionDataset<Station>(stations, temps)));
+  const auto pred = fit_model.predict(grid).marginal();
+  for (int i = 0; i < n; ++i)
+    std::printf("station,%.17g,%.17g,%.17g,%.17g,%.17g\n", stations[i].ecef[0], stations[i].ecef[1], stations[i].ecef[2],
+                stations[i].height, temps[i]);
+  for (int i = 0; i < m; ++i)
+    std::printf("pred,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n", grid[i].ecef[0], grid[i].ecef[1], grid[i].ecef[2], grid[i].height,
+                pred.mean[i], pred.covariance[i]);
+  return 0;
+}

@@ -101,3 +101,32 @@ def test_cpp_api_matches_oracle():
     assert float(one["joint_asymmetry"]) == 0.
     assert float(one["solve_residual"]) < 1e-10
     assert "not positive definite" in one["singular"] and "pivot 1" in one["singular"]
+
+
+@pytest.mark.gpu
+def test_temperature_example_config4_kernel():
+    """BASELINE config 4's spatial kernel (examples/temperature_example) in fp64 on synthetic
+    stations: a user feature type (Station: ECEF coords, equality by ECEF, elevation-dependent
+    ScalingTerm) through the C++ surface vs the oracle."""
+    rows = run("temperature_example", "1500", "100")
+    st = np.array(rows["station"], dtype=float)
+    pr = np.array(rows["pred"], dtype=float)
+    assert rows["name"][0][0] == ("(((elevation_scaled*constant)+independent_noise)+"
+                                  "(exponential[angular_distance]*squared_exponential[radial_distance]))")
+
+    class Elev(ab.ScalingFunction):
+        def _call_impl(self, c):
+            raise AssertionError("scale columns are supplied explicitly")
+
+    cov = ab.ScalingTerm(Elev()) * ab.Constant(5.07288) + ab.IndependentNoise(1.75027) \
+        + ab.Exponential(1.10298, 1.0, ab.AngularDistance()) * ab.SquaredExponential(5835.56, 13.913, ab.RadialDistance())
+    scale = lambda h: 1. + 0.000153439 * np.maximum(0., 4446.5 - h)
+    train = ab.FeatureSet(st[:, :3], [scale(st[:, 3])])
+    test = ab.FeatureSet(pr[:, :3], [scale(pr[:, 3])])
+    ofit = orc.OracleFit(cov, train, st[:, 4])
+    om, ov = ofit.predict_marginal(test)
+    assert np.abs(pr[:, 4] - om).max() <= 1e-8 * np.abs(om).max()
+    assert np.abs(pr[:, 5] - ov).max() <= 1e-8 * np.abs(ov).max()
+    assert abs(float(rows["loglik"][0][0]) + orc.nll(cov, train, st[:, 4])) <= 1e-6 * 1500
+    # the prediction placed on a station sees that station's noise term (IndependentNoise<Station>, x == y)
+    assert pr[0, 5] > 0
