@@ -94,7 +94,9 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const DevProgram *__
       if (ra == col) va += diag_add[col];
       if (rb == col) vb += diag_add[col];
     }
-    saw_nan = saw_nan || (va != va) || (vb != vb);
+    // only entries that are stored count (padding rows of an edge tile are zero
+    // vectors: the angular metric makes NaN out of them)
+    saw_nan = saw_nan || (ra < X.n && va != va) || (rb < X.n && vb != vb);
     double *dst = out + col * ld + ra;
     if (rb < X.n) {
       if (wide) {
@@ -216,7 +218,9 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_fast_kernel(FastParams fp, 
       if (ra == col) va += diag_add[col];
       if (rb == col) vb += diag_add[col];
     }
-    saw_nan = saw_nan || (va != va) || (vb != vb);
+    // only entries that are stored count (padding rows of an edge tile are zero
+    // vectors: the angular metric makes NaN out of them)
+    saw_nan = saw_nan || (ra < X.n && va != va) || (rb < X.n && vb != vb);
     double *dst = out + col * ld + ra;
     if (rb < X.n) {
       if (wide) *reinterpret_cast<double2 *>(dst) = make_double2(va, vb);
