@@ -128,5 +128,6 @@ def test_temperature_example_config4_kernel():
     assert np.abs(pr[:, 4] - om).max() <= 1e-8 * np.abs(om).max()
     assert np.abs(pr[:, 5] - ov).max() <= 1e-8 * np.abs(ov).max()
     assert abs(float(rows["loglik"][0][0]) + orc.nll(cov, train, st[:, 4])) <= 1e-6 * 1500
-    # the prediction placed on a station sees that station's noise term (IndependentNoise<Station>, x == y)
-    assert pr[0, 5] > 0
+    # the prediction placed ON a station: IndependentNoise<Station> is not measurement-only, so the
+    # equal feature (x == y by ECEF) shares its noise and the observed value is reproduced exactly
+    assert abs(pr[0, 5]) < 1e-8 and abs(pr[0, 4] - st[3, 4]) < 1e-8
