@@ -33,6 +33,10 @@ struct FeatView {
 struct DeviceFeatures {
   FeatView v{};
   void *owned[3] = {nullptr, nullptr, nullptr};
+  DeviceFeatures() = default;
+  DeviceFeatures(const DeviceFeatures &) = delete;
+  DeviceFeatures &operator=(const DeviceFeatures &) = delete;
+  ~DeviceFeatures() { release(); }  // error paths return early: the owned device copies go with the object
   void release();
 };
 
