@@ -112,6 +112,8 @@ int agp_context_create(int device_id, agp_context **out) {
     AGP_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi));
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo));
+    AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo));
+    AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
   }
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
@@ -147,6 +149,8 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
   delete ctx;
 }
 

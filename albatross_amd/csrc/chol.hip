@@ -489,7 +489,18 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     if (next_end < n) {
       (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       const double *Q = A + K0 * lda + next_end;
-      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true);
+      const double hf = hybrid_split_fraction();
+      if (hf > 0. && n - next_end >= 4096 && K >= 256) {
+        // experiment: MFMA kernel on the left tile columns, VALU kernel on the right triangle, concurrently
+        hipStream_t sc = ctx->stream3;
+        (void)hipStreamWaitEvent(sc, ctx->ev_a, 0);
+        (void)hipStreamWaitEvent(sc, ctx->ev_b, 0);  // after the previous bulk update (recorded on sb)
+        launch_trailing_update_split(sb, sc, A + next_end * lda + next_end, lda, Q, lda, n - next_end, K, hf);
+        (void)hipEventRecord(ctx->ev_c, sc);
+        (void)hipStreamWaitEvent(sb, ctx->ev_c, 0);  // ev_b below then covers both halves
+      } else {
+        timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true);
+      }
       (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;
     } else {

@@ -50,6 +50,8 @@ struct agp_context {
   int device = 0;
   hipStream_t stream = nullptr;   // main chain
   hipStream_t stream2 = nullptr;  // look-ahead / side chain
+  hipStream_t stream3 = nullptr;  // second bulk stream (hybrid MFMA + VALU experiment)
+  hipEvent_t ev_c = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   std::vector<hipEvent_t> ev_pool;
   std::string last_error;
@@ -159,4 +161,7 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
 // bulk trailing update of the factorisation: C(M x M, lower tiles) -= P Q^T
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K);
+double hybrid_split_fraction();
+void launch_trailing_update_split(hipStream_t s_mfma, hipStream_t s_valu, double *C, long long ldc, const double *P,
+                                  long long ldp, long long M, long long K, double frac);
 }  // namespace agp

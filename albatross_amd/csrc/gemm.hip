@@ -17,6 +17,7 @@
 //
 // Roofline: MFMA-bound.  Per tile 2*128*128*K flop against (2*128*K + 2*128*128)
 // * 8 B of operand + C traffic (K = 512: 64 flop/B).
+#include <cmath>
 #include <cstdlib>
 #include "common.h"
 #include "mfma_f64.h"
@@ -477,6 +478,49 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
   else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<false, true>), grid, block, 0, s, g);
   else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<true, false>), grid, block, 0, s, g);
   else hipLaunchKernelGGL((gemm_nt_sub_kernel<true, true>), grid, block, 0, s, g);
+}
+
+// Experiment (AGP_HYBRID_SPLIT=f, 0 < f < 1): the bulk update as two concurrent launches on two
+// streams — the left tile columns (a trapezoid) on the MFMA kernel, the right lower triangle,
+// holding about the fraction f of the tiles, on the VALU-FMA kernel — so that MFMA and VALU
+// instructions are in flight on every SIMD together.
+double hybrid_split_fraction() {
+  static double f = -1.;
+  if (f < 0.) {
+    const char *e = getenv("AGP_HYBRID_SPLIT");
+    f = e ? atof(e) : 0.;
+    if (!(f > 0. && f < 1.)) f = 0.;
+  }
+  return f;
+}
+
+void launch_trailing_update_split(hipStream_t s_mfma, hipStream_t s_valu, double *C, long long ldc, const double *P,
+                                  long long ldp, long long M, long long K, double frac) {
+  const int ntr = (int)((M + GT - 1) / GT);
+  int right = (int)(ntr * sqrt(frac) + 0.5);  // tile columns handed to the VALU kernel
+  if (right < 1) right = 1;
+  if (right >= ntr) right = ntr - 1;
+  const int c = ntr - right;  // first tile column of the right triangle
+  {  // left trapezoid: all rows, columns [0, c * 128)
+    GemmArgs g;
+    g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = P; g.ldb = ldp;
+    g.M = M; g.N = (long long)c * GT; g.K = K; g.tri = 1;
+    g.remap = 0; g.nsuper = 0; g.nb8 = 0;
+    g.ntr = ntr; g.ntc = c;
+    long long tiles = 0;
+    for (int bj = 0; bj < c; ++bj) tiles += ntr - bj;
+    hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s_mfma, g);
+  }
+  {  // right triangle: origin shifted onto the diagonal at tile (c, c)
+    const long long off = (long long)c * GT;
+    GemmArgs g;
+    g.C = C + off + off * ldc; g.ldc = ldc; g.A = P + off; g.lda = ldp; g.B = P + off; g.ldb = ldp;
+    g.M = M - off; g.N = M - off; g.K = K; g.tri = 1;
+    g.remap = 0; g.nsuper = 0; g.nb8 = 0;
+    g.ntr = right; g.ntc = right;
+    const long long tiles = (long long)right * (right + 1) / 2;
+    hipLaunchKernelGGL(trailing_update_valu_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s_valu, g);
+  }
 }
 
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
