@@ -560,7 +560,11 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[3], s));
   FIT_CHECK(hipMemcpyAsync(fit->alpha, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
   invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);
-  backward_solve_vec(s, fit->A, n, fit->lda, fit->winv, fit->alpha);
+  {
+    const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)round_up(n, 2));
+    if (st2 != AGP_OK) { agp_fit_destroy(fit); return st2; }
+  }
+  backward_solve_vec(s, fit->A, n, fit->lda, fit->winv, fit->alpha, ctx->ws_aux);
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[4], s));
   if (information) FIT_CHECK(hipMemcpyAsync(information, fit->alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   FIT_CHECK(hipStreamSynchronize(s));

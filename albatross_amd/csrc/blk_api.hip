@@ -70,7 +70,7 @@ int agp_blk_back_diag(agp_context *ctx, const double *A, int64_t lda, int64_t wi
   if (!ctx || !A || !img || !z || width <= 0) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long nblk = (width + NB - 1) / NB;
-  const size_t need = sizeof(double) * (size_t)nblk * NB * NB;
+  const size_t need = sizeof(double) * ((size_t)nblk * NB * NB + (size_t)nblk * NB);
   if (ctx->ws_aux_bytes < need) {
     if (ctx->ws_aux) {
       AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -82,7 +82,7 @@ int agp_blk_back_diag(agp_context *ctx, const double *A, int64_t lda, int64_t wi
     ctx->ws_aux_bytes = need;
   }
   invert_diag_blocks(ctx->stream, A, width, lda, img, ctx->ws_aux);
-  backward_solve_vec(ctx->stream, A, width, lda, ctx->ws_aux, z);
+  backward_solve_vec(ctx->stream, A, width, lda, ctx->ws_aux, z, ctx->ws_aux + (size_t)nblk * NB * NB);
   AGP_HIP_CHECK(ctx, hipGetLastError());
   return AGP_OK;
 }

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void set_identity_blocks_kernel(double *W, lon
   W[i] = ((within >> 7) == (within & (NB - 1))) ? 1. : 0.;
 }
 
-// Winv[b] = inv(L_bb), column-major NB x NB (lower), for every diagonal block.
+// Winv[b] = inv(L_bb)^T as a column-major NB x NB array (i.e. inv(L_bb) row-major), for every diagonal block.
 void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                         double *Winv) {
   const long long nblk = (n + NB - 1) / NB;
@@ -596,43 +596,77 @@ void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long l
   TrsmArgs t;
   (void)A; (void)lda;
   t.img = invd; t.nbk = NB;
-  t.Y = Winv; t.stride_m = 1; t.stride_n = NB; t.ncols = NB;
+  // element (m, n) of inv(L_bb) goes to Winv[m * NB + n]: the blocks are stored TRANSPOSED
+  // (row-major), so that the mat-vec x = inv(L_bb)^T z reads them coalesced
+  t.Y = Winv; t.stride_m = NB; t.stride_n = 1; t.ncols = NB;
   t.z = nullptr; t.yrest = nullptr;
   t.batch_img = IMG_DOUBLES; t.batch_Y = NB * NB; t.n_total = n;
   hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
 }
 
-// x_b = Winv_b^T z_b : 8 waves, 16 columns each, all 16 column segments of a
-// wave requested before the first is consumed (one L2 round trip per step —
-// this kernel sits on the serial chain of the back substitution)
-__global__ __launch_bounds__(512) void diag_back_kernel(const double *__restrict__ Winv, int nbk,
-                                                        double *__restrict__ zb) {
-  __shared__ double out[NB];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double2 zv = (2 * lane + 1 < nbk) ? *reinterpret_cast<const double2 *>(zb + 2 * lane)
-                                          : make_double2(2 * lane < nbk ? zb[2 * lane] : 0., 0.);
-  const int c0 = wave * 16;
-  double2 w[16];
+// One step of the right-looking back substitution, ONE launch:
+//   x_b = inv(L_bb)^T z_b            (every workgroup recomputes this 128 x 128 mat-vec from the
+//                                     L2-resident transposed inverse: 128 KB, coalesced rows)
+//   z[c] -= sum_r L[k0 + r][c] x_b[r]  for this workgroup's 32 columns c < k0
+// Workgroup 0 also publishes x_b into `x_out` (z_b itself stays untouched: other workgroups may
+// still be reading it).
+__global__ __launch_bounds__(256) void back_step_kernel(const double *__restrict__ A, long long lda, long long k0,
+                                                        int nbk, const double *__restrict__ WinvT,
+                                                        double *__restrict__ z, double *__restrict__ x_out) {
+  __shared__ double xs[NB], part[NB], zs[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < NB) zs[tid] = (tid < nbk) ? z[k0 + tid] : 0.;
+  __syncthreads();
+  {
+    // x[c] = sum_r inv(L)[r][c] z[r];  WinvT holds inv(L)[r][c] at [r * NB + c]
+    const int c = tid & (NB - 1), half = tid >> 7;
+    double acc = 0.;
+#pragma unroll 8
+    for (int r = half * 64; r < half * 64 + 64; ++r) acc += WinvT[r * NB + c] * zs[r];
+    if (half == 1) part[c] = acc;
+    __syncthreads();
+    if (half == 0) {
+      const double v = (c < nbk) ? acc + part[c] : 0.;
+      xs[c] = v;
+      if (blockIdx.x == 0 && c < nbk) x_out[k0 + c] = v;
+    }
+    __syncthreads();
+  }
+  const long long c0 = ((long long)blockIdx.x * 4 + wave) * 8;
+  if (c0 >= k0) return;
+  const int r = 2 * lane;
+  const double x0 = xs[r], x1 = xs[r + 1];
+  const bool vec = ((lda & 1) == 0) && ((k0 & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  double acc[8];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) w[q] = *reinterpret_cast<const double2 *>(Winv + (c0 + q) * NB + 2 * lane);
-  double acc[16];
+  for (int q = 0; q < 8; ++q) {
+    const long long c = c0 + q;
+    double a0 = 0., a1 = 0.;
+    if (c < k0) {
+      const double *p = A + c * lda + k0 + r;
+      if (vec && r + 1 < nbk) {
+        const double2 v = *reinterpret_cast<const double2 *>(p);
+        a0 = v.x; a1 = v.y;
+      } else {
+        a0 = r < nbk ? p[0] : 0.;
+        a1 = r + 1 < nbk ? p[1] : 0.;
+      }
+    }
+    acc[q] = a0 * x0 + a1 * x1;
+  }
 #pragma unroll
-  for (int q = 0; q < 16; ++q) acc[q] = w[q].x * zv.x + w[q].y * zv.y;
-  // 16 values per lane -> 16 column sums: fold halves (transpose-reduce), 6 steps
+  for (int q = 0; q < 8; ++q) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off, 64);
+    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
   }
   if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) out[c0 + q] = acc[q];
+    for (int q = 0; q < 8; ++q)
+      if (c0 + q < k0) z[c0 + q] -= acc[q];
   }
-  __syncthreads();
-  if (threadIdx.x < nbk) zb[threadIdx.x] = out[threadIdx.x];
 }
 
-// z[c] -= sum_r L[k0 + r][c] x[r]  for c < k0 ; r < nbk.   8 columns per wave.
+// z[c] -= sum_r L[k0 + r][c] x[r]  for c < ncols ; r < nbk.   8 columns per wave.
 __global__ __launch_bounds__(256) void back_update_kernel(const double *__restrict__ A, long long lda,
                                                           long long k0, int nbk, long long ncols,
                                                           const double *__restrict__ x, double *__restrict__ z) {
@@ -680,14 +714,19 @@ void launch_back_update(hipStream_t s, const double *A, long long lda, long long
 }
 
 void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Winv,
-                        double *z) {
+                        double *z, double *xstage) {
+  // z is consumed; the solution is produced in `xstage` (n doubles) block by block and copied
+  // back at the end: x of block b may not overwrite z_b while other workgroups of the same
+  // launch still read z_b
   const long long nblk = (n + NB - 1) / NB;
   for (long long b = nblk - 1; b >= 0; --b) {
     const long long k = b * NB;
     const int nbk = (int)((n - k < NB) ? n - k : NB);
-    hipLaunchKernelGGL(diag_back_kernel, dim3(1), dim3(512), 0, s, Winv + b * (long long)(NB * NB), nbk, z + k);
-    if (k > 0) launch_back_update(s, A, lda, k, nbk, k, z + k, z);
+    const unsigned grid = (unsigned)(k > 0 ? (k + 31) / 32 : 1);
+    hipLaunchKernelGGL(back_step_kernel, dim3(grid), dim3(256), 0, s, A, lda, k, nbk,
+                       Winv + b * (long long)(NB * NB), z, xstage);
   }
+  (void)hipMemcpyAsync(z, xstage, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }
 
 }  // namespace agp

@@ -129,7 +129,7 @@ void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long l
                         double *Winv);
 // x = L^-T z (one right-hand side), z overwritten.
 void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Winv,
-                        double *z);
+                        double *z, double *xstage);
 // B (n x m, ldb) <- L^-1 B
 void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                        double *B, long long m, long long ldb, bool rhs_lower = false);
