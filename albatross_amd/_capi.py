@@ -88,8 +88,8 @@ EXPORTS = [
     ("agp_fit_download_information", C.c_int, [_P, _P, _P]),
     ("agp_nll", C.c_int, [_P, _P, C.POINTER(Features), _P, _P, _D]),
     ("agp_solve", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int]),
-    ("agp_factor_create", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, _PP]),
-    ("agp_nll_dense", C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, _D]),
+    ("agp_factor_create", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _PP]),
+    ("agp_nll_dense", C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _D]),
     ("agp_fit_inverse_diagonal", C.c_int, [_P, _P, _P, C.c_int]),
     ("agp_loo_marginal", C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     ("agp_predict_mean", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, C.c_int]),

@@ -15,6 +15,8 @@ void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n);
 void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n);
 void launch_set_identity(hipStream_t s, double *B, long long ld, long long n);
 void launch_nan_scan_lower(hipStream_t s, const double *A, long long ld, long long n, int *flag);
+void launch_upper_to_lower(hipStream_t s, const double *src, long long ld_src, double *dst, long long ld_dst,
+                           long long n);
 void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const double *information, long long n,
                 double *mean, double *variance);
 
@@ -672,8 +674,8 @@ int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs, int64_t n
 // ---- dense-matrix factor ---------------------------------------------------------
 // copies the lower triangle of K into a fresh factor buffer and runs the LL^T;
 // y (device, optional) receives the fused forward substitution
-static int factor_dense(agp_context *c, const double *K, long long n, long long ld, int location, agp_fit *fit,
-                        double *y) {
+static int factor_dense(agp_context *c, const double *K, long long n, long long ld, int uplo, int location,
+                        agp_fit *fit, double *y) {
   agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
   hipStream_t s = ctx->stream;
   const long long nblk = (n + NB - 1) / NB;
@@ -690,6 +692,7 @@ static int factor_dense(agp_context *c, const double *K, long long n, long long 
     AGP_HIP_CHECK(ctx, hipMalloc(&fit->A, fit->A_bytes));
   }
   AGP_HIP_CHECK(ctx, hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * (36 * MB * MB)));
+  const double *src = K;  // device-resident source of the triangle
   if (location == AGP_HOST) {
     // a pitched copy from pageable host memory degenerates into one small copy per
     // column; upload the matrix in one piece and re-pitch it on the device
@@ -697,12 +700,13 @@ static int factor_dense(agp_context *c, const double *K, long long n, long long 
     int st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, bytes);
     if (st != AGP_OK) return st;
     AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws_aux, K, bytes - sizeof(double) * (size_t)(ld - n), hipMemcpyHostToDevice, s));
-    AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(fit->A, sizeof(double) * (size_t)fit->lda, ctx->ws_aux, sizeof(double) * (size_t)ld,
-                                        sizeof(double) * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, s));
-  } else {
-    AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(fit->A, sizeof(double) * (size_t)fit->lda, K, sizeof(double) * (size_t)ld,
-                                        sizeof(double) * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, s));
+    src = ctx->ws_aux;
   }
+  if (uplo == 0)
+    AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(fit->A, sizeof(double) * (size_t)fit->lda, src, sizeof(double) * (size_t)ld,
+                                        sizeof(double) * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, s));
+  else
+    launch_upper_to_lower(s, src, ld, fit->A, fit->lda, n);
   AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
   AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 4 * sizeof(double), s));
   launch_nan_scan_lower(s, fit->A, fit->lda, n, ctx->d_flags);
@@ -716,21 +720,22 @@ static int factor_dense(agp_context *c, const double *K, long long n, long long 
   return status_from_flags(ctx);
 }
 
-int agp_factor_create(agp_context *ctx, const double *K, int64_t n, int64_t ld, int location, agp_fit **out) {
-  if (!ctx || !K || !out || n <= 0 || ld < n) return AGP_ERR_INVALID_ARGUMENT;
+int agp_factor_create(agp_context *ctx, const double *K, int64_t n, int64_t ld, int uplo, int location,
+                      agp_fit **out) {
+  if (!ctx || !K || !out || n <= 0 || ld < n || (uplo != 0 && uplo != 1)) return AGP_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   agp_fit *fit = new (std::nothrow) agp_fit();
   if (!fit) return AGP_ERR_INVALID_ARGUMENT;
-  const int st = factor_dense(ctx, K, n, ld, location, fit, nullptr);
+  const int st = factor_dense(ctx, K, n, ld, uplo, location, fit, nullptr);
   if (st == AGP_ERR_HIP) { agp_fit_destroy(fit); return st; }
   *out = fit;  // on NOT_POSITIVE_DEFINITE / NAN the handle only carries the failed pivot
   return st;
 }
 
-int agp_nll_dense(agp_context *ctx, const double *deviation, const double *K, int64_t n, int64_t ld, int location,
-                  double *out) {
-  if (!ctx || !deviation || !K || !out || n <= 0 || ld < n) return AGP_ERR_INVALID_ARGUMENT;
+int agp_nll_dense(agp_context *ctx, const double *deviation, const double *K, int64_t n, int64_t ld, int uplo,
+                  int location, double *out) {
+  if (!ctx || !deviation || !K || !out || n <= 0 || ld < n || (uplo != 0 && uplo != 1)) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (n == 1) {  // univariate shortcut, likelihood.hpp:57-60 -> -gaussian::log_pdf(deviation, variance)
     double d = 0., v = 0.;
@@ -746,7 +751,7 @@ int agp_nll_dense(agp_context *ctx, const double *deviation, const double *K, in
   hipError_t e = hipMalloc(&z, sizeof(double) * (size_t)n);
   if (e != hipSuccess) { delete fit; ctx->last_error = hipGetErrorString(e); return AGP_ERR_HIP; }
   int st = vector_to_device(ctx, deviation, n, location, z);
-  if (st == AGP_OK) st = factor_dense(ctx, K, n, ld, location, fit, z);
+  if (st == AGP_OK) st = factor_dense(ctx, K, n, ld, uplo, location, fit, z);
   if (st == AGP_OK) {
     launch_dot(ctx->stream, z, z, n, ctx->d_scalars + 1);  // dev^T K^-1 dev = z^T z
     e = hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);

@@ -87,6 +87,33 @@ void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n) {
   hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)n), dim3(256), 0, s, A, ld, n);
 }
 
+// dst lower triangle (ld_dst) <- transpose of the upper triangle of src (ld_src)
+__global__ __launch_bounds__(256) void upper_to_lower_kernel(const double *__restrict__ src, long long ld_src,
+                                                             double *__restrict__ dst, long long ld_dst, long long n) {
+  __shared__ double tile[32][33];
+  const long long bi = blockIdx.x, bj = blockIdx.y;  // destination tile (rows bi, cols bj), bi >= bj
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    // source element (row = bj*32 + tx, col = bi*32 + r): upper part since bj <= bi
+    const long long row = bj * 32 + tx, col = bi * 32 + r;
+    tile[r][tx] = (row < n && col < n) ? src[col * ld_src + row] : 0.;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    // destination element (row = bi*32 + tx, col = bj*32 + r) = source (col', row') transposed
+    const long long row = bi * 32 + tx, col = bj * 32 + r;
+    if (row < n && col < n && row >= col) dst[col * ld_dst + row] = tile[tx][r];
+  }
+}
+
+void launch_upper_to_lower(hipStream_t s, const double *src, long long ld_src, double *dst, long long ld_dst,
+                           long long n) {
+  if (n <= 0) return;
+  const unsigned nb = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(upper_to_lower_kernel, dim3(nb, nb), dim3(256), 0, s, src, ld_src, dst, ld_dst, n);
+}
+
 // NaN scan of the lower triangle (ALBATROSS_ASSERT(!cov.hasNaN()), gp.hpp:66)
 __global__ __launch_bounds__(256) void nan_scan_lower_kernel(const double *A, long long ld, long long n, int *flag) {
   const long long col = blockIdx.x;

@@ -292,10 +292,12 @@ class DenseFactor:
             raise ValueError("square matrix expected")
         if not (K.flags.f_contiguous or K.flags.c_contiguous):
             K = np.asfortranarray(K)
-        # a C-ordered symmetric matrix read column-major is its own transpose: no copy needed
+        # the LOWER triangle of the array is what is read.  A C-ordered (row-major) array seen
+        # column-major is its transpose, whose UPPER triangle that is: no host copy, uplo = 1.
+        uplo = 0 if K.flags.f_contiguous else 1
         self.n = K.shape[0]
         h = C.c_void_p()
-        st = self._ctx._lib.agp_factor_create(self._ctx._h, _ptr(K), self.n, self.n, capi.HOST, C.byref(h))
+        st = self._ctx._lib.agp_factor_create(self._ctx._h, _ptr(K), self.n, self.n, uplo, capi.HOST, C.byref(h))
         if st != capi.AGP_OK:
             pivot = self._ctx._lib.agp_fit_failed_pivot(h) if h else -1
             if h:
@@ -324,10 +326,13 @@ def negative_log_likelihood(deviation, covariance, context=None):
     """negative_log_likelihood(deviation, covariance) (evaluation/likelihood.hpp:53-66)."""
     ctx = context or default_context()
     d = np.ascontiguousarray(deviation, dtype=np.float64)
-    K = np.asfortranarray(covariance, dtype=np.float64)
+    K = np.asarray(covariance, dtype=np.float64)
+    if not (K.flags.f_contiguous or K.flags.c_contiguous):
+        K = np.asfortranarray(K)
+    uplo = 0 if K.flags.f_contiguous else 1
     out = C.c_double()
-    ctx._check(ctx._lib.agp_nll_dense(ctx._h, _ptr(d), _ptr(K), d.shape[0], K.shape[0], capi.HOST, C.byref(out)),
-               "agp_nll_dense")
+    ctx._check(ctx._lib.agp_nll_dense(ctx._h, _ptr(d), _ptr(K), d.shape[0], K.shape[0], uplo, capi.HOST,
+                                      C.byref(out)), "agp_nll_dense")
     return out.value
 
 

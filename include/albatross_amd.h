@@ -181,16 +181,17 @@ int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs,
 /* Eigen::SerializableLDLT(const MatrixXd &) (src/eigen/serializable_ldlt.hpp:27)
  * as used by update() (models/gp.hpp:393), BlockSymmetric (linalg/block_symmetric.hpp:
  * 46-60) and the dense negative_log_likelihood: factor a symmetric positive-definite
- * matrix given by its LOWER triangle (column-major, ld, at `location`).  The handle
+ * matrix given by ONE triangle (column-major, ld, at `location`): uplo = 0 reads the
+ * lower triangle, uplo = 1 the upper one (a row-major array handed over as it is).  The handle
  * supports agp_solve, agp_fit_log_determinant, agp_fit_inverse_diagonal,
  * agp_fit_download_factor, agp_fit_size, agp_fit_failed_pivot; it has no training
  * features (agp_predict_* and agp_loo_marginal reject it). */
 int agp_factor_create(agp_context *ctx, const double *K, int64_t n, int64_t ld,
-                      int location, agp_fit **out);
+                      int uplo, int location, agp_fit **out);
 /* negative_log_likelihood(deviation, covariance) (src/evaluation/likelihood.hpp:53-66):
  * 0.5 (log|K| + dev^T K^-1 dev + n log 2 pi); the univariate shortcut (:57-60) included. */
 int agp_nll_dense(agp_context *ctx, const double *deviation, const double *K,
-                  int64_t n, int64_t ld, int location, double *out);
+                  int64_t n, int64_t ld, int uplo, int location, double *out);
 
 /* ---- leave-one-out fast path (the tuner's LeaveOneOutLikelihood objective) --- */
 /* diag(K^-1): SerializableLDLT::inverse_diagonal (src/eigen/serializable_ldlt.hpp:

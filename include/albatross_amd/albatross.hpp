@@ -589,7 +589,7 @@ class SerializableLDLT {
   SerializableLDLT() = default;
   explicit SerializableLDLT(const Matrix &x) : context_(detail::default_context()), n_(x.rows()) {
     agp_fit *h = nullptr;
-    const int st = agp_factor_create(context_->ctx, x.data.data(), x.rows(), x.rows(), AGP_HOST, &h);
+    const int st = agp_factor_create(context_->ctx, x.data.data(), x.rows(), x.rows(), /*uplo=*/0, AGP_HOST, &h);
     if (st != AGP_OK) {
       const long long pivot = h ? static_cast<long long>(agp_fit_failed_pivot(h)) : -1;
       agp_fit_destroy(h);
@@ -634,7 +634,7 @@ inline double negative_log_likelihood(const Vector &deviation, const Matrix &cov
   auto ctx = detail::default_context();
   double out = 0.;
   detail::check(agp_nll_dense(ctx->ctx, deviation.data(), covariance.data.data(), covariance.rows(), covariance.rows(),
-                              AGP_HOST, &out),
+                              /*uplo=*/0, AGP_HOST, &out),
                 ctx->ctx, "agp_nll_dense");
   return out;
 }

@@ -21,9 +21,9 @@ from albatross_amd import _capi as capi
 Kf = np.asfortranarray(K)
 h = C.c_void_p()
 t = time.perf_counter()
-st = ctx._lib.agp_factor_create(ctx._h, C.c_void_p(Kf.ctypes.data), 4096, 4096, capi.HOST, C.byref(h)); dt = time.perf_counter() - t
+st = ctx._lib.agp_factor_create(ctx._h, C.c_void_p(Kf.ctypes.data), 4096, 4096, 0, capi.HOST, C.byref(h)); dt = time.perf_counter() - t
 print(f"agp_factor_create n=4096 from a host matrix: {dt*1e3:.1f} ms (status {st})")
 ctx._lib.agp_fit_destroy(h)
 t = time.perf_counter()
-st = ctx._lib.agp_factor_create(ctx._h, C.c_void_p(Kf.ctypes.data), 4096, 4096, capi.HOST, C.byref(h)); dt = time.perf_counter() - t
+st = ctx._lib.agp_factor_create(ctx._h, C.c_void_p(Kf.ctypes.data), 4096, 4096, 0, capi.HOST, C.byref(h)); dt = time.perf_counter() - t
 print(f"  second call: {dt*1e3:.1f} ms")

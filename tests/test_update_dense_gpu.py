@@ -44,6 +44,14 @@ def test_dense_factor_matches_oracle(ctx, n):
     assert abs(ab.negative_log_likelihood(dev, A, context=ctx) - orc.nll_dense(dev, A)) <= 1e-9 * n
 
 
+def test_dense_factor_reads_only_the_lower_triangle(ctx):
+    A = spd(200, 9)
+    want = np.linalg.solve(A, np.ones(200))
+    for order in ("F", "C"):  # column-major: uplo = 0; row-major: handed over untransposed, uplo = 1
+        M = np.array(np.tril(A) + np.triu(np.full_like(A, 1e9), 1), order=order)  # garbage above the diagonal
+        assert np.abs(ab.DenseFactor(M, ctx).solve(np.ones(200)) - want).max() <= 1e-10 * np.abs(want).max()
+
+
 def test_dense_factor_error_paths(ctx):
     A = spd(50, 1)
     A[30, 30] = -1.
