@@ -122,6 +122,8 @@ __device__ __forceinline__ void micro_syrk_tile(double *T, int ib, int kb, int j
 }
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
+  // serial panel chain: issue ahead of the bulk-update waves that share this CU
+  __builtin_amdgcn_s_setprio(3);
   __shared__ double T[IMG_DOUBLES + 2 * MB * MB + NB];  // tiles | two inverse buffers | y
   double *Wc = T + IMG_DOUBLES;
   double *ys = Wc + 2 * MB * MB;
@@ -257,6 +259,7 @@ struct TrsmArgs {
 
 template <bool TRANS, bool FUSE_Y>
 __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
+  __builtin_amdgcn_s_setprio(3);  // panel chain (see potrf_diag_kernel)
   __shared__ double F[NFRAG_TILES * 4 * 64 + NB];
   double *zs = F + NFRAG_TILES * 4 * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -463,6 +466,17 @@ static long long pick_nbo(long long remaining) {
   return NB;
 }
 
+// Remaining size below which the bulk update U2(j) is held back until U1(j) has finished
+// (AGP_U1_FIRST; default 0 = never: measured no gain on MI355X).
+static long long u1_first_below() {
+  static long long v = -1;
+  if (v < 0) {
+    const char *e = getenv("AGP_U1_FIRST");
+    v = e ? atoll(e) : 0;
+  }
+  return v;
+}
+
 // Right-looking LL^T with one outer block of look-ahead on two streams:
 //   stream  (high priority): panel phase P(j), then U1(j) = update of the
 //            NEXT outer block column, then P(j + 1) ...
@@ -487,20 +501,16 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     // U1: block column [kend, next_end), all rows below its diagonal
     timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
     if (next_end < n) {
-      (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
-      const double *Q = A + K0 * lda + next_end;
-      const double hf = hybrid_split_fraction();
-      if (hf > 0. && n - next_end >= 4096 && K >= 256) {
-        // experiment: MFMA kernel on the left tile columns, VALU kernel on the right triangle, concurrently
-        hipStream_t sc = ctx->stream3;
-        (void)hipStreamWaitEvent(sc, ctx->ev_a, 0);
-        (void)hipStreamWaitEvent(sc, ctx->ev_b, 0);  // after the previous bulk update (recorded on sb)
-        launch_trailing_update_split(sb, sc, A + next_end * lda + next_end, lda, Q, lda, n - next_end, K, hf);
-        (void)hipEventRecord(ctx->ev_c, sc);
-        (void)hipStreamWaitEvent(sb, ctx->ev_c, 0);  // ev_b below then covers both halves
+      if (n - kend <= u1_first_below()) {
+        // late phase: the panel chain is the critical path.  Let U1 have the chip to itself
+        // (tens of microseconds) instead of sharing it with the bulk update it is launched with.
+        (void)hipEventRecord(ctx->ev_c, sa);
+        (void)hipStreamWaitEvent(sb, ctx->ev_c, 0);
       } else {
-        timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true);
+        (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       }
+      const double *Q = A + K0 * lda + next_end;
+      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true);
       (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;
     } else {

@@ -159,9 +159,8 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
                         bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
                         long long N, long long K, bool tri);
 // bulk trailing update of the factorisation: C(M x M, lower tiles) -= P Q^T
+void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
+                               const double *Q, long long ldp, long long M, long long K);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K);
-double hybrid_split_fraction();
-void launch_trailing_update_split(hipStream_t s_mfma, hipStream_t s_valu, double *C, long long ldc, const double *P,
-                                  long long ldp, long long M, long long K, double frac);
 }  // namespace agp

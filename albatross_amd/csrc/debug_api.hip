@@ -2,10 +2,12 @@
 // building blocks (MFMA lane map, update kernel, factorisation) in isolation.
 // Not part of include/albatross_amd.h.
 #include <algorithm>
+#include <cstdio>
 #include "common.h"
 #include "mfma_f64.h"
 
 namespace agp {
+void read_valu_clock(unsigned long long out[4], bool reset);
 
 __global__ void mfma_tile_kernel(const double *A, const double *B, double *D) {
   const int l = threadIdx.x;
@@ -66,6 +68,45 @@ __global__ __launch_bounds__(256) void mix_clock_kernel(unsigned long long *out,
   for (int i = 0; i < (NV > 0 ? NV : 1); ++i) s += v[i];
   const unsigned long long c1 = __builtin_amdgcn_s_memtime();
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
+  if (s == 1.2345e300) out[0] = 0;
+}
+
+// 64 independent v_fmac_f64 per loop iteration: MODE 0 plain VGPR operands, 1 SGPR src0,
+// 2 DPP row_newbcast src0.  out[0..63] (MODE 2 semantics probe): acc after ONE fmac with b = lane id, a = 1.
+template <int MODE>
+__global__ __launch_bounds__(256) void fmac_rate_kernel(unsigned long long *out, double *probe, int iters, double b0) {
+  double acc[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = 0.;
+  double a[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a[r] = 1.0 + 0.001 * r + threadIdx.x * 1e-6;
+  double b = b0 * (1.0 + (threadIdx.x & 63) * 0.01);
+  const double bs = __builtin_amdgcn_readfirstlane((int)(b0 * 1000.0)) * 0.001;
+  if (probe && MODE == 2) {
+    double pa = 1.0, pb = (double)(threadIdx.x & 63), pacc = 0.;
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(pacc) : "v"(pb), "v"(pa));
+    if (blockIdx.x == 0 && threadIdx.x < 64) probe[threadIdx.x] = pacc;
+  }
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (MODE == 0) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(acc[i]) : "v"(b), "v"(a[i & 3]));
+      else if (MODE == 1) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(acc[i]) : "s"(bs), "v"(a[i & 3]));
+      else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:7 row_mask:0xf bank_mask:0xf" : "+v"(acc[i]) : "v"(b), "v"(a[i & 3]));
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) s += acc[i];
   if (threadIdx.x == 0) {
     out[2 * blockIdx.x] = c1 - c0;
     out[2 * blockIdx.x + 1] = r1 - r0;
@@ -203,6 +244,109 @@ int agp_debug_gemm(agp_context *ctx, double *C, int64_t ldc, const double *A, in
   AGP_HIP_CHECK(ctx, hipMemcpy(C, dC, cb, hipMemcpyDeviceToHost));
   (void)hipFree(dC); (void)hipFree(dA); (void)hipFree(dB);
   return AGP_OK;
+}
+
+// v_fmac_f64 issue rate with VGPR (mode 0), SGPR (1) or DPP row_newbcast (2) src0.
+// out[0] = cycles per 64-FMA iteration per wave, out[1] = clock GHz, out[2] = chip TFLOP/s;
+// probe[64] (mode 2): result of one fmac with b = lane id, a = 1, row_newbcast:5.
+int agp_debug_fmac_rate(agp_context *ctx, int waves_per_simd, int mode, int iters, double *out, double *probe) {
+  if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int nblk = 256 * waves_per_simd;
+  unsigned long long *d = nullptr;
+  double *dp = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&d, sizeof(unsigned long long) * 2 * nblk));
+  AGP_HIP_CHECK(ctx, hipMalloc(&dp, sizeof(double) * 64));
+  hipEvent_t e0, e1;
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    AGP_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+    if (mode == 0) hipLaunchKernelGGL(fmac_rate_kernel<0>, dim3(nblk), dim3(256), 0, ctx->stream, d, dp, iters, 1.1);
+    else if (mode == 1) hipLaunchKernelGGL(fmac_rate_kernel<1>, dim3(nblk), dim3(256), 0, ctx->stream, d, dp, iters, 1.1);
+    else hipLaunchKernelGGL(fmac_rate_kernel<2>, dim3(nblk), dim3(256), 0, ctx->stream, d, dp, iters, 1.1);
+    AGP_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+    AGP_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  }
+  float ms = 0.f;
+  AGP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h(2 * nblk);
+  AGP_HIP_CHECK(ctx, hipMemcpy(h.data(), d, sizeof(unsigned long long) * 2 * nblk, hipMemcpyDeviceToHost));
+  if (probe) AGP_HIP_CHECK(ctx, hipMemcpy(probe, dp, sizeof(double) * 64, hipMemcpyDeviceToHost));
+  std::vector<double> cyc(nblk), clk(nblk);
+  for (int i = 0; i < nblk; ++i) {
+    cyc[i] = (double)h[2 * i] / (double)iters;
+    clk[i] = (double)h[2 * i] / ((double)h[2 * i + 1] * 10.0);
+  }
+  std::sort(cyc.begin(), cyc.end());
+  std::sort(clk.begin(), clk.end());
+  out[0] = cyc[nblk / 2];
+  out[1] = clk[nblk / 2];
+  out[2] = (double)nblk * 4.0 * iters * 64.0 * 128.0 / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d); (void)hipFree(dp);
+  return AGP_OK;
+}
+
+// Bulk trailing update C (M x M, lower tiles) -= P P^T on host data.  variant 0: MFMA kernel,
+// 2: DPP-broadcast VALU kernel.
+int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t ldc, const double *P, int64_t ldp, int64_t M,
+                              int64_t K, int variant) {
+  if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t cb = sizeof(double) * (size_t)ldc * (size_t)M;
+  const size_t pb = sizeof(double) * (size_t)ldp * (size_t)K;
+  double *dC = nullptr, *dP = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&dC, cb));
+  AGP_HIP_CHECK(ctx, hipMalloc(&dP, pb));
+  AGP_HIP_CHECK(ctx, hipMemcpy(dC, C, cb, hipMemcpyHostToDevice));
+  AGP_HIP_CHECK(ctx, hipMemcpy(dP, P, pb, hipMemcpyHostToDevice));
+  int st = AGP_OK;
+  launch_trailing_update_as(variant, ctx->stream, dC, ldc, dP, dP, ldp, M, K);
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  AGP_HIP_CHECK(ctx, hipGetLastError());
+  AGP_HIP_CHECK(ctx, hipMemcpy(C, dC, cb, hipMemcpyDeviceToHost));
+  (void)hipFree(dC); (void)hipFree(dP);
+  return st;
+}
+
+// Average milliseconds of `reps` bulk trailing updates of an M x M matrix (device-side random-ish data).
+int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, int64_t K, int variant, int reps, double *ms_out) {
+  if (!ctx || M <= 0 || K <= 0 || reps <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const long long ld = M + 8;
+  double *dC = nullptr, *dP = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&dC, sizeof(double) * (size_t)ld * (size_t)M));
+  AGP_HIP_CHECK(ctx, hipMalloc(&dP, sizeof(double) * (size_t)ld * (size_t)K));
+  std::vector<double> h((size_t)ld * (size_t)K);
+  unsigned long long x = 88172645463325252ull;
+  for (auto &v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+  AGP_HIP_CHECK(ctx, hipMemcpy(dP, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+  for (long long c = 0; c < M; c += K) {
+    const long long w = (M - c < K) ? M - c : K;
+    AGP_HIP_CHECK(ctx, hipMemcpy(dC + c * ld, h.data(), sizeof(double) * (size_t)ld * (size_t)w, hipMemcpyHostToDevice));
+  }
+  hipEvent_t e0, e1;
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e1));
+  int st = AGP_OK;
+  for (int r = -2; r < reps && st == AGP_OK; ++r) {
+    if (r == 0) AGP_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+    launch_trailing_update_as(variant, ctx->stream, dC, ld, dP, dP, ld, M, K);
+  }
+  AGP_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+  AGP_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  AGP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = (double)ms / reps;
+  if (variant == 2) {
+    unsigned long long c[4];
+    read_valu_clock(c, true);
+    if (c[2]) fprintf(stderr, "  [dpp kernel] main loop per workgroup: %.0f cycles, clock %.3f GHz, %.1f cycles per k-step (K=%lld)\n",
+                      (double)c[0] / c[2], (double)c[0] / ((double)c[1] * 10.0), (double)c[0] / c[2] / (double)K, (long long)K);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(dC); (void)hipFree(dP);
+  return st;
 }
 
 // In-place LL^T of the lower triangle of a host matrix; y (optional) -> L^-1 y.

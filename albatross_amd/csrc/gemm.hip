@@ -216,97 +216,173 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g) {
+  __builtin_amdgcn_s_setprio(3);  // everything but the bulk update (its own kernel below)
   // one LDS array: [buffer][operand][k][row]
   __shared__ double lds[2 * 2 * GK * GLD];
   gemm_nt_sub_body<A_KMAJOR, B_KMAJOR>(g, lds);
 }
 
 // ---------------------------------------------------------------------------
-// fp64 VALU variant of the same update.  On gfx950 the fp64 MFMA pipe saturates
-// at ~48 TFLOP/s while plain v_fma_f64 reaches ~69 TFLOP/s (profiles/r01/
-// microbench_fp64.txt), so the bulk update can also run as a register-tiled
-// FMA kernel: 16 x 16 threads, 8 x 8 accumulators per lane, both operand strips
-// read from the same [k][row] LDS image (a: 16 lanes share an address ->
-// broadcast; b: 16 distinct 64-B segments = one contiguous 1 KiB row).
+// fp64 VALU variant of the same update: "DPP-broadcast" register tiling.
+//
+// On gfx950 the fp64 MFMA pipe saturates at ~48 TFLOP/s while plain v_fmac_f64
+// issues at full vector rate (profiles/r01/microbench_fp64.txt: 58-69 TFLOP/s,
+// clock-limited).  A classic register-tiled FMA kernel is LDS-bound (an 8 x 8
+// tile per lane needs 16 LDS doubles per 64 FMAs).  Here the COLUMN operand is
+// not replicated per lane: a wave keeps ONE VGPR pair with 64 different column
+// values (lane l holds column l of the wave's 64) and every FMA reads it through
+// DPP  row_newbcast:c  — each 16-lane row broadcasts ITS lane c — so
+//
+//   lane (rho = l >> 4, i = l & 15) owns rows {2i, 2i+1, 32+2i, 33+2i} x columns 16 rho + 0..15
+//   wave = 64 x 64 of C, workgroup = 2 x 2 waves = the same 128 x 128 tile as the MFMA kernel
+//   k-step = 2 ds_read_b128 (row pairs; the four 16-lane rows read the same addresses)
+//          + 1 ds_read_b64 (64 consecutive columns) + 64 v_fmac_f64_dpp     (LDS port: ~8 %)
+//
+// The FMAs and LDS reads are inline asm with explicit s_waitcnt: written in C++
+// the compiler reorders them for register pressure and the issue pattern is lost.
+// Accumulators start from C (the LDS row image is negated), the epilogue is pure stores.
 // ---------------------------------------------------------------------------
+typedef double dpp_d2 __attribute__((ext_vector_type(2)));
+
+template <int C>
+__device__ __forceinline__ void fmac_bcast(double &acc, double b, double a) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc) : "v"(b), "v"(a), "n"(C));
+}
+
+template <int C>
+__device__ __forceinline__ void fmac_bcast4(double (&acc)[4][16], double b, const dpp_d2 &a01, const dpp_d2 &a23) {
+  fmac_bcast<C>(acc[0][C], b, a01.x);
+  fmac_bcast<C>(acc[1][C], b, a01.y);
+  fmac_bcast<C>(acc[2][C], b, a23.x);
+  fmac_bcast<C>(acc[3][C], b, a23.y);
+}
+
+__device__ __forceinline__ void fmac_step(double (&acc)[4][16], double b, const dpp_d2 &a01, const dpp_d2 &a23) {
+  fmac_bcast4<0>(acc, b, a01, a23);  fmac_bcast4<1>(acc, b, a01, a23);
+  fmac_bcast4<2>(acc, b, a01, a23);  fmac_bcast4<3>(acc, b, a01, a23);
+  fmac_bcast4<4>(acc, b, a01, a23);  fmac_bcast4<5>(acc, b, a01, a23);
+  fmac_bcast4<6>(acc, b, a01, a23);  fmac_bcast4<7>(acc, b, a01, a23);
+  fmac_bcast4<8>(acc, b, a01, a23);  fmac_bcast4<9>(acc, b, a01, a23);
+  fmac_bcast4<10>(acc, b, a01, a23); fmac_bcast4<11>(acc, b, a01, a23);
+  fmac_bcast4<12>(acc, b, a01, a23); fmac_bcast4<13>(acc, b, a01, a23);
+  fmac_bcast4<14>(acc, b, a01, a23); fmac_bcast4<15>(acc, b, a01, a23);
+}
+
+// operands of k-row K of the current chunk (byte offsets are literals: no address arithmetic)
+template <int K>
+__device__ __forceinline__ void dpp_lds_read(dpp_d2 &a01, dpp_d2 &a23, double &b, unsigned a_addr, unsigned b_addr) {
+  asm volatile("ds_read_b128 %0, %3 offset:%5\n\tds_read_b128 %1, %3 offset:%6\n\tds_read_b64 %2, %4 offset:%5"
+               : "=&v"(a01), "=&v"(a23), "=&v"(b)
+               : "v"(a_addr), "v"(b_addr), "n"(K * GLD * 8), "n"(K * GLD * 8 + 256));
+}
+
+template <int K>
+__device__ __forceinline__ void dpp_k_steps(double (&acc)[4][16], dpp_d2 (&a01)[2], dpp_d2 (&a23)[2], double (&b)[2],
+                                            unsigned a_addr, unsigned b_addr) {
+  constexpr int cur = K & 1, nxt = cur ^ 1;
+  if constexpr (K + 1 < GK) dpp_lds_read<K + 1>(a01[nxt], a23[nxt], b[nxt], a_addr, b_addr);
+  fmac_step(acc, b[cur], a01[cur], a23[cur]);
+  if constexpr (K + 1 < GK) {
+    // LDS returns in order and nothing else is outstanding: the operands of step K + 1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01[nxt]), "+v"(a23[nxt]), "+v"(b[nxt]));
+    dpp_k_steps<K + 1>(acc, a01, a23, b, a_addr, b_addr);
+  }
+}
+
+// debug: summed shader-clock cycles, 100 MHz ticks and workgroup count of the main loops
+__device__ unsigned long long g_valu_clock[4];
+
 template <bool A_KMAJOR, bool B_KMAJOR>
-__device__ __forceinline__ void gemm_valu_body(const GemmArgs &g, double *lds) {
+__device__ __forceinline__ void gemm_dpp_body(const GemmArgs &g, double *lds) {
   int bi, bj;
   if (!tile_of_block(g, bi, bj)) return;
   const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // tx: column group, ty: row group
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, rho = lane >> 4;
 
   const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
   const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
-
-  // Ownership is interleaved so that every ds_read_b128 of a wave is one
-  // contiguous run: lane (tx, ty) owns rows 32 q + 2 ty + {0,1} and columns
-  // 32 q + 2 tx + {0,1}, q = 0..3 (8 x 8 accumulators as 4 x 4 blocks of 2 x 2).
-  double acc[8][8];  // [col index c = 2 qc + e][row index r = 2 qr + f]
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) acc[c][r] = 0.;
+  const bool c_vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
 
   double ra[8], rb[8];
   const long long nk = (g.K + GK - 1) / GK;
   load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
   load_chunk<B_KMAJOR>(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb);
-  store_chunk<A_KMAJOR, false>(lds, ra);
-  store_chunk<B_KMAJOR, true>(lds + GK * GLD, rb);
+
+  // accumulators start from C (entries outside C: zero, never stored)
+  const long long row0 = i0 + 64 * wr + 2 * li, col0 = j0 + 64 * wc + 16 * rho;
+  double acc[4][16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long row = row0 + 32 * h, col = col0 + c;
+      const double *cp = g.C + row + col * g.ldc;
+      dpp_d2 v = {0., 0.};
+      if (col < g.N) {
+        if (c_vec && row + 1 < g.M) v = *reinterpret_cast<const dpp_d2 *>(cp);
+        else {
+          if (row < g.M) v.x = cp[0];
+          if (row + 1 < g.M) v.y = cp[1];
+        }
+      }
+      acc[2 * h][c] = v.x;
+      acc[2 * h + 1][c] = v.y;
+    }
+  }
+
+  store_chunk<A_KMAJOR, true>(lds, ra);  // rows negated: acc = C + (-a) b
+  store_chunk<B_KMAJOR, false>(lds + GK * GLD, rb);
   __syncthreads();
 
+  // LDS byte addresses (the truncated flat address of a __shared__ object is its LDS offset)
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(lds);
+  const unsigned a_lane = lds0 + 8u * (unsigned)(64 * wr + 2 * li);
+  const unsigned b_lane = lds0 + 8u * (unsigned)(GK * GLD + 64 * wc + lane);
+
+  const unsigned long long t_c0 = __builtin_amdgcn_s_memtime(), t_r0 = __builtin_amdgcn_s_memrealtime();
   for (long long kc = 0; kc < nk; ++kc) {
-    const int cur = (int)(kc & 1);
-    const double *As = lds + cur * (2 * GK * GLD) + 2 * ty;
-    const double *Bs = lds + cur * (2 * GK * GLD) + GK * GLD + 2 * tx;
+    const unsigned cur = (unsigned)(kc & 1) * (2u * GK * GLD * 8u);
     const bool more = kc + 1 < nk;
     if (more) {
       load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, (kc + 1) * GK, g.K, a_vec, ra);
       load_chunk<B_KMAJOR>(g.B, g.ldb, j0, g.N, (kc + 1) * GK, g.K, b_vec, rb);
     }
-#pragma unroll 2
-    for (int k = 0; k < GK; ++k) {
-      double a[8], b[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double2 av = *reinterpret_cast<const double2 *>(As + k * GLD + 32 * q);
-        const double2 bv = *reinterpret_cast<const double2 *>(Bs + k * GLD + 32 * q);
-        a[2 * q] = av.x; a[2 * q + 1] = av.y;
-        b[2 * q] = bv.x; b[2 * q + 1] = bv.y;
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[c][r] = __builtin_fma(a[r], b[c], acc[c][r]);
-    }
+    dpp_d2 a01[2], a23[2];
+    double b[2];
+    dpp_lds_read<0>(a01[0], a23[0], b[0], a_lane + cur, b_lane + cur);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01[0]), "+v"(a23[0]), "+v"(b[0]));
+    dpp_k_steps<0>(acc, a01, a23, b, a_lane + cur, b_lane + cur);
     if (more) {
-      double *An = lds + (cur ^ 1) * (2 * GK * GLD);
-      store_chunk<A_KMAJOR, false>(An, ra);
-      store_chunk<B_KMAJOR, true>(An + GK * GLD, rb);
+      double *An = lds + ((kc + 1) & 1) * (2 * GK * GLD);
+      store_chunk<A_KMAJOR, true>(An, ra);
+      store_chunk<B_KMAJOR, false>(An + GK * GLD, rb);
     }
     __syncthreads();
   }
 
-  // epilogue: C += acc; per (column, qr) a lane updates 2 consecutive rows (16 B),
-  // the 16 ty-lanes together 256 contiguous bytes
-  const bool c_vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_valu_clock[0], __builtin_amdgcn_s_memtime() - t_c0);
+    atomicAdd(&g_valu_clock[1], __builtin_amdgcn_s_memrealtime() - t_r0);
+    atomicAdd(&g_valu_clock[2], 1ull);
+  }
+  // epilogue: pure stores; per instruction a 16-lane row writes 256 contiguous bytes of one column
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const long long col = j0 + 32 * (c >> 1) + 2 * tx + (c & 1);
+  for (int c = 0; c < 16; ++c) {
+    const long long col = col0 + c;
     if (col >= g.N) continue;
 #pragma unroll
-    for (int qr = 0; qr < 4; ++qr) {
-      const long long row = i0 + 32 * qr + 2 * ty;
+    for (int h = 0; h < 2; ++h) {
+      const long long row = row0 + 32 * h;
       double *cp = g.C + row + col * g.ldc;
-      if (c_vec && row + 2 <= g.M) {
-        double2 v = *reinterpret_cast<double2 *>(cp);
-        v.x += acc[c][2 * qr];
-        v.y += acc[c][2 * qr + 1];
-        *reinterpret_cast<double2 *>(cp) = v;
+      if (c_vec && row + 1 < g.M) {
+        dpp_d2 v = {acc[2 * h][c], acc[2 * h + 1][c]};
+        *reinterpret_cast<dpp_d2 *>(cp) = v;
       } else {
-        if (row < g.M) cp[0] += acc[c][2 * qr];
-        if (row + 1 < g.M) cp[1] += acc[c][2 * qr + 1];
+        if (row < g.M) cp[0] = acc[2 * h][c];
+        if (row + 1 < g.M) cp[1] = acc[2 * h + 1][c];
       }
     }
   }
@@ -314,7 +390,7 @@ __device__ __forceinline__ void gemm_valu_body(const GemmArgs &g, double *lds) {
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_valu_kernel(GemmArgs g) {
   __shared__ double lds[2 * 2 * GK * GLD];
-  gemm_valu_body<false, false>(g, lds);
+  gemm_dpp_body<false, false>(g, lds);
 }
 
 // The bulk trailing update of the factorisation (C -= P P^T, lower tiles, K =
@@ -362,6 +438,7 @@ __device__ __forceinline__ void store_chunk64(double *__restrict__ Ls, const dou
 }
 
 __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs g) {
+  __builtin_amdgcn_s_setprio(3);  // panel-chain updates: issue ahead of co-resident bulk-update waves
   __shared__ double lds[2 * 2 * GK * SLD];
   int bj = 0;
   long long id = blockIdx.x;
@@ -480,51 +557,9 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
   else hipLaunchKernelGGL((gemm_nt_sub_kernel<true, true>), grid, block, 0, s, g);
 }
 
-// Experiment (AGP_HYBRID_SPLIT=f, 0 < f < 1): the bulk update as two concurrent launches on two
-// streams — the left tile columns (a trapezoid) on the MFMA kernel, the right lower triangle,
-// holding about the fraction f of the tiles, on the VALU-FMA kernel — so that MFMA and VALU
-// instructions are in flight on every SIMD together.
-double hybrid_split_fraction() {
-  static double f = -1.;
-  if (f < 0.) {
-    const char *e = getenv("AGP_HYBRID_SPLIT");
-    f = e ? atof(e) : 0.;
-    if (!(f > 0. && f < 1.)) f = 0.;
-  }
-  return f;
-}
-
-void launch_trailing_update_split(hipStream_t s_mfma, hipStream_t s_valu, double *C, long long ldc, const double *P,
-                                  long long ldp, long long M, long long K, double frac) {
-  const int ntr = (int)((M + GT - 1) / GT);
-  int right = (int)(ntr * sqrt(frac) + 0.5);  // tile columns handed to the VALU kernel
-  if (right < 1) right = 1;
-  if (right >= ntr) right = ntr - 1;
-  const int c = ntr - right;  // first tile column of the right triangle
-  {  // left trapezoid: all rows, columns [0, c * 128)
-    GemmArgs g;
-    g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = P; g.ldb = ldp;
-    g.M = M; g.N = (long long)c * GT; g.K = K; g.tri = 1;
-    g.remap = 0; g.nsuper = 0; g.nb8 = 0;
-    g.ntr = ntr; g.ntc = c;
-    long long tiles = 0;
-    for (int bj = 0; bj < c; ++bj) tiles += ntr - bj;
-    hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s_mfma, g);
-  }
-  {  // right triangle: origin shifted onto the diagonal at tile (c, c)
-    const long long off = (long long)c * GT;
-    GemmArgs g;
-    g.C = C + off + off * ldc; g.ldc = ldc; g.A = P + off; g.lda = ldp; g.B = P + off; g.ldb = ldp;
-    g.M = M - off; g.N = M - off; g.K = K; g.tri = 1;
-    g.remap = 0; g.nsuper = 0; g.nb8 = 0;
-    g.ntr = right; g.ntc = right;
-    const long long tiles = (long long)right * (right + 1) / 2;
-    hipLaunchKernelGGL(trailing_update_valu_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s_valu, g);
-  }
-}
-
-void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
-                            long long ldp, long long M, long long K) {
+// variant 0: MFMA kernel, 2: DPP-broadcast VALU kernel (experiment)
+void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
+                               const double *Q, long long ldp, long long M, long long K) {
   if (M <= 0 || K <= 0) return;
   GemmArgs g;
   g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = Q; g.ldb = ldp;
@@ -546,13 +581,29 @@ void launch_trailing_update(hipStream_t s, double *C, long long ldc, const doubl
     g.nsuper = g.nb8 * (g.nb8 + 1) / 2;
     tiles = (long long)((g.nsuper + 7) / 8) * 8 * 64;
   }
-  static int use_valu = -1;
-  if (use_valu < 0) {
-    const char *e = getenv("AGP_UPDATE_VALU");
-    use_valu = (e && e[0] == '1') ? 1 : 0;
-  }
-  if (use_valu) hipLaunchKernelGGL(trailing_update_valu_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+  if (variant == 2) hipLaunchKernelGGL(trailing_update_valu_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
   else hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+}
+
+void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
+                            long long ldp, long long M, long long K) {
+  static int variant = -1;
+  if (variant < 0) {
+    // mfma (default) | dpp.  Measured on MI355X (scripts/time_update.py, M = 15872, K = 512): MFMA
+    // 48 TFLOP/s at 2.38 GHz; the VALU kernel issues 88 % of its FMA slots but the chip drops to
+    // ~1.77 GHz under fp64 vector load (power), which leaves it at 44-45 TFLOP/s.
+    const char *e = getenv("AGP_UPDATE_KERNEL");
+    variant = (e && e[0] == 'd') ? 2 : 0;
+  }
+  launch_trailing_update_as(variant, s, C, ldc, P, Q, ldp, M, K);
+}
+
+void read_valu_clock(unsigned long long out[4], bool reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_valu_clock), sizeof(unsigned long long) * 4);
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_valu_clock), z, sizeof(z));
+  }
 }
 
 // ---- bare MFMA issue loop: measured fp64 matrix peak of this device ----------

@@ -26,6 +26,9 @@ def dbg(ctx):
     lib.agp_debug_factor.restype = C.c_int
     lib.agp_debug_factor.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                      C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.agp_debug_trailing_update.restype = C.c_int
+    lib.agp_debug_trailing_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                              C.c_int64, C.c_int]
     return lib
 
 
@@ -76,6 +79,23 @@ def test_gemm_nt_sub(ctx, dbg, M, N, K, tri, akm, bkm):
         err = (np.abs(got - want) / scale).max()
     assert err < 8 * np.finfo(float).eps * np.sqrt(K)
     assert np.array_equal(Cd[M:], np.zeros((ldc - M, N)))  # padding rows untouched
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("M,K", [(256, 16), (640, 128), (1000, 256), (1418, 512), (130, 32)])
+def test_trailing_update_variants(ctx, dbg, M, K, variant):
+    """Bulk update C -= P P^T on the lower tiles: MFMA kernel (0) and the DPP-broadcast VALU kernel (2)."""
+    rng = np.random.default_rng(M + K)
+    ldc, ldp = M + 8 - (M % 2), M + 10 - (M % 2)
+    Cm = np.asfortranarray(rng.standard_normal((ldc, M)))
+    P = np.asfortranarray(rng.standard_normal((ldp, K)))
+    want = Cm[:M] - P[:M] @ P[:M].T
+    got = Cm.copy(order="F")
+    assert dbg.agp_debug_trailing_update(ctx._h, _p(got), ldc, _p(P), ldp, M, K, variant) == 0
+    low = np.tril_indices(M)
+    scale = np.abs(P[:M]).sum(axis=1).max() ** 2
+    assert np.abs(got[:M][low] - want[low]).max() <= 1e-14 * scale
+    assert np.array_equal(got[M:], Cm[M:])  # padding rows untouched
 
 
 @pytest.mark.parametrize("n", [16, 100, 128, 129, 300, 512, 640, 1000, 1537])
