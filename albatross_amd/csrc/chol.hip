@@ -65,37 +65,71 @@ constexpr int IMG_DOUBLES = NTILE * MB * MB;  // 9216 doubles = 72 KiB per diago
 // straight coalesced copy.
 __device__ __forceinline__ int tile_off(int ib, int kb) { return (ib * (ib + 1) / 2 + kb) * (MB * MB); }
 
-// POTRF16 + INV16 of one diagonal micro tile by one wave, in registers.
-// Lane ln (= lane & 15) owns row ln of the tile / column ln of the inverse.
-__device__ __forceinline__ void micro_potrf_inv(double *D, double *Wout, double *img_diag, int lane, int ln,
-                                                int pivot_base, int &bad_pivot) {
-  double a[MB], dinv[MB], w[MB];
-#pragma unroll
-  for (int c = 0; c < MB; ++c) a[c] = D[c * MB + ln];
-#pragma unroll
-  for (int c = 0; c < MB; ++c) {
-    const double piv = readlane_f64(a[c], c);
-    if (!(piv > 0.) && bad_pivot == 0) bad_pivot = pivot_base + c + 1;
+// DPP row broadcast on fp64 (gfx90a+ "DPP64": row_newbcast only): every lane reads lane J of its
+// own 16-lane row.  One VALU instruction, no SGPR round trip (v_readlane x2 + use).  The leading
+// s_nop covers the "VALU write -> DPP read" hazard (2 wait states), which the compiler cannot see
+// inside inline asm.
+template <int J>
+__device__ __forceinline__ double bcast_row(double v) {
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+  return r;
+}
+
+// acc -= (lane J's value of src) * a
+template <int J>
+__device__ __forceinline__ void fnmac_bcast_row(double &acc, double src, double a) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(src), "v"(a), "n"(J));
+}
+
+// a[j] -= L[j][C] * a[C]  for j = J .. 15   (rank-1 update of the columns right of C)
+template <int C, int J>
+__device__ __forceinline__ void potrf16_update(double (&a)[MB]) {
+  if constexpr (J < MB) {
+    fnmac_bcast_row<J>(a[J], a[C], a[C]);
+    potrf16_update<C, J + 1>(a);
+  }
+}
+
+// w[r] -= L[r][K] * w[K]  for r = R .. 15   (column sweep of W = L^-1)
+template <int K, int R>
+__device__ __forceinline__ void inv16_update(double (&w)[MB], const double (&a)[MB]) {
+  if constexpr (R < MB) {
+    fnmac_bcast_row<R>(w[R], a[K], w[K]);
+    inv16_update<K, R + 1>(w, a);
+  }
+}
+
+// column C of the 16 x 16 Cholesky and of the inverse sweep (two independent dependency chains)
+template <int C>
+__device__ __forceinline__ void potrf16_column(double (&a)[MB], double (&w)[MB], int ln, int pivot_base,
+                                               int &bad_pivot) {
+  if constexpr (C < MB) {
+    const double piv = bcast_row<C>(a[C]);
+    if (!(piv > 0.) && bad_pivot == 0) bad_pivot = pivot_base + C + 1;
     const double inv = rsqrt_nr(piv);
     double s = piv * inv;
     s = s + 0.5 * inv * (piv - s * s);  // Heron correction of sqrt(piv)
-    dinv[c] = inv;
-    a[c] = (ln == c) ? s : a[c] * inv;
-#pragma unroll
-    for (int j = c + 1; j < MB; ++j) {
-      const double ljc = readlane_f64(a[c], j);
-      a[j] -= a[c] * ljc;
-    }
+    a[C] = (ln == C) ? s : a[C] * inv;
+    potrf16_update<C, C + 1>(a);
+    w[C] *= inv;
+    inv16_update<C, C + 1>(w, a);
+    potrf16_column<C + 1>(a, w, ln, pivot_base, bad_pivot);
   }
-  // W = L16^-1 by column sweep (short dependent chain)
+}
+
+// POTRF16 + INV16 of one diagonal micro tile by one wave, in registers.
+// Lane ln (= lane & 15) owns row ln of the tile / column ln of the inverse; the four 16-lane
+// rows of the wave compute the same thing.
+__device__ __forceinline__ void micro_potrf_inv(double *D, double *Wout, double *img_diag, int lane, int ln,
+                                                int pivot_base, int &bad_pivot) {
+  double a[MB], w[MB];
+#pragma unroll
+  for (int c = 0; c < MB; ++c) a[c] = D[c * MB + ln];
 #pragma unroll
   for (int r = 0; r < MB; ++r) w[r] = (ln == r) ? 1. : 0.;
-#pragma unroll
-  for (int k = 0; k < MB; ++k) {
-    w[k] *= dinv[k];
-#pragma unroll
-    for (int r = k + 1; r < MB; ++r) w[r] -= readlane_f64(a[k], r) * w[k];
-  }
+  potrf16_column<0>(a, w, ln, pivot_base, bad_pivot);
   if (lane < MB) {
 #pragma unroll
     for (int c = 0; c < MB; ++c) D[c * MB + ln] = (c <= ln) ? a[c] : 0.;
