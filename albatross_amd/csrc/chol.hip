@@ -83,39 +83,110 @@ __device__ __forceinline__ void fnmac_bcast_row(double &acc, double src, double 
       : "+v"(acc) : "v"(src), "v"(a), "n"(J));
 }
 
-// a[j] -= L[j][C] * a[C]  for j = J .. 15   (rank-1 update of the columns right of C)
-template <int C, int J>
-__device__ __forceinline__ void potrf16_update(double (&a)[MB]) {
-  if constexpr (J < MB) {
-    fnmac_bcast_row<J>(a[J], a[C], a[C]);
-    potrf16_update<C, J + 1>(a);
+// ---- hand-scheduled 16 x 16 POTRF + inverse ---------------------------------------------------
+// One wave issues in order, so the serial pivot chain (broadcast -> rsq -> Newton -> scale ->
+// first rank-1 term) decides the run time unless the ~30 independent rank-1 terms of every column
+// are slotted into its latency shadows.  The compiler does not do that for inline asm, so the
+// arithmetic on the chain is volatile asm too and the issue order below is the source order:
+// the terms of column C that are not needed at once ("deferred": a[j] for j > C + 1, the inverse
+// sweep w[r] for r > C) are emitted between the chain steps of column C + 1.
+__device__ __forceinline__ double vmul(double a, double b) {
+  double r;
+  asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vfma(double a, double b, double c) {
+  double r;
+  asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ double vfnma(double a, double b, double c) {  // c - a b
+  double r;
+  asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ double vrsq(double a) {
+  double r;
+  asm volatile("v_rsq_f64 %0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+template <int J>
+__device__ __forceinline__ double vbcast(double v) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+  return r;
+}
+// acc -= src[lane J of the row] * a.  HAZARD: src may have been written by the previous one or two
+// VALU instructions (2 wait states before a DPP read); a whole issue slot, so only where needed.
+template <int J, bool HAZARD>
+__device__ __forceinline__ void vfnmac_bcast(double &acc, double src, double a) {
+  if constexpr (HAZARD)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(src), "v"(a), "n"(J));
+  else
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(src), "v"(a), "n"(J));
+}
+
+// deferred term I of column K (K < 0: nothing).  Order: w[K] *= inv_K, then alternately the
+// a-terms j = K + 2 + i and the w-terms r = K + 1 + i.
+template <int K, int I>
+__device__ __forceinline__ void potrf16_deferred(double (&a)[MB], double (&w)[MB], const double (&dinv)[MB]) {
+  if constexpr (K >= 0) {
+    constexpr int NA = MB - 2 - K;      // a-terms: j = K + 2 .. 15
+    constexpr int NW = MB - 1 - K;      // w-terms: r = K + 1 .. 15
+    if constexpr (I == 0) {
+      w[K] = vmul(w[K], dinv[K]);
+    } else {
+      constexpr int q = (I - 1) / 2;
+      if constexpr (((I - 1) & 1) == 0) {
+        if constexpr (q < NA) vfnmac_bcast<K + 2 + q, false>(a[K + 2 + q], a[K], a[K]);
+      } else {
+        if constexpr (q < NW) vfnmac_bcast<K + 1 + q, false>(w[K + 1 + q], a[K], w[K]);
+      }
+    }
   }
 }
 
-// w[r] -= L[r][K] * w[K]  for r = R .. 15   (column sweep of W = L^-1)
-template <int K, int R>
-__device__ __forceinline__ void inv16_update(double (&w)[MB], const double (&a)[MB]) {
-  if constexpr (R < MB) {
-    fnmac_bcast_row<R>(w[R], a[K], w[K]);
-    inv16_update<K, R + 1>(w, a);
+template <int K, int I0, int I1>
+__device__ __forceinline__ void potrf16_deferred_range(double (&a)[MB], double (&w)[MB], const double (&dinv)[MB]) {
+  if constexpr (I0 < I1) {
+    potrf16_deferred<K, I0>(a, w, dinv);
+    potrf16_deferred_range<K, I0 + 1, I1>(a, w, dinv);
   }
 }
 
-// column C of the 16 x 16 Cholesky and of the inverse sweep (two independent dependency chains)
+constexpr int POTRF16_DEFERRED_MAX = 1 + 2 * MB;  // indices beyond a column's last term are no-ops
+
 template <int C>
-__device__ __forceinline__ void potrf16_column(double (&a)[MB], double (&w)[MB], int ln, int pivot_base,
-                                               int &bad_pivot) {
+__device__ __forceinline__ void potrf16_column(double (&a)[MB], double (&w)[MB], double (&dinv)[MB], double &diag,
+                                               int ln, int pivot_base, int &bad_pivot) {
   if constexpr (C < MB) {
-    const double piv = bcast_row<C>(a[C]);
+    const double piv = vbcast<C>(a[C]);
+    potrf16_deferred_range<C - 1, 0, 3>(a, w, dinv);
+    const double y0 = vrsq(piv);
+    potrf16_deferred_range<C - 1, 3, 8>(a, w, dinv);
+    // third-order correction of the hardware estimate: e = 1 - piv y0^2, inv = y0 (1 + e/2 + 3 e^2/8)
+    const double t = vmul(y0, y0);
+    potrf16_deferred_range<C - 1, 8, 10>(a, w, dinv);
+    const double e = vfnma(piv, t, 1.0);
+    potrf16_deferred_range<C - 1, 10, 12>(a, w, dinv);
+    const double pp = vfma(0.375, e, 0.5);
+    const double ye = vmul(y0, e);
+    potrf16_deferred_range<C - 1, 12, 13>(a, w, dinv);
+    const double inv = vfma(ye, pp, y0);
+    potrf16_deferred_range<C - 1, 13, 15>(a, w, dinv);
+    a[C] = vmul(a[C], inv);  // lane C now holds piv * inv ~ sqrt(piv); the exact diagonal goes to `diag`
+    dinv[C] = inv;
+    potrf16_deferred_range<C - 1, 15, 17>(a, w, dinv);
+    if constexpr (C + 1 < MB) vfnmac_bcast<C + 1, true>(a[C + 1], a[C], a[C]);  // the term the next pivot waits for
+    potrf16_deferred_range<C - 1, 17, POTRF16_DEFERRED_MAX>(a, w, dinv);
+    // off the chain: pivot check and the Heron-corrected diagonal entry
     if (!(piv > 0.) && bad_pivot == 0) bad_pivot = pivot_base + C + 1;
-    const double inv = rsqrt_nr(piv);
-    double s = piv * inv;
-    s = s + 0.5 * inv * (piv - s * s);  // Heron correction of sqrt(piv)
-    a[C] = (ln == C) ? s : a[C] * inv;
-    potrf16_update<C, C + 1>(a);
-    w[C] *= inv;
-    inv16_update<C, C + 1>(w, a);
-    potrf16_column<C + 1>(a, w, ln, pivot_base, bad_pivot);
+    double sq = piv * inv;
+    sq = sq + 0.5 * inv * (piv - sq * sq);
+    diag = (ln == C) ? sq : diag;
+    potrf16_column<C + 1>(a, w, dinv, diag, ln, pivot_base, bad_pivot);
   }
 }
 
@@ -124,15 +195,16 @@ __device__ __forceinline__ void potrf16_column(double (&a)[MB], double (&w)[MB],
 // rows of the wave compute the same thing.
 __device__ __forceinline__ void micro_potrf_inv(double *D, double *Wout, double *img_diag, int lane, int ln,
                                                 int pivot_base, int &bad_pivot) {
-  double a[MB], w[MB];
+  double a[MB], w[MB], dinv[MB], diag = 0.;
 #pragma unroll
   for (int c = 0; c < MB; ++c) a[c] = D[c * MB + ln];
 #pragma unroll
   for (int r = 0; r < MB; ++r) w[r] = (ln == r) ? 1. : 0.;
-  potrf16_column<0>(a, w, ln, pivot_base, bad_pivot);
+  potrf16_column<0>(a, w, dinv, diag, ln, pivot_base, bad_pivot);
+  potrf16_deferred_range<MB - 1, 0, POTRF16_DEFERRED_MAX>(a, w, dinv);  // last column: only w[15] *= inv
   if (lane < MB) {
 #pragma unroll
-    for (int c = 0; c < MB; ++c) D[c * MB + ln] = (c <= ln) ? a[c] : 0.;
+    for (int c = 0; c < MB; ++c) D[c * MB + ln] = (c < ln) ? a[c] : ((c == ln) ? diag : 0.);
 #pragma unroll
     for (int r = 0; r < MB; ++r) {
       Wout[ln * MB + r] = w[r];
@@ -155,6 +227,39 @@ __device__ __forceinline__ void micro_syrk_tile(double *T, int ib, int kb, int j
   for (int r = 0; r < 4; ++r) Cc[(lg + 4 * r) * MB + ln] = acc0[r] + acc1[r];
 }
 
+#ifdef AGP_POTRF_TIMING
+__device__ unsigned long long g_potrf_t[64];
+#define PT(i) do { if (threadIdx.x == 0) g_potrf_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PT(i)
+#endif
+
+// two SYRK tiles at once (independent accumulators: the MFMA latencies overlap)
+__device__ __forceinline__ void micro_syrk_tile2(double *T, int ib0, int kb0, int ib1, int kb1, int jb, int ln, int lg) {
+  double *C0 = T + tile_off(ib0, kb0), *C1 = T + tile_off(ib1, kb1);
+  const double *Xk0 = T + tile_off(kb0, jb), *Xi0 = T + tile_off(ib0, jb);
+  const double *Xk1 = T + tile_off(kb1, jb), *Xi1 = T + tile_off(ib1, jb);
+  v4d a0, a1 = v4zero(), b0, b1 = v4zero();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    a0[r] = C0[(lg + 4 * r) * MB + ln];
+    b0[r] = C1[(lg + 4 * r) * MB + ln];
+  }
+  a0 = mfma16(-Xk0[(0 + lg) * MB + ln], Xi0[(0 + lg) * MB + ln], a0);
+  b0 = mfma16(-Xk1[(0 + lg) * MB + ln], Xi1[(0 + lg) * MB + ln], b0);
+  a1 = mfma16(-Xk0[(4 + lg) * MB + ln], Xi0[(4 + lg) * MB + ln], a1);
+  b1 = mfma16(-Xk1[(4 + lg) * MB + ln], Xi1[(4 + lg) * MB + ln], b1);
+  a0 = mfma16(-Xk0[(8 + lg) * MB + ln], Xi0[(8 + lg) * MB + ln], a0);
+  b0 = mfma16(-Xk1[(8 + lg) * MB + ln], Xi1[(8 + lg) * MB + ln], b0);
+  a1 = mfma16(-Xk0[(12 + lg) * MB + ln], Xi0[(12 + lg) * MB + ln], a1);
+  b1 = mfma16(-Xk1[(12 + lg) * MB + ln], Xi1[(12 + lg) * MB + ln], b1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    C0[(lg + 4 * r) * MB + ln] = a0[r] + a1[r];
+    C1[(lg + 4 * r) * MB + ln] = b0[r] + b1[r];
+  }
+}
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
   // serial panel chain: issue ahead of the bulk-update waves that share this CU
   __builtin_amdgcn_s_setprio(3);
@@ -164,6 +269,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 15, lg = lane >> 4;
   const int nbk = p.nbk;
+  PT(0);
 
   {  // thread (r, c) of every tile; all 36 loads in flight
     const int r = tid & 15, c = tid >> 4;
@@ -183,10 +289,13 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
   }
   if (tid < NB) ys[tid] = (p.y && tid < nbk) ? p.y[tid] : 0.;
   __syncthreads();
+  PT(1);
 
   int bad_pivot = 0;
   if (wave == 0) micro_potrf_inv(T + tile_off(0, 0), Wc, p.img + tile_off(0, 0), lane, ln, 0, bad_pivot);
+  PT(2);
   __syncthreads();
+  PT(3);
 
 #pragma unroll 1
   for (int jb = 0; jb < NMB; ++jb) {
@@ -211,21 +320,39 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
       if (lane < MB) ys[o + ln] = zz;
     }
     __syncthreads();
+    PT(4 + 4 * jb);
     if (jb == NMB - 1) break;
 
     // ---- stage B: wave 0 updates the NEXT diagonal tile and factors it right
     // away (look-ahead) while waves 1-3 run the remaining SYRK tiles + y update
     if (wave == 0) {
       micro_syrk_tile(T, jb + 1, jb + 1, jb, ln, lg);
+      PT(5 + 4 * jb);
       micro_potrf_inv(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB),
                       p.img + tile_off(jb + 1, jb + 1), lane, ln, o + MB, bad_pivot);
+      PT(6 + 4 * jb);
     } else {
       const int rem = NMB - 1 - jb;
       const int ntile = rem * (rem + 1) / 2;
-      for (int tix = wave; tix < ntile; tix += 3) {  // tix 0 is the diagonal tile done by wave 0
-        int kb = 0, left = tix;
+      auto tile_of = [&](int tix, int &ib, int &kb) {
+        int left = tix;
+        kb = 0;
         while (left >= rem - kb) { left -= rem - kb; ++kb; }
-        micro_syrk_tile(T, jb + 1 + kb + left, jb + 1 + kb, jb, ln, lg);
+        ib = jb + 1 + kb + left;
+        kb = jb + 1 + kb;
+      };
+      // tix 0 is the diagonal tile done by wave 0; two tiles per trip: four independent MFMA chains
+      int tix = wave;
+      for (; tix + 3 < ntile; tix += 6) {
+        int i0, k0, i1, k1;
+        tile_of(tix, i0, k0);
+        tile_of(tix + 3, i1, k1);
+        micro_syrk_tile2(T, i0, k0, i1, k1, jb, ln, lg);
+      }
+      if (tix < ntile) {
+        int i0, k0;
+        tile_of(tix, i0, k0);
+        micro_syrk_tile(T, i0, k0, jb, ln, lg);
       }
       const int row = o + MB + (tid - 64);
       if (row < NB) {
@@ -237,7 +364,9 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
       }
     }
     __syncthreads();
+    PT(7 + 4 * jb);
   }
+  PT(40);
 
   {
     const int r = tid & 15, c = tid >> 4;
@@ -264,7 +393,14 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
     p.scalars[0] += (ys[0] + ys[1]) + (ys[2] + ys[3]);
     if (bad_pivot && p.flags[1] == 0) p.flags[1] = (int)(p.k0 + bad_pivot);
   }
+  PT(41);
 }
+
+#ifdef AGP_POTRF_TIMING
+void read_potrf_timing(unsigned long long *out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potrf_t), sizeof(unsigned long long) * 64);
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // Substitution against one NB x NB diagonal block over its micro blocks.

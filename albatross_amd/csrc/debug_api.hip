@@ -118,6 +118,11 @@ __global__ __launch_bounds__(256) void fmac_rate_kernel(unsigned long long *out,
 
 using namespace agp;
 
+#ifdef AGP_POTRF_TIMING
+namespace agp { void read_potrf_timing(unsigned long long *out); }
+extern "C" int agp_debug_potrf_timing(unsigned long long *out) { read_potrf_timing(out); return 0; }
+#endif
+
 extern "C" {
 
 int agp_debug_mfma_tile(agp_context *ctx, const double *A, const double *B, double *D) {
