@@ -457,47 +457,67 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs
   const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
   const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
 
+  // These launches sit on the serial panel chain and are latency-bound (a 64 x 64 x K tile is a
+  // few microseconds of MFMA work behind K / 16 global-load round trips), so the operand stream
+  // runs TWO chunks ahead of the MFMAs (two register stages + the two LDS buffers) and the
+  // accumulators start from C, loaded while the first chunks are in flight: no read-modify-write
+  // at the end.
+  double ra[2][4], rb[2][4];
+  const long long nk = (g.K + GK - 1) / GK;
+  load_chunk64(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra[0]);
+  load_chunk64(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb[0]);
+  if (nk > 1) {
+    load_chunk64(g.A, g.lda, i0, g.M, GK, g.K, a_vec, ra[1]);
+    load_chunk64(g.B, g.ldb, j0, g.N, GK, g.K, b_vec, rb[1]);
+  }
   v4d acc[2][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = v4zero();
-  double ra[4], rb[4];
-  const long long nk = (g.K + GK - 1) / GK;
-  load_chunk64(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
-  load_chunk64(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb);
-  store_chunk64<false>(lds, ra);
-  store_chunk64<true>(lds + GK * SLD, rb);
-  __syncthreads();
-  for (long long kc = 0; kc < nk; ++kc) {
-    const int cur = (int)(kc & 1);
-    const double *As = lds + cur * (2 * GK * SLD);
-    const double *Bs = As + GK * SLD;
-    const bool more = kc + 1 < nk;
-    if (more) {
-      load_chunk64(g.A, g.lda, i0, g.M, (kc + 1) * GK, g.K, a_vec, ra);
-      load_chunk64(g.B, g.ldb, j0, g.N, (kc + 1) * GK, g.K, b_vec, rb);
+    for (int ti = 0; ti < 2; ++ti) {
+      const long long row = i0 + 32 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
+        acc[tj][ti][r] = (row < g.M && col < g.N) ? g.C[row + col * g.ldc] : 0.;
+      }
     }
+  store_chunk64<false>(lds, ra[0]);
+  store_chunk64<true>(lds + GK * SLD, rb[0]);
+  __syncthreads();
+  for (long long kc = 0; kc < nk; kc += 2) {
+    // two chunks per trip so that the register stages are compile-time indices
 #pragma unroll
-    for (int s = 0; s < GK / 4; ++s) {
-      const int krow = (4 * s + lg) * SLD;
-      double fa[2], fb[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        fa[t] = Bs[krow + 32 * wc + 16 * t + ln];
-        fb[t] = As[krow + 32 * wr + 16 * t + ln];
+    for (int half = 0; half < 2; ++half) {
+      const long long k = kc + half;
+      if (k >= nk) break;
+      const double *As = lds + half * (2 * GK * SLD);
+      const double *Bs = As + GK * SLD;
+      if (k + 2 < nk) {  // stage `half` was stored to LDS one trip ago: refill it with chunk k + 2
+        load_chunk64(g.A, g.lda, i0, g.M, (k + 2) * GK, g.K, a_vec, ra[half]);
+        load_chunk64(g.B, g.ldb, j0, g.N, (k + 2) * GK, g.K, b_vec, rb[half]);
       }
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
+      for (int s = 0; s < GK / 4; ++s) {
+        const int krow = (4 * s + lg) * SLD;
+        double fa[2], fb[2];
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
+        for (int t = 0; t < 2; ++t) {
+          fa[t] = Bs[krow + 32 * wc + 16 * t + ln];
+          fb[t] = As[krow + 32 * wr + 16 * t + ln];
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
+      }
+      if (k + 1 < nk) {  // chunk k + 1 (register stage half ^ 1, loaded a trip ago) -> the other LDS buffer
+        double *An = lds + (half ^ 1) * (2 * GK * SLD);
+        store_chunk64<false>(An, ra[half ^ 1]);
+        store_chunk64<true>(An + GK * SLD, rb[half ^ 1]);
+      }
+      __syncthreads();
     }
-    if (more) {
-      double *An = lds + (cur ^ 1) * (2 * GK * SLD);
-      store_chunk64<false>(An, ra);
-      store_chunk64<true>(An + GK * SLD, rb);
-    }
-    __syncthreads();
   }
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
@@ -507,10 +527,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
-        if (row < g.M && col < g.N) {
-          double *c = g.C + row + col * g.ldc;
-          *c = *c + acc[tj][ti][r];
-        }
+        if (row < g.M && col < g.N) g.C[row + col * g.ldc] = acc[tj][ti][r];
       }
     }
 }
