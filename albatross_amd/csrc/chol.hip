@@ -610,16 +610,16 @@ void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n,
   panel_phase(ctx, s, A, n, lda, img, y, K0, kend, nullptr);
 }
 
-// Outer block width as a function of the remaining (trailing) size.  Wide
-// blocks (K = 512) keep the bulk update's C traffic off the HBM roofline while
-// the trailing matrix is far larger than the 256 MiB Infinity Cache; once it is
-// not, narrow blocks take the inner-update launches out of the serial panel
-// chain, which is what bounds the late phase.  Tunable for experiments through
-// AGP_NBO_SWITCH="m512,m256" (remaining size above which 512 / 256 is used).
+// Outer block width as a function of the remaining (trailing) size.  Wide blocks (K = 512) keep
+// the bulk update's C traffic off the HBM roofline and its MFMA efficiency up; narrow blocks
+// shorten the serial panel chain per step.  With the current panel kernels the choice barely
+// matters at N = 16384 (scripts/sweep_nbo.sh: 27.3-27.8 fits/s for every split at or below
+// 4096); 512 is kept until 2048 rows remain.  AGP_NBO_SWITCH="m512,m256" overrides (remaining
+// size above which 512 / 256 is used).
 static void nbo_thresholds(long long *m512, long long *m256) {
   static long long t512 = -1, t256 = -1;
   if (t512 < 0) {
-    t512 = 8192; t256 = 4096;
+    t512 = 2048; t256 = 1024;
     if (const char *e = getenv("AGP_NBO_SWITCH")) {
       long long a = 0, b = 0;
       if (sscanf(e, "%lld,%lld", &a, &b) == 2) { t512 = a; t256 = b; }
@@ -758,7 +758,8 @@ void backward_solve_mat(hipStream_t s, const double *A, long long n, long long l
 //   x_b = inv(L_bb)^T z_b                      (128 x 128 mat-vec, one workgroup)
 //   z[0:k] -= L[k:k+nb, 0:k]^T x_b             (one wave per 8 columns, coalesced
 //                                               1-KiB column segments)
-// Bandwidth: L is read exactly once (8 N^2 / 2 bytes).
+// Bandwidth: L is read exactly once (8 N^2 / 2 bytes).  (Tried: two blocks per launch with the
+// three 128 x 128 mat-vecs recomputed in every workgroup - 44 us per launch instead of 2 x 11.)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void set_identity_blocks_kernel(double *W, long long count) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -1,5 +1,7 @@
 #!/bin/bash
-# experiment: outer-block switch points of the factorisation
-for sw in "10240,6144" "99999,99999" "0,0" "12288,8192" "8192,4096" "6144,3072" "16384,8192" "4096,0"; do
-  echo "AGP_NBO_SWITCH=$sw"; AGP_NBO_SWITCH=$sw python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"stages_ms_per_fit": {[^}]*}' | tr '\n' ' '; echo
+# Sweep the outer-block switch points (remaining size above which NBO = 512 / 256 is used).
+for sw in "2048,1024" "0,0" "1024,512" "1024,0" "2048,0" "512,0" "3072,1024" "2048,512"; do
+  AGP_NBO_SWITCH=$sw python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-predict | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$sw', round(d['value'],3), round(d['ms_per_step'],3), round(d['stages_ms_per_fit']['factor'],3))"
 done
