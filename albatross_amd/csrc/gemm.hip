@@ -115,6 +115,28 @@ __device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const doubl
 
 // Which C tile a workgroup computes.  Returns false for padding workgroups.
 __device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int &bi, int &bj) {
+  if (g.remap == 2) {
+    // XCD-aware order for the triangular bulk update.  Workgroups b, b + 8, ... run on the same
+    // XCD (round-robin dispatch) and share its L2.  The tiles are dealt in SUPER-COLUMNS of 4
+    // tile columns; inside one, 8 consecutive ids walk down 8 tile rows (one per XCD) and the
+    // next 8 ids take the next column of the SAME rows: an XCD therefore runs the 4 tiles of a
+    // tile row back to back (their row strip of the panel is fetched from HBM/MALL once instead
+    // of four times) while the 4 column strips stay resident for the whole super-column.
+    // Every super-column is padded to a multiple of 8 rows so that (id mod 8) keeps meaning XCD.
+    long long l = blockIdx.x;
+    int sc = 0;
+    while (true) {
+      const int rows = g.ntr - 4 * sc;
+      const long long cnt = (long long)((rows + 7) / 8) * 32;
+      if (l < cnt) break;
+      l -= cnt;
+      ++sc;
+    }
+    const int rr = (int)(l & 7), q = (int)(l >> 3);
+    bj = 4 * sc + (q & 3);
+    bi = 4 * sc + (q >> 2) * 8 + rr;
+    return bi < g.ntr && bj < g.ntc && bi >= bj;
+  }
   if (g.remap) {
     const unsigned b = blockIdx.x;
     const int xcd = (int)(b & 7), l = (int)(b >> 3);
@@ -587,12 +609,16 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
   long long tiles = count_tiles(g.ntr, g.ntc, 1);
   static int use_remap = -1;
   if (use_remap < 0) {
-    // measured on MI355X at N = 16384: 35.7 TFLOP/s with the remap vs 39.0 without
-    // (uneven super-tiles on the diagonal), so it is OFF unless AGP_XCD_REMAP=1
+    // AGP_XCD_REMAP=1: 8 x 8 super-tiles per XCD (measured slower: uneven super-tiles on the
+    // diagonal); 2: super-columns of 4 tile columns, see tile_of_block
     const char *e = getenv("AGP_XCD_REMAP");
-    use_remap = (e && e[0] == '1') ? 1 : 0;
+    use_remap = e ? atoi(e) : 0;
   }
-  if (use_remap && g.ntr >= 16) {
+  if (use_remap == 2 && g.ntr >= 16) {
+    g.remap = 2;
+    tiles = 0;
+    for (int sc = 0; 4 * sc < g.ntr; ++sc) tiles += (long long)((g.ntr - 4 * sc + 7) / 8) * 32;
+  } else if (use_remap == 1 && g.ntr >= 16) {
     g.remap = 1;
     g.nb8 = (g.ntr + 7) / 8;
     g.nsuper = g.nb8 * (g.nb8 + 1) / 2;
