@@ -160,4 +160,54 @@ void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const d
                      variance);
 }
 
+// G[i, a] = R[i, idx[a]] for i >= row0 (columns of the inverse Cholesky factor of one index group)
+__global__ __launch_bounds__(256) void gather_cols_kernel(const double *__restrict__ R, long long ldr,
+                                                          const long long *__restrict__ idx, long long row0,
+                                                          long long n, double *__restrict__ G, long long ldg) {
+  const long long a = blockIdx.y;
+  const double *src = R + idx[a] * ldr;
+  double *dst = G + a * ldg;
+  for (long long i = row0 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    dst[i] = src[i];
+}
+
+void launch_gather_cols(hipStream_t s, const double *R, long long ldr, const long long *idx, long long m,
+                        long long row0, long long n, double *G, long long ldg) {
+  if (m <= 0 || n <= row0) return;
+  long long chunks = (n - row0 + 255) / 256;
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)chunks, (unsigned)m), dim3(256), 0, s, R, ldr, idx, row0, n, G, ldg);
+}
+
+// out[a] = base ? base[idx[a]] - sub[a] : src[idx[a]]     (subset(v, indices); y - solve(v))
+__global__ __launch_bounds__(256) void gather_vec_kernel(const double *__restrict__ src, const long long *__restrict__ idx,
+                                                         long long m, const double *__restrict__ sub,
+                                                         double *__restrict__ out) {
+  const long long a = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (a >= m) return;
+  const double v = src[idx[a]];
+  out[a] = sub ? v - sub[a] : v;
+}
+
+void launch_gather_vec(hipStream_t s, const double *src, const long long *idx, long long m, const double *sub,
+                       double *out) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(gather_vec_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, src, idx, m, sub, out);
+}
+
+// A (m x m, ld) <- -A ; optionally diag_out[i] = new A[i, i]
+__global__ __launch_bounds__(256) void negate_kernel(double *A, long long ld, long long m, double *diag_out) {
+  const long long col = blockIdx.x;
+  for (long long r = threadIdx.x; r < m; r += 256) {
+    const double v = -A[col * ld + r];
+    A[col * ld + r] = v;
+    if (diag_out && r == col) diag_out[col] = v;
+  }
+}
+
+void launch_negate(hipStream_t s, double *A, long long ld, long long m, double *diag_out) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(negate_kernel, dim3((unsigned)m), dim3(256), 0, s, A, ld, m, diag_out);
+}
+
 }  // namespace agp

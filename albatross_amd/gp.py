@@ -274,6 +274,55 @@ class GPFit:
                                                          capi.HOST), "agp_loo_marginal")
         return MarginalDistribution(mean, var)
 
+    @staticmethod
+    def _flatten_groups(groups, n):
+        offsets = np.zeros(len(groups) + 1, dtype=np.int64)
+        if len(groups):
+            offsets[1:] = np.cumsum([len(g) for g in groups])
+        parts = [np.asarray(g, dtype=np.int64).reshape(-1) for g in groups]
+        indices = np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int64)
+        if indices.size and (indices.min() < 0 or indices.max() >= n):
+            raise IndexError("group index out of range")
+        return offsets, indices
+
+    def inverse_blocks(self, groups):
+        """SerializableLDLT::inverse_blocks (serializable_ldlt.hpp:137-179): [(K^-1)[I_g, I_g] for g in groups]."""
+        offsets, indices = self._flatten_groups(groups, self.n)
+        out = np.empty(int(sum(len(g) ** 2 for g in groups)))
+        self._ctx._check(self._ctx._lib.agp_fit_inverse_blocks(self._ctx._h, self._h, len(groups), _ptr(offsets),
+                                                               _ptr(indices), _ptr(out), capi.HOST),
+                         "agp_fit_inverse_blocks")
+        blocks, pos = [], 0
+        for g in groups:
+            m = len(g)
+            blocks.append(out[pos:pos + m * m].reshape(m, m, order="F").copy())
+            pos += m * m
+        return blocks
+
+    def held_out_predictions(self, target_mean, groups, joint=False):
+        """details::held_out_predictions (cross_validation_utils.hpp:165-232): for every index group the
+        prediction of its targets from all other groups, without refitting.  Returns one
+        MarginalDistribution (joint=False) or JointDistribution (joint=True) per group."""
+        y = np.ascontiguousarray(target_mean, dtype=np.float64)
+        if y.shape[0] != self.n:
+            raise ValueError("target size")
+        offsets, indices = self._flatten_groups(groups, self.n)
+        total = int(offsets[-1])
+        mean, var = np.empty(total), np.empty(total)
+        jb = np.empty(int(sum(len(g) ** 2 for g in groups))) if joint else None
+        self._ctx._check(self._ctx._lib.agp_held_out_predictions(
+            self._ctx._h, self._h, _ptr(y), len(groups), _ptr(offsets), _ptr(indices), _ptr(mean), _ptr(var),
+            _ptr(jb), capi.HOST), "agp_held_out_predictions")
+        out, pos = [], 0
+        for gi, g in enumerate(groups):
+            m, o = len(g), int(offsets[gi])
+            if joint:
+                out.append(JointDistribution(mean[o:o + m].copy(), jb[pos:pos + m * m].reshape(m, m, order="F").copy()))
+                pos += m * m
+            else:
+                out.append(MarginalDistribution(mean[o:o + m].copy(), var[o:o + m].copy()))
+        return out
+
     def factor(self):
         L = np.empty((self.n, self.n), order="F")
         self._ctx._check(self._ctx._lib.agp_fit_download_factor(self._ctx._h, self._h, _ptr(L), self.n),
@@ -565,6 +614,9 @@ class GaussianProcessRegression:
             ctx._check(st, f"agp_fit_create (pivot {pivot})")
         return FitModel(self, GPFit(ctx, h, fs.n, dataset.features))
 
+    def cross_validate(self):
+        return CrossValidation(self)
+
     def log_likelihood(self, dataset):
         """gp.hpp:442-451 (without priors: the parameter-prior subsystem is out of scope)."""
         ctx = self._ctx()
@@ -575,6 +627,112 @@ class GaussianProcessRegression:
         ctx._check(ctx._lib.agp_nll(ctx._h, ctx.kernel(self.covariance_function_), C.byref(s), _ptr(y), _ptr(yv),
                                     C.byref(out)), "agp_nll")
         return -out.value
+
+
+class LeaveOneOutGrouper:
+    """LeaveOneOutGrouper (indexing/group_by.hpp): every observation is its own group."""
+
+    def __call__(self, feature, index=None):
+        return index
+
+
+def group_indexer(features, grouper):
+    """dataset.group_by(grouper).indexers(): ordered {key: [indices]} (std::map order = sorted keys)."""
+    feats = _values_of(features)
+    groups = {}
+    for i in range(len(feats)):
+        key = i if isinstance(grouper, LeaveOneOutGrouper) else grouper(feats[i])
+        groups.setdefault(key, []).append(i)
+    return dict(sorted(groups.items(), key=lambda kv: kv[0]))
+
+
+class CrossValidationPrediction:
+    """Prediction<CrossValidation<Model>, Feature, GroupIndexer> (evaluation/cross_validation.hpp:28-260).
+
+    means() / marginals() / joints() use the GP fast path (gp_cross_validated_predictions, gp.hpp:465-482:
+    ONE fit, then held_out_predictions); predictions() is the generic refit-per-fold path."""
+
+    def __init__(self, model, dataset, indexer):
+        self.model_, self.dataset_, self.indexer_ = model, dataset, indexer
+        self._fit_model = None
+
+    def _fit(self):
+        if self._fit_model is None:
+            self._fit_model = self.model_.fit(self.dataset_)
+        return self._fit_model.get_fit()
+
+    def _held_out(self, joint):
+        groups = list(self.indexer_.values())
+        preds = self._fit().held_out_predictions(self.dataset_.targets.mean, groups, joint=joint)
+        return dict(zip(self.indexer_.keys(), preds))
+
+    def predictions(self):
+        """predict_fold for every group: fit on the rest, predict the group (cross_validation.hpp:20-43)."""
+        feats = _values_of(self.dataset_.features)
+        y, yv = self.dataset_.targets.mean, self.dataset_.targets.covariance
+        n = len(feats)
+        out = {}
+        for key, idx in self.indexer_.items():
+            held = np.zeros(n, dtype=bool)
+            held[np.asarray(idx)] = True
+            train = np.nonzero(~held)[0]
+            tr_feats = [feats[i] for i in train] if isinstance(feats, list) else feats[train]
+            te_feats = [feats[i] for i in idx] if isinstance(feats, list) else feats[np.asarray(idx)]
+            targets = MarginalDistribution(y[train], None if yv is None else yv[train])
+            out[key] = self.model_.fit(RegressionDataset(tr_feats, targets)).predict(te_feats)
+        return out
+
+    def means(self):
+        return {k: p.mean for k, p in self._held_out(False).items()}
+
+    def marginals(self):
+        return self._held_out(False)
+
+    def joints(self):
+        return self._held_out(True)
+
+    def _concatenate(self, per_group):
+        n = self.dataset_.size()
+        out = np.empty(n)
+        for key, idx in self.indexer_.items():
+            out[np.asarray(idx)] = per_group[key]
+        return out
+
+    def mean(self):
+        """concatenate_mean_predictions: group results scattered back to dataset order."""
+        return self._concatenate(self.means())
+
+    def marginal(self):
+        m = self.marginals()
+        return MarginalDistribution(self._concatenate({k: p.mean for k, p in m.items()}),
+                                    self._concatenate({k: p.covariance for k, p in m.items()}))
+
+
+class CrossValidation:
+    """model.cross_validate() (core/model.hpp:154-156, evaluation/cross_validation.hpp:262-330)."""
+
+    def __init__(self, model):
+        self.model_ = model
+
+    def predict(self, dataset, grouper):
+        indexer = grouper if isinstance(grouper, dict) else group_indexer(dataset.features, grouper)
+        return CrossValidationPrediction(self.model_, dataset, indexer)
+
+    def predictions(self, dataset, grouper):
+        return self.predict(dataset, grouper).predictions()
+
+    def scores(self, metric, dataset, grouper):
+        """cross_validated_scores: metric(prediction of the group, truth of the group) per group."""
+        pred = self.predict(dataset, grouper)
+        marg = pred.marginals()
+        y = dataset.targets.mean
+        return np.array([metric(marg[k], MarginalDistribution(y[np.asarray(idx)])) for k, idx in pred.indexer_.items()])
+
+
+def root_mean_square_error(prediction, truth):
+    """RootMeanSquareError (evaluation/prediction_metrics.hpp)."""
+    d = prediction.mean - truth.mean
+    return float(np.sqrt(np.mean(d * d)))
 
 
 def gp_from_covariance(covariance_function, model_name="gaussian_process_regression", context=None):

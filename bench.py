@@ -80,7 +80,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predict", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded-fit code path even on 1 GPU")
-    ap.add_argument("--no-sharded-aux", action="store_true", help="N > 1: skip the auxiliary sharded single-fit block")
+    ap.add_argument("--sharded-aux", action="store_true",
+                    help="N > 1: also time ONE fit sharded over all ranks (RCCL panel broadcasts) after the timed "
+                         "region; opt-in because a rank failing inside a collective would stall the other ranks")
     ap.add_argument("--multi-gpu", choices=["sharded", "replicas"], default="replicas",
                     help="N > 1: 'replicas' (default) = one independent fit per rank, no data-path collective, "
                          "value = aggregate fits/s (weak scaling); 'sharded' = value is ONE fit block-column-sharded "
@@ -188,7 +190,7 @@ def main():
         t = torch.tensor([tr], device=f"cuda:{local_rank}", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         replicas = {"fits_per_sec": 3 * world / float(t.item()), "note": "one independent fit per GPU, no collective"}
-    if world > 1 and not sharded and not args.no_sharded_aux:
+    if world > 1 and not sharded and args.sharded_aux:
         # ONE fit sharded over all ranks (albatross_amd/distributed.py): block-column-cyclic LL^T with a
         # panel broadcast per 512 columns over RCCL.  A failure here is reported, it does not void `value`.
         try:

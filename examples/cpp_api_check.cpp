@@ -86,6 +86,36 @@ int main() {
   const auto loo = fm.get_fit().leave_one_out(y);
   const auto kinv = fm.get_fit().inverse_diagonal();
   for (int i = 0; i < n; ++i) std::printf("loo,%d,%.17g,%.17g,%.17g\n", i, loo.mean[i], loo.covariance[i], kinv[i]);
+  // leave-one-GROUP-out through model.cross_validate() (tests/test_cross_validation.cc:56-72,202-321):
+  // groups by the integer part of x[0] / 2.5; fast path vs refit-per-fold
+  {
+    const auto grouper = [](const P3 &p) { return static_cast<int>(p[0] / 2.5); };
+    const auto cv = model.cross_validate().predict(data, grouper);
+    const auto fast = cv.joints();
+    const auto brute = cv.predictions();
+    double dmean = 0., dcov = 0.;
+    for (const auto &kv : fast) {
+      const auto &b = brute.at(kv.first);
+      for (std::size_t a = 0; a < kv.second.size(); ++a) {
+        dmean = std::fmax(dmean, std::fabs(kv.second.mean[a] - b.mean[a]));
+        for (std::size_t c = 0; c < kv.second.size(); ++c)
+          dcov = std::fmax(dcov, std::fabs(kv.second.covariance(static_cast<std::int64_t>(a), static_cast<std::int64_t>(c)) -
+                                           b.covariance(static_cast<std::int64_t>(a), static_cast<std::int64_t>(c))));
+      }
+    }
+    std::printf("cv_groups,%zu\n", fast.size());
+    std::printf("cv_mean_diff,%.17g\n", dmean);
+    std::printf("cv_cov_diff,%.17g\n", dcov);
+    const auto cvm = cv.marginal();
+    for (const auto &kv : cv.indexer())
+      for (std::size_t a = 0; a < kv.second.size(); ++a)
+        std::printf("cv,%zu,%d,%.17g,%.17g\n", kv.second[a], kv.first, cvm.mean[kv.second[a]], cvm.covariance[kv.second[a]]);
+    // LeaveOneOutGrouper == the LOO fast path
+    const auto loo_cv = model.cross_validate().predict(data, LeaveOneOutGrouper()).marginal();
+    double dl = 0.;
+    for (int i = 0; i < n; ++i) dl = std::fmax(dl, std::fabs(loo_cv.mean[i] - loo.mean[i]) + std::fabs(loo_cv.covariance[i] - loo.covariance[i]));
+    std::printf("cv_loo_diff,%.17g\n", dl);
+  }
   // dense-matrix factor, dense NLL (tests/test_evaluate.cc:20-44) and update == full fit (tests/test_gp.cc:182-219)
   {
     Matrix c3(3, 3);

@@ -207,6 +207,28 @@ int agp_fit_inverse_diagonal(agp_context *ctx, const agp_fit *fit, double *out,
 int agp_loo_marginal(agp_context *ctx, const agp_fit *fit, const double *y,
                      double *mean, double *variance, int location);
 
+/* Leave-one-GROUP-out.  Groups are index sets into the training data: group g is
+ * indices[offsets[g] .. offsets[g + 1]) (offsets has n_groups + 1 entries, offsets[0] = 0; both
+ * arrays live on the host).
+ *
+ * agp_fit_inverse_blocks = SerializableLDLT::inverse_blocks
+ * (include/albatross/src/eigen/serializable_ldlt.hpp:137-179): blocks receives, concatenated, the
+ * column-major |g| x |g| matrices (K^-1)[I_g, I_g].
+ *
+ * agp_held_out_predictions = details::held_out_predictions
+ * (include/albatross/src/evaluation/cross_validation_utils.hpp:165-232; called by
+ * gp_cross_validated_predictions, models/gp.hpp:465-482): for every group the prediction of its
+ * own targets from all OTHER groups, without refitting:
+ *   mean_g = y_g - B_g^-1 information_g,  marginal variance = diag(B_g^-1),  joint = B_g^-1,
+ *   B_g = (K^-1)[I_g, I_g].
+ * mean / variance (variance may be NULL) are written in the order of `indices`; joint (may be NULL)
+ * receives the concatenated column-major blocks.  y, mean, variance, joint live at `location`. */
+int agp_fit_inverse_blocks(agp_context *ctx, const agp_fit *fit, int64_t n_groups, const int64_t *offsets,
+                           const int64_t *indices, double *blocks, int out_location);
+int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double *y, int64_t n_groups,
+                             const int64_t *offsets, const int64_t *indices, double *mean, double *variance,
+                             double *joint, int location);
+
 /* ---- predict ------------------------------------------------------------- */
 /* gp_mean_prediction (gp.hpp:82-85) via _predict_impl (gp.hpp:350-366):
  *   mean = k(train, xs)^T information.  mean: m doubles at out_location. */

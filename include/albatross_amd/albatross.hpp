@@ -437,6 +437,18 @@ class ScalingTerm : public CovarianceFunction<ScalingTerm<ScalingFunction>> {
 };
 
 namespace detail {
+// index groups -> offsets / indices of the C-ABI (agp_fit_inverse_blocks, agp_held_out_predictions)
+inline void flatten_groups(const std::vector<std::vector<std::size_t>> &groups, std::vector<std::int64_t> *offsets,
+                           std::vector<std::int64_t> *indices) {
+  offsets->assign(1, 0);
+  indices->clear();
+  for (const auto &g : groups) {
+    for (std::size_t i : g) indices->push_back(static_cast<std::int64_t>(i));
+    offsets->push_back(static_cast<std::int64_t>(indices->size()));
+  }
+  if (indices->empty()) indices->push_back(0);  // keep data() non-null for empty inputs
+}
+
 template <class LHS, class RHS, int OP, char SYM, typename Self>
 class Binary : public CovarianceFunction<Self> {
  public:
@@ -568,6 +580,57 @@ struct GPFit {
     detail::check(agp_loo_marginal(context->ctx, handle.get(), target_mean.data(), out.mean.data(),
                                    out.covariance.data(), AGP_HOST),
                   context->ctx, "agp_loo_marginal");
+    return out;
+  }
+
+  // SerializableLDLT::inverse_blocks, eigen/serializable_ldlt.hpp:137-179: (K^-1)[I_g, I_g] per index group
+  std::vector<Matrix> inverse_blocks(const std::vector<std::vector<std::size_t>> &blocks) const {
+    std::vector<std::int64_t> offsets, indices;
+    detail::flatten_groups(blocks, &offsets, &indices);
+    std::size_t elems = 0;
+    for (const auto &b : blocks) elems += b.size() * b.size();
+    std::vector<double> flat(elems ? elems : 1);
+    detail::check(agp_fit_inverse_blocks(context->ctx, handle.get(), static_cast<std::int64_t>(blocks.size()),
+                                         offsets.data(), indices.data(), flat.data(), AGP_HOST),
+                  context->ctx, "agp_fit_inverse_blocks");
+    std::vector<Matrix> out;
+    std::size_t pos = 0;
+    for (const auto &b : blocks) {
+      Matrix m(static_cast<std::int64_t>(b.size()), static_cast<std::int64_t>(b.size()));
+      std::copy(flat.begin() + static_cast<std::ptrdiff_t>(pos), flat.begin() + static_cast<std::ptrdiff_t>(pos + b.size() * b.size()),
+                m.data.begin());
+      pos += b.size() * b.size();
+      out.push_back(std::move(m));
+    }
+    return out;
+  }
+
+  // details::held_out_predictions, evaluation/cross_validation_utils.hpp:165-232: per group the
+  // joint prediction of its targets from all other groups (mean, full covariance), no refit
+  std::vector<JointDistribution> held_out_predictions(const Vector &target_mean,
+                                                      const std::vector<std::vector<std::size_t>> &groups) const {
+    std::vector<std::int64_t> offsets, indices;
+    detail::flatten_groups(groups, &offsets, &indices);
+    std::size_t elems = 0;
+    for (const auto &g : groups) elems += g.size() * g.size();
+    Vector mean(indices.size() ? indices.size() : 1), var(indices.size() ? indices.size() : 1);
+    std::vector<double> flat(elems ? elems : 1);
+    detail::check(agp_held_out_predictions(context->ctx, handle.get(), target_mean.data(),
+                                           static_cast<std::int64_t>(groups.size()), offsets.data(), indices.data(),
+                                           mean.data(), var.data(), flat.data(), AGP_HOST),
+                  context->ctx, "agp_held_out_predictions");
+    std::vector<JointDistribution> out;
+    std::size_t pos = 0;
+    for (std::size_t g = 0; g < groups.size(); ++g) {
+      const std::size_t m = groups[g].size(), o = static_cast<std::size_t>(offsets[g]);
+      JointDistribution j;
+      j.mean = Vector(mean.begin() + static_cast<std::ptrdiff_t>(o), mean.begin() + static_cast<std::ptrdiff_t>(o + m));
+      j.covariance = Matrix(static_cast<std::int64_t>(m), static_cast<std::int64_t>(m));
+      std::copy(flat.begin() + static_cast<std::ptrdiff_t>(pos), flat.begin() + static_cast<std::ptrdiff_t>(pos + m * m),
+                j.covariance.data.begin());
+      pos += m * m;
+      out.push_back(std::move(j));
+    }
     return out;
   }
 
@@ -920,6 +983,9 @@ class GaussianProcessRegression {
     return FitModel<GaussianProcessRegression, FeatureType>(*this, std::move(fit));
   }
 
+  // core/model.hpp:154-156
+  auto cross_validate() const;
+
   // gp.hpp:442-451 (prior_log_likelihood() is outside the hot path and not included)
   template <typename FeatureType>
   double log_likelihood(const RegressionDataset<FeatureType> &dataset) const {
@@ -942,6 +1008,126 @@ class GaussianProcessRegression {
   MeanFunc mean_function_;
   std::string model_name_ = "gaussian_process_regression";
 };
+
+// ---------------------------------------------------------------------------
+// Cross validation: indexing/group_by.hpp (LeaveOneOutGrouper, GroupIndexer),
+// evaluation/cross_validation.hpp:28-330 (model.cross_validate().predict(dataset, grouper)),
+// GP fast path gp_cross_validated_predictions, models/gp.hpp:465-482
+// ---------------------------------------------------------------------------
+struct LeaveOneOutGrouper {};
+
+template <typename GroupKey>
+using GroupIndexer = std::map<GroupKey, std::vector<std::size_t>>;
+
+template <typename FeatureType, typename Grouper>
+auto group_indexer(const std::vector<FeatureType> &features, const Grouper &grouper)
+    -> GroupIndexer<decltype(grouper(features[0]))> {
+  GroupIndexer<decltype(grouper(features[0]))> out;
+  for (std::size_t i = 0; i < features.size(); ++i) out[grouper(features[i])].push_back(i);
+  return out;
+}
+
+template <typename FeatureType>
+GroupIndexer<std::size_t> group_indexer(const std::vector<FeatureType> &features, const LeaveOneOutGrouper &) {
+  GroupIndexer<std::size_t> out;
+  for (std::size_t i = 0; i < features.size(); ++i) out[i] = {i};
+  return out;
+}
+
+template <typename ModelType, typename FeatureType, typename GroupKey>
+class CrossValidationPrediction {
+ public:
+  CrossValidationPrediction(const ModelType &model, const RegressionDataset<FeatureType> &dataset,
+                            const GroupIndexer<GroupKey> &indexer)
+      : model_(model), dataset_(dataset), indexer_(indexer) {}
+
+  const GroupIndexer<GroupKey> &indexer() const { return indexer_; }
+
+  // ONE fit, then held_out_predictions (gp.hpp:465-482)
+  std::map<GroupKey, JointDistribution> joints() const {
+    std::vector<std::vector<std::size_t>> groups;
+    for (const auto &kv : indexer_) groups.push_back(kv.second);
+    const auto fit_model = model_.fit(dataset_);
+    const auto preds = fit_model.get_fit().held_out_predictions(dataset_.targets.mean, groups);
+    std::map<GroupKey, JointDistribution> out;
+    std::size_t g = 0;
+    for (const auto &kv : indexer_) out[kv.first] = preds[g++];
+    return out;
+  }
+  std::map<GroupKey, MarginalDistribution> marginals() const {
+    std::map<GroupKey, MarginalDistribution> out;
+    for (const auto &kv : joints()) out[kv.first] = kv.second.marginal();
+    return out;
+  }
+  std::map<GroupKey, Vector> means() const {
+    std::map<GroupKey, Vector> out;
+    for (const auto &kv : joints()) out[kv.first] = kv.second.mean;
+    return out;
+  }
+  // concatenate_*_predictions: group results scattered back to dataset order
+  MarginalDistribution marginal() const {
+    MarginalDistribution out(Vector(dataset_.size()), Vector(dataset_.size()));
+    const auto m = marginals();
+    for (const auto &kv : indexer_) {
+      const auto &p = m.at(kv.first);
+      for (std::size_t a = 0; a < kv.second.size(); ++a) {
+        out.mean[kv.second[a]] = p.mean[a];
+        out.covariance[kv.second[a]] = p.covariance[a];
+      }
+    }
+    return out;
+  }
+  Vector mean() const { return marginal().mean; }
+
+  // generic path (cross_validation.hpp:20-43): refit on the other groups, predict the held-out one
+  std::map<GroupKey, JointDistribution> predictions() const {
+    std::map<GroupKey, JointDistribution> out;
+    for (const auto &kv : indexer_) {
+      std::vector<bool> held(dataset_.size(), false);
+      for (std::size_t i : kv.second) held[i] = true;
+      RegressionDataset<FeatureType> train;
+      std::vector<FeatureType> test;
+      const bool has_var = !dataset_.targets.covariance.empty();
+      for (std::size_t i = 0; i < dataset_.size(); ++i) {
+        if (held[i]) continue;
+        train.features.push_back(dataset_.features[i]);
+        train.targets.mean.push_back(dataset_.targets.mean[i]);
+        if (has_var) train.targets.covariance.push_back(dataset_.targets.covariance[i]);
+      }
+      for (std::size_t i : kv.second) test.push_back(dataset_.features[i]);
+      out[kv.first] = model_.fit(train).predict(test).joint();
+    }
+    return out;
+  }
+
+ private:
+  ModelType model_;
+  RegressionDataset<FeatureType> dataset_;
+  GroupIndexer<GroupKey> indexer_;
+};
+
+template <typename ModelType>
+class CrossValidation {
+ public:
+  explicit CrossValidation(const ModelType &model) : model_(model) {}
+  template <typename FeatureType, typename Grouper>
+  auto predict(const RegressionDataset<FeatureType> &dataset, const Grouper &grouper) const {
+    auto indexer = group_indexer(dataset.features, grouper);
+    using Key = typename decltype(indexer)::key_type;
+    return CrossValidationPrediction<ModelType, FeatureType, Key>(model_, dataset, indexer);
+  }
+
+ private:
+  ModelType model_;
+};
+
+template <typename ModelType>
+CrossValidation<ModelType> cross_validate(const ModelType &model) { return CrossValidation<ModelType>(model); }
+
+template <typename CovFunc, typename MeanFunc>
+auto GaussianProcessRegression<CovFunc, MeanFunc>::cross_validate() const {
+  return CrossValidation<GaussianProcessRegression<CovFunc, MeanFunc>>(*this);
+}
 
 // factories, gp.hpp:507-537
 template <typename CovFunc>

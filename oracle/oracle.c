@@ -754,3 +754,103 @@ ORC_API void orc_fit_loo_marginal(const orc_fit *f, const double *y, double *mea
   }
   free(d);
 }
+
+/* R^-1 = D^-1/2 L^-1 P (pivoted LDLT) or L^-1 (LLT) of the fit's covariance, n x n column-major
+ * (serializable_ldlt.hpp:154-165) */
+static double *fit_inverse_cholesky(const orc_fit *f) {
+  const int64_t n = f->n;
+  double *R = malloc(sizeof(double) * (size_t)(n * n));
+  if (f->use_llt) {
+    for (int64_t j = 0; j < n; ++j)
+      for (int64_t i = 0; i < n; ++i) R[i + j * n] = (i == j) ? 1. : 0.;
+    for (int64_t c = 0; c < n; ++c) {
+      double *b = R + c * n;
+      for (int64_t j = c; j < n; ++j) {
+        b[j] /= f->ldlt[j + j * n];
+        const double bj = b[j];
+        const double *col = f->ldlt + j * n;
+        for (int64_t i = j + 1; i < n; ++i) b[i] -= col[i] * bj;
+      }
+    }
+  } else {
+    ldlt_inverse_cholesky(f->ldlt, n, n, f->tr, R);
+  }
+  return R;
+}
+
+/* SerializableLDLT::inverse_blocks (serializable_ldlt.hpp:137-179): for every index group the
+ * block (K^-1)[I_g, I_g] = sub_matrix^T sub_matrix of the columns I_g of R^-1.
+ * offsets has n_groups + 1 entries into indices; blocks are written column-major, concatenated. */
+ORC_API void orc_fit_inverse_blocks(const orc_fit *f, int64_t n_groups, const int64_t *offsets,
+                                    const int64_t *indices, double *out) {
+  const int64_t n = f->n;
+  double *R = fit_inverse_cholesky(f);
+  for (int64_t g = 0; g < n_groups; ++g) {
+    const int64_t m = offsets[g + 1] - offsets[g];
+    const int64_t *idx = indices + offsets[g];
+    for (int64_t b = 0; b < m; ++b)
+      for (int64_t a = 0; a < m; ++a) {
+        const double *ca = R + idx[a] * n, *cb = R + idx[b] * n;
+        double s = 0.;
+        for (int64_t i = 0; i < n; ++i) s += ca[i] * cb[i];
+        out[a + b * m] = s;
+      }
+    out += m * m;
+  }
+  free(R);
+}
+
+/* held_out_predictions for arbitrary groups (cross_validation_utils.hpp:165-232):
+ *   A = inverse block of the group, v = information[I_g], y = targets[I_g]
+ *   mean = y - A.ldlt().solve(v)                       (:171-176)
+ *   marginal variance = SerializableLDLT(A).inverse_diagonal()   (:178-186)
+ *   joint covariance  = A.inverse()                    (:188-197)
+ * mean / variance are written in the order of `indices`; joint (may be NULL) as concatenated
+ * column-major blocks.  Returns 0 if a block is not invertible. */
+ORC_API int orc_fit_held_out(const orc_fit *f, const double *y, int64_t n_groups, const int64_t *offsets,
+                             const int64_t *indices, double *mean, double *variance, double *joint) {
+  const int64_t total = offsets[n_groups];
+  int64_t blk_elems = 0;
+  for (int64_t g = 0; g < n_groups; ++g) {
+    const int64_t m = offsets[g + 1] - offsets[g];
+    blk_elems += m * m;
+  }
+  double *blocks = malloc(sizeof(double) * (size_t)(blk_elems > 0 ? blk_elems : 1));
+  orc_fit_inverse_blocks(f, n_groups, offsets, indices, blocks);
+  int ok = 1;
+  const double *A = blocks;
+  (void)total;
+  for (int64_t g = 0; g < n_groups; ++g) {
+    const int64_t m = offsets[g + 1] - offsets[g];
+    const int64_t *idx = indices + offsets[g];
+    double *P = malloc(sizeof(double) * (size_t)(m * m));
+    int64_t *tr = malloc(sizeof(int64_t) * (size_t)m);
+    double *v = malloc(sizeof(double) * (size_t)m);
+    double *Rg = malloc(sizeof(double) * (size_t)(m * m));
+    memcpy(P, A, sizeof(double) * (size_t)(m * m));
+    if (!orc_ldlt(P, m, m, tr)) ok = 0;
+    for (int64_t a = 0; a < m; ++a) v[a] = f->information[idx[a]];
+    orc_ldlt_solve(P, m, m, tr, v, 1, m);
+    for (int64_t a = 0; a < m; ++a) mean[offsets[g] + a] = y[idx[a]] - v[a];
+    ldlt_inverse_cholesky(P, m, m, tr, Rg); /* columns of R^-1 of the block */
+    if (variance)
+      for (int64_t a = 0; a < m; ++a) {
+        double s = 0.;
+        for (int64_t i = 0; i < m; ++i) s += Rg[i + a * m] * Rg[i + a * m];
+        variance[offsets[g] + a] = s;
+      }
+    if (joint) {
+      for (int64_t b = 0; b < m; ++b)
+        for (int64_t a = 0; a < m; ++a) {
+          double s = 0.;
+          for (int64_t i = 0; i < m; ++i) s += Rg[i + a * m] * Rg[i + b * m];
+          joint[a + b * m] = s;
+        }
+      joint += m * m;
+    }
+    free(P); free(tr); free(v); free(Rg);
+    A += m * m;
+  }
+  free(blocks);
+  return ok;
+}

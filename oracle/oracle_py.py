@@ -55,6 +55,9 @@ def lib():
         L.orc_fit_solve.argtypes = [V, V, I64]
         L.orc_fit_inverse_diagonal.argtypes = [V, V]
         L.orc_fit_loo_marginal.argtypes = [V, V, V, V]
+        L.orc_fit_inverse_blocks.argtypes = [V, I64, V, V, V]
+        L.orc_fit_held_out.restype = C.c_int
+        L.orc_fit_held_out.argtypes = [V, V, I64, V, V, V, V, V]
         L.orc_nll_dense.restype = C.c_double
         L.orc_nll_dense.argtypes = [V, V, I64, I64]
         L.orc_nll.restype = C.c_double
@@ -201,6 +204,46 @@ class OracleFit:
         mean, var = np.zeros(self.n), np.zeros(self.n)
         lib().orc_fit_loo_marginal(self.h, _ptr(y), _ptr(mean), _ptr(var))
         return mean, var
+
+    @staticmethod
+    def _groups(groups):
+        offsets = np.zeros(len(groups) + 1, dtype=np.int64)
+        offsets[1:] = np.cumsum([len(g) for g in groups])
+        indices = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.int64) for g in groups])
+                                       if len(groups) else np.zeros(0, dtype=np.int64))
+        return offsets, indices
+
+    def inverse_blocks(self, groups):
+        """SerializableLDLT::inverse_blocks: list of (K^-1)[I_g, I_g]."""
+        offsets, indices = self._groups(groups)
+        out = np.zeros(int(sum(len(g) ** 2 for g in groups)))
+        lib().orc_fit_inverse_blocks(self.h, len(groups), _ptr(offsets), _ptr(indices), _ptr(out))
+        blocks, pos = [], 0
+        for g in groups:
+            m = len(g)
+            blocks.append(out[pos:pos + m * m].reshape(m, m, order="F").copy())
+            pos += m * m
+        return blocks
+
+    def held_out(self, y, groups, joint=False):
+        """held_out_predictions: per group (mean, variance[, joint covariance])."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        offsets, indices = self._groups(groups)
+        total = int(offsets[-1])
+        mean, var = np.zeros(total), np.zeros(total)
+        jb = np.zeros(int(sum(len(g) ** 2 for g in groups))) if joint else None
+        ok = lib().orc_fit_held_out(self.h, _ptr(y), len(groups), _ptr(offsets), _ptr(indices), _ptr(mean),
+                                    _ptr(var), _ptr(jb))
+        assert ok
+        out, pos = [], 0
+        for gi, g in enumerate(groups):
+            m, o = len(g), int(offsets[gi])
+            item = [mean[o:o + m].copy(), var[o:o + m].copy()]
+            if joint:
+                item.append(jb[pos:pos + m * m].reshape(m, m, order="F").copy())
+                pos += m * m
+            out.append(tuple(item))
+        return out
 
     def predict_mean(self, xs, xs_meas=False):
         f, keep = _feat(self.cov, xs, xs_meas)

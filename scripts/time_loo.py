@@ -12,6 +12,14 @@ fit = fm.get_fit()
 fit.leave_one_out(y)
 t = time.perf_counter(); loo = fit.leave_one_out(y); dt = time.perf_counter() - t
 print(f"LOO marginals of all {n} points: {dt*1e3:.1f} ms ({n**3/3/dt/1e12:.1f} TFLOP/s on N^3/3)")
+perm = rng.permutation(n)
+for gs in (512, 64):
+    groups = [list(map(int, perm[g * gs:(g + 1) * gs])) for g in range(n // gs)]
+    fit.held_out_predictions(y, groups[:2])
+    t = time.perf_counter(); preds = fit.held_out_predictions(y, groups); dt = time.perf_counter() - t
+    t = time.perf_counter(); pj = fit.held_out_predictions(y, groups, joint=True); dtj = time.perf_counter() - t
+    print(f"leave-one-group-out, {len(groups)} groups of {gs}: marginals {dt*1e3:.1f} ms, joints {dtj*1e3:.1f} ms "
+          f"(N refits of the other groups would be {len(groups)} fits)")
 K = rng.standard_normal((4096, 4100)); K = K @ K.T / 4096 + np.eye(4096)
 ab.DenseFactor(K, ctx)
 t = time.perf_counter(); f = ab.DenseFactor(K, ctx); dt = time.perf_counter() - t

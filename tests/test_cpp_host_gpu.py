@@ -95,6 +95,16 @@ def test_cpp_api_matches_oracle():
     lm, lv = ofit.loo_marginal(y)
     assert np.abs(loo[:, 1] - lm).max() <= 1e-8 * np.abs(lm).max() and np.abs(loo[:, 2] - lv).max() <= 1e-8 * lv.max()
     assert np.abs(loo[:, 3] - ofit.inverse_diagonal()).max() <= 1e-8 * ofit.inverse_diagonal().max()
+    # leave-one-group-out: fast path == refit per fold (the brute-force predict(test) is the latent
+    # prediction: the held-out noise term only appears in the fast path's covariance diagonal)
+    assert int(one["cv_groups"]) == 4 and float(one["cv_mean_diff"]) < 1e-7 and float(one["cv_cov_diff"]) < 1e-7
+    cvr = np.array(rows["cv"], dtype=float)
+    groups = [list(map(int, cvr[cvr[:, 1] == k, 0])) for k in sorted(set(cvr[:, 1]))]
+    want = ofit.held_out(y, groups)
+    for (wm, wv), g in zip(want, groups):
+        sel = np.array([np.nonzero(cvr[:, 0] == i)[0][0] for i in g])
+        assert np.abs(cvr[sel, 2] - wm).max() <= 1e-8 * np.abs(wm).max() and np.abs(cvr[sel, 3] - wv).max() <= 1e-8
+    assert float(one["cv_loo_diff"]) < 1e-9
     assert abs(float(one["mvn_nll"]) - 6.0946974293510134) < 1e-12  # tests/test_evaluate.cc:26,41
     assert abs(float(one["mvn_logdet"]) - np.linalg.slogdet(np.array([[1, .9, .8], [.9, 1, .9], [.8, .9, 1.]]))[1]) < 1e-13
     assert float(one["update_mean_diff"]) < 1e-8 and float(one["update_cov_diff"]) < 1e-6  # tests/test_gp.cc:213

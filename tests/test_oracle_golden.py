@@ -191,3 +191,28 @@ def test_loo_fast_path_equals_brute_force():
             idx = np.r_[0:i, i + 1:n]
             sol = np.linalg.solve(K[np.ix_(idx, idx)], K[idx, i])
             assert abs(m[i] - sol @ y[idx]) < 1e-8 and abs(v[i] - (K[i, i] - K[idx, i] @ sol)) < 1e-8
+
+
+def test_group_held_out_equals_brute_force():
+    # tests/test_serializable_ldlt.cc:40-66 (inverse blocks == blocks of cov.inverse()) and
+    # tests/test_cross_validation.cc:202-321 (leave-one-group-out == refit without the group), 1e-8
+    rng = np.random.default_rng(2)
+    n = 70
+    x = rng.uniform(0, 10, (n, 2))
+    y = np.sin(x).sum(1) + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.05, n)
+    cov = ab.Matern52(2., 1.) + ab.IndependentNoise(0.1)
+    K = orc.gram(cov, x, x_meas=True) + np.diag(yvar)
+    Kinv = np.linalg.inv(K)
+    perm = rng.permutation(n)
+    groups = [list(map(int, perm[:9])), list(map(int, perm[9:40])), [int(perm[40])], list(map(int, perm[41:]))]
+    for use_llt in (False, True):
+        f = orc.OracleFit(cov, x, y, yvar, use_llt=use_llt)
+        for blk, g in zip(f.inverse_blocks(groups), groups):
+            assert np.abs(blk - Kinv[np.ix_(g, g)]).max() < 1e-8
+        for (m, v, J), g in zip(f.held_out(y, groups, joint=True), groups):
+            rest = np.setdiff1d(np.arange(n), g)
+            sol = np.linalg.solve(K[np.ix_(rest, rest)], K[np.ix_(rest, g)])
+            assert np.abs(m - sol.T @ y[rest]).max() < 1e-8
+            C = K[np.ix_(g, g)] - K[np.ix_(rest, g)].T @ sol
+            assert np.abs(J - C).max() < 1e-8 and np.abs(v - np.diag(C)).max() < 1e-8
