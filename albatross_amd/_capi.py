@@ -92,6 +92,14 @@ EXPORTS = [
     ("agp_nll_dense", C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _D]),
     ("agp_fit_inverse_diagonal", C.c_int, [_P, _P, _P, C.c_int]),
     ("agp_loo_marginal", C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
+    ("agp_sparse_fit_create", C.c_int, [_P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.POINTER(Features), C.c_double, C.c_double, _PP, _P, _D]),
+    ("agp_sparse_fit_destroy", None, [_P]),
+    ("agp_sparse_fit_size", C.c_int64, [_P]),
+    ("agp_sparse_fit_information", C.c_int, [_P, _P, _P]),
+    ("agp_sparse_nll", C.c_int, [_P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.POINTER(Features), C.c_double, C.c_double, _D]),
+    ("agp_sparse_predict_mean", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, C.c_int]),
+    ("agp_sparse_predict_marginal", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
+    ("agp_sparse_predict_joint", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
     ("agp_fit_inverse_blocks", C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int]),
     ("agp_held_out_predictions", C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int]),
     ("agp_predict_mean", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, C.c_int]),

@@ -728,6 +728,29 @@ void forward_solve_mat(hipStream_t s, const double *A, long long n, long long ld
   }
 }
 
+// X (nrows x n, ldx) <- X L^-T : the panel TRSM of the factorisation applied to a free-standing
+// matrix (sparse GP: K_uf[:, group] L_A^-T = (A^-1/2 K_fu)^T, models/sparse_gp.hpp:347-349).
+void right_solve_lt(hipStream_t s, const double *A, long long n, long long lda, const double *invd, double *X,
+                    long long nrows, long long ldx) {
+  if (nrows <= 0) return;
+  for (long long k = 0; k < n; k += NB) {
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    TrsmArgs t;
+    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+    t.nbk = nbk;
+    t.Y = X + k * ldx;           // Y = X[:, k : k + nbk]^T : element (m, n) at Y[m * ldx + n]
+    t.stride_m = ldx; t.stride_n = 1;
+    t.ncols = nrows;
+    t.z = nullptr; t.yrest = nullptr;
+    t.batch_img = t.batch_Y = 0; t.n_total = 0;
+    hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((nrows + 63) / 64)), dim3(256), 0, s, t);
+    const long long rest = n - (k + nbk);
+    if (rest > 0)  // X[:, k + nbk :] -= X[:, k : k + nbk] L[k + nbk :, k : k + nbk]^T
+      launch_gemm_nt_sub(s, X + (k + nbk) * ldx, ldx, X + k * ldx, ldx, false, A + k * lda + (k + nbk), lda, false,
+                         nrows, rest, nbk, false);
+  }
+}
+
 void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                         double *B, long long m, long long ldb) {
   if (m <= 0 || n <= 0) return;

@@ -134,6 +134,8 @@ void backward_solve_vec(hipStream_t s, const double *A, long long n, long long l
 void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                        double *B, long long m, long long ldb, bool rhs_lower = false);
 // B (n x m, ldb) <- L^-T B
+void right_solve_lt(hipStream_t s, const double *A, long long n, long long lda, const double *invd, double *X,
+                    long long nrows, long long ldx);
 void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                         double *B, long long m, long long ldb);
 

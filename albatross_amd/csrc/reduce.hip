@@ -210,4 +210,83 @@ void launch_negate(hipStream_t s, double *A, long long ld, long long m, double *
   hipLaunchKernelGGL(negate_kernel, dim3((unsigned)m), dim3(256), 0, s, A, ld, m, diag_out);
 }
 
+// ---- small dense helpers of the sparse-GP path (W is m x n column-major, m << n) ---------------
+// partial[chunk * m + i] = sum_{j in chunk} W[i, j] x[j]   (rows across threads: coalesced)
+__global__ __launch_bounds__(256) void matvec_partial_kernel(const double *__restrict__ W, long long ld, long long m,
+                                                             long long n, long long chunk,
+                                                             const double *__restrict__ x,
+                                                             double *__restrict__ partial) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long j0 = (long long)blockIdx.y * chunk;
+  long long j1 = j0 + chunk;
+  if (j1 > n) j1 = n;
+  if (i >= m) return;
+  double a0 = 0., a1 = 0.;
+  long long j = j0;
+  for (; j + 1 < j1; j += 2) {
+    a0 += W[i + j * ld] * x[j];
+    a1 += W[i + (j + 1) * ld] * x[j + 1];
+  }
+  if (j < j1) a0 += W[i + j * ld] * x[j];
+  partial[(long long)blockIdx.y * m + i] = a0 + a1;
+}
+
+// out[i] = alpha * sum_c partial[c * m + i] + beta * base[i]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void matvec_reduce_kernel(const double *__restrict__ partial, long long m,
+                                                            long long chunks, double alpha, double beta,
+                                                            const double *base, double *out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  double s = 0.;
+  for (long long c = 0; c < chunks; ++c) s += partial[c * m + i];
+  out[i] = alpha * s + (base ? beta * base[i] : 0.);
+}
+
+// out = alpha * W x + beta * base ; `partial` needs ceil(n / 1024) * m doubles
+void launch_matvec(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *x,
+                   double *partial, double alpha, double beta, const double *base, double *out) {
+  if (m <= 0) return;
+  const long long chunk = 1024, chunks = n > 0 ? (n + chunk - 1) / chunk : 0;
+  if (chunks > 0)
+    hipLaunchKernelGGL(matvec_partial_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)chunks), dim3(256), 0, s, W, ld,
+                       m, n, chunk, x, partial);
+  hipLaunchKernelGGL(matvec_reduce_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, partial, m, chunks, alpha,
+                     beta, base, out);
+}
+
+// out[j] = alpha * sum_i W[i, j] v[i] + beta * base[j]   (one workgroup per column)
+__global__ __launch_bounds__(256) void colvec_dot_kernel(const double *__restrict__ W, long long ld, long long m,
+                                                         const double *__restrict__ v, double alpha, double beta,
+                                                         const double *base, double *out) {
+  __shared__ double red[4];
+  const long long j = blockIdx.x;
+  const double *w = W + j * ld;
+  double acc = 0.;
+  for (long long i = threadIdx.x; i < m; i += 256) acc += w[i] * v[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[j] = alpha * ((red[0] + red[1]) + (red[2] + red[3])) + (base ? beta * base[j] : 0.);
+}
+
+void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,
+                       double alpha, double beta, const double *base, double *out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(colvec_dot_kernel, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out);
+}
+
+// out[i] = a * x[i] + b * (y ? y[i] : 1)
+__global__ __launch_bounds__(256) void axpby_kernel(long long n, double a, const double *x, double b, const double *y,
+                                                    double *out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = (x ? a * x[i] : 0.) + b * (y ? y[i] : 1.);
+}
+
+void launch_axpby(hipStream_t s, long long n, double a, const double *x, double b, const double *y, double *out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a, x, b, y, out);
+}
+
 }  // namespace agp

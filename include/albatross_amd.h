@@ -229,6 +229,44 @@ int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double 
                              const int64_t *offsets, const int64_t *indices, double *mean, double *variance,
                              double *joint, int location);
 
+/* ---- sparse Gaussian process (FITC / PITC) --------------------------------------------------
+ * SparseGaussianProcessRegression, include/albatross/src/models/sparse_gp.hpp.
+ *
+ * agp_sparse_fit_create = _fit_impl (:354-381) on compute_internal_components (:631-706):
+ *   x        the n training features ALREADY reordered group by group (reordered_inds, :645-662):
+ *            independent group g = rows offsets[g] .. offsets[g + 1) (offsets: n_groups + 1 host
+ *            entries, offsets[0] = 0, offsets[n_groups] = n); they are wrapped as measurements
+ *            inside (as_measurements, :649-650)
+ *   y, y_var target means / variances (or NULL) in the same order, at x->location; y is used as
+ *            given (the reference copies y before it removes the mean function, :664-668)
+ *   u        the m inducing features (the InducingPointStrategy's result, :358-360)
+ *   nuggets  measurement_nugget on every diagonal of A (:692-696), inducing_nugget on K_uu (:676-677)
+ * The handle keeps what prediction needs (Fit<SparseGPFit>: inducing features, the K_uu factor,
+ * the factor of Sigma^-1 = K_uu + K_uf A^-1 K_fu, the information vector).  information (m doubles,
+ * host) and nll (= -log_likelihood, :524-596, without parameter priors) are optional outputs.
+ * out may be NULL (only nll / information wanted); agp_sparse_nll is that call.
+ * Errors: AGP_ERR_NOT_POSITIVE_DEFINITE if K_uu, a block of A or Sigma^-1 is not numerically
+ * positive definite (the reference's pivoted LDLT / QR would continue), AGP_ERR_NAN_INPUT. */
+typedef struct agp_sparse_fit agp_sparse_fit;
+int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *kernel, const agp_features *x, int64_t n_groups,
+                          const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
+                          double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
+                          double *information, double *nll);
+void agp_sparse_fit_destroy(agp_sparse_fit *fit);
+int64_t agp_sparse_fit_size(const agp_sparse_fit *fit); /* number of inducing points */
+int agp_sparse_fit_information(agp_context *ctx, const agp_sparse_fit *fit, double *information);
+int agp_sparse_nll(agp_context *ctx, const agp_kernel *kernel, const agp_features *x, int64_t n_groups,
+                   const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
+                   double measurement_nugget, double inducing_nugget, double *out);
+/* _predict_impl (:447-521): mean = K_*u v; covariance = K_** - Q_** + K_*u Sigma K_u*.  The mean
+ * function is the caller's (mean_function_.add_to). */
+int agp_sparse_predict_mean(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *fit,
+                            const agp_features *xs, double *mean, int out_location);
+int agp_sparse_predict_marginal(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *fit,
+                                const agp_features *xs, double *mean, double *variance, int out_location);
+int agp_sparse_predict_joint(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *fit,
+                             const agp_features *xs, double *mean, double *covariance, int out_location);
+
 /* ---- predict ------------------------------------------------------------- */
 /* gp_mean_prediction (gp.hpp:82-85) via _predict_impl (gp.hpp:350-366):
  *   mean = k(train, xs)^T information.  mean: m doubles at out_location. */

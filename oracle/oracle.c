@@ -854,3 +854,430 @@ ORC_API int orc_fit_held_out(const orc_fit *f, const double *y, int64_t n_groups
   free(blocks);
   return ok;
 }
+
+/* ====================================================================== */
+/* Sparse Gaussian process (FITC / PITC): models/sparse_gp.hpp             */
+/* ====================================================================== */
+/* SerializableLDLT::sqrt_solve (serializable_ldlt.hpp:99-109): B <- D^-1/2 L^-1 P B, in place */
+static void ldlt_sqrt_solve(const double *A, int64_t n, int64_t ld, const int64_t *tr, double *B, int64_t nrhs,
+                            int64_t ldb) {
+  for (int64_t c = 0; c < nrhs; ++c) {
+    double *b = B + c * ldb;
+    for (int64_t k = 0; k < n; ++k)
+      if (tr[k] != k) { const double t = b[k]; b[k] = b[tr[k]]; b[tr[k]] = t; }
+    for (int64_t j = 0; j < n; ++j) {
+      const double bj = b[j];
+      const double *col = A + j * ld;
+      for (int64_t i = j + 1; i < n; ++i) b[i] -= col[i] * bj;
+    }
+    for (int64_t i = 0; i < n; ++i) b[i] /= sqrt(A[i + i * ld]); /* diagonal_sqrt_inverse */
+  }
+}
+
+/* SerializableLDLT::sqrt_transpose (:111-115): out = D^1/2 (P^T L)^T, n x n column-major */
+static void ldlt_sqrt_transpose(const double *A, int64_t n, int64_t ld, const int64_t *tr, double *out) {
+  double *M = malloc(sizeof(double) * (size_t)(n * n));
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < n; ++i) M[i + j * n] = (i == j) ? 1. : (i > j ? A[i + j * ld] : 0.);
+  for (int64_t k = n - 1; k >= 0; --k) /* P^T: the transpositions in reverse order, on the rows */
+    if (tr[k] != k)
+      for (int64_t c = 0; c < n; ++c) {
+        const double t = M[k + c * n];
+        M[k + c * n] = M[tr[k] + c * n];
+        M[tr[k] + c * n] = t;
+      }
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < n; ++i) out[i + j * n] = sqrt(A[i + i * ld]) * M[j + i * n];
+  free(M);
+}
+
+/* Householder QR with column pivoting (the published algorithm behind Eigen::ColPivHouseholderQR,
+ * which DenseQRImplementation uses, sparse_gp.hpp:80-88): at every step the remaining column of
+ * largest norm is brought forward.  Eigen down-dates the column norms; here they are recomputed,
+ * which picks the same pivots except on ties at rounding level.
+ * B (rows x cols, ld) is overwritten: R in the upper triangle, Householder vectors below;
+ * perm[k] = original index of the column at position k. */
+typedef struct {
+  int64_t rows, cols;
+  double *qr;   /* rows x cols */
+  double *tau;  /* cols */
+  int64_t *perm;
+  int64_t nonzero_pivots, rank;
+} orc_qr;
+
+static orc_qr *colpiv_qr(const double *B, int64_t rows, int64_t cols) {
+  orc_qr *q = calloc(1, sizeof(orc_qr));
+  q->rows = rows; q->cols = cols;
+  q->qr = malloc(sizeof(double) * (size_t)(rows * cols));
+  memcpy(q->qr, B, sizeof(double) * (size_t)(rows * cols));
+  q->tau = calloc((size_t)cols, sizeof(double));
+  q->perm = malloc(sizeof(int64_t) * (size_t)cols);
+  for (int64_t j = 0; j < cols; ++j) q->perm[j] = j;
+  double *A = q->qr;
+  double max_norm = 0.;
+  for (int64_t j = 0; j < cols; ++j) {
+    double s = 0.;
+    for (int64_t i = 0; i < rows; ++i) s += A[i + j * rows] * A[i + j * rows];
+    if (sqrt(s) > max_norm) max_norm = sqrt(s);
+  }
+  const double eps = 2.220446049250313e-16;
+  const double threshold_helper = (max_norm * eps / (double)rows) * (max_norm * eps / (double)rows);
+  q->nonzero_pivots = cols;
+  double maxpivot = 0.;
+  for (int64_t k = 0; k < cols; ++k) {
+    int64_t best = k;
+    double best_sq = -1.;
+    for (int64_t j = k; j < cols; ++j) {
+      double s = 0.;
+      for (int64_t i = k; i < rows; ++i) s += A[i + j * rows] * A[i + j * rows];
+      if (s > best_sq) { best_sq = s; best = j; }
+    }
+    if (q->nonzero_pivots == cols && best_sq < threshold_helper * (double)(rows - k)) q->nonzero_pivots = k;
+    if (best != k) {
+      for (int64_t i = 0; i < rows; ++i) {
+        const double t = A[i + k * rows]; A[i + k * rows] = A[i + best * rows]; A[i + best * rows] = t;
+      }
+      const int64_t t = q->perm[k]; q->perm[k] = q->perm[best]; q->perm[best] = t;
+    }
+    /* makeHouseholderInPlace */
+    double *x = A + k + k * rows;
+    const int64_t len = rows - k;
+    double tail = 0.;
+    for (int64_t i = 1; i < len; ++i) tail += x[i] * x[i];
+    double beta, tau;
+    if (tail <= 2.2250738585072014e-308) {
+      tau = 0.; beta = x[0];
+      for (int64_t i = 1; i < len; ++i) x[i] = 0.;
+    } else {
+      beta = sqrt(x[0] * x[0] + tail);
+      if (x[0] >= 0.) beta = -beta;
+      for (int64_t i = 1; i < len; ++i) x[i] /= (x[0] - beta);
+      tau = (beta - x[0]) / beta;
+    }
+    x[0] = beta;
+    q->tau[k] = tau;
+    /* apply H = I - tau v v^T (v = [1; essential]) to the remaining columns */
+    for (int64_t j = k + 1; j < cols; ++j) {
+      double *c = A + k + j * rows;
+      double s = c[0];
+      for (int64_t i = 1; i < len; ++i) s += x[i] * c[i];
+      s *= tau;
+      c[0] -= s;
+      for (int64_t i = 1; i < len; ++i) c[i] -= s * x[i];
+    }
+    if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
+  }
+  const double thr = maxpivot * eps * (double)cols; /* rank(): |R_ii| > maxpivot * eps * diagSize */
+  q->rank = 0;
+  for (int64_t k = 0; k < cols; ++k)
+    if (fabs(A[k + k * rows]) > thr) ++q->rank;
+  return q;
+}
+
+static void qr_free(orc_qr *q) {
+  if (!q) return;
+  free(q->qr); free(q->tau); free(q->perm); free(q);
+}
+
+/* ColPivHouseholderQR::solve: dst = P [R11^-1 (Q^T rhs)_{1:np}; 0] */
+static void qr_solve(const orc_qr *q, const double *rhs, double *dst) {
+  const int64_t rows = q->rows, cols = q->cols, np = q->nonzero_pivots;
+  double *c = malloc(sizeof(double) * (size_t)rows);
+  memcpy(c, rhs, sizeof(double) * (size_t)rows);
+  for (int64_t k = 0; k < np; ++k) {
+    const double *v = q->qr + k + k * rows;
+    double s = c[k];
+    for (int64_t i = 1; i < rows - k; ++i) s += v[i] * c[k + i];
+    s *= q->tau[k];
+    c[k] -= s;
+    for (int64_t i = 1; i < rows - k; ++i) c[k + i] -= s * v[i];
+  }
+  for (int64_t i = np - 1; i >= 0; --i) {
+    double s = c[i];
+    for (int64_t j = i + 1; j < np; ++j) s -= q->qr[i + j * rows] * c[j];
+    c[i] = s / q->qr[i + i * rows];
+  }
+  for (int64_t i = 0; i < cols; ++i) dst[q->perm[i]] = (i < np) ? c[i] : 0.;
+  free(c);
+}
+
+/* sqrt_solve(R, P, rhs) = R^-T P^T rhs (linalg/qr_utils.hpp:37-45), rhs m x nrhs in place */
+static void qr_sqrt_solve(const double *R, const int64_t *perm, int64_t m, double *rhs, int64_t nrhs, int64_t ld) {
+  double *t = malloc(sizeof(double) * (size_t)m);
+  for (int64_t c = 0; c < nrhs; ++c) {
+    double *b = rhs + c * ld;
+    for (int64_t i = 0; i < m; ++i) t[i] = b[perm[i]]; /* P^T rhs */
+    for (int64_t i = 0; i < m; ++i) {                  /* R^T lower-triangular solve */
+      double s = t[i];
+      for (int64_t j = 0; j < i; ++j) s -= R[j + i * m] * t[j];
+      t[i] = s / R[i + i * m];
+    }
+    memcpy(b, t, sizeof(double) * (size_t)m);
+  }
+  free(t);
+}
+
+typedef struct {
+  int64_t m;             /* inducing points */
+  agp_features u;        /* train_features = inducing points (owned copies) */
+  double *coords_copy; int64_t *eq_copy; double *scales_copy;
+  double *kuu_ldlt; int64_t *kuu_tr;   /* train_covariance */
+  double *R; int64_t *perm;            /* R (m x m upper), P */
+  double *information;
+  int64_t numerical_rank;
+  double nll;                          /* of the data the fit was made from */
+} orc_sparse_fit;
+
+typedef struct {
+  int64_t n, m, n_groups;
+  int64_t *order, *offsets;      /* reordered_inds; group g = order[offsets[g] .. offsets[g+1]) */
+  double **a_ldlt; int64_t **a_tr; /* BlockDiagonalLDLT A */
+  double *kuu_ldlt; int64_t *kuu_tr;
+  double *K_fu;                  /* n x m, rows in reordered order */
+  double *y;                     /* reordered targets */
+} sparse_parts;
+
+static int cmp_key_index(const void *a, const void *b) {
+  const int64_t *x = a, *y = b;
+  if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+  return x[1] < y[1] ? -1 : (x[1] > y[1]);
+}
+
+static void sparse_parts_free(sparse_parts *p) {
+  if (!p) return;
+  for (int64_t g = 0; g < p->n_groups; ++g) { free(p->a_ldlt[g]); free(p->a_tr[g]); }
+  free(p->a_ldlt); free(p->a_tr); free(p->order); free(p->offsets);
+  free(p->kuu_ldlt); free(p->kuu_tr); free(p->K_fu); free(p->y);
+  free(p);
+}
+
+static agp_features subset_features(const agp_features *x, const int64_t *idx, int64_t cnt, int is_measurement,
+                                    double **coords, int64_t **eq, double **scales) {
+  agp_features s = *x;
+  s.n = cnt; s.is_measurement = is_measurement;
+  *coords = malloc(sizeof(double) * (size_t)(cnt * x->dim + 1));
+  for (int64_t a = 0; a < cnt; ++a)
+    memcpy(*coords + a * x->dim, x->coords + idx[a] * x->dim, sizeof(double) * (size_t)x->dim);
+  s.coords = *coords;
+  *eq = NULL; *scales = NULL;
+  if (x->eq_id) {
+    *eq = malloc(sizeof(int64_t) * (size_t)(cnt + 1));
+    for (int64_t a = 0; a < cnt; ++a) (*eq)[a] = x->eq_id[idx[a]];
+    s.eq_id = *eq;
+  }
+  if (x->scales && x->n_scale_columns > 0) {
+    const int c = x->n_scale_columns;
+    *scales = malloc(sizeof(double) * (size_t)(cnt * c + 1));
+    for (int64_t a = 0; a < cnt; ++a) memcpy(*scales + a * c, x->scales + idx[a] * c, sizeof(double) * (size_t)c);
+    s.scales = *scales;
+  }
+  return s;
+}
+
+/* compute_internal_components (sparse_gp.hpp:631-706).  group_key[i] is the grouper's value for
+ * feature i; groups are visited in ascending key order (std::map), members in ascending index
+ * order.  y is copied BEFORE the mean function is removed (:664-668), so the caller passes the
+ * raw target means. */
+static sparse_parts *sparse_components(const agp_kernel_node *prog, int n_nodes, const agp_features *x,
+                                       const int64_t *group_key, const double *y, const double *y_var,
+                                       const agp_features *u, double measurement_nugget, double inducing_nugget) {
+  const int64_t n = x->n, m = u->n;
+  sparse_parts *p = calloc(1, sizeof(sparse_parts));
+  p->n = n; p->m = m;
+  int64_t *ki = malloc(sizeof(int64_t) * 2 * (size_t)(n + 1));
+  for (int64_t i = 0; i < n; ++i) { ki[2 * i] = group_key[i]; ki[2 * i + 1] = i; }
+  qsort(ki, (size_t)n, 2 * sizeof(int64_t), cmp_key_index);
+  p->order = malloc(sizeof(int64_t) * (size_t)(n + 1));
+  p->offsets = malloc(sizeof(int64_t) * (size_t)(n + 2));
+  p->n_groups = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    p->order[i] = ki[2 * i + 1];
+    if (i == 0 || ki[2 * i] != ki[2 * (i - 1)]) p->offsets[p->n_groups++] = i;
+  }
+  p->offsets[p->n_groups] = n;
+  free(ki);
+  /* reordered measurement features, K_fu, K_uu + nugget, P = K_uu^-1/2 K_uf */
+  double *cc; int64_t *ee; double *ss;
+  agp_features xr = subset_features(x, p->order, n, 1, &cc, &ee, &ss);
+  p->y = malloc(sizeof(double) * (size_t)(n + 1));
+  for (int64_t i = 0; i < n; ++i) p->y[i] = y[p->order[i]];
+  p->K_fu = malloc(sizeof(double) * (size_t)(n * m + 1));
+  orc_gram_cross(prog, n_nodes, &xr, u, p->K_fu, n);
+  p->kuu_ldlt = malloc(sizeof(double) * (size_t)(m * m));
+  p->kuu_tr = malloc(sizeof(int64_t) * (size_t)m);
+  orc_gram_sym(prog, n_nodes, u, p->kuu_ldlt, m);
+  for (int64_t i = 0; i < m; ++i) p->kuu_ldlt[i + i * m] += inducing_nugget;
+  orc_ldlt(p->kuu_ldlt, m, m, p->kuu_tr);
+  double *P = malloc(sizeof(double) * (size_t)(m * n + 1)); /* m x n */
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < m; ++i) P[i + j * m] = p->K_fu[j + i * n];
+  ldlt_sqrt_solve(p->kuu_ldlt, m, m, p->kuu_tr, P, n, m);
+  /* A = K_ff (block diagonal, + target variance) - diag blocks of P^T P + measurement nugget */
+  p->a_ldlt = calloc((size_t)p->n_groups, sizeof(double *));
+  p->a_tr = calloc((size_t)p->n_groups, sizeof(int64_t *));
+  for (int64_t g = 0; g < p->n_groups; ++g) {
+    const int64_t o = p->offsets[g], s = p->offsets[g + 1] - o;
+    double *c2; int64_t *e2; double *s2;
+    agp_features xg = subset_features(x, p->order + o, s, 1, &c2, &e2, &s2);
+    double *A = malloc(sizeof(double) * (size_t)(s * s));
+    orc_gram_sym(prog, n_nodes, &xg, A, s);
+    for (int64_t a = 0; a < s; ++a) A[a + a * s] += y_var ? y_var[p->order[o + a]] : 0.;
+    for (int64_t b = 0; b < s; ++b)
+      for (int64_t a = 0; a < s; ++a) {
+        double q = 0.;
+        for (int64_t k = 0; k < m; ++k) q += P[k + (o + a) * m] * P[k + (o + b) * m];
+        A[a + b * s] -= q;
+      }
+    for (int64_t a = 0; a < s; ++a) A[a + a * s] += measurement_nugget;
+    p->a_tr[g] = malloc(sizeof(int64_t) * (size_t)s);
+    orc_ldlt(A, s, s, p->a_tr[g]);
+    p->a_ldlt[g] = A;
+    free(c2); free(e2); free(s2);
+  }
+  free(P); free(cc); free(ee); free(ss);
+  return p;
+}
+
+/* compute_sigma_qr (sparse_gp.hpp:343-352): B = [A^-1/2 K_fu; K_uu^T/2] */
+static orc_qr *sparse_sigma_qr(const sparse_parts *p) {
+  const int64_t n = p->n, m = p->m, rows = n + m;
+  double *B = malloc(sizeof(double) * (size_t)(rows * m));
+  for (int64_t g = 0; g < p->n_groups; ++g) {
+    const int64_t o = p->offsets[g], s = p->offsets[g + 1] - o;
+    double *blk = malloc(sizeof(double) * (size_t)(s * m));
+    for (int64_t c = 0; c < m; ++c)
+      for (int64_t a = 0; a < s; ++a) blk[a + c * s] = p->K_fu[(o + a) + c * n];
+    ldlt_sqrt_solve(p->a_ldlt[g], s, s, p->a_tr[g], blk, m, s);
+    for (int64_t c = 0; c < m; ++c)
+      for (int64_t a = 0; a < s; ++a) B[(o + a) + c * rows] = blk[a + c * s];
+    free(blk);
+  }
+  double *st = malloc(sizeof(double) * (size_t)(m * m));
+  ldlt_sqrt_transpose(p->kuu_ldlt, m, m, p->kuu_tr, st);
+  for (int64_t c = 0; c < m; ++c)
+    for (int64_t a = 0; a < m; ++a) B[(n + a) + c * rows] = st[a + c * m];
+  free(st);
+  orc_qr *q = colpiv_qr(B, rows, m);
+  free(B);
+  return q;
+}
+
+/* A_ldlt.sqrt_solve(y) / A_ldlt.solve(y), block by block */
+static void sparse_a_apply(const sparse_parts *p, const double *y, double *out, int full_solve) {
+  memcpy(out, y, sizeof(double) * (size_t)p->n);
+  for (int64_t g = 0; g < p->n_groups; ++g) {
+    const int64_t o = p->offsets[g], s = p->offsets[g + 1] - o;
+    if (full_solve) orc_ldlt_solve(p->a_ldlt[g], s, s, p->a_tr[g], out + o, 1, s);
+    else ldlt_sqrt_solve(p->a_ldlt[g], s, s, p->a_tr[g], out + o, 1, s);
+  }
+}
+
+/* log_likelihood (sparse_gp.hpp:524-596), returned as the NEGATIVE log likelihood, without priors */
+static double sparse_nll_from(const sparse_parts *p, const orc_qr *q) {
+  const int64_t n = p->n, m = p->m, rows = q->rows;
+  double log_det_a = 0.;
+  for (int64_t g = 0; g < p->n_groups; ++g) {
+    const int64_t s = p->offsets[g + 1] - p->offsets[g];
+    log_det_a += orc_ldlt_logdet(p->a_ldlt[g], s, s);
+  }
+  double log_det_r = 0.;
+  for (int64_t i = 0; i < m; ++i) log_det_r += log(fabs(q->qr[i + i * rows]));
+  const double log_det = log_det_a + 2. * log_det_r - orc_ldlt_logdet(p->kuu_ldlt, m, m);
+  double *y_a = malloc(sizeof(double) * (size_t)n), *y_b = calloc((size_t)m, sizeof(double));
+  sparse_a_apply(p, p->y, y_a, 1);
+  for (int64_t c = 0; c < m; ++c)
+    for (int64_t i = 0; i < n; ++i) y_b[c] += p->K_fu[i + c * n] * y_a[i];
+  double *R = malloc(sizeof(double) * (size_t)(m * m));
+  for (int64_t j = 0; j < m; ++j)
+    for (int64_t i = 0; i < m; ++i) R[i + j * m] = (i <= j) ? q->qr[i + j * rows] : 0.;
+  qr_sqrt_solve(R, q->perm, m, y_b, 1, m);
+  double quad = 0.;
+  for (int64_t i = 0; i < n; ++i) quad += p->y[i] * y_a[i];
+  for (int64_t i = 0; i < m; ++i) quad -= y_b[i] * y_b[i];
+  free(y_a); free(y_b); free(R);
+  return 0.5 * (log_det + quad + (double)n * log(2. * M_PI));
+}
+
+/* _fit_impl (sparse_gp.hpp:354-381) */
+ORC_API orc_sparse_fit *orc_sparse_fit_create(const agp_kernel_node *prog, int n_nodes, const agp_features *x,
+                                              const int64_t *group_key, const double *y, const double *y_var,
+                                              const agp_features *u, double measurement_nugget,
+                                              double inducing_nugget) {
+  const int64_t n = x->n, m = u->n;
+  sparse_parts *p = sparse_components(prog, n_nodes, x, group_key, y, y_var, u, measurement_nugget, inducing_nugget);
+  orc_qr *q = sparse_sigma_qr(p);
+  double *y_aug = calloc((size_t)(n + m), sizeof(double));
+  sparse_a_apply(p, p->y, y_aug, 0);
+  orc_sparse_fit *f = calloc(1, sizeof(orc_sparse_fit));
+  f->m = m;
+  f->information = malloc(sizeof(double) * (size_t)m);
+  qr_solve(q, y_aug, f->information);
+  f->R = malloc(sizeof(double) * (size_t)(m * m));
+  for (int64_t j = 0; j < m; ++j)
+    for (int64_t i = 0; i < m; ++i) f->R[i + j * m] = (i <= j) ? q->qr[i + j * q->rows] : 0.;
+  f->perm = malloc(sizeof(int64_t) * (size_t)m);
+  memcpy(f->perm, q->perm, sizeof(int64_t) * (size_t)m);
+  f->numerical_rank = q->rank;
+  f->nll = sparse_nll_from(p, q);
+  f->kuu_ldlt = p->kuu_ldlt; p->kuu_ldlt = NULL;
+  f->kuu_tr = p->kuu_tr; p->kuu_tr = NULL;
+  int64_t *all = malloc(sizeof(int64_t) * (size_t)(m + 1));
+  for (int64_t i = 0; i < m; ++i) all[i] = i;
+  f->u = subset_features(u, all, m, u->is_measurement, &f->coords_copy, &f->eq_copy, &f->scales_copy);
+  free(all); free(y_aug);
+  qr_free(q);
+  sparse_parts_free(p);
+  return f;
+}
+
+ORC_API void orc_sparse_fit_destroy(orc_sparse_fit *f) {
+  if (!f) return;
+  free(f->coords_copy); free(f->eq_copy); free(f->scales_copy);
+  free(f->kuu_ldlt); free(f->kuu_tr); free(f->R); free(f->perm); free(f->information);
+  free(f);
+}
+
+ORC_API void orc_sparse_fit_information(const orc_sparse_fit *f, double *out) {
+  memcpy(out, f->information, sizeof(double) * (size_t)f->m);
+}
+ORC_API int64_t orc_sparse_fit_rank(const orc_sparse_fit *f) { return f->numerical_rank; }
+ORC_API double orc_sparse_fit_nll(const orc_sparse_fit *f) { return f->nll; }
+
+/* _predict_impl x 3 (sparse_gp.hpp:447-521); mean function handled by the caller.
+ * variance / cov may be NULL (mean only); joint != 0 fills cov (M x M), else variance (M). */
+ORC_API void orc_sparse_predict(const orc_sparse_fit *f, const agp_kernel_node *prog, int n_nodes,
+                                const agp_features *xs, double *mean, double *variance, double *cov) {
+  const int64_t m = f->m, M = xs->n;
+  double *cross = malloc(sizeof(double) * (size_t)(m * M + 1));
+  orc_gram_cross(prog, n_nodes, &f->u, xs, cross, m);
+  for (int64_t j = 0; j < M; ++j) {
+    double s = 0.;
+    for (int64_t i = 0; i < m; ++i) s += cross[i + j * m] * f->information[i];
+    mean[j] = s;
+  }
+  if (variance || cov) {
+    double *Q = malloc(sizeof(double) * (size_t)(m * M + 1)), *S = malloc(sizeof(double) * (size_t)(m * M + 1));
+    memcpy(Q, cross, sizeof(double) * (size_t)(m * M));
+    memcpy(S, cross, sizeof(double) * (size_t)(m * M));
+    ldlt_sqrt_solve(f->kuu_ldlt, m, m, f->kuu_tr, Q, M, m); /* Q_sqrt */
+    qr_sqrt_solve(f->R, f->perm, m, S, M, m);                /* S_sqrt */
+    orc_set XS = as_set(xs);
+    if (variance)
+      for (int64_t j = 0; j < M; ++j) {
+        double qd = 0., sd = 0.;
+        for (int64_t i = 0; i < m; ++i) { qd += Q[i + j * m] * Q[i + j * m]; sd += S[i + j * m] * S[i + j * m]; }
+        variance[j] = eval_pair(prog, n_nodes, &XS, j, &XS, j) - qd + sd;
+      }
+    if (cov) {
+      orc_gram_sym(prog, n_nodes, xs, cov, M);
+      for (int64_t b = 0; b < M; ++b)
+        for (int64_t a = 0; a < M; ++a) {
+          double qd = 0., sd = 0.;
+          for (int64_t i = 0; i < m; ++i) { qd += Q[i + a * m] * Q[i + b * m]; sd += S[i + a * m] * S[i + b * m]; }
+          cov[a + b * M] += sd - qd;
+        }
+    }
+    free(Q); free(S);
+  }
+  free(cross);
+}

@@ -58,6 +58,15 @@ def lib():
         L.orc_fit_inverse_blocks.argtypes = [V, I64, V, V, V]
         L.orc_fit_held_out.restype = C.c_int
         L.orc_fit_held_out.argtypes = [V, V, I64, V, V, V, V, V]
+        L.orc_sparse_fit_create.restype = V
+        L.orc_sparse_fit_create.argtypes = [PN, C.c_int, PF, V, V, V, PF, C.c_double, C.c_double]
+        L.orc_sparse_fit_destroy.argtypes = [V]
+        L.orc_sparse_fit_information.argtypes = [V, V]
+        L.orc_sparse_fit_rank.restype = I64
+        L.orc_sparse_fit_rank.argtypes = [V]
+        L.orc_sparse_fit_nll.restype = C.c_double
+        L.orc_sparse_fit_nll.argtypes = [V]
+        L.orc_sparse_predict.argtypes = [V, PN, C.c_int, PF, V, V, V]
         L.orc_nll_dense.restype = C.c_double
         L.orc_nll_dense.argtypes = [V, V, I64, I64]
         L.orc_nll.restype = C.c_double
@@ -272,3 +281,47 @@ def nll(cov, x, y, y_var=None):
     y = np.ascontiguousarray(y, dtype=np.float64)
     yv = None if y_var is None else np.ascontiguousarray(y_var, dtype=np.float64)
     return lib().orc_nll(p, n, C.byref(fx), _ptr(y), _ptr(yv))
+
+
+class OracleSparseFit:
+    """Fit<SparseGPFit> of SparseGaussianProcessRegression::_fit_impl (models/sparse_gp.hpp:354-381) with the
+    DenseQRImplementation, restated on the CPU.  group_keys[i] = grouper(features[i]); y are the RAW
+    target means (the reference copies y before it removes the mean function, :664-668)."""
+
+    def __init__(self, cov, x, group_keys, y, y_var, u, measurement_nugget=1e-8, inducing_nugget=1e-8):
+        self.cov = cov
+        self._p, self._n = _prog(cov)
+        fx, self._kx = _feat(cov, x, False)
+        fu, self._ku = _feat(cov, u, False)
+        keys = np.ascontiguousarray(group_keys, dtype=np.int64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        yv = None if y_var is None else np.ascontiguousarray(y_var, dtype=np.float64)
+        self.m = int(fu.n)
+        self.h = lib().orc_sparse_fit_create(self._p, self._n, C.byref(fx), _ptr(keys), _ptr(y), _ptr(yv),
+                                             C.byref(fu), measurement_nugget, inducing_nugget)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_sparse_fit_destroy(self.h)
+            self.h = None
+
+    @property
+    def information(self):
+        out = np.zeros(self.m)
+        lib().orc_sparse_fit_information(self.h, _ptr(out))
+        return out
+
+    @property
+    def numerical_rank(self):
+        return int(lib().orc_sparse_fit_rank(self.h))
+
+    @property
+    def nll(self):
+        return lib().orc_sparse_fit_nll(self.h)
+
+    def predict(self, xs, xs_meas=False, joint=False):
+        f, keep = _feat(self.cov, xs, xs_meas)
+        mean, var = np.zeros(f.n), np.zeros(f.n)
+        cov = np.zeros((f.n, f.n), order="F") if joint else None
+        lib().orc_sparse_predict(self.h, self._p, self._n, C.byref(f), _ptr(mean), _ptr(var), _ptr(cov))
+        return (mean, var, cov) if joint else (mean, var)

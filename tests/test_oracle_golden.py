@@ -216,3 +216,42 @@ def test_group_held_out_equals_brute_force():
             assert np.abs(m - sol.T @ y[rest]).max() < 1e-8
             C = K[np.ix_(g, g)] - K[np.ix_(rest, g)].T @ sol
             assert np.abs(J - C).max() < 1e-8 and np.abs(v - np.diag(C)).max() < 1e-8
+
+
+def test_sparse_gp_oracle_equals_dense_formulas():
+    # models/sparse_gp.hpp:129-243 (the documented identities) and tests/test_sparse_gp.cc:172-218:
+    # the QR-based restatement equals the textbook FITC/PITC expressions evaluated densely
+    rng = np.random.default_rng(0)
+    n, m = 90, 12
+    x = np.sort(rng.uniform(0, 20, n))
+    y = np.sin(x) + 0.1 * rng.standard_normal(n) + 0.3 * x
+    yvar = rng.uniform(0.01, 0.03, n)
+    cov = ab.SquaredExponential(3., 2.) + ab.measurement_only(ab.IndependentNoise(0.2))
+    u = np.linspace(x.min(), x.max(), m)
+    keys = np.floor(x / 5.).astype(np.int64)
+    mn, inn = 1e-12, 1e-3
+    f = orc.OracleSparseFit(cov, x, keys, y, yvar, u, mn, inn)
+    Kuu = orc.gram(cov, u) + inn * np.eye(m)
+    Kfu = orc.gram(cov, x, u, x_meas=True)
+    Kff = orc.gram(cov, x, x_meas=True)
+    Q = Kfu @ np.linalg.solve(Kuu, Kfu.T)
+    K = Q.copy()
+    for k in np.unique(keys):
+        idx = np.nonzero(keys == k)[0]
+        K[np.ix_(idx, idx)] = Kff[np.ix_(idx, idx)]
+    K += np.diag(yvar) + mn * np.eye(n)
+    A = K - Q
+    nll = 0.5 * (np.linalg.slogdet(K)[1] + y @ np.linalg.solve(K, y) + n * np.log(2 * np.pi))
+    assert abs(f.nll - nll) < 1e-9 * n and f.numerical_rank == m
+    Sigma = np.linalg.inv(Kuu + Kfu.T @ np.linalg.solve(A, Kfu))
+    v = Sigma @ Kfu.T @ np.linalg.solve(A, y)
+    assert np.abs(f.information - v).max() < 1e-9 * np.abs(v).max()
+    xs = np.linspace(0.01, 19.9, 11)
+    Ksu = orc.gram(cov, xs, u, x_meas=True)
+    C = orc.gram(cov, xs, x_meas=True) - Ksu @ np.linalg.solve(Kuu, Ksu.T) + Ksu @ Sigma @ Ksu.T
+    mean, var, J = f.predict(xs, xs_meas=True, joint=True)
+    assert np.abs(mean - Ksu @ v).max() < 1e-9 and np.abs(J - C).max() < 1e-10 and np.abs(var - np.diag(C)).max() < 1e-10
+    # shuffled input order: the grouping / reordering is internal (reordered_inds, :645-662)
+    perm = rng.permutation(n)
+    g = orc.OracleSparseFit(cov, x[perm], keys[perm], y[perm], yvar[perm], u, mn, inn)
+    assert np.abs(g.information - f.information).max() < 1e-9 * np.abs(v).max()

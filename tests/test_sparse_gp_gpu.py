@@ -1,0 +1,149 @@
+"""GPU tests of the sparse Gaussian process: SparseGaussianProcessRegression
+fit / predict / log_likelihood (include/albatross/src/models/sparse_gp.hpp) through the C-ABI,
+against the CPU oracle's restatement (pivoted Householder QR, block LDLT) and restating
+tests/test_sparse_gp.cc:48-133 (test_sanity) and :172-218 (test_likelihood)."""
+import numpy as np
+import pytest
+
+import albatross_amd as ab
+from conftest import golden
+from oracle import oracle_py as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def interval_grouper(width):
+    return lambda f: int(np.floor(np.atleast_1d(f)[0] / width))
+
+
+def toy_linear():
+    g = golden("toy_linear.json")  # make_toy_linear_data(), tests/lib/albatross/test/test_utils.h:42-60
+    return np.array(g["x"]), np.array(g["y"])
+
+
+def simple_cov(length_scale):
+    # make_simple_covariance_function(): SE(100, 100) + measurement_only(IndependentNoise(0.1)), test_models.h:26-30
+    return ab.SquaredExponential(length_scale, 100.0) + ab.measurement_only(ab.IndependentNoise(0.1))
+
+
+@pytest.mark.parametrize("n,m,width,dim", [(60, 7, 5.0, 1), (400, 40, 2.5, 1), (900, 130, 1.7, 3)])
+def test_sparse_fit_and_predict_match_oracle(ctx, n, m, width, dim):
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0., 20., (n, dim)) if dim > 1 else rng.uniform(0., 20., n)
+    col = x[:, 0] if dim > 1 else x
+    y = np.sin(col) + 0.3 * col + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.04, n)
+    cov = ab.Matern52(4.0, 2.0) + ab.measurement_only(ab.IndependentNoise(0.2))
+    u = rng.uniform(0., 20., (m, dim)) if dim > 1 else np.linspace(0., 20., m)
+    grouper = interval_grouper(width)
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "sparse", context=ctx)
+    model.set_param("inducing_nugget", 1e-6)
+    model.set_param("measurement_nugget", 1e-10)
+    ds = ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar))
+    fm = model.fit(ds)
+    keys = np.array([grouper(f) for f in x])
+    ofit = orc.OracleSparseFit(cov, x, keys, y, yvar, u, 1e-10, 1e-6)
+    v = ofit.information
+    assert np.abs(fm.get_fit().information - v).max() <= 1e-7 * np.abs(v).max()
+    assert abs(fm.get_fit().nll - ofit.nll) <= 1e-8 * n
+    assert abs(model.log_likelihood(ds) + ofit.nll) <= 1e-8 * n
+    xs = rng.uniform(0., 20., (37, dim)) if dim > 1 else np.linspace(0.01, 19.9, 37)
+    om, ov, oj = ofit.predict(xs, xs_meas=True, joint=True)
+    scale = max(1., np.abs(om).max())
+    pred = fm.predict_with_measurement_noise(xs)
+    assert np.abs(pred.mean() - om).max() <= 1e-8 * scale
+    marg, joint = pred.marginal(), pred.joint()
+    assert np.abs(marg.mean - om).max() <= 1e-8 * scale and np.abs(marg.covariance - ov).max() <= 1e-8 * ov.max()
+    assert np.abs(joint.covariance - oj).max() <= 1e-8 * np.abs(oj).max()
+    assert np.abs(joint.covariance - joint.covariance.T).max() == 0.
+    # latent prediction (no measurement wrapper): the measurement-only noise drops out of K_**
+    lm, lv = ofit.predict(xs, xs_meas=False)
+    lat = fm.predict(xs).marginal()
+    assert np.abs(lat.covariance - lv).max() <= 1e-8 * ov.max() and np.abs(lat.mean - lm).max() <= 1e-8 * scale
+
+
+@pytest.mark.parametrize("length_scale,sparse_thr,really_sparse_thr", [(1000., 1e-2, 0.5), (100., 1e-2, 0.5),
+                                                                        (10., 5e-2, 100.)])
+def test_sanity_against_direct_gp(ctx, length_scale, sparse_thr, really_sparse_thr):
+    """tests/test_sparse_gp.cc:48-133: 8 uniformly spaced inducing points track the direct GP, 3 do worse."""
+    x, y = toy_linear()
+    cov = simple_cov(length_scale)
+    ds = ab.RegressionDataset(x, y)
+    grouper = interval_grouper(5.0)  # LeaveOneIntervalOut / get_group, :22-29
+    direct = ab.gp_from_covariance(cov, context=ctx).fit(ds)
+    xs = np.linspace(0.01, 9.9, 11)
+    dp = direct.predict_with_measurement_noise(xs).joint()
+    errs = []
+    for num in (8, 3):
+        sp = ab.sparse_gp_from_covariance(cov, grouper, ab.UniformlySpacedInducingPoints(num), "sparse", context=ctx)
+        sp.set_param_value("inducing_nugget", 1e-3)
+        sp.set_param_value("measurement_nugget", 1e-12)
+        p = sp.fit(ds).predict_with_measurement_noise(xs).joint()
+        errs.append((np.linalg.norm(p.mean - dp.mean), np.linalg.norm(p.covariance - dp.covariance)))
+    (sparse_err, sparse_cov), (really_err, really_cov) = errs
+    assert sparse_err < sparse_thr and really_err < really_sparse_thr
+    assert really_err > sparse_err - 1e-4
+    assert sparse_cov < sparse_thr and really_cov < really_sparse_thr and really_cov > sparse_cov
+
+
+def test_likelihood_equals_dense_equivalent(ctx):
+    """tests/test_sparse_gp.cc:172-218: the sparse log likelihood is the dense one of K = Q_ff with the
+    group blocks replaced by K_ff (+ noise + nuggets); reference tolerance 1e-2 absolute, here 1e-9
+    relative (the value is ~ -6.8e3 and the 2 x 2 K_uu has a condition number of 1e12)."""
+    n = 12
+    x = np.arange(n, dtype=float)
+    rng = np.random.default_rng(3)
+    y = 5. * np.sin(x * 10.) + 0.1 * rng.standard_normal(n)  # make_toy_sine_data(5, 10, 0.1, 12) shape
+    cov = simple_cov(100.)
+    grouper = interval_grouper(5.0)
+    strategy = ab.UniformlySpacedInducingPoints(2)
+    sparse = ab.sparse_gp_from_covariance(cov, grouper, strategy, "sparse", context=ctx)
+    u = strategy(cov, x)
+    K_uu = ctx.gram(cov, u) + sparse.get_params()["inducing_nugget"] * np.eye(2)
+    K_fu = ctx.gram(cov, ab.Measurement(x), u)
+    K = K_fu @ np.linalg.solve(K_uu, K_fu.T)
+    K_ff = ctx.gram(cov, ab.Measurement(x))
+    keys = np.array([grouper(f) for f in x])
+    for key in np.unique(keys):
+        idx = np.nonzero(keys == key)[0]
+        K[np.ix_(idx, idx)] = K_ff[np.ix_(idx, idx)]
+    K[np.diag_indices(n)] += sparse.get_params()["measurement_nugget"]
+    expected = -ab.negative_log_likelihood(y, K, context=ctx)
+    assert abs(sparse.log_likelihood(ab.RegressionDataset(x, y)) - expected) <= 1e-9 * abs(expected)
+
+
+def test_inducing_points_on_the_data_recover_the_dense_gp(ctx):
+    """Property at a size the oracle does not reach: with u = the training points the FITC/PITC
+    posterior is the exact GP posterior (Q_ff = K_ff up to the nuggets)."""
+    n = 3000
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0., 10., (n, 3))
+    y = np.sin(x).sum(axis=1) + 0.1 * rng.standard_normal(n)
+    cov = ab.SquaredExponential(2.0, 1.0) + ab.measurement_only(ab.IndependentNoise(0.3))
+    ds = ab.RegressionDataset(x, y)
+    dense = ab.gp_from_covariance(cov, context=ctx).fit(ds)
+    sparse = ab.sparse_gp_from_covariance(cov, interval_grouper(1.0), ab.FixedInducingPoints(x), "sparse", context=ctx)
+    sparse.set_param("inducing_nugget", 1e-9)
+    sparse.set_param("measurement_nugget", 1e-9)
+    fm = sparse.fit(ds)
+    xs = rng.uniform(0., 10., (200, 3))
+    d, s = dense.predict(xs).marginal(), fm.predict(xs).marginal()
+    assert np.abs(d.mean - s.mean).max() <= 1e-5 and np.abs(d.covariance - s.covariance).max() <= 1e-5
+    assert abs(sparse.log_likelihood(ds) - ab.gp_from_covariance(cov, context=ctx).log_likelihood(ds)) <= 1e-4 * n
+
+
+def test_sparse_error_paths(ctx):
+    x, y = toy_linear()
+    cov = simple_cov(100.)
+    with pytest.raises(ValueError):
+        ab.sparse_gp_from_covariance(cov, None, None)
+    dup = ab.sparse_gp_from_covariance(cov, interval_grouper(5.0), ab.FixedInducingPoints(np.array([1.0, 1.0, 2.0])),
+                                       "dup", context=ctx)
+    dup.set_param("inducing_nugget", 0.0)
+    with pytest.raises(ab.NotPositiveDefiniteError):  # singular K_uu: reported, not silently factored
+        dup.fit(ab.RegressionDataset(x, y))
+    bad = ab.sparse_gp_from_covariance(cov, interval_grouper(5.0), ab.UniformlySpacedInducingPoints(4), context=ctx)
+    yn = y.copy()
+    with pytest.raises(KeyError):
+        bad.set_param("no_such_parameter", 1.0)
+    assert np.isfinite(bad.log_likelihood(ab.RegressionDataset(x, yn)))
