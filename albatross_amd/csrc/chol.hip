@@ -48,6 +48,8 @@ struct PotrfArgs {
   double *y;        // y + k0 or nullptr
   int *flags;
   double *scalars;
+  // batched launches (blockIdx.y = batch entry): element offsets per entry; all 0 = not batched
+  long long batch_A = 0, batch_img = 0, batch_y = 0, batch_scalars = 0;
 };
 
 constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
@@ -263,6 +265,13 @@ __device__ __forceinline__ void micro_syrk_tile2(double *T, int ib0, int kb0, in
 __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
   // serial panel chain: issue ahead of the bulk-update waves that share this CU
   __builtin_amdgcn_s_setprio(3);
+  {
+    const long long b = blockIdx.y;
+    p.A += b * p.batch_A;
+    p.img += b * p.batch_img;
+    if (p.y) p.y += b * p.batch_y;
+    p.scalars += b * p.batch_scalars;
+  }
   __shared__ double T[IMG_DOUBLES + 2 * MB * MB + NB];  // tiles | two inverse buffers | y
   double *Wc = T + IMG_DOUBLES;
   double *ys = Wc + 2 * MB * MB;
@@ -425,6 +434,7 @@ struct TrsmArgs {
   // batched launches (blockIdx.y = diagonal block index): element strides
   long long batch_img, batch_Y;
   long long n_total;  // matrix size, to derive nbk per batch entry (0: use nbk)
+  long long batch_z = 0;  // FUSE_Y: offset of z / yrest per batch entry
 };
 
 template <bool TRANS, bool FUSE_Y>
@@ -438,6 +448,10 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
     const long long b = blockIdx.y;
     p.img += b * p.batch_img;
     p.Y += b * p.batch_Y;
+    if (FUSE_Y) {
+      p.z += b * p.batch_z;
+      p.yrest += b * p.batch_z;
+    }
     if (p.n_total > 0) {
       const long long left = p.n_total - b * NB;
       p.nbk = (int)(left < NB ? left : NB);
@@ -725,6 +739,67 @@ void forward_solve_mat(hipStream_t s, const double *A, long long n, long long ld
       launch_gemm_nt_sub(s, B + kend, ldb, A + K0 * lda + kend, lda, false, B + K0, ldb, true, n - kend, m_act,
                          kend - K0, false);
     }
+  }
+}
+
+// `count` independent n x n factorisations in lock step (blockIdx.y = problem): the blocks of a sparse
+// GP's A.  Problem b lives at A + b * stride_A (leading dimension lda), its tile images at
+// invd + b * stride_invd, its right-hand side (optional, fused forward substitution) at y + b * stride_y;
+// logsum[b] receives sum log L_ii.  No look-ahead: every step is three launches for all problems.
+void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long long n, long long lda, double *invd,
+                          long long stride_invd, double *y, long long stride_y, long long count, int *flags,
+                          double *logsum) {
+  if (count <= 0 || n <= 0) return;
+  for (long long k = 0; k < n; k += NB) {
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    PotrfArgs p;
+    p.A = A; p.lda = lda; p.k0 = k; p.nbk = nbk;
+    p.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+    p.y = y ? y + k : nullptr;
+    p.flags = flags; p.scalars = logsum;
+    p.batch_A = stride_A; p.batch_img = stride_invd; p.batch_y = stride_y; p.batch_scalars = 1;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)count), dim3(256), 0, s, p);
+    const long long below = n - (k + nbk);
+    if (below <= 0) continue;
+    TrsmArgs t;
+    t.img = p.img;
+    t.nbk = nbk;
+    t.Y = A + k * lda + (k + nbk);
+    t.stride_m = lda; t.stride_n = 1;
+    t.ncols = below;
+    t.z = y ? y + k : nullptr;
+    t.yrest = y ? y + k + nbk : nullptr;
+    t.batch_img = stride_invd; t.batch_Y = stride_A; t.n_total = 0; t.batch_z = stride_y;
+    const dim3 grid((unsigned)((below + 63) / 64), (unsigned)count);
+    if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), grid, dim3(256), 0, s, t);
+    else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), grid, dim3(256), 0, s, t);
+    const double *P = A + k * lda + (k + nbk);
+    launch_gemm_nt_sub_batched(s, A + (k + nbk) * lda + (k + nbk), lda, stride_A, P, lda, false, stride_A, P, lda, false,
+                               stride_A, below, below, nbk, true, count);
+  }
+}
+
+// X_b (nrows x n, ldx) <- X_b L_b^-T for `count` problems: X_b = X + b * stride_X, L_b = A + b * stride_A
+void right_solve_lt_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
+                            const double *invd, long long stride_invd, double *X, long long stride_X, long long nrows,
+                            long long ldx, long long count) {
+  if (nrows <= 0 || count <= 0) return;
+  for (long long k = 0; k < n; k += NB) {
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    TrsmArgs t;
+    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+    t.nbk = nbk;
+    t.Y = X + k * ldx;
+    t.stride_m = ldx; t.stride_n = 1;
+    t.ncols = nrows;
+    t.z = nullptr; t.yrest = nullptr;
+    t.batch_img = stride_invd; t.batch_Y = stride_X; t.n_total = 0;
+    hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((nrows + 63) / 64), (unsigned)count), dim3(256), 0,
+                       s, t);
+    const long long rest = n - (k + nbk);
+    if (rest > 0)
+      launch_gemm_nt_sub_batched(s, X + (k + nbk) * ldx, ldx, stride_X, X + k * ldx, ldx, false, stride_X,
+                                 A + k * lda + (k + nbk), lda, false, stride_A, nrows, rest, nbk, false, count);
   }
 }
 

@@ -134,6 +134,16 @@ void backward_solve_vec(hipStream_t s, const double *A, long long n, long long l
 void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                        double *B, long long m, long long ldb, bool rhs_lower = false);
 // B (n x m, ldb) <- L^-T B
+void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long long n, long long lda, double *invd,
+                          long long stride_invd, double *y, long long stride_y, long long count, int *flags,
+                          double *logsum);
+void right_solve_lt_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
+                            const double *invd, long long stride_invd, double *X, long long stride_X, long long nrows,
+                            long long ldx, long long count);
+void launch_gemm_nt_sub_batched(hipStream_t s, double *C, long long ldc, long long batch_C, const double *A,
+                                long long lda, bool a_kmajor, long long batch_A, const double *B, long long ldb,
+                                bool b_kmajor, long long batch_B, long long M, long long N, long long K, bool tri,
+                                long long count);
 void right_solve_lt(hipStream_t s, const double *A, long long n, long long lda, const double *invd, double *X,
                     long long nrows, long long ldx);
 void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,

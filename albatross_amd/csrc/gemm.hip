@@ -44,6 +44,8 @@ struct GemmArgs {
   // 8 x 8 super-tile of C, so they share 8 row strips and 8 column strips of
   // the panel in that XCD's L2.  nsuper = number of lower super-tiles.
   int remap, nsuper, nb8;
+  // batched launches (blockIdx.y = batch entry): element offsets per entry; 0 = not batched
+  long long batch_C = 0, batch_A = 0, batch_B = 0;
 };
 
 // Load this thread's 8 doubles of a 128 x 16 operand chunk.
@@ -239,6 +241,9 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g) {
   __builtin_amdgcn_s_setprio(3);  // everything but the bulk update (its own kernel below)
+  g.C += (long long)blockIdx.y * g.batch_C;
+  g.A += (long long)blockIdx.y * g.batch_A;
+  g.B += (long long)blockIdx.y * g.batch_B;
   // one LDS array: [buffer][operand][k][row]
   __shared__ double lds[2 * 2 * GK * GLD];
   gemm_nt_sub_body<A_KMAJOR, B_KMAJOR>(g, lds);
@@ -461,6 +466,9 @@ __device__ __forceinline__ void store_chunk64(double *__restrict__ Ls, const dou
 
 __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs g) {
   __builtin_amdgcn_s_setprio(3);  // panel-chain updates: issue ahead of co-resident bulk-update waves
+  g.C += (long long)blockIdx.y * g.batch_C;
+  g.A += (long long)blockIdx.y * g.batch_A;
+  g.B += (long long)blockIdx.y * g.batch_B;
   __shared__ double lds[2 * 2 * GK * SLD];
   int bj = 0;
   long long id = blockIdx.x;
@@ -561,14 +569,17 @@ static long long count_tiles(int ntr, int ntc, int tri) {
 }
 
 // C(M x N) -= A(M x K) * B(N x K)^T ; tri != 0 keeps only tiles on/below the diagonal.
-void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
-                        bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
-                        long long N, long long K, bool tri) {
-  if (M <= 0 || N <= 0 || K <= 0) return;
+// count > 1: the same product for `count` independent problems whose operands are batch_* elements apart.
+void launch_gemm_nt_sub_batched(hipStream_t s, double *C, long long ldc, long long batch_C, const double *A,
+                                long long lda, bool a_kmajor, long long batch_A, const double *B, long long ldb,
+                                bool b_kmajor, long long batch_B, long long M, long long N, long long K, bool tri,
+                                long long count) {
+  if (M <= 0 || N <= 0 || K <= 0 || count <= 0) return;
   GemmArgs g;
   g.C = C; g.ldc = ldc; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
   g.M = M; g.N = N; g.K = K; g.tri = tri ? 1 : 0;
   g.remap = 0; g.nsuper = 0; g.nb8 = 0;
+  g.batch_C = batch_C; g.batch_A = batch_A; g.batch_B = batch_B;
   g.ntr = (int)((M + GT - 1) / GT);
   g.ntc = (int)((N + GT - 1) / GT);
   if (tri && g.ntc > g.ntr) g.ntc = g.ntr;
@@ -580,20 +591,26 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
     const char *e = getenv("AGP_SMALL_TILE_LIMIT");
     small_limit = e ? atoi(e) : 512;
   }
-  if (!a_kmajor && !b_kmajor && tiles < small_limit) {
+  if (!a_kmajor && !b_kmajor && tiles * count < small_limit) {
     GemmArgs h = g;
     h.ntr = (int)((M + ST - 1) / ST);
     h.ntc = (int)((N + ST - 1) / ST);
     if (tri && h.ntc > h.ntr) h.ntc = h.ntr;
     const long long t64 = count_tiles(h.ntr, h.ntc, h.tri);
-    hipLaunchKernelGGL(gemm64_nt_sub_kernel, dim3((unsigned)t64), dim3(GEMM_THREADS), 0, s, h);
+    hipLaunchKernelGGL(gemm64_nt_sub_kernel, dim3((unsigned)t64, (unsigned)count), dim3(GEMM_THREADS), 0, s, h);
     return;
   }
-  dim3 grid((unsigned)tiles), block(GEMM_THREADS);
+  dim3 grid((unsigned)tiles, (unsigned)count), block(GEMM_THREADS);
   if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<false, false>), grid, block, 0, s, g);
   else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<false, true>), grid, block, 0, s, g);
   else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<true, false>), grid, block, 0, s, g);
   else hipLaunchKernelGGL((gemm_nt_sub_kernel<true, true>), grid, block, 0, s, g);
+}
+
+void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
+                        bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
+                        long long N, long long K, bool tri) {
+  launch_gemm_nt_sub_batched(s, C, ldc, 0, A, lda, a_kmajor, 0, B, ldb, b_kmajor, 0, M, N, K, tri, 1);
 }
 
 // variant 0: MFMA kernel, 2: DPP-broadcast VALU kernel (experiment)

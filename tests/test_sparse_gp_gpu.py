@@ -62,6 +62,33 @@ def test_sparse_fit_and_predict_match_oracle(ctx, n, m, width, dim):
     assert np.abs(lat.covariance - lv).max() <= 1e-8 * ov.max() and np.abs(lat.mean - lm).max() <= 1e-8 * scale
 
 
+@pytest.mark.parametrize("n,gs,m", [(512, 128, 30), (900, 300, 64), (1200, 150, 100)])
+def test_uniform_groups_batched_path_matches_oracle(ctx, n, gs, m):
+    """Equal group sizes take the batched (lock-step) block path; ragged ones the per-block path above."""
+    rng = np.random.default_rng(n + gs)
+    x = np.sort(rng.uniform(0., 30., n))
+    y = np.sin(x) + 0.2 * x + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.04, n)
+    cov = ab.SquaredExponential(2.5, 1.5) + ab.measurement_only(ab.IndependentNoise(0.2))
+    u = np.linspace(0., 30., m)
+    rank = {float(v): i for i, v in enumerate(x)}
+    grouper = lambda f: rank[float(f)] // gs
+    perm = rng.permutation(n)  # the caller's order is arbitrary: the mirror regroups
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "sparse", context=ctx)
+    model.set_param("inducing_nugget", 1e-6)
+    fm = model.fit(ab.RegressionDataset(x[perm], ab.MarginalDistribution(y[perm], yvar[perm])))
+    keys = np.array([grouper(f) for f in x])
+    ofit = orc.OracleSparseFit(cov, x, keys, y, yvar, u, 1e-8, 1e-6)
+    v = ofit.information
+    assert np.abs(fm.get_fit().information - v).max() <= 1e-7 * np.abs(v).max()
+    assert abs(fm.get_fit().nll - ofit.nll) <= 1e-8 * n
+    xs = np.linspace(0.5, 29.5, 40)
+    om, ov, oj = ofit.predict(xs, xs_meas=True, joint=True)
+    j = fm.predict_with_measurement_noise(xs).joint()
+    assert np.abs(j.mean - om).max() <= 1e-8 * max(1., np.abs(om).max())
+    assert np.abs(j.covariance - oj).max() <= 1e-8 * np.abs(oj).max()
+
+
 @pytest.mark.parametrize("length_scale,sparse_thr,really_sparse_thr", [(1000., 1e-2, 0.5), (100., 1e-2, 0.5),
                                                                         (10., 5e-2, 100.)])
 def test_sanity_against_direct_gp(ctx, length_scale, sparse_thr, really_sparse_thr):
