@@ -976,7 +976,7 @@ int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double 
 // the factor is repaired the CholeskyQR2 way: Q1^T = L1^-1 B^T is formed explicitly (one more
 // triangular solve over all n columns), Q1^T Q1 = I + O(eps cond) is factored again (L2), and
 // B^T B = (L1 L2)(L1 L2)^T holds to working accuracy: log|R|, R^-T x and the information vector
-// (plus two refinement steps against B itself) then agree with the QR-based oracle to ~1e-9 even
+// (plus two refinement steps against B itself) then agree with the QR-based reference algorithm to ~1e-9 even
 // with cond(K_uu) ~ 1e7.  K_uu and every block of A use LL^T as well.
 struct agp_sparse_fit {
   agp_context *ctx = nullptr;
