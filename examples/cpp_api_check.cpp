@@ -141,6 +141,38 @@ int main() {
     std::printf("update_mean_diff,%.17g\n", dm);
     std::printf("update_cov_diff,%.17g\n", dc);
   }
+  // sparse GP (tests/test_sparse_gp.cc:48-133 test_sanity shape): toy linear data, LeaveOneIntervalOut groups
+  {
+    std::vector<double> tx(10);
+    Vector ty(10);
+    const double toy_y[10] = {5.01841281968535, 5.899404483909093, 6.9658019644108045, 7.995527586269562,
+                              9.027844091455382, 9.941910600141895, 10.984848510737773, 11.885256581824562,
+                              12.938899996351795, 13.881048261401078};  // make_toy_linear_data(): tests/golden/toy_linear.json
+    for (int i = 0; i < 10; ++i) { tx[i] = i; ty[i] = toy_y[i]; }
+    auto scov = SquaredExponential<EuclideanDistance>(100., 100.) + measurement_only(IndependentNoise<double>(0.1));
+    const auto grouper = [](const double &f) { return static_cast<long>(std::floor(f / 5.)); };
+    auto sparse = sparse_gp_from_covariance(scov, grouper, UniformlySpacedInducingPoints(8), "sparse");
+    sparse.set_param_value(details::inducing_nugget_name(), 1e-3);
+    sparse.set_param_value(details::measurement_nugget_name(), 1e-12);
+    RegressionDataset<double> tds(tx, ty);
+    const auto sfit = sparse.fit(tds);
+    const auto dfit = gp_from_covariance(scov, "direct").fit(tds);
+    std::vector<double> txs(11);
+    for (int i = 0; i < 11; ++i) txs[i] = 0.01 + (9.9 - 0.01) * i / 10.;
+    const auto sp = sfit.predict_with_measurement_noise(txs).joint();
+    const auto dp = dfit.predict_with_measurement_noise(txs).joint();
+    double em = 0., ec = 0.;
+    for (int i = 0; i < 11; ++i) {
+      em += (sp.mean[i] - dp.mean[i]) * (sp.mean[i] - dp.mean[i]);
+      for (int j = 0; j < 11; ++j) ec += (sp.covariance(i, j) - dp.covariance(i, j)) * (sp.covariance(i, j) - dp.covariance(i, j));
+    }
+    std::printf("sparse_mean_err,%.17g\n", std::sqrt(em));
+    std::printf("sparse_cov_err,%.17g\n", std::sqrt(ec));
+    std::printf("sparse_loglik,%.17g\n", sparse.log_likelihood(tds));
+    for (std::size_t i = 0; i < sfit.get_fit().information.size(); ++i) std::printf("sparse_info,%zu,%.17g\n", i, sfit.get_fit().information[i]);
+    const auto sm = sfit.predict(txs).marginal();
+    for (int i = 0; i < 11; ++i) std::printf("sparse_pred,%d,%.17g,%.17g,%.17g\n", i, sfit.predict(txs).mean()[i], sm.mean[i], sm.covariance[i]);
+  }
   // a singular covariance is reported, not silently factored
   try {
     std::vector<double> dup = {0., 0., 1.};

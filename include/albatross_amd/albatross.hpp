@@ -1142,6 +1142,227 @@ GaussianProcessRegression<CovFunc, MeanFunc> gp_from_covariance_and_mean(
   return GaussianProcessRegression<CovFunc, MeanFunc>(cov, mean, name);
 }
 
+// ---------------------------------------------------------------------------
+// SparseGaussianProcessRegression (models/sparse_gp.hpp:245-797): FITC / PITC.
+// Grouping, reordering and the inducing-point strategy are host bookkeeping exactly as in
+// compute_internal_components (:631-706); K_uu, K_fu, the blocks of A, Sigma and every prediction
+// run on the device (agp_sparse_*).
+// ---------------------------------------------------------------------------
+namespace details {
+constexpr double DEFAULT_NUGGET = 1e-8;  // :22
+inline std::string measurement_nugget_name() { return "measurement_nugget"; }
+inline std::string inducing_nugget_name() { return "inducing_nugget"; }
+}  // namespace details
+
+struct UniformlySpacedInducingPoints {  // :36-49
+  explicit UniformlySpacedInducingPoints(std::size_t num_points_ = 10) : num_points(num_points_) {}
+  template <typename CovarianceFunction>
+  std::vector<double> operator()(const CovarianceFunction &, const std::vector<double> &features) const {
+    double lo = features.at(0), hi = features.at(0);
+    for (double f : features) { lo = f < lo ? f : lo; hi = f > hi ? f : hi; }
+    std::vector<double> out(num_points);
+    for (std::size_t i = 0; i < num_points; ++i)  // linspace(min, max, num_points)
+      out[i] = num_points > 1 ? lo + (hi - lo) * static_cast<double>(i) / static_cast<double>(num_points - 1) : lo;
+    return out;
+  }
+  std::size_t num_points;
+};
+
+// Fit<SparseGPFit<InducingFeature>> (:92-124)
+template <typename InducingFeature>
+struct SparseGPFit {
+  std::vector<InducingFeature> train_features;  // the inducing points
+  Vector information;
+  double negative_log_likelihood = 0.;
+  std::shared_ptr<agp_sparse_fit> handle;
+  std::shared_ptr<detail::ContextHolder> context;
+};
+
+template <typename ModelType, typename InducingFeature>
+class SparseFitModel;
+
+template <typename ModelType, typename InducingFeature, typename PredictFeature>
+class SparsePrediction {
+ public:
+  SparsePrediction(const SparseFitModel<ModelType, InducingFeature> *fm, std::vector<PredictFeature> features)
+      : fm_(fm), features_(std::move(features)) {}
+  Vector mean() const { return fm_->predict_(features_, 0).mean; }
+  MarginalDistribution marginal() const { return fm_->predict_(features_, 1).marginal(); }
+  JointDistribution joint() const { return fm_->predict_(features_, 2); }
+
+ private:
+  const SparseFitModel<ModelType, InducingFeature> *fm_;
+  std::vector<PredictFeature> features_;
+};
+
+template <typename ModelType, typename InducingFeature>
+class SparseFitModel {
+ public:
+  SparseFitModel(const ModelType &model, SparseGPFit<InducingFeature> fit) : model_(model), fit_(std::move(fit)) {}
+  const SparseGPFit<InducingFeature> &get_fit() const { return fit_; }
+  const ModelType &get_model() const { return model_; }
+
+  template <typename P>
+  SparsePrediction<ModelType, InducingFeature, P> predict(const std::vector<P> &features) const {
+    return SparsePrediction<ModelType, InducingFeature, P>(this, features);
+  }
+  template <typename P>
+  SparsePrediction<ModelType, InducingFeature, Measurement<P>> predict_with_measurement_noise(
+      const std::vector<P> &features) const {
+    return SparsePrediction<ModelType, InducingFeature, Measurement<P>>(this, as_measurements(features));
+  }
+
+  // _predict_impl x 3 (:447-521); mode 0: mean, 1: marginal (diagonal filled), 2: joint
+  template <typename P>
+  JointDistribution predict_(const std::vector<P> &xs, int mode) const {
+    detail::KernelHolder k(model_.get_covariance().program());
+    detail::Flat f = detail::flatten(model_.get_covariance(), xs);
+    JointDistribution out;
+    out.mean.resize(xs.size());
+    agp_context *c = fit_.context->ctx;
+    if (xs.empty()) return out;
+    if (mode == 0) {
+      detail::check(agp_sparse_predict_mean(c, k.k, fit_.handle.get(), &f.view, out.mean.data(), AGP_HOST), c,
+                    "agp_sparse_predict_mean");
+    } else if (mode == 1) {
+      Vector var(xs.size());
+      detail::check(agp_sparse_predict_marginal(c, k.k, fit_.handle.get(), &f.view, out.mean.data(), var.data(), AGP_HOST), c,
+                    "agp_sparse_predict_marginal");
+      out.covariance = Matrix(static_cast<std::int64_t>(xs.size()), static_cast<std::int64_t>(xs.size()));
+      for (std::size_t i = 0; i < xs.size(); ++i) out.covariance(static_cast<std::int64_t>(i), static_cast<std::int64_t>(i)) = var[i];
+    } else {
+      out.covariance = Matrix(static_cast<std::int64_t>(xs.size()), static_cast<std::int64_t>(xs.size()));
+      detail::check(agp_sparse_predict_joint(c, k.k, fit_.handle.get(), &f.view, out.mean.data(), out.covariance.data.data(),
+                                             AGP_HOST),
+                    c, "agp_sparse_predict_joint");
+    }
+    model_.add_mean(xs, &out.mean);  // mean_function_.add_to (:457,473,516)
+    return out;
+  }
+
+ private:
+  ModelType model_;
+  SparseGPFit<InducingFeature> fit_;
+};
+
+template <typename CovFunc, typename MeanFunc, typename GrouperFunction, typename InducingPointStrategy>
+class SparseGaussianProcessRegression {
+ public:
+  SparseGaussianProcessRegression() = default;
+  SparseGaussianProcessRegression(const CovFunc &cov, const MeanFunc &mean, const GrouperFunction &grouper,
+                                  const InducingPointStrategy &strategy, const std::string &name)
+      : covariance_function_(cov), mean_function_(mean), independent_group_function_(grouper),
+        inducing_point_strategy_(strategy), model_name_(name) {}
+
+  std::string get_name() const { return model_name_; }
+  const CovFunc &get_covariance() const { return covariance_function_; }
+  InducingPointStrategy get_inducing_point_strategy() const { return inducing_point_strategy_; }
+  GrouperFunction get_grouper_function() const { return independent_group_function_; }
+
+  ParameterStore get_params() const {  // :300-306
+    ParameterStore p = mean_function_.get_params();
+    for (const auto &kv : covariance_function_.get_params()) p[kv.first] = kv.second;
+    p[details::measurement_nugget_name()] = measurement_nugget_;
+    p[details::inducing_nugget_name()] = inducing_nugget_;
+    return p;
+  }
+  void set_param(const std::string &n, double v) {  // :308-320
+    if (n == details::measurement_nugget_name()) measurement_nugget_ = v;
+    else if (n == details::inducing_nugget_name()) inducing_nugget_ = v;
+    else if (covariance_function_.has_param(n)) covariance_function_.set_param(n, v);
+    else if (mean_function_.has_param(n)) mean_function_.set_param(n, v);
+    else throw std::out_of_range("unknown parameter " + n);
+  }
+  void set_param_value(const std::string &n, double v) { set_param(n, v); }
+
+  template <typename P>
+  void add_mean(const std::vector<P> &xs, Vector *mean) const {
+    if (std::is_same<MeanFunc, ZeroMean>::value) return;
+    for (std::size_t i = 0; i < xs.size(); ++i) (*mean)[i] += mean_function_._call_impl(detail::unwrap<P>::get(xs[i]));
+  }
+
+  // _fit_impl (:354-381)
+  template <typename FeatureType>
+  auto fit(const RegressionDataset<FeatureType> &dataset) const {
+    using U = typename std::decay<decltype(inducing_point_strategy_(covariance_function_, dataset.features)[0])>::type;
+    SparseGPFit<U> fit;
+    run(dataset, &fit, true);
+    return SparseFitModel<SparseGaussianProcessRegression, U>(*this, std::move(fit));
+  }
+
+  // :524-596 (prior_log_likelihood() is outside the hot path and not included)
+  template <typename FeatureType>
+  double log_likelihood(const RegressionDataset<FeatureType> &dataset) const {
+    using U = typename std::decay<decltype(inducing_point_strategy_(covariance_function_, dataset.features)[0])>::type;
+    SparseGPFit<U> fit;
+    run(dataset, &fit, false);
+    return -fit.negative_log_likelihood;
+  }
+
+ private:
+  // the host half of compute_internal_components (:642-668) + the device call
+  template <typename FeatureType, typename U>
+  void run(const RegressionDataset<FeatureType> &dataset, SparseGPFit<U> *fit, bool keep) const {
+    const std::size_t n = dataset.features.size();
+    if (n != dataset.targets.size()) throw std::invalid_argument("features and targets differ in size");
+    using Key = typename std::decay<decltype(independent_group_function_(dataset.features[0]))>::type;
+    std::map<Key, std::vector<std::size_t>> indexer;  // group_by(features, grouper).indexers()
+    for (std::size_t i = 0; i < n; ++i) indexer[independent_group_function_(dataset.features[i])].push_back(i);
+    std::vector<std::size_t> reordered_inds;
+    std::vector<std::int64_t> offsets(1, 0);
+    for (const auto &kv : indexer) {
+      reordered_inds.insert(reordered_inds.end(), kv.second.begin(), kv.second.end());
+      offsets.push_back(static_cast<std::int64_t>(reordered_inds.size()));
+    }
+    std::vector<FeatureType> features(n);
+    Vector y(n), yv;
+    const bool has_var = !dataset.targets.covariance.empty();
+    if (has_var) yv.resize(n);
+    for (std::size_t a = 0; a < n; ++a) {
+      features[a] = dataset.features[reordered_inds[a]];
+      y[a] = dataset.targets.mean[reordered_inds[a]];  // y is copied BEFORE the mean function is removed (:664-668)
+      if (has_var) yv[a] = dataset.targets.covariance[reordered_inds[a]];
+    }
+    fit->train_features = inducing_point_strategy_(covariance_function_, dataset.features);
+    if (fit->train_features.empty()) throw std::invalid_argument("Empty inducing points!");  // :361
+    fit->context = detail::default_context();
+    agp_context *c = fit->context->ctx;
+    detail::KernelHolder k(covariance_function_.program());
+    detail::Flat fx = detail::flatten(covariance_function_, features);
+    detail::Flat fu = detail::flatten(covariance_function_, fit->train_features);
+    fit->information.resize(fit->train_features.size());
+    agp_sparse_fit *h = nullptr;
+    detail::check(agp_sparse_fit_create(c, k.k, &fx.view, static_cast<std::int64_t>(offsets.size() - 1), offsets.data(), y.data(),
+                                        has_var ? yv.data() : nullptr, &fu.view, measurement_nugget_, inducing_nugget_,
+                                        keep ? &h : nullptr, fit->information.data(), &fit->negative_log_likelihood),
+                  c, "agp_sparse_fit_create");
+    auto ctx = fit->context;
+    if (keep) fit->handle = std::shared_ptr<agp_sparse_fit>(h, [ctx](agp_sparse_fit *p) { agp_sparse_fit_destroy(p); });
+  }
+
+  CovFunc covariance_function_;
+  MeanFunc mean_function_;
+  GrouperFunction independent_group_function_;
+  InducingPointStrategy inducing_point_strategy_;
+  std::string model_name_ = "sparse_gaussian_process_regression";
+  double measurement_nugget_ = details::DEFAULT_NUGGET;  // initialize_params, :292-298
+  double inducing_nugget_ = details::DEFAULT_NUGGET;
+};
+
+// factories, :740-775
+template <typename CovFunc, typename MeanFunc, typename GrouperFunction, typename InducingPointStrategy>
+auto sparse_gp_from_covariance_and_mean(const CovFunc &cov, const MeanFunc &mean, const GrouperFunction &grouper,
+                                        const InducingPointStrategy &strategy, const std::string &model_name) {
+  return SparseGaussianProcessRegression<CovFunc, MeanFunc, GrouperFunction, InducingPointStrategy>(cov, mean, grouper, strategy,
+                                                                                                   model_name);
+}
+
+template <typename CovFunc, typename GrouperFunction, typename InducingPointStrategy>
+auto sparse_gp_from_covariance(const CovFunc &cov, const GrouperFunction &grouper, const InducingPointStrategy &strategy,
+                               const std::string &model_name) {
+  return sparse_gp_from_covariance_and_mean(cov, ZeroMean(), grouper, strategy, model_name);
+}
+
 // GaussianProcessNegativeLogLikelihood, gp.hpp:542-550: the tuner's objective
 struct GaussianProcessNegativeLogLikelihood {
   template <typename FeatureType, typename CovFunc, typename MeanFunc>

@@ -14,6 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EX = os.path.join(ROOT, "examples")
 
 
+def golden_toy_y():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "toy_linear.json")) as fh:
+        return json.load(fh)["y"]
+
+
 def run(binary, *args):
     subprocess.check_call(["make", "-s", "-C", EX])
     out = subprocess.check_output([os.path.join(EX, binary), *args], text=True)
@@ -105,6 +111,22 @@ def test_cpp_api_matches_oracle():
         sel = np.array([np.nonzero(cvr[:, 0] == i)[0][0] for i in g])
         assert np.abs(cvr[sel, 2] - wm).max() <= 1e-8 * np.abs(wm).max() and np.abs(cvr[sel, 3] - wv).max() <= 1e-8
     assert float(one["cv_loo_diff"]) < 1e-9
+    # sparse GP through the C++ surface: close to the direct GP (test_sparse_gp.cc:115-133 thresholds) and
+    # equal to the oracle's QR-based restatement
+    assert float(one["sparse_mean_err"]) < 1e-2 and float(one["sparse_cov_err"]) < 1e-2
+    tx = np.arange(10.)
+    ty = np.array(golden_toy_y())
+    scov = ab.SquaredExponential(100., 100.) + ab.measurement_only(ab.IndependentNoise(0.1))
+    u8 = np.linspace(0., 9., 8)
+    so = orc.OracleSparseFit(scov, tx, np.floor(tx / 5.).astype(np.int64), ty, None, u8, 1e-12, 1e-3)
+    sinfo = np.array(rows["sparse_info"], dtype=float)[:, 1]
+    assert np.abs(sinfo - so.information).max() <= 1e-6 * np.abs(so.information).max()
+    assert abs(float(one["sparse_loglik"]) + so.nll) <= 1e-7
+    sp = np.array(rows["sparse_pred"], dtype=float)
+    txs = 0.01 + (9.9 - 0.01) * np.arange(11) / 10.
+    smean, svar = so.predict(txs)
+    assert np.abs(sp[:, 1] - smean).max() <= 1e-7 and np.abs(sp[:, 2] - smean).max() <= 1e-7
+    assert np.abs(sp[:, 3] - svar).max() <= 1e-7
     assert abs(float(one["mvn_nll"]) - 6.0946974293510134) < 1e-12  # tests/test_evaluate.cc:26,41
     assert abs(float(one["mvn_logdet"]) - np.linalg.slogdet(np.array([[1, .9, .8], [.9, 1, .9], [.8, .9, 1.]]))[1]) < 1e-13
     assert float(one["update_mean_diff"]) < 1e-8 and float(one["update_cov_diff"]) < 1e-6  # tests/test_gp.cc:213
