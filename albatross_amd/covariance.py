@@ -306,6 +306,8 @@ class ScalingFunction:
         return dict(self._params)
 
     def set_param(self, name, value):
+        if "_params" not in self.__dict__:  # class-level defaults: copy on first write
+            self._params = dict(type(self)._params)
         self._params[name] = float(value)
 
     def __call__(self, coords):

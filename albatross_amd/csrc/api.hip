@@ -672,6 +672,79 @@ int agp_nll(agp_context *c, const agp_kernel *k, const agp_features *x, const do
   return st;
 }
 
+// ---- tuner objective batching ---------------------------------------------------------
+// The negative log likelihoods of `count` parameter vectors of one model on one dataset, in lock step:
+// what compute_gradient (tune/finite_difference.hpp:20-94) and the ModelTuner objective
+// (tune/tune.hpp:151-161,276-290) evaluate one after the other.  `count` Gram matrices are built into
+// slabs and factored by the batched kernels (blockIdx.y = parameter vector), so small and medium N pay
+// the launch chain once instead of `count` times.  A parameter vector whose covariance is not positive
+// definite (or has NaN) yields NaN in its slot, like the reference's NaN metric (tune.hpp:163-165).
+int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, const agp_features *const *features,
+                  const double *y, int64_t ldy, const double *y_var, double *out) {
+  if (!c || count <= 0 || !kernels || !features || !y || !out) return AGP_ERR_INVALID_ARGUMENT;
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const long long n = features[0] ? features[0]->n : 0;
+  if (n <= 0 || (ldy != 0 && ldy < n)) return AGP_ERR_INVALID_ARGUMENT;
+  int st = AGP_OK;
+  for (int b = 0; b < count; ++b) {
+    if (!kernels[b] || !features[b] || features[b]->n != n || features[b]->location != features[0]->location)
+      return AGP_ERR_INVALID_ARGUMENT;
+    if ((st = validate_features(features[b])) != AGP_OK) return st;
+  }
+  const long long lda = factor_ld(n), nblk = (n + NB - 1) / NB, np2 = round_up(n, 2);
+  const long long stride_A = lda * n, stride_I = nblk * (36 * MB * MB);
+  hipStream_t s = ctx->stream;
+  // workspace: [A slabs | tile images | y slabs | yvar | logsum | quad]
+  const size_t elems = (size_t)count * ((size_t)stride_A + (size_t)stride_I + (size_t)np2) + (size_t)np2 +
+                       2 * (size_t)round_up(count, 2);
+  if ((st = ensure_ws(ctx, &ctx->ws_A, &ctx->ws_A_bytes, sizeof(double) * elems)) != AGP_OK) return st;
+  double *A = ctx->ws_A, *invd = A + (size_t)count * (size_t)stride_A, *ys = invd + (size_t)count * (size_t)stride_I;
+  double *yvar_d = ys + (size_t)count * (size_t)np2, *logsum = yvar_d + np2, *quad = logsum + round_up(count, 2);
+  const int loc = features[0]->location;
+  const hipMemcpyKind kind = loc == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  for (int b = 0; b < count; ++b)
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(ys + (size_t)b * (size_t)np2, y + (size_t)b * (size_t)ldy, sizeof(double) * (size_t)n,
+                                      kind, s));
+  if (y_var) AGP_HIP_CHECK(ctx, hipMemcpyAsync(yvar_d, y_var, sizeof(double) * (size_t)n, kind, s));
+  if (loc == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)round_up(count, 2), s));
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
+  std::vector<DeviceFeatures> dxs((size_t)count);
+  const agp_features *last = nullptr;
+  int last_b = -1;
+  for (int b = 0; b < count && st == AGP_OK; ++b) {
+    const DevProgram *dprog = nullptr;
+    if ((st = device_program(ctx, kernels[b], &dprog)) != AGP_OK) break;
+    // parameter vectors usually share one feature array: upload it once
+    const bool same = last && features[b]->coords == last->coords && features[b]->scales == last->scales &&
+                      features[b]->eq_id == last->eq_id;
+    if (!same) {
+      if ((st = to_device(ctx, features[b], false, &dxs[(size_t)b])) != AGP_OK) break;
+      last = features[b];
+      last_b = b;
+    }
+    FeatView xm = dxs[(size_t)(same ? last_b : b)].v;
+    xm.meas = 1;  // as_measurements(features), gp.hpp:288
+    launch_gram(s, dprog, xm, xm, true, true, A + (size_t)b * (size_t)stride_A, lda, y_var ? yvar_d : nullptr, nullptr,
+                &kernels[b]->prog);
+  }
+  if (st == AGP_OK) {
+    factor_lower_batched(s, A, stride_A, n, lda, invd, stride_I, ys, np2, count, ctx->d_flags, logsum);
+    launch_coldot(s, ys, np2, ys, np2, n, count, quad, -1.0, nullptr);  // z_b^T z_b, z_b = L_b^-1 y_b
+    std::vector<double> h(2 * (size_t)round_up(count, 2));
+    hipError_t e = hipMemcpyAsync(h.data(), logsum, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); st = AGP_ERR_HIP; }
+    else
+      for (int b = 0; b < count; ++b)  // likelihood.hpp:38-47
+        out[b] = 0.5 * (2. * h[(size_t)b] + h[(size_t)round_up(count, 2) + (size_t)b] + (double)n * std::log(2 * M_PI));
+  }
+  for (auto &d : dxs) d.release();
+  return st;
+}
+
 // ---- solve -----------------------------------------------------------------
 int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs, int64_t nrhs, double *out, int location) {
   if (!ctx || !fit || !rhs || !out || nrhs < 0) return AGP_ERR_INVALID_ARGUMENT;

@@ -617,6 +617,41 @@ class GaussianProcessRegression:
     def cross_validate(self):
         return CrossValidation(self)
 
+    def log_likelihoods(self, dataset, parameter_sets):
+        """log_likelihood(dataset) for several parameter vectors at once (agp_nll_batch): the evaluations
+        compute_gradient (tune/finite_difference.hpp:20-94) and ModelTuner (tune/tune.hpp:151-161) make one
+        after the other.  parameter_sets: iterable of {name: value} overrides of the current parameters.
+        A parameter vector whose covariance is not positive definite gives NaN."""
+        import copy
+        ctx = self._ctx()
+        models = []
+        for overrides in parameter_sets:
+            m = copy.copy(self)
+            m.covariance_function_ = copy.deepcopy(self.covariance_function_)
+            m.mean_function_ = copy.deepcopy(self.mean_function_)
+            m.set_param_values(overrides)
+            models.append(m)
+        count = len(models)
+        if count == 0:
+            return np.zeros(0)
+        feats = _values_of(dataset.features)
+        fsets, structs, ys = [], [], []
+        yv = None
+        for m in models:
+            fs = m.covariance_function_.features(feats)
+            y, yv = m._targets(fs, dataset.targets)
+            fsets.append(fs)
+            structs.append(fs.as_struct())
+            ys.append(y)
+        n = fsets[0].n
+        Y = np.asfortranarray(np.stack(ys, axis=1))
+        kernels = (C.c_void_p * count)(*[ctx.kernel(m.covariance_function_) for m in models])
+        fptrs = (C.c_void_p * count)(*[C.addressof(st) for st in structs])
+        out = np.empty(count)
+        ctx._check(ctx._lib.agp_nll_batch(ctx._h, count, kernels, fptrs, _ptr(Y), n, _ptr(yv), _ptr(out)),
+                   "agp_nll_batch")
+        return -out
+
     def log_likelihood(self, dataset):
         """gp.hpp:442-451 (without priors: the parameter-prior subsystem is out of scope)."""
         ctx = self._ctx()

@@ -141,6 +141,20 @@ int main() {
     std::printf("update_mean_diff,%.17g\n", dm);
     std::printf("update_cov_diff,%.17g\n", dc);
   }
+  // batched log likelihoods == single calls (the tuner's finite-difference gradient, tune/finite_difference.hpp:20-94)
+  {
+    std::vector<ParameterStore> sets(1);
+    for (const auto &kv : model.get_params()) sets.push_back({{kv.first, kv.second + 1e-6}});
+    const Vector batch = model.log_likelihoods(data, sets);
+    double worst = 0.;
+    for (std::size_t b = 0; b < sets.size(); ++b) {
+      auto m2 = model;
+      m2.set_param_values(sets[b]);
+      worst = std::fmax(worst, std::fabs(batch[b] - m2.log_likelihood(data)));
+    }
+    std::printf("nll_batch_count,%zu\n", sets.size());
+    std::printf("nll_batch_diff,%.17g\n", worst);
+  }
   // sparse GP (tests/test_sparse_gp.cc:48-133 test_sanity shape): toy linear data, LeaveOneIntervalOut groups
   {
     std::vector<double> tx(10);

@@ -172,6 +172,21 @@ int agp_fit_download_information(agp_context *ctx, const agp_fit *fit,
 int agp_nll(agp_context *ctx, const agp_kernel *k, const agp_features *x,
             const double *y, const double *y_var, double *out);
 
+/* Tuner objective batching: agp_nll for `count` parameter vectors of one model on one dataset in lock step
+ * (batched Gram slabs + batched LL^T; blockIdx.y = parameter vector) — the evaluations that
+ * compute_gradient (include/albatross/src/tune/finite_difference.hpp:20-94) and the ModelTuner objective
+ * (include/albatross/src/tune/tune.hpp:151-161,276-290) perform one after the other.
+ *   kernels[b]   the covariance function with parameter vector b
+ *   features[b]  its feature view (normally all the same arrays; they differ only when a ScalingTerm
+ *                parameter is tuned); all n equal, all at the same location
+ *   y            n x count column-major with leading dimension ldy at that location (mean function removed
+ *                per parameter vector); ldy = 0: one target vector shared by all
+ *   out[b]       the negative log likelihood (host); NaN where the covariance is not positive definite or
+ *                has NaN (the reference turns a NaN metric into +inf, tune.hpp:163-165) */
+int agp_nll_batch(agp_context *ctx, int count, const agp_kernel *const *kernels,
+                  const agp_features *const *features, const double *y, int64_t ldy, const double *y_var,
+                  double *out);
+
 /* ---- solve (CovarianceRepresentation::solve, gp.hpp:42-45,68,96,111) ----- */
 /* out = K^-1 rhs; rhs/out column-major n x nrhs (ld = n), at `location`. */
 int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs,

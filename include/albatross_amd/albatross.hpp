@@ -986,6 +986,42 @@ class GaussianProcessRegression {
   // core/model.hpp:154-156
   auto cross_validate() const;
 
+  // log_likelihood(dataset) for several parameter vectors in ONE batched device pass (agp_nll_batch): the
+  // evaluations compute_gradient (tune/finite_difference.hpp:20-94) and ModelTuner (tune/tune.hpp:151-161)
+  // make one after the other.  Every entry overrides some of the current parameters; a parameter vector whose
+  // covariance is not positive definite yields NaN.
+  template <typename FeatureType>
+  Vector log_likelihoods(const RegressionDataset<FeatureType> &dataset, const std::vector<ParameterStore> &parameter_sets) const {
+    const std::size_t count = parameter_sets.size(), n = dataset.features.size();
+    Vector out(count);
+    if (count == 0) return out;
+    auto ctx = detail::default_context();
+    std::vector<GaussianProcessRegression> models(count, *this);
+    std::vector<std::unique_ptr<detail::KernelHolder>> kernels;
+    std::vector<detail::Flat> flats(count);
+    std::vector<const agp_kernel *> kptr(count);
+    std::vector<const agp_features *> fptr(count);
+    std::vector<double> Y(n * count);
+    for (std::size_t b = 0; b < count; ++b) {
+      models[b].set_param_values(parameter_sets[b]);
+      kernels.emplace_back(new detail::KernelHolder(models[b].covariance_function_.program()));
+      flats[b] = detail::flatten(models[b].covariance_function_, dataset.features);
+      kptr[b] = kernels.back()->k;
+      for (std::size_t i = 0; i < n; ++i) {
+        double v = dataset.targets.mean[i];
+        if (!std::is_same<MeanFunc, ZeroMean>::value)
+          v -= models[b].mean_function_._call_impl(detail::unwrap<FeatureType>::get(dataset.features[i]));
+        Y[b * n + i] = v;
+      }
+    }
+    for (std::size_t b = 0; b < count; ++b) fptr[b] = &flats[b].view;  // after the vector stopped moving
+    detail::check(agp_nll_batch(ctx->ctx, static_cast<int>(count), kptr.data(), fptr.data(), Y.data(), static_cast<std::int64_t>(n),
+                                dataset.targets.covariance.empty() ? nullptr : dataset.targets.covariance.data(), out.data()),
+                  ctx->ctx, "agp_nll_batch");
+    for (double &v : out) v = -v;
+    return out;
+  }
+
   // gp.hpp:442-451 (prior_log_likelihood() is outside the hot path and not included)
   template <typename FeatureType>
   double log_likelihood(const RegressionDataset<FeatureType> &dataset) const {

@@ -207,3 +207,47 @@ def test_leave_one_out_n16384_property(ctx):
     assert np.abs(X[idx, np.arange(6)] - d[idx]).max() <= 1e-9 * d.max()
     loo = fm.get_fit().leave_one_out(y)
     assert np.all(loo.covariance > 0) and np.abs(loo.mean - y).max() < 1.0
+
+
+@pytest.mark.parametrize("n", [60, 256, 700])
+def test_batched_log_likelihoods_match_single_calls(ctx, n):
+    """agp_nll_batch == agp_nll per parameter vector (the tuner's finite-difference gradient,
+    tune/finite_difference.hpp:20-94), including a ScalingTerm parameter, a mean-function parameter and a
+    parameter vector that is not positive definite."""
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0., 10., (n, 3))
+    y = np.sin(x).sum(axis=1) + 0.5 * x[:, 0] + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.03, n)
+
+    class Elevation(ab.ScalingFunction):
+        _params = {"elevation_scaling_center": 4.0, "elevation_scaling_factor": 0.3}
+
+        def get_name(self):
+            return "elevation_scaling"
+
+        def _call_impl(self, c):
+            p = self.get_params()
+            return 1. + p["elevation_scaling_factor"] * np.maximum(p["elevation_scaling_center"] - np.asarray(c)[:, 2], 0.)
+
+    cov = ab.ScalingTerm(Elevation()) * ab.Constant(0.5) + ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+    model = ab.gp_from_covariance_and_mean(cov, ab.LinearMean(), context=ctx)
+    ds = ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar))
+    base = model.get_params()
+    sets = [{}]
+    for name in base:  # forward differences, epsilon as in compute_gradient
+        sets.append({name: base[name] + 1e-6 * max(1., abs(base[name]))})
+    sets.append({"matern_52_length_scale": 0.5, "sigma_matern_52": 3.0})
+    got = model.log_likelihoods(ds, sets)
+    for overrides, g in zip(sets, got):
+        m = ab.gp_from_covariance_and_mean(cov, ab.LinearMean(), context=ctx)
+        import copy
+        m.covariance_function_ = copy.deepcopy(cov)
+        m.mean_function_ = copy.deepcopy(model.mean_function_)
+        m.set_param_values(overrides)
+        want = m.log_likelihood(ds)
+        assert abs(g - want) <= 1e-9 * max(1., abs(want)), overrides
+    # not positive definite: duplicate points without noise
+    xd = np.concatenate([x[:10], x[:10]])
+    bad = ab.gp_from_covariance(ab.SquaredExponential(1.0, 1.0), context=ctx)
+    out = bad.log_likelihoods(ab.RegressionDataset(xd, np.zeros(20)), [{}, {"sigma_squared_exponential": 2.0}])
+    assert np.all(np.isnan(out))
