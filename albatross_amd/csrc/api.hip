@@ -11,27 +11,9 @@
 #include <new>
 #include <thread>
 
-#include "common.h"
+#include "api_internal.h"
 
 namespace agp {
-void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n);
-void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n);
-void launch_set_identity(hipStream_t s, double *B, long long ld, long long n);
-void launch_nan_scan_lower(hipStream_t s, const double *A, long long ld, long long n, int *flag);
-void launch_upper_to_lower(hipStream_t s, const double *src, long long ld_src, double *dst, long long ld_dst,
-                           long long n);
-void launch_gather_cols(hipStream_t s, const double *R, long long ldr, const long long *idx, long long m,
-                        long long row0, long long n, double *G, long long ldg);
-void launch_gather_vec(hipStream_t s, const double *src, const long long *idx, long long m, const double *sub,
-                       double *out);
-void launch_negate(hipStream_t s, double *A, long long ld, long long m, double *diag_out);
-void launch_matvec(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *x,
-                   double *partial, double alpha, double beta, const double *base, double *out);
-void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,
-                       double alpha, double beta, const double *base, double *out);
-void launch_axpby(hipStream_t s, long long n, double a, const double *x, double b, const double *y, double *out);
-void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const double *information, long long n,
-                double *mean, double *variance);
 
 void DeviceFeatures::release() {
   for (void *&p : owned) {
@@ -41,12 +23,12 @@ void DeviceFeatures::release() {
   v = FeatView{};
 }
 
-static long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
+long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 
 // leading dimension of the factor: even (16-B aligned columns) and not a
 // multiple of 256 doubles, so that consecutive columns do not alias the same
 // HBM channel / L2 set pattern
-static long long factor_ld(long long n) {
+long long factor_ld(long long n) {
   long long ld = round_up(n, 8);
   if (ld % 256 == 0) ld += 8;
   return ld;
@@ -56,40 +38,8 @@ static long long factor_ld(long long n) {
 
 using namespace agp;
 
-struct ProgSlot {
-  unsigned long long uid = 0;
-  DevProgram *dev = nullptr;
-};
-
-struct agp_context_ext {
-  ProgSlot slots[8];
-  int next = 0;
-};
-
-static std::atomic<unsigned long long> g_kernel_uid{1};
-
-struct agp_kernel_full : agp_kernel {
-  unsigned long long uid;
-};
-
-// context extension kept out of common.h (host-only bookkeeping)
-static agp_context_ext *ext_of(agp_context *ctx);
-
-struct agp_context_impl : agp_context {
-  agp_context_ext ext;
-  std::vector<hipEvent_t> gemm_events;
-  std::vector<double> gemm_flops;
-  hipEvent_t stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  double *partial_ws = nullptr;
-  size_t partial_bytes = 0;
-  double gemm_ms_sum = 0., gemm_flop_sum = 0.;
-  int gemm_launches = 0;
-  // helper contexts (own streams / workspaces) for host threads that work through independent
-  // small problems concurrently (the blocks of a sparse GP); created on first use
-  std::vector<agp_context *> helpers;
-};
-
 static agp_context_ext *ext_of(agp_context *ctx) { return &static_cast<agp_context_impl *>(ctx)->ext; }
+std::atomic<unsigned long long> g_kernel_uid{1};
 
 extern "C" {
 
@@ -256,7 +206,7 @@ void agp_kernel_destroy(agp_kernel *k) { delete static_cast<agp_kernel_full *>(k
 }  // extern "C"
 
 // device copy of a kernel program (small LRU ring per context)
-static int device_program(agp_context *ctx, const agp_kernel *k, const DevProgram **out) {
+int device_program(agp_context *ctx, const agp_kernel *k, const DevProgram **out) {
   agp_context_ext *x = ext_of(ctx);
   const unsigned long long uid = static_cast<const agp_kernel_full *>(k)->uid;
   for (auto &sl : x->slots)
@@ -280,7 +230,7 @@ int device_program_for(agp_context *ctx, const agp_kernel *k, const DevProgram *
 }
 }  // namespace agp
 
-static int validate_features(const agp_features *f) {
+int validate_features(const agp_features *f) {
   if (!f || f->n < 0 || f->dim < 1 || f->dim > AGP_MAX_DIM) return AGP_ERR_INVALID_ARGUMENT;
   if (f->n_scale_columns < 0 || f->n_scale_columns > AGP_MAX_SCALE_COLUMNS) return AGP_ERR_INVALID_ARGUMENT;
   if (f->n > 0 && !f->coords) return AGP_ERR_INVALID_ARGUMENT;
@@ -290,7 +240,7 @@ static int validate_features(const agp_features *f) {
 
 // Make a device view of a feature vector (uploads host data; `copy` forces an
 // owned device copy of device-resident data as well).
-static int to_device(agp_context *ctx, const agp_features *f, bool copy, DeviceFeatures *out) {
+int to_device(agp_context *ctx, const agp_features *f, bool copy, DeviceFeatures *out) {
   const int st = validate_features(f);
   if (st != AGP_OK) return st;
   out->release();
@@ -334,7 +284,7 @@ int features_to_device(agp_context *ctx, const agp_features *f, bool copy, Devic
 }
 }  // namespace agp
 
-static int ensure_ws(agp_context *ctx, double **ws, size_t *have, size_t need) {
+int ensure_ws(agp_context *ctx, double **ws, size_t *have, size_t need) {
   if (*have >= need) return AGP_OK;
   if (*ws) {
     AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -348,21 +298,21 @@ static int ensure_ws(agp_context *ctx, double **ws, size_t *have, size_t need) {
 }
 
 // a device staging copy of an n-vector living at `location`
-static int vector_to_device(agp_context *ctx, const double *src, long long n, int location, double *dst) {
+int vector_to_device(agp_context *ctx, const double *src, long long n, int location, double *dst) {
   const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   AGP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, kind, ctx->stream));
   if (location == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return AGP_OK;
 }
 
-static int copy_out(agp_context *ctx, const double *dev, long long count, double *dst, int location) {
+int copy_out(agp_context *ctx, const double *dev, long long count, double *dst, int location) {
   const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   AGP_HIP_CHECK(ctx, hipMemcpyAsync(dst, dev, sizeof(double) * (size_t)count, kind, ctx->stream));
   AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return AGP_OK;
 }
 
-static int copy_out_2d(agp_context *ctx, const double *dev, long long ld_dev, long long rows, long long cols,
+int copy_out_2d(agp_context *ctx, const double *dev, long long ld_dev, long long rows, long long cols,
                        double *dst, long long ld_dst, int location) {
   if (location == AGP_HOST && ld_dev == ld_dst) {  // one contiguous transfer instead of one per column
     AGP_HIP_CHECK(ctx, hipMemcpyAsync(dst, dev, sizeof(double) * ((size_t)ld_dev * (size_t)(cols - 1) + (size_t)rows),
@@ -442,7 +392,7 @@ static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevPr
   return AGP_OK;
 }
 
-static int status_from_flags(const agp_context *ctx) {
+int status_from_flags(const agp_context *ctx) {
   if (ctx->h_flags[0]) return AGP_ERR_NAN_INPUT;
   if (ctx->h_flags[1]) return AGP_ERR_NOT_POSITIVE_DEFINITE;
   return AGP_OK;
@@ -897,540 +847,6 @@ int agp_loo_marginal(agp_context *ctx, const agp_fit *fit, const double *y, doub
   launch_loo(ctx->stream, diag, yd, fit->alpha, n, md, diag);
   if ((st = copy_out(ctx, md, n, mean, location)) != AGP_OK) return st;
   return copy_out(ctx, diag, n, variance, location);
-}
-
-// ---- leave-one-GROUP-out -------------------------------------------------------
-// SerializableLDLT::inverse_blocks (serializable_ldlt.hpp:137-179) and held_out_predictions
-// (cross_validation_utils.hpp:165-232).  R = L^-1 is built once (N^3/3 flop on MFMA, the solve
-// kernels on a triangular right-hand side); per group the columns I_g are gathered and
-// B_g = G^T G = (K^-1)[I_g, I_g] is one MFMA product; the |g| x |g| system is then factored with
-// the same LL^T kernels.
-namespace {
-
-struct GroupWork {
-  agp_context *ctx = nullptr;
-  double *R = nullptr, *G = nullptr, *B = nullptr, *tmp = nullptr;
-  long long *idx = nullptr;
-  long long n = 0, ldr = 0, ldg = 0, ldb = 0, mmax = 0;
-  ~GroupWork() {
-    (void)hipFree(R); (void)hipFree(G); (void)hipFree(B); (void)hipFree(tmp); (void)hipFree(idx);
-  }
-};
-
-int group_work_init(agp_context *ctx, const agp_fit *fit, int64_t n_groups, const int64_t *offsets,
-                    const int64_t *indices, GroupWork *w) {
-  const long long n = fit->n;
-  if (n_groups < 0 || !offsets || offsets[0] != 0) return AGP_ERR_INVALID_ARGUMENT;
-  long long mmax = 0;
-  for (int64_t g = 0; g < n_groups; ++g) {
-    const long long m = offsets[g + 1] - offsets[g];
-    if (m < 0) return AGP_ERR_INVALID_ARGUMENT;
-    if (m > mmax) mmax = m;
-  }
-  const long long total = offsets[n_groups];
-  if (total > 0 && !indices) return AGP_ERR_INVALID_ARGUMENT;
-  for (long long i = 0; i < total; ++i)
-    if (indices[i] < 0 || indices[i] >= n) return AGP_ERR_INVALID_ARGUMENT;
-  w->ctx = ctx; w->n = n; w->mmax = mmax;
-  if (total == 0) return AGP_OK;
-  w->ldr = factor_ld(n); w->ldg = round_up(n, 2); w->ldb = factor_ld(mmax);
-  AGP_HIP_CHECK(ctx, hipMalloc(&w->R, sizeof(double) * (size_t)w->ldr * (size_t)n));
-  AGP_HIP_CHECK(ctx, hipMalloc(&w->G, sizeof(double) * (size_t)w->ldg * (size_t)mmax));
-  AGP_HIP_CHECK(ctx, hipMalloc(&w->B, sizeof(double) * (size_t)w->ldb * (size_t)mmax));
-  AGP_HIP_CHECK(ctx, hipMalloc(&w->tmp, sizeof(double) * (size_t)(4 * round_up(mmax, 2) + 2 * round_up(n, 2))));
-  AGP_HIP_CHECK(ctx, hipMalloc(&w->idx, sizeof(long long) * (size_t)total));
-  static_assert(sizeof(long long) == sizeof(int64_t), "index width");
-  AGP_HIP_CHECK(ctx, hipMemcpyAsync(w->idx, indices, sizeof(long long) * (size_t)total, hipMemcpyHostToDevice, ctx->stream));
-  hipStream_t s = ctx->stream;
-  launch_set_identity(s, w->R, w->ldr, n);
-  forward_solve_mat(s, fit->A, n, fit->lda, fit->invd, w->R, n, w->ldr, /*rhs_lower=*/true);
-  AGP_HIP_CHECK(ctx, hipGetLastError());
-  return AGP_OK;
-}
-
-// B (m x m, w->ldb) = (K^-1)[I_g, I_g] on the device
-int group_inverse_block(GroupWork *w, const int64_t *indices, long long off, long long m) {
-  agp_context *ctx = w->ctx;
-  hipStream_t s = ctx->stream;
-  long long row0 = w->n;
-  for (long long a = 0; a < m; ++a)
-    if (indices[off + a] < row0) row0 = indices[off + a];
-  row0 &= ~1LL;  // column j of R is zero above row j: only rows >= min(I_g) contribute
-  launch_gather_cols(s, w->R, w->ldr, w->idx + off, m, row0, w->n, w->G, w->ldg);
-  AGP_HIP_CHECK(ctx, hipMemsetAsync(w->B, 0, sizeof(double) * (size_t)w->ldb * (size_t)m, s));
-  // B -= G^T G (k-major operands), then negate
-  launch_gemm_nt_sub(s, w->B, w->ldb, w->G + row0, w->ldg, true, w->G + row0, w->ldg, true, m, m, w->n - row0, false);
-  launch_negate(s, w->B, w->ldb, m, nullptr);
-  AGP_HIP_CHECK(ctx, hipGetLastError());
-  return AGP_OK;
-}
-
-}  // namespace
-
-int agp_fit_inverse_blocks(agp_context *ctx, const agp_fit *fit, int64_t n_groups, const int64_t *offsets,
-                           const int64_t *indices, double *blocks, int out_location) {
-  if (!ctx || !fit || !fit->A || !blocks) return AGP_ERR_INVALID_ARGUMENT;
-  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  GroupWork w;
-  int st = group_work_init(ctx, fit, n_groups, offsets, indices, &w);
-  if (st != AGP_OK) return st;
-  for (int64_t g = 0; g < n_groups; ++g) {
-    const long long off = offsets[g], m = offsets[g + 1] - off;
-    if (m == 0) continue;
-    if ((st = group_inverse_block(&w, indices, off, m)) != AGP_OK) return st;
-    if ((st = copy_out_2d(ctx, w.B, w.ldb, m, m, blocks, m, out_location)) != AGP_OK) return st;
-    blocks += m * m;
-  }
-  return AGP_OK;
-}
-
-int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double *y, int64_t n_groups,
-                             const int64_t *offsets, const int64_t *indices, double *mean, double *variance,
-                             double *joint, int location) {
-  if (!ctx || !fit || !fit->A || !fit->alpha || !y || !mean) return AGP_ERR_INVALID_ARGUMENT;
-  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  GroupWork w;
-  int st = group_work_init(ctx, fit, n_groups, offsets, indices, &w);
-  if (st != AGP_OK) return st;
-  if (w.mmax == 0) return AGP_OK;
-  const long long n = fit->n, mp = round_up(w.mmax, 2);
-  double *v = w.tmp, *x = v + mp, *mu = x + mp, *var = mu + mp, *yd = var + mp;
-  if ((st = vector_to_device(ctx, y, n, location, yd)) != AGP_OK) return st;
-  hipStream_t s = ctx->stream;
-  for (int64_t g = 0; g < n_groups; ++g) {
-    const long long off = offsets[g], m = offsets[g + 1] - off;
-    if (m == 0) continue;
-    if ((st = group_inverse_block(&w, indices, off, m)) != AGP_OK) return st;
-    // A_ldlt = SerializableLDLT(inverse_block)   (cross_validation_utils.hpp:181)
-    agp_fit *fb = nullptr;
-    st = agp_factor_create(ctx, w.B, m, w.ldb, 0, AGP_DEVICE, &fb);
-    if (st != AGP_OK) { if (fb) agp_fit_destroy(fb); return st; }
-    // mean = y - A_ldlt.solve(v), v = subset(information, indices)   (:175,182)
-    launch_gather_vec(s, fit->alpha, w.idx + off, m, nullptr, v);
-    st = agp_solve(ctx, fb, v, 1, x, AGP_DEVICE);
-    if (st == AGP_OK) {
-      launch_gather_vec(s, yd, w.idx + off, m, x, mu);
-      st = copy_out(ctx, mu, m, mean + off, location);
-    }
-    if (st == AGP_OK && (variance || joint)) {
-      // R_B = L_B^-1 ; inverse = R_B^T R_B  (inverse_diagonal :183 / inverse :192)
-      const long long ldq = factor_ld(m);
-      st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * 2 * (size_t)ldq * (size_t)m);
-      if (st == AGP_OK) {
-        double *Q = ctx->ws_aux, *J = Q + (size_t)ldq * (size_t)m;
-        launch_set_identity(s, Q, ldq, m);
-        forward_solve_mat(s, fb->A, m, fb->lda, fb->invd, Q, m, ldq, /*rhs_lower=*/true);
-        if (joint) {
-          (void)hipMemsetAsync(J, 0, sizeof(double) * (size_t)ldq * (size_t)m, s);
-          launch_gemm_nt_sub(s, J, ldq, Q, ldq, true, Q, ldq, true, m, m, m, false);
-          launch_negate(s, J, ldq, m, var);
-          st = copy_out_2d(ctx, J, ldq, m, m, joint, m, location);
-          joint += m * m;
-        } else {
-          launch_coldot(s, Q, ldq, Q, ldq, m, m, var, -1.0, nullptr);
-        }
-        if (st == AGP_OK && variance) st = copy_out(ctx, var, m, variance + off, location);
-      }
-    }
-    agp_fit_destroy(fb);
-    if (st != AGP_OK) return st;
-  }
-  AGP_HIP_CHECK(ctx, hipGetLastError());
-  return AGP_OK;
-}
-
-// ---- sparse Gaussian process (FITC / PITC) -----------------------------------------
-// SparseGaussianProcessRegression (include/albatross/src/models/sparse_gp.hpp).  The reference
-// stores Sigma = (K_uu + K_uf A^-1 K_fu)^-1 through the pivoted Householder QR of
-// B = [A^-1/2 K_fu; K_uu^T/2] (:343-352); only R^T R = B^T B enters any result, so the device path
-// forms  M = B^T B = K_uu + W W^T  (W = K_uf A^-T/2, one MFMA SYRK), factors it with the same
-// LL^T kernels (M = L1 L1^T, i.e. R = L1^T up to the column permutation) and removes the squared
-// LL^T kernels.  Forming B^T B squares the condition number, which the reference's QR avoids, so
-// the factor is repaired the CholeskyQR2 way: Q1^T = L1^-1 B^T is formed explicitly (one more
-// triangular solve over all n columns), Q1^T Q1 = I + O(eps cond) is factored again (L2), and
-// B^T B = (L1 L2)(L1 L2)^T holds to working accuracy: log|R|, R^-T x and the information vector
-// (plus two refinement steps against B itself) then agree with the QR-based reference algorithm to ~1e-9 even
-// with cond(K_uu) ~ 1e7.  K_uu and every block of A use LL^T as well.
-struct agp_sparse_fit {
-  agp_context *ctx = nullptr;
-  long long m = 0;
-  DeviceFeatures u;            // train_features = inducing points
-  agp_fit *kuu = nullptr;      // train_covariance = factor of K_uu + inducing_nugget I
-  agp_fit *sigma = nullptr;    // L1: LL^T of M = B^T B as formed in floating point
-  agp_fit *sigma2 = nullptr;   // L2: LL^T of Q1^T Q1, Q1 = B L1^-T (CholeskyQR2: B^T B = L1 L2 L2^T L1^T to working accuracy)
-  double *v = nullptr;         // information (m)
-  double nll = 0.;
-};
-
-namespace {
-
-struct SparseScratch {
-  double *Kuf = nullptr, *Pbuf = nullptr, *M0 = nullptr, *Ksym = nullptr, *vecs = nullptr, *partial = nullptr,
-         *Ag = nullptr, *Pimg = nullptr, *Q1T = nullptr;
-  std::vector<agp_fit *> blocks;
-  ~SparseScratch() {
-    (void)hipFree(Kuf); (void)hipFree(Pbuf); (void)hipFree(M0); (void)hipFree(Ksym); (void)hipFree(vecs);
-    (void)hipFree(partial); (void)hipFree(Ag); (void)hipFree(Pimg); (void)hipFree(Q1T);
-    for (agp_fit *b : blocks) agp_fit_destroy(b);
-  }
-};
-
-FeatView feature_rows(const FeatView &v, long long o, long long cnt) {
-  FeatView r = v;
-  r.n = cnt;
-  r.coords = v.coords + o * v.dim;
-  if (v.ids) r.ids = v.ids + o;
-  if (v.scales) r.scales = v.scales + o * v.nsc;
-  return r;
-}
-
-}  // namespace
-
-void agp_sparse_fit_destroy(agp_sparse_fit *f) {
-  if (!f) return;
-  if (f->ctx) (void)hipSetDevice(f->ctx->device);
-  f->u.release();
-  if (f->kuu) agp_fit_destroy(f->kuu);
-  if (f->sigma) agp_fit_destroy(f->sigma);
-  if (f->sigma2) agp_fit_destroy(f->sigma2);
-  if (f->v) (void)hipFree(f->v);
-  delete f;
-}
-
-int64_t agp_sparse_fit_size(const agp_sparse_fit *f) { return f ? f->m : 0; }
-
-int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t n_groups,
-                          const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
-                          double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
-                          double *information, double *nll_out) {
-  if (!ctx || !k || !x || !u || !y || !offsets || n_groups <= 0) return AGP_ERR_INVALID_ARGUMENT;
-  if (out) *out = nullptr;
-  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int st = validate_features(x);
-  if (st == AGP_OK) st = validate_features(u);
-  if (st != AGP_OK) return st;
-  const long long n = x->n, m = u->n;
-  if (n <= 0 || m <= 0 || u->dim != x->dim || offsets[0] != 0 || offsets[n_groups] != n) return AGP_ERR_INVALID_ARGUMENT;
-  long long smax = 0;
-  for (int64_t g = 0; g < n_groups; ++g) {
-    const long long sg = offsets[g + 1] - offsets[g];
-    if (sg <= 0) return AGP_ERR_INVALID_ARGUMENT;
-    if (sg > smax) smax = sg;
-  }
-  const DevProgram *dprog = nullptr;
-  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
-  hipStream_t s = ctx->stream;
-
-  agp_sparse_fit *f = new (std::nothrow) agp_sparse_fit();
-  if (!f) return AGP_ERR_INVALID_ARGUMENT;
-  f->ctx = ctx; f->m = m;
-  SparseScratch w;
-  // AGP_SPARSE_TIMING=1: wall time of every stage (with a stream synchronisation at each boundary) on stderr
-  static const bool timing = getenv("AGP_SPARSE_TIMING") != nullptr;
-  auto t_last = std::chrono::steady_clock::now();
-  auto stage = [&](const char *name) {
-    if (!timing) return;
-    (void)hipStreamSynchronize(s);
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "  [sparse fit] %-28s %8.2f ms\n", name, std::chrono::duration<double, std::milli>(now - t_last).count());
-    t_last = now;
-  };
-  DeviceFeatures dx;
-#define SP_FAIL(code) do { dx.release(); agp_sparse_fit_destroy(f); return (code); } while (0)
-#define SP_HIP(expr)                                                                     \
-  do {                                                                                   \
-    hipError_t _e = (expr);                                                              \
-    if (_e != hipSuccess) {                                                              \
-      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
-      SP_FAIL(AGP_ERR_HIP);                                                              \
-    }                                                                                    \
-  } while (0)
-  if ((st = to_device(ctx, u, true, &f->u)) != AGP_OK) SP_FAIL(st);
-  if ((st = to_device(ctx, x, false, &dx)) != AGP_OK) SP_FAIL(st);
-  FeatView xm = dx.v;
-  xm.meas = 1;  // as_measurements(out_of_order_features), sparse_gp.hpp:649-650
-
-  const long long ldm = factor_ld(m), ldk = round_up(m, 2), np2 = round_up(n, 2), mp2 = round_up(m, 2);
-  const long long chunks = (n + 1023) / 1024;
-  // vectors: dvar (n) | yw (n) | t (n) | nug (m) | b (m) | v (m) | r (m) | dv (m)
-  SP_HIP(hipMalloc(&w.vecs, sizeof(double) * (size_t)(3 * np2 + 5 * mp2)));
-  double *dvar = w.vecs, *yw = dvar + np2, *tvec = yw + np2, *nug = tvec + np2, *bvec = nug + mp2, *vvec = bvec + mp2,
-         *rvec = vvec + mp2, *dv = rvec + mp2;
-  SP_HIP(hipMalloc(&w.partial, sizeof(double) * (size_t)(chunks > 0 ? chunks : 1) * (size_t)m));
-  const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-  SP_HIP(hipMemcpyAsync(yw, y, sizeof(double) * (size_t)n, kind, s));
-  if (y_var) {
-    SP_HIP(hipMemcpyAsync(tvec, y_var, sizeof(double) * (size_t)n, kind, s));
-    if (x->location == AGP_HOST) SP_HIP(hipStreamSynchronize(s));
-    launch_axpby(s, n, 1.0, tvec, measurement_nugget, nullptr, dvar);   // target variance + measurement nugget, :692-696
-  } else {
-    if (x->location == AGP_HOST) SP_HIP(hipStreamSynchronize(s));
-    launch_axpby(s, n, 0.0, nullptr, measurement_nugget, nullptr, dvar);
-  }
-  launch_axpby(s, m, 0.0, nullptr, inducing_nugget, nullptr, nug);
-
-  stage("upload");
-  // K_uu + inducing_nugget I  (:674-679) -> LL^T
-  SP_HIP(hipMalloc(&w.M0, sizeof(double) * (size_t)ldm * (size_t)m));
-  SP_HIP(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
-  launch_gram(s, dprog, f->u.v, f->u.v, true, true, w.M0, ldm, nug, ctx->d_flags, &k->prog);
-  st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->kuu);
-  if (st != AGP_OK) SP_FAIL(st);
-
-  stage("K_uu + factor");
-  // K_uf (m x n) and P = K_uu^-1/2 K_uf = L_u^-1 K_uf  (:669-685)
-  SP_HIP(hipMalloc(&w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n));
-  SP_HIP(hipMalloc(&w.Pbuf, sizeof(double) * (size_t)ldk * (size_t)n));
-  launch_gram(s, dprog, f->u.v, xm, false, false, w.Kuf, ldk, nullptr, nullptr, &k->prog);
-  SP_HIP(hipMemcpyAsync(w.Pbuf, w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n, hipMemcpyDeviceToDevice, s));
-  forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, w.Pbuf, n, ldk);
-
-  // A = K_ff (block diagonal) + target variance - diag blocks of P^T P + measurement nugget, block LL^T
-  // (:652-704); then W = K_uf A^-T/2 (in place in K_uf) and y_w = A^-1/2 y, block by block (B's top block
-  // transposed, :347-349; :372).
-  SP_HIP(hipStreamSynchronize(s));
-  stage("K_uf, P = L_u^-1 K_uf");
-  bool uniform = true;
-  for (int64_t g = 0; g < n_groups; ++g) uniform = uniform && (offsets[g + 1] - offsets[g] == smax);
-  double log_det_a = 0.;
-  if (uniform) {
-    // All groups have the same size: the blocks advance in LOCK STEP through batched launches
-    // (blockIdx.y = group) - a dozen launches for the whole of A instead of ~40 per block, which
-    // is what the per-block path below is bound by (the HIP launch path is serial per process).
-    const long long sb = smax, lda_b = factor_ld(sb), nblk_b = (sb + NB - 1) / NB;
-    const long long stride_A = lda_b * sb, stride_I = nblk_b * (36 * MB * MB);
-    SP_HIP(hipMalloc(&w.Ag, sizeof(double) * (size_t)stride_A * (size_t)n_groups));
-    SP_HIP(hipMalloc(&w.Pimg, sizeof(double) * ((size_t)stride_I + 1) * (size_t)n_groups));
-    double *logsum = w.Pimg + (size_t)stride_I * (size_t)n_groups;
-    SP_HIP(hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)n_groups, s));
-    SP_HIP(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
-    for (int64_t g = 0; g < n_groups; ++g) {
-      const FeatView xg = feature_rows(xm, g * sb, sb);
-      launch_gram(s, dprog, xg, xg, true, true, w.Ag + g * stride_A, lda_b, dvar + g * sb, ctx->d_flags, &k->prog);
-    }
-    // A_g -= P_g^T P_g, all groups
-    launch_gemm_nt_sub_batched(s, w.Ag, lda_b, stride_A, w.Pbuf, ldk, true, sb * ldk, w.Pbuf, ldk, true, sb * ldk, sb, sb, m,
-                               true, n_groups);
-    // block LL^T with y_w = A^-1/2 y carried along (fused forward substitution), then W = K_uf A^-T/2 in place
-    factor_lower_batched(s, w.Ag, stride_A, sb, lda_b, w.Pimg, stride_I, yw, sb, n_groups, ctx->d_flags, logsum);
-    right_solve_lt_batched(s, w.Ag, stride_A, sb, lda_b, w.Pimg, stride_I, w.Kuf, sb * ldk, m, ldk, n_groups);
-    std::vector<double> hl((size_t)n_groups);
-    SP_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    SP_HIP(hipMemcpyAsync(hl.data(), logsum, sizeof(double) * (size_t)n_groups, hipMemcpyDeviceToHost, s));
-    SP_HIP(hipStreamSynchronize(s));
-    SP_HIP(hipGetLastError());
-    if ((st = status_from_flags(ctx)) != AGP_OK) SP_FAIL(st);
-    for (int64_t g = 0; g < n_groups; ++g) log_det_a += 2. * hl[(size_t)g];  // fixed order
-  } else {
-    // ragged groups: one block at a time, T host threads on T helper contexts (own streams)
-    agp_context_impl *ci = static_cast<agp_context_impl *>(ctx);
-    static int want_threads = -1;
-    if (want_threads < 0) {
-      const char *e = getenv("AGP_SPARSE_THREADS");
-      want_threads = e ? atoi(e) : 4;  // measured: 4 threads 590 ms, 16: 650 ms, 32: 740 ms at 512 blocks of 512
-      if (want_threads < 1) want_threads = 1;
-    }
-    const int T = (int)std::min<long long>(want_threads, n_groups);
-    while ((int)ci->helpers.size() < T) {
-      agp_context *h = nullptr;
-      if ((st = agp_context_create(ctx->device, &h)) != AGP_OK) SP_FAIL(st);
-      ci->helpers.push_back(h);
-    }
-    w.blocks.assign((size_t)n_groups, nullptr);
-    std::vector<int> status((size_t)T, AGP_OK);
-    std::vector<std::string> errors((size_t)T);
-    const long long lda_g = factor_ld(smax);
-    double *Kuf = w.Kuf, *Pbuf = w.Pbuf;
-    auto worker = [&](int t) {
-      agp_context *h = ci->helpers[(size_t)t];
-      int &stt = status[(size_t)t];
-      if (hipSetDevice(ctx->device) != hipSuccess) { stt = AGP_ERR_HIP; return; }
-      const DevProgram *hprog = nullptr;
-      if ((stt = device_program(h, k, &hprog)) != AGP_OK) return;
-      double *Ag = nullptr;
-      if (hipMalloc(&Ag, sizeof(double) * (size_t)lda_g * (size_t)smax) != hipSuccess) { stt = AGP_ERR_HIP; return; }
-      hipStream_t hs = h->stream;
-      for (int64_t g = t; g < n_groups && stt == AGP_OK; g += T) {
-        const long long o = offsets[g], sg = offsets[g + 1] - o;
-        const FeatView xg = feature_rows(xm, o, sg);
-        launch_gram(hs, hprog, xg, xg, true, true, Ag, lda_g, dvar + o, nullptr, &k->prog);
-        launch_gemm_nt_sub(hs, Ag, lda_g, Pbuf + o * ldk, ldk, true, Pbuf + o * ldk, ldk, true, sg, sg, m, true);
-        agp_fit *blk = nullptr;
-        stt = agp_factor_create(h, Ag, sg, lda_g, 0, AGP_DEVICE, &blk);
-        w.blocks[(size_t)g] = blk;
-        if (stt != AGP_OK) break;
-        right_solve_lt(hs, blk->A, sg, blk->lda, blk->invd, Kuf + o * ldk, m, ldk);
-        forward_solve_mat(hs, blk->A, sg, blk->lda, blk->invd, yw + o, 1, sg);
-      }
-      if (hipStreamSynchronize(hs) != hipSuccess && stt == AGP_OK) stt = AGP_ERR_HIP;
-      if (stt != AGP_OK) errors[(size_t)t] = h->last_error;
-      (void)hipFree(Ag);
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(worker, t);
-    worker(0);
-    for (auto &th : pool) th.join();
-    for (int t = 0; t < T; ++t)
-      if (status[(size_t)t] != AGP_OK) {
-        ctx->last_error = errors[(size_t)t];
-        SP_FAIL(status[(size_t)t]);
-      }
-    for (int64_t g = 0; g < n_groups; ++g) log_det_a += w.blocks[(size_t)g]->log_det;  // fixed order
-  }
-  (void)hipFree(w.Pbuf); w.Pbuf = nullptr;
-  stage("blocks of A, W, y_w");
-  double *W = w.Kuf;
-
-  // M = B^T B = (K_uu + nugget I) + W W^T ; keep a symmetric copy of K_uu' for the refinement
-  SP_HIP(hipMalloc(&w.Ksym, sizeof(double) * (size_t)ldm * (size_t)m));
-  SP_HIP(hipMemcpyAsync(w.Ksym, w.M0, sizeof(double) * (size_t)ldm * (size_t)m, hipMemcpyDeviceToDevice, s));
-  launch_symmetrize(s, w.Ksym, ldm, m);
-  launch_negate(s, w.M0, ldm, m, nullptr);
-  launch_gemm_nt_sub(s, w.M0, ldm, W, ldk, false, W, ldk, false, m, m, n, true);
-  launch_negate(s, w.M0, ldm, m, nullptr);
-  stage("M = K_uu + W W^T");
-  st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma);
-  if (st != AGP_OK) SP_FAIL(st);
-  stage("factor M");
-
-  // CholeskyQR2: Q1^T = L1^-1 [W | L_u]  (m x (n + m)), G = Q1^T Q1 = L2 L2^T
-  {
-    double *Q1T = nullptr;
-    SP_HIP(hipMalloc(&Q1T, sizeof(double) * (size_t)ldk * (size_t)(n + m)));
-    w.Q1T = Q1T;
-    SP_HIP(hipMemcpyAsync(Q1T, W, sizeof(double) * (size_t)ldk * (size_t)n, hipMemcpyDeviceToDevice, s));
-    SP_HIP(hipMemcpy2DAsync(Q1T + (size_t)ldk * (size_t)n, sizeof(double) * (size_t)ldk, f->kuu->A,
-                            sizeof(double) * (size_t)f->kuu->lda, sizeof(double) * (size_t)m, (size_t)m,
-                            hipMemcpyDeviceToDevice, s));
-    launch_zero_upper(s, Q1T + (size_t)ldk * (size_t)n, ldk, m);  // K_uu^T/2 = L_u^T: its transpose L_u, lower
-    forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, Q1T, n + m, ldk);
-    SP_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
-    launch_gemm_nt_sub(s, w.M0, ldm, Q1T, ldk, false, Q1T, ldk, false, m, m, n + m, true);
-    launch_negate(s, w.M0, ldm, m, nullptr);
-    st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma2);
-    (void)hipFree(Q1T); w.Q1T = nullptr;
-    if (st != AGP_OK) SP_FAIL(st);
-  }
-  stage("CholeskyQR2 (Q1, L2)");
-
-  // x <- (B^T B)^-1 x = L1^-T (G^-1 (L1^-1 x))
-  auto sigma_solve = [&](double *xv) -> int {
-    forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, xv, 1, m);
-    const int e = agp_solve(ctx, f->sigma2, xv, 1, xv, AGP_DEVICE);
-    if (e != AGP_OK) return e;
-    backward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, xv, 1, m);
-    return AGP_OK;
-  };
-  // information v = (B^T B)^-1 B^T [y_w; 0]  (:370-373), then two refinement steps against B:
-  //   r = W (y_w - W^T v) - K_uu' v ,  v += (B^T B)^-1 r
-  launch_matvec(s, W, ldk, m, n, yw, w.partial, 1.0, 0.0, nullptr, bvec);
-  SP_HIP(hipMemcpyAsync(vvec, bvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
-  if ((st = sigma_solve(vvec)) != AGP_OK) SP_FAIL(st);
-  for (int it = 0; it < 2; ++it) {
-    launch_colvec_dot(s, W, ldk, m, n, vvec, -1.0, 1.0, yw, tvec);                  // t = y_w - W^T v
-    launch_matvec(s, w.Ksym, ldm, m, m, vvec, w.partial, 1.0, 0.0, nullptr, rvec);  // K_uu' v
-    launch_matvec(s, W, ldk, m, n, tvec, w.partial, 1.0, -1.0, rvec, dv);           // r = W t - K_uu' v
-    if ((st = sigma_solve(dv)) != AGP_OK) SP_FAIL(st);
-    launch_axpby(s, m, 1.0, vvec, 1.0, dv, vvec);
-  }
-  stage("information + refinement");
-  SP_HIP(hipMalloc(&f->v, sizeof(double) * (size_t)m));
-  SP_HIP(hipMemcpyAsync(f->v, vvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
-
-  // negative log likelihood (:524-596): log|K| = log|A| + log|B^T B| - log|K_uu'| ,
-  // y^T K^-1 y = y_w^T y_w - || L1^-1 W y_w ||^2
-  forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, bvec, 1, m);
-  forward_solve_mat(s, f->sigma2->A, m, f->sigma2->lda, f->sigma2->invd, bvec, 1, m);  // y_b = L2^-1 L1^-1 W y_w
-  launch_dot(s, yw, yw, n, ctx->d_scalars + 1);
-  launch_dot(s, bvec, bvec, m, ctx->d_scalars + 2);
-  SP_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (information) SP_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
-  SP_HIP(hipStreamSynchronize(s));
-  SP_HIP(hipGetLastError());
-  const double log_det = log_det_a + (f->sigma->log_det + f->sigma2->log_det) - f->kuu->log_det;
-  f->nll = 0.5 * (log_det + (ctx->h_scalars[1] - ctx->h_scalars[2]) + (double)n * std::log(2 * M_PI));
-  if (nll_out) *nll_out = f->nll;
-  dx.release();
-  if (out) *out = f;
-  else agp_sparse_fit_destroy(f);
-#undef SP_HIP
-#undef SP_FAIL
-  return AGP_OK;
-}
-
-int agp_sparse_nll(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t n_groups,
-                   const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
-                   double measurement_nugget, double inducing_nugget, double *out) {
-  if (!out) return AGP_ERR_INVALID_ARGUMENT;
-  return agp_sparse_fit_create(ctx, k, x, n_groups, offsets, y, y_var, u, measurement_nugget, inducing_nugget, nullptr,
-                               nullptr, out);
-}
-
-int agp_sparse_fit_information(agp_context *ctx, const agp_sparse_fit *f, double *information) {
-  if (!ctx || !f || !information) return AGP_ERR_INVALID_ARGUMENT;
-  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  return copy_out(ctx, f->v, f->m, information, AGP_HOST);
-}
-
-// _predict_impl x 3 (sparse_gp.hpp:447-521): mean = K_*u v ; C = K_** - Q_sqrt^T Q_sqrt + S_sqrt^T S_sqrt with
-// Q_sqrt = K_uu^-1/2 K_u* = L_u^-1 K_u* and S_sqrt = R^-T P^T K_u* == L2^-1 L1^-1 K_u*
-static int sparse_predict_common(agp_context *ctx, const agp_kernel *k, const agp_sparse_fit *f, const agp_features *xs,
-                                 double *mean, double *var_or_cov, int mode, int out_location) {
-  if (!ctx || !k || !f || !xs || !mean || (mode > 0 && !var_or_cov)) return AGP_ERR_INVALID_ARGUMENT;
-  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int st = validate_features(xs);
-  if (st != AGP_OK) return st;
-  if (xs->dim != f->u.v.dim) return AGP_ERR_INVALID_ARGUMENT;
-  const long long M = xs->n, m = f->m;
-  if (M == 0) return AGP_OK;
-  const DevProgram *dprog = nullptr;
-  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
-  DeviceFeatures dxs;
-  if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
-  const long long ldq = round_up(m, 2), ldc = round_up(M, 2);
-  const size_t q_elems = (size_t)ldq * (size_t)M;
-  const size_t p_elems = mode == 2 ? (size_t)ldc * (size_t)M : (size_t)ldc;
-  st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (2 * q_elems + (size_t)ldc + p_elems));
-  if (st != AGP_OK) { dxs.release(); return st; }
-  double *Q = ctx->ws_aux, *S = Q + q_elems, *mean_d = S + q_elems, *prior = mean_d + ldc;
-  hipStream_t s = ctx->stream;
-  launch_predict_mean(s, dprog, f->u.v, dxs.v, f->v, mean_d, &k->prog);
-  if (mode > 0) {
-    launch_gram(s, dprog, f->u.v, dxs.v, false, false, Q, ldq, nullptr, nullptr, &k->prog);
-    (void)hipMemcpyAsync(S, Q, sizeof(double) * q_elems, hipMemcpyDeviceToDevice, s);
-    forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, Q, M, ldq);
-    forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, S, M, ldq);
-    forward_solve_mat(s, f->sigma2->A, m, f->sigma2->lda, f->sigma2->invd, S, M, ldq);
-  }
-  if (mode == 1) {
-    launch_gram_diagonal(s, dprog, dxs.v, prior);
-    launch_coldot(s, Q, ldq, Q, ldq, m, M, prior, 1.0, prior);   // - Q_diag
-    launch_coldot(s, S, ldq, S, ldq, m, M, prior, -1.0, prior);  // + S_diag
-  } else if (mode == 2) {
-    launch_gram(s, dprog, dxs.v, dxs.v, true, false, prior, ldc, nullptr, nullptr, &k->prog);
-    launch_gemm_nt_sub(s, prior, ldc, Q, ldq, true, Q, ldq, true, M, M, m, true);  // - max_explained
-    launch_axpby(s, (long long)q_elems, -1.0, S, 0.0, nullptr, Q);  // Q <- -S
-    launch_gemm_nt_sub(s, prior, ldc, Q, ldq, true, S, ldq, true, M, M, m, true);  // + unexplained
-    launch_symmetrize(s, prior, ldc, M);
-  }
-  st = copy_out(ctx, mean_d, M, mean, out_location);
-  if (st == AGP_OK && mode == 1) st = copy_out(ctx, prior, M, var_or_cov, out_location);
-  if (st == AGP_OK && mode == 2) st = copy_out_2d(ctx, prior, ldc, M, M, var_or_cov, M, out_location);
-  dxs.release();
-  return st;
-}
-
-int agp_sparse_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_sparse_fit *f, const agp_features *xs,
-                            double *mean, int out_location) {
-  return sparse_predict_common(ctx, k, f, xs, mean, nullptr, 0, out_location);
-}
-int agp_sparse_predict_marginal(agp_context *ctx, const agp_kernel *k, const agp_sparse_fit *f,
-                                const agp_features *xs, double *mean, double *variance, int out_location) {
-  return sparse_predict_common(ctx, k, f, xs, mean, variance, 1, out_location);
-}
-int agp_sparse_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_sparse_fit *f, const agp_features *xs,
-                             double *mean, double *covariance, int out_location) {
-  return sparse_predict_common(ctx, k, f, xs, mean, covariance, 2, out_location);
 }
 
 // ---- predict ---------------------------------------------------------------

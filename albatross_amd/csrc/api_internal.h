@@ -1,0 +1,75 @@
+// api_internal.h — host-side helpers shared by the translation units that implement the C-ABI
+// (api.hip: context / Gram / dense fit / predict; cv_api.hip: leave-one-group-out;
+// sparse_api.hip: sparse GP).  Not part of the public interface.
+#pragma once
+#include <atomic>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace agp {
+void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n);
+void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n);
+void launch_set_identity(hipStream_t s, double *B, long long ld, long long n);
+void launch_nan_scan_lower(hipStream_t s, const double *A, long long ld, long long n, int *flag);
+void launch_upper_to_lower(hipStream_t s, const double *src, long long ld_src, double *dst, long long ld_dst,
+                           long long n);
+void launch_gather_cols(hipStream_t s, const double *R, long long ldr, const long long *idx, long long m,
+                        long long row0, long long n, double *G, long long ldg);
+void launch_gather_vec(hipStream_t s, const double *src, const long long *idx, long long m, const double *sub,
+                       double *out);
+void launch_negate(hipStream_t s, double *A, long long ld, long long m, double *diag_out);
+void launch_matvec(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *x,
+                   double *partial, double alpha, double beta, const double *base, double *out);
+void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,
+                       double alpha, double beta, const double *base, double *out);
+void launch_axpby(hipStream_t s, long long n, double a, const double *x, double b, const double *y, double *out);
+void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const double *information, long long n,
+                double *mean, double *variance);
+long long round_up(long long x, long long m);
+long long factor_ld(long long n);
+}  // namespace agp
+
+struct ProgSlot {
+  unsigned long long uid = 0;
+  agp::DevProgram *dev = nullptr;
+};
+
+struct agp_context_ext {
+  ProgSlot slots[8];
+  int next = 0;
+};
+
+extern std::atomic<unsigned long long> g_kernel_uid;
+
+struct agp_kernel_full : agp_kernel {
+  unsigned long long uid;
+};
+
+
+struct agp_context_impl : agp_context {
+  agp_context_ext ext;
+  std::vector<hipEvent_t> gemm_events;
+  std::vector<double> gemm_flops;
+  hipEvent_t stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double *partial_ws = nullptr;
+  size_t partial_bytes = 0;
+  double gemm_ms_sum = 0., gemm_flop_sum = 0.;
+  int gemm_launches = 0;
+  // helper contexts (own streams / workspaces) for host threads that work through independent
+  // small problems concurrently (the blocks of a sparse GP); created on first use
+  std::vector<agp_context *> helpers;
+};
+
+// device copy of a kernel program (small LRU ring per context)
+int device_program(agp_context *ctx, const agp_kernel *k, const agp::DevProgram **out);
+int validate_features(const agp_features *f);
+// device view of a feature vector (uploads host data; `copy` forces an owned device copy)
+int to_device(agp_context *ctx, const agp_features *f, bool copy, agp::DeviceFeatures *out);
+int ensure_ws(agp_context *ctx, double **ws, size_t *have, size_t need);
+int vector_to_device(agp_context *ctx, const double *src, long long n, int location, double *dst);
+int copy_out(agp_context *ctx, const double *dev, long long count, double *dst, int location);
+int copy_out_2d(agp_context *ctx, const double *dev, long long ld_dev, long long rows, long long cols, double *dst,
+                long long ld_dst, int location);
+int status_from_flags(const agp_context *ctx);
