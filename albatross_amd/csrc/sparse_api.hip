@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <thread>
 
@@ -11,41 +12,44 @@
 
 using namespace agp;
 
-extern "C" {
-
 // ---- sparse Gaussian process (FITC / PITC) -----------------------------------------
 // SparseGaussianProcessRegression (include/albatross/src/models/sparse_gp.hpp).  The reference
 // stores Sigma = (K_uu + K_uf A^-1 K_fu)^-1 through the pivoted Householder QR of
-// B = [A^-1/2 K_fu; K_uu^T/2] (:343-352); only R^T R = B^T B enters any result, so the device path
-// forms  M = B^T B = K_uu + W W^T  (W = K_uf A^-T/2, one MFMA SYRK), factors it with the same
-// LL^T kernels (M = L1 L1^T, i.e. R = L1^T up to the column permutation) and removes the squared
-// LL^T kernels.  Forming B^T B squares the condition number, which the reference's QR avoids, so
-// the factor is repaired the CholeskyQR2 way: Q1^T = L1^-1 B^T is formed explicitly (one more
-// triangular solve over all n columns), Q1^T Q1 = I + O(eps cond) is factored again (L2), and
-// B^T B = (L1 L2)(L1 L2)^T holds to working accuracy: log|R|, R^-T x and the information vector
-// (plus two refinement steps against B itself) then agree with the QR-based reference algorithm to ~1e-9 even
-// with cond(K_uu) ~ 1e7.  K_uu and every block of A use LL^T as well.
+// B = [A^-1/2 K_fu; K_uu^T/2] (:343-352); only R^T R = B^T B enters any result.  The device path
+// works on B^T = [T | W] (m x (m + n), column-major: every product is a panel-major MFMA GEMM),
+// T = L_u the root of K_uu, W = K_uf A^-T/2, forms M = B^T B = T T^T + W W^T (MFMA SYRK) and factors
+// it with the LL^T kernels (L1).  Forming B^T B squares the condition number, which the reference's
+// QR avoids, so the factor is repaired the CholeskyQR2 way: Q1^T = L1^-1 B^T is formed explicitly
+// (one more triangular solve over all columns), Q1^T Q1 = I + O(eps cond) is factored again (L2),
+// and B^T B = (L1 L2)(L1 L2)^T holds to working accuracy: log|R|, R^-T x and the information
+// vector (plus two refinement steps against B itself) then agree with the QR-based reference
+// algorithm to ~1e-8 even with cond(K_uu) ~ 1e7.  K_uu and every block of A use LL^T as well.
+// L_acc = L1 L2 (the transpose of the reference's R P^T, up to an orthogonal factor) is kept for
+// FitModel::update.
 struct agp_sparse_fit {
   agp_context *ctx = nullptr;
   long long m = 0;
-  DeviceFeatures u;            // train_features = inducing points
-  agp_fit *kuu = nullptr;      // train_covariance = factor of K_uu + inducing_nugget I
-  agp_fit *sigma = nullptr;    // L1: LL^T of M = B^T B as formed in floating point
-  agp_fit *sigma2 = nullptr;   // L2: LL^T of Q1^T Q1, Q1 = B L1^-T (CholeskyQR2: B^T B = L1 L2 L2^T L1^T to working accuracy)
-  double *v = nullptr;         // information (m)
+  std::shared_ptr<DeviceFeatures> u;   // train_features = inducing points (shared with updated fits)
+  std::shared_ptr<agp_fit> kuu;        // train_covariance = factor of K_uu + inducing_nugget I
+  agp_fit *sigma = nullptr;            // L1
+  agp_fit *sigma2 = nullptr;           // L2
+  double *Lacc = nullptr;              // L1 L2, m x ldm, zero above the diagonal
+  double *v = nullptr;                 // information (m)
   double nll = 0.;
 };
 
 namespace {
 
 struct SparseScratch {
-  double *Kuf = nullptr, *Pbuf = nullptr, *M0 = nullptr, *Ksym = nullptr, *vecs = nullptr, *partial = nullptr,
+  double *Kuf = nullptr, *Pbuf = nullptr, *M0 = nullptr, *T = nullptr, *vecs = nullptr, *partial = nullptr,
          *Ag = nullptr, *Pimg = nullptr, *Q1T = nullptr;
   std::vector<agp_fit *> blocks;
+  DeviceFeatures dx;
   ~SparseScratch() {
-    (void)hipFree(Kuf); (void)hipFree(Pbuf); (void)hipFree(M0); (void)hipFree(Ksym); (void)hipFree(vecs);
+    (void)hipFree(Kuf); (void)hipFree(Pbuf); (void)hipFree(M0); (void)hipFree(T); (void)hipFree(vecs);
     (void)hipFree(partial); (void)hipFree(Ag); (void)hipFree(Pimg); (void)hipFree(Q1T);
     for (agp_fit *b : blocks) agp_fit_destroy(b);
+    dx.release();
   }
 };
 
@@ -58,112 +62,75 @@ FeatView feature_rows(const FeatView &v, long long o, long long cnt) {
   return r;
 }
 
-}  // namespace
+// AGP_SPARSE_TIMING=1: wall time of every stage (with a stream synchronisation at each boundary) on stderr
+struct StageTimer {
+  hipStream_t s;
+  bool on;
+  std::chrono::steady_clock::time_point last;
+  explicit StageTimer(hipStream_t st) : s(st), on(getenv("AGP_SPARSE_TIMING") != nullptr), last(std::chrono::steady_clock::now()) {}
+  void operator()(const char *name) {
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "  [sparse fit] %-28s %8.2f ms\n", name, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+  }
+};
 
-void agp_sparse_fit_destroy(agp_sparse_fit *f) {
-  if (!f) return;
-  if (f->ctx) (void)hipSetDevice(f->ctx->device);
-  f->u.release();
-  if (f->kuu) agp_fit_destroy(f->kuu);
-  if (f->sigma) agp_fit_destroy(f->sigma);
-  if (f->sigma2) agp_fit_destroy(f->sigma2);
-  if (f->v) (void)hipFree(f->v);
-  delete f;
-}
+#define SPX_HIP(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+      return AGP_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
 
-int64_t agp_sparse_fit_size(const agp_sparse_fit *f) { return f ? f->m : 0; }
-
-int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t n_groups,
-                          const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
-                          double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
-                          double *information, double *nll_out) {
-  if (!ctx || !k || !x || !u || !y || !offsets || n_groups <= 0) return AGP_ERR_INVALID_ARGUMENT;
-  if (out) *out = nullptr;
-  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int st = validate_features(x);
-  if (st == AGP_OK) st = validate_features(u);
-  if (st != AGP_OK) return st;
-  const long long n = x->n, m = u->n;
-  if (n <= 0 || m <= 0 || u->dim != x->dim || offsets[0] != 0 || offsets[n_groups] != n) return AGP_ERR_INVALID_ARGUMENT;
+// The data-dependent half of compute_internal_components (sparse_gp.hpp:642-704) for one set of
+// observations: uploads x / y / y_var, builds K_uf, P = L_u^-1 K_uf, the blocks of
+// A = K_ff + target variance - P_g^T P_g + measurement nugget with their LL^T, and returns
+//   w.Kuf = W = K_uf A^-T/2 (m x n, ld round_up(m, 2)),   yw = A^-1/2 y (inside w.vecs),   log|A|.
+int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram *dprog, const agp_features *x,
+                        int64_t n_groups, const int64_t *offsets, const double *y, const double *y_var,
+                        double measurement_nugget, const FeatView &uv, const agp_fit *kuu, SparseScratch &w,
+                        double **yw_out, double *log_det_a_out, StageTimer &stage) {
+  const long long n = x->n, m = uv.n;
+  hipStream_t s = ctx->stream;
+  int st = AGP_OK;
   long long smax = 0;
   for (int64_t g = 0; g < n_groups; ++g) {
     const long long sg = offsets[g + 1] - offsets[g];
     if (sg <= 0) return AGP_ERR_INVALID_ARGUMENT;
     if (sg > smax) smax = sg;
   }
-  const DevProgram *dprog = nullptr;
-  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
-  hipStream_t s = ctx->stream;
-
-  agp_sparse_fit *f = new (std::nothrow) agp_sparse_fit();
-  if (!f) return AGP_ERR_INVALID_ARGUMENT;
-  f->ctx = ctx; f->m = m;
-  SparseScratch w;
-  // AGP_SPARSE_TIMING=1: wall time of every stage (with a stream synchronisation at each boundary) on stderr
-  static const bool timing = getenv("AGP_SPARSE_TIMING") != nullptr;
-  auto t_last = std::chrono::steady_clock::now();
-  auto stage = [&](const char *name) {
-    if (!timing) return;
-    (void)hipStreamSynchronize(s);
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "  [sparse fit] %-28s %8.2f ms\n", name, std::chrono::duration<double, std::milli>(now - t_last).count());
-    t_last = now;
-  };
-  DeviceFeatures dx;
-#define SP_FAIL(code) do { dx.release(); agp_sparse_fit_destroy(f); return (code); } while (0)
-#define SP_HIP(expr)                                                                     \
-  do {                                                                                   \
-    hipError_t _e = (expr);                                                              \
-    if (_e != hipSuccess) {                                                              \
-      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
-      SP_FAIL(AGP_ERR_HIP);                                                              \
-    }                                                                                    \
-  } while (0)
-  if ((st = to_device(ctx, u, true, &f->u)) != AGP_OK) SP_FAIL(st);
-  if ((st = to_device(ctx, x, false, &dx)) != AGP_OK) SP_FAIL(st);
-  FeatView xm = dx.v;
+  if ((st = to_device(ctx, x, false, &w.dx)) != AGP_OK) return st;
+  FeatView xm = w.dx.v;
   xm.meas = 1;  // as_measurements(out_of_order_features), sparse_gp.hpp:649-650
-
-  const long long ldm = factor_ld(m), ldk = round_up(m, 2), np2 = round_up(n, 2), mp2 = round_up(m, 2);
-  const long long chunks = (n + 1023) / 1024;
-  // vectors: dvar (n) | yw (n) | t (n) | nug (m) | b (m) | v (m) | r (m) | dv (m)
-  SP_HIP(hipMalloc(&w.vecs, sizeof(double) * (size_t)(3 * np2 + 5 * mp2)));
-  double *dvar = w.vecs, *yw = dvar + np2, *tvec = yw + np2, *nug = tvec + np2, *bvec = nug + mp2, *vvec = bvec + mp2,
-         *rvec = vvec + mp2, *dv = rvec + mp2;
-  SP_HIP(hipMalloc(&w.partial, sizeof(double) * (size_t)(chunks > 0 ? chunks : 1) * (size_t)m));
+  const long long ldk = round_up(m, 2), np2 = round_up(n, 2);
+  // vectors: dvar (n) | yw (n) | t (n)
+  SPX_HIP(hipMalloc(&w.vecs, sizeof(double) * (size_t)(3 * np2)));
+  double *dvar = w.vecs, *yw = dvar + np2, *tvec = yw + np2;
   const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-  SP_HIP(hipMemcpyAsync(yw, y, sizeof(double) * (size_t)n, kind, s));
+  SPX_HIP(hipMemcpyAsync(yw, y, sizeof(double) * (size_t)n, kind, s));
   if (y_var) {
-    SP_HIP(hipMemcpyAsync(tvec, y_var, sizeof(double) * (size_t)n, kind, s));
-    if (x->location == AGP_HOST) SP_HIP(hipStreamSynchronize(s));
-    launch_axpby(s, n, 1.0, tvec, measurement_nugget, nullptr, dvar);   // target variance + measurement nugget, :692-696
+    SPX_HIP(hipMemcpyAsync(tvec, y_var, sizeof(double) * (size_t)n, kind, s));
+    if (x->location == AGP_HOST) SPX_HIP(hipStreamSynchronize(s));
+    launch_axpby(s, n, 1.0, tvec, measurement_nugget, nullptr, dvar);  // target variance + measurement nugget, :692-696
   } else {
-    if (x->location == AGP_HOST) SP_HIP(hipStreamSynchronize(s));
+    if (x->location == AGP_HOST) SPX_HIP(hipStreamSynchronize(s));
     launch_axpby(s, n, 0.0, nullptr, measurement_nugget, nullptr, dvar);
   }
-  launch_axpby(s, m, 0.0, nullptr, inducing_nugget, nullptr, nug);
-
   stage("upload");
-  // K_uu + inducing_nugget I  (:674-679) -> LL^T
-  SP_HIP(hipMalloc(&w.M0, sizeof(double) * (size_t)ldm * (size_t)m));
-  SP_HIP(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
-  launch_gram(s, dprog, f->u.v, f->u.v, true, true, w.M0, ldm, nug, ctx->d_flags, &k->prog);
-  st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->kuu);
-  if (st != AGP_OK) SP_FAIL(st);
-
-  stage("K_uu + factor");
   // K_uf (m x n) and P = K_uu^-1/2 K_uf = L_u^-1 K_uf  (:669-685)
-  SP_HIP(hipMalloc(&w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n));
-  SP_HIP(hipMalloc(&w.Pbuf, sizeof(double) * (size_t)ldk * (size_t)n));
-  launch_gram(s, dprog, f->u.v, xm, false, false, w.Kuf, ldk, nullptr, nullptr, &k->prog);
-  SP_HIP(hipMemcpyAsync(w.Pbuf, w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n, hipMemcpyDeviceToDevice, s));
-  forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, w.Pbuf, n, ldk);
-
-  // A = K_ff (block diagonal) + target variance - diag blocks of P^T P + measurement nugget, block LL^T
-  // (:652-704); then W = K_uf A^-T/2 (in place in K_uf) and y_w = A^-1/2 y, block by block (B's top block
-  // transposed, :347-349; :372).
-  SP_HIP(hipStreamSynchronize(s));
+  SPX_HIP(hipMalloc(&w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n));
+  SPX_HIP(hipMalloc(&w.Pbuf, sizeof(double) * (size_t)ldk * (size_t)n));
+  launch_gram(s, dprog, uv, xm, false, false, w.Kuf, ldk, nullptr, nullptr, &k->prog);
+  SPX_HIP(hipMemcpyAsync(w.Pbuf, w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n, hipMemcpyDeviceToDevice, s));
+  forward_solve_mat(s, kuu->A, m, kuu->lda, kuu->invd, w.Pbuf, n, ldk);
+  SPX_HIP(hipStreamSynchronize(s));
   stage("K_uf, P = L_u^-1 K_uf");
+  // A block by block, then W = K_uf A^-T/2 (in place in K_uf) and y_w = A^-1/2 y  (:652-704; B's top block
+  // transposed, :347-349; :372)
   bool uniform = true;
   for (int64_t g = 0; g < n_groups; ++g) uniform = uniform && (offsets[g + 1] - offsets[g] == smax);
   double log_det_a = 0.;
@@ -173,11 +140,11 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_featu
     // is what the per-block path below is bound by (the HIP launch path is serial per process).
     const long long sb = smax, lda_b = factor_ld(sb), nblk_b = (sb + NB - 1) / NB;
     const long long stride_A = lda_b * sb, stride_I = nblk_b * (36 * MB * MB);
-    SP_HIP(hipMalloc(&w.Ag, sizeof(double) * (size_t)stride_A * (size_t)n_groups));
-    SP_HIP(hipMalloc(&w.Pimg, sizeof(double) * ((size_t)stride_I + 1) * (size_t)n_groups));
+    SPX_HIP(hipMalloc(&w.Ag, sizeof(double) * (size_t)stride_A * (size_t)n_groups));
+    SPX_HIP(hipMalloc(&w.Pimg, sizeof(double) * ((size_t)stride_I + 1) * (size_t)n_groups));
     double *logsum = w.Pimg + (size_t)stride_I * (size_t)n_groups;
-    SP_HIP(hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)n_groups, s));
-    SP_HIP(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
+    SPX_HIP(hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)n_groups, s));
+    SPX_HIP(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
     for (int64_t g = 0; g < n_groups; ++g) {
       const FeatView xg = feature_rows(xm, g * sb, sb);
       launch_gram(s, dprog, xg, xg, true, true, w.Ag + g * stride_A, lda_b, dvar + g * sb, ctx->d_flags, &k->prog);
@@ -189,11 +156,11 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_featu
     factor_lower_batched(s, w.Ag, stride_A, sb, lda_b, w.Pimg, stride_I, yw, sb, n_groups, ctx->d_flags, logsum);
     right_solve_lt_batched(s, w.Ag, stride_A, sb, lda_b, w.Pimg, stride_I, w.Kuf, sb * ldk, m, ldk, n_groups);
     std::vector<double> hl((size_t)n_groups);
-    SP_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    SP_HIP(hipMemcpyAsync(hl.data(), logsum, sizeof(double) * (size_t)n_groups, hipMemcpyDeviceToHost, s));
-    SP_HIP(hipStreamSynchronize(s));
-    SP_HIP(hipGetLastError());
-    if ((st = status_from_flags(ctx)) != AGP_OK) SP_FAIL(st);
+    SPX_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipMemcpyAsync(hl.data(), logsum, sizeof(double) * (size_t)n_groups, hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipStreamSynchronize(s));
+    SPX_HIP(hipGetLastError());
+    if ((st = status_from_flags(ctx)) != AGP_OK) return st;
     for (int64_t g = 0; g < n_groups; ++g) log_det_a += 2. * hl[(size_t)g];  // fixed order
   } else {
     // ragged groups: one block at a time, T host threads on T helper contexts (own streams)
@@ -207,7 +174,7 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_featu
     const int T = (int)std::min<long long>(want_threads, n_groups);
     while ((int)ci->helpers.size() < T) {
       agp_context *h = nullptr;
-      if ((st = agp_context_create(ctx->device, &h)) != AGP_OK) SP_FAIL(st);
+      if ((st = agp_context_create(ctx->device, &h)) != AGP_OK) return st;
       ci->helpers.push_back(h);
     }
     w.blocks.assign((size_t)n_groups, nullptr);
@@ -247,44 +214,51 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_featu
     for (int t = 0; t < T; ++t)
       if (status[(size_t)t] != AGP_OK) {
         ctx->last_error = errors[(size_t)t];
-        SP_FAIL(status[(size_t)t]);
+        return status[(size_t)t];
       }
     for (int64_t g = 0; g < n_groups; ++g) log_det_a += w.blocks[(size_t)g]->log_det;  // fixed order
   }
   (void)hipFree(w.Pbuf); w.Pbuf = nullptr;
   stage("blocks of A, W, y_w");
-  double *W = w.Kuf;
+  *yw_out = yw;
+  *log_det_a_out = log_det_a;
+  return AGP_OK;
+}
 
-  // M = B^T B = (K_uu + nugget I) + W W^T ; keep a symmetric copy of K_uu' for the refinement
-  SP_HIP(hipMalloc(&w.Ksym, sizeof(double) * (size_t)ldm * (size_t)m));
-  SP_HIP(hipMemcpyAsync(w.Ksym, w.M0, sizeof(double) * (size_t)ldm * (size_t)m, hipMemcpyDeviceToDevice, s));
-  launch_symmetrize(s, w.Ksym, ldm, m);
+// Sigma^-1 = B^T B for B^T = [T | W] and the information vector v = (B^T B)^-1 (T y_t + W y_w):
+//   T   m x m lower-triangular root of the "prior" part (zero above the diagonal, ld ldt):
+//       L_u for a fit (compute_sigma_qr, :343-352), the old L_acc for an update (:336-339)
+//   W   m x n (ld ldk), y_w (n);  y_t (m) or nullptr (zero)
+// Fills f->sigma (L1), f->sigma2 (L2), f->Lacc, f->v.  bq (optional, device, 1 double) receives
+// || L2^-1 L1^-1 (T y_t + W y_w) ||^2 for the likelihood.
+int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long ldt, const double *W, long long ldk,
+                 long long n, const double *yw, const double *yt, SparseScratch &w, double *bq, StageTimer &stage) {
+  const long long m = f->m, ldm = factor_ld(m), mp2 = round_up(m, 2), np2 = round_up(std::max<long long>(n, 1), 2);
+  hipStream_t s = ctx->stream;
+  int st = AGP_OK;
+  // M = T T^T + W W^T
+  SPX_HIP(hipMalloc(&w.M0, sizeof(double) * (size_t)ldm * (size_t)m));
+  SPX_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
+  launch_gemm_nt_sub(s, w.M0, ldm, T, ldt, false, T, ldt, false, m, m, m, true);
+  if (n > 0) launch_gemm_nt_sub(s, w.M0, ldm, W, ldk, false, W, ldk, false, m, m, n, true);
   launch_negate(s, w.M0, ldm, m, nullptr);
-  launch_gemm_nt_sub(s, w.M0, ldm, W, ldk, false, W, ldk, false, m, m, n, true);
-  launch_negate(s, w.M0, ldm, m, nullptr);
-  stage("M = K_uu + W W^T");
-  st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma);
-  if (st != AGP_OK) SP_FAIL(st);
+  stage("M = T T^T + W W^T");
+  if ((st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma)) != AGP_OK) return st;
   stage("factor M");
-
-  // CholeskyQR2: Q1^T = L1^-1 [W | L_u]  (m x (n + m)), G = Q1^T Q1 = L2 L2^T
-  {
-    double *Q1T = nullptr;
-    SP_HIP(hipMalloc(&Q1T, sizeof(double) * (size_t)ldk * (size_t)(n + m)));
-    w.Q1T = Q1T;
-    SP_HIP(hipMemcpyAsync(Q1T, W, sizeof(double) * (size_t)ldk * (size_t)n, hipMemcpyDeviceToDevice, s));
-    SP_HIP(hipMemcpy2DAsync(Q1T + (size_t)ldk * (size_t)n, sizeof(double) * (size_t)ldk, f->kuu->A,
-                            sizeof(double) * (size_t)f->kuu->lda, sizeof(double) * (size_t)m, (size_t)m,
-                            hipMemcpyDeviceToDevice, s));
-    launch_zero_upper(s, Q1T + (size_t)ldk * (size_t)n, ldk, m);  // K_uu^T/2 = L_u^T: its transpose L_u, lower
-    forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, Q1T, n + m, ldk);
-    SP_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
-    launch_gemm_nt_sub(s, w.M0, ldm, Q1T, ldk, false, Q1T, ldk, false, m, m, n + m, true);
-    launch_negate(s, w.M0, ldm, m, nullptr);
-    st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma2);
-    (void)hipFree(Q1T); w.Q1T = nullptr;
-    if (st != AGP_OK) SP_FAIL(st);
-  }
+  // CholeskyQR2: Q1^T = L1^-1 [T | W]  (m x (m + n)), G = Q1^T Q1 = L2 L2^T
+  SPX_HIP(hipMalloc(&w.Q1T, sizeof(double) * (size_t)ldk * (size_t)(n + m)));
+  SPX_HIP(hipMemcpy2DAsync(w.Q1T, sizeof(double) * (size_t)ldk, T, sizeof(double) * (size_t)ldt, sizeof(double) * (size_t)m,
+                           (size_t)m, hipMemcpyDeviceToDevice, s));
+  if (n > 0)
+    SPX_HIP(hipMemcpyAsync(w.Q1T + (size_t)ldk * (size_t)m, W, sizeof(double) * (size_t)ldk * (size_t)n,
+                           hipMemcpyDeviceToDevice, s));
+  forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, w.Q1T, n + m, ldk);
+  SPX_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
+  launch_gemm_nt_sub(s, w.M0, ldm, w.Q1T, ldk, false, w.Q1T, ldk, false, m, m, n + m, true);
+  launch_negate(s, w.M0, ldm, m, nullptr);
+  st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma2);
+  (void)hipFree(w.Q1T); w.Q1T = nullptr;
+  if (st != AGP_OK) return st;
   stage("CholeskyQR2 (Q1, L2)");
 
   // x <- (B^T B)^-1 x = L1^-T (G^-1 (L1^-1 x))
@@ -295,40 +269,177 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_featu
     backward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, xv, 1, m);
     return AGP_OK;
   };
-  // information v = (B^T B)^-1 B^T [y_w; 0]  (:370-373), then two refinement steps against B:
-  //   r = W (y_w - W^T v) - K_uu' v ,  v += (B^T B)^-1 r
-  launch_matvec(s, W, ldk, m, n, yw, w.partial, 1.0, 0.0, nullptr, bvec);
-  SP_HIP(hipMemcpyAsync(vvec, bvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
-  if ((st = sigma_solve(vvec)) != AGP_OK) SP_FAIL(st);
+  // vectors: b | v | r | dv | tt (m each) | t (n) ; partial sums of the mat-vecs
+  double *mv = nullptr;
+  SPX_HIP(hipMalloc(&mv, sizeof(double) * (size_t)(5 * mp2 + np2)));
+  std::unique_ptr<double, void (*)(double *)> mv_guard(mv, [](double *p) { (void)hipFree(p); });
+  double *bvec = mv, *vvec = bvec + mp2, *rvec = vvec + mp2, *dv = rvec + mp2, *tt = dv + mp2, *tvec = tt + mp2;
+  const long long cols = std::max(n, m), chunks = (cols + 1023) / 1024;
+  SPX_HIP(hipMalloc(&w.partial, sizeof(double) * (size_t)chunks * (size_t)m));
+  // b = T y_t + W y_w   (B^T y_aug: :370-372 for a fit, :344-350 for an update)
+  if (n > 0) launch_matvec(s, W, ldk, m, n, yw, w.partial, 1.0, 0.0, nullptr, bvec);
+  else launch_axpby(s, m, 0.0, nullptr, 0.0, nullptr, bvec);
+  if (yt) launch_matvec(s, T, ldt, m, m, yt, w.partial, 1.0, 1.0, bvec, bvec);
+  SPX_HIP(hipMemcpyAsync(vvec, bvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
+  if ((st = sigma_solve(vvec)) != AGP_OK) return st;
+  // two refinement steps against B itself: r = W (y_w - W^T v) + T (y_t - T^T v), v += (B^T B)^-1 r
   for (int it = 0; it < 2; ++it) {
-    launch_colvec_dot(s, W, ldk, m, n, vvec, -1.0, 1.0, yw, tvec);                  // t = y_w - W^T v
-    launch_matvec(s, w.Ksym, ldm, m, m, vvec, w.partial, 1.0, 0.0, nullptr, rvec);  // K_uu' v
-    launch_matvec(s, W, ldk, m, n, tvec, w.partial, 1.0, -1.0, rvec, dv);           // r = W t - K_uu' v
-    if ((st = sigma_solve(dv)) != AGP_OK) SP_FAIL(st);
+    launch_colvec_dot(s, T, ldt, m, m, vvec, -1.0, 1.0, yt, tt);
+    launch_matvec(s, T, ldt, m, m, tt, w.partial, 1.0, 0.0, nullptr, rvec);
+    if (n > 0) {
+      launch_colvec_dot(s, W, ldk, m, n, vvec, -1.0, 1.0, yw, tvec);
+      launch_matvec(s, W, ldk, m, n, tvec, w.partial, 1.0, 1.0, rvec, rvec);
+    }
+    SPX_HIP(hipMemcpyAsync(dv, rvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
+    if ((st = sigma_solve(dv)) != AGP_OK) return st;
     launch_axpby(s, m, 1.0, vvec, 1.0, dv, vvec);
   }
+  SPX_HIP(hipMalloc(&f->v, sizeof(double) * (size_t)m));
+  SPX_HIP(hipMemcpyAsync(f->v, vvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
+  if (bq) {  // y_b = R^-T P^T B^T y_aug = L2^-1 L1^-1 b  (:590)
+    forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, bvec, 1, m);
+    forward_solve_mat(s, f->sigma2->A, m, f->sigma2->lda, f->sigma2->invd, bvec, 1, m);
+    launch_dot(s, bvec, bvec, m, bq);
+  }
   stage("information + refinement");
-  SP_HIP(hipMalloc(&f->v, sizeof(double) * (size_t)m));
-  SP_HIP(hipMemcpyAsync(f->v, vvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
+  // L_acc = L1 L2 (for update): C = 0 - L1z (L2z^T)^T, negated
+  SPX_HIP(hipMalloc(&f->Lacc, sizeof(double) * (size_t)ldm * (size_t)m));
+  {
+    double *L1z = w.M0;  // m x ldm scratch, no longer needed
+    double *L2z = nullptr;
+    SPX_HIP(hipMalloc(&L2z, sizeof(double) * (size_t)ldm * (size_t)m));
+    std::unique_ptr<double, void (*)(double *)> g2(L2z, [](double *p) { (void)hipFree(p); });
+    SPX_HIP(hipMemcpy2DAsync(L1z, sizeof(double) * (size_t)ldm, f->sigma->A, sizeof(double) * (size_t)f->sigma->lda,
+                             sizeof(double) * (size_t)m, (size_t)m, hipMemcpyDeviceToDevice, s));
+    SPX_HIP(hipMemcpy2DAsync(L2z, sizeof(double) * (size_t)ldm, f->sigma2->A, sizeof(double) * (size_t)f->sigma2->lda,
+                             sizeof(double) * (size_t)m, (size_t)m, hipMemcpyDeviceToDevice, s));
+    launch_zero_upper(s, L1z, ldm, m);
+    launch_zero_upper(s, L2z, ldm, m);
+    SPX_HIP(hipMemsetAsync(f->Lacc, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
+    launch_gemm_nt_sub(s, f->Lacc, ldm, L1z, ldm, false, L2z, ldm, true, m, m, m, false);
+    launch_negate(s, f->Lacc, ldm, m, nullptr);
+    SPX_HIP(hipStreamSynchronize(s));
+  }
+  SPX_HIP(hipGetLastError());
+  return AGP_OK;
+}
 
-  // negative log likelihood (:524-596): log|K| = log|A| + log|B^T B| - log|K_uu'| ,
-  // y^T K^-1 y = y_w^T y_w - || L1^-1 W y_w ||^2
-  forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, bvec, 1, m);
-  forward_solve_mat(s, f->sigma2->A, m, f->sigma2->lda, f->sigma2->invd, bvec, 1, m);  // y_b = L2^-1 L1^-1 W y_w
-  launch_dot(s, yw, yw, n, ctx->d_scalars + 1);
-  launch_dot(s, bvec, bvec, m, ctx->d_scalars + 2);
-  SP_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (information) SP_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
-  SP_HIP(hipStreamSynchronize(s));
-  SP_HIP(hipGetLastError());
+}  // namespace
+
+extern "C" {
+
+void agp_sparse_fit_destroy(agp_sparse_fit *f) {
+  if (!f) return;
+  if (f->ctx) (void)hipSetDevice(f->ctx->device);
+  f->u.reset();
+  f->kuu.reset();
+  if (f->sigma) agp_fit_destroy(f->sigma);
+  if (f->sigma2) agp_fit_destroy(f->sigma2);
+  if (f->Lacc) (void)hipFree(f->Lacc);
+  if (f->v) (void)hipFree(f->v);
+  delete f;
+}
+
+int64_t agp_sparse_fit_size(const agp_sparse_fit *f) { return f ? f->m : 0; }
+
+int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t n_groups,
+                          const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
+                          double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
+                          double *information, double *nll_out) {
+  if (!ctx || !k || !x || !u || !y || !offsets || n_groups <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  if (out) *out = nullptr;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(x);
+  if (st == AGP_OK) st = validate_features(u);
+  if (st != AGP_OK) return st;
+  const long long n = x->n, m = u->n;
+  if (n <= 0 || m <= 0 || u->dim != x->dim || offsets[0] != 0 || offsets[n_groups] != n) return AGP_ERR_INVALID_ARGUMENT;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  hipStream_t s = ctx->stream;
+  StageTimer stage(s);
+  std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
+  if (!f) return AGP_ERR_INVALID_ARGUMENT;
+  f->ctx = ctx; f->m = m;
+  SparseScratch w;
+  f->u = std::shared_ptr<DeviceFeatures>(new DeviceFeatures(), [](DeviceFeatures *d) { d->release(); delete d; });
+  if ((st = to_device(ctx, u, true, f->u.get())) != AGP_OK) return st;
+
+  // K_uu + inducing_nugget I  (:674-679) -> LL^T ; T = L_u with explicit zeros above the diagonal
+  const long long ldm = factor_ld(m);
+  double *nug = nullptr;
+  SPX_HIP(hipMalloc(&nug, sizeof(double) * (size_t)round_up(m, 2)));
+  std::unique_ptr<double, void (*)(double *)> nug_guard(nug, [](double *p) { (void)hipFree(p); });
+  launch_axpby(s, m, 0.0, nullptr, inducing_nugget, nullptr, nug);
+  SPX_HIP(hipMalloc(&w.T, sizeof(double) * (size_t)ldm * (size_t)m));
+  launch_gram(s, dprog, f->u->v, f->u->v, true, true, w.T, ldm, nug, nullptr, &k->prog);
+  {
+    agp_fit *kuu = nullptr;
+    st = agp_factor_create(ctx, w.T, m, ldm, 0, AGP_DEVICE, &kuu);
+    f->kuu = std::shared_ptr<agp_fit>(kuu, [](agp_fit *p) { agp_fit_destroy(p); });
+    if (st != AGP_OK) return st;
+  }
+  SPX_HIP(hipMemcpy2DAsync(w.T, sizeof(double) * (size_t)ldm, f->kuu->A, sizeof(double) * (size_t)f->kuu->lda,
+                           sizeof(double) * (size_t)m, (size_t)m, hipMemcpyDeviceToDevice, s));
+  launch_zero_upper(s, w.T, ldm, m);  // K_uu^T/2 = L_u^T (sqrt_transpose, :349): its transpose L_u
+  stage("K_uu + factor");
+
+  double *yw = nullptr, log_det_a = 0.;
+  if ((st = sparse_observations(ctx, k, dprog, x, n_groups, offsets, y, y_var, measurement_nugget, f->u->v, f->kuu.get(), w,
+                                &yw, &log_det_a, stage)) != AGP_OK)
+    return st;
+  if ((st = sparse_sigma(ctx, f.get(), w.T, ldm, w.Kuf, round_up(m, 2), n, yw, nullptr, w, ctx->d_scalars + 2, stage)) != AGP_OK)
+    return st;
+  launch_dot(s, yw, yw, n, ctx->d_scalars + 1);  // y^T A^-1 y = y_w^T y_w  (:583-592); after the factor calls, which reset the scalars
+  // negative log likelihood (:524-596): log|K| = log|A| + log|B^T B| - log|K_uu'|
+  SPX_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (information) SPX_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
+  SPX_HIP(hipStreamSynchronize(s));
+  SPX_HIP(hipGetLastError());
   const double log_det = log_det_a + (f->sigma->log_det + f->sigma2->log_det) - f->kuu->log_det;
   f->nll = 0.5 * (log_det + (ctx->h_scalars[1] - ctx->h_scalars[2]) + (double)n * std::log(2 * M_PI));
   if (nll_out) *nll_out = f->nll;
-  dx.release();
-  if (out) *out = f;
-  else agp_sparse_fit_destroy(f);
-#undef SP_HIP
-#undef SP_FAIL
+  if (out) *out = f.release();
+  return AGP_OK;
+}
+
+// FitModel::update for the sparse GP: _update_impl (sparse_gp.hpp:322-371).  B = [R_old P_old^T; A^-1/2 K_fu],
+// y_aug = [R_old P_old^T v_old; A^-1/2 y]: with the kept root L_acc (L_acc L_acc^T = Sigma_old^-1) that is
+// B^T = [L_acc | W_new], y_t = L_acc^T v_old.  The inducing points and their K_uu factor are shared with the old fit.
+int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *k, const agp_sparse_fit *old, const agp_features *x,
+                          int64_t n_groups, const int64_t *offsets, const double *y, const double *y_var,
+                          double measurement_nugget, agp_sparse_fit **out, double *information) {
+  if (!ctx || !k || !old || !x || !y || !offsets || !out || n_groups <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(x);
+  if (st != AGP_OK) return st;
+  const long long n = x->n, m = old->m;
+  if (n <= 0 || x->dim != old->u->v.dim || offsets[0] != 0 || offsets[n_groups] != n) return AGP_ERR_INVALID_ARGUMENT;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  hipStream_t s = ctx->stream;
+  StageTimer stage(s);
+  std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
+  if (!f) return AGP_ERR_INVALID_ARGUMENT;
+  f->ctx = ctx; f->m = m;
+  f->u = old->u;
+  f->kuu = old->kuu;
+  SparseScratch w;
+  double *yw = nullptr, log_det_a = 0.;
+  if ((st = sparse_observations(ctx, k, dprog, x, n_groups, offsets, y, y_var, measurement_nugget, f->u->v, f->kuu.get(), w,
+                                &yw, &log_det_a, stage)) != AGP_OK)
+    return st;
+  const long long ldm = factor_ld(m);
+  double *yt = nullptr;
+  SPX_HIP(hipMalloc(&yt, sizeof(double) * (size_t)round_up(m, 2)));
+  std::unique_ptr<double, void (*)(double *)> yt_guard(yt, [](double *p) { (void)hipFree(p); });
+  launch_colvec_dot(s, old->Lacc, ldm, m, m, old->v, 1.0, 0.0, nullptr, yt);  // y_t = L_acc^T v_old  (:344-347)
+  if ((st = sparse_sigma(ctx, f.get(), old->Lacc, ldm, w.Kuf, round_up(m, 2), n, yw, yt, w, nullptr, stage)) != AGP_OK) return st;
+  if (information) SPX_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
+  SPX_HIP(hipStreamSynchronize(s));
+  f->nll = std::nan("");  // the likelihood of an updated fit is not defined by the reference
+  *out = f.release();
   return AGP_OK;
 }
 
@@ -354,7 +465,7 @@ static int sparse_predict_common(agp_context *ctx, const agp_kernel *k, const ag
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   int st = validate_features(xs);
   if (st != AGP_OK) return st;
-  if (xs->dim != f->u.v.dim) return AGP_ERR_INVALID_ARGUMENT;
+  if (xs->dim != f->u->v.dim) return AGP_ERR_INVALID_ARGUMENT;
   const long long M = xs->n, m = f->m;
   if (M == 0) return AGP_OK;
   const DevProgram *dprog = nullptr;
@@ -368,9 +479,9 @@ static int sparse_predict_common(agp_context *ctx, const agp_kernel *k, const ag
   if (st != AGP_OK) { dxs.release(); return st; }
   double *Q = ctx->ws_aux, *S = Q + q_elems, *mean_d = S + q_elems, *prior = mean_d + ldc;
   hipStream_t s = ctx->stream;
-  launch_predict_mean(s, dprog, f->u.v, dxs.v, f->v, mean_d, &k->prog);
+  launch_predict_mean(s, dprog, f->u->v, dxs.v, f->v, mean_d, &k->prog);
   if (mode > 0) {
-    launch_gram(s, dprog, f->u.v, dxs.v, false, false, Q, ldq, nullptr, nullptr, &k->prog);
+    launch_gram(s, dprog, f->u->v, dxs.v, false, false, Q, ldq, nullptr, nullptr, &k->prog);
     (void)hipMemcpyAsync(S, Q, sizeof(double) * q_elems, hipMemcpyDeviceToDevice, s);
     forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, Q, M, ldq);
     forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, S, M, ldq);

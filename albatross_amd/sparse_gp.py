@@ -83,6 +83,22 @@ class SparseFitModel:
     def predict_with_measurement_noise(self, features):
         return Prediction(self, features if isinstance(features, Measurement) else Measurement(features))
 
+    def update(self, dataset, targets=None):
+        """FitModel::update -> _update_impl (:322-371): fold further observations into the fit; the inducing
+        points stay.  Returns a new SparseFitModel."""
+        if targets is not None:
+            dataset = RegressionDataset(dataset, targets)
+        m, ctx = self._model, self._model._ctx()
+        cov = m.covariance_function_
+        reordered, offsets, y, yv = m._group(dataset)
+        fx = cov.features(reordered)
+        sx = fx.as_struct()
+        h = C.c_void_p()
+        ctx._check(ctx._lib.agp_sparse_fit_update(ctx._h, ctx.kernel(cov), self._fit._h, C.byref(sx), len(offsets) - 1,
+                                                  _ptr(offsets), _ptr(y), _ptr(yv), m.measurement_nugget_, C.byref(h),
+                                                  None), "agp_sparse_fit_update")
+        return SparseFitModel(m, SparseGPFit(ctx, h, self._fit.train_features, float("nan")))
+
     def _call(self, fn, features, n_out):
         m, ctx = self._model, self._model._ctx()
         fs = m.covariance_function_.features(features)
@@ -164,8 +180,15 @@ class SparseGaussianProcessRegression:
             self.set_param(k, v)
 
     def _components(self, dataset):
-        """The host part of compute_internal_components (:642-668): group_by(features, grouper).indexers()
-        in key order, reordered_inds, subset of features / targets."""
+        """The host part of compute_internal_components (:642-668) plus the inducing point strategy (:358-360)."""
+        reordered, offsets, y, yv = self._group(dataset)
+        u = self.inducing_point_strategy_(self.covariance_function_, _values_of(dataset.features))
+        if len(u) == 0:
+            raise ValueError("Empty inducing points!")  # :361
+        return reordered, offsets, y, yv, u
+
+    def _group(self, dataset):
+        """group_by(features, grouper).indexers() in key order, reordered_inds, subset of features / targets."""
         feats = _values_of(dataset.features)
         n = len(feats)
         groups = {}
@@ -181,10 +204,7 @@ class SparseGaussianProcessRegression:
         yv = None
         if dataset.targets.covariance is not None:
             yv = np.ascontiguousarray(np.asarray(dataset.targets.covariance, dtype=np.float64)[order])
-        u = self.inducing_point_strategy_(self.covariance_function_, feats)
-        if len(u) == 0:
-            raise ValueError("Empty inducing points!")  # :361
-        return reordered, offsets, y, yv, u
+        return reordered, offsets, y, yv
 
     def _create(self, dataset, want_fit):
         ctx = self._ctx()

@@ -184,6 +184,30 @@ int main() {
     std::printf("sparse_cov_err,%.17g\n", std::sqrt(ec));
     std::printf("sparse_loglik,%.17g\n", sparse.log_likelihood(tds));
     for (std::size_t i = 0; i < sfit.get_fit().information.size(); ++i) std::printf("sparse_info,%zu,%.17g\n", i, sfit.get_fit().information[i]);
+    // update == full fit (tests/test_sparse_gp.cc:293-371): hold out the first interval, then fold it back in
+    {
+      std::vector<double> xa, xb;
+      Vector ya, yb;
+      for (int i = 0; i < 10; ++i) (tx[i] < 5. ? xa : xb).push_back(tx[i]), (tx[i] < 5. ? ya : yb).push_back(ty[i]);
+      struct FixedInducingPoints {  // tests/test_sparse_gp.cc:219-235: the same inducing points for every dataset
+        std::vector<double> operator()(const decltype(scov) &, const std::vector<double> &) const {
+          return UniformlySpacedInducingPoints(8)(0, std::vector<double>{0., 9.});
+        }
+      };
+      auto fixed = sparse_gp_from_covariance(scov, grouper, FixedInducingPoints(), "sparse_fixed");
+      fixed.set_param_value(details::inducing_nugget_name(), 1e-3);
+      fixed.set_param_value(details::measurement_nugget_name(), 1e-12);
+      const auto upd = fixed.fit(RegressionDataset<double>(xb, yb)).update(RegressionDataset<double>(xa, ya));
+      const auto up = upd.predict_with_measurement_noise(txs).joint();
+      const auto fp = fixed.fit(tds).predict_with_measurement_noise(txs).joint();
+      double um = 0., uc = 0.;
+      for (int i = 0; i < 11; ++i) {
+        um = std::fmax(um, std::fabs(up.mean[i] - fp.mean[i]));
+        for (int j = 0; j < 11; ++j) uc = std::fmax(uc, std::fabs(up.covariance(i, j) - fp.covariance(i, j)));
+      }
+      std::printf("sparse_update_mean_diff,%.17g\n", um);
+      std::printf("sparse_update_cov_diff,%.17g\n", uc);
+    }
     const auto sm = sfit.predict(txs).marginal();
     for (int i = 0; i < 11; ++i) std::printf("sparse_pred,%d,%.17g,%.17g,%.17g\n", i, sfit.predict(txs).mean()[i], sm.mean[i], sm.covariance[i]);
   }

@@ -270,6 +270,16 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *kernel, const agp_
 void agp_sparse_fit_destroy(agp_sparse_fit *fit);
 int64_t agp_sparse_fit_size(const agp_sparse_fit *fit); /* number of inducing points */
 int agp_sparse_fit_information(agp_context *ctx, const agp_sparse_fit *fit, double *information);
+/* FitModel::update for a sparse fit: _update_impl (sparse_gp.hpp:322-371).  Further observations (grouped
+ * like those of agp_sparse_fit_create; wrapped as measurements inside) are folded into `old` through
+ * B = [R_old P_old^T; A^-1/2 K_fu],  y_aug = [R_old P_old^T v_old; A^-1/2 y]; the inducing points and their
+ * K_uu factor are shared with `old`, which stays valid.  Returns a NEW handle in *out; information
+ * (m doubles, host) is optional.  (fit_from_prediction / rebase_inducing_points, :383-445, need the
+ * rank-revealing factorisations of a singular K_zz and stay on the caller's side.) */
+int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *old,
+                          const agp_features *x, int64_t n_groups, const int64_t *offsets, const double *y,
+                          const double *y_var, double measurement_nugget, agp_sparse_fit **out,
+                          double *information);
 int agp_sparse_nll(agp_context *ctx, const agp_kernel *kernel, const agp_features *x, int64_t n_groups,
                    const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
                    double measurement_nugget, double inducing_nugget, double *out);

@@ -21,6 +21,7 @@
 #define ALBATROSS_AMD_ALBATROSS_HPP
 
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -1248,6 +1249,28 @@ class SparseFitModel {
     return SparsePrediction<ModelType, InducingFeature, Measurement<P>>(this, as_measurements(features));
   }
 
+  // FitModel::update -> _update_impl (:322-371): fold further observations into the fit (the inducing points stay)
+  template <typename FeatureType>
+  SparseFitModel update(const RegressionDataset<FeatureType> &dataset) const {
+    const auto grouped = model_.group(dataset);
+    detail::KernelHolder k(model_.get_covariance().program());
+    detail::Flat fx = detail::flatten(model_.get_covariance(), grouped.features);
+    SparseGPFit<InducingFeature> fit;
+    fit.train_features = fit_.train_features;
+    fit.context = fit_.context;
+    fit.information.resize(fit_.information.size());
+    fit.negative_log_likelihood = std::nan("");
+    agp_context *c = fit.context->ctx;
+    agp_sparse_fit *h = nullptr;
+    detail::check(agp_sparse_fit_update(c, k.k, fit_.handle.get(), &fx.view, static_cast<std::int64_t>(grouped.offsets.size() - 1),
+                                        grouped.offsets.data(), grouped.y.data(), grouped.yv.empty() ? nullptr : grouped.yv.data(),
+                                        model_.measurement_nugget(), &h, fit.information.data()),
+                  c, "agp_sparse_fit_update");
+    auto ctx = fit.context;
+    fit.handle = std::shared_ptr<agp_sparse_fit>(h, [ctx](agp_sparse_fit *p) { agp_sparse_fit_destroy(p); });
+    return SparseFitModel(model_, std::move(fit));
+  }
+
   // _predict_impl x 3 (:447-521); mode 0: mean, 1: marginal (diagonal filled), 2: joint
   template <typename P>
   JointDistribution predict_(const std::vector<P> &xs, int mode) const {
@@ -1335,30 +1358,50 @@ class SparseGaussianProcessRegression {
     return -fit.negative_log_likelihood;
   }
 
- private:
-  // the host half of compute_internal_components (:642-668) + the device call
-  template <typename FeatureType, typename U>
-  void run(const RegressionDataset<FeatureType> &dataset, SparseGPFit<U> *fit, bool keep) const {
+  double measurement_nugget() const { return measurement_nugget_; }
+
+  // the host half of compute_internal_components (:642-668): group_by(features, grouper).indexers() in key
+  // order, reordered_inds, subsets of features / targets
+  template <typename FeatureType>
+  struct Grouped {
+    std::vector<FeatureType> features;
+    std::vector<std::int64_t> offsets;
+    Vector y, yv;
+  };
+  template <typename FeatureType>
+  Grouped<FeatureType> group(const RegressionDataset<FeatureType> &dataset) const {
     const std::size_t n = dataset.features.size();
     if (n != dataset.targets.size()) throw std::invalid_argument("features and targets differ in size");
     using Key = typename std::decay<decltype(independent_group_function_(dataset.features[0]))>::type;
-    std::map<Key, std::vector<std::size_t>> indexer;  // group_by(features, grouper).indexers()
+    std::map<Key, std::vector<std::size_t>> indexer;
     for (std::size_t i = 0; i < n; ++i) indexer[independent_group_function_(dataset.features[i])].push_back(i);
     std::vector<std::size_t> reordered_inds;
-    std::vector<std::int64_t> offsets(1, 0);
+    Grouped<FeatureType> g;
+    g.offsets.assign(1, 0);
     for (const auto &kv : indexer) {
       reordered_inds.insert(reordered_inds.end(), kv.second.begin(), kv.second.end());
-      offsets.push_back(static_cast<std::int64_t>(reordered_inds.size()));
+      g.offsets.push_back(static_cast<std::int64_t>(reordered_inds.size()));
     }
-    std::vector<FeatureType> features(n);
-    Vector y(n), yv;
+    g.features.resize(n);
+    g.y.resize(n);
     const bool has_var = !dataset.targets.covariance.empty();
-    if (has_var) yv.resize(n);
+    if (has_var) g.yv.resize(n);
     for (std::size_t a = 0; a < n; ++a) {
-      features[a] = dataset.features[reordered_inds[a]];
-      y[a] = dataset.targets.mean[reordered_inds[a]];  // y is copied BEFORE the mean function is removed (:664-668)
-      if (has_var) yv[a] = dataset.targets.covariance[reordered_inds[a]];
+      g.features[a] = dataset.features[reordered_inds[a]];
+      g.y[a] = dataset.targets.mean[reordered_inds[a]];  // y is copied BEFORE the mean function is removed (:664-668)
+      if (has_var) g.yv[a] = dataset.targets.covariance[reordered_inds[a]];
     }
+    return g;
+  }
+
+ private:
+  template <typename FeatureType, typename U>
+  void run(const RegressionDataset<FeatureType> &dataset, SparseGPFit<U> *fit, bool keep) const {
+    const Grouped<FeatureType> grouped = group(dataset);
+    const std::vector<FeatureType> &features = grouped.features;
+    const std::vector<std::int64_t> &offsets = grouped.offsets;
+    const Vector &y = grouped.y, &yv = grouped.yv;
+    const bool has_var = !yv.empty();
     fit->train_features = inducing_point_strategy_(covariance_function_, dataset.features);
     if (fit->train_features.empty()) throw std::invalid_argument("Empty inducing points!");  // :361
     fit->context = detail::default_context();

@@ -1281,3 +1281,65 @@ ORC_API void orc_sparse_predict(const orc_sparse_fit *f, const agp_kernel_node *
   }
   free(cross);
 }
+
+/* _update_impl (sparse_gp.hpp:322-371): B = [R_old P_old^T; A^-1/2 K_fu], y_aug = [R_old P_old^T v_old; A^-1/2 y];
+ * the new fit keeps the old inducing points and train_covariance.  The inducing nugget passed here is the
+ * model's current one (compute_internal_components recomputes K_uu_ldlt for P, :674-685). */
+ORC_API orc_sparse_fit *orc_sparse_fit_update(const orc_sparse_fit *old, const agp_kernel_node *prog, int n_nodes,
+                                              const agp_features *x, const int64_t *group_key, const double *y,
+                                              const double *y_var, double measurement_nugget,
+                                              double inducing_nugget) {
+  const int64_t n = x->n, m = old->m;
+  sparse_parts *p = sparse_components(prog, n_nodes, x, group_key, y, y_var, &old->u, measurement_nugget,
+                                      inducing_nugget);
+  const int64_t rows = m + n;
+  double *B = calloc((size_t)(rows * m), sizeof(double));
+  /* top: R_old P_old^T   (P^T permutes the columns: column perm[i] of the product is column i of R) */
+  for (int64_t i = 0; i < m; ++i)
+    for (int64_t r = 0; r < m; ++r) B[r + old->perm[i] * rows] = old->R[r + i * m];
+  for (int64_t g = 0; g < p->n_groups; ++g) {
+    const int64_t o = p->offsets[g], s = p->offsets[g + 1] - o;
+    double *blk = malloc(sizeof(double) * (size_t)(s * m));
+    for (int64_t c = 0; c < m; ++c)
+      for (int64_t a = 0; a < s; ++a) blk[a + c * s] = p->K_fu[(o + a) + c * n];
+    ldlt_sqrt_solve(p->a_ldlt[g], s, s, p->a_tr[g], blk, m, s);
+    for (int64_t c = 0; c < m; ++c)
+      for (int64_t a = 0; a < s; ++a) B[(m + o + a) + c * rows] = blk[a + c * s];
+    free(blk);
+  }
+  orc_qr *q = colpiv_qr(B, rows, m);
+  double *y_aug = calloc((size_t)rows, sizeof(double));
+  /* y_aug.top = R_old (P_old^T v_old) */
+  double *pv = malloc(sizeof(double) * (size_t)m);
+  for (int64_t i = 0; i < m; ++i) pv[i] = old->information[old->perm[i]];
+  for (int64_t r = 0; r < m; ++r) {
+    double s = 0.;
+    for (int64_t i = r; i < m; ++i) s += old->R[r + i * m] * pv[i];
+    y_aug[r] = s;
+  }
+  sparse_a_apply(p, p->y, y_aug + m, 0);
+  orc_sparse_fit *f = calloc(1, sizeof(orc_sparse_fit));
+  f->m = m;
+  f->information = malloc(sizeof(double) * (size_t)m);
+  qr_solve(q, y_aug, f->information);
+  f->R = malloc(sizeof(double) * (size_t)(m * m));
+  for (int64_t j = 0; j < m; ++j)
+    for (int64_t i = 0; i < m; ++i) f->R[i + j * m] = (i <= j) ? q->qr[i + j * rows] : 0.;
+  if (q->rank < m) /* "Inflate the diagonal of R in an attempt to avoid singularity" (:361-365) */
+    for (int64_t i = 0; i < m; ++i) f->R[i + i * m] += 1.e-10;
+  f->perm = malloc(sizeof(int64_t) * (size_t)m);
+  memcpy(f->perm, q->perm, sizeof(int64_t) * (size_t)m);
+  f->numerical_rank = q->rank;
+  f->nll = NAN;
+  f->kuu_ldlt = malloc(sizeof(double) * (size_t)(m * m));
+  memcpy(f->kuu_ldlt, old->kuu_ldlt, sizeof(double) * (size_t)(m * m));
+  f->kuu_tr = malloc(sizeof(int64_t) * (size_t)m);
+  memcpy(f->kuu_tr, old->kuu_tr, sizeof(int64_t) * (size_t)m);
+  int64_t *all = malloc(sizeof(int64_t) * (size_t)(m + 1));
+  for (int64_t i = 0; i < m; ++i) all[i] = i;
+  f->u = subset_features(&old->u, all, m, old->u.is_measurement, &f->coords_copy, &f->eq_copy, &f->scales_copy);
+  free(all); free(pv); free(y_aug); free(B);
+  qr_free(q);
+  sparse_parts_free(p);
+  return f;
+}

@@ -60,6 +60,8 @@ def lib():
         L.orc_fit_held_out.argtypes = [V, V, I64, V, V, V, V, V]
         L.orc_sparse_fit_create.restype = V
         L.orc_sparse_fit_create.argtypes = [PN, C.c_int, PF, V, V, V, PF, C.c_double, C.c_double]
+        L.orc_sparse_fit_update.restype = V
+        L.orc_sparse_fit_update.argtypes = [V, PN, C.c_int, PF, V, V, V, C.c_double, C.c_double]
         L.orc_sparse_fit_destroy.argtypes = [V]
         L.orc_sparse_fit_information.argtypes = [V, V]
         L.orc_sparse_fit_rank.restype = I64
@@ -299,6 +301,18 @@ class OracleSparseFit:
         self.m = int(fu.n)
         self.h = lib().orc_sparse_fit_create(self._p, self._n, C.byref(fx), _ptr(keys), _ptr(y), _ptr(yv),
                                              C.byref(fu), measurement_nugget, inducing_nugget)
+
+    def update(self, x, group_keys, y, y_var, measurement_nugget=1e-8, inducing_nugget=1e-8):
+        """_update_impl (:322-371): a new OracleSparseFit with the further observations folded in."""
+        fx, kx = _feat(self.cov, x, False)
+        keys = np.ascontiguousarray(group_keys, dtype=np.int64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        yv = None if y_var is None else np.ascontiguousarray(y_var, dtype=np.float64)
+        new = OracleSparseFit.__new__(OracleSparseFit)
+        new.cov, new._p, new._n, new.m = self.cov, self._p, self._n, self.m
+        new.h = lib().orc_sparse_fit_update(self.h, self._p, self._n, C.byref(fx), _ptr(keys), _ptr(y), _ptr(yv),
+                                            measurement_nugget, inducing_nugget)
+        return new
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -115,6 +115,7 @@ def test_cpp_api_matches_oracle():
     # sparse GP through the C++ surface: close to the direct GP (test_sparse_gp.cc:115-133 thresholds) and
     # equal to the oracle's QR-based restatement
     assert float(one["sparse_mean_err"]) < 1e-2 and float(one["sparse_cov_err"]) < 1e-2
+    assert float(one["sparse_update_mean_diff"]) < 1e-6 and float(one["sparse_update_cov_diff"]) < 1e-6
     tx = np.arange(10.)
     ty = np.array(golden_toy_y())
     scov = ab.SquaredExponential(100., 100.) + ab.measurement_only(ab.IndependentNoise(0.1))

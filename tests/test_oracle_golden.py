@@ -255,3 +255,25 @@ def test_sparse_gp_oracle_equals_dense_formulas():
     perm = rng.permutation(n)
     g = orc.OracleSparseFit(cov, x[perm], keys[perm], y[perm], yvar[perm], u, mn, inn)
     assert np.abs(g.information - f.information).max() < 1e-9 * np.abs(v).max()
+
+
+def test_sparse_gp_oracle_update_equals_full_fit():
+    # tests/test_sparse_gp.cc:293-371: partial fit + update with the held-out group == full fit (1e-6)
+    rng = np.random.default_rng(0)
+    n = 90
+    x = np.sort(rng.uniform(0, 20, n))
+    y = np.sin(x) + 0.1 * rng.standard_normal(n) + 0.3 * x
+    yvar = rng.uniform(0.01, 0.03, n)
+    cov = ab.SquaredExponential(3., 2.) + ab.measurement_only(ab.IndependentNoise(0.2))
+    u = np.linspace(x.min(), x.max(), 12)
+    keys = np.floor(x / 5.).astype(np.int64)
+    full = orc.OracleSparseFit(cov, x, keys, y, yvar, u, 1e-12, 1e-3)
+    held = keys == keys.min()
+    part = orc.OracleSparseFit(cov, x[~held], keys[~held], y[~held], yvar[~held], u, 1e-12, 1e-3)
+    upd = part.update(x[held], keys[held], y[held], yvar[held], 1e-12, 1e-3)
+    xs = np.linspace(0.01, 19.9, 11)
+    fm, fv, fj = full.predict(xs, xs_meas=True, joint=True)
+    pm, pv, pj = part.predict(xs, xs_meas=True, joint=True)
+    um, uv, uj = upd.predict(xs, xs_meas=True, joint=True)
+    assert np.linalg.norm(pm - fm) > 1e-2 and np.linalg.norm(pj - fj) > 1e-1
+    assert np.linalg.norm(um - fm) < 1e-9 and np.linalg.norm(uj - fj) < 1e-9

@@ -174,3 +174,57 @@ def test_sparse_error_paths(ctx):
     with pytest.raises(KeyError):
         bad.set_param("no_such_parameter", 1.0)
     assert np.isfinite(bad.log_likelihood(ab.RegressionDataset(x, yn)))
+
+
+def test_update_equals_full_fit(ctx):
+    """tests/test_sparse_gp.cc:293-371 (test_update): fit without the first group, update with it ==
+    fit on everything (1e-6 on mean / covariance), while the partial fit is clearly different."""
+    x, y = toy_linear()
+    cov = simple_cov(100.)
+    grouper = interval_grouper(5.0)
+    u = np.linspace(x.min(), x.max(), 8)  # FixedInducingPoints(min, max, 8)
+    sparse = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "sparse", context=ctx)
+    sparse.set_param_value("inducing_nugget", 1e-3)
+    sparse.set_param_value("measurement_nugget", 1e-12)
+    keys = np.array([grouper(f) for f in x])
+    held = keys == keys.min()
+    full = sparse.fit(ab.RegressionDataset(x, y))
+    partial = sparse.fit(ab.RegressionDataset(x[~held], y[~held]))
+    updated = partial.update(ab.RegressionDataset(x[held], y[held]))
+    xs = np.linspace(0.01, 9.9, 11)
+    fp, pp, up = (f.predict_with_measurement_noise(xs).joint() for f in (full, partial, updated))
+    assert np.linalg.norm(pp.mean - fp.mean) > 1e-2 and np.linalg.norm(pp.covariance - fp.covariance) > 1e-1
+    assert np.linalg.norm(up.mean - fp.mean) < 1e-6 and np.linalg.norm(up.covariance - fp.covariance) < 1e-6
+    assert np.abs(updated.get_fit().information - full.get_fit().information).max() < 1e-6
+    # the old handle is untouched and still predicts as before
+    assert np.array_equal(partial.predict_with_measurement_noise(xs).joint().mean, pp.mean)
+
+
+@pytest.mark.parametrize("n,m,gs", [(600, 40, 100), (1024, 96, 128)])
+def test_update_matches_oracle_and_chains(ctx, n, m, gs):
+    rng = np.random.default_rng(n)
+    x = np.sort(rng.uniform(0., 30., n))
+    y = np.sin(x) + 0.2 * x + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.04, n)
+    cov = ab.Matern52(3.0, 1.5) + ab.measurement_only(ab.IndependentNoise(0.2))
+    u = np.linspace(0., 30., m)
+    rank = {float(v): i for i, v in enumerate(x)}
+    grouper = lambda f: rank[float(f)] // gs
+    keys = np.array([grouper(f) for f in x])
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "sparse", context=ctx)
+    model.set_param("inducing_nugget", 1e-6)
+    first, second, third = keys < 2, (keys >= 2) & (keys < 4), keys >= 4
+    ds = lambda sel: ab.RegressionDataset(x[sel], ab.MarginalDistribution(y[sel], yvar[sel]))
+    chained = model.fit(ds(first)).update(ds(second)).update(ds(third))
+    o = orc.OracleSparseFit(cov, x[first], keys[first], y[first], yvar[first], u, 1e-8, 1e-6)
+    o = o.update(x[second], keys[second], y[second], yvar[second], 1e-8, 1e-6)
+    o = o.update(x[third], keys[third], y[third], yvar[third], 1e-8, 1e-6)
+    v = o.information
+    assert np.abs(chained.get_fit().information - v).max() <= 1e-6 * np.abs(v).max()
+    xs = np.linspace(0.5, 29.5, 33)
+    om, ov, oj = o.predict(xs, xs_meas=True, joint=True)
+    j = chained.predict_with_measurement_noise(xs).joint()
+    assert np.abs(j.mean - om).max() <= 1e-7 * max(1., np.abs(om).max())
+    assert np.abs(j.covariance - oj).max() <= 1e-7 * np.abs(oj).max()
+    full = model.fit(ds(np.ones(n, dtype=bool))).predict_with_measurement_noise(xs).joint()
+    assert np.abs(j.mean - full.mean).max() <= 1e-6 and np.abs(j.covariance - full.covariance).max() <= 1e-6
