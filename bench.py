@@ -324,7 +324,7 @@ def main():
             out["replicas"] = replicas
         if sharded_aux is not None:
             out["sharded_single_fit"] = sharded_aux
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
