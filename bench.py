@@ -123,11 +123,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # BENCH_SINGLE_DEVICE=1 (testing the N > 1 code path on a one-GPU box): every rank uses GPU 0 and the
+    # control collectives (barrier, max of the elapsed times) go over gloo - RCCL refuses two ranks per device.
+    single_device = os.environ.get("BENCH_SINGLE_DEVICE") == "1"
+    if single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     torch.cuda.init()  # torch's HIP runtime first, then the library's (albatross_amd/distributed.py)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = "gloo" if single_device else "nccl"
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+    ctl_device = f"cuda:{local_rank}" if backend == "nccl" else "cpu"  # where the timing scalars are reduced
 
     import albatross_amd as ab
     from albatross_amd import _capi as capi
@@ -191,7 +202,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=ctl_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -212,7 +223,7 @@ def main():
             replica_step()
         barrier()
         tr = time.perf_counter() - tr
-        t = torch.tensor([tr], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([tr], device=ctl_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         replicas = {"fits_per_sec": 3 * world / float(t.item()), "note": "one independent fit per GPU, no collective"}
     if world > 1 and not sharded and args.sharded_aux:
@@ -229,7 +240,7 @@ def main():
                 res = sf.fit(xs_h, ys_h)
             barrier()
             tr = time.perf_counter() - tr
-            t = torch.tensor([tr], device=f"cuda:{local_rank}", dtype=torch.float64)
+            t = torch.tensor([tr], device=ctl_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sharded_aux = {"single_fit_ms": 1e3 * float(t.item()) / 3, "fits_per_sec": 3 / float(t.item()),
                            "scaling": "strong",
