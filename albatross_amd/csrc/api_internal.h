@@ -27,6 +27,9 @@ void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m
 void launch_axpby(hipStream_t s, long long n, double a, const double *x, double b, const double *y, double *out);
 void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const double *information, long long n,
                 double *mean, double *variance);
+void launch_colvec_dot_batched(hipStream_t s, const double *Q, long long ld, long long stride_Q, long long m,
+                               const double *z, long long stride_z, long long count, double *out);
+void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);
 long long round_up(long long x, long long m);
 long long factor_ld(long long n);
 }  // namespace agp

@@ -779,6 +779,31 @@ void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long lon
   }
 }
 
+// B_b (n x m, ldb) <- L_b^-1 B_b for `count` problems (B_b = B + b * stride_B); rhs_lower as in forward_solve_mat
+void forward_solve_mat_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
+                               const double *invd, long long stride_invd, double *B, long long stride_B, long long m,
+                               long long ldb, bool rhs_lower, long long count) {
+  if (m <= 0 || count <= 0) return;
+  for (long long k = 0; k < n; k += NB) {
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    const long long m_act = (rhs_lower && k + nbk < m) ? k + nbk : m;
+    TrsmArgs t;
+    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+    t.nbk = nbk;
+    t.Y = B + k;
+    t.stride_m = 1; t.stride_n = ldb;
+    t.ncols = m_act;
+    t.z = nullptr; t.yrest = nullptr;
+    t.batch_img = stride_invd; t.batch_Y = stride_B; t.n_total = 0;
+    hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m_act + 63) / 64), (unsigned)count), dim3(256), 0,
+                       s, t);
+    const long long rows = n - (k + nbk);
+    if (rows > 0)  // B[k + nbk :] -= L[k + nbk :, k : k + nbk] B[k : k + nbk]
+      launch_gemm_nt_sub_batched(s, B + k + nbk, ldb, stride_B, A + k * lda + (k + nbk), lda, false, stride_A, B + k, ldb,
+                                 true, stride_B, rows, m_act, nbk, false, count);
+  }
+}
+
 // X_b (nrows x n, ldx) <- X_b L_b^-T for `count` problems: X_b = X + b * stride_X, L_b = A + b * stride_A
 void right_solve_lt_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
                             const double *invd, long long stride_invd, double *X, long long stride_X, long long nrows,

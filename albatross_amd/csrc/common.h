@@ -137,6 +137,9 @@ void forward_solve_mat(hipStream_t s, const double *A, long long n, long long ld
 void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long long n, long long lda, double *invd,
                           long long stride_invd, double *y, long long stride_y, long long count, int *flags,
                           double *logsum);
+void forward_solve_mat_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
+                               const double *invd, long long stride_invd, double *B, long long stride_B, long long m,
+                               long long ldb, bool rhs_lower, long long count);
 void right_solve_lt_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
                             const double *invd, long long stride_invd, double *X, long long stride_X, long long nrows,
                             long long ldx, long long count);

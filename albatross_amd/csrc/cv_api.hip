@@ -79,6 +79,45 @@ int group_inverse_block(GroupWork *w, const int64_t *indices, long long off, lon
   return AGP_OK;
 }
 
+// ---- equal group sizes: every group in lock step through batched launches -------------------
+struct UniformGroups {
+  double *Gall = nullptr, *Ball = nullptr, *img = nullptr, *Q = nullptr, *vecs = nullptr;
+  ~UniformGroups() { (void)hipFree(Gall); (void)hipFree(Ball); (void)hipFree(img); (void)hipFree(Q); (void)hipFree(vecs); }
+};
+
+bool uniform_groups(int64_t n_groups, const int64_t *offsets, long long *m_out) {
+  if (n_groups < 2) return false;
+  const long long m = offsets[1] - offsets[0];
+  if (m <= 0) return false;
+  for (int64_t g = 0; g < n_groups; ++g)
+    if (offsets[g + 1] - offsets[g] != m) return false;
+  *m_out = m;
+  return true;
+}
+
+// Ball[g] (m x m slabs, ld ldb, stride ldb * m) = (K^-1)[I_g, I_g] for all groups: one gather, one batched product
+int uniform_inverse_blocks(GroupWork *w, long long count, long long m, UniformGroups *u) {
+  agp_context *ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  const long long total = count * m, ldb = factor_ld(m);
+  AGP_HIP_CHECK(ctx, hipMalloc(&u->Gall, sizeof(double) * (size_t)w->ldg * (size_t)total));
+  AGP_HIP_CHECK(ctx, hipMalloc(&u->Ball, sizeof(double) * (size_t)ldb * (size_t)total));
+  launch_gather_cols(s, w->R, w->ldr, w->idx, total, 0, w->n, u->Gall, w->ldg);
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(u->Ball, 0, sizeof(double) * (size_t)ldb * (size_t)total, s));
+  launch_gemm_nt_sub_batched(s, u->Ball, ldb, ldb * m, u->Gall, w->ldg, true, m * w->ldg, u->Gall, w->ldg, true, m * w->ldg, m,
+                             m, w->n, false, count);
+  launch_axpby(s, ldb * total, -1.0, u->Ball, 0.0, nullptr, u->Ball);
+  (void)hipFree(u->Gall); u->Gall = nullptr;
+  AGP_HIP_CHECK(ctx, hipGetLastError());
+  return AGP_OK;
+}
+
+// all columns of all slabs are ldb apart: the packed output is ONE pitched copy
+int copy_out_slabs(agp_context *ctx, const double *slabs, long long ld, long long m, long long count, double *dst,
+                   int location) {
+  return copy_out_2d(ctx, slabs, ld, m, m * count, dst, m, location);
+}
+
 }  // namespace
 
 int agp_fit_inverse_blocks(agp_context *ctx, const agp_fit *fit, int64_t n_groups, const int64_t *offsets,
@@ -88,6 +127,12 @@ int agp_fit_inverse_blocks(agp_context *ctx, const agp_fit *fit, int64_t n_group
   GroupWork w;
   int st = group_work_init(ctx, fit, n_groups, offsets, indices, &w);
   if (st != AGP_OK) return st;
+  long long mu = 0;
+  if (uniform_groups(n_groups, offsets, &mu)) {
+    UniformGroups u;
+    if ((st = uniform_inverse_blocks(&w, n_groups, mu, &u)) != AGP_OK) return st;
+    return copy_out_slabs(ctx, u.Ball, factor_ld(mu), mu, n_groups, blocks, out_location);
+  }
   for (int64_t g = 0; g < n_groups; ++g) {
     const long long off = offsets[g], m = offsets[g + 1] - off;
     if (m == 0) continue;
@@ -111,6 +156,45 @@ int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double 
   double *v = w.tmp, *x = v + mp, *mu = x + mp, *var = mu + mp, *yd = var + mp;
   if ((st = vector_to_device(ctx, y, n, location, yd)) != AGP_OK) return st;
   hipStream_t s = ctx->stream;
+  long long mu_sz = 0;
+  if (uniform_groups(n_groups, offsets, &mu_sz)) {
+    // equal group sizes: blocks, LL^T, inverses and solves of ALL groups in lock step (blockIdx.y = group)
+    const long long m = mu_sz, count = n_groups, total = count * m;
+    const long long ldb = factor_ld(m), nblk_b = (m + NB - 1) / NB, stride_B = ldb * m, stride_I = nblk_b * (36 * MB * MB);
+    UniformGroups u;
+    if ((st = uniform_inverse_blocks(&w, count, m, &u)) != AGP_OK) return st;
+    AGP_HIP_CHECK(ctx, hipMalloc(&u.img, sizeof(double) * ((size_t)stride_I * (size_t)count + (size_t)round_up(count, 2))));
+    AGP_HIP_CHECK(ctx, hipMalloc(&u.Q, sizeof(double) * (size_t)stride_B * (size_t)count));
+    AGP_HIP_CHECK(ctx, hipMalloc(&u.vecs, sizeof(double) * 3 * (size_t)round_up(total, 2)));
+    double *logsum = u.img + (size_t)stride_I * (size_t)count;
+    double *vz = u.vecs, *xs = vz + round_up(total, 2), *outv = xs + round_up(total, 2);
+    AGP_HIP_CHECK(ctx, hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)round_up(count, 2), s));
+    AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
+    // v_g = subset(information, indices); z_g = L_g^-1 v_g rides along the factorisation   (:175,181-182)
+    launch_gather_vec(s, fit->alpha, w.idx, total, nullptr, vz);
+    factor_lower_batched(s, u.Ball, stride_B, m, ldb, u.img, stride_I, vz, m, count, ctx->d_flags, logsum);
+    // R_g = L_g^-1 ;  A_g^-1 v_g = R_g^T z_g ;  inverse = R_g^T R_g
+    launch_set_identity_batched(s, u.Q, ldb, stride_B, m, count);
+    forward_solve_mat_batched(s, u.Ball, stride_B, m, ldb, u.img, stride_I, u.Q, stride_B, m, ldb, /*rhs_lower=*/true, count);
+    launch_colvec_dot_batched(s, u.Q, ldb, stride_B, m, vz, m, count, xs);
+    launch_gather_vec(s, yd, w.idx, total, xs, outv);  // mean = y - A^-1 v
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if ((st = copy_out(ctx, outv, total, mean, location)) != AGP_OK) return st;
+    if ((st = status_from_flags(ctx)) != AGP_OK) return st;
+    if (variance) {  // diag(R^T R): the columns of all slabs are ldb apart
+      launch_coldot(s, u.Q, ldb, u.Q, ldb, m, total, outv, -1.0, nullptr);
+      if ((st = copy_out(ctx, outv, total, variance, location)) != AGP_OK) return st;
+    }
+    if (joint) {
+      AGP_HIP_CHECK(ctx, hipMemsetAsync(u.Ball, 0, sizeof(double) * (size_t)stride_B * (size_t)count, s));
+      launch_gemm_nt_sub_batched(s, u.Ball, ldb, stride_B, u.Q, ldb, true, stride_B, u.Q, ldb, true, stride_B, m, m, m, false,
+                                 count);
+      launch_axpby(s, stride_B * count, -1.0, u.Ball, 0.0, nullptr, u.Ball);
+      if ((st = copy_out_slabs(ctx, u.Ball, ldb, m, count, joint, location)) != AGP_OK) return st;
+    }
+    AGP_HIP_CHECK(ctx, hipGetLastError());
+    return AGP_OK;
+  }
   for (int64_t g = 0; g < n_groups; ++g) {
     const long long off = offsets[g], m = offsets[g + 1] - off;
     if (m == 0) continue;

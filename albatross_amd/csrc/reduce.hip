@@ -276,6 +276,43 @@ void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m
   hipLaunchKernelGGL(colvec_dot_kernel, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out);
 }
 
+// batched: out[b * m + j] = sum_i Q_b[i, j] z_b[i], Q_b = Q + b * stride_Q (m x m, ld), z_b = z + b * stride_z
+__global__ __launch_bounds__(256) void colvec_dot_batched_kernel(const double *__restrict__ Q, long long ld,
+                                                                 long long stride_Q, long long m,
+                                                                 const double *__restrict__ z, long long stride_z,
+                                                                 double *__restrict__ out) {
+  __shared__ double red[4];
+  const long long j = blockIdx.x, b = blockIdx.y;
+  const double *q = Q + b * stride_Q + j * ld;
+  const double *zb = z + b * stride_z;
+  double acc = 0.;
+  for (long long i = threadIdx.x; i < m; i += 256) acc += q[i] * zb[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b * m + j] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+void launch_colvec_dot_batched(hipStream_t s, const double *Q, long long ld, long long stride_Q, long long m,
+                               const double *z, long long stride_z, long long count, double *out) {
+  if (m <= 0 || count <= 0) return;
+  hipLaunchKernelGGL(colvec_dot_batched_kernel, dim3((unsigned)m, (unsigned)count), dim3(256), 0, s, Q, ld, stride_Q, m, z,
+                     stride_z, out);
+}
+
+// identity in every m x m slab (ld, stride) of `count`
+__global__ __launch_bounds__(256) void set_identity_batched_kernel(double *B, long long ld, long long stride, long long m) {
+  double *b = B + (long long)blockIdx.y * stride;
+  const long long col = blockIdx.x;
+  for (long long r = threadIdx.x; r < m; r += 256) b[col * ld + r] = (r == col) ? 1. : 0.;
+}
+
+void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count) {
+  if (m <= 0 || count <= 0) return;
+  hipLaunchKernelGGL(set_identity_batched_kernel, dim3((unsigned)m, (unsigned)count), dim3(256), 0, s, B, ld, stride, m);
+}
+
 // out[i] = a * x[i] + b * (y ? y[i] : 1)
 __global__ __launch_bounds__(256) void axpby_kernel(long long n, double a, const double *x, double b, const double *y,
                                                     double *out) {

@@ -141,3 +141,26 @@ def test_leave_one_group_out_config3_property(ctx):
     err = np.concatenate([p.mean - y[np.asarray(g)] for p, g in zip(preds, groups)])
     assert np.all(np.concatenate([p.covariance for p in preds]) > 0)
     assert np.sqrt(np.mean(err ** 2)) < 0.5
+
+
+@pytest.mark.parametrize("n,m", [(240, 40), (600, 150), (1024, 128), (900, 300)])
+def test_equal_size_groups_take_the_batched_path(ctx, n, m):
+    """Groups of one size are processed in lock step (batched launches); same answers as the oracle."""
+    x, y, yvar, cov = make_case(n, 7 * n)
+    fm = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar)))
+    ofit = orc.OracleFit(cov, x, y, yvar)
+    perm = np.random.default_rng(n).permutation(n)
+    groups = [list(map(int, perm[g * m:(g + 1) * m])) for g in range(n // m)]
+    want = ofit.held_out(y, groups, joint=True)
+    blocks = fm.get_fit().inverse_blocks(groups)
+    wb = ofit.inverse_blocks(groups)
+    scale = max(np.abs(b).max() for b in wb)
+    for a, b in zip(blocks, wb):
+        assert np.abs(a - b).max() <= 1e-9 * scale
+    marg = fm.get_fit().held_out_predictions(y, groups)
+    joint = fm.get_fit().held_out_predictions(y, groups, joint=True)
+    for (wm, wv, wj), mg, jt in zip(want, marg, joint):
+        assert np.abs(mg.mean - wm).max() <= 1e-8 * max(1., np.abs(wm).max())
+        assert np.abs(mg.covariance - wv).max() <= 1e-8 * wv.max()
+        assert np.abs(jt.covariance - wj).max() <= 1e-8 * np.abs(wj).max()
+        assert np.abs(jt.mean - wm).max() <= 1e-8 * max(1., np.abs(wm).max())
