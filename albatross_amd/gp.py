@@ -411,8 +411,27 @@ class BlockSymmetric:
         return out.reshape(rhs.shape)
 
 
+class ExplainedCovariance:
+    """ExplainedCovariance (covariance_functions/representations.hpp:64-96): S^-1 = A^-1 B A^-1 with the
+    outer matrix A held through its factor (the device LL^T) and the inner matrix B kept as it is, because B
+    may be singular."""
+
+    def __init__(self, outer, inner, context=None):
+        self.outer_ldlt = outer if isinstance(outer, DenseFactor) else DenseFactor(outer, context)
+        self.inner = np.asarray(inner, dtype=np.float64)
+
+    def rows(self):
+        return self.inner.shape[0]
+
+    def solve(self, rhs):  # representations.hpp:80-82
+        rhs = np.asarray(rhs, dtype=np.float64)
+        r2 = rhs.reshape(rhs.shape[0], -1)
+        return self.outer_ldlt.solve(self.inner @ self.outer_ldlt.solve(np.ascontiguousarray(r2))).reshape(rhs.shape)
+
+
 class UpdatedGPFit:
-    """Fit<GPFit<BlockSymmetric<Solver>, F>> produced by update() (gp.hpp:384-414)."""
+    """Fit<GPFit<Representation, F>> whose solver is not the plain factor: BlockSymmetric<Solver> from
+    update() (gp.hpp:384-414) or ExplainedCovariance from fit_from_prediction (gp.hpp:139-153)."""
 
     def __init__(self, train_features, train_covariance, information):
         self.train_features = train_features
@@ -616,6 +635,20 @@ class GaussianProcessRegression:
 
     def cross_validate(self):
         return CrossValidation(self)
+
+    def fit_from_prediction(self, features, prediction):
+        """fit_from_prediction (gp.hpp:236-245) -> gp_fit_from_prediction (gp.hpp:139-153): the model that
+        reproduces a joint prediction at `features`: information = prior^-1 (mean - mean_function),
+        train_covariance = ExplainedCovariance(prior_ldlt, prior - prediction.covariance)."""
+        ctx = self._ctx()
+        feats = _values_of(features)
+        fs = self.covariance_function_.features(feats)
+        mean = np.asarray(prediction.mean, dtype=np.float64) - self.mean_function_(fs.coords)  # remove_from, :240
+        prior = ctx.gram(self.covariance_function_, feats)                                      # :243
+        prior_ldlt = DenseFactor(prior, ctx)
+        cov = ExplainedCovariance(prior_ldlt, prior - np.asarray(prediction.covariance, dtype=np.float64))
+        info = prior_ldlt.solve(mean)
+        return FitModel(self, UpdatedGPFit(feats, cov, info))
 
     def log_likelihoods(self, dataset, parameter_sets):
         """log_likelihood(dataset) for several parameter vectors at once (agp_nll_batch): the evaluations

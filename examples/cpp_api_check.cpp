@@ -141,6 +141,19 @@ int main() {
     std::printf("update_mean_diff,%.17g\n", dm);
     std::printf("update_cov_diff,%.17g\n", dc);
   }
+  // fit_from_prediction round trip (tests/test_gp.cc:343-371)
+  {
+    const std::vector<P3> pts(xs.begin(), xs.begin() + 5);
+    const auto jp = fm.predict(pts).joint();
+    const auto again = model.fit_from_prediction(pts, jp).predict_joint(pts);
+    double dm = 0., dc = 0.;
+    for (int i = 0; i < 5; ++i) {
+      dm = std::fmax(dm, std::fabs(again.mean[i] - jp.mean[i]));
+      for (int j = 0; j < 5; ++j) dc = std::fmax(dc, std::fabs(again.covariance(i, j) - jp.covariance(i, j)));
+    }
+    std::printf("from_prediction_mean_diff,%.17g\n", dm);
+    std::printf("from_prediction_cov_diff,%.17g\n", dc);
+  }
   // batched log likelihoods == single calls (the tuner's finite-difference gradient, tune/finite_difference.hpp:20-94)
   {
     std::vector<ParameterStore> sets(1);

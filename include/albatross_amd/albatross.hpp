@@ -900,6 +900,69 @@ class UpdatedFitModel {
   ModelType model_;
 };
 
+// covariance_functions/representations.hpp:64-96: S^-1 = A^-1 B A^-1, A through its factor, B kept as it is
+struct ExplainedCovariance {
+  ExplainedCovariance() = default;
+  ExplainedCovariance(const SerializableLDLT &outer_ldlt_, const Matrix &inner_) : outer_ldlt(outer_ldlt_), inner(inner_) {}
+  ExplainedCovariance(const Matrix &outer, const Matrix &inner_) : outer_ldlt(outer), inner(inner_) {}
+  std::int64_t rows() const { return inner.rows(); }
+  std::int64_t cols() const { return inner.cols(); }
+  Matrix solve(const Matrix &rhs) const {  // :80-82
+    const Matrix t = outer_ldlt.solve(rhs);
+    Matrix bt(inner.rows(), t.cols());
+    for (std::int64_t j = 0; j < t.cols(); ++j)
+      for (std::int64_t k = 0; k < inner.cols(); ++k) {
+        const double tk = t(k, j);
+        for (std::int64_t i = 0; i < inner.rows(); ++i) bt(i, j) += inner(i, k) * tk;
+      }
+    return outer_ldlt.solve(bt);
+  }
+  SerializableLDLT outer_ldlt;
+  Matrix inner;
+};
+
+// FitModel over a Fit<GPFit<Representation, F>> whose solver is any CovarianceRepresentation
+// (gp.hpp:42-45): predictions through the generic _predict_impl (gp.hpp:305-366), device Gram + solve().
+template <typename ModelType, typename FeatureType, typename Representation>
+class RepresentationFitModel {
+ public:
+  RepresentationFitModel(const ModelType &model, std::vector<FeatureType> features, Representation cov, Vector info)
+      : train_features(std::move(features)), train_covariance(std::move(cov)), information(std::move(info)), model_(model) {}
+
+  Vector predict_mean(const std::vector<FeatureType> &xs) const { return mean_of(model_.get_covariance()(train_features, xs), xs); }
+  JointDistribution predict_joint(const std::vector<FeatureType> &xs) const {
+    const Matrix cross = model_.get_covariance()(train_features, xs);
+    const Matrix explained = train_covariance.solve(cross);
+    JointDistribution out;
+    out.mean = mean_of(cross, xs);
+    out.covariance = model_.get_covariance()(xs);
+    for (std::int64_t a = 0; a < cross.cols(); ++a)
+      for (std::int64_t b = 0; b < cross.cols(); ++b) {
+        double s = 0.;
+        for (std::int64_t i = 0; i < cross.rows(); ++i) s += cross(i, a) * explained(i, b);
+        out.covariance(a, b) -= s;
+      }
+    return out;
+  }
+
+  std::vector<FeatureType> train_features;
+  Representation train_covariance;
+  Vector information;
+
+ private:
+  Vector mean_of(const Matrix &cross, const std::vector<FeatureType> &xs) const {
+    Vector mean(xs.size(), 0.);
+    for (std::int64_t j = 0; j < cross.cols(); ++j) {
+      double s = 0.;
+      for (std::int64_t i = 0; i < cross.rows(); ++i) s += cross(i, j) * information[static_cast<std::size_t>(i)];
+      mean[static_cast<std::size_t>(j)] = s;
+    }
+    model_.add_mean(xs, &mean);
+    return mean;
+  }
+  ModelType model_;
+};
+
 // update(fit_model, dataset), core/fit_model.hpp:117-120
 template <typename ModelType, typename FeatureType>
 UpdatedFitModel<ModelType, FeatureType, GPFit<FeatureType>> update(const FitModel<ModelType, FeatureType> &fm,
@@ -986,6 +1049,22 @@ class GaussianProcessRegression {
 
   // core/model.hpp:154-156
   auto cross_validate() const;
+
+  // fit_from_prediction (gp.hpp:236-245) -> gp_fit_from_prediction (gp.hpp:139-153): the model that reproduces a
+  // joint prediction at `features`
+  template <typename FeatureType>
+  RepresentationFitModel<GaussianProcessRegression, FeatureType, ExplainedCovariance> fit_from_prediction(
+      const std::vector<FeatureType> &features, const JointDistribution &prediction) const {
+    Vector mean = prediction.mean;  // mean_function_.remove_from, :240
+    if (!std::is_same<MeanFunc, ZeroMean>::value)
+      for (std::size_t i = 0; i < mean.size(); ++i) mean[i] -= mean_function_._call_impl(detail::unwrap<FeatureType>::get(features[i]));
+    const Matrix prior = covariance_function_(features);  // :243
+    const SerializableLDLT prior_ldlt(prior);
+    Matrix inner = prior;
+    for (std::size_t e = 0; e < inner.data.size(); ++e) inner.data[e] -= prediction.covariance.data[e];
+    return RepresentationFitModel<GaussianProcessRegression, FeatureType, ExplainedCovariance>(
+        *this, features, ExplainedCovariance(prior_ldlt, inner), prior_ldlt.solve(mean));
+  }
 
   // log_likelihood(dataset) for several parameter vectors in ONE batched device pass (agp_nll_batch): the
   // evaluations compute_gradient (tune/finite_difference.hpp:20-94) and ModelTuner (tune/tune.hpp:151-161)

@@ -104,3 +104,31 @@ def test_update_equals_full_fit(ctx):
     # the updated information vector is the full fit's
     assert np.abs(split.get_fit().information - full.get_fit().information).max() \
         <= 1e-8 * np.abs(full.get_fit().information).max()
+
+
+def test_fit_from_prediction_round_trip(ctx):
+    """tests/test_gp.cc:343-371 (test_model_from_prediction_with_mean): the fit built from a joint prediction
+    reproduces it (1e-6), mean function included exactly once; and it keeps predicting like the original
+    model elsewhere when the prediction points carry the information (tests/test_gp.cc:308-341 in spirit)."""
+    g = golden("toy_linear.json")
+    x, y = np.array(g["x"]), np.array(g["y"])
+    cov = ab.SquaredExponential(2.0, 1.0) + ab.measurement_only(ab.IndependentNoise(0.1))
+    model = ab.gp_from_covariance_and_mean(cov, ab.LinearMean(slope=1.0, offset=5.0), context=ctx)
+    fit_model = model.fit(ab.RegressionDataset(x, y))
+    features = np.array([1.3, 4.2, 7.1])
+    pred = fit_model.predict(features).joint()
+    again = model.fit_from_prediction(features, pred).predict(features).joint()
+    assert np.linalg.norm(again.mean - pred.mean) <= 1e-6
+    assert np.linalg.norm(again.covariance - pred.covariance) <= 1e-6
+    # ExplainedCovariance::solve = A^-1 B A^-1 (representations.hpp:80-82) against numpy
+    A, B = spd(40, 3), spd(40, 4) - np.eye(40)
+    rhs = np.random.default_rng(0).standard_normal((40, 3))
+    ec = ab.ExplainedCovariance(A, B, ctx)
+    want = np.linalg.solve(A, B @ np.linalg.solve(A, rhs))
+    assert np.abs(ec.solve(rhs) - want).max() <= 1e-10 * np.abs(want).max()
+    # dense inducing set: the rebuilt model agrees with the original at new points
+    dense_pts = np.linspace(0., 9., 19)
+    rebuilt = model.fit_from_prediction(dense_pts, fit_model.predict(dense_pts).joint())
+    xs = np.array([0.7, 3.3, 8.4])
+    a, b = fit_model.predict(xs).joint(), rebuilt.predict(xs).joint()
+    assert np.abs(a.mean - b.mean).max() <= 1e-5 and np.abs(a.covariance - b.covariance).max() <= 1e-5
