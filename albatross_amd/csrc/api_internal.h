@@ -30,6 +30,10 @@ void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const d
 void launch_colvec_dot_batched(hipStream_t s, const double *Q, long long ld, long long stride_Q, long long m,
                                const double *z, long long stride_z, long long count, double *out);
 void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);
+void launch_pad_columns(hipStream_t s, const double *src, long long ld_src, const long long *off, long long smax,
+                        long long n_groups, long long rows, double *dst, long long ld_dst, int dir);
+void launch_pad_identity(hipStream_t s, double *A, long long ld, long long stride, const long long *off, long long smax,
+                         long long n_groups);
 long long round_up(long long x, long long m);
 long long factor_ld(long long n);
 }  // namespace agp

@@ -313,6 +313,53 @@ void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long lo
   hipLaunchKernelGGL(set_identity_batched_kernel, dim3((unsigned)m, (unsigned)count), dim3(256), 0, s, B, ld, stride, m);
 }
 
+// ---- ragged groups <-> slabs of one width (sparse GP blocks) --------------------------------
+// group g owns the source columns off[g] .. off[g + 1); in the padded layout it owns the columns
+// g * smax .. (g + 1) * smax, the ones beyond its size zero-filled.
+// dir = 0: dst(padded) <- src(compact); dir = 1: dst(compact) <- src(padded), padding dropped.
+__global__ __launch_bounds__(256) void pad_columns_kernel(const double *__restrict__ src, long long ld_src,
+                                                          const long long *__restrict__ off, long long smax,
+                                                          long long rows, double *__restrict__ dst, long long ld_dst,
+                                                          int dir) {
+  const long long pc = blockIdx.x;  // padded column
+  const long long g = pc / smax, a = pc % smax;
+  const long long sg = off[g + 1] - off[g];
+  const bool real = a < sg;
+  const long long cc = off[g] + a;  // compact column
+  if (dir == 0) {
+    double *d = dst + pc * ld_dst;
+    const double *sp = src + cc * ld_src;
+    for (long long i = threadIdx.x; i < rows; i += 256) d[i] = real ? sp[i] : 0.;
+  } else if (real) {
+    double *d = dst + cc * ld_dst;
+    const double *sp = src + pc * ld_src;
+    for (long long i = threadIdx.x; i < rows; i += 256) d[i] = sp[i];
+  }
+}
+
+void launch_pad_columns(hipStream_t s, const double *src, long long ld_src, const long long *off, long long smax,
+                        long long n_groups, long long rows, double *dst, long long ld_dst, int dir) {
+  if (n_groups <= 0 || smax <= 0 || rows <= 0) return;
+  hipLaunchKernelGGL(pad_columns_kernel, dim3((unsigned)(smax * n_groups)), dim3(256), 0, s, src, ld_src, off, smax, rows, dst,
+                     ld_dst, dir);
+}
+
+// every smax x smax slab (ld, stride): rows / columns beyond the group's size become identity (lower part)
+__global__ __launch_bounds__(256) void pad_identity_kernel(double *A, long long ld, long long stride,
+                                                           const long long *__restrict__ off, long long smax) {
+  const long long g = blockIdx.y, col = blockIdx.x;
+  const long long sg = off[g + 1] - off[g];
+  double *a = A + g * stride + col * ld;
+  for (long long r = col + threadIdx.x; r < smax; r += 256)
+    if (r >= sg || col >= sg) a[r] = (r == col) ? 1. : 0.;
+}
+
+void launch_pad_identity(hipStream_t s, double *A, long long ld, long long stride, const long long *off, long long smax,
+                         long long n_groups) {
+  if (n_groups <= 0 || smax <= 0) return;
+  hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)smax, (unsigned)n_groups), dim3(256), 0, s, A, ld, stride, off, smax);
+}
+
 // out[i] = a * x[i] + b * (y ? y[i] : 1)
 __global__ __launch_bounds__(256) void axpby_kernel(long long n, double a, const double *x, double b, const double *y,
                                                     double *out) {

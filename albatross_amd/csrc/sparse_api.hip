@@ -162,8 +162,59 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
     SPX_HIP(hipGetLastError());
     if ((st = status_from_flags(ctx)) != AGP_OK) return st;
     for (int64_t g = 0; g < n_groups; ++g) log_det_a += 2. * hl[(size_t)g];  // fixed order
+  } else if (n_groups >= 4 && smax * n_groups <= 3 * n) {
+    // Ragged groups of comparable size: the same lock-step path on slabs of ONE width smax, every group
+    // padded with an identity block (A_pad = [A 0; 0 I]); the operands P_g, K_uf[:, g], y_g are copied into
+    // zero-padded slabs and W / y_w copied back.  At most 3x the compact memory.
+    const long long sb = smax, lda_b = factor_ld(sb), nblk_b = (sb + NB - 1) / NB, G = n_groups;
+    const long long stride_A = lda_b * sb, stride_I = nblk_b * (36 * MB * MB), padded = sb * G;
+    double *Ppad = nullptr, *Kpad = nullptr, *ypad = nullptr;
+    long long *off_d = nullptr;
+    auto free_pads = [&]() { (void)hipFree(Ppad); (void)hipFree(Kpad); (void)hipFree(ypad); (void)hipFree(off_d); };
+#define SPX_HIP2(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+      free_pads();                                                                       \
+      return AGP_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+    SPX_HIP2(hipMalloc(&off_d, sizeof(long long) * (size_t)(G + 1)));
+    SPX_HIP2(hipMemcpyAsync(off_d, offsets, sizeof(long long) * (size_t)(G + 1), hipMemcpyHostToDevice, s));
+    SPX_HIP2(hipMalloc(&Ppad, sizeof(double) * (size_t)ldk * (size_t)padded));
+    SPX_HIP2(hipMalloc(&Kpad, sizeof(double) * (size_t)ldk * (size_t)padded));
+    SPX_HIP2(hipMalloc(&ypad, sizeof(double) * (size_t)round_up(padded, 2)));
+    SPX_HIP2(hipMalloc(&w.Ag, sizeof(double) * (size_t)stride_A * (size_t)G));
+    SPX_HIP2(hipMalloc(&w.Pimg, sizeof(double) * ((size_t)stride_I + 1) * (size_t)G));
+    double *logsum = w.Pimg + (size_t)stride_I * (size_t)G;
+    SPX_HIP2(hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)G, s));
+    SPX_HIP2(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
+    launch_pad_columns(s, w.Pbuf, ldk, off_d, sb, G, m, Ppad, ldk, 0);
+    launch_pad_columns(s, w.Kuf, ldk, off_d, sb, G, m, Kpad, ldk, 0);
+    launch_pad_columns(s, yw, 1, off_d, sb, G, 1, ypad, 1, 0);
+    for (int64_t g = 0; g < G; ++g) {
+      const long long o = offsets[g], sg = offsets[g + 1] - o;
+      const FeatView xg = feature_rows(xm, o, sg);
+      launch_gram(s, dprog, xg, xg, true, true, w.Ag + g * stride_A, lda_b, dvar + o, ctx->d_flags, &k->prog);
+    }
+    launch_pad_identity(s, w.Ag, lda_b, stride_A, off_d, sb, G);
+    launch_gemm_nt_sub_batched(s, w.Ag, lda_b, stride_A, Ppad, ldk, true, sb * ldk, Ppad, ldk, true, sb * ldk, sb, sb, m, true, G);
+    factor_lower_batched(s, w.Ag, stride_A, sb, lda_b, w.Pimg, stride_I, ypad, sb, G, ctx->d_flags, logsum);
+    right_solve_lt_batched(s, w.Ag, stride_A, sb, lda_b, w.Pimg, stride_I, Kpad, sb * ldk, m, ldk, G);
+    launch_pad_columns(s, Kpad, ldk, off_d, sb, G, m, w.Kuf, ldk, 1);
+    launch_pad_columns(s, ypad, 1, off_d, sb, G, 1, yw, 1, 1);
+    std::vector<double> hl((size_t)G);
+    SPX_HIP2(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SPX_HIP2(hipMemcpyAsync(hl.data(), logsum, sizeof(double) * (size_t)G, hipMemcpyDeviceToHost, s));
+    SPX_HIP2(hipStreamSynchronize(s));
+    SPX_HIP2(hipGetLastError());
+#undef SPX_HIP2
+    free_pads();
+    if ((st = status_from_flags(ctx)) != AGP_OK) return st;
+    for (int64_t g = 0; g < G; ++g) log_det_a += 2. * hl[(size_t)g];  // fixed order
   } else {
-    // ragged groups: one block at a time, T host threads on T helper contexts (own streams)
+    // few or very uneven groups: one block at a time, T host threads on T helper contexts (own streams)
     agp_context_impl *ci = static_cast<agp_context_impl *>(ctx);
     static int want_threads = -1;
     if (want_threads < 0) {

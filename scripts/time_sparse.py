@@ -5,14 +5,20 @@ import numpy as np
 import albatross_amd as ab
 
 ctx = ab.Context(0)
-for n, m, gs in ((32768, 1024, 512), (262144, 2048, 512)):
+for n, m, gs in ((32768, 1024, 512), (262144, 2048, 512), (262144, 2048, -512)):
     rng = np.random.default_rng(n)
     x = np.sort(rng.uniform(0., n / 16., n))              # 1-D, ~16 points per unit length
     y = np.sin(x) + 0.1 * np.cos(10. * x) + 0.1 * rng.standard_normal(n)
     cov = ab.SquaredExponential(1.0, 1.0) + ab.measurement_only(ab.IndependentNoise(0.1))  # bench covariance
     u = np.linspace(x.min(), x.max(), m)
     rank = np.argsort(np.argsort(x))
-    group_of = {float(xi): int(r // gs) for xi, r in zip(x, rank)}
+    if gs > 0:
+        group_of = {float(xi): int(r // gs) for xi, r in zip(x, rank)}
+    else:  # ragged: group sizes uniform in [0.5, 1.3] * |gs|
+        sizes = rng.integers(int(0.5 * -gs), int(1.3 * -gs), size=2 * n // -gs)
+        bounds = np.cumsum(sizes)
+        gid = np.searchsorted(bounds, np.arange(n), side="right")
+        group_of = {float(xi): int(gid[r]) for xi, r in zip(x, rank)}
     model = ab.sparse_gp_from_covariance(cov, lambda f: group_of[float(f)], ab.FixedInducingPoints(u), "pitc", context=ctx)
     model.set_param("inducing_nugget", 1e-6)
     ds = ab.RegressionDataset(x, y)
