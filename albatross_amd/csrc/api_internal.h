@@ -34,6 +34,8 @@ void launch_pad_columns(hipStream_t s, const double *src, long long ld_src, cons
                         long long n_groups, long long rows, double *dst, long long ld_dst, int dir);
 void launch_pad_identity(hipStream_t s, double *A, long long ld, long long stride, const long long *off, long long smax,
                          long long n_groups);
+void launch_compact_blocks(hipStream_t s, const double *slabs, long long ld, long long stride, const long long *off,
+                           const long long *boff, long long smax, long long n_groups, double *out);
 long long round_up(long long x, long long m);
 long long factor_ld(long long n);
 }  // namespace agp

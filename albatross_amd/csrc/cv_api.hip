@@ -79,43 +79,87 @@ int group_inverse_block(GroupWork *w, const int64_t *indices, long long off, lon
   return AGP_OK;
 }
 
-// ---- equal group sizes: every group in lock step through batched launches -------------------
-struct UniformGroups {
-  double *Gall = nullptr, *Ball = nullptr, *img = nullptr, *Q = nullptr, *vecs = nullptr;
-  ~UniformGroups() { (void)hipFree(Gall); (void)hipFree(Ball); (void)hipFree(img); (void)hipFree(Q); (void)hipFree(vecs); }
+// ---- lock-step path: every group advances through the same batched launches (blockIdx.y = group) ----
+// Groups of one size use slabs of that size; ragged groups of comparable size are padded to the largest
+// one (padding columns of G are zero, the padded diagonal of B_g is set to one: B_pad = [B 0; 0 I]).
+struct LockStep {
+  double *Gall = nullptr, *Ball = nullptr, *img = nullptr, *Q = nullptr, *vecs = nullptr, *packed = nullptr;
+  long long *meta = nullptr;  // idx_pad (count * smax) | off (count + 1) | boff (count + 1)
+  long long smax = 0, count = 0, total = 0, padded = 0, elems = 0;
+  const long long *idx_pad = nullptr, *off_d = nullptr, *boff_d = nullptr;
+  ~LockStep() {
+    (void)hipFree(Gall); (void)hipFree(Ball); (void)hipFree(img); (void)hipFree(Q); (void)hipFree(vecs); (void)hipFree(packed);
+    (void)hipFree(meta);
+  }
 };
 
-bool uniform_groups(int64_t n_groups, const int64_t *offsets, long long *m_out) {
+// true when the lock-step path applies: >= 2 non-empty groups whose padded size stays within 3x
+bool lock_step_plan(GroupWork *w, int64_t n_groups, const int64_t *offsets, const int64_t *indices, LockStep *u) {
   if (n_groups < 2) return false;
-  const long long m = offsets[1] - offsets[0];
-  if (m <= 0) return false;
-  for (int64_t g = 0; g < n_groups; ++g)
-    if (offsets[g + 1] - offsets[g] != m) return false;
-  *m_out = m;
+  long long smax = 0, total = offsets[n_groups];
+  for (int64_t g = 0; g < n_groups; ++g) {
+    const long long m = offsets[g + 1] - offsets[g];
+    if (m <= 0) return false;
+    if (m > smax) smax = m;
+  }
+  if (smax * n_groups > 3 * total) return false;
+  u->smax = smax; u->count = n_groups; u->total = total; u->padded = smax * n_groups;
+  std::vector<long long> meta((size_t)u->padded + 2 * (size_t)(n_groups + 1), -1);
+  long long *off = meta.data() + u->padded, *boff = off + (n_groups + 1);
+  long long e = 0;
+  for (int64_t g = 0; g < n_groups; ++g) {
+    const long long m = offsets[g + 1] - offsets[g];
+    for (long long a = 0; a < m; ++a) meta[(size_t)(g * smax + a)] = indices[offsets[g] + a];
+    off[g] = offsets[g];
+    boff[g] = e;
+    e += m * m;
+  }
+  off[n_groups] = total;
+  boff[n_groups] = e;
+  u->elems = e;
+  agp_context *ctx = w->ctx;
+  if (hipMalloc(&u->meta, sizeof(long long) * meta.size()) != hipSuccess) return false;
+  if (hipMemcpy(u->meta, meta.data(), sizeof(long long) * meta.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
+  (void)ctx;
+  u->idx_pad = u->meta;
+  u->off_d = u->meta + u->padded;
+  u->boff_d = u->off_d + (n_groups + 1);
   return true;
 }
 
-// Ball[g] (m x m slabs, ld ldb, stride ldb * m) = (K^-1)[I_g, I_g] for all groups: one gather, one batched product
-int uniform_inverse_blocks(GroupWork *w, long long count, long long m, UniformGroups *u) {
+// Ball[g] (smax x smax slabs, ld ldb, stride ldb * smax) = [(K^-1)[I_g, I_g] 0; 0 I]: one gather, one batched product
+int lock_step_inverse_blocks(GroupWork *w, LockStep *u) {
   agp_context *ctx = w->ctx;
   hipStream_t s = ctx->stream;
-  const long long total = count * m, ldb = factor_ld(m);
-  AGP_HIP_CHECK(ctx, hipMalloc(&u->Gall, sizeof(double) * (size_t)w->ldg * (size_t)total));
-  AGP_HIP_CHECK(ctx, hipMalloc(&u->Ball, sizeof(double) * (size_t)ldb * (size_t)total));
-  launch_gather_cols(s, w->R, w->ldr, w->idx, total, 0, w->n, u->Gall, w->ldg);
-  AGP_HIP_CHECK(ctx, hipMemsetAsync(u->Ball, 0, sizeof(double) * (size_t)ldb * (size_t)total, s));
+  const long long m = u->smax, ldb = factor_ld(m);
+  AGP_HIP_CHECK(ctx, hipMalloc(&u->Gall, sizeof(double) * (size_t)w->ldg * (size_t)u->padded));
+  AGP_HIP_CHECK(ctx, hipMalloc(&u->Ball, sizeof(double) * (size_t)ldb * (size_t)u->padded));
+  launch_gather_cols(s, w->R, w->ldr, u->idx_pad, u->padded, 0, w->n, u->Gall, w->ldg);
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(u->Ball, 0, sizeof(double) * (size_t)ldb * (size_t)u->padded, s));
   launch_gemm_nt_sub_batched(s, u->Ball, ldb, ldb * m, u->Gall, w->ldg, true, m * w->ldg, u->Gall, w->ldg, true, m * w->ldg, m,
-                             m, w->n, false, count);
-  launch_axpby(s, ldb * total, -1.0, u->Ball, 0.0, nullptr, u->Ball);
+                             m, w->n, false, u->count);
+  launch_axpby(s, ldb * u->padded, -1.0, u->Ball, 0.0, nullptr, u->Ball);
+  if (u->padded != u->total) launch_pad_identity(s, u->Ball, ldb, ldb * m, u->off_d, m, u->count);
   (void)hipFree(u->Gall); u->Gall = nullptr;
   AGP_HIP_CHECK(ctx, hipGetLastError());
   return AGP_OK;
 }
 
-// all columns of all slabs are ldb apart: the packed output is ONE pitched copy
-int copy_out_slabs(agp_context *ctx, const double *slabs, long long ld, long long m, long long count, double *dst,
-                   int location) {
-  return copy_out_2d(ctx, slabs, ld, m, m * count, dst, m, location);
+// the packed (ragged) blocks of all slabs to the caller
+int copy_out_blocks(agp_context *ctx, LockStep *u, const double *slabs, long long ld, double *dst, int location) {
+  const long long m = u->smax;
+  if (u->padded == u->total)  // one size: all columns of all slabs are ld apart, ONE pitched copy
+    return copy_out_2d(ctx, slabs, ld, m, m * u->count, dst, m, location);
+  if (!u->packed) AGP_HIP_CHECK(ctx, hipMalloc(&u->packed, sizeof(double) * (size_t)u->elems));
+  launch_compact_blocks(ctx->stream, slabs, ld, ld * m, u->off_d, u->boff_d, m, u->count, u->packed);
+  return copy_out(ctx, u->packed, u->elems, dst, location);
+}
+
+// padded vector (count * smax) -> the caller's compact vector (total)
+int copy_out_vector(agp_context *ctx, LockStep *u, const double *padded_vec, double *scratch, double *dst, int location) {
+  if (u->padded == u->total) return copy_out(ctx, padded_vec, u->total, dst, location);
+  launch_pad_columns(ctx->stream, padded_vec, 1, u->off_d, u->smax, u->count, 1, scratch, 1, 1);
+  return copy_out(ctx, scratch, u->total, dst, location);
 }
 
 }  // namespace
@@ -127,11 +171,12 @@ int agp_fit_inverse_blocks(agp_context *ctx, const agp_fit *fit, int64_t n_group
   GroupWork w;
   int st = group_work_init(ctx, fit, n_groups, offsets, indices, &w);
   if (st != AGP_OK) return st;
-  long long mu = 0;
-  if (uniform_groups(n_groups, offsets, &mu)) {
-    UniformGroups u;
-    if ((st = uniform_inverse_blocks(&w, n_groups, mu, &u)) != AGP_OK) return st;
-    return copy_out_slabs(ctx, u.Ball, factor_ld(mu), mu, n_groups, blocks, out_location);
+  {
+    LockStep u;
+    if (offsets[n_groups] > 0 && lock_step_plan(&w, n_groups, offsets, indices, &u)) {
+      if ((st = lock_step_inverse_blocks(&w, &u)) != AGP_OK) return st;
+      return copy_out_blocks(ctx, &u, u.Ball, factor_ld(u.smax), blocks, out_location);
+    }
   }
   for (int64_t g = 0; g < n_groups; ++g) {
     const long long off = offsets[g], m = offsets[g + 1] - off;
@@ -156,41 +201,40 @@ int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double 
   double *v = w.tmp, *x = v + mp, *mu = x + mp, *var = mu + mp, *yd = var + mp;
   if ((st = vector_to_device(ctx, y, n, location, yd)) != AGP_OK) return st;
   hipStream_t s = ctx->stream;
-  long long mu_sz = 0;
-  if (uniform_groups(n_groups, offsets, &mu_sz)) {
-    // equal group sizes: blocks, LL^T, inverses and solves of ALL groups in lock step (blockIdx.y = group)
-    const long long m = mu_sz, count = n_groups, total = count * m;
+  LockStep u;
+  if (lock_step_plan(&w, n_groups, offsets, indices, &u)) {
+    // blocks, LL^T, inverses and solves of ALL groups in lock step (blockIdx.y = group)
+    const long long m = u.smax, count = u.count, padded = u.padded;
     const long long ldb = factor_ld(m), nblk_b = (m + NB - 1) / NB, stride_B = ldb * m, stride_I = nblk_b * (36 * MB * MB);
-    UniformGroups u;
-    if ((st = uniform_inverse_blocks(&w, count, m, &u)) != AGP_OK) return st;
+    if ((st = lock_step_inverse_blocks(&w, &u)) != AGP_OK) return st;
     AGP_HIP_CHECK(ctx, hipMalloc(&u.img, sizeof(double) * ((size_t)stride_I * (size_t)count + (size_t)round_up(count, 2))));
     AGP_HIP_CHECK(ctx, hipMalloc(&u.Q, sizeof(double) * (size_t)stride_B * (size_t)count));
-    AGP_HIP_CHECK(ctx, hipMalloc(&u.vecs, sizeof(double) * 3 * (size_t)round_up(total, 2)));
+    AGP_HIP_CHECK(ctx, hipMalloc(&u.vecs, sizeof(double) * 4 * (size_t)round_up(padded, 2)));
     double *logsum = u.img + (size_t)stride_I * (size_t)count;
-    double *vz = u.vecs, *xs = vz + round_up(total, 2), *outv = xs + round_up(total, 2);
+    double *vz = u.vecs, *xs = vz + round_up(padded, 2), *outv = xs + round_up(padded, 2), *compact = outv + round_up(padded, 2);
     AGP_HIP_CHECK(ctx, hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)round_up(count, 2), s));
     AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
     // v_g = subset(information, indices); z_g = L_g^-1 v_g rides along the factorisation   (:175,181-182)
-    launch_gather_vec(s, fit->alpha, w.idx, total, nullptr, vz);
+    launch_gather_vec(s, fit->alpha, u.idx_pad, padded, nullptr, vz);
     factor_lower_batched(s, u.Ball, stride_B, m, ldb, u.img, stride_I, vz, m, count, ctx->d_flags, logsum);
     // R_g = L_g^-1 ;  A_g^-1 v_g = R_g^T z_g ;  inverse = R_g^T R_g
     launch_set_identity_batched(s, u.Q, ldb, stride_B, m, count);
     forward_solve_mat_batched(s, u.Ball, stride_B, m, ldb, u.img, stride_I, u.Q, stride_B, m, ldb, /*rhs_lower=*/true, count);
     launch_colvec_dot_batched(s, u.Q, ldb, stride_B, m, vz, m, count, xs);
-    launch_gather_vec(s, yd, w.idx, total, xs, outv);  // mean = y - A^-1 v
+    launch_gather_vec(s, yd, u.idx_pad, padded, xs, outv);  // mean = y - A^-1 v
     AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    if ((st = copy_out(ctx, outv, total, mean, location)) != AGP_OK) return st;
+    if ((st = copy_out_vector(ctx, &u, outv, compact, mean, location)) != AGP_OK) return st;
     if ((st = status_from_flags(ctx)) != AGP_OK) return st;
     if (variance) {  // diag(R^T R): the columns of all slabs are ldb apart
-      launch_coldot(s, u.Q, ldb, u.Q, ldb, m, total, outv, -1.0, nullptr);
-      if ((st = copy_out(ctx, outv, total, variance, location)) != AGP_OK) return st;
+      launch_coldot(s, u.Q, ldb, u.Q, ldb, m, padded, outv, -1.0, nullptr);
+      if ((st = copy_out_vector(ctx, &u, outv, compact, variance, location)) != AGP_OK) return st;
     }
     if (joint) {
       AGP_HIP_CHECK(ctx, hipMemsetAsync(u.Ball, 0, sizeof(double) * (size_t)stride_B * (size_t)count, s));
       launch_gemm_nt_sub_batched(s, u.Ball, ldb, stride_B, u.Q, ldb, true, stride_B, u.Q, ldb, true, stride_B, m, m, m, false,
                                  count);
       launch_axpby(s, stride_B * count, -1.0, u.Ball, 0.0, nullptr, u.Ball);
-      if ((st = copy_out_slabs(ctx, u.Ball, ldb, m, count, joint, location)) != AGP_OK) return st;
+      if ((st = copy_out_blocks(ctx, &u, u.Ball, ldb, joint, location)) != AGP_OK) return st;
     }
     AGP_HIP_CHECK(ctx, hipGetLastError());
     return AGP_OK;

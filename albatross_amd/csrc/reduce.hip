@@ -165,10 +165,11 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(const double *__restri
                                                           const long long *__restrict__ idx, long long row0,
                                                           long long n, double *__restrict__ G, long long ldg) {
   const long long a = blockIdx.y;
-  const double *src = R + idx[a] * ldr;
+  const long long j = idx[a];  // < 0: padding column, zero-filled
+  const double *src = R + (j < 0 ? 0 : j) * ldr;
   double *dst = G + a * ldg;
   for (long long i = row0 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    dst[i] = src[i];
+    dst[i] = j < 0 ? 0. : src[i];
 }
 
 void launch_gather_cols(hipStream_t s, const double *R, long long ldr, const long long *idx, long long m,
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(256) void gather_vec_kernel(const double *__restric
                                                          double *__restrict__ out) {
   const long long a = (long long)blockIdx.x * 256 + threadIdx.x;
   if (a >= m) return;
-  const double v = src[idx[a]];
+  const long long j = idx[a];  // < 0: padding entry
+  const double v = j < 0 ? 0. : src[j];
   out[a] = sub ? v - sub[a] : v;
 }
 
@@ -358,6 +360,25 @@ void launch_pad_identity(hipStream_t s, double *A, long long ld, long long strid
                          long long n_groups) {
   if (n_groups <= 0 || smax <= 0) return;
   hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)smax, (unsigned)n_groups), dim3(256), 0, s, A, ld, stride, off, smax);
+}
+
+// packed ragged blocks <- slabs: block g (sg x sg, ld sg) at out + boff[g] from the top-left of slab g
+__global__ __launch_bounds__(256) void compact_blocks_kernel(const double *__restrict__ slabs, long long ld, long long stride,
+                                                             const long long *__restrict__ off,
+                                                             const long long *__restrict__ boff, double *__restrict__ out) {
+  const long long g = blockIdx.y, c = blockIdx.x;
+  const long long sg = off[g + 1] - off[g];
+  if (c >= sg) return;
+  const double *sp = slabs + g * stride + c * ld;
+  double *d = out + boff[g] + c * sg;
+  for (long long r = threadIdx.x; r < sg; r += 256) d[r] = sp[r];
+}
+
+void launch_compact_blocks(hipStream_t s, const double *slabs, long long ld, long long stride, const long long *off,
+                           const long long *boff, long long smax, long long n_groups, double *out) {
+  if (n_groups <= 0 || smax <= 0) return;
+  hipLaunchKernelGGL(compact_blocks_kernel, dim3((unsigned)smax, (unsigned)n_groups), dim3(256), 0, s, slabs, ld, stride, off,
+                     boff, out);
 }
 
 // out[i] = a * x[i] + b * (y ? y[i] : 1)

@@ -20,6 +20,11 @@ for gs in (512, 64):
     t = time.perf_counter(); pj = fit.held_out_predictions(y, groups, joint=True); dtj = time.perf_counter() - t
     print(f"leave-one-group-out, {len(groups)} groups of {gs}: marginals {dt*1e3:.1f} ms, joints {dtj*1e3:.1f} ms "
           f"(N refits of the other groups would be {len(groups)} fits)")
+sizes = rng.integers(300, 700, size=40); bounds = np.cumsum(sizes); bounds = bounds[bounds < n]
+ragged = [list(map(int, g)) for g in np.split(perm, bounds) if len(g)]
+fit.held_out_predictions(y, ragged[:2])
+t = time.perf_counter(); preds = fit.held_out_predictions(y, ragged); dt = time.perf_counter() - t
+print(f"leave-one-group-out, {len(ragged)} ragged groups of {min(map(len, ragged))}..{max(map(len, ragged))}: marginals {dt*1e3:.1f} ms")
 K = rng.standard_normal((4096, 4100)); K = K @ K.T / 4096 + np.eye(4096)
 ab.DenseFactor(K, ctx)
 t = time.perf_counter(); f = ab.DenseFactor(K, ctx); dt = time.perf_counter() - t
