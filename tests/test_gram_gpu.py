@@ -142,3 +142,55 @@ def test_gram_config3_shape_properties(ctx):
     assert np.all(np.diag(K) == 1.0 + 0.1 * 0.1)
     idx = np.random.default_rng(0).choice(16384, 300, replace=False)
     assert close(K[np.ix_(idx, idx)], orc.gram(cov, x[idx]))
+
+
+def _random_tree(rng, depth, dim):
+    """A random composed covariance function over every leaf / operator the descriptor can express."""
+    metrics = [ab.EuclideanDistance, ab.RadialDistance] + ([ab.AngularDistance] if dim > 1 else [])
+    if depth == 0 or rng.random() < 0.3:
+        kind = rng.integers(0, 9)
+        if kind < 4:
+            cls = [ab.SquaredExponential, ab.Exponential, ab.Matern32, ab.Matern52][kind]
+            metric = metrics[rng.integers(len(metrics))]
+            if cls is ab.SquaredExponential and metric is ab.AngularDistance:
+                metric = ab.RadialDistance  # static_assert in radial.hpp:138-141: SE over angles is not PSD
+            return cls(float(rng.uniform(0.5, 6.0)), float(rng.uniform(0.3, 2.0)), metric())
+        if kind == 4:
+            return ab.Constant(float(rng.uniform(0.2, 2.0)))
+        if kind == 5:
+            return ab.IndependentNoise(float(rng.uniform(0.05, 0.5)))
+        if kind == 6:
+            return ab.Nugget(float(rng.uniform(0.01, 0.1)))
+        if kind == 7:
+            return ab.Polynomial(int(rng.integers(0, 3)), float(rng.uniform(0.1, 0.5)))
+        return ab.measurement_only(ab.IndependentNoise(float(rng.uniform(0.05, 0.5))))
+    op = rng.integers(0, 5)
+    lhs, rhs = _random_tree(rng, depth - 1, dim), _random_tree(rng, depth - 1, dim)
+    if op < 2:
+        return lhs + rhs
+    if op < 4:
+        return lhs * rhs
+    return ab.measurement_only(lhs) + rhs
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_covariance_trees_match_oracle(ctx, seed):
+    """Parity sweep of the postfix interpreter: random sums / products / measurement-only wrappers of every
+    leaf, symmetric and cross Gram, plain and Measurement<> features, with repeated points (equality terms)."""
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.integers(1, 4))
+    cov = _random_tree(rng, 3, dim)
+    n, m = 137, 61
+    x = rng.uniform(0.5, 5.0, (n, dim)) if dim > 1 else rng.uniform(0.5, 5.0, n)
+    x[5] = x[17]  # equal features: IndependentNoise / Nugget fire off the diagonal too
+    xs = rng.uniform(0.5, 5.0, (m, dim)) if dim > 1 else rng.uniform(0.5, 5.0, m)
+    xs[3] = x[9]
+    for x_meas in (False, True):
+        got = ctx.gram(cov, ab.Measurement(x) if x_meas else x)
+        want = orc.gram(cov, x, x_meas=x_meas)
+        assert close(got, want), cov.get_name()
+        assert np.array_equal(got, got.T)
+        for y_meas in (False, True):
+            gc = ctx.gram(cov, ab.Measurement(x) if x_meas else x, ab.Measurement(xs) if y_meas else xs)
+            wc = orc.gram(cov, x, xs, x_meas=x_meas, y_meas=y_meas)
+            assert close(gc, wc), cov.get_name()
