@@ -251,3 +251,35 @@ def test_batched_log_likelihoods_match_single_calls(ctx, n):
     bad = ab.gp_from_covariance(ab.SquaredExponential(1.0, 1.0), context=ctx)
     out = bad.log_likelihoods(ab.RegressionDataset(xd, np.zeros(20)), [{}, {"sigma_squared_exponential": 2.0}])
     assert np.all(np.isnan(out))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_models_fit_predict_match_oracle(ctx, seed):
+    """End-to-end parity sweep: a random composed covariance function (+ noise so that it is positive
+    definite), random target variances, fit / log-likelihood / all three prediction types vs the oracle's
+    pivoted LDL^T, plain and with measurement noise."""
+    from test_gram_gpu import _random_tree
+    rng = np.random.default_rng(5000 + seed)
+    dim = int(rng.integers(1, 4))
+    cov = _random_tree(rng, 2, dim) + ab.measurement_only(ab.IndependentNoise(0.3)) + ab.SquaredExponential(1.5, 1.0)
+    n, m = int(rng.integers(150, 400)), 45
+    x = rng.uniform(0.5, 5.0, (n, dim)) if dim > 1 else rng.uniform(0.5, 5.0, n)
+    xs = rng.uniform(0.5, 5.0, (m, dim)) if dim > 1 else rng.uniform(0.5, 5.0, m)
+    y = rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.1, n) if seed % 2 else None
+    model = ab.gp_from_covariance(cov, context=ctx)
+    ds = ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar))
+    fm = model.fit(ds)
+    ofit = orc.OracleFit(cov, x, y, yvar)
+    info = ofit.information
+    assert np.abs(fm.get_fit().information - info).max() <= 1e-8 * np.abs(info).max(), cov.get_name()
+    assert abs(model.log_likelihood(ds) + orc.nll(cov, x, y, yvar)) <= 1e-8 * n
+    for meas in (False, True):
+        om, ov = ofit.predict_marginal(xs, xs_meas=meas)
+        _, oj = ofit.predict_joint(xs, xs_meas=meas)
+        pred = fm.predict_with_measurement_noise(xs) if meas else fm.predict(xs)
+        scale = max(1., np.abs(om).max())
+        assert np.abs(pred.mean() - om).max() <= 1e-8 * scale
+        mg, jt = pred.marginal(), pred.joint()
+        vs = max(np.abs(ov).max(), 1e-3)
+        assert np.abs(mg.covariance - ov).max() <= 1e-8 * vs and np.abs(jt.covariance - oj).max() <= 1e-8 * np.abs(oj).max()
