@@ -14,3 +14,43 @@ def test_no_device_memory_growth():
                          timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.strip().endswith("ok")
+
+
+def test_two_contexts_in_two_threads():
+    """"One context per host thread; calls on distinct contexts are concurrent-safe" (include/albatross_amd.h):
+    two threads fit / predict concurrently on their own contexts and get the single-thread answers."""
+    import threading
+
+    import numpy as np
+
+    import albatross_amd as ab
+
+    rng = np.random.default_rng(3)
+    n = 900
+    x = rng.uniform(0., 10., (n, 3))
+    ys = [np.sin(x).sum(axis=1) + 0.1 * rng.standard_normal(n) for _ in range(2)]
+    xs = rng.uniform(0., 10., (64, 3))
+    covs = [ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.2), ab.SquaredExponential(1.5, 0.8) + ab.IndependentNoise(0.1)]
+
+    def work(i, ctx, out):
+        model = ab.gp_from_covariance(covs[i], context=ctx)
+        res = []
+        for _ in range(6):
+            fm = model.fit(ab.RegressionDataset(x, ys[i]))
+            res.append((fm.get_fit().information, fm.predict(xs).joint().covariance, model.log_likelihood(ab.RegressionDataset(x, ys[i]))))
+        out[i] = res
+
+    ref = {}
+    ctx0 = ab.Context(0)
+    for i in range(2):
+        work(i, ctx0, ref)
+    got = {}
+    ctxs = [ab.Context(0), ab.Context(0)]
+    threads = [threading.Thread(target=work, args=(i, ctxs[i], got)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        for (a, b, c), (ra, rb, rc) in zip(got[i], ref[i]):
+            assert np.array_equal(a, ra) and np.array_equal(b, rb) and c == rc  # same kernels, same order: bit-identical
