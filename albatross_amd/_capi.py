@@ -93,6 +93,13 @@ EXPORTS = [
     ("agp_nll_dense", C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _D]),
     ("agp_fit_inverse_diagonal", C.c_int, [_P, _P, _P, C.c_int]),
     ("agp_loo_marginal", C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
+    ("agp_ldlt_create", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _PP, C.POINTER(C.c_int)]),
+    ("agp_ldlt_destroy", None, [_P]),
+    ("agp_ldlt_size", C.c_int64, [_P]),
+    ("agp_ldlt_solve", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int]),
+    ("agp_ldlt_vector_d", C.c_int, [_P, _P]),
+    ("agp_ldlt_transpositions", C.c_int, [_P, _P]),
+    ("agp_ldlt_download", C.c_int, [_P, _P, _P, C.c_int64]),
     ("agp_sparse_fit_create", C.c_int, [_P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.POINTER(Features), C.c_double, C.c_double, _PP, _P, _D]),
     ("agp_sparse_fit_update", C.c_int, [_P, _P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.c_double, _PP, _P]),
     ("agp_sparse_fit_destroy", None, [_P]),

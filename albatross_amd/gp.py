@@ -371,6 +371,69 @@ class DenseFactor:
     log_determinant = GPFit.log_determinant
 
 
+class PivotedLDLT:
+    """Eigen::LDLT<MatrixXd, Lower> as SerializableLDLT wraps it (eigen/serializable_ldlt.hpp:27): the
+    diagonally pivoted P A P^T = L D L^T on the device, for symmetric matrices that are only semi-definite
+    (the un-pivoted DenseFactor rejects those).  Same operation order as the reference's unblocked
+    algorithm: matrix_ldlt(), vector_d() and transpositions() are bit-identical to the CPU restatement."""
+
+    def __init__(self, matrix, context=None):
+        self._ctx = context or default_context()
+        K = np.asarray(matrix, dtype=np.float64)
+        if K.ndim != 2 or K.shape[0] != K.shape[1]:
+            raise ValueError("square matrix expected")
+        if not (K.flags.f_contiguous or K.flags.c_contiguous):
+            K = np.asfortranarray(K)
+        uplo = 0 if K.flags.f_contiguous else 1  # lower triangle of the array, whatever its memory order
+        self.n = K.shape[0]
+        h, ok = C.c_void_p(), C.c_int(1)
+        self._ctx._check(self._ctx._lib.agp_ldlt_create(self._ctx._h, _ptr(K), self.n, self.n, uplo, capi.HOST,
+                                                        C.byref(h), C.byref(ok)), "agp_ldlt_create")
+        self._h = h
+        self.success = bool(ok.value)  # info() == Eigen::Success
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._ctx._h:
+                self._ctx._lib.agp_ldlt_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    def rows(self):
+        return self.n
+
+    def solve(self, rhs):
+        """LDLT::solve: P^T L^-T D^+ L^-1 P rhs."""
+        rhs = np.asarray(rhs, dtype=np.float64)
+        r2 = np.asfortranarray(rhs.reshape(rhs.shape[0], -1))
+        out = np.empty_like(r2, order="F")
+        self._ctx._check(self._ctx._lib.agp_ldlt_solve(self._ctx._h, self._h, _ptr(r2), r2.shape[1], _ptr(out),
+                                                       capi.HOST), "agp_ldlt_solve")
+        return out.reshape(rhs.shape, order="F")
+
+    def vector_d(self):
+        d = np.empty(self.n)
+        self._ctx._check(self._ctx._lib.agp_ldlt_vector_d(self._h, _ptr(d)), "agp_ldlt_vector_d")
+        return d
+
+    def transpositions(self):
+        tr = np.empty(self.n, dtype=np.int64)
+        self._ctx._check(self._ctx._lib.agp_ldlt_transpositions(self._h, _ptr(tr)), "agp_ldlt_transpositions")
+        return tr
+
+    def matrix_ldlt(self):
+        out = np.empty((self.n, self.n), order="F")
+        self._ctx._check(self._ctx._lib.agp_ldlt_download(self._ctx._h, self._h, _ptr(out), self.n), "agp_ldlt_download")
+        return out
+
+    @property
+    def log_determinant(self):
+        """serializable_ldlt.hpp:128-135: sum(log(vectorD)) (NaN / -inf for non-positive pivots, like the reference)."""
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return float(np.log(self.vector_d()).sum())
+
+
 def negative_log_likelihood(deviation, covariance, context=None):
     """negative_log_likelihood(deviation, covariance) (evaluation/likelihood.hpp:53-66)."""
     ctx = context or default_context()

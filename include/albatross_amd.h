@@ -244,6 +244,30 @@ int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double 
                              const int64_t *offsets, const int64_t *indices, double *mean, double *variance,
                              double *joint, int location);
 
+/* ---- pivoted L D L^T ------------------------------------------------------------------------
+ * Eigen::LDLT<MatrixXd, Lower> as albatross uses it through SerializableLDLT
+ * (include/albatross/src/eigen/serializable_ldlt.hpp:27; evaluation/likelihood.hpp:63,
+ * covariance_functions/representations.hpp:64-96, models/gp.hpp:148,393): P A P^T = L D L^T with
+ * diagonal pivoting, for symmetric matrices that are only SEMI-definite or too ill-conditioned for
+ * the un-pivoted LL^T of agp_factor_create.  The factorisation follows the reference's unblocked
+ * left-looking algorithm operation by operation (L, D and the transpositions are bit-identical to
+ * the CPU restatement); it is a correctness path, level-2 bound, meant for moderate n.
+ *   agp_ldlt_create   K as in agp_factor_create (one triangle, uplo); *success (optional) = Eigen's
+ *                     info() == Success (0: a non-zero pivot followed a zero one, NumericalIssue)
+ *   agp_ldlt_solve    LDLT::solve: P^T L^-T D^+ L^-1 P rhs, D^+ zeroing the pivots that are not above
+ *                     the smallest normal number; rhs / out are n x nrhs column-major at `location`
+ *   agp_ldlt_vector_d / _transpositions / _download   vectorD(), transpositionsP(), matrixLDLT() (host) */
+typedef struct agp_ldlt agp_ldlt;
+int agp_ldlt_create(agp_context *ctx, const double *K, int64_t n, int64_t ld, int uplo, int location,
+                    agp_ldlt **out, int *success);
+void agp_ldlt_destroy(agp_ldlt *ldlt);
+int64_t agp_ldlt_size(const agp_ldlt *ldlt);
+int agp_ldlt_solve(agp_context *ctx, const agp_ldlt *ldlt, const double *rhs, int64_t nrhs, double *out,
+                   int location);
+int agp_ldlt_vector_d(const agp_ldlt *ldlt, double *d);
+int agp_ldlt_transpositions(const agp_ldlt *ldlt, int64_t *tr);
+int agp_ldlt_download(agp_context *ctx, const agp_ldlt *ldlt, double *packed, int64_t ld);
+
 /* ---- sparse Gaussian process (FITC / PITC) --------------------------------------------------
  * SparseGaussianProcessRegression, include/albatross/src/models/sparse_gp.hpp.
  *
