@@ -70,7 +70,15 @@ __global__ __launch_bounds__(1024) void ldlt_pivot_kernel(double *A, long long l
     __syncthreads();
     if (tid == 0) {  // left-to-right sum, as the reference accumulates it
       double d = dot_s;
-      for (long long c = 0; c < cnt; ++c) d += prod[c];
+      long long c = 0;
+      for (; c + 8 <= cnt; c += 8) {
+        double q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = prod[c + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += q[e];
+      }
+      for (; c < cnt; ++c) d += prod[c];
       dot_s = d;
     }
     __syncthreads();
@@ -96,7 +104,26 @@ __global__ __launch_bounds__(256) void ldlt_column_kernel(double *A, long long l
   const long long r = k + 1 + (long long)blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
   double v = A[r + k * lda];
-  for (long long c = 0; c < k; ++c) v -= A[r + c * lda] * temp[c];
+  // left-to-right like the reference, with 2 x 32 loads in flight (few rows -> few waves: the latency of a
+  // dependent load per term would otherwise be fully exposed); the chain is only the subtractions
+  long long c = 0;
+  if (k >= 32) {
+    double a[32], b[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) a[q] = A[r + q * lda];
+    for (; c + 64 <= k; c += 32) {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) b[q] = A[r + (c + 32 + q) * lda];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v -= a[q] * temp[c + q];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) a[q] = b[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) v -= a[q] * temp[c + q];
+    c += 32;
+  }
+  for (; c < k; ++c) v -= A[r + c * lda] * temp[c];
   if (scal[1] != 0.) v /= scal[0];
   else if (v != 0.) info[1] = 0;
   A[r + k * lda] = v;
@@ -139,9 +166,9 @@ template <bool TRANS>
 __global__ __launch_bounds__(256) void ldlt_diag_solve_kernel(const double *__restrict__ A, long long lda, long long k0,
                                                               int nb, double *W, long long ldw, long long nrhs) {
   __shared__ double L[LB * LB];
-  for (int e = threadIdx.x; e < nb * nb; e += 256) {
-    const int i = e % nb, j = e / nb;
-    L[i + j * LB] = (i > j) ? A[(k0 + i) + (k0 + j) * lda] : 0.;
+  for (int e = threadIdx.x; e < LB * LB; e += 256) {  // the whole LDS block: rows / columns beyond nb are zero
+    const int i = e % LB, j = e / LB;
+    L[e] = (i > j && i < nb && j < nb) ? A[(k0 + i) + (k0 + j) * lda] : 0.;
   }
   __syncthreads();
   const long long col = (long long)blockIdx.x * 256 + threadIdx.x;

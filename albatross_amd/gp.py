@@ -480,7 +480,7 @@ class ExplainedCovariance:
     may be singular."""
 
     def __init__(self, outer, inner, context=None):
-        self.outer_ldlt = outer if isinstance(outer, DenseFactor) else DenseFactor(outer, context)
+        self.outer_ldlt = outer if isinstance(outer, (DenseFactor, PivotedLDLT)) else DenseFactor(outer, context)
         self.inner = np.asarray(inner, dtype=np.float64)
 
     def rows(self):
@@ -693,8 +693,27 @@ class GaussianProcessRegression:
             pivot = ctx._lib.agp_fit_failed_pivot(h) if h else -1
             if h:
                 ctx._lib.agp_fit_destroy(h)
+            if st == capi.AGP_ERR_NOT_POSITIVE_DEFINITE and self.pivoted_fallback:
+                return self._fit_pivoted(dataset, fs, y, yv)
             ctx._check(st, f"agp_fit_create (pivot {pivot})")
         return FitModel(self, GPFit(ctx, h, fs.n, dataset.features))
+
+    pivoted_fallback = True
+
+    def _fit_pivoted(self, dataset, fs, y, yv):
+        """The reference's own route for covariances that are only positive SEMI-definite ("unobservable" models,
+        tests/test_gp.cc:20-33): Fit<GPFit<SerializableLDLT>> with the pivoted L D L^T (gp.hpp:61-69).  Gram and
+        factor run on the device; predictions go through the generic CovarianceRepresentation form of
+        _predict_impl.  Set `pivoted_fallback = False` to get NotPositiveDefiniteError instead."""
+        ctx = self._ctx()
+        feats = _values_of(dataset.features)
+        K = ctx.gram(self.covariance_function_, Measurement(feats))  # as_measurements(features), gp.hpp:288-290
+        if yv is not None:
+            K[np.diag_indices_from(K)] += yv                          # gp.hpp:65
+        if np.isnan(K).any():
+            raise NanInputError(capi.AGP_ERR_NAN_INPUT, "covariance has NaN")  # gp.hpp:66
+        ldlt = PivotedLDLT(K, ctx)                                    # gp.hpp:67
+        return FitModel(self, UpdatedGPFit(feats, ldlt, ldlt.solve(y)))  # gp.hpp:68
 
     def cross_validate(self):
         return CrossValidation(self)
@@ -708,7 +727,10 @@ class GaussianProcessRegression:
         fs = self.covariance_function_.features(feats)
         mean = np.asarray(prediction.mean, dtype=np.float64) - self.mean_function_(fs.coords)  # remove_from, :240
         prior = ctx.gram(self.covariance_function_, feats)                                      # :243
-        prior_ldlt = DenseFactor(prior, ctx)
+        try:
+            prior_ldlt = DenseFactor(prior, ctx)
+        except NotPositiveDefiniteError:  # low-rank priors (tests/test_gp.cc:308-341): the pivoted factor
+            prior_ldlt = PivotedLDLT(prior, ctx)
         cov = ExplainedCovariance(prior_ldlt, prior - np.asarray(prediction.covariance, dtype=np.float64))
         info = prior_ldlt.solve(mean)
         return FitModel(self, UpdatedGPFit(feats, cov, info))

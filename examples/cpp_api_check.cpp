@@ -224,6 +224,17 @@ int main() {
     const auto sm = sfit.predict(txs).marginal();
     for (int i = 0; i < 11; ++i) std::printf("sparse_pred,%d,%.17g,%.17g,%.17g\n", i, sfit.predict(txs).mean()[i], sm.mean[i], sm.covariance[i]);
   }
+  // pivoted LDL^T fallback for a semi-definite covariance (duplicated observations, no noise)
+  {
+    std::vector<double> dx = {0.5, 1.5, 2.5, 3.5, 0.5, 2.5};
+    Vector dy(dx.size());
+    for (std::size_t i = 0; i < dx.size(); ++i) dy[i] = std::sin(dx[i]);
+    auto pm = gp_from_covariance(SquaredExponential<EuclideanDistance>(1.5, 1.0) + Constant(0.3));
+    const auto pf = fit_pivoted(pm, RegressionDataset<double>(dx, dy));
+    const auto pj = pf.predict_joint(std::vector<double>{0.5, 2.0, 3.5});
+    std::printf("pivoted_pred,%.17g,%.17g,%.17g\n", pj.mean[0], pj.mean[1], pj.mean[2]);
+    std::printf("pivoted_var0,%.17g\n", pj.covariance(0, 0));
+  }
   // a singular covariance is reported, not silently factored
   try {
     std::vector<double> dup = {0., 0., 1.};

@@ -693,6 +693,59 @@ class SerializableLDLT {
   std::int64_t n_ = 0;
 };
 
+// ---------------------------------------------------------------------------
+// Eigen::LDLT<MatrixXd, Lower> as SerializableLDLT wraps it (eigen/serializable_ldlt.hpp:27): the diagonally
+// pivoted P A P^T = L D L^T on the device, for symmetric matrices that are only SEMI-definite (the un-pivoted
+// factor above rejects those).  Same operation order as the reference's unblocked algorithm.
+// ---------------------------------------------------------------------------
+class PivotedLDLT {
+ public:
+  PivotedLDLT() = default;
+  explicit PivotedLDLT(const Matrix &x) : context_(detail::default_context()), n_(x.rows()) {
+    agp_ldlt *h = nullptr;
+    int ok = 1;
+    detail::check(agp_ldlt_create(context_->ctx, x.data.data(), x.rows(), x.rows(), /*uplo=*/0, AGP_HOST, &h, &ok), context_->ctx,
+                  "agp_ldlt_create");
+    success_ = ok != 0;
+    auto ctx = context_;
+    handle_ = std::shared_ptr<agp_ldlt>(h, [ctx](agp_ldlt *p) { agp_ldlt_destroy(p); });
+  }
+  std::int64_t rows() const { return n_; }
+  bool success() const { return success_; }  // info() == Eigen::Success
+  Matrix solve(const Matrix &rhs) const {    // P^T L^-T D^+ L^-1 P rhs
+    Matrix out(rhs.rows(), rhs.cols());
+    detail::check(agp_ldlt_solve(context_->ctx, handle_.get(), rhs.data.data(), rhs.cols(), out.data.data(), AGP_HOST), context_->ctx,
+                  "agp_ldlt_solve");
+    return out;
+  }
+  Vector solve(const Vector &rhs) const {
+    Vector out(rhs.size());
+    detail::check(agp_ldlt_solve(context_->ctx, handle_.get(), rhs.data(), 1, out.data(), AGP_HOST), context_->ctx, "agp_ldlt_solve");
+    return out;
+  }
+  Vector vectorD() const {
+    Vector d(static_cast<std::size_t>(n_));
+    detail::check(agp_ldlt_vector_d(handle_.get(), d.data()), context_->ctx, "agp_ldlt_vector_d");
+    return d;
+  }
+  std::vector<std::int64_t> transpositionsP() const {
+    std::vector<std::int64_t> tr(static_cast<std::size_t>(n_));
+    detail::check(agp_ldlt_transpositions(handle_.get(), tr.data()), context_->ctx, "agp_ldlt_transpositions");
+    return tr;
+  }
+  double log_determinant() const {  // serializable_ldlt.hpp:128-135
+    double s = 0.;
+    for (double d : vectorD()) s += std::log(d);
+    return s;
+  }
+
+ private:
+  std::shared_ptr<detail::ContextHolder> context_;
+  std::shared_ptr<agp_ldlt> handle_;
+  std::int64_t n_ = 0;
+  bool success_ = true;
+};
+
 // negative_log_likelihood(deviation, covariance), evaluation/likelihood.hpp:53-66
 inline double negative_log_likelihood(const Vector &deviation, const Matrix &covariance) {
   auto ctx = detail::default_context();
@@ -962,6 +1015,25 @@ class RepresentationFitModel {
   }
   ModelType model_;
 };
+
+// The reference's route for covariances that are only positive semi-definite ("unobservable" models,
+// tests/test_gp.cc:20-33): Fit<GPFit<SerializableLDLT>> with the pivoted factor (gp.hpp:61-69).  model.fit()
+// reports such inputs as "not positive definite"; this is the explicit fallback.
+template <typename ModelType, typename FeatureType>
+RepresentationFitModel<ModelType, FeatureType, PivotedLDLT> fit_pivoted(const ModelType &model,
+                                                                        const RegressionDataset<FeatureType> &dataset) {
+  Matrix K = model.get_covariance()(as_measurements(dataset.features));  // gp.hpp:288-290
+  if (!dataset.targets.covariance.empty())
+    for (std::size_t i = 0; i < dataset.features.size(); ++i)
+      K(static_cast<std::int64_t>(i), static_cast<std::int64_t>(i)) += dataset.targets.covariance[i];  // gp.hpp:65
+  Vector y = dataset.targets.mean;
+  Vector zero(y.size(), 0.);
+  model.add_mean(dataset.features, &zero);  // remove_from == subtract what add_to adds
+  for (std::size_t i = 0; i < y.size(); ++i) y[i] -= zero[i];
+  PivotedLDLT ldlt(K);                                                   // gp.hpp:67
+  Vector info = ldlt.solve(y);                                           // gp.hpp:68
+  return RepresentationFitModel<ModelType, FeatureType, PivotedLDLT>(model, dataset.features, std::move(ldlt), std::move(info));
+}
 
 // update(fit_model, dataset), core/fit_model.hpp:117-120
 template <typename ModelType, typename FeatureType>

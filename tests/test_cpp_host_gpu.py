@@ -130,6 +130,9 @@ def test_cpp_api_matches_oracle():
     smean, svar = so.predict(txs)
     assert np.abs(sp[:, 1] - smean).max() <= 1e-7 and np.abs(sp[:, 2] - smean).max() <= 1e-7
     assert np.abs(sp[:, 3] - svar).max() <= 1e-7
+    # semi-definite model through the pivoted factor: interpolates the (duplicated) observations
+    pp = [float(v) for v in rows["pivoted_pred"][0]]
+    assert abs(pp[0] - np.sin(0.5)) < 1e-6 and abs(pp[2] - np.sin(3.5)) < 1e-6 and abs(float(one["pivoted_var0"])) < 1e-6
     assert abs(float(one["mvn_nll"]) - 6.0946974293510134) < 1e-12  # tests/test_evaluate.cc:26,41
     assert abs(float(one["mvn_logdet"]) - np.linalg.slogdet(np.array([[1, .9, .8], [.9, 1, .9], [.8, .9, 1.]]))[1]) < 1e-13
     assert float(one["update_mean_diff"]) < 1e-8 and float(one["update_cov_diff"]) < 1e-6  # tests/test_gp.cc:213

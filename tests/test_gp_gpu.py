@@ -121,6 +121,7 @@ def test_mean_function_is_removed_and_added(ctx):
 def test_not_positive_definite_and_nan_are_reported(ctx):
     x = np.array([0., 0., 1.])  # duplicate point, no noise: singular Gram
     model = ab.gp_from_covariance(ab.SquaredExponential(1., 1.), context=ctx)
+    model.pivoted_fallback = False  # the un-pivoted device factor alone: reported with the failing pivot
     with pytest.raises(ab.NotPositiveDefiniteError, match="pivot 1"):
         model.fit(ab.RegressionDataset(x, np.zeros(3)))
     with pytest.raises(ab.NanInputError):
@@ -283,3 +284,31 @@ def test_random_models_fit_predict_match_oracle(ctx, seed):
         mg, jt = pred.marginal(), pred.joint()
         vs = max(np.abs(ov).max(), 1e-3)
         assert np.abs(mg.covariance - ov).max() <= 1e-8 * vs and np.abs(jt.covariance - oj).max() <= 1e-8 * np.abs(oj).max()
+
+
+def test_semi_definite_model_falls_back_to_the_pivoted_factor(ctx):
+    """An "unobservable" model (tests/test_gp.cc:20-33 style): duplicated observations without noise make the
+    Gram matrix singular.  The reference's pivoted LDL^T goes through; so does the mirror (device Gram +
+    agp_ldlt_*), with the oracle's predictions."""
+    rng = np.random.default_rng(8)
+    x = rng.uniform(0., 10., 40)
+    x = np.concatenate([x, x[:7]])  # exact duplicates
+    f = np.sin(x)
+    cov = ab.SquaredExponential(2.0, 1.0) + ab.Constant(0.5)
+    model = ab.gp_from_covariance(cov, context=ctx)
+    fm = model.fit(ab.RegressionDataset(x, f))
+    assert isinstance(fm.get_fit().train_covariance, ab.PivotedLDLT)
+    ofit = orc.OracleFit(cov, x, f)
+    # the information vector of a singular system is rounding noise amplified by 1e6 (the oracle's Gram differs
+    # from the device's by 1 ulp): only what the data determine is comparable - the predictions
+    assert np.all(np.isfinite(fm.get_fit().information))
+    xs = np.linspace(0.5, 9.5, 21)
+    om, ov = ofit.predict_marginal(xs)
+    pm = fm.predict(xs).marginal()
+    assert np.abs(pm.mean - om).max() <= 1e-4 * max(1., np.abs(om).max())
+    assert np.abs(pm.covariance - ov).max() <= 1e-6
+    # and on the SAME Gram matrix the device factor is the oracle's, bit for bit
+    K = ctx.gram(cov, ab.Measurement(x))
+    packed, tr, ok = orc.ldlt(K)
+    ldlt = fm.get_fit().train_covariance
+    assert np.array_equal(ldlt.transpositions(), tr) and np.array_equal(np.tril(ldlt.matrix_ldlt()), np.tril(packed))
