@@ -16,7 +16,7 @@ def spd(n, seed):
     return G @ G.T / n + np.eye(n)
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 64, 65, 200, 513])
+@pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 97, 200, 513, 1100])
 def test_factor_is_bit_identical_to_oracle(ctx, n):
     sc = np.random.default_rng(n).uniform(0.1, 10., n)
     A = spd(n, n) * sc[:, None] * sc[None, :]  # widely varying diagonal: plenty of pivoting
