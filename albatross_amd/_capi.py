@@ -80,6 +80,7 @@ EXPORTS = [
     ("agp_kernel_destroy", None, [_P]),
     ("agp_gram", C.c_int, [_P, _P, C.POINTER(Features), C.POINTER(Features), _P, C.c_int64, C.c_int]),
     ("agp_fit_create", C.c_int, [_P, _P, C.POINTER(Features), _P, _P, _PP, _P, _P]),
+    ("agp_fit_create_mixed", C.c_int, [_P, _P, C.POINTER(Features), _P, _P, C.c_int, C.c_double, _PP, _P, _P, _P, _P]),
     ("agp_fit_destroy", None, [_P]),
     ("agp_fit_size", C.c_int64, [_P]),
     ("agp_fit_failed_pivot", C.c_int64, [_P]),

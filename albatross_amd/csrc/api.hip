@@ -459,8 +459,21 @@ void agp_fit_destroy(agp_fit *fit) {
   delete fit;
 }
 
-int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y,
-                   const double *y_var, agp_fit **out, double *information, double *log_det) {
+namespace {
+struct MixedRequest {
+  int max_iterations = 0;
+  double tolerance = 0.;
+  int iterations = 0;       // out
+  double residual = 0.;     // out: ||y - K a||_2 / ||y||_2 of the returned information vector
+};
+}  // namespace
+
+static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double *Kfull, const double *Wfwd,
+                              double *vec, MixedRequest *mixed);
+
+static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y,
+                           const double *y_var, agp_fit **out, double *information, double *log_det,
+                           MixedRequest *mixed) {
   if (!c || !k || !x || !y || !out) return AGP_ERR_INVALID_ARGUMENT;
   agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
   *out = nullptr;
@@ -480,12 +493,20 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   const long long nblk = (n + NB - 1) / NB;
   hipStream_t s = ctx->stream;
   double *yvar_d = nullptr;
+  double *Kfull = nullptr, *Wfwd = nullptr, *vec = nullptr;  // mixed precision only
+  auto drop_mixed = [&]() {
+    if (Kfull) (void)hipFree(Kfull);
+    if (Wfwd) (void)hipFree(Wfwd);
+    if (vec) (void)hipFree(vec);
+    Kfull = Wfwd = vec = nullptr;
+  };
 #define FIT_CHECK(expr)                                                                  \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
     if (_e != hipSuccess) {                                                              \
       ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
       if (yvar_d) (void)hipFree(yvar_d);                                                 \
+      drop_mixed();                                                                      \
       agp_fit_destroy(fit);                                                              \
       return AGP_ERR_HIP;                                                                \
     }                                                                                    \
@@ -515,14 +536,29 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   if (x->location == AGP_HOST) FIT_CHECK(hipStreamSynchronize(s));
   FeatView xm = fit->train.v;
   xm.meas = 1;  // as_measurements(features), gp.hpp:288
+  if (mixed) {
+    // the exact fp64 covariance (both triangles) for the residuals of the refinement, the targets,
+    // and the work vectors r, z, p, q
+    FIT_CHECK(hipMalloc(&Kfull, fit->A_bytes));
+    FIT_CHECK(hipMalloc(&Wfwd, sizeof(double) * (size_t)nblk * NB * NB));
+    FIT_CHECK(hipMalloc(&vec, sizeof(double) * (size_t)n * 5));
+    FIT_CHECK(hipMemcpyAsync(vec, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/false, Kfull, fit->lda, yvar_d, ctx->d_flags,
+                &k->prog);
+    ctx->update_variant = 3;  // fp32-product bulk updates
+    if (const char *e = getenv("AGP_MIXED_NBO")) ctx->nbo_override = atoll(e);  // experiment: fixed outer width
+  }
   st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d);
+  ctx->update_variant = -1;
+  ctx->nbo_override = 0;
   if (yvar_d) { (void)hipFree(yvar_d); yvar_d = nullptr; }
-  if (st != AGP_OK) { agp_fit_destroy(fit); return st; }
+  if (st != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st; }
   st = status_from_flags(ctx);
   fit->failed_pivot = ctx->h_flags[1] ? (int64_t)ctx->h_flags[1] - 1 : -1;
   fit->log_det = 2. * ctx->h_scalars[0];
   if (st != AGP_OK) {
     // keep a handle so the caller can query the failed pivot, but no factor
+    drop_mixed();
     *out = fit;
     return st;
   }
@@ -532,9 +568,15 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);
   {
     const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)round_up(n, 2));
-    if (st2 != AGP_OK) { agp_fit_destroy(fit); return st2; }
+    if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
   }
   backward_solve_vec(s, fit->A, n, fit->lda, fit->winv, fit->alpha, ctx->ws_aux);
+  if (mixed) {
+    invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
+    const int st3 = refine_information(ctx, fit, Kfull, Wfwd, vec, mixed);
+    drop_mixed();
+    if (st3 != AGP_OK) { agp_fit_destroy(fit); return st3; }
+  }
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[4], s));
   if (information) FIT_CHECK(hipMemcpyAsync(information, fit->alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   FIT_CHECK(hipStreamSynchronize(s));
@@ -547,6 +589,95 @@ int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, c
   if (log_det) *log_det = fit->log_det;
   *out = fit;
 #undef FIT_CHECK
+  return AGP_OK;
+}
+
+int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y,
+                   const double *y_var, agp_fit **out, double *information, double *log_det) {
+  return fit_create_impl(c, k, x, y, y_var, out, information, log_det, nullptr);
+}
+
+int agp_fit_create_mixed(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y,
+                         const double *y_var, int max_iterations, double tolerance, agp_fit **out,
+                         double *information, double *log_det, int *iterations, double *residual) {
+  if (max_iterations < 0 || !(tolerance >= 0.)) return AGP_ERR_INVALID_ARGUMENT;
+  MixedRequest m;
+  m.max_iterations = max_iterations;
+  m.tolerance = tolerance;
+  const int st = fit_create_impl(c, k, x, y, y_var, out, information, log_det, &m);
+  if (iterations) *iterations = m.iterations;
+  if (residual) *residual = m.residual;
+  return st;
+}
+
+// Conjugate gradients on K a = y in fp64, preconditioned with the mixed-precision factor (M = L L^T,
+// ||I - M^-1 K|| ~ cond(K) * 2^-24): fit->alpha enters as M^-1 y and leaves as K^-1 y to the requested
+// relative residual.  vec: 5 n doubles, vec[0:n] = y on entry.
+static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double *Kfull, const double *Wfwd,
+                              double *vec, MixedRequest *mixed) {
+  hipStream_t s = ctx->stream;
+  const long long n = fit->n, lda = fit->lda;
+  double *yv = vec, *r = vec + n, *z = vec + 2 * n, *p = vec + 3 * n, *q = vec + 4 * n;
+  double *xa = fit->alpha;
+  double *dots = ctx->d_scalars;  // 4 device doubles (log-det already read back)
+  auto read_dots = [&](int count, double *host) -> int {
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scalars, dots, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+    AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < count; ++i) host[i] = ctx->h_scalars[i];
+    return AGP_OK;
+  };
+  auto precondition = [&](const double *in, double *outv) {
+    (void)hipMemcpyAsync(outv, in, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+    forward_solve_vec(s, fit->A, n, lda, Wfwd, outv, ctx->ws_aux);
+    backward_solve_vec(s, fit->A, n, lda, fit->winv, outv, ctx->ws_aux);
+  };
+  double h[4];
+  int st;
+  // r = y - K a
+  launch_colvec_dot(s, Kfull, lda, n, n, xa, -1., 1., yv, r);
+  launch_dot(s, yv, yv, n, dots + 0);
+  launch_dot(s, r, r, n, dots + 1);
+  if ((st = read_dots(2, h)) != AGP_OK) return st;
+  const double ynorm = std::sqrt(h[0]);
+  double rnorm = std::sqrt(h[1]);
+  const double target = mixed->tolerance * ynorm;
+  int it = 0;
+  if (rnorm > target && mixed->max_iterations > 0) {
+    precondition(r, z);
+    (void)hipMemcpyAsync(p, z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+    launch_dot(s, r, z, n, dots + 0);
+    if ((st = read_dots(1, h)) != AGP_OK) return st;
+    double rz = h[0];
+    double best = rnorm;
+    int stalled = 0;
+    while (it < mixed->max_iterations && rnorm > target) {
+      launch_colvec_dot(s, Kfull, lda, n, n, p, 1., 0., nullptr, q);
+      launch_dot(s, p, q, n, dots + 0);
+      if ((st = read_dots(1, h)) != AGP_OK) return st;
+      if (!(h[0] > 0.) || !(rz > 0.)) break;  // breakdown: K or the preconditioner lost definiteness
+      const double a = rz / h[0];
+      launch_axpby(s, n, a, p, 1., xa, xa);
+      launch_axpby(s, n, -a, q, 1., r, r);
+      ++it;
+      precondition(r, z);
+      launch_dot(s, r, r, n, dots + 0);
+      launch_dot(s, r, z, n, dots + 1);
+      if ((st = read_dots(2, h)) != AGP_OK) return st;
+      rnorm = std::sqrt(h[0]);
+      if (rnorm < 0.9 * best) { best = rnorm; stalled = 0; }
+      else if (++stalled >= 3) break;  // at the fp64 floor of this system
+      const double beta = h[1] / rz;
+      rz = h[1];
+      launch_axpby(s, n, 1., z, beta, p, p);
+    }
+    // report the TRUE residual of what is returned (the recurrence drifts)
+    launch_colvec_dot(s, Kfull, lda, n, n, xa, -1., 1., yv, r);
+    launch_dot(s, r, r, n, dots + 0);
+    if ((st = read_dots(1, h)) != AGP_OK) return st;
+    rnorm = std::sqrt(h[0]);
+  }
+  mixed->iterations = it;
+  mixed->residual = ynorm > 0. ? rnorm / ynorm : rnorm;
   return AGP_OK;
 }
 

@@ -574,12 +574,13 @@ static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, 
 // trailing update C -= P P^T (lower tiles) bracketed by a HIP-event pair when
 // the caller collects per-launch timings (bench.py's roofline block)
 static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long lda, const double *P,
-                       const double *Q, long long M, long long N, long long K, bool bulk) {
+                       const double *Q, long long M, long long N, long long K, bool bulk, int variant = -1) {
   // only the bulk trailing updates (their own kernel symbol) are event-timed:
   // they run on the second stream, where an event gap is off the critical path
   const bool timed = bulk && timers && timers->ev && timers->used + 2 <= timers->n_ev;
   if (timed) (void)hipEventRecord(timers->ev[timers->used], s);
-  if (bulk) launch_trailing_update(s, C, lda, P, Q, lda, M, K);
+  if (bulk && variant >= 0) launch_trailing_update_as(variant, s, C, lda, P, Q, lda, M, K);
+  else if (bulk) launch_trailing_update(s, C, lda, P, Q, lda, M, K);
   else launch_gemm_nt_sub(s, C, lda, P, lda, false, Q, lda, false, M, N, K, true);
   if (timed) {
     (void)hipEventRecord(timers->ev[timers->used + 1], s);
@@ -642,7 +643,8 @@ static void nbo_thresholds(long long *m512, long long *m256) {
   *m512 = t512; *m256 = t256;
 }
 
-static long long pick_nbo(long long remaining) {
+static long long pick_nbo(long long remaining, long long override_nbo = 0) {
+  if (override_nbo > 0) return override_nbo;
   long long m512, m256;
   nbo_thresholds(&m512, &m256);
   if (remaining > m512) return 512;
@@ -672,11 +674,13 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   hipStream_t sa = ctx->stream, sb = ctx->stream2;
   bool have_u2 = false;
   long long K0 = 0;
-  long long kend = K0 + pick_nbo(n);
+  const long long nbo_fixed = ctx->nbo_override;
+  const int variant = ctx->update_variant;
+  long long kend = K0 + pick_nbo(n, nbo_fixed);
   if (kend > n) kend = n;
   panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers);
   while (kend < n) {
-    long long next_end = kend + pick_nbo(n - kend);
+    long long next_end = kend + pick_nbo(n - kend, nbo_fixed);
     if (next_end > n) next_end = n;
     const long long K = kend - K0;
     const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
@@ -694,7 +698,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
         (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       }
       const double *Q = A + K0 * lda + next_end;
-      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true);
+      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant);
       (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;
     } else {
@@ -906,6 +910,75 @@ void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long l
   t.z = nullptr; t.yrest = nullptr;
   t.batch_img = IMG_DOUBLES; t.batch_Y = NB * NB; t.n_total = n;
   hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
+}
+
+// Wfwd[b] = inv(L_bb) column-major (element (m, n) at [n * NB + m]): what the FORWARD vector
+// substitution reads coalesced.
+void invert_diag_blocks_forward(hipStream_t s, long long n, const double *invd, double *Wfwd) {
+  const long long nblk = (n + NB - 1) / NB;
+  const long long count = nblk * NB * NB;
+  hipLaunchKernelGGL(set_identity_blocks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, Wfwd, count);
+  TrsmArgs t;
+  t.img = invd; t.nbk = NB;
+  t.Y = Wfwd; t.stride_m = 1; t.stride_n = NB; t.ncols = NB;
+  t.z = nullptr; t.yrest = nullptr;
+  t.batch_img = IMG_DOUBLES; t.batch_Y = NB * NB; t.n_total = n;
+  hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
+}
+
+// One step of the right-looking FORWARD substitution on a vector, ONE launch:
+//   x_b = inv(L_bb) z_b                         (recomputed by every workgroup, as in back_step_kernel)
+//   z[i] -= sum_c L[i][k0 + c] x_b[c]           for this workgroup's 64 rows i >= k0 + nbk
+// (wave w sums columns 32 w .. 32 w + 31, lane = row: coalesced 512-B column segments)
+__global__ __launch_bounds__(256) void fwd_step_kernel(const double *__restrict__ A, long long lda, long long k0,
+                                                       int nbk, long long n, const double *__restrict__ Wfwd,
+                                                       double *__restrict__ z, double *__restrict__ x_out) {
+  __shared__ double xs[NB], part[NB], zs[NB], red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < NB) zs[tid] = (tid < nbk) ? z[k0 + tid] : 0.;
+  __syncthreads();
+  {
+    // x[c] = sum_r inv(L)[c][r] z[r];  Wfwd holds inv(L)[c][r] at [r * NB + c]
+    const int c = tid & (NB - 1), half = tid >> 7;
+    double acc = 0.;
+#pragma unroll 8
+    for (int r = half * 64; r < half * 64 + 64; ++r) acc += Wfwd[r * NB + c] * zs[r];
+    if (half == 1) part[c] = acc;
+    __syncthreads();
+    if (half == 0) {
+      const double v = (c < nbk) ? acc + part[c] : 0.;
+      xs[c] = v;
+      if (blockIdx.x == 0 && c < nbk) x_out[k0 + c] = v;
+    }
+    __syncthreads();
+  }
+  const long long i = k0 + nbk + (long long)blockIdx.x * 64 + lane;
+  double acc = 0.;
+  if (i < n) {
+    const double *p = A + (k0 + 32 * wave) * lda + i;
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c)
+      if (32 * wave + c < nbk) acc += p[(long long)c * lda] * xs[32 * wave + c];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && i < n) z[i] -= (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// z <- L^-1 z for one vector (the fused substitution of the factorisation covers the fit's own y; this
+// one serves the refinement steps of the mixed-precision fit).  xstage: n doubles.
+void forward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Wfwd, double *z,
+                       double *xstage) {
+  const long long nblk = (n + NB - 1) / NB;
+  for (long long b = 0; b < nblk; ++b) {
+    const long long k = b * NB;
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    const long long below = n - k - nbk;
+    const unsigned grid = (unsigned)(below > 0 ? (below + 63) / 64 : 1);
+    hipLaunchKernelGGL(fwd_step_kernel, dim3(grid), dim3(256), 0, s, A, lda, k, nbk, n,
+                       Wfwd + b * (long long)(NB * NB), z, xstage);
+  }
+  (void)hipMemcpyAsync(z, xstage, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }
 
 // One step of the right-looking back substitution, ONE launch:

@@ -70,6 +70,10 @@ struct agp_context {
   // the next agp_fit_create of the same size takes it instead of hipMalloc)
   double *pool_A = nullptr;
   size_t pool_A_bytes = 0;
+  // bulk-update kernel of the next factorisation: -1 = default (fp64 MFMA), 3 = fp32 products
+  // (agp_fit_create_mixed sets and resets it around its factor_lower call)
+  int update_variant = -1;
+  long long nbo_override = 0;  // outer block width of the next factorisation (0 = default schedule)
 };
 
 struct agp_fit {
@@ -128,6 +132,9 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
 void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                         double *Winv);
 // x = L^-T z (one right-hand side), z overwritten.
+void invert_diag_blocks_forward(hipStream_t s, long long n, const double *invd, double *Wfwd);
+void forward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Wfwd, double *z,
+                       double *xstage);
 void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Winv,
                         double *z, double *xstage);
 // B (n x m, ldb) <- L^-1 B

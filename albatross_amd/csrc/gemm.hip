@@ -429,6 +429,98 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmAr
 }
 
 // ---------------------------------------------------------------------------
+// Mixed-precision bulk update (BASELINE config 4): the SAME tile, but the two
+// panels are rounded to fp32 while they are staged into LDS and multiplied with
+// v_mfma_f32_16x16x4_f32 (4x the fp64 MFMA issue rate); the K <= 512 products of
+// one launch accumulate in fp32 registers and are then subtracted from the fp64
+// matrix, so the rounding of one outer step never compounds over the next.
+// Lane maps as in mfma_f64.h except C/D: register r of lane l holds
+// D[m = 4 (l >> 4) + r][n = l & 15].
+// ---------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool NEGATE>
+__device__ __forceinline__ void store_chunk_f32(float *__restrict__ Ls, const double (&r)[8]) {
+  const int t = threadIdx.x;
+  const int kk = t >> 4, seg = (t & 15) * 8;
+  float4 *dst = reinterpret_cast<float4 *>(Ls + kk * GLD + seg);
+  const float sg = NEGATE ? -1.f : 1.f;
+  dst[0] = make_float4(sg * (float)r[0], sg * (float)r[1], sg * (float)r[2], sg * (float)r[3]);
+  dst[1] = make_float4(sg * (float)r[4], sg * (float)r[5], sg * (float)r[6], sg * (float)r[7]);
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_f32_kernel(GemmArgs g) {
+  __shared__ float lds[2 * 2 * GK * GLD];
+  int bi, bj;
+  if (!tile_of_block(g, bi, bj)) return;
+  const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ln = lane & 15, lg = lane >> 4;
+  const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
+
+  v4f acc[4][4];  // [tj][ti]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  double ra[8], rb[8];
+  const long long nk = (g.K + GK - 1) / GK;
+  load_chunk<false>(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
+  load_chunk<false>(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb);
+  store_chunk_f32<false>(lds, ra);
+  store_chunk_f32<true>(lds + GK * GLD, rb);
+  __syncthreads();
+  for (long long kc = 0; kc < nk; ++kc) {
+    const int cur = (int)(kc & 1);
+    const float *As = lds + cur * (2 * GK * GLD);
+    const float *Bs = As + GK * GLD;
+    const bool more = kc + 1 < nk;
+    if (more) {
+      load_chunk<false>(g.A, g.lda, i0, g.M, (kc + 1) * GK, g.K, a_vec, ra);
+      load_chunk<false>(g.B, g.ldb, j0, g.N, (kc + 1) * GK, g.K, b_vec, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < GK / 4; ++s) {
+      float fa[4], fb[4];
+      const int krow = (4 * s + lg) * GLD;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = Bs[krow + 64 * wc + 16 * t + ln];  // MFMA A operand: C-column panel (negated)
+        fb[t] = As[krow + 64 * wr + 16 * t + ln];  // MFMA B operand: C-row panel
+      }
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          acc[tj][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[tj], fb[ti], acc[tj][ti], 0, 0, 0);
+    }
+    if (more) {
+      float *An = lds + (cur ^ 1) * (2 * GK * GLD);
+      store_chunk_f32<false>(An, ra);
+      store_chunk_f32<true>(An + GK * GLD, rb);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const long long row = i0 + 64 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 64 * wc + 16 * tj + 4 * lg + r;
+        if (row < g.M && col < g.N) {
+          double *c = g.C + row + col * g.ldc;
+          *c = *c + (double)acc[tj][ti][r];
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // 64 x 64-tile variant for launches too small to fill the chip with 128 x 128
 // tiles (the next-panel and inner updates of the serial panel chain): four
 // times as many, four times shorter workgroups, 3-4 of them per CU.
@@ -613,7 +705,7 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
   launch_gemm_nt_sub_batched(s, C, ldc, 0, A, lda, a_kmajor, 0, B, ldb, b_kmajor, 0, M, N, K, tri, 1);
 }
 
-// variant 0: MFMA kernel, 2: DPP-broadcast VALU kernel (experiment)
+// variant 0: MFMA kernel, 2: DPP-broadcast VALU kernel (experiment), 3: fp32-product MFMA kernel (mixed precision)
 void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
                                const double *Q, long long ldp, long long M, long long K) {
   if (M <= 0 || K <= 0) return;
@@ -642,6 +734,7 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
     tiles = (long long)((g.nsuper + 7) / 8) * 8 * 64;
   }
   if (variant == 2) hipLaunchKernelGGL(trailing_update_valu_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+  else if (variant == 3) hipLaunchKernelGGL(trailing_update_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
   else hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
 }
 

@@ -687,8 +687,19 @@ class GaussianProcessRegression:
         y, yv = self._targets(fs, dataset.targets)
         s = fs.as_struct()
         h = C.c_void_p()
-        st = ctx._lib.agp_fit_create(ctx._h, ctx.kernel(self.covariance_function_), C.byref(s), _ptr(y), _ptr(yv),
-                                     C.byref(h), None, None)
+        if self.precision == "mixed":
+            # agp_fit_create_mixed: fp32-product bulk updates + fp64 conjugate-gradient refinement of the
+            # information vector (BASELINE configs[3]); `refinement_` keeps (iterations, relative residual)
+            it, res = C.c_int(0), C.c_double(0.)
+            st = ctx._lib.agp_fit_create_mixed(ctx._h, ctx.kernel(self.covariance_function_), C.byref(s), _ptr(y),
+                                               _ptr(yv), int(self.max_refinements), float(self.refinement_tolerance),
+                                               C.byref(h), None, None, C.byref(it), C.byref(res))
+            self.refinement_ = (it.value, res.value)
+        elif self.precision == "fp64":
+            st = ctx._lib.agp_fit_create(ctx._h, ctx.kernel(self.covariance_function_), C.byref(s), _ptr(y), _ptr(yv),
+                                         C.byref(h), None, None)
+        else:
+            raise ValueError(f"precision must be 'fp64' or 'mixed', not {self.precision!r}")
         if st != capi.AGP_OK:
             pivot = ctx._lib.agp_fit_failed_pivot(h) if h else -1
             if h:
@@ -699,6 +710,12 @@ class GaussianProcessRegression:
         return FitModel(self, GPFit(ctx, h, fs.n, dataset.features))
 
     pivoted_fallback = True
+    # 'fp64' (the reference's arithmetic) or 'mixed' (fp32 MFMA products in the bulk updates of the factorisation,
+    # information vector refined to fp64; see agp_fit_create_mixed in include/albatross_amd.h)
+    precision = "fp64"
+    max_refinements = 50
+    refinement_tolerance = 1e-12
+    refinement_ = None
 
     def _fit_pivoted(self, dataset, fs, y, yv):
         """The reference's own route for covariances that are only positive SEMI-definite ("unobservable" models,

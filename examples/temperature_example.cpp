@@ -7,6 +7,7 @@
 // Output (CSV on stdout): station,<x>,<y>,<z>,<height>,<temp> / pred,<x>,<y>,<z>,<height>,<mean>,<var>
 // Usage: temperature_example [n_train] [n_predict]
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <random>
 
@@ -86,6 +87,23 @@ int main(int argc, char *argv[]) {
   const auto fit_model = model.fit(RegressionDataset<Station>(stations, temps));
   std::printf("loglik,%.17g\n", model.log_likelihood(RegressionDataset<Station>(stations, temps)));
   const auto pred = fit_model.predict(grid).marginal();
+  if (argc > 3 && std::string(argv[3]) == "mixed") {
+    // BASELINE configs[3]: the same fit with fp32 MFMA products in the bulk updates and an fp64-refined
+    // information vector; predicted means must agree with the all-fp64 fit
+    auto mixed_model = model;
+    mixed_model.mixed_precision.enabled = true;
+    const auto mixed_fit = mixed_model.fit(RegressionDataset<Station>(stations, temps));
+    const auto mixed_pred = mixed_fit.predict(grid).marginal();
+    double dmax = 0., mmax = 0., vmax = 0., vdiff = 0.;
+    for (int i = 0; i < m; ++i) {
+      dmax = std::max(dmax, std::fabs(mixed_pred.mean[i] - pred.mean[i]));
+      mmax = std::max(mmax, std::fabs(pred.mean[i]));
+      vdiff = std::max(vdiff, std::fabs(mixed_pred.covariance[i] - pred.covariance[i]));
+      vmax = std::max(vmax, std::fabs(pred.covariance[i]));
+    }
+    std::printf("mixed,%d,%.3g,%.3g,%.3g\n", mixed_model.mixed_precision.iterations, mixed_model.mixed_precision.residual,
+                dmax / mmax, vdiff / vmax);
+  }
   for (int i = 0; i < n; ++i)
     std::printf("station,%.17g,%.17g,%.17g,%.17g,%.17g\n", stations[i].ecef[0], stations[i].ecef[1], stations[i].ecef[2],
                 stations[i].height, temps[i]);

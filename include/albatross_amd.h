@@ -152,6 +152,23 @@ int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x,
 int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x,
                    const double *y, const double *y_var, agp_fit **out,
                    double *information, double *log_det);
+/* Mixed-precision variant of agp_fit_create (BASELINE.json configs[3], SURVEY
+ * section 8d config 4): the same Fit<GPFit> constructor (models/gp.hpp:61-69),
+ * but the bulk trailing updates of the LL^T multiply fp32-rounded panels on the
+ * fp32 MFMA path (the panel chain, the matrix and every accumulation between
+ * outer steps stay fp64) and the information vector is then refined in fp64:
+ * conjugate gradients on the exact fp64 covariance, preconditioned with that
+ * factor, until ||y - K a||_2 <= tolerance * ||y||_2, `max_iterations` steps, or
+ * the fp64 floor of the system.  *iterations / *residual (may be NULL) report
+ * the steps taken and the final relative residual.  The factor kept in *out is
+ * the mixed-precision one: predicted means use the refined information vector,
+ * variances and log_det carry the fp32 rounding of the products (relative
+ * ~1e-6).  The reference has no reduced-precision path; this one exists for
+ * problems where one fp64 factorisation is too slow (N >= 32768). */
+int agp_fit_create_mixed(agp_context *ctx, const agp_kernel *k, const agp_features *x,
+                         const double *y, const double *y_var, int max_iterations,
+                         double tolerance, agp_fit **out, double *information,
+                         double *log_det, int *iterations, double *residual);
 void agp_fit_destroy(agp_fit *fit);
 int64_t agp_fit_size(const agp_fit *fit);
 /* 0-based index of the first non-positive pivot of the last failed factor */

@@ -1106,8 +1106,16 @@ class GaussianProcessRegression {
     fit.information.resize(features.size());
     fit.context = ctx;
     agp_fit *h = nullptr;
-    const int st = agp_fit_create(ctx->ctx, k.k, &f.view, y.data(), targets.covariance.empty() ? nullptr : targets.covariance.data(),
-                                  &h, fit.information.data(), &fit.log_determinant);
+    const double *yvar = targets.covariance.empty() ? nullptr : targets.covariance.data();
+    int st;
+    if (mixed_precision.enabled) {
+      // fp32 MFMA products in the bulk updates of the factorisation, information vector refined to fp64
+      st = agp_fit_create_mixed(ctx->ctx, k.k, &f.view, y.data(), yvar, mixed_precision.max_iterations,
+                                mixed_precision.tolerance, &h, fit.information.data(), &fit.log_determinant,
+                                &mixed_precision.iterations, &mixed_precision.residual);
+    } else {
+      st = agp_fit_create(ctx->ctx, k.k, &f.view, y.data(), yvar, &h, fit.information.data(), &fit.log_determinant);
+    }
     if (st != AGP_OK) {
       const long long pivot = h ? static_cast<long long>(agp_fit_failed_pivot(h)) : -1;
       agp_fit_destroy(h);
@@ -1121,6 +1129,17 @@ class GaussianProcessRegression {
 
   // core/model.hpp:154-156
   auto cross_validate() const;
+
+  // Not in the reference: opt-in mixed-precision fit (agp_fit_create_mixed; BASELINE configs[3]).  `iterations` and
+  // `residual` report the refinement of the last fit.
+  struct MixedPrecision {
+    bool enabled = false;
+    int max_iterations = 50;
+    double tolerance = 1e-12;
+    mutable int iterations = 0;
+    mutable double residual = 0.;
+  };
+  MixedPrecision mixed_precision;
 
   // fit_from_prediction (gp.hpp:236-245) -> gp_fit_from_prediction (gp.hpp:139-153): the model that reproduces a
   // joint prediction at `features`

@@ -146,7 +146,9 @@ def test_temperature_example_config4_kernel():
     """BASELINE config 4's spatial kernel (examples/temperature_example) in fp64 on synthetic
     stations: a user feature type (Station: ECEF coords, equality by ECEF, elevation-dependent
     ScalingTerm) through the C++ surface vs the oracle."""
-    rows = run("temperature_example", "1500", "100")
+    rows = run("temperature_example", "1500", "100", "mixed")
+    its, res, dmean, dvar = (float(v) for v in rows["mixed"][0])
+    assert res <= 1e-12 and dmean <= 1e-8 and dvar <= 1e-4, rows["mixed"]  # mixed-precision fit of the same model
     st = np.array(rows["station"], dtype=float)
     pr = np.array(rows["pred"], dtype=float)
     assert rows["name"][0][0] == ("(((elevation_scaled*constant)+independent_noise)+"

@@ -1,0 +1,121 @@
+"""BASELINE.json configs[3] / SURVEY.md section 8d config 4: the mixed-precision fit (agp_fit_create_mixed: fp32 MFMA
+products in the bulk trailing updates, fp64 panel chain and accumulation, fp64 conjugate-gradient refinement of the
+information vector) against the oracle and against the all-fp64 fit.
+
+Stated tolerances: information vector and predicted means 1e-8 relative (the same as the fp64 path: the refinement
+runs to a 1e-12 relative residual); log-determinant 1e-5 relative and predictive variances 1e-4 relative (they keep
+the fp32 rounding of the products)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import albatross_amd as ab
+from albatross_amd import _capi as capi
+from conftest import synthetic_3d, synthetic_stations, temperature_covariance
+from oracle import oracle_py as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+@pytest.mark.parametrize("M,K", [(256, 16), (640, 128), (1000, 256), (1418, 512), (130, 32)])
+def test_fp32_product_update_kernel(ctx, M, K):
+    """trailing_update_f32_kernel: C(fp64) -= fl32(P) fl32(P)^T with fp32 accumulation inside the launch."""
+    lib = capi.load()
+    lib.agp_debug_trailing_update.restype = C.c_int
+    lib.agp_debug_trailing_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                              C.c_int64, C.c_int]
+    rng = np.random.default_rng(M + K)
+    ldc, ldp = M + 8 - (M % 2), M + 10 - (M % 2)
+    Cm = np.asfortranarray(rng.standard_normal((ldc, M)))
+    P = np.asfortranarray(rng.standard_normal((ldp, K)))
+    P32 = P[:M].astype(np.float32).astype(np.float64)
+    want = Cm[:M] - P32 @ P32.T
+    got = Cm.copy(order="F")
+    assert lib.agp_debug_trailing_update(ctx._h, _p(got), ldc, _p(P), ldp, M, K, 3) == 0
+    low = np.tril_indices(M)
+    err = np.abs(got[:M][low] - want[low]).max()
+    bound = np.abs(P[:M]).sum(axis=1).max() ** 2
+    assert err <= 2. ** -22 * bound                      # fp32 accumulation of K products
+    exact = Cm[:M] - P[:M] @ P[:M].T
+    assert np.abs(got[:M][low] - exact[low]).max() > 1e-12  # ... and it really is the fp32 path
+    assert np.array_equal(got[M:], Cm[M:])               # padding rows untouched
+
+
+@pytest.mark.parametrize("n", [300, 1100, 2300])
+def test_mixed_fit_matches_oracle(ctx, n):
+    x, y = synthetic_3d(n, 5 + n)
+    cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+    model = ab.gp_from_covariance(cov, context=ctx)
+    model.precision = "mixed"
+    fm = model.fit(ab.RegressionDataset(x, y))
+    its, res = model.refinement_
+    ofit = orc.OracleFit(cov, ab.FeatureSet(x), y)
+    assert res <= 1e-12 and its >= 1, (its, res)
+    assert rel(fm.get_fit().information, ofit.information) <= 1e-8
+    xs, _ = synthetic_3d(200, 77)
+    om, ov = ofit.predict_marginal(ab.FeatureSet(xs))
+    pred = fm.predict(xs).marginal()
+    assert rel(pred.mean, om) <= 1e-8
+    assert np.abs(pred.covariance - ov).max() <= 1e-4 * np.abs(ov).max()
+    assert abs(fm.get_fit().log_determinant - ofit.log_determinant) <= 1e-5 * abs(ofit.log_determinant)
+
+
+def test_mixed_fit_config4_kernel(ctx):
+    """The temperature-example covariance on synthetic stations: mixed vs all-fp64 vs oracle (small N)."""
+    n = 1500
+    ecef, h, temp = synthetic_stations(n, 11)
+    cov, scale = temperature_covariance(ab)
+    train = ab.FeatureSet(ecef, [scale(h)])
+    y = temp - temp.mean()
+    m64 = ab.gp_from_covariance(cov, context=ctx)
+    f64 = m64.fit(ab.RegressionDataset(train, y))
+    mm = ab.gp_from_covariance(cov, context=ctx)
+    mm.precision = "mixed"
+    fmx = mm.fit(ab.RegressionDataset(train, y))
+    its, res = mm.refinement_
+    assert res <= 1e-12, (its, res)
+    ofit = orc.OracleFit(cov, train, y)
+    assert rel(f64.get_fit().information, ofit.information) <= 1e-8
+    assert rel(fmx.get_fit().information, ofit.information) <= 1e-8
+    assert abs(fmx.get_fit().log_determinant - ofit.log_determinant) <= 1e-5 * abs(ofit.log_determinant)
+
+
+def test_mixed_fit_large_property(ctx):
+    """Size-independent property at N = 8192: the returned information vector solves K a = y (checked against an
+    independently built Gram matrix), and agrees with the all-fp64 fit."""
+    n = 8192
+    x, y = synthetic_3d(n, 44)
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+    mm = ab.gp_from_covariance(cov, context=ctx)
+    mm.precision = "mixed"
+    fmx = mm.fit(ab.RegressionDataset(x, y))
+    its, res = mm.refinement_
+    a = fmx.get_fit().information
+    K = ctx.gram(cov, ab.Measurement(x))
+    assert np.linalg.norm(K @ a - y) <= 1e-11 * np.linalg.norm(y)
+    assert res <= 1e-12 and 1 <= its <= 30, (its, res)
+    f64 = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
+    assert rel(a, f64.get_fit().information) <= 1e-8
+    assert abs(fmx.get_fit().log_determinant - f64.get_fit().log_determinant) <= 1e-5 * abs(f64.get_fit().log_determinant)
+
+
+def test_mixed_fit_reports_failures(ctx):
+    x, y = synthetic_3d(300, 3)
+    x[17] = x[3]  # duplicate point and no noise: singular
+    model = ab.gp_from_covariance(ab.SquaredExponential(1.0, 1.0), context=ctx)
+    model.precision = "mixed"
+    model.pivoted_fallback = False
+    with pytest.raises(ab.NotPositiveDefiniteError):
+        model.fit(ab.RegressionDataset(x, y))
+    model.precision = "fp16"
+    with pytest.raises(ValueError):
+        model.fit(ab.RegressionDataset(x, y))
