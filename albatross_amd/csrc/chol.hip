@@ -575,17 +575,19 @@ static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, 
 // the caller collects per-launch timings (bench.py's roofline block)
 static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long lda, const double *P,
                        const double *Q, long long M, long long N, long long K, bool bulk, int variant = -1) {
-  // only the bulk trailing updates (their own kernel symbol) are event-timed:
-  // they run on the second stream, where an event gap is off the critical path
-  const bool timed = bulk && timers && timers->ev && timers->used + 2 <= timers->n_ev;
-  if (timed) (void)hipEventRecord(timers->ev[timers->used], s);
-  if (bulk && variant >= 0) launch_trailing_update_as(variant, s, C, lda, P, Q, lda, M, K);
-  else if (bulk) launch_trailing_update(s, C, lda, P, Q, lda, M, K);
-  else launch_gemm_nt_sub(s, C, lda, P, lda, false, Q, lda, false, M, N, K, true);
-  if (timed) {
-    (void)hipEventRecord(timers->ev[timers->used + 1], s);
-    // algorithmic flop: 2 K per C entry on or below the diagonal
-    timers->flops[timers->used / 2] = 2. * (double)K * ((double)M * (double)N - 0.5 * (double)N * (double)(N - 1));
+  // only the bulk trailing updates' trailing_update_kernel launches (their own kernel symbol) are
+  // event-timed: they run on the second stream, where an event gap is off the critical path
+  if (!bulk) {
+    launch_gemm_nt_sub(s, C, lda, P, lda, false, Q, lda, false, M, N, K, true);
+    return;
+  }
+  BulkTiming bt;
+  const bool timed = timers && timers->ev && timers->used + 2 <= timers->n_ev;
+  if (timed) { bt.e0 = timers->ev[timers->used]; bt.e1 = timers->ev[timers->used + 1]; }
+  if (variant >= 0) launch_trailing_update_as(variant, s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
+  else launch_trailing_update(s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
+  if (timed && bt.flops > 0.) {
+    timers->flops[timers->used / 2] = bt.flops;  // algorithmic flop: 2 K per covered C entry on or below the diagonal
     timers->used += 2;
   }
 }

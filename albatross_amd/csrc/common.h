@@ -181,8 +181,16 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
                         bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
                         long long N, long long K, bool tri);
 // bulk trailing update of the factorisation: C(M x M, lower tiles) -= P Q^T
+// `timing` (optional): an event pair recorded around the trailing_update_kernel launch of this update
+// (not around the 64-tile tail launch) and the algorithmic flop of exactly the tiles that launch covers;
+// flops == 0 on return means no such launch was made and the events were not recorded.
+struct BulkTiming {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double flops = 0.;
+};
 void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
-                               const double *Q, long long ldp, long long M, long long K);
+                               const double *Q, long long ldp, long long M, long long K,
+                               BulkTiming *timing = nullptr);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
-                            long long ldp, long long M, long long K);
+                            long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
 }  // namespace agp

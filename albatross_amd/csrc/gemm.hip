@@ -46,6 +46,7 @@ struct GemmArgs {
   int remap, nsuper, nb8;
   // batched launches (blockIdx.y = batch entry): element offsets per entry; 0 = not batched
   long long batch_C = 0, batch_A = 0, batch_B = 0;
+  long long tile_first = 0;  // first tile (in column-major tile order) of this launch: split bulk updates
 };
 
 // Load this thread's 8 doubles of a 128 x 16 operand chunk.
@@ -152,7 +153,7 @@ __device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int &bi, int &b
     return bi < g.ntr && bj < g.ntc && bi >= bj;
   }
   bj = 0;
-  long long id = blockIdx.x;
+  long long id = blockIdx.x + g.tile_first;
   while (true) {
     const int cnt = g.tri ? (g.ntr - bj) : g.ntr;
     if (id < cnt) break;
@@ -556,23 +557,7 @@ __device__ __forceinline__ void store_chunk64(double *__restrict__ Ls, const dou
   dst[1] = NEGATE ? make_double2(-r[2], -r[3]) : make_double2(r[2], r[3]);
 }
 
-__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs g) {
-  __builtin_amdgcn_s_setprio(3);  // panel-chain updates: issue ahead of co-resident bulk-update waves
-  g.C += (long long)blockIdx.y * g.batch_C;
-  g.A += (long long)blockIdx.y * g.batch_A;
-  g.B += (long long)blockIdx.y * g.batch_B;
-  __shared__ double lds[2 * 2 * GK * SLD];
-  int bj = 0;
-  long long id = blockIdx.x;
-  while (true) {
-    // tri: column bj of 64-tiles holds the row tiles bi >= bj
-    const int cnt = g.tri ? (g.ntr - bj) : g.ntr;
-    if (id < cnt) break;
-    id -= cnt;
-    ++bj;
-  }
-  const int bi = (g.tri ? bj : 0) + (int)id;
-  const long long i0 = (long long)bi * ST, j0 = (long long)bj * ST;
+__device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i0, const long long j0, double *lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int ln = lane & 15, lg = lane >> 4;
@@ -654,6 +639,45 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs
     }
 }
 
+
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs g) {
+  __builtin_amdgcn_s_setprio(3);  // panel-chain updates: issue ahead of co-resident bulk-update waves
+  g.C += (long long)blockIdx.y * g.batch_C;
+  g.A += (long long)blockIdx.y * g.batch_A;
+  g.B += (long long)blockIdx.y * g.batch_B;
+  __shared__ double lds[2 * 2 * GK * SLD];
+  int bj = 0;
+  long long id = blockIdx.x;
+  while (true) {
+    // tri: column bj of 64-tiles holds the row tiles bi >= bj
+    const int cnt = g.tri ? (g.ntr - bj) : g.ntr;
+    if (id < cnt) break;
+    id -= cnt;
+    ++bj;
+  }
+  const int bi = (g.tri ? bj : 0) + (int)id;
+  gemm64_body(g, (long long)bi * ST, (long long)bj * ST, lds);
+}
+
+// The LAST tiles of a bulk update (those that would form a partial round of 128 x 128 workgroups) as
+// four 64 x 64 workgroups each: the tail of the launch is a quarter as long.  ntr / ntc / tile_first
+// are in 128-tile units like trailing_update_kernel's.
+__global__ __launch_bounds__(GEMM_THREADS, 4) void trailing_update_tail_kernel(GemmArgs g) {
+  __shared__ double lds[2 * 2 * GK * SLD];
+  int bj = 0;
+  long long id = (long long)(blockIdx.x >> 2) + g.tile_first;
+  while (true) {
+    const int cnt = g.ntr - bj;
+    if (id < cnt) break;
+    id -= cnt;
+    ++bj;
+  }
+  const int bi = bj + (int)id;
+  const int q = blockIdx.x & 3, qi = q & 1, qj = q >> 1;
+  if (bi == bj && qj > qi) return;  // upper quadrant of a diagonal tile
+  gemm64_body(g, (long long)bi * GT + qi * ST, (long long)bj * GT + qj * ST, lds);
+}
+
 static long long count_tiles(int ntr, int ntc, int tri) {
   long long total = 0;
   for (int bj = 0; bj < ntc; ++bj) total += tri ? (ntr - bj > 0 ? ntr - bj : 0) : ntr;
@@ -706,8 +730,22 @@ void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A
 }
 
 // variant 0: MFMA kernel, 2: DPP-broadcast VALU kernel (experiment), 3: fp32-product MFMA kernel (mixed precision)
+// entries on or below the diagonal of C covered by the first `count` lower tiles (column-major tile order)
+static double lower_entries(long long M, int ntr, long long count) {
+  double e = 0.;
+  for (int bj = 0; bj < ntr && count > 0; ++bj) {
+    const long long w = (M - (long long)bj * GT < GT) ? M - (long long)bj * GT : GT;  // tile column width
+    for (int bi = bj; bi < ntr && count > 0; ++bi, --count) {
+      const long long h = (M - (long long)bi * GT < GT) ? M - (long long)bi * GT : GT;
+      e += (bi == bj) ? 0.5 * (double)w * (double)(w + 1) : (double)h * (double)w;
+    }
+  }
+  return e;
+}
+
 void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
-                               const double *Q, long long ldp, long long M, long long K) {
+                               const double *Q, long long ldp, long long M, long long K, BulkTiming *timing) {
+  if (timing) timing->flops = 0.;
   if (M <= 0 || K <= 0) return;
   GemmArgs g;
   g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = Q; g.ldb = ldp;
@@ -733,13 +771,56 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
     g.nsuper = g.nb8 * (g.nb8 + 1) / 2;
     tiles = (long long)((g.nsuper + 7) / 8) * 8 * 64;
   }
+  if ((variant == 0 || variant == 4 || variant == 5) && g.remap == 0) {
+    // Tail split: a launch of T tiles runs floor(T / slots) full rounds of 128 x 128 workgroups (slots = 2 per
+    // CU); the T mod slots tiles left over would occupy a fraction of the chip for a whole further round.
+    // They go to trailing_update_tail_kernel as four 64 x 64 workgroups each.
+    static int split = -1, slots = 512;
+    if (split < 0) {
+      // AGP_TAIL_SPLIT=0: one launch of 128 x 128 tiles (the behaviour before the tail split)
+      const char *e = getenv("AGP_TAIL_SPLIT");
+      split = e ? atoi(e) : 1;
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess &&
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        slots = 2 * cus;
+    }
+    const bool do_split = variant == 5 || (variant == 0 && split == 1);
+    long long full = tiles, rem = 0;
+    if (variant == 4) { full = 0; rem = tiles; }
+    else if (do_split) {
+      if (variant == 0 && tiles < 4LL * slots) {
+        // fewer than four rounds of large tiles: 64 x 64 workgroups throughout balance the CUs better
+        // (scripts/time_tail_split.py: M = 4096, K = 512: 0.196 ms instead of 0.272)
+        full = 0; rem = tiles;
+      } else {
+        full = (tiles / slots) * slots;
+        rem = tiles - full;
+        if (rem * 4 >= 3LL * slots) { full = tiles; rem = 0; }  // an almost full round: leave it to the large tiles
+      }
+    }
+    if (full > 0) {
+      if (timing && timing->e0) (void)hipEventRecord(timing->e0, s);
+      hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)full), dim3(GEMM_THREADS), 0, s, g);
+      if (timing && timing->e1) {
+        (void)hipEventRecord(timing->e1, s);
+        timing->flops = 2. * (double)K * lower_entries(M, g.ntr, full);
+      }
+    }
+    if (rem > 0) {
+      GemmArgs h = g;
+      h.tile_first = full;
+      hipLaunchKernelGGL(trailing_update_tail_kernel, dim3((unsigned)(4 * rem)), dim3(GEMM_THREADS), 0, s, h);
+    }
+    return;
+  }
   if (variant == 2) hipLaunchKernelGGL(trailing_update_valu_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
   else if (variant == 3) hipLaunchKernelGGL(trailing_update_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
   else hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
 }
 
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
-                            long long ldp, long long M, long long K) {
+                            long long ldp, long long M, long long K, BulkTiming *timing) {
   static int variant = -1;
   if (variant < 0) {
     // mfma (default) | dpp.  Measured on MI355X (scripts/time_update.py, M = 15872, K = 512): MFMA
@@ -748,7 +829,7 @@ void launch_trailing_update(hipStream_t s, double *C, long long ldc, const doubl
     const char *e = getenv("AGP_UPDATE_KERNEL");
     variant = (e && e[0] == 'd') ? 2 : 0;
   }
-  launch_trailing_update_as(variant, s, C, ldc, P, Q, ldp, M, K);
+  launch_trailing_update_as(variant, s, C, ldc, P, Q, ldp, M, K, timing);
 }
 
 void read_valu_clock(unsigned long long out[4], bool reset) {

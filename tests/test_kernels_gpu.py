@@ -81,10 +81,11 @@ def test_gemm_nt_sub(ctx, dbg, M, N, K, tri, akm, bkm):
     assert np.array_equal(Cd[M:], np.zeros((ldc - M, N)))  # padding rows untouched
 
 
-@pytest.mark.parametrize("variant", [0, 2])
-@pytest.mark.parametrize("M,K", [(256, 16), (640, 128), (1000, 256), (1418, 512), (130, 32)])
+@pytest.mark.parametrize("variant", [0, 2, 4, 5])
+@pytest.mark.parametrize("M,K", [(256, 16), (640, 128), (1000, 256), (1418, 512), (130, 32), (4300, 64)])
 def test_trailing_update_variants(ctx, dbg, M, K, variant):
-    """Bulk update C -= P P^T on the lower tiles: MFMA kernel (0) and the DPP-broadcast VALU kernel (2)."""
+    """Bulk update C -= P P^T on the lower tiles: MFMA kernel (0), the DPP-broadcast VALU kernel (2), every tile as
+    four 64 x 64 workgroups (4), full rounds of 128-tiles + a 64-tile tail (5)."""
     rng = np.random.default_rng(M + K)
     ldc, ldp = M + 8 - (M % 2), M + 10 - (M % 2)
     Cm = np.asfortranarray(rng.standard_normal((ldc, M)))
