@@ -838,7 +838,7 @@ int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs, int64_t n
   AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->ws_aux, sizeof(double) * (size_t)ldb, rhs, sizeof(double) * (size_t)n,
                                       sizeof(double) * (size_t)n, (size_t)nrhs, kind, ctx->stream));
   if (location == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  forward_solve_mat(ctx->stream, fit->A, n, fit->lda, fit->invd, ctx->ws_aux, nrhs, ldb);
+  forward_solve_mat_lookahead(ctx, fit->A, n, fit->lda, fit->invd, ctx->ws_aux, nrhs, ldb);
   backward_solve_mat(ctx->stream, fit->A, n, fit->lda, fit->invd, ctx->ws_aux, nrhs, ldb);
   return copy_out_2d(ctx, ctx->ws_aux, ldb, n, nrhs, out, n, location);
 }
@@ -947,7 +947,7 @@ static int inverse_diagonal_device(agp_context *ctx, const agp_fit *fit, double 
   hipStream_t s = ctx->stream;
   launch_set_identity(s, R, ldr, n);
   // R = L^-1 (serializable_ldlt.hpp:154-160), exploiting the triangular right-hand side
-  forward_solve_mat(s, fit->A, n, fit->lda, fit->invd, R, n, ldr, /*rhs_lower=*/true);
+  forward_solve_mat_lookahead(ctx, fit->A, n, fit->lda, fit->invd, R, n, ldr, /*rhs_lower=*/true);
   // (K^-1)_ii = || R[:, i] ||^2   (sub_matrix^T * sub_matrix, :171-172)
   launch_coldot(s, R, ldr, R, ldr, n, n, diag, -1.0, nullptr);
   AGP_HIP_CHECK(ctx, hipGetLastError());
@@ -1030,7 +1030,7 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
   // cross_cov = cov(train_features, features)   (gp.hpp:316,337)
   launch_gram(s, dprog, fit->train.v, dxs.v, false, false, V, ldv, nullptr, nullptr, &k->prog);
   // V = L^-1 K*  ;  explained = V^T V  (== K*^T K^-1 K*, gp.hpp:96,111)
-  forward_solve_mat(s, fit->A, n, fit->lda, fit->invd, V, m, ldv);
+  forward_solve_mat_lookahead(ctx, fit->A, n, fit->lda, fit->invd, V, m, ldv);
   if (!joint) {
     launch_gram_diagonal(s, dprog, dxs.v, prior);                   // gp.hpp:339-343
     launch_coldot(s, V, ldv, V, ldv, n, m, prior, 1.0, prior);      // gp.hpp:97-99

@@ -748,6 +748,59 @@ void forward_solve_mat(hipStream_t s, const double *A, long long n, long long ld
   }
 }
 
+// The same substitution with one outer block of look-ahead on the context's two streams (like
+// factor_lower): the solve of block rows j + 1 (small, latency-bound launches) runs on the main
+// stream while the update of everything below with block j's solution (the MFMA-bound bulk) runs on
+// the second one.  Returns with the main stream ordered after all work.
+void forward_solve_mat_lookahead(agp_context *ctx, const double *A, long long n, long long lda, const double *invd,
+                                 double *B, long long m, long long ldb, bool rhs_lower) {
+  if (m <= 0) return;
+  hipStream_t sa = ctx->stream, sb = ctx->stream2;
+  if (n <= 2 * NBO || !sb || m < 64) {  // too small for the second stream to pay for its events
+    forward_solve_mat(sa, A, n, lda, invd, B, m, ldb, rhs_lower);
+    return;
+  }
+  bool have_u2 = false;
+  for (long long K0 = 0; K0 < n; K0 += NBO) {
+    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
+    for (long long k = K0; k < kend; k += NB) {
+      const int nbk = (int)((n - k < NB) ? n - k : NB);
+      TrsmArgs t;
+      t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+      t.nbk = nbk;
+      t.Y = B + k;
+      t.stride_m = 1; t.stride_n = ldb;
+      const long long m_act = (rhs_lower && k + nbk < m) ? k + nbk : m;
+      t.ncols = m_act;
+      t.z = nullptr; t.yrest = nullptr;
+      t.batch_img = t.batch_Y = 0; t.n_total = 0;
+      hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m_act + 63) / 64)), dim3(256), 0, sa, t);
+      const long long rows = kend - (k + nbk);
+      if (rows > 0)
+        launch_gemm_nt_sub(sa, B + k + nbk, ldb, A + k * lda + (k + nbk), lda, false, B + k, ldb, true, rows, m_act,
+                           nbk, false);
+    }
+    if (kend >= n) break;
+    const long long next_end = (kend + NBO < n) ? kend + NBO : n;
+    const long long m_act = (rhs_lower && kend < m) ? kend : m;
+    (void)hipEventRecord(ctx->ev_a, sa);                      // block j solved
+    if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);  // U2(j - 1) done: it wrote the rows U1(j) writes
+    // U1(j): the next block's rows
+    launch_gemm_nt_sub(sa, B + kend, ldb, A + K0 * lda + kend, lda, false, B + K0, ldb, true, next_end - kend, m_act,
+                       kend - K0, false);
+    if (next_end < n) {
+      (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
+      launch_gemm_nt_sub(sb, B + next_end, ldb, A + K0 * lda + next_end, lda, false, B + K0, ldb, true, n - next_end,
+                         m_act, kend - K0, false);
+      (void)hipEventRecord(ctx->ev_b, sb);
+      have_u2 = true;
+    } else {
+      have_u2 = false;
+    }
+  }
+  if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
+}
+
 // `count` independent n x n factorisations in lock step (blockIdx.y = problem): the blocks of a sparse
 // GP's A.  Problem b lives at A + b * stride_A (leading dimension lda), its tile images at
 // invd + b * stride_invd, its right-hand side (optional, fused forward substitution) at y + b * stride_y;

@@ -156,6 +156,8 @@ void launch_gemm_nt_sub_batched(hipStream_t s, double *C, long long ldc, long lo
                                 long long count);
 void right_solve_lt(hipStream_t s, const double *A, long long n, long long lda, const double *invd, double *X,
                     long long nrows, long long ldx);
+void forward_solve_mat_lookahead(agp_context *ctx, const double *A, long long n, long long lda, const double *invd,
+                                 double *B, long long m, long long ldb, bool rhs_lower = false);
 void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                         double *B, long long m, long long ldb);
 

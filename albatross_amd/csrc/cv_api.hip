@@ -57,7 +57,7 @@ int group_work_init(agp_context *ctx, const agp_fit *fit, int64_t n_groups, cons
   AGP_HIP_CHECK(ctx, hipMemcpyAsync(w->idx, indices, sizeof(long long) * (size_t)total, hipMemcpyHostToDevice, ctx->stream));
   hipStream_t s = ctx->stream;
   launch_set_identity(s, w->R, w->ldr, n);
-  forward_solve_mat(s, fit->A, n, fit->lda, fit->invd, w->R, n, w->ldr, /*rhs_lower=*/true);
+  forward_solve_mat_lookahead(ctx, fit->A, n, fit->lda, fit->invd, w->R, n, w->ldr, /*rhs_lower=*/true);
   AGP_HIP_CHECK(ctx, hipGetLastError());
   return AGP_OK;
 }
