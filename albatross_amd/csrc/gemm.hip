@@ -787,7 +787,7 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
     }
     const bool do_split = variant == 5 || (variant == 0 && split == 1);
     long long full = tiles, rem = 0;
-    if (variant == 4) { full = 0; rem = tiles; }
+    if (variant == 4 || (variant == 0 && split == 2)) { full = 0; rem = tiles; }  // AGP_TAIL_SPLIT=2: 64-tiles only
     else if (do_split) {
       if (variant == 0 && tiles < 4LL * slots) {
         // fewer than four rounds of large tiles: 64 x 64 workgroups throughout balance the CUs better

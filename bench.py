@@ -43,7 +43,7 @@ def make_dataset(n, seed):
     return x, y
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=30.0):
     """Oracle ("port") timed on host cores: albatross-faithful default = serial
     Gram + single-threaded unblocked pivoted LDL^T.  Bounded sample, scaled to
     fits/sec at N = 16384 by the N^3 law of the factorisation."""
