@@ -118,6 +118,68 @@ __global__ __launch_bounds__(256) void fmac_rate_kernel(unsigned long long *out,
 
 using namespace agp;
 
+// Bare issue loops of the two fp64 MFMA shapes: mode 0 = v_mfma_f64_16x16x4_f64 with NACC independent
+// accumulators, mode 1 = v_mfma_f64_4x4x4_4b_f64 (four 4 x 4 x 4 blocks, 512 flop) with NACC accumulators.
+template <int MODE, int NACC>
+__global__ __launch_bounds__(256) void mfma_shape_kernel(double *sink, int iters, double a0, double b0) {
+  double a = a0 + threadIdx.x * 1e-9, b = b0 - threadIdx.x * 1e-9;
+  double s = 0.;
+  if (MODE == 0) {
+    agp::v4d acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = agp::v4zero();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  } else if (MODE == 1) {
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+  } else {
+    // mode 2: as mode 1 but with 16 different A and 4 different B operand registers (the GEMM pattern)
+    double acc[NACC], av[16], bv[4];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) av[i] = a + i * 1e-3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = b - i * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[i & 15], bv[(i >> 4) & 3], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(av[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+  }
+  if (s == 123.456) sink[0] = s;
+}
+
+
+// Lane-map probe of v_mfma_f64_4x4x4_4b_f64: for every pair (la, lb) the operand A is one-hot in lane la and
+// B one-hot in lane lb; out[(la * 64 + lb)] = mask of result lanes that are non-zero.
+template <int CBSZ, int ABID>
+__global__ __launch_bounds__(64) void mfma44_probe_kernel(unsigned long long *out) {
+  const int lane = threadIdx.x;
+  for (int la = 0; la < 64; ++la)
+    for (int lb = 0; lb < 64; ++lb) {
+      const double a = lane == la ? 1. : 0., b = lane == lb ? 1. : 0.;
+      const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0., CBSZ, ABID, 0);
+      const unsigned long long m = __ballot(d != 0.);
+      if (lane == 0) out[la * 64 + lb] = m;
+    }
+}
+
 #ifdef AGP_POTRF_TIMING
 namespace agp { void read_potrf_timing(unsigned long long *out); }
 extern "C" int agp_debug_potrf_timing(unsigned long long *out) { read_potrf_timing(out); return 0; }
@@ -292,6 +354,62 @@ int agp_debug_fmac_rate(agp_context *ctx, int waves_per_simd, int mode, int iter
   return AGP_OK;
 }
 
+// mode 0: cbsz = 0; mode 1..4: cbsz = 2, abid = mode - 1.  out: 4096 masks.
+int agp_debug_mfma44_probe(agp_context *ctx, int mode, unsigned long long *out) {
+  if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  unsigned long long *d = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&d, sizeof(unsigned long long) * 4096));
+  hipStream_t s = ctx->stream;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((mfma44_probe_kernel<0, 0>), dim3(1), dim3(64), 0, s, d); break;
+    case 1: hipLaunchKernelGGL((mfma44_probe_kernel<2, 0>), dim3(1), dim3(64), 0, s, d); break;
+    case 2: hipLaunchKernelGGL((mfma44_probe_kernel<2, 1>), dim3(1), dim3(64), 0, s, d); break;
+    case 3: hipLaunchKernelGGL((mfma44_probe_kernel<2, 2>), dim3(1), dim3(64), 0, s, d); break;
+    default: hipLaunchKernelGGL((mfma44_probe_kernel<2, 3>), dim3(1), dim3(64), 0, s, d); break;
+  }
+  AGP_HIP_CHECK(ctx, hipMemcpyAsync(out, d, sizeof(unsigned long long) * 4096, hipMemcpyDeviceToHost, s));
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  (void)hipFree(d);
+  return AGP_OK;
+}
+
+// out[0] = chip TFLOP/s, out[1] = ms
+int agp_debug_mfma_shape(agp_context *ctx, int mode, int nacc, int waves_per_simd, int iters, double *out) {
+  if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  double *sink = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&sink, 8));
+  hipEvent_t e0, e1;
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e1));
+  const int blocks = 256 * waves_per_simd;
+  hipStream_t s = ctx->stream;
+  for (int rep = 0; rep < 2; ++rep) {
+    AGP_HIP_CHECK(ctx, hipEventRecord(e0, s));
+#define SHAPE_LAUNCH(M_, N_) hipLaunchKernelGGL((mfma_shape_kernel<M_, N_>), dim3(blocks), dim3(256), 0, s, sink, iters, 1.0, 2.0)
+    if (mode == 0 && nacc == 8) SHAPE_LAUNCH(0, 8);
+    else if (mode == 0 && nacc == 16) SHAPE_LAUNCH(0, 16);
+    else if (mode == 1 && nacc == 8) SHAPE_LAUNCH(1, 8);
+    else if (mode == 1 && nacc == 16) SHAPE_LAUNCH(1, 16);
+    else if (mode == 1 && nacc == 32) SHAPE_LAUNCH(1, 32);
+    else if (mode == 1 && nacc == 64) SHAPE_LAUNCH(1, 64);
+    else if (mode == 2 && nacc == 64) SHAPE_LAUNCH(2, 64);
+    else if (mode == 2 && nacc == 32) SHAPE_LAUNCH(2, 32);
+    else return AGP_ERR_INVALID_ARGUMENT;
+#undef SHAPE_LAUNCH
+    AGP_HIP_CHECK(ctx, hipEventRecord(e1, s));
+    AGP_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  }
+  float ms = 0.f;
+  AGP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  const double flop_per_mfma = mode == 0 ? 2.0 * 16 * 16 * 4 : 2.0 * 4 * 4 * 4 * 4;
+  out[0] = (double)blocks * 4.0 * (double)iters * nacc * flop_per_mfma / (ms * 1e-3) / 1e12;
+  out[1] = ms;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+  return AGP_OK;
+}
+
 // Bulk trailing update C (M x M, lower tiles) -= P P^T on host data.  variant 0: MFMA kernel,
 // 2: DPP-broadcast VALU kernel.
 int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t ldc, const double *P, int64_t ldp, int64_t M,
@@ -343,10 +461,10 @@ int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, int64_t K, int v
   float ms = 0.f;
   AGP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
   *ms_out = (double)ms / reps;
-  if (variant == 2) {
+  {
     unsigned long long c[4];
     read_valu_clock(c, true);
-    if (c[2]) fprintf(stderr, "  [dpp kernel] main loop per workgroup: %.0f cycles, clock %.3f GHz, %.1f cycles per k-step (K=%lld)\n",
+    if (c[2]) fprintf(stderr, "  [update kernel] main loop per workgroup: %.0f cycles, clock %.3f GHz, %.1f cycles per k-step (K=%lld)\n",
                       (double)c[0] / c[2], (double)c[0] / ((double)c[1] * 10.0), (double)c[0] / c[2] / (double)K, (long long)K);
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -25,6 +25,21 @@ __device__ __forceinline__ v4d mfma16(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 products D_b = A_b * B_b + C_b in one instruction
+// (lane maps measured with scripts/probe_mfma44.py; cbsz / abid have no effect on the f64 shapes):
+//     A operand : lane l holds A_b[i = l & 3][k = l >> 4],  b = (l >> 2) & 3
+//     B operand : lane l holds B_b[k = l >> 4][j = l & 3],  b = (l >> 2) & 3
+//     C/D       : lane l holds D_b[i = l >> 4][j = l & 3],  b = (l >> 2) & 3
+// It issues at 76 TFLOP/s chip-wide on MI355X where the 16x16x4 shape saturates at 47
+// (scripts/diag_mfma_shapes.py), so the GEMM kernels build their 16 x 16 tiles from FOUR of these:
+// call `rot` pairs B block b (4 values of the operand indexed by l & 15) with A block (b + rot) & 3, i.e.
+// the A fragment is read from LDS four times with its 4-element groups rotated.  A 16 x 16 x 4 product
+// D[m][n] (m: A index, n: B index) then lives in four accumulators:
+//     acc[rot], lane l  =  D[m = 4 (((l >> 2) + rot) & 3) + (l >> 4)][n = l & 15]
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ v4d v4zero() {
   v4d z = {0., 0., 0., 0.};
   return z;
