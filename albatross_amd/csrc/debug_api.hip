@@ -374,6 +374,7 @@ int agp_debug_mfma44_probe(agp_context *ctx, int mode, unsigned long long *out) 
   return AGP_OK;
 }
 
+
 // out[0] = chip TFLOP/s, out[1] = ms
 int agp_debug_mfma_shape(agp_context *ctx, int mode, int nacc, int waves_per_simd, int iters, double *out) {
   if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;
@@ -464,7 +465,7 @@ int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, int64_t K, int v
   {
     unsigned long long c[4];
     read_valu_clock(c, true);
-    if (c[2]) fprintf(stderr, "  [update kernel] main loop per workgroup: %.0f cycles, clock %.3f GHz, %.1f cycles per k-step (K=%lld)\n",
+    if (c[2]) fprintf(stderr, "  [dpp kernel] main loop per workgroup: %.0f cycles, clock %.3f GHz, %.1f cycles per k-step (K=%lld)\n",
                       (double)c[0] / c[2], (double)c[0] / ((double)c[1] * 10.0), (double)c[0] / c[2] / (double)K, (long long)K);
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

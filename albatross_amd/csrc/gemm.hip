@@ -116,18 +116,6 @@ __device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const doubl
   }
 }
 
-// shader-clock instrumentation of the update kernels' main loops (experiments; read_valu_clock)
-__device__ unsigned long long g_valu_clock[4];
-
-// C entry += v without waiting for the old value (global_atomic_add_f64, no return)
-__device__ __forceinline__ void add_to(double *p, double v) {
-#ifdef AGP_RMW_EPILOGUE
-  *p = *p + v;
-#else
-  (void)unsafeAtomicAdd(p, v);
-#endif
-}
-
 // Which C tile a workgroup computes.  Returns false for padding workgroups.
 __device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int &bi, int &bj) {
   if (g.remap == 2) {
@@ -185,12 +173,11 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int ln = lane & 15, lg = lane >> 4;
-  const int lq = ln >> 2, lr = ln & 3;
 
   const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
   const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
 
-  v4d acc[4][4];  // [tj][ti], component = rotation (mfma_f64.h)
+  v4d acc[4][4];  // [tj][ti]
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -198,9 +185,6 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
 
   double ra[8], rb[8];
   const long long nk = (g.K + GK - 1) / GK;
-#ifdef AGP_GEMM_CLOCK
-  const unsigned long long t_c0 = __builtin_amdgcn_s_memtime(), t_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
   load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
   load_chunk<B_KMAJOR>(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb);
   store_chunk<A_KMAJOR, false>(lds, ra);
@@ -218,21 +202,17 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
     }
 #pragma unroll
     for (int s = 0; s < GK / 4; ++s) {
-      double fa[4][4], fb[4];
+      double fa[4], fb[4];
       const int krow = (4 * s + lg) * GLD;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+        fa[t] = Bs[krow + 64 * wc + 16 * t + ln];  // MFMA A operand: C-column panel (negated)
         fb[t] = As[krow + 64 * wr + 16 * t + ln];  // MFMA B operand: C-row panel
-#pragma unroll
-        for (int rot = 0; rot < 4; ++rot)  // MFMA A operand: C-column panel (negated), 4-groups rotated by rot
-          fa[t][rot] = Bs[krow + 64 * wc + 16 * t + 4 * ((lq + rot) & 3) + lr];
       }
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-          for (int rot = 0; rot < 4; ++rot) acc[tj][ti][rot] = mfma4(fa[tj][rot], fb[ti], acc[tj][ti][rot]);
+        for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
     }
     if (more) {
       double *An = lds + (cur ^ 1) * (2 * GK * GLD);
@@ -242,26 +222,19 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
     __syncthreads();
   }
 
-#ifdef AGP_GEMM_CLOCK
-  if (threadIdx.x == 0) {
-    atomicAdd(&g_valu_clock[0], __builtin_amdgcn_s_memtime() - t_c0);
-    atomicAdd(&g_valu_clock[1], __builtin_amdgcn_s_memrealtime() - t_r0);
-    atomicAdd(&g_valu_clock[2], 1ull);
-  }
-#endif
-  // ---- epilogue: C += acc (acc already holds -A B^T); accumulator `rot` of lane (ln, lg) is
-  // C[row 16 ti + ln][col 16 tj + 4 (((ln >> 2) + rot) & 3) + lg] (mfma_f64.h).  Every C entry belongs to
-  // exactly one workgroup of the launch, so the update goes out as a no-return fp64 atomic add: the
-  // result is the same single rounded addition as load-add-store, but nothing waits for the load ----
+  // ---- epilogue: C += acc (acc already holds -A B^T) ----
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
       const long long row = i0 + 64 * wr + 16 * ti + ln;
 #pragma unroll
-      for (int rot = 0; rot < 4; ++rot) {
-        const long long col = j0 + 64 * wc + 16 * tj + 4 * ((lq + rot) & 3) + lg;
-        if (row < g.M && col < g.N) add_to(g.C + row + col * g.ldc, acc[tj][ti][rot]);
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 64 * wc + 16 * tj + lg + 4 * r;
+        if (row < g.M && col < g.N) {
+          double *c = g.C + row + col * g.ldc;
+          *c = *c + acc[tj][ti][r];
+        }
       }
     }
 }
@@ -346,6 +319,7 @@ __device__ __forceinline__ void dpp_k_steps(double (&acc)[4][16], dpp_d2 (&a01)[
 }
 
 // debug: summed shader-clock cycles, 100 MHz ticks and workgroup count of the main loops
+__device__ unsigned long long g_valu_clock[4];
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __device__ __forceinline__ void gemm_dpp_body(const GemmArgs &g, double *lds) {
@@ -587,7 +561,6 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int ln = lane & 15, lg = lane >> 4;
-  const int lq = ln >> 2, lr = ln & 3;
   const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
   const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
 
@@ -611,8 +584,8 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
     for (int ti = 0; ti < 2; ++ti) {
       const long long row = i0 + 32 * wr + 16 * ti + ln;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {  // r = rotation of the 4x4x4 products (mfma_f64.h)
-        const long long col = j0 + 32 * wc + 16 * tj + 4 * ((lq + r) & 3) + lg;
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
         acc[tj][ti][r] = (row < g.M && col < g.N) ? g.C[row + col * g.ldc] : 0.;
       }
     }
@@ -634,19 +607,16 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
 #pragma unroll
       for (int s = 0; s < GK / 4; ++s) {
         const int krow = (4 * s + lg) * SLD;
-        double fa[2][4], fb[2];
+        double fa[2], fb[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+          fa[t] = Bs[krow + 32 * wc + 16 * t + ln];
           fb[t] = As[krow + 32 * wr + 16 * t + ln];
-#pragma unroll
-          for (int rot = 0; rot < 4; ++rot) fa[t][rot] = Bs[krow + 32 * wc + 16 * t + 4 * ((lq + rot) & 3) + lr];
         }
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-          for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int rot = 0; rot < 4; ++rot) acc[tj][ti][rot] = mfma4(fa[tj][rot], fb[ti], acc[tj][ti][rot]);
+          for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
       }
       if (k + 1 < nk) {  // chunk k + 1 (register stage half ^ 1, loaded a trip ago) -> the other LDS buffer
         double *An = lds + (half ^ 1) * (2 * GK * SLD);
@@ -663,14 +633,14 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
       const long long row = i0 + 32 * wr + 16 * ti + ln;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long long col = j0 + 32 * wc + 16 * tj + 4 * ((lq + r) & 3) + lg;
+        const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
         if (row < g.M && col < g.N) g.C[row + col * g.ldc] = acc[tj][ti][r];
       }
     }
 }
 
 
-__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm64_nt_sub_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs g) {
   __builtin_amdgcn_s_setprio(3);  // panel-chain updates: issue ahead of co-resident bulk-update waves
   g.C += (long long)blockIdx.y * g.batch_C;
   g.A += (long long)blockIdx.y * g.batch_A;
@@ -692,7 +662,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm64_nt_sub_kernel(GemmArgs
 // The LAST tiles of a bulk update (those that would form a partial round of 128 x 128 workgroups) as
 // four 64 x 64 workgroups each: the tail of the launch is a quarter as long.  ntr / ntc / tile_first
 // are in 128-tile units like trailing_update_kernel's.
-__global__ __launch_bounds__(GEMM_THREADS, 3) void trailing_update_tail_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, 4) void trailing_update_tail_kernel(GemmArgs g) {
   __shared__ double lds[2 * 2 * GK * SLD];
   int bj = 0;
   long long id = (long long)(blockIdx.x >> 2) + g.tile_first;
