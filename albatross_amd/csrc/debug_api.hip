@@ -149,10 +149,19 @@ __global__ __launch_bounds__(256) void mfma_shape_kernel(double *sink, int iters
     double acc[NACC], av[16], bv[4];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.;
+    // a0 < 0 selects operands with random mantissas in [1, 2) x (+-1): data-dependent power
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    auto rnd = [&]() {
+      h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+      const unsigned lo = h;
+      h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+      const unsigned hi = (h & 0x800fffffu) | 0x3ff00000u;
+      return __hiloint2double((int)hi, (int)lo);
+    };
 #pragma unroll
-    for (int i = 0; i < 16; ++i) av[i] = a + i * 1e-3;
+    for (int i = 0; i < 16; ++i) av[i] = a0 < 0. ? rnd() * 0.01 : a + i * 1e-3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bv[i] = b - i * 1e-3;
+    for (int i = 0; i < 4; ++i) bv[i] = a0 < 0. ? rnd() * 0.01 : b - i * 1e-3;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[i & 15], bv[(i >> 4) & 3], acc[i], 0, 0, 0);
@@ -377,6 +386,8 @@ int agp_debug_mfma44_probe(agp_context *ctx, int mode, unsigned long long *out) 
 
 // out[0] = chip TFLOP/s, out[1] = ms
 int agp_debug_mfma_shape(agp_context *ctx, int mode, int nacc, int waves_per_simd, int iters, double *out) {
+  const double a0 = iters < 0 ? -1.0 : 1.0;  // negative iteration count: random operands
+  if (iters < 0) iters = -iters;
   if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   double *sink = nullptr;
@@ -388,7 +399,7 @@ int agp_debug_mfma_shape(agp_context *ctx, int mode, int nacc, int waves_per_sim
   hipStream_t s = ctx->stream;
   for (int rep = 0; rep < 2; ++rep) {
     AGP_HIP_CHECK(ctx, hipEventRecord(e0, s));
-#define SHAPE_LAUNCH(M_, N_) hipLaunchKernelGGL((mfma_shape_kernel<M_, N_>), dim3(blocks), dim3(256), 0, s, sink, iters, 1.0, 2.0)
+#define SHAPE_LAUNCH(M_, N_) hipLaunchKernelGGL((mfma_shape_kernel<M_, N_>), dim3(blocks), dim3(256), 0, s, sink, iters, a0, 2.0)
     if (mode == 0 && nacc == 8) SHAPE_LAUNCH(0, 8);
     else if (mode == 0 && nacc == 16) SHAPE_LAUNCH(0, 16);
     else if (mode == 1 && nacc == 8) SHAPE_LAUNCH(1, 8);

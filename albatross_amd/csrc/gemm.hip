@@ -28,6 +28,9 @@ constexpr int GT = 128;        // C tile edge
 constexpr int GK = 16;         // K chunk
 constexpr int GLD = GT + 16;   // LDS row pitch in doubles
 constexpr int GEMM_THREADS = 256;
+#ifndef AGP_GEMM_4X4
+#define AGP_GEMM_4X4 0  // 1: 128 x 128 kernels on v_mfma_f64_4x4x4 with DPP-rotated fragments (same speed)
+#endif
 
 struct GemmArgs {
   double *C;
@@ -209,10 +212,30 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
         fa[t] = Bs[krow + 64 * wc + 16 * t + ln];  // MFMA A operand: C-column panel (negated)
         fb[t] = As[krow + 64 * wr + 16 * t + ln];  // MFMA B operand: C-row panel
       }
+#if AGP_GEMM_4X4
+      // four 4x4x4 products per 16 x 16 tile: block b pairs column group (b + ra) with row group (b + rb),
+      // (ra, rb) = (0,0), (1,0), (0,2), (1,2): all 16 group pairs; the rotated fragments come from DPP
+      double fa1[4], fb2[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa1[t] = rotate_groups<1>(fa[t]);
+        fb2[t] = rotate_groups<2>(fb[t]);
+      }
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          acc[tj][ti][0] = mfma4(fa[tj], fb[ti], acc[tj][ti][0]);
+          acc[tj][ti][1] = mfma4(fa1[tj], fb[ti], acc[tj][ti][1]);
+          acc[tj][ti][2] = mfma4(fa[tj], fb2[ti], acc[tj][ti][2]);
+          acc[tj][ti][3] = mfma4(fa1[tj], fb2[ti], acc[tj][ti][3]);
+        }
+#else
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
+#endif
     }
     if (more) {
       double *An = lds + (cur ^ 1) * (2 * GK * GLD);
@@ -227,10 +250,20 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
   for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
+#if !AGP_GEMM_4X4
       const long long row = i0 + 64 * wr + 16 * ti + ln;
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+#if AGP_GEMM_4X4
+        // accumulator r = (ra, rb) = (r & 1, r & 2): lane (ln = 4 lq + lr, lg) holds
+        // C[row 4 ((lq + rb) & 3) + lr][col 4 ((lq + ra) & 3) + lg] of the 16 x 16 tile
+        const int lq = ln >> 2, lr = ln & 3;
+        const long long row = i0 + 64 * wr + 16 * ti + 4 * ((lq + (r & 2)) & 3) + lr;
+        const long long col = j0 + 64 * wc + 16 * tj + 4 * ((lq + (r & 1)) & 3) + lg;
+#else
         const long long col = j0 + 64 * wc + 16 * tj + lg + 4 * r;
+#endif
         if (row < g.M && col < g.N) {
           double *c = g.C + row + col * g.ldc;
           *c = *c + acc[tj][ti][r];

@@ -40,6 +40,18 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// x of lane (row r, position p of 16) <- x of lane (r, (p + 4 groups) mod 16): the 4-element groups of a fragment
+// rotated inside each 16-lane row by DPP row_ror, without another LDS read.
+template <int GROUPS>
+__device__ __forceinline__ double rotate_groups(double x) {
+  // row_ror:n moves lane i's value to lane (i + n) mod 16, i.e. lane p receives lane (p - n) mod 16;
+  // receiving from (p + 4 GROUPS) therefore is a right rotation by 16 - 4 GROUPS
+  constexpr int ctrl = 0x120 + ((16 - 4 * GROUPS) & 15);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ v4d v4zero() {
   v4d z = {0., 0., 0., 0.};
   return z;
