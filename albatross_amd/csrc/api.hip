@@ -570,7 +570,37 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)round_up(n, 2));
     if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
   }
-  backward_solve_vec(s, fit->A, n, fit->lda, fit->winv, fit->alpha, ctx->ws_aux);
+  {
+    // x = L^-T z.  Wide path (n a multiple of 512): the 512 x 512 diagonal blocks are inverted explicitly (one
+    // batched triangular solve against the identity), after which a step is two column-dot launches per 512 rows
+    // instead of four fused launches per 128 rows: the chain is launch-latency-bound (AGP_WIDE_BACKSOLVE=0: off).
+    static int wide = -1;
+    if (wide < 0) {
+      const char *e = getenv("AGP_WIDE_BACKSOLVE");
+      wide = e ? atoi(e) : 1;
+    }
+    const long long BW = wide > 1 ? wide : 512;  // AGP_WIDE_BACKSOLVE=<multiple of 128> selects another width
+    if (wide && n >= 4 * BW && n % BW == 0) {
+      const long long nb = n / BW;
+      const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes,
+                                sizeof(double) * ((size_t)round_up(n, 2) + (size_t)nb * BW * BW));
+      if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
+      double *xs = ctx->ws_aux, *R = ctx->ws_aux + round_up(n, 2);
+      launch_set_identity_batched(s, R, BW, BW * BW, BW, nb);
+      forward_solve_mat_batched(s, fit->A, BW * (fit->lda + 1), BW, fit->lda, fit->invd, (BW / NB) * (long long)(36 * MB * MB),
+                                R, BW * BW, BW, BW, /*rhs_lower=*/true, nb);
+      for (long long b = nb - 1; b >= 0; --b) {
+        const long long k0 = b * BW;
+        // x_B[c] = sum_r inv(L_BB)[r][c] z_B[r]
+        launch_colvec_dot(s, R + b * BW * BW, BW, BW, BW, fit->alpha + k0, 1.0, 0.0, nullptr, xs + k0);
+        // z[0 : k0] -= L[k0 : k0 + 512, 0 : k0]^T x_B
+        if (k0 > 0) launch_colvec_dot(s, fit->A + k0, fit->lda, BW, k0, xs + k0, -1.0, 1.0, fit->alpha, fit->alpha);
+      }
+      FIT_CHECK(hipMemcpyAsync(fit->alpha, xs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    } else {
+      backward_solve_vec(s, fit->A, n, fit->lda, fit->winv, fit->alpha, ctx->ws_aux);
+    }
+  }
   if (mixed) {
     invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
     const int st3 = refine_information(ctx, fit, Kfull, Wfwd, vec, mixed);
