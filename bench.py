@@ -60,10 +60,19 @@ def cpu_baseline(seconds_budget=30.0):
         dt = time.perf_counter() - t0
         del fit
         best = (n, dt)
-        # next size costs ~8x; stop when it would blow the budget
-        if dt * 8.0 > seconds_budget or n >= 8192:
+        # next size costs ~8x (more once the matrix leaves the caches: x12); stop when it would blow the budget
+        if dt * 12.0 > seconds_budget or n >= 8192:
             break
         n *= 2
+    # one more sample at 1.5x the size when that still fits: the sample should be 10-30 s of CPU work
+    if best[1] * 3.375 * 1.5 <= seconds_budget and best[0] < 8192:
+        n = best[0] * 3 // 2
+        x, y = make_dataset(n, 44)
+        t0 = time.perf_counter()
+        fit = orc.OracleFit(cov, x, y)
+        _ = fit.information
+        best = (n, time.perf_counter() - t0)
+        del fit
     n, dt = best
     scaled = dt * (N_TRAIN / n) ** 3
     out = {"value": 1.0 / scaled, "unit": "fits/sec", "cores": 1, "kind": "port",
