@@ -312,3 +312,17 @@ def test_semi_definite_model_falls_back_to_the_pivoted_factor(ctx):
     packed, tr, ok = orc.ldlt(K)
     ldlt = fm.get_fit().train_covariance
     assert np.array_equal(ldlt.transpositions(), tr) and np.array_equal(np.tril(ldlt.matrix_ldlt()), np.tril(packed))
+
+
+@pytest.mark.parametrize("n", [2048, 2560])
+def test_ill_conditioned_fit_wide_backward_path(ctx, n):
+    """N a multiple of 512 takes the 512-row backward substitution (explicit inverses of the 512 x 512 diagonal
+    blocks): an ill-conditioned covariance (cond ~ 1e8) must still solve K a = y to fp64 working accuracy."""
+    x, y = synthetic_3d(n, 91)
+    cov = ab.SquaredExponential(2.0, 1.0) + ab.IndependentNoise(3e-3)
+    fm = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
+    a = fm.get_fit().information
+    K = ctx.gram(cov, ab.Measurement(x))
+    assert np.abs(K @ a - y).max() <= 1e-9 * np.abs(K).sum(axis=1).max() * np.abs(a).max()
+    ofit = orc.OracleFit(cov, ab.FeatureSet(x), y, use_llt=True)
+    assert rel(a, ofit.information) <= 1e-6   # cond(K) * eps ~ 1e-8 for either path
