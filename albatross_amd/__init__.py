@@ -5,7 +5,7 @@ call surface over the C-ABI in include/albatross_amd.h.  All Gram / factor /
 solve / predict arithmetic runs in the HIP library; there is no CPU fallback.
 """
 from .covariance import (AngularDistance, Constant, CovarianceFunction, EuclideanDistance, Exponential,
-                         FeatureSet, IndependentNoise, Matern32, Matern52, Measurement, MeasurementOnly,
+                         FeatureSet, IndependentNoise, LinearCombination, Matern32, Matern52, Measurement, MeasurementOnly,
                          Nugget, Polynomial, ProductOfCovarianceFunctions, RadialDistance, ScalingFunction,
                          ScalingTerm, SquaredExponential, SumOfCovarianceFunctions, as_measurements,
                          measurement_only)

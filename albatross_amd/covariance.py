@@ -86,6 +86,49 @@ class Measurement:
         self.values = values
 
 
+class LinearCombination:
+    """LinearCombination<X> (core/linear_combination.hpp:18-44): a feature that is sum_i coefficients[i] * values[i].
+    cov(a, b) = sum_ij a_i b_j cov(x_i, y_j) and mean(a) = sum_i a_i mean(x_i), applied at the TOP of the caller chain
+    (LinearCombinationCaller, covariance_functions/callers.hpp:321-396).  Here: the Gram matrix of the expanded
+    points is built on the device and contracted with the coefficients on the host."""
+
+    def __init__(self, values, coefficients=None):
+        self.values = [np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in values]
+        self.coefficients = (np.ones(len(self.values)) if coefficients is None
+                             else np.asarray(coefficients, dtype=np.float64).reshape(-1))
+        if len(self.values) != self.coefficients.shape[0]:
+            raise ValueError("values and coefficients differ in size")  # linear_combination.hpp:33
+
+    def __eq__(self, other):  # linear_combination.hpp:36-38
+        return (isinstance(other, LinearCombination) and len(self.values) == len(other.values)
+                and all(np.array_equal(a, b) for a, b in zip(self.values, other.values))
+                and np.array_equal(self.coefficients, other.coefficients))
+
+
+def has_linear_combinations(features):
+    values = features.values if isinstance(features, Measurement) else features
+    return isinstance(values, (list, tuple)) and any(isinstance(f, LinearCombination) for f in values)
+
+
+def expand_linear_combinations(features):
+    """(expanded features, C): C is the (number of expanded points) x (number of features) coefficient matrix; a
+    plain feature is the combination of itself with coefficient 1.  A Measurement<> wrapper stays on the expanded
+    vector (MeasurementForwarder sits outside LinearCombinationCaller in the DefaultCaller chain, callers.hpp:546-553)."""
+    meas = isinstance(features, Measurement)
+    values = features.values if meas else features
+    points, rows, cols, coefs = [], [], [], []
+    for j, f in enumerate(values):
+        if isinstance(f, LinearCombination):
+            for v, a in zip(f.values, f.coefficients):
+                rows.append(len(points)); cols.append(j); coefs.append(a); points.append(v)
+        else:
+            rows.append(len(points)); cols.append(j); coefs.append(1.); points.append(np.atleast_1d(np.asarray(f, dtype=np.float64)))
+    C = np.zeros((len(points), len(values)))
+    C[rows, cols] = coefs
+    pts = np.stack(points) if points else np.zeros((0, 1))
+    return (Measurement(pts) if meas else pts), C
+
+
 def as_measurements(features):
     return features if isinstance(features, Measurement) else Measurement(features)
 

@@ -12,7 +12,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi as capi
-from .covariance import CovarianceFunction, FeatureSet, Measurement, nodes_to_array
+from .covariance import (CovarianceFunction, FeatureSet, LinearCombination, Measurement, expand_linear_combinations,
+                         has_linear_combinations, nodes_to_array)
 
 
 class AlbatrossAmdError(RuntimeError):
@@ -110,6 +111,13 @@ class Context:
     # --- Gram ------------------------------------------------------------------
     def gram(self, cov, xs, ys=None):
         """compute_covariance_matrix (callers.hpp:38-166) on the device."""
+        if has_linear_combinations(xs) or (ys is not None and has_linear_combinations(ys)):
+            # LinearCombinationCaller (callers.hpp:321-396): Gram of the expanded points, contracted with the coefficients
+            ex, Cx = expand_linear_combinations(xs)
+            if ys is None:
+                return np.asfortranarray(Cx.T @ self.gram(cov, ex) @ Cx)
+            ey, Cy = expand_linear_combinations(ys)
+            return np.asfortranarray(Cx.T @ self.gram(cov, ex, ey) @ Cy)
         fx = cov.features(xs)
         sx = fx.as_struct()
         kh = self.kernel(cov)
@@ -125,6 +133,8 @@ class Context:
         return out
 
     def gram_diagonal(self, cov, xs):
+        if has_linear_combinations(xs):
+            return np.diag(self.gram(cov, xs)).copy()
         f = cov.features(xs)
         return np.array([self.gram(cov, FeatureSet(f.coords[i:i + 1],
                                                    None if f.scales is None else list(f.scales[i:i + 1].T),
@@ -210,6 +220,14 @@ class LinearMean:
 
 def _values_of(features):
     return features.values if isinstance(features, Measurement) else features
+
+
+def _mean_at(mean_function, cov, features):
+    """mean_function(features) including LinearCombination features: sum_i a_i m(x_i) (callers.hpp:386-396)"""
+    if has_linear_combinations(features):
+        ex, Cx = expand_linear_combinations(_values_of(features))
+        return Cx.T @ mean_function(np.asarray(ex, dtype=np.float64))
+    return mean_function(cov.features(features).coords)
 
 
 # ---------------------------------------------------------------------------
@@ -575,6 +593,16 @@ class FitModel:
         used for fits whose solver is a BlockSymmetric; Gram and solves still run on the device."""
         m, ctx = self._model, self._model._ctx()
         cov = m.covariance_function_
+        if has_linear_combinations(features) or has_linear_combinations(self._fit.train_features):
+            cross = ctx.gram(cov, self._fit.train_features, features)
+            mean = cross.T @ self._fit.information + _mean_at(m.mean_function_, cov, features)
+            if want == "mean":
+                return mean
+            explained = self._fit.solve(cross)
+            prior = ctx.gram(cov, features)
+            if want == "marginal":
+                return MarginalDistribution(mean, np.diag(prior) - np.einsum("ij,ij->j", explained, cross))
+            return JointDistribution(mean, prior - cross.T @ explained)
         fs = cov.features(features)
         cross = ctx.gram(cov, self._fit.train_features, fs)
         mean = cross.T @ self._fit.information + m.mean_function_(fs.coords)
@@ -683,6 +711,8 @@ class GaussianProcessRegression:
         if targets is not None:
             dataset = RegressionDataset(dataset, targets)
         ctx = self._ctx()
+        if has_linear_combinations(dataset.features):
+            return self._fit_dense(dataset)
         fs = self.covariance_function_.features(_values_of(dataset.features))
         y, yv = self._targets(fs, dataset.targets)
         s = fs.as_struct()
@@ -731,6 +761,26 @@ class GaussianProcessRegression:
             raise NanInputError(capi.AGP_ERR_NAN_INPUT, "covariance has NaN")  # gp.hpp:66
         ldlt = PivotedLDLT(K, ctx)                                    # gp.hpp:67
         return FitModel(self, UpdatedGPFit(feats, ldlt, ldlt.solve(y)))  # gp.hpp:68
+
+    def _fit_dense(self, dataset):
+        """Datasets with LinearCombination features: Fit<GPFit<SerializableLDLT>> (gp.hpp:61-69) from the contracted
+        covariance matrix.  Gram of the expanded points, factorisation and solves run on the device; the
+        contraction with the coefficients is host work."""
+        ctx = self._ctx()
+        feats = _values_of(dataset.features)
+        y = np.ascontiguousarray(dataset.targets.mean - _mean_at(self.mean_function_, self.covariance_function_, feats))
+        K = ctx.gram(self.covariance_function_, Measurement(feats))   # as_measurements(features), gp.hpp:288-290
+        if dataset.targets.covariance is not None:
+            K[np.diag_indices_from(K)] += np.asarray(dataset.targets.covariance, dtype=np.float64)  # gp.hpp:65
+        if np.isnan(K).any():
+            raise NanInputError(capi.AGP_ERR_NAN_INPUT, "covariance has NaN")                     # gp.hpp:66
+        try:
+            factor = DenseFactor(K, ctx)
+        except NotPositiveDefiniteError:
+            if not self.pivoted_fallback:
+                raise
+            factor = PivotedLDLT(K, ctx)
+        return FitModel(self, UpdatedGPFit(feats, factor, factor.solve(y)))
 
     def cross_validate(self):
         return CrossValidation(self)
@@ -790,6 +840,13 @@ class GaussianProcessRegression:
     def log_likelihood(self, dataset):
         """gp.hpp:442-451 (without priors: the parameter-prior subsystem is out of scope)."""
         ctx = self._ctx()
+        if has_linear_combinations(dataset.features):
+            feats = _values_of(dataset.features)
+            K = ctx.gram(self.covariance_function_, Measurement(feats))
+            if dataset.targets.covariance is not None:
+                K[np.diag_indices_from(K)] += np.asarray(dataset.targets.covariance, dtype=np.float64)
+            dev = dataset.targets.mean - _mean_at(self.mean_function_, self.covariance_function_, feats)
+            return -negative_log_likelihood(dev, K, ctx)
         fs = self.covariance_function_.features(_values_of(dataset.features))
         y, yv = self._targets(fs, dataset.targets)
         s = fs.as_struct()
