@@ -235,6 +235,35 @@ int main() {
     std::printf("pivoted_pred,%.17g,%.17g,%.17g\n", pj.mean[0], pj.mean[1], pj.mean[2]);
     std::printf("pivoted_var0,%.17g\n", pj.covariance(0, 0));
   }
+  // LinearCombination features (core/linear_combination.hpp; tests/test_gp.cc:395-462): 12 plain observations
+  // (single-term combinations) + "f(0.7) - f(2.9) = 0" and "mean of f at four points = 1" observed with variance 1e-5
+  {
+    using LC = LinearCombination<double>;
+    std::vector<LC> feats;
+    Vector ty, tv;
+    for (int i = 0; i < 12; ++i) {
+      const double xi = 0.4 * i;
+      feats.push_back(LC({xi}));
+      ty.push_back(std::sin(xi) + 1.5);
+      tv.push_back(0.05 * 0.05);
+    }
+    feats.push_back(LC({0.7, 2.9}, Vector{1., -1.}));
+    ty.push_back(0.); tv.push_back(1e-5);
+    feats.push_back(LC({0.4, 1.9, 3.3, 4.6}, Vector{0.25, 0.25, 0.25, 0.25}));
+    ty.push_back(1.); tv.push_back(1e-5);
+    auto lm = gp_from_covariance_and_mean(SquaredExponential<EuclideanDistance>(1.2, 2.0) + Constant(3.0) +
+                                              measurement_only(IndependentNoise<double>(0.2)),
+                                          LinearMean{0.3, -1.0});
+    const Matrix K = lm.get_covariance()(as_measurements(feats));
+    for (std::size_t i = 0; i < feats.size(); ++i) std::printf("lc_gram_row,%zu,%.17g,%.17g,%.17g\n", i, K(12, (long)i), K(13, (long)i), K((long)i, (long)i));
+    const auto lf = lm.fit(RegressionDataset<LC>(feats, MarginalDistribution(ty, tv)));
+    for (std::size_t i = 0; i < lf.information.size(); ++i) std::printf("lc_info,%zu,%.17g\n", i, lf.information[i]);
+    const std::vector<double> pts = {0.7, 2.9, 0.4, 1.9, 3.3, 4.6};
+    const auto lj = lf.predict_joint(pts);
+    for (std::size_t i = 0; i < pts.size(); ++i) std::printf("lc_pred,%zu,%.17g,%.17g\n", i, lj.mean[i], lj.covariance((long)i, (long)i));
+    const auto lq = lf.predict_joint(std::vector<LC>{feats[12], feats[13]});
+    std::printf("lc_constraints,%.17g,%.17g,%.17g,%.17g\n", lq.mean[0], lq.mean[1], lq.covariance(0, 0), lq.covariance(1, 1));
+  }
   // a singular covariance is reported, not silently factored
   try {
     std::vector<double> dup = {0., 0., 1.};

@@ -97,6 +97,24 @@ std::vector<Measurement<X>> as_measurements(const std::vector<X> &features) {
   return std::vector<Measurement<X>>(features.begin(), features.end());
 }
 
+// core/linear_combination.hpp:18-44: a feature that is sum_i coefficients[i] * values[i].  The covariance
+// functions and models below accept std::vector<LinearCombination<X>> wherever they accept std::vector<X>:
+// LinearCombinationCaller (covariance_functions/callers.hpp:321-396) applies the double sum at the top of the
+// caller chain, so the Gram matrix of the EXPANDED points is built on the device and contracted with the
+// coefficients on the host.  (The reference mixes plain and combined features through variant<X, LinearCombination<X>>;
+// here a plain feature in such a vector is the combination of itself: LinearCombination<X>({x}).)
+template <typename X>
+struct LinearCombination {
+  LinearCombination() = default;
+  explicit LinearCombination(const std::vector<X> &values_) : values(values_), coefficients(values_.size(), 1.) {}
+  LinearCombination(const std::vector<X> &values_, const Vector &coefficients_) : values(values_), coefficients(coefficients_) {
+    if (values.size() != coefficients.size()) throw std::invalid_argument("values and coefficients differ in size");
+  }
+  bool operator==(const LinearCombination &other) const { return values == other.values && coefficients == other.coefficients; }
+  std::vector<X> values;
+  Vector coefficients;
+};
+
 // ---------------------------------------------------------------------------
 // feature flattening: how a feature type becomes the POD record of the C-ABI.
 // Specialise FeatureTraits<X> for user types (coords, optional equality id).
@@ -167,6 +185,61 @@ struct unwrap<Measurement<X>> {
   static constexpr bool is_measurement = true;
   static const X &get(const Measurement<X> &m) { return m.value; }
 };
+
+// LinearCombination features -> the points they are made of + (owner, coefficient) per point
+template <typename F>
+struct expansion {
+  static constexpr bool expands = false;
+};
+template <typename X>
+struct expansion<LinearCombination<X>> {
+  static constexpr bool expands = true;
+  using point = X;
+  static const LinearCombination<X> &get(const LinearCombination<X> &f) { return f; }
+  static point make(const X &x) { return x; }
+};
+template <typename X>
+struct expansion<Measurement<LinearCombination<X>>> {  // MeasurementForwarder sits outside LinearCombinationCaller
+  static constexpr bool expands = true;
+  using point = Measurement<X>;
+  static const LinearCombination<X> &get(const Measurement<LinearCombination<X>> &f) { return f.value; }
+  static point make(const X &x) { return Measurement<X>(x); }
+};
+
+template <typename F, bool = expansion<F>::expands>
+struct Expanded {  // plain features: nothing to do
+  static constexpr bool expands = false;
+};
+template <typename F>
+struct Expanded<F, true> {
+  static constexpr bool expands = true;
+  std::vector<typename expansion<F>::point> points;
+  std::vector<std::size_t> owner;
+  std::vector<double> coefficient;
+  std::size_t n = 0;
+  explicit Expanded(const std::vector<F> &features) : n(features.size()) {
+    for (std::size_t j = 0; j < features.size(); ++j) {
+      const auto &lc = expansion<F>::get(features[j]);
+      for (std::size_t i = 0; i < lc.values.size(); ++i) {
+        points.push_back(expansion<F>::make(lc.values[i]));
+        owner.push_back(j);
+        coefficient.push_back(lc.coefficients[i]);
+      }
+    }
+  }
+};
+
+// mean_function(feature): sum_i a_i m(x_i) for a LinearCombination (callers.hpp:386-396)
+template <typename Mean, typename P>
+double mean_at(const Mean &m, const P &x) { return m._call_impl(unwrap<P>::get(x)); }
+template <typename Mean, typename X>
+double mean_at(const Mean &m, const LinearCombination<X> &x) {
+  double s = 0.;
+  for (std::size_t i = 0; i < x.values.size(); ++i) s += x.coefficients[i] * m._call_impl(x.values[i]);
+  return s;
+}
+template <typename Mean, typename X>
+double mean_at(const Mean &m, const Measurement<LinearCombination<X>> &x) { return mean_at(m, x.value); }
 
 // flattened feature vector + the agp_features view over it
 struct Flat {
@@ -272,6 +345,16 @@ class CovarianceFunction {
   // cov(xs): symmetric Gram, callers.hpp:107-166
   template <typename F>
   Matrix operator()(const std::vector<F> &xs) const {
+    if constexpr (detail::expansion<F>::expands) {  // LinearCombinationCaller, callers.hpp:336-347
+      const detail::Expanded<F> ex(xs);
+      const Matrix G = (*this)(ex.points);
+      Matrix out(static_cast<std::int64_t>(ex.n), static_cast<std::int64_t>(ex.n));
+      for (std::size_t b = 0; b < ex.points.size(); ++b)
+        for (std::size_t a = 0; a < ex.points.size(); ++a)
+          out(static_cast<std::int64_t>(ex.owner[a]), static_cast<std::int64_t>(ex.owner[b])) +=
+              ex.coefficient[a] * ex.coefficient[b] * G(static_cast<std::int64_t>(a), static_cast<std::int64_t>(b));
+      return out;
+    } else {
     auto ctx = detail::default_context();
     detail::KernelHolder k(program());
     detail::Flat fx = detail::flatten(derived(), xs);
@@ -279,11 +362,29 @@ class CovarianceFunction {
     if (fx.view.n > 0)
       detail::check(agp_gram(ctx->ctx, k.k, &fx.view, nullptr, out.data.data(), fx.view.n, AGP_HOST), ctx->ctx, "agp_gram");
     return out;
+    }
   }
 
   // cov(xs, ys): cross Gram, callers.hpp:38-102
   template <typename F, typename G>
   Matrix operator()(const std::vector<F> &xs, const std::vector<G> &ys) const {
+    if constexpr (detail::expansion<F>::expands) {  // callers.hpp:336-376: expand the left argument ...
+      const detail::Expanded<F> ex(xs);
+      const Matrix Gm = (*this)(ex.points, ys);
+      Matrix out(static_cast<std::int64_t>(ex.n), Gm.cols());
+      for (std::int64_t j = 0; j < Gm.cols(); ++j)
+        for (std::size_t a = 0; a < ex.points.size(); ++a)
+          out(static_cast<std::int64_t>(ex.owner[a]), j) += ex.coefficient[a] * Gm(static_cast<std::int64_t>(a), j);
+      return out;
+    } else if constexpr (detail::expansion<G>::expands) {  // ... then the right one
+      const detail::Expanded<G> ey(ys);
+      const Matrix Gm = (*this)(xs, ey.points);
+      Matrix out(Gm.rows(), static_cast<std::int64_t>(ey.n));
+      for (std::size_t b = 0; b < ey.points.size(); ++b)
+        for (std::int64_t i = 0; i < Gm.rows(); ++i)
+          out(i, static_cast<std::int64_t>(ey.owner[b])) += ey.coefficient[b] * Gm(i, static_cast<std::int64_t>(b));
+      return out;
+    } else {
     auto ctx = detail::default_context();
     detail::KernelHolder k(program());
     detail::Flat fx = detail::flatten(derived(), xs), fy = detail::flatten(derived(), ys);
@@ -291,6 +392,7 @@ class CovarianceFunction {
     if (fx.view.n > 0 && fy.view.n > 0)
       detail::check(agp_gram(ctx->ctx, k.k, &fx.view, &fy.view, out.data.data(), fx.view.n, AGP_HOST), ctx->ctx, "agp_gram");
     return out;
+    }
   }
 
   // cov(x, y) for two single features (CovarianceFunction::call)
@@ -940,7 +1042,8 @@ class UpdatedFitModel {
   Vector information;
 
  private:
-  Vector mean_of(const Matrix &cross, const std::vector<FeatureType> &xs) const {
+  template <typename P>
+  Vector mean_of(const Matrix &cross, const std::vector<P> &xs) const {
     Vector mean(xs.size(), 0.);
     for (std::int64_t j = 0; j < cross.cols(); ++j) {
       double s = 0.;
@@ -982,8 +1085,10 @@ class RepresentationFitModel {
   RepresentationFitModel(const ModelType &model, std::vector<FeatureType> features, Representation cov, Vector info)
       : train_features(std::move(features)), train_covariance(std::move(cov)), information(std::move(info)), model_(model) {}
 
-  Vector predict_mean(const std::vector<FeatureType> &xs) const { return mean_of(model_.get_covariance()(train_features, xs), xs); }
-  JointDistribution predict_joint(const std::vector<FeatureType> &xs) const {
+  template <typename P>
+  Vector predict_mean(const std::vector<P> &xs) const { return mean_of(model_.get_covariance()(train_features, xs), xs); }
+  template <typename P>
+  JointDistribution predict_joint(const std::vector<P> &xs) const {
     const Matrix cross = model_.get_covariance()(train_features, xs);
     const Matrix explained = train_covariance.solve(cross);
     JointDistribution out;
@@ -1003,7 +1108,8 @@ class RepresentationFitModel {
   Vector information;
 
  private:
-  Vector mean_of(const Matrix &cross, const std::vector<FeatureType> &xs) const {
+  template <typename P>
+  Vector mean_of(const Matrix &cross, const std::vector<P> &xs) const {
     Vector mean(xs.size(), 0.);
     for (std::int64_t j = 0; j < cross.cols(); ++j) {
       double s = 0.;
@@ -1080,7 +1186,31 @@ class GaussianProcessRegression {
   template <typename P>
   void add_mean(const std::vector<P> &xs, Vector *mean) const {  // mean_function_.add_to, mean_function.hpp:86-95
     if (std::is_same<MeanFunc, ZeroMean>::value) return;
-    for (std::size_t i = 0; i < xs.size(); ++i) (*mean)[i] += mean_function_._call_impl(detail::unwrap<P>::get(xs[i]));
+    for (std::size_t i = 0; i < xs.size(); ++i) (*mean)[i] += detail::mean_at(mean_function_, xs[i]);
+  }
+
+  // Datasets of LinearCombination features: Fit<GPFit<SerializableLDLT>> (gp.hpp:61-69) from the contracted
+  // covariance matrix; Gram of the expanded points, factorisation and solves on the device.
+  template <typename X>
+  RepresentationFitModel<GaussianProcessRegression, LinearCombination<X>, SerializableLDLT> fit(
+      const std::vector<LinearCombination<X>> &features, const MarginalDistribution &targets) const {
+    if (features.size() != targets.size()) throw std::invalid_argument("features and targets differ in size");
+    Matrix K = covariance_function_(as_measurements(features));  // gp.hpp:288-290
+    if (!targets.covariance.empty())
+      for (std::size_t i = 0; i < features.size(); ++i)
+        K(static_cast<std::int64_t>(i), static_cast<std::int64_t>(i)) += targets.covariance[i];  // gp.hpp:65
+    Vector y = targets.mean;
+    Vector m(y.size(), 0.);
+    add_mean(features, &m);  // mean_function_.remove_from, gp.hpp:291-292
+    for (std::size_t i = 0; i < y.size(); ++i) y[i] -= m[i];
+    SerializableLDLT ldlt(K);        // gp.hpp:67
+    Vector info = ldlt.solve(y);     // gp.hpp:68
+    return RepresentationFitModel<GaussianProcessRegression, LinearCombination<X>, SerializableLDLT>(*this, features, std::move(ldlt),
+                                                                                                   std::move(info));
+  }
+  template <typename X>
+  auto fit(const RegressionDataset<LinearCombination<X>> &dataset) const {
+    return fit(dataset.features, dataset.targets);
   }
 
   // ModelBase::fit (core/model.hpp:137-152) -> _fit_impl (gp.hpp:281-294)
@@ -1507,7 +1637,7 @@ class SparseGaussianProcessRegression {
   template <typename P>
   void add_mean(const std::vector<P> &xs, Vector *mean) const {
     if (std::is_same<MeanFunc, ZeroMean>::value) return;
-    for (std::size_t i = 0; i < xs.size(); ++i) (*mean)[i] += mean_function_._call_impl(detail::unwrap<P>::get(xs[i]));
+    for (std::size_t i = 0; i < xs.size(); ++i) (*mean)[i] += detail::mean_at(mean_function_, xs[i]);
   }
 
   // _fit_impl (:354-381)

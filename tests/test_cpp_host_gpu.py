@@ -101,6 +101,31 @@ def test_cpp_api_matches_oracle():
     lm, lv = ofit.loo_marginal(y)
     assert np.abs(loo[:, 1] - lm).max() <= 1e-8 * np.abs(lm).max() and np.abs(loo[:, 2] - lv).max() <= 1e-8 * lv.max()
     assert np.abs(loo[:, 3] - ofit.inverse_diagonal()).max() <= 1e-8 * ofit.inverse_diagonal().max()
+    # LinearCombination features: the C++ surface against the Python mirror (itself checked against the defining
+    # double sum over the oracle's covariance in tests/test_linear_combination_gpu.py)
+    lc_feats = [ab.LinearCombination([0.4 * i]) for i in range(12)] + [
+        ab.LinearCombination([0.7, 2.9], [1., -1.]), ab.LinearCombination([0.4, 1.9, 3.3, 4.6], [0.25] * 4)]
+    lc_y = np.array([np.sin(0.4 * i) + 1.5 for i in range(12)] + [0., 1.])
+    lc_v = np.array([0.05 ** 2] * 12 + [1e-5, 1e-5])
+    lc_cov = ab.SquaredExponential(1.2, 2.0) + ab.Constant(3.0) + ab.measurement_only(ab.IndependentNoise(0.2))
+    lc_model = ab.gp_from_covariance_and_mean(lc_cov, ab.LinearMean(0.3, -1.0))
+    Kpy = lc_model._ctx().gram(lc_cov, ab.Measurement(lc_feats))
+    grow = np.array(rows["lc_gram_row"], dtype=float)
+    assert np.abs(grow[:, 1] - Kpy[12]).max() <= 1e-13 * np.abs(Kpy).max()
+    assert np.abs(grow[:, 2] - Kpy[13]).max() <= 1e-13 * np.abs(Kpy).max()
+    assert np.abs(grow[:, 3] - np.diag(Kpy)).max() <= 1e-13 * np.abs(Kpy).max()
+    lc_fm = lc_model.fit(ab.RegressionDataset(lc_feats, ab.MarginalDistribution(lc_y, lc_v)))
+    lc_info = np.array(rows["lc_info"], dtype=float)[:, 1]
+    assert np.abs(lc_info - lc_fm.get_fit().information).max() <= 1e-9 * np.abs(lc_info).max()
+    lcp = np.array(rows["lc_pred"], dtype=float)
+    want = lc_fm.predict([0.7, 2.9, 0.4, 1.9, 3.3, 4.6]).joint()
+    assert np.abs(lcp[:, 1] - want.mean).max() <= 1e-9 * np.abs(want.mean).max()
+    assert np.abs(lcp[:, 2] - np.diag(want.covariance)).max() <= 1e-9
+    cm0, cm1, cv0, cv1 = (float(v) for v in rows["lc_constraints"][0])
+    wq = lc_fm.predict([lc_feats[12], lc_feats[13]]).joint()   # predictions AT the two combined features
+    assert abs(cm0 - wq.mean[0]) < 1e-9 and abs(cm1 - wq.mean[1]) < 1e-9
+    assert abs(cv0 - wq.covariance[0, 0]) < 1e-9 and abs(cv1 - wq.covariance[1, 1]) < 1e-9
+    assert abs((lcp[0, 1] - lcp[1, 1]) - cm0) < 1e-9             # = the same combination of the point predictions
     # leave-one-group-out: fast path == refit per fold (the brute-force predict(test) is the latent
     # prediction: the held-out noise term only appears in the fast path's covariance diagonal)
     assert int(one["cv_groups"]) == 4 and float(one["cv_mean_diff"]) < 1e-7 and float(one["cv_cov_diff"]) < 1e-7
