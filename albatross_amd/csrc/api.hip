@@ -565,7 +565,6 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   // information = L^-T (L^-1 y)
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[3], s));
   FIT_CHECK(hipMemcpyAsync(fit->alpha, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-  invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);
   {
     const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)round_up(n, 2));
     if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
@@ -580,7 +579,10 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
       wide = e ? atoi(e) : 1;
     }
     const long long BW = wide > 1 ? wide : 512;  // AGP_WIDE_BACKSOLVE=<multiple of 128> selects another width
-    if (wide && n >= 4 * BW && n % BW == 0) {
+    const bool wide_path = wide && n >= 4 * BW && n % BW == 0;
+    // the 128 x 128 inverses serve the 128-row chain (and the refinement steps of the mixed-precision fit)
+    if (!wide_path || mixed) invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);
+    if (wide_path) {
       const long long nb = n / BW;
       const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes,
                                 sizeof(double) * ((size_t)round_up(n, 2) + (size_t)nb * BW * BW));
