@@ -196,3 +196,21 @@ def test_temperature_example_config4_kernel():
     # the prediction placed ON a station: IndependentNoise<Station> is not measurement-only, so the
     # equal feature (x == y by ECEF) shares its noise and the observed value is reproduced exactly
     assert abs(pr[0, 5]) < 1e-8 and abs(pr[0, 4] - st[3, 4]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_cpp_bench_fit_runs():
+    """examples/bench_fit.cpp (BASELINE config 3 through the C++ surface only) at a small size: exit code 0 means
+    the fit reproduces its targets; the log-likelihood is checked against the oracle."""
+    rows = run("bench_fit", "600", "2")
+    assert float(rows["fit"][0][0]) > 0.
+    # the data come from std::mt19937(44): same engine in numpy (init_genrand seeding), and libstdc++'s
+    bits = np.random.MT19937()
+    bits._legacy_seeding(44)
+    # std::uniform_real_distribution<double> on mt19937 consumes two 32-bit words per draw (generate_canonical)
+    raw = bits.random_raw(600 * 3 * 2).astype(np.float64)
+    u = (raw[0::2] + raw[1::2] * 4294967296.0) / 18446744073709551616.0 * 10.
+    x = u.reshape(600, 3)
+    y = np.sin(x).sum(axis=1) + 0.1 * np.cos(10. * x[:, 0])
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+    assert abs(float(rows["loglik"][0][0]) + orc.nll(cov, x, y)) <= 1e-6 * 600
