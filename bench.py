@@ -78,6 +78,21 @@ def cpu_baseline(seconds_budget=30.0):
     out = {"value": 1.0 / scaled, "unit": "fits/sec", "cores": 1, "kind": "port",
            "sample": f"one oracle fit (serial Gram + unblocked pivoted LDLT) at N={n}: {dt:.2f} s; "
                      f"scaled by (16384/{n})^3 to N=16384"}
+    # BASELINE.md section 2, B2 "albatross-faithful, pooled": the Gram over all host cores (callers.hpp:134-166), the
+    # factor unchanged (Eigen's LDLT has no parallel path) - the same fit once more with the pooled Gram
+    try:
+        import os as _os
+        cores = _os.cpu_count() or 1
+        xg, yg = make_dataset(n, 44)
+        t0 = time.perf_counter()
+        fit = orc.OracleFit(cov, xg, yg, threads=cores)
+        _ = fit.information
+        t_pooled = time.perf_counter() - t0
+        del fit
+        out["pooled_gram"] = {"value": 1.0 / (t_pooled * (N_TRAIN / n) ** 3), "unit": "fits/sec", "cores": cores,
+                              "sample": f"the same oracle fit at N={n} with the Gram pooled over {cores} threads: {t_pooled:.2f} s"}
+    except Exception as exc:  # noqa: BLE001 - context only
+        out["pooled_gram"] = {"error": f"{type(exc).__name__}: {exc}"}
     # For context ("strong CPU"): the same fit on all host cores with a blocked,
     # multi-threaded LAPACK Cholesky (scipy) and a vectorised numpy Gram.  Not the reference's algorithm
     # (albatross factors with Eigen's unblocked single-threaded LDL^T), so it is reported beside `value`.
