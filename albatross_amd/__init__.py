@@ -8,7 +8,7 @@ from .covariance import (AngularDistance, Constant, CovarianceFunction, Euclidea
                          FeatureSet, IndependentNoise, LinearCombination, Matern32, Matern52, Measurement, MeasurementOnly,
                          Nugget, Polynomial, ProductOfCovarianceFunctions, RadialDistance, ScalingFunction,
                          ScalingTerm, SquaredExponential, SumOfCovarianceFunctions, as_measurements,
-                         measurement_only)
+                         measurement_only, OnlyForAlternatives, VariantFeatures, only_for_alternatives)
 
 from .gp import (AlbatrossAmdError, BlockSymmetric, ExplainedCovariance, PivotedLDLT, Context, CrossValidation, CrossValidationPrediction, DenseFactor,
                  LeaveOneOutGrouper, group_indexer, root_mean_square_error, UpdatedGPFit, negative_log_likelihood, FitModel, GaussianProcessRegression, GPFit, JointDistribution,

@@ -28,6 +28,7 @@ OP_SCALING = 9
 OP_SUM = 10
 OP_PRODUCT = 11
 OP_MEASUREMENT_ONLY = 12
+OP_TYPE_PAIR = 13
 
 METRIC_EUCLIDEAN = 0
 METRIC_RADIAL = 1

@@ -86,6 +86,36 @@ class Measurement:
         self.values = values
 
 
+class _AlternativeIndex:
+    """Pseudo scaling function: the scale column that carries the alternative index of every point of a
+    variant<> feature vector (read by AGP_OP_TYPE_PAIR).  Plain feature vectors are alternative 0."""
+
+    def __call__(self, coords):
+        return np.zeros(len(coords))
+
+
+_ALTERNATIVE_INDEX = _AlternativeIndex()
+
+
+class VariantFeatures:
+    """std::vector<variant<T0, T1, ...>>: element i holds alternative `alternatives[i]` with value `values[i]`
+    (a scalar or a coordinate vector; alternatives may have different dimensions, the POD record is zero-padded
+    to the largest).  See only_for_alternatives()."""
+
+    def __init__(self, alternatives, values):
+        self.alternatives = np.asarray(alternatives, dtype=np.int64).reshape(-1)
+        vals = [np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in values]
+        if len(vals) != self.alternatives.shape[0]:
+            raise ValueError("one alternative index per value")
+        dim = max([v.shape[0] for v in vals] + [1])
+        self.coords = np.zeros((len(vals), dim))
+        for i, v in enumerate(vals):
+            self.coords[i, :v.shape[0]] = v
+
+    def __len__(self):
+        return self.alternatives.shape[0]
+
+
 class LinearCombination:
     """LinearCombination<X> (core/linear_combination.hpp:18-44): a feature that is sum_i coefficients[i] * values[i].
     cov(a, b) = sum_ij a_i b_j cov(x_i, y_j) and mean(a) = sum_i a_i mean(x_i), applied at the TOP of the caller chain
@@ -199,11 +229,22 @@ class CovarianceFunction:
                 return x
             return FeatureSet(x.coords, None if x.scales is None else list(x.scales.T), x.eq_id, is_measurement)
         _, scalers = self.program()
+        alternatives = None
+        if isinstance(x, VariantFeatures):
+            alternatives, x = x.alternatives.astype(np.float64), x.coords
         coords = np.asarray(x, dtype=np.float64)
         if coords.ndim == 1:
             coords = coords.reshape(-1, 1)  # scaling functions always see n x dim
-        cols = [np.asarray(s(coords), dtype=np.float64).reshape(-1) for s in scalers]
-        return FeatureSet(coords, cols, None, is_measurement)
+        cols = [(alternatives if (s is _ALTERNATIVE_INDEX and alternatives is not None)
+                 else np.asarray(s(coords), dtype=np.float64).reshape(-1)) for s in scalers]
+        eq_id = None
+        if alternatives is not None:
+            # variant equality = same alternative AND equal value (the zero-padded coordinates alone would make
+            # a 1-D alternative at t equal to a 3-D one at (t, 0, 0)): a 63-bit hash of both, identical for equal
+            # features of any two feature vectors
+            eq_id = np.array([hash((int(a), row.tobytes())) & 0x7fffffffffffffff
+                              for a, row in zip(alternatives, np.ascontiguousarray(coords))], dtype=np.int64)
+        return FeatureSet(coords, cols, eq_id, is_measurement)
 
     # --- calls ------------------------------------------------------------------
     def __call__(self, xs, ys=None):
@@ -447,6 +488,37 @@ class MeasurementOnly(CovarianceFunction):
 
 def measurement_only(cov):
     return MeasurementOnly(cov)
+
+
+class OnlyForAlternatives(CovarianceFunction):
+    """A covariance function that is defined for ONE pair of alternatives (a, b) of a variant<> feature type (in
+    either order): what a `_call_impl(const A &, const B &)` overload is in the reference.  VariantForwarder
+    (covariance_functions/callers.hpp:419-544) returns 0 for every pair of alternatives without an overload; a
+    covariance function with several overloads (tests/lib/albatross/test/test_covariance_utils.h:42-62) is the sum of
+    one of these per overload."""
+
+    def __init__(self, sub_cov, a, b=None):
+        self.sub_cov_ = sub_cov
+        self.a_, self.b_ = int(a), int(a if b is None else b)
+
+    def name(self):
+        return f"alternatives[{self.a_},{self.b_}][{self.sub_cov_.get_name()}]"
+
+    def get_params(self):
+        return self.sub_cov_.get_params()
+
+    def set_param(self, name, value):
+        self.sub_cov_.set_param(name, value)
+
+    def _emit(self, nodes, scalers):
+        self.sub_cov_._emit(nodes, scalers)
+        if _ALTERNATIVE_INDEX not in scalers:
+            scalers.append(_ALTERNATIVE_INDEX)  # one shared column for every gate of the program
+        nodes.append(_node(capi.OP_TYPE_PAIR, column=scalers.index(_ALTERNATIVE_INDEX), params=(self.a_, self.b_)))
+
+
+def only_for_alternatives(cov, a, b=None):
+    return OnlyForAlternatives(cov, a, b)
 
 
 def nodes_to_array(nodes):

@@ -184,6 +184,9 @@ int agp_kernel_create(const agp_kernel_node *postfix, int n_nodes, agp_kernel **
     case AGP_OP_MEASUREMENT_ONLY:
       if (depth < 1) return AGP_ERR_INVALID_ARGUMENT;
       break;
+    case AGP_OP_TYPE_PAIR:
+      if (depth < 1 || nd.column < 0 || nd.column >= AGP_MAX_SCALE_COLUMNS) return AGP_ERR_INVALID_ARGUMENT;
+      break;
     default: return AGP_ERR_INVALID_ARGUMENT;
     }
     if (depth > AGP_MAX_STACK) return AGP_ERR_UNSUPPORTED;

@@ -147,6 +147,15 @@ __device__ __forceinline__ double eval_pair(const DevProgram *__restrict__ Pp, c
       --sp;
     } else if (op == AGP_OP_MEASUREMENT_ONLY) {
       if (!both_measurement) stack_set(st, sp - 1, 0.);
+    } else if (op == AGP_OP_TYPE_PAIR) {  // VariantForwarder, callers.hpp:419-544: undefined pair of alternatives -> 0
+      double tx = x.s[0], ty = y.s[0];
+#pragma unroll
+      for (int k = 1; k < AGP_MAX_SCALE_COLUMNS; ++k) {
+        tx = (nd.column == k) ? x.s[k] : tx;
+        ty = (nd.column == k) ? y.s[k] : ty;
+      }
+      const double a = nd.params[0], b = nd.params[1];
+      if (!((tx == a && ty == b) || (tx == b && ty == a))) stack_set(st, sp - 1, 0.);
     }
   }
   return st[0];

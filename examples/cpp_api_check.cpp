@@ -6,6 +6,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <variant>
 #include <random>
 
 #include <albatross_amd/albatross.hpp>
@@ -263,6 +264,35 @@ int main() {
     for (std::size_t i = 0; i < pts.size(); ++i) std::printf("lc_pred,%zu,%.17g,%.17g\n", i, lj.mean[i], lj.covariance((long)i, (long)i));
     const auto lq = lf.predict_joint(std::vector<LC>{feats[12], feats[13]});
     std::printf("lc_constraints,%.17g,%.17g,%.17g,%.17g\n", lq.mean[0], lq.mean[1], lq.covariance(0, 0), lq.covariance(1, 1));
+  }
+  // variant features (VariantForwarder, callers.hpp:419-544) with the reference's dispatch table
+  // (tests/lib/albatross/test/test_covariance_utils.h:42-62: (X,X)=1, (X,Y)=3, (Y,Y)=5, (W,W)=7, (V,V)=11, else 0)
+  {
+    using A2 = std::array<double, 2>;
+    using A3 = std::array<double, 3>;
+    using A4 = std::array<double, 4>;
+    using F = std::variant<double, A2, A3, A4>;  // alternatives X, Y, W, V
+    auto c = [](double v) { return Constant(std::sqrt(v)); };
+    auto has_multiple = only_for_alternatives<0>(c(1.)) + only_for_alternatives<0, 1>(c(3.)) + only_for_alternatives<1>(c(5.)) +
+                        only_for_alternatives<2>(c(7.)) + only_for_alternatives<3>(c(11.));
+    const std::vector<F> fs = {F(0.), F(A2{0., 0.}), F(A3{0., 0., 0.}), F(A4{0., 0., 0., 0.})};
+    const Matrix K = has_multiple(fs);
+    for (int i = 0; i < 4; ++i) std::printf("variant_gram,%d,%.17g,%.17g,%.17g,%.17g\n", i, K(i, 0), K(i, 1), K(i, 2), K(i, 3));
+    // a GP over two kinds of observations: 1-D positions (alternative 0) and 2-D points (alternative 1)
+    using G = std::variant<double, A2>;
+    std::vector<G> gx;
+    Vector gy;
+    for (int i = 0; i < 30; ++i) {
+      if (i % 2 == 0) gx.push_back(G(0.3 * i)); else gx.push_back(G(A2{0.2 * i, 1. + 0.1 * i}));
+      gy.push_back(std::sin(0.4 * i));
+    }
+    auto gcov = only_for_alternatives<0>(SquaredExponential<EuclideanDistance>(1.5, 1.0)) +
+                only_for_alternatives<1>(Matern52<EuclideanDistance>(2.0, 0.8)) + Constant(0.5) + IndependentNoise<G>(0.1);
+    auto gm = gp_from_covariance(gcov);
+    const auto gf = gm.fit(RegressionDataset<G>(gx, gy));
+    for (std::size_t i = 0; i < gx.size(); ++i) std::printf("variant_info,%zu,%.17g\n", i, gf.get_fit().information[i]);
+    const auto gp = gf.predict(std::vector<G>{G(2.5), G(A2{1., 2.})}).marginal();
+    std::printf("variant_pred,%.17g,%.17g,%.17g,%.17g\n", gp.mean[0], gp.mean[1], gp.covariance[0], gp.covariance[1]);
   }
   // a singular covariance is reported, not silently factored
   try {

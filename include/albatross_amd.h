@@ -69,7 +69,14 @@ typedef enum {
   AGP_OP_PRODUCT = 11,
   /* sub-covariance iff BOTH arguments are Measurement<>, else 0;
    * measurement.hpp:70-106 */
-  AGP_OP_MEASUREMENT_ONLY = 12
+  AGP_OP_MEASUREMENT_ONLY = 12,
+  /* sub-covariance iff the two arguments hold the alternatives (a, b) of a
+   * variant<> feature type, in either order, else 0: VariantForwarder
+   * (covariance_functions/callers.hpp:419-544) returns 0 for every pair of
+   * alternatives a covariance function defines no _call_impl for.  The
+   * alternative index of each point travels as a value in scale column
+   * `column`; params = {a, b}. */
+  AGP_OP_TYPE_PAIR = 13
 } agp_op;
 
 typedef enum {
@@ -86,7 +93,7 @@ typedef enum {
 typedef struct {
   int32_t op;     /* agp_op */
   int32_t metric; /* agp_metric, radial leaves only */
-  int32_t column; /* AGP_OP_SCALING: which scale column */
+  int32_t column; /* AGP_OP_SCALING / AGP_OP_TYPE_PAIR: which scale column */
   int32_t order;  /* AGP_OP_POLYNOMIAL: polynomial order */
   double params[4];
 } agp_kernel_node;

@@ -20,15 +20,18 @@
 #ifndef ALBATROSS_AMD_ALBATROSS_HPP
 #define ALBATROSS_AMD_ALBATROSS_HPP
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <variant>
 #include <vector>
 
 #include "../albatross_amd.h"
@@ -141,7 +144,43 @@ struct FeatureTraits<std::array<double, N>> {
   static std::int64_t eq_id(const std::array<double, N> &) { return 0; }
 };
 
+// std::vector<std::variant<T0, T1, ...>> (the reference uses mapbox::variant; VariantForwarder,
+// covariance_functions/callers.hpp:419-544): the POD record is zero-padded to the widest alternative, equality is
+// "same alternative and equal value" (a hash of both as equality id), and every point carries the index of the
+// alternative it holds in the last scale column, where only_for_alternatives<A, B>(cov) terms read it.
+template <typename... Ts>
+struct FeatureTraits<std::variant<Ts...>> {
+  static constexpr int dim = std::max({FeatureTraits<Ts>::dim...});
+  static constexpr bool has_eq_id = true;
+  static void coords(const std::variant<Ts...> &x, double *out) {
+    for (int d = 0; d < dim; ++d) out[d] = 0.;
+    std::visit([out](const auto &v) { FeatureTraits<std::decay_t<decltype(v)>>::coords(v, out); }, x);
+  }
+  static std::int64_t eq_id(const std::variant<Ts...> &x) {
+    double c[dim];
+    coords(x, c);
+    std::uint64_t h = 1469598103934665603ull ^ static_cast<std::uint64_t>(x.index());  // FNV-1a over index + coordinate bits
+    h *= 1099511628211ull;
+    for (int d = 0; d < dim; ++d) {
+      std::uint64_t bits;
+      static_assert(sizeof(bits) == sizeof(double), "double is 64 bits");
+      std::memcpy(&bits, &c[d], sizeof(bits));
+      for (int b = 0; b < 8; ++b) {
+        h ^= (bits >> (8 * b)) & 0xffu;
+        h *= 1099511628211ull;
+      }
+    }
+    return static_cast<std::int64_t>(h & 0x7fffffffffffffffull);
+  }
+};
+
 namespace detail {
+
+constexpr int kAlternativeColumn = AGP_MAX_SCALE_COLUMNS - 1;  // scale column that carries the alternative index
+template <typename X>
+double alternative_index(const X &) { return 0.; }  // plain feature types are alternative 0
+template <typename... Ts>
+double alternative_index(const std::variant<Ts...> &x) { return static_cast<double>(x.index()); }
 
 inline void check(int status, agp_context *ctx, const char *what) {
   if (status == AGP_OK) return;
@@ -334,6 +373,11 @@ class CovarianceFunction {
     std::vector<agp_kernel_node> nodes;
     int column = 0;
     derived().emit(nodes, column);
+    for (const auto &nd : nodes)
+      if (nd.op == AGP_OP_TYPE_PAIR) {  // the alternative index lives in the last column
+        if (column > detail::kAlternativeColumn) throw std::invalid_argument("too many ScalingTerms next to only_for_alternatives");
+        return detail::kAlternativeColumn + 1;
+      }
     return column;
   }
 
@@ -629,6 +673,45 @@ class MeasurementOnly : public CovarianceFunction<MeasurementOnly<SubCovariance>
 template <typename SubCovariance>
 MeasurementOnly<SubCovariance> measurement_only(const SubCovariance &cov) {
   return MeasurementOnly<SubCovariance>(cov);
+}
+
+// A covariance term that is defined for ONE pair (A, B) of alternatives of a variant feature type, in either order:
+// what a `_call_impl(const TA &, const TB &)` overload is in the reference.  VariantForwarder
+// (covariance_functions/callers.hpp:419-544) returns 0 for pairs of alternatives without an overload; a covariance
+// function with several overloads (tests/lib/albatross/test/test_covariance_utils.h:42-62) is the sum of one such
+// term per overload.  A, B: alternative indices (std::variant::index()).
+template <typename SubCovariance>
+class OnlyForAlternatives : public CovarianceFunction<OnlyForAlternatives<SubCovariance>> {
+ public:
+  OnlyForAlternatives() = default;
+  OnlyForAlternatives(const SubCovariance &sub, int a, int b) : sub_cov_(sub), a_(a), b_(b) {}
+  std::string name() const {
+    return "alternatives[" + std::to_string(a_) + "," + std::to_string(b_) + "][" + sub_cov_.get_name() + "]";
+  }
+  ParameterStore get_params() const { return sub_cov_.get_params(); }
+  bool has_param(const std::string &n) const { return sub_cov_.has_param(n); }
+  void set_param(const std::string &n, double v) { sub_cov_.set_param(n, v); }
+  void emit(std::vector<agp_kernel_node> &nodes, int &column) const {
+    sub_cov_.emit(nodes, column);
+    agp_kernel_node nd = detail::node(AGP_OP_TYPE_PAIR, 0, detail::kAlternativeColumn, 0);
+    nd.params[0] = a_;
+    nd.params[1] = b_;
+    nodes.push_back(nd);
+  }
+  template <typename X>
+  void fill_scales(const X &x, double *out, int &column) const {
+    sub_cov_.template fill_scales<X>(x, out, column);
+    out[detail::kAlternativeColumn] = detail::alternative_index(x);
+  }
+
+ private:
+  SubCovariance sub_cov_;
+  int a_ = 0, b_ = 0;
+};
+
+template <int A, int B = A, typename SubCovariance>
+OnlyForAlternatives<SubCovariance> only_for_alternatives(const SubCovariance &cov) {
+  return OnlyForAlternatives<SubCovariance>(cov, A, B);
 }
 
 // ---------------------------------------------------------------------------

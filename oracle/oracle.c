@@ -167,6 +167,10 @@ static double eval_pair(const agp_kernel_node *prog, int n_nodes,
     case AGP_OP_MEASUREMENT_ONLY: /* measurement.hpp:87-102 */
       if (!(X->is_measurement && Y->is_measurement)) st[sp - 1] = 0.;
       break;
+    case AGP_OP_TYPE_PAIR: { /* VariantForwarder, callers.hpp:419-544: no _call_impl for the pair of alternatives -> 0 */
+      const double tx = X->scales[nd->column * X->n + i], ty = Y->scales[nd->column * Y->n + j];
+      if (!((tx == p[0] && ty == p[1]) || (tx == p[1] && ty == p[0]))) st[sp - 1] = 0.;
+    } break;
     default:
       st[sp++] = NAN;
     }

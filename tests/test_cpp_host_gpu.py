@@ -126,6 +126,22 @@ def test_cpp_api_matches_oracle():
     assert abs(cm0 - wq.mean[0]) < 1e-9 and abs(cm1 - wq.mean[1]) < 1e-9
     assert abs(cv0 - wq.covariance[0, 0]) < 1e-9 and abs(cv1 - wq.covariance[1, 1]) < 1e-9
     assert abs((lcp[0, 1] - lcp[1, 1]) - cm0) < 1e-9             # = the same combination of the point predictions
+    # variant features: the reference's dispatch table and a two-kinds-of-observations GP against the oracle
+    vg = np.array(rows["variant_gram"], dtype=float)[:, 1:]
+    want = np.array([[1., 3., 0., 0.], [3., 5., 0., 0.], [0., 0., 7., 0.], [0., 0., 0., 11.]])
+    assert np.abs(vg - want).max() <= 1e-14 and np.array_equal(vg == 0., want == 0.)
+    alt = [i % 2 for i in range(30)]
+    vals = [0.3 * i if i % 2 == 0 else [0.2 * i, 1. + 0.1 * i] for i in range(30)]
+    vfeats = ab.VariantFeatures(alt, vals)
+    vy = np.array([np.sin(0.4 * i) for i in range(30)])
+    vcov = (ab.only_for_alternatives(ab.SquaredExponential(1.5, 1.0), 0) + ab.only_for_alternatives(ab.Matern52(2.0, 0.8), 1)
+            + ab.Constant(0.5) + ab.IndependentNoise(0.1))
+    vfit = orc.OracleFit(vcov, vfeats, vy)
+    vinfo = np.array(rows["variant_info"], dtype=float)[:, 1]
+    assert np.abs(vinfo - vfit.information).max() <= 1e-8 * np.abs(vfit.information).max()
+    vm, vv = vfit.predict_marginal(ab.VariantFeatures([0, 1], [2.5, [1., 2.]]))
+    vp = [float(v) for v in rows["variant_pred"][0]]
+    assert abs(vp[0] - vm[0]) <= 1e-8 and abs(vp[1] - vm[1]) <= 1e-8 and abs(vp[2] - vv[0]) <= 1e-8 and abs(vp[3] - vv[1]) <= 1e-8
     # leave-one-group-out: fast path == refit per fold (the brute-force predict(test) is the latent
     # prediction: the held-out noise term only appears in the fast path's covariance diagonal)
     assert int(one["cv_groups"]) == 4 and float(one["cv_mean_diff"]) < 1e-7 and float(one["cv_cov_diff"]) < 1e-7

@@ -277,3 +277,26 @@ def test_sparse_gp_oracle_update_equals_full_fit():
     um, uv, uj = upd.predict(xs, xs_meas=True, joint=True)
     assert np.linalg.norm(pm - fm) > 1e-2 and np.linalg.norm(pj - fj) > 1e-1
     assert np.linalg.norm(um - fm) < 1e-9 and np.linalg.norm(uj - fj) < 1e-9
+
+
+def _has_multiple():
+    """tests/lib/albatross/test/test_covariance_utils.h:42-62 (HasMultiple): one _call_impl overload per pair of
+    alternatives X=0, Y=1, W=2, V=3: (X,X)=1, (X,Y)=3, (Y,Y)=5, (W,W)=7, (V,V)=11."""
+    c = lambda v: ab.Constant(np.sqrt(v))
+    return (ab.only_for_alternatives(c(1.), 0) + ab.only_for_alternatives(c(3.), 0, 1) + ab.only_for_alternatives(c(5.), 1)
+            + ab.only_for_alternatives(c(7.), 2) + ab.only_for_alternatives(c(11.), 3))
+
+
+def test_variant_dispatch_values_of_the_reference():
+    """tests/test_covariance_function.cc:57-170: cov(variant holding a, variant holding b) = the overload for (a, b) in
+    either order, 0 where the covariance function has none (X-W, Y-W, ...)."""
+    cov = _has_multiple()
+    X, Y, W, V = 0, 1, 2, 3
+    feats = ab.VariantFeatures([X, Y, W, V], [0., 0., 0., 0.])
+    K = orc.gram(cov, feats)
+    want = np.array([[1., 3., 0., 0.],
+                     [3., 5., 0., 0.],
+                     [0., 0., 7., 0.],
+                     [0., 0., 0., 11.]])
+    assert np.abs(K - want).max() <= 4 * np.finfo(float).eps * 11.   # Constant(sigma) returns sigma * sigma
+    assert np.array_equal(K == 0., want == 0.)                          # the undefined pairs are exactly 0
