@@ -88,6 +88,10 @@ __device__ __forceinline__ double eval_pair(const DevProgram *__restrict__ Pp, c
 
   stack_t st = (stack_t)(0.);
   int sp = 0;
+  // bit i: stack slot i holds a DEFINED value.  A term gated to another pair of variant alternatives is
+  // undefined for this pair (no _call_impl overload): a sum or product then keeps its other side alone
+  // (covariance_function.hpp:266-294, 357-389) and an undefined final result is 0 (VariantForwarder).
+  unsigned defined = 0u;
   for (int t = 0; t < P.n_nodes; ++t) {
     const agp_kernel_node &nd = P.nodes[t];
     const int op = nd.op;
@@ -139,11 +143,16 @@ __device__ __forceinline__ double eval_pair(const DevProgram *__restrict__ Pp, c
       ++sp;
     } else if (op == AGP_OP_SUM) {
       const double r = stack_get(st, sp - 1), l = stack_get(st, sp - 2);
-      stack_set(st, sp - 2, l + r);
+      const bool dl = (defined >> (sp - 2)) & 1u, dr = (defined >> (sp - 1)) & 1u;
+      stack_set(st, sp - 2, l + r);  // an undefined side holds 0
+      defined = (defined & ~(3u << (sp - 2))) | ((unsigned)(dl || dr) << (sp - 2));
       --sp;
     } else if (op == AGP_OP_PRODUCT) {
       const double r = stack_get(st, sp - 1), l = stack_get(st, sp - 2);
-      stack_set(st, sp - 2, (l != 0.) ? l * r : l);  // rhs skipped when lhs == 0
+      const bool dl = (defined >> (sp - 2)) & 1u, dr = (defined >> (sp - 1)) & 1u;
+      // both sides defined: lhs * rhs, rhs skipped when lhs == 0; one side only: that side; none: undefined
+      stack_set(st, sp - 2, (dl && dr) ? ((l != 0.) ? l * r : l) : (dl ? l : (dr ? r : 0.)));
+      defined = (defined & ~(3u << (sp - 2))) | ((unsigned)(dl || dr) << (sp - 2));
       --sp;
     } else if (op == AGP_OP_MEASUREMENT_ONLY) {
       if (!both_measurement) stack_set(st, sp - 1, 0.);
@@ -155,8 +164,12 @@ __device__ __forceinline__ double eval_pair(const DevProgram *__restrict__ Pp, c
         ty = (nd.column == k) ? y.s[k] : ty;
       }
       const double a = nd.params[0], b = nd.params[1];
-      if (!((tx == a && ty == b) || (tx == b && ty == a))) stack_set(st, sp - 1, 0.);
+      if (!((tx == a && ty == b) || (tx == b && ty == a))) {
+        stack_set(st, sp - 1, 0.);
+        defined &= ~(1u << (sp - 1));
+      }
     }
+    if (op <= AGP_OP_SCALING) defined |= 1u << (sp - 1);  // a leaf was pushed: defined for every pair
   }
   return st[0];
 }

@@ -75,7 +75,9 @@ typedef enum {
    * (covariance_functions/callers.hpp:419-544) returns 0 for every pair of
    * alternatives a covariance function defines no _call_impl for.  The
    * alternative index of each point travels as a value in scale column
-   * `column`; params = {a, b}. */
+   * `column`; params = {a, b}.  A gated-off term is UNDEFINED for the pair:
+   * AGP_OP_SUM / AGP_OP_PRODUCT then keep their other operand alone
+   * (covariance_function.hpp:266-294, 357-389); an undefined result is 0. */
   AGP_OP_TYPE_PAIR = 13
 } agp_op;
 

@@ -116,6 +116,7 @@ static double eval_pair(const agp_kernel_node *prog, int n_nodes,
                         const orc_set *X, int64_t i, const orc_set *Y,
                         int64_t j) {
   double st[AGP_MAX_STACK];
+  int def[AGP_MAX_STACK]; /* slot holds the value of a term that HAS a caller for this pair of feature types */
   int sp = 0;
   const double *x = X->coords + i * X->dim;
   const double *y = Y->coords + j * Y->dim;
@@ -123,6 +124,7 @@ static double eval_pair(const agp_kernel_node *prog, int n_nodes,
   for (int t = 0; t < n_nodes; ++t) {
     const agp_kernel_node *nd = &prog[t];
     const double *p = nd->params;
+    if (nd->op <= AGP_OP_SCALING) def[sp] = 1; /* every leaf is defined for every pair */
     switch (nd->op) {
     case AGP_OP_SQUARED_EXPONENTIAL:
       st[sp++] = squared_exponential(distance(nd->metric, x, y, dim), p[0], p[1]);
@@ -154,14 +156,25 @@ static double eval_pair(const agp_kernel_node *prog, int n_nodes,
     case AGP_OP_SCALING: /* scaling_function.hpp:79-83: f(x) * f(y) */
       st[sp++] = X->scales[nd->column * X->n + i] * Y->scales[nd->column * Y->n + j];
       break;
-    case AGP_OP_SUM: /* covariance_function.hpp:266-272 */
-      st[sp - 2] = st[sp - 2] + st[sp - 1];
+    case AGP_OP_SUM: /* covariance_function.hpp:266-294: both sides, or the one side that has a caller */
+      st[sp - 2] = st[sp - 2] + st[sp - 1]; /* a side without a caller holds 0 */
+      def[sp - 2] = def[sp - 2] || def[sp - 1];
       --sp;
       break;
-    case AGP_OP_PRODUCT: { /* covariance_function.hpp:357-367 */
-      double out = st[sp - 2];
-      if (out != 0.) out *= st[sp - 1];
+    case AGP_OP_PRODUCT: { /* covariance_function.hpp:357-389 */
+      double out;
+      if (def[sp - 2] && def[sp - 1]) { /* :357-367 */
+        out = st[sp - 2];
+        if (out != 0.) out *= st[sp - 1];
+      } else if (def[sp - 2]) { /* :372-378: only LHS has a caller, R is ignored */
+        out = st[sp - 2];
+      } else if (def[sp - 1]) { /* :383-389 */
+        out = st[sp - 1];
+      } else {
+        out = 0.;
+      }
       st[sp - 2] = out;
+      def[sp - 2] = def[sp - 2] || def[sp - 1];
       --sp;
     } break;
     case AGP_OP_MEASUREMENT_ONLY: /* measurement.hpp:87-102 */
@@ -169,7 +182,10 @@ static double eval_pair(const agp_kernel_node *prog, int n_nodes,
       break;
     case AGP_OP_TYPE_PAIR: { /* VariantForwarder, callers.hpp:419-544: no _call_impl for the pair of alternatives -> 0 */
       const double tx = X->scales[nd->column * X->n + i], ty = Y->scales[nd->column * Y->n + j];
-      if (!((tx == p[0] && ty == p[1]) || (tx == p[1] && ty == p[0]))) st[sp - 1] = 0.;
+      if (!((tx == p[0] && ty == p[1]) || (tx == p[1] && ty == p[0]))) {
+        st[sp - 1] = 0.;
+        def[sp - 1] = 0; /* no _call_impl for this pair of alternatives */
+      }
     } break;
     default:
       st[sp++] = NAN;

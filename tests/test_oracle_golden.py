@@ -300,3 +300,21 @@ def test_variant_dispatch_values_of_the_reference():
                      [0., 0., 0., 11.]])
     assert np.abs(K - want).max() <= 4 * np.finfo(float).eps * 11.   # Constant(sigma) returns sigma * sigma
     assert np.array_equal(K == 0., want == 0.)                          # the undefined pairs are exactly 0
+
+
+def test_sum_and_product_ignore_a_side_without_a_caller():
+    """covariance_function.hpp:266-294, 357-389: a sum / product whose one side has no caller for the pair of
+    types keeps the OTHER side alone (it does not become 0); with no caller on either side the pair contributes 0."""
+    only_xx = ab.only_for_alternatives(ab.Constant(np.sqrt(2.)), 0)        # defined for (X, X) only
+    anywhere = ab.Constant(np.sqrt(3.))
+    feats = ab.VariantFeatures([0, 1], [0., 0.])
+    Kp = orc.gram(only_xx * anywhere, feats)
+    assert abs(Kp[0, 0] - 6.) < 1e-14 and abs(Kp[1, 1] - 3.) < 1e-14 and abs(Kp[0, 1] - 3.) < 1e-14   # (Y,Y), (X,Y): rhs alone
+    Ks = orc.gram(only_xx + anywhere, feats)
+    assert abs(Ks[0, 0] - 5.) < 1e-14 and abs(Ks[1, 1] - 3.) < 1e-14
+    only_yy = ab.only_for_alternatives(ab.Constant(np.sqrt(5.)), 1)
+    Kn = orc.gram(only_xx * only_yy, feats)                                 # no pair has both; each diagonal pair has one
+    assert abs(Kn[0, 0] - 2.) < 1e-14 and abs(Kn[1, 1] - 5.) < 1e-14 and Kn[0, 1] == 0. and Kn[1, 0] == 0.
+    # a defined side that EVALUATES to 0 still annihilates a product (the lhs == 0 short circuit, :361-365)
+    meas = ab.measurement_only(ab.IndependentNoise(0.5))
+    assert orc.gram(meas * anywhere, feats)[0, 0] == 0.

@@ -52,3 +52,20 @@ def test_gp_on_two_observation_types(ctx):
     assert np.abs(pred.mean - om).max() <= 1e-8 * np.abs(om).max()
     assert np.abs(pred.covariance - ov).max() <= 1e-8 * np.abs(ov).max()
     assert abs(-model.log_likelihood(ab.RegressionDataset(feats, y)) - orc.nll(cov, feats, y)) <= 1e-6 * (nA + nB)
+
+
+def test_products_and_sums_with_undefined_sides_on_the_device(ctx):
+    """device == oracle for the `ignore the side without a caller` rules (covariance_function.hpp:266-294, 357-389)"""
+    rng = np.random.default_rng(3)
+    alt = rng.integers(0, 3, 60)
+    feats = ab.VariantFeatures(alt, [rng.uniform(0., 5.) if a < 2 else rng.uniform(0., 5., 2) for a in alt])
+    se0 = ab.only_for_alternatives(ab.SquaredExponential(1.3, 1.1), 0)
+    m1 = ab.only_for_alternatives(ab.Matern32(2.0, 0.7), 1)
+    x01 = ab.only_for_alternatives(ab.Constant(0.4), 0, 1)
+    for cov in (se0 * ab.Constant(1.5) + m1, (se0 + m1) * (x01 + ab.Constant(0.9)), se0 * m1 + x01,
+                ab.measurement_only(ab.IndependentNoise(0.3)) * se0 + m1 * ab.Constant(2.0)):
+        for meas in (False, True):
+            f = ab.Measurement(feats) if meas else feats
+            K = ctx.gram(cov, f)
+            Ko = orc.gram(cov, feats, x_meas=meas)
+            assert np.abs(K - Ko).max() <= 1e-14 * max(np.abs(Ko).max(), 1.), cov.get_name()
