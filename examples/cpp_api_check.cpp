@@ -291,6 +291,16 @@ int main() {
     auto gm = gp_from_covariance(gcov);
     const auto gf = gm.fit(RegressionDataset<G>(gx, gy));
     for (std::size_t i = 0; i < gx.size(); ++i) std::printf("variant_info,%zu,%.17g\n", i, gf.get_fit().information[i]);
+    // a ScalingTerm whose function only knows the first alternative scales the other by 1 (scaling_function.hpp:92-112)
+    struct TimeScale {
+      std::string get_name() const { return "time_scale"; }
+      ParameterStore get_params() const { return {}; }
+      void set_param(const std::string &, double) {}
+      double _call_impl(const double &t) const { return 1. + 0.1 * t; }
+    };
+    const auto sc = ScalingTerm<TimeScale>(TimeScale()) * Constant(0.7);
+    const Matrix Ks = sc(std::vector<G>{G(2.0), G(A2{1., 2.}), G(5.0)});
+    std::printf("variant_scaling,%.17g,%.17g,%.17g,%.17g\n", Ks(0, 0), Ks(0, 1), Ks(1, 1), Ks(0, 2));
     const auto gp = gf.predict(std::vector<G>{G(2.5), G(A2{1., 2.})}).marginal();
     std::printf("variant_pred,%.17g,%.17g,%.17g,%.17g\n", gp.mean[0], gp.mean[1], gp.covariance[0], gp.covariance[1]);
   }

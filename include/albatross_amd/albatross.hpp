@@ -182,6 +182,23 @@ double alternative_index(const X &) { return 0.; }  // plain feature types are a
 template <typename... Ts>
 double alternative_index(const std::variant<Ts...> &x) { return static_cast<double>(x.index()); }
 
+// f(x) of a ScalingTerm; a feature type the scaling function has no _call_impl for is ignored, i.e. scales by 1
+// (the one-sided overloads of scaling_function.hpp:92-112); a variant is visited
+template <typename F, typename X, typename = void>
+struct has_scaling_call : std::false_type {};
+template <typename F, typename X>
+struct has_scaling_call<F, X, std::void_t<decltype(std::declval<const F &>()._call_impl(std::declval<const X &>()))>>
+    : std::true_type {};
+template <typename F, typename X>
+double scale_of(const F &f, const X &x) {
+  if constexpr (has_scaling_call<F, X>::value) return f._call_impl(x);
+  else return 1.;
+}
+template <typename F, typename... Ts>
+double scale_of(const F &f, const std::variant<Ts...> &x) {
+  return std::visit([&f](const auto &v) { return scale_of(f, v); }, x);
+}
+
 inline void check(int status, agp_context *ctx, const char *what) {
   if (status == AGP_OK) return;
   std::string msg = std::string("albatross_amd: ") + what + ": " + agp_status_string(status);
@@ -576,7 +593,7 @@ class ScalingTerm : public CovarianceFunction<ScalingTerm<ScalingFunction>> {
   }
   template <typename X>
   void fill_scales(const X &x, double *out, int &column) const {
-    out[column++] = scaling_function_._call_impl(x);  // evaluated once per point, not per pair
+    out[column++] = detail::scale_of(scaling_function_, x);  // evaluated once per point, not per pair
   }
 
  private:

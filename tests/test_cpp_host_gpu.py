@@ -142,6 +142,8 @@ def test_cpp_api_matches_oracle():
     vm, vv = vfit.predict_marginal(ab.VariantFeatures([0, 1], [2.5, [1., 2.]]))
     vp = [float(v) for v in rows["variant_pred"][0]]
     assert abs(vp[0] - vm[0]) <= 1e-8 and abs(vp[1] - vm[1]) <= 1e-8 and abs(vp[2] - vv[0]) <= 1e-8 and abs(vp[3] - vv[1]) <= 1e-8
+    vs = [float(v) for v in rows["variant_scaling"][0]]   # f(2.0) = 1.2, f(5.0) = 1.5, the 2-D alternative scales by 1
+    assert np.allclose(vs, [1.2 * 1.2 * 0.49, 1.2 * 0.49, 0.49, 1.2 * 1.5 * 0.49], rtol=1e-14)
     # leave-one-group-out: fast path == refit per fold (the brute-force predict(test) is the latent
     # prediction: the held-out noise term only appears in the fast path's covariance diagonal)
     assert int(one["cv_groups"]) == 4 and float(one["cv_mean_diff"]) < 1e-7 and float(one["cv_cov_diff"]) < 1e-7
