@@ -27,6 +27,7 @@ sequencing is backend-agnostic: tests/test_distributed_cpu.py runs it on CPU
 tensors over gloo with a numpy implementation of the same block interface.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch  # noqa: F401  (imported BEFORE the HIP library is loaded, see _init_torch_first)
@@ -196,6 +197,18 @@ class ShardedGaussianProcessFit:
             self.dist.broadcast(tensor, src=self._src(owner), group=self.group)
             self.ops.sync()
 
+    def _broadcast_start(self, tensor, owner):
+        """asynchronous broadcast (the caller keeps working on OTHER buffers); returns a handle for _broadcast_finish"""
+        if self.active and (self.world > 1 or self.force_collectives):
+            self.ops.sync()
+            return self.dist.broadcast(tensor, src=self._src(owner), group=self.group, async_op=True)
+        return None
+
+    def _broadcast_finish(self, work):
+        if work is not None:
+            work.wait()
+            self.ops.sync()
+
     def _all_max(self, value):
         if not (self.active and (self.world > 1 or self.force_collectives)):
             return value
@@ -218,6 +231,7 @@ class ShardedGaussianProcessFit:
             st["img"][c] = ops.empty(((lay.width(c) + NB - 1) // NB) * IMG_DOUBLES)
         st["ldp"] = _round_ld(max(lay.n - lay.block, 1))
         st["buf"] = ops.empty(st["ldp"] * lay.block + lay.n + 8)
+        st["buf2"] = ops.empty(st["ldp"] * lay.block + lay.n + 8)  # look-ahead: panel c + 1 travels while panel c is applied
         st["y"] = ops.empty(lay.n + 8)
         st["z"] = ops.empty(lay.n + 8)
         self._store = st
@@ -248,30 +262,51 @@ class ShardedGaussianProcessFit:
         if self._all_max(nan) > 0:
             raise NanInputError(capi.AGP_ERR_NAN_INPUT, "sharded fit")
 
-        # ---- 2. right-looking LL^T, one panel broadcast per block column ----
+        # ---- 2. right-looking LL^T, one panel broadcast per block column, ONE block column of look-ahead:
+        # as soon as panel c has arrived, the owner of block column c + 1 applies it to THAT column only, factors
+        # panel c + 1 and starts broadcasting it; everybody applies panel c to the rest of their columns while
+        # panel c + 1 travels.  The serial part of a step is one narrow update + one panel phase, the broadcast
+        # overlaps the bulk of the updates.  (AGP_SHARDED_LOOKAHEAD=0: the synchronous schedule.) ----
         y_cur = st["y"]
         y_cur[:n].copy_(ops.from_host(y_host))
         ops.sync()
-        y_off = 0                 # y_cur[y_off + i] belongs to training row start(c) + i
         z_local = st["z"]         # z entries of the owned block columns, at their global index
+        bufs, ldp = [st["buf"], st["buf2"]], st["ldp"]
+        lookahead = os.environ.get("AGP_SHARDED_LOOKAHEAD", "1") != "0"
+
+        def used_of(c):
+            mp_ = lay.rows(c) - lay.width(c)
+            return (ldp * lay.width(c) + mp_ + 2) if mp_ > 0 else 2
+
+        def factor_and_pack(c, log_sum_before):
+            """owner of c: panel phase on the (fully updated) block column, panel + running y + status into its buffer"""
+            s0, w, m = lay.start(c), lay.width(c), lay.rows(c)
+            mp_, buf = m - w, bufs[c % 2]
+            ycol = y_cur[:m]   # y_cur[i] belongs to training row start(c) + i
+            bad, lsum = ops.panel_factor(st["cols"][c], m, st["ld"][c], w, st["img"][c], ycol)
+            ops.sync()
+            z_local[s0:s0 + w].copy_(ycol[:w])
+            if mp_ > 0:
+                ops.pack_panel(st["cols"][c], st["ld"][c], m, w, buf, ldp)
+                buf[ldp * w:ldp * w + mp_].copy_(ycol[w:m])
+            tail = used_of(c) - 2
+            status = np.array([float(s0 + bad) if bad >= 0 else -1., log_sum_before + lsum])
+            buf[tail:tail + 2].copy_(ops.from_host(status))
+
+        def apply_panel(c, c2):
+            """block column c2 (> c) -= panel c"""
+            r0 = lay.start(c2) - (lay.start(c) + lay.width(c))  # first panel row that meets block column c2
+            ops.update(st["cols"][c2], st["ld"][c2], bufs[c % 2], r0, ldp, lay.rows(c2), lay.width(c2), lay.width(c))
+
         log_sum = 0.
-        buf, ldp = st["buf"], st["ldp"]
+        if self.rank == lay.owner(0):
+            factor_and_pack(0, 0.)
+        self._broadcast(bufs[0][:used_of(0)], lay.owner(0))
         for c in range(lay.n_blocks):
-            owner, s0, w, m = lay.owner(c), lay.start(c), lay.width(c), lay.rows(c)
+            w, m = lay.width(c), lay.rows(c)
             mp = m - w  # rows of the sub-diagonal panel
-            used = ldp * w + mp + 2 if mp > 0 else 2
-            tail = used - 2
-            if self.rank == owner:
-                ycol = y_cur[y_off:y_off + m]
-                bad, lsum = ops.panel_factor(st["cols"][c], m, st["ld"][c], w, st["img"][c], ycol)
-                ops.sync()
-                z_local[s0:s0 + w].copy_(ycol[:w])
-                if mp > 0:
-                    ops.pack_panel(st["cols"][c], st["ld"][c], m, w, buf, ldp)
-                    buf[ldp * w:ldp * w + mp].copy_(ycol[w:m])
-                status = np.array([float(s0 + bad) if bad >= 0 else -1., log_sum + lsum])
-                buf[tail:tail + 2].copy_(ops.from_host(status))
-            self._broadcast(buf[:used], owner)
+            buf = bufs[c % 2]
+            tail = used_of(c) - 2
             status = ops.to_host(buf[tail:tail + 2])
             if status[0] >= 0:
                 raise NotPositiveDefiniteError(capi.AGP_ERR_NOT_POSITIVE_DEFINITE, f"sharded fit (pivot {int(status[0])})")
@@ -280,13 +315,25 @@ class ShardedGaussianProcessFit:
                 break
             # the running y travels with the panel: rows start(c + 1) ..
             y_cur[:mp].copy_(buf[ldp * w:ldp * w + mp])
-            y_off = 0
-            for c2 in lay.owned(self.rank):
-                if c2 <= c:
-                    continue
-                r0 = lay.start(c2) - (s0 + w)  # first panel row that meets block column c2
-                ops.update(st["cols"][c2], st["ld"][c2], buf, r0, ldp, lay.rows(c2), lay.width(c2), w)
+            nxt = c + 1
+            mine = [c2 for c2 in lay.owned(self.rank) if c2 > c]
+            work = None
+            if lookahead:
+                if self.rank == lay.owner(nxt):
+                    apply_panel(c, nxt)
+                    ops.sync()
+                    factor_and_pack(nxt, log_sum)
+                    mine = [c2 for c2 in mine if c2 != nxt]
+                work = self._broadcast_start(bufs[nxt % 2][:used_of(nxt)], lay.owner(nxt))
+            for c2 in mine:
+                apply_panel(c, c2)
             ops.sync()
+            if lookahead:
+                self._broadcast_finish(work)
+            else:
+                if self.rank == lay.owner(nxt):
+                    factor_and_pack(nxt, log_sum)
+                self._broadcast(bufs[nxt % 2][:used_of(nxt)], lay.owner(nxt))
 
         # ---- 3. information = L^-T z, right-looking, one small broadcast per block ----
         xbuf = ops.empty(lay.block + 8)

@@ -269,7 +269,7 @@ def main():
             sharded_aux = {"single_fit_ms": 1e3 * float(t.item()) / 3, "fits_per_sec": 3 / float(t.item()),
                            "scaling": "strong",
                            "note": f"one N={n} fit block-column-sharded over {world} GPUs, RCCL panel broadcasts; "
-                                   "synchronous schedule (DESIGN.md section 6)"}
+                                   "one block column of look-ahead (DESIGN.md section 6)"}
         except Exception as exc:  # noqa: BLE001 - reported in the JSON line
             sharded_aux = {"error": f"{type(exc).__name__}: {exc}"}
 
