@@ -70,8 +70,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n,block", [(2, 700, 128), (3, 1000, 256), (2, 512, 512), (4, 300, 128)])
-def test_sharded_fit_over_gloo(world, n, block):
+@pytest.mark.parametrize("world,n,block,lookahead", [(2, 700, 128, "1"), (3, 1000, 256, "1"), (2, 512, 512, "1"),
+                                                     (4, 300, 128, "1"), (3, 700, 128, "0")])
+def test_sharded_fit_over_gloo(world, n, block, lookahead, monkeypatch):
+    # AGP_SHARDED_LOOKAHEAD: "1" = panel c + 1 is factored and broadcast while panel c is applied (default),
+    # "0" = the synchronous schedule; the spawned ranks inherit the environment
+    monkeypatch.setenv("AGP_SHARDED_LOOKAHEAD", lookahead)
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
