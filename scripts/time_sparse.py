@@ -19,7 +19,14 @@ for n, m, gs in ((32768, 1024, 512), (262144, 2048, 512), (262144, 2048, -512)):
         bounds = np.cumsum(sizes)
         gid = np.searchsorted(bounds, np.arange(n), side="right")
         group_of = {float(xi): int(gid[r]) for xi, r in zip(x, rank)}
-    model = ab.sparse_gp_from_covariance(cov, lambda f: group_of[float(f)], ab.FixedInducingPoints(u), "pitc", context=ctx)
+    sorted_x = np.sort(x)
+    if gs > 0:
+        def grouper(f):  # group = rank of the feature // group size; accepts one feature or the whole array
+            return np.searchsorted(sorted_x, np.asarray(f, dtype=np.float64).reshape(-1)) // gs if np.ndim(f) else group_of[float(f)]
+        grouper.vectorized = True
+    else:
+        grouper = lambda f: group_of[float(f)]
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "pitc", context=ctx)
     model.set_param("inducing_nugget", 1e-6)
     ds = ab.RegressionDataset(x, y)
     t = time.perf_counter(); fm = model.fit(ds); t1 = time.perf_counter() - t

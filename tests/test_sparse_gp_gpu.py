@@ -228,3 +228,21 @@ def test_update_matches_oracle_and_chains(ctx, n, m, gs):
     assert np.abs(j.covariance - oj).max() <= 1e-7 * np.abs(oj).max()
     full = model.fit(ds(np.ones(n, dtype=bool))).predict_with_measurement_noise(xs).joint()
     assert np.abs(j.mean - full.mean).max() <= 1e-6 and np.abs(j.covariance - full.covariance).max() <= 1e-6
+
+
+def test_vectorized_grouper_gives_the_same_fit(ctx):
+    """a grouper marked `vectorized` is called once on the whole feature array; same groups, same fit"""
+    rng = np.random.default_rng(4)
+    x = np.sort(rng.uniform(0., 40., 600))
+    y = np.sin(x) + 0.1 * rng.standard_normal(600)
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.measurement_only(ab.IndependentNoise(0.1))
+    u = np.linspace(0., 40., 40)
+    scalar = lambda f: int(float(f) // 5.)
+    def vec(f):
+        return (np.asarray(f, dtype=np.float64).reshape(-1) // 5.).astype(np.int64)
+    vec.vectorized = True
+    fits = []
+    for g in (scalar, vec):
+        m = ab.sparse_gp_from_covariance(cov, g, ab.FixedInducingPoints(u), "pitc", context=ctx)
+        fits.append(m.fit(ab.RegressionDataset(x, y)).get_fit())
+    assert np.array_equal(fits[0].information, fits[1].information) and fits[0].nll == fits[1].nll
