@@ -462,6 +462,48 @@ void agp_fit_destroy(agp_fit *fit) {
   delete fit;
 }
 
+// ---- x = L^-T z for ONE vector ------------------------------------------------------------------------------
+// Wide path (n a multiple of 512, n >= 2048): the 512 x 512 diagonal blocks are inverted explicitly (one batched
+// triangular solve against the identity), after which a step is two column-dot launches per 512 rows instead of
+// four fused launches per 128 rows: the chain is launch-latency-bound (AGP_WIDE_BACKSOLVE=0: off, =<width>: other
+// block width).  Otherwise the 128-row chain on 128 x 128 inverses.  ws: backsolve_ws_elems(n) doubles of scratch.
+static long long backsolve_width(long long n) {
+  static int wide = -1;
+  if (wide < 0) {
+    const char *e = getenv("AGP_WIDE_BACKSOLVE");
+    wide = e ? atoi(e) : 1;
+  }
+  const long long BW = wide > 1 ? wide : 512;
+  return (wide && n >= 4 * BW && n % BW == 0) ? BW : 0;
+}
+
+static size_t backsolve_ws_elems(long long n) {
+  const long long BW = backsolve_width(n);
+  const size_t blocks = BW ? (size_t)(n / BW) * (size_t)BW * (size_t)BW : (size_t)((n + NB - 1) / NB) * NB * NB;
+  return (size_t)round_up(n, 2) + blocks;
+}
+
+static void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                                   double *z, double *ws) {
+  double *xs = ws, *W = ws + round_up(n, 2);
+  const long long BW = backsolve_width(n);
+  if (!BW) {
+    invert_diag_blocks(s, A, n, lda, invd, W);
+    backward_solve_vec(s, A, n, lda, W, z, xs);
+    return;
+  }
+  const long long nb = n / BW;
+  launch_set_identity_batched(s, W, BW, BW * BW, BW, nb);
+  forward_solve_mat_batched(s, A, BW * (lda + 1), BW, lda, invd, (BW / NB) * (long long)(36 * MB * MB), W, BW * BW, BW, BW,
+                            /*rhs_lower=*/true, nb);
+  for (long long b = nb - 1; b >= 0; --b) {
+    const long long k0 = b * BW;
+    launch_colvec_dot(s, W + b * BW * BW, BW, BW, BW, z + k0, 1.0, 0.0, nullptr, xs + k0);  // x_B = inv(L_BB)^T z_B
+    if (k0 > 0) launch_colvec_dot(s, A + k0, lda, BW, k0, xs + k0, -1.0, 1.0, z, z);         // z[0:k0] -= L[B, 0:k0]^T x_B
+  }
+  (void)hipMemcpyAsync(z, xs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+}
+
 namespace {
 struct MixedRequest {
   int max_iterations = 0;
@@ -573,38 +615,11 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
   }
   {
-    // x = L^-T z.  Wide path (n a multiple of 512): the 512 x 512 diagonal blocks are inverted explicitly (one
-    // batched triangular solve against the identity), after which a step is two column-dot launches per 512 rows
-    // instead of four fused launches per 128 rows: the chain is launch-latency-bound (AGP_WIDE_BACKSOLVE=0: off).
-    static int wide = -1;
-    if (wide < 0) {
-      const char *e = getenv("AGP_WIDE_BACKSOLVE");
-      wide = e ? atoi(e) : 1;
-    }
-    const long long BW = wide > 1 ? wide : 512;  // AGP_WIDE_BACKSOLVE=<multiple of 128> selects another width
-    const bool wide_path = wide && n >= 4 * BW && n % BW == 0;
-    // the 128 x 128 inverses serve the 128-row chain (and the refinement steps of the mixed-precision fit)
-    if (!wide_path || mixed) invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);
-    if (wide_path) {
-      const long long nb = n / BW;
-      const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes,
-                                sizeof(double) * ((size_t)round_up(n, 2) + (size_t)nb * BW * BW));
-      if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
-      double *xs = ctx->ws_aux, *R = ctx->ws_aux + round_up(n, 2);
-      launch_set_identity_batched(s, R, BW, BW * BW, BW, nb);
-      forward_solve_mat_batched(s, fit->A, BW * (fit->lda + 1), BW, fit->lda, fit->invd, (BW / NB) * (long long)(36 * MB * MB),
-                                R, BW * BW, BW, BW, /*rhs_lower=*/true, nb);
-      for (long long b = nb - 1; b >= 0; --b) {
-        const long long k0 = b * BW;
-        // x_B[c] = sum_r inv(L_BB)[r][c] z_B[r]
-        launch_colvec_dot(s, R + b * BW * BW, BW, BW, BW, fit->alpha + k0, 1.0, 0.0, nullptr, xs + k0);
-        // z[0 : k0] -= L[k0 : k0 + 512, 0 : k0]^T x_B
-        if (k0 > 0) launch_colvec_dot(s, fit->A + k0, fit->lda, BW, k0, xs + k0, -1.0, 1.0, fit->alpha, fit->alpha);
-      }
-      FIT_CHECK(hipMemcpyAsync(fit->alpha, xs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    } else {
-      backward_solve_vec(s, fit->A, n, fit->lda, fit->winv, fit->alpha, ctx->ws_aux);
-    }
+    const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * backsolve_ws_elems(n));
+    if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
+    backward_solve_vec_any(s, fit->A, n, fit->lda, fit->invd, fit->alpha, ctx->ws_aux);
+    // the refinement steps of the mixed-precision fit use the 128-row chain on fit->winv
+    if (mixed) invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);
   }
   if (mixed) {
     invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
@@ -867,9 +882,25 @@ int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs, int64_t n
   if (nrhs == 0) return AGP_OK;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long n = fit->n, ldb = round_up(n, 2);
+  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  if (nrhs == 1 && n >= 1024) {
+    // one right-hand side: the matrix kernels would run 2 N / 128 launches on a single column; the vector chains
+    // (fused 128-row forward steps, blocked backward substitution) are 4x shorter (N = 16384: 11.3 -> 2.7 ms)
+    const long long nblk = (n + NB - 1) / NB;
+    const size_t wf = (size_t)nblk * NB * NB;
+    int st1 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * ((size_t)ldb + wf + backsolve_ws_elems(n)));
+    if (st1 != AGP_OK) return st1;
+    double *z = ctx->ws_aux, *Wfwd = z + ldb, *ws = Wfwd + wf;
+    hipStream_t s = ctx->stream;
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(z, rhs, sizeof(double) * (size_t)n, kind, s));
+    if (location == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
+    forward_solve_vec(s, fit->A, n, fit->lda, Wfwd, z, ws);  // ws[0 : n] as the staging vector
+    backward_solve_vec_any(s, fit->A, n, fit->lda, fit->invd, z, ws);
+    return copy_out(ctx, z, n, out, location);
+  }
   int st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)ldb * (size_t)nrhs);
   if (st != AGP_OK) return st;
-  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->ws_aux, sizeof(double) * (size_t)ldb, rhs, sizeof(double) * (size_t)n,
                                       sizeof(double) * (size_t)n, (size_t)nrhs, kind, ctx->stream));
   if (location == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
