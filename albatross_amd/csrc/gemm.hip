@@ -590,6 +590,33 @@ __device__ __forceinline__ void store_chunk64(double *__restrict__ Ls, const dou
   dst[1] = NEGATE ? make_double2(-r[2], -r[3]) : make_double2(r[2], r[3]);
 }
 
+// transposed operand storage (element (row, k) at P[k + row * ld]): thread t holds 4 consecutive k of row t >> 2
+__device__ __forceinline__ void load_chunk64_kmajor(const double *__restrict__ P, long long ld, long long row0,
+                                                    long long nrows, long long k0, long long K, bool vec_ok,
+                                                    double (&r)[4]) {
+  const int t = threadIdx.x;
+  const int j = t >> 2, kq = (t & 3) * 4;
+  const long long row = row0 + j, k = k0 + kq;
+  const double *p = P + k + row * ld;
+  if (vec_ok && row < nrows && k + 4 <= K) {
+    const double2 a = *reinterpret_cast<const double2 *>(p);
+    const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+    r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (row < nrows && k + q < K) ? p[q] : 0.;
+  }
+}
+
+template <bool NEGATE>
+__device__ __forceinline__ void store_chunk64_kmajor(double *__restrict__ Ls, const double (&r)[4]) {
+  const int t = threadIdx.x;
+  const int j = t >> 2, kq = (t & 3) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) Ls[(kq + q) * SLD + j] = NEGATE ? -r[q] : r[q];
+}
+
+template <bool B_KMAJOR = false, bool A_KMAJOR = false>
 __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i0, const long long j0, double *lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -604,11 +631,15 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
   // at the end.
   double ra[2][4], rb[2][4];
   const long long nk = (g.K + GK - 1) / GK;
-  load_chunk64(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra[0]);
-  load_chunk64(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb[0]);
+  if (A_KMAJOR) load_chunk64_kmajor(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra[0]);
+  else load_chunk64(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra[0]);
+  if (B_KMAJOR) load_chunk64_kmajor(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb[0]);
+  else load_chunk64(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb[0]);
   if (nk > 1) {
-    load_chunk64(g.A, g.lda, i0, g.M, GK, g.K, a_vec, ra[1]);
-    load_chunk64(g.B, g.ldb, j0, g.N, GK, g.K, b_vec, rb[1]);
+    if (A_KMAJOR) load_chunk64_kmajor(g.A, g.lda, i0, g.M, GK, g.K, a_vec, ra[1]);
+    else load_chunk64(g.A, g.lda, i0, g.M, GK, g.K, a_vec, ra[1]);
+    if (B_KMAJOR) load_chunk64_kmajor(g.B, g.ldb, j0, g.N, GK, g.K, b_vec, rb[1]);
+    else load_chunk64(g.B, g.ldb, j0, g.N, GK, g.K, b_vec, rb[1]);
   }
   v4d acc[2][2];
 #pragma unroll
@@ -622,8 +653,10 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
         acc[tj][ti][r] = (row < g.M && col < g.N) ? g.C[row + col * g.ldc] : 0.;
       }
     }
-  store_chunk64<false>(lds, ra[0]);
-  store_chunk64<true>(lds + GK * SLD, rb[0]);
+  if (A_KMAJOR) store_chunk64_kmajor<false>(lds, ra[0]);
+  else store_chunk64<false>(lds, ra[0]);
+  if (B_KMAJOR) store_chunk64_kmajor<true>(lds + GK * SLD, rb[0]);
+  else store_chunk64<true>(lds + GK * SLD, rb[0]);
   __syncthreads();
   for (long long kc = 0; kc < nk; kc += 2) {
     // two chunks per trip so that the register stages are compile-time indices
@@ -634,8 +667,10 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
       const double *As = lds + half * (2 * GK * SLD);
       const double *Bs = As + GK * SLD;
       if (k + 2 < nk) {  // stage `half` was stored to LDS one trip ago: refill it with chunk k + 2
-        load_chunk64(g.A, g.lda, i0, g.M, (k + 2) * GK, g.K, a_vec, ra[half]);
-        load_chunk64(g.B, g.ldb, j0, g.N, (k + 2) * GK, g.K, b_vec, rb[half]);
+        if (A_KMAJOR) load_chunk64_kmajor(g.A, g.lda, i0, g.M, (k + 2) * GK, g.K, a_vec, ra[half]);
+        else load_chunk64(g.A, g.lda, i0, g.M, (k + 2) * GK, g.K, a_vec, ra[half]);
+        if (B_KMAJOR) load_chunk64_kmajor(g.B, g.ldb, j0, g.N, (k + 2) * GK, g.K, b_vec, rb[half]);
+        else load_chunk64(g.B, g.ldb, j0, g.N, (k + 2) * GK, g.K, b_vec, rb[half]);
       }
 #pragma unroll
       for (int s = 0; s < GK / 4; ++s) {
@@ -653,8 +688,10 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
       }
       if (k + 1 < nk) {  // chunk k + 1 (register stage half ^ 1, loaded a trip ago) -> the other LDS buffer
         double *An = lds + (half ^ 1) * (2 * GK * SLD);
-        store_chunk64<false>(An, ra[half ^ 1]);
-        store_chunk64<true>(An + GK * SLD, rb[half ^ 1]);
+        if (A_KMAJOR) store_chunk64_kmajor<false>(An, ra[half ^ 1]);
+        else store_chunk64<false>(An, ra[half ^ 1]);
+        if (B_KMAJOR) store_chunk64_kmajor<true>(An + GK * SLD, rb[half ^ 1]);
+        else store_chunk64<true>(An + GK * SLD, rb[half ^ 1]);
       }
       __syncthreads();
     }
@@ -690,6 +727,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs
   }
   const int bi = (g.tri ? bj : 0) + (int)id;
   gemm64_body(g, (long long)bi * ST, (long long)bj * ST, lds);
+}
+
+// 64 x 64 tiles with a TRANSPOSED second operand (B(j, k) at B[k + j * ldb]): the updates of the multi-RHS
+// substitutions with few right-hand sides, where a 128 x 128 tile would be mostly padding.  Not triangular.
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_bk_kernel(GemmArgs g) {
+  __builtin_amdgcn_s_setprio(3);
+  g.C += (long long)blockIdx.y * g.batch_C;
+  g.A += (long long)blockIdx.y * g.batch_A;
+  g.B += (long long)blockIdx.y * g.batch_B;
+  __shared__ double lds[2 * 2 * GK * SLD];
+  const long long id = blockIdx.x;
+  const int bj = (int)(id / g.ntr), bi = (int)(id % g.ntr);
+  if (g.remap) gemm64_body<true, true>(g, (long long)bi * ST, (long long)bj * ST, lds);  // remap = 1: A transposed too
+  else gemm64_body<true, false>(g, (long long)bi * ST, (long long)bj * ST, lds);
 }
 
 // The LAST tiles of a bulk update (those that would form a partial round of 128 x 128 workgroups) as
@@ -739,6 +790,16 @@ void launch_gemm_nt_sub_batched(hipStream_t s, double *C, long long ldc, long lo
   if (small_limit < 0) {
     const char *e = getenv("AGP_SMALL_TILE_LIMIT");
     small_limit = e ? atoi(e) : 512;
+  }
+  if (b_kmajor && !tri && N <= 64 && tiles * count < small_limit) {
+    // skinny second dimension (few right-hand sides): 64 x 64 tiles with the transposed-operand loader(s)
+    GemmArgs h = g;
+    h.remap = a_kmajor ? 1 : 0;  // (the XCD remap field is unused by this kernel: it selects the A loader)
+    h.ntr = (int)((M + ST - 1) / ST);
+    h.ntc = (int)((N + ST - 1) / ST);
+    hipLaunchKernelGGL(gemm64_nt_sub_bk_kernel, dim3((unsigned)((long long)h.ntr * h.ntc), (unsigned)count), dim3(GEMM_THREADS), 0, s,
+                       h);
+    return;
   }
   if (!a_kmajor && !b_kmajor && tiles * count < small_limit) {
     GemmArgs h = g;

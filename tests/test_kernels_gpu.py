@@ -55,6 +55,9 @@ def test_mfma_peak_is_sane(ctx):
     (140, 90, 50, 0, 1, 1), (300, 64, 128, 0, 1, 0), (130, 130, 1000, 1, 1, 1),
     # >= 512 tiles of 128 x 128: the large-tile kernel (smaller launches use 64 x 64 tiles)
     (4500, 4500, 48, 1, 0, 0), (3000, 2900, 40, 0, 0, 0), (70, 70, 300, 1, 0, 0),
+    # skinny second dimension with a transposed second operand: the 64 x 64-tile kernel with the k-major loader
+    (300, 8, 128, 0, 0, 1), (1000, 64, 512, 0, 0, 1), (130, 1, 70, 0, 0, 1), (4000, 33, 128, 0, 0, 1), (64, 64, 16, 0, 0, 1),
+    (300, 8, 128, 0, 1, 1), (1000, 64, 512, 0, 1, 1), (131, 3, 70, 0, 1, 1), (4000, 33, 130, 0, 1, 1),
 ])
 def test_gemm_nt_sub(ctx, dbg, M, N, K, tri, akm, bkm):
     rng = np.random.default_rng(M * 7 + N * 3 + K)
