@@ -791,8 +791,10 @@ void launch_gemm_nt_sub_batched(hipStream_t s, double *C, long long ldc, long lo
     const char *e = getenv("AGP_SMALL_TILE_LIMIT");
     small_limit = e ? atoi(e) : 512;
   }
-  if (b_kmajor && !tri && N <= 64 && tiles * count < small_limit) {
-    // skinny second dimension (few right-hand sides): 64 x 64 tiles with the transposed-operand loader(s)
+  if (b_kmajor && !tri && tiles * count < small_limit) {
+    // launches that cannot fill the chip with 128 x 128 tiles (few right-hand sides, or the inner updates of a
+    // substitution with few rows): 64 x 64 tiles with the transposed-operand loader(s).  N = 16384, predict
+    // marginal: M = 64: 10.5 -> 5.0 ms, M = 1024: 12.3 -> 8.9 ms, M = 4096: 25.8 -> 24.8 ms.
     GemmArgs h = g;
     h.remap = a_kmajor ? 1 : 0;  // (the XCD remap field is unused by this kernel: it selects the A loader)
     h.ntr = (int)((M + ST - 1) / ST);

@@ -8,7 +8,7 @@ ctx = ab.Context(0)
 for n in (4096, 16384):
     x, y = synthetic_3d(n, 1)
     fm = ab.gp_from_covariance(ab.SquaredExponential(1., 1.) + ab.IndependentNoise(0.1), context=ctx).fit(ab.RegressionDataset(x, y))
-    for m in (1, 8, 64, 512):
+    for m in (1, 8, 64, 512, 1024, 2048, 4096):
         xs, _ = synthetic_3d(m, 2)
         fm.predict(xs).marginal()
         t0 = time.perf_counter()
