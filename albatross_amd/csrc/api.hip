@@ -1096,7 +1096,23 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
   // cross_cov = cov(train_features, features)   (gp.hpp:316,337)
   launch_gram(s, dprog, fit->train.v, dxs.v, false, false, V, ldv, nullptr, nullptr, &k->prog);
   // V = L^-1 K*  ;  explained = V^T V  (== K*^T K^-1 K*, gp.hpp:96,111)
-  forward_solve_mat_lookahead(ctx, fit->A, n, fit->lda, fit->invd, V, m, ldv);
+  if (m == 1 && n >= 1024) {
+    // a single test point: the vector chain (one fused launch per 128 rows) instead of the matrix kernels
+    const long long nblk = (n + NB - 1) / NB;
+    double *Wfwd = nullptr, *stage = nullptr;
+    if (hipMalloc(&Wfwd, sizeof(double) * ((size_t)nblk * NB * NB + (size_t)round_up(n, 2))) != hipSuccess) {
+      dxs.release();
+      ctx->last_error = "hipMalloc (single-point prediction workspace)";
+      return AGP_ERR_HIP;
+    }
+    stage = Wfwd + (size_t)nblk * NB * NB;
+    invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
+    forward_solve_vec(s, fit->A, n, fit->lda, Wfwd, V, stage);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(Wfwd);
+  } else {
+    forward_solve_mat_lookahead(ctx, fit->A, n, fit->lda, fit->invd, V, m, ldv);
+  }
   if (!joint) {
     launch_gram_diagonal(s, dprog, dxs.v, prior);                   // gp.hpp:339-343
     launch_coldot(s, V, ldv, V, ldv, n, m, prior, 1.0, prior);      // gp.hpp:97-99

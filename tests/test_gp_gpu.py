@@ -326,3 +326,18 @@ def test_ill_conditioned_fit_wide_backward_path(ctx, n):
     assert np.abs(K @ a - y).max() <= 1e-9 * np.abs(K).sum(axis=1).max() * np.abs(a).max()
     ofit = orc.OracleFit(cov, ab.FeatureSet(x), y, use_llt=True)
     assert rel(a, ofit.information) <= 1e-6   # cond(K) * eps ~ 1e-8 for either path
+
+
+def test_single_point_prediction_uses_the_vector_chain(ctx):
+    """M = 1 and N >= 1024: the forward substitution runs as one fused launch per 128 rows (agp_predict_*)"""
+    n = 1500
+    x, y = synthetic_3d(n, 17)
+    cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+    fm = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
+    ofit = orc.OracleFit(cov, ab.FeatureSet(x), y)
+    xs = np.array([[3.3, 4.4, 5.5]])
+    om, ov = ofit.predict_marginal(ab.FeatureSet(xs))
+    pm = fm.predict(xs).marginal()
+    pj = fm.predict(xs).joint()
+    assert abs(pm.mean[0] - om[0]) <= 1e-8 * abs(om[0]) and abs(pm.covariance[0] - ov[0]) <= 1e-8 * abs(ov[0])
+    assert abs(pj.covariance[0, 0] - ov[0]) <= 1e-8 * abs(ov[0])
