@@ -81,15 +81,26 @@ class Context:
         nodes = cov.program_nodes()
         arr = nodes_to_array(nodes)
         key = bytes(arr)
-        kh = self._kernels.get(key)
+        kh = self._kernels.pop(key, None)
         if kh is None:
             kh = C.c_void_p()
             self._check(self._lib.agp_kernel_create(arr, len(nodes), C.byref(kh)), "agp_kernel_create")
-            if len(self._kernels) > 64:
-                for old in self._kernels.values():
-                    self._lib.agp_kernel_destroy(old)
-                self._kernels = {}
-            self._kernels[key] = kh
+            # least-recently-used eviction, ONE entry at a time: a handle returned by this method stays valid for
+            # the next KERNEL_CACHE - 1 calls at least (callers that collect more handles than that before using
+            # them make private ones, see private_kernel)
+            while len(self._kernels) >= self.KERNEL_CACHE:
+                oldest = next(iter(self._kernels))
+                self._lib.agp_kernel_destroy(self._kernels.pop(oldest))
+        self._kernels[key] = kh  # (re-)inserted last = most recently used
+        return kh
+
+    KERNEL_CACHE = 64
+
+    def private_kernel(self, cov):
+        """an agp_kernel the CALLER owns (agp_kernel_destroy when done): outside the cache, never evicted"""
+        nodes = cov.program_nodes()
+        kh = C.c_void_p()
+        self._check(self._lib.agp_kernel_create(nodes_to_array(nodes), len(nodes), C.byref(kh)), "agp_kernel_create")
         return kh
 
     def synchronize(self):
@@ -191,17 +202,35 @@ class RegressionDataset:
         return self.targets.size()
 
 
-class ZeroMean:
-    """mean_function.hpp:274-276"""
+class MeanFunction:
+    """MeanFunction<Derived> (covariance_functions/mean_function.hpp:18-134): `m(coords)` is the mean vector
+    (operator()(std::vector<X>), :73-84); `+` / `*` compose (:136-271).  `nodes()` is the function flattened to
+    postfix tuples ("zero",) / ("linear", slope, offset) / ("sum",) / ("product",), like get_name() a description."""
 
     def get_params(self):
         return {}
 
+    def set_param(self, name, value):
+        raise KeyError(name)
+
+    def __add__(self, other):
+        return SumOfMeanFunctions(self, other)
+
+    def __mul__(self, other):
+        return ProductOfMeanFunctions(self, other)
+
+
+class ZeroMean(MeanFunction):
+    """mean_function.hpp:274-276"""
+
     def __call__(self, coords):
         return np.zeros(len(coords))
 
+    def nodes(self):
+        return [("zero",)]
 
-class LinearMean:
+
+class LinearMean(MeanFunction):
     """slope * x + offset on 1-D features (polynomials.hpp:92-106)."""
 
     def __init__(self, slope=0., offset=0.):
@@ -211,11 +240,59 @@ class LinearMean:
         return dict(self._params)
 
     def set_param(self, name, value):
+        if name not in self._params:
+            raise KeyError(name)
         self._params[name] = float(value)
 
     def __call__(self, coords):
         x = np.asarray(coords, dtype=np.float64).reshape(len(coords), -1)[:, 0]
         return self._params["slope"] * x + self._params["offset"]
+
+    def nodes(self):
+        return [("linear", self._params["slope"], self._params["offset"])]
+
+
+class _BinaryMean(MeanFunction):
+    def __init__(self, lhs, rhs):
+        self.lhs_, self.rhs_ = lhs, rhs
+
+    def get_params(self):  # map_join(lhs_.get_params(), rhs_.get_params())
+        out = dict(self.lhs_.get_params())
+        out.update(self.rhs_.get_params())
+        return out
+
+    def set_param(self, name, value):  # set_param_if_exists_in_any
+        done = False
+        for side in (self.lhs_, self.rhs_):
+            if name in side.get_params():
+                side.set_param(name, value)
+                done = True
+        if not done:
+            raise KeyError(name)
+
+
+class SumOfMeanFunctions(_BinaryMean):
+    """mean_function.hpp:136-190"""
+
+    def __call__(self, coords):
+        return self.lhs_(coords) + self.rhs_(coords)
+
+    def nodes(self):
+        return self.lhs_.nodes() + self.rhs_.nodes() + [("sum",)]
+
+
+class ProductOfMeanFunctions(_BinaryMean):
+    """mean_function.hpp:192-260: lhs * rhs with rhs skipped where lhs == 0 (:221-227)"""
+
+    def __call__(self, coords):
+        out = np.array(self.lhs_(coords), dtype=np.float64)
+        nz = out != 0.
+        if nz.any():
+            out[nz] *= np.asarray(self.rhs_(coords), dtype=np.float64)[nz]
+        return out
+
+    def nodes(self):
+        return self.lhs_.nodes() + self.rhs_.nodes() + [("product",)]
 
 
 def _values_of(features):
@@ -830,28 +907,36 @@ class GaussianProcessRegression:
             ys.append(y)
         n = fsets[0].n
         Y = np.asfortranarray(np.stack(ys, axis=1))
-        kernels = (C.c_void_p * count)(*[ctx.kernel(m.covariance_function_) for m in models])
-        fptrs = (C.c_void_p * count)(*[C.addressof(st) for st in structs])
-        out = np.empty(count)
-        ctx._check(ctx._lib.agp_nll_batch(ctx._h, count, kernels, fptrs, _ptr(Y), n, _ptr(yv), _ptr(out)),
-                   "agp_nll_batch")
+        # private handles for the duration of the call: the context's cache may evict while the batch is assembled
+        handles = []
+        try:
+            for m in models:
+                handles.append(ctx.private_kernel(m.covariance_function_))
+            kernels = (C.c_void_p * count)(*handles)
+            fptrs = (C.c_void_p * count)(*[C.addressof(st) for st in structs])
+            out = np.empty(count)
+            # log_likelihood ignores the target variance (gp.hpp:442-451): y_var = NULL
+            ctx._check(ctx._lib.agp_nll_batch(ctx._h, count, kernels, fptrs, _ptr(Y), n, None, _ptr(out)),
+                       "agp_nll_batch")
+        finally:
+            for kh in handles:
+                ctx._lib.agp_kernel_destroy(kh)
         return -out
 
     def log_likelihood(self, dataset):
-        """gp.hpp:442-451 (without priors: the parameter-prior subsystem is out of scope)."""
+        """gp.hpp:442-451 (without priors: the parameter-prior subsystem is out of scope).  Like the reference, the
+        covariance is covariance_function_(measurement_features) ALONE: dataset.targets.covariance is not added."""
         ctx = self._ctx()
         if has_linear_combinations(dataset.features):
             feats = _values_of(dataset.features)
             K = ctx.gram(self.covariance_function_, Measurement(feats))
-            if dataset.targets.covariance is not None:
-                K[np.diag_indices_from(K)] += np.asarray(dataset.targets.covariance, dtype=np.float64)
             dev = dataset.targets.mean - _mean_at(self.mean_function_, self.covariance_function_, feats)
             return -negative_log_likelihood(dev, K, ctx)
         fs = self.covariance_function_.features(_values_of(dataset.features))
-        y, yv = self._targets(fs, dataset.targets)
+        y, _ = self._targets(fs, dataset.targets)
         s = fs.as_struct()
         out = C.c_double()
-        ctx._check(ctx._lib.agp_nll(ctx._h, ctx.kernel(self.covariance_function_), C.byref(s), _ptr(y), _ptr(yv),
+        ctx._check(ctx._lib.agp_nll(ctx._h, ctx.kernel(self.covariance_function_), C.byref(s), _ptr(y), None,
                                     C.byref(out)), "agp_nll")
         return -out.value
 

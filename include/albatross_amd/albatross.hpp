@@ -1416,14 +1416,16 @@ class GaussianProcessRegression {
       }
     }
     for (std::size_t b = 0; b < count; ++b) fptr[b] = &flats[b].view;  // after the vector stopped moving
+    // like log_likelihood below: the target variance is NOT part of the covariance (gp.hpp:442-451)
     detail::check(agp_nll_batch(ctx->ctx, static_cast<int>(count), kptr.data(), fptr.data(), Y.data(), static_cast<std::int64_t>(n),
-                                dataset.targets.covariance.empty() ? nullptr : dataset.targets.covariance.data(), out.data()),
+                                nullptr, out.data()),
                   ctx->ctx, "agp_nll_batch");
     for (double &v : out) v = -v;
     return out;
   }
 
-  // gp.hpp:442-451 (prior_log_likelihood() is outside the hot path and not included)
+  // gp.hpp:442-451 (prior_log_likelihood() is outside the hot path and not included).  As in the reference the
+  // covariance is covariance_function_(measurement_features) alone: dataset.targets.covariance is NOT added.
   template <typename FeatureType>
   double log_likelihood(const RegressionDataset<FeatureType> &dataset) const {
     auto ctx = detail::default_context();
@@ -1434,9 +1436,7 @@ class GaussianProcessRegression {
       for (std::size_t i = 0; i < y.size(); ++i)
         y[i] -= mean_function_._call_impl(detail::unwrap<FeatureType>::get(dataset.features[i]));
     double nll = 0.;
-    detail::check(agp_nll(ctx->ctx, k.k, &f.view, y.data(),
-                          dataset.targets.covariance.empty() ? nullptr : dataset.targets.covariance.data(), &nll),
-                  ctx->ctx, "agp_nll");
+    detail::check(agp_nll(ctx->ctx, k.k, &f.view, y.data(), nullptr, &nll), ctx->ctx, "agp_nll");
     return -nll;
   }
 

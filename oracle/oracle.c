@@ -622,20 +622,75 @@ ORC_API double orc_nll_dense(const double *dev, const double *cov, int64_t n,
   return 0.5 * (log_det + maha + (double)n * log(2 * M_PI));
 }
 
-/* -log_likelihood without the prior term: gp.hpp:442-451 */
-ORC_API double orc_nll(const agp_kernel_node *prog, int n_nodes,
-                       const agp_features *x, const double *y,
-                       const double *y_var) {
+/* negative_log_likelihood(y, k(x, x) + diag(y_var)) with the features wrapped
+ * as measurements; y_var may be NULL.  NOT a reference entry point by itself:
+ * the checker of the C-ABI's agp_nll, which takes an optional variance. */
+ORC_API double orc_nll_with_variance(const agp_kernel_node *prog, int n_nodes,
+                                     const agp_features *x, const double *y,
+                                     const double *y_var) {
   const int64_t n = x->n;
   agp_features meas = *x;
-  meas.is_measurement = 1;
+  meas.is_measurement = 1; /* as_measurements(dataset.features), gp.hpp:445 */
   double *K = malloc(sizeof(double) * (size_t)(n * n));
-  orc_gram_sym(prog, n_nodes, &meas, K, n);
+  orc_gram_sym(prog, n_nodes, &meas, K, n); /* gp.hpp:447 */
   if (y_var)
     for (int64_t i = 0; i < n; ++i) K[i + i * n] += y_var[i];
-  const double out = orc_nll_dense(y, K, n, n);
+  const double out = orc_nll_dense(y, K, n, n); /* gp.hpp:448 */
   free(K);
   return out;
+}
+
+/* -log_likelihood without the prior term: GaussianProcessBase::log_likelihood,
+ * gp.hpp:442-451.  y = targets.mean with the mean function already removed
+ * (:446).  The covariance is covariance_function_(measurement_features) ALONE:
+ * the reference does not add dataset.targets.covariance here. */
+ORC_API double orc_nll(const agp_kernel_node *prog, int n_nodes,
+                       const agp_features *x, const double *y) {
+  return orc_nll_with_variance(prog, n_nodes, x, y, NULL);
+}
+
+/* ---------------------------------------------------------------------- */
+/* mean functions: covariance_functions/mean_function.hpp,                 */
+/* LinearMean polynomials.hpp:92-106                                       */
+/* ---------------------------------------------------------------------- */
+/* A mean function flattened to a postfix program like the covariance
+ * functions: op 0 = ZeroMean (mean_function.hpp:274-276), 1 = LinearMean
+ * {slope, offset} on the first coordinate (polynomials.hpp:103-105),
+ * 2 = constant {value} (a user mean function with _call_impl = value),
+ * 10 = SumOfMeanFunctions (:150-155), 11 = ProductOfMeanFunctions with the
+ * `output != 0` short circuit (:221-227). */
+typedef struct { int32_t op; int32_t pad; double params[2]; } orc_mean_node;
+
+static double mean_eval(const orc_mean_node *prog, int n_nodes, const double *x) {
+  double stack[16];
+  int sp = 0;
+  for (int t = 0; t < n_nodes; ++t) {
+    const orc_mean_node *nd = &prog[t];
+    switch (nd->op) {
+    case 0: stack[sp++] = 0.; break;                                        /* :275 */
+    case 1: stack[sp++] = nd->params[0] * x[0] + nd->params[1]; break;      /* polynomials.hpp:104 */
+    case 2: stack[sp++] = nd->params[0]; break;
+    case 10: { const double r = stack[--sp]; stack[sp - 1] = stack[sp - 1] + r; break; } /* :154 */
+    case 11: { const double r = stack[--sp]; double o = stack[sp - 1];      /* :222-226 */
+               if (o != 0.) o *= r;
+               stack[sp - 1] = o; break; }
+    default: return NAN;
+    }
+  }
+  return stack[0];
+}
+
+/* MeanFunction::operator()(std::vector<X>) -> compute_mean_vector, mean_function.hpp:73-84
+ * (Measurement<X> features are unwrapped by DefaultCaller, callers.hpp) */
+ORC_API void orc_mean_vector(const orc_mean_node *prog, int n_nodes, const agp_features *x, double *out) {
+  for (int64_t i = 0; i < x->n; ++i) out[i] = mean_eval(prog, n_nodes, x->coords + i * x->dim);
+}
+
+/* remove_from (:98-107) / add_to (:86-95): target -= / += mean(features); sign = -1 / +1.
+ * A pure ZeroMean program returns without touching the target (:90-92, :101-103). */
+ORC_API void orc_mean_apply(const orc_mean_node *prog, int n_nodes, const agp_features *x, double sign, double *target) {
+  if (n_nodes == 1 && prog[0].op == 0) return;
+  for (int64_t i = 0; i < x->n; ++i) target[i] += sign * mean_eval(prog, n_nodes, x->coords + i * x->dim);
 }
 
 /* gp.hpp:350-366 + 82-85 */

@@ -72,7 +72,13 @@ def lib():
         L.orc_nll_dense.restype = C.c_double
         L.orc_nll_dense.argtypes = [V, V, I64, I64]
         L.orc_nll.restype = C.c_double
-        L.orc_nll.argtypes = [PN, C.c_int, PF, V, V]
+        L.orc_nll.argtypes = [PN, C.c_int, PF, V]
+        L.orc_nll_with_variance.restype = C.c_double
+        L.orc_nll_with_variance.argtypes = [PN, C.c_int, PF, V, V]
+        L.orc_mean_vector.restype = None
+        L.orc_mean_vector.argtypes = [V, C.c_int, PF, V]
+        L.orc_mean_apply.restype = None
+        L.orc_mean_apply.argtypes = [V, C.c_int, PF, C.c_double, V]
         L.orc_predict_mean.argtypes = [V, PN, C.c_int, PF, V]
         L.orc_predict_marginal.argtypes = [V, PN, C.c_int, PF, V, V]
         L.orc_predict_joint.argtypes = [V, PN, C.c_int, PF, V, V]
@@ -170,11 +176,17 @@ def nll_dense(dev, cov):
 class OracleFit:
     """Fit<GPFit<SerializableLDLT, F>> restated on the CPU (gp.hpp:43-77)."""
 
-    def __init__(self, cov, x, y, y_var=None, threads=0, use_llt=False):
+    def __init__(self, cov, x, y, y_var=None, threads=0, use_llt=False, mean=None):
+        """mean: a mean function (object with nodes() or a postfix node list, see mean_program): removed from
+        the targets before the fit (_fit_impl, gp.hpp:291-292) and added back to every predicted mean
+        (_predict_impl, gp.hpp:322,346,364)."""
         self.cov = cov
+        self.mean = mean
         self._p, self._n = _prog(cov)
         fx, self._keep = _feat(cov, x, False)
         y = np.ascontiguousarray(y, dtype=np.float64)
+        if mean is not None:
+            y = remove_mean(mean, cov, x, y)
         yv = None if y_var is None else np.ascontiguousarray(y_var, dtype=np.float64)
         st = C.c_int(0)
         self.h = lib().orc_fit_create(self._p, self._n, C.byref(fx), _ptr(y), _ptr(yv), threads,
@@ -260,29 +272,88 @@ class OracleFit:
         f, keep = _feat(self.cov, xs, xs_meas)
         mean = np.zeros(f.n)
         lib().orc_predict_mean(self.h, self._p, self._n, C.byref(f), _ptr(mean))
-        return mean
+        return self._add_mean(xs, mean)
 
     def predict_marginal(self, xs, xs_meas=False):
         f, keep = _feat(self.cov, xs, xs_meas)
         mean = np.zeros(f.n)
         var = np.zeros(f.n)
         lib().orc_predict_marginal(self.h, self._p, self._n, C.byref(f), _ptr(mean), _ptr(var))
-        return mean, var
+        return self._add_mean(xs, mean), var
 
     def predict_joint(self, xs, xs_meas=False):
         f, keep = _feat(self.cov, xs, xs_meas)
         mean = np.zeros(f.n)
         cov = np.zeros((f.n, f.n), order="F")
         lib().orc_predict_joint(self.h, self._p, self._n, C.byref(f), _ptr(mean), _ptr(cov))
-        return mean, cov
+        return self._add_mean(xs, mean), cov
+
+    def _add_mean(self, xs, mean):
+        return mean if self.mean is None else add_mean(self.mean, self.cov, xs, mean)
 
 
-def nll(cov, x, y, y_var=None):
+def nll(cov, x, y, mean=None):
+    """-GaussianProcessBase::log_likelihood(dataset) without priors (gp.hpp:442-451): the mean function is
+    removed from y, the covariance is covariance_function_(as_measurements(x)) alone (no target variance)."""
+    p, n = _prog(cov)
+    fx, keep = _feat(cov, x, False)
+    y = np.array(y, dtype=np.float64)
+    if mean is not None:
+        y = remove_mean(mean, cov, x, y)
+    return lib().orc_nll(p, n, C.byref(fx), _ptr(y))
+
+
+def nll_with_variance(cov, x, y, y_var):
+    """negative_log_likelihood(y, k(x, x) + diag(y_var)) on measurement-wrapped features: the checker of the
+    C-ABI's agp_nll when a variance is passed (no reference entry point adds it)."""
     p, n = _prog(cov)
     fx, keep = _feat(cov, x, False)
     y = np.ascontiguousarray(y, dtype=np.float64)
     yv = None if y_var is None else np.ascontiguousarray(y_var, dtype=np.float64)
-    return lib().orc_nll(p, n, C.byref(fx), _ptr(y), _ptr(yv))
+    return lib().orc_nll_with_variance(p, n, C.byref(fx), _ptr(y), _ptr(yv))
+
+
+# ---- mean functions (mean_function.hpp; LinearMean polynomials.hpp:92-106) ----
+_MEAN_NODE = np.dtype([("op", np.int32), ("pad", np.int32), ("params", np.float64, 2)])
+
+
+def mean_program(nodes):
+    """nodes: postfix list of ("zero",) | ("linear", slope, offset) | ("constant", v) | ("sum",) | ("product",)"""
+    ops = {"zero": 0, "linear": 1, "constant": 2, "sum": 10, "product": 11}
+    arr = np.zeros(len(nodes), dtype=_MEAN_NODE)
+    for i, nd in enumerate(nodes):
+        arr[i]["op"] = ops[nd[0]]
+        for j, v in enumerate(nd[1:]):
+            arr[i]["params"][j] = float(v)
+    return arr
+
+
+def _mean_nodes(mean):
+    return mean if isinstance(mean, (list, tuple)) and mean and isinstance(mean[0], tuple) else mean.nodes()
+
+
+def mean_vector(mean, cov, x):
+    arr = mean_program(_mean_nodes(mean))
+    fx, keep = _feat(cov, x, False)
+    out = np.zeros(fx.n)
+    lib().orc_mean_vector(_ptr(arr), len(arr), C.byref(fx), _ptr(out))
+    return out
+
+
+def remove_mean(mean, cov, x, y):
+    arr = mean_program(_mean_nodes(mean))
+    fx, keep = _feat(cov, x, False)
+    out = np.array(y, dtype=np.float64)
+    lib().orc_mean_apply(_ptr(arr), len(arr), C.byref(fx), -1.0, _ptr(out))
+    return out
+
+
+def add_mean(mean, cov, x, y):
+    arr = mean_program(_mean_nodes(mean))
+    fx, keep = _feat(cov, x, False)
+    out = np.array(y, dtype=np.float64)
+    lib().orc_mean_apply(_ptr(arr), len(arr), C.byref(fx), 1.0, _ptr(out))
+    return out
 
 
 class OracleSparseFit:

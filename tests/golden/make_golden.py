@@ -17,6 +17,7 @@ implementation independent of both the oracle and the HIP library:
   distances.json                distance-metric known values
         /root/reference/tests/test_distance_metrics.cc:20-75
   toy_linear.json               make_toy_linear_data() + make_simple_covariance_function()
+  toy_linear_mean.json          the same data under GPs with a LinearMean (test_models.h:75-96, test_gp.cc:344-371)
         tests/lib/albatross/test/test_utils.h:42-60, test_models.h:26-30,
         test_models.cc:134-148, tests/test_gp.cc:464-490
   bench512.json                 benchmarks/bench_utils.h:25-85 (N=512 1-D)
@@ -170,6 +171,33 @@ def toy_fixture(rows):
     dump("toy_linear.json", out)
 
 
+def toy_mean_fixture(rows):
+    """The same toy data under a GP WITH a mean function: MakeGaussianProcessWithMean
+    (tests/lib/albatross/test/test_models.h:75-96: simple covariance + LinearMean{offset 5, slope 1}) and the model of
+    tests/test_gp.cc:344-371 (SE(2, 1) + measurement_only(IndependentNoise(0.1)) + the same LinearMean, predicted at
+    {1.3, 4.2, 7.1}).  Expected values: numpy/scipy on y - m(x) (remove_from, gp.hpp:291-292) with m(x*) added to the
+    predicted mean (add_to, gp.hpp:322,346,364); log-likelihood of the mean-removed targets (gp.hpp:442-451)."""
+    y = rows["toy"]
+    x = np.arange(10, dtype=float)
+    a, b = 5., 1.  # offset, slope
+    models = []
+    for (ell, sigma, xs_list) in ((100., 100., ([0.1, 1.1, 2.2], [-20., 0.01])), (2., 1., ([1.3, 4.2, 7.1], [-3., 12.5]))):
+        K = se(x, x, ell, sigma) + 0.01 * np.eye(10)
+        z = y - (b * x + a)
+        preds = []
+        for xs in xs_list:
+            xs = np.array(xs)
+            alpha, logdet, mean, cov, nll = gp_expected(K, se(x, xs, ell, sigma), se(xs, xs, ell, sigma), z)
+            preds.append({"xs": xs.tolist(), "mean": (mean + b * xs + a).tolist(), "cov": cov.tolist()})
+        models.append({"cov": {"squared_exponential_length_scale": ell, "sigma_squared_exponential": sigma,
+                               "sigma_independent_noise": 0.1},
+                       "information": alpha.tolist(), "log_det": float(logdet), "nll": float(nll), "predictions": preds,
+                       "tolerance_rel": 1e-7 if ell == 100. else 1e-10})
+    dump("toy_linear_mean.json", {
+        "source": "test_utils.h:42-60 make_toy_linear_data(5, 1); test_models.h:75-96; tests/test_gp.cc:344-371",
+        "x": x.tolist(), "y": y.tolist(), "mean": {"offset": a, "slope": b}, "models": models})
+
+
 def bench_fixture(rows):
     x = rows["bench"]
     y = np.sin(x) + 0.1 * np.cos(10. * x)
@@ -205,5 +233,6 @@ if __name__ == "__main__":
     edges_fixture()
     rows = run_cxx()
     toy_fixture(rows)
+    toy_mean_fixture(rows)
     bench_fixture(rows)
     algebra_fixture()

@@ -67,7 +67,7 @@ def test_device_resident_fit_and_predict_match_host_path(ctx):
     # NLL with device inputs
     nll = C.c_double()
     assert lib.agp_nll(ctx._h, kh, C.byref(fx), C.c_void_p(yd.data_ptr()), C.c_void_p(vd.data_ptr()), C.byref(nll)) == 0
-    assert abs(nll.value - orc.nll(cov, x, y, yvar)) <= 1e-6 * n
+    assert abs(nll.value - orc.nll_with_variance(cov, x, y, yvar)) <= 1e-6 * n
     # Gram into a device buffer with a padded leading dimension
     ld = n + 6
     Kd = torch.full((ld * m,), float("nan"), dtype=torch.float64, device="cuda")

@@ -85,7 +85,7 @@ def test_fit_predict_matches_oracle(ctx, label, make, dim, n, m):
     ofit = orc.OracleFit(cov, x, y, yvar)  # pivoted LDL^T, as the reference
     assert rel(fm.get_fit().information, ofit.information) <= 1e-8
     assert abs(fm.get_fit().log_determinant - ofit.log_determinant) <= 1e-6 * n
-    assert abs(-model.log_likelihood(ds) - orc.nll(cov, x, y, yvar)) <= 1e-6 * n
+    assert abs(-model.log_likelihood(ds) - orc.nll(cov, x, y)) <= 1e-6 * n  # no target variance: gp.hpp:442-451
     pred = fm.predict(xs)
     om, ov = ofit.predict_marginal(xs)
     marg = pred.marginal()
@@ -116,6 +116,68 @@ def test_mean_function_is_removed_and_added(ctx):
     far = np.array([-20., 40.])
     assert np.abs(with_mean.predict(far).mean() - (3. * far + 1.)).max() < 1e-3
     assert np.linalg.norm(with_mean.predict(far).mean() - without.predict(far).mean()) > 1.
+
+
+def test_linear_mean_gp_matches_golden_and_oracle(ctx):
+    """MeanFunction::remove_from / add_to (mean_function.hpp:86-107), LinearMean (polynomials.hpp:92-106) through
+    fit / predict / log_likelihood: against tests/golden/toy_linear_mean.json (MakeGaussianProcessWithMean,
+    test_models.h:75-96, and the model of tests/test_gp.cc:344-371; expected values from scipy) and against the oracle."""
+    g = golden("toy_linear_mean.json")
+    x, y = np.array(g["x"]), np.array(g["y"])
+    mean = ab.LinearMean(g["mean"]["slope"], g["mean"]["offset"])
+    for mdl in g["models"]:
+        c = mdl["cov"]
+        cov = ab.SquaredExponential(c["squared_exponential_length_scale"], c["sigma_squared_exponential"]) \
+            + ab.measurement_only(ab.IndependentNoise(c["sigma_independent_noise"]))
+        tol = mdl["tolerance_rel"]
+        model = ab.gp_from_covariance_and_mean(cov, mean, context=ctx)
+        ds = ab.RegressionDataset(x, y)
+        fm = model.fit(ds)
+        ofit = orc.OracleFit(cov, x, y, mean=mean)
+        assert rel(fm.get_fit().information, np.array(mdl["information"])) <= tol
+        assert rel(fm.get_fit().information, ofit.information) <= tol
+        for p in mdl["predictions"]:
+            xs, want = np.array(p["xs"]), np.array(p["mean"])
+            pred = fm.predict(xs)
+            for got in (pred.mean(), pred.marginal().mean, pred.joint().mean):
+                assert rel(got, want) <= tol and rel(got, ofit.predict_mean(xs)) <= tol
+            assert np.abs(pred.joint().covariance - np.array(p["cov"])).max() <= 1e-5 * c["sigma_squared_exponential"] ** 2
+        assert abs(-model.log_likelihood(ds) - mdl["nll"]) <= 1e-7 * abs(mdl["nll"])
+        assert abs(-model.log_likelihood(ds) - orc.nll(cov, x, y, mean=mean)) <= 1e-7 * abs(mdl["nll"])
+    # composed mean functions, 3-D features (LinearMean reads the first coordinate), target variance
+    rng = np.random.default_rng(11)
+    x3 = rng.uniform(0., 10., (200, 3))
+    y3 = np.sin(x3).sum(axis=1) + 0.7 * x3[:, 0] - 2.
+    yv = rng.uniform(0.01, 0.05, 200)
+    xs3 = rng.uniform(0., 10., (30, 3))
+    comp = ab.LinearMean(0.7, -2.) + ab.LinearMean(0.1, 0.) * ab.LinearMean(0., 0.5)
+    cov3 = ab.Matern52(2., 1.) + ab.IndependentNoise(0.1)
+    model = ab.gp_from_covariance_and_mean(cov3, comp, context=ctx)
+    ds3 = ab.RegressionDataset(x3, ab.MarginalDistribution(y3, yv))
+    fm = model.fit(ds3)
+    ofit = orc.OracleFit(cov3, x3, y3, yv, mean=comp)
+    assert rel(fm.get_fit().information, ofit.information) <= 1e-8
+    om, ov = ofit.predict_marginal(xs3)
+    marg = fm.predict(xs3).marginal()
+    assert rel(marg.mean, om) <= 1e-8 and np.abs(marg.covariance - ov).max() <= 1e-8
+    assert abs(-model.log_likelihood(ds3) - orc.nll(cov3, x3, y3, mean=comp)) <= 1e-6 * 200
+
+
+def test_fit_from_prediction_with_mean(ctx):
+    """tests/test_gp.cc:344-371 (test_model_from_prediction_with_mean): fit_from_prediction must remove the mean
+    function from the prediction before it builds the new fit (gp.hpp:236-245)."""
+    g = golden("toy_linear_mean.json")
+    x, y = np.array(g["x"]), np.array(g["y"])
+    cov = ab.SquaredExponential(2., 1.) + ab.measurement_only(ab.IndependentNoise(0.1))
+    model = ab.gp_from_covariance_and_mean(cov, ab.LinearMean(g["mean"]["slope"], g["mean"]["offset"]), context=ctx)
+    fm = model.fit(ab.RegressionDataset(x, y))
+    feats = np.array([1.3, 4.2, 7.1])
+    pred = fm.predict(feats).joint()
+    again = model.fit_from_prediction(feats, pred).predict(feats).joint()
+    assert np.linalg.norm(again.mean - pred.mean) <= 1e-6                 # the reference's own bars
+    assert np.linalg.norm(again.covariance - pred.covariance) <= 1e-6
+    want = np.array(g["models"][1]["predictions"][0]["mean"])
+    assert rel(again.mean, want) <= 1e-8
 
 
 def test_not_positive_definite_and_nan_are_reported(ctx):
@@ -210,16 +272,7 @@ def test_leave_one_out_n16384_property(ctx):
     assert np.all(loo.covariance > 0) and np.abs(loo.mean - y).max() < 1.0
 
 
-@pytest.mark.parametrize("n", [60, 256, 700])
-def test_batched_log_likelihoods_match_single_calls(ctx, n):
-    """agp_nll_batch == agp_nll per parameter vector (the tuner's finite-difference gradient,
-    tune/finite_difference.hpp:20-94), including a ScalingTerm parameter, a mean-function parameter and a
-    parameter vector that is not positive definite."""
-    rng = np.random.default_rng(n)
-    x = rng.uniform(0., 10., (n, 3))
-    y = np.sin(x).sum(axis=1) + 0.5 * x[:, 0] + 0.1 * rng.standard_normal(n)
-    yvar = rng.uniform(0.01, 0.03, n)
-
+def _elevation_model(ctx):
     class Elevation(ab.ScalingFunction):
         _params = {"elevation_scaling_center": 4.0, "elevation_scaling_factor": 0.3}
 
@@ -231,27 +284,72 @@ def test_batched_log_likelihoods_match_single_calls(ctx, n):
             return 1. + p["elevation_scaling_factor"] * np.maximum(p["elevation_scaling_center"] - np.asarray(c)[:, 2], 0.)
 
     cov = ab.ScalingTerm(Elevation()) * ab.Constant(0.5) + ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
-    model = ab.gp_from_covariance_and_mean(cov, ab.LinearMean(), context=ctx)
+    return cov, ab.gp_from_covariance_and_mean(cov, ab.LinearMean(), context=ctx)
+
+
+def _with_overrides(ctx, cov, mean_function, overrides):
+    import copy
+    m = ab.gp_from_covariance_and_mean(copy.deepcopy(cov), copy.deepcopy(mean_function), context=ctx)
+    m.set_param_values(overrides)
+    return m
+
+
+@pytest.mark.parametrize("n", [60, 256, 700])
+def test_batched_log_likelihoods_match_oracle(ctx, n):
+    """agp_nll_batch against the ORACLE's log_likelihood (gp.hpp:442-451) per parameter vector
+    - the evaluations of the tuner's finite-difference gradient (tune/finite_difference.hpp:20-94) - including a
+    ScalingTerm parameter, a mean-function parameter, and a parameter vector that is not positive definite; and
+    against agp_nll one by one."""
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0., 10., (n, 3))
+    y = np.sin(x).sum(axis=1) + 0.5 * x[:, 0] + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.03, n)  # must be ignored by log_likelihood
+    cov, model = _elevation_model(ctx)
     ds = ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar))
     base = model.get_params()
     sets = [{}]
     for name in base:  # forward differences, epsilon as in compute_gradient
         sets.append({name: base[name] + 1e-6 * max(1., abs(base[name]))})
     sets.append({"matern_52_length_scale": 0.5, "sigma_matern_52": 3.0})
+    sets.append({"slope": 0.4, "offset": -1.0})
     got = model.log_likelihoods(ds, sets)
     for overrides, g in zip(sets, got):
-        m = ab.gp_from_covariance_and_mean(cov, ab.LinearMean(), context=ctx)
-        import copy
-        m.covariance_function_ = copy.deepcopy(cov)
-        m.mean_function_ = copy.deepcopy(model.mean_function_)
-        m.set_param_values(overrides)
-        want = m.log_likelihood(ds)
-        assert abs(g - want) <= 1e-9 * max(1., abs(want)), overrides
+        m = _with_overrides(ctx, cov, model.mean_function_, overrides)
+        want = -orc.nll(m.covariance_function_, x, y, mean=m.mean_function_)
+        assert abs(g - want) <= 1e-8 * n, overrides
+        assert abs(g - m.log_likelihood(ds)) <= 1e-9 * max(1., abs(want)), overrides
     # not positive definite: duplicate points without noise
     xd = np.concatenate([x[:10], x[:10]])
     bad = ab.gp_from_covariance(ab.SquaredExponential(1.0, 1.0), context=ctx)
     out = bad.log_likelihoods(ab.RegressionDataset(xd, np.zeros(20)), [{}, {"sigma_squared_exponential": 2.0}])
     assert np.all(np.isnan(out))
+
+
+def test_batched_log_likelihoods_many_parameter_sets(ctx):
+    """More parameter vectors in one batch than the context's kernel cache holds (64): every slot must still be
+    evaluated with ITS parameters (the batch owns its kernel handles; the cache evicts one entry at a time)."""
+    n, count = 96, 75
+    rng = np.random.default_rng(77)
+    x = rng.uniform(0., 10., (n, 3))
+    y = np.sin(x).sum(axis=1)
+    cov = ab.SquaredExponential(1.5, 1.0) + ab.IndependentNoise(0.2)
+    model = ab.gp_from_covariance(cov, context=ctx)
+    ds = ab.RegressionDataset(x, y)
+    sets = [{"squared_exponential_length_scale": 0.8 + 0.03 * i, "sigma_independent_noise": 0.1 + 0.01 * (i % 7)}
+            for i in range(count)]
+    got = model.log_likelihoods(ds, sets)
+    for overrides, g in zip(sets, got):
+        m = _with_overrides(ctx, cov, model.mean_function_, overrides)
+        assert abs(g + orc.nll(m.covariance_function_, x, y)) <= 1e-8 * n, overrides
+    # the cache itself: handles handed out stay valid while more than 64 distinct kernels pass through it
+    handles = {}
+    for i in range(count):
+        m = _with_overrides(ctx, cov, model.mean_function_, sets[i])
+        handles[i] = ctx.kernel(m.covariance_function_).value
+        assert len(ctx._kernels) <= ctx.KERNEL_CACHE
+    m_last = _with_overrides(ctx, cov, model.mean_function_, sets[count - 1])
+    assert ctx.kernel(m_last.covariance_function_).value == handles[count - 1]  # most recent entry still cached
+    assert abs(m_last.log_likelihood(ds) + orc.nll(m_last.covariance_function_, x, y)) <= 1e-8 * n
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -274,7 +372,7 @@ def test_random_models_fit_predict_match_oracle(ctx, seed):
     ofit = orc.OracleFit(cov, x, y, yvar)
     info = ofit.information
     assert np.abs(fm.get_fit().information - info).max() <= 1e-8 * np.abs(info).max(), cov.get_name()
-    assert abs(model.log_likelihood(ds) + orc.nll(cov, x, y, yvar)) <= 1e-8 * n
+    assert abs(model.log_likelihood(ds) + orc.nll(cov, x, y)) <= 1e-8 * n
     for meas in (False, True):
         om, ov = ofit.predict_marginal(xs, xs_meas=meas)
         _, oj = ofit.predict_joint(xs, xs_meas=meas)

@@ -318,3 +318,59 @@ def test_sum_and_product_ignore_a_side_without_a_caller():
     # a defined side that EVALUATES to 0 still annihilates a product (the lhs == 0 short circuit, :361-365)
     meas = ab.measurement_only(ab.IndependentNoise(0.5))
     assert orc.gram(meas * anywhere, feats)[0, 0] == 0.
+
+
+def test_toy_linear_gp_with_linear_mean():
+    """GPs with a mean function (MakeGaussianProcessWithMean, test_models.h:75-96; tests/test_gp.cc:344-371):
+    remove_from before the fit, add_to after the prediction (mean_function.hpp:86-107, polynomials.hpp:92-106)."""
+    g = golden("toy_linear_mean.json")
+    x, y = np.array(g["x"]), np.array(g["y"])
+    mean = ab.LinearMean(g["mean"]["slope"], g["mean"]["offset"])
+    assert np.array_equal(orc.mean_vector(mean, ab.SquaredExponential(), x), g["mean"]["slope"] * x + g["mean"]["offset"])
+    for mdl in g["models"]:
+        c = mdl["cov"]
+        cov = ab.SquaredExponential(c["squared_exponential_length_scale"], c["sigma_squared_exponential"]) \
+            + ab.measurement_only(ab.IndependentNoise(c["sigma_independent_noise"]))
+        tol = mdl["tolerance_rel"]
+        fit = orc.OracleFit(cov, x, y, mean=mean)
+        info = np.array(mdl["information"])
+        assert np.abs(fit.information - info).max() <= tol * np.abs(info).max()
+        for p in mdl["predictions"]:
+            xs, want = np.array(p["xs"]), np.array(p["mean"])
+            for got in (fit.predict_mean(xs), fit.predict_marginal(xs)[0], fit.predict_joint(xs)[0]):
+                assert np.abs(got - want).max() <= tol * np.abs(want).max()
+            assert np.abs(fit.predict_joint(xs)[1] - np.array(p["cov"])).max() <= 1e-5 * c["sigma_squared_exponential"] ** 2
+        assert abs(orc.nll(cov, x, y, mean=mean) - mdl["nll"]) <= 1e-7 * abs(mdl["nll"])
+
+
+def test_mean_function_composition():
+    # SumOfMeanFunctions / ProductOfMeanFunctions incl. the `output != 0` short circuit (mean_function.hpp:150-155,221-227)
+    x = np.array([-1., 0., 2., 5.])
+    cov = ab.SquaredExponential()
+    lin, lin2, zero = ab.LinearMean(2., 1.), ab.LinearMean(0.5, 0.), ab.ZeroMean()
+    assert np.array_equal(orc.mean_vector(lin + lin2, cov, x), (2. * x + 1.) + 0.5 * x)
+    assert np.array_equal(orc.mean_vector(lin * lin2, cov, x), (2. * x + 1.) * (0.5 * x))
+    assert np.array_equal(orc.mean_vector(zero * lin, cov, x), np.zeros(4))
+    # 0 * inf stays 0: the right-hand side is not evaluated where the left one is zero
+    inf = [("linear", 0.5, 0.), ("constant", np.inf), ("product",)]
+    assert np.array_equal(orc.mean_vector(inf, cov, x), np.array([-np.inf, 0., np.inf, np.inf]))
+    for m in (lin + lin2, lin * lin2, zero * lin, (lin + zero) * lin2):
+        assert np.array_equal(orc.mean_vector(m, cov, x), m(x))  # the host mirror evaluates the same
+    # ZeroMean leaves the target untouched (mean_function.hpp:90-92,101-103), also NaN entries
+    t = np.array([1., np.nan, 3., 4.])
+    assert np.array_equal(orc.remove_mean(zero, cov, x, t), t, equal_nan=True)
+    assert np.array_equal(orc.add_mean(lin, cov, x, orc.remove_mean(lin, cov, x, np.ones(4))), np.ones(4))
+
+
+def test_log_likelihood_ignores_target_variance():
+    """GaussianProcessBase::log_likelihood (gp.hpp:442-451) evaluates covariance_function_(measurement_features)
+    alone; negative_log_likelihood on K + diag(var) is a different number."""
+    rng = np.random.default_rng(4)
+    x = rng.uniform(0., 5., 40)
+    y = np.sin(x)
+    cov = ab.SquaredExponential(1., 1.) + ab.measurement_only(ab.IndependentNoise(0.2))
+    K = orc.gram(cov, x, x_meas=True)
+    assert abs(orc.nll(cov, x, y) - orc.nll_dense(y, K)) < 1e-10
+    var = rng.uniform(0.1, 0.2, 40)
+    assert abs(orc.nll_with_variance(cov, x, y, var) - orc.nll_dense(y, K + np.diag(var))) < 1e-10
+    assert abs(orc.nll_with_variance(cov, x, y, var) - orc.nll(cov, x, y)) > 1e-3
