@@ -50,9 +50,8 @@ def test_config4_n32768_mixed(ctx):
 
     # (2) full size: all-fp64 fit and mixed-precision fit
     m64 = ab.gp_from_covariance(cov, context=ctx)
-    a64 = np.array(m64.fit(ab.RegressionDataset(train, y)).get_fit().information)
-    ld64 = None
     f64 = m64.fit(ab.RegressionDataset(train, y))
+    a64 = np.array(f64.get_fit().information)
     ld64 = f64.get_fit().log_determinant
     mm = ab.gp_from_covariance(cov, context=ctx)
     mm.precision = "mixed"
