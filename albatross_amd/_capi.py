@@ -116,15 +116,57 @@ EXPORTS = [
     ("agp_predict_mean", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, C.c_int]),
     ("agp_predict_marginal", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
     ("agp_predict_joint", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
-    ("agp_blk_gram", C.c_int, [_P, _P, C.POINTER(Features), C.POINTER(Features), _P, C.c_int64, _P, C.POINTER(C.c_int)]),
-    ("agp_blk_panel_factor", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, C.POINTER(C.c_int64), _D]),
-    ("agp_blk_update", C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
-    ("agp_blk_back_diag", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
-    ("agp_blk_back_update", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    ("agp_comm_unique_id", C.c_int, [_P]),
+    ("agp_comm_create", C.c_int, [_P, C.c_int, C.c_int, _P, _PP]),
+    ("agp_comm_create_callbacks", C.c_int, [C.c_int, C.c_int, _P, _PP]),
+    ("agp_comm_destroy", None, [_P]),
+    ("agp_comm_size", C.c_int, [_P]),
+    ("agp_comm_rank", C.c_int, [_P]),
+    ("agp_comm_all_reduce_host", C.c_int, [_P, _P, C.c_int64, C.c_int]),
+    ("agp_comm_barrier", C.c_int, [_P]),
+    ("agp_shard_local_rows", C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    ("agp_shard_global_row", C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64]),
+    ("agp_shard_owner", C.c_int, [C.c_int64, C.c_int]),
+    ("agp_shard_work_doubles", C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    ("agp_sharded_fit_create", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, _PP, _P, _D]),
+    ("agp_sharded_fit_destroy", None, [_P]),
+    ("agp_sharded_fit_failed_pivot", C.c_int64, [_P]),
+    ("agp_sharded_fit_replicate", C.c_int, [_P, _P, _PP]),
+    ("agp_sharded_fit_stage", C.c_int, [_P, C.c_int, _D]),
+    ("agp_shard_factor_custom", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P, _D, C.POINTER(C.c_int64)]),
     ("agp_last_stage_ms", C.c_int, [_P, C.c_int, _D]),
     ("agp_set_profiling", C.c_int, [_P, C.c_int]),
     ("agp_mfma_f64_peak", C.c_int, [_P, C.c_int, _D]),
 ]
+
+COMM_ID_BYTES = 128
+
+# agp_comm_callbacks / agp_shard_ops_callbacks (include/albatross_amd.h): collectives and block arithmetic supplied by
+# the caller (tests; one-GPU boxes).  Pointers arrive as plain integers (c_void_p).
+BROADCAST_FN = C.CFUNCTYPE(C.c_int, _P, _P, C.c_int64, C.c_int)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, _P, _P, _P, C.c_int64)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, _P, _P, C.c_int64, C.c_int)
+
+
+class CommCallbacks(C.Structure):
+    _fields_ = [("user", _P), ("broadcast", BROADCAST_FN), ("all_gather", ALL_GATHER_FN), ("all_reduce", ALL_REDUCE_FN)]
+
+
+FACTOR_DIAG_FN = C.CFUNCTYPE(C.c_int64, _P, _P, C.c_int64, C.c_int64, _P, _P, _D)
+TRSM_ROWS_FN = C.CFUNCTYPE(None, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P)
+GEMM_FN = C.CFUNCTYPE(None, _P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int)
+COPY2D_FN = C.CFUNCTYPE(None, _P, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64)
+INVERT_DIAG_FN = C.CFUNCTYPE(None, _P, _P, C.c_int64, C.c_int64, _P, _P)
+COLVEC_DOT_FN = C.CFUNCTYPE(None, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_double, C.c_double, _P, _P)
+AXPBY_FN = C.CFUNCTYPE(None, _P, C.c_int64, C.c_double, _P, C.c_double, _P, _P)
+FILL_ZERO_FN = C.CFUNCTYPE(None, _P, _P, C.c_int64)
+
+
+class ShardOpsCallbacks(C.Structure):
+    _fields_ = [("user", _P), ("factor_diag", FACTOR_DIAG_FN), ("trsm_rows", TRSM_ROWS_FN), ("gemm", GEMM_FN),
+                ("copy2d", COPY2D_FN), ("invert_diag", INVERT_DIAG_FN), ("colvec_dot", COLVEC_DOT_FN),
+                ("axpby", AXPBY_FN), ("fill_zero", FILL_ZERO_FN)]
+
 
 LIB_NAME = "libalbatross_amd.so"
 

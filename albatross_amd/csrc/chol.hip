@@ -644,6 +644,35 @@ void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n,
   panel_phase(ctx, s, A, n, lda, img, y, K0, kend, nullptr);
 }
 
+// X (nrows x w, ld) <- X L^-T against an ALREADY FACTORED w x w diagonal block (w <= 512) given by its lower
+// triangle Lkk (leading dimension ldl) and the tile images of its 128 x 128 diagonal sub-blocks; yrows (optional)
+// receives the fused forward substitution y -= X z.  The panel TRSM of the row-block-sharded fit (shard.h): every
+// rank runs it on its own rows against the diagonal block the owner broadcast.  Right-looking over the sub-blocks:
+// the same trsm_micro_kernel / MFMA update launches as panel_phase, minus the POTRFs.
+void trsm_rows_wide(hipStream_t s, double *X, long long ld, long long nrows, long long w, const double *Lkk,
+                    long long ldl, const double *img, const double *z, double *yrows) {
+  if (nrows <= 0 || w <= 0) return;
+  for (long long c = 0; c < w; c += NB) {
+    const int nbk = (int)((w - c < NB) ? w - c : NB);
+    TrsmArgs t;
+    t.img = img + (c / NB) * (long long)IMG_DOUBLES;
+    t.nbk = nbk;
+    t.Y = X + c * ld;
+    t.stride_m = ld; t.stride_n = 1;
+    t.ncols = nrows;
+    t.z = (z && yrows) ? z + c : nullptr;
+    t.yrest = (z && yrows) ? yrows : nullptr;
+    t.batch_img = t.batch_Y = 0; t.n_total = 0;
+    const unsigned grid = (unsigned)((nrows + 63) / 64);
+    if (t.z) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
+    else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
+    const long long rest = w - (c + nbk);
+    if (rest > 0)  // X[:, c + nbk :] -= X[:, c : c + nbk] L[c + nbk :, c : c + nbk]^T
+      launch_gemm_nt_sub(s, X + (c + nbk) * ld, ld, X + c * ld, ld, false, Lkk + (c + nbk) + c * ldl, ldl, false, nrows, rest,
+                         nbk, false);
+  }
+}
+
 // Outer block width as a function of the remaining (trailing) size.  Wide blocks (K = 512) keep
 // the bulk update's C traffic off the HBM roofline and its MFMA efficiency up; narrow blocks
 // shorten the serial panel chain per step.  With the current panel kernels the choice barely

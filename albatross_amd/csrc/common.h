@@ -28,7 +28,10 @@ struct FeatView {
   int dim;
   int nsc;
   int meas;
+  long long sstride = 0;  // distance between scale columns (0: n) - lets a view cover a sub-range of a larger vector
 };
+
+__host__ __device__ inline long long scale_stride(const FeatView &f) { return f.sstride ? f.sstride : f.n; }
 
 struct DeviceFeatures {
   FeatView v{};

@@ -40,7 +40,7 @@ __device__ __forceinline__ void stage_points(TileLds<DIMP> &L, int slot0, int co
     L.norm[slot0 + t] = need_norm ? sqrt(nn) : 0.;
 #pragma unroll
     for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k)
-      L.s[k][slot0 + t] = (ok && k < F.nsc) ? F.scales[(long long)k * F.n + g] : 0.;
+      L.s[k][slot0 + t] = (ok && k < F.nsc) ? F.scales[(long long)k * scale_stride(F) + g] : 0.;
     L.id[slot0 + t] = (ok && F.ids) ? F.ids[g] : -1;
   }
 }
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void gram_diag_kernel(const DevProgram *__rest
   }
   p.norm = sqrt(nn);
 #pragma unroll
-  for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) p.s[k] = k < X.nsc ? X.scales[(long long)k * X.n + i] : 0.;
+  for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) p.s[k] = k < X.nsc ? X.scales[(long long)k * scale_stride(X) + i] : 0.;
   p.id = X.ids ? X.ids[i] : -1;
   out[i] = eval_pair<DIMP>(P, p, p, false, X.ids != nullptr, X.meas != 0);
 }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_kernel(const DevPr
   }
   y.norm = need_norm ? sqrt(nn) : 0.;
 #pragma unroll
-  for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) y.s[k] = k < XS.nsc ? XS.scales[(long long)k * XS.n + j] : 0.;
+  for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) y.s[k] = k < XS.nsc ? XS.scales[(long long)k * scale_stride(XS) + j] : 0.;
   y.id = XS.ids ? XS.ids[j] : -1;
   const bool have_ids = X.ids != nullptr && XS.ids != nullptr;
   const bool both_meas = X.meas && XS.meas;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_kernel(const DevPr
     }
     x.norm = need_norm ? sqrt(xn) : 0.;
 #pragma unroll
-    for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) x.s[k] = k < X.nsc ? X.scales[(long long)k * X.n + i] : 0.;
+    for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) x.s[k] = k < X.nsc ? X.scales[(long long)k * scale_stride(X) + i] : 0.;
     x.id = X.ids ? X.ids[i] : -1;
     acc += eval_pair<DIMP>(P, x, y, false, have_ids, both_meas) * alpha[i];
   }

@@ -1,0 +1,624 @@
+// shard_hip.hip — the GPU half of the sharded fit (shard.h): HipShardOps (the block arithmetic on HIP streams with
+// the kernels of the single-GPU fit), the RCCL transport, and the C-ABI entry points agp_comm_* / agp_sharded_fit_*.
+//
+// Reference work replaced: GaussianProcessBase::_fit_impl (include/albatross/src/models/gp.hpp:281-294) + the
+// Fit<GPFit> constructor (gp.hpp:61-69) for one dataset over the GPUs of a node.
+//
+// RCCL is bound at run time (dlopen of the ROCm installation's librccl.so.1, the one built against the HIP runtime
+// this library links): processes that never create a communicator do not load it, and a torch wheel's private
+// librccl elsewhere in the process is never picked up by accident.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enumerators only; every function goes through the table below
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <thread>
+
+#include "api_internal.h"
+#include "shard_internal.h"
+
+namespace agp {
+void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *img, double *y,
+                        long long K0, long long kend);
+void trsm_rows_wide(hipStream_t s, double *X, long long ld, long long nrows, long long w, const double *Lkk, long long ldl,
+                    const double *img, const double *z, double *yrows);
+
+// ---------------------------------------------------------------------------------------------------------------
+// RCCL, bound at run time
+// ---------------------------------------------------------------------------------------------------------------
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  std::string error;
+};
+
+static RcclApi *rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.handle ? &api : nullptr;
+  tried = true;
+  const char *names[] = {getenv("AGP_RCCL_LIB"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  for (const char *nm : names) {
+    if (!nm || !nm[0]) continue;
+    api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (api.handle) break;
+    api.error = dlerror();
+  }
+  if (!api.handle) return nullptr;
+#define AGP_BIND(field, sym)                                                  \
+  api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym)); \
+  if (!api.field) { api.error = std::string("missing symbol ") + sym; dlclose(api.handle); api.handle = nullptr; return nullptr; }
+  AGP_BIND(GetUniqueId, "ncclGetUniqueId")
+  AGP_BIND(CommInitRank, "ncclCommInitRank")
+  AGP_BIND(CommDestroy, "ncclCommDestroy")
+  AGP_BIND(CommAbort, "ncclCommAbort")
+  AGP_BIND(CommGetAsyncError, "ncclCommGetAsyncError")
+  AGP_BIND(GetErrorString, "ncclGetErrorString")
+  AGP_BIND(Broadcast, "ncclBroadcast")
+  AGP_BIND(AllGather, "ncclAllGather")
+  AGP_BIND(AllReduce, "ncclAllReduce")
+#undef AGP_BIND
+  return &api;
+}
+
+static double comm_timeout_seconds() {
+  static double t = -1.;
+  if (t < 0.) {
+    const char *e = getenv("AGP_COMM_TIMEOUT_S");
+    t = e ? atof(e) : 120.;
+    if (!(t > 0.)) t = 120.;
+  }
+  return t;
+}
+
+// Wait for a stream with a deadline: a peer that died inside a collective must not hang this rank for ever.
+static int wait_stream(agp_context *ctx, hipStream_t s, double timeout_s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int spins = 0;
+  while (true) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return AGP_OK;
+    if (e != hipErrorNotReady) {
+      if (ctx) ctx->last_error = std::string("hipStreamQuery: ") + hipGetErrorString(e);
+      return AGP_ERR_HIP;
+    }
+    if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+      if (ctx) ctx->last_error = "timeout waiting for the device (a collective did not complete)";
+      return AGP_ERR_COMM;
+    }
+  }
+}
+
+struct RcclComm : HostReducingComm {
+  RcclApi *api = nullptr;
+  ncclComm_t comm = nullptr;
+  agp_context *ctx = nullptr;
+  double *scratch = nullptr;  // device staging of the host-side all-reduce
+  static constexpr long long SCRATCH = 4096;
+  bool broken = false;
+
+  ~RcclComm() override {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (scratch) (void)hipFree(scratch);
+    if (comm && api) {
+      if (broken) (void)api->CommAbort(comm);
+      else (void)api->CommDestroy(comm);
+    }
+  }
+  int check(ncclResult_t r, const char *what) {
+    if (r == ncclSuccess) return AGP_OK;
+    if (ctx) ctx->last_error = std::string(what) + ": " + api->GetErrorString(r);
+    broken = true;
+    return AGP_ERR_COMM;
+  }
+  int broadcast(ShardOps &ops, int q, double *buf, long long count, int root) override {
+    return check(api->Broadcast(buf, buf, (size_t)count, ncclDouble, root, comm, (hipStream_t)ops.stream(q)), "ncclBroadcast");
+  }
+  int all_gather(ShardOps &ops, int q, const double *send, double *recv, long long count) override {
+    return check(api->AllGather(send, recv, (size_t)count, ncclDouble, comm, (hipStream_t)ops.stream(q)), "ncclAllGather");
+  }
+  int all_reduce(ShardOps &ops, int q, double *buf, long long count, int op) override {
+    return check(api->AllReduce(buf, buf, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, comm,
+                                (hipStream_t)ops.stream(q)), "ncclAllReduce");
+  }
+  int all_reduce_host(double *buf, long long count, int op) override {
+    if (hipSetDevice(ctx->device) != hipSuccess) return AGP_ERR_HIP;
+    hipStream_t s = ctx->stream3;
+    for (long long off = 0; off < count; off += SCRATCH) {
+      const long long c = count - off < SCRATCH ? count - off : SCRATCH;
+      if (hipMemcpyAsync(scratch, buf + off, sizeof(double) * (size_t)c, hipMemcpyHostToDevice, s) != hipSuccess) return AGP_ERR_HIP;
+      const int st = check(api->AllReduce(scratch, scratch, (size_t)c, ncclDouble, op == 1 ? ncclMax : ncclSum, comm, s), "ncclAllReduce");
+      if (st != AGP_OK) return st;
+      if (hipMemcpyAsync(buf + off, scratch, sizeof(double) * (size_t)c, hipMemcpyDeviceToHost, s) != hipSuccess) return AGP_ERR_HIP;
+      const int sw = wait_stream(ctx, s, comm_timeout_seconds());
+      if (sw != AGP_OK) { broken = true; return sw; }
+    }
+    return AGP_OK;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels of the HIP backend that the single-GPU path does not have
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shard_copy2d_kernel(double *__restrict__ dst, long long ldd, const double *__restrict__ src,
+                                                           long long lds, long long rows, long long cols) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  for (long long c = blockIdx.y; c < cols; c += gridDim.y) dst[r + c * ldd] = src[r + c * lds];
+}
+
+// Pall[(i - k - 1) B + r][c] = recv[owner(i)][c][(li(i) - li0(owner, k)) B + r]: the all-gathered per-rank stacks back
+// into global row order (snake ownership, see ShardPlan)
+__global__ __launch_bounds__(256) void shard_gather_kernel(double *__restrict__ Pall, long long ldP, const double *__restrict__ recv,
+                                                           long long cnt_rows, long long w, long long n, long long B, int world,
+                                                           long long k) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;  // row of Pall
+  const long long g = (k + 1) * B + row;                            // global row
+  if (g >= n) return;
+  const long long i = g / B, r = g - i * B;
+  const long long rr = i % world, rnd = i / world;
+  const int o = (int)((rnd & 1) ? world - 1 - rr : rr);
+  long long li0 = (k + 1) / world;
+  const long long gb = li0 * world + ((li0 & 1) ? world - 1 - o : o);
+  if (gb <= k) ++li0;
+  const double *src = recv + (long long)o * cnt_rows * w + (rnd - li0) * B + r;
+  for (long long c = blockIdx.y; c < w; c += gridDim.y) Pall[row + c * ldP] = src[c * cnt_rows];
+}
+
+__global__ __launch_bounds__(256) void shard_add_diag_kernel(double *A, long long ld, long long lrow0, long long gcol0, long long w,
+                                                            const double *yvar) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r < w) A[(lrow0 + r) + (gcol0 + r) * ld] += yvar[gcol0 + r];
+}
+
+// full[g][c] (lower triangle, ldf) <- row-block stacks of all ranks (each nlb_max * B rows x n, ld_loc)
+__global__ __launch_bounds__(256) void shard_unstack_kernel(double *__restrict__ full, long long ldf, const double *__restrict__ stacks,
+                                                            long long ld_loc, long long per_rank, long long n, long long B, int world) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n) return;
+  const long long i = g / B, r = g - i * B;
+  const long long rr = i % world, rnd = i / world;
+  const int o = (int)((rnd & 1) ? world - 1 - rr : rr);
+  const double *src = stacks + (long long)o * per_rank + rnd * B + r;
+  for (long long c = blockIdx.y; c <= g; c += gridDim.y) full[g + c * ldf] = src[c * ld_loc];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// HipShardOps
+// ---------------------------------------------------------------------------------------------------------------
+struct HipShardOps : ShardOps {
+  agp_context_impl *ctx;
+  hipStream_t sq[3];
+  hipStream_t own_comm_stream = nullptr;
+  hipEvent_t ev[EV_COUNT];
+  bool ok = true;
+  double timeout_s;
+  // bulk-update timing (profiling only)
+  std::vector<hipEvent_t> tev;
+  std::vector<double> tflop;
+  size_t tused = 0;
+
+  explicit HipShardOps(agp_context_impl *c) : ctx(c), timeout_s(comm_timeout_seconds()) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    ok = hipStreamCreateWithPriority(&own_comm_stream, hipStreamNonBlocking, hi) == hipSuccess;
+    sq[QP] = ctx->stream; sq[QB] = ctx->stream2; sq[QC] = own_comm_stream;
+    for (auto &e : ev) {
+      e = nullptr;
+      ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    }
+  }
+  ~HipShardOps() override {
+    for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto e : tev) (void)hipEventDestroy(e);
+    if (own_comm_stream) (void)hipStreamDestroy(own_comm_stream);
+  }
+  void *stream(int q) override { return sq[q]; }
+  bool device_memory() const override { return true; }
+
+  void factor_diag(int q, double *D, long long ld, long long w, long long pivot_base, double *img, double *zblk) override {
+    // the panel phase of the single-GPU factorisation on the w x w block alone; the pointers are shifted so that the
+    // block sits at row / column `pivot_base` and a non-positive pivot is reported with its GLOBAL index
+    panel_phase_public(ctx, sq[q], D - pivot_base * (ld + 1), pivot_base + w, ld, img - (pivot_base / NB) * (long long)SHARD_IMG,
+                       zblk - pivot_base, pivot_base, pivot_base + w);
+  }
+  void trsm_rows(int q, double *X, long long ld, long long nrows, long long w, const double *Lkk, const double *img,
+                 const double *z, double *yrows) override {
+    trsm_rows_wide(sq[q], X, ld, nrows, w, Lkk, w, img, z, yrows);
+  }
+  void gemm(int q, double *C, long long ldc, const double *P, long long ldp, const double *Q, long long ldq, long long M,
+            long long N, long long K, bool tri, int bulk) override {
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    hipStream_t s = sq[q];
+    const bool timed = bulk && ctx->profiling;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+      while (tev.size() < tused + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        tev.push_back(e);
+      }
+      if (tev.size() >= tused + 2) { e0 = tev[tused]; e1 = tev[tused + 1]; }
+    }
+    if (bulk && tri && M == N && ldp == ldq) {
+      // the single-GPU bulk update: full rounds of 128 x 128 workgroups + the 64 x 64 tail (gemm.hip)
+      BulkTiming bt;
+      bt.e0 = e0; bt.e1 = e1;
+      launch_trailing_update(s, C, ldc, P, Q, ldp, M, K, e0 ? &bt : nullptr);
+      if (e0 && bt.flops > 0.) {
+        tflop.resize(tused / 2 + 1);
+        tflop[tused / 2] = bt.flops;
+        tused += 2;
+      }
+      return;
+    }
+    if (e0) (void)hipEventRecord(e0, s);
+    launch_gemm_nt_sub(s, C, ldc, P, ldp, false, Q, ldq, false, M, N, K, tri);
+    if (e0) {
+      (void)hipEventRecord(e1, s);
+      tflop.resize(tused / 2 + 1);
+      tflop[tused / 2] = 2. * (double)K * (double)M * (double)N * (tri ? 0.5 : 1.);
+      tused += 2;
+    }
+  }
+  void copy2d(int q, double *dst, long long ldd, const double *src, long long lds, long long rows, long long cols) override {
+    if (rows <= 0 || cols <= 0) return;
+    const unsigned gy = (unsigned)(cols < 256 ? cols : 256);
+    hipLaunchKernelGGL(shard_copy2d_kernel, dim3((unsigned)((rows + 255) / 256), gy), dim3(256), 0, sq[q], dst, ldd, src, lds, rows, cols);
+  }
+  void gather_panel(int q, double *Pall, long long ldP, const double *recv, long long cnt_rows, long long w, const ShardPlan &plan,
+                    long long k) override {
+    const long long rows = plan.n - (k + 1) * plan.B;
+    if (rows <= 0) return;
+    const unsigned gy = (unsigned)(w < 128 ? w : 128);
+    hipLaunchKernelGGL(shard_gather_kernel, dim3((unsigned)((rows + 255) / 256), gy), dim3(256), 0, sq[q], Pall, ldP, recv, cnt_rows, w,
+                       plan.n, plan.B, plan.world, k);
+  }
+  void invert_diag(int q, const double *D, long long ld, long long w, const double *img, double *W) override {
+    launch_set_identity_batched(sq[q], W, w, w * w, w, 1);
+    forward_solve_mat_batched(sq[q], D, 0, w, ld, img, 0, W, 0, w, w, /*rhs_lower=*/true, 1);
+  }
+  void colvec_dot(int q, const double *W, long long ld, long long m, long long n, const double *v, double alpha, double beta,
+                  const double *base, double *out) override {
+    launch_colvec_dot(sq[q], W, ld, m, n, v, alpha, beta, base, out);
+  }
+  void axpby(int q, long long n, double a, const double *x, double b, const double *y, double *out) override {
+    launch_axpby(sq[q], n, a, x, b, y, out);
+  }
+  void fill_zero(int q, double *p, long long count) override {
+    if (count > 0) (void)hipMemsetAsync(p, 0, sizeof(double) * (size_t)count, sq[q]);
+  }
+  void record(int e, int q) override { (void)hipEventRecord(ev[e], sq[q]); }
+  void wait(int q, int e) override { (void)hipStreamWaitEvent(sq[q], ev[e], 0); }
+  int sync_all() override {
+    for (int q = 0; q < 3; ++q) {
+      const int st = wait_stream(ctx, sq[q], timeout_s);
+      if (st != AGP_OK) return st;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return AGP_ERR_HIP; }
+    return AGP_OK;
+  }
+  void status(double out[2]) override {
+    int flags[4] = {0, 0, 0, 0};
+    double scal[4] = {0., 0., 0., 0.};
+    (void)hipMemcpy(flags, ctx->d_flags, sizeof(flags), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(scal, ctx->d_scalars, sizeof(scal), hipMemcpyDeviceToHost);
+    out[0] = scal[0];
+    out[1] = (double)flags[1];
+  }
+  int to_host(int q, const double *dev, double *host, long long count) override {
+    if (hipMemcpyAsync(host, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, sq[q]) != hipSuccess) return AGP_ERR_HIP;
+    return wait_stream(ctx, sq[q], timeout_s);
+  }
+  int from_host(int q, const double *host, double *dev, long long count) override {
+    if (hipMemcpyAsync(dev, host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, sq[q]) != hipSuccess) return AGP_ERR_HIP;
+    return wait_stream(ctx, sq[q], timeout_s);  // pageable source: must be consumed before the caller reuses it
+  }
+};
+
+}  // namespace agp
+
+using namespace agp;
+
+struct agp_sharded_fit {
+  agp_context_impl *ctx = nullptr;
+  agp_comm *comm = nullptr;
+  ShardPlan plan;
+  double *A = nullptr;      // local stacked rows, column-major, ld
+  long long ld = 0;
+  double *work = nullptr;
+  ShardBuffers buf;
+  double *y = nullptr;      // the local entries of z = L^-1 y
+  DeviceFeatures train;     // all training features (every rank holds the whole dataset)
+  double log_det = 0.;
+  int64_t failed_pivot = -1;
+  double stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+extern "C" {
+
+int agp_comm_unique_id(void *id) {
+  if (!id) return AGP_ERR_INVALID_ARGUMENT;
+  RcclApi *api = rccl_api();
+  if (!api) return AGP_ERR_COMM;
+  static_assert(sizeof(ncclUniqueId) <= AGP_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId u;
+  if (api->GetUniqueId(&u) != ncclSuccess) return AGP_ERR_COMM;
+  std::memset(id, 0, AGP_COMM_ID_BYTES);
+  std::memcpy(id, &u, sizeof(u));
+  return AGP_OK;
+}
+
+int agp_comm_create(agp_context *ctx, int nranks, int rank, const void *id, agp_comm **out) {
+  if (!ctx || !id || !out || nranks < 1 || rank < 0 || rank >= nranks) return AGP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  RcclApi *api = rccl_api();
+  if (!api) { ctx->last_error = "librccl could not be loaded"; return AGP_ERR_COMM; }
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  RcclComm *c = new (std::nothrow) RcclComm();
+  if (!c) return AGP_ERR_INVALID_ARGUMENT;
+  c->api = api;
+  c->ctx = ctx;
+  c->world = nranks;
+  c->rank = rank;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  const ncclResult_t r = api->CommInitRank(&c->comm, nranks, u, rank);
+  if (r != ncclSuccess) {
+    ctx->last_error = std::string("ncclCommInitRank: ") + api->GetErrorString(r);
+    c->comm = nullptr;
+    delete c;
+    return AGP_ERR_COMM;
+  }
+  if (hipMalloc(&c->scratch, sizeof(double) * RcclComm::SCRATCH) != hipSuccess) { delete c; return AGP_ERR_HIP; }
+  agp_comm *h = new (std::nothrow) agp_comm();
+  if (!h) { delete c; return AGP_ERR_INVALID_ARGUMENT; }
+  h->impl = c;
+  *out = h;
+  return AGP_OK;
+}
+
+void agp_sharded_fit_destroy(agp_sharded_fit *f) {
+  if (!f) return;
+  if (f->ctx) (void)hipSetDevice(f->ctx->device);
+  if (f->A) (void)hipFree(f->A);
+  if (f->work) (void)hipFree(f->work);
+  if (f->y) (void)hipFree(f->y);
+  f->train.release();
+  delete f;
+}
+
+int64_t agp_sharded_fit_failed_pivot(const agp_sharded_fit *f) { return f ? f->failed_pivot : -1; }
+
+int agp_sharded_fit_stage(const agp_sharded_fit *f, int stage, double *value) {
+  if (!f || !value || stage < 0 || stage > 7) return AGP_ERR_INVALID_ARGUMENT;
+  *value = f->stage[stage];
+  return AGP_OK;
+}
+
+int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, const agp_features *x, const double *y,
+                           const double *y_var, agp_sharded_fit **out, double *information, double *log_det) {
+  if (!c || !k || !x || !y || !out) return AGP_ERR_INVALID_ARGUMENT;
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  *out = nullptr;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(x);
+  if (st != AGP_OK) return st;
+  const long long n = x->n;
+  if (n <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  HostReducingComm *tr = comm ? comm->impl : nullptr;
+  const int world = tr ? tr->world : 1, rank = tr ? tr->rank : 0;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+
+  agp_sharded_fit *f = new (std::nothrow) agp_sharded_fit();
+  if (!f) return AGP_ERR_INVALID_ARGUMENT;
+  f->ctx = ctx;
+  f->comm = comm;
+  long long block = NBO;
+  if (const char *e = getenv("AGP_SHARD_BLOCK")) {  // tests: many row blocks at small n (128 / 256 / 512)
+    const long long b = atoll(e);
+    if (b == 128 || b == 256 || b == 512) block = b;
+  }
+  f->plan = ShardPlan(n, block, world, rank);
+  f->plan.force_comm = tr && shard_force_comm();
+  const ShardPlan &plan = f->plan;
+  const long long nlb = plan.n_local_blocks(rank), B = plan.B;
+  f->ld = factor_ld(plan.max_local_blocks() * B);  // the same on every rank (agp_sharded_fit_replicate gathers the stacks)
+  hipStream_t s = ctx->stream;
+  double *yvar_d = nullptr;
+#define SFIT_CHECK(expr)                                                     \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);   \
+      if (yvar_d) (void)hipFree(yvar_d);                                     \
+      agp_sharded_fit_destroy(f);                                            \
+      return AGP_ERR_HIP;                                                    \
+    }                                                                        \
+  } while (0)
+  if ((st = to_device(ctx, x, true, &f->train)) != AGP_OK) { agp_sharded_fit_destroy(f); return st; }
+  f->train.v.meas = 0;
+  SFIT_CHECK(hipMalloc(&f->A, sizeof(double) * (size_t)f->ld * (size_t)n));
+  SFIT_CHECK(hipMalloc(&f->work, sizeof(double) * (size_t)shard_work_doubles(plan)));
+  SFIT_CHECK(hipMalloc(&f->y, sizeof(double) * (size_t)(plan.max_local_blocks() * B + 8)));
+  shard_carve(plan, f->work, &f->buf);
+  const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  // the local targets: block by block in local order
+  for (long long li = 0; li < nlb; ++li) {
+    const long long i = plan.global_block(rank, li);
+    SFIT_CHECK(hipMemcpyAsync(f->y + li * B, y + i * B, sizeof(double) * (size_t)plan.width(i), kind, s));
+  }
+  if (y_var) {
+    SFIT_CHECK(hipMalloc(&yvar_d, sizeof(double) * (size_t)n));
+    SFIT_CHECK(hipMemcpyAsync(yvar_d, y_var, sizeof(double) * (size_t)n, kind, s));
+  }
+  SFIT_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
+  SFIT_CHECK(hipMemsetAsync(ctx->d_scalars, 0, 4 * sizeof(double), s));
+  if (x->location == AGP_HOST) SFIT_CHECK(hipStreamSynchronize(s));
+
+  // ---- Gram of the own row blocks: no communication (as_measurements(features), gp.hpp:288-290) ----
+  const auto t0 = std::chrono::steady_clock::now();
+  FeatView all = f->train.v;
+  all.meas = 1;
+  all.sstride = all.n;
+  if (world == 1 && !plan.force_comm) {
+    launch_gram(s, dprog, all, all, /*symmetric=*/true, /*lower_only=*/true, f->A, f->ld, yvar_d, ctx->d_flags, &k->prog);
+  } else {
+    for (long long li = 0; li < nlb; ++li) {
+      const long long i = plan.global_block(rank, li), w = plan.width(i);
+      FeatView rows = all, cols = all;
+      rows.coords = all.coords + i * B * all.dim;
+      rows.ids = all.ids ? all.ids + i * B : nullptr;
+      rows.scales = all.scales ? all.scales + i * B : nullptr;
+      rows.n = w;
+      cols.n = i * B + w;
+      launch_gram(s, dprog, rows, cols, /*symmetric=*/false, /*lower_only=*/false, f->A + li * B, f->ld, nullptr, ctx->d_flags,
+                  &k->prog);
+      if (yvar_d)
+        hipLaunchKernelGGL(shard_add_diag_kernel, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, s, f->A, f->ld, li * B, i * B, w,
+                           yvar_d);
+    }
+  }
+  int nan_flag = 0;
+  SFIT_CHECK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  SFIT_CHECK(hipStreamSynchronize(s));
+  nan_flag = ctx->h_flags[0];
+  const auto t1 = std::chrono::steady_clock::now();
+  if (yvar_d) { (void)hipFree(yvar_d); yvar_d = nullptr; }
+  if (tr) {  // ALBATROSS_ASSERT(!cov.hasNaN()), gp.hpp:66 - every rank must take the same exit
+    double v = (double)nan_flag;
+    if ((st = tr->all_reduce_host(&v, 1, 1)) != AGP_OK) { agp_sharded_fit_destroy(f); return st; }
+    nan_flag = v > 0.;
+  }
+  if (nan_flag) { agp_sharded_fit_destroy(f); return AGP_ERR_NAN_INPUT; }
+
+  // ---- factorisation + both substitutions ----
+  ShardResult res;
+  {
+    HipShardOps ops(ctx);
+    if (!ops.ok) { agp_sharded_fit_destroy(f); ctx->last_error = "stream / event creation failed"; return AGP_ERR_HIP; }
+    st = shard_factor_solve(ops, tr, plan, f->A, f->ld, f->y, f->buf, &res);
+    if (ctx->profiling) {
+      double ms_sum = 0., flop = 0.;
+      for (size_t i = 0; i + 1 < ops.tused; i += 2) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ops.tev[i], ops.tev[i + 1]);
+        ms_sum += ms;
+        flop += ops.tflop[i / 2];
+      }
+      f->stage[3] = ms_sum;
+      f->stage[4] = (double)(ops.tused / 2);
+      f->stage[5] = flop;
+    }
+  }
+  const auto t2 = std::chrono::steady_clock::now();
+  f->stage[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  f->stage[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  f->log_det = res.log_det;
+  f->failed_pivot = res.bad_pivot;
+  if (st == AGP_ERR_NOT_POSITIVE_DEFINITE) { *out = f; return st; }  // the handle reports the pivot
+  if (st != AGP_OK) { agp_sharded_fit_destroy(f); return st; }
+  if (information) SFIT_CHECK(hipMemcpy(information, f->buf.xfull, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  if (log_det) *log_det = f->log_det;
+  *out = f;
+#undef SFIT_CHECK
+  return AGP_OK;
+}
+
+int agp_sharded_fit_replicate(agp_context *c, agp_sharded_fit *f, agp_fit **out) {
+  if (!c || !f || !out || f->failed_pivot >= 0 || !f->A) return AGP_ERR_INVALID_ARGUMENT;
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  if (ctx != f->ctx) return AGP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const ShardPlan &plan = f->plan;
+  const long long n = plan.n, B = plan.B, nlbm = plan.max_local_blocks();
+  const int world = plan.world;
+  HostReducingComm *tr = f->comm ? f->comm->impl : nullptr;
+  if (plan.multi() && !tr) return AGP_ERR_INVALID_ARGUMENT;
+  agp_fit *fit = new (std::nothrow) agp_fit();
+  if (!fit) return AGP_ERR_INVALID_ARGUMENT;
+  fit->ctx = ctx;
+  fit->device = ctx->device;
+  fit->n = n;
+  fit->lda = factor_ld(n);
+  fit->A_bytes = sizeof(double) * (size_t)fit->lda * (size_t)n;
+  fit->log_det = f->log_det;
+  const long long nblk = (n + NB - 1) / NB;
+  double *stacks = nullptr, *imgs = nullptr;
+  const long long per_rank = f->ld * n, img_per_rank = nlbm * 4 * SHARD_IMG;
+#define REP_CHECK(expr)                                                      \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);   \
+      if (stacks && stacks != f->A) (void)hipFree(stacks);                   \
+      if (imgs && imgs != f->buf.img_local) (void)hipFree(imgs);             \
+      agp_fit_destroy(fit);                                                  \
+      return AGP_ERR_HIP;                                                    \
+    }                                                                        \
+  } while (0)
+  REP_CHECK(hipMalloc(&fit->A, fit->A_bytes));
+  REP_CHECK(hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * SHARD_IMG));
+  REP_CHECK(hipMalloc(&fit->alpha, sizeof(double) * (size_t)n));
+  int st = AGP_OK;
+  {
+    HipShardOps ops(ctx);
+    hipStream_t s = (hipStream_t)ops.stream(QC);
+    if (plan.multi()) {
+      REP_CHECK(hipMalloc(&stacks, sizeof(double) * (size_t)per_rank * (size_t)world));
+      REP_CHECK(hipMalloc(&imgs, sizeof(double) * (size_t)img_per_rank * (size_t)world));
+      st = tr->all_gather(ops, QC, f->A, stacks, per_rank);
+      if (st == AGP_OK) st = tr->all_gather(ops, QC, f->buf.img_local, imgs, img_per_rank);
+    } else {
+      stacks = f->A;
+      imgs = f->buf.img_local;
+    }
+    if (st == AGP_OK) {
+      hipLaunchKernelGGL(shard_unstack_kernel, dim3((unsigned)((n + 255) / 256), 64), dim3(256), 0, s, fit->A, (long long)fit->lda, stacks,
+                         f->ld, per_rank, n, B, world);
+      for (long long i = 0; i < plan.nb; ++i) {
+        const long long sub = (plan.width(i) + NB - 1) / NB;  // 128-blocks of this row block
+        (void)hipMemcpyAsync(fit->invd + i * (B / NB) * SHARD_IMG,
+                             imgs + (long long)plan.owner(i) * img_per_rank + plan.local_index(i) * 4 * SHARD_IMG,
+                             sizeof(double) * (size_t)(sub * SHARD_IMG), hipMemcpyDeviceToDevice, s);
+      }
+      (void)hipMemcpyAsync(fit->alpha, f->buf.xfull, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+      st = ops.sync_all();
+    }
+  }
+  if (stacks && stacks != f->A) (void)hipFree(stacks);
+  if (imgs && imgs != f->buf.img_local) (void)hipFree(imgs);
+  stacks = imgs = nullptr;
+  if (st != AGP_OK) { agp_fit_destroy(fit); return st; }
+  // train_features = features (gp.hpp:63): an owned copy, like agp_fit_create
+  {
+    agp_features view;
+    view.n = f->train.v.n; view.dim = f->train.v.dim; view.n_scale_columns = f->train.v.nsc;
+    view.coords = f->train.v.coords;
+    view.eq_id = reinterpret_cast<const int64_t *>(f->train.v.ids);
+    view.scales = f->train.v.scales;
+    view.is_measurement = 0;
+    view.location = AGP_DEVICE;
+    if ((st = to_device(ctx, &view, true, &fit->train)) != AGP_OK) { agp_fit_destroy(fit); return st; }
+    REP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+#undef REP_CHECK
+  *out = fit;
+  return AGP_OK;
+}
+
+}  // extern "C"

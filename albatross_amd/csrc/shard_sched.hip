@@ -1,0 +1,412 @@
+// shard_sched.hip — the backend-agnostic half of the sharded fit (shard.h): buffer carving, the schedule of
+// the row-block-cyclic LL^T with one block column of look-ahead, the two substitutions, and the callback backends
+// (CallbackShardOps / CallbackComm) behind agp_shard_factor_custom / agp_comm_create_callbacks.
+//
+// Reference work replaced: Fit<GPFit>::Fit (include/albatross/src/models/gp.hpp:61-69) - SerializableLDLT(cov)
+// (eigen/serializable_ldlt.hpp:27) and information = ldlt.solve(y) - for ONE dataset over several GPUs.
+//
+// No HIP call is made in this file: with callback backends it runs on machines without a GPU.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "shard_internal.h"
+
+namespace agp {
+
+static long long round_even(long long x) { return (x + 1) / 2 * 2; }
+
+bool shard_force_comm() {
+  const char *e = getenv("AGP_SHARD_FORCE_COMM");
+  return e && e[0] == '1';
+}
+
+long long shard_msg_doubles(const ShardPlan &p) { return p.B * p.B + 4 * SHARD_IMG + round_even(p.B); }
+
+static long long pall_ld(const ShardPlan &p) {
+  long long rows = p.n - p.B;
+  if (rows < 2) rows = 2;
+  long long ld = (rows + 7) / 8 * 8;
+  if (ld % 256 == 0) ld += 8;  // consecutive columns on different HBM channels (api.hip: factor_ld)
+  return ld;
+}
+
+long long shard_work_doubles(const ShardPlan &p) {
+  const long long nlb = p.max_local_blocks();
+  long long total = 2 * shard_msg_doubles(p) + nlb * 4 * SHARD_IMG + nlb * p.B * p.B + 2 * round_even(p.n) + round_even(p.B) + 8;
+  if (p.multi()) total += nlb * p.B * p.B * (1 + p.world) + 2 * pall_ld(p) * p.B;
+  return total;
+}
+
+void shard_carve(const ShardPlan &p, double *w, ShardBuffers *b) {
+  const long long nlb = p.max_local_blocks(), msg = shard_msg_doubles(p);
+  b->msg[0] = w; w += msg;
+  b->msg[1] = w; w += msg;
+  b->img_local = w; w += nlb * 4 * SHARD_IMG;
+  b->W = w; w += nlb * p.B * p.B;
+  b->t = w; w += round_even(p.n);
+  b->xfull = w; w += round_even(p.n);
+  b->tmp = w; w += round_even(p.B);
+  b->stat = w; w += 8;
+  b->ldp = pall_ld(p);
+  if (p.multi()) {
+    b->send = w; w += nlb * p.B * p.B;
+    b->recv = w; w += nlb * p.B * p.B * p.world;
+    b->pall[0] = w; w += b->ldp * p.B;
+    b->pall[1] = w; w += b->ldp * p.B;
+  } else {
+    b->send = b->recv = b->pall[0] = b->pall[1] = nullptr;
+  }
+}
+
+void ShardOps::gather_panel(int q, double *Pall, long long ldP, const double *recv, long long cnt_rows, long long w,
+                            const ShardPlan &plan, long long k) {
+  for (long long i = k + 1; i < plan.nb; ++i) {
+    const int o = plan.owner(i);
+    const long long li = plan.local_index(i) - plan.first_local_after(o, k);
+    copy2d(q, Pall + (i - k - 1) * plan.B, ldP, recv + (long long)o * cnt_rows * w + li * plan.B, cnt_rows, plan.width(i), w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The schedule.  Queues: QP = panel chain, QB = bulk updates, QC = collectives (see shard.h).  Step k:
+//   [owner(k)]  D_k factored (done in the look-ahead part of step k - 1), message packed
+//   QC          broadcast of the message
+//   QP          X = A[own rows of blocks > k, block column k] L_kk^-T, y -= X z_k;  pack of X for the all-gather
+//   [owner(k+1)] QP: D_{k+1} -= X_{k+1} X_{k+1}^T, factor D_{k+1}, pack its message   (look-ahead: runs while ...)
+//   QC          ... all-gather of the packed panel rows, re-ordering into global row order (Pall)
+//   QP          U1: block column k + 1 of the own row blocks >= k + 2
+//   QB          U2: the columns right of block column k + 1 of the own row blocks >= k + 2
+// With one rank the panel is used in place (no pack / gather), U1 covers D_{k+1} and U2 is ONE launch over the whole
+// trailing triangle: the launch sequence of the single-GPU factorisation (chol.hip: factor_lower).
+// ---------------------------------------------------------------------------------------------------------------
+int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, double *A, long long ld, double *y,
+                       ShardBuffers &buf, ShardResult *result) {
+  const int me = plan.rank;
+  const long long B = plan.B, nb = plan.nb, n = plan.n;
+  const long long n_loc = plan.local_rows(me);
+  const bool multi = plan.multi();
+  if (multi && !comm) return AGP_ERR_INVALID_ARGUMENT;
+  int st = AGP_OK;
+  auto Aat = [&](long long lrow, long long gcol) { return A + lrow + gcol * ld; };
+  auto msg_L = [&](int slot) { return buf.msg[slot]; };
+  auto msg_img = [&](int slot) { return buf.msg[slot] + B * B; };
+  auto msg_z = [&](int slot) { return buf.msg[slot] + B * B + 4 * SHARD_IMG; };
+  const long long msg_count = shard_msg_doubles(plan);
+
+  // diagonal block of global block b (owned by this rank): factor in place, keep its tile images, pack the message
+  auto factor_and_pack = [&](long long b) {
+    const long long li = plan.local_index(b), w = plan.width(b);
+    const int slot = (int)(b & 1);
+    double *D = Aat(li * B, b * B);
+    double *img = buf.img_local + li * 4 * SHARD_IMG;
+    ops.factor_diag(QP, D, ld, w, b * B, img, y + li * B);
+    ops.copy2d(QP, msg_L(slot), w, D, ld, w, w);  // L_kk with leading dimension w
+    ops.copy2d(QP, msg_img(slot), 4 * SHARD_IMG, img, 4 * SHARD_IMG, 4 * SHARD_IMG, 1);
+    ops.copy2d(QP, msg_z(slot), B, y + li * B, B, w, 1);
+    ops.record(EV_MSG, QP);
+  };
+
+  if (plan.owner(0) == me) factor_and_pack(0);
+  for (long long k = 0; k < nb && st == AGP_OK; ++k) {
+    const int o = plan.owner(k), slot = (int)(k & 1);
+    const long long w = plan.width(k);
+    if (multi) {
+      if (o == me) ops.wait(QC, EV_MSG);
+      st = comm->broadcast(ops, QC, buf.msg[slot], msg_count, o);
+      if (st != AGP_OK) break;
+      ops.record(EV_BCAST, QC);
+      ops.wait(QP, EV_BCAST);
+    }
+    if (k == nb - 1) break;
+    const long long li0 = plan.first_local_after(me, k);
+    const long long nrows = n_loc - li0 * B > 0 ? n_loc - li0 * B : 0;
+    if (nrows > 0)
+      ops.trsm_rows(QP, Aat(li0 * B, k * B), ld, nrows, w, msg_L(slot), msg_img(slot), msg_z(slot), y + li0 * B);
+    const long long w1 = plan.width(k + 1);
+    const int o1 = plan.owner(k + 1);
+    const double *Q;
+    long long ldq;
+    const int ev_u2_prev = ((k - 1) & 1) ? EV_U2_B : EV_U2_A, ev_u2_cur = (k & 1) ? EV_U2_B : EV_U2_A;
+    if (multi) {
+      const long long cnt_rows = plan.max_blocks_after(k) * B;
+      if (nrows > 0) ops.copy2d(QP, buf.send, cnt_rows, Aat(li0 * B, k * B), ld, nrows, w);
+      ops.record(EV_PACK, QP);
+      // look-ahead: the owner of block k + 1 has everything D_{k+1} still needs in its own panel rows
+      if (k >= 1) ops.wait(QP, ev_u2_prev);  // U2(k - 1) wrote D_{k+1} and the columns U1(k) is about to update
+      if (o1 == me) {
+        const long long li1 = plan.local_index(k + 1);
+        const double *X1 = Aat(li1 * B, k * B);
+        ops.gemm(QP, Aat(li1 * B, (k + 1) * B), ld, X1, ld, X1, ld, w1, w1, w, true, 0);
+        factor_and_pack(k + 1);
+      }
+      ops.wait(QC, EV_PACK);
+      ops.wait(QC, ev_u2_cur);  // U2(k - 2) read pall[slot]
+      st = comm->all_gather(ops, QC, buf.send, buf.recv, cnt_rows * w);
+      if (st != AGP_OK) break;
+      ops.gather_panel(QC, buf.pall[slot], buf.ldp, buf.recv, cnt_rows, w, plan, k);
+      ops.record(EV_GATHER, QC);
+      ops.wait(QP, EV_GATHER);
+      ops.wait(QB, EV_GATHER);
+      Q = buf.pall[slot];
+      ldq = buf.ldp;
+      const long long nlb = plan.n_local_blocks(me);
+      for (long long li = plan.first_local_after(me, k + 1); li < nlb; ++li) {
+        const long long i = plan.global_block(me, li), wi = plan.width(i);
+        const double *Xi = Aat(li * B, k * B);
+        // U1: block column k + 1
+        ops.gemm(QP, Aat(li * B, (k + 1) * B), ld, Xi, ld, Q, ldq, wi, w1, w, false, 0);
+      }
+      for (long long li = plan.first_local_after(me, k + 1); li < nlb; ++li) {
+        const long long i = plan.global_block(me, li), wi = plan.width(i);
+        const double *Xi = Aat(li * B, k * B);
+        // U2: columns (k + 2) B .. end of the row block's own diagonal block
+        const long long ncols = (i * B + wi) - (k + 2) * B;
+        if (ncols > 0) ops.gemm(QB, Aat(li * B, (k + 2) * B), ld, Xi, ld, Q + B, ldq, wi, ncols, w, false, 1);
+      }
+      ops.record(ev_u2_cur, QB);
+    } else {
+      // one rank: the panel stays where it is
+      ops.record(EV_TRSM, QP);
+      Q = Aat((k + 1) * B, k * B);
+      ldq = ld;
+      if (k >= 1) ops.wait(QP, ev_u2_prev);
+      const long long below1 = n - (k + 1) * B;
+      ops.gemm(QP, Aat((k + 1) * B, (k + 1) * B), ld, Q, ldq, Q, ldq, below1, w1, w, true, 0);  // U1 incl. D_{k+1}
+      const long long below2 = n - (k + 2) * B;
+      if (below2 > 0) {
+        ops.wait(QB, EV_TRSM);
+        const double *P2 = Aat((k + 2) * B, k * B);
+        ops.gemm(QB, Aat((k + 2) * B, (k + 2) * B), ld, P2, ld, P2, ld, below2, below2, w, true, 1);
+        ops.record(ev_u2_cur, QB);
+      }
+      factor_and_pack(k + 1);
+    }
+  }
+  if (st != AGP_OK) { (void)ops.sync_all(); return st; }
+
+  // ---- information = L^-T z, row block by row block from the bottom (gp.hpp:68) --------------------------------
+  // t[c] collects sum_r L[r][c] x[r] over the rows this rank owns; the owner of block i needs the sum over all
+  // ranks for its own columns: one small all-reduce per block.  x of the own blocks goes into a zero-padded full
+  // vector that one final all-reduce replicates.
+  // Everything of this phase - arithmetic and collectives - is enqueued on ONE queue (QC): the chain is serial
+  // anyway, and all collectives of the communicator stay on one stream in one order.
+  ops.record(EV_DONE_B, QB);
+  ops.wait(QC, EV_DONE_B);
+  ops.record(EV_DONE_P, QP);
+  ops.wait(QC, EV_DONE_P);
+  const int QS = QC;
+  const long long nlb = plan.n_local_blocks(me);
+  for (long long li = 0; li < nlb; ++li) {
+    const long long i = plan.global_block(me, li);
+    ops.invert_diag(QS, Aat(li * B, i * B), ld, plan.width(i), buf.img_local + li * 4 * SHARD_IMG, buf.W + li * B * B);
+  }
+  ops.fill_zero(QS, buf.t, n);
+  ops.fill_zero(QS, buf.xfull, n);
+  for (long long i = nb - 1; i >= 0 && st == AGP_OK; --i) {
+    const long long w = plan.width(i);
+    if (multi) st = comm->all_reduce(ops, QS, buf.t + i * B, w, 0);
+    if (st != AGP_OK) break;
+    if (plan.owner(i) != me) continue;
+    const long long li = plan.local_index(i);
+    ops.axpby(QS, w, 1., y + li * B, -1., buf.t + i * B, buf.tmp);
+    ops.colvec_dot(QS, buf.W + li * B * B, w, w, w, buf.tmp, 1., 0., nullptr, buf.xfull + i * B);  // x_i = inv(L_ii)^T (z_i - S_i)
+    if (i > 0) ops.colvec_dot(QS, Aat(li * B, 0), ld, w, i * B, buf.xfull + i * B, 1., 1., buf.t, buf.t);
+  }
+  if (st == AGP_OK && multi) st = comm->all_reduce(ops, QS, buf.xfull, n, 0);
+  const int st_sync = ops.sync_all();
+  if (st == AGP_OK) st = st_sync;
+  if (st != AGP_OK) return st;
+
+  // ---- status: every rank learns the log-determinant and the first bad pivot ----
+  double s[2];
+  ops.status(s);
+  double code = s[1] > 0. ? (double)(n + 1) - s[1] : 0.;  // larger = earlier pivot; max over ranks = the first one
+  if (multi) {
+    double host[2] = {s[0], code};
+    double *dev = buf.stat;
+    if (ops.device_memory()) {
+      if ((st = ops.from_host(QC, host, dev, 2)) != AGP_OK) return st;
+    } else {
+      dev[0] = host[0]; dev[1] = host[1];
+    }
+    if ((st = comm->all_reduce(ops, QC, dev, 1, 0)) != AGP_OK) return st;
+    if ((st = comm->all_reduce(ops, QC, dev + 1, 1, 1)) != AGP_OK) return st;
+    if (ops.device_memory()) {
+      if ((st = ops.to_host(QC, dev, host, 2)) != AGP_OK) return st;
+    } else {
+      if ((st = ops.sync_all()) != AGP_OK) return st;
+      host[0] = dev[0]; host[1] = dev[1];
+    }
+    s[0] = host[0];
+    code = host[1];
+  }
+  if (result) {
+    result->log_det = 2. * s[0];
+    result->bad_pivot = code > 0. ? (long long)((double)(n + 1) - code) - 1 : -1;
+  }
+  return code > 0. ? AGP_ERR_NOT_POSITIVE_DEFINITE : AGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// callback backends
+// ---------------------------------------------------------------------------------------------------------------
+struct CallbackShardOps : ShardOps {
+  agp_shard_ops_callbacks cb;
+  double logsum = 0.;
+  long long bad = 0;
+  explicit CallbackShardOps(const agp_shard_ops_callbacks &c) : cb(c) {}
+  void factor_diag(int, double *D, long long ld, long long w, long long pivot_base, double *img, double *zblk) override {
+    double ls = 0.;
+    const long long b = cb.factor_diag(cb.user, D, ld, w, img, zblk, &ls);
+    logsum += ls;
+    if (b > 0 && bad == 0) bad = pivot_base + b;
+  }
+  void trsm_rows(int, double *X, long long ld, long long nrows, long long w, const double *Lkk, const double *img,
+                 const double *z, double *yrows) override {
+    cb.trsm_rows(cb.user, X, ld, nrows, w, Lkk, img, z, yrows);
+  }
+  void gemm(int, double *C, long long ldc, const double *P, long long ldp, const double *Q, long long ldq, long long M,
+            long long N, long long K, bool tri, int) override {
+    cb.gemm(cb.user, C, ldc, P, ldp, Q, ldq, M, N, K, tri ? 1 : 0);
+  }
+  void copy2d(int, double *dst, long long ldd, const double *src, long long lds, long long rows, long long cols) override {
+    cb.copy2d(cb.user, dst, ldd, src, lds, rows, cols);
+  }
+  void invert_diag(int, const double *D, long long ld, long long w, const double *img, double *W) override {
+    cb.invert_diag(cb.user, D, ld, w, img, W);
+  }
+  void colvec_dot(int, const double *W, long long ld, long long m, long long n, const double *v, double alpha, double beta,
+                  const double *base, double *out) override {
+    cb.colvec_dot(cb.user, W, ld, m, n, v, alpha, beta, base, out);
+  }
+  void axpby(int, long long n, double a, const double *x, double b, const double *y, double *out) override {
+    cb.axpby(cb.user, n, a, x, b, y, out);
+  }
+  void fill_zero(int, double *p, long long count) override { cb.fill_zero(cb.user, p, count); }
+  void status(double out[2]) override { out[0] = logsum; out[1] = (double)bad; }
+};
+
+int CallbackComm::staged(ShardOps &ops, int q, double *buf, long long count, int kind, int arg, const double *send,
+                         long long send_count) {
+  // host transport: device data is staged through host memory around the caller's collective
+  if (!ops.device_memory()) {
+    if (kind == 0) return cb.broadcast(cb.user, buf, count, arg) ? AGP_ERR_COMM : AGP_OK;
+    if (kind == 1) return cb.all_gather(cb.user, send, buf, send_count) ? AGP_ERR_COMM : AGP_OK;
+    return cb.all_reduce(cb.user, buf, count, arg) ? AGP_ERR_COMM : AGP_OK;
+  }
+  int st;
+  if ((long long)stage.size() < count + send_count) stage.resize((size_t)(count + send_count));
+  double *h = stage.data(), *hs = h + count;
+  if (kind == 1) {
+    if ((st = ops.to_host(q, send, hs, send_count)) != AGP_OK) return st;
+    if (cb.all_gather(cb.user, hs, h, send_count)) return AGP_ERR_COMM;
+  } else {
+    if ((st = ops.to_host(q, buf, h, count)) != AGP_OK) return st;
+    const int rc = kind == 0 ? cb.broadcast(cb.user, h, count, arg) : cb.all_reduce(cb.user, h, count, arg);
+    if (rc) return AGP_ERR_COMM;
+  }
+  return ops.from_host(q, h, buf, count);
+}
+
+int CallbackComm::broadcast(ShardOps &ops, int q, double *buf, long long count, int root) {
+  return staged(ops, q, buf, count, 0, root, nullptr, 0);
+}
+int CallbackComm::all_gather(ShardOps &ops, int q, const double *send, double *recv, long long count) {
+  return staged(ops, q, recv, count * world, 1, 0, send, count);
+}
+int CallbackComm::all_reduce(ShardOps &ops, int q, double *buf, long long count, int op) {
+  return staged(ops, q, buf, count, 2, op, nullptr, 0);
+}
+int CallbackComm::all_reduce_host(double *buf, long long count, int op) {
+  return cb.all_reduce(cb.user, buf, count, op) ? AGP_ERR_COMM : AGP_OK;
+}
+
+}  // namespace agp
+
+using namespace agp;
+
+extern "C" {
+
+int agp_comm_create_callbacks(int nranks, int rank, const agp_comm_callbacks *cb, agp_comm **out) {
+  if (!out || !cb || nranks < 1 || rank < 0 || rank >= nranks || !cb->broadcast || !cb->all_gather || !cb->all_reduce)
+    return AGP_ERR_INVALID_ARGUMENT;
+  CallbackComm *c = new (std::nothrow) CallbackComm(*cb);
+  if (!c) return AGP_ERR_INVALID_ARGUMENT;
+  c->world = nranks;
+  c->rank = rank;
+  agp_comm *h = new (std::nothrow) agp_comm();
+  if (!h) { delete c; return AGP_ERR_INVALID_ARGUMENT; }
+  h->impl = c;
+  *out = h;
+  return AGP_OK;
+}
+
+void agp_comm_destroy(agp_comm *comm) {
+  if (!comm) return;
+  delete comm->impl;  // virtual: the RCCL transport destroys its communicator
+  delete comm;
+}
+
+int agp_comm_size(const agp_comm *comm) { return comm && comm->impl ? comm->impl->world : 1; }
+int agp_comm_rank(const agp_comm *comm) { return comm && comm->impl ? comm->impl->rank : 0; }
+
+int agp_comm_all_reduce_host(agp_comm *comm, double *buf, int64_t count, int op) {
+  if (!comm || !comm->impl || !buf || count < 0 || (op != 0 && op != 1)) return AGP_ERR_INVALID_ARGUMENT;
+  if (count == 0) return AGP_OK;
+  return comm->impl->all_reduce_host(buf, count, op);
+}
+
+int agp_comm_barrier(agp_comm *comm) {
+  double token = 0.;
+  return agp_comm_all_reduce_host(comm, &token, 1, 0);
+}
+
+int64_t agp_shard_local_rows(int64_t n, int64_t block, int nranks, int rank) {
+  if (n <= 0 || block <= 0 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+  return ShardPlan(n, block, nranks, rank).local_rows(rank);
+}
+
+int64_t agp_shard_global_row(int64_t n, int64_t block, int nranks, int rank, int64_t l) {
+  if (n <= 0 || block <= 0 || nranks < 1 || rank < 0 || rank >= nranks || l < 0) return -1;
+  const ShardPlan p(n, block, nranks, rank);
+  if (l >= p.local_rows(rank)) return -1;
+  return p.global_block(rank, l / block) * block + l % block;
+}
+
+int agp_shard_owner(int64_t block_index, int nranks) {
+  if (block_index < 0 || nranks < 1) return -1;
+  return ShardPlan::owner_of(block_index, nranks);
+}
+
+int64_t agp_shard_work_doubles(int64_t n, int64_t block, int nranks, int rank) {
+  if (n <= 0 || block <= 0 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+  ShardPlan p(n, block, nranks, rank);
+  p.force_comm = shard_force_comm();
+  return shard_work_doubles(p);
+}
+
+int agp_shard_factor_custom(const agp_shard_ops_callbacks *ops, agp_comm *comm, int64_t n, int64_t block, double *A,
+                            int64_t ld, double *y, double *work, double *information, double *log_det,
+                            int64_t *bad_pivot) {
+  if (!ops || !A || !y || !work || n <= 0 || block <= 0 || block % 128 != 0) return AGP_ERR_INVALID_ARGUMENT;
+  if (!ops->factor_diag || !ops->trsm_rows || !ops->gemm || !ops->copy2d || !ops->invert_diag || !ops->colvec_dot ||
+      !ops->axpby || !ops->fill_zero)
+    return AGP_ERR_INVALID_ARGUMENT;
+  const int world = comm && comm->impl ? comm->impl->world : 1, rank = comm && comm->impl ? comm->impl->rank : 0;
+  ShardPlan plan(n, block, world, rank);
+  plan.force_comm = comm && comm->impl && shard_force_comm();
+  if (ld < plan.local_rows(rank)) return AGP_ERR_INVALID_ARGUMENT;
+  CallbackShardOps cops(*ops);
+  ShardBuffers buf;
+  shard_carve(plan, work, &buf);
+  ShardResult res;
+  const int st = shard_factor_solve(cops, comm ? comm->impl : nullptr, plan, A, ld, y, buf, &res);
+  if (log_det) *log_det = res.log_det;
+  if (bad_pivot) *bad_pivot = res.bad_pivot;
+  if (st == AGP_OK && information) std::memcpy(information, buf.xfull, sizeof(double) * (size_t)n);
+  return st;
+}
+
+}  // extern "C"

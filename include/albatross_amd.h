@@ -358,46 +358,107 @@ int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
                       const agp_features *xs, double *mean, double *cov,
                       int out_location);
 
-/* ---- block-level building blocks of the multi-GPU sharded fit ------------ */
-/* One fit sharded block-column-cyclically over the GPUs of a node
- * (albatross_amd/distributed.py): every rank owns whole block columns of the
- * lower triangle of K; per outer block the owner factors the panel and the
- * panel is broadcast (RCCL) so that every rank updates its own block columns.
- * These entry points are the per-rank arithmetic; all pointers are DEVICE
- * pointers unless stated, matrices column-major.  Reference work replaced:
- * the same Fit<GPFit> constructor (models/gp.hpp:61-69) as agp_fit_create. */
+/* ---- multi-GPU: ONE fit sharded over the GPUs of a node ---------------------------------------
+ * The work of the Fit<GPFit> constructor (include/albatross/src/models/gp.hpp:61-69: covariance +
+ * diag(targets.covariance), SerializableLDLT, information = ldlt.solve(y)) and of _fit_impl's Gram
+ * (gp.hpp:281-294) for one dataset, spread over `nranks` processes with one GPU each.
+ *
+ * Layout: ROW-block cyclic.  The training points are cut into row blocks of 512; row block b (the rows
+ * 512 b .. 512 b + 511 of the lower triangle, columns 0 .. 512 (b + 1)) belongs to rank
+ * snake(b) = 0..G-1, G-1..0, ... (equal work per pair of rounds); every rank stacks its row blocks into one
+ * local column-major matrix and builds their Gram entries itself (no communication).  Per block column k:
+ *   owner(k)   LL^T of the 512 x 512 diagonal block (+ the fused forward substitution), BROADCAST of
+ *              L_kk / its tile images / z_k                                  (2.4 MB, RCCL broadcast)
+ *   every rank X = A[own rows > k, k] L_kk^-T on its own rows, y_own -= X z_k
+ *   all ranks  ALL-GATHER of the panel rows (each rank contributes its rows; every xGMI link of every GPU
+ *              carries 1/G of the panel at the same time)                    (RCCL all-gather)
+ *   every rank C[own rows, cols > k] -= X_own P^T                            (fp64 MFMA update kernels)
+ * with one block column of look-ahead: the owner of block k + 1 updates and factors its diagonal block while the
+ * panel of step k is still being gathered and applied.  information = L^-T z follows block by block with one
+ * small all-reduce per block.  Every rank receives the full information vector and log-determinant.
+ *
+ * agp_comm wraps the transport: RCCL (librccl of the ROCm installation, loaded at first use), or - for tests and
+ * for boxes where RCCL cannot be used (it refuses two ranks on one device) - collectives supplied by the caller. */
+typedef struct agp_comm agp_comm;
+#define AGP_COMM_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 calls it and hands the bytes to every rank by any means (a file, MPI, a TCP store). */
+int agp_comm_unique_id(void *id);
+/* ncclCommInitRank on ctx's device; collective over all ranks.  AGP_ERR_COMM when RCCL is unavailable or fails. */
+int agp_comm_create(agp_context *ctx, int nranks, int rank, const void *id, agp_comm **out);
+/* op for all_reduce: 0 = sum, 1 = max */
+typedef struct {
+  void *user;
+  /* every callback works on HOST doubles and returns 0 on success; all ranks call them in the same order */
+  int (*broadcast)(void *user, double *buf, int64_t count, int root);
+  int (*all_gather)(void *user, const double *send, double *recv, int64_t count_per_rank);
+  int (*all_reduce)(void *user, double *buf, int64_t count, int op);
+} agp_comm_callbacks;
+int agp_comm_create_callbacks(int nranks, int rank, const agp_comm_callbacks *cb, agp_comm **out);
+void agp_comm_destroy(agp_comm *comm);
+int agp_comm_size(const agp_comm *comm);
+int agp_comm_rank(const agp_comm *comm);
+/* control-plane helpers for host code (bench.py's barrier and max-over-ranks timing): in-place on host doubles */
+int agp_comm_all_reduce_host(agp_comm *comm, double *buf, int64_t count, int op);
+int agp_comm_barrier(agp_comm *comm);
 
-/* Lower part of one block column of the training Gram: out(i, j) =
- * k(rows_i, cols_j) for i >= j (tiles strictly above the diagonal are
- * skipped), both feature vectors measurement-wrapped by the caller, rows and
- * cols starting at the same training index.  diag_add (device, one value per
- * column, or NULL) is added where i == j.  *nan_flag (host) is set to 1 if any
- * written entry is NaN. */
-int agp_blk_gram(agp_context *ctx, const agp_kernel *k, const agp_features *rows,
-                 const agp_features *cols, double *out, int64_t ld,
-                 const double *diag_add, int *nan_flag);
-/* LL^T panel factorisation of an m x width block column whose diagonal block
- * is at its top (POTRF + TRSM + inner updates over its 128-wide sub-blocks).
- * y (m entries aligned with the rows, or NULL) receives the fused forward
- * substitution.  img: ceil(width / 128) tile images (9216 doubles each).
- * Host outputs: *bad_pivot = first non-positive pivot (0-based, -1 if none),
- * *log_sum = sum of log L_ii of these columns. */
-int agp_blk_panel_factor(agp_context *ctx, double *A, int64_t m, int64_t lda,
-                         int64_t width, double *img, double *y,
-                         int64_t *bad_pivot, double *log_sum);
-/* C (M x N, ldc) -= P (M x K, ldp) * Q (N x K, ldq)^T; tri != 0: only the
- * tiles on / below the diagonal of C. */
-int agp_blk_update(agp_context *ctx, double *C, int64_t ldc, const double *P,
-                   int64_t ldp, const double *Q, int64_t ldq, int64_t M,
-                   int64_t N, int64_t K, int tri);
-/* x = L_BB^-T z for the width x width lower-triangular diagonal block at the
- * top of a factored block column (z overwritten by x). */
-int agp_blk_back_diag(agp_context *ctx, const double *A, int64_t lda,
-                      int64_t width, const double *img, double *z);
-/* z[c] -= sum_r L[r][c] x[r] for c < ncols, r < nrows, L = Arows(r, c). */
-int agp_blk_back_update(agp_context *ctx, const double *Arows, int64_t lda,
-                        int64_t nrows, int64_t ncols, const double *x,
-                        double *z);
+/* ownership arithmetic of the row-block-cyclic layout (pure host functions) */
+int64_t agp_shard_local_rows(int64_t n, int64_t block, int nranks, int rank);
+/* global row of local row l of `rank` (l < agp_shard_local_rows) */
+int64_t agp_shard_global_row(int64_t n, int64_t block, int nranks, int rank, int64_t l);
+int agp_shard_owner(int64_t block_index, int nranks);
+/* doubles of scratch agp_shard_factor_custom needs */
+int64_t agp_shard_work_doubles(int64_t n, int64_t block, int nranks, int rank);
+
+typedef struct agp_sharded_fit agp_sharded_fit;
+/* One fit over all ranks of `comm`; collective.  Every rank passes the SAME full dataset (x, y, y_var as in
+ * agp_fit_create; at x->location) and receives information (n doubles, host, may be NULL) and log_det.
+ * A failure (NaN, non-positive pivot, transport error or timeout: AGP_COMM_TIMEOUT_S seconds, default 120) is
+ * reported with the same status on every rank that can still be reached.  comm == NULL: one rank, no transport. */
+int agp_sharded_fit_create(agp_context *ctx, agp_comm *comm, const agp_kernel *k, const agp_features *x,
+                           const double *y, const double *y_var, agp_sharded_fit **out, double *information,
+                           double *log_det);
+void agp_sharded_fit_destroy(agp_sharded_fit *fit);
+int64_t agp_sharded_fit_failed_pivot(const agp_sharded_fit *fit);
+/* Replicate the factor: all-gather of the row blocks, after which every rank holds an ordinary agp_fit of the whole
+ * problem (the factor of gp.hpp:61-69) and predicts ITS share of the test points with agp_predict_* - predictions
+ * are independent per test point (gp.hpp:82-113), so sharding M needs no further exchange.  Collective. */
+int agp_sharded_fit_replicate(agp_context *ctx, agp_sharded_fit *fit, agp_fit **out);
+/* per-stage device time of the last sharded fit on this rank, ms: 0 gram, 1 factor, 2 back substitution,
+ * 3 sum of the bulk update launches, 4 their count, 5 their algorithmic flop */
+int agp_sharded_fit_stage(const agp_sharded_fit *fit, int stage, double *value);
+
+/* The same schedule (factorisation + both substitutions) on a rank-local matrix the CALLER built, with the block
+ * arithmetic supplied through callbacks instead of the HIP kernels: test instrumentation - tests/ drives the
+ * library's C++ schedule with numpy block operations and gloo collectives on CPU-only machines, world size > 1.
+ * All matrices column-major; pointers are whatever the callbacks understand (host memory in the tests).
+ *   A      local stacked rows (agp_shard_local_rows x n, leading dimension ld), lower staircase filled
+ *   y      the targets of the local rows (agp_shard_local_rows doubles), overwritten
+ *   work   agp_shard_work_doubles doubles of scratch in the same memory space */
+typedef struct {
+  void *user;
+  /* LL^T of the w x w block D (ld) in place, z <- L^-1 z on the w entries at zblk; img: scratch the other callbacks
+   * get back (4 * 9216 doubles); returns 0, or 1 + index of the first non-positive pivot */
+  int64_t (*factor_diag)(void *user, double *D, int64_t ld, int64_t w, double *img, double *zblk, double *logsum);
+  /* X (nrows x w, ld) <- X L^-T with L the w x w lower triangle at Lkk (leading dimension w);
+   * yrows[r] -= sum_c X[r][c] z[c] */
+  void (*trsm_rows)(void *user, double *X, int64_t ld, int64_t nrows, int64_t w, const double *Lkk,
+                    const double *img, const double *z, double *yrows);
+  /* C (M x N, ldc) -= P (M x K, ldp) Q (N x K, ldq)^T; tri: only entries on / below the diagonal of C are needed */
+  void (*gemm)(void *user, double *C, int64_t ldc, const double *P, int64_t ldp, const double *Q, int64_t ldq,
+               int64_t M, int64_t N, int64_t K, int tri);
+  void (*copy2d)(void *user, double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int64_t cols);
+  /* W (w x w, ld = w) <- inv(L) of the factored diagonal block D */
+  void (*invert_diag)(void *user, const double *D, int64_t ld, int64_t w, const double *img, double *W);
+  /* out[c] = alpha sum_r W[r][c] v[r] + beta base[c],  r < m, c < n (base may be NULL when beta == 0) */
+  void (*colvec_dot)(void *user, const double *W, int64_t ld, int64_t m, int64_t n, const double *v, double alpha,
+                     double beta, const double *base, double *out);
+  /* out = a x + b y */
+  void (*axpby)(void *user, int64_t n, double a, const double *x, double b, const double *y, double *out);
+  void (*fill_zero)(void *user, double *p, int64_t count);
+} agp_shard_ops_callbacks;
+int agp_shard_factor_custom(const agp_shard_ops_callbacks *ops, agp_comm *comm, int64_t n, int64_t block, double *A,
+                            int64_t ld, double *y, double *work, double *information, double *log_det,
+                            int64_t *bad_pivot);
 
 /* ---- instrumentation (bench.py) ----------------------------------------- */
 /* Per-stage device time of the LAST fit / nll on this context, measured with

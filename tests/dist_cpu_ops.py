@@ -1,72 +1,116 @@
-"""TEST-ONLY numpy / oracle implementation of the block interface that
-albatross_amd/distributed.py sequences, so that the sharded-fit schedule
-(ownership, panel broadcasts, running y, back substitution) can run on CPU
-tensors over gloo.  The product's HipBlockOps calls the HIP library instead."""
+"""TEST-ONLY numpy implementation of the block arithmetic (`agp_shard_ops_callbacks`, include/albatross_amd.h) that the
+library's C++ sharded-fit schedule (albatross_amd/csrc/shard_sched.hip) is written against, so that the schedule -
+ownership, broadcasts, all-gathers, look-ahead, both substitutions - runs on CPU-only machines over gloo with world
+sizes > 1.  The product uses HipShardOps (the HIP kernels) instead; nothing under albatross_amd/ imports this file."""
+import ctypes as C
+
 import numpy as np
 import scipy.linalg
-import torch
 
-from oracle import oracle_py as orc
+from albatross_amd import _capi as capi
 
 
-class NumpyBlockOps:
-    def empty(self, count):
-        return torch.full((int(count),), float("nan"), dtype=torch.float64)
+def _mat(ptr, ld, rows, cols):
+    """column-major view of rows x cols doubles at `ptr` with leading dimension ld"""
+    rows, cols, ld = int(rows), int(cols), int(ld)
+    if rows <= 0 or cols <= 0:
+        return np.zeros((max(rows, 0), max(cols, 0)))
+    flat = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(ld * (cols - 1) + rows,))
+    return np.lib.stride_tricks.as_strided(flat, shape=(rows, cols), strides=(8, 8 * ld))
 
-    def from_host(self, array):
-        return torch.from_numpy(np.array(array, dtype=np.float64))
 
-    def to_host(self, tensor):
-        return tensor.detach().clone().numpy()
+def _vec(ptr, n):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(int(n),))
 
-    def sync(self):
-        pass
 
-    @staticmethod
-    def _mat(t, offset, ld, rows, cols):
-        return np.lib.stride_tricks.as_strided(t.numpy()[offset:], shape=(rows, cols), strides=(8, 8 * ld))
+class NumpyShardOps:
+    def __init__(self):
+        self.calls = {"factor_diag": 0, "trsm_rows": 0, "gemm": 0}
 
-    def pack_panel(self, col, lda, m, width, buf, ldp):
-        if m - width > 0:
-            self._mat(buf, 0, ldp, m - width, width)[:] = self._mat(col, width, lda, m - width, width)
+        def factor_diag(user, D, ld, w, img, zblk, logsum):
+            self.calls["factor_diag"] += 1
+            A = _mat(D, ld, w, w)
+            L = np.tril(A).copy()
+            bad = 0
+            # unblocked LL^T so that the FIRST non-positive pivot is known (np.linalg.cholesky only raises)
+            for j in range(w):
+                d = L[j, j] - L[j, :j] @ L[j, :j]
+                if not d > 0. and bad == 0:
+                    bad = j + 1
+                L[j, j] = np.sqrt(d) if d > 0. else np.nan
+                L[j + 1:, j] = (L[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+            A[np.tril_indices(w)] = L[np.tril_indices(w)]
+            z = _vec(zblk, w)
+            z[:] = scipy.linalg.solve_triangular(L, z, lower=True, check_finite=False) if bad == 0 else np.nan
+            logsum[0] = float(np.sum(np.log(np.diag(L)))) if bad == 0 else float("nan")
+            return bad
 
-    def gram_block(self, cov, rows_fs, cols_fs, out, ld, diag_add, diag_offset):
-        K = orc.gram(cov, rows_fs, cols_fs, x_meas=True, y_meas=True)
-        if diag_add is not None:
-            w = K.shape[1]
-            K[np.arange(w), np.arange(w)] += diag_add.numpy()[diag_offset:diag_offset + w]
-        view = self._mat(out, 0, ld, K.shape[0], K.shape[1])
-        view[:] = np.tril(K) + np.triu(np.full(K.shape, np.nan), 1)  # the strict upper part is never read
-        return int(np.isnan(np.tril(K)).any())
+        def trsm_rows(user, X, ld, nrows, w, Lkk, img, z, yrows):
+            self.calls["trsm_rows"] += 1
+            Xv = _mat(X, ld, nrows, w)
+            L = np.tril(_mat(Lkk, w, w, w))
+            Xv[:] = scipy.linalg.solve_triangular(L, Xv.T, lower=True, check_finite=False).T
+            y = _vec(yrows, nrows)
+            y -= Xv @ _vec(z, w)
 
-    def panel_factor(self, col, m, lda, width, img, y):
-        A = self._mat(col, 0, lda, m, width)
-        D = np.tril(A[:width]) + np.tril(A[:width], -1).T
-        L, info = orc.llt(D)
-        if info:
-            return info - 1, 0.
-        L = np.tril(L)
-        A[:width] = L + np.triu(np.full((width, width), np.nan), 1)
-        if m > width:
-            A[width:] = scipy.linalg.solve_triangular(L, A[width:].T, lower=True).T
-        yv = y.numpy()
-        yv[:width] = scipy.linalg.solve_triangular(L, yv[:width], lower=True)
-        if m > width:
-            yv[width:m] -= A[width:] @ yv[:width]
-        return -1, float(np.log(np.diag(L)).sum())
+        def gemm(user, Cp, ldc, P, ldp, Q, ldq, M, N, K, tri):
+            self.calls["gemm"] += 1
+            Cv = _mat(Cp, ldc, M, N)
+            upd = _mat(P, ldp, M, K) @ _mat(Q, ldq, N, K).T
+            if tri:  # only the entries on / below the diagonal are required: leave the rest untouched on purpose
+                upd = np.tril(upd)
+            Cv -= upd
 
-    def update(self, col, ldc, buf, row_offset, ldp, M, N, K):
-        P = self._mat(buf, row_offset, ldp, M, K)
-        Cm = self._mat(col, 0, ldc, M, N)
-        upd = P @ P[:N].T
-        mask = np.tril(np.ones((M, N), dtype=bool))
-        Cm[mask] -= upd[mask]
+        def copy2d(user, dst, ldd, src, lds, rows, cols):
+            _mat(dst, ldd, rows, cols)[:] = _mat(src, lds, rows, cols)
 
-    def back_diag(self, col, lda, width, img, z):
-        L = np.tril(self._mat(col, 0, lda, width, width))
-        zv = z.numpy()
-        zv[:width] = scipy.linalg.solve_triangular(L.T, zv[:width], lower=False)
+        def invert_diag(user, D, ld, w, img, W):
+            L = np.tril(_mat(D, ld, w, w))
+            _mat(W, w, w, w)[:] = scipy.linalg.solve_triangular(L, np.eye(w), lower=True, check_finite=False)
 
-    def back_update(self, col, row_offset, lda, nrows, ncols, x, z):
-        Lr = self._mat(col, row_offset, lda, nrows, ncols)
-        z.numpy()[:ncols] -= Lr.T @ x.numpy()[:nrows]
+        def colvec_dot(user, W, ld, m, n, v, alpha, beta, base, out):
+            r = alpha * (_mat(W, ld, m, n).T @ _vec(v, m))
+            if base:
+                r = r + beta * _vec(base, n)
+            _vec(out, n)[:] = r
+
+        def axpby(user, n, a, x, b, y, out):
+            _vec(out, n)[:] = a * _vec(x, n) + b * _vec(y, n)
+
+        def fill_zero(user, p, count):
+            _vec(p, count)[:] = 0.
+
+        self._fns = (capi.FACTOR_DIAG_FN(factor_diag), capi.TRSM_ROWS_FN(trsm_rows), capi.GEMM_FN(gemm),
+                     capi.COPY2D_FN(copy2d), capi.INVERT_DIAG_FN(invert_diag), capi.COLVEC_DOT_FN(colvec_dot),
+                     capi.AXPBY_FN(axpby), capi.FILL_ZERO_FN(fill_zero))
+        self.struct = capi.ShardOpsCallbacks(None, *self._fns)
+
+
+def sharded_factor_numpy(K_lower_full, y, block, comm):
+    """Run the library's schedule on this rank's rows of the dense symmetric matrix K (only its lower triangle is
+    used).  comm: albatross_amd.distributed.Communicator or None.  Returns (status, information, log_det, bad_pivot,
+    ops.calls)."""
+    from albatross_amd.distributed import ShardLayout
+    lib = capi.load()
+    n = K_lower_full.shape[0]
+    world = 1 if comm is None else comm.world
+    rank = 0 if comm is None else comm.rank
+    lay = ShardLayout(n, world, block)
+    rows = lay.global_rows(rank)
+    n_loc = len(rows)
+    assert n_loc == lay.local_rows(rank)
+    ld = max(n_loc, 1) + 3  # an odd padding on purpose
+    A = np.full((ld, n), np.nan, order="F")
+    for l, g in enumerate(rows):  # the staircase: row g holds columns 0 .. end of its own diagonal block
+        end = min(n, (g // block + 1) * block)
+        A[l, :g + 1] = K_lower_full[g, :g + 1]
+        A[l, g + 1:end] = K_lower_full[g + 1:end, g]  # the upper part of the diagonal block may be touched (symmetric)
+    yl = np.ascontiguousarray(y[rows], dtype=np.float64) if n_loc else np.zeros(1)
+    work = np.full(lay.work_doubles(rank), np.nan)
+    info = np.full(n, np.nan)
+    logdet, bad = C.c_double(), C.c_int64(-1)
+    ops = NumpyShardOps()
+    st = lib.agp_shard_factor_custom(C.byref(ops.struct), None if comm is None else comm._h, n, block,
+                                     C.c_void_p(A.ctypes.data), ld, C.c_void_p(yl.ctypes.data), C.c_void_p(work.ctypes.data),
+                                     C.c_void_p(info.ctypes.data), C.byref(logdet), C.byref(bad))
+    return st, info, logdet.value, bad.value, ops.calls

@@ -1,16 +1,24 @@
-"""GPU tests of the sharded-fit path on one rank: the same schedule as the
-gloo tests, but with HipBlockOps (block-level C-ABI on CUDA tensors), with and
-without an initialised single-rank RCCL process group."""
+"""GPU tests of the sharded fit (include/albatross_amd.h: agp_comm_* / agp_sharded_fit_*): the library's schedule with the
+HIP block operations
+  - on one rank without a transport (the launch sequence of the single-GPU factorisation),
+  - on one rank with an RCCL communicator of size one and AGP_SHARD_FORCE_COMM=1: every broadcast, all-gather and
+    all-reduce of the multi-rank schedule goes through RCCL on buffers the kernels wrote,
+  - on TWO processes sharing this box's one GPU, collectives over gloo through the callback transport (RCCL refuses two
+    ranks per device): the real multi-rank data flow with the real kernels,
+and the replicated factor's predictions; all against the oracle."""
 import os
+import socket
+import sys
 
 import numpy as np
 import pytest
 
 import albatross_amd as ab
-from albatross_amd.distributed import HipBlockOps, ShardedGaussianProcessFit
+from albatross_amd.distributed import Communicator, ShardedGaussianProcessFit
 from oracle import oracle_py as orc
 
 pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def problem(n, dim=3):
@@ -22,12 +30,12 @@ def problem(n, dim=3):
     return x, y, yvar
 
 
-@pytest.mark.parametrize("n,block", [(100, 128), (700, 128), (1500, 512), (2048, 512), (1000, 256)])
-def test_sharded_fit_one_rank_matches_oracle(ctx, n, block):
+@pytest.mark.parametrize("n,block", [(100, 128), (700, 128), (1500, 512), (2048, 512), (1000, 256), (3000, 512)])
+def test_sharded_fit_one_rank_matches_oracle(ctx, n, block, monkeypatch):
+    monkeypatch.setenv("AGP_SHARD_BLOCK", str(block))
     x, y, yvar = problem(n)
     cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
-    fit = ShardedGaussianProcessFit(HipBlockOps(ctx, "cuda:0"), cov, block=block)
-    res = fit.fit(x, y, yvar)
+    res = ShardedGaussianProcessFit(ctx, cov).fit(x, y, yvar)
     ofit = orc.OracleFit(cov, x, y, yvar)
     assert np.abs(res.information - ofit.information).max() <= 1e-8 * np.abs(ofit.information).max()
     assert abs(res.log_determinant - ofit.log_determinant) <= 1e-6 * n
@@ -36,32 +44,130 @@ def test_sharded_fit_one_rank_matches_oracle(ctx, n, block):
     assert np.abs(res.information - fm.get_fit().information).max() <= 1e-9 * np.abs(ofit.information).max()
 
 
-def test_sharded_fit_errors(ctx):
+def test_sharded_fit_config3_size_one_rank(ctx):
+    """N = 16384 through the sharded entry point on one rank: same result as agp_fit_create."""
+    from conftest import synthetic_3d
+    x, y = synthetic_3d(16384, 44)
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+    res = ShardedGaussianProcessFit(ctx, cov).fit(x, y)
+    fm = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
+    info = fm.get_fit().information
+    assert np.abs(res.information - info).max() <= 1e-9 * np.abs(info).max()
+    assert abs(res.log_determinant - fm.get_fit().log_determinant) <= 1e-9 * abs(res.log_determinant)
+
+
+def test_sharded_fit_errors(ctx, monkeypatch):
+    monkeypatch.setenv("AGP_SHARD_BLOCK", "128")
     x, y, yvar = problem(600)
-    ops = HipBlockOps(ctx, "cuda:0")
     with pytest.raises(ab.NotPositiveDefiniteError, match="pivot 5"):
-        ShardedGaussianProcessFit(ops, ab.SquaredExponential(1., 1.), block=128).fit(x, y)
+        ShardedGaussianProcessFit(ctx, ab.SquaredExponential(1., 1.)).fit(x, y)
+    xs = np.random.default_rng(99).uniform(0., 10., (600, 3))
+    xs[303] = xs[1]  # singular at a pivot inside a later row block
+    with pytest.raises(ab.NotPositiveDefiniteError, match="pivot 303"):
+        ShardedGaussianProcessFit(ctx, ab.SquaredExponential(1., 1.)).fit(xs, y)
     xn = x.copy()
     xn[300, 0] = np.nan
     with pytest.raises(ab.NanInputError):
-        ShardedGaussianProcessFit(ops, ab.Matern52(2., 1.) + ab.IndependentNoise(0.1), block=128).fit(xn, y)
+        ShardedGaussianProcessFit(ctx, ab.Matern52(2., 1.) + ab.IndependentNoise(0.1)).fit(xn, y)
 
 
-def test_sharded_fit_with_rccl_group_of_one(ctx):
-    import torch
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+@pytest.mark.parametrize("n,block", [(900, 256), (1700, 128), (2048, 512)])
+def test_sharded_fit_through_rccl_group_of_one(ctx, n, block, monkeypatch):
+    """RCCL itself (the ROCm installation's librccl, bound by the library at run time): communicator of size one, the
+    multi-rank schedule forced on, so that ncclBroadcast / ncclAllGather / ncclAllReduce run on the library's streams"""
+    monkeypatch.setenv("AGP_SHARD_BLOCK", str(block))
+    monkeypatch.setenv("AGP_SHARD_FORCE_COMM", "1")
+    comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id())
     try:
-        x, y, yvar = problem(900)
+        assert comm.world == 1 and comm.rank == 0
+        assert comm.all_reduce([3.5, -1.0], "sum").tolist() == [3.5, -1.0]
+        comm.barrier()
+        x, y, yvar = problem(n)
         cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
-        # force_collectives: every panel / solution broadcast and the NaN all-reduce really go
-        # through RCCL (self-broadcast) on buffers written by the HIP library's kernels
-        fit = ShardedGaussianProcessFit(HipBlockOps(ctx, "cuda:0"), cov, block=256, force_collectives=True)
-        assert fit.active and fit.world == 1
-        res = fit.fit(x, y, yvar)
+        sharded = ShardedGaussianProcessFit(ctx, cov, comm)
+        res = sharded.fit(x, y, yvar)
         ofit = orc.OracleFit(cov, x, y, yvar)
         assert np.abs(res.information - ofit.information).max() <= 1e-8 * np.abs(ofit.information).max()
+        assert abs(res.log_determinant - ofit.log_determinant) <= 1e-6 * n
+        # replicated factor (all-gather of the row blocks through RCCL) -> ordinary predictions
+        model = ab.gp_from_covariance(cov, context=ctx)
+        fm = sharded.replicate(model)
+        xs = np.random.default_rng(3).uniform(0., 10., (50, 3))
+        om, ov = ofit.predict_marginal(xs)
+        marg = fm.predict(xs).marginal()
+        assert np.abs(marg.mean - om).max() <= 1e-8 * np.abs(om).max()
+        assert np.abs(marg.covariance - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-9
+        L = fm.get_fit().factor()
+        K = orc.gram(cov, x, x_meas=True) + np.diag(yvar)
+        assert np.abs(L @ L.T - K).max() <= 1e-11 * np.abs(K).max()
+    finally:
+        comm.close()
+
+
+def _worker(rank, world, port, n, block, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["AGP_SHARD_BLOCK"] = str(block)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.init()  # torch's HIP runtime first (tests/conftest.py)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = ab.Context(0)  # every rank on THIS box's one GPU
+        comm = Communicator.from_torch(ctx, transport="callbacks")
+        x, y, yvar = problem(n)
+        cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+        sharded = ShardedGaussianProcessFit(ctx, cov, comm)
+        res = sharded.fit(x, y, yvar)
+        fm = sharded.replicate(ab.gp_from_covariance(cov, context=ctx))
+        xs = np.random.default_rng(3).uniform(0., 10., (64, 3))
+        mine = slice(rank * 64 // world, (rank + 1) * 64 // world)  # this rank's share of the test points
+        marg = fm.predict(xs[mine]).marginal()
+        bad = None
+        try:
+            xb = np.random.default_rng(99).uniform(0., 10., (n, 3))
+            xb[n // 2 + 3] = xb[1]
+            ShardedGaussianProcessFit(ctx, ab.SquaredExponential(1., 1.), comm).fit(xb, y)
+        except ab.NotPositiveDefiniteError as e:
+            bad = str(e)
+        out[rank] = (res.information, res.log_determinant, marg.mean, marg.covariance, bad)
+        comm.close()
+        ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,n,block", [(2, 1500, 128), (3, 2100, 256), (2, 2048, 512)])
+def test_sharded_fit_two_processes_one_gpu(world, n, block):
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    with mpc.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [mpc.Process(target=_worker, args=(r, world, port, n, block, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        x, y, yvar = problem(n)
+        cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+        ofit = orc.OracleFit(cov, x, y, yvar)
+        xs = np.random.default_rng(3).uniform(0., 10., (64, 3))
+        om, ov = ofit.predict_marginal(xs)
+        mean = np.concatenate([out[r][2] for r in range(world)])
+        var = np.concatenate([out[r][3] for r in range(world)])
+        for r in range(world):
+            info, logdet, _, _, bad = out[r]
+            assert np.abs(info - ofit.information).max() <= 1e-8 * np.abs(ofit.information).max()
+            assert abs(logdet - ofit.log_determinant) <= 1e-6 * n
+            assert bad is not None and f"pivot {n // 2 + 3}" in bad
+        assert np.abs(mean - om).max() <= 1e-8 * np.abs(om).max()
+        assert np.abs(var - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-9
+        assert all(np.array_equal(out[0][0], out[r][0]) for r in range(world))
