@@ -11,6 +11,9 @@ variance on the diagonal, in-place LL^T, information vector K^-1 y and log|K|
 Workload = BASELINE.json config 3's problem (3-D SquaredExponential(1,1) +
 IndependentNoise(0.1), N = 16384, fp64), the size the metric is quoted on.
 
+N > 1: `value` is ONE fit of the same problem row-block-sharded over the N GPUs (RCCL inside the library; strong
+scaling); N independent fits ("replicas", weak scaling) are reported in an auxiliary block.
+
 Rank 0 prints ONE JSON line (contract in the task statement) including
   roofline      for the dominant kernel (fp64 MFMA trailing update), from HIP
                 events recorded on the library's stream around every launch
@@ -35,10 +38,21 @@ DIM = 3
 MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix; cross-checked by agp_mfma_f64_peak
 
 
+def mt19937_uniform(seed, count, lo=0., hi=10.):
+    """`std::mt19937 gen(seed); std::uniform_real_distribution<double> dist(lo, hi)` of libstdc++, as the reference's
+    benchmarks draw their features (benchmarks/bench_utils.h:25-34): generate_canonical<double, 53> takes two 32-bit
+    draws, low word first.  Bit-identical to the compiled generator (tests/test_oracle_golden.py checks it on
+    tests/golden/bench512.json)."""
+    rs = np.random.RandomState(seed)  # init_genrand(seed) == std::mt19937(seed)
+    raw = np.frombuffer(rs.bytes(8 * count), dtype="<u4").astype(np.float64)
+    u = (raw[0::2] + raw[1::2] * 4294967296.0) / 18446744073709551616.0
+    return lo + (hi - lo) * np.minimum(u, np.nextafter(1.0, 0.0))
+
+
 def make_dataset(n, seed):
-    """SURVEY.md §8d config 3 generator: X ~ U[0,10]^3, y = sum sin x_k + 0.1 cos(10 x_0)."""
-    rng = np.random.default_rng(seed)
-    x = rng.uniform(0., 10., size=(n, DIM))
+    """SURVEY.md section 8d config 3 generator: X ~ U[0,10]^3 from mt19937(seed), row-major;
+    y = sum_k sin x_k + 0.1 cos(10 x_0)."""
+    x = mt19937_uniform(seed, n * DIM).reshape(n, DIM)
     y = np.sin(x).sum(axis=1) + 0.1 * np.cos(10. * x[:, 0])
     return x, y
 
@@ -81,8 +95,7 @@ def cpu_baseline(seconds_budget=30.0):
     # BASELINE.md section 2, B2 "albatross-faithful, pooled": the Gram over all host cores (callers.hpp:134-166), the
     # factor unchanged (Eigen's LDLT has no parallel path) - the same fit once more with the pooled Gram
     try:
-        import os as _os
-        cores = _os.cpu_count() or 1
+        cores = os.cpu_count() or 1
         xg, yg = make_dataset(n, 44)
         t0 = time.perf_counter()
         fit = orc.OracleFit(cov, xg, yg, threads=cores)
@@ -93,28 +106,43 @@ def cpu_baseline(seconds_budget=30.0):
                               "sample": f"the same oracle fit at N={n} with the Gram pooled over {cores} threads: {t_pooled:.2f} s"}
     except Exception as exc:  # noqa: BLE001 - context only
         out["pooled_gram"] = {"error": f"{type(exc).__name__}: {exc}"}
-    # For context ("strong CPU"): the same fit on all host cores with a blocked,
-    # multi-threaded LAPACK Cholesky (scipy) and a vectorised numpy Gram.  Not the reference's algorithm
-    # (albatross factors with Eigen's unblocked single-threaded LDL^T), so it is reported beside `value`.
+    # For context ("strong CPU"): the same fit with a blocked, multi-threaded LAPACK Cholesky (scipy) and a
+    # vectorised numpy Gram.  Not the reference's algorithm (albatross factors with Eigen's unblocked single-threaded
+    # LDL^T), so it is reported beside `value`.  Timed at N >= 8192 with the BLAS pool pinned to the physical cores
+    # (a small matrix on every hardware thread measures oversubscription, not the factorisation).
     try:
-        import os as _os
         import scipy.linalg as sla
-        m = 4096
-        xs, ys = make_dataset(m, 44)
-        t0 = time.perf_counter()
-        sq = (xs * xs).sum(axis=1)
-        d2 = np.maximum(sq[:, None] + sq[None, :] - 2.0 * (xs @ xs.T), 0.0)
-        K = np.exp(-d2)
-        K[np.diag_indices(m)] += 0.1 * 0.1
-        t_gram = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        c = sla.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
-        sla.cho_solve(c, ys, check_finite=False)
-        t_chol = time.perf_counter() - t0
-        scaled_s = t_gram * (N_TRAIN / m) ** 2 + t_chol * (N_TRAIN / m) ** 3
-        out["strong_cpu"] = {"value": 1.0 / scaled_s, "unit": "fits/sec", "cores": _os.cpu_count(),
-                             "sample": f"numpy Gram ({t_gram:.2f} s, scaled by N^2) + LAPACK dpotrf/dpotrs via scipy on all "
-                                       f"host cores ({t_chol:.2f} s, scaled by N^3) at N={m}"}
+        from threadpoolctl import threadpool_limits
+        threads = max(1, min((os.cpu_count() or 2) // 2, 64))
+
+        def strong_fit(m):
+            xs, ys = make_dataset(m, 44)
+            t0 = time.perf_counter()
+            sq = (xs * xs).sum(axis=1)
+            K = sq[:, None] + sq[None, :] - 2.0 * (xs @ xs.T)
+            np.maximum(K, 0.0, out=K)
+            np.negative(K, out=K)
+            np.exp(K, out=K)
+            K[np.diag_indices(m)] += 0.1 * 0.1
+            t_gram = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            c = sla.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
+            sla.cho_solve(c, ys, check_finite=False)
+            return t_gram, time.perf_counter() - t0
+
+        with threadpool_limits(limits=threads):
+            strong_fit(2048)  # warm the pool
+            t_gram, t_chol = strong_fit(8192)
+            if t_gram + t_chol < 3.0:
+                t_gram, t_chol = strong_fit(N_TRAIN)
+                out["strong_cpu"] = {"value": 1.0 / (t_gram + t_chol), "unit": "fits/sec", "cores": threads,
+                                     "sample": f"numpy Gram ({t_gram:.2f} s) + LAPACK dpotrf/dpotrs via scipy ({t_chol:.2f} s) "
+                                               f"at N={N_TRAIN} itself, BLAS pool pinned to {threads} threads"}
+            else:
+                scaled_s = t_gram * 4.0 + t_chol * 8.0
+                out["strong_cpu"] = {"value": 1.0 / scaled_s, "unit": "fits/sec", "cores": threads,
+                                     "sample": f"numpy Gram ({t_gram:.2f} s, x4) + LAPACK dpotrf/dpotrs via scipy ({t_chol:.2f} s, "
+                                               f"x8) at N=8192, BLAS pool pinned to {threads} threads"}
     except Exception as exc:  # noqa: BLE001 - context only
         out["strong_cpu"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
@@ -125,56 +153,66 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=N_TRAIN)
+    ap.add_argument("--n", type=int, default=N_TRAIN,
+                    help="training points (default 16384 = BASELINE config 3; 32768 / 65536: sizes where sharding one fit pays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predict", action="store_true")
-    ap.add_argument("--force-sharded", action="store_true", help="use the sharded-fit code path even on 1 GPU")
-    ap.add_argument("--sharded-aux", action="store_true",
-                    help="N > 1: also time ONE fit sharded over all ranks (RCCL panel broadcasts) after the timed "
-                         "region; opt-in because a rank failing inside a collective would stall the other ranks")
-    ap.add_argument("--multi-gpu", choices=["sharded", "replicas"], default="replicas",
-                    help="N > 1: 'replicas' (default) = one independent fit per rank, no data-path collective, "
-                         "value = aggregate fits/s (weak scaling); 'sharded' = value is ONE fit block-column-sharded "
-                         "over all ranks with a panel broadcast per 512 columns over RCCL (strong scaling).  The mode "
-                         "that is not `value` is still measured and reported in an auxiliary block.")
+    ap.add_argument("--force-sharded", action="store_true", help="N = 1: time the sharded entry point (one rank, no transport)")
+    ap.add_argument("--multi-gpu", choices=["sharded", "replicas"], default="sharded",
+                    help="N > 1: 'sharded' (default) = `value` is ONE fit row-block-sharded over all ranks (RCCL broadcast + "
+                         "all-gather per block column, strong scaling); 'replicas' = one independent fit per rank, no "
+                         "data-path collective (weak scaling).  The other mode is measured too and reported in an auxiliary block.")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # one process per GPU: N > 1 is launched as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`;
+        # nothing has touched the GPU yet, the launcher can simply be re-run
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"bench.py --gpus {args.gpus} ...`")
+
+    import datetime
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    # BENCH_SINGLE_DEVICE=1 (testing the N > 1 code path on a one-GPU box): every rank uses GPU 0 and the
-    # control collectives (barrier, max of the elapsed times) go over gloo - RCCL refuses two ranks per device.
+    # BENCH_SINGLE_DEVICE=1 (testing the N > 1 code path on a one-GPU box): every rank uses GPU 0 and the collectives of
+    # the sharded fit go over gloo through the library's callback transport - RCCL refuses two ranks per device.
     single_device = os.environ.get("BENCH_SINGLE_DEVICE") == "1"
     if single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    torch.cuda.init()  # torch's HIP runtime first, then the library's (albatross_amd/distributed.py)
-    backend = "none"
+    torch.cuda.init()  # torch's HIP runtime first, then the library's
     if world > 1:
+        # torch.distributed is the CONTROL plane only (rendezvous, exchange of the 128-byte RCCL id): gloo, finite timeout.
+        # The data path - and the barrier / max-over-ranks of the timing - run on the library's own RCCL communicator.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "gloo" if single_device else "nccl"
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend="gloo")
-    ctl_device = f"cuda:{local_rank}" if backend == "nccl" else "cpu"  # where the timing scalars are reduced
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
 
     import albatross_amd as ab
     from albatross_amd import _capi as capi
+    from albatross_amd.distributed import Communicator, ShardedGaussianProcessFit
 
     n = args.n
     ctx = ab.Context(local_rank)
     lib = ctx._lib
     cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
     kh = ctx.kernel(cov)
+    comm = None
+    transport = "none"
+    if world > 1:
+        transport = "callbacks" if single_device else "rccl"
+        comm = Communicator.from_torch(ctx, transport=transport)
+        assert comm.world == world and comm.rank == rank
 
-    # inputs resident in HBM before the timed region
-    x_h, y_h = make_dataset(n, 44 + rank)
+    sharded = (world > 1 and args.multi_gpu == "sharded") or (world == 1 and args.force_sharded)
+    # inputs resident in HBM before the timed region.  Sharded: every rank holds the SAME dataset (one fit over all
+    # ranks); replicas: one dataset per rank.
+    x_h, y_h = make_dataset(n, 44 if sharded or world == 1 else 44 + rank)
     x_d = torch.from_numpy(x_h).to(f"cuda:{local_rank}")
     y_d = torch.from_numpy(y_h).to(f"cuda:{local_rank}")
     torch.cuda.synchronize()
@@ -185,17 +223,9 @@ def main():
     feats.scales = None
     feats.is_measurement = 0
     feats.location = capi.DEVICE
+    sfit = ShardedGaussianProcessFit(ctx, cov, comm) if (sharded or world > 1) else None
 
-    sharded = (world > 1 and args.multi_gpu == "sharded") or args.force_sharded
-    if sharded:
-        from albatross_amd.distributed import HipBlockOps, ShardedGaussianProcessFit
-        x_h, y_h = make_dataset(n, 44)  # every rank holds the same dataset: ONE fit over all ranks
-        sfit = ShardedGaussianProcessFit(HipBlockOps(ctx, f"cuda:{local_rank}"), cov, block=512)
-
-    def step():
-        if sharded:
-            sfit.fit(x_h, y_h)
-            return
+    def replica_step():
         h = C.c_void_p()
         st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
         if st != capi.AGP_OK:
@@ -203,79 +233,78 @@ def main():
                                f"{lib.agp_last_error(ctx._h).decode()}")
         lib.agp_fit_destroy(h)
 
+    def sharded_step():
+        sfit.fit(None, None, features_struct=feats, device_targets=y_d.data_ptr())
+
+    step = sharded_step if sharded else replica_step
+
     def barrier():
-        if world > 1:
-            dist.barrier()
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
         torch.cuda.synchronize()
 
-    ctx.set_profiling(True)
-    for _ in range(args.warmup):
-        step()
-    gemm_ms = gemm_flop = gemm_launches = 0.0
-    gram_ms = factor_ms = solve_ms = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()  # agp_fit_create returns after its stream has drained
-        gram_ms += ctx.stage_ms(0)
-        factor_ms += ctx.stage_ms(1)
-        solve_ms += ctx.stage_ms(2)
-        gemm_ms += ctx.stage_ms(3)
-        gemm_launches += ctx.stage_ms(4)
-        gemm_flop += ctx.stage_ms(5)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=ctl_device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def max_over_ranks(v):
+        return float(comm.all_reduce([v], "max")[0]) if comm is not None else v
 
-    # ---- auxiliary (N > 1): the multi-GPU mode that is not `value` ----
-    replicas = None
-    sharded_aux = None
-    if world > 1 and sharded:
-        def replica_step():
-            h = C.c_void_p()
-            st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
-            if st != capi.AGP_OK:
-                raise RuntimeError("agp_fit_create failed")
-            lib.agp_fit_destroy(h)
-        replica_step()
+    try:
+        ctx.set_profiling(True)
+        for _ in range(args.warmup):
+            step()
+        gemm_ms = gemm_flop = gemm_launches = 0.0
+        gram_ms = factor_ms = solve_ms = 0.0
         barrier()
-        tr = time.perf_counter()
-        for _ in range(3):
-            replica_step()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()  # returns after its streams have drained
+            if sharded:
+                gram_ms += sfit.stage(0)
+                factor_ms += sfit.stage(1)
+                gemm_ms += sfit.stage(3)
+                gemm_launches += sfit.stage(4)
+                gemm_flop += sfit.stage(5)
+            else:
+                gram_ms += ctx.stage_ms(0)
+                factor_ms += ctx.stage_ms(1)
+                solve_ms += ctx.stage_ms(2)
+                gemm_ms += ctx.stage_ms(3)
+                gemm_launches += ctx.stage_ms(4)
+                gemm_flop += ctx.stage_ms(5)
         barrier()
-        tr = time.perf_counter() - tr
-        t = torch.tensor([tr], device=ctl_device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        replicas = {"fits_per_sec": 3 * world / float(t.item()), "note": "one independent fit per GPU, no collective"}
-    if world > 1 and not sharded and args.sharded_aux:
-        # ONE fit sharded over all ranks (albatross_amd/distributed.py): block-column-cyclic LL^T with a
-        # panel broadcast per 512 columns over RCCL.  A failure here is reported, it does not void `value`.
-        try:
-            from albatross_amd.distributed import HipBlockOps, ShardedGaussianProcessFit
-            xs_h, ys_h = make_dataset(n, 44)
-            sf = ShardedGaussianProcessFit(HipBlockOps(ctx, f"cuda:{local_rank}"), cov, block=512)
-            sf.fit(xs_h, ys_h)
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+
+        # ---- auxiliary (N > 1): the multi-GPU mode that is not `value` ----
+        aux = None
+        if world > 1:
+            other = replica_step if sharded else sharded_step
+            if not sharded:  # the sharded mode needs the same dataset on every rank
+                x_h, y_h = make_dataset(n, 44)
+                x_d.copy_(torch.from_numpy(x_h))
+                y_d.copy_(torch.from_numpy(y_h))
+                torch.cuda.synchronize()
+            other()
             barrier()
             tr = time.perf_counter()
             for _ in range(3):
-                res = sf.fit(xs_h, ys_h)
+                other()
             barrier()
-            tr = time.perf_counter() - tr
-            t = torch.tensor([tr], device=ctl_device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sharded_aux = {"single_fit_ms": 1e3 * float(t.item()) / 3, "fits_per_sec": 3 / float(t.item()),
-                           "scaling": "strong",
-                           "note": f"one N={n} fit block-column-sharded over {world} GPUs, RCCL panel broadcasts; "
-                                   "one block column of look-ahead (DESIGN.md section 6)"}
-        except Exception as exc:  # noqa: BLE001 - reported in the JSON line
-            sharded_aux = {"error": f"{type(exc).__name__}: {exc}"}
+            tr = max_over_ranks(time.perf_counter() - tr)
+            if sharded:
+                aux = {"replicas": {"fits_per_sec": 3 * world / tr, "scaling": "weak",
+                                    "note": "one independent fit per GPU (every rank its own copy of the problem), no collective"}}
+            else:
+                aux = {"sharded_single_fit": {"single_fit_ms": 1e3 * tr / 3, "fits_per_sec": 3 / tr, "scaling": "strong",
+                                              "note": f"one N={n} fit row-block-sharded over {world} GPUs"}}
+    except Exception as exc:  # noqa: BLE001
+        # a failed or timed-out collective leaves the other ranks inside theirs: report, and leave with a non-zero code at
+        # once (no destructors, no re-exec: the launcher starts fresh children)
+        sys.stderr.write(f"bench.py rank {rank}: {type(exc).__name__}: {exc}\n")
+        sys.stderr.flush()
+        os._exit(3)
 
     # ---- secondary: predict points/sec at M = 4096 against one resident fit ----
     predict = None
-    if rank == 0 and not args.no_predict and not sharded:
+    if rank == 0 and not args.no_predict and world == 1 and not sharded:
         m = 4096
         xs_h, _ = make_dataset(m, 43)
         xs_d = torch.from_numpy(xs_h).to(f"cuda:{local_rank}")
@@ -307,22 +336,33 @@ def main():
         predict = {"m": m, "mean_pts_per_sec": m / t_mean, "marginal_pts_per_sec": m / t_marg,
                    "mean_ms": 1e3 * t_mean, "marginal_ms": 1e3 * t_marg}
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
-    # the per-launch figure comes from the committed rocprofv3 --pmc passes (profiles/r01/pmc_traffic.json,
-    # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction applied); null if absent.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
-            traffic = json.load(fh)["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the per-launch figure
+    # comes from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read
+    # correction applied) of the single-GPU run; null if absent or not applicable.
+    traffic = traffic_src = None
+    if world == 1 and not sharded and n == N_TRAIN:
+        for rnd in ("r02", "r01"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
+                    traffic = json.load(fh)["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/{rnd}/pmc_traffic.json"
+                break
+            except (OSError, KeyError, ValueError):
+                continue
 
     if rank == 0:
         # sharded: one fit per step over all ranks; replicas: every rank fits its own dataset
         fits = args.steps if (sharded or world == 1) else args.steps * world
-        achieved = (gemm_flop / 1e12) / (gemm_ms * 1e-3) if gemm_ms > 0 else 0.0
+        achieved = (gemm_flop / 1e12) / (gemm_ms * 1e-3) if gemm_ms > 0 else None
+        if sharded and world > 1:
+            parallelism = (f"ONE fit row-block-sharded (512-row blocks, snake-cyclic) over {world} GPUs: per block column an RCCL "
+                           "broadcast of the diagonal block and an all-gather of the panel, one block column of look-ahead")
+            kernel_name = "agp::gemm_nt_sub_kernel (fp64 MFMA updates of rank 0's own row blocks, K=512)"
+        else:
+            parallelism = "1 GPU" if world == 1 else f"{world} independent fits, one per GPU, no data-path collective"
+            kernel_name = "agp::trailing_update_kernel (fp64 MFMA bulk trailing update C -= P P^T, K=512)"
         out = {
-            "metric": "GP fits/sec (Gram+Chol+solve) at N=16384 fp64",
+            "metric": f"GP fits/sec (Gram+Chol+solve) at N={n} fp64",
             "value": fits / elapsed,
             "unit": "fits/sec",
             "n_gpus": world,
@@ -330,40 +370,41 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak",
+            "scaling": "strong" if (sharded and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"dense GP fit, N={n}, 3-D SquaredExponential(1,1)+IndependentNoise(0.1), "
-                                   "inputs resident in HBM (BASELINE config 3 problem)",
-                       "parallelism": ("1 GPU" if world == 1 else
-                                       (f"one fit block-column-sharded over {world} GPUs, panel broadcast per 512 columns (RCCL)"
-                                        if sharded else f"{world} independent fits, one per GPU, no data-path collective"))},
-            "roofline": {
-                "bound": "mfma", "kernel": "agp::trailing_update_kernel (fp64 MFMA bulk trailing update C -= P P^T, K=512)",
+            "config": {"workload": f"dense GP fit, N={n}, 3-D SquaredExponential(1,1)+IndependentNoise(0.1), features from "
+                                   "mt19937(44), inputs resident in HBM (BASELINE config 3 problem)",
+                       "parallelism": parallelism,
+                       "transport": transport, "n_ranks": (comm.world if comm is not None else 1)},
+            "roofline": ({
+                "bound": "mfma", "kernel": kernel_name,
                 "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F64_PEAK_TFLOPS,
                 "traffic": traffic,
-                "traffic_unit": "bytes per launch (rocprofv3 PMC passes, profiles/r01/pmc_traffic.json)",
+                "traffic_unit": f"bytes per launch (rocprofv3 PMC passes, {traffic_src})" if traffic_src else None,
                 "launches_per_fit": gemm_launches / args.steps,
                 "avg_launch_ms": gemm_ms / max(gemm_launches, 1.0),
                 "flop_per_fit": gemm_flop / args.steps,
-            },
+            } if achieved is not None else None),
             "stages_ms_per_fit": {"gram": gram_ms / args.steps, "factor": factor_ms / args.steps,
                                   "backward_solve": solve_ms / args.steps,
                                   "trailing_update_kernels": gemm_ms / args.steps},
         }
+        if sharded:
+            out["stages_ms_per_fit"]["note"] = "sharded entry point: `factor` is host wall time of factorisation + both substitutions"
         if predict is not None:
             out["predict"] = predict
-        if replicas is not None:
-            out["replicas"] = replicas
-        if sharded_aux is not None:
-            out["sharded_single_fit"] = sharded_aux
+        if aux is not None:
+            out.update(aux)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
     ctx.close()
 

@@ -374,3 +374,15 @@ def test_log_likelihood_ignores_target_variance():
     var = rng.uniform(0.1, 0.2, 40)
     assert abs(orc.nll_with_variance(cov, x, y, var) - orc.nll_dense(y, K + np.diag(var))) < 1e-10
     assert abs(orc.nll_with_variance(cov, x, y, var) - orc.nll(cov, x, y)) > 1e-3
+
+
+def test_bench_generator_is_libstdcxx_mt19937():
+    """bench.py's dataset generator against the compiled one: tests/golden/bench512.json holds
+    `std::mt19937 gen(4); std::uniform_real_distribution<double>(0, 10)` (benchmarks/bench_utils.h:25-34) drawn by a C++
+    program (tests/golden/make_golden.py)."""
+    import bench
+    g = golden("bench512.json")
+    assert np.array_equal(bench.mt19937_uniform(4, 512), np.array(g["x"]))
+    x, y = bench.make_dataset(100, 44)
+    assert x.shape == (100, 3) and x.min() >= 0. and x.max() < 10.
+    assert np.array_equal(x.reshape(-1), bench.mt19937_uniform(44, 300))  # row-major fill
