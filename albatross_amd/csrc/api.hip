@@ -110,6 +110,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->partial_ws) (void)hipFree(ctx->partial_ws);
   if (ctx->ws_A) (void)hipFree(ctx->ws_A);
   if (ctx->pool_A) (void)hipFree(ctx->pool_A);
+  if (ctx->pool_shard) (void)hipFree(ctx->pool_shard);
   if (ctx->ws_aux) (void)hipFree(ctx->ws_aux);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -467,7 +468,7 @@ void agp_fit_destroy(agp_fit *fit) {
 // triangular solve against the identity), after which a step is two column-dot launches per 512 rows instead of
 // four fused launches per 128 rows: the chain is launch-latency-bound (AGP_WIDE_BACKSOLVE=0: off, =<width>: other
 // block width).  Otherwise the 128-row chain on 128 x 128 inverses.  ws: backsolve_ws_elems(n) doubles of scratch.
-static long long backsolve_width(long long n) {
+long long backsolve_width(long long n) {
   static int wide = -1;
   if (wide < 0) {
     const char *e = getenv("AGP_WIDE_BACKSOLVE");
@@ -477,14 +478,14 @@ static long long backsolve_width(long long n) {
   return (wide && n >= 4 * BW && n % BW == 0) ? BW : 0;
 }
 
-static size_t backsolve_ws_elems(long long n) {
+size_t backsolve_ws_elems(long long n) {
   const long long BW = backsolve_width(n);
   const size_t blocks = BW ? (size_t)(n / BW) * (size_t)BW * (size_t)BW : (size_t)((n + NB - 1) / NB) * NB * NB;
   return (size_t)round_up(n, 2) + blocks;
 }
 
-static void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
-                                   double *z, double *ws) {
+void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                            double *z, double *ws) {
   double *xs = ws, *W = ws + round_up(n, 2);
   const long long BW = backsolve_width(n);
   if (!BW) {

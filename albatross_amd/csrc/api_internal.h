@@ -82,3 +82,9 @@ int copy_out(agp_context *ctx, const double *dev, long long count, double *dst, 
 int copy_out_2d(agp_context *ctx, const double *dev, long long ld_dev, long long rows, long long cols, double *dst,
                 long long ld_dst, int location);
 int status_from_flags(const agp_context *ctx);
+// x = L^-T z for ONE vector (api.hip): z is overwritten with x; ws: backsolve_ws_elems(n) doubles of scratch
+extern "C" {  // (defined inside api.hip's extern "C" block)
+size_t backsolve_ws_elems(long long n);
+void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long long lda, const double *invd, double *z,
+                            double *ws);
+}

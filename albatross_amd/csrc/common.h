@@ -77,6 +77,9 @@ struct agp_context {
   // (agp_fit_create_mixed sets and resets it around its factor_lower call)
   int update_variant = -1;
   long long nbo_override = 0;  // outer block width of the next factorisation (0 = default schedule)
+  // scratch of the sharded fit (agp_sharded_fit_destroy parks it here, like pool_A)
+  double *pool_shard = nullptr;
+  size_t pool_shard_bytes = 0;
 };
 
 struct agp_fit {

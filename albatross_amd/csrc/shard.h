@@ -92,6 +92,10 @@ struct ShardOps {
   // Pall (rows of the global blocks k+1.., ldP) <- the all-gathered send buffers (default: one copy2d per block)
   virtual void gather_panel(int q, double *Pall, long long ldP, const double *recv, long long cnt_rows, long long w,
                             const ShardPlan &plan, long long k);
+  // msg = [L (w x w, leading dimension w) at 0 | the 4 tile images at B * B | z (w) at B * B + 4 SHARD_IMG]
+  // (default: three copy2d)
+  virtual void pack_msg(int q, double *msg, long long B, const double *D, long long ld, long long w, const double *img,
+                        const double *z);
   virtual void invert_diag(int q, const double *D, long long ld, long long w, const double *img, double *W) = 0;
   virtual void colvec_dot(int q, const double *W, long long ld, long long m, long long n, const double *v, double alpha,
                           double beta, const double *base, double *out) = 0;

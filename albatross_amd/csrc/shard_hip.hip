@@ -176,6 +176,16 @@ __global__ __launch_bounds__(256) void shard_gather_kernel(double *__restrict__ 
   for (long long c = blockIdx.y; c < w; c += gridDim.y) Pall[row + c * ldP] = src[c * cnt_rows];
 }
 
+// the broadcast message of a diagonal block in ONE launch: L (w x w, ld = w) | tile images | z
+__global__ __launch_bounds__(256) void shard_pack_msg_kernel(double *__restrict__ msg, long long B, const double *__restrict__ D,
+                                                            long long ld, long long w, const double *__restrict__ img,
+                                                            const double *__restrict__ z) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < w * w) msg[i] = D[(i % w) + (i / w) * ld];
+  if (i < 4 * SHARD_IMG) msg[B * B + i] = img[i];
+  if (i < w) msg[B * B + 4 * SHARD_IMG + i] = z[i];
+}
+
 __global__ __launch_bounds__(256) void shard_add_diag_kernel(double *A, long long ld, long long lrow0, long long gcol0, long long w,
                                                             const double *yvar) {
   const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -277,6 +287,11 @@ struct HipShardOps : ShardOps {
     const unsigned gy = (unsigned)(cols < 256 ? cols : 256);
     hipLaunchKernelGGL(shard_copy2d_kernel, dim3((unsigned)((rows + 255) / 256), gy), dim3(256), 0, sq[q], dst, ldd, src, lds, rows, cols);
   }
+  void pack_msg(int q, double *msg, long long B, const double *D, long long ld, long long w, const double *img,
+                const double *z) override {
+    const long long count = w * w > 4 * SHARD_IMG ? w * w : 4 * SHARD_IMG;
+    hipLaunchKernelGGL(shard_pack_msg_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, sq[q], msg, B, D, ld, w, img, z);
+  }
   void gather_panel(int q, double *Pall, long long ldP, const double *recv, long long cnt_rows, long long w, const ShardPlan &plan,
                     long long k) override {
     const long long rows = plan.n - (k + 1) * plan.B;
@@ -338,9 +353,11 @@ struct agp_sharded_fit {
   ShardPlan plan;
   double *A = nullptr;      // local stacked rows, column-major, ld
   long long ld = 0;
-  double *work = nullptr;
+  size_t A_bytes = 0;
+  double *work = nullptr;   // scratch of the schedule (ShardBuffers) followed by y
+  size_t work_bytes = 0;
   ShardBuffers buf;
-  double *y = nullptr;      // the local entries of z = L^-1 y
+  double *y = nullptr;      // the local entries of z = L^-1 y (inside `work`)
   DeviceFeatures train;     // all training features (every rank holds the whole dataset)
   double log_det = 0.;
   int64_t failed_pivot = -1;
@@ -393,9 +410,16 @@ int agp_comm_create(agp_context *ctx, int nranks, int rank, const void *id, agp_
 void agp_sharded_fit_destroy(agp_sharded_fit *f) {
   if (!f) return;
   if (f->ctx) (void)hipSetDevice(f->ctx->device);
-  if (f->A) (void)hipFree(f->A);
-  if (f->work) (void)hipFree(f->work);
-  if (f->y) (void)hipFree(f->y);
+  // park the two large buffers in the context for the next fit of the same size (kernels that used them were enqueued
+  // on the context's streams, and so is whatever uses them next)
+  if (f->A) {
+    if (f->ctx && !f->ctx->pool_A) { f->ctx->pool_A = f->A; f->ctx->pool_A_bytes = f->A_bytes; }
+    else (void)hipFree(f->A);
+  }
+  if (f->work) {
+    if (f->ctx && !f->ctx->pool_shard) { f->ctx->pool_shard = f->work; f->ctx->pool_shard_bytes = f->work_bytes; }
+    else (void)hipFree(f->work);
+  }
   f->train.release();
   delete f;
 }
@@ -451,9 +475,24 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
   } while (0)
   if ((st = to_device(ctx, x, true, &f->train)) != AGP_OK) { agp_sharded_fit_destroy(f); return st; }
   f->train.v.meas = 0;
-  SFIT_CHECK(hipMalloc(&f->A, sizeof(double) * (size_t)f->ld * (size_t)n));
-  SFIT_CHECK(hipMalloc(&f->work, sizeof(double) * (size_t)shard_work_doubles(plan)));
-  SFIT_CHECK(hipMalloc(&f->y, sizeof(double) * (size_t)(plan.max_local_blocks() * B + 8)));
+  f->A_bytes = sizeof(double) * (size_t)f->ld * (size_t)n;
+  if (ctx->pool_A && ctx->pool_A_bytes == f->A_bytes) {
+    f->A = ctx->pool_A;
+    ctx->pool_A = nullptr;
+    ctx->pool_A_bytes = 0;
+  } else {
+    SFIT_CHECK(hipMalloc(&f->A, f->A_bytes));
+  }
+  const long long work_doubles = shard_work_doubles(plan);
+  f->work_bytes = sizeof(double) * (size_t)(work_doubles + plan.max_local_blocks() * B + 8);
+  if (ctx->pool_shard && ctx->pool_shard_bytes == f->work_bytes) {
+    f->work = ctx->pool_shard;
+    ctx->pool_shard = nullptr;
+    ctx->pool_shard_bytes = 0;
+  } else {
+    SFIT_CHECK(hipMalloc(&f->work, f->work_bytes));
+  }
+  f->y = f->work + work_doubles;
   shard_carve(plan, f->work, &f->buf);
   const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   // the local targets: block by block in local order
@@ -507,7 +546,50 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
 
   // ---- factorisation + both substitutions ----
   ShardResult res;
-  {
+  if (!plan.multi()) {
+    // ONE rank: the local matrix is the whole matrix - the single-GPU factorisation itself (chol.hip: factor_lower with
+    // its two-stream look-ahead, api.hip: blocked backward substitution), exactly what agp_fit_create runs
+    FactorTimers timers;
+    if (ctx->profiling) {
+      const size_t want = (size_t)(2 * (2 * ((n + NB - 1) / NB) + 4));
+      while (ctx->gemm_events.size() < want) {
+        hipEvent_t e;
+        SFIT_CHECK(hipEventCreate(&e));
+        ctx->gemm_events.push_back(e);
+      }
+      ctx->gemm_flops.assign(want / 2, 0.);
+      timers.ev = ctx->gemm_events.data();
+      timers.flops = ctx->gemm_flops.data();
+      timers.n_ev = (int)want;
+    }
+    factor_lower(ctx, f->A, n, f->ld, f->buf.img_local, f->y, ctx->profiling ? &timers : nullptr);
+    SFIT_CHECK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SFIT_CHECK(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    SFIT_CHECK(hipStreamSynchronize(s));
+    res.log_det = 2. * ctx->h_scalars[0];
+    res.bad_pivot = ctx->h_flags[1] ? (long long)ctx->h_flags[1] - 1 : -1;
+    st = res.bad_pivot >= 0 ? AGP_ERR_NOT_POSITIVE_DEFINITE : AGP_OK;
+    if (st == AGP_OK) {
+      SFIT_CHECK(hipMemcpyAsync(f->buf.xfull, f->y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+      const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * backsolve_ws_elems(n));
+      if (st2 != AGP_OK) { agp_sharded_fit_destroy(f); return st2; }
+      backward_solve_vec_any(s, f->A, n, f->ld, f->buf.img_local, f->buf.xfull, ctx->ws_aux);
+      SFIT_CHECK(hipStreamSynchronize(s));
+      SFIT_CHECK(hipGetLastError());
+    }
+    if (ctx->profiling) {
+      double ms_sum = 0., flop = 0.;
+      for (int i = 0; i + 1 < timers.used; i += 2) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, timers.ev[i], timers.ev[i + 1]);
+        ms_sum += ms;
+        flop += timers.flops[i / 2];
+      }
+      f->stage[3] = ms_sum;
+      f->stage[4] = timers.used / 2;
+      f->stage[5] = flop;
+    }
+  } else {
     HipShardOps ops(ctx);
     if (!ops.ok) { agp_sharded_fit_destroy(f); ctx->last_error = "stream / event creation failed"; return AGP_ERR_HIP; }
     st = shard_factor_solve(ops, tr, plan, f->A, f->ld, f->y, f->buf, &res);

@@ -60,6 +60,13 @@ void shard_carve(const ShardPlan &p, double *w, ShardBuffers *b) {
   }
 }
 
+void ShardOps::pack_msg(int q, double *msg, long long B, const double *D, long long ld, long long w, const double *img,
+                        const double *z) {
+  copy2d(q, msg, w, D, ld, w, w);
+  copy2d(q, msg + B * B, 4 * SHARD_IMG, img, 4 * SHARD_IMG, 4 * SHARD_IMG, 1);
+  copy2d(q, msg + B * B + 4 * SHARD_IMG, B, z, B, w, 1);
+}
+
 void ShardOps::gather_panel(int q, double *Pall, long long ldP, const double *recv, long long cnt_rows, long long w,
                             const ShardPlan &plan, long long k) {
   for (long long i = k + 1; i < plan.nb; ++i) {
@@ -102,9 +109,7 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
     double *D = Aat(li * B, b * B);
     double *img = buf.img_local + li * 4 * SHARD_IMG;
     ops.factor_diag(QP, D, ld, w, b * B, img, y + li * B);
-    ops.copy2d(QP, msg_L(slot), w, D, ld, w, w);  // L_kk with leading dimension w
-    ops.copy2d(QP, msg_img(slot), 4 * SHARD_IMG, img, 4 * SHARD_IMG, 4 * SHARD_IMG, 1);
-    ops.copy2d(QP, msg_z(slot), B, y + li * B, B, w, 1);
+    ops.pack_msg(QP, buf.msg[slot], B, D, ld, w, img, y + li * B);
     ops.record(EV_MSG, QP);
   };
 

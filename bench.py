@@ -206,7 +206,26 @@ def main():
     transport = "none"
     if world > 1:
         transport = "callbacks" if single_device else "rccl"
-        comm = Communicator.from_torch(ctx, transport=transport)
+        if transport == "rccl":
+            # RCCL bootstrap can fail on a box whose network set-up it does not like; every rank must then take the same
+            # exit.  The fallback is the SAME sharded fit with its collectives staged over gloo (slow, and said so in
+            # the JSON line) - a measured line beats none.
+            err = ""
+            try:
+                comm = Communicator.from_torch(ctx, transport="rccl")
+            except Exception as exc:  # noqa: BLE001
+                err = f"{type(exc).__name__}: {exc}"
+            flag = torch.tensor([1.0 if comm is None else 0.0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() > 0:
+                if comm is not None:
+                    comm.close()
+                sys.stderr.write(f"bench.py rank {rank}: RCCL communicator not available ({err or 'failed on another rank'}); "
+                                 "falling back to collectives staged over gloo\n")
+                transport = "callbacks (RCCL communicator could not be created: collectives staged through host memory over gloo)"
+                comm = Communicator.from_torch(ctx, transport="callbacks")
+        else:
+            comm = Communicator.from_torch(ctx, transport="callbacks")
         assert comm.world == world and comm.rank == rank
 
     sharded = (world > 1 and args.multi_gpu == "sharded") or (world == 1 and args.force_sharded)
