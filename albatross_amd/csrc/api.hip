@@ -82,6 +82,22 @@ int agp_context_create(int device_id, agp_context **out) {
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo));
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo));
     AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
+    // CU mask of the end-phase bulk stream: bit i = CU i, and CU i sits on XCD i % 8 (measured with
+    // scripts/probe_cumask.py: dropping the LAST indices keeps the XCDs balanced, dropping i % 32 >= 28 does not).
+    // AGP_MASK_CUS = CUs the bulk stream keeps (multiple of 8; 0 = no masked stream)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
+    int keep = 224;  // scripts/sweep_mask.sh: 224 CUs (28 per XCD) from 8704 remaining rows on is the best pair at N = 16384
+    if (const char *e = getenv("AGP_MASK_CUS")) keep = atoi(e);
+    keep = keep / 8 * 8;
+    if (keep > 0 && keep < cus) {
+      uint32_t mask[16] = {0};
+      for (int i = 0; i < keep && i < 512; ++i) mask[i / 32] |= 1u << (i % 32);
+      if (hipExtStreamCreateWithCUMask(&ctx->stream_masked, (uint32_t)((cus + 31) / 32), mask) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->stream_masked = nullptr;
+      }
+    }
   }
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
@@ -121,6 +137,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->stream_masked) (void)hipStreamDestroy(ctx->stream_masked);
   if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
   delete ctx;
 }

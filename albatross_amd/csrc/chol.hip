@@ -711,6 +711,27 @@ static long long u1_first_below() {
   return v;
 }
 
+// Remaining size at or below which U2 launches are held back on the HOST until their panel has finished
+// (AGP_THROTTLE_BELOW, 0 = never; see factor_lower)
+static long long throttle_below() {
+  static long long v = -1;
+  if (v < 0) {
+    const char *e = getenv("AGP_THROTTLE_BELOW");
+    v = e ? atoll(e) : 8192;
+  }
+  return v;
+}
+
+// Remaining size at or below which the bulk updates run on the CU-masked stream (AGP_MASK_BELOW, 0 = never)
+static long long mask_below() {
+  static long long v = -1;
+  if (v < 0) {
+    const char *e = getenv("AGP_MASK_BELOW");
+    v = e ? atoll(e) : 8704;
+  }
+  return v;
+}
+
 // Right-looking LL^T with one outer block of look-ahead on two streams:
 //   stream  (high priority): panel phase P(j), then U1(j) = update of the
 //            NEXT outer block column, then P(j + 1) ...
@@ -720,6 +741,7 @@ static long long u1_first_below() {
 void factor_lower(agp_context *ctx, double *A, long long n, long long lda, double *invd, double *y,
                   FactorTimers *timers) {
   hipStream_t sa = ctx->stream, sb = ctx->stream2;
+  hipStream_t sb_prev = sb;
   bool have_u2 = false;
   long long K0 = 0;
   const long long nbo_fixed = ctx->nbo_override;
@@ -736,8 +758,25 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);   // U2(j - 1) done
     // U1: block column [kend, next_end), all rows below its diagonal
     timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
+    // Chain-bound phase (few rows left): a stream that sits at an UNSATISFIED hipStreamWaitEvent slows every dependent
+    // launch of the other streams (measured, scripts/probe_chain.py: the panel chain takes 121 instead of 44 us per 128
+    // columns while another stream waits on an event) - and here the bulk stream would wait for the panel chain all the
+    // time.  So the host enqueues the next panel phase first and hands U2(j) to the bulk stream only once P(j) HAS
+    // finished (hipEventQuery): the bulk stream is idle instead of blocked.  In the bulk-bound phase the host must run
+    // far ahead, and the waits of the bulk stream are satisfied by the time it reaches them.
+    // End phase: the bulk updates move to the CU-masked stream.  A bulk update that fills every CU (the 64 x 64-tile
+    // kernel takes all 160 KB of LDS) keeps the panel kernels - 75-79 KB of LDS per workgroup - out until its grid has
+    // drained: POTRF took 400-500 us instead of 30 (profiles/r02), panel chain and bulk update ran one after the
+    // other.  With a few CUs per XCD left free the two overlap.
+    sb = (ctx->stream_masked && (n - kend) <= mask_below()) ? ctx->stream_masked : ctx->stream2;
+    if (sb != sb_prev && have_u2) (void)hipStreamWaitEvent(sb, ctx->ev_b, 0);  // U2(j - 1) ran on the other bulk stream
+    sb_prev = sb;
+    const bool throttle = next_end < n && (n - kend) <= throttle_below();
+    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers);
     if (next_end < n) {
-      if (n - kend <= u1_first_below()) {
+      if (throttle) {
+        while (hipEventQuery(ctx->ev_a) == hipErrorNotReady) {}
+      } else if (n - kend <= u1_first_below()) {
         // late phase: the panel chain is the critical path.  Let U1 have the chip to itself
         // (tens of microseconds) instead of sharing it with the bulk update it is launched with.
         (void)hipEventRecord(ctx->ev_c, sa);
@@ -752,7 +791,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     } else {
       have_u2 = false;
     }
-    panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers);
+    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers);
     K0 = kend;
     kend = next_end;
   }

@@ -54,6 +54,9 @@ struct agp_context {
   hipStream_t stream = nullptr;   // main chain
   hipStream_t stream2 = nullptr;  // look-ahead / side chain
   hipStream_t stream3 = nullptr;  // second bulk stream (hybrid MFMA + VALU experiment)
+  // bulk stream restricted to a CU mask (hipExtStreamCreateWithCUMask): in the chain-bound end phase of the
+  // factorisation the bulk updates run here and leave a few CUs per XCD to the panel chain (chol.hip: factor_lower)
+  hipStream_t stream_masked = nullptr;
   hipEvent_t ev_c = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   std::vector<hipEvent_t> ev_pool;
@@ -188,6 +191,9 @@ namespace agp {
 void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
                         bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
                         long long N, long long K, bool tri);
+void launch_gemm_nt_sub_stair(hipStream_t s, double *C, long long ldc, const double *A, long long lda, const double *B,
+                              long long ldb, long long M, long long N, long long K, int world, int rank, long long lb0,
+                              long long block, long long c0);
 // bulk trailing update of the factorisation: C(M x M, lower tiles) -= P Q^T
 // `timing` (optional): an event pair recorded around the trailing_update_kernel launch of this update
 // (not around the 64-tile tail launch) and the algorithmic flop of exactly the tiles that launch covers;

@@ -189,6 +189,131 @@ __global__ __launch_bounds__(64) void mfma44_probe_kernel(unsigned long long *ou
     }
 }
 
+// ---- launch-chain latency probe ------------------------------------------------------------------------------
+// Synthetic kernels with a chosen static LDS footprint: every workgroup writes a little, then spins `spin` shader
+// clocks.  Used to find out what a dependent launch costs on this part when consecutive kernels of one stream
+// differ (code, LDS size, grid): the panel chain of the factorisation is such a sequence of tiny launches.
+template <int LDS_DOUBLES>
+__global__ __launch_bounds__(256) void chain_probe_kernel(double *buf, long long stride, int spin, int touch) {
+  __shared__ double lds[LDS_DOUBLES > 0 ? LDS_DOUBLES : 1];
+  if (LDS_DOUBLES > 0) lds[threadIdx.x % LDS_DOUBLES] = threadIdx.x;
+  __syncthreads();
+  double v = (LDS_DOUBLES > 0) ? lds[(threadIdx.x + 1) % (LDS_DOUBLES > 0 ? LDS_DOUBLES : 1)] : 1.0;
+  double *p = buf + (long long)blockIdx.x * stride;
+  for (int t = 0; t < touch; ++t) p[threadIdx.x + 256 * t] = p[threadIdx.x + 256 * t] * 0.5 + v;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  while ((long long)(__builtin_amdgcn_s_memtime() - c0) < spin) {}
+}
+
+static void launch_probe(hipStream_t s, int kind, int wgs, double *buf, long long stride, int spin, int touch) {
+  switch (kind) {
+  case 0: hipLaunchKernelGGL(chain_probe_kernel<0>, dim3(wgs), dim3(256), 0, s, buf, stride, spin, touch); break;
+  case 1: hipLaunchKernelGGL(chain_probe_kernel<5120>, dim3(wgs), dim3(256), 0, s, buf, stride, spin, touch); break;   // 40 KB
+  case 2: hipLaunchKernelGGL(chain_probe_kernel<9344>, dim3(wgs), dim3(256), 0, s, buf, stride, spin, touch); break;   // 73 KB
+  default: hipLaunchKernelGGL(chain_probe_kernel<9856>, dim3(wgs), dim3(256), 0, s, buf, stride, spin, touch); break;  // 77 KB
+  }
+}
+
+extern "C" int agp_debug_chain_probe(agp_context *ctx, const int *kinds, const int *wgs, int period, int reps, int spin,
+                                     int touch, int priority_stream, double *us_per_launch) {
+  if (!ctx || !kinds || !wgs || period <= 0 || reps <= 0 || !us_per_launch) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = priority_stream ? ctx->stream : ctx->stream2;
+  const long long stride = 256LL * (touch > 0 ? touch : 1);
+  double *buf = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&buf, sizeof(double) * (size_t)stride * 4096));
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(buf, 0, sizeof(double) * (size_t)stride * 4096, s));
+  hipEvent_t e0, e1;
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e1));
+  for (int i = 0; i < period * 3; ++i) launch_probe(s, kinds[i % period], wgs[i % period], buf, stride, spin, touch);
+  AGP_HIP_CHECK(ctx, hipEventRecord(e0, s));
+  for (int i = 0; i < period * reps; ++i) launch_probe(s, kinds[i % period], wgs[i % period], buf, stride, spin, touch);
+  AGP_HIP_CHECK(ctx, hipEventRecord(e1, s));
+  AGP_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *us_per_launch = 1e3 * ms / (double)(period * reps);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(buf);
+  return AGP_OK;
+}
+
+// the REAL chain: the panel phase (POTRF, TRSM, inner update per 128 columns) of an n x n block, `reps` times
+namespace agp {
+void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *img, double *y,
+                        long long K0, long long kend);
+}
+// blocked: while the chain runs, `blocked` other streams sit at a hipStreamWaitEvent on an event that is recorded
+// behind a long one-workgroup spinner on yet another stream (a queue whose head is an unsatisfied barrier packet)
+extern "C" int agp_debug_panel_chain(agp_context *ctx, int64_t n, int64_t width, int reps, int blocked, double *us_per_phase) {
+  if (!ctx || n <= 0 || width <= 0 || width > n || reps <= 0 || !us_per_phase) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  hipStream_t extra[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t gate = nullptr;
+  double *spinbuf = nullptr;
+  // blocked = -1: only the spinner (a long one-workgroup kernel on another stream), nobody waits on it
+  // blocked = -2: a stream blocked in hipStreamWaitValue32 on host memory, NO kernel running elsewhere
+  unsigned int *flag = nullptr;
+  if (blocked == -2) {
+    AGP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&extra[1], hipStreamNonBlocking));
+    AGP_HIP_CHECK(ctx, hipExtMallocWithFlags((void **)&flag, 64, hipMallocSignalMemory));
+    *flag = 0;
+    AGP_HIP_CHECK(ctx, hipMalloc(&spinbuf, sizeof(double) * 4096));
+    AGP_HIP_CHECK(ctx, hipStreamWaitValue32(extra[1], flag, 1, hipStreamWaitValueEq, 0xffffffffu));
+    hipLaunchKernelGGL(chain_probe_kernel<0>, dim3(1), dim3(256), 0, extra[1], spinbuf, 256, 100, 1);
+  }
+  if (blocked == -1) {
+    AGP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&extra[0], hipStreamNonBlocking));
+    AGP_HIP_CHECK(ctx, hipMalloc(&spinbuf, sizeof(double) * 4096));
+    hipLaunchKernelGGL(chain_probe_kernel<0>, dim3(1), dim3(256), 0, extra[0], spinbuf, 256, 144000000, 1);
+  }
+  if (blocked > 0) {
+    if (blocked > 2) blocked = 2;
+    for (int i = 0; i <= blocked; ++i) AGP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&extra[i], hipStreamNonBlocking));
+    AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&gate, hipEventDisableTiming));
+    AGP_HIP_CHECK(ctx, hipMalloc(&spinbuf, sizeof(double) * 4096));
+    // ~60 ms spinner (2.4 GHz shader clock) on extra[0]; the gate event completes when it ends
+    hipLaunchKernelGGL(chain_probe_kernel<0>, dim3(1), dim3(256), 0, extra[0], spinbuf, 256, 144000000, 1);
+    AGP_HIP_CHECK(ctx, hipEventRecord(gate, extra[0]));
+    for (int i = 1; i <= blocked; ++i) {
+      AGP_HIP_CHECK(ctx, hipStreamWaitEvent(extra[i], gate, 0));
+      hipLaunchKernelGGL(chain_probe_kernel<0>, dim3(1), dim3(256), 0, extra[i], spinbuf + 1024 * i, 256, 100, 1);
+    }
+  }
+  const long long lda = n + 8;
+  double *A = nullptr, *img = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&A, sizeof(double) * (size_t)lda * (size_t)width));
+  AGP_HIP_CHECK(ctx, hipMalloc(&img, sizeof(double) * (size_t)((width + NB - 1) / NB) * 36 * 256));
+  AGP_HIP_CHECK(ctx, hipMemsetAsync(A, 0, sizeof(double) * (size_t)lda * (size_t)width, s));  // zeros: NaN results, same timing
+  hipEvent_t e0, e1;
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e1));
+  agp::panel_phase_public(ctx, s, A, n, lda, img, nullptr, 0, width);
+  AGP_HIP_CHECK(ctx, hipEventRecord(e0, s));
+  for (int r = 0; r < reps; ++r) agp::panel_phase_public(ctx, s, A, n, lda, img, nullptr, 0, width);
+  AGP_HIP_CHECK(ctx, hipEventRecord(e1, s));
+  AGP_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *us_per_phase = 1e3 * ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(A);
+  (void)hipFree(img);
+  if (flag) *flag = 1;  // release the stream blocked on host memory
+  if (blocked != 0) {
+    (void)hipDeviceSynchronize();
+    for (auto st : extra) if (st) (void)hipStreamDestroy(st);
+    if (gate) (void)hipEventDestroy(gate);
+    (void)hipFree(spinbuf);
+    if (flag) (void)hipFree(flag);
+  }
+  return AGP_OK;
+}
+
 #ifdef AGP_POTRF_TIMING
 namespace agp { void read_potrf_timing(unsigned long long *out); }
 extern "C" int agp_debug_potrf_timing(unsigned long long *out) { read_potrf_timing(out); return 0; }
@@ -442,6 +567,58 @@ int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t ldc, const do
   AGP_HIP_CHECK(ctx, hipMemcpy(C, dC, cb, hipMemcpyDeviceToHost));
   (void)hipFree(dC); (void)hipFree(dP);
   return st;
+}
+
+// The same on a stream restricted to a CU mask (hipExtStreamCreateWithCUMask): mask_words 32-bit words, bit i = CU i.
+// At the same time (optional, chain_reps > 0) the panel chain of an n = M block runs on the context's main stream:
+// *chain_us = its time per 512-wide panel phase while the masked bulk updates are in flight.
+int agp_debug_time_masked_update(agp_context *ctx, int64_t M, int64_t K, int variant, int reps, const uint32_t *mask,
+                                 int mask_words, int chain_reps, double *ms_out, double *chain_us) {
+  if (!ctx || M <= 0 || K <= 0 || reps <= 0 || !ms_out) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t sm = nullptr;
+  if (mask && mask_words > 0) AGP_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&sm, (uint32_t)mask_words, mask));
+  else AGP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&sm, hipStreamNonBlocking));
+  const long long ld = M + 8;
+  double *dC = nullptr, *dP = nullptr, *pA = nullptr, *pimg = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&dC, sizeof(double) * (size_t)ld * (size_t)M));
+  AGP_HIP_CHECK(ctx, hipMalloc(&dP, sizeof(double) * (size_t)ld * (size_t)K));
+  AGP_HIP_CHECK(ctx, hipMemset(dC, 0, sizeof(double) * (size_t)ld * (size_t)M));
+  AGP_HIP_CHECK(ctx, hipMemset(dP, 0, sizeof(double) * (size_t)ld * (size_t)K));
+  const long long pw = 512, plda = M + 8;
+  AGP_HIP_CHECK(ctx, hipMalloc(&pA, sizeof(double) * (size_t)plda * (size_t)pw));
+  AGP_HIP_CHECK(ctx, hipMalloc(&pimg, sizeof(double) * 4 * 36 * 256));
+  AGP_HIP_CHECK(ctx, hipMemset(pA, 0, sizeof(double) * (size_t)plda * (size_t)pw));
+  hipEvent_t e0, e1, c0, c1;
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&e1));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&c0));
+  AGP_HIP_CHECK(ctx, hipEventCreate(&c1));
+  for (int r = -2; r < reps; ++r) {
+    if (r == 0) AGP_HIP_CHECK(ctx, hipEventRecord(e0, sm));
+    launch_trailing_update_as(variant, sm, dC, ld, dP, dP, ld, M, K);
+    if (r == 0 && chain_reps > 0) {
+      AGP_HIP_CHECK(ctx, hipEventRecord(c0, ctx->stream));
+      for (int c = 0; c < chain_reps; ++c) agp::panel_phase_public(ctx, ctx->stream, pA, M, plda, pimg, nullptr, 0, pw);
+      AGP_HIP_CHECK(ctx, hipEventRecord(c1, ctx->stream));
+    }
+  }
+  AGP_HIP_CHECK(ctx, hipEventRecord(e1, sm));
+  AGP_HIP_CHECK(ctx, hipDeviceSynchronize());
+  float ms = 0.f;
+  AGP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = (double)ms / reps;
+  if (chain_us) {
+    *chain_us = 0.;
+    if (chain_reps > 0) {
+      AGP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, c0, c1));
+      *chain_us = 1e3 * (double)ms / chain_reps;
+    }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(c0); (void)hipEventDestroy(c1);
+  (void)hipFree(dC); (void)hipFree(dP); (void)hipFree(pA); (void)hipFree(pimg);
+  (void)hipStreamDestroy(sm);
+  return AGP_OK;
 }
 
 // Average milliseconds of `reps` bulk trailing updates of an M x M matrix (device-side random-ish data).

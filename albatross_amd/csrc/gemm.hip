@@ -50,6 +50,11 @@ struct GemmArgs {
   // batched launches (blockIdx.y = batch entry): element offsets per entry; 0 = not batched
   long long batch_C = 0, batch_A = 0, batch_B = 0;
   long long tile_first = 0;  // first tile (in column-major tile order) of this launch: split bulk updates
+  // "staircase" launches of the row-block-sharded fit (shard.h): C = the stacked local row blocks of one rank, the row
+  // tile bi belongs to local block st_lb0 + bi / st_tpb = global block gi (snake deal over st_world ranks) and owns the
+  // tile columns up to its own diagonal tile: bj <= gi * st_tpb - st_c0t + bi % st_tpb.  stair == 0: off.
+  int stair = 0, st_world = 1, st_rank = 0, st_tpb = 4;
+  long long st_lb0 = 0, st_c0t = 0;
 };
 
 // Load this thread's 8 doubles of a 128 x 16 operand chunk.
@@ -154,6 +159,14 @@ __device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int &bi, int &b
     bi = 8 * si + (within & 7);
     bj = 8 * sj + (within >> 3);
     return bi < g.ntr && bj < g.ntc && bi >= bj;
+  }
+  if (g.stair) {
+    const long long id = blockIdx.x;
+    bi = (int)(id % g.ntr);
+    bj = (int)(id / g.ntr);
+    const long long lb = g.st_lb0 + bi / g.st_tpb;
+    const long long gi = lb * g.st_world + ((lb & 1) ? g.st_world - 1 - g.st_rank : g.st_rank);
+    return bj <= gi * g.st_tpb - g.st_c0t + (bi % g.st_tpb);
   }
   bj = 0;
   long long id = blockIdx.x + g.tile_first;
@@ -817,6 +830,23 @@ void launch_gemm_nt_sub_batched(hipStream_t s, double *C, long long ldc, long lo
   else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<false, true>), grid, block, 0, s, g);
   else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_nt_sub_kernel<true, false>), grid, block, 0, s, g);
   else hipLaunchKernelGGL((gemm_nt_sub_kernel<true, true>), grid, block, 0, s, g);
+}
+
+// C (M x N: the stacked local row blocks lb0.. of rank `rank` of `world`, columns from global column c0) -= A B^T on the
+// tiles of the staircase only (see GemmArgs::stair).  block = rows per row block (multiple of 128); c0 a multiple of 128.
+void launch_gemm_nt_sub_stair(hipStream_t s, double *C, long long ldc, const double *A, long long lda, const double *B,
+                              long long ldb, long long M, long long N, long long K, int world, int rank, long long lb0,
+                              long long block, long long c0) {
+  if (M <= 0 || N <= 0 || K <= 0) return;
+  GemmArgs g;
+  g.C = C; g.ldc = ldc; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
+  g.M = M; g.N = N; g.K = K; g.tri = 0;
+  g.remap = 0; g.nsuper = 0; g.nb8 = 0;
+  g.ntr = (int)((M + GT - 1) / GT);
+  g.ntc = (int)((N + GT - 1) / GT);
+  g.stair = 1; g.st_world = world; g.st_rank = rank; g.st_tpb = (int)(block / GT);
+  g.st_lb0 = lb0; g.st_c0t = c0 / GT;
+  hipLaunchKernelGGL((gemm_nt_sub_kernel<false, false>), dim3((unsigned)((long long)g.ntr * g.ntc)), dim3(GEMM_THREADS), 0, s, g);
 }
 
 void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,

@@ -88,6 +88,10 @@ struct ShardOps {
   // bulk != 0: one of the large trailing updates (timed when profiling is on)
   virtual void gemm(int q, double *C, long long ldc, const double *P, long long ldp, const double *Q, long long ldq,
                     long long M, long long N, long long K, bool tri, int bulk) = 0;
+  // U2 of step k on the stacked local matrix A (ld): for every own row block i >= k + 2 (local rows li * B ..), its
+  // columns (k + 2) B .. end of its own diagonal block -= X_i Q^T with X_i = A[rows of i, block column k] and
+  // Q = the panel rows of the global blocks k + 2 .. (ldq).  Default: one gemm per row block.
+  virtual void update_staircase(int q, double *A, long long ld, const double *Q, long long ldq, const ShardPlan &plan, long long k);
   virtual void copy2d(int q, double *dst, long long ldd, const double *src, long long lds, long long rows, long long cols) = 0;
   // Pall (rows of the global blocks k+1.., ldP) <- the all-gathered send buffers (default: one copy2d per block)
   virtual void gather_panel(int q, double *Pall, long long ldP, const double *recv, long long cnt_rows, long long w,
@@ -103,6 +107,11 @@ struct ShardOps {
   virtual void fill_zero(int q, double *p, long long count) = 0;
   virtual void record(int ev, int q) { (void)ev; (void)q; }
   virtual void wait(int q, int ev) { (void)q; (void)ev; }
+  // The HOST waits until the last record of `ev` has completed.  Used instead of wait(q, ev) where the queue would
+  // otherwise sit at an unsatisfied wait for long: on this GPU a stream blocked in hipStreamWaitEvent slows the
+  // dependent launches of every other stream (121 instead of 44 us per 128 columns of the panel chain, measured with
+  // scripts/probe_chain.py), so the collectives and bulk queues are fed only when their inputs are ready.
+  virtual void host_wait(int ev) { (void)ev; }
   // drain every queue; AGP_OK or an error status
   virtual int sync_all() { return AGP_OK; }
   // {sum of log L_ii over this rank's diagonal blocks, 1 + global index of its first non-positive pivot or 0}
@@ -141,6 +150,9 @@ void shard_carve(const ShardPlan &plan, double *work, ShardBuffers *out);
 struct ShardResult {
   double log_det = 0.;
   long long bad_pivot = -1;  // global index of the first non-positive pivot, -1 if none
+  // host time spent ENQUEUEING the factorisation / the back substitution (ms), and total until the device drained:
+  // enqueue ~ total means the host, not the GPU, is the bottleneck
+  double enqueue_factor_ms = 0., enqueue_solve_ms = 0., total_ms = 0.;
 };
 
 // LL^T of the staircase held in A (local stacked rows, ld) + z = L^-1 y + information = L^-T z.

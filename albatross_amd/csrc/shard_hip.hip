@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>  // types and enumerators only; every function goes through the table below
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -148,6 +149,16 @@ struct RcclComm : HostReducingComm {
   }
 };
 
+// A transport that moves nothing (debug: AGP_SHARD_FAKE_WORLD="G,r" times ONE rank's share of a G-rank fit on a box
+// with one GPU - same kernels, same shapes, same launch chain; the peers' data is whatever the buffers hold, so the
+// numerical result is meaningless and the entry point says so by returning AGP_ERR_UNSUPPORTED after timing).
+struct NullComm : HostReducingComm {
+  int broadcast(ShardOps &, int, double *, long long, int) override { return AGP_OK; }
+  int all_gather(ShardOps &, int, const double *, double *, long long) override { return AGP_OK; }
+  int all_reduce(ShardOps &, int, double *, long long, int) override { return AGP_OK; }
+  int all_reduce_host(double *, long long, int) override { return AGP_OK; }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // kernels of the HIP backend that the single-GPU path does not have
 // ---------------------------------------------------------------------------------------------------------------
@@ -282,6 +293,35 @@ struct HipShardOps : ShardOps {
       tused += 2;
     }
   }
+  void update_staircase(int q, double *A, long long ld, const double *Q, long long ldq, const ShardPlan &plan, long long k) override {
+    // ONE launch over all own row blocks >= k + 2: the tiles right of a row block's own diagonal tile exit at once
+    const long long B = plan.B, li2 = plan.first_local_after(plan.rank, k + 1);
+    const long long M = plan.local_rows(plan.rank) - li2 * B, c0 = (k + 2) * B, N = plan.n - c0, K = plan.width(k);
+    if (M <= 0 || N <= 0) return;
+    hipStream_t s = sq[q];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->profiling) {
+      while (tev.size() < tused + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        tev.push_back(e);
+      }
+      if (tev.size() >= tused + 2) { e0 = tev[tused]; e1 = tev[tused + 1]; }
+    }
+    if (e0) (void)hipEventRecord(e0, s);
+    launch_gemm_nt_sub_stair(s, A + li2 * B + c0 * ld, ld, A + li2 * B + k * B * ld, ld, Q, ldq, M, N, K, plan.world, plan.rank, li2, B, c0);
+    if (e0) {
+      (void)hipEventRecord(e1, s);
+      double entries = 0.;  // algorithmic: the entries on / below the diagonal of the own row blocks' columns >= c0
+      for (long long li = li2; li < plan.n_local_blocks(plan.rank); ++li) {
+        const long long i = plan.global_block(plan.rank, li), wi = plan.width(i);
+        entries += (double)wi * (double)(i * B - c0) + 0.5 * (double)wi * (double)(wi + 1);
+      }
+      tflop.resize(tused / 2 + 1);
+      tflop[tused / 2] = 2. * (double)K * entries;
+      tused += 2;
+    }
+  }
   void copy2d(int q, double *dst, long long ldd, const double *src, long long lds, long long rows, long long cols) override {
     if (rows <= 0 || cols <= 0) return;
     const unsigned gy = (unsigned)(cols < 256 ? cols : 256);
@@ -313,6 +353,13 @@ struct HipShardOps : ShardOps {
   }
   void fill_zero(int q, double *p, long long count) override {
     if (count > 0) (void)hipMemsetAsync(p, 0, sizeof(double) * (size_t)count, sq[q]);
+  }
+  void host_wait(int e) override {
+    const auto t0 = std::chrono::steady_clock::now();
+    long long spins = 0;
+    while (hipEventQuery(ev[e]) == hipErrorNotReady) {
+      if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) break;
+    }
   }
   void record(int e, int q) override { (void)hipEventRecord(ev[e], sq[q]); }
   void wait(int q, int e) override { (void)hipStreamWaitEvent(sq[q], ev[e], 0); }
@@ -443,6 +490,18 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
   const long long n = x->n;
   if (n <= 0) return AGP_ERR_INVALID_ARGUMENT;
   HostReducingComm *tr = comm ? comm->impl : nullptr;
+  NullComm fake;
+  bool faked = false;
+  if (!tr) {
+    if (const char *e = getenv("AGP_SHARD_FAKE_WORLD")) {
+      int g = 0, r = 0;
+      if (sscanf(e, "%d,%d", &g, &r) == 2 && g > 1 && r >= 0 && r < g) {
+        fake.world = g; fake.rank = r;
+        tr = &fake;
+        faked = true;
+      }
+    }
+  }
   const int world = tr ? tr->world : 1, rank = tr ? tr->rank : 0;
   const DevProgram *dprog = nullptr;
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
@@ -593,6 +652,8 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
     HipShardOps ops(ctx);
     if (!ops.ok) { agp_sharded_fit_destroy(f); ctx->last_error = "stream / event creation failed"; return AGP_ERR_HIP; }
     st = shard_factor_solve(ops, tr, plan, f->A, f->ld, f->y, f->buf, &res);
+    f->stage[6] = res.enqueue_factor_ms + res.enqueue_solve_ms;
+    f->stage[7] = res.total_ms;
     if (ctx->profiling) {
       double ms_sum = 0., flop = 0.;
       for (size_t i = 0; i + 1 < ops.tused; i += 2) {
@@ -611,6 +672,11 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
   f->stage[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
   f->log_det = res.log_det;
   f->failed_pivot = res.bad_pivot;
+  if (faked) {  // timing-only run: keep the handle for agp_sharded_fit_stage, report that the numbers mean nothing
+    f->comm = nullptr;
+    *out = f;
+    return AGP_ERR_UNSUPPORTED;
+  }
   if (st == AGP_ERR_NOT_POSITIVE_DEFINITE) { *out = f; return st; }  // the handle reports the pivot
   if (st != AGP_OK) { agp_sharded_fit_destroy(f); return st; }
   if (information) SFIT_CHECK(hipMemcpy(information, f->buf.xfull, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));

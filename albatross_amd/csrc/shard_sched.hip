@@ -6,6 +6,7 @@
 // (eigen/serializable_ldlt.hpp:27) and information = ldlt.solve(y) - for ONE dataset over several GPUs.
 //
 // No HIP call is made in this file: with callback backends it runs on machines without a GPU.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +68,15 @@ void ShardOps::pack_msg(int q, double *msg, long long B, const double *D, long l
   copy2d(q, msg + B * B + 4 * SHARD_IMG, B, z, B, w, 1);
 }
 
+void ShardOps::update_staircase(int q, double *A, long long ld, const double *Q, long long ldq, const ShardPlan &plan, long long k) {
+  const long long B = plan.B, nlb = plan.n_local_blocks(plan.rank), w = plan.width(k);
+  for (long long li = plan.first_local_after(plan.rank, k + 1); li < nlb; ++li) {
+    const long long i = plan.global_block(plan.rank, li), wi = plan.width(i);
+    const long long ncols = (i * B + wi) - (k + 2) * B;
+    if (ncols > 0) gemm(q, A + li * B + (k + 2) * B * ld, ld, A + li * B + k * B * ld, ld, Q, ldq, wi, ncols, w, false, 1);
+  }
+}
+
 void ShardOps::gather_panel(int q, double *Pall, long long ldP, const double *recv, long long cnt_rows, long long w,
                             const ShardPlan &plan, long long k) {
   for (long long i = k + 1; i < plan.nb; ++i) {
@@ -113,12 +123,16 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
     ops.record(EV_MSG, QP);
   };
 
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
   if (plan.owner(0) == me) factor_and_pack(0);
   for (long long k = 0; k < nb && st == AGP_OK; ++k) {
     const int o = plan.owner(k), slot = (int)(k & 1);
     const long long w = plan.width(k);
     if (multi) {
-      if (o == me) ops.wait(QC, EV_MSG);
+      if (o == me) ops.host_wait(EV_MSG);
       st = comm->broadcast(ops, QC, buf.msg[slot], msg_count, o);
       if (st != AGP_OK) break;
       ops.record(EV_BCAST, QC);
@@ -146,29 +160,25 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
         ops.gemm(QP, Aat(li1 * B, (k + 1) * B), ld, X1, ld, X1, ld, w1, w1, w, true, 0);
         factor_and_pack(k + 1);
       }
-      ops.wait(QC, EV_PACK);
-      ops.wait(QC, ev_u2_cur);  // U2(k - 2) read pall[slot]
+      ops.host_wait(EV_PACK);
+      ops.host_wait(ev_u2_cur);  // U2(k - 2) read pall[slot]
       st = comm->all_gather(ops, QC, buf.send, buf.recv, cnt_rows * w);
       if (st != AGP_OK) break;
       ops.gather_panel(QC, buf.pall[slot], buf.ldp, buf.recv, cnt_rows, w, plan, k);
       ops.record(EV_GATHER, QC);
       ops.wait(QP, EV_GATHER);
-      ops.wait(QB, EV_GATHER);
       Q = buf.pall[slot];
       ldq = buf.ldp;
       const long long nlb = plan.n_local_blocks(me);
-      for (long long li = plan.first_local_after(me, k + 1); li < nlb; ++li) {
-        const long long i = plan.global_block(me, li), wi = plan.width(i);
-        const double *Xi = Aat(li * B, k * B);
-        // U1: block column k + 1
-        ops.gemm(QP, Aat(li * B, (k + 1) * B), ld, Xi, ld, Q, ldq, wi, w1, w, false, 0);
-      }
-      for (long long li = plan.first_local_after(me, k + 1); li < nlb; ++li) {
-        const long long i = plan.global_block(me, li), wi = plan.width(i);
-        const double *Xi = Aat(li * B, k * B);
-        // U2: columns (k + 2) B .. end of the row block's own diagonal block
-        const long long ncols = (i * B + wi) - (k + 2) * B;
-        if (ncols > 0) ops.gemm(QB, Aat(li * B, (k + 2) * B), ld, Xi, ld, Q + B, ldq, wi, ncols, w, false, 1);
+      // U1: block column k + 1 of ALL own row blocks >= k + 2 (they are contiguous local rows): one rectangle
+      const long long li2 = plan.first_local_after(me, k + 1);
+      const long long rows2 = n_loc - li2 * B;
+      (void)nlb;
+      if (rows2 > 0) {
+        ops.gemm(QP, Aat(li2 * B, (k + 1) * B), ld, Aat(li2 * B, k * B), ld, Q, ldq, rows2, w1, w, false, 0);
+        // U2: the columns from (k + 2) B to the end of every row block's own diagonal block (a staircase)
+        ops.host_wait(EV_GATHER);
+        ops.update_staircase(QB, A, ld, Q + B, ldq, plan, k);
       }
       ops.record(ev_u2_cur, QB);
     } else {
@@ -195,6 +205,8 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
   // t[c] collects sum_r L[r][c] x[r] over the rows this rank owns; the owner of block i needs the sum over all
   // ranks for its own columns: one small all-reduce per block.  x of the own blocks goes into a zero-padded full
   // vector that one final all-reduce replicates.
+  if (result) result->enqueue_factor_ms = ms_since(t_begin);
+  const auto t_solve = std::chrono::steady_clock::now();
   // Everything of this phase - arithmetic and collectives - is enqueued on ONE queue (QC): the chain is serial
   // anyway, and all collectives of the communicator stay on one stream in one order.
   ops.record(EV_DONE_B, QB);
@@ -220,7 +232,9 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
     if (i > 0) ops.colvec_dot(QS, Aat(li * B, 0), ld, w, i * B, buf.xfull + i * B, 1., 1., buf.t, buf.t);
   }
   if (st == AGP_OK && multi) st = comm->all_reduce(ops, QS, buf.xfull, n, 0);
+  if (result) result->enqueue_solve_ms = ms_since(t_solve);
   const int st_sync = ops.sync_all();
+  if (result) result->total_ms = ms_since(t_begin);
   if (st == AGP_OK) st = st_sync;
   if (st != AGP_OK) return st;
 

@@ -424,7 +424,8 @@ int64_t agp_sharded_fit_failed_pivot(const agp_sharded_fit *fit);
  * are independent per test point (gp.hpp:82-113), so sharding M needs no further exchange.  Collective. */
 int agp_sharded_fit_replicate(agp_context *ctx, agp_sharded_fit *fit, agp_fit **out);
 /* per-stage device time of the last sharded fit on this rank, ms: 0 gram, 1 factor, 2 back substitution,
- * 3 sum of the bulk update launches, 4 their count, 5 their algorithmic flop */
+ * 3 sum of the bulk update launches, 4 their count, 5 their algorithmic flop, 6 host time spent enqueueing the
+ * schedule, 7 host time until the device had drained (6 ~ 7: the host is the bottleneck) */
 int agp_sharded_fit_stage(const agp_sharded_fit *fit, int stage, double *value);
 
 /* The same schedule (factorisation + both substitutions) on a rank-local matrix the CALLER built, with the block
