@@ -36,6 +36,40 @@ struct Point {
   long long id;                      // equality id (only when ids are supplied)
 };
 
+// exp(-t) for t >= 0 (NaN in -> NaN out, t = +inf -> 0).  Every radial kernel of the reference ends in such an exp
+// (radial.hpp:25-33,191-198,289-297,461-470) and the Gram kernels are VALU-bound on it: the library exp is ~35
+// instructions per call, half of them v_mov of 64-bit literals feeding v_fmac.  This one is 22: Cody-Waite reduction
+// r = -t - k ln2 (ln2 split so that k ln2_hi is exact), degree-13 Taylor polynomial in Horner form with the
+// coefficients held in SCALAR registers (one v_fma_f64 per step; truncation 4e-18, rounding ~1 ulp), v_ldexp_f64.
+// Accuracy: <= 1.5 ulp against the correctly rounded value (tests/test_gram_gpu.py::test_exp_neg_accuracy).
+__device__ __forceinline__ double horner_step(double p, double r, double c) {
+  double o;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
+  return o;
+}
+
+__device__ __forceinline__ double exp_neg(double t) {
+  t = (t > 1100.) ? 1100. : t;  // exp(-1100) = 0 in fp64; keeps +inf out of the reduction, lets NaN through
+  const double kf = __builtin_rint(t * -1.4426950408889634074);
+  double r = __builtin_fma(kf, -6.93147180369123816490e-01, -t);
+  r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;             // 1/13!
+  p = horner_step(p, r, 2.0876756987868100e-09);  // 1/12!
+  p = horner_step(p, r, 2.5052108385441720e-08);  // 1/11!
+  p = horner_step(p, r, 2.7557319223985888e-07);  // 1/10!
+  p = horner_step(p, r, 2.7557319223985893e-06);  // 1/9!
+  p = horner_step(p, r, 2.4801587301587302e-05);  // 1/8!
+  p = horner_step(p, r, 1.9841269841269841e-04);  // 1/7!
+  p = horner_step(p, r, 1.3888888888888889e-03);  // 1/6!
+  p = horner_step(p, r, 8.3333333333333332e-03);  // 1/5!
+  p = horner_step(p, r, 4.1666666666666664e-02);  // 1/4!
+  p = horner_step(p, r, 1.6666666666666666e-01);  // 1/3!
+  p = horner_step(p, r, 0.5);
+  p = horner_step(p, r, 1.0);
+  p = horner_step(p, r, 1.0);
+  return __builtin_ldexp(p, (int)kf);
+}
+
 // The evaluation stack is an 8-wide fp64 vector indexed by the wave-uniform
 // stack pointer: the backend lowers that to VGPR-indexed moves (no scratch,
 // no LDS), which a plain `double st[8]` does not get.
@@ -104,15 +138,15 @@ __device__ __forceinline__ double eval_pair(const DevProgram *__restrict__ Pp, c
         v = 0.;
       } else if (op == AGP_OP_SQUARED_EXPONENTIAL) {
         const double q = dist / l;
-        v = sigma * sigma * exp(-(q * q));  // exp(-pow(d/l, 2))
+        v = sigma * sigma * exp_neg(q * q);  // exp(-pow(d/l, 2))
       } else if (op == AGP_OP_EXPONENTIAL) {
-        v = sigma * sigma * exp(-fabs(dist / l));
+        v = sigma * sigma * exp_neg(fabs(dist / l));
       } else if (op == AGP_OP_MATERN32) {
         const double q = sqrt(3.) * dist / l;
-        v = sigma * sigma * (1 + q) * exp(-q);
+        v = sigma * sigma * (1 + q) * exp_neg(q);
       } else {
         const double q = sqrt(5.) * dist / l;
-        v = sigma * sigma * (1 + q + q * q / 3.) * exp(-q);
+        v = sigma * sigma * (1 + q + q * q / 3.) * exp_neg(q);
       }
       stack_set(st, sp, v);
       ++sp;

@@ -124,22 +124,28 @@ struct FastParams {
   double noise_var;   // sigma_noise^2 (0 when there is no noise term)
   int has_noise;      // tree is radial + noise
   int noise_meas_only;  // the noise term is wrapped in MeasurementOnly
+  // host-side precomputation (match_fast): the pair loop multiplies instead of dividing
+  double sigma2;      // sigma^2
+  double inv_l2;      // SquaredExponential: 1 / l^2      (exp(-(d/l)^2) = exp(-d^2 / l^2): no sqrt, no divide per pair)
+  double cq;          // Exponential: 1 / l, Matern-3/2: sqrt(3) / l, Matern-5/2: sqrt(5) / l
 };
 
+// k(x, y) from the SQUARED Euclidean distance s2 (radial.hpp:25-33,191-198,289-297,461-470).  Differs from the
+// reference's operation sequence (sqrt, divide by l, square) by a few ulp of the exponent argument; the parity bar of
+// tests/test_gram_gpu.py (4e-16 max|K| + 2e-14 |value|) holds with a margin of 10x.
 template <int OP>
-__device__ __forceinline__ double radial_value(double dist, double l, double sigma) {
-  if (l <= 0.) return 0.;
+__device__ __forceinline__ double radial_fast(double s2, const FastParams &fp) {
+  if (fp.length_scale <= 0.) return 0.;
   if (OP == AGP_OP_SQUARED_EXPONENTIAL) {
-    const double q = dist / l;
-    return sigma * sigma * exp(-(q * q));
+    return fp.sigma2 * exp_neg(s2 * fp.inv_l2);
   } else if (OP == AGP_OP_EXPONENTIAL) {
-    return sigma * sigma * exp(-fabs(dist / l));
+    return fp.sigma2 * exp_neg(sqrt(s2) * fp.cq);
   } else if (OP == AGP_OP_MATERN32) {
-    const double q = sqrt(3.) * dist / l;
-    return sigma * sigma * (1 + q) * exp(-q);
+    const double q = sqrt(s2) * fp.cq;
+    return fp.sigma2 * (1 + q) * exp_neg(q);
   } else {
-    const double q = sqrt(5.) * dist / l;
-    return sigma * sigma * (1 + q + q * q / 3.) * exp(-q);
+    const double q = sqrt(s2) * fp.cq;
+    return fp.sigma2 * (1 + q + q * q / 3.) * exp_neg(q);
   }
 }
 
@@ -177,39 +183,27 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_fast_kernel(FastParams fp, 
   const bool wide = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   const bool noise_on = fp.has_noise && (!fp.noise_meas_only || (X.meas && Y.meas));
   bool saw_nan = false;
-#pragma unroll 2
   for (int jj = 0; jj < TN / 4; ++jj) {
     const int cslot = cgrp * (TN / 4) + jj;
     const long long col = col0 + cslot;
     if (col >= Y.n) break;
-    double da, db;
     bool ea = true, eb = true;
-    if (DIMP == 1) {
-      const double y0 = ys[0][cslot];
-      da = fabs(xa[0] - y0);
-      db = fabs(xb[0] - y0);
-      ea = xa[0] == y0;
-      eb = xb[0] == y0;
-    } else {
-      double sa = 0., sb = 0.;
+    double sa = 0., sb = 0.;
 #pragma unroll
-      for (int d = 0; d < DIMP; ++d) {
-        const double yd = ys[d][cslot];
-        const double ta = xa[d] - yd, tb = xb[d] - yd;
-        sa += ta * ta;
-        sb += tb * tb;
-        ea = ea && (xa[d] == yd);
-        eb = eb && (xb[d] == yd);
-      }
-      da = sqrt(sa);
-      db = sqrt(sb);
+    for (int d = 0; d < DIMP; ++d) {
+      const double yd = ys[d][cslot];
+      const double ta = xa[d] - yd, tb = xb[d] - yd;
+      sa += ta * ta;
+      sb += tb * tb;
+      ea = ea && (xa[d] == yd);
+      eb = eb && (xb[d] == yd);
     }
     if (have_ids) {
       ea = ida == yid[cslot];
       eb = idb == yid[cslot];
     }
-    double va = radial_value<OP>(da, fp.length_scale, fp.sigma);
-    double vb = radial_value<OP>(db, fp.length_scale, fp.sigma);
+    double va = radial_fast<OP>(sa, fp);
+    double vb = radial_fast<OP>(sb, fp);
     if (fp.has_noise) {  // lhs + rhs with rhs = noise (0 when not measurements / not equal)
       va = va + ((noise_on && ea) ? fp.noise_var : 0.);
       vb = vb + ((noise_on && eb) ? fp.noise_var : 0.);
@@ -239,6 +233,9 @@ static bool match_fast(const DevProgram &H, FastParams *fp, int *op) {
   *op = n[0].op;
   fp->length_scale = n[0].params[0];
   fp->sigma = n[0].params[1];
+  fp->sigma2 = fp->sigma * fp->sigma;
+  fp->inv_l2 = fp->length_scale > 0. ? 1. / (fp->length_scale * fp->length_scale) : 0.;
+  fp->cq = fp->length_scale > 0. ? (n[0].op == AGP_OP_MATERN32 ? sqrt(3.) : (n[0].op == AGP_OP_MATERN52 ? sqrt(5.) : 1.)) / fp->length_scale : 0.;
   fp->noise_var = 0.; fp->has_noise = 0; fp->noise_meas_only = 0;
   if (H.n_nodes == 1) return true;
   const bool is_noise = n[1].op == AGP_OP_INDEPENDENT_NOISE || n[1].op == AGP_OP_NUGGET;
@@ -407,27 +404,18 @@ __global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_fast_kernel(FastPa
   const long long yid = have_ids ? XS.ids[j] : -1;
   const bool noise_on = fp.has_noise && (!fp.noise_meas_only || (X.meas && XS.meas));
   double acc = 0.;
-#pragma unroll 2
   for (long long i = lane; i < X.n; i += 64) {
-    double dist;
     bool eq = true;
-    if (DIMP == 1) {
-      const double x0 = X.coords[i];
-      dist = fabs(x0 - y[0]);
-      eq = x0 == y[0];
-    } else {
-      double s = 0.;
+    double s = 0.;
 #pragma unroll
-      for (int d = 0; d < DIMP; ++d) {
-        const double xd = X.coords[i * DIMP + d];
-        const double t = xd - y[d];
-        s += t * t;
-        eq = eq && (xd == y[d]);
-      }
-      dist = sqrt(s);
+    for (int d = 0; d < DIMP; ++d) {
+      const double xd = X.coords[i * DIMP + d];
+      const double t = xd - y[d];
+      s += t * t;
+      eq = eq && (xd == y[d]);
     }
     if (have_ids) eq = X.ids[i] == yid;
-    double v = radial_value<OP>(dist, fp.length_scale, fp.sigma);
+    double v = radial_fast<OP>(s, fp);
     if (fp.has_noise) v = v + ((noise_on && eq) ? fp.noise_var : 0.);
     acc += v * alpha[i];
   }

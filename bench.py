@@ -372,7 +372,7 @@ def main():
     if rank == 0:
         # sharded: one fit per step over all ranks; replicas: every rank fits its own dataset
         fits = args.steps if (sharded or world == 1) else args.steps * world
-        achieved = (gemm_flop / 1e12) / (gemm_ms * 1e-3) if gemm_ms > 0 else None
+        achieved = (gemm_flop / 1e12) / (gemm_ms * 1e-3) if gemm_ms > 0 else 0.0  # 0: no launch of that kernel at this size
         if sharded and world > 1:
             parallelism = (f"ONE fit row-block-sharded (512-row blocks, snake-cyclic) over {world} GPUs: per block column an RCCL "
                            "broadcast of the diagonal block and an all-gather of the panel, one block column of look-ahead")
@@ -397,7 +397,7 @@ def main():
                                    "mt19937(44), inputs resident in HBM (BASELINE config 3 problem)",
                        "parallelism": parallelism,
                        "transport": transport, "n_ranks": (comm.world if comm is not None else 1)},
-            "roofline": ({
+            "roofline": {
                 "bound": "mfma", "kernel": kernel_name,
                 "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F64_PEAK_TFLOPS,
@@ -406,7 +406,7 @@ def main():
                 "launches_per_fit": gemm_launches / args.steps,
                 "avg_launch_ms": gemm_ms / max(gemm_launches, 1.0),
                 "flop_per_fit": gemm_flop / args.steps,
-            } if achieved is not None else None),
+            },
             "stages_ms_per_fit": {"gram": gram_ms / args.steps, "factor": factor_ms / args.steps,
                                   "backward_solve": solve_ms / args.steps,
                                   "trailing_update_kernels": gemm_ms / args.steps},

@@ -194,3 +194,26 @@ def test_random_covariance_trees_match_oracle(ctx, seed):
             gc = ctx.gram(cov, ab.Measurement(x) if x_meas else x, ab.Measurement(xs) if y_meas else xs)
             wc = orc.gram(cov, x, xs, x_meas=x_meas, y_meas=y_meas)
             assert close(gc, wc), cov.get_name()
+
+
+def test_exp_neg_accuracy(ctx):
+    """The library's own exp(-t) (csrc/cov_eval.h: Cody-Waite reduction + degree-13 polynomial, 22 instructions)
+    against the correctly rounded value (mpmath, 40 digits): <= 1.5 ulp over the whole range, exact at the edge cases."""
+    import ctypes as C
+    import mpmath as mp
+    mp.mp.dps = 40
+    lib = ctx._lib
+    lib.agp_debug_exp_neg.restype = C.c_int
+    lib.agp_debug_exp_neg.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    rng = np.random.default_rng(0)
+    t = np.concatenate([rng.uniform(0., 40., 4000), rng.uniform(0., 1., 2000), rng.uniform(40., 700., 1000),
+                        np.array([0., 1e-300, 0.34657359027997264, 0.6931471805599453, 36., 708., 745., 1e6, np.inf, np.nan])])
+    out = np.empty_like(t)
+    assert lib.agp_debug_exp_neg(ctx._h, C.c_void_p(t.ctypes.data), t.size, C.c_void_p(out.ctypes.data)) == 0
+    assert out[-5] < 1e-300 and out[-4] < 1e-300 and out[-3] == 0. and out[-2] == 0. and np.isnan(out[-1])  # 708, 745: denormal range
+    assert out[-10] == 1.
+    worst = 0.
+    for ti, vi in zip(t[:-5], out[:-5]):
+        exact = mp.exp(-mp.mpf(float(ti)))
+        worst = max(worst, float(abs(mp.mpf(float(vi)) - exact) / mp.mpf(float(np.spacing(float(exact))))))
+    assert worst <= 1.5, worst
