@@ -749,7 +749,7 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
   return AGP_OK;
 }
 
-int64_t agp_fit_size(const agp_fit *fit) { return fit ? fit->n : 0; }
+int64_t agp_fit_size(const agp_fit *fit) { return fit ? fit_real_rows(fit) : 0; }
 int64_t agp_fit_failed_pivot(const agp_fit *fit) { return fit ? fit->failed_pivot : -1; }
 
 int agp_fit_log_determinant(const agp_fit *fit, double *out) {
@@ -761,13 +761,35 @@ int agp_fit_log_determinant(const agp_fit *fit, double *out) {
 int agp_fit_download_information(agp_context *ctx, const agp_fit *fit, double *information) {
   if (!ctx || !fit || !information || !fit->alpha) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!fit->phantom.empty()) return fit_compact_vector(ctx, fit, fit->alpha, information, AGP_HOST);
   return copy_out(ctx, fit->alpha, fit->n, information, AGP_HOST);
 }
 
 int agp_fit_download_factor(agp_context *ctx, const agp_fit *fit, double *L, int64_t ld) {
-  if (!ctx || !fit || !L || ld < fit->n) return AGP_ERR_INVALID_ARGUMENT;
+  if (!ctx || !fit || !L || ld < fit_real_rows(fit)) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long n = fit->n;
+  if (!fit->phantom.empty()) {
+    // drop the phantom rows AND columns: they are decoupled (identity rows), what remains is the factor of the real matrix
+    const long long nr = fit_real_rows(fit), ldt = round_up(nr, 2);
+    int st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * ((size_t)fit->lda * (size_t)n + (size_t)ldt * (size_t)n));
+    if (st != AGP_OK) return st;
+    double *full = ctx->ws_aux, *rows = full + (size_t)fit->lda * (size_t)n;
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(full, fit->A, sizeof(double) * (size_t)fit->lda * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    launch_zero_upper(ctx->stream, full, fit->lda, n);
+    if ((st = fit_compact_matrix(ctx, fit, full, fit->lda, n, rows, ldt, AGP_DEVICE)) != AGP_OK) return st;  // rows: nr x n
+    // columns: one strided copy per run of real columns
+    long long pad = 0, real = 0;
+    auto copy_cols = [&](long long p0, long long r0, long long len) -> int {
+      return copy_out_2d(ctx, rows + p0 * ldt, ldt, nr, len, L + r0 * ld, ld, AGP_HOST);
+    };
+    for (const auto &ph : fit->phantom) {
+      if (ph.first > pad) { if ((st = copy_cols(pad, real, ph.first - pad)) != AGP_OK) return st; real += ph.first - pad; }
+      pad = ph.second;
+    }
+    if (n > pad && (st = copy_cols(pad, real, n - pad)) != AGP_OK) return st;
+    return AGP_OK;
+  }
   int st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)fit->lda * (size_t)n);
   if (st != AGP_OK) return st;
   AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws_aux, fit->A, sizeof(double) * (size_t)fit->lda * (size_t)n,
@@ -901,6 +923,21 @@ int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs, int64_t n
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long n = fit->n, ldb = round_up(n, 2);
   const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  if (!fit->phantom.empty()) {
+    // rhs / out hold the REAL rows: spread them over the padded rows (phantom rows zero), solve, gather
+    const long long nr = fit_real_rows(fit);
+    double *B = nullptr;
+    AGP_HIP_CHECK(ctx, hipMalloc(&B, sizeof(double) * (size_t)ldb * (size_t)nrhs));
+    int st = fit_expand_matrix(ctx, fit, rhs, nr, nrhs, B, ldb, location);
+    if (st == AGP_OK) {
+      forward_solve_mat_lookahead(ctx, fit->A, n, fit->lda, fit->invd, B, nrhs, ldb);
+      backward_solve_mat(ctx->stream, fit->A, n, fit->lda, fit->invd, B, nrhs, ldb);
+      st = fit_compact_matrix(ctx, fit, B, ldb, nrhs, out, nr, location);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(B);
+    return st;
+  }
   if (nrhs == 1 && n >= 1024) {
     // one right-hand side: the matrix kernels would run 2 N / 128 launches on a single column; the vector chains
     // (fused 128-row forward steps, blocked backward substitution) are 4x shorter (N = 16384: 11.3 -> 2.7 ms)
@@ -1045,12 +1082,14 @@ int agp_fit_inverse_diagonal(agp_context *ctx, const agp_fit *fit, double *out, 
   double *diag = nullptr;
   int st = inverse_diagonal_device(ctx, fit, &diag);
   if (st != AGP_OK) return st;
+  if (!fit->phantom.empty()) return fit_compact_vector(ctx, fit, diag, out, out_location);
   return copy_out(ctx, diag, fit->n, out, out_location);
 }
 
 int agp_loo_marginal(agp_context *ctx, const agp_fit *fit, const double *y, double *mean, double *variance,
                      int location) {
   if (!ctx || !fit || !y || !mean || !variance || !fit->A || !fit->alpha) return AGP_ERR_INVALID_ARGUMENT;
+  if (!fit->phantom.empty()) return AGP_ERR_UNSUPPORTED;  // cross validation of a fit grown by agp_fit_update: refit instead
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long n = fit->n;
   double *diag = nullptr;
@@ -1113,6 +1152,7 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
   launch_predict_mean(s, dprog, fit->train.v, dxs.v, fit->alpha, mean_d, &k->prog);
   // cross_cov = cov(train_features, features)   (gp.hpp:316,337)
   launch_gram(s, dprog, fit->train.v, dxs.v, false, false, V, ldv, nullptr, nullptr, &k->prog);
+  fit_zero_phantom_rows(s, fit, V, ldv, m);
   // V = L^-1 K*  ;  explained = V^T V  (== K*^T K^-1 K*, gp.hpp:96,111)
   if (m == 1 && n >= 1024) {
     // a single test point: the vector chain (one fused launch per 128 rows) instead of the matrix kernels

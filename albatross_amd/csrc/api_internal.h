@@ -38,6 +38,14 @@ void launch_compact_blocks(hipStream_t s, const double *slabs, long long ld, lon
                            const long long *boff, long long smax, long long n_groups, double *out);
 long long round_up(long long x, long long m);
 long long factor_ld(long long n);
+// fits grown by agp_fit_update carry phantom rows (common.h: agp_fit::phantom); update_api.hip
+long long fit_real_rows(const agp_fit *f);
+int fit_compact_vector(agp_context *ctx, const agp_fit *f, const double *padded_dev, double *real_out, int location);
+int fit_expand_matrix(agp_context *ctx, const agp_fit *f, const double *real_in, long long ldr, long long nrhs, double *padded_dev,
+                      long long ldp, int location);
+int fit_compact_matrix(agp_context *ctx, const agp_fit *f, const double *padded_dev, long long ldp, long long nrhs, double *real_out,
+                       long long ldr, int location);
+void fit_zero_phantom_rows(hipStream_t s, const agp_fit *f, double *V, long long ldv, long long cols);
 }  // namespace agp
 
 struct ProgSlot {

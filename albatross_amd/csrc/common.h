@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/albatross_amd.h"
@@ -100,6 +101,12 @@ struct agp_fit {
   agp::DeviceFeatures train;
   double log_det = 0.;
   int64_t failed_pivot = -1;
+  // Fits grown by agp_fit_update: the appended block starts at a multiple of 128, so when the size before the update
+  // was not one, the rows in between are PHANTOM rows (identity rows of the factor, zero information, decoupled from
+  // everything).  `n` counts them - every kernel works on the padded factor -, `n_real` does not (0: no phantoms) and
+  // the C-ABI only ever shows real rows.  phantom: sorted half-open ranges [first, last) of padded row indices.
+  int64_t n_real = 0;
+  std::vector<std::pair<long long, long long>> phantom;
 };
 
 #define AGP_HIP_CHECK(ctx, expr)                                              \

@@ -34,6 +34,7 @@ struct GroupWork {
 int group_work_init(agp_context *ctx, const agp_fit *fit, int64_t n_groups, const int64_t *offsets,
                     const int64_t *indices, GroupWork *w) {
   const long long n = fit->n;
+  if (!fit->phantom.empty()) return AGP_ERR_UNSUPPORTED;  // fits grown by agp_fit_update: cross-validate a fresh fit
   if (n_groups < 0 || !offsets || offsets[0] != 0) return AGP_ERR_INVALID_ARGUMENT;
   long long mmax = 0;
   for (int64_t g = 0; g < n_groups; ++g) {

@@ -649,6 +649,8 @@ class FitModel:
             dataset = RegressionDataset(dataset, targets)
         m, ctx = self._model, self._model._ctx()
         feats = _values_of(dataset.features)
+        if isinstance(self._fit, GPFit) and not has_linear_combinations(feats):
+            return self._update_on_device(dataset, feats)
         pred = self.predict(feats).joint()                                   # gp.hpp:388-389
         delta = np.asarray(dataset.targets.mean, dtype=np.float64) - pred.mean
         S = np.array(pred.covariance)
@@ -663,6 +665,29 @@ class FitModel:
         new_feats = np.concatenate([np.asarray(old_feats, dtype=np.float64).reshape(self._fit.rows(), -1),
                                     np.asarray(feats, dtype=np.float64).reshape(len(delta), -1)])
         return FitModel(m, UpdatedGPFit(new_feats, new_cov, info))
+
+    def _update_on_device(self, dataset, feats):
+        """agp_fit_update: the resident factor grows by one block row (V^T = (L^-1 B)^T, L_S from the Schur complement);
+        triangular solve, SYRK, LL^T of the new block and the back substitution all run in the HIP library."""
+        m, ctx = self._model, self._model._ctx()
+        cov = m.covariance_function_
+        fs = cov.features(feats)
+        y, yv = m._targets(fs, dataset.targets)      # mean function removed (ModelBase::update -> remove_from)
+        s = fs.as_struct()
+        h = C.c_void_p()
+        st = ctx._lib.agp_fit_update(ctx._h, ctx.kernel(cov), self._fit._h, C.byref(s), _ptr(y), _ptr(yv), C.byref(h), None, None)
+        if st != capi.AGP_OK:
+            pivot = ctx._lib.agp_fit_failed_pivot(h) if h else -1
+            if h:
+                ctx._lib.agp_fit_destroy(h)
+            ctx._check(st, f"agp_fit_update (pivot {pivot})")
+        old_feats = _values_of(self._fit.train_features)
+        try:
+            new_feats = np.concatenate([np.asarray(old_feats, dtype=np.float64).reshape(self._fit.rows(), -1),
+                                        np.asarray(feats, dtype=np.float64).reshape(fs.n, -1)])
+        except (TypeError, ValueError):  # feature containers numpy cannot stack: keep them side by side
+            new_feats = (old_feats, feats)
+        return FitModel(m, GPFit(ctx, h, self._fit.rows() + fs.n, new_feats))
 
     # --- _predict_impl (gp.hpp:305-366) ------------------------------------------
     def _host_predict(self, features, want):

@@ -234,6 +234,24 @@ int agp_factor_create(agp_context *ctx, const double *K, int64_t n, int64_t ld,
 int agp_nll_dense(agp_context *ctx, const double *deviation, const double *K,
                   int64_t n, int64_t ld, int uplo, int location, double *out);
 
+/* ---- update: condition a fit on further observations without refitting ------------------------------------
+ * FitModel::update -> GaussianProcessBase::_update_impl (src/models/gp.hpp:384-414) with BlockSymmetric
+ * (src/linalg/block_symmetric.hpp:46-115).  The reference keeps the old solver plus Ai_B = A^-1 B and the factor of the
+ * Schur complement S = C - B^T A^-1 B; here the same algebra extends the RESIDENT factor by one block row,
+ *     [[A, B], [B^T, C]] = [[L, 0], [V^T, L_S]] [[L, 0], [V^T, L_S]]^T,   V = L^-1 B,  L_S L_S^T = S,
+ * all on the device (triangular solve and SYRK on MFMA, LL^T of the m x m block, one back substitution).  As in the
+ * reference: cross = k(train_features, features) and prior = k(features, features) on PLAIN features (gp.hpp:388-396:
+ * no Measurement<> wrapper), targets.covariance on the diagonal of the new block, and
+ * information = [old - Ai_B S^-1 delta; S^-1 delta].
+ *   old      a fit made by agp_fit_create / agp_fit_update on this context (it stays valid)
+ *   x_new    the m further features (same dim / scale columns / id convention as the training features)
+ *   y_new    their targets with the mean function removed, y_var_new their variances or NULL, at x_new->location
+ *   out      a NEW fit of old + m observations for agp_predict_*, agp_solve, agp_fit_download_*, agp_fit_update;
+ *            cross-validation entry points reject it (AGP_ERR_UNSUPPORTED)
+ *   information  (optional, host) all agp_fit_size(*out) entries: the old observations first, then the new ones */
+int agp_fit_update(agp_context *ctx, const agp_kernel *k, const agp_fit *old, const agp_features *x_new, const double *y_new,
+                   const double *y_var_new, agp_fit **out, double *information, double *log_det);
+
 /* ---- leave-one-out fast path (the tuner's LeaveOneOutLikelihood objective) --- */
 /* diag(K^-1): SerializableLDLT::inverse_diagonal (src/eigen/serializable_ldlt.hpp:
  * 137-199: R = L^-1, then the squared column norms of R).  out: n doubles. */

@@ -510,6 +510,13 @@ typedef struct {
   int64_t *eq_copy;
   double *scales_copy;
   int use_llt;
+  /* Fit<GPFit<BlockSymmetric<Solver>, F>> made by update (gp.hpp:384-414): the old fit as solver A, Ai_B = A^-1 B
+   * (n_A x m) and the pivoted LDL^T of S (m x m): linalg/block_symmetric.hpp:46-60.  base == NULL: plain factor. */
+  const void *base;  /* const orc_fit *: the fit that was updated (must outlive this one) */
+  double *Ai_B;
+  double *S_ldlt;
+  int64_t *S_tr;
+  int64_t m;         /* rows of S */
 } orc_fit;
 
 static int has_nan(const double *A, int64_t n, int64_t ld) {
@@ -583,6 +590,7 @@ ORC_API void orc_fit_destroy(orc_fit *f) {
   if (!f) return;
   free(f->ldlt); free(f->tr); free(f->information);
   free(f->coords_copy); free(f->eq_copy); free(f->scales_copy);
+  free(f->Ai_B); free(f->S_ldlt); free(f->S_tr);
   free(f);
 }
 
@@ -595,9 +603,112 @@ ORC_API double orc_fit_logdet(const orc_fit *f) {
                     : orc_ldlt_logdet(f->ldlt, f->n, f->n);
 }
 
+ORC_API void orc_fit_solve(const orc_fit *f, double *B, int64_t nrhs);
+
+/* BlockSymmetric<Solver>::solve, linalg/block_symmetric.hpp:75-98 (block-matrix inversion with the pre-computed
+ * Ai_B = A^-1 B and the factor of S = C - B^T A^-1 B); B is n x nrhs with leading dimension n, overwritten. */
+static void block_symmetric_solve(const orc_fit *f, double *B, int64_t nrhs) {
+  const orc_fit *A = (const orc_fit *)f->base;
+  const int64_t na = A->n, m = f->m, n = f->n;
+  double *rhs_a = malloc(sizeof(double) * (size_t)(na * nrhs));
+  double *rhs_b = malloc(sizeof(double) * (size_t)(m * nrhs));
+  double *t = malloc(sizeof(double) * (size_t)(m * nrhs));
+  for (int64_t j = 0; j < nrhs; ++j) {
+    memcpy(rhs_a + j * na, B + j * n, sizeof(double) * (size_t)na);      /* rhs.topRows */
+    memcpy(rhs_b + j * m, B + j * n + na, sizeof(double) * (size_t)m);   /* rhs.bottomRows */
+  }
+  for (int64_t j = 0; j < nrhs; ++j)                                     /* Bt_Ai_rhs = Ai_B^T rhs_a   :86 */
+    for (int64_t c = 0; c < m; ++c) {
+      double acc = 0.;
+      for (int64_t i = 0; i < na; ++i) acc += f->Ai_B[i + c * na] * rhs_a[i + j * na];
+      t[c + j * m] = acc;
+    }
+  orc_ldlt_solve(f->S_ldlt, m, m, f->S_tr, t, nrhs, m);                  /* Si_Bt_Ai_rhs               :87 */
+  orc_ldlt_solve(f->S_ldlt, m, m, f->S_tr, rhs_b, nrhs, m);              /* Si_rhs_b                   :88 */
+  orc_fit_solve(A, rhs_a, nrhs);                                         /* A.solve(rhs_a)             :91 */
+  for (int64_t j = 0; j < nrhs; ++j) {
+    for (int64_t i = 0; i < na; ++i) {                                   /* + Ai_B (Si_Bt_Ai_rhs - Si_rhs_b) */
+      double acc = 0.;
+      for (int64_t c = 0; c < m; ++c) acc += f->Ai_B[i + c * na] * (t[c + j * m] - rhs_b[c + j * m]);
+      B[i + j * n] = rhs_a[i + j * na] + acc;
+    }
+    for (int64_t c = 0; c < m; ++c) B[na + c + j * n] = rhs_b[c + j * m] - t[c + j * m];  /* :92 */
+  }
+  free(rhs_a); free(rhs_b); free(t);
+}
+
 ORC_API void orc_fit_solve(const orc_fit *f, double *B, int64_t nrhs) {
-  if (f->use_llt) orc_llt_solve(f->ldlt, f->n, f->n, B, nrhs, f->n);
+  if (f->base) block_symmetric_solve(f, B, nrhs);
+  else if (f->use_llt) orc_llt_solve(f->ldlt, f->n, f->n, B, nrhs, f->n);
   else orc_ldlt_solve(f->ldlt, f->n, f->n, f->tr, B, nrhs, f->n);
+}
+
+ORC_API void orc_predict_joint(const orc_fit *f, const agp_kernel_node *prog, int n_nodes, const agp_features *xs,
+                               double *mean, double *cov);
+ORC_API void orc_gram_cross(const agp_kernel_node *prog, int n_nodes, const agp_features *x, const agp_features *y,
+                            double *out, int64_t ld);
+
+/* GaussianProcessBase::_update_impl, models/gp.hpp:384-414: condition `old` on further observations.
+ * y = targets.mean with the mean function removed by the caller (FitModel::update -> ModelBase::update).
+ * `old` must outlive the returned fit (it is the `A` solver of the BlockSymmetric). */
+ORC_API orc_fit *orc_fit_update(const orc_fit *old, const agp_kernel_node *prog, int n_nodes, const agp_features *x,
+                                const double *y, const double *y_var) {
+  const int64_t na = old->n, m = x->n, n = na + m;
+  const int dim = x->dim, nsc = x->n_scale_columns;
+  orc_fit *f = calloc(1, sizeof(orc_fit));
+  f->n = n; f->m = m; f->base = old;
+  /* new_features = concatenate(fit_.train_features, features)                                     :387 */
+  f->train = old->train;
+  f->train.n = n;
+  f->coords_copy = malloc(sizeof(double) * (size_t)(n * dim));
+  memcpy(f->coords_copy, old->train.coords, sizeof(double) * (size_t)(na * dim));
+  memcpy(f->coords_copy + na * dim, x->coords, sizeof(double) * (size_t)(m * dim));
+  f->train.coords = f->coords_copy;
+  if (old->train.eq_id && x->eq_id) {
+    f->eq_copy = malloc(sizeof(int64_t) * (size_t)n);
+    memcpy(f->eq_copy, old->train.eq_id, sizeof(int64_t) * (size_t)na);
+    memcpy(f->eq_copy + na, x->eq_id, sizeof(int64_t) * (size_t)m);
+    f->train.eq_id = f->eq_copy;
+  } else {
+    f->train.eq_id = NULL;
+  }
+  if (nsc > 0) {
+    f->scales_copy = malloc(sizeof(double) * (size_t)(n * nsc));
+    for (int kc = 0; kc < nsc; ++kc) {
+      memcpy(f->scales_copy + (int64_t)kc * n, old->train.scales + (int64_t)kc * na, sizeof(double) * (size_t)na);
+      memcpy(f->scales_copy + (int64_t)kc * n + na, x->scales + (int64_t)kc * m, sizeof(double) * (size_t)m);
+    }
+    f->train.scales = f->scales_copy;
+  }
+  /* pred = _predict_impl(features, fit_, JointDistribution)                                       :389-390 */
+  agp_features plain = *x;
+  plain.is_measurement = 0;
+  double *pmean = malloc(sizeof(double) * (size_t)m);
+  double *S = malloc(sizeof(double) * (size_t)(m * m));
+  orc_predict_joint(old, prog, n_nodes, &plain, pmean, S);
+  /* delta = targets.mean - pred.mean; pred.covariance += targets.covariance; S_ldlt = ...ldlt()    :392-394 */
+  double *delta = malloc(sizeof(double) * (size_t)m);
+  for (int64_t i = 0; i < m; ++i) delta[i] = y[i] - pmean[i];
+  if (y_var)
+    for (int64_t i = 0; i < m; ++i) S[i + i * m] += y_var[i];
+  f->S_ldlt = S;
+  f->S_tr = malloc(sizeof(int64_t) * (size_t)m);
+  orc_ldlt(f->S_ldlt, m, m, f->S_tr);
+  /* cross = covariance_function_(fit_.train_features, features); BlockSymmetric(A, cross, S_ldlt)  :396-400 */
+  f->Ai_B = malloc(sizeof(double) * (size_t)(na * m));
+  orc_gram_cross(prog, n_nodes, &old->train, &plain, f->Ai_B, na);
+  orc_fit_solve(old, f->Ai_B, m);                             /* Ai_B(A_.solve(B_)), block_symmetric.hpp:51 */
+  /* Si_delta = S_ldlt.solve(delta); new_information = [information - Ai_B Si_delta; Si_delta]       :402-407 */
+  orc_ldlt_solve(f->S_ldlt, m, m, f->S_tr, delta, 1, m);
+  f->information = malloc(sizeof(double) * (size_t)n);
+  for (int64_t i = 0; i < na; ++i) {
+    double acc = 0.;
+    for (int64_t c = 0; c < m; ++c) acc += f->Ai_B[i + c * na] * delta[c];
+    f->information[i] = old->information[i] - acc;
+  }
+  memcpy(f->information + na, delta, sizeof(double) * (size_t)m);
+  free(pmean); free(delta);
+  return f;
 }
 
 /* negative_log_likelihood(deviation, covariance): likelihood.hpp:38-66 */

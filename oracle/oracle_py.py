@@ -50,6 +50,8 @@ def lib():
         L.orc_fit_create.argtypes = [PN, C.c_int, PF, V, V, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.orc_fit_destroy.argtypes = [V]
         L.orc_fit_information.argtypes = [V, V]
+        L.orc_fit_update.restype = C.c_void_p
+        L.orc_fit_update.argtypes = [V, PN, C.c_int, PF, V, V]
         L.orc_fit_logdet.restype = C.c_double
         L.orc_fit_logdet.argtypes = [V]
         L.orc_fit_solve.argtypes = [V, V, I64]
@@ -200,6 +202,24 @@ class OracleFit:
         if getattr(self, "h", None):
             lib().orc_fit_destroy(self.h)
             self.h = None
+
+    def update(self, x, y, y_var=None):
+        """FitModel::update -> _update_impl (gp.hpp:384-414): a new OracleFit whose solver is the BlockSymmetric of this
+        fit (which it keeps alive), Ai_B and the pivoted LDL^T of the Schur complement.  y: raw targets (the mean
+        function, if any, is removed here like ModelBase::update does)."""
+        fx, keep = _feat(self.cov, x, False)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if self.mean is not None:
+            y = remove_mean(self.mean, self.cov, x, y)
+        yv = None if y_var is None else np.ascontiguousarray(y_var, dtype=np.float64)
+        new = OracleFit.__new__(OracleFit)
+        new.cov, new.mean, new._p, new._n = self.cov, self.mean, self._p, self._n
+        new._base = self  # the C side keeps a pointer to this fit
+        new._keep = keep
+        new.h = lib().orc_fit_update(self.h, self._p, self._n, C.byref(fx), _ptr(y), _ptr(yv))
+        new.n = self.n + int(fx.n)
+        new.status = 0
+        return new
 
     @property
     def information(self):

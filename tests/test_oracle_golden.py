@@ -386,3 +386,29 @@ def test_bench_generator_is_libstdcxx_mt19937():
     x, y = bench.make_dataset(100, 44)
     assert x.shape == (100, 3) and x.min() >= 0. and x.max() < 10.
     assert np.array_equal(x.reshape(-1), bench.mt19937_uniform(44, 300))  # row-major fill
+
+
+def test_oracle_update_equals_full_fit():
+    """_update_impl / BlockSymmetric restated in the oracle (gp.hpp:384-414, block_symmetric.hpp:46-98) on the
+    reference's own property: a partial fit followed by update (also nested) == a full fit (tests/test_gp.cc:182-219,
+    tests/test_block_utils.cc:125-147) - when the noise enters through the target variance only."""
+    rng = np.random.default_rng(0)
+    n = 90
+    x = rng.uniform(0., 10., (n, 2))
+    y = np.sin(x).sum(axis=1)
+    var = rng.uniform(0.05, 0.15, n)
+    cov = ab.SquaredExponential(1.5, 1.0) + ab.Constant(2.0)
+    full = orc.OracleFit(cov, x, y, var)
+    upd = orc.OracleFit(cov, x[:50], y[:50], var[:50]).update(x[50:70], y[50:70], var[50:70]).update(x[70:], y[70:], var[70:])
+    assert np.abs(upd.information - full.information).max() <= 1e-10 * np.abs(full.information).max()
+    xs = rng.uniform(0., 10., (7, 2))
+    for a, b in zip(upd.predict_joint(xs), full.predict_joint(xs)):
+        assert np.abs(a - b).max() <= 1e-10
+    rhs = rng.standard_normal((n, 3))
+    assert np.abs(upd.solve(rhs) - full.solve(rhs)).max() <= 1e-9 * np.abs(full.solve(rhs)).max()
+    # with MEASUREMENT-ONLY noise in the covariance function the update is NOT the full fit: the new block's prior is
+    # evaluated on plain features (gp.hpp:388-396), the measurement noise of the new observations is left out
+    covm = ab.SquaredExponential(1.5, 1.0) + ab.measurement_only(ab.IndependentNoise(0.3))
+    fullm = orc.OracleFit(covm, x, y, var)
+    updm = orc.OracleFit(covm, x[:50], y[:50], var[:50]).update(x[50:], y[50:], var[50:])
+    assert np.abs(updm.information - fullm.information).max() > 1e-3 * np.abs(fullm.information).max()

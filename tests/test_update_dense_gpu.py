@@ -132,3 +132,64 @@ def test_fit_from_prediction_round_trip(ctx):
     xs = np.array([0.7, 3.3, 8.4])
     a, b = fit_model.predict(xs).joint(), rebuilt.predict(xs).joint()
     assert np.abs(a.mean - b.mean).max() <= 1e-5 and np.abs(a.covariance - b.covariance).max() <= 1e-5
+
+
+@pytest.mark.parametrize("n0,m1,m2", [(250, 80, 70), (256, 128, 40), (1000, 300, 1), (130, 1, 129)])
+def test_device_update_matches_oracle_update(ctx, n0, m1, m2):
+    """agp_fit_update (the resident factor grows by a block row) against the oracle's literal _update_impl +
+    BlockSymmetric restatement (gp.hpp:384-414): information, all three predictions, solve, log-determinant; nested;
+    sizes that are / are not multiples of 128 (phantom rows); a covariance with measurement-only noise AND
+    IndependentNoise, where update differs from a full fit, so that the reference's exact semantics are pinned."""
+    rng = np.random.default_rng(n0 + m1)
+    n = n0 + m1 + m2
+    x = rng.uniform(0., 10., (n, 3))
+    x[n0 + 1] = x[3]  # a new observation AT an old point: IndependentNoise correlates them (plain features, by value)
+    y = np.sin(x).sum(axis=1) + 0.05 * rng.standard_normal(n)
+    var = rng.uniform(0.05, 0.1, n)
+    xs = rng.uniform(0., 10., (33, 3))
+    cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.2) + ab.measurement_only(ab.IndependentNoise(0.3))
+    model = ab.gp_from_covariance_and_mean(cov, ab.LinearMean(0.2, -0.5), context=ctx)
+    a, b, c = slice(0, n0), slice(n0, n0 + m1), slice(n0 + m1, n)
+    fm = model.fit(ab.RegressionDataset(x[a], ab.MarginalDistribution(y[a], var[a])))
+    of = orc.OracleFit(cov, x[a], y[a], var[a], mean=model.mean_function_)
+    for sl in (b, c):
+        fm = fm.update(ab.RegressionDataset(x[sl], ab.MarginalDistribution(y[sl], var[sl])))
+        of = of.update(x[sl], y[sl], var[sl])
+        assert isinstance(fm.get_fit(), ab.GPFit)  # still a device factor, not a host composition
+        info = of.information
+        assert fm.get_fit().rows() == of.n
+        assert np.abs(fm.get_fit().information - info).max() <= 1e-8 * np.abs(info).max()
+        om, ov = of.predict_marginal(xs)
+        _, oj = of.predict_joint(xs)
+        pred = fm.predict(xs)
+        assert np.abs(pred.mean() - om).max() <= 1e-8 * np.abs(om).max()
+        marg, joint = pred.marginal(), pred.joint()
+        assert np.abs(marg.covariance - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-10
+        assert np.abs(joint.covariance - oj).max() <= 1e-8 * np.abs(oj).max() + 1e-10
+        rhs = rng.standard_normal((of.n, 3))
+        assert np.abs(fm.get_fit().solve(rhs) - of.solve(rhs)).max() <= 1e-8 * np.abs(of.solve(rhs)).max()
+        assert np.abs(fm.get_fit().solve(rhs[:, 0]) - of.solve(rhs[:, 0])).max() <= 1e-8 * np.abs(of.solve(rhs[:, 0])).max()
+    # the grown factor really is the LL^T of the block matrix the reference's BlockSymmetric inverts
+    L = fm.get_fit().factor()
+    K = orc.gram(cov, x[a], x_meas=True) + np.diag(var[a])
+    M = np.block([[K, orc.gram(cov, x[a], x[n0:])], [orc.gram(cov, x[n0:], x[a]), orc.gram(cov, x[n0:]) + np.diag(var[n0:])]])
+    assert np.abs(L @ L.T - M).max() <= 1e-10 * np.abs(M).max()
+    assert abs(fm.get_fit().log_determinant - np.linalg.slogdet(M)[1]) <= 1e-8 * n
+    with pytest.raises(ab.AlbatrossAmdError):
+        fm.get_fit().leave_one_out(y)  # cross validation of a grown fit is not offered
+
+
+def test_device_update_reports_not_positive_definite(ctx):
+    rng = np.random.default_rng(1)
+    x = rng.uniform(0., 10., (200, 2))
+    y = np.sin(x).sum(axis=1)
+    model = ab.gp_from_covariance(ab.SquaredExponential(1.5, 1.0) + ab.IndependentNoise(0.1), context=ctx)
+    fm = model.fit(ab.RegressionDataset(x, y))
+    xn = rng.uniform(0., 10., (20, 2))
+    xn[7] = xn[2]  # duplicate among the NEW points and no target variance: the Schur complement is singular
+    cov_nn = ab.SquaredExponential(1.5, 1.0)
+    fm2 = ab.gp_from_covariance(cov_nn, context=ctx)
+    fit0 = fm2.fit(ab.RegressionDataset(x, ab.MarginalDistribution(y, np.full(200, 0.1))))
+    with pytest.raises(ab.NotPositiveDefiniteError, match="pivot 207"):
+        fit0.update(ab.RegressionDataset(xn, np.zeros(20)))
+    assert fm.update(ab.RegressionDataset(xn[:5], np.zeros(5))).get_fit().rows() == 205
