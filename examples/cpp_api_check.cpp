@@ -133,7 +133,7 @@ int main() {
     const auto up1 = update(part, RegressionDataset<P3>(xb, MarginalDistribution(yb, Vector(80, 0.1))));
     const auto up2 = up1.update(RegressionDataset<P3>(xc, MarginalDistribution(yc, Vector(yc.size(), 0.1))));
     const auto fj = full.predict(xs).joint();
-    const auto uj = up2.predict_joint(xs);
+    const auto uj = up2.predict(xs).joint();
     double dm = 0., dc = 0.;
     for (int i = 0; i < ms; ++i) {
       dm = std::fmax(dm, std::fabs(fj.mean[i] - uj.mean[i]));

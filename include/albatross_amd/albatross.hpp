@@ -1028,6 +1028,9 @@ class FitModel {
     return Prediction<ModelType, FeatureType, Measurement<P>>(this, as_measurements(features));
   }
 
+  // FitModel::update, core/fit_model.hpp:68-81 (defined after the free function update() below)
+  FitModel update(const RegressionDataset<FeatureType> &dataset) const;
+
   // _predict_impl, gp.hpp:305-366
   template <typename P>
   Vector predict_mean_(const std::vector<P> &xs) const {
@@ -1241,16 +1244,46 @@ RepresentationFitModel<ModelType, FeatureType, PivotedLDLT> fit_pivoted(const Mo
   return RepresentationFitModel<ModelType, FeatureType, PivotedLDLT>(model, dataset.features, std::move(ldlt), std::move(info));
 }
 
-// update(fit_model, dataset), core/fit_model.hpp:117-120
+// update(fit_model, dataset), core/fit_model.hpp:117-120 -> _update_impl, gp.hpp:384-414.  The reference returns a fit
+// whose solver is BlockSymmetric<Solver>; here the RESIDENT factor grows by one block row on the device (agp_fit_update:
+// triangular solve + SYRK on MFMA, LL^T of the Schur complement), so the result is an ordinary FitModel again: nested
+// updates, predictions and solves all stay on the device factor.  (UpdatedFitModel above remains for solvers that are
+// not a device factor: PivotedLDLT, ExplainedCovariance.)
 template <typename ModelType, typename FeatureType>
-UpdatedFitModel<ModelType, FeatureType, GPFit<FeatureType>> update(const FitModel<ModelType, FeatureType> &fm,
-                                                                    const RegressionDataset<FeatureType> &d) {
-  struct Adapter {  // FitModel seen through the interface update_impl needs
-    const FitModel<ModelType, FeatureType> *fm;
-    JointDistribution predict_joint(const std::vector<FeatureType> &xs) const { return fm->predict(xs).joint(); }
-  } self{&fm};
-  return UpdatedFitModel<ModelType, FeatureType, GPFit<FeatureType>>::template update_impl<ModelType, FeatureType, GPFit<FeatureType>>(
-      fm.get_model(), self, fm.get_fit(), fm.get_fit().train_features, fm.get_fit().information, d);
+FitModel<ModelType, FeatureType> update(const FitModel<ModelType, FeatureType> &fm, const RegressionDataset<FeatureType> &d) {
+  if (d.features.size() != d.targets.size()) throw std::invalid_argument("features and targets differ in size");
+  const ModelType &model = fm.get_model();
+  const GPFit<FeatureType> &old = fm.get_fit();
+  detail::KernelHolder k(model.get_covariance().program());
+  detail::Flat f = detail::flatten(model.get_covariance(), d.features);
+  Vector y = d.targets.mean;
+  Vector zero(y.size(), 0.);
+  model.add_mean(d.features, &zero);  // remove_from == subtract what add_to adds (ModelBase::update)
+  for (std::size_t i = 0; i < y.size(); ++i) y[i] -= zero[i];
+  GPFit<FeatureType> fit;
+  fit.train_features = old.train_features;                                   // concatenate(...), gp.hpp:387
+  fit.train_features.insert(fit.train_features.end(), d.features.begin(), d.features.end());
+  fit.information.resize(fit.train_features.size());
+  fit.context = old.context;
+  agp_fit *h = nullptr;
+  const double *yvar = d.targets.covariance.empty() ? nullptr : d.targets.covariance.data();
+  const int st = agp_fit_update(old.context->ctx, k.k, old.handle.get(), &f.view, y.data(), yvar, &h, fit.information.data(),
+                                &fit.log_determinant);
+  if (st != AGP_OK) {
+    const long long pivot = h ? static_cast<long long>(agp_fit_failed_pivot(h)) : -1;
+    agp_fit_destroy(h);
+    std::string what = "agp_fit_update";
+    if (st == AGP_ERR_NOT_POSITIVE_DEFINITE) what += " (pivot " + std::to_string(pivot) + ")";
+    detail::check(st, old.context->ctx, what.c_str());
+  }
+  auto ctx = old.context;
+  fit.handle = std::shared_ptr<agp_fit>(h, [ctx](agp_fit *p) { agp_fit_destroy(p); });
+  return FitModel<ModelType, FeatureType>(model, std::move(fit));
+}
+
+template <typename ModelType, typename FeatureType>
+FitModel<ModelType, FeatureType> FitModel<ModelType, FeatureType>::update(const RegressionDataset<FeatureType> &dataset) const {
+  return albatross::update(*this, dataset);
 }
 
 // ---------------------------------------------------------------------------
