@@ -522,6 +522,42 @@ void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long lo
   (void)hipMemcpyAsync(z, xs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }
 
+// ---- one right-hand side through explicitly inverted BW x BW diagonal blocks (n a multiple of BW) ----------------
+// W[b] = inv(L_BB), column-major BW x BW: one batched triangular solve against the identity for all blocks.
+static void invert_wide_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd, long long BW,
+                               double *W) {
+  const long long nb = n / BW;
+  launch_set_identity_batched(s, W, BW, BW * BW, BW, nb);
+  forward_solve_mat_batched(s, A, BW * (lda + 1), BW, lda, invd, (BW / NB) * (long long)(36 * MB * MB), W, BW * BW, BW, BW,
+                            /*rhs_lower=*/true, nb);
+}
+
+// z <- L^-1 z, right-looking: x_B = W_B z_B (in place), z[below] -= L[below, B] x_B: two mat-vec launches per BW rows
+// instead of one fused launch per 128 (the chain is launch-latency-bound).  partial: n doubles of scratch.
+static void forward_solve_vec_wide(hipStream_t s, const double *A, long long n, long long lda, const double *W, long long BW,
+                                   double *z, double *partial) {
+  const long long nb = n / BW;
+  for (long long b = 0; b < nb; ++b) {
+    const long long k0 = b * BW, below = n - k0 - BW;
+    // (x_B goes through `partial` first: the kernel may not overwrite z_B while other workgroups still read it)
+    launch_tall_matvec(s, W + b * BW * BW, BW, BW, BW, z + k0, 1.0, 0.0, nullptr, partial);
+    (void)hipMemcpyAsync(z + k0, partial, sizeof(double) * (size_t)BW, hipMemcpyDeviceToDevice, s);
+    if (below > 0) launch_tall_matvec(s, A + k0 * lda + k0 + BW, lda, below, BW, z + k0, -1.0, 1.0, z + k0 + BW, z + k0 + BW);
+  }
+}
+
+// z <- L^-T z with the same inverses (the loop of backward_solve_vec_any); xs: n doubles of scratch
+static void backward_solve_vec_wide(hipStream_t s, const double *A, long long n, long long lda, const double *W, long long BW,
+                                    double *z, double *xs) {
+  const long long nb = n / BW;
+  for (long long b = nb - 1; b >= 0; --b) {
+    const long long k0 = b * BW;
+    launch_colvec_dot(s, W + b * BW * BW, BW, BW, BW, z + k0, 1.0, 0.0, nullptr, xs + k0);
+    if (k0 > 0) launch_colvec_dot(s, A + k0, lda, BW, k0, xs + k0, -1.0, 1.0, z, z);
+  }
+  (void)hipMemcpyAsync(z, xs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+}
+
 namespace {
 struct MixedRequest {
   int max_iterations = 0;
@@ -694,10 +730,24 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
     for (int i = 0; i < count; ++i) host[i] = ctx->h_scalars[i];
     return AGP_OK;
   };
+  // the substitutions of every step: through 512-wide inverted diagonal blocks when the size allows (2 x n / 512
+  // mat-vec launches per direction instead of n / 128 fused steps: the chains are launch-latency-bound)
+  const long long BW = backsolve_width(n);
+  double *Wwide = nullptr;
+  if (BW) {
+    AGP_HIP_CHECK(ctx, hipMalloc(&Wwide, sizeof(double) * (size_t)(n / BW) * (size_t)BW * (size_t)BW));
+    invert_wide_blocks(s, fit->A, n, lda, fit->invd, BW, Wwide);
+  }
+  struct FreeW { double *p; ~FreeW() { if (p) (void)hipFree(p); } } free_w{Wwide};
   auto precondition = [&](const double *in, double *outv) {
     (void)hipMemcpyAsync(outv, in, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
-    forward_solve_vec(s, fit->A, n, lda, Wfwd, outv, ctx->ws_aux);
-    backward_solve_vec(s, fit->A, n, lda, fit->winv, outv, ctx->ws_aux);
+    if (BW) {
+      forward_solve_vec_wide(s, fit->A, n, lda, Wwide, BW, outv, ctx->ws_aux);
+      backward_solve_vec_wide(s, fit->A, n, lda, Wwide, BW, outv, ctx->ws_aux);
+    } else {
+      forward_solve_vec(s, fit->A, n, lda, Wfwd, outv, ctx->ws_aux);
+      backward_solve_vec(s, fit->A, n, lda, fit->winv, outv, ctx->ws_aux);
+    }
   };
   double h[4];
   int st;
@@ -949,6 +999,15 @@ int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs, int64_t n
     hipStream_t s = ctx->stream;
     AGP_HIP_CHECK(ctx, hipMemcpyAsync(z, rhs, sizeof(double) * (size_t)n, kind, s));
     if (location == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (const long long BW = backsolve_width(n)) {
+      // both directions through 512-wide inverted diagonal blocks (ws holds the backward solve's staging + inverses;
+      // the inverses are shared)
+      double *xs = ws, *W = ws + round_up(n, 2);
+      invert_wide_blocks(s, fit->A, n, fit->lda, fit->invd, BW, W);
+      forward_solve_vec_wide(s, fit->A, n, fit->lda, W, BW, z, xs);
+      backward_solve_vec_wide(s, fit->A, n, fit->lda, W, BW, z, xs);
+      return copy_out(ctx, z, n, out, location);
+    }
     invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
     forward_solve_vec(s, fit->A, n, fit->lda, Wfwd, z, ws);  // ws[0 : n] as the staging vector
     backward_solve_vec_any(s, fit->A, n, fit->lda, fit->invd, z, ws);
@@ -1158,14 +1217,21 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
     // a single test point: the vector chain (one fused launch per 128 rows) instead of the matrix kernels
     const long long nblk = (n + NB - 1) / NB;
     double *Wfwd = nullptr, *stage = nullptr;
-    if (hipMalloc(&Wfwd, sizeof(double) * ((size_t)nblk * NB * NB + (size_t)round_up(n, 2))) != hipSuccess) {
+    const long long BWp = backsolve_width(n);
+    const size_t w_elems = BWp ? (size_t)(n / BWp) * (size_t)BWp * (size_t)BWp : (size_t)nblk * NB * NB;
+    if (hipMalloc(&Wfwd, sizeof(double) * (w_elems + (size_t)round_up(n, 2))) != hipSuccess) {
       dxs.release();
       ctx->last_error = "hipMalloc (single-point prediction workspace)";
       return AGP_ERR_HIP;
     }
-    stage = Wfwd + (size_t)nblk * NB * NB;
-    invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
-    forward_solve_vec(s, fit->A, n, fit->lda, Wfwd, V, stage);
+    stage = Wfwd + w_elems;
+    if (BWp) {  // through 512-wide inverted diagonal blocks (see agp_solve)
+      invert_wide_blocks(s, fit->A, n, fit->lda, fit->invd, BWp, Wfwd);
+      forward_solve_vec_wide(s, fit->A, n, fit->lda, Wfwd, BWp, V, stage);
+    } else {
+      invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
+      forward_solve_vec(s, fit->A, n, fit->lda, Wfwd, V, stage);
+    }
     (void)hipStreamSynchronize(s);
     (void)hipFree(Wfwd);
   } else {

@@ -22,6 +22,8 @@ void launch_gather_vec(hipStream_t s, const double *src, const long long *idx, l
 void launch_negate(hipStream_t s, double *A, long long ld, long long m, double *diag_out);
 void launch_matvec(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *x,
                    double *partial, double alpha, double beta, const double *base, double *out);
+void launch_tall_matvec(hipStream_t s, const double *W, long long ld, long long rows, long long ncols, const double *x, double alpha,
+                        double beta, const double *base, double *out);
 void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,
                        double alpha, double beta, const double *base, double *out);
 void launch_axpby(hipStream_t s, long long n, double a, const double *x, double b, const double *y, double *out);

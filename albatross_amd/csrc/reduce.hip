@@ -256,6 +256,45 @@ void launch_matvec(hipStream_t s, const double *W, long long ld, long long m, lo
                      beta, base, out);
 }
 
+// out[i] = alpha * sum_{c < ncols} W[i, c] x[c] + beta * base[i] for a TALL matrix (rows >> ncols <= 2048): a workgroup
+// owns 64 rows (lane = row: every load is a 512-B segment of one column), its 4 waves split the columns and keep 8
+// loads in flight each; fixed-order reduction through LDS.  The right-looking vector substitutions are sequences of
+// such products (rows below x 512).
+__global__ __launch_bounds__(256) void tall_matvec_kernel(const double *__restrict__ W, long long ld, long long rows, int ncols,
+                                                          const double *__restrict__ x, double alpha, double beta,
+                                                          const double *base, double *out) {
+  __shared__ double xs[2048], red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < ncols; c += 256) xs[c] = x[c];
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * 64 + lane;
+  const int per = (ncols + 3) / 4, c0 = wave * per, c1 = (c0 + per < ncols) ? c0 + per : ncols;
+  double acc = 0.;
+  if (i < rows) {
+    const double *p = W + i + (long long)c0 * ld;
+    int c = c0;
+    for (; c + 8 <= c1; c += 8, p += 8 * ld) {
+      const double v0 = p[0], v1 = p[ld], v2 = p[2 * ld], v3 = p[3 * ld], v4 = p[4 * ld], v5 = p[5 * ld], v6 = p[6 * ld], v7 = p[7 * ld];
+      acc += ((v0 * xs[c] + v1 * xs[c + 1]) + (v2 * xs[c + 2] + v3 * xs[c + 3])) +
+             ((v4 * xs[c + 4] + v5 * xs[c + 5]) + (v6 * xs[c + 6] + v7 * xs[c + 7]));
+    }
+    for (; c < c1; ++c, p += ld) acc += p[0] * xs[c];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && i < rows) {
+    const double sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    out[i] = alpha * sum + (base ? beta * base[i] : 0.);
+  }
+}
+
+void launch_tall_matvec(hipStream_t s, const double *W, long long ld, long long rows, long long ncols, const double *x, double alpha,
+                        double beta, const double *base, double *out) {
+  if (rows <= 0 || ncols <= 0 || ncols > 2048) return;
+  hipLaunchKernelGGL(tall_matvec_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, W, ld, rows, (int)ncols, x, alpha, beta,
+                     base, out);
+}
+
 // out[j] = alpha * sum_i W[i, j] v[i] + beta * base[j]   (one workgroup per column)
 __global__ __launch_bounds__(256) void colvec_dot_kernel(const double *__restrict__ W, long long ld, long long m,
                                                          const double *__restrict__ v, double alpha, double beta,
