@@ -12,6 +12,7 @@
 #include <thread>
 
 #include "api_internal.h"
+#include "trace.h"
 
 namespace agp {
 
@@ -373,8 +374,12 @@ static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevPr
   const bool prof = ctx->profiling;
   if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[0], s));
   // as_measurements(features) -> covariance_function_(measurement_features)   gp.hpp:288-290
-  launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, A, lda, yvar, ctx->d_flags, hprog);
+  {
+    TraceRange tr("agp: gram (compute_covariance_matrix, callers.hpp:107-166)");
+    launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, A, lda, yvar, ctx->d_flags, hprog);
+  }
   if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[1], s));
+  TraceRange tr_factor("agp: factor LL^T + forward substitution (SerializableLDLT, serializable_ldlt.hpp:27)");
   FactorTimers timers;
   if (prof) {
     const size_t want = (size_t)(2 * (2 * ((n + NB - 1) / NB) + 4));
@@ -671,7 +676,10 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   {
     const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * backsolve_ws_elems(n));
     if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
-    backward_solve_vec_any(s, fit->A, n, fit->lda, fit->invd, fit->alpha, ctx->ws_aux);
+    {
+      TraceRange tr("agp: backward substitution (information = ldlt.solve(y), gp.hpp:68)");
+      backward_solve_vec_any(s, fit->A, n, fit->lda, fit->invd, fit->alpha, ctx->ws_aux);
+    }
     // the refinement steps of the mixed-precision fit use the 128-row chain on fit->winv
     if (mixed) invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);
   }
@@ -1199,6 +1207,7 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
   DeviceFeatures dxs;
   if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
+  TraceRange tr_predict(joint ? "agp: predict joint (gp.hpp:103-113)" : "agp: predict marginal (gp.hpp:87-101)");
   const long long ldv = round_up(n, 2), ldc = round_up(m, 2);
   // workspace: V (n x m) | mean (m) | prior (m or m x m)
   const size_t v_elems = (size_t)ldv * (size_t)m;

@@ -19,6 +19,7 @@
 
 #include "api_internal.h"
 #include "shard_internal.h"
+#include "trace.h"
 
 namespace agp {
 void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *img, double *y,
@@ -604,6 +605,7 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
   if (nan_flag) { agp_sharded_fit_destroy(f); return AGP_ERR_NAN_INPUT; }
 
   // ---- factorisation + both substitutions ----
+  TraceRange tr_factor("agp: sharded factor + substitutions (gp.hpp:61-69 over the ranks)");
   ShardResult res;
   if (!plan.multi()) {
     // ONE rank: the local matrix is the whole matrix - the single-GPU factorisation itself (chol.hip: factor_lower with

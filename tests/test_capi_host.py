@@ -90,3 +90,19 @@ def test_product_path_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle"
+
+
+def test_host_cxx_under_address_and_ub_sanitizers():
+    """examples/Makefile `asan`: the sharded-fit schedule (albatross_amd/csrc/shard_sched.hip, plain C++, compiled into
+    the test binary with -fsanitize=address,undefined) driven with naive block operations on one rank and through the
+    forced multi-rank path, plus the header-only host layer; no GPU involved."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    ex = os.path.join(ROOT, "examples")
+    subprocess.check_call(["make", "-s", "-C", ex, "asan"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    run = subprocess.run([os.path.join(ex, "host_sanitize_check_asan")], env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "host_sanitize_check ok" in run.stdout and "ERROR" not in run.stderr
