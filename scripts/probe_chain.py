@@ -39,7 +39,7 @@ for name, kinds, wgs in [("same, 73 KB LDS, 24 WGs", [2], [24]), ("alternate 77(
 print("large touch (each WG rewrites 256 KB):")
 for name, kinds, wgs in [("same, no LDS, 64 WGs", [0], [64]), ("alternate 64 / 512 WGs", [0, 0], [64, 512])]:
     print(f"  {name:55s}: {probe(kinds, wgs, touch=128):7.2f} us per launch")
-for blocked in (0, -1, -2, 1, 2):
+for blocked in (0, -1, 1, 2):
     for n, width in ((512, 512), (2560, 512), (16384, 512), (16384, 128)):
         out = C.c_double()
         assert lib.agp_debug_panel_chain(ctx._h, n, width, 50, blocked, C.byref(out)) == 0
