@@ -116,6 +116,8 @@ EXPORTS = [
     ("agp_predict_mean", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, C.c_int]),
     ("agp_predict_marginal", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
     ("agp_predict_joint", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, C.c_int]),
+    ("agp_gram_combined", C.c_int, [_P, _P, C.POINTER(Features), C.c_int64, _P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P,
+                           C.c_int64, C.c_int]),
     ("agp_fit_update", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, _PP, _P, _D]),
     ("agp_comm_unique_id", C.c_int, [_P]),
     ("agp_comm_create", C.c_int, [_P, C.c_int, C.c_int, _P, _PP]),

@@ -159,6 +159,27 @@ def expand_linear_combinations(features):
     return (Measurement(pts) if meas else pts), C
 
 
+def expand_with_offsets(features):
+    """(expanded features, offsets, coefficients) for agp_gram_combined: combination j = expanded points
+    offsets[j] .. offsets[j + 1] with the given coefficients (a plain feature is the combination of itself)."""
+    ex, Cm = expand_linear_combinations(features)
+    rows, cols = np.nonzero(Cm != 0.) if Cm.size else (np.zeros(0, int), np.zeros(0, int))
+    n_exp, n = Cm.shape
+    # the expansion appends the members of combination 0, then of 1, ...: owners are non-decreasing; zero coefficients
+    # still occupy their slot, so offsets come from the construction order, not from the non-zeros
+    owner = np.zeros(n_exp, dtype=np.int64)
+    values = features.values if isinstance(features, Measurement) else features
+    pos = 0
+    for j, f in enumerate(values):
+        cnt = len(f.values) if isinstance(f, LinearCombination) else 1
+        owner[pos:pos + cnt] = j
+        pos += cnt
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(np.bincount(owner, minlength=n))
+    coefficients = np.ascontiguousarray(Cm[np.arange(n_exp), owner], dtype=np.float64)
+    return ex, offsets, coefficients
+
+
 def as_measurements(features):
     return features if isinstance(features, Measurement) else Measurement(features)
 

@@ -462,6 +462,62 @@ int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x, const
   return st;
 }
 
+// ---- Gram of LinearCombination features ------------------------------------------------------------------
+int agp_gram_combined(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t nx, const int64_t *x_offsets,
+                      const double *x_coefficients, const agp_features *y, int64_t ny, const int64_t *y_offsets,
+                      const double *y_coefficients, double *out, int64_t ld, int out_location) {
+  if (!ctx || !k || !x || !out || nx < 0 || ny < 0) return AGP_ERR_INVALID_ARGUMENT;
+  if ((x_offsets == nullptr) != (x_coefficients == nullptr) || (y_offsets == nullptr) != (y_coefficients == nullptr))
+    return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(x);
+  if (st != AGP_OK) return st;
+  if (y && (st = validate_features(y)) != AGP_OK) return st;
+  if (y && y->dim != x->dim) return AGP_ERR_INVALID_ARGUMENT;
+  const bool symmetric = y == nullptr;
+  const long long ex = x->n, ey = y ? y->n : x->n;
+  const long long na = x_offsets ? nx : ex, nb = symmetric ? na : (y_offsets ? ny : ey);
+  if (na == 0 || nb == 0) return AGP_OK;
+  if (ld < na) return AGP_ERR_INVALID_ARGUMENT;
+  if (x_offsets && (x_offsets[0] != 0 || x_offsets[nx] != ex)) return AGP_ERR_INVALID_ARGUMENT;
+  if (!symmetric && y_offsets && (y_offsets[0] != 0 || y_offsets[ny] != ey)) return AGP_ERR_INVALID_ARGUMENT;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  DeviceFeatures dx, dy;
+  if ((st = to_device(ctx, x, false, &dx)) != AGP_OK) return st;
+  if (y && (st = to_device(ctx, y, false, &dy)) != AGP_OK) return st;
+  const FeatView &vy = y ? dy.v : dx.v;
+  // workspace: expanded Gram | contracted result | offsets / coefficients of both sides
+  const long long ldk = round_up(ex, 2), ldo = round_up(na, 2);
+  const size_t k_elems = (size_t)ldk * (size_t)ey, o_elems = (size_t)ldo * (size_t)nb;
+  const size_t meta = (size_t)(x_offsets ? 2 * (nx + 1) + ex : 0) + (size_t)((!symmetric && y_offsets) ? 2 * (ny + 1) + ey : 0) + 8;
+  if ((st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (k_elems + o_elems + meta))) != AGP_OK) return st;
+  double *Kd = ctx->ws_aux, *Od = Kd + k_elems, *m = Od + o_elems;
+  hipStream_t s = ctx->stream;
+  const long long *xoff_d = nullptr, *yoff_d = nullptr;
+  const double *xc_d = nullptr, *yc_d = nullptr;
+  if (x_offsets) {
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(m, x_offsets, sizeof(int64_t) * (size_t)(nx + 1), hipMemcpyHostToDevice, s));
+    xoff_d = reinterpret_cast<const long long *>(m);
+    m += nx + 1;
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(m, x_coefficients, sizeof(double) * (size_t)ex, hipMemcpyHostToDevice, s));
+    xc_d = m;
+    m += ex;
+  }
+  if (symmetric) { yoff_d = xoff_d; yc_d = xc_d; }
+  else if (y_offsets) {
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(m, y_offsets, sizeof(int64_t) * (size_t)(ny + 1), hipMemcpyHostToDevice, s));
+    yoff_d = reinterpret_cast<const long long *>(m);
+    m += ny + 1;
+    AGP_HIP_CHECK(ctx, hipMemcpyAsync(m, y_coefficients, sizeof(double) * (size_t)ey, hipMemcpyHostToDevice, s));
+    yc_d = m;
+  }
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // pageable sources
+  launch_gram(s, dprog, dx.v, vy, symmetric, false, Kd, ldk, nullptr, nullptr, &k->prog);
+  launch_contract_combinations(s, Kd, ldk, xoff_d, xc_d, na, yoff_d, yc_d, nb, symmetric, Od, ldo);
+  return copy_out_2d(ctx, Od, ldo, na, nb, out, ld, out_location);
+}
+
 // ---- fit -------------------------------------------------------------------
 void agp_fit_destroy(agp_fit *fit) {
   if (!fit) return;

@@ -22,6 +22,8 @@ void launch_gather_vec(hipStream_t s, const double *src, const long long *idx, l
 void launch_negate(hipStream_t s, double *A, long long ld, long long m, double *diag_out);
 void launch_matvec(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *x,
                    double *partial, double alpha, double beta, const double *base, double *out);
+void launch_contract_combinations(hipStream_t s, const double *K, long long ldk, const long long *xoff, const double *xc, long long na,
+                                  const long long *yoff, const double *yc, long long nb, bool symmetric, double *out, long long ldo);
 void launch_tall_matvec(hipStream_t s, const double *W, long long ld, long long rows, long long ncols, const double *x, double alpha,
                         double beta, const double *base, double *out);
 void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,

@@ -256,6 +256,35 @@ void launch_matvec(hipStream_t s, const double *W, long long ld, long long m, lo
                      beta, base, out);
 }
 
+// LinearCombinationCaller (covariance_functions/callers.hpp:336-347): out(a, b) = c_a^T K[members(a), members(b)] c_b,
+// evaluated like xs.coefficients.dot(mat * ys.coefficients): inner sum over the members of b, outer over those of a.
+// members(a) = expanded points xoff[a] .. xoff[a + 1] (xoff == nullptr: a itself, coefficient 1).  symmetric: only a >= b
+// is evaluated and mirrored, like the symmetric compute_covariance_matrix (callers.hpp:119-127).
+__global__ __launch_bounds__(256) void contract_combinations_kernel(const double *__restrict__ K, long long ldk,
+                                                                    const long long *xoff, const double *xc, long long na,
+                                                                    const long long *yoff, const double *yc, long long nb,
+                                                                    int symmetric, double *out, long long ldo) {
+  const long long a = (long long)blockIdx.x * 16 + (threadIdx.x & 15), b = (long long)blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (a >= na || b >= nb || (symmetric && a < b)) return;
+  const long long i0 = xoff ? xoff[a] : a, i1 = xoff ? xoff[a + 1] : a + 1;
+  const long long j0 = yoff ? yoff[b] : b, j1 = yoff ? yoff[b + 1] : b + 1;
+  double acc = 0.;
+  for (long long i = i0; i < i1; ++i) {
+    double t = 0.;
+    for (long long j = j0; j < j1; ++j) t += K[i + j * ldk] * (yc ? yc[j] : 1.);
+    acc += (xc ? xc[i] : 1.) * t;
+  }
+  out[a + b * ldo] = acc;
+  if (symmetric && a != b) out[b + a * ldo] = acc;
+}
+
+void launch_contract_combinations(hipStream_t s, const double *K, long long ldk, const long long *xoff, const double *xc, long long na,
+                                  const long long *yoff, const double *yc, long long nb, bool symmetric, double *out, long long ldo) {
+  if (na <= 0 || nb <= 0) return;
+  hipLaunchKernelGGL(contract_combinations_kernel, dim3((unsigned)((na + 15) / 16), (unsigned)((nb + 15) / 16)), dim3(256), 0, s, K, ldk,
+                     xoff, xc, na, yoff, yc, nb, symmetric ? 1 : 0, out, ldo);
+}
+
 // out[i] = alpha * sum_{c < ncols} W[i, c] x[c] + beta * base[i] for a TALL matrix (rows >> ncols <= 2048): a workgroup
 // owns 64 rows (lane = row: every load is a 512-B segment of one column), its 4 waves split the columns and keep 8
 // loads in flight each; fixed-order reduction through LDS.  The right-looking vector substitutions are sequences of

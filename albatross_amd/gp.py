@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _capi as capi
 from .covariance import (CovarianceFunction, FeatureSet, LinearCombination, Measurement, expand_linear_combinations,
-                         has_linear_combinations, nodes_to_array)
+                         expand_with_offsets, has_linear_combinations, nodes_to_array)
 
 
 class AlbatrossAmdError(RuntimeError):
@@ -123,12 +123,27 @@ class Context:
     def gram(self, cov, xs, ys=None):
         """compute_covariance_matrix (callers.hpp:38-166) on the device."""
         if has_linear_combinations(xs) or (ys is not None and has_linear_combinations(ys)):
-            # LinearCombinationCaller (callers.hpp:321-396): Gram of the expanded points, contracted with the coefficients
-            ex, Cx = expand_linear_combinations(xs)
+            # LinearCombinationCaller (callers.hpp:321-396): Gram of the expanded points AND its contraction with the
+            # coefficients on the device (agp_gram_combined)
+            ex, xoff, xc = expand_with_offsets(xs)
+            fx = cov.features(ex)
+            sx = fx.as_struct()
+            kh = self.kernel(cov)
+            nx = len(xoff) - 1
             if ys is None:
-                return np.asfortranarray(Cx.T @ self.gram(cov, ex) @ Cx)
-            ey, Cy = expand_linear_combinations(ys)
-            return np.asfortranarray(Cx.T @ self.gram(cov, ex, ey) @ Cy)
+                out = np.empty((nx, nx), order="F")
+                st = self._lib.agp_gram_combined(self._h, kh, C.byref(sx), nx, _ptr(xoff), _ptr(xc), None, 0, None, None,
+                                                 _ptr(out), max(nx, 1), capi.HOST)
+            else:
+                ey, yoff, yc = expand_with_offsets(ys)
+                fy = cov.features(ey)
+                sy = fy.as_struct()
+                ny = len(yoff) - 1
+                out = np.empty((nx, ny), order="F")
+                st = self._lib.agp_gram_combined(self._h, kh, C.byref(sx), nx, _ptr(xoff), _ptr(xc), C.byref(sy), ny, _ptr(yoff),
+                                                 _ptr(yc), _ptr(out), max(nx, 1), capi.HOST)
+            self._check(st, "agp_gram_combined")
+            return out
         fx = cov.features(xs)
         sx = fx.as_struct()
         kh = self.kernel(cov)

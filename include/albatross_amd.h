@@ -149,6 +149,18 @@ void agp_kernel_destroy(agp_kernel *k);
 int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x,
              const agp_features *y, double *out, int64_t ld, int out_location);
 
+/* Gram of LinearCombination<X> features: LinearCombinationCaller (covariance_functions/callers.hpp:321-396),
+ *   out(a, b) = sum_{i in a} sum_{j in b} c_i c_j k(x_i, y_j).
+ * x (y) holds the EXPANDED points, combination a = expanded points x_offsets[a] .. x_offsets[a + 1) with coefficients
+ * x_coefficients[..] (nx + 1 offsets and one coefficient per expanded point, host arrays; offsets[0] = 0,
+ * offsets[nx] = x->n).  A side with offsets == NULL is a vector of plain features (nx ignored).  y == NULL: the
+ * symmetric Gram of x with itself (evaluated for a >= b and mirrored, callers.hpp:119-127).  The Measurement<> flag
+ * of x / y applies to the expanded points (MeasurementForwarder sits outside LinearCombinationCaller).  Gram and
+ * contraction both run on the device. */
+int agp_gram_combined(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t nx, const int64_t *x_offsets,
+                      const double *x_coefficients, const agp_features *y, int64_t ny, const int64_t *y_offsets,
+                      const double *y_coefficients, double *out, int64_t ld, int out_location);
+
 /* ---- fit ----------------------------------------------------------------- */
 /* Fit<GPFit<...>>::Fit(features, train_cov, targets) (src/models/gp.hpp:61-69)
  * preceded by the Gram of GaussianProcessBase::_fit_impl (gp.hpp:281-294):

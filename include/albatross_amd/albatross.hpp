@@ -283,6 +283,13 @@ struct Expanded<F, true> {
       }
     }
   }
+  // combination j = expanded points offsets()[j] .. offsets()[j + 1] (the members were appended feature by feature)
+  std::vector<std::int64_t> offsets() const {
+    std::vector<std::int64_t> off(n + 1, 0);
+    for (std::size_t a = 0; a < owner.size(); ++a) ++off[owner[a] + 1];
+    for (std::size_t j = 0; j < n; ++j) off[j + 1] += off[j];
+    return off;
+  }
 };
 
 // mean_function(feature): sum_i a_i m(x_i) for a LinearCombination (callers.hpp:386-396)
@@ -406,14 +413,17 @@ class CovarianceFunction {
   // cov(xs): symmetric Gram, callers.hpp:107-166
   template <typename F>
   Matrix operator()(const std::vector<F> &xs) const {
-    if constexpr (detail::expansion<F>::expands) {  // LinearCombinationCaller, callers.hpp:336-347
-      const detail::Expanded<F> ex(xs);
-      const Matrix G = (*this)(ex.points);
+    if constexpr (detail::expansion<F>::expands) {  // LinearCombinationCaller, callers.hpp:336-347: Gram of the expanded
+      const detail::Expanded<F> ex(xs);              // points and its contraction on the device (agp_gram_combined)
+      auto ctx = detail::default_context();
+      detail::KernelHolder k(program());
+      detail::Flat fx = detail::flatten(derived(), ex.points);
+      const std::vector<std::int64_t> off = ex.offsets();
       Matrix out(static_cast<std::int64_t>(ex.n), static_cast<std::int64_t>(ex.n));
-      for (std::size_t b = 0; b < ex.points.size(); ++b)
-        for (std::size_t a = 0; a < ex.points.size(); ++a)
-          out(static_cast<std::int64_t>(ex.owner[a]), static_cast<std::int64_t>(ex.owner[b])) +=
-              ex.coefficient[a] * ex.coefficient[b] * G(static_cast<std::int64_t>(a), static_cast<std::int64_t>(b));
+      if (ex.n > 0)
+        detail::check(agp_gram_combined(ctx->ctx, k.k, &fx.view, static_cast<std::int64_t>(ex.n), off.data(), ex.coefficient.data(),
+                                        nullptr, 0, nullptr, nullptr, out.data.data(), static_cast<std::int64_t>(ex.n), AGP_HOST),
+                      ctx->ctx, "agp_gram_combined");
       return out;
     } else {
     auto ctx = detail::default_context();
@@ -429,21 +439,35 @@ class CovarianceFunction {
   // cov(xs, ys): cross Gram, callers.hpp:38-102
   template <typename F, typename G>
   Matrix operator()(const std::vector<F> &xs, const std::vector<G> &ys) const {
-    if constexpr (detail::expansion<F>::expands) {  // callers.hpp:336-376: expand the left argument ...
-      const detail::Expanded<F> ex(xs);
-      const Matrix Gm = (*this)(ex.points, ys);
-      Matrix out(static_cast<std::int64_t>(ex.n), Gm.cols());
-      for (std::int64_t j = 0; j < Gm.cols(); ++j)
-        for (std::size_t a = 0; a < ex.points.size(); ++a)
-          out(static_cast<std::int64_t>(ex.owner[a]), j) += ex.coefficient[a] * Gm(static_cast<std::int64_t>(a), j);
-      return out;
-    } else if constexpr (detail::expansion<G>::expands) {  // ... then the right one
-      const detail::Expanded<G> ey(ys);
-      const Matrix Gm = (*this)(xs, ey.points);
-      Matrix out(Gm.rows(), static_cast<std::int64_t>(ey.n));
-      for (std::size_t b = 0; b < ey.points.size(); ++b)
-        for (std::int64_t i = 0; i < Gm.rows(); ++i)
-          out(i, static_cast<std::int64_t>(ey.owner[b])) += ey.coefficient[b] * Gm(i, static_cast<std::int64_t>(b));
+    if constexpr (detail::expansion<F>::expands || detail::expansion<G>::expands) {  // callers.hpp:336-376, on the device
+      auto ctx = detail::default_context();
+      detail::KernelHolder k(program());
+      std::vector<std::int64_t> xoff, yoff;
+      std::vector<double> xc, yc;
+      std::int64_t nx = static_cast<std::int64_t>(xs.size()), ny = static_cast<std::int64_t>(ys.size());
+      detail::Flat fx, fy;
+      if constexpr (detail::expansion<F>::expands) {
+        const detail::Expanded<F> ex(xs);
+        fx = detail::flatten(derived(), ex.points);
+        xoff = ex.offsets();
+        xc = ex.coefficient;
+      } else {
+        fx = detail::flatten(derived(), xs);
+      }
+      if constexpr (detail::expansion<G>::expands) {
+        const detail::Expanded<G> ey(ys);
+        fy = detail::flatten(derived(), ey.points);
+        yoff = ey.offsets();
+        yc = ey.coefficient;
+      } else {
+        fy = detail::flatten(derived(), ys);
+      }
+      Matrix out(nx, ny);
+      if (nx > 0 && ny > 0)
+        detail::check(agp_gram_combined(ctx->ctx, k.k, &fx.view, nx, xoff.empty() ? nullptr : xoff.data(), xoff.empty() ? nullptr : xc.data(),
+                                        &fy.view, ny, yoff.empty() ? nullptr : yoff.data(), yoff.empty() ? nullptr : yc.data(),
+                                        out.data.data(), nx, AGP_HOST),
+                      ctx->ctx, "agp_gram_combined");
       return out;
     } else {
     auto ctx = detail::default_context();
