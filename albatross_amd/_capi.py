@@ -103,6 +103,7 @@ EXPORTS = [
     ("agp_ldlt_transpositions", C.c_int, [_P, _P]),
     ("agp_ldlt_download", C.c_int, [_P, _P, _P, C.c_int64]),
     ("agp_sparse_fit_create", C.c_int, [_P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.POINTER(Features), C.c_double, C.c_double, _PP, _P, _D]),
+    ("agp_sparse_fit_create_sharded", C.c_int, [_P, _P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.POINTER(Features), C.c_double, C.c_double, _PP, _P, _D]),
     ("agp_sparse_fit_update", C.c_int, [_P, _P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.c_double, _PP, _P]),
     ("agp_sparse_fit_destroy", None, [_P]),
     ("agp_sparse_fit_size", C.c_int64, [_P]),

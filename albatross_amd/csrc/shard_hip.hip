@@ -395,6 +395,40 @@ struct HipShardOps : ShardOps {
 
 using namespace agp;
 
+// all-reduce of a device buffer that kernels on the context's MAIN stream produced / will consume: used by entry points
+// outside the sharded dense fit (the sparse GP's group-sharded fit).  The minimal ShardOps a transport needs.
+namespace agp {
+struct MainStreamOps : ShardOps {
+  agp_context *ctx;
+  explicit MainStreamOps(agp_context *c) : ctx(c) {}
+  void *stream(int) override { return ctx->stream; }
+  bool device_memory() const override { return true; }
+  int to_host(int, const double *dev, double *host, long long count) override {
+    if (hipMemcpyAsync(host, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return AGP_ERR_HIP;
+    return wait_stream(ctx, ctx->stream, comm_timeout_seconds());
+  }
+  int from_host(int, const double *host, double *dev, long long count) override {
+    if (hipMemcpyAsync(dev, host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return AGP_ERR_HIP;
+    return wait_stream(ctx, ctx->stream, comm_timeout_seconds());
+  }
+  void factor_diag(int, double *, long long, long long, long long, double *, double *) override {}
+  void trsm_rows(int, double *, long long, long long, long long, const double *, const double *, const double *, double *) override {}
+  void gemm(int, double *, long long, const double *, long long, const double *, long long, long long, long long, long long, bool, int) override {}
+  void copy2d(int, double *, long long, const double *, long long, long long, long long) override {}
+  void invert_diag(int, const double *, long long, long long, const double *, double *) override {}
+  void colvec_dot(int, const double *, long long, long long, long long, const double *, double, double, const double *, double *) override {}
+  void axpby(int, long long, double, const double *, double, const double *, double *) override {}
+  void fill_zero(int, double *, long long) override {}
+  void status(double out[2]) override { out[0] = out[1] = 0.; }
+};
+
+int comm_all_reduce_device(agp_context *ctx, agp_comm *comm, double *dev, long long count, int op) {
+  if (!comm || !comm->impl || comm->impl->world == 1) return AGP_OK;
+  MainStreamOps ops(ctx);
+  return comm->impl->all_reduce(ops, QP, dev, count, op);
+}
+}  // namespace agp
+
 struct agp_sharded_fit {
   agp_context_impl *ctx = nullptr;
   agp_comm *comm = nullptr;

@@ -38,6 +38,10 @@ struct agp_sparse_fit {
   double nll = 0.;
 };
 
+namespace agp {
+int comm_all_reduce_device(agp_context *ctx, agp_comm *comm, double *dev, long long count, int op);  // shard_hip.hip
+}
+
 namespace {
 
 struct SparseScratch {
@@ -282,16 +286,21 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
 //   W   m x n (ld ldk), y_w (n);  y_t (m) or nullptr (zero)
 // Fills f->sigma (L1), f->sigma2 (L2), f->Lacc, f->v.  bq (optional, device, 1 double) receives
 // || L2^-1 L1^-1 (T y_t + W y_w) ||^2 for the likelihood.
+// comm (optional): the observations are split over the ranks of a communicator BY GROUP (every rank holds the W and y_w
+// of its own groups, all hold the same T): the m x m sums over observations - W W^T, Q1_W Q1_W^T - and the m-vectors
+// W y_w, W (y_w - W^T v) are all-reduced, everything else is replicated arithmetic; every rank ends with the same fit.
 int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long ldt, const double *W, long long ldk,
-                 long long n, const double *yw, const double *yt, SparseScratch &w, double *bq, StageTimer &stage) {
+                 long long n, const double *yw, const double *yt, SparseScratch &w, double *bq, StageTimer &stage,
+                 agp_comm *comm = nullptr) {
   const long long m = f->m, ldm = factor_ld(m), mp2 = round_up(m, 2), np2 = round_up(std::max<long long>(n, 1), 2);
   hipStream_t s = ctx->stream;
   int st = AGP_OK;
-  // M = T T^T + W W^T
+  // M = T T^T + W W^T   (the W part summed over the ranks)
   SPX_HIP(hipMalloc(&w.M0, sizeof(double) * (size_t)ldm * (size_t)m));
   SPX_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
-  launch_gemm_nt_sub(s, w.M0, ldm, T, ldt, false, T, ldt, false, m, m, m, true);
   if (n > 0) launch_gemm_nt_sub(s, w.M0, ldm, W, ldk, false, W, ldk, false, m, m, n, true);
+  if ((st = comm_all_reduce_device(ctx, comm, w.M0, ldm * m, 0)) != AGP_OK) return st;
+  launch_gemm_nt_sub(s, w.M0, ldm, T, ldt, false, T, ldt, false, m, m, m, true);
   launch_negate(s, w.M0, ldm, m, nullptr);
   stage("M = T T^T + W W^T");
   if ((st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma)) != AGP_OK) return st;
@@ -305,7 +314,10 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
                            hipMemcpyDeviceToDevice, s));
   forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, w.Q1T, n + m, ldk);
   SPX_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
-  launch_gemm_nt_sub(s, w.M0, ldm, w.Q1T, ldk, false, w.Q1T, ldk, false, m, m, n + m, true);
+  if (n > 0)  // the W columns of Q1 (summed over the ranks), then the T columns
+    launch_gemm_nt_sub(s, w.M0, ldm, w.Q1T + (size_t)ldk * (size_t)m, ldk, false, w.Q1T + (size_t)ldk * (size_t)m, ldk, false, m, m, n, true);
+  if ((st = comm_all_reduce_device(ctx, comm, w.M0, ldm * m, 0)) != AGP_OK) return st;
+  launch_gemm_nt_sub(s, w.M0, ldm, w.Q1T, ldk, false, w.Q1T, ldk, false, m, m, m, true);
   launch_negate(s, w.M0, ldm, m, nullptr);
   st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma2);
   (void)hipFree(w.Q1T); w.Q1T = nullptr;
@@ -330,17 +342,22 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
   // b = T y_t + W y_w   (B^T y_aug: :370-372 for a fit, :344-350 for an update)
   if (n > 0) launch_matvec(s, W, ldk, m, n, yw, w.partial, 1.0, 0.0, nullptr, bvec);
   else launch_axpby(s, m, 0.0, nullptr, 0.0, nullptr, bvec);
+  if ((st = comm_all_reduce_device(ctx, comm, bvec, m, 0)) != AGP_OK) return st;
   if (yt) launch_matvec(s, T, ldt, m, m, yt, w.partial, 1.0, 1.0, bvec, bvec);
   SPX_HIP(hipMemcpyAsync(vvec, bvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
   if ((st = sigma_solve(vvec)) != AGP_OK) return st;
   // two refinement steps against B itself: r = W (y_w - W^T v) + T (y_t - T^T v), v += (B^T B)^-1 r
   for (int it = 0; it < 2; ++it) {
-    launch_colvec_dot(s, T, ldt, m, m, vvec, -1.0, 1.0, yt, tt);
-    launch_matvec(s, T, ldt, m, m, tt, w.partial, 1.0, 0.0, nullptr, rvec);
+    // the observations' part first (summed over the ranks), then the prior part
     if (n > 0) {
       launch_colvec_dot(s, W, ldk, m, n, vvec, -1.0, 1.0, yw, tvec);
-      launch_matvec(s, W, ldk, m, n, tvec, w.partial, 1.0, 1.0, rvec, rvec);
+      launch_matvec(s, W, ldk, m, n, tvec, w.partial, 1.0, 0.0, nullptr, rvec);
+    } else {
+      launch_axpby(s, m, 0.0, nullptr, 0.0, nullptr, rvec);
     }
+    if ((st = comm_all_reduce_device(ctx, comm, rvec, m, 0)) != AGP_OK) return st;
+    launch_colvec_dot(s, T, ldt, m, m, vvec, -1.0, 1.0, yt, tt);
+    launch_matvec(s, T, ldt, m, m, tt, w.partial, 1.0, 1.0, rvec, rvec);
     SPX_HIP(hipMemcpyAsync(dv, rvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
     if ((st = sigma_solve(dv)) != AGP_OK) return st;
     launch_axpby(s, m, 1.0, vvec, 1.0, dv, vvec);
@@ -393,10 +410,10 @@ void agp_sparse_fit_destroy(agp_sparse_fit *f) {
 
 int64_t agp_sparse_fit_size(const agp_sparse_fit *f) { return f ? f->m : 0; }
 
-int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t n_groups,
-                          const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
-                          double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
-                          double *information, double *nll_out) {
+static int sparse_fit_create_impl(agp_context *ctx, agp_comm *comm, const agp_kernel *k, const agp_features *x, int64_t n_groups,
+                                  const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
+                                  double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
+                                  double *information, double *nll_out) {
   if (!ctx || !k || !x || !u || !y || !offsets || n_groups <= 0) return AGP_ERR_INVALID_ARGUMENT;
   if (out) *out = nullptr;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -439,7 +456,7 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_featu
   if ((st = sparse_observations(ctx, k, dprog, x, n_groups, offsets, y, y_var, measurement_nugget, f->u->v, f->kuu.get(), w,
                                 &yw, &log_det_a, stage)) != AGP_OK)
     return st;
-  if ((st = sparse_sigma(ctx, f.get(), w.T, ldm, w.Kuf, round_up(m, 2), n, yw, nullptr, w, ctx->d_scalars + 2, stage)) != AGP_OK)
+  if ((st = sparse_sigma(ctx, f.get(), w.T, ldm, w.Kuf, round_up(m, 2), n, yw, nullptr, w, ctx->d_scalars + 2, stage, comm)) != AGP_OK)
     return st;
   launch_dot(s, yw, yw, n, ctx->d_scalars + 1);  // y^T A^-1 y = y_w^T y_w  (:583-592); after the factor calls, which reset the scalars
   // negative log likelihood (:524-596): log|K| = log|A| + log|B^T B| - log|K_uu'|
@@ -447,11 +464,31 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_featu
   if (information) SPX_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
   SPX_HIP(hipStreamSynchronize(s));
   SPX_HIP(hipGetLastError());
-  const double log_det = log_det_a + (f->sigma->log_det + f->sigma2->log_det) - f->kuu->log_det;
-  f->nll = 0.5 * (log_det + (ctx->h_scalars[1] - ctx->h_scalars[2]) + (double)n * std::log(2 * M_PI));
+  // sums over the observations of all ranks: log|A|, y^T A^-1 y, n
+  double sums[3] = {log_det_a, ctx->h_scalars[1], (double)n};
+  if (comm && (st = agp_comm_all_reduce_host(comm, sums, 3, 0)) != AGP_OK) return st;
+  const double log_det = sums[0] + (f->sigma->log_det + f->sigma2->log_det) - f->kuu->log_det;
+  f->nll = 0.5 * (log_det + (sums[1] - ctx->h_scalars[2]) + sums[2] * std::log(2 * M_PI));
   if (nll_out) *nll_out = f->nll;
   if (out) *out = f.release();
   return AGP_OK;
+}
+
+int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t n_groups,
+                          const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
+                          double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
+                          double *information, double *nll_out) {
+  return sparse_fit_create_impl(ctx, nullptr, k, x, n_groups, offsets, y, y_var, u, measurement_nugget, inducing_nugget, out,
+                                information, nll_out);
+}
+
+int agp_sparse_fit_create_sharded(agp_context *ctx, agp_comm *comm, const agp_kernel *k, const agp_features *x, int64_t n_groups,
+                                  const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
+                                  double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
+                                  double *information, double *nll_out) {
+  if (!comm) return AGP_ERR_INVALID_ARGUMENT;
+  return sparse_fit_create_impl(ctx, comm, k, x, n_groups, offsets, y, y_var, u, measurement_nugget, inducing_nugget, out,
+                                information, nll_out);
 }
 
 // FitModel::update for the sparse GP: _update_impl (sparse_gp.hpp:322-371).  B = [R_old P_old^T; A^-1/2 K_fu],

@@ -220,7 +220,7 @@ class SparseGaussianProcessRegression:
             yv = np.ascontiguousarray(np.asarray(dataset.targets.covariance, dtype=np.float64)[order])
         return reordered, offsets, y, yv
 
-    def _create(self, dataset, want_fit):
+    def _create(self, dataset, want_fit, comm=None):
         ctx = self._ctx()
         cov = self.covariance_function_
         reordered, offsets, y, yv, u = self._components(dataset)
@@ -228,23 +228,31 @@ class SparseGaussianProcessRegression:
         sx, su = fx.as_struct(), fu.as_struct()
         h = C.c_void_p()
         nll = C.c_double()
-        st = ctx._lib.agp_sparse_fit_create(ctx._h, ctx.kernel(cov), C.byref(sx), len(offsets) - 1, _ptr(offsets),
-                                            _ptr(y), _ptr(yv), C.byref(su), self.measurement_nugget_,
-                                            self.inducing_nugget_, C.byref(h) if want_fit else None, None,
-                                            C.byref(nll))
+        if comm is None:
+            st = ctx._lib.agp_sparse_fit_create(ctx._h, ctx.kernel(cov), C.byref(sx), len(offsets) - 1, _ptr(offsets),
+                                                _ptr(y), _ptr(yv), C.byref(su), self.measurement_nugget_,
+                                                self.inducing_nugget_, C.byref(h) if want_fit else None, None,
+                                                C.byref(nll))
+        else:  # this rank's groups only; the m x m sums over observations are all-reduced inside the library
+            st = ctx._lib.agp_sparse_fit_create_sharded(ctx._h, comm._h, ctx.kernel(cov), C.byref(sx), len(offsets) - 1,
+                                                        _ptr(offsets), _ptr(y), _ptr(yv), C.byref(su), self.measurement_nugget_,
+                                                        self.inducing_nugget_, C.byref(h) if want_fit else None, None,
+                                                        C.byref(nll))
         ctx._check(st, "agp_sparse_fit_create")
         return (SparseGPFit(ctx, h, u, nll.value) if want_fit else None), nll.value
 
-    def fit(self, dataset, targets=None):
-        """_fit_impl (:354-381)."""
+    def fit(self, dataset, targets=None, comm=None):
+        """_fit_impl (:354-381).  comm (albatross_amd.distributed.Communicator): `dataset` holds THIS rank's groups of
+        one fit spread over all ranks (whole groups per rank; the inducing point strategy must return the same points
+        on every rank); every rank receives the same fit."""
         if targets is not None:
             dataset = RegressionDataset(dataset, targets)
-        fit, _ = self._create(dataset, True)
+        fit, _ = self._create(dataset, True, comm)
         return SparseFitModel(self, fit)
 
-    def log_likelihood(self, dataset):
+    def log_likelihood(self, dataset, comm=None):
         """:524-596, without the parameter priors (out of scope)."""
-        return -self._create(dataset, False)[1]
+        return -self._create(dataset, False, comm)[1]
 
 
 def sparse_gp_from_covariance_and_mean(covariance_function, mean_function, grouper_function, strategy,

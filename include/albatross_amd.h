@@ -120,6 +120,7 @@ typedef struct {
 typedef struct agp_context agp_context;
 typedef struct agp_kernel agp_kernel;
 typedef struct agp_fit agp_fit;
+typedef struct agp_comm agp_comm; /* transport of the multi-GPU entry points, see "multi-GPU" below */
 
 /* ---- context ------------------------------------------------------------- */
 /* One context per host thread (or externally locked).  Owns the HIP streams
@@ -347,6 +348,17 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *kernel, const agp_
                           const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
                           double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
                           double *information, double *nll);
+/* The same fit with the observations split BY GROUP over the ranks of a communicator (BASELINE
+ * configs[4]: "SparseGP (PITC) ... on 8 GPUs").  The groups of a PITC / FITC model are independent given the inducing
+ * points (sparse_gp.hpp:129-243), so every rank builds K_uf, P, the blocks of A and W for ITS groups alone (x, offsets, y,
+ * y_var: this rank's groups only, at least one) and the m x m sums over observations - W W^T and its CholeskyQR2
+ * repair - plus four m-vectors are all-reduced (2 x 8 m^2 B + O(m) per fit: 2 x 32 MiB at m = 2048).  Every rank passes
+ * the same inducing points u and receives the same fit (handle, information, nll of ALL observations); predictions then
+ * need no further exchange.  Collective. */
+int agp_sparse_fit_create_sharded(agp_context *ctx, agp_comm *comm, const agp_kernel *kernel, const agp_features *x,
+                                  int64_t n_groups, const int64_t *offsets, const double *y, const double *y_var,
+                                  const agp_features *u, double measurement_nugget, double inducing_nugget,
+                                  agp_sparse_fit **out, double *information, double *nll);
 void agp_sparse_fit_destroy(agp_sparse_fit *fit);
 int64_t agp_sparse_fit_size(const agp_sparse_fit *fit); /* number of inducing points */
 int agp_sparse_fit_information(agp_context *ctx, const agp_sparse_fit *fit, double *information);
@@ -409,7 +421,6 @@ int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
  *
  * agp_comm wraps the transport: RCCL (librccl of the ROCm installation, loaded at first use), or - for tests and
  * for boxes where RCCL cannot be used (it refuses two ranks on one device) - collectives supplied by the caller. */
-typedef struct agp_comm agp_comm;
 #define AGP_COMM_ID_BYTES 128
 /* ncclGetUniqueId: rank 0 calls it and hands the bytes to every rank by any means (a file, MPI, a TCP store). */
 int agp_comm_unique_id(void *id);

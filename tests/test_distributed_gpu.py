@@ -171,3 +171,95 @@ def test_sharded_fit_two_processes_one_gpu(world, n, block):
         assert np.abs(mean - om).max() <= 1e-8 * np.abs(om).max()
         assert np.abs(var - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-9
         assert all(np.array_equal(out[0][0], out[r][0]) for r in range(world))
+
+
+# ---- sparse GP (PITC) with its observations split by group over the ranks (BASELINE configs[4]) ----
+def _pitc(n, m, seed):
+    rng = np.random.default_rng(seed)
+    x = np.sort(rng.uniform(0., n / 16., n))
+    y = np.sin(x) + 0.1 * np.cos(10. * x) + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.02, n)
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.measurement_only(ab.IndependentNoise(0.1))
+    return x, y, yvar, cov, np.linspace(x.min(), x.max(), m)
+
+
+def _sparse_model(ctx, cov, x, u, gs):
+    sorted_x = np.sort(x)
+
+    def grouper(f):
+        r = np.searchsorted(sorted_x, np.asarray(f, dtype=np.float64).reshape(-1)) // gs
+        return r if np.ndim(f) else int(r[0])
+    grouper.vectorized = True
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "pitc", context=ctx)
+    model.set_param("inducing_nugget", 1e-6)
+    return model
+
+
+def _sparse_worker(rank, world, port, n, m, gs, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.init()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = ab.Context(0)
+        comm = Communicator.from_torch(ctx, transport="callbacks")
+        x, y, yvar, cov, u = _pitc(n, m, 7)
+        model = _sparse_model(ctx, cov, x, u, gs)
+        groups = np.arange(n) // gs
+        mine = (groups % world) == rank  # whole groups, dealt round-robin
+        ds = ab.RegressionDataset(x[mine], ab.MarginalDistribution(y[mine], yvar[mine]))
+        fm = model.fit(ds, comm=comm)
+        xs = np.linspace(x.min(), x.max(), 40)
+        marg = fm.predict(xs).marginal()
+        out[rank] = (fm.get_fit().information, fm.get_fit().nll, marg.mean, marg.covariance, model.log_likelihood(ds, comm=comm))
+        comm.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,m,gs", [(2, 4096, 96, 256), (3, 3000, 64, 250)])
+def test_sparse_fit_sharded_by_group(ctx, world, n, m, gs):
+    """agp_sparse_fit_create_sharded: every rank its own groups, the m x m sums all-reduced; == the one-process fit of
+    all observations (and through it the oracle, tests/test_sparse_gp_gpu.py)."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    with mpc.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [mpc.Process(target=_sparse_worker, args=(r, world, port, n, m, gs, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        x, y, yvar, cov, u = _pitc(n, m, 7)
+        model = _sparse_model(ctx, cov, x, u, gs)
+        ds = ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar))
+        ref = model.fit(ds)
+        v = ref.get_fit().information
+        xs = np.linspace(x.min(), x.max(), 40)
+        rm = ref.predict(xs).marginal()
+        keys = np.arange(n) // gs
+        ofit = orc.OracleSparseFit(cov, x, keys, y, yvar, u, model.get_params()["measurement_nugget"], 1e-6)
+        for r in range(world):
+            info, nll, mean, var, ll = out[r]
+            assert np.abs(info - v).max() <= 1e-8 * np.abs(v).max()
+            assert np.abs(info - ofit.information).max() <= 1e-7 * np.abs(v).max()
+            assert abs(nll - ref.get_fit().nll) <= 1e-8 * n and abs(nll - ofit.nll) <= 1e-8 * n and abs(ll + nll) <= 1e-9 * n
+            assert np.abs(mean - rm.mean).max() <= 1e-8 and np.abs(var - rm.covariance).max() <= 1e-8
+        assert all(np.array_equal(out[0][0], out[r][0]) for r in range(world))
+
+
+def test_sparse_fit_sharded_through_rccl_group_of_one(ctx):
+    comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id())
+    try:
+        x, y, yvar, cov, u = _pitc(2048, 64, 3)
+        model = _sparse_model(ctx, cov, x, u, 256)
+        ds = ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar))
+        a, b = model.fit(ds, comm=comm), model.fit(ds)
+        assert np.array_equal(a.get_fit().information, b.get_fit().information) and a.get_fit().nll == b.get_fit().nll
+    finally:
+        comm.close()
