@@ -146,7 +146,7 @@ __device__ __forceinline__ double eval_pair(const DevProgram *__restrict__ Pp, c
         v = sigma * sigma * (1 + q) * exp_neg(q);
       } else {
         const double q = sqrt(5.) * dist / l;
-        v = sigma * sigma * (1 + q + q * q / 3.) * exp_neg(q);
+        v = sigma * sigma * (1 + q + q * q * (1. / 3.)) * exp_neg(q);
       }
       stack_set(st, sp, v);
       ++sp;
@@ -206,6 +206,131 @@ __device__ __forceinline__ double eval_pair(const DevProgram *__restrict__ Pp, c
     if (op <= AGP_OP_SCALING) defined |= 1u << (sp - 1);  // a leaf was pushed: defined for every pair
   }
   return st[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sum-of-products form.  Most covariance functions in use are sums of products of leaves, possibly wrapped in
+// MeasurementOnly (the temperature example: scaling * constant + noise + exponential<angular> * squared_exponential
+// <radial>; sinc: polynomial + squared_exponential + measurement_only(noise)).  For those the postfix interpreter above
+// - a VGPR-indexed evaluation stack walked node by node - is replaced by a flat loop over terms and factors, and the
+// radial factors of one product share ONE exp: prod_i sigma_i^2 p_i(q_i) exp(-e_i) = (prod ...) exp(-sum_i e_i).
+// Differences to the reference's operation sequence: the exponents of a product are summed before the exp, and
+// distances are multiplied by 1/l instead of divided by l - a few ulp of the exponent argument (the parity bar of
+// tests/test_gram_gpu.py holds with a margin).  The product's `lhs != 0` short circuit (covariance_function.hpp:
+// 362-366) is kept in effect: a zero factor makes the term zero.  Trees that are not sums of products (a sum inside a
+// product, variant alternatives) keep the interpreter.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SOP_MAX_TERMS = 6;
+constexpr int SOP_MAX_FACTORS = 4;
+
+struct SopFactor {
+  int op;       // agp_op of the leaf
+  int metric;   // radial leaves
+  int column;   // scaling
+  int order;    // polynomial
+  double a;     // radial: sigma^2;  constant / noise / nugget: sigma^2;  polynomial: sigma_0
+  double b;     // radial: SE 1 / l, EXP 1 / l, M32 sqrt(3) / l, M52 sqrt(5) / l  (0 when l <= 0: the leaf is 0)
+  double c, d, e;  // polynomial: sigma_1..sigma_3
+};
+
+struct SopTerm {
+  int n_factors;
+  int measurement_only;  // the term (or one of its factors) is wrapped in MeasurementOnly: 0 unless both are measurements
+  SopFactor f[SOP_MAX_FACTORS];
+};
+
+struct SopProgram {
+  int n_terms;
+  int metric_mask;
+  int uses_equality;
+  int pad;
+  SopTerm t[SOP_MAX_TERMS];
+};
+
+template <int DIMP>
+__device__ __forceinline__ double eval_sop(const SopProgram &P, const Point<DIMP> &x, const Point<DIMP> &y, bool swapped,
+                                           bool have_ids, bool both_measurement) {
+  double d_euclid = 0., d_radial = 0., d_angular = 0.;
+  if (P.metric_mask & (1 << AGP_METRIC_EUCLIDEAN)) {
+    if (DIMP == 1) {
+      d_euclid = fabs(x.c[0] - y.c[0]);
+    } else {
+      double s = 0.;
+#pragma unroll
+      for (int d = 0; d < DIMP; ++d) {
+        const double t = x.c[d] - y.c[d];
+        s += t * t;
+      }
+      d_euclid = sqrt(s);
+    }
+  }
+  if (P.metric_mask & (1 << AGP_METRIC_RADIAL)) d_radial = fabs(x.norm - y.norm);
+  if (P.metric_mask & (1 << AGP_METRIC_ANGULAR)) {
+    double dot = 0.;
+#pragma unroll
+    for (int d = 0; d < DIMP; ++d) dot += x.c[d] * y.c[d];
+    const double c = dot / (x.norm * y.norm);
+    const double eps = 1e-16;  // EPSILON, distance_metrics.hpp:18
+    d_angular = (c > 1. - eps) ? 0. : ((c < -1. + eps) ? M_PI : acos(c));
+  }
+  bool equal = false;
+  if (P.uses_equality) {
+    if (have_ids) {
+      equal = (x.id == y.id);
+    } else {
+      equal = true;
+#pragma unroll
+      for (int d = 0; d < DIMP; ++d) equal = equal && (x.c[d] == y.c[d]);
+    }
+  }
+  double sum = 0.;
+  for (int ti = 0; ti < P.n_terms; ++ti) {
+    const SopTerm &T = P.t[ti];
+    if (T.measurement_only && !both_measurement) continue;  // measurement.hpp:87-102
+    double v = 1., expo = 0.;
+    bool any_exp = false;
+    // lhs * rhs with rhs skipped once lhs == 0 (covariance_function.hpp:362-366): 0 * inf stays 0
+    auto mul = [&v](double f) { v = (v != 0.) ? v * f : v; };
+    for (int fi = 0; fi < T.n_factors; ++fi) {
+      const SopFactor &F = T.f[fi];
+      const int op = F.op;
+      if (op <= AGP_OP_MATERN52) {
+        const double dist = F.metric == AGP_METRIC_EUCLIDEAN ? d_euclid : (F.metric == AGP_METRIC_RADIAL ? d_radial : d_angular);
+        const double q = dist * F.b;
+        double coef = F.a;
+        if (op == AGP_OP_SQUARED_EXPONENTIAL) expo += q * q;
+        else if (op == AGP_OP_EXPONENTIAL) expo += fabs(q);
+        else if (op == AGP_OP_MATERN32) { coef = coef * (1 + q); expo += q; }
+        else { coef = coef * (1 + q + q * q * (1. / 3.)); expo += q; }
+        mul((F.b > 0.) ? coef : 0.);  // length_scale <= 0: the leaf is 0 (radial.hpp:26-28)
+        any_exp = true;
+      } else if (op == AGP_OP_CONSTANT) {
+        mul(F.a);
+      } else if (op == AGP_OP_INDEPENDENT_NOISE || op == AGP_OP_NUGGET) {
+        mul(equal ? F.a : 0.);
+      } else if (op == AGP_OP_SCALING) {
+        double fx = x.s[0], fy = y.s[0];
+#pragma unroll
+        for (int k = 1; k < AGP_MAX_SCALE_COLUMNS; ++k) {
+          fx = (F.column == k) ? x.s[k] : fx;
+          fy = (F.column == k) ? y.s[k] : fy;
+        }
+        mul(fx * fy);
+      } else {  // AGP_OP_POLYNOMIAL, polynomials.hpp:78-86
+        const double sg[4] = {F.a, F.c, F.d, F.e};
+        double cov = 0., xp = 1., yp = 1.;
+        for (int q = 0; q <= F.order; ++q) {
+          cov += swapped ? sg[q] * sg[q] * yp * xp : sg[q] * sg[q] * xp * yp;
+          xp *= x.c[0];
+          yp *= y.c[0];
+        }
+        mul(cov);
+      }
+    }
+    if (any_exp) v = (v != 0.) ? v * exp_neg(expo) : v;
+    sum += v;
+  }
+  return sum;
 }
 
 }  // namespace agp

@@ -7,7 +7,9 @@
 // rows, so each wave store is 64 lanes x 16 B = 1 KiB of one output column
 // (fully coalesced), and the y-point of a column is an LDS broadcast read.
 // HBM-write bound: 8 B per entry out, 8*dim B per point in.
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include "common.h"
 
 namespace agp {
@@ -57,8 +59,10 @@ __device__ __forceinline__ Point<DIMP> read_point(const TileLds<DIMP> &L, int sl
   return p;
 }
 
-template <int DIMP>
-__global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const DevProgram *__restrict__ P, FeatView X, FeatView Y,
+// SOP: the covariance function is given in sum-of-products form (cov_eval.h: eval_sop), by value in the kernel
+// arguments; otherwise P is the postfix program for the interpreter.
+template <int DIMP, bool SOP>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const DevProgram *__restrict__ P, SopProgram sop, FeatView X, FeatView Y,
                                                             int symmetric, int lower_only, double *out,
                                                             long long ld, const double *diag_add,
                                                             int *nan_flag) {
@@ -66,7 +70,8 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const DevProgram *__
   const long long row0 = (long long)blockIdx.x * TM;
   const long long col0 = (long long)blockIdx.y * TN;
   if (lower_only && col0 > row0 + TM - 1) return;  // tile strictly above the diagonal
-  const bool need_norm = (P->metric_mask & ((1 << AGP_METRIC_RADIAL) | (1 << AGP_METRIC_ANGULAR))) != 0;
+  const int metric_mask = SOP ? sop.metric_mask : P->metric_mask;
+  const bool need_norm = (metric_mask & ((1 << AGP_METRIC_RADIAL) | (1 << AGP_METRIC_ANGULAR))) != 0;
   stage_points<DIMP>(L, 0, TM, X, row0, need_norm);
   stage_points<DIMP>(L, TM, TN, Y, col0, need_norm);
   __syncthreads();
@@ -88,8 +93,14 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const DevProgram *__
     const Point<DIMP> y = read_point<DIMP>(L, TM + cslot);
     // symmetric Gram: the reference evaluates caller(xs[i], xs[j]) with i >= j
     // and mirrors (callers.hpp:119-127); keep the same argument order.
-    double va = eval_pair<DIMP>(P, xa, y, symmetric && ra < col, have_ids, both_meas);
-    double vb = eval_pair<DIMP>(P, xb, y, symmetric && rb < col, have_ids, both_meas);
+    double va, vb;
+    if (SOP) {
+      va = eval_sop<DIMP>(sop, xa, y, symmetric && ra < col, have_ids, both_meas);
+      vb = eval_sop<DIMP>(sop, xb, y, symmetric && rb < col, have_ids, both_meas);
+    } else {
+      va = eval_pair<DIMP>(P, xa, y, symmetric && ra < col, have_ids, both_meas);
+      vb = eval_pair<DIMP>(P, xb, y, symmetric && rb < col, have_ids, both_meas);
+    }
     if (diag_add) {
       if (ra == col) va += diag_add[col];
       if (rb == col) vb += diag_add[col];
@@ -145,7 +156,7 @@ __device__ __forceinline__ double radial_fast(double s2, const FastParams &fp) {
     return fp.sigma2 * (1 + q) * exp_neg(q);
   } else {
     const double q = sqrt(s2) * fp.cq;
-    return fp.sigma2 * (1 + q + q * q / 3.) * exp_neg(q);
+    return fp.sigma2 * (1 + q + q * q * (1. / 3.)) * exp_neg(q);
   }
 }
 
@@ -273,12 +284,89 @@ static bool launch_gram_fast_t(hipStream_t s, const FastParams &fp, int op, cons
   }
 }
 
+// Postfix program -> sum-of-products form, when the tree is one (cov_eval.h).  A host-side symbolic evaluation of the
+// postfix program: every stack entry is a list of terms; SUM concatenates, PRODUCT joins two single-term operands,
+// MEASUREMENT_ONLY flags the terms of its operand.
+static bool build_sop(const DevProgram &H, SopProgram *out) {
+  struct Expr { int n_terms; SopTerm t[SOP_MAX_TERMS]; };
+  static thread_local Expr stack[AGP_MAX_STACK];
+  int sp = 0;
+  for (int i = 0; i < H.n_nodes; ++i) {
+    const agp_kernel_node &nd = H.nodes[i];
+    if (nd.op <= AGP_OP_SCALING) {
+      if (sp >= AGP_MAX_STACK) return false;
+      Expr &e = stack[sp++];
+      e.n_terms = 1;
+      SopTerm &t = e.t[0];
+      t.n_factors = 1;
+      t.measurement_only = 0;
+      SopFactor &f = t.f[0];
+      f.op = nd.op; f.metric = nd.metric; f.column = nd.column; f.order = nd.order;
+      f.a = f.b = f.c = f.d = f.e = 0.;
+      if (nd.op <= AGP_OP_MATERN52) {
+        const double l = nd.params[0], sg = nd.params[1];
+        f.a = sg * sg;
+        const double scale = nd.op == AGP_OP_MATERN32 ? sqrt(3.) : (nd.op == AGP_OP_MATERN52 ? sqrt(5.) : 1.);
+        f.b = l > 0. ? scale / l : 0.;
+      } else if (nd.op == AGP_OP_CONSTANT || nd.op == AGP_OP_INDEPENDENT_NOISE || nd.op == AGP_OP_NUGGET) {
+        f.a = nd.params[0] * nd.params[0];
+      } else if (nd.op == AGP_OP_POLYNOMIAL) {
+        f.a = nd.params[0]; f.c = nd.params[1]; f.d = nd.params[2]; f.e = nd.params[3];
+      }
+    } else if (nd.op == AGP_OP_SUM) {
+      if (sp < 2) return false;
+      Expr &l = stack[sp - 2], &r = stack[sp - 1];
+      if (l.n_terms + r.n_terms > SOP_MAX_TERMS) return false;
+      for (int k = 0; k < r.n_terms; ++k) l.t[l.n_terms + k] = r.t[k];
+      l.n_terms += r.n_terms;
+      --sp;
+    } else if (nd.op == AGP_OP_PRODUCT) {
+      if (sp < 2) return false;
+      Expr &l = stack[sp - 2], &r = stack[sp - 1];
+      if (l.n_terms != 1 || r.n_terms != 1) return false;  // a sum inside a product: not a sum of products
+      SopTerm &lt = l.t[0];
+      const SopTerm &rt = r.t[0];
+      if (lt.n_factors + rt.n_factors > SOP_MAX_FACTORS) return false;
+      for (int k = 0; k < rt.n_factors; ++k) lt.f[lt.n_factors + k] = rt.f[k];
+      lt.n_factors += rt.n_factors;
+      lt.measurement_only = lt.measurement_only || rt.measurement_only;  // a zero factor zeroes the product
+      --sp;
+    } else if (nd.op == AGP_OP_MEASUREMENT_ONLY) {
+      if (sp < 1) return false;
+      Expr &e = stack[sp - 1];
+      for (int k = 0; k < e.n_terms; ++k) e.t[k].measurement_only = 1;
+    } else {
+      return false;  // AGP_OP_TYPE_PAIR: defined / undefined bookkeeping stays with the interpreter
+    }
+  }
+  if (sp != 1) return false;
+  std::memset(out, 0, sizeof(*out));
+  out->n_terms = stack[0].n_terms;
+  out->metric_mask = H.metric_mask;
+  out->uses_equality = H.uses_equality;
+  for (int k = 0; k < stack[0].n_terms; ++k) out->t[k] = stack[0].t[k];
+  return true;
+}
+
+static bool sop_enabled() {
+  // read per call (a getenv is nothing next to a launch): the parity tests switch evaluators in one process
+  const char *e = getenv("AGP_GRAM_SOP");  // 0: always the postfix interpreter
+  return !(e && e[0] == '0');
+}
+
 template <int DIMP>
 static void launch_gram_t(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y,
                           bool symmetric, bool lower_only, double *out, long long ld,
-                          const double *diag_add, int *nan_flag) {
+                          const double *diag_add, int *nan_flag, const DevProgram *host_program) {
   dim3 grid((unsigned)((X.n + TM - 1) / TM), (unsigned)((Y.n + TN - 1) / TN));
-  hipLaunchKernelGGL(gram_kernel<DIMP>, grid, dim3(GRAM_THREADS), 0, s, P, X, Y, symmetric ? 1 : 0,
+  SopProgram sop;
+  if (host_program && sop_enabled() && build_sop(*host_program, &sop)) {
+    hipLaunchKernelGGL((gram_kernel<DIMP, true>), grid, dim3(GRAM_THREADS), 0, s, P, sop, X, Y, symmetric ? 1 : 0,
+                       lower_only ? 1 : 0, out, ld, diag_add, nan_flag);
+    return;
+  }
+  std::memset(&sop, 0, sizeof(sop));
+  hipLaunchKernelGGL((gram_kernel<DIMP, false>), grid, dim3(GRAM_THREADS), 0, s, P, sop, X, Y, symmetric ? 1 : 0,
                      lower_only ? 1 : 0, out, ld, diag_add, nan_flag);
 }
 
@@ -305,11 +393,11 @@ void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const Fe
       if (done) return;
     }
   }
-  if (dim == 1) launch_gram_t<1>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
-  else if (dim == 2) launch_gram_t<2>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
-  else if (dim == 3) launch_gram_t<3>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
-  else if (dim == 4) launch_gram_t<4>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
-  else launch_gram_t<8>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag);
+  if (dim == 1) launch_gram_t<1>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag, host_program);
+  else if (dim == 2) launch_gram_t<2>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag, host_program);
+  else if (dim == 3) launch_gram_t<3>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag, host_program);
+  else if (dim == 4) launch_gram_t<4>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag, host_program);
+  else launch_gram_t<8>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag, host_program);
 }
 
 // ---- diagonal: prior_variance[i] = cov(f_i, f_i)  (gp.hpp:339-343) -----------
@@ -348,13 +436,14 @@ void launch_gram_diagonal(hipStream_t s, const DevProgram *P, const FeatView &X,
 // strides over the training points; wave reduction at the end.
 constexpr int PM_WAVES = 4;
 
-template <int DIMP>
-__global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_kernel(const DevProgram *__restrict__ P, FeatView X, FeatView XS,
-                                                                      const double *alpha, double *mean) {
+template <int DIMP, bool SOP>
+__global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_kernel(const DevProgram *__restrict__ P, SopProgram sop, FeatView X,
+                                                                      FeatView XS, const double *alpha, double *mean) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long j = (long long)blockIdx.x * PM_WAVES + wave;
   if (j >= XS.n) return;
-  const bool need_norm = (P->metric_mask & ((1 << AGP_METRIC_RADIAL) | (1 << AGP_METRIC_ANGULAR))) != 0;
+  const int metric_mask = SOP ? sop.metric_mask : P->metric_mask;
+  const bool need_norm = (metric_mask & ((1 << AGP_METRIC_RADIAL) | (1 << AGP_METRIC_ANGULAR))) != 0;
   Point<DIMP> y;
   double nn = 0.;
 #pragma unroll
@@ -381,7 +470,7 @@ __global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_kernel(const DevPr
 #pragma unroll
     for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) x.s[k] = k < X.nsc ? X.scales[(long long)k * scale_stride(X) + i] : 0.;
     x.id = X.ids ? X.ids[i] : -1;
-    acc += eval_pair<DIMP>(P, x, y, false, have_ids, both_meas) * alpha[i];
+    acc += (SOP ? eval_sop<DIMP>(sop, x, y, false, have_ids, both_meas) : eval_pair<DIMP>(P, x, y, false, have_ids, both_meas)) * alpha[i];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -462,11 +551,20 @@ void launch_predict_mean(hipStream_t s, const DevProgram *P, const FeatView &X, 
   }
   dim3 grid((unsigned)((XS.n + PM_WAVES - 1) / PM_WAVES)), block(64 * PM_WAVES);
   const int dim = X.dim;
-  if (dim == 1) hipLaunchKernelGGL(predict_mean_kernel<1>, grid, block, 0, s, P, X, XS, alpha, mean);
-  else if (dim == 2) hipLaunchKernelGGL(predict_mean_kernel<2>, grid, block, 0, s, P, X, XS, alpha, mean);
-  else if (dim == 3) hipLaunchKernelGGL(predict_mean_kernel<3>, grid, block, 0, s, P, X, XS, alpha, mean);
-  else if (dim == 4) hipLaunchKernelGGL(predict_mean_kernel<4>, grid, block, 0, s, P, X, XS, alpha, mean);
-  else hipLaunchKernelGGL(predict_mean_kernel<8>, grid, block, 0, s, P, X, XS, alpha, mean);
+  SopProgram sop;
+  const bool use_sop = host_program && sop_enabled() && build_sop(*host_program, &sop);
+  if (!use_sop) std::memset(&sop, 0, sizeof(sop));
+#define AGP_PM_LAUNCH(D)                                                                                                      \
+  do {                                                                                                                       \
+    if (use_sop) hipLaunchKernelGGL((predict_mean_kernel<D, true>), grid, block, 0, s, P, sop, X, XS, alpha, mean);           \
+    else hipLaunchKernelGGL((predict_mean_kernel<D, false>), grid, block, 0, s, P, sop, X, XS, alpha, mean);                  \
+  } while (0)
+  if (dim == 1) AGP_PM_LAUNCH(1);
+  else if (dim == 2) AGP_PM_LAUNCH(2);
+  else if (dim == 3) AGP_PM_LAUNCH(3);
+  else if (dim == 4) AGP_PM_LAUNCH(4);
+  else AGP_PM_LAUNCH(8);
+#undef AGP_PM_LAUNCH
 }
 
 }  // namespace agp
