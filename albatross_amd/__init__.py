@@ -16,6 +16,7 @@ from .gp import (AlbatrossAmdError, BlockSymmetric, ExplainedCovariance, Pivoted
                  RegressionDataset, ZeroMean, default_context, gp_from_covariance, gp_from_covariance_and_mean)
 
 from .sparse_gp import (FixedInducingPoints, SparseFitModel, SparseGaussianProcessRegression, SparseGPFit,
-                        UniformlySpacedInducingPoints, sparse_gp_from_covariance, sparse_gp_from_covariance_and_mean)
+                        UniformlySpacedInducingPoints, rebase_inducing_points, sparse_gp_from_covariance,
+                        sparse_gp_from_covariance_and_mean)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -105,6 +105,8 @@ EXPORTS = [
     ("agp_sparse_fit_create", C.c_int, [_P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.POINTER(Features), C.c_double, C.c_double, _PP, _P, _D]),
     ("agp_sparse_fit_create_sharded", C.c_int, [_P, _P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.POINTER(Features), C.c_double, C.c_double, _PP, _P, _D]),
     ("agp_sparse_fit_update", C.c_int, [_P, _P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.c_double, _PP, _P]),
+    ("agp_sparse_fit_from_prediction", C.c_int, [_P, _P, C.POINTER(Features), _P, _P, C.c_int64, C.c_int, C.c_double, _PP, _P, _P]),
+    ("agp_sparse_fit_numerical_rank", C.c_int64, [_P]),
     ("agp_sparse_fit_destroy", None, [_P]),
     ("agp_sparse_fit_size", C.c_int64, [_P]),
     ("agp_sparse_fit_information", C.c_int, [_P, _P, _P]),

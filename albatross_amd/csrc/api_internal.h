@@ -50,7 +50,36 @@ int fit_expand_matrix(agp_context *ctx, const agp_fit *f, const double *real_in,
 int fit_compact_matrix(agp_context *ctx, const agp_fit *f, const double *padded_dev, long long ldp, long long nrhs, double *real_out,
                        long long ldr, int location);
 void fit_zero_phantom_rows(hipStream_t s, const agp_fit *f, double *V, long long ldv, long long cols);
+// pivoted L D L^T (ldlt.hip)
+void ldlt_factor(hipStream_t s, double *A, long long lda, long long n, const long long *tr_host, double *temp, int *info,
+                 double *scal);
+void ldlt_factor_blocked(hipStream_t s, double *Ap, long long lda, long long n, double *T, double *dotacc, int *info);
+void ldlt_permute_sym(hipStream_t s, const double *S, long long lds, const long long *q_dev, long long n, double *Ap,
+                      long long lda);
+void ldlt_solve(hipStream_t s, const double *A, long long lda, long long n, const long long *q_dev, double *W,
+                double *R, long long ldw, long long nrhs);
+void ldlt_sqrt_solve(hipStream_t s, const double *A, long long lda, long long n, const long long *q_dev, double *W,
+                     const double *R, long long ldw, long long nrhs);
+// column-pivoted Householder QR and the substitutions against R (qr.hip)
+void colpiv_qr(hipStream_t s, double *A, long long lda, long long rows, long long cols, long long extra, double *tau,
+               long long *perm, double *norms, double *state);
+void qr_extract_r(hipStream_t s, const double *A, long long lda, long long m, double *R, long long ldr, double inflate);
+void qr_root(hipStream_t s, const double *R, long long ldr, const long long *perm, long long m, double *T, long long ldt);
+void qr_sqrt_solve(hipStream_t s, const double *R, long long ldr, const long long *perm, long long m, const double *X,
+                   long long ldx, double *W, long long ldw, long long nrhs);
+void qr_back_solve(hipStream_t s, const double *R, long long ldr, const long long *perm, long long m, long long np, double *c,
+                   double *out);
 }  // namespace agp
+
+struct agp_ldlt {
+  agp_context *ctx = nullptr;
+  long long n = 0, lda = 0;
+  double *A = nullptr;          // matrixLDLT: L strictly below the diagonal (unit diagonal implied), D on it
+  long long *q_dev = nullptr;   // the permutation the transpositions compose to: (P b)[i] = b[q[i]]
+  std::vector<long long> tr;
+  std::vector<double> d;        // vectorD (host copy)
+  int success = 1;              // Eigen's info() == Success
+};
 
 struct ProgSlot {
   unsigned long long uid = 0;

@@ -361,6 +361,37 @@ __global__ __launch_bounds__(256) void ldlt_dscale_kernel(const double *__restri
   }
 }
 
+// D^-1/2 : 1 / sqrt(D_i) where D_i > 0, else 0 (diagonal_sqrt_inverse, serializable_ldlt.hpp:58-69)
+__global__ __launch_bounds__(256) void ldlt_dsqrt_scale_kernel(const double *__restrict__ A, long long lda, long long n,
+                                                               double *W, long long ldw, long long nrhs) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double d = A[i + i * lda];
+  const double f = d > 0. ? 1. / sqrt(d) : 0.;
+  for (long long j = blockIdx.y; j < nrhs; j += gridDim.y) {
+    double *w = W + j * ldw + i;
+    *w = *w * f;
+  }
+}
+
+// sqrt_solve (serializable_ldlt.hpp:99-109): W <- D^-1/2 L^-1 P R.  R (n x nrhs, ldw) is only read.
+void ldlt_sqrt_solve(hipStream_t s, const double *A, long long lda, long long n, const long long *q_dev, double *W,
+                     const double *R, long long ldw, long long nrhs) {
+  if (n <= 0 || nrhs <= 0) return;
+  const unsigned cgrid = (unsigned)((nrhs + 3) / 4);
+  const dim3 pgrid((unsigned)((n + 255) / 256), (unsigned)nrhs);
+  hipLaunchKernelGGL(ldlt_permute_kernel, pgrid, dim3(256), 0, s, W, R, (double *)nullptr, ldw, n, q_dev, 0);
+  for (long long k = 0; k < n; k += LB) {
+    const int nb = (int)((n - k < LB) ? n - k : LB);
+    hipLaunchKernelGGL((ldlt_diag_solve_kernel<false>), dim3(cgrid), dim3(256), 0, s, A, lda, k, nb, W, ldw, nrhs);
+    const long long rows = n - (k + nb);
+    if (rows > 0)
+      launch_gemm_nt_sub(s, W + k + nb, ldw, A + k * lda + (k + nb), lda, false, W + k, ldw, true, rows, nrhs, nb, false);
+  }
+  const unsigned gy = (unsigned)(nrhs < 64 ? nrhs : 64);
+  hipLaunchKernelGGL(ldlt_dsqrt_scale_kernel, dim3((unsigned)((n + 255) / 256), gy), dim3(256), 0, s, A, lda, n, W, ldw, nrhs);
+}
+
 // R (n x nrhs, ldw) holds the right-hand sides on entry and the solution on return; W is scratch of the same shape
 void ldlt_solve(hipStream_t s, const double *A, long long lda, long long n, const long long *q_dev, double *W,
                 double *R, long long ldw, long long nrhs) {

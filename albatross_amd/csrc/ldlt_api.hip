@@ -7,27 +7,8 @@
 
 #include "api_internal.h"
 
-namespace agp {
-void ldlt_factor(hipStream_t s, double *A, long long lda, long long n, const long long *tr_host, double *temp, int *info,
-                 double *scal);
-void ldlt_factor_blocked(hipStream_t s, double *Ap, long long lda, long long n, double *T, double *dotacc, int *info);
-void ldlt_permute_sym(hipStream_t s, const double *S, long long lds, const long long *q_dev, long long n, double *Ap,
-                      long long lda);
-void ldlt_solve(hipStream_t s, const double *A, long long lda, long long n, const long long *q_dev, double *W,
-                double *R, long long ldw, long long nrhs);
-}  // namespace agp
 
 using namespace agp;
-
-struct agp_ldlt {
-  agp_context *ctx = nullptr;
-  long long n = 0, lda = 0;
-  double *A = nullptr;          // matrixLDLT: L strictly below the diagonal (unit diagonal implied), D on it
-  long long *q_dev = nullptr;   // the permutation the transpositions compose to: (P b)[i] = b[q[i]]
-  std::vector<long long> tr;
-  std::vector<double> d;        // vectorD (host copy)
-  int success = 1;              // Eigen's info() == Success
-};
 
 extern "C" {
 

@@ -36,6 +36,16 @@ struct agp_sparse_fit {
   double *Lacc = nullptr;              // L1 L2, m x ldm, zero above the diagonal
   double *v = nullptr;                 // information (m)
   double nll = 0.;
+  // "pivoted form" of a fit made by agp_sparse_fit_from_prediction (rebase_inducing_points) or by an update of one:
+  // the reference's own representation, for covariances that are singular to working precision.
+  std::shared_ptr<agp_ldlt> kz;        // train_covariance as a pivoted L D L^T: K_zz WITHOUT nugget after fit_from_prediction
+                                       // (:416-418), K_uu + inducing nugget after a pivoted fit (:676-679); else kuu
+  std::shared_ptr<agp_ldlt> kp;        // pivoted L D L^T of K_uu + inducing nugget for P = K_uu^-1/2 K_uf of an update, when
+                                       // the LL^T of that matrix (kuu) does not exist
+  double *R = nullptr;                 // m x round_up(m, 2), upper triangular: Sigma^-1 = P R^T R P^T; else sigma/sigma2
+  long long *perm = nullptr;           // P: perm[i] = original index of the column at position i
+  long long rank = -1;                 // numerical_rank of the QR (-1: not a pivoted fit)
+  double inducing_nugget = 0.;         // the nugget an update adds to K_uu for P = K_uu^-1/2 K_uf (:674-685)
 };
 
 namespace agp {
@@ -97,7 +107,7 @@ struct StageTimer {
 int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram *dprog, const agp_features *x,
                         int64_t n_groups, const int64_t *offsets, const double *y, const double *y_var,
                         double measurement_nugget, const FeatView &uv, const agp_fit *kuu, SparseScratch &w,
-                        double **yw_out, double *log_det_a_out, StageTimer &stage) {
+                        double **yw_out, double *log_det_a_out, StageTimer &stage, const agp_ldlt *kp = nullptr) {
   const long long n = x->n, m = uv.n;
   hipStream_t s = ctx->stream;
   int st = AGP_OK;
@@ -129,8 +139,12 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
   SPX_HIP(hipMalloc(&w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n));
   SPX_HIP(hipMalloc(&w.Pbuf, sizeof(double) * (size_t)ldk * (size_t)n));
   launch_gram(s, dprog, uv, xm, false, false, w.Kuf, ldk, nullptr, nullptr, &k->prog);
-  SPX_HIP(hipMemcpyAsync(w.Pbuf, w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n, hipMemcpyDeviceToDevice, s));
-  forward_solve_mat(s, kuu->A, m, kuu->lda, kuu->invd, w.Pbuf, n, ldk);
+  if (kp) {  // P = K_uu_ldlt.sqrt_solve(K_uf) with the pivoted L D L^T (:680-685)
+    ldlt_sqrt_solve(s, kp->A, kp->lda, m, kp->q_dev, w.Pbuf, w.Kuf, ldk, n);
+  } else {
+    SPX_HIP(hipMemcpyAsync(w.Pbuf, w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n, hipMemcpyDeviceToDevice, s));
+    forward_solve_mat(s, kuu->A, m, kuu->lda, kuu->invd, w.Pbuf, n, ldk);
+  }
   SPX_HIP(hipStreamSynchronize(s));
   stage("K_uf, P = L_u^-1 K_uf");
   // A block by block, then W = K_uf A^-T/2 (in place in K_uf) and y_w = A^-1/2 y  (:652-704; B's top block
@@ -405,12 +419,157 @@ void agp_sparse_fit_destroy(agp_sparse_fit *f) {
   if (f->sigma2) agp_fit_destroy(f->sigma2);
   if (f->Lacc) (void)hipFree(f->Lacc);
   if (f->v) (void)hipFree(f->v);
+  f->kz.reset();
+  f->kp.reset();
+  if (f->R) (void)hipFree(f->R);
+  if (f->perm) (void)hipFree(f->perm);
   delete f;
 }
 
 int64_t agp_sparse_fit_size(const agp_sparse_fit *f) { return f ? f->m : 0; }
 
-static int sparse_fit_create_impl(agp_context *ctx, agp_comm *comm, const agp_kernel *k, const agp_features *x, int64_t n_groups,
+// B[r0 + a, c] = W[c, a]: the observations' rows of B = [R P^T; A^-1/2 K_fu] from W = K_uf A^-T/2 (m x n)
+__global__ __launch_bounds__(256) void transpose_into_kernel(const double *__restrict__ W, long long ldw, long long m, long long n,
+                                                             double *B, long long ldb, long long r0) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const long long c0 = (long long)blockIdx.x * 32, a0 = (long long)blockIdx.y * 32;
+  for (int q = ty; q < 32; q += 8) {
+    const long long c = c0 + tx, a = a0 + q;
+    tile[q][tx] = (c < m && a < n) ? W[c + a * ldw] : 0.;
+  }
+  __syncthreads();
+  for (int q = ty; q < 32; q += 8) {
+    const long long a = a0 + tx, c = c0 + q;
+    if (a < n && c < m) B[r0 + a + c * ldb] = tile[tx][q];
+  }
+}
+
+__global__ __launch_bounds__(256) void add_to_diagonal_kernel(double *A, long long ld, long long n, double value) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) A[i + i * ld] += value;
+}
+
+// LL^T of K_uu + nugget I  (compute_internal_components, sparse_gp.hpp:674-679)
+static int factor_kuu(agp_context *ctx, const agp_kernel *k, const DevProgram *dprog, const FeatView &uv, double nugget,
+                      std::shared_ptr<agp_fit> *out, double **T_out) {
+  const long long m = uv.n, ldm = factor_ld(m);
+  hipStream_t s = ctx->stream;
+  double *nug = nullptr, *T = nullptr;
+  SPX_HIP(hipMalloc(&nug, sizeof(double) * (size_t)round_up(m, 2)));
+  std::unique_ptr<double, void (*)(double *)> nug_guard(nug, [](double *p) { (void)hipFree(p); });
+  launch_axpby(s, m, 0.0, nullptr, nugget, nullptr, nug);
+  SPX_HIP(hipMalloc(&T, sizeof(double) * (size_t)ldm * (size_t)m));
+  std::unique_ptr<double, void (*)(double *)> t_guard(T, [](double *p) { (void)hipFree(p); });
+  launch_gram(s, dprog, uv, uv, true, true, T, ldm, nug, nullptr, &k->prog);
+  agp_fit *kuu = nullptr;
+  const int st = agp_factor_create(ctx, T, m, ldm, 0, AGP_DEVICE, &kuu);
+  *out = std::shared_ptr<agp_fit>(kuu, [](agp_fit *p) { agp_fit_destroy(p); });
+  if (st != AGP_OK) return st;
+  if (T_out) *T_out = t_guard.release();
+  return AGP_OK;
+}
+
+// T = P^T L D^1/2 (m x ldt) from a pivoted L D L^T: T T^T = P^T L D L^T P is the factored matrix; its transpose is the
+// reference's sqrt_transpose() = D^1/2 (P^T L)^T (serializable_ldlt.hpp:111-115), the prior rows of B (:349)
+__global__ __launch_bounds__(256) void ldlt_root_kernel(const double *__restrict__ A, long long lda, const long long *__restrict__ q,
+                                                        long long m, double *T, long long ldt) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if (i >= m) return;
+  const double d = A[c + c * lda];
+  const double sd = d > 0. ? sqrt(d) : 0.;  // diagonal_sqrt (:74-84)
+  const double l = i == c ? 1. : (i > c ? A[i + c * lda] : 0.);
+  T[q[i] + c * ldt] = l * sd;
+}
+
+// pivoted L D L^T of K_uu + nugget I  (compute_internal_components, sparse_gp.hpp:674-679, as the reference factors it)
+static int factor_kuu_pivoted(agp_context *ctx, const agp_kernel *k, const DevProgram *dprog, const FeatView &uv, double nugget,
+                              std::shared_ptr<agp_ldlt> *out) {
+  const long long m = uv.n, ldq = round_up(m, 2);
+  hipStream_t s = ctx->stream;
+  double *K = nullptr;
+  SPX_HIP(hipMalloc(&K, sizeof(double) * (size_t)ldq * (size_t)m));
+  std::unique_ptr<double, void (*)(double *)> guard(K, [](double *p) { (void)hipFree(p); });
+  launch_gram(s, dprog, uv, uv, true, false, K, ldq, nullptr, nullptr, &k->prog);
+  hipLaunchKernelGGL(add_to_diagonal_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, K, ldq, m, nugget);
+  agp_ldlt *kz = nullptr;
+  const int st = agp_ldlt_create(ctx, K, m, ldq, 0, AGP_DEVICE, &kz, nullptr);
+  *out = std::shared_ptr<agp_ldlt>(kz, [](agp_ldlt *p) { agp_ldlt_destroy(p); });
+  return st;
+}
+
+static int sparse_pivoted_from_rows(agp_context *ctx, agp_sparse_fit *f, const double *T, long long ldt, const double *W,
+                                    long long ldw, long long n, const double *yt, const double *yw, bool inflate);
+
+// _fit_impl (:354-381) with the reference's own factorisations - pivoted L D L^T of K_uu + nugget, column-pivoted QR of
+// B = [A^-1/2 K_fu; K_uu^T/2] - for the cases the LL^T / CholeskyQR2 path below rejects (K_uu or B^T B singular to
+// working precision: inducing points denser than the length scale).  Level-2 bound: moderate m.
+static int sparse_fit_create_pivoted(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t n_groups,
+                                     const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
+                                     double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
+                                     double *information, double *nll_out) {
+  if (!ctx || !k || !x || !u || !y || !offsets || n_groups <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  if (out) *out = nullptr;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(x);
+  if (st == AGP_OK) st = validate_features(u);
+  if (st != AGP_OK) return st;
+  const long long n = x->n, m = u->n, ldm = factor_ld(m), ldk = round_up(m, 2);
+  if (n <= 0 || m <= 0 || u->dim != x->dim || offsets[0] != 0 || offsets[n_groups] != n) return AGP_ERR_INVALID_ARGUMENT;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  hipStream_t s = ctx->stream;
+  StageTimer stage(s);
+  std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
+  if (!f) return AGP_ERR_INVALID_ARGUMENT;
+  f->ctx = ctx; f->m = m; f->inducing_nugget = inducing_nugget;
+  SparseScratch w;
+  f->u = std::shared_ptr<DeviceFeatures>(new DeviceFeatures(), [](DeviceFeatures *d) { d->release(); delete d; });
+  if ((st = to_device(ctx, u, true, f->u.get())) != AGP_OK) return st;
+  if ((st = factor_kuu_pivoted(ctx, k, dprog, f->u->v, inducing_nugget, &f->kz)) != AGP_OK) return st;
+  f->kp = f->kz;
+  SPX_HIP(hipMalloc(&w.T, sizeof(double) * (size_t)ldm * (size_t)m));
+  SPX_HIP(hipMemsetAsync(w.T, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
+  hipLaunchKernelGGL(ldlt_root_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, s, f->kz->A, f->kz->lda,
+                     f->kz->q_dev, m, w.T, ldm);
+  stage("K_uu + pivoted factor");
+  double *yw = nullptr, log_det_a = 0.;
+  if ((st = sparse_observations(ctx, k, dprog, x, n_groups, offsets, y, y_var, measurement_nugget, f->u->v, nullptr, w, &yw,
+                                &log_det_a, stage, f->kp.get())) != AGP_OK)
+    return st;
+  if ((st = sparse_pivoted_from_rows(ctx, f.get(), w.T, ldm, w.Kuf, ldk, n, nullptr, yw, false)) != AGP_OK) return st;
+  stage("pivoted QR of B");
+  // negative log likelihood (:524-596): log|K| = log|A| + 2 log|R| - log|K_uu|; q = y^T A^-1 y - y_b^T y_b, y_b = R^-T P^T K_uf A^-1 y
+  const long long chunks = (std::max(n, m) + 1023) / 1024;
+  double *vb = nullptr;
+  SPX_HIP(hipMalloc(&vb, sizeof(double) * ((size_t)chunks * (size_t)m + (size_t)3 * (size_t)ldk)));
+  std::unique_ptr<double, void (*)(double *)> vb_guard(vb, [](double *p) { (void)hipFree(p); });
+  double *partial = vb, *bvec = vb + (size_t)chunks * (size_t)m, *yb = bvec + ldk, *rdiag = yb + ldk;
+  launch_matvec(s, w.Kuf, ldk, m, n, yw, partial, 1.0, 0.0, nullptr, bvec);
+  qr_sqrt_solve(s, f->R, ldk, f->perm, m, bvec, ldk, yb, ldk, 1);
+  launch_dot(s, yw, yw, n, ctx->d_scalars + 1);
+  launch_dot(s, yb, yb, m, ctx->d_scalars + 2);
+  SPX_HIP(hipMemcpy2DAsync(rdiag, sizeof(double), f->R, sizeof(double) * (size_t)(ldk + 1), sizeof(double), (size_t)m,
+                           hipMemcpyDeviceToDevice, s));
+  std::vector<double> hr((size_t)m);
+  SPX_HIP(hipMemcpyAsync(hr.data(), rdiag, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
+  SPX_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (information) SPX_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
+  SPX_HIP(hipStreamSynchronize(s));
+  SPX_HIP(hipGetLastError());
+  double log_det_r = 0., log_det_kuu = 0.;
+  for (long long i = 0; i < m; ++i) {
+    log_det_r += std::log(std::fabs(hr[(size_t)i]));     // matrixR().diagonal().array().cwiseAbs().log().sum() (:549-550)
+    log_det_kuu += std::log(f->kz->d[(size_t)i]);       // vectorD().array().log().sum() (serializable_ldlt.hpp:128-135)
+  }
+  const double log_det = log_det_a + 2. * log_det_r - log_det_kuu;
+  f->nll = 0.5 * (log_det + (ctx->h_scalars[1] - ctx->h_scalars[2]) + (double)n * std::log(2 * M_PI));
+  if (nll_out) *nll_out = f->nll;
+  if (out) *out = f.release();
+  return AGP_OK;
+}
+
+static int sparse_fit_create_fast(agp_context *ctx, agp_comm *comm, const agp_kernel *k, const agp_features *x, int64_t n_groups,
                                   const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
                                   double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
                                   double *information, double *nll_out) {
@@ -428,25 +587,14 @@ static int sparse_fit_create_impl(agp_context *ctx, agp_comm *comm, const agp_ke
   StageTimer stage(s);
   std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
   if (!f) return AGP_ERR_INVALID_ARGUMENT;
-  f->ctx = ctx; f->m = m;
+  f->ctx = ctx; f->m = m; f->inducing_nugget = inducing_nugget;
   SparseScratch w;
   f->u = std::shared_ptr<DeviceFeatures>(new DeviceFeatures(), [](DeviceFeatures *d) { d->release(); delete d; });
   if ((st = to_device(ctx, u, true, f->u.get())) != AGP_OK) return st;
 
   // K_uu + inducing_nugget I  (:674-679) -> LL^T ; T = L_u with explicit zeros above the diagonal
   const long long ldm = factor_ld(m);
-  double *nug = nullptr;
-  SPX_HIP(hipMalloc(&nug, sizeof(double) * (size_t)round_up(m, 2)));
-  std::unique_ptr<double, void (*)(double *)> nug_guard(nug, [](double *p) { (void)hipFree(p); });
-  launch_axpby(s, m, 0.0, nullptr, inducing_nugget, nullptr, nug);
-  SPX_HIP(hipMalloc(&w.T, sizeof(double) * (size_t)ldm * (size_t)m));
-  launch_gram(s, dprog, f->u->v, f->u->v, true, true, w.T, ldm, nug, nullptr, &k->prog);
-  {
-    agp_fit *kuu = nullptr;
-    st = agp_factor_create(ctx, w.T, m, ldm, 0, AGP_DEVICE, &kuu);
-    f->kuu = std::shared_ptr<agp_fit>(kuu, [](agp_fit *p) { agp_fit_destroy(p); });
-    if (st != AGP_OK) return st;
-  }
+  if ((st = factor_kuu(ctx, k, dprog, f->u->v, inducing_nugget, &f->kuu, &w.T)) != AGP_OK) return st;
   SPX_HIP(hipMemcpy2DAsync(w.T, sizeof(double) * (size_t)ldm, f->kuu->A, sizeof(double) * (size_t)f->kuu->lda,
                            sizeof(double) * (size_t)m, (size_t)m, hipMemcpyDeviceToDevice, s));
   launch_zero_upper(s, w.T, ldm, m);  // K_uu^T/2 = L_u^T (sqrt_transpose, :349): its transpose L_u
@@ -474,6 +622,23 @@ static int sparse_fit_create_impl(agp_context *ctx, agp_comm *comm, const agp_ke
   return AGP_OK;
 }
 
+// The LL^T / CholeskyQR2 path first; where it finds K_uu or B^T B not numerically positive definite the reference's
+// pivoted algorithm takes over (one process only).  AGP_SPARSE_PIVOTED=1 forces the pivoted path.
+static int sparse_fit_create_impl(agp_context *ctx, agp_comm *comm, const agp_kernel *k, const agp_features *x, int64_t n_groups,
+                                  const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
+                                  double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
+                                  double *information, double *nll_out) {
+  const char *force = getenv("AGP_SPARSE_PIVOTED");
+  int st = AGP_ERR_NOT_POSITIVE_DEFINITE;
+  if (comm || !(force && force[0] == '1'))
+    st = sparse_fit_create_fast(ctx, comm, k, x, n_groups, offsets, y, y_var, u, measurement_nugget, inducing_nugget, out,
+                                information, nll_out);
+  if (st == AGP_ERR_NOT_POSITIVE_DEFINITE && !comm)
+    st = sparse_fit_create_pivoted(ctx, k, x, n_groups, offsets, y, y_var, u, measurement_nugget, inducing_nugget, out,
+                                   information, nll_out);
+  return st;
+}
+
 int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t n_groups,
                           const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
                           double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
@@ -489,6 +654,57 @@ int agp_sparse_fit_create_sharded(agp_context *ctx, agp_comm *comm, const agp_ke
   if (!comm) return AGP_ERR_INVALID_ARGUMENT;
   return sparse_fit_create_impl(ctx, comm, k, x, n_groups, offsets, y, y_var, u, measurement_nugget, inducing_nugget, out,
                                 information, nll_out);
+}
+
+// Pivoted form of Sigma from the rows of B: B = [T^T; W^T] ((m + n) x m; T m x m with ld ldt, W m x n with ld ldw, either
+// part may be absent) and, optionally, y_aug = [y_t; y_w] carried through the QR as one more column.  Fills f->R, f->perm,
+// f->rank, f->Lacc = P R^T and - with a right-hand side - f->v = B_qr.solve(y_aug).  inflate: the update's
+// "inflate the diagonal of R" when the QR is rank deficient (:361-365).
+static int sparse_pivoted_from_rows(agp_context *ctx, agp_sparse_fit *f, const double *T, long long ldt, const double *W,
+                                    long long ldw, long long n, const double *yt, const double *yw, bool inflate) {
+  const long long m = f->m, rows = (T ? m : 0) + n, ldb = round_up(rows, 2), ldr = round_up(m, 2), ldm = factor_ld(m);
+  const long long extra = (yt || yw) ? 1 : 0;
+  hipStream_t s = ctx->stream;
+  double *B = nullptr, *aux = nullptr;
+  SPX_HIP(hipMalloc(&B, sizeof(double) * (size_t)ldb * (size_t)(m + extra)));
+  std::unique_ptr<double, void (*)(double *)> b_guard(B, [](double *p) { (void)hipFree(p); });
+  SPX_HIP(hipMalloc(&aux, sizeof(double) * (size_t)(2 * ldr + 8)));  // tau | norms | state
+  std::unique_ptr<double, void (*)(double *)> a_guard(aux, [](double *p) { (void)hipFree(p); });
+  double *tau = aux, *norms = aux + ldr, *state = norms + ldr;
+  SPX_HIP(hipMemsetAsync(B, 0, sizeof(double) * (size_t)ldb * (size_t)(m + extra), s));
+  long long r0 = 0;
+  const dim3 tb(256);
+  if (T) {
+    hipLaunchKernelGGL(transpose_into_kernel, dim3((unsigned)((m + 31) / 32), (unsigned)((m + 31) / 32)), tb, 0, s, T, ldt, m, m, B,
+                       ldb, 0ll);
+    if (yt) SPX_HIP(hipMemcpyAsync(B + (size_t)ldb * (size_t)m, yt, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
+    r0 = m;
+  }
+  if (n > 0) {
+    hipLaunchKernelGGL(transpose_into_kernel, dim3((unsigned)((m + 31) / 32), (unsigned)((n + 31) / 32)), tb, 0, s, W, ldw, m, n, B,
+                       ldb, r0);
+    if (yw) SPX_HIP(hipMemcpyAsync(B + (size_t)ldb * (size_t)m + r0, yw, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+  }
+  if (!f->perm) SPX_HIP(hipMalloc(&f->perm, sizeof(long long) * (size_t)m));
+  colpiv_qr(s, B, ldb, rows, m, extra, tau, f->perm, norms, state);
+  double hstate[4] = {0., 0., 0., 0.};
+  SPX_HIP(hipMemcpyAsync(hstate, state, sizeof(hstate), hipMemcpyDeviceToHost, s));
+  SPX_HIP(hipStreamSynchronize(s));
+  SPX_HIP(hipGetLastError());
+  f->rank = (long long)hstate[3];
+  const long long nonzero_pivots = (long long)hstate[2];
+  if (!f->R) SPX_HIP(hipMalloc(&f->R, sizeof(double) * (size_t)ldr * (size_t)m));
+  qr_extract_r(s, B, ldb, m, f->R, ldr, 0.0);
+  if (extra) {
+    if (!f->v) SPX_HIP(hipMalloc(&f->v, sizeof(double) * (size_t)m));
+    qr_back_solve(s, f->R, ldr, f->perm, m, nonzero_pivots, B + (size_t)ldb * (size_t)m, f->v);  // the last column is Q^T y_aug
+  }
+  if (inflate && f->rank < m) qr_extract_r(s, B, ldb, m, f->R, ldr, 1e-10);
+  if (!f->Lacc) SPX_HIP(hipMalloc(&f->Lacc, sizeof(double) * (size_t)ldm * (size_t)m));
+  qr_root(s, f->R, ldr, f->perm, m, f->Lacc, ldm);
+  SPX_HIP(hipStreamSynchronize(s));
+  SPX_HIP(hipGetLastError());
+  return AGP_OK;
 }
 
 // FitModel::update for the sparse GP: _update_impl (sparse_gp.hpp:322-371).  B = [R_old P_old^T; A^-1/2 K_fu],
@@ -513,23 +729,124 @@ int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *k, const agp_spars
   f->ctx = ctx; f->m = m;
   f->u = old->u;
   f->kuu = old->kuu;
+  f->kz = old->kz;
+  f->kp = old->kp;
+  f->inducing_nugget = old->inducing_nugget;
+  if (!f->kuu && !f->kp) {  // a rebased fit's first update: K_uu + inducing nugget (:674-679), LL^T where that exists
+    st = factor_kuu(ctx, k, dprog, f->u->v, old->inducing_nugget, &f->kuu, nullptr);
+    if (st == AGP_ERR_NOT_POSITIVE_DEFINITE) {
+      f->kuu.reset();
+      st = factor_kuu_pivoted(ctx, k, dprog, f->u->v, old->inducing_nugget, &f->kp);
+    }
+    if (st != AGP_OK) return st;
+  }
   SparseScratch w;
   double *yw = nullptr, log_det_a = 0.;
   if ((st = sparse_observations(ctx, k, dprog, x, n_groups, offsets, y, y_var, measurement_nugget, f->u->v, f->kuu.get(), w,
-                                &yw, &log_det_a, stage)) != AGP_OK)
+                                &yw, &log_det_a, stage, f->kuu ? nullptr : f->kp.get())) != AGP_OK)
     return st;
   const long long ldm = factor_ld(m);
   double *yt = nullptr;
   SPX_HIP(hipMalloc(&yt, sizeof(double) * (size_t)round_up(m, 2)));
   std::unique_ptr<double, void (*)(double *)> yt_guard(yt, [](double *p) { (void)hipFree(p); });
   launch_colvec_dot(s, old->Lacc, ldm, m, m, old->v, 1.0, 0.0, nullptr, yt);  // y_t = L_acc^T v_old  (:344-347)
-  if ((st = sparse_sigma(ctx, f.get(), old->Lacc, ldm, w.Kuf, round_up(m, 2), n, yw, yt, w, nullptr, stage)) != AGP_OK) return st;
+  if (old->R) {
+    // pivoted form: the reference's own algorithm (:336-371) - column-pivoted QR of B = [R_old P_old^T; A^-1/2 K_fu]
+    // with y_aug = [R_old P_old^T v_old; A^-1/2 y] carried as one more column, v = B_qr.solve(y_aug)
+    if ((st = sparse_pivoted_from_rows(ctx, f.get(), old->Lacc, ldm, w.Kuf, round_up(m, 2), n, yt, yw, true)) != AGP_OK) return st;
+    if (information) SPX_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
+    SPX_HIP(hipStreamSynchronize(s));
+    f->nll = std::nan("");
+    *out = f.release();
+    return AGP_OK;
+  }
+  st = sparse_sigma(ctx, f.get(), old->Lacc, ldm, w.Kuf, round_up(m, 2), n, yw, yt, w, nullptr, stage);
+  if (st == AGP_ERR_NOT_POSITIVE_DEFINITE) {  // B^T B singular to working precision: the pivoted QR of B instead
+    if (f->sigma) { agp_fit_destroy(f->sigma); f->sigma = nullptr; }
+    if (f->sigma2) { agp_fit_destroy(f->sigma2); f->sigma2 = nullptr; }
+    st = sparse_pivoted_from_rows(ctx, f.get(), old->Lacc, ldm, w.Kuf, round_up(m, 2), n, yt, yw, true);
+  }
+  if (st != AGP_OK) return st;
   if (information) SPX_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
   SPX_HIP(hipStreamSynchronize(s));
   f->nll = std::nan("");  // the likelihood of an updated fit is not defined by the reference
   *out = f.release();
   return AGP_OK;
 }
+
+// SparseGaussianProcessRegression::fit_from_prediction (sparse_gp.hpp:406-461), the body of rebase_inducing_points
+// (:714-725): the fit on the inducing points z that reproduces a joint prediction (mean, covariance) made AT z.
+//   train_covariance = LDLT(K_zz), information = train_covariance.solve(mean),
+//   C = covariance + DEFAULT_NUGGET I, B_z = C^-1/2 K_zz = C_ldlt.sqrt_solve(K_zz), (R, P) = QR(B_z)
+// K_zz carries no nugget and is singular to working precision whenever z is denser than the length scale, so this path
+// keeps the reference's pivoted factorisations (ldlt.hip, qr.hip) instead of the LL^T / CholeskyQR2 of a fit.
+int agp_sparse_fit_from_prediction(agp_context *ctx, const agp_kernel *k, const agp_features *z, const double *mean,
+                                   const double *covariance, int64_t ldc, int location, double inducing_nugget,
+                                   agp_sparse_fit **out, double *information, int64_t *numerical_rank) {
+  if (!ctx || !k || !z || !mean || !covariance || !out) return AGP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(z);
+  if (st != AGP_OK) return st;
+  const long long m = z->n, ldq = round_up(m, 2);
+  if (m <= 0 || ldc < m) return AGP_ERR_INVALID_ARGUMENT;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  hipStream_t s = ctx->stream;
+  std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
+  if (!f) return AGP_ERR_INVALID_ARGUMENT;
+  f->ctx = ctx; f->m = m; f->inducing_nugget = inducing_nugget;
+  f->u = std::shared_ptr<DeviceFeatures>(new DeviceFeatures(), [](DeviceFeatures *d) { d->release(); delete d; });
+  if ((st = to_device(ctx, z, true, f->u.get())) != AGP_OK) return st;
+  // buffers: K_zz | C (later B_z) | W (m x m each, ld ldq) | mean, scratch (2 ldq)
+  double *buf = nullptr;
+  SPX_HIP(hipMalloc(&buf, sizeof(double) * ((size_t)3 * (size_t)ldq * (size_t)m + (size_t)2 * (size_t)ldq)));
+  std::unique_ptr<double, void (*)(double *)> guard(buf, [](double *p) { (void)hipFree(p); });
+  double *Kzz = buf, *C = Kzz + (size_t)ldq * (size_t)m, *Bz = C + (size_t)ldq * (size_t)m, *mv = Bz + (size_t)ldq * (size_t)m,
+         *mw = mv + ldq;
+  launch_gram(s, dprog, f->u->v, f->u->v, true, false, Kzz, ldq, nullptr, nullptr, &k->prog);  // K_zz, both triangles (:416-417)
+  {
+    agp_ldlt *kz = nullptr;
+    st = agp_ldlt_create(ctx, Kzz, m, ldq, 0, AGP_DEVICE, &kz, nullptr);                      // train_covariance (:418)
+    f->kz = std::shared_ptr<agp_ldlt>(kz, [](agp_ldlt *p) { agp_ldlt_destroy(p); });
+    if (st != AGP_OK) return st;
+  }
+  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  SPX_HIP(hipMemcpyAsync(mv, mean, sizeof(double) * (size_t)m, kind, s));
+  SPX_HIP(hipMemcpy2DAsync(C, sizeof(double) * (size_t)ldq, covariance, sizeof(double) * (size_t)ldc, sizeof(double) * (size_t)m,
+                           (size_t)m, kind, s));
+  if (location == AGP_HOST) SPX_HIP(hipStreamSynchronize(s));
+  ldlt_solve(s, f->kz->A, f->kz->lda, m, f->kz->q_dev, mw, mv, ldq, 1);                        // information (:426)
+  SPX_HIP(hipMalloc(&f->v, sizeof(double) * (size_t)m));
+  SPX_HIP(hipMemcpyAsync(f->v, mv, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
+  {
+    // DEFAULT_NUGGET on the diagonal of the predictive covariance (:20, 423-425)
+    hipLaunchKernelGGL(add_to_diagonal_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, C, ldq, m, 1e-8);
+    agp_ldlt *cl = nullptr;
+    st = agp_ldlt_create(ctx, C, m, ldq, 0, AGP_DEVICE, &cl, nullptr);                        // C_ldlt (:452)
+    std::unique_ptr<agp_ldlt, void (*)(agp_ldlt *)> cl_guard(cl, agp_ldlt_destroy);
+    if (st != AGP_OK) return st;
+    ldlt_sqrt_solve(s, cl->A, cl->lda, m, cl->q_dev, Bz, Kzz, ldq, m);                        // sigma_inv_sqrt (:453)
+    SPX_HIP(hipStreamSynchronize(s));
+  }
+  // (R, P) = QR(B_z) (:454-458): B_z is handed over as W^T, i.e. W = B_z^T ... the helper transposes, so pass B_z^T's
+  // transpose: rows of B are the rows of B_z
+  {
+    double *Wt = C;  // C is free now: W = B_z^T (m x m)
+    hipLaunchKernelGGL(transpose_into_kernel, dim3((unsigned)((m + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0, s, Bz, ldq, m,
+                       m, Wt, ldq, 0ll);
+    if ((st = sparse_pivoted_from_rows(ctx, f.get(), nullptr, 0, Wt, ldq, m, nullptr, nullptr, false)) != AGP_OK) return st;
+  }
+  if (information) SPX_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
+  SPX_HIP(hipStreamSynchronize(s));
+  SPX_HIP(hipGetLastError());
+  if (numerical_rank) *numerical_rank = f->rank;
+  f->nll = std::nan("");
+  *out = f.release();
+  return AGP_OK;
+}
+
+int64_t agp_sparse_fit_numerical_rank(const agp_sparse_fit *f) { return f ? (f->rank >= 0 ? f->rank : f->m) : 0; }
 
 int agp_sparse_nll(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t n_groups,
                    const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
@@ -563,17 +880,34 @@ static int sparse_predict_common(agp_context *ctx, const agp_kernel *k, const ag
   const long long ldq = round_up(m, 2), ldc = round_up(M, 2);
   const size_t q_elems = (size_t)ldq * (size_t)M;
   const size_t p_elems = mode == 2 ? (size_t)ldc * (size_t)M : (size_t)ldc;
-  st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (2 * q_elems + (size_t)ldc + p_elems));
+  const bool pivoted = f->kz || f->R;  // a third m x M buffer: the pivoted substitutions are out of place
+  st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes,
+                 sizeof(double) * ((pivoted ? 3 : 2) * q_elems + (size_t)ldc + p_elems));
   if (st != AGP_OK) { dxs.release(); return st; }
-  double *Q = ctx->ws_aux, *S = Q + q_elems, *mean_d = S + q_elems, *prior = mean_d + ldc;
+  double *Q = ctx->ws_aux, *S = Q + q_elems, *mean_d = S + q_elems, *prior = mean_d + ldc, *X = prior + p_elems;
   hipStream_t s = ctx->stream;
   launch_predict_mean(s, dprog, f->u->v, dxs.v, f->v, mean_d, &k->prog);
-  if (mode > 0) {
+  if (mode > 0 && !pivoted) {
     launch_gram(s, dprog, f->u->v, dxs.v, false, false, Q, ldq, nullptr, nullptr, &k->prog);
     (void)hipMemcpyAsync(S, Q, sizeof(double) * q_elems, hipMemcpyDeviceToDevice, s);
     forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, Q, M, ldq);
     forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, S, M, ldq);
     forward_solve_mat(s, f->sigma2->A, m, f->sigma2->lda, f->sigma2->invd, S, M, ldq);
+  } else if (mode > 0) {
+    launch_gram(s, dprog, f->u->v, dxs.v, false, false, X, ldq, nullptr, nullptr, &k->prog);
+    if (f->kz) {  // Q_sqrt = train_covariance.sqrt_solve(cross_cov) with the pivoted L D L^T (:497-498)
+      ldlt_sqrt_solve(s, f->kz->A, f->kz->lda, m, f->kz->q_dev, Q, X, ldq, M);
+    } else {
+      (void)hipMemcpyAsync(Q, X, sizeof(double) * q_elems, hipMemcpyDeviceToDevice, s);
+      forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, Q, M, ldq);
+    }
+    if (f->R) {   // S_sqrt = sqrt_solve(R, P, cross_cov) = R^-T P^T cross_cov (:503-504)
+      qr_sqrt_solve(s, f->R, ldq, f->perm, m, X, ldq, S, ldq, M);
+    } else {
+      (void)hipMemcpyAsync(S, X, sizeof(double) * q_elems, hipMemcpyDeviceToDevice, s);
+      forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, S, M, ldq);
+      forward_solve_mat(s, f->sigma2->A, m, f->sigma2->lda, f->sigma2->invd, S, M, ldq);
+    }
   }
   if (mode == 1) {
     launch_gram_diagonal(s, dprog, dxs.v, prior);

@@ -52,6 +52,10 @@ class SparseGPFit:
         self.m = int(ctx._lib.agp_sparse_fit_size(handle))
         self.nll = nll
 
+    @property
+    def numerical_rank(self):
+        return int(self._ctx._lib.agp_sparse_fit_numerical_rank(self._h))
+
     def __del__(self):
         if getattr(self, "_h", None) and self._ctx._h:
             self._ctx._lib.agp_sparse_fit_destroy(self._h)
@@ -253,6 +257,29 @@ class SparseGaussianProcessRegression:
     def log_likelihood(self, dataset, comm=None):
         """:524-596, without the parameter priors (out of scope)."""
         return -self._create(dataset, False, comm)[1]
+
+    def fit_from_prediction(self, new_inducing_points, prediction):
+        """fit_from_prediction (:406-461): the fit on `new_inducing_points` that reproduces `prediction`, a
+        JointDistribution made AT those points.  Like the reference, the mean is used as given (the mean function is not
+        removed from it)."""
+        ctx, cov = self._ctx(), self.covariance_function_
+        fz = cov.features(new_inducing_points)
+        sz = fz.as_struct()
+        mean = np.ascontiguousarray(prediction.mean, dtype=np.float64)
+        covariance = np.asfortranarray(prediction.covariance, dtype=np.float64)
+        if mean.shape != (fz.n,) or covariance.shape != (fz.n, fz.n):
+            raise ValueError("the prediction must be a joint distribution over the new inducing points")
+        h = C.c_void_p()
+        ctx._check(ctx._lib.agp_sparse_fit_from_prediction(ctx._h, ctx.kernel(cov), C.byref(sz), _ptr(mean), _ptr(covariance),
+                                                           fz.n, capi.HOST, self.inducing_nugget_, C.byref(h), None, None),
+                   "agp_sparse_fit_from_prediction")
+        return SparseFitModel(self, SparseGPFit(ctx, h, new_inducing_points, float("nan")))
+
+
+def rebase_inducing_points(fit_model, new_inducing_points):
+    """rebase_inducing_points (:714-725): a fit relative to new inducing points, from the old fit's joint prediction at
+    them.  NOT equivalent to fitting with the new inducing points: information may be lost."""
+    return fit_model.get_model().fit_from_prediction(new_inducing_points, fit_model.predict(new_inducing_points).joint())
 
 
 def sparse_gp_from_covariance_and_mean(covariance_function, mean_function, grouper_function, strategy,

@@ -222,6 +222,22 @@ int main() {
       std::printf("sparse_update_mean_diff,%.17g\n", um);
       std::printf("sparse_update_cov_diff,%.17g\n", uc);
     }
+    // rebase_inducing_points (tests/test_sparse_gp.cc:374-416): one point loses information, 51 points change nothing
+    {
+      double low = 0., high = 0.;
+      const auto lp = rebase_inducing_points(sfit, std::vector<double>{5.}).predict_with_measurement_noise(txs).joint();
+      std::vector<double> z(51);
+      for (int i = 0; i < 51; ++i) z[i] = 0.01 + (9.9 - 0.01) * i / 50.;
+      const auto hfit = rebase_inducing_points(sfit, z);
+      const auto hp = hfit.predict_with_measurement_noise(txs).joint();
+      for (int i = 0; i < 11; ++i) {
+        low += (lp.mean[i] - sp.mean[i]) * (lp.mean[i] - sp.mean[i]);
+        high += (hp.mean[i] - sp.mean[i]) * (hp.mean[i] - sp.mean[i]);
+      }
+      std::printf("sparse_rebase_low_diff,%.17g\n", std::sqrt(low));
+      std::printf("sparse_rebase_high_diff,%.17g\n", std::sqrt(high));
+      std::printf("sparse_rebase_high_rank,%lld\n", static_cast<long long>(hfit.numerical_rank()));
+    }
     const auto sm = sfit.predict(txs).marginal();
     for (int i = 0; i < 11; ++i) std::printf("sparse_pred,%d,%.17g,%.17g,%.17g\n", i, sfit.predict(txs).mean()[i], sm.mean[i], sm.covariance[i]);
   }

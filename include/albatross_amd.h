@@ -341,8 +341,14 @@ int agp_ldlt_download(agp_context *ctx, const agp_ldlt *ldlt, double *packed, in
  * the factor of Sigma^-1 = K_uu + K_uf A^-1 K_fu, the information vector).  information (m doubles,
  * host) and nll (= -log_likelihood, :524-596, without parameter priors) are optional outputs.
  * out may be NULL (only nll / information wanted); agp_sparse_nll is that call.
- * Errors: AGP_ERR_NOT_POSITIVE_DEFINITE if K_uu, a block of A or Sigma^-1 is not numerically
- * positive definite (the reference's pivoted LDLT / QR would continue), AGP_ERR_NAN_INPUT. */
+ * Two algorithms: LL^T of K_uu and CholeskyQR2 of B (MFMA-bound, the fast path) first; where that finds K_uu or
+ * B^T B not numerically positive definite - inducing points denser than the length scale, as in the reference's own
+ * tests - the reference's algorithm itself runs on the device: pivoted L D L^T of K_uu (agp_ldlt_*) and the
+ * column-pivoted Householder QR of B (level-2 bound, moderate m; AGP_SPARSE_PIVOTED=1 forces it; not with a
+ * communicator).  Fits of the second kind are in "pivoted form" (R, P as the reference stores them) and stay so
+ * under agp_sparse_fit_update.
+ * Errors: AGP_ERR_NOT_POSITIVE_DEFINITE if a block of A is not numerically positive definite (the reference's
+ * block LDLT would continue), AGP_ERR_NAN_INPUT. */
 typedef struct agp_sparse_fit agp_sparse_fit;
 int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *kernel, const agp_features *x, int64_t n_groups,
                           const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
@@ -366,12 +372,29 @@ int agp_sparse_fit_information(agp_context *ctx, const agp_sparse_fit *fit, doub
  * like those of agp_sparse_fit_create; wrapped as measurements inside) are folded into `old` through
  * B = [R_old P_old^T; A^-1/2 K_fu],  y_aug = [R_old P_old^T v_old; A^-1/2 y]; the inducing points and their
  * K_uu factor are shared with `old`, which stays valid.  Returns a NEW handle in *out; information
- * (m doubles, host) is optional.  (fit_from_prediction / rebase_inducing_points, :383-445, need the
- * rank-revealing factorisations of a singular K_zz and stay on the caller's side.) */
+ * (m doubles, host) is optional.  An `old` made by agp_sparse_fit_from_prediction (or by an update of one) is
+ * updated with the reference's own algorithm - the column-pivoted QR of B, v = B_qr.solve(y_aug), R's diagonal
+ * inflated by 1e-10 when B is rank deficient (:353-365) - and the result stays in that pivoted form. */
 int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *old,
                           const agp_features *x, int64_t n_groups, const int64_t *offsets, const double *y,
                           const double *y_var, double measurement_nugget, agp_sparse_fit **out,
                           double *information);
+/* SparseGaussianProcessRegression::fit_from_prediction (sparse_gp.hpp:406-461), the body of
+ * rebase_inducing_points (:714-725): the fit on the m inducing features z that reproduces a joint prediction made
+ * AT z - mean (m) and covariance (m x m column-major, leading dimension ldc, both triangles), at `location`.
+ *   train_covariance = LDLT(K_zz) (no nugget), information = train_covariance.solve(mean),
+ *   C = covariance + 1e-8 I (DEFAULT_NUGGET, :20), B_z = C_ldlt.sqrt_solve(K_zz), (R, P) = QR(B_z).
+ * K_zz is singular to working precision whenever z is denser than the length scale, so this path runs the
+ * reference's pivoted factorisations on the device (the pivoted L D L^T of agp_ldlt_*, a column-pivoted Householder
+ * QR) instead of the LL^T / CholeskyQR2 of agp_sparse_fit_create; they are level-2 bound, meant for moderate m.
+ * inducing_nugget is what a later agp_sparse_fit_update adds to K_zz for P = K_zz^-1/2 K_zf (:674-685).
+ * Optional outputs: information (m doubles, host), numerical_rank (B_qr->rank(), :458). */
+int agp_sparse_fit_from_prediction(agp_context *ctx, const agp_kernel *kernel, const agp_features *z,
+                                   const double *mean, const double *covariance, int64_t ldc, int location,
+                                   double inducing_nugget, agp_sparse_fit **out, double *information,
+                                   int64_t *numerical_rank);
+/* Fit<SparseGPFit>::numerical_rank: the rank of the pivoted QR for fits in pivoted form, m otherwise. */
+int64_t agp_sparse_fit_numerical_rank(const agp_sparse_fit *fit);
 int agp_sparse_nll(agp_context *ctx, const agp_kernel *kernel, const agp_features *x, int64_t n_groups,
                    const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
                    double measurement_nugget, double inducing_nugget, double *out);

@@ -1695,6 +1695,9 @@ class SparseFitModel {
   SparseFitModel(const ModelType &model, SparseGPFit<InducingFeature> fit) : model_(model), fit_(std::move(fit)) {}
   const SparseGPFit<InducingFeature> &get_fit() const { return fit_; }
   const ModelType &get_model() const { return model_; }
+  // Fit<SparseGPFit>::numerical_rank (:98): the rank of the pivoted QR where the fit is in that form, else the number of
+  // inducing points
+  std::int64_t numerical_rank() const { return agp_sparse_fit_numerical_rank(fit_.handle.get()); }
 
   template <typename P>
   SparsePrediction<ModelType, InducingFeature, P> predict(const std::vector<P> &features) const {
@@ -1815,6 +1818,32 @@ class SparseGaussianProcessRegression {
     return -fit.negative_log_likelihood;
   }
 
+  // fit_from_prediction (:406-461): the fit on `new_inducing_points` that reproduces `prediction`, a joint distribution
+  // made AT those points.  Like the reference, the mean is used as given (the mean function is not removed from it).
+  template <typename FeatureType>
+  auto fit_from_prediction(const std::vector<FeatureType> &new_inducing_points, const JointDistribution &prediction) const {
+    const std::size_t m = new_inducing_points.size();
+    if (m == 0 || prediction.mean.size() != m || prediction.covariance.rows() != static_cast<std::int64_t>(m) ||
+        prediction.covariance.cols() != static_cast<std::int64_t>(m))
+      throw std::invalid_argument("the prediction must be a joint distribution over the new inducing points");
+    SparseGPFit<FeatureType> fit;
+    fit.train_features = new_inducing_points;
+    fit.context = detail::default_context();
+    fit.information.resize(m);
+    fit.negative_log_likelihood = std::nan("");
+    agp_context *c = fit.context->ctx;
+    detail::KernelHolder k(covariance_function_.program());
+    detail::Flat fz = detail::flatten(covariance_function_, new_inducing_points);
+    agp_sparse_fit *h = nullptr;
+    detail::check(agp_sparse_fit_from_prediction(c, k.k, &fz.view, prediction.mean.data(), prediction.covariance.data.data(),
+                                                 static_cast<std::int64_t>(m), AGP_HOST, inducing_nugget_, &h,
+                                                 fit.information.data(), nullptr),
+                  c, "agp_sparse_fit_from_prediction");
+    auto ctx = fit.context;
+    fit.handle = std::shared_ptr<agp_sparse_fit>(h, [ctx](agp_sparse_fit *p) { agp_sparse_fit_destroy(p); });
+    return SparseFitModel<SparseGaussianProcessRegression, FeatureType>(*this, std::move(fit));
+  }
+
   double measurement_nugget() const { return measurement_nugget_; }
 
   // the host half of compute_internal_components (:642-668): group_by(features, grouper).indexers() in key
@@ -1897,6 +1926,14 @@ template <typename CovFunc, typename GrouperFunction, typename InducingPointStra
 auto sparse_gp_from_covariance(const CovFunc &cov, const GrouperFunction &grouper, const InducingPointStrategy &strategy,
                                const std::string &model_name) {
   return sparse_gp_from_covariance_and_mean(cov, ZeroMean(), grouper, strategy, model_name);
+}
+
+// rebase_inducing_points (:714-725): a fit relative to new inducing points, from the old fit's joint prediction at them.
+// NOT equivalent to fitting with the new inducing points: information may be lost.
+template <typename ModelType, typename InducingFeature, typename NewFeatureType>
+auto rebase_inducing_points(const SparseFitModel<ModelType, InducingFeature> &fit_model,
+                            const std::vector<NewFeatureType> &new_inducing_points) {
+  return fit_model.get_model().fit_from_prediction(new_inducing_points, fit_model.predict(new_inducing_points).joint());
 }
 
 // GaussianProcessNegativeLogLikelihood, gp.hpp:542-550: the tuner's objective

@@ -1056,7 +1056,10 @@ static void ldlt_sqrt_solve(const double *A, int64_t n, int64_t ld, const int64_
       const double *col = A + j * ld;
       for (int64_t i = j + 1; i < n; ++i) b[i] -= col[i] * bj;
     }
-    for (int64_t i = 0; i < n; ++i) b[i] /= sqrt(A[i + i * ld]); /* diagonal_sqrt_inverse */
+    for (int64_t i = 0; i < n; ++i) { /* diagonal_sqrt_inverse (:58-69): 1 / sqrt(D_i) where D_i > 0, else 0 */
+      const double d = A[i + i * ld];
+      b[i] = d > 0. ? b[i] * (1. / sqrt(d)) : 0.;
+    }
   }
 }
 
@@ -1413,6 +1416,47 @@ ORC_API orc_sparse_fit *orc_sparse_fit_create(const agp_kernel_node *prog, int n
   free(all); free(y_aug);
   qr_free(q);
   sparse_parts_free(p);
+  return f;
+}
+
+/* SparseGaussianProcessRegression::fit_from_prediction (sparse_gp.hpp:406-461), which rebase_inducing_points
+ * (:714-725) calls with the old fit's joint prediction at the new inducing points z:
+ *   train_covariance = LDLT(K_zz)  (no nugget),  information = train_covariance.solve(mean),
+ *   C = covariance + DEFAULT_NUGGET I,  B_z = C^-1/2 K_zz = C_ldlt.sqrt_solve(K_zz),  (R, P) = QR(B_z).
+ * cov is m x m column-major (both triangles). */
+ORC_API orc_sparse_fit *orc_sparse_fit_from_prediction(const agp_kernel_node *prog, int n_nodes, const agp_features *z,
+                                                       const double *mean, const double *cov) {
+  const int64_t m = z->n;
+  orc_sparse_fit *f = calloc(1, sizeof(orc_sparse_fit));
+  f->m = m;
+  double *K = malloc(sizeof(double) * (size_t)(m * m + 1));
+  orc_gram_sym(prog, n_nodes, z, K, m);                                 /* K_zz                  :416-417 */
+  f->kuu_ldlt = malloc(sizeof(double) * (size_t)(m * m + 1));
+  memcpy(f->kuu_ldlt, K, sizeof(double) * (size_t)(m * m));
+  f->kuu_tr = malloc(sizeof(int64_t) * (size_t)(m + 1));
+  orc_ldlt(f->kuu_ldlt, m, m, f->kuu_tr);                               /* train_covariance      :418 */
+  f->information = malloc(sizeof(double) * (size_t)(m + 1));
+  memcpy(f->information, mean, sizeof(double) * (size_t)m);
+  orc_ldlt_solve(f->kuu_ldlt, m, m, f->kuu_tr, f->information, 1, m);   /* information           :426 */
+  double *C = malloc(sizeof(double) * (size_t)(m * m + 1));
+  memcpy(C, cov, sizeof(double) * (size_t)(m * m));
+  for (int64_t i = 0; i < m; ++i) C[i + i * m] += 1e-8;                 /* DEFAULT_NUGGET        :20, 423-425 */
+  int64_t *c_tr = malloc(sizeof(int64_t) * (size_t)(m + 1));
+  orc_ldlt(C, m, m, c_tr);                                              /* C_ldlt                :452 */
+  ldlt_sqrt_solve(C, m, m, c_tr, K, m, m);                              /* sigma_inv_sqrt        :453 */
+  orc_qr *q = colpiv_qr(K, m, m);                                       /* B_qr                  :454 */
+  f->R = malloc(sizeof(double) * (size_t)(m * m + 1));
+  for (int64_t j = 0; j < m; ++j)
+    for (int64_t i = 0; i < m; ++i) f->R[i + j * m] = (i <= j) ? q->qr[i + j * m] : 0.;
+  f->perm = malloc(sizeof(int64_t) * (size_t)(m + 1));
+  memcpy(f->perm, q->perm, sizeof(int64_t) * (size_t)m);
+  f->numerical_rank = q->rank;
+  f->nll = NAN;
+  int64_t *all = malloc(sizeof(int64_t) * (size_t)(m + 1));
+  for (int64_t i = 0; i < m; ++i) all[i] = i;
+  f->u = subset_features(z, all, m, z->is_measurement, &f->coords_copy, &f->eq_copy, &f->scales_copy);
+  free(all); free(c_tr); free(C); free(K);
+  qr_free(q);
   return f;
 }
 

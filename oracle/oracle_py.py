@@ -62,6 +62,8 @@ def lib():
         L.orc_fit_held_out.argtypes = [V, V, I64, V, V, V, V, V]
         L.orc_sparse_fit_create.restype = V
         L.orc_sparse_fit_create.argtypes = [PN, C.c_int, PF, V, V, V, PF, C.c_double, C.c_double]
+        L.orc_sparse_fit_from_prediction.restype = V
+        L.orc_sparse_fit_from_prediction.argtypes = [PN, C.c_int, PF, V, V]
         L.orc_sparse_fit_update.restype = V
         L.orc_sparse_fit_update.argtypes = [V, PN, C.c_int, PF, V, V, V, C.c_double, C.c_double]
         L.orc_sparse_fit_destroy.argtypes = [V]
@@ -404,6 +406,26 @@ class OracleSparseFit:
         new.h = lib().orc_sparse_fit_update(self.h, self._p, self._n, C.byref(fx), _ptr(keys), _ptr(y), _ptr(yv),
                                             measurement_nugget, inducing_nugget)
         return new
+
+    @classmethod
+    def from_prediction(cls, cov, z, mean, covariance):
+        """fit_from_prediction (sparse_gp.hpp:406-461): the fit on the inducing points z that reproduces a joint
+        prediction (mean, covariance) made AT z."""
+        new = cls.__new__(cls)
+        new.cov = cov
+        new._p, new._n = _prog(cov)
+        fz, new._ku = _feat(cov, z, False)
+        new.m = int(fz.n)
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        covariance = np.asfortranarray(covariance, dtype=np.float64)
+        assert mean.shape == (new.m,) and covariance.shape == (new.m, new.m)
+        new.h = lib().orc_sparse_fit_from_prediction(new._p, new._n, C.byref(fz), _ptr(mean), _ptr(covariance))
+        return new
+
+    def rebase(self, z):
+        """rebase_inducing_points (sparse_gp.hpp:714-725): fit_from_prediction(z, predict(z).joint())."""
+        mean, _, covariance = self.predict(z, joint=True)
+        return OracleSparseFit.from_prediction(self.cov, z, mean, covariance)
 
     def __del__(self):
         if getattr(self, "h", None):

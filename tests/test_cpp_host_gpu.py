@@ -160,6 +160,9 @@ def test_cpp_api_matches_oracle():
     # equal to the oracle's QR-based restatement
     assert float(one["sparse_mean_err"]) < 1e-2 and float(one["sparse_cov_err"]) < 1e-2
     assert float(one["sparse_update_mean_diff"]) < 1e-6 and float(one["sparse_update_cov_diff"]) < 1e-6
+    # rebase_inducing_points through the C++ surface, thresholds of tests/test_sparse_gp.cc:374-416
+    assert float(one["sparse_rebase_low_diff"]) > 10. and float(one["sparse_rebase_high_diff"]) < 1e-6
+    assert int(one["sparse_rebase_high_rank"]) < 51
     tx = np.arange(10.)
     ty = np.array(golden_toy_y())
     scov = ab.SquaredExponential(100., 100.) + ab.measurement_only(ab.IndependentNoise(0.1))

@@ -279,6 +279,51 @@ def test_sparse_gp_oracle_update_equals_full_fit():
     assert np.linalg.norm(um - fm) < 1e-9 and np.linalg.norm(uj - fj) < 1e-9
 
 
+def _toy_sparse_problem():
+    """make_toy_linear_data + make_simple_covariance_function + LeaveOneIntervalOut (tests/test_sparse_gp.cc:22-29,
+    tests/lib/albatross/test/test_models.h:26-30)."""
+    g = golden("toy_linear.json")
+    x, y = np.array(g["x"]), np.array(g["y"])
+    cov = ab.SquaredExponential(100., 100.) + ab.measurement_only(ab.IndependentNoise(0.1))
+    keys = np.floor(x / 5.).astype(np.int64)
+    return cov, x, y, keys
+
+
+def test_sparse_gp_oracle_rebase_inducing_points():
+    # tests/test_sparse_gp.cc:374-416 (test_rebase_inducing_points), same thresholds
+    cov, x, y, keys = _toy_sparse_problem()
+    u = np.linspace(x.min(), x.max(), 8)
+    full = orc.OracleSparseFit(cov, x, keys, y, None, u, 1e-12, 1e-3)
+    xs = np.linspace(0.01, 9.9, 11)
+    full_mean = full.predict(xs, xs_meas=True)[0]
+    low = full.rebase(np.array([5.]))
+    assert np.linalg.norm(low.predict(xs, xs_meas=True)[0] - full_mean) > 10.  # a single point loses information
+    high = full.rebase(np.linspace(0.01, 9.9, 51))
+    assert np.linalg.norm(high.predict(xs, xs_meas=True)[0] - full_mean) < 1e-6  # more points: nothing changes
+    low_high = low.rebase(np.linspace(0.01, 9.9, 51))
+    assert np.linalg.norm(low_high.predict(xs, xs_meas=True)[0] - full_mean) > 10.  # what was lost stays lost
+
+
+def test_sparse_gp_oracle_rebase_and_update():
+    # tests/test_sparse_gp.cc:418-456 (test_rebase_and_update): fit the first group, rebase to the inducing points of
+    # the whole data set, update with the other groups == direct fit (4e-3 on the mean, 8e-3 on the covariance)
+    cov, x, y, keys = _toy_sparse_problem()
+    u_all = np.linspace(x.min(), x.max(), 10)
+    first = keys == keys.min()
+    u_first = np.linspace(x[first].min(), x[first].max(), 10)
+    fit = orc.OracleSparseFit(cov, x[first], keys[first], y[first], None, u_first)
+    fit = fit.rebase(u_all)
+    for k in np.unique(keys[~first]):
+        sel = keys == k
+        fit = fit.update(x[sel], keys[sel], y[sel], None)
+    direct = orc.OracleSparseFit(cov, x, keys, y, None, u_all)
+    xs = np.linspace(0.1, 9.9, 5)
+    im, _, ic = fit.predict(xs, joint=True)
+    dm, _, dc = direct.predict(xs, joint=True)
+    assert np.linalg.norm(im - dm) < 4e-3
+    assert np.linalg.norm(ic - dc) < 8e-3
+
+
 def _has_multiple():
     """tests/lib/albatross/test/test_covariance_utils.h:42-62 (HasMultiple): one _call_impl overload per pair of
     alternatives X=0, Y=1, W=2, V=3: (X,X)=1, (X,Y)=3, (Y,Y)=5, (W,W)=7, (V,V)=11."""

@@ -167,8 +167,20 @@ def test_sparse_error_paths(ctx):
     dup = ab.sparse_gp_from_covariance(cov, interval_grouper(5.0), ab.FixedInducingPoints(np.array([1.0, 1.0, 2.0])),
                                        "dup", context=ctx)
     dup.set_param("inducing_nugget", 0.0)
-    with pytest.raises(ab.NotPositiveDefiniteError):  # singular K_uu: reported, not silently factored
-        dup.fit(ab.RegressionDataset(x, y))
+    # an exactly singular K_uu (a repeated inducing point, no nugget): LL^T rejects it and the reference's pivoted
+    # L D L^T / QR take over - the fit the reference itself would produce, rank deficient, with finite predictions
+    fm = dup.fit(ab.RegressionDataset(x, y))
+    keys = np.floor(x / 5.).astype(np.int64)
+    ofit = orc.OracleSparseFit(cov, x, keys, y, None, np.array([1.0, 1.0, 2.0]), 1e-8, 0.0)
+    assert fm.get_fit().numerical_rank == ofit.numerical_rank == 2
+    xs = np.linspace(0.1, 9.9, 5)
+    om, ov = ofit.predict(xs)
+    p = fm.predict(xs).marginal()
+    assert np.all(np.isfinite(p.mean)) and np.abs(p.mean - om).max() <= 1e-6 * np.abs(om).max()
+    # the pivot that is zero in exact arithmetic comes out as +-1e-12 from the last bits of K_uu (the device's exp differs
+    # from libm's by an ulp), and D^-1/2 either zeroes or amplifies that direction: the variance is only defined to the
+    # size of the term that direction carries
+    assert np.all(np.isfinite(p.covariance)) and np.abs(p.covariance - ov).max() <= 0.05 * ov.max()
     bad = ab.sparse_gp_from_covariance(cov, interval_grouper(5.0), ab.UniformlySpacedInducingPoints(4), context=ctx)
     yn = y.copy()
     with pytest.raises(KeyError):
@@ -246,3 +258,171 @@ def test_vectorized_grouper_gives_the_same_fit(ctx):
         m = ab.sparse_gp_from_covariance(cov, g, ab.FixedInducingPoints(u), "pitc", context=ctx)
         fits.append(m.fit(ab.RegressionDataset(x, y)).get_fit())
     assert np.array_equal(fits[0].information, fits[1].information) and fits[0].nll == fits[1].nll
+
+
+def _toy_model(ctx, strategy, inducing_nugget=None, measurement_nugget=None):
+    model = ab.sparse_gp_from_covariance(simple_cov(100.0), interval_grouper(5.0), strategy, "sparse", context=ctx)
+    if inducing_nugget is not None:
+        model.set_param("inducing_nugget", inducing_nugget)
+    if measurement_nugget is not None:
+        model.set_param("measurement_nugget", measurement_nugget)
+    return model
+
+
+def test_rebase_inducing_points(ctx):
+    """tests/test_sparse_gp.cc:374-416 (test_rebase_inducing_points) on the device, with the reference's thresholds, and
+    every rebased fit against the oracle's restatement of fit_from_prediction (sparse_gp.hpp:406-461).  K_zz of 51
+    points under a length scale of 100 has numerical rank 5: the path runs the pivoted L D L^T and the pivoted QR."""
+    x, y = toy_linear()
+    u = np.linspace(x.min(), x.max(), 8)
+    model = _toy_model(ctx, ab.FixedInducingPoints(u), 1e-3, 1e-12)
+    full = model.fit(ab.RegressionDataset(x, ab.MarginalDistribution(y)))
+    xs = np.linspace(0.01, 9.9, 11)
+    full_mean = full.predict_with_measurement_noise(xs).joint().mean
+    keys = np.floor(x / 5.).astype(np.int64)
+    ofull = orc.OracleSparseFit(simple_cov(100.0), x, keys, y, None, u, 1e-12, 1e-3)
+
+    low = ab.rebase_inducing_points(full, np.array([5.]))
+    low_mean = low.predict_with_measurement_noise(xs).joint().mean
+    assert np.linalg.norm(low_mean - full_mean) > 10.
+    olow = ofull.rebase(np.array([5.]))
+    assert np.abs(low.get_fit().information - olow.information).max() <= 1e-9 * np.abs(olow.information).max()
+    om, ov = olow.predict(xs, xs_meas=True)
+    lp = low.predict_with_measurement_noise(xs).marginal()
+    assert np.abs(lp.mean - om).max() <= 1e-8 * np.abs(om).max() and np.abs(lp.covariance - ov).max() <= 1e-8 * ov.max()
+
+    z = np.linspace(0.01, 9.9, 51)
+    high = ab.rebase_inducing_points(full, z)
+    hp = high.predict_with_measurement_noise(xs).joint()
+    assert np.linalg.norm(hp.mean - full_mean) < 1e-6
+    ohigh = ofull.rebase(z)
+    om, ov, oj = ohigh.predict(xs, xs_meas=True, joint=True)
+    # the rebased fit is defined through a numerically singular K_zz: parity is on what it predicts.  The predictive
+    # covariance K_** - Q_** + S_** cancels terms of the size of the prior variance (1e4) down to 1e-2: its bar is
+    # relative to the prior (a different pivot at a rounding-level tie changes it by ~1e-7 of that).
+    prior = 100.0 ** 2
+    assert np.abs(hp.mean - om).max() <= 1e-6 and np.abs(hp.covariance - oj).max() <= 5e-7 * prior
+    assert high.get_fit().numerical_rank < 51 and ohigh.numerical_rank < 51
+
+    low_high = ab.rebase_inducing_points(low, z)
+    assert np.linalg.norm(low_high.predict_with_measurement_noise(xs).joint().mean - full_mean) > 10.
+
+
+def test_rebase_and_update(ctx):
+    """tests/test_sparse_gp.cc:418-456 (test_rebase_and_update): fit the first group, rebase to the inducing points of
+    the whole data set, update with the remaining groups == direct fit (4e-3 on the mean, 8e-3 on the covariance), and
+    the device chain against the oracle's."""
+    x, y = toy_linear()
+    keys = np.floor(x / 5.).astype(np.int64)
+    model = _toy_model(ctx, ab.UniformlySpacedInducingPoints(10))
+    u_all = np.linspace(x.min(), x.max(), 10)
+    first = keys == keys.min()
+    fit = model.fit(ab.RegressionDataset(x[first], ab.MarginalDistribution(y[first])))
+    fit = ab.rebase_inducing_points(fit, u_all)
+    ofit = orc.OracleSparseFit(simple_cov(100.0), x[first], keys[first], y[first], None,
+                               np.linspace(x[first].min(), x[first].max(), 10)).rebase(u_all)
+    for k in np.unique(keys[~first]):
+        sel = keys == k
+        fit = fit.update(ab.RegressionDataset(x[sel], ab.MarginalDistribution(y[sel])))
+        ofit = ofit.update(x[sel], keys[sel], y[sel], None)
+    direct = model.fit(ab.RegressionDataset(x, ab.MarginalDistribution(y)))
+    xs = np.linspace(0.1, 9.9, 5)
+    ip, dp = fit.predict(xs).joint(), direct.predict(xs).joint()
+    assert np.linalg.norm(ip.mean - dp.mean) < 4e-3
+    assert np.linalg.norm(ip.covariance - dp.covariance) < 8e-3
+    om, _, oc = ofit.predict(xs, joint=True)
+    assert np.linalg.norm(ip.mean - om) < 4e-3 and np.linalg.norm(ip.covariance - oc) < 8e-3
+
+
+def test_rebase_well_conditioned_matches_oracle(ctx):
+    """fit_from_prediction where nothing is singular (short length scale, few inducing points): information, rank and
+    predictions agree with the oracle to rounding; then an update of the rebased fit (the pivoted-QR update)."""
+    rng = np.random.default_rng(5)
+    n = 300
+    x = np.sort(rng.uniform(0., 30., n))
+    y = np.sin(x) + 0.2 * x + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.04, n)
+    cov = ab.Matern52(3.0, 1.5) + ab.measurement_only(ab.IndependentNoise(0.2))
+    grouper = interval_grouper(3.0)
+    keys = np.array([grouper(f) for f in x])
+    u = np.linspace(0., 30., 12)
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "sparse", context=ctx)
+    model.set_param("inducing_nugget", 1e-6)
+    old = x < 20.
+    fm = model.fit(ab.RegressionDataset(x[old], ab.MarginalDistribution(y[old], yvar[old])))
+    ofit = orc.OracleSparseFit(cov, x[old], keys[old], y[old], yvar[old], u, 1e-8, 1e-6)
+    z = np.linspace(0.5, 29.5, 16)
+    rb, orb = ab.rebase_inducing_points(fm, z), ofit.rebase(z)
+    assert rb.get_fit().numerical_rank == orb.numerical_rank == 16
+    assert np.abs(rb.get_fit().information - orb.information).max() <= 1e-7 * np.abs(orb.information).max()
+    xs = np.linspace(0.2, 29.8, 41)
+    om, ov, oj = orb.predict(xs, xs_meas=True, joint=True)
+    p = rb.predict_with_measurement_noise(xs).joint()
+    assert np.abs(p.mean - om).max() <= 1e-7 * np.abs(om).max()
+    assert np.abs(p.covariance - oj).max() <= 1e-7 * np.abs(oj).max()
+    new = ~old
+    up = rb.update(ab.RegressionDataset(x[new], ab.MarginalDistribution(y[new], yvar[new])))
+    oup = orb.update(x[new], keys[new], y[new], yvar[new], 1e-8, 1e-6)
+    assert np.abs(up.get_fit().information - oup.information).max() <= 1e-7 * np.abs(oup.information).max()
+    om, ov, oj = oup.predict(xs, xs_meas=True, joint=True)
+    p = up.predict_with_measurement_noise(xs).joint()
+    assert np.abs(p.mean - om).max() <= 1e-7 * np.abs(om).max()
+    assert np.abs(p.covariance - oj).max() <= 1e-7 * np.abs(oj).max()
+
+
+@pytest.mark.parametrize("n,m,width", [(60, 7, 5.0), (400, 40, 2.5)])
+def test_pivoted_fit_matches_oracle(ctx, monkeypatch, n, m, width):
+    """The reference's own algorithm on the device (pivoted L D L^T of K_uu, column-pivoted QR of B: the path that takes
+    over where LL^T / CholeskyQR2 reject the matrices), forced on a well-conditioned problem: fit, likelihood, rank,
+    predictions and an update against the oracle."""
+    monkeypatch.setenv("AGP_SPARSE_PIVOTED", "1")
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0., 20., n)
+    y = np.sin(x) + 0.3 * x + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.04, n)
+    cov = ab.Matern52(4.0, 2.0) + ab.measurement_only(ab.IndependentNoise(0.2))
+    u = np.linspace(0., 20., m)
+    grouper = interval_grouper(width)
+    keys = np.array([grouper(f) for f in x])
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "sparse", context=ctx)
+    model.set_param("inducing_nugget", 1e-6)
+    model.set_param("measurement_nugget", 1e-10)
+    old = keys != keys.max()
+    fm = model.fit(ab.RegressionDataset(x[old], ab.MarginalDistribution(y[old], yvar[old])))
+    ofit = orc.OracleSparseFit(cov, x[old], keys[old], y[old], yvar[old], u, 1e-10, 1e-6)
+    v = ofit.information
+    assert fm.get_fit().numerical_rank == ofit.numerical_rank == m
+    assert np.abs(fm.get_fit().information - v).max() <= 1e-8 * np.abs(v).max()
+    assert abs(fm.get_fit().nll - ofit.nll) <= 1e-9 * n
+    xs = np.linspace(0.01, 19.9, 37)
+    om, ov, oj = ofit.predict(xs, xs_meas=True, joint=True)
+    p = fm.predict_with_measurement_noise(xs).joint()
+    assert np.abs(p.mean - om).max() <= 1e-9 * np.abs(om).max()
+    assert np.abs(p.covariance - oj).max() <= 1e-9 * np.abs(oj).max()
+    new = ~old
+    up = fm.update(ab.RegressionDataset(x[new], ab.MarginalDistribution(y[new], yvar[new])))
+    oup = ofit.update(x[new], keys[new], y[new], yvar[new], 1e-10, 1e-6)
+    assert np.abs(up.get_fit().information - oup.information).max() <= 1e-8 * np.abs(oup.information).max()
+    om, ov, oj = oup.predict(xs, xs_meas=True, joint=True)
+    p = up.predict_with_measurement_noise(xs).joint()
+    assert np.abs(p.mean - om).max() <= 1e-9 * np.abs(om).max()
+    assert np.abs(p.covariance - oj).max() <= 1e-9 * np.abs(oj).max()
+
+
+def test_singular_inducing_covariance_falls_back_to_the_pivoted_path(ctx):
+    """make_simple_covariance_function() with the DEFAULT nuggets (1e-8) on 10 inducing points under a length scale of
+    100 (the model of tests/test_sparse_gp.cc:418-456): B^T B is singular to working precision, LL^T rejects it, the
+    pivoted path produces the reference's fit - against the oracle, which runs the same algorithm on the CPU."""
+    x, y = toy_linear()
+    keys = np.floor(x / 5.).astype(np.int64)
+    model = _toy_model(ctx, ab.UniformlySpacedInducingPoints(10))
+    fm = model.fit(ab.RegressionDataset(x, ab.MarginalDistribution(y)))
+    u = np.linspace(x.min(), x.max(), 10)
+    ofit = orc.OracleSparseFit(simple_cov(100.0), x, keys, y, None, u)
+    assert fm.get_fit().numerical_rank <= 10
+    xs = np.linspace(0.1, 9.9, 5)
+    om, _, oc = ofit.predict(xs, joint=True)
+    p = fm.predict(xs).joint()
+    assert np.linalg.norm(p.mean - om) < 1e-6 * np.linalg.norm(om)
+    assert np.abs(p.covariance - oc).max() <= 5e-7 * 100.0 ** 2
+    assert abs(fm.get_fit().nll - ofit.nll) <= 1e-6 * max(1., abs(ofit.nll))
