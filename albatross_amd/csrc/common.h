@@ -84,6 +84,10 @@ struct agp_context {
   // scratch of the sharded fit (agp_sharded_fit_destroy parks it here, like pool_A)
   double *pool_shard = nullptr;
   size_t pool_shard_bytes = 0;
+  // the n-sized buffers of a sparse GP fit (K_uf / W, P / Q1^T, split-K slabs): grow-only, kept between fits - a tuner
+  // re-fits the same shapes, and hipMalloc / hipFree of several GB per call costs more than some of the stages
+  double *pool_sparse = nullptr;
+  size_t pool_sparse_bytes = 0;
 };
 
 struct agp_fit {

@@ -59,9 +59,12 @@ struct SparseScratch {
          *Ag = nullptr, *Pimg = nullptr, *Q1T = nullptr;
   std::vector<agp_fit *> blocks;
   DeviceFeatures dx;
+  // Kuf, Pbuf / Q1T (one region: P is dead before Q1^T is formed) and the split-K slabs live in ctx->pool_sparse
+  double *slabs = nullptr, *pads = nullptr;
+  long long slab_count = 0;
   ~SparseScratch() {
-    (void)hipFree(Kuf); (void)hipFree(Pbuf); (void)hipFree(M0); (void)hipFree(T); (void)hipFree(vecs);
-    (void)hipFree(partial); (void)hipFree(Ag); (void)hipFree(Pimg); (void)hipFree(Q1T);
+    (void)hipFree(M0); (void)hipFree(T); (void)hipFree(vecs);
+    (void)hipFree(partial); (void)hipFree(Ag); (void)hipFree(Pimg);
     for (agp_fit *b : blocks) agp_fit_destroy(b);
     dx.release();
   }
@@ -100,6 +103,40 @@ struct StageTimer {
     }                                                                                    \
   } while (0)
 
+// C (m x m, lower tiles) -= W W^T for W m x n with n >> m: 136 tiles of 128 x 128 at m = 2048 would leave most of the
+// chip idle behind one very long K loop, so the columns are cut into `slab_count` equal slices that run as one batched
+// launch into separate m x m slabs, summed in a fixed order afterwards (deterministic; no atomics).
+static long long syrk_slabs(long long m, long long n) {
+  const long long tr = (m + 127) / 128, tiles = tr * (tr + 1) / 2;
+  long long s = (768 + tiles - 1) / tiles;
+  while (s > 1 && n / s < 4096) --s;
+  return s < 1 ? 1 : (s > 32 ? 32 : s);
+}
+
+__global__ __launch_bounds__(256) void sum_slabs_kernel(double *C, const double *__restrict__ slabs, long long elems, long long count) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= elems) return;
+  double acc = 0.;
+  for (long long b = 0; b < count; ++b) acc += slabs[b * elems + i];
+  C[i] += acc;
+}
+
+static void syrk_over_observations(hipStream_t s, SparseScratch &w, double *C, long long ldc, const double *W, long long ldw,
+                                   long long m, long long n) {
+  const long long S = w.slab_count;
+  const long long per = S > 1 ? n / S : 0;
+  if (S <= 1 || !w.slabs || per <= 0) {
+    launch_gemm_nt_sub(s, C, ldc, W, ldw, false, W, ldw, false, m, m, n, true);
+    return;
+  }
+  const long long elems = ldc * m;
+  (void)hipMemsetAsync(w.slabs, 0, sizeof(double) * (size_t)elems * (size_t)S, s);
+  launch_gemm_nt_sub_batched(s, w.slabs, ldc, elems, W, ldw, false, per * ldw, W, ldw, false, per * ldw, m, m, per, true, S);
+  const long long rest = n - per * S;
+  if (rest > 0) launch_gemm_nt_sub(s, C, ldc, W + (size_t)(per * S) * (size_t)ldw, ldw, false, W + (size_t)(per * S) * (size_t)ldw, ldw, false, m, m, rest, true);
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, C, w.slabs, elems, S);
+}
+
 // The data-dependent half of compute_internal_components (sparse_gp.hpp:642-704) for one set of
 // observations: uploads x / y / y_var, builds K_uf, P = L_u^-1 K_uf, the blocks of
 // A = K_ff + target variance - P_g^T P_g + measurement nugget with their LL^T, and returns
@@ -136,8 +173,26 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
   }
   stage("upload");
   // K_uf (m x n) and P = K_uu^-1/2 K_uf = L_u^-1 K_uf  (:669-685)
-  SPX_HIP(hipMalloc(&w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n));
-  SPX_HIP(hipMalloc(&w.Pbuf, sizeof(double) * (size_t)ldk * (size_t)n));
+  {
+    // pool: K_uf | P, later Q1^T (ldk x (n + m)) | split-K slabs of the m x m products over the observations
+    const long long ldm_p = factor_ld(m);
+    w.slab_count = syrk_slabs(m, n);
+    // the padded lock-step path of ragged groups (below) adds two zero-padded copies of P and K_uf
+    bool all_equal = true;
+    for (int64_t g = 0; g < n_groups; ++g) all_equal = all_equal && (offsets[g + 1] - offsets[g] == smax);
+    const bool padded_path = !all_equal && n_groups >= 4 && smax * n_groups <= 3 * n;
+    const size_t kuf_e = (size_t)ldk * (size_t)n, pq_e = (size_t)ldk * (size_t)(n + m),
+                 slab_e = (size_t)w.slab_count * (size_t)ldm_p * (size_t)m,
+                 pad_e = padded_path ? (size_t)ldk * (size_t)(smax * n_groups) : 0;
+    if ((st = ensure_ws(ctx, &ctx->pool_sparse, &ctx->pool_sparse_bytes,
+                        sizeof(double) * (kuf_e + pq_e + slab_e + 2 * pad_e))) != AGP_OK)
+      return st;
+    w.Kuf = ctx->pool_sparse;
+    w.Pbuf = w.Kuf + kuf_e;
+    w.Q1T = w.Pbuf;
+    w.slabs = w.Pbuf + pq_e;
+    w.pads = w.slabs + slab_e;
+  }
   launch_gram(s, dprog, uv, xm, false, false, w.Kuf, ldk, nullptr, nullptr, &k->prog);
   if (kp) {  // P = K_uu_ldlt.sqrt_solve(K_uf) with the pivoted L D L^T (:680-685)
     ldlt_sqrt_solve(s, kp->A, kp->lda, m, kp->q_dev, w.Pbuf, w.Kuf, ldk, n);
@@ -188,7 +243,7 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
     const long long stride_A = lda_b * sb, stride_I = nblk_b * (36 * MB * MB), padded = sb * G;
     double *Ppad = nullptr, *Kpad = nullptr, *ypad = nullptr;
     long long *off_d = nullptr;
-    auto free_pads = [&]() { (void)hipFree(Ppad); (void)hipFree(Kpad); (void)hipFree(ypad); (void)hipFree(off_d); };
+    auto free_pads = [&]() { (void)hipFree(ypad); (void)hipFree(off_d); };
 #define SPX_HIP2(expr)                                                                   \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
@@ -200,8 +255,8 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
   } while (0)
     SPX_HIP2(hipMalloc(&off_d, sizeof(long long) * (size_t)(G + 1)));
     SPX_HIP2(hipMemcpyAsync(off_d, offsets, sizeof(long long) * (size_t)(G + 1), hipMemcpyHostToDevice, s));
-    SPX_HIP2(hipMalloc(&Ppad, sizeof(double) * (size_t)ldk * (size_t)padded));
-    SPX_HIP2(hipMalloc(&Kpad, sizeof(double) * (size_t)ldk * (size_t)padded));
+    Ppad = w.pads;  // in the pool (sized above)
+    Kpad = Ppad + (size_t)ldk * (size_t)padded;
     SPX_HIP2(hipMalloc(&ypad, sizeof(double) * (size_t)round_up(padded, 2)));
     SPX_HIP2(hipMalloc(&w.Ag, sizeof(double) * (size_t)stride_A * (size_t)G));
     SPX_HIP2(hipMalloc(&w.Pimg, sizeof(double) * ((size_t)stride_I + 1) * (size_t)G));
@@ -287,7 +342,7 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
       }
     for (int64_t g = 0; g < n_groups; ++g) log_det_a += w.blocks[(size_t)g]->log_det;  // fixed order
   }
-  (void)hipFree(w.Pbuf); w.Pbuf = nullptr;
+  w.Pbuf = nullptr;  // dead: its region of the pool becomes Q1^T
   stage("blocks of A, W, y_w");
   *yw_out = yw;
   *log_det_a_out = log_det_a;
@@ -312,7 +367,7 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
   // M = T T^T + W W^T   (the W part summed over the ranks)
   SPX_HIP(hipMalloc(&w.M0, sizeof(double) * (size_t)ldm * (size_t)m));
   SPX_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
-  if (n > 0) launch_gemm_nt_sub(s, w.M0, ldm, W, ldk, false, W, ldk, false, m, m, n, true);
+  if (n > 0) syrk_over_observations(s, w, w.M0, ldm, W, ldk, m, n);
   if ((st = comm_all_reduce_device(ctx, comm, w.M0, ldm * m, 0)) != AGP_OK) return st;
   launch_gemm_nt_sub(s, w.M0, ldm, T, ldt, false, T, ldt, false, m, m, m, true);
   launch_negate(s, w.M0, ldm, m, nullptr);
@@ -320,7 +375,6 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
   if ((st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma)) != AGP_OK) return st;
   stage("factor M");
   // CholeskyQR2: Q1^T = L1^-1 [T | W]  (m x (m + n)), G = Q1^T Q1 = L2 L2^T
-  SPX_HIP(hipMalloc(&w.Q1T, sizeof(double) * (size_t)ldk * (size_t)(n + m)));
   SPX_HIP(hipMemcpy2DAsync(w.Q1T, sizeof(double) * (size_t)ldk, T, sizeof(double) * (size_t)ldt, sizeof(double) * (size_t)m,
                            (size_t)m, hipMemcpyDeviceToDevice, s));
   if (n > 0)
@@ -329,12 +383,11 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
   forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, w.Q1T, n + m, ldk);
   SPX_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
   if (n > 0)  // the W columns of Q1 (summed over the ranks), then the T columns
-    launch_gemm_nt_sub(s, w.M0, ldm, w.Q1T + (size_t)ldk * (size_t)m, ldk, false, w.Q1T + (size_t)ldk * (size_t)m, ldk, false, m, m, n, true);
+    syrk_over_observations(s, w, w.M0, ldm, w.Q1T + (size_t)ldk * (size_t)m, ldk, m, n);
   if ((st = comm_all_reduce_device(ctx, comm, w.M0, ldm * m, 0)) != AGP_OK) return st;
   launch_gemm_nt_sub(s, w.M0, ldm, w.Q1T, ldk, false, w.Q1T, ldk, false, m, m, m, true);
   launch_negate(s, w.M0, ldm, m, nullptr);
   st = agp_factor_create(ctx, w.M0, m, ldm, 0, AGP_DEVICE, &f->sigma2);
-  (void)hipFree(w.Q1T); w.Q1T = nullptr;
   if (st != AGP_OK) return st;
   stage("CholeskyQR2 (Q1, L2)");
 
