@@ -224,13 +224,16 @@ constexpr int SOP_MAX_TERMS = 6;
 constexpr int SOP_MAX_FACTORS = 4;
 
 struct SopFactor {
-  int op;       // agp_op of the leaf
-  int metric;   // radial leaves
-  int column;   // scaling
-  int order;    // polynomial
+  // op | metric << 8 | column << 16 | order << 24 in ONE word: the device reads a factor with one scalar load and one
+  // wait (field-by-field loads behind the branches on `op` cost ~5 dependent scalar-cache round trips per factor)
+  int packed;
+  int pad;
   double a;     // radial: sigma^2;  constant / noise / nugget: sigma^2;  polynomial: sigma_0
   double b;     // radial: SE 1 / l, EXP 1 / l, M32 sqrt(3) / l, M52 sqrt(5) / l  (0 when l <= 0: the leaf is 0)
   double c, d, e;  // polynomial: sigma_1..sigma_3
+  __host__ __device__ static int pack(int op, int metric, int column, int order) {
+    return (op & 0xff) | ((metric & 0xff) << 8) | ((column & 0xff) << 16) | ((order & 0xff) << 24);
+  }
 };
 
 struct SopTerm {
@@ -247,90 +250,130 @@ struct SopProgram {
   SopTerm t[SOP_MAX_TERMS];
 };
 
-template <int DIMP>
-__device__ __forceinline__ double eval_sop(const SopProgram &P, const Point<DIMP> &x, const Point<DIMP> &y, bool swapped,
-                                           bool have_ids, bool both_measurement) {
-  double d_euclid = 0., d_radial = 0., d_angular = 0.;
-  if (P.metric_mask & (1 << AGP_METRIC_EUCLIDEAN)) {
-    if (DIMP == 1) {
-      d_euclid = fabs(x.c[0] - y.c[0]);
-    } else {
-      double s = 0.;
+// NP pairs (xs[p], ys[p]) per walk of the program: the term / factor loop is wave-uniform scalar work (loads of the
+// program from the kernel arguments, branches on the leaf kind) and costs as much as the arithmetic of one pair, so the
+// Gram kernel amortises it over the 2 rows x 2 columns a thread has in hand.
+template <int DIMP, int NP>
+__device__ __forceinline__ void eval_sop_n(const SopProgram &P, const Point<DIMP> *const (&xs)[NP], const Point<DIMP> *const (&ys)[NP],
+                                           const bool (&swapped)[NP], bool have_ids, bool both_measurement, double (&out)[NP]) {
+  double d_euclid[NP], d_radial[NP], d_angular[NP];
+  bool equal[NP];
 #pragma unroll
-      for (int d = 0; d < DIMP; ++d) {
-        const double t = x.c[d] - y.c[d];
-        s += t * t;
+  for (int p = 0; p < NP; ++p) {
+    const Point<DIMP> &x = *xs[p], &y = *ys[p];
+    d_euclid[p] = 0.; d_radial[p] = 0.; d_angular[p] = 0.;
+    if (P.metric_mask & (1 << AGP_METRIC_EUCLIDEAN)) {
+      if (DIMP == 1) {
+        d_euclid[p] = fabs(x.c[0] - y.c[0]);
+      } else {
+        double s = 0.;
+#pragma unroll
+        for (int d = 0; d < DIMP; ++d) {
+          const double t = x.c[d] - y.c[d];
+          s += t * t;
+        }
+        d_euclid[p] = sqrt(s);
       }
-      d_euclid = sqrt(s);
     }
-  }
-  if (P.metric_mask & (1 << AGP_METRIC_RADIAL)) d_radial = fabs(x.norm - y.norm);
-  if (P.metric_mask & (1 << AGP_METRIC_ANGULAR)) {
-    double dot = 0.;
+    if (P.metric_mask & (1 << AGP_METRIC_RADIAL)) d_radial[p] = fabs(x.norm - y.norm);
+    if (P.metric_mask & (1 << AGP_METRIC_ANGULAR)) {
+      double dot = 0.;
 #pragma unroll
-    for (int d = 0; d < DIMP; ++d) dot += x.c[d] * y.c[d];
-    const double c = dot / (x.norm * y.norm);
-    const double eps = 1e-16;  // EPSILON, distance_metrics.hpp:18
-    d_angular = (c > 1. - eps) ? 0. : ((c < -1. + eps) ? M_PI : acos(c));
-  }
-  bool equal = false;
-  if (P.uses_equality) {
-    if (have_ids) {
-      equal = (x.id == y.id);
-    } else {
-      equal = true;
-#pragma unroll
-      for (int d = 0; d < DIMP; ++d) equal = equal && (x.c[d] == y.c[d]);
+      for (int d = 0; d < DIMP; ++d) dot += x.c[d] * y.c[d];
+      const double c = dot / (x.norm * y.norm);
+      const double eps = 1e-16;  // EPSILON, distance_metrics.hpp:18
+      d_angular[p] = (c > 1. - eps) ? 0. : ((c < -1. + eps) ? M_PI : acos(c));
     }
+    equal[p] = false;
+    if (P.uses_equality) {
+      if (have_ids) {
+        equal[p] = (x.id == y.id);
+      } else {
+        bool e = true;
+#pragma unroll
+        for (int d = 0; d < DIMP; ++d) e = e && (x.c[d] == y.c[d]);
+        equal[p] = e;
+      }
+    }
+    out[p] = 0.;
   }
-  double sum = 0.;
   for (int ti = 0; ti < P.n_terms; ++ti) {
     const SopTerm &T = P.t[ti];
     if (T.measurement_only && !both_measurement) continue;  // measurement.hpp:87-102
-    double v = 1., expo = 0.;
+    double v[NP], expo[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { v[p] = 1.; expo[p] = 0.; }
     bool any_exp = false;
-    // lhs * rhs with rhs skipped once lhs == 0 (covariance_function.hpp:362-366): 0 * inf stays 0
-    auto mul = [&v](double f) { v = (v != 0.) ? v * f : v; };
     for (int fi = 0; fi < T.n_factors; ++fi) {
+      // the whole factor up front (the asm pins the loads here: one wait instead of one per branch)
       const SopFactor &F = T.f[fi];
-      const int op = F.op;
+      int packed = F.packed;
+      double fa = F.a, fb = F.b, fc = F.c, fd = F.d, fe = F.e;
+      asm volatile("" : "+s"(packed), "+s"(fa), "+s"(fb), "+s"(fc), "+s"(fd), "+s"(fe));
+      const int op = packed & 0xff, metric = (packed >> 8) & 0xff, column = (packed >> 16) & 0xff, order = (packed >> 24) & 0xff;
+      // lhs * rhs with rhs skipped once lhs == 0 (covariance_function.hpp:362-366): 0 * inf stays 0
       if (op <= AGP_OP_MATERN52) {
-        const double dist = F.metric == AGP_METRIC_EUCLIDEAN ? d_euclid : (F.metric == AGP_METRIC_RADIAL ? d_radial : d_angular);
-        const double q = dist * F.b;
-        double coef = F.a;
-        if (op == AGP_OP_SQUARED_EXPONENTIAL) expo += q * q;
-        else if (op == AGP_OP_EXPONENTIAL) expo += fabs(q);
-        else if (op == AGP_OP_MATERN32) { coef = coef * (1 + q); expo += q; }
-        else { coef = coef * (1 + q + q * q * (1. / 3.)); expo += q; }
-        mul((F.b > 0.) ? coef : 0.);  // length_scale <= 0: the leaf is 0 (radial.hpp:26-28)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const double dist = metric == AGP_METRIC_EUCLIDEAN ? d_euclid[p] : (metric == AGP_METRIC_RADIAL ? d_radial[p] : d_angular[p]);
+          const double q = dist * fb;
+          double coef = fa;
+          if (op == AGP_OP_SQUARED_EXPONENTIAL) expo[p] += q * q;
+          else if (op == AGP_OP_EXPONENTIAL) expo[p] += fabs(q);
+          else if (op == AGP_OP_MATERN32) { coef = coef * (1 + q); expo[p] += q; }
+          else { coef = coef * (1 + q + q * q * (1. / 3.)); expo[p] += q; }
+          const double f = (fb > 0.) ? coef : 0.;  // length_scale <= 0: the leaf is 0 (radial.hpp:26-28)
+          v[p] = (v[p] != 0.) ? v[p] * f : v[p];
+        }
         any_exp = true;
       } else if (op == AGP_OP_CONSTANT) {
-        mul(F.a);
-      } else if (op == AGP_OP_INDEPENDENT_NOISE || op == AGP_OP_NUGGET) {
-        mul(equal ? F.a : 0.);
-      } else if (op == AGP_OP_SCALING) {
-        double fx = x.s[0], fy = y.s[0];
 #pragma unroll
-        for (int k = 1; k < AGP_MAX_SCALE_COLUMNS; ++k) {
-          fx = (F.column == k) ? x.s[k] : fx;
-          fy = (F.column == k) ? y.s[k] : fy;
+        for (int p = 0; p < NP; ++p) v[p] = (v[p] != 0.) ? v[p] * fa : v[p];
+      } else if (op == AGP_OP_INDEPENDENT_NOISE || op == AGP_OP_NUGGET) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) v[p] = (v[p] != 0.) ? v[p] * (equal[p] ? fa : 0.) : v[p];
+      } else if (op == AGP_OP_SCALING) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          double fx = xs[p]->s[0], fy = ys[p]->s[0];
+#pragma unroll
+          for (int k = 1; k < AGP_MAX_SCALE_COLUMNS; ++k) {
+            fx = (column == k) ? xs[p]->s[k] : fx;
+            fy = (column == k) ? ys[p]->s[k] : fy;
+          }
+          v[p] = (v[p] != 0.) ? v[p] * (fx * fy) : v[p];
         }
-        mul(fx * fy);
       } else {  // AGP_OP_POLYNOMIAL, polynomials.hpp:78-86
-        const double sg[4] = {F.a, F.c, F.d, F.e};
-        double cov = 0., xp = 1., yp = 1.;
-        for (int q = 0; q <= F.order; ++q) {
-          cov += swapped ? sg[q] * sg[q] * yp * xp : sg[q] * sg[q] * xp * yp;
-          xp *= x.c[0];
-          yp *= y.c[0];
+        const double sg[4] = {fa, fc, fd, fe};
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          double cov = 0., xp = 1., yp = 1.;
+          for (int q = 0; q <= order; ++q) {
+            cov += swapped[p] ? sg[q] * sg[q] * yp * xp : sg[q] * sg[q] * xp * yp;
+            xp *= xs[p]->c[0];
+            yp *= ys[p]->c[0];
+          }
+          v[p] = (v[p] != 0.) ? v[p] * cov : v[p];
         }
-        mul(cov);
       }
     }
-    if (any_exp) v = (v != 0.) ? v * exp_neg(expo) : v;
-    sum += v;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (any_exp) v[p] = (v[p] != 0.) ? v[p] * exp_neg(expo[p]) : v[p];
+      out[p] += v[p];
+    }
   }
-  return sum;
+}
+
+template <int DIMP>
+__device__ __forceinline__ double eval_sop(const SopProgram &P, const Point<DIMP> &x, const Point<DIMP> &y, bool swapped,
+                                           bool have_ids, bool both_measurement) {
+  const Point<DIMP> *const xs[1] = {&x};
+  const Point<DIMP> *const ys[1] = {&y};
+  const bool sw[1] = {swapped};
+  double out[1];
+  eval_sop_n<DIMP, 1>(P, xs, ys, sw, have_ids, both_measurement, out);
+  return out[0];
 }
 
 }  // namespace agp

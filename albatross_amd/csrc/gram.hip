@@ -85,22 +85,8 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const DevProgram *__
   const bool both_meas = X.meas && Y.meas;
   const bool wide = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   bool saw_nan = false;
-#pragma unroll 1
-  for (int jj = 0; jj < TN / 4; ++jj) {
-    const int cslot = cgrp * (TN / 4) + jj;
-    const long long col = col0 + cslot;
-    if (col >= Y.n) break;
-    const Point<DIMP> y = read_point<DIMP>(L, TM + cslot);
-    // symmetric Gram: the reference evaluates caller(xs[i], xs[j]) with i >= j
-    // and mirrors (callers.hpp:119-127); keep the same argument order.
-    double va, vb;
-    if (SOP) {
-      va = eval_sop<DIMP>(sop, xa, y, symmetric && ra < col, have_ids, both_meas);
-      vb = eval_sop<DIMP>(sop, xb, y, symmetric && rb < col, have_ids, both_meas);
-    } else {
-      va = eval_pair<DIMP>(P, xa, y, symmetric && ra < col, have_ids, both_meas);
-      vb = eval_pair<DIMP>(P, xb, y, symmetric && rb < col, have_ids, both_meas);
-    }
+  // one column: add the diagonal term, note NaNs, store the two rows
+  auto finish = [&](long long col, double va, double vb) {
     if (diag_add) {
       if (ra == col) va += diag_add[col];
       if (rb == col) vb += diag_add[col];
@@ -118,6 +104,36 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const DevProgram *__
       }
     } else if (ra < X.n) {
       dst[0] = va;
+    }
+  };
+  if (SOP) {
+    // the two rows of a thread per walk of the program: the pairs share the scalar work (cov_eval.h: eval_sop_n)
+#pragma unroll 1
+    for (int jj = 0; jj < TN / 4; ++jj) {
+      const int cslot = cgrp * (TN / 4) + jj;
+      const long long col = col0 + cslot;
+      if (col >= Y.n) break;
+      const Point<DIMP> y = read_point<DIMP>(L, TM + cslot);
+      // symmetric Gram: the reference evaluates caller(xs[i], xs[j]) with i >= j and mirrors (callers.hpp:119-127)
+      const Point<DIMP> *const xs2[2] = {&xa, &xb};
+      const Point<DIMP> *const ys2[2] = {&y, &y};
+      const bool sw2[2] = {symmetric && ra < col, symmetric && rb < col};
+      double v2[2];
+      eval_sop_n<DIMP, 2>(sop, xs2, ys2, sw2, have_ids, both_meas, v2);
+      finish(col, v2[0], v2[1]);
+    }
+  } else {
+#pragma unroll 1
+    for (int jj = 0; jj < TN / 4; ++jj) {
+      const int cslot = cgrp * (TN / 4) + jj;
+      const long long col = col0 + cslot;
+      if (col >= Y.n) break;
+      const Point<DIMP> y = read_point<DIMP>(L, TM + cslot);
+      // symmetric Gram: the reference evaluates caller(xs[i], xs[j]) with i >= j
+      // and mirrors (callers.hpp:119-127); keep the same argument order.
+      const double va = eval_pair<DIMP>(P, xa, y, symmetric && ra < col, have_ids, both_meas);
+      const double vb = eval_pair<DIMP>(P, xb, y, symmetric && rb < col, have_ids, both_meas);
+      finish(col, va, vb);
     }
   }
   if (saw_nan && nan_flag) atomicOr(nan_flag, 1);
@@ -301,7 +317,7 @@ static bool build_sop(const DevProgram &H, SopProgram *out) {
       t.n_factors = 1;
       t.measurement_only = 0;
       SopFactor &f = t.f[0];
-      f.op = nd.op; f.metric = nd.metric; f.column = nd.column; f.order = nd.order;
+      f.packed = SopFactor::pack(nd.op, nd.metric, nd.column, nd.order); f.pad = 0;
       f.a = f.b = f.c = f.d = f.e = 0.;
       if (nd.op <= AGP_OP_MATERN52) {
         const double l = nd.params[0], sg = nd.params[1];
@@ -458,7 +474,7 @@ __global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_kernel(const DevPr
   const bool have_ids = X.ids != nullptr && XS.ids != nullptr;
   const bool both_meas = X.meas && XS.meas;
   double acc = 0.;
-  for (long long i = lane; i < X.n; i += 64) {
+  auto load_x = [&](long long i) {
     Point<DIMP> x;
     double xn = 0.;
 #pragma unroll
@@ -470,6 +486,23 @@ __global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_kernel(const DevPr
 #pragma unroll
     for (int k = 0; k < AGP_MAX_SCALE_COLUMNS; ++k) x.s[k] = k < X.nsc ? X.scales[(long long)k * scale_stride(X) + i] : 0.;
     x.id = X.ids ? X.ids[i] : -1;
+    return x;
+  };
+  long long i = lane;
+  if (SOP) {  // two training points per walk of the program (cov_eval.h: eval_sop_n)
+    for (; i + 64 < X.n; i += 128) {
+      const Point<DIMP> x0 = load_x(i), x1 = load_x(i + 64);
+      const Point<DIMP> *const xs2[2] = {&x0, &x1};
+      const Point<DIMP> *const ys2[2] = {&y, &y};
+      const bool sw2[2] = {false, false};
+      double v2[2];
+      eval_sop_n<DIMP, 2>(sop, xs2, ys2, sw2, have_ids, both_meas, v2);
+      acc += v2[0] * alpha[i];
+      acc += v2[1] * alpha[i + 64];
+    }
+  }
+  for (; i < X.n; i += 64) {
+    const Point<DIMP> x = load_x(i);
     acc += (SOP ? eval_sop<DIMP>(sop, x, y, false, have_ids, both_meas) : eval_pair<DIMP>(P, x, y, false, have_ids, both_meas)) * alpha[i];
   }
 #pragma unroll
