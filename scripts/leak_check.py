@@ -36,6 +36,8 @@ def cycle():
     sf = sparse.fit(ds)
     sf.predict(xs).joint(); sf.update(ab.RegressionDataset(xs, np.zeros(200))).predict(xs).marginal()
     sparse.log_likelihood(ds)
+    rb = ab.rebase_inducing_points(sf, rng.uniform(0., 10., (40, 2)))   # pivoted L D L^T + pivoted QR
+    rb.predict(xs).marginal(); rb.update(ab.RegressionDataset(xs, np.zeros(200))).predict(xs).joint()
     ab.DenseFactor(np.eye(300) * 2.0, ctx).solve(np.ones(300))
     ctx.gram(cov, x[:100], xs)
 

@@ -426,3 +426,29 @@ def test_singular_inducing_covariance_falls_back_to_the_pivoted_path(ctx):
     assert np.linalg.norm(p.mean - om) < 1e-6 * np.linalg.norm(om)
     assert np.abs(p.covariance - oc).max() <= 5e-7 * 100.0 ** 2
     assert abs(fm.get_fit().nll - ofit.nll) <= 1e-6 * max(1., abs(ofit.nll))
+
+
+def test_rebase_many_points_2d_matches_oracle(ctx):
+    """fit_from_prediction with 150 new inducing points in two dimensions: the blocked paths of the pivoted
+    factorisations (64-wide diagonal blocks of the L D L^T and R^T substitutions, the blocked L D L^T itself)."""
+    rng = np.random.default_rng(11)
+    n = 500
+    x = rng.uniform(0., 10., (n, 2))
+    y = np.sin(x[:, 0]) * np.cos(x[:, 1]) + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.04, n)
+    cov = ab.Matern32(1.5, 1.2) + ab.measurement_only(ab.IndependentNoise(0.2))
+    grouper = lambda f: int(f[0] // 2.0) * 8 + int(f[1] // 2.0)
+    keys = np.array([grouper(f) for f in x])
+    u = rng.uniform(0., 10., (90, 2))
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "sparse", context=ctx)
+    model.set_param("inducing_nugget", 1e-6)
+    fm = model.fit(ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar)))
+    ofit = orc.OracleSparseFit(cov, x, keys, y, yvar, u, 1e-8, 1e-6)
+    z = rng.uniform(0., 10., (150, 2))
+    rb, orb = ab.rebase_inducing_points(fm, z), ofit.rebase(z)
+    assert rb.get_fit().numerical_rank == orb.numerical_rank
+    xs = rng.uniform(0., 10., (60, 2))
+    om, ov, oj = orb.predict(xs, xs_meas=True, joint=True)
+    p = rb.predict_with_measurement_noise(xs).joint()
+    assert np.abs(p.mean - om).max() <= 1e-6 * np.abs(om).max()
+    assert np.abs(p.covariance - oj).max() <= 1e-6 * np.abs(oj).max()
