@@ -452,3 +452,48 @@ def test_rebase_many_points_2d_matches_oracle(ctx):
     p = rb.predict_with_measurement_noise(xs).joint()
     assert np.abs(p.mean - om).max() <= 1e-6 * np.abs(om).max()
     assert np.abs(p.covariance - oj).max() <= 1e-6 * np.abs(oj).max()
+
+
+def test_fit_from_prediction_device_resident_inputs(ctx):
+    """agp_sparse_fit_from_prediction with the prediction already in HBM (location = AGP_DEVICE, a leading dimension
+    larger than m) gives the fit it gives for host inputs."""
+    import ctypes as C
+    import torch
+    from albatross_amd import _capi as capi
+    rng = np.random.default_rng(3)
+    z = np.linspace(0.5, 9.5, 20)
+    cov = ab.Matern52(2.0, 1.5) + ab.measurement_only(ab.IndependentNoise(0.2))
+    K = orc.gram(cov, z)
+    mean = rng.standard_normal(20)
+    Cm = 0.3 * K + 0.05 * np.eye(20)
+    fz = cov.features(z)
+    sz = fz.as_struct()
+    lib = ctx._lib
+    infos, ranks = [], []
+    ld = 24
+    pad = np.zeros((ld, 20), order="F")
+    pad[:20] = Cm
+    dev_mean = torch.from_numpy(mean).cuda()
+    dev_cov = torch.from_numpy(np.ascontiguousarray(pad.T)).cuda()  # memory of the column-major ld x 20 array
+    host_cov = np.asfortranarray(Cm)  # kept alive: .ctypes.data of a temporary would dangle
+    for args in ((mean.ctypes.data, host_cov.ctypes.data, 20, capi.HOST),
+                 (dev_mean.data_ptr(), dev_cov.data_ptr(), ld, capi.DEVICE)):
+        h = C.c_void_p()
+        info = np.zeros(20)
+        rank = C.c_int64()
+        st = lib.agp_sparse_fit_from_prediction(ctx._h, ctx.kernel(cov), C.byref(sz), C.c_void_p(args[0]), C.c_void_p(args[1]),
+                                                args[2], args[3], 1e-8, C.byref(h), info.ctypes.data_as(C.c_void_p), C.byref(rank))
+        assert st == capi.AGP_OK
+        ranks.append(rank.value)
+        xs = np.linspace(0., 10., 7)
+        fs = cov.features(xs).as_struct()
+        m, v = np.zeros(7), np.zeros(7)
+        assert lib.agp_sparse_predict_marginal(ctx._h, ctx.kernel(cov), h, C.byref(fs), m.ctypes.data_as(C.c_void_p),
+                                               v.ctypes.data_as(C.c_void_p), capi.HOST) == capi.AGP_OK
+        lib.agp_sparse_fit_destroy(h)
+        infos.append((info, m, v))
+    for a, b in zip(infos[0], infos[1]):
+        assert np.array_equal(a, b)
+    ofit = orc.OracleSparseFit.from_prediction(cov, z, mean, Cm)
+    assert ranks[0] == ranks[1] == ofit.numerical_rank
+    assert np.abs(infos[0][0] - ofit.information).max() <= 1e-6 * np.abs(ofit.information).max()
