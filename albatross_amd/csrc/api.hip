@@ -3,6 +3,7 @@
 // Host-side orchestration only: uploads POD feature vectors, enqueues the HIP
 // kernels of gram.hip / chol.hip / gemm.hip / reduce.hip on the context's
 // stream, reads back the small results.  No CPU arithmetic fallback exists.
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -1251,6 +1252,28 @@ int agp_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, 
   return st;
 }
 
+// rows [o, o + cnt) of a device feature view (scale columns keep the stride of the whole vector)
+static FeatView feature_range(const FeatView &v, long long o, long long cnt) {
+  FeatView r = v;
+  r.sstride = scale_stride(v);
+  r.n = cnt;
+  r.coords = v.coords + o * v.dim;
+  r.ids = v.ids ? v.ids + o : nullptr;
+  r.scales = v.scales ? v.scales + o : nullptr;
+  return r;
+}
+
+// Test points per pass of a marginal prediction: the n x m block L^-1 K* is the only large buffer, and nothing couples
+// the columns of a marginal prediction, so m is cut into passes that keep it at 2 GiB (AGP_PREDICT_CHUNK=<points>
+// overrides; a joint prediction needs all columns at once).
+static long long marginal_chunk(long long rows) {
+  const char *e = getenv("AGP_PREDICT_CHUNK");  // read per call: the tests switch it within one process
+  const long long forced = e ? atoll(e) : 0;
+  if (forced > 0) return forced;
+  const long long c = (1LL << 28) / (rows > 0 ? rows : 1);
+  return c < 1024 ? 1024 : c;
+}
+
 static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, const agp_features *xs,
                           double *mean, double *var_or_cov, bool joint, int out_location) {
   if (!ctx || !k || !fit || !xs || !mean || !var_or_cov) return AGP_ERR_INVALID_ARGUMENT;
@@ -1258,62 +1281,68 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
   int st = validate_features(xs);
   if (st != AGP_OK) return st;
   if (!fit->alpha || xs->dim != fit->train.v.dim) return AGP_ERR_INVALID_ARGUMENT;
-  const long long m = xs->n, n = fit->n;
-  if (m == 0) return AGP_OK;
+  const long long m_all = xs->n, n = fit->n;
+  if (m_all == 0) return AGP_OK;
   const DevProgram *dprog = nullptr;
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
   DeviceFeatures dxs;
   if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
   TraceRange tr_predict(joint ? "agp: predict joint (gp.hpp:103-113)" : "agp: predict marginal (gp.hpp:87-101)");
-  const long long ldv = round_up(n, 2), ldc = round_up(m, 2);
-  // workspace: V (n x m) | mean (m) | prior (m or m x m)
-  const size_t v_elems = (size_t)ldv * (size_t)m;
-  const size_t p_elems = joint ? (size_t)ldc * (size_t)m : (size_t)round_up(m, 2);
-  st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (v_elems + (size_t)round_up(m, 2) + p_elems));
+  const long long ldv = round_up(n, 2);
+  const long long chunk = joint ? m_all : std::min(m_all, marginal_chunk(ldv));
+  // workspace: V (n x chunk) | mean (chunk) | prior (chunk, or m x m for a joint prediction)
+  const long long ldc = round_up(chunk, 2);
+  const size_t v_elems = (size_t)ldv * (size_t)chunk;
+  const size_t p_elems = joint ? (size_t)ldc * (size_t)chunk : (size_t)ldc;
+  st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (v_elems + (size_t)ldc + p_elems));
   if (st != AGP_OK) { dxs.release(); return st; }
-  double *V = ctx->ws_aux, *mean_d = V + v_elems, *prior = mean_d + round_up(m, 2);
+  double *V = ctx->ws_aux, *mean_d = V + v_elems, *prior = mean_d + ldc;
   hipStream_t s = ctx->stream;
-  // mean (gp.hpp:82-85)
-  launch_predict_mean(s, dprog, fit->train.v, dxs.v, fit->alpha, mean_d, &k->prog);
-  // cross_cov = cov(train_features, features)   (gp.hpp:316,337)
-  launch_gram(s, dprog, fit->train.v, dxs.v, false, false, V, ldv, nullptr, nullptr, &k->prog);
-  fit_zero_phantom_rows(s, fit, V, ldv, m);
-  // V = L^-1 K*  ;  explained = V^T V  (== K*^T K^-1 K*, gp.hpp:96,111)
-  if (m == 1 && n >= 1024) {
-    // a single test point: the vector chain (one fused launch per 128 rows) instead of the matrix kernels
-    const long long nblk = (n + NB - 1) / NB;
-    double *Wfwd = nullptr, *stage = nullptr;
-    const long long BWp = backsolve_width(n);
-    const size_t w_elems = BWp ? (size_t)(n / BWp) * (size_t)BWp * (size_t)BWp : (size_t)nblk * NB * NB;
-    if (hipMalloc(&Wfwd, sizeof(double) * (w_elems + (size_t)round_up(n, 2))) != hipSuccess) {
-      dxs.release();
-      ctx->last_error = "hipMalloc (single-point prediction workspace)";
-      return AGP_ERR_HIP;
-    }
-    stage = Wfwd + w_elems;
-    if (BWp) {  // through 512-wide inverted diagonal blocks (see agp_solve)
-      invert_wide_blocks(s, fit->A, n, fit->lda, fit->invd, BWp, Wfwd);
-      forward_solve_vec_wide(s, fit->A, n, fit->lda, Wfwd, BWp, V, stage);
+  for (long long o = 0; o < m_all && st == AGP_OK; o += chunk) {
+    const long long m = std::min(chunk, m_all - o);
+    const FeatView xv = (o == 0 && m == m_all) ? dxs.v : feature_range(dxs.v, o, m);
+    // mean (gp.hpp:82-85)
+    launch_predict_mean(s, dprog, fit->train.v, xv, fit->alpha, mean_d, &k->prog);
+    // cross_cov = cov(train_features, features)   (gp.hpp:316,337)
+    launch_gram(s, dprog, fit->train.v, xv, false, false, V, ldv, nullptr, nullptr, &k->prog);
+    fit_zero_phantom_rows(s, fit, V, ldv, m);
+    // V = L^-1 K*  ;  explained = V^T V  (== K*^T K^-1 K*, gp.hpp:96,111)
+    if (m == 1 && n >= 1024) {
+      // a single test point: the vector chain (one fused launch per 128 rows) instead of the matrix kernels
+      const long long nblk = (n + NB - 1) / NB;
+      double *Wfwd = nullptr, *stage = nullptr;
+      const long long BWp = backsolve_width(n);
+      const size_t w_elems = BWp ? (size_t)(n / BWp) * (size_t)BWp * (size_t)BWp : (size_t)nblk * NB * NB;
+      if (hipMalloc(&Wfwd, sizeof(double) * (w_elems + (size_t)round_up(n, 2))) != hipSuccess) {
+        dxs.release();
+        ctx->last_error = "hipMalloc (single-point prediction workspace)";
+        return AGP_ERR_HIP;
+      }
+      stage = Wfwd + w_elems;
+      if (BWp) {  // through 512-wide inverted diagonal blocks (see agp_solve)
+        invert_wide_blocks(s, fit->A, n, fit->lda, fit->invd, BWp, Wfwd);
+        forward_solve_vec_wide(s, fit->A, n, fit->lda, Wfwd, BWp, V, stage);
+      } else {
+        invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
+        forward_solve_vec(s, fit->A, n, fit->lda, Wfwd, V, stage);
+      }
+      (void)hipStreamSynchronize(s);
+      (void)hipFree(Wfwd);
     } else {
-      invert_diag_blocks_forward(s, n, fit->invd, Wfwd);
-      forward_solve_vec(s, fit->A, n, fit->lda, Wfwd, V, stage);
+      forward_solve_mat_lookahead(ctx, fit->A, n, fit->lda, fit->invd, V, m, ldv);
     }
-    (void)hipStreamSynchronize(s);
-    (void)hipFree(Wfwd);
-  } else {
-    forward_solve_mat_lookahead(ctx, fit->A, n, fit->lda, fit->invd, V, m, ldv);
-  }
-  if (!joint) {
-    launch_gram_diagonal(s, dprog, dxs.v, prior);                   // gp.hpp:339-343
-    launch_coldot(s, V, ldv, V, ldv, n, m, prior, 1.0, prior);      // gp.hpp:97-99
-    st = copy_out(ctx, mean_d, m, mean, out_location);
-    if (st == AGP_OK) st = copy_out(ctx, prior, m, var_or_cov, out_location);
-  } else {
-    launch_gram(s, dprog, dxs.v, dxs.v, true, false, prior, ldc, nullptr, nullptr, &k->prog);  // prior_cov, gp.hpp:317
-    launch_gemm_nt_sub(s, prior, ldc, V, ldv, true, V, ldv, true, m, m, n, true);   // lower tiles
-    launch_symmetrize(s, prior, ldc, m);
-    st = copy_out(ctx, mean_d, m, mean, out_location);
-    if (st == AGP_OK) st = copy_out_2d(ctx, prior, ldc, m, m, var_or_cov, m, out_location);
+    if (!joint) {
+      launch_gram_diagonal(s, dprog, xv, prior);                      // gp.hpp:339-343
+      launch_coldot(s, V, ldv, V, ldv, n, m, prior, 1.0, prior);      // gp.hpp:97-99
+      st = copy_out(ctx, mean_d, m, mean + o, out_location);
+      if (st == AGP_OK) st = copy_out(ctx, prior, m, var_or_cov + o, out_location);
+    } else {
+      launch_gram(s, dprog, xv, xv, true, false, prior, ldc, nullptr, nullptr, &k->prog);  // prior_cov, gp.hpp:317
+      launch_gemm_nt_sub(s, prior, ldc, V, ldv, true, V, ldv, true, m, m, n, true);   // lower tiles
+      launch_symmetrize(s, prior, ldc, m);
+      st = copy_out(ctx, mean_d, m, mean, out_location);
+      if (st == AGP_OK) st = copy_out_2d(ctx, prior, ldc, m, m, var_or_cov, m, out_location);
+    }
   }
   dxs.release();
   return st;

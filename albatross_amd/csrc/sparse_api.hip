@@ -924,58 +924,80 @@ static int sparse_predict_common(agp_context *ctx, const agp_kernel *k, const ag
   int st = validate_features(xs);
   if (st != AGP_OK) return st;
   if (xs->dim != f->u->v.dim) return AGP_ERR_INVALID_ARGUMENT;
-  const long long M = xs->n, m = f->m;
-  if (M == 0) return AGP_OK;
+  const long long M_all = xs->n, m = f->m;
+  if (M_all == 0) return AGP_OK;
   const DevProgram *dprog = nullptr;
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
   DeviceFeatures dxs;
   if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
-  const long long ldq = round_up(m, 2), ldc = round_up(M, 2);
-  const size_t q_elems = (size_t)ldq * (size_t)M;
-  const size_t p_elems = mode == 2 ? (size_t)ldc * (size_t)M : (size_t)ldc;
+  const long long ldq = round_up(m, 2);
+  // mean and marginal predictions pass over the test points in slices that keep the m x M buffers at 2 GiB each
+  // (AGP_PREDICT_CHUNK=<points> overrides); a joint prediction needs all of them at once
+  long long chunk = M_all;
+  if (mode != 2) {
+    const char *e = getenv("AGP_PREDICT_CHUNK");
+    const long long forced = e ? atoll(e) : 0;
+    const long long c = forced > 0 ? forced : std::max<long long>(1024, (1LL << 28) / ldq);
+    chunk = std::min(M_all, c);
+  }
+  const long long ldc = round_up(chunk, 2);
+  const size_t q_elems = (size_t)ldq * (size_t)chunk;
+  const size_t p_elems = mode == 2 ? (size_t)ldc * (size_t)chunk : (size_t)ldc;
   const bool pivoted = f->kz || f->R;  // a third m x M buffer: the pivoted substitutions are out of place
   st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes,
                  sizeof(double) * ((pivoted ? 3 : 2) * q_elems + (size_t)ldc + p_elems));
   if (st != AGP_OK) { dxs.release(); return st; }
   double *Q = ctx->ws_aux, *S = Q + q_elems, *mean_d = S + q_elems, *prior = mean_d + ldc, *X = prior + p_elems;
   hipStream_t s = ctx->stream;
-  launch_predict_mean(s, dprog, f->u->v, dxs.v, f->v, mean_d, &k->prog);
-  if (mode > 0 && !pivoted) {
-    launch_gram(s, dprog, f->u->v, dxs.v, false, false, Q, ldq, nullptr, nullptr, &k->prog);
-    (void)hipMemcpyAsync(S, Q, sizeof(double) * q_elems, hipMemcpyDeviceToDevice, s);
-    forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, Q, M, ldq);
-    forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, S, M, ldq);
-    forward_solve_mat(s, f->sigma2->A, m, f->sigma2->lda, f->sigma2->invd, S, M, ldq);
-  } else if (mode > 0) {
-    launch_gram(s, dprog, f->u->v, dxs.v, false, false, X, ldq, nullptr, nullptr, &k->prog);
-    if (f->kz) {  // Q_sqrt = train_covariance.sqrt_solve(cross_cov) with the pivoted L D L^T (:497-498)
-      ldlt_sqrt_solve(s, f->kz->A, f->kz->lda, m, f->kz->q_dev, Q, X, ldq, M);
-    } else {
-      (void)hipMemcpyAsync(Q, X, sizeof(double) * q_elems, hipMemcpyDeviceToDevice, s);
-      forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, Q, M, ldq);
+  for (long long o = 0; o < M_all && st == AGP_OK; o += chunk) {
+    const long long M = std::min(chunk, M_all - o);
+    FeatView xv = dxs.v;
+    if (!(o == 0 && M == M_all)) {
+      xv.sstride = scale_stride(dxs.v);
+      xv.n = M;
+      xv.coords = dxs.v.coords + o * dxs.v.dim;
+      xv.ids = dxs.v.ids ? dxs.v.ids + o : nullptr;
+      xv.scales = dxs.v.scales ? dxs.v.scales + o : nullptr;
     }
-    if (f->R) {   // S_sqrt = sqrt_solve(R, P, cross_cov) = R^-T P^T cross_cov (:503-504)
-      qr_sqrt_solve(s, f->R, ldq, f->perm, m, X, ldq, S, ldq, M);
-    } else {
-      (void)hipMemcpyAsync(S, X, sizeof(double) * q_elems, hipMemcpyDeviceToDevice, s);
+    const size_t q_used = (size_t)ldq * (size_t)M;
+    launch_predict_mean(s, dprog, f->u->v, xv, f->v, mean_d, &k->prog);
+    if (mode > 0 && !pivoted) {
+      launch_gram(s, dprog, f->u->v, xv, false, false, Q, ldq, nullptr, nullptr, &k->prog);
+      (void)hipMemcpyAsync(S, Q, sizeof(double) * q_used, hipMemcpyDeviceToDevice, s);
+      forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, Q, M, ldq);
       forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, S, M, ldq);
       forward_solve_mat(s, f->sigma2->A, m, f->sigma2->lda, f->sigma2->invd, S, M, ldq);
+    } else if (mode > 0) {
+      launch_gram(s, dprog, f->u->v, xv, false, false, X, ldq, nullptr, nullptr, &k->prog);
+      if (f->kz) {  // Q_sqrt = train_covariance.sqrt_solve(cross_cov) with the pivoted L D L^T (:497-498)
+        ldlt_sqrt_solve(s, f->kz->A, f->kz->lda, m, f->kz->q_dev, Q, X, ldq, M);
+      } else {
+        (void)hipMemcpyAsync(Q, X, sizeof(double) * q_used, hipMemcpyDeviceToDevice, s);
+        forward_solve_mat(s, f->kuu->A, m, f->kuu->lda, f->kuu->invd, Q, M, ldq);
+      }
+      if (f->R) {   // S_sqrt = sqrt_solve(R, P, cross_cov) = R^-T P^T cross_cov (:503-504)
+        qr_sqrt_solve(s, f->R, ldq, f->perm, m, X, ldq, S, ldq, M);
+      } else {
+        (void)hipMemcpyAsync(S, X, sizeof(double) * q_used, hipMemcpyDeviceToDevice, s);
+        forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, S, M, ldq);
+        forward_solve_mat(s, f->sigma2->A, m, f->sigma2->lda, f->sigma2->invd, S, M, ldq);
+      }
     }
+    if (mode == 1) {
+      launch_gram_diagonal(s, dprog, xv, prior);
+      launch_coldot(s, Q, ldq, Q, ldq, m, M, prior, 1.0, prior);   // - Q_diag
+      launch_coldot(s, S, ldq, S, ldq, m, M, prior, -1.0, prior);  // + S_diag
+    } else if (mode == 2) {
+      launch_gram(s, dprog, xv, xv, true, false, prior, ldc, nullptr, nullptr, &k->prog);
+      launch_gemm_nt_sub(s, prior, ldc, Q, ldq, true, Q, ldq, true, M, M, m, true);  // - max_explained
+      launch_axpby(s, (long long)q_used, -1.0, S, 0.0, nullptr, Q);  // Q <- -S
+      launch_gemm_nt_sub(s, prior, ldc, Q, ldq, true, S, ldq, true, M, M, m, true);  // + unexplained
+      launch_symmetrize(s, prior, ldc, M);
+    }
+    st = copy_out(ctx, mean_d, M, mean + o, out_location);
+    if (st == AGP_OK && mode == 1) st = copy_out(ctx, prior, M, var_or_cov + o, out_location);
+    if (st == AGP_OK && mode == 2) st = copy_out_2d(ctx, prior, ldc, M, M, var_or_cov, M, out_location);
   }
-  if (mode == 1) {
-    launch_gram_diagonal(s, dprog, dxs.v, prior);
-    launch_coldot(s, Q, ldq, Q, ldq, m, M, prior, 1.0, prior);   // - Q_diag
-    launch_coldot(s, S, ldq, S, ldq, m, M, prior, -1.0, prior);  // + S_diag
-  } else if (mode == 2) {
-    launch_gram(s, dprog, dxs.v, dxs.v, true, false, prior, ldc, nullptr, nullptr, &k->prog);
-    launch_gemm_nt_sub(s, prior, ldc, Q, ldq, true, Q, ldq, true, M, M, m, true);  // - max_explained
-    launch_axpby(s, (long long)q_elems, -1.0, S, 0.0, nullptr, Q);  // Q <- -S
-    launch_gemm_nt_sub(s, prior, ldc, Q, ldq, true, S, ldq, true, M, M, m, true);  // + unexplained
-    launch_symmetrize(s, prior, ldc, M);
-  }
-  st = copy_out(ctx, mean_d, M, mean, out_location);
-  if (st == AGP_OK && mode == 1) st = copy_out(ctx, prior, M, var_or_cov, out_location);
-  if (st == AGP_OK && mode == 2) st = copy_out_2d(ctx, prior, ldc, M, M, var_or_cov, M, out_location);
   dxs.release();
   return st;
 }

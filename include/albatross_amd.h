@@ -413,7 +413,9 @@ int agp_sparse_predict_joint(agp_context *ctx, const agp_kernel *kernel, const a
 int agp_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
                      const agp_features *xs, double *mean, int out_location);
 /* gp_marginal_prediction (gp.hpp:87-101) via _predict_impl (gp.hpp:326-348):
- *   var_j = k(xs_j, xs_j) - sum_i (K^-1 K*)_ij K*_ij. */
+ *   var_j = k(xs_j, xs_j) - sum_i (K^-1 K*)_ij K*_ij.
+ * Any number of test points: they pass in slices that keep the n x m workspace at 2 GiB (nothing couples the
+ * columns of a marginal prediction). */
 int agp_predict_marginal(agp_context *ctx, const agp_kernel *k,
                          const agp_fit *fit, const agp_features *xs,
                          double *mean, double *variance, int out_location);

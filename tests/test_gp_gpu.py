@@ -439,3 +439,40 @@ def test_single_point_prediction_uses_the_vector_chain(ctx):
     pj = fm.predict(xs).joint()
     assert abs(pm.mean[0] - om[0]) <= 1e-8 * abs(om[0]) and abs(pm.covariance[0] - ov[0]) <= 1e-8 * abs(ov[0])
     assert abs(pj.covariance[0, 0] - ov[0]) <= 1e-8 * abs(ov[0])
+
+
+def test_marginal_prediction_in_slices_matches_one_pass(ctx, monkeypatch):
+    """Marginal predictions pass over the test points in slices that bound the n x M workspace (2 GiB by default;
+    AGP_PREDICT_CHUNK forces the slice): same numbers as one pass, for the dense and the sparse model, with a scaling
+    term in the covariance (the sub-views keep the stride of the scale columns)."""
+    rng = np.random.default_rng(21)
+    n, M = 700, 2500
+    x = rng.uniform(0.5, 5., (n, 2))
+    y = np.sin(x).sum(axis=1) + 0.1 * rng.standard_normal(n)
+    xs = rng.uniform(0.5, 5., (M, 2))
+    class Ramp(ab.ScalingFunction):
+        _params = {}
+
+        def get_name(self):
+            return "ramp"
+
+        def _call_impl(self, c):
+            return 1. + 0.1 * np.asarray(c)[:, 0]
+
+    cov = ab.ScalingTerm(Ramp()) * ab.Constant(0.7) + ab.Matern52(1.5, 1.2) + ab.measurement_only(ab.IndependentNoise(0.2))
+    model = ab.gp_from_covariance(cov, context=ctx)
+    fm = model.fit(ab.RegressionDataset(x, y))
+    sparse = ab.sparse_gp_from_covariance(cov, lambda f: int(f[0] // 1.0), ab.FixedInducingPoints(x[:60]), "s", context=ctx)
+    sparse.set_param("inducing_nugget", 1e-6)
+    sfm = sparse.fit(ab.RegressionDataset(x, y))
+    results = []
+    for chunk in ("0", "1000"):  # one pass; three slices, the last one partial
+        monkeypatch.setenv("AGP_PREDICT_CHUNK", chunk)
+        dense = fm.predict_with_measurement_noise(xs).marginal()
+        sm = sfm.predict_with_measurement_noise(xs).marginal()
+        results.append((dense.mean, dense.covariance, sm.mean, sm.covariance))
+    for a, b in zip(results[0], results[1]):
+        assert np.abs(a - b).max() <= 1e-12 * max(1., np.abs(a).max())
+    om, ov = orc.OracleFit(cov, x, y).predict_marginal(xs, xs_meas=True)
+    assert np.abs(results[1][0] - om).max() <= 1e-9 * np.abs(om).max()
+    assert np.abs(results[1][1] - ov).max() <= 1e-9 * np.abs(ov).max()
