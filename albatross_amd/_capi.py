@@ -99,6 +99,7 @@ EXPORTS = [
     ("agp_ldlt_destroy", None, [_P]),
     ("agp_ldlt_size", C.c_int64, [_P]),
     ("agp_ldlt_solve", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int]),
+    ("agp_ldlt_sqrt_solve", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int]),
     ("agp_ldlt_vector_d", C.c_int, [_P, _P]),
     ("agp_ldlt_transpositions", C.c_int, [_P, _P]),
     ("agp_ldlt_download", C.c_int, [_P, _P, _P, C.c_int64]),

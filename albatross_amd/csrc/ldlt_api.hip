@@ -146,6 +146,22 @@ int agp_ldlt_solve(agp_context *ctx, const agp_ldlt *f, const double *rhs, int64
   return copy_out_2d(ctx, R, ldw, n, nrhs, out, n, location);
 }
 
+int agp_ldlt_sqrt_solve(agp_context *ctx, const agp_ldlt *f, const double *rhs, int64_t nrhs, double *out, int location) {
+  if (!ctx || !f || !rhs || !out || nrhs < 0) return AGP_ERR_INVALID_ARGUMENT;
+  if (nrhs == 0) return AGP_OK;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const long long n = f->n, ldw = round_up(n, 2);
+  int st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * 2 * (size_t)ldw * (size_t)nrhs);
+  if (st != AGP_OK) return st;
+  double *W = ctx->ws_aux, *R = W + (size_t)ldw * (size_t)nrhs;
+  const hipMemcpyKind kind = location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  AGP_HIP_CHECK(ctx, hipMemcpy2DAsync(R, sizeof(double) * (size_t)ldw, rhs, sizeof(double) * (size_t)n,
+                                      sizeof(double) * (size_t)n, (size_t)nrhs, kind, ctx->stream));
+  if (location == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ldlt_sqrt_solve(ctx->stream, f->A, f->lda, n, f->q_dev, W, R, ldw, nrhs);
+  return copy_out_2d(ctx, W, ldw, n, nrhs, out, n, location);
+}
+
 int agp_ldlt_vector_d(const agp_ldlt *f, double *d) {
   if (!f || !d) return AGP_ERR_INVALID_ARGUMENT;
   for (long long i = 0; i < f->n; ++i) d[i] = f->d[(size_t)i];

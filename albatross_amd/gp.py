@@ -522,6 +522,15 @@ class PivotedLDLT:
                                                        capi.HOST), "agp_ldlt_solve")
         return out.reshape(rhs.shape, order="F")
 
+    def sqrt_solve(self, rhs):
+        """SerializableLDLT::sqrt_solve (:99-109): D^-1/2 L^-1 P rhs."""
+        rhs = np.asarray(rhs, dtype=np.float64)
+        r2 = np.asfortranarray(rhs.reshape(rhs.shape[0], -1))
+        out = np.empty_like(r2, order="F")
+        self._ctx._check(self._ctx._lib.agp_ldlt_sqrt_solve(self._ctx._h, self._h, _ptr(r2), r2.shape[1], _ptr(out),
+                                                            capi.HOST), "agp_ldlt_sqrt_solve")
+        return out.reshape(rhs.shape, order="F")
+
     def vector_d(self):
         d = np.empty(self.n)
         self._ctx._check(self._ctx._lib.agp_ldlt_vector_d(self._h, _ptr(d)), "agp_ldlt_vector_d")

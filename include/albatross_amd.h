@@ -321,6 +321,10 @@ void agp_ldlt_destroy(agp_ldlt *ldlt);
 int64_t agp_ldlt_size(const agp_ldlt *ldlt);
 int agp_ldlt_solve(agp_context *ctx, const agp_ldlt *ldlt, const double *rhs, int64_t nrhs, double *out,
                    int location);
+/* SerializableLDLT::sqrt_solve (serializable_ldlt.hpp:99-109): D^-1/2 L^-1 P rhs, D^-1/2 zero where D_i <= 0 (:58-69);
+ * out^T out = rhs^T A^-1 rhs.  rhs / out n x nrhs column-major at `location`. */
+int agp_ldlt_sqrt_solve(agp_context *ctx, const agp_ldlt *ldlt, const double *rhs, int64_t nrhs, double *out,
+                        int location);
 int agp_ldlt_vector_d(const agp_ldlt *ldlt, double *d);
 int agp_ldlt_transpositions(const agp_ldlt *ldlt, int64_t *tr);
 int agp_ldlt_download(agp_context *ctx, const agp_ldlt *ldlt, double *packed, int64_t ld);

@@ -1063,6 +1063,11 @@ static void ldlt_sqrt_solve(const double *A, int64_t n, int64_t ld, const int64_
   }
 }
 
+ORC_API void orc_ldlt_sqrt_solve(const double *A, int64_t n, int64_t ld, const int64_t *tr, double *B, int64_t nrhs,
+                                 int64_t ldb) {
+  ldlt_sqrt_solve(A, n, ld, tr, B, nrhs, ldb);
+}
+
 /* SerializableLDLT::sqrt_transpose (:111-115): out = D^1/2 (P^T L)^T, n x n column-major */
 static void ldlt_sqrt_transpose(const double *A, int64_t n, int64_t ld, const int64_t *tr, double *out) {
   double *M = malloc(sizeof(double) * (size_t)(n * n));

@@ -39,6 +39,7 @@ def lib():
         L.orc_ldlt.restype = C.c_int
         L.orc_ldlt.argtypes = [V, I64, I64, V]
         L.orc_ldlt_solve.argtypes = [V, I64, I64, V, V, I64, I64]
+        L.orc_ldlt_sqrt_solve.argtypes = [V, I64, I64, V, V, I64, I64]
         L.orc_ldlt_logdet.restype = C.c_double
         L.orc_ldlt_logdet.argtypes = [V, I64, I64]
         L.orc_llt.restype = I64
@@ -145,6 +146,15 @@ def ldlt_solve(packed, tr, B):
     B2 = np.asfortranarray(B.reshape(B.shape[0], -1, order="F"))
     n = packed.shape[0]
     lib().orc_ldlt_solve(_ptr(packed), n, n, _ptr(tr), _ptr(B2), B2.shape[1], n)
+    return B2.reshape(B.shape, order="F")
+
+
+def ldlt_sqrt_solve(packed, tr, B):
+    """SerializableLDLT::sqrt_solve (serializable_ldlt.hpp:99-109): D^-1/2 L^-1 P B."""
+    B = np.array(B, dtype=np.float64, order="F")
+    B2 = np.asfortranarray(B.reshape(B.shape[0], -1, order="F"))
+    n = packed.shape[0]
+    lib().orc_ldlt_sqrt_solve(_ptr(packed), n, n, _ptr(tr), _ptr(B2), B2.shape[1], n)
     return B2.reshape(B.shape, order="F")
 
 

@@ -32,6 +32,10 @@ def test_factor_is_bit_identical_to_oracle(ctx, n):
     X = orc.ldlt_solve(packed, tr, B)
     assert np.abs(f.solve(B) - X).max() <= 1e-12 * max(1., np.abs(X).max())
     assert abs(f.log_determinant - orc.ldlt_logdet(packed)) <= 1e-12 * n
+    # sqrt_solve (serializable_ldlt.hpp:99-109; tests/test_serializable_ldlt.cc pins S^T S = B^T A^-1 B at 1e-14)
+    S, So = f.sqrt_solve(B), orc.ldlt_sqrt_solve(packed, tr, B)
+    assert np.abs(S - So).max() <= 1e-13 * max(1., np.abs(So).max())
+    assert np.abs(S.T @ S - B.T @ X).max() <= 1e-12 * max(1., np.abs(B.T @ X).max())
 
 
 def test_semi_definite_matrix(ctx):
