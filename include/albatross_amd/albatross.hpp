@@ -949,6 +949,12 @@ class PivotedLDLT {
     detail::check(agp_ldlt_solve(context_->ctx, handle_.get(), rhs.data(), 1, out.data(), AGP_HOST), context_->ctx, "agp_ldlt_solve");
     return out;
   }
+  Matrix sqrt_solve(const Matrix &rhs) const {  // D^-1/2 L^-1 P rhs (serializable_ldlt.hpp:99-109)
+    Matrix out(rhs.rows(), rhs.cols());
+    detail::check(agp_ldlt_sqrt_solve(context_->ctx, handle_.get(), rhs.data.data(), rhs.cols(), out.data.data(), AGP_HOST),
+                  context_->ctx, "agp_ldlt_sqrt_solve");
+    return out;
+  }
   Vector vectorD() const {
     Vector d(static_cast<std::size_t>(n_));
     detail::check(agp_ldlt_vector_d(handle_.get(), d.data()), context_->ctx, "agp_ldlt_vector_d");
