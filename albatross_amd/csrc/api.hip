@@ -1271,7 +1271,7 @@ static long long marginal_chunk(long long rows) {
   const long long forced = e ? atoll(e) : 0;
   if (forced > 0) return forced;
   const long long c = (1LL << 28) / (rows > 0 ? rows : 1);
-  return c < 1024 ? 1024 : c;
+  return c < 1024 ? 1024 : (c > (1LL << 20) ? (1LL << 20) : c);  // (a million points: the Gram kernels' grids stay in range)
 }
 
 static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, const agp_features *xs,

@@ -308,11 +308,14 @@ void ldlt_permute_sym(hipStream_t s, const double *S, long long lds, const long 
 // P b and P^T b through the permutation q the transpositions compose to (position i of P b holds b[q[i]]):
 // forward: W[i, j] = R[q[i], j];  backward: R[q[i], j] = W[i, j]
 __global__ __launch_bounds__(256) void ldlt_permute_kernel(double *W, const double *R_in, double *R_out, long long ld,
-                                                           long long n, const long long *__restrict__ q, int backward) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+                                                           long long n, const long long *__restrict__ q, int backward, long long nrhs) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  if (!backward) W[i + j * ld] = R_in[q[i] + j * ld];
-  else R_out[q[i] + j * ld] = W[i + j * ld];
+  const long long qi = q[i];
+  for (long long j = blockIdx.y; j < nrhs; j += gridDim.y) {  // (the y extent of a grid ends at 65535)
+    if (!backward) W[i + j * ld] = R_in[qi + j * ld];
+    else R_out[qi + j * ld] = W[i + j * ld];
+  }
 }
 
 // unit-lower (TRANS = false) / unit-upper L^T (TRANS = true) substitution against one LB x LB diagonal
@@ -379,8 +382,8 @@ void ldlt_sqrt_solve(hipStream_t s, const double *A, long long lda, long long n,
                      const double *R, long long ldw, long long nrhs) {
   if (n <= 0 || nrhs <= 0) return;
   const unsigned cgrid = (unsigned)((nrhs + 3) / 4);
-  const dim3 pgrid((unsigned)((n + 255) / 256), (unsigned)nrhs);
-  hipLaunchKernelGGL(ldlt_permute_kernel, pgrid, dim3(256), 0, s, W, R, (double *)nullptr, ldw, n, q_dev, 0);
+  const dim3 pgrid((unsigned)((n + 255) / 256), (unsigned)(nrhs < 4096 ? nrhs : 4096));
+  hipLaunchKernelGGL(ldlt_permute_kernel, pgrid, dim3(256), 0, s, W, R, (double *)nullptr, ldw, n, q_dev, 0, nrhs);
   for (long long k = 0; k < n; k += LB) {
     const int nb = (int)((n - k < LB) ? n - k : LB);
     hipLaunchKernelGGL((ldlt_diag_solve_kernel<false>), dim3(cgrid), dim3(256), 0, s, A, lda, k, nb, W, ldw, nrhs);
@@ -397,8 +400,8 @@ void ldlt_solve(hipStream_t s, const double *A, long long lda, long long n, cons
                 double *R, long long ldw, long long nrhs) {
   if (n <= 0 || nrhs <= 0) return;
   const unsigned cgrid = (unsigned)((nrhs + 3) / 4);  // one wave per right-hand side
-  const dim3 pgrid((unsigned)((n + 255) / 256), (unsigned)nrhs);
-  hipLaunchKernelGGL(ldlt_permute_kernel, pgrid, dim3(256), 0, s, W, R, R, ldw, n, q_dev, 0);
+  const dim3 pgrid((unsigned)((n + 255) / 256), (unsigned)(nrhs < 4096 ? nrhs : 4096));
+  hipLaunchKernelGGL(ldlt_permute_kernel, pgrid, dim3(256), 0, s, W, R, R, ldw, n, q_dev, 0, nrhs);
   for (long long k = 0; k < n; k += LB) {  // L^-1
     const int nb = (int)((n - k < LB) ? n - k : LB);
     hipLaunchKernelGGL((ldlt_diag_solve_kernel<false>), dim3(cgrid), dim3(256), 0, s, A, lda, k, nb, W, ldw, nrhs);
@@ -418,7 +421,7 @@ void ldlt_solve(hipStream_t s, const double *A, long long lda, long long n, cons
     if (k > 0)  // W[0 : k] -= L[k : k + nb, 0 : k]^T W[k : k + nb]   (short K = nb, many tiles)
       launch_gemm_nt_sub(s, W, ldw, A + k, lda, true, W + k, ldw, true, k, nrhs, nb, false);
   }
-  hipLaunchKernelGGL(ldlt_permute_kernel, pgrid, dim3(256), 0, s, W, R, R, ldw, n, q_dev, 1);
+  hipLaunchKernelGGL(ldlt_permute_kernel, pgrid, dim3(256), 0, s, W, R, R, ldw, n, q_dev, 1, nrhs);
 }
 
 }  // namespace agp

@@ -209,10 +209,11 @@ __global__ __launch_bounds__(256) void qr_root_kernel(const double *__restrict__
 
 // W[i, c] = X[perm[i], c]   (P^T X)
 __global__ __launch_bounds__(256) void qr_permute_rows_kernel(const double *__restrict__ X, long long ldx, const long long *__restrict__ perm,
-                                                              long long m, double *W, long long ldw) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+                                                              long long m, double *W, long long ldw, long long nrhs) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
-  W[i + c * ldw] = X[perm[i] + c * ldx];
+  const long long src = perm[i];
+  for (long long c = blockIdx.y; c < nrhs; c += gridDim.y) W[i + c * ldw] = X[src + c * ldx];
 }
 
 // forward substitution against one QB x QB diagonal block of the lower-triangular R^T (L[i][j] = R[j][i], non-unit),
@@ -294,8 +295,8 @@ void qr_root(hipStream_t s, const double *R, long long ldr, const long long *per
 void qr_sqrt_solve(hipStream_t s, const double *R, long long ldr, const long long *perm, long long m, const double *X,
                    long long ldx, double *W, long long ldw, long long nrhs) {
   if (m <= 0 || nrhs <= 0) return;
-  hipLaunchKernelGGL(qr_permute_rows_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)nrhs), dim3(256), 0, s, X, ldx, perm, m, W,
-                     ldw);
+  hipLaunchKernelGGL(qr_permute_rows_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)(nrhs < 4096 ? nrhs : 4096)), dim3(256), 0,
+                     s, X, ldx, perm, m, W, ldw, nrhs);
   const unsigned cgrid = (unsigned)((nrhs + 3) / 4);
   for (long long k = 0; k < m; k += QB) {
     const int nb = (int)((m - k < QB) ? m - k : QB);

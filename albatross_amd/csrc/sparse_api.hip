@@ -937,7 +937,7 @@ static int sparse_predict_common(agp_context *ctx, const agp_kernel *k, const ag
   if (mode != 2) {
     const char *e = getenv("AGP_PREDICT_CHUNK");
     const long long forced = e ? atoll(e) : 0;
-    const long long c = forced > 0 ? forced : std::max<long long>(1024, (1LL << 28) / ldq);
+    const long long c = forced > 0 ? forced : std::min<long long>(1LL << 20, std::max<long long>(1024, (1LL << 28) / ldq));
     chunk = std::min(M_all, c);
   }
   const long long ldc = round_up(chunk, 2);

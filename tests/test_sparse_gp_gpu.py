@@ -497,3 +497,22 @@ def test_fit_from_prediction_device_resident_inputs(ctx):
     ofit = orc.OracleSparseFit.from_prediction(cov, z, mean, Cm)
     assert ranks[0] == ranks[1] == ofit.numerical_rank
     assert np.abs(infos[0][0] - ofit.information).max() <= 1e-6 * np.abs(ofit.information).max()
+
+
+def test_rebased_fit_predicts_many_points(ctx):
+    """A fit in pivoted form predicts 200 000 points in one call (more right-hand sides than the y extent of a grid:
+    the permutation kernels stride over them) and agrees with the oracle on a sample."""
+    x, y = toy_linear()
+    u = np.linspace(x.min(), x.max(), 8)
+    model = _toy_model(ctx, ab.FixedInducingPoints(u), 1e-3, 1e-12)
+    full = model.fit(ab.RegressionDataset(x, ab.MarginalDistribution(y)))
+    rb = ab.rebase_inducing_points(full, np.linspace(0.5, 9.5, 6))
+    xs = np.linspace(0., 10., 200000)
+    p = rb.predict(xs).marginal()
+    assert np.all(np.isfinite(p.mean)) and np.all(np.isfinite(p.covariance))
+    keys = np.floor(x / 5.).astype(np.int64)
+    orb = orc.OracleSparseFit(simple_cov(100.0), x, keys, y, None, u, 1e-12, 1e-3).rebase(np.linspace(0.5, 9.5, 6))
+    idx = np.arange(0, 200000, 9973)
+    om, ov = orb.predict(xs[idx])
+    assert np.abs(p.mean[idx] - om).max() <= 1e-7 * np.abs(om).max()
+    assert np.abs(p.covariance[idx] - ov).max() <= 5e-7 * 100.0 ** 2
