@@ -71,6 +71,21 @@ int main() {
   for (int i = 0; i < ms; ++i)
     for (int j = 0; j < ms; ++j) asym = std::fmax(asym, std::fabs(joint.covariance(i, j) - joint.covariance(j, i)));
   std::printf("joint_asymmetry,%.17g\n", asym);
+  // the same fit through a communicator (here of ONE rank: the RCCL bootstrap, the sharded entry point and the
+  // replication of the factor run; with N processes every rank would pass the same dataset)
+  {
+    const Communicator comm(1, 0, Communicator::unique_id());
+    const auto sfm = model.fit(data, comm);
+    double di = 0., dp = 0.;
+    for (int i = 0; i < n; ++i) di = std::fmax(di, std::fabs(sfm.get_fit().information[i] - fm.get_fit().information[i]));
+    const auto smarg = sfm.predict(xs).marginal();
+    for (int i = 0; i < ms; ++i)
+      dp = std::fmax(dp, std::fmax(std::fabs(smarg.mean[i] - marg.mean[i]), std::fabs(smarg.covariance[i] - marg.covariance[i])));
+    std::printf("sharded_ranks,%d\n", comm.size());
+    std::printf("sharded_information_diff,%.17g\n", di);
+    std::printf("sharded_prediction_diff,%.17g\n", dp);
+    std::printf("sharded_logdet_diff,%.17g\n", std::fabs(sfm.get_fit().log_determinant - fm.get_fit().log_determinant));
+  }
   // CovarianceRepresentation::solve round trip: K (K^-1 e_0) = e_0
   Matrix rhs(n, 1);
   rhs(0, 0) = 1.;

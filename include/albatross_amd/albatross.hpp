@@ -214,8 +214,13 @@ struct ContextHolder {
   ContextHolder &operator=(const ContextHolder &) = delete;
 };
 
+inline int &default_device() {
+  static int device = 0;
+  return device;
+}
+
 inline std::shared_ptr<ContextHolder> default_context() {
-  static std::shared_ptr<ContextHolder> c = std::make_shared<ContextHolder>(0);
+  static std::shared_ptr<ContextHolder> c = std::make_shared<ContextHolder>(default_device());
   return c;
 }
 
@@ -1317,6 +1322,46 @@ FitModel<ModelType, FeatureType> FitModel<ModelType, FeatureType>::update(const 
 }
 
 // ---------------------------------------------------------------------------
+// Several GPUs: one process per GPU, one Communicator per process (agp_comm_*: RCCL over xGMI inside the library).
+// Not in the reference (a single-process library); `model.fit(dataset, comm)` is the same fit with the Gram matrix
+// and its factorisation sharded row-block-wise over the ranks (gp.hpp:61-69, 281-294).
+// ---------------------------------------------------------------------------
+// The GPU of this process (call before anything else touches the library; default 0).  With one process per GPU:
+// set_device(local_rank).
+inline void set_device(int device) { detail::default_device() = device; }
+
+class Communicator {
+ public:
+  using UniqueId = std::array<unsigned char, AGP_COMM_ID_BYTES>;
+  // ncclGetUniqueId: rank 0 calls it and hands the bytes to every rank by any means (MPI, a file, a TCP store)
+  static UniqueId unique_id() {
+    UniqueId id{};
+    detail::check(agp_comm_unique_id(id.data()), nullptr, "agp_comm_unique_id");
+    return id;
+  }
+  // collective over all ranks (ncclCommInitRank on this process's GPU)
+  Communicator(int nranks, int rank, const UniqueId &id) : context_(detail::default_context()) {
+    agp_comm *c = nullptr;
+    detail::check(agp_comm_create(context_->ctx, nranks, rank, id.data(), &c), context_->ctx, "agp_comm_create");
+    auto ctx = context_;
+    handle_ = std::shared_ptr<agp_comm>(c, [ctx](agp_comm *p) { agp_comm_destroy(p); });
+  }
+  int size() const { return agp_comm_size(handle_.get()); }
+  int rank() const { return agp_comm_rank(handle_.get()); }
+  void barrier() const { detail::check(agp_comm_barrier(handle_.get()), context_->ctx, "agp_comm_barrier"); }
+  // in place on host doubles; every rank receives the result
+  void all_reduce_sum(Vector *v) const {
+    detail::check(agp_comm_all_reduce_host(handle_.get(), v->data(), static_cast<std::int64_t>(v->size()), 0), context_->ctx,
+                  "agp_comm_all_reduce_host");
+  }
+  agp_comm *handle() const { return handle_.get(); }
+
+ private:
+  std::shared_ptr<detail::ContextHolder> context_;
+  std::shared_ptr<agp_comm> handle_;
+};
+
+// ---------------------------------------------------------------------------
 // GaussianProcessRegression (gp.hpp:170-505)
 // ---------------------------------------------------------------------------
 template <typename CovFunc, typename MeanFunc = ZeroMean>
@@ -1416,6 +1461,45 @@ class GaussianProcessRegression {
       if (st == AGP_ERR_NOT_POSITIVE_DEFINITE) what += " (pivot " + std::to_string(pivot) + ")";
       detail::check(st, ctx->ctx, what.c_str());
     }
+    fit.handle = std::shared_ptr<agp_fit>(h, [ctx](agp_fit *p) { agp_fit_destroy(p); });
+    return FitModel<GaussianProcessRegression, FeatureType>(*this, std::move(fit));
+  }
+
+  // The same fit over the GPUs of a communicator: every rank passes the SAME dataset, the Gram matrix and its LL^T are
+  // sharded row-block-wise (agp_sharded_fit_create), then the factor is replicated (agp_sharded_fit_replicate) so that
+  // every rank holds an ordinary FitModel and predicts its own share of the test points - predictions are independent
+  // per point (gp.hpp:82-113), nothing further is exchanged.  Collective.
+  template <typename FeatureType>
+  FitModel<GaussianProcessRegression, FeatureType> fit(const RegressionDataset<FeatureType> &dataset,
+                                                       const Communicator &comm) const {
+    const std::vector<FeatureType> &features = dataset.features;
+    const MarginalDistribution &targets = dataset.targets;
+    if (features.size() != targets.size()) throw std::invalid_argument("features and targets differ in size");
+    auto ctx = detail::default_context();
+    detail::KernelHolder k(covariance_function_.program());
+    detail::Flat f = detail::flatten(covariance_function_, features);
+    Vector y = targets.mean;  // mean_function_.remove_from, gp.hpp:291-292
+    if (!std::is_same<MeanFunc, ZeroMean>::value)
+      for (std::size_t i = 0; i < y.size(); ++i) y[i] -= mean_function_._call_impl(detail::unwrap<FeatureType>::get(features[i]));
+    GPFit<FeatureType> fit;
+    fit.train_features = features;
+    fit.information.resize(features.size());
+    fit.context = ctx;
+    const double *yvar = targets.covariance.empty() ? nullptr : targets.covariance.data();
+    agp_sharded_fit *sf = nullptr;
+    int st = agp_sharded_fit_create(ctx->ctx, comm.handle(), k.k, &f.view, y.data(), yvar, &sf, fit.information.data(),
+                                    &fit.log_determinant);
+    if (st != AGP_OK) {
+      const long long pivot = sf ? static_cast<long long>(agp_sharded_fit_failed_pivot(sf)) : -1;
+      agp_sharded_fit_destroy(sf);
+      std::string what = "agp_sharded_fit_create";
+      if (st == AGP_ERR_NOT_POSITIVE_DEFINITE) what += " (pivot " + std::to_string(pivot) + ")";
+      detail::check(st, ctx->ctx, what.c_str());
+    }
+    agp_fit *h = nullptr;
+    st = agp_sharded_fit_replicate(ctx->ctx, sf, &h);
+    agp_sharded_fit_destroy(sf);
+    detail::check(st, ctx->ctx, "agp_sharded_fit_replicate");
     fit.handle = std::shared_ptr<agp_fit>(h, [ctx](agp_fit *p) { agp_fit_destroy(p); });
     return FitModel<GaussianProcessRegression, FeatureType>(*this, std::move(fit));
   }

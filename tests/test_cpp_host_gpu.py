@@ -155,6 +155,10 @@ def test_cpp_api_matches_oracle():
         assert np.abs(cvr[sel, 2] - wm).max() <= 1e-8 * np.abs(wm).max() and np.abs(cvr[sel, 3] - wv).max() <= 1e-8
     assert float(one["cv_loo_diff"]) < 1e-9
     assert float(one["from_prediction_mean_diff"]) < 1e-6 and float(one["from_prediction_cov_diff"]) < 1e-6
+    # GaussianProcessRegression::fit(dataset, Communicator): the sharded entry point + replicated factor (one rank here)
+    assert int(one["sharded_ranks"]) == 1
+    assert float(one["sharded_information_diff"]) < 1e-10 and float(one["sharded_prediction_diff"]) < 1e-10
+    assert float(one["sharded_logdet_diff"]) < 1e-9
     assert int(one["nll_batch_count"]) == 7 and float(one["nll_batch_diff"]) < 1e-8  # agp_nll_batch == agp_nll
     # sparse GP through the C++ surface: close to the direct GP (test_sparse_gp.cc:115-133 thresholds) and
     # equal to the oracle's QR-based restatement
