@@ -253,6 +253,14 @@ int main() {
       std::printf("sparse_rebase_high_diff,%.17g\n", std::sqrt(high));
       std::printf("sparse_rebase_high_rank,%lld\n", static_cast<long long>(hfit.numerical_rank()));
     }
+    {  // the sparse fit through a communicator of one rank (agp_sparse_fit_create_sharded)
+      const Communicator comm(1, 0, Communicator::unique_id());
+      const auto cfit = sparse.fit(tds, comm);
+      double d = 0.;
+      for (std::size_t i = 0; i < sfit.get_fit().information.size(); ++i)
+        d = std::fmax(d, std::fabs(cfit.get_fit().information[i] - sfit.get_fit().information[i]));
+      std::printf("sparse_sharded_information_diff,%.17g\n", d);
+    }
     const auto sm = sfit.predict(txs).marginal();
     for (int i = 0; i < 11; ++i) std::printf("sparse_pred,%d,%.17g,%.17g,%.17g\n", i, sfit.predict(txs).mean()[i], sm.mean[i], sm.covariance[i]);
   }

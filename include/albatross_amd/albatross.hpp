@@ -1899,6 +1899,17 @@ class SparseGaussianProcessRegression {
     return SparseFitModel<SparseGaussianProcessRegression, U>(*this, std::move(fit));
   }
 
+  // The same fit with the observations split BY GROUP over the ranks of a communicator: `dataset` holds THIS rank's
+  // groups (whole groups per rank; the inducing point strategy must return the same points on every rank - e.g. fixed
+  // ones); every rank receives the same fit.  Collective.
+  template <typename FeatureType>
+  auto fit(const RegressionDataset<FeatureType> &dataset, const Communicator &comm) const {
+    using U = typename std::decay<decltype(inducing_point_strategy_(covariance_function_, dataset.features)[0])>::type;
+    SparseGPFit<U> fit;
+    run(dataset, &fit, true, &comm);
+    return SparseFitModel<SparseGaussianProcessRegression, U>(*this, std::move(fit));
+  }
+
   // :524-596 (prior_log_likelihood() is outside the hot path and not included)
   template <typename FeatureType>
   double log_likelihood(const RegressionDataset<FeatureType> &dataset) const {
@@ -1972,7 +1983,7 @@ class SparseGaussianProcessRegression {
 
  private:
   template <typename FeatureType, typename U>
-  void run(const RegressionDataset<FeatureType> &dataset, SparseGPFit<U> *fit, bool keep) const {
+  void run(const RegressionDataset<FeatureType> &dataset, SparseGPFit<U> *fit, bool keep, const Communicator *comm = nullptr) const {
     const Grouped<FeatureType> grouped = group(dataset);
     const std::vector<FeatureType> &features = grouped.features;
     const std::vector<std::int64_t> &offsets = grouped.offsets;
@@ -1987,10 +1998,17 @@ class SparseGaussianProcessRegression {
     detail::Flat fu = detail::flatten(covariance_function_, fit->train_features);
     fit->information.resize(fit->train_features.size());
     agp_sparse_fit *h = nullptr;
-    detail::check(agp_sparse_fit_create(c, k.k, &fx.view, static_cast<std::int64_t>(offsets.size() - 1), offsets.data(), y.data(),
-                                        has_var ? yv.data() : nullptr, &fu.view, measurement_nugget_, inducing_nugget_,
-                                        keep ? &h : nullptr, fit->information.data(), &fit->negative_log_likelihood),
-                  c, "agp_sparse_fit_create");
+    if (comm)  // this rank's groups of one fit spread over all ranks (agp_sparse_fit_create_sharded; collective)
+      detail::check(agp_sparse_fit_create_sharded(c, comm->handle(), k.k, &fx.view, static_cast<std::int64_t>(offsets.size() - 1),
+                                                  offsets.data(), y.data(), has_var ? yv.data() : nullptr, &fu.view,
+                                                  measurement_nugget_, inducing_nugget_, keep ? &h : nullptr,
+                                                  fit->information.data(), &fit->negative_log_likelihood),
+                    c, "agp_sparse_fit_create_sharded");
+    else
+      detail::check(agp_sparse_fit_create(c, k.k, &fx.view, static_cast<std::int64_t>(offsets.size() - 1), offsets.data(), y.data(),
+                                          has_var ? yv.data() : nullptr, &fu.view, measurement_nugget_, inducing_nugget_,
+                                          keep ? &h : nullptr, fit->information.data(), &fit->negative_log_likelihood),
+                    c, "agp_sparse_fit_create");
     auto ctx = fit->context;
     if (keep) fit->handle = std::shared_ptr<agp_sparse_fit>(h, [ctx](agp_sparse_fit *p) { agp_sparse_fit_destroy(p); });
   }

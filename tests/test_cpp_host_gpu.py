@@ -167,6 +167,7 @@ def test_cpp_api_matches_oracle():
     # rebase_inducing_points through the C++ surface, thresholds of tests/test_sparse_gp.cc:374-416
     assert float(one["sparse_rebase_low_diff"]) > 10. and float(one["sparse_rebase_high_diff"]) < 1e-6
     assert int(one["sparse_rebase_high_rank"]) < 51
+    assert float(one["sparse_sharded_information_diff"]) < 1e-9  # SparseGaussianProcessRegression::fit(dataset, comm)
     tx = np.arange(10.)
     ty = np.array(golden_toy_y())
     scov = ab.SquaredExponential(100., 100.) + ab.measurement_only(ab.IndependentNoise(0.1))
