@@ -185,6 +185,22 @@ def lib_path():
 _lib = None
 
 
+_debug_lib = None
+
+
+def load_debug():
+    """libalbatross_amd_debug.so: the product objects plus the kernel-level probes `agp_debug_*` (csrc/debug_api.hip).
+    For tests/ and scripts/ only - the package itself never loads it.  Handles made by the product library (contexts)
+    are plain structs of the same build and are accepted by these entry points."""
+    global _debug_lib
+    if _debug_lib is None:
+        path = os.path.join(os.path.dirname(lib_path()), "libalbatross_amd_debug.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C albatross_amd/csrc`")
+        _debug_lib = C.CDLL(path)
+    return _debug_lib
+
+
 def load():
     """Load the HIP library.  There is no CPU fallback: a missing or
     unloadable library is an error."""

@@ -1,10 +1,14 @@
-// debug_api.hip — kernel-level entry points used only by tests/ to check the
+// debug_api.hip — kernel-level entry points used only by tests/ and scripts/ to check and time the
 // building blocks (MFMA lane map, update kernel, factorisation) in isolation.
-// Not part of include/albatross_amd.h.
+// Not part of include/albatross_amd.h and NOT linked into libalbatross_amd.so: they live in
+// libalbatross_amd_debug.so (the product objects + this file; csrc/Makefile), loaded by
+// albatross_amd._capi.load_debug().
 #include <algorithm>
 #include <cstdio>
 #include "common.h"
 #include "mfma_f64.h"
+
+#define AGP_DEBUG_API __attribute__((visibility("default")))
 
 namespace agp {
 void read_valu_clock(unsigned long long out[4], bool reset);
@@ -194,7 +198,7 @@ __global__ void exp_neg_kernel(const double *t, double *out, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = agp::exp_neg(t[i]);
 }
-extern "C" int agp_debug_exp_neg(agp_context *ctx, const double *t, int64_t n, double *out) {
+extern "C" AGP_DEBUG_API int agp_debug_exp_neg(agp_context *ctx, const double *t, int64_t n, double *out) {
   if (!ctx || !t || !out || n <= 0) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   double *d = nullptr;
@@ -232,7 +236,7 @@ static void launch_probe(hipStream_t s, int kind, int wgs, double *buf, long lon
   }
 }
 
-extern "C" int agp_debug_chain_probe(agp_context *ctx, const int *kinds, const int *wgs, int period, int reps, int spin,
+extern "C" AGP_DEBUG_API int agp_debug_chain_probe(agp_context *ctx, const int *kinds, const int *wgs, int period, int reps, int spin,
                                      int touch, int priority_stream, double *us_per_launch) {
   if (!ctx || !kinds || !wgs || period <= 0 || reps <= 0 || !us_per_launch) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -265,7 +269,7 @@ void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n,
 }
 // blocked: while the chain runs, `blocked` other streams sit at a hipStreamWaitEvent on an event that is recorded
 // behind a long one-workgroup spinner on yet another stream (a queue whose head is an unsatisfied barrier packet)
-extern "C" int agp_debug_panel_chain(agp_context *ctx, int64_t n, int64_t width, int reps, int blocked, double *us_per_phase) {
+extern "C" AGP_DEBUG_API int agp_debug_panel_chain(agp_context *ctx, int64_t n, int64_t width, int reps, int blocked, double *us_per_phase) {
   if (!ctx || n <= 0 || width <= 0 || width > n || reps <= 0 || !us_per_phase) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -334,12 +338,12 @@ extern "C" int agp_debug_panel_chain(agp_context *ctx, int64_t n, int64_t width,
 
 #ifdef AGP_POTRF_TIMING
 namespace agp { void read_potrf_timing(unsigned long long *out); }
-extern "C" int agp_debug_potrf_timing(unsigned long long *out) { read_potrf_timing(out); return 0; }
+extern "C" AGP_DEBUG_API int agp_debug_potrf_timing(unsigned long long *out) { read_potrf_timing(out); return 0; }
 #endif
 
 extern "C" {
 
-int agp_debug_mfma_tile(agp_context *ctx, const double *A, const double *B, double *D) {
+AGP_DEBUG_API int agp_debug_mfma_tile(agp_context *ctx, const double *A, const double *B, double *D) {
   if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   double *d = nullptr;
@@ -355,7 +359,7 @@ int agp_debug_mfma_tile(agp_context *ctx, const double *A, const double *B, doub
 
 // out[0] = median cycles per MFMA per wave, out[1] = effective clock (GHz),
 // out[2] = chip TFLOP/s.  waves_per_simd in {1, 2}; nacc in {1, 4, 8}.
-int agp_debug_mfma_clock(agp_context *ctx, int blocks, int waves_per_simd, int nacc, int iters, double a0,
+AGP_DEBUG_API int agp_debug_mfma_clock(agp_context *ctx, int blocks, int waves_per_simd, int nacc, int iters, double a0,
                          double b0, double *out) {
   if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -393,7 +397,7 @@ int agp_debug_mfma_clock(agp_context *ctx, int blocks, int waves_per_simd, int n
 }
 
 // out[0] = cycles per loop iteration per wave, out[1] = clock GHz, out[2] = chip TFLOP/s (MFMA + VALU flops)
-int agp_debug_mix_clock(agp_context *ctx, int waves_per_simd, int variant, int iters, double *out) {
+AGP_DEBUG_API int agp_debug_mix_clock(agp_context *ctx, int waves_per_simd, int variant, int iters, double *out) {
   if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int nblk = 256 * waves_per_simd;
@@ -443,7 +447,7 @@ int agp_debug_mix_clock(agp_context *ctx, int waves_per_simd, int variant, int i
 // C (M x N, ldc) -= A * B^T on host arrays.
 //   a_kmajor == 0: A is M x K column-major (lda >= M); else K x M column-major (lda >= K)
 //   b_kmajor likewise with N.
-int agp_debug_gemm(agp_context *ctx, double *C, int64_t ldc, const double *A, int64_t lda, int a_kmajor,
+AGP_DEBUG_API int agp_debug_gemm(agp_context *ctx, double *C, int64_t ldc, const double *A, int64_t lda, int a_kmajor,
                    const double *B, int64_t ldb, int b_kmajor, int64_t M, int64_t N, int64_t K, int tri) {
   if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -468,7 +472,7 @@ int agp_debug_gemm(agp_context *ctx, double *C, int64_t ldc, const double *A, in
 // v_fmac_f64 issue rate with VGPR (mode 0), SGPR (1) or DPP row_newbcast (2) src0.
 // out[0] = cycles per 64-FMA iteration per wave, out[1] = clock GHz, out[2] = chip TFLOP/s;
 // probe[64] (mode 2): result of one fmac with b = lane id, a = 1, row_newbcast:5.
-int agp_debug_fmac_rate(agp_context *ctx, int waves_per_simd, int mode, int iters, double *out, double *probe) {
+AGP_DEBUG_API int agp_debug_fmac_rate(agp_context *ctx, int waves_per_simd, int mode, int iters, double *out, double *probe) {
   if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int nblk = 256 * waves_per_simd;
@@ -507,7 +511,7 @@ int agp_debug_fmac_rate(agp_context *ctx, int waves_per_simd, int mode, int iter
 }
 
 // mode 0: cbsz = 0; mode 1..4: cbsz = 2, abid = mode - 1.  out: 4096 masks.
-int agp_debug_mfma44_probe(agp_context *ctx, int mode, unsigned long long *out) {
+AGP_DEBUG_API int agp_debug_mfma44_probe(agp_context *ctx, int mode, unsigned long long *out) {
   if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   unsigned long long *d = nullptr;
@@ -528,7 +532,7 @@ int agp_debug_mfma44_probe(agp_context *ctx, int mode, unsigned long long *out) 
 
 
 // out[0] = chip TFLOP/s, out[1] = ms
-int agp_debug_mfma_shape(agp_context *ctx, int mode, int nacc, int waves_per_simd, int iters, double *out) {
+AGP_DEBUG_API int agp_debug_mfma_shape(agp_context *ctx, int mode, int nacc, int waves_per_simd, int iters, double *out) {
   const double a0 = iters < 0 ? -1.0 : 1.0;  // negative iteration count: random operands
   if (iters < 0) iters = -iters;
   if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;
@@ -567,7 +571,7 @@ int agp_debug_mfma_shape(agp_context *ctx, int mode, int nacc, int waves_per_sim
 
 // Bulk trailing update C (M x M, lower tiles) -= P P^T on host data.  variant 0: MFMA kernel,
 // 2: DPP-broadcast VALU kernel.
-int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t ldc, const double *P, int64_t ldp, int64_t M,
+AGP_DEBUG_API int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t ldc, const double *P, int64_t ldp, int64_t M,
                               int64_t K, int variant) {
   if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -590,7 +594,7 @@ int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t ldc, const do
 // The same on a stream restricted to a CU mask (hipExtStreamCreateWithCUMask): mask_words 32-bit words, bit i = CU i.
 // At the same time (optional, chain_reps > 0) the panel chain of an n = M block runs on the context's main stream:
 // *chain_us = its time per 512-wide panel phase while the masked bulk updates are in flight.
-int agp_debug_time_masked_update(agp_context *ctx, int64_t M, int64_t K, int variant, int reps, const uint32_t *mask,
+AGP_DEBUG_API int agp_debug_time_masked_update(agp_context *ctx, int64_t M, int64_t K, int variant, int reps, const uint32_t *mask,
                                  int mask_words, int chain_reps, double *ms_out, double *chain_us) {
   if (!ctx || M <= 0 || K <= 0 || reps <= 0 || !ms_out) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -640,7 +644,7 @@ int agp_debug_time_masked_update(agp_context *ctx, int64_t M, int64_t K, int var
 }
 
 // Average milliseconds of `reps` bulk trailing updates of an M x M matrix (device-side random-ish data).
-int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, int64_t K, int variant, int reps, double *ms_out) {
+AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, int64_t K, int variant, int reps, double *ms_out) {
   if (!ctx || M <= 0 || K <= 0 || reps <= 0) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long ld = M + 8;
@@ -680,7 +684,7 @@ int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, int64_t K, int v
 }
 
 // In-place LL^T of the lower triangle of a host matrix; y (optional) -> L^-1 y.
-int agp_debug_factor(agp_context *ctx, double *A, int64_t n, int64_t lda, double *y, double *log_det,
+AGP_DEBUG_API int agp_debug_factor(agp_context *ctx, double *A, int64_t n, int64_t lda, double *y, double *log_det,
                      int64_t *bad_pivot) {
   if (!ctx || !A || n <= 0 || lda < n) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));

@@ -111,7 +111,8 @@ struct ShardOps {
   // otherwise sit at an unsatisfied wait for long: on this GPU a stream blocked in hipStreamWaitEvent slows the
   // dependent launches of every other stream (121 instead of 44 us per 128 columns of the panel chain, measured with
   // scripts/probe_chain.py), so the collectives and bulk queues are fed only when their inputs are ready.
-  virtual void host_wait(int ev) { (void)ev; }
+  // AGP_OK, AGP_ERR_COMM after the transport's timeout (a stalled peer or stream), AGP_ERR_HIP on a device error
+  virtual int host_wait(int ev) { (void)ev; return AGP_OK; }
   // drain every queue; AGP_OK or an error status
   virtual int sync_all() { return AGP_OK; }
   // {sum of log L_ii over this rank's diagonal blocks, 1 + global index of its first non-positive pivot or 0}
@@ -130,6 +131,8 @@ struct ShardComm {
   virtual int broadcast(ShardOps &ops, int q, double *buf, long long count, int root) = 0;
   virtual int all_gather(ShardOps &ops, int q, const double *send, double *recv, long long count) = 0;
   virtual int all_reduce(ShardOps &ops, int q, double *buf, long long count, int op) = 0;  // op 0 sum, 1 max
+  // a wait of the schedule timed out: the communicator may hold a collective no peer will join - abort, not destroy
+  virtual void mark_broken() {}
 };
 
 // scratch of the schedule, carved out of one allocation of shard_work_doubles(plan) doubles

@@ -118,6 +118,7 @@ struct RcclComm : HostReducingComm {
       else (void)api->CommDestroy(comm);
     }
   }
+  void mark_broken() override { broken = true; }
   int check(ncclResult_t r, const char *what) {
     if (r == ncclSuccess) return AGP_OK;
     if (ctx) ctx->last_error = std::string(what) + ": " + api->GetErrorString(r);
@@ -355,11 +356,20 @@ struct HipShardOps : ShardOps {
   void fill_zero(int q, double *p, long long count) override {
     if (count > 0) (void)hipMemsetAsync(p, 0, sizeof(double) * (size_t)count, sq[q]);
   }
-  void host_wait(int e) override {
+  int host_wait(int e) override {
     const auto t0 = std::chrono::steady_clock::now();
     long long spins = 0;
-    while (hipEventQuery(ev[e]) == hipErrorNotReady) {
-      if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) break;
+    while (true) {
+      const hipError_t r = hipEventQuery(ev[e]);
+      if (r == hipSuccess) return AGP_OK;
+      if (r != hipErrorNotReady) {
+        ctx->last_error = std::string("hipEventQuery: ") + hipGetErrorString(r);
+        return AGP_ERR_HIP;
+      }
+      if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+        ctx->last_error = "timeout waiting for an event of the sharded schedule (a peer or a stream stalled)";
+        return AGP_ERR_COMM;
+      }
     }
   }
   void record(int e, int q) override { (void)hipEventRecord(ev[e], sq[q]); }
@@ -425,8 +435,14 @@ struct MainStreamOps : ShardOps {
 int comm_all_reduce_device(agp_context *ctx, agp_comm *comm, double *dev, long long count, int op) {
   if (!comm || !comm->impl || comm->impl->world == 1) return AGP_OK;
   MainStreamOps ops(ctx);
-  return comm->impl->all_reduce(ops, QP, dev, count, op);
+  const int st = comm->impl->all_reduce(ops, QP, dev, count, op);
+  if (st != AGP_OK) return st;
+  // the caller goes on with calls that synchronise the stream without a deadline (factorisations, stage timers): find a
+  // collective that a dead peer never joins HERE, where it becomes AGP_ERR_COMM
+  return wait_stream(ctx, ctx->stream, comm_timeout_seconds());
 }
+
+int comm_wait_stream(agp_context *ctx, hipStream_t s) { return wait_stream(ctx, s, comm_timeout_seconds()); }
 }  // namespace agp
 
 struct agp_sharded_fit {
@@ -774,7 +790,11 @@ int agp_sharded_fit_replicate(agp_context *c, agp_sharded_fit *f, agp_fit **out)
     if (st == AGP_OK) {
       hipLaunchKernelGGL(shard_unstack_kernel, dim3((unsigned)((n + 255) / 256), 64), dim3(256), 0, s, fit->A, (long long)fit->lda, stacks,
                          f->ld, per_rank, n, B, world);
-      for (long long i = 0; i < plan.nb; ++i) {
+      if (!plan.multi()) {
+        // one rank, single-GPU factorisation (factor_lower): one image per 128-block, contiguous whatever the row-block size
+        (void)hipMemcpyAsync(fit->invd, imgs, sizeof(double) * (size_t)(nblk * SHARD_IMG), hipMemcpyDeviceToDevice, s);
+      }
+      for (long long i = 0; plan.multi() && i < plan.nb; ++i) {
         const long long sub = (plan.width(i) + NB - 1) / NB;  // 128-blocks of this row block
         (void)hipMemcpyAsync(fit->invd + i * (B / NB) * SHARD_IMG,
                              imgs + (long long)plan.owner(i) * img_per_rank + plan.local_index(i) * 4 * SHARD_IMG,

@@ -132,7 +132,7 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
     const int o = plan.owner(k), slot = (int)(k & 1);
     const long long w = plan.width(k);
     if (multi) {
-      if (o == me) ops.host_wait(EV_MSG);
+      if (o == me && (st = ops.host_wait(EV_MSG)) != AGP_OK) break;
       st = comm->broadcast(ops, QC, buf.msg[slot], msg_count, o);
       if (st != AGP_OK) break;
       ops.record(EV_BCAST, QC);
@@ -160,8 +160,8 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
         ops.gemm(QP, Aat(li1 * B, (k + 1) * B), ld, X1, ld, X1, ld, w1, w1, w, true, 0);
         factor_and_pack(k + 1);
       }
-      ops.host_wait(EV_PACK);
-      ops.host_wait(ev_u2_cur);  // U2(k - 2) read pall[slot]
+      if ((st = ops.host_wait(EV_PACK)) != AGP_OK) break;
+      if ((st = ops.host_wait(ev_u2_cur)) != AGP_OK) break;  // U2(k - 2) read pall[slot]
       st = comm->all_gather(ops, QC, buf.send, buf.recv, cnt_rows * w);
       if (st != AGP_OK) break;
       ops.gather_panel(QC, buf.pall[slot], buf.ldp, buf.recv, cnt_rows, w, plan, k);
@@ -177,7 +177,7 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
       if (rows2 > 0) {
         ops.gemm(QP, Aat(li2 * B, (k + 1) * B), ld, Aat(li2 * B, k * B), ld, Q, ldq, rows2, w1, w, false, 0);
         // U2: the columns from (k + 2) B to the end of every row block's own diagonal block (a staircase)
-        ops.host_wait(EV_GATHER);
+        if ((st = ops.host_wait(EV_GATHER)) != AGP_OK) break;
         ops.update_staircase(QB, A, ld, Q + B, ldq, plan, k);
       }
       ops.record(ev_u2_cur, QB);
@@ -199,7 +199,11 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
       factor_and_pack(k + 1);
     }
   }
-  if (st != AGP_OK) { (void)ops.sync_all(); return st; }
+  if (st != AGP_OK) {
+    if (comm && st == AGP_ERR_COMM) comm->mark_broken();
+    (void)ops.sync_all();
+    return st;
+  }
 
   // ---- information = L^-T z, row block by row block from the bottom (gp.hpp:68) --------------------------------
   // t[c] collects sum_r L[r][c] x[r] over the rows this rank owns; the owner of block i needs the sum over all

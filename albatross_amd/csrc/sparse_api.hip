@@ -50,6 +50,7 @@ struct agp_sparse_fit {
 
 namespace agp {
 int comm_all_reduce_device(agp_context *ctx, agp_comm *comm, double *dev, long long count, int op);  // shard_hip.hip
+int comm_wait_stream(agp_context *ctx, hipStream_t s);                                               // shard_hip.hip
 }
 
 namespace {
@@ -622,48 +623,107 @@ static int sparse_fit_create_pivoted(agp_context *ctx, const agp_kernel *k, cons
   return AGP_OK;
 }
 
+// One status for all ranks: the largest code any rank holds (AGP_OK = 0).  Every exit of the sharded fit that only ONE
+// rank may take - bad arguments, a non-positive-definite or NaN block of its own groups, an allocation failure - goes
+// through here BEFORE the next device collective, so that no rank is left waiting inside an all-reduce for a peer that
+// has already returned.
+static int agree_status(agp_comm *comm, int st) {
+  if (!comm) return st;
+  double v = (double)st;
+  if (agp_comm_all_reduce_host(comm, &v, 1, 1) != AGP_OK) return AGP_ERR_COMM;
+  return (int)v;
+}
+
+// 52-bit checksum of a feature set's coordinates (host or device), exact in a double
+static int features_checksum(agp_context *ctx, const agp_features *u, double *out) {
+  const size_t cnt = (size_t)u->n * (size_t)u->dim;
+  std::vector<double> host;
+  const double *p = u->coords;
+  if (u->location != AGP_HOST) {
+    host.resize(cnt);
+    SPX_HIP(hipMemcpy(host.data(), u->coords, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    p = host.data();
+  }
+  unsigned long long h = 1469598103934665603ull;
+  for (size_t i = 0; i < cnt; ++i) {
+    unsigned long long b;
+    std::memcpy(&b, p + i, sizeof(b));
+    h = (h ^ b) * 1099511628211ull;
+    h ^= h >> 29;
+  }
+  *out = (double)(h & ((1ull << 52) - 1));
+  return AGP_OK;
+}
+
 static int sparse_fit_create_fast(agp_context *ctx, agp_comm *comm, const agp_kernel *k, const agp_features *x, int64_t n_groups,
                                   const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
                                   double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
                                   double *information, double *nll_out) {
-  if (!ctx || !k || !x || !u || !y || !offsets || n_groups <= 0) return AGP_ERR_INVALID_ARGUMENT;
   if (out) *out = nullptr;
-  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int st = validate_features(x);
+  // ---- argument checks: rank-local, agreed before anything else when the fit is sharded ----
+  int st = AGP_OK;
+  if (!ctx || !k || !x || !u || !y || !offsets || n_groups <= 0) st = AGP_ERR_INVALID_ARGUMENT;
+  if (st == AGP_OK && hipSetDevice(ctx->device) != hipSuccess) st = AGP_ERR_HIP;
+  if (st == AGP_OK) st = validate_features(x);
   if (st == AGP_OK) st = validate_features(u);
-  if (st != AGP_OK) return st;
+  if (st == AGP_OK && (x->n <= 0 || u->n <= 0 || u->dim != x->dim || offsets[0] != 0 || offsets[n_groups] != x->n))
+    st = AGP_ERR_INVALID_ARGUMENT;
+  if (comm) {
+    // every rank must pass the SAME inducing points (the m x m sums below add matrices built against them): compare a
+    // checksum of u over the ranks - max and min in one all-reduce - together with the status
+    double cks = 0.;
+    if (st == AGP_OK && ctx) st = features_checksum(ctx, u, &cks);
+    double v[3] = {(double)st, cks, -cks};
+    if (agp_comm_all_reduce_host(comm, v, 3, 1) != AGP_OK) return AGP_ERR_COMM;
+    if (v[0] != 0.) return st != AGP_OK ? st : (int)v[0];
+    if (v[1] != -v[2]) {
+      ctx->last_error = "agp_sparse_fit_create_sharded: the inducing points differ between the ranks";
+      return AGP_ERR_INVALID_ARGUMENT;
+    }
+  } else if (st != AGP_OK) {
+    return st;
+  }
   const long long n = x->n, m = u->n;
-  if (n <= 0 || m <= 0 || u->dim != x->dim || offsets[0] != 0 || offsets[n_groups] != n) return AGP_ERR_INVALID_ARGUMENT;
-  const DevProgram *dprog = nullptr;
-  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
   hipStream_t s = ctx->stream;
   StageTimer stage(s);
   std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
-  if (!f) return AGP_ERR_INVALID_ARGUMENT;
-  f->ctx = ctx; f->m = m; f->inducing_nugget = inducing_nugget;
   SparseScratch w;
-  f->u = std::shared_ptr<DeviceFeatures>(new DeviceFeatures(), [](DeviceFeatures *d) { d->release(); delete d; });
-  if ((st = to_device(ctx, u, true, f->u.get())) != AGP_OK) return st;
-
-  // K_uu + inducing_nugget I  (:674-679) -> LL^T ; T = L_u with explicit zeros above the diagonal
   const long long ldm = factor_ld(m);
-  if ((st = factor_kuu(ctx, k, dprog, f->u->v, inducing_nugget, &f->kuu, &w.T)) != AGP_OK) return st;
-  SPX_HIP(hipMemcpy2DAsync(w.T, sizeof(double) * (size_t)ldm, f->kuu->A, sizeof(double) * (size_t)f->kuu->lda,
-                           sizeof(double) * (size_t)m, (size_t)m, hipMemcpyDeviceToDevice, s));
-  launch_zero_upper(s, w.T, ldm, m);  // K_uu^T/2 = L_u^T (sqrt_transpose, :349): its transpose L_u
-  stage("K_uu + factor");
-
   double *yw = nullptr, log_det_a = 0.;
-  if ((st = sparse_observations(ctx, k, dprog, x, n_groups, offsets, y, y_var, measurement_nugget, f->u->v, f->kuu.get(), w,
-                                &yw, &log_det_a, stage)) != AGP_OK)
-    return st;
+  // ---- everything up to the first device collective: K_uu (replicated arithmetic) and this rank's own groups ----
+  auto local_part = [&]() -> int {
+    const DevProgram *dprog = nullptr;
+    int e = device_program(ctx, k, &dprog);
+    if (e != AGP_OK) return e;
+    if (!f) return AGP_ERR_INVALID_ARGUMENT;
+    f->ctx = ctx; f->m = m; f->inducing_nugget = inducing_nugget;
+    f->u = std::shared_ptr<DeviceFeatures>(new DeviceFeatures(), [](DeviceFeatures *d) { d->release(); delete d; });
+    if ((e = to_device(ctx, u, true, f->u.get())) != AGP_OK) return e;
+    // K_uu + inducing_nugget I  (:674-679) -> LL^T ; T = L_u with explicit zeros above the diagonal
+    if ((e = factor_kuu(ctx, k, dprog, f->u->v, inducing_nugget, &f->kuu, &w.T)) != AGP_OK) return e;
+    SPX_HIP(hipMemcpy2DAsync(w.T, sizeof(double) * (size_t)ldm, f->kuu->A, sizeof(double) * (size_t)f->kuu->lda,
+                             sizeof(double) * (size_t)m, (size_t)m, hipMemcpyDeviceToDevice, s));
+    launch_zero_upper(s, w.T, ldm, m);  // K_uu^T/2 = L_u^T (sqrt_transpose, :349): its transpose L_u
+    stage("K_uu + factor");
+    return sparse_observations(ctx, k, dprog, x, n_groups, offsets, y, y_var, measurement_nugget, f->u->v, f->kuu.get(), w, &yw,
+                               &log_det_a, stage);
+  };
+  st = local_part();
+  {
+    const int agreed = agree_status(comm, st);
+    if (agreed != AGP_OK) return st != AGP_OK ? st : agreed;  // a peer failed: this rank reports the peer's code
+  }
   if ((st = sparse_sigma(ctx, f.get(), w.T, ldm, w.Kuf, round_up(m, 2), n, yw, nullptr, w, ctx->d_scalars + 2, stage, comm)) != AGP_OK)
     return st;
   launch_dot(s, yw, yw, n, ctx->d_scalars + 1);  // y^T A^-1 y = y_w^T y_w  (:583-592); after the factor calls, which reset the scalars
   // negative log likelihood (:524-596): log|K| = log|A| + log|B^T B| - log|K_uu'|
   SPX_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
   if (information) SPX_HIP(hipMemcpyAsync(information, f->v, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
-  SPX_HIP(hipStreamSynchronize(s));
+  if (comm) {
+    if ((st = comm_wait_stream(ctx, s)) != AGP_OK) return st;  // bounded: a dead peer is AGP_ERR_COMM, not a hang
+  } else {
+    SPX_HIP(hipStreamSynchronize(s));
+  }
   SPX_HIP(hipGetLastError());
   // sums over the observations of all ranks: log|A|, y^T A^-1 y, n
   double sums[3] = {log_det_a, ctx->h_scalars[1], (double)n};

@@ -60,6 +60,7 @@ class Communicator:
         self._lib = capi.load()
         self._h = handle
         self._keep = keepalive
+        self._ctx = None
 
     # ---- constructors ----
     @staticmethod
@@ -75,7 +76,9 @@ class Communicator:
         h = C.c_void_p()
         idbuf = C.create_string_buffer(bytes(unique_id), capi.COMM_ID_BYTES)
         ctx._check(ctx._lib.agp_comm_create(ctx._h, world, rank, idbuf, C.byref(h)), "agp_comm_create")
-        return cls(h)
+        c = cls(h)
+        c._ctx = ctx  # the RCCL transport dereferences its context until it is destroyed: keep it alive, and see close()
+        return c
 
     @classmethod
     def callbacks(cls, world, rank, broadcast, all_gather, all_reduce):
@@ -160,7 +163,9 @@ class Communicator:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.agp_comm_destroy(self._h)
+            ctx = getattr(self, "_ctx", None)
+            if ctx is None or ctx._h:  # a context that is already closed took its streams with it: nothing left to destroy safely
+                self._lib.agp_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):

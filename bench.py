@@ -159,7 +159,154 @@ def cpu_baseline(seconds_budget=30.0):
     return out
 
 
-def main():
+def synthetic_stations(n, seed):
+    """stations lat ~ U[25, 50] deg, lon ~ U[-125, -65] deg, h ~ U[0, 3000] m -> ECEF
+    (WGS-84, km); temperature = 60 - 0.0065 h 1.8 + a smooth field + N(0, 1.75).  Returns (ecef km, elevation m,
+    temperature); the real file of the example has only 2133 rows (examples/temperature_example/gsod.csv)."""
+    rng = np.random.default_rng(seed)
+    lat = np.deg2rad(rng.uniform(25., 50., n))
+    lon = np.deg2rad(rng.uniform(-125., -65., n))
+    h = rng.uniform(0., 3000., n)
+    a, f = 6378137.0, 1. / 298.257223563
+    e2 = f * (2. - f)
+    nu = a / np.sqrt(1. - e2 * np.sin(lat) ** 2)
+    ecef = np.stack([(nu + h) * np.cos(lat) * np.cos(lon), (nu + h) * np.cos(lat) * np.sin(lon),
+                     (nu * (1. - e2) + h) * np.sin(lat)], axis=1) / 1000.
+    smooth = 8. * np.sin(3. * lat) * np.cos(2. * lon) + 5. * np.cos(5. * lon)
+    temp = 60. - 0.0065 * h * 1.8 + smooth + rng.normal(0., 1.75, n)
+    return ecef, h, temp
+
+
+def temperature_covariance(ab):
+    """The tuned covariance of examples/temperature_example/temperature_example.cc:34-85; the elevation scaling
+    1 + factor * max(0, center - h) (temperature_example_utils.h:78-84) is supplied as an explicit scale column."""
+    class Elevation(ab.ScalingFunction):
+        def _call_impl(self, c):
+            raise AssertionError("scale columns are supplied explicitly")
+
+    cov = ab.ScalingTerm(Elevation()) * ab.Constant(5.07288) + ab.IndependentNoise(1.75027) \
+        + ab.Exponential(1.10298, 1.0, ab.AngularDistance()) * ab.SquaredExponential(5835.56, 13.913, ab.RadialDistance())
+    scale = lambda h: 1. + 0.000153439 * np.maximum(0., 4446.5 - h)  # noqa: E731
+    return cov, scale
+
+
+def sampled_residual(x, y, information, ell=1.0, sigma=1.0, noise=0.1, rows=64):
+    """Self-check carried by every bench line: max_r |(K a)_r - y_r| / max|y| over `rows` sampled rows of
+    K = SE(ell, sigma)(x, x) + noise^2 I, evaluated with numpy from the features (independent of the library and
+    of the oracle).  cond(K) ~ 1.6e6 for the bench problem, so a correct fp64 fit lands around 1e-11."""
+    n = x.shape[0]
+    idx = np.unique(np.linspace(0, n - 1, rows).astype(np.int64))
+    d2 = ((x[idx, None, :] - x[None, :, :]) ** 2).sum(axis=2)
+    k = sigma * sigma * np.exp(-d2 / (ell * ell))
+    r = k @ information + noise * noise * information[idx] - y[idx]
+    return float(np.abs(r).max() / np.abs(y).max())
+
+
+def other_configs(ab, ctx):
+    """BASELINE.json configs 2, 4 and 5 on this GPU, each with its algorithmic work and fraction of peak - measured after
+    the headline, outside `value`.  Host-resident inputs through the Python mirror (the uploads are << the fits)."""
+    out = {}
+
+    def best(f, reps):
+        f()
+        t = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f()
+            t = min(t, time.perf_counter() - t0)
+        return t
+
+    # ---- config 2: 3-D Matern-5/2 + noise, N = 4096 fp64 dense fit + predict (M = 4096) ----
+    try:
+        n = m = 4096
+        x, y = make_dataset(n, 42)
+        xs, _ = make_dataset(m, 43)
+        model = ab.gp_from_covariance(ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1), context=ctx)
+        ds = ab.RegressionDataset(x, y)
+        t_fit = best(lambda: model.fit(ds), 7)
+        fm = model.fit(ds)
+        p = fm.predict(xs)
+        t_mean, t_marg, t_joint = best(p.mean, 7), best(p.marginal, 5), best(p.joint, 3)
+        fit_flop, marg_flop, joint_flop = n ** 3 / 3., float(n) * n * m, float(n) * n * m + float(n) * m * m
+        out["config2"] = {
+            "workload": "3-D Matern-5/2(2,1)+IndependentNoise(0.1), N=4096 fp64, features mt19937(42), predict at M=4096 mt19937(43)",
+            "fit_ms": 1e3 * t_fit, "fit_flop": fit_flop, "fit_frac_of_mfma_peak": fit_flop / t_fit / 1e12 / MFMA_F64_PEAK_TFLOPS,
+            "predict_mean_ms": 1e3 * t_mean, "predict_mean_pts_per_sec": m / t_mean,
+            "predict_marginal_ms": 1e3 * t_marg, "predict_marginal_flop": marg_flop,
+            "predict_marginal_frac_of_mfma_peak": marg_flop / t_marg / 1e12 / MFMA_F64_PEAK_TFLOPS,
+            "predict_joint_ms": 1e3 * t_joint, "predict_joint_flop": joint_flop,
+            "predict_joint_frac_of_mfma_peak": joint_flop / t_joint / 1e12 / MFMA_F64_PEAK_TFLOPS,
+            "note": "joint includes the 134 MB download of the M x M covariance"}
+        del fm, p
+    except Exception as exc:  # noqa: BLE001
+        out["config2"] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # ---- config 4: temperature-example kernel, N = 32768, fp64 vs mixed precision ----
+    try:
+        n = 32768
+        ecef, h, temp = synthetic_stations(n, 11)
+        cov, scale = temperature_covariance(ab)
+        ds = ab.RegressionDataset(ab.FeatureSet(ecef, [scale(h)]), temp - temp.mean())
+        res = {}
+        for prec in ("fp64", "mixed"):
+            model = ab.gp_from_covariance(cov, context=ctx)
+            model.precision = prec
+            t = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter()
+                fm = model.fit(ds)
+                t = min(t, time.perf_counter() - t0)
+                fit = fm.get_fit()
+                info, ld = fit.information.copy(), fit.log_determinant
+                del fm, fit
+            res[prec] = (t, info, ld, model.refinement_)
+        flop = n ** 3 / 3.
+        t64, a64, ld64, _ = res["fp64"]
+        tmx, amx, ldm, (its, rel_res) = res["mixed"]
+        out["config4"] = {
+            "workload": "temperature-example covariance (ScalingTerm*Constant + IndependentNoise + Exponential<Angular>*SE<Radial>, "
+                        "tuned values) on N=32768 synthetic stations",
+            "fit_flop": flop, "fp64_fit_ms": 1e3 * t64, "fp64_frac_of_mfma_f64_peak": flop / t64 / 1e12 / MFMA_F64_PEAK_TFLOPS,
+            "mixed_fit_ms": 1e3 * tmx, "mixed_speedup": t64 / tmx, "mixed_fp64_equivalent_tflops": flop / tmx / 1e12,
+            "cg_steps": int(its), "cg_relative_residual": float(rel_res),
+            "information_rel_err_vs_fp64": float(np.abs(amx - a64).max() / np.abs(a64).max()),
+            "log_det_rel_err_vs_fp64": float(abs(ldm - ld64) / abs(ld64))}
+    except Exception as exc:  # noqa: BLE001
+        out["config4"] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # ---- config 5: sparse GP (PITC), N = 262144, 2048 inducing points, independent groups of 512 ----
+    try:
+        n, m, gs = 262144, 2048, 512
+        rng = np.random.default_rng(n)
+        x = np.sort(rng.uniform(0., n / 16., n))
+        y = np.sin(x) + 0.1 * np.cos(10. * x) + 0.1 * rng.standard_normal(n)
+        cov = ab.SquaredExponential(1.0, 1.0) + ab.measurement_only(ab.IndependentNoise(0.1))  # benchmarks/bench_utils.h:61-65
+        u = np.linspace(x.min(), x.max(), m)
+
+        def grouper(f):
+            return np.searchsorted(x, np.asarray(f, dtype=np.float64).reshape(-1)) // gs
+        grouper.vectorized = True
+        model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "pitc", context=ctx)
+        model.set_param("inducing_nugget", 1e-6)
+        ds = ab.RegressionDataset(x, y)
+        fm = model.fit(ds)
+        t_fit = best(lambda: model.fit(ds), 2)
+        xs = np.linspace(x.min(), x.max(), 4096)
+        t_pred = best(lambda: fm.predict(xs).marginal(), 2)
+        rms = float(np.sqrt(np.mean((fm.predict(x[::64]).mean() - np.sin(x[::64]) - 0.1 * np.cos(10. * x[::64])) ** 2)))
+        flop = 3. * m * m * n + float(n) * gs * m + n * float(gs) ** 2 / 3.
+        out["config5"] = {
+            "workload": "sparse GP (PITC), N=262144 1-D, 2048 inducing points, groups of 512, bench covariance",
+            "fit_ms": 1e3 * t_fit, "fit_flop": flop, "fit_frac_of_mfma_peak": flop / t_fit / 1e12 / MFMA_F64_PEAK_TFLOPS,
+            "predict_marginal_m4096_ms": 1e3 * t_pred, "rms_error_vs_truth": rms,
+            "flop_formula": "3 m^2 n (P, W W^T, Q1) + n s m (A, W) + n s^2 / 3 (block LL^T)"}
+        del fm
+    except Exception as exc:  # noqa: BLE001
+        out["config5"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -168,22 +315,82 @@ def main():
                     help="training points (default 16384 = BASELINE config 3; 32768 / 65536: sizes where sharding one fit pays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-predict", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 2, 4, 5)")
     ap.add_argument("--force-sharded", action="store_true", help="N = 1: time the sharded entry point (one rank, no transport)")
     ap.add_argument("--multi-gpu", choices=["sharded", "replicas"], default="sharded",
                     help="N > 1: 'sharded' (default) = `value` is ONE fit row-block-sharded over all ranks (RCCL broadcast + "
                          "all-gather per block column, strong scaling); 'replicas' = one independent fit per rank, no "
                          "data-path collective (weak scaling).  The other mode is measured too and reported in an auxiliary block.")
-    args = ap.parse_args()
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="N > 1: fail instead of falling back to replicas when the sharded fit cannot run or fails its self-check")
+    ap.add_argument("--fallback-note", default="", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run) before
+    anything here has touched the GPU, relay rank 0's JSON line and the children's exit code.  No re-exec."""
+    import signal
+    import socket
+    import subprocess
+    import torch  # device_count() does not initialise the GPU
+    visible = torch.cuda.device_count()
+    if visible < args.gpus and os.environ.get("BENCH_SINGLE_DEVICE") != "1":
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but {visible} device(s) visible (BENCH_SINGLE_DEVICE=1 runs every rank on "
+                         "GPU 0 with gloo-staged collectives: a test mode, not a measurement)\n")
+        return 2
+    limit = float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "1500"))
+
+    def attempt(extra):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv) + extra
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+        try:
+            stdout, _ = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)  # the process group this call started, nothing else
+            except ProcessLookupError:
+                pass
+            stdout, _ = p.communicate()
+            sys.stderr.write(f"bench.py: the {args.gpus}-rank run did not finish within {limit:.0f} s; killed\n")
+            return 124, None
+        line = None
+        for ln in (stdout or "").splitlines():
+            if ln.startswith('{"metric"'):
+                line = ln
+        return p.returncode, line
+
+    rc, line = attempt([])
+    if rc == 0 and line:
+        print(line, flush=True)
+        return 0
+    if args.multi_gpu == "sharded" and not args.no_fallback:
+        note = f"the sharded {args.gpus}-rank run exited with code {rc}" + ("" if line else " and printed no result line")
+        sys.stderr.write(f"bench.py: {note}; measuring {args.gpus} independent fits (replicas) instead\n")
+        rc2, line2 = attempt(["--multi-gpu", "replicas", "--fallback-note", note])
+        if rc2 == 0 and line2:
+            print(line2, flush=True)
+            return 0
+        return rc2 or 1
+    if line:
+        print(line, flush=True)
+    return rc or 1
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        # one process per GPU: N > 1 is launched as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`;
-        # nothing has touched the GPU yet, the launcher can simply be re-run
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks with "
-                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
-                         f"bench.py --gpus {args.gpus} ...`")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    os.environ.setdefault("AGP_COMM_TIMEOUT_S", "60")  # a dead peer / deadlocked collective becomes an error within a minute
 
     import datetime
     import torch
@@ -199,14 +406,23 @@ def main():
     torch.cuda.set_device(local_rank)
     torch.cuda.init()  # torch's HIP runtime first, then the library's
     if world > 1:
-        # torch.distributed is the CONTROL plane only (rendezvous, exchange of the 128-byte RCCL id): gloo, finite timeout.
-        # The data path - and the barrier / max-over-ranks of the timing - run on the library's own RCCL communicator.
+        # torch.distributed is the CONTROL plane only (rendezvous, exchange of the 128-byte RCCL id, agreeing on a
+        # fallback): gloo, finite timeout.  The data path - and the barrier / max-over-ranks of the timing - run on the
+        # library's own RCCL communicator.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
 
     import albatross_amd as ab
     from albatross_amd import _capi as capi
     from albatross_amd.distributed import Communicator, ShardedGaussianProcessFit
+
+    def all_agree(ok):
+        """True iff `ok` on every rank (gloo)"""
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.item() > 0
 
     n = args.n
     ctx = ab.Context(local_rank)
@@ -215,56 +431,94 @@ def main():
     kh = ctx.kernel(cov)
     comm = None
     transport = "none"
-    if world > 1:
-        transport = "callbacks" if single_device else "rccl"
-        if transport == "rccl":
-            # RCCL bootstrap can fail on a box whose network set-up it does not like; every rank must then take the same
-            # exit.  The fallback is the SAME sharded fit with its collectives staged over gloo (slow, and said so in
-            # the JSON line) - a measured line beats none.
+    fallback_note = args.fallback_note
+    want_sharded = (world > 1 and args.multi_gpu == "sharded") or (world == 1 and args.force_sharded)
+    if world > 1 and want_sharded:
+        if single_device:
+            transport = "callbacks (BENCH_SINGLE_DEVICE test mode: collectives staged through host memory over gloo - not RCCL)"
+            comm = Communicator.from_torch(ctx, transport="callbacks")
+        else:
             err = ""
             try:
                 comm = Communicator.from_torch(ctx, transport="rccl")
-            except Exception as exc:  # noqa: BLE001
+                transport = "rccl"
+            except Exception as exc:  # noqa: BLE001 - every rank must take the same exit
                 err = f"{type(exc).__name__}: {exc}"
-            flag = torch.tensor([1.0 if comm is None else 0.0])
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if flag.item() > 0:
+            if not all_agree(comm is not None):
                 if comm is not None:
-                    comm.close()
-                sys.stderr.write(f"bench.py rank {rank}: RCCL communicator not available ({err or 'failed on another rank'}); "
-                                 "falling back to collectives staged over gloo\n")
-                transport = "callbacks (RCCL communicator could not be created: collectives staged through host memory over gloo)"
-                comm = Communicator.from_torch(ctx, transport="callbacks")
-        else:
-            comm = Communicator.from_torch(ctx, transport="callbacks")
-        assert comm.world == world and comm.rank == rank
+                    comm._h = None  # peers may never have joined: do not run the communicator's destructor
+                comm = None
+                fallback_note = f"no RCCL communicator ({err or 'creation failed on another rank'})"
+        if comm is not None:
+            assert comm.world == world and comm.rank == rank
 
-    sharded = (world > 1 and args.multi_gpu == "sharded") or (world == 1 and args.force_sharded)
+    def gloo_barrier():
+        if world > 1:
+            dist.barrier()
+
+    def make_feats(ptr, count):
+        f = capi.Features()
+        f.n, f.dim, f.n_scale_columns = count, DIM, 0
+        f.coords = ptr
+        f.eq_id = None
+        f.scales = None
+        f.is_measurement = 0
+        f.location = capi.DEVICE
+        return f
+
     # inputs resident in HBM before the timed region.  Sharded: every rank holds the SAME dataset (one fit over all
     # ranks); replicas: one dataset per rank.
-    x_h, y_h = make_dataset(n, 44 if sharded or world == 1 else 44 + rank)
-    x_d = torch.from_numpy(x_h).to(f"cuda:{local_rank}")
-    y_d = torch.from_numpy(y_h).to(f"cuda:{local_rank}")
-    torch.cuda.synchronize()
-    feats = capi.Features()
-    feats.n, feats.dim, feats.n_scale_columns = n, DIM, 0
-    feats.coords = x_d.data_ptr()
-    feats.eq_id = None
-    feats.scales = None
-    feats.is_measurement = 0
-    feats.location = capi.DEVICE
-    sfit = ShardedGaussianProcessFit(ctx, cov, comm) if (sharded or world > 1) else None
+    def load(seed):
+        xh, yh = make_dataset(n, seed)
+        return xh, yh, torch.from_numpy(xh).to(f"cuda:{local_rank}"), torch.from_numpy(yh).to(f"cuda:{local_rank}")
 
-    def replica_step():
+    sharded = want_sharded and (world == 1 or comm is not None)
+    x_h, y_h, x_d, y_d = load(44 if sharded or world == 1 else 44 + rank)
+    torch.cuda.synchronize()
+    feats = make_feats(x_d.data_ptr(), n)
+    sfit = ShardedGaussianProcessFit(ctx, cov, comm) if sharded else None
+
+    def replica_step(want_information=False):
         h = C.c_void_p()
-        st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+        info = np.empty(n) if want_information else None
+        st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h),
+                                None if info is None else C.c_void_p(info.ctypes.data), None)
         if st != capi.AGP_OK:
             raise RuntimeError(f"agp_fit_create failed: {lib.agp_status_string(st).decode()} "
                                f"{lib.agp_last_error(ctx._h).decode()}")
         lib.agp_fit_destroy(h)
+        return info
 
-    def sharded_step():
-        sfit.fit(None, None, features_struct=feats, device_targets=y_d.data_ptr())
+    def sharded_step(want_information=False):
+        res = sfit.fit(None, None, features_struct=feats, device_targets=y_d.data_ptr())
+        return res.information if want_information else None
+
+    # ---- self-check (and, for N > 1, the decision whether the sharded path is usable at all) ----
+    self_check = None
+    if sharded:
+        ok, why = True, ""
+        try:
+            resid = sampled_residual(x_h, y_h, sharded_step(True))
+            self_check = {"rows": 64, "max_rel_residual": resid, "ok": bool(resid < 1e-8),
+                          "what": "max_r |(K a)_r - y_r| / max|y| of a sharded fit before the timed region, numpy from the features"}
+            if not self_check["ok"]:
+                ok, why = False, f"sharded fit failed its self-check (residual {resid:.2e})"
+        except Exception as exc:  # noqa: BLE001
+            ok, why = False, f"{type(exc).__name__}: {exc}"
+        if world > 1 and not all_agree(ok):
+            sys.stderr.write(f"bench.py rank {rank}: sharded fit unusable ({why or 'failed on another rank'})\n")
+            if args.no_fallback:
+                sys.stderr.flush()
+                os._exit(3)
+            fallback_note = f"the sharded fit over {transport} failed on at least one rank" + (f" (rank {rank}: {why})" if why else "")
+            comm._h = None  # broken or possibly mid-collective on a peer: never destroyed, the process ends with os._exit
+            comm, sfit, sharded, transport = None, None, False, "none"
+            x_h, y_h, x_d, y_d = load(44 + rank)
+            feats = make_feats(x_d.data_ptr(), n)
+            torch.cuda.synchronize()
+        elif world == 1 and not ok:
+            raise SystemExit(f"bench.py: {why}")
+    fell_back = world > 1 and want_sharded and not sharded
 
     step = sharded_step if sharded else replica_step
 
@@ -272,10 +526,18 @@ def main():
         torch.cuda.synchronize()
         if comm is not None:
             comm.barrier()
+        else:
+            gloo_barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(v):
-        return float(comm.all_reduce([v], "max")[0]) if comm is not None else v
+        if comm is not None:
+            return float(comm.all_reduce([v], "max")[0])
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return v
 
     try:
         ctx.set_profiling(True)
@@ -303,28 +565,23 @@ def main():
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
 
-        # ---- auxiliary (N > 1): the multi-GPU mode that is not `value` ----
+        if not sharded:  # self-check of the replica path: one more fit of the timed problem, outside the timed region
+            resid = sampled_residual(x_h, y_h, replica_step(True))
+            self_check = {"rows": 64, "max_rel_residual": resid, "ok": bool(resid < 1e-8),
+                          "what": "max_r |(K a)_r - y_r| / max|y| of one more fit of the timed problem, numpy from the features"}
+
+        # ---- auxiliary (N > 1, sharded): N independent fits, one per GPU ("replicas") ----
         aux = None
-        if world > 1:
-            other = replica_step if sharded else sharded_step
-            if not sharded:  # the sharded mode needs the same dataset on every rank
-                x_h, y_h = make_dataset(n, 44)
-                x_d.copy_(torch.from_numpy(x_h))
-                y_d.copy_(torch.from_numpy(y_h))
-                torch.cuda.synchronize()
-            other()
+        if world > 1 and sharded:
+            replica_step()
             barrier()
             tr = time.perf_counter()
             for _ in range(3):
-                other()
+                replica_step()
             barrier()
             tr = max_over_ranks(time.perf_counter() - tr)
-            if sharded:
-                aux = {"replicas": {"fits_per_sec": 3 * world / tr, "scaling": "weak",
-                                    "note": "one independent fit per GPU (every rank its own copy of the problem), no collective"}}
-            else:
-                aux = {"sharded_single_fit": {"single_fit_ms": 1e3 * tr / 3, "fits_per_sec": 3 / tr, "scaling": "strong",
-                                              "note": f"one N={n} fit row-block-sharded over {world} GPUs"}}
+            aux = {"replicas": {"fits_per_sec": 3 * world / tr, "scaling": "weak",
+                                "note": "one independent fit per GPU (every rank a copy of the problem), no collective"}}
     except Exception as exc:  # noqa: BLE001
         # a failed or timed-out collective leaves the other ranks inside theirs: report, and leave with a non-zero code at
         # once (no destructors, no re-exec: the launcher starts fresh children)
@@ -339,13 +596,7 @@ def main():
         xs_h, _ = make_dataset(m, 43)
         xs_d = torch.from_numpy(xs_h).to(f"cuda:{local_rank}")
         out_d = torch.empty(2 * m, dtype=torch.float64, device=f"cuda:{local_rank}")
-        fx = capi.Features()
-        fx.n, fx.dim, fx.n_scale_columns = m, DIM, 0
-        fx.coords = xs_d.data_ptr()
-        fx.eq_id = None
-        fx.scales = None
-        fx.is_measurement = 0
-        fx.location = capi.DEVICE
+        fx = make_feats(xs_d.data_ptr(), m)
         h = C.c_void_p()
         st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
         assert st == capi.AGP_OK
@@ -371,7 +622,7 @@ def main():
     # correction applied) of the single-GPU run; null if absent or not applicable.
     traffic = traffic_src = None
     if world == 1 and not sharded and n == N_TRAIN:
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
                     traffic = json.load(fh)["traffic_bytes_per_launch"]
@@ -380,16 +631,24 @@ def main():
             except (OSError, KeyError, ValueError):
                 continue
 
+    configs = None
+    if rank == 0 and world == 1 and not sharded and not args.no_configs:
+        del x_d, y_d
+        torch.cuda.empty_cache()
+        configs = other_configs(ab, ctx)
+
     if rank == 0:
         # sharded: one fit per step over all ranks; replicas: every rank fits its own dataset
         fits = args.steps if (sharded or world == 1) else args.steps * world
         achieved = (gemm_flop / 1e12) / (gemm_ms * 1e-3) if gemm_ms > 0 else 0.0  # 0: no launch of that kernel at this size
         if sharded and world > 1:
-            parallelism = (f"ONE fit row-block-sharded (512-row blocks, snake-cyclic) over {world} GPUs: per block column an RCCL "
-                           "broadcast of the diagonal block and an all-gather of the panel, one block column of look-ahead")
+            parallelism = (f"ONE fit row-block-sharded (512-row blocks, snake-cyclic) over {world} GPUs: per block column ONE RCCL "
+                           "all-gather carrying the panel rows and the next diagonal block, one block column of look-ahead")
             kernel_name = "agp::gemm_nt_sub_kernel (fp64 MFMA updates of rank 0's own row blocks, K=512)"
         else:
             parallelism = "1 GPU" if world == 1 else f"{world} independent fits, one per GPU, no data-path collective"
+            if fell_back or fallback_note:
+                parallelism = "FALLBACK - " + parallelism + f" (the sharded single-fit path was not used: {fallback_note})"
             kernel_name = "agp::trailing_update_kernel (fp64 MFMA bulk trailing update C -= P P^T, K=512)"
         out = {
             "metric": f"GP fits/sec (Gram+Chol+solve) at N={n} fp64",
@@ -407,7 +666,8 @@ def main():
             "config": {"workload": f"dense GP fit, N={n}, 3-D SquaredExponential(1,1)+IndependentNoise(0.1), features from "
                                    "mt19937(44), inputs resident in HBM (BASELINE config 3 problem)",
                        "parallelism": parallelism,
-                       "transport": transport, "n_ranks": (comm.world if comm is not None else 1)},
+                       "transport": transport, "n_ranks": (comm.world if comm is not None else (world if not sharded else 1))},
+            "self_check": self_check,
             "roofline": {
                 "bound": "mfma", "kernel": kernel_name,
                 "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -428,19 +688,40 @@ def main():
         }
         if sharded:
             out["stages_ms_per_fit"]["note"] = "sharded entry point: `factor` is host wall time of factorisation + both substitutions"
+        if fell_back or fallback_note:
+            out["sharded_fallback"] = fallback_note
         if predict is not None:
             out["predict"] = predict
         if aux is not None:
             out.update(aux)
+        if configs is not None:
+            out["configs"] = configs
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
+    bad_check = self_check is not None and not self_check["ok"]
+    if fell_back:
+        # the abandoned communicator must not run its destructors (peers may sit in a collective of it)
+        gloo_barrier()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(4 if bad_check else 0)
     if comm is not None:
         comm.barrier()
         comm.close()
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
+    if bad_check:
+        raise SystemExit("bench.py: self-check failed (see self_check in the JSON line)")
+
+
+def main():
+    args = parse_args()
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

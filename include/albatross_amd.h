@@ -17,6 +17,14 @@
 
 #include <stdint.h>
 
+/* Every entry point below is exported with default visibility; the library is built with -fvisibility=hidden, so these
+ * declarations ARE its export list (tests/test_capi_host.py compares them with `nm -D`). */
+#if defined(__GNUC__) || defined(__clang__)
+#define AGP_API __attribute__((visibility("default")))
+#else
+#define AGP_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -126,28 +134,28 @@ typedef struct agp_comm agp_comm; /* transport of the multi-GPU entry points, se
 /* One context per host thread (or externally locked).  Owns the HIP streams
  * and scratch workspaces.  The reference's equivalent state is the model's
  * ThreadPool (src/core/model.hpp:30-36,133-135). */
-int agp_context_create(int device_id, agp_context **out);
-void agp_context_destroy(agp_context *ctx);
-int agp_context_synchronize(agp_context *ctx);
+AGP_API int agp_context_create(int device_id, agp_context **out);
+AGP_API void agp_context_destroy(agp_context *ctx);
+AGP_API int agp_context_synchronize(agp_context *ctx);
 /* last HIP error text for AGP_ERR_HIP, "" otherwise */
-const char *agp_last_error(const agp_context *ctx);
-const char *agp_status_string(int status);
+AGP_API const char *agp_last_error(const agp_context *ctx);
+AGP_API const char *agp_status_string(int status);
 /* number of visible HIP devices (0 when no GPU / no driver) */
-int agp_device_count(void);
+AGP_API int agp_device_count(void);
 
 /* ---- covariance function ------------------------------------------------- */
 /* Flattened get_params() of a composed covariance function
  * (covariance_function.hpp:222-420). Immutable after creation. */
-int agp_kernel_create(const agp_kernel_node *postfix, int n_nodes,
+AGP_API int agp_kernel_create(const agp_kernel_node *postfix, int n_nodes,
                       agp_kernel **out);
-void agp_kernel_destroy(agp_kernel *k);
+AGP_API void agp_kernel_destroy(agp_kernel *k);
 
 /* ---- Gram ---------------------------------------------------------------- */
 /* compute_covariance_matrix (src/covariance_functions/callers.hpp:38-166).
  * y == NULL: symmetric n x n Gram of x (callers.hpp:107-166), full matrix
  * written. Else the n_x x n_y cross Gram (callers.hpp:38-102).
  * `out` is column-major with leading dimension ld, at out_location. */
-int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x,
+AGP_API int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x,
              const agp_features *y, double *out, int64_t ld, int out_location);
 
 /* Gram of LinearCombination<X> features: LinearCombinationCaller (covariance_functions/callers.hpp:321-396),
@@ -158,7 +166,7 @@ int agp_gram(agp_context *ctx, const agp_kernel *k, const agp_features *x,
  * symmetric Gram of x with itself (evaluated for a >= b and mirrored, callers.hpp:119-127).  The Measurement<> flag
  * of x / y applies to the expanded points (MeasurementForwarder sits outside LinearCombinationCaller).  Gram and
  * contraction both run on the device. */
-int agp_gram_combined(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t nx, const int64_t *x_offsets,
+AGP_API int agp_gram_combined(agp_context *ctx, const agp_kernel *k, const agp_features *x, int64_t nx, const int64_t *x_offsets,
                       const double *x_coefficients, const agp_features *y, int64_t ny, const int64_t *y_offsets,
                       const double *y_coefficients, double *out, int64_t ld, int out_location);
 
@@ -171,7 +179,7 @@ int agp_gram_combined(agp_context *ctx, const agp_kernel *k, const agp_features 
  * NULL.  The training features are copied into the fit (gp.hpp:63). */
 /* A fit belongs to the context that created it and must be destroyed before
  * that context. */
-int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x,
+AGP_API int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x,
                    const double *y, const double *y_var, agp_fit **out,
                    double *information, double *log_det);
 /* Mixed-precision variant of agp_fit_create (BASELINE.json configs[3], SURVEY
@@ -187,28 +195,28 @@ int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_features *x,
  * variances and log_det carry the fp32 rounding of the products (relative
  * ~1e-6).  The reference has no reduced-precision path; this one exists for
  * problems where one fp64 factorisation is too slow (N >= 32768). */
-int agp_fit_create_mixed(agp_context *ctx, const agp_kernel *k, const agp_features *x,
+AGP_API int agp_fit_create_mixed(agp_context *ctx, const agp_kernel *k, const agp_features *x,
                          const double *y, const double *y_var, int max_iterations,
                          double tolerance, agp_fit **out, double *information,
                          double *log_det, int *iterations, double *residual);
-void agp_fit_destroy(agp_fit *fit);
-int64_t agp_fit_size(const agp_fit *fit);
+AGP_API void agp_fit_destroy(agp_fit *fit);
+AGP_API int64_t agp_fit_size(const agp_fit *fit);
 /* 0-based index of the first non-positive pivot of the last failed factor */
-int64_t agp_fit_failed_pivot(const agp_fit *fit);
+AGP_API int64_t agp_fit_failed_pivot(const agp_fit *fit);
 /* sum(log D) of the reference's LDLT == 2 sum(log L_ii)
  * (src/eigen/serializable_ldlt.hpp:128-135) */
-int agp_fit_log_determinant(const agp_fit *fit, double *out);
+AGP_API int agp_fit_log_determinant(const agp_fit *fit, double *out);
 /* lower-triangular factor, column-major n x n, strictly-upper part zeroed */
-int agp_fit_download_factor(agp_context *ctx, const agp_fit *fit, double *L,
+AGP_API int agp_fit_download_factor(agp_context *ctx, const agp_fit *fit, double *L,
                             int64_t ld);
-int agp_fit_download_information(agp_context *ctx, const agp_fit *fit,
+AGP_API int agp_fit_download_information(agp_context *ctx, const agp_fit *fit,
                                  double *information);
 
 /* negative_log_likelihood(deviation, covariance)
  * (src/evaluation/likelihood.hpp:38-66) on K = k(x,x) + diag(y_var):
  *   0.5 (log|K| + y^T K^-1 y + n log 2 pi).
  * Factor is not kept (GaussianProcessBase::log_likelihood, gp.hpp:442-451). */
-int agp_nll(agp_context *ctx, const agp_kernel *k, const agp_features *x,
+AGP_API int agp_nll(agp_context *ctx, const agp_kernel *k, const agp_features *x,
             const double *y, const double *y_var, double *out);
 
 /* Tuner objective batching: agp_nll for `count` parameter vectors of one model on one dataset in lock step
@@ -222,13 +230,13 @@ int agp_nll(agp_context *ctx, const agp_kernel *k, const agp_features *x,
  *                per parameter vector); ldy = 0: one target vector shared by all
  *   out[b]       the negative log likelihood (host); NaN where the covariance is not positive definite or
  *                has NaN (the reference turns a NaN metric into +inf, tune.hpp:163-165) */
-int agp_nll_batch(agp_context *ctx, int count, const agp_kernel *const *kernels,
+AGP_API int agp_nll_batch(agp_context *ctx, int count, const agp_kernel *const *kernels,
                   const agp_features *const *features, const double *y, int64_t ldy, const double *y_var,
                   double *out);
 
 /* ---- solve (CovarianceRepresentation::solve, gp.hpp:42-45,68,96,111) ----- */
 /* out = K^-1 rhs; rhs/out column-major n x nrhs (ld = n), at `location`. */
-int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs,
+AGP_API int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs,
               int64_t nrhs, double *out, int location);
 
 /* ---- dense-matrix factor (CovarianceRepresentation from a matrix) ----------- */
@@ -240,11 +248,11 @@ int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs,
  * supports agp_solve, agp_fit_log_determinant, agp_fit_inverse_diagonal,
  * agp_fit_download_factor, agp_fit_size, agp_fit_failed_pivot; it has no training
  * features (agp_predict_* and agp_loo_marginal reject it). */
-int agp_factor_create(agp_context *ctx, const double *K, int64_t n, int64_t ld,
+AGP_API int agp_factor_create(agp_context *ctx, const double *K, int64_t n, int64_t ld,
                       int uplo, int location, agp_fit **out);
 /* negative_log_likelihood(deviation, covariance) (src/evaluation/likelihood.hpp:53-66):
  * 0.5 (log|K| + dev^T K^-1 dev + n log 2 pi); the univariate shortcut (:57-60) included. */
-int agp_nll_dense(agp_context *ctx, const double *deviation, const double *K,
+AGP_API int agp_nll_dense(agp_context *ctx, const double *deviation, const double *K,
                   int64_t n, int64_t ld, int uplo, int location, double *out);
 
 /* ---- update: condition a fit on further observations without refitting ------------------------------------
@@ -262,13 +270,13 @@ int agp_nll_dense(agp_context *ctx, const double *deviation, const double *K,
  *   out      a NEW fit of old + m observations for agp_predict_*, agp_solve, agp_fit_download_*, agp_fit_update;
  *            cross-validation entry points reject it (AGP_ERR_UNSUPPORTED)
  *   information  (optional, host) all agp_fit_size(*out) entries: the old observations first, then the new ones */
-int agp_fit_update(agp_context *ctx, const agp_kernel *k, const agp_fit *old, const agp_features *x_new, const double *y_new,
+AGP_API int agp_fit_update(agp_context *ctx, const agp_kernel *k, const agp_fit *old, const agp_features *x_new, const double *y_new,
                    const double *y_var_new, agp_fit **out, double *information, double *log_det);
 
 /* ---- leave-one-out fast path (the tuner's LeaveOneOutLikelihood objective) --- */
 /* diag(K^-1): SerializableLDLT::inverse_diagonal (src/eigen/serializable_ldlt.hpp:
  * 137-199: R = L^-1, then the squared column norms of R).  out: n doubles. */
-int agp_fit_inverse_diagonal(agp_context *ctx, const agp_fit *fit, double *out,
+AGP_API int agp_fit_inverse_diagonal(agp_context *ctx, const agp_fit *fit, double *out,
                              int out_location);
 /* Leave-one-out predictive marginals, all n at once: held_out_predictions with
  * singleton groups (src/evaluation/cross_validation_utils.hpp:165-232) ==
@@ -276,7 +284,7 @@ int agp_fit_inverse_diagonal(agp_context *ctx, const agp_fit *fit, double *out,
  *   variance_i = 1 / (K^-1)_ii ,  mean_i = y_i - information_i / (K^-1)_ii.
  * y = the target means as passed to the fit's dataset (n doubles at `location`);
  * mean / variance: n doubles each at `location`. */
-int agp_loo_marginal(agp_context *ctx, const agp_fit *fit, const double *y,
+AGP_API int agp_loo_marginal(agp_context *ctx, const agp_fit *fit, const double *y,
                      double *mean, double *variance, int location);
 
 /* Leave-one-GROUP-out.  Groups are index sets into the training data: group g is
@@ -295,9 +303,9 @@ int agp_loo_marginal(agp_context *ctx, const agp_fit *fit, const double *y,
  *   B_g = (K^-1)[I_g, I_g].
  * mean / variance (variance may be NULL) are written in the order of `indices`; joint (may be NULL)
  * receives the concatenated column-major blocks.  y, mean, variance, joint live at `location`. */
-int agp_fit_inverse_blocks(agp_context *ctx, const agp_fit *fit, int64_t n_groups, const int64_t *offsets,
+AGP_API int agp_fit_inverse_blocks(agp_context *ctx, const agp_fit *fit, int64_t n_groups, const int64_t *offsets,
                            const int64_t *indices, double *blocks, int out_location);
-int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double *y, int64_t n_groups,
+AGP_API int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double *y, int64_t n_groups,
                              const int64_t *offsets, const int64_t *indices, double *mean, double *variance,
                              double *joint, int location);
 
@@ -315,19 +323,19 @@ int agp_held_out_predictions(agp_context *ctx, const agp_fit *fit, const double 
  *                     the smallest normal number; rhs / out are n x nrhs column-major at `location`
  *   agp_ldlt_vector_d / _transpositions / _download   vectorD(), transpositionsP(), matrixLDLT() (host) */
 typedef struct agp_ldlt agp_ldlt;
-int agp_ldlt_create(agp_context *ctx, const double *K, int64_t n, int64_t ld, int uplo, int location,
+AGP_API int agp_ldlt_create(agp_context *ctx, const double *K, int64_t n, int64_t ld, int uplo, int location,
                     agp_ldlt **out, int *success);
-void agp_ldlt_destroy(agp_ldlt *ldlt);
-int64_t agp_ldlt_size(const agp_ldlt *ldlt);
-int agp_ldlt_solve(agp_context *ctx, const agp_ldlt *ldlt, const double *rhs, int64_t nrhs, double *out,
+AGP_API void agp_ldlt_destroy(agp_ldlt *ldlt);
+AGP_API int64_t agp_ldlt_size(const agp_ldlt *ldlt);
+AGP_API int agp_ldlt_solve(agp_context *ctx, const agp_ldlt *ldlt, const double *rhs, int64_t nrhs, double *out,
                    int location);
 /* SerializableLDLT::sqrt_solve (serializable_ldlt.hpp:99-109): D^-1/2 L^-1 P rhs, D^-1/2 zero where D_i <= 0 (:58-69);
  * out^T out = rhs^T A^-1 rhs.  rhs / out n x nrhs column-major at `location`. */
-int agp_ldlt_sqrt_solve(agp_context *ctx, const agp_ldlt *ldlt, const double *rhs, int64_t nrhs, double *out,
+AGP_API int agp_ldlt_sqrt_solve(agp_context *ctx, const agp_ldlt *ldlt, const double *rhs, int64_t nrhs, double *out,
                         int location);
-int agp_ldlt_vector_d(const agp_ldlt *ldlt, double *d);
-int agp_ldlt_transpositions(const agp_ldlt *ldlt, int64_t *tr);
-int agp_ldlt_download(agp_context *ctx, const agp_ldlt *ldlt, double *packed, int64_t ld);
+AGP_API int agp_ldlt_vector_d(const agp_ldlt *ldlt, double *d);
+AGP_API int agp_ldlt_transpositions(const agp_ldlt *ldlt, int64_t *tr);
+AGP_API int agp_ldlt_download(agp_context *ctx, const agp_ldlt *ldlt, double *packed, int64_t ld);
 
 /* ---- sparse Gaussian process (FITC / PITC) --------------------------------------------------
  * SparseGaussianProcessRegression, include/albatross/src/models/sparse_gp.hpp.
@@ -354,7 +362,7 @@ int agp_ldlt_download(agp_context *ctx, const agp_ldlt *ldlt, double *packed, in
  * Errors: AGP_ERR_NOT_POSITIVE_DEFINITE if a block of A is not numerically positive definite (the reference's
  * block LDLT would continue), AGP_ERR_NAN_INPUT. */
 typedef struct agp_sparse_fit agp_sparse_fit;
-int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *kernel, const agp_features *x, int64_t n_groups,
+AGP_API int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *kernel, const agp_features *x, int64_t n_groups,
                           const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
                           double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
                           double *information, double *nll);
@@ -365,13 +373,13 @@ int agp_sparse_fit_create(agp_context *ctx, const agp_kernel *kernel, const agp_
  * repair - plus four m-vectors are all-reduced (2 x 8 m^2 B + O(m) per fit: 2 x 32 MiB at m = 2048).  Every rank passes
  * the same inducing points u and receives the same fit (handle, information, nll of ALL observations); predictions then
  * need no further exchange.  Collective. */
-int agp_sparse_fit_create_sharded(agp_context *ctx, agp_comm *comm, const agp_kernel *kernel, const agp_features *x,
+AGP_API int agp_sparse_fit_create_sharded(agp_context *ctx, agp_comm *comm, const agp_kernel *kernel, const agp_features *x,
                                   int64_t n_groups, const int64_t *offsets, const double *y, const double *y_var,
                                   const agp_features *u, double measurement_nugget, double inducing_nugget,
                                   agp_sparse_fit **out, double *information, double *nll);
-void agp_sparse_fit_destroy(agp_sparse_fit *fit);
-int64_t agp_sparse_fit_size(const agp_sparse_fit *fit); /* number of inducing points */
-int agp_sparse_fit_information(agp_context *ctx, const agp_sparse_fit *fit, double *information);
+AGP_API void agp_sparse_fit_destroy(agp_sparse_fit *fit);
+AGP_API int64_t agp_sparse_fit_size(const agp_sparse_fit *fit); /* number of inducing points */
+AGP_API int agp_sparse_fit_information(agp_context *ctx, const agp_sparse_fit *fit, double *information);
 /* FitModel::update for a sparse fit: _update_impl (sparse_gp.hpp:322-371).  Further observations (grouped
  * like those of agp_sparse_fit_create; wrapped as measurements inside) are folded into `old` through
  * B = [R_old P_old^T; A^-1/2 K_fu],  y_aug = [R_old P_old^T v_old; A^-1/2 y]; the inducing points and their
@@ -379,7 +387,7 @@ int agp_sparse_fit_information(agp_context *ctx, const agp_sparse_fit *fit, doub
  * (m doubles, host) is optional.  An `old` made by agp_sparse_fit_from_prediction (or by an update of one) is
  * updated with the reference's own algorithm - the column-pivoted QR of B, v = B_qr.solve(y_aug), R's diagonal
  * inflated by 1e-10 when B is rank deficient (:353-365) - and the result stays in that pivoted form. */
-int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *old,
+AGP_API int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *old,
                           const agp_features *x, int64_t n_groups, const int64_t *offsets, const double *y,
                           const double *y_var, double measurement_nugget, agp_sparse_fit **out,
                           double *information);
@@ -393,39 +401,39 @@ int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *kernel, const agp_
  * QR) instead of the LL^T / CholeskyQR2 of agp_sparse_fit_create; they are level-2 bound, meant for moderate m.
  * inducing_nugget is what a later agp_sparse_fit_update adds to K_zz for P = K_zz^-1/2 K_zf (:674-685).
  * Optional outputs: information (m doubles, host), numerical_rank (B_qr->rank(), :458). */
-int agp_sparse_fit_from_prediction(agp_context *ctx, const agp_kernel *kernel, const agp_features *z,
+AGP_API int agp_sparse_fit_from_prediction(agp_context *ctx, const agp_kernel *kernel, const agp_features *z,
                                    const double *mean, const double *covariance, int64_t ldc, int location,
                                    double inducing_nugget, agp_sparse_fit **out, double *information,
                                    int64_t *numerical_rank);
 /* Fit<SparseGPFit>::numerical_rank: the rank of the pivoted QR for fits in pivoted form, m otherwise. */
-int64_t agp_sparse_fit_numerical_rank(const agp_sparse_fit *fit);
-int agp_sparse_nll(agp_context *ctx, const agp_kernel *kernel, const agp_features *x, int64_t n_groups,
+AGP_API int64_t agp_sparse_fit_numerical_rank(const agp_sparse_fit *fit);
+AGP_API int agp_sparse_nll(agp_context *ctx, const agp_kernel *kernel, const agp_features *x, int64_t n_groups,
                    const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
                    double measurement_nugget, double inducing_nugget, double *out);
 /* _predict_impl (:447-521): mean = K_*u v; covariance = K_** - Q_** + K_*u Sigma K_u*.  The mean
  * function is the caller's (mean_function_.add_to). */
-int agp_sparse_predict_mean(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *fit,
+AGP_API int agp_sparse_predict_mean(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *fit,
                             const agp_features *xs, double *mean, int out_location);
-int agp_sparse_predict_marginal(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *fit,
+AGP_API int agp_sparse_predict_marginal(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *fit,
                                 const agp_features *xs, double *mean, double *variance, int out_location);
-int agp_sparse_predict_joint(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *fit,
+AGP_API int agp_sparse_predict_joint(agp_context *ctx, const agp_kernel *kernel, const agp_sparse_fit *fit,
                              const agp_features *xs, double *mean, double *covariance, int out_location);
 
 /* ---- predict ------------------------------------------------------------- */
 /* gp_mean_prediction (gp.hpp:82-85) via _predict_impl (gp.hpp:350-366):
  *   mean = k(train, xs)^T information.  mean: m doubles at out_location. */
-int agp_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
+AGP_API int agp_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
                      const agp_features *xs, double *mean, int out_location);
 /* gp_marginal_prediction (gp.hpp:87-101) via _predict_impl (gp.hpp:326-348):
  *   var_j = k(xs_j, xs_j) - sum_i (K^-1 K*)_ij K*_ij.
  * Any number of test points: they pass in slices that keep the n x m workspace at 2 GiB (nothing couples the
  * columns of a marginal prediction). */
-int agp_predict_marginal(agp_context *ctx, const agp_kernel *k,
+AGP_API int agp_predict_marginal(agp_context *ctx, const agp_kernel *k,
                          const agp_fit *fit, const agp_features *xs,
                          double *mean, double *variance, int out_location);
 /* gp_joint_prediction (gp.hpp:103-113) via _predict_impl (gp.hpp:305-324):
  *   cov = k(xs, xs) - K*^T K^-1 K*.  cov: m x m column-major, ld = m. */
-int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
+AGP_API int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
                       const agp_features *xs, double *mean, double *cov,
                       int out_location);
 
@@ -452,9 +460,9 @@ int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_fit *fit,
  * for boxes where RCCL cannot be used (it refuses two ranks on one device) - collectives supplied by the caller. */
 #define AGP_COMM_ID_BYTES 128
 /* ncclGetUniqueId: rank 0 calls it and hands the bytes to every rank by any means (a file, MPI, a TCP store). */
-int agp_comm_unique_id(void *id);
+AGP_API int agp_comm_unique_id(void *id);
 /* ncclCommInitRank on ctx's device; collective over all ranks.  AGP_ERR_COMM when RCCL is unavailable or fails. */
-int agp_comm_create(agp_context *ctx, int nranks, int rank, const void *id, agp_comm **out);
+AGP_API int agp_comm_create(agp_context *ctx, int nranks, int rank, const void *id, agp_comm **out);
 /* op for all_reduce: 0 = sum, 1 = max */
 typedef struct {
   void *user;
@@ -463,40 +471,40 @@ typedef struct {
   int (*all_gather)(void *user, const double *send, double *recv, int64_t count_per_rank);
   int (*all_reduce)(void *user, double *buf, int64_t count, int op);
 } agp_comm_callbacks;
-int agp_comm_create_callbacks(int nranks, int rank, const agp_comm_callbacks *cb, agp_comm **out);
-void agp_comm_destroy(agp_comm *comm);
-int agp_comm_size(const agp_comm *comm);
-int agp_comm_rank(const agp_comm *comm);
+AGP_API int agp_comm_create_callbacks(int nranks, int rank, const agp_comm_callbacks *cb, agp_comm **out);
+AGP_API void agp_comm_destroy(agp_comm *comm);
+AGP_API int agp_comm_size(const agp_comm *comm);
+AGP_API int agp_comm_rank(const agp_comm *comm);
 /* control-plane helpers for host code (bench.py's barrier and max-over-ranks timing): in-place on host doubles */
-int agp_comm_all_reduce_host(agp_comm *comm, double *buf, int64_t count, int op);
-int agp_comm_barrier(agp_comm *comm);
+AGP_API int agp_comm_all_reduce_host(agp_comm *comm, double *buf, int64_t count, int op);
+AGP_API int agp_comm_barrier(agp_comm *comm);
 
 /* ownership arithmetic of the row-block-cyclic layout (pure host functions) */
-int64_t agp_shard_local_rows(int64_t n, int64_t block, int nranks, int rank);
+AGP_API int64_t agp_shard_local_rows(int64_t n, int64_t block, int nranks, int rank);
 /* global row of local row l of `rank` (l < agp_shard_local_rows) */
-int64_t agp_shard_global_row(int64_t n, int64_t block, int nranks, int rank, int64_t l);
-int agp_shard_owner(int64_t block_index, int nranks);
+AGP_API int64_t agp_shard_global_row(int64_t n, int64_t block, int nranks, int rank, int64_t l);
+AGP_API int agp_shard_owner(int64_t block_index, int nranks);
 /* doubles of scratch agp_shard_factor_custom needs */
-int64_t agp_shard_work_doubles(int64_t n, int64_t block, int nranks, int rank);
+AGP_API int64_t agp_shard_work_doubles(int64_t n, int64_t block, int nranks, int rank);
 
 typedef struct agp_sharded_fit agp_sharded_fit;
 /* One fit over all ranks of `comm`; collective.  Every rank passes the SAME full dataset (x, y, y_var as in
  * agp_fit_create; at x->location) and receives information (n doubles, host, may be NULL) and log_det.
  * A failure (NaN, non-positive pivot, transport error or timeout: AGP_COMM_TIMEOUT_S seconds, default 120) is
  * reported with the same status on every rank that can still be reached.  comm == NULL: one rank, no transport. */
-int agp_sharded_fit_create(agp_context *ctx, agp_comm *comm, const agp_kernel *k, const agp_features *x,
+AGP_API int agp_sharded_fit_create(agp_context *ctx, agp_comm *comm, const agp_kernel *k, const agp_features *x,
                            const double *y, const double *y_var, agp_sharded_fit **out, double *information,
                            double *log_det);
-void agp_sharded_fit_destroy(agp_sharded_fit *fit);
-int64_t agp_sharded_fit_failed_pivot(const agp_sharded_fit *fit);
+AGP_API void agp_sharded_fit_destroy(agp_sharded_fit *fit);
+AGP_API int64_t agp_sharded_fit_failed_pivot(const agp_sharded_fit *fit);
 /* Replicate the factor: all-gather of the row blocks, after which every rank holds an ordinary agp_fit of the whole
  * problem (the factor of gp.hpp:61-69) and predicts ITS share of the test points with agp_predict_* - predictions
  * are independent per test point (gp.hpp:82-113), so sharding M needs no further exchange.  Collective. */
-int agp_sharded_fit_replicate(agp_context *ctx, agp_sharded_fit *fit, agp_fit **out);
+AGP_API int agp_sharded_fit_replicate(agp_context *ctx, agp_sharded_fit *fit, agp_fit **out);
 /* per-stage device time of the last sharded fit on this rank, ms: 0 gram, 1 factor, 2 back substitution,
  * 3 sum of the bulk update launches, 4 their count, 5 their algorithmic flop, 6 host time spent enqueueing the
  * schedule, 7 host time until the device had drained (6 ~ 7: the host is the bottleneck) */
-int agp_sharded_fit_stage(const agp_sharded_fit *fit, int stage, double *value);
+AGP_API int agp_sharded_fit_stage(const agp_sharded_fit *fit, int stage, double *value);
 
 /* The same schedule (factorisation + both substitutions) on a rank-local matrix the CALLER built, with the block
  * arithmetic supplied through callbacks instead of the HIP kernels: test instrumentation - tests/ drives the
@@ -527,7 +535,7 @@ typedef struct {
   void (*axpby)(void *user, int64_t n, double a, const double *x, double b, const double *y, double *out);
   void (*fill_zero)(void *user, double *p, int64_t count);
 } agp_shard_ops_callbacks;
-int agp_shard_factor_custom(const agp_shard_ops_callbacks *ops, agp_comm *comm, int64_t n, int64_t block, double *A,
+AGP_API int agp_shard_factor_custom(const agp_shard_ops_callbacks *ops, agp_comm *comm, int64_t n, int64_t block, double *A,
                             int64_t ld, double *y, double *work, double *information, double *log_det,
                             int64_t *bad_pivot);
 
@@ -536,13 +544,13 @@ int agp_shard_factor_custom(const agp_shard_ops_callbacks *ops, agp_comm *comm, 
  * HIP events on the stream the kernels were launched on.  Stages:
  * 0 gram, 1 factor (total), 2 solve, 3 trailing-update kernels only (sum),
  * 4 number of trailing-update launches.  Returns ms (or a count for 4). */
-int agp_last_stage_ms(const agp_context *ctx, int stage, double *ms);
+AGP_API int agp_last_stage_ms(const agp_context *ctx, int stage, double *ms);
 /* enable (1) / disable (0) per-stage event timing (default off: events add
  * host overhead to the launch chain). */
-int agp_set_profiling(agp_context *ctx, int enabled);
+AGP_API int agp_set_profiling(agp_context *ctx, int enabled);
 /* Bare v_mfma_f64_16x16x4_f64 issue loop: measured fp64 MFMA TFLOP/s of this
  * device (used as a cross-check of the roofline denominator). */
-int agp_mfma_f64_peak(agp_context *ctx, int iters, double *tflops);
+AGP_API int agp_mfma_f64_peak(agp_context *ctx, int iters, double *tflops);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ import numpy as np
 import albatross_amd as ab
 from albatross_amd import _capi as capi
 ctx = ab.Context(0)
-lib = capi.load()
+lib = capi.load_debug()
 lib.agp_debug_fmac_rate.restype = C.c_int
 lib.agp_debug_fmac_rate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 for mode, name in ((0, "vgpr"), (1, "sgpr"), (2, "dpp row_newbcast")):

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import albatross_amd as ab
 from albatross_amd import _capi as capi
 ctx = ab.Context(0)
-lib = capi.load()
+lib = capi.load_debug()
 lib.agp_debug_mfma_clock.restype = C.c_int
 lib.agp_debug_mfma_clock.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
 out = (C.c_double * 3)()

@@ -5,7 +5,7 @@ import numpy as np
 import albatross_amd as ab
 from albatross_amd import _capi as capi
 ctx = ab.Context(0)
-lib = capi.load()
+lib = capi.load_debug()
 lib.agp_debug_factor.restype = C.c_int
 lib.agp_debug_factor.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
 rng = np.random.default_rng(0)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import albatross_amd as ab
 
 ctx = ab.Context(0)
-lib = ctx._lib
+lib = ab._capi.load_debug()
 lib.agp_debug_chain_probe.restype = C.c_int
 lib.agp_debug_chain_probe.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.POINTER(C.c_double)]

@@ -8,7 +8,7 @@ import numpy as np
 import albatross_amd as ab
 
 ctx = ab.Context(0)
-lib = ctx._lib
+lib = ab._capi.load_debug()
 lib.agp_debug_time_masked_update.restype = C.c_int
 lib.agp_debug_time_masked_update.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                              C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import albatross_amd as ab
 from albatross_amd import _capi as capi
 ctx = ab.Context(0)
-lib = capi.load()
+lib = capi.load_debug()
 lib.agp_debug_mfma44_probe.restype = C.c_int
 lib.agp_debug_mfma44_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 for mode in range(5):

@@ -3,7 +3,7 @@ sys.path.insert(0,".")
 import albatross_amd as ab
 from albatross_amd import _capi as capi
 ctx = ab.Context(0)
-lib = capi.load()
+lib = capi.load_debug()
 lib.agp_debug_time_trailing_update.restype = C.c_int
 lib.agp_debug_time_trailing_update.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]
 tot = {0:0.,4:0.,5:0.}

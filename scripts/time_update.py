@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import albatross_amd as ab
 from albatross_amd import _capi as capi
 ctx = ab.Context(0)
-lib = capi.load()
+lib = capi.load_debug()
 lib.agp_debug_time_trailing_update.restype = C.c_int
 lib.agp_debug_time_trailing_update.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]
 for M, K in ((15872, 512), (12288, 512), (8192, 512), (8192, 256), (4096, 256), (4096, 128), (2048, 128)):

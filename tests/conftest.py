@@ -38,38 +38,20 @@ def ctx():
 
 
 def synthetic_3d(n, seed):
-    """X ~ U[0,10]^3, y = sum_k sin x_k + 0.1 cos(10 x_0)."""
-    rng = np.random.default_rng(seed)
-    x = rng.uniform(0., 10., size=(n, 3))
-    y = np.sin(x).sum(axis=1) + 0.1 * np.cos(10. * x[:, 0])
-    return x, y
+    """SURVEY.md section 8d configs 2/3, exactly as pinned there and as bench.py times them: X ~ U[0,10]^3 from libstdc++'s
+    mt19937(seed) + uniform_real_distribution (bench.mt19937_uniform reproduces it bit for bit, checked against the
+    compiled generator's tests/golden/bench512.json), y = sum_k sin x_k + 0.1 cos(10 x_0)."""
+    from bench import make_dataset
+    return make_dataset(n, seed)
 
 
 def synthetic_stations(n, seed):
-    """stations lat ~ U[25, 50] deg, lon ~ U[-125, -65] deg, h ~ U[0, 3000] m -> ECEF (WGS-84,
-    km); temperature = 60 - 0.0065 h 1.8 + a smooth field + N(0, 1.75).  Returns (ecef km, elevation m, temperature)."""
-    rng = np.random.default_rng(seed)
-    lat = np.deg2rad(rng.uniform(25., 50., n))
-    lon = np.deg2rad(rng.uniform(-125., -65., n))
-    h = rng.uniform(0., 3000., n)
-    a, f = 6378137.0, 1. / 298.257223563
-    e2 = f * (2. - f)
-    nu = a / np.sqrt(1. - e2 * np.sin(lat) ** 2)
-    ecef = np.stack([(nu + h) * np.cos(lat) * np.cos(lon), (nu + h) * np.cos(lat) * np.sin(lon),
-                     (nu * (1. - e2) + h) * np.sin(lat)], axis=1) / 1000.
-    smooth = 8. * np.sin(3. * lat) * np.cos(2. * lon) + 5. * np.cos(5. * lon)
-    temp = 60. - 0.0065 * h * 1.8 + smooth + rng.normal(0., 1.75, n)
-    return ecef, h, temp
+    """SURVEY.md section 8d config 4 (bench.synthetic_stations): (ecef km, elevation m, temperature)."""
+    import bench
+    return bench.synthetic_stations(n, seed)
 
 
 def temperature_covariance(ab):
-    """The tuned covariance of examples/temperature_example/temperature_example.cc:34-85; the elevation scaling
-    1 + factor * max(0, center - h) (temperature_example_utils.h:78-84) is supplied as an explicit scale column."""
-    class Elevation(ab.ScalingFunction):
-        def _call_impl(self, c):
-            raise AssertionError("scale columns are supplied explicitly")
-
-    cov = ab.ScalingTerm(Elevation()) * ab.Constant(5.07288) + ab.IndependentNoise(1.75027) \
-        + ab.Exponential(1.10298, 1.0, ab.AngularDistance()) * ab.SquaredExponential(5835.56, 13.913, ab.RadialDistance())
-    scale = lambda h: 1. + 0.000153439 * np.maximum(0., 4446.5 - h)
-    return cov, scale
+    """The tuned covariance of examples/temperature_example/temperature_example.cc:34-85 (bench.temperature_covariance)."""
+    import bench
+    return bench.temperature_covariance(ab)

@@ -29,6 +29,25 @@ def test_library_exports_every_declared_symbol():
     assert sorted(n for n, _, _ in capi.EXPORTS) == names
 
 
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+
+
+def test_exported_symbols_are_exactly_the_declared_ones():
+    """-fvisibility=hidden + AGP_API: the product library exports the entry points of include/albatross_amd.h and
+    nothing else of its own - no internal C++ symbol, no agp_debug_* probe (those live in libalbatross_amd_debug.so)."""
+    syms = _exported(capi.lib_path())
+    ours = sorted(s for s in syms if s.startswith("agp_"))
+    assert ours == declared_symbols()
+    assert not [s for s in syms if "agp" in s and not s.startswith("agp_")], "internal C++ symbols are exported"
+    assert not [s for s in ours if s.startswith("agp_debug")]
+    dbg = _exported(os.path.join(os.path.dirname(capi.lib_path()), "libalbatross_amd_debug.so"))
+    assert len([s for s in dbg if s.startswith("agp_debug_")]) >= 10
+    assert set(ours) <= set(dbg)
+
+
 def test_status_strings_and_device_count_without_gpu():
     lib = capi.load()
     assert lib.agp_status_string(capi.AGP_OK) == b"ok"

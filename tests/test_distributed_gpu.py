@@ -44,6 +44,27 @@ def test_sharded_fit_one_rank_matches_oracle(ctx, n, block, monkeypatch):
     assert np.abs(res.information - fm.get_fit().information).max() <= 1e-9 * np.abs(ofit.information).max()
 
 
+@pytest.mark.parametrize("n,block", [(700, 128), (1000, 256), (1500, 512)])
+def test_one_rank_replicate_any_block(ctx, n, block, monkeypatch):
+    """agp_sharded_fit_replicate on the one-rank, no-transport path: the tile images are laid out per 128-block by the
+    single-GPU factorisation whatever AGP_SHARD_BLOCK says (it used to read them with the 512-block stride)."""
+    monkeypatch.setenv("AGP_SHARD_BLOCK", str(block))
+    monkeypatch.delenv("AGP_SHARD_FORCE_COMM", raising=False)
+    x, y, yvar = problem(n)
+    cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+    sharded = ShardedGaussianProcessFit(ctx, cov)
+    sharded.fit(x, y, yvar)
+    fm = sharded.replicate(ab.gp_from_covariance(cov, context=ctx))
+    ofit = orc.OracleFit(cov, x, y, yvar)
+    xs = np.random.default_rng(3).uniform(0., 10., (40, 3))
+    om, ov = ofit.predict_marginal(xs)
+    marg = fm.predict(xs).marginal()
+    assert np.abs(marg.mean - om).max() <= 1e-8 * np.abs(om).max()
+    assert np.abs(marg.covariance - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-9
+    rhs = np.random.default_rng(4).standard_normal(n)
+    assert np.abs(fm.get_fit().solve(rhs) - ofit.solve(rhs)).max() <= 1e-8 * np.abs(ofit.solve(rhs)).max()
+
+
 def test_sharded_fit_config3_size_one_rank(ctx):
     """N = 16384 through the sharded entry point on one rank: same result as agp_fit_create."""
     from conftest import synthetic_3d
@@ -104,6 +125,76 @@ def test_sharded_fit_through_rccl_group_of_one(ctx, n, block, monkeypatch):
         comm.close()
 
 
+def test_sharded_fit_config3_size_through_rccl(ctx, monkeypatch):
+    """The multi-rank schedule at BASELINE config 3's size (N = 16384, 512-row blocks, 32 block columns) with every
+    broadcast / all-gather / all-reduce a real RCCL call (communicator of size one): same answer as agp_fit_create on
+    the dataset bench.py times."""
+    from bench import make_dataset
+    monkeypatch.setenv("AGP_SHARD_FORCE_COMM", "1")
+    monkeypatch.delenv("AGP_SHARD_BLOCK", raising=False)
+    comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id())
+    try:
+        x, y = make_dataset(16384, 44)
+        cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+        res = ShardedGaussianProcessFit(ctx, cov, comm).fit(x, y)
+        fit = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y)).get_fit()
+        info = fit.information
+        assert np.abs(res.information - info).max() <= 1e-9 * np.abs(info).max()
+        assert abs(res.log_determinant - fit.log_determinant) <= 1e-9 * abs(fit.log_determinant)
+    finally:
+        comm.close()
+
+
+def _rccl_worker(rank, world, port, n, block, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["AGP_SHARD_BLOCK"] = str(block)
+    os.environ["AGP_COMM_TIMEOUT_S"] = "30"  # a deadlock fails fast
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    torch.cuda.init()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = ab.Context(rank)  # one rank per GPU
+        comm = Communicator.from_torch(ctx, transport="rccl")
+        x, y, yvar = problem(n)
+        cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+        sharded = ShardedGaussianProcessFit(ctx, cov, comm)
+        res = sharded.fit(x, y, yvar)
+        fm = sharded.replicate(ab.gp_from_covariance(cov, context=ctx))
+        xs = np.random.default_rng(3).uniform(0., 10., (64, 3))
+        mine = slice(rank * 64 // world, (rank + 1) * 64 // world)
+        marg = fm.predict(xs[mine]).marginal()
+        out[rank] = (res.information, res.log_determinant, marg.mean, marg.covariance, None)
+        comm.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,block", [(1500, 128), (4096, 256), (6000, 512)])
+def test_sharded_fit_rccl_one_rank_per_gpu(n, block):
+    """The real thing: one rank per GPU, RCCL broadcast / all-gather / all-reduce between them.  Needs >= 2 GPUs (the pool's
+    boxes have one: skipped there, run by whoever has a node)."""
+    ngpu = ab._capi.load().agp_device_count()
+    if ngpu < 2:
+        pytest.skip("needs at least two GPUs")
+    world = min(ngpu, 4)
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    with mpc.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [mpc.Process(target=_rccl_worker, args=(r, world, port, n, block, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        _check_against_oracle(out, world, n, expect_bad=False)
+
+
 def _worker(rank, world, port, n, block, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -143,7 +234,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n,block", [(2, 1500, 128), (3, 2100, 256), (2, 2048, 512)])
+# (4, 4200, 128): 33 block columns over 4 ranks in snake order - every rank is the root of several broadcasts (roots != 0)
+@pytest.mark.parametrize("world,n,block", [(2, 1500, 128), (3, 2100, 256), (2, 2048, 512), (4, 4200, 128)])
 def test_sharded_fit_two_processes_one_gpu(world, n, block):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
@@ -156,21 +248,26 @@ def test_sharded_fit_two_processes_one_gpu(world, n, block):
         for p in procs:
             p.join(300)
             assert p.exitcode == 0
-        x, y, yvar = problem(n)
-        cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
-        ofit = orc.OracleFit(cov, x, y, yvar)
-        xs = np.random.default_rng(3).uniform(0., 10., (64, 3))
-        om, ov = ofit.predict_marginal(xs)
-        mean = np.concatenate([out[r][2] for r in range(world)])
-        var = np.concatenate([out[r][3] for r in range(world)])
-        for r in range(world):
-            info, logdet, _, _, bad = out[r]
-            assert np.abs(info - ofit.information).max() <= 1e-8 * np.abs(ofit.information).max()
-            assert abs(logdet - ofit.log_determinant) <= 1e-6 * n
+        _check_against_oracle(out, world, n, expect_bad=True)
+
+
+def _check_against_oracle(out, world, n, expect_bad):
+    x, y, yvar = problem(n)
+    cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+    ofit = orc.OracleFit(cov, x, y, yvar)
+    xs = np.random.default_rng(3).uniform(0., 10., (64, 3))
+    om, ov = ofit.predict_marginal(xs)
+    mean = np.concatenate([out[r][2] for r in range(world)])
+    var = np.concatenate([out[r][3] for r in range(world)])
+    for r in range(world):
+        info, logdet, _, _, bad = out[r]
+        assert np.abs(info - ofit.information).max() <= 1e-8 * np.abs(ofit.information).max()
+        assert abs(logdet - ofit.log_determinant) <= 1e-6 * n
+        if expect_bad:
             assert bad is not None and f"pivot {n // 2 + 3}" in bad
-        assert np.abs(mean - om).max() <= 1e-8 * np.abs(om).max()
-        assert np.abs(var - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-9
-        assert all(np.array_equal(out[0][0], out[r][0]) for r in range(world))
+    assert np.abs(mean - om).max() <= 1e-8 * np.abs(om).max()
+    assert np.abs(var - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-9
+    assert all(np.array_equal(out[0][0], out[r][0]) for r in range(world))
 
 
 # ---- sparse GP (PITC) with its observations split by group over the ranks (BASELINE configs[4]) ----
@@ -251,6 +348,61 @@ def test_sparse_fit_sharded_by_group(ctx, world, n, m, gs):
             assert abs(nll - ref.get_fit().nll) <= 1e-8 * n and abs(nll - ofit.nll) <= 1e-8 * n and abs(ll + nll) <= 1e-9 * n
             assert np.abs(mean - rm.mean).max() <= 1e-8 and np.abs(var - rm.covariance).max() <= 1e-8
         assert all(np.array_equal(out[0][0], out[r][0]) for r in range(world))
+
+
+def _sparse_error_worker(rank, world, port, case, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.init()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = ab.Context(0)
+        comm = Communicator.from_torch(ctx, transport="callbacks")
+        n, m, gs = 2048, 48, 256
+        x, y, yvar, cov, u = _pitc(n, m, 11)
+        if case == "inducing" and rank == 1:
+            u = u + 1e-3  # a data-dependent inducing-point strategy run on rank-local features would do this
+        model = _sparse_model(ctx, cov, x, u, gs)
+        mine = ((np.arange(n) // gs) % world) == rank
+        xm, ym, vm = x[mine], y[mine].copy(), yvar[mine].copy()
+        if case == "nan" and rank == 1:
+            vm[5] = np.nan  # NaN in ONE rank's own blocks of A
+        if case == "not_pd" and rank == 0:
+            vm[:] = -5.0  # ONE rank's blocks of A are not positive definite
+        try:
+            model.fit(ab.RegressionDataset(xm, ab.MarginalDistribution(ym, vm)), comm=comm)
+            out[rank] = "ok"
+        except ab.AlbatrossAmdError as e:
+            out[rank] = f"{type(e).__name__}: {e}"
+        # the communicator is still usable: every rank left the failed fit at the same point
+        out[rank] += " | " + str(comm.all_reduce([1.0], "sum")[0])
+        comm.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["nan", "not_pd", "inducing"])
+def test_sparse_fit_sharded_rank_local_failure_is_agreed(case):
+    """A failure only ONE rank can see (NaN / a non-positive-definite block among its own groups, different inducing
+    points) must end the collective fit on EVERY rank with an error - not leave the peers inside an all-reduce."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    world = 2
+    with mpc.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [mpc.Process(target=_sparse_error_worker, args=(r, world, port, case, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+            assert p.exitcode == 0
+        for r in range(world):
+            assert not out[r].startswith("ok"), out[r]
+            assert out[r].endswith("| 2.0"), out[r]
 
 
 def test_sparse_fit_sharded_through_rccl_group_of_one(ctx):

@@ -205,7 +205,7 @@ def test_exp_neg_accuracy(ctx):
     import ctypes as C
     import mpmath as mp
     mp.mp.dps = 40
-    lib = ctx._lib
+    lib = ab._capi.load_debug()
     lib.agp_debug_exp_neg.restype = C.c_int
     lib.agp_debug_exp_neg.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     rng = np.random.default_rng(0)

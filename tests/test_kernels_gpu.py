@@ -17,7 +17,7 @@ def _p(a):
 
 @pytest.fixture(scope="module")
 def dbg(ctx):
-    lib = capi.load()
+    lib = capi.load_debug()
     lib.agp_debug_mfma_tile.restype = C.c_int
     lib.agp_debug_mfma_tile.argtypes = [C.c_void_p] * 4
     lib.agp_debug_gemm.restype = C.c_int

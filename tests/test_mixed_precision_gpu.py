@@ -29,7 +29,7 @@ def _p(a):
 @pytest.mark.parametrize("M,K", [(256, 16), (640, 128), (1000, 256), (1418, 512), (130, 32)])
 def test_fp32_product_update_kernel(ctx, M, K):
     """trailing_update_f32_kernel: C(fp64) -= fl32(P) fl32(P)^T with fp32 accumulation inside the launch."""
-    lib = capi.load()
+    lib = capi.load_debug()
     lib.agp_debug_trailing_update.restype = C.c_int
     lib.agp_debug_trailing_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                               C.c_int64, C.c_int]
