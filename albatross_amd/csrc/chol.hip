@@ -50,6 +50,10 @@ struct PotrfArgs {
   double *scalars;
   // batched launches (blockIdx.y = batch entry): element offsets per entry; all 0 = not batched
   long long batch_A = 0, batch_img = 0, batch_y = 0, batch_scalars = 0;
+  // fused panel kernel only: z of this block is also PUBLISHED here (device-scope stores) for the workgroups that solve
+  // the rows below in the same launch; `below` = number of those rows
+  double *zpub = nullptr;
+  long long below = 0;
 };
 
 constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
@@ -66,6 +70,32 @@ constexpr int IMG_DOUBLES = NTILE * MB * MB;  // 9216 doubles = 72 KiB per diago
 // A-operand fragments the substitution kernels need, so they stage it with a
 // straight coalesced copy.
 __device__ __forceinline__ int tile_off(int ib, int kb) { return (ib * (ib + 1) / 2 + kb) * (MB * MB); }
+
+// ---- hand-over of the factored diagonal block INSIDE one launch (panel_fused_kernel) ----------------------------
+// The workgroup that factors the 128 x 128 diagonal block emits its tile image tile by tile while it runs; the
+// workgroups that solve the rows below consume those tiles as they appear.  No flags: the image (and the slot of
+// z_b) is filled with a sentinel bit pattern before the launch, the producer writes every value ONCE with a
+// device-scope store (global_store ... sc1: written through to the memory side, past the XCD-private L2), and a
+// consumer re-reads a fragment with device-scope loads (sc1) until none of its values is the sentinel.  8-byte
+// accesses are single-copy atomic, so a value is either the sentinel or final.  The producer never waits for an
+// acknowledgement - nothing is added to the serial pivot chain - and a consumer waits for exactly the values it is
+// about to multiply.  The sentinel is a NaN payload no arithmetic produces (hardware NaNs are 0x7FF8000000000000).
+constexpr unsigned long long PUB_SENTINEL = 0xFFF8A5A5DEADBEEFull;
+
+__device__ __forceinline__ void store_pub(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_pub(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool is_unpublished(double v) {
+  return (unsigned long long)__double_as_longlong(v) == PUB_SENTINEL;
+}
+
+__global__ __launch_bounds__(256) void fill_sentinel_kernel(double *p, long long count) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) p[i] = __longlong_as_double((long long)PUB_SENTINEL);
+}
 
 // DPP row broadcast on fp64 (gfx90a+ "DPP64": row_newbcast only): every lane reads lane J of its
 // own 16-lane row.  One VALU instruction, no SGPR round trip (v_readlane x2 + use).  The leading
@@ -195,6 +225,7 @@ __device__ __forceinline__ void potrf16_column(double (&a)[MB], double (&w)[MB],
 // POTRF16 + INV16 of one diagonal micro tile by one wave, in registers.
 // Lane ln (= lane & 15) owns row ln of the tile / column ln of the inverse; the four 16-lane
 // rows of the wave compute the same thing.
+template <bool PUB = false>
 __device__ __forceinline__ void micro_potrf_inv(double *D, double *Wout, double *img_diag, int lane, int ln,
                                                 int pivot_base, int &bad_pivot) {
   double a[MB], w[MB], dinv[MB], diag = 0.;
@@ -210,7 +241,8 @@ __device__ __forceinline__ void micro_potrf_inv(double *D, double *Wout, double 
 #pragma unroll
     for (int r = 0; r < MB; ++r) {
       Wout[ln * MB + r] = w[r];
-      img_diag[ln * MB + r] = w[r];
+      if constexpr (PUB) store_pub(img_diag + ln * MB + r, w[r]);
+      else img_diag[ln * MB + r] = w[r];
     }
   }
 }
@@ -262,17 +294,11 @@ __device__ __forceinline__ void micro_syrk_tile2(double *T, int ib0, int kb0, in
   }
 }
 
-__global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
-  // serial panel chain: issue ahead of the bulk-update waves that share this CU
-  __builtin_amdgcn_s_setprio(3);
-  {
-    const long long b = blockIdx.y;
-    p.A += b * p.batch_A;
-    p.img += b * p.batch_img;
-    if (p.y) p.y += b * p.batch_y;
-    p.scalars += b * p.batch_scalars;
-  }
-  __shared__ double T[IMG_DOUBLES + 2 * MB * MB + NB];  // tiles | two inverse buffers | y
+constexpr int POTRF_LDS_DOUBLES = IMG_DOUBLES + 2 * MB * MB + NB;  // tiles | two inverse buffers | y
+
+// PUB: the fused panel kernel - every tile of the image goes out (store_pub) the moment it is final, z_b too
+template <bool PUB>
+__device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
   double *Wc = T + IMG_DOUBLES;
   double *ys = Wc + 2 * MB * MB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -301,7 +327,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
   PT(1);
 
   int bad_pivot = 0;
-  if (wave == 0) micro_potrf_inv(T + tile_off(0, 0), Wc, p.img + tile_off(0, 0), lane, ln, 0, bad_pivot);
+  if (wave == 0) micro_potrf_inv<PUB>(T + tile_off(0, 0), Wc, p.img + tile_off(0, 0), lane, ln, 0, bad_pivot);
   PT(2);
   __syncthreads();
   PT(3);
@@ -319,7 +345,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
       acc0 = mfma16(W[(8 + lg) * MB + ln], X[(8 + lg) * MB + ln], acc0);
       acc1 = mfma16(W[(12 + lg) * MB + ln], X[(12 + lg) * MB + ln], acc1);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) X[(lg + 4 * r) * MB + ln] = acc0[r] + acc1[r];
+      for (int r = 0; r < 4; ++r) {
+        const double x = acc0[r] + acc1[r];
+        X[(lg + 4 * r) * MB + ln] = x;
+        if constexpr (PUB) store_pub(p.img + tile_off(ib, jb) + (lg + 4 * r) * MB + ln, -x);  // final: tile (ib, jb) of L, negated
+      }
     }
     // z_jb = W y_jb  (wave 3; reads precede the write in program order)
     if (wave == 3) {
@@ -337,8 +367,8 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
     if (wave == 0) {
       micro_syrk_tile(T, jb + 1, jb + 1, jb, ln, lg);
       PT(5 + 4 * jb);
-      micro_potrf_inv(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB),
-                      p.img + tile_off(jb + 1, jb + 1), lane, ln, o + MB, bad_pivot);
+      micro_potrf_inv<PUB>(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB),
+                           p.img + tile_off(jb + 1, jb + 1), lane, ln, o + MB, bad_pivot);
       PT(6 + 4 * jb);
     } else {
       const int rem = NMB - 1 - jb;
@@ -376,6 +406,9 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
     PT(7 + 4 * jb);
   }
   PT(40);
+  if constexpr (PUB) {  // z_b first: the workgroups below wait for it, nobody in this launch waits for the write-back of L11
+    if (p.zpub && tid < nbk) store_pub(p.zpub + tid, ys[tid]);
+  }
 
   {
     const int r = tid & 15, c = tid >> 4;
@@ -386,7 +419,9 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
         const int gr = ib * MB + r, gc = kb * MB + c;
         const double v = T[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r];
         if (gr < nbk && gc < nbk && gr >= gc) p.A[(p.k0 + gc) * p.lda + p.k0 + gr] = v;
-        if (ib != kb) p.img[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r] = -v;
+        if constexpr (!PUB) {
+          if (ib != kb) p.img[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r] = -v;
+        }
       }
   }
   if (p.y && tid < nbk) p.y[tid] = ys[tid];
@@ -403,6 +438,20 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
     if (bad_pivot && p.flags[1] == 0) p.flags[1] = (int)(p.k0 + bad_pivot);
   }
   PT(41);
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
+  // serial panel chain: issue ahead of the bulk-update waves that share this CU
+  __builtin_amdgcn_s_setprio(3);
+  {
+    const long long b = blockIdx.y;
+    p.A += b * p.batch_A;
+    p.img += b * p.batch_img;
+    if (p.y) p.y += b * p.batch_y;
+    p.scalars += b * p.batch_scalars;
+  }
+  __shared__ double T[POTRF_LDS_DOUBLES];
+  potrf_diag_body<false>(p, T);
 }
 
 #ifdef AGP_POTRF_TIMING
@@ -556,6 +605,113 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused panel kernel: ONE launch per 128-column panel instead of POTRF -> TRSM.
+//   workgroup 0        factors the diagonal block (potrf_diag_body<true>) and publishes its tile image as it goes
+//   workgroup 1 + i    solves rows [64 i, 64 i + 64) below the block, X <- X L11^-T (+ the fused y -= X z_b), micro
+//                      column by micro column, each as soon as the row of image tiles it needs has appeared
+// Row jb of the image (tiles (jb, 0 .. jb - 1)) is final after micro step jb - 1's TRSM stage of the producer, the
+// inverted diagonal tile (jb, jb) after its look-ahead POTRF16: the consumers run one micro step behind the producer
+// and finish ~1 us after it, instead of starting a 12-40 us kernel after a launch gap.  Consumers keep nothing in
+// LDS and never synchronise: every wave reads its MFMA A-operand fragments straight from L2.
+// Workgroup 0 is dispatched first (workgroups are dispatched in order), so the consumers only ever wait for a
+// workgroup that is already running or will be as soon as a slot of its XCD frees up.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void poll_tiles(const double *img_row, int lane, double (&f)[NMB][4]) {
+  // tiles 0 .. NT - 1 of one image row, as A-operand fragments (f[t][s] = element s * 64 + lane of tile t)
+  while (true) {
+    bool ok = true;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f[t][s] = load_pub(img_row + t * (MB * MB) + s * 64 + lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ok = ok && !is_unpublished(f[t][s]);
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+template <int JB>
+__device__ __forceinline__ void trsm_fused_step(const PotrfArgs &p, int lane, v4d (&Y)[NMB], double *base, bool nok,
+                                                int lg) {
+  if constexpr (JB < NMB) {
+    const double *row = p.img + (JB * (JB + 1) / 2) * (MB * MB);
+    v4d pa[4] = {Y[JB], v4zero(), v4zero(), v4zero()};
+    double f[NMB][4];
+    if constexpr (JB > 0) {
+      poll_tiles<JB>(row, lane, f);
+#pragma unroll
+      for (int ib = 0; ib < JB; ++ib)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pa[s] = mfma16(f[ib][s], Y[ib][s], pa[s]);
+    }
+    const v4d acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+    poll_tiles<1>(row + JB * (MB * MB), lane, f);  // the inverted diagonal tile: the last thing the producer emits for this row
+    v4d po[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) po[s] = mfma16(f[0][s], acc[s], po[s]);
+    const v4d out = (po[0] + po[1]) + (po[2] + po[3]);
+    Y[JB] = out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = JB * MB + lg + 4 * r;
+      if (nok && m < p.nbk) base[m * p.lda] = out[r];
+    }
+    trsm_fused_step<JB + 1>(p, lane, Y, base, nok, lg);
+  }
+}
+
+__device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, lg = lane >> 4;
+  const long long n0 = ((long long)(blockIdx.x - 1) * 4 + wave) * 16;
+  if (n0 >= p.below) return;  // waves are independent: no barrier below
+  const bool nok = n0 + ln < p.below;
+  double *base = p.A + p.k0 * p.lda + (p.k0 + p.nbk) + (n0 + ln);  // X[n][m] at base[m * lda]
+  v4d Y[NMB];
+#pragma unroll
+  for (int jb = 0; jb < NMB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = jb * MB + lg + 4 * r;
+      Y[jb][r] = (nok && m < p.nbk) ? base[m * p.lda] : 0.;
+    }
+  trsm_fused_step<0>(p, lane, Y, base, nok, lg);
+  if (p.y) {
+    // y[n] -= sum_m X[n][m] z[m]: z_b is published when the producer has finished the whole block
+    double part = 0.;
+#pragma unroll
+    for (int jb = 0; jb < NMB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = jb * MB + lg + 4 * r;
+        double z = 0.;
+        if (m < p.nbk) {
+          z = load_pub(p.zpub + m);
+          while (is_unpublished(z)) {
+            __builtin_amdgcn_s_sleep(4);
+            z = load_pub(p.zpub + m);
+          }
+        }
+        part += Y[jb][r] * z;
+      }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (lg == 0 && nok) p.y[p.nbk + n0 + ln] -= part;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ double T[POTRF_LDS_DOUBLES];
+  if (blockIdx.x == 0) potrf_diag_body<true>(p, T);
+  else trsm_fused_body(p);
+}
+
 // In the TRANS staging above the image is indexed t = jb(jb+1)/2 + ib with
 // ib <= jb; for the transposed solve the "row block" of the stored pair is jb
 // and the "column block" ib, i.e. tile (jb, ib) of L, used when solving micro
@@ -592,6 +748,50 @@ static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long
   }
 }
 
+// AGP_PANEL_FUSED=0 switches the fused panel kernel off (POTRF and TRSM as two launches, the round-2 path)
+static bool panel_fused_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("AGP_PANEL_FUSED");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
+static long long fused_below() {
+  static long long v = -1;
+  if (v < 0) {
+    const char *e = getenv("AGP_FUSED_BELOW");
+    v = e ? atoll(e) : 4608;  // scripts/sweep_fused.sh: 2048 .. 4608 best, 8704 and above lose to the two-launch path
+    if (v == 0) v = 1LL << 60;  // 0: always
+  }
+  return v;
+}
+
+// Before the fused panel kernels of one factorisation run: sentinel-fill the tile images of the diagonal blocks
+// [k_begin, k_end) and the z slots of those rows (stream-ordered before the first panel launch on `s`).
+// A no-op (and the two-launch path is used) if the fused kernel is off or the z buffer cannot be allocated.
+void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long long k_begin, long long k_end) {
+  ctx->img_ready = nullptr;
+  if (!panel_fused_enabled() || k_end <= k_begin) return;
+  if (ctx->zpub_cap < k_end) {
+    // grow; the old buffer may still be read by kernels in flight on this context's streams: drain them first
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_zpub) (void)hipFree(ctx->d_zpub);
+    ctx->d_zpub = nullptr;
+    ctx->zpub_cap = 0;
+    const long long cap = (k_end + 4095) / 4096 * 4096;
+    if (hipMalloc(&ctx->d_zpub, sizeof(double) * (size_t)cap) != hipSuccess) { (void)hipGetLastError(); return; }
+    ctx->zpub_cap = cap;
+  }
+  const long long b0 = k_begin / NB, b1 = (k_end + NB - 1) / NB;
+  const long long cnt_img = (b1 - b0) * (long long)IMG_DOUBLES, cnt_z = k_end - k_begin;
+  hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_img + 255) / 256)), dim3(256), 0, s, invd + b0 * (long long)IMG_DOUBLES, cnt_img);
+  hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_z + 255) / 256)), dim3(256), 0, s, ctx->d_zpub + k_begin, cnt_z);
+  ctx->zpub_ready_n = k_end;
+  ctx->img_ready = invd;
+}
+
 // Panel phase of one outer block [K0, kend): for every NB-wide diagonal block
 // POTRF, panel TRSM (with the fused forward substitution on y) and the update
 // of the remaining columns of the outer block.  Everything on stream s.
@@ -610,14 +810,30 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
     if (left_above == 0) left_above = 1LL << 60;  // 0: never
   }
   const bool inner_left = (n - K0) > left_above;
+  // The consumers of the fused kernel hold their slots for the whole POTRF (~30 us): while the bulk update fills the
+  // chip that costs it more than the saved launch (measured: 43.3 -> 41.8 TFLOP/s), so the fused kernel takes over
+  // where the panel chain is the critical path (AGP_FUSED_BELOW remaining rows)
+  const bool fused = panel_fused_enabled() && ctx->d_zpub && ctx->zpub_ready_n >= kend && ctx->img_ready == invd &&
+                     (n - K0) <= fused_below();
   for (long long k = K0; k < kend; k += NB) {
     const int nbk = (int)((n - k < NB) ? n - k : NB);
     if (inner_left && k > K0) {
       const double *P = A + K0 * lda + k;  // rows k.., columns K0..k
       timed_gemm(s, timers, A + k * lda + k, lda, P, P, n - k, nbk, k - K0, false);
     }
-    launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars);
     const long long below = n - (k + nbk);
+    if (fused) {
+      PotrfArgs pa;
+      pa.A = A; pa.lda = lda; pa.k0 = k; pa.nbk = nbk;
+      pa.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+      pa.y = y ? y + k : nullptr;
+      pa.flags = ctx->d_flags; pa.scalars = ctx->d_scalars;
+      pa.zpub = y ? ctx->d_zpub + k : nullptr;
+      pa.below = below > 0 ? below : 0;
+      hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(1 + (pa.below + 63) / 64)), dim3(256), 0, s, pa);
+      if (below <= 0) continue;
+    } else {
+    launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars);
     if (below <= 0) continue;
     TrsmArgs t;
     t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
@@ -631,6 +847,7 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
     const unsigned grid = (unsigned)((below + 63) / 64);
     if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
     else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
+    }
     const long long width = kend - (k + nbk);
     if (width > 0 && !inner_left) {
       const double *P = A + k * lda + (k + nbk);
@@ -641,7 +858,9 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
 
 void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *img,
                         double *y, long long K0, long long kend) {
+  panel_fused_prepare(ctx, s, img, K0, kend);
   panel_phase(ctx, s, A, n, lda, img, y, K0, kend, nullptr);
+  ctx->img_ready = nullptr;
 }
 
 // X (nrows x w, ld) <- X L^-T against an ALREADY FACTORED w x w diagonal block (w <= 512) given by its lower
@@ -722,6 +941,15 @@ static long long throttle_below() {
   return v;
 }
 
+static long long single_below() {
+  static long long v = -1;
+  if (v < 0) {
+    const char *e = getenv("AGP_SINGLE_BELOW");
+    v = e ? atoll(e) : 1536;
+  }
+  return v;
+}
+
 // Remaining size at or below which the bulk updates run on the CU-masked stream (AGP_MASK_BELOW, 0 = never)
 static long long mask_below() {
   static long long v = -1;
@@ -748,10 +976,16 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   const int variant = ctx->update_variant;
   long long kend = K0 + pick_nbo(n, nbo_fixed);
   if (kend > n) kend = n;
+  panel_fused_prepare(ctx, sa, invd, 0, n);
   panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers);
   while (kend < n) {
     long long next_end = kend + pick_nbo(n - kend, nbo_fixed);
     if (next_end > n) next_end = n;
+    // The very end runs on ONE stream: with <= AGP_SINGLE_BELOW rows left the bulk updates are 10-20 us launches, less
+    // than the ~10 us of event record / wait packets that hand each of them to the second stream and back - so the last
+    // outer block spans all remaining columns: U1 covers everything, its panels update the whole trailing triangle
+    // right-looking, nothing leaves the chain stream
+    if (nbo_fixed == 0 && n - kend <= single_below()) next_end = n;
     const long long K = kend - K0;
     const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
@@ -796,6 +1030,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     kend = next_end;
   }
   // the panel stream ran last (its final panel depends on every update)
+  ctx->img_ready = nullptr;
 }
 
 // ---------------------------------------------------------------------------

@@ -88,6 +88,12 @@ struct agp_context {
   // re-fits the same shapes, and hipMalloc / hipFree of several GB per call costs more than some of the stages
   double *pool_sparse = nullptr;
   size_t pool_sparse_bytes = 0;
+  // fused panel kernel (chol.hip: panel_fused_kernel): the slots through which a diagonal block's z_b reaches the
+  // workgroups solving the rows below in the same launch (one per matrix row, sentinel-filled per factorisation), and
+  // which tile-image buffer has been sentinel-filled for the factorisation in progress
+  double *d_zpub = nullptr;
+  long long zpub_cap = 0, zpub_ready_n = 0;
+  const double *img_ready = nullptr;
 };
 
 struct agp_fit {
