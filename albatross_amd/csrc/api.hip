@@ -82,7 +82,12 @@ int agp_context_create(int device_id, agp_context **out) {
     AGP_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi));
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo));
-    AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo));
+    if (getenv("AGP_NO_STREAM3")) ctx->stream3 = ctx->stream2;  // experiment: one stream fewer for the runtime to map
+    else AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo));
+    // the side chain of the factorisation shares stream3: a FOURTH stream of its own changed how the runtime maps streams
+    // onto its few hardware queues and cost 3.5 ms per N = 16384 fit (33.7 -> 37.2 ms) before it was used at all
+    ctx->stream_side = ctx->stream3;
+    AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
     AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
     // CU mask of the end-phase bulk stream: bit i = CU i, and CU i sits on XCD i % 8 (measured with
     // scripts/probe_cumask.py: dropping the LAST indices keeps the XCDs balanced, dropping i % 32 >= 28 does not).
@@ -140,7 +145,8 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->stream3 && ctx->stream3 != ctx->stream2) (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->ev_d) (void)hipEventDestroy(ctx->ev_d);
   if (ctx->stream_masked) (void)hipStreamDestroy(ctx->stream_masked);
   if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
   delete ctx;
@@ -422,6 +428,10 @@ static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevPr
 }
 
 int status_from_flags(const agp_context *ctx) {
+  if (ctx->h_flags[2]) {  // a consumer of the fused panel kernel gave up waiting for its producer (chol.hip)
+    const_cast<agp_context *>(ctx)->last_error = "panel kernel: hand-over of a diagonal block timed out";
+    return AGP_ERR_HIP;
+  }
   if (ctx->h_flags[0]) return AGP_ERR_NAN_INPUT;
   if (ctx->h_flags[1]) return AGP_ERR_NOT_POSITIVE_DEFINITE;
   return AGP_OK;

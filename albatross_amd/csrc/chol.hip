@@ -225,12 +225,12 @@ __device__ __forceinline__ void potrf16_column(double (&a)[MB], double (&w)[MB],
 // POTRF16 + INV16 of one diagonal micro tile by one wave, in registers.
 // Lane ln (= lane & 15) owns row ln of the tile / column ln of the inverse; the four 16-lane
 // rows of the wave compute the same thing.
+// `a` holds row ln of the (updated) diagonal tile.  Results: the tile of L into D (LDS), its inverse into Wout (LDS) and
+// img_diag (the tile image; PUB: published, see above).
 template <bool PUB = false>
-__device__ __forceinline__ void micro_potrf_inv(double *D, double *Wout, double *img_diag, int lane, int ln,
-                                                int pivot_base, int &bad_pivot) {
-  double a[MB], w[MB], dinv[MB], diag = 0.;
-#pragma unroll
-  for (int c = 0; c < MB; ++c) a[c] = D[c * MB + ln];
+__device__ __forceinline__ void micro_potrf_inv_regs(double (&a)[MB], double *D, double *Wout, double *img_diag, int lane,
+                                                     int ln, int pivot_base, int &bad_pivot) {
+  double w[MB], dinv[MB], diag = 0.;
 #pragma unroll
   for (int r = 0; r < MB; ++r) w[r] = (ln == r) ? 1. : 0.;
   potrf16_column<0>(a, w, dinv, diag, ln, pivot_base, bad_pivot);
@@ -245,6 +245,18 @@ __device__ __forceinline__ void micro_potrf_inv(double *D, double *Wout, double 
       else img_diag[ln * MB + r] = w[r];
     }
   }
+}
+
+// POTRF16 + INV16 of one diagonal micro tile by one wave, in registers.
+// Lane ln (= lane & 15) owns row ln of the tile / column ln of the inverse; the four 16-lane
+// rows of the wave compute the same thing.
+template <bool PUB = false>
+__device__ __forceinline__ void micro_potrf_inv(double *D, double *Wout, double *img_diag, int lane, int ln, int pivot_base,
+                                                int &bad_pivot) {
+  double a[MB];
+#pragma unroll
+  for (int c = 0; c < MB; ++c) a[c] = D[c * MB + ln];
+  micro_potrf_inv_regs<PUB>(a, D, Wout, img_diag, lane, ln, pivot_base, bad_pivot);
 }
 
 __device__ __forceinline__ void micro_syrk_tile(double *T, int ib, int kb, int jb, int ln, int lg) {
@@ -306,6 +318,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
   const int nbk = p.nbk;
   PT(0);
 
+  double *Adiag = p.A + p.k0 * p.lda + p.k0;  // element (r, c) of the block at Adiag[c * lda + r]
   {  // thread (r, c) of every tile; all 36 loads in flight
     const int r = tid & 15, c = tid >> 4;
     double v[NTILE];
@@ -315,7 +328,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
       for (int kb = 0; kb <= ib; ++kb) {
         const int gr = ib * MB + r, gc = kb * MB + c;
         double x;
-        if (gr < nbk && gc < nbk) x = (gr >= gc) ? p.A[(p.k0 + gc) * p.lda + p.k0 + gr] : 0.;
+        if (gr < nbk && gc < nbk) x = (gr >= gc) ? Adiag[gc * p.lda + gr] : 0.;
         else x = (gr == gc) ? 1. : 0.;  // identity padding of a partial last block
         v[ib * (ib + 1) / 2 + kb] = x;
       }
@@ -346,9 +359,10 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
       acc1 = mfma16(W[(12 + lg) * MB + ln], X[(12 + lg) * MB + ln], acc1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double x = acc0[r] + acc1[r];
+        const double x = acc0[r] + acc1[r];  // final: element (ln, lg + 4 r) of tile (ib, jb) of L (the image holds -L)
         X[(lg + 4 * r) * MB + ln] = x;
-        if constexpr (PUB) store_pub(p.img + tile_off(ib, jb) + (lg + 4 * r) * MB + ln, -x);  // final: tile (ib, jb) of L, negated
+        if constexpr (PUB) store_pub(p.img + tile_off(ib, jb) + (lg + 4 * r) * MB + ln, -x);
+        else p.img[tile_off(ib, jb) + (lg + 4 * r) * MB + ln] = -x;
       }
     }
     // z_jb = W y_jb  (wave 3; reads precede the write in program order)
@@ -367,8 +381,8 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
     if (wave == 0) {
       micro_syrk_tile(T, jb + 1, jb + 1, jb, ln, lg);
       PT(5 + 4 * jb);
-      micro_potrf_inv<PUB>(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB),
-                           p.img + tile_off(jb + 1, jb + 1), lane, ln, o + MB, bad_pivot);
+      micro_potrf_inv<PUB>(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB), p.img + tile_off(jb + 1, jb + 1),
+                           lane, ln, o + MB, bad_pivot);
       PT(6 + 4 * jb);
     } else {
       const int rem = NMB - 1 - jb;
@@ -410,18 +424,14 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
     if (p.zpub && tid < nbk) store_pub(p.zpub + tid, ys[tid]);
   }
 
-  {
+  {  // L11 back into the matrix: thread (r, c) of every tile
     const int r = tid & 15, c = tid >> 4;
 #pragma unroll
     for (int ib = 0; ib < NMB; ++ib)
 #pragma unroll
       for (int kb = 0; kb <= ib; ++kb) {
         const int gr = ib * MB + r, gc = kb * MB + c;
-        const double v = T[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r];
-        if (gr < nbk && gc < nbk && gr >= gc) p.A[(p.k0 + gc) * p.lda + p.k0 + gr] = v;
-        if constexpr (!PUB) {
-          if (ib != kb) p.img[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r] = -v;
-        }
+        if (gr < nbk && gc < nbk && gr >= gc) Adiag[gc * p.lda + gr] = T[(ib * (ib + 1) / 2 + kb) * (MB * MB) + c * MB + r];
       }
   }
   if (p.y && tid < nbk) p.y[tid] = ys[tid];
@@ -617,10 +627,22 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
 // Workgroup 0 is dispatched first (workgroups are dispatched in order), so the consumers only ever wait for a
 // workgroup that is already running or will be as soon as a slot of its XCD frees up.
 // ---------------------------------------------------------------------------------------------------------------
+// A consumer never spins for ever: after ~2 s (s_memrealtime, 100 MHz) without the values it waits for it records the
+// failure in flags[2] and carries on with whatever it has read - the host turns that flag into AGP_ERR_HIP instead of
+// the launch hanging the GPU (that can only happen if the producer workgroup died).
+constexpr unsigned long long PUB_TIMEOUT_TICKS = 200000000ull;
+
+__device__ __forceinline__ bool poll_expired(unsigned long long t0, int *flags) {
+  if (__builtin_amdgcn_s_memrealtime() - t0 < PUB_TIMEOUT_TICKS) return false;
+  if ((threadIdx.x & 63) == 0) atomicExch(flags + 2, 1);
+  return true;
+}
+
 template <int NT>
-__device__ __forceinline__ void poll_tiles(const double *img_row, int lane, double (&f)[NMB][4]) {
+__device__ __forceinline__ void poll_tiles(const double *img_row, int lane, double (&f)[NMB][4], int *flags) {
   // tiles 0 .. NT - 1 of one image row, as A-operand fragments (f[t][s] = element s * 64 + lane of tile t)
-  while (true) {
+  unsigned long long t0 = 0;
+  for (int spin = 0;; ++spin) {
     bool ok = true;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -631,6 +653,8 @@ __device__ __forceinline__ void poll_tiles(const double *img_row, int lane, doub
 #pragma unroll
       for (int s = 0; s < 4; ++s) ok = ok && !is_unpublished(f[t][s]);
     if (__all(ok)) break;
+    if (spin == 0) t0 = __builtin_amdgcn_s_memrealtime();
+    else if ((spin & 63) == 0 && poll_expired(t0, flags)) break;
     __builtin_amdgcn_s_sleep(4);
   }
 }
@@ -643,14 +667,14 @@ __device__ __forceinline__ void trsm_fused_step(const PotrfArgs &p, int lane, v4
     v4d pa[4] = {Y[JB], v4zero(), v4zero(), v4zero()};
     double f[NMB][4];
     if constexpr (JB > 0) {
-      poll_tiles<JB>(row, lane, f);
+      poll_tiles<JB>(row, lane, f, p.flags);
 #pragma unroll
       for (int ib = 0; ib < JB; ++ib)
 #pragma unroll
         for (int s = 0; s < 4; ++s) pa[s] = mfma16(f[ib][s], Y[ib][s], pa[s]);
     }
     const v4d acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
-    poll_tiles<1>(row + JB * (MB * MB), lane, f);  // the inverted diagonal tile: the last thing the producer emits for this row
+    poll_tiles<1>(row + JB * (MB * MB), lane, f, p.flags);  // the inverted diagonal tile: the last thing the producer emits for this row
     v4d po[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
 #pragma unroll
     for (int s = 0; s < 4; ++s) po[s] = mfma16(f[0][s], acc[s], po[s]);
@@ -692,9 +716,16 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p) {
         double z = 0.;
         if (m < p.nbk) {
           z = load_pub(p.zpub + m);
-          while (is_unpublished(z)) {
-            __builtin_amdgcn_s_sleep(4);
-            z = load_pub(p.zpub + m);
+          if (is_unpublished(z)) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (int spin = 1; is_unpublished(z); ++spin) {
+              if ((spin & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 >= PUB_TIMEOUT_TICKS) {
+                atomicExch(p.flags + 2, 1);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(4);
+              z = load_pub(p.zpub + m);
+            }
           }
         }
         part += Y[jb][r] * z;
@@ -796,7 +827,7 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
 // POTRF, panel TRSM (with the fused forward substitution on y) and the update
 // of the remaining columns of the outer block.  Everything on stream s.
 static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *invd,
-                        double *y, long long K0, long long kend, FactorTimers *timers) {
+                        double *y, long long K0, long long kend, FactorTimers *timers, hipEvent_t after_first = nullptr) {
   // AGP_INNER_LEFT=1: left-looking inside the outer block - panel k is brought up to date with the panels
   // [K0, k) of this outer block in ONE product of depth k - K0 just before it is factored, instead of every
   // panel updating all later columns of the outer block with depth 128 (same flop, a third of the C traffic,
@@ -848,6 +879,9 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
     if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
     else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
     }
+    // the columns right of the first panel receive the rest of U1 on the side stream (factor_lower): nothing of this
+    // outer block may touch them before that has finished
+    if (after_first && k == K0) (void)hipStreamWaitEvent(s, after_first, 0);
     const long long width = kend - (k + nbk);
     if (width > 0 && !inner_left) {
       const double *P = A + k * lda + (k + nbk);
@@ -941,6 +975,15 @@ static long long throttle_below() {
   return v;
 }
 
+static long long u1_split_below() {
+  static long long v = -1;
+  if (v < 0) {
+    const char *e = getenv("AGP_U1_SPLIT_BELOW");
+    v = e ? atoll(e) : 0;  // off: measured 33.8-34.0 against 33.75 ms (the event packets cost what the overlap gains)
+  }
+  return v;
+}
+
 static long long single_below() {
   static long long v = -1;
   if (v < 0) {
@@ -990,8 +1033,22 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
     if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);   // U2(j - 1) done
-    // U1: block column [kend, next_end), all rows below its diagonal
-    timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
+    // U1: block column [kend, next_end), all rows below its diagonal.  In the chain-bound phase only its first 128
+    // columns - all the next diagonal block and its panel wait for - stay on the chain; the other columns go to the side
+    // stream and are awaited right after the first panel kernel of P(j + 1) (AGP_U1_SPLIT_BELOW remaining rows).
+    hipEvent_t after_first = nullptr;
+    if (ctx->stream_side && next_end - kend > NB && (n - kend) <= u1_split_below()) {
+      hipStream_t sc = ctx->stream_side;
+      (void)hipStreamWaitEvent(sc, ctx->ev_a, 0);
+      if (have_u2) (void)hipStreamWaitEvent(sc, ctx->ev_b, 0);
+      timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, NB, K, false);
+      const double *P2 = P + NB;  // rows kend + NB .. of the panel
+      timed_gemm(sc, timers, A + (kend + NB) * lda + (kend + NB), lda, P2, P2, n - kend - NB, next_end - kend - NB, K, false);
+      (void)hipEventRecord(ctx->ev_d, sc);
+      after_first = ctx->ev_d;
+    } else {
+      timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
+    }
     // Chain-bound phase (few rows left): a stream that sits at an UNSATISFIED hipStreamWaitEvent slows every dependent
     // launch of the other streams (measured, scripts/probe_chain.py: the panel chain takes 121 instead of 44 us per 128
     // columns while another stream waits on an event) - and here the bulk stream would wait for the panel chain all the
@@ -1006,7 +1063,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     if (sb != sb_prev && have_u2) (void)hipStreamWaitEvent(sb, ctx->ev_b, 0);  // U2(j - 1) ran on the other bulk stream
     sb_prev = sb;
     const bool throttle = next_end < n && (n - kend) <= throttle_below();
-    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers);
+    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first);
     if (next_end < n) {
       if (throttle) {
         while (hipEventQuery(ctx->ev_a) == hipErrorNotReady) {}
@@ -1025,7 +1082,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     } else {
       have_u2 = false;
     }
-    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers);
+    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first);
     K0 = kend;
     kend = next_end;
   }

@@ -59,6 +59,9 @@ struct agp_context {
   // factorisation the bulk updates run here and leave a few CUs per XCD to the panel chain (chol.hip: factor_lower)
   hipStream_t stream_masked = nullptr;
   hipEvent_t ev_c = nullptr;
+  // side chain of the factorisation (high priority): the part of U1 the next diagonal block does not wait for
+  hipStream_t stream_side = nullptr;
+  hipEvent_t ev_d = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   std::vector<hipEvent_t> ev_pool;
   std::string last_error;

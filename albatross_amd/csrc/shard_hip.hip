@@ -390,7 +390,9 @@ struct HipShardOps : ShardOps {
     (void)hipMemcpy(scal, ctx->d_scalars, sizeof(scal), hipMemcpyDeviceToHost);
     out[0] = scal[0];
     out[1] = (double)flags[1];
+    handover_timeout = flags[2] != 0;
   }
+  bool handover_timeout = false;  // a consumer of the fused panel kernel gave up waiting (chol.hip): the factor is garbage
   int to_host(int q, const double *dev, double *host, long long count) override {
     if (hipMemcpyAsync(host, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, sq[q]) != hipSuccess) return AGP_ERR_HIP;
     return wait_stream(ctx, sq[q], timeout_s);
@@ -680,6 +682,7 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
     res.log_det = 2. * ctx->h_scalars[0];
     res.bad_pivot = ctx->h_flags[1] ? (long long)ctx->h_flags[1] - 1 : -1;
     st = res.bad_pivot >= 0 ? AGP_ERR_NOT_POSITIVE_DEFINITE : AGP_OK;
+    if (ctx->h_flags[2]) { agp_sharded_fit_destroy(f); return status_from_flags(ctx); }
     if (st == AGP_OK) {
       SFIT_CHECK(hipMemcpyAsync(f->buf.xfull, f->y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
       const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * backsolve_ws_elems(n));
@@ -704,6 +707,10 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
     HipShardOps ops(ctx);
     if (!ops.ok) { agp_sharded_fit_destroy(f); ctx->last_error = "stream / event creation failed"; return AGP_ERR_HIP; }
     st = shard_factor_solve(ops, tr, plan, f->A, f->ld, f->y, f->buf, &res);
+    if (ops.handover_timeout && (st == AGP_OK || st == AGP_ERR_NOT_POSITIVE_DEFINITE)) {
+      ctx->last_error = "panel kernel: hand-over of a diagonal block timed out";
+      st = AGP_ERR_HIP;
+    }
     f->stage[6] = res.enqueue_factor_ms + res.enqueue_solve_ms;
     f->stage[7] = res.total_ms;
     if (ctx->profiling) {

@@ -59,7 +59,9 @@ def test_mixed_fit_matches_oracle(ctx, n):
     fm = model.fit(ab.RegressionDataset(x, y))
     its, res = model.refinement_
     ofit = orc.OracleFit(cov, ab.FeatureSet(x), y)
-    assert res <= 1e-12 and its >= 1, (its, res)
+    # (up to 1536 rows the factorisation has no bulk update at all - chol.hip: single_below - so nothing is rounded to fp32
+    # and the first solve already meets the tolerance)
+    assert res <= 1e-12 and (its >= 1 or n <= 1536), (its, res)
     assert rel(fm.get_fit().information, ofit.information) <= 1e-8
     xs, _ = synthetic_3d(200, 77)
     om, ov = ofit.predict_marginal(ab.FeatureSet(xs))
