@@ -70,6 +70,39 @@ __device__ __forceinline__ double exp_neg(double t) {
   return __builtin_ldexp(p, (int)kf);
 }
 
+// acos(x) for the angular metric (distance_metrics.hpp:64-90).  The library acos is 93 VALU instructions, 26 of them
+// v_mov of literals; this one is ~45: branch-free argument reduction to z in [0, 1/4] (|x| >= 1/2: z = (1 - |x|) / 2,
+// exact by Sterbenz, acos = 2 asin(sqrt z) or pi - that; |x| < 1/2: z = x^2, acos = pi/2 - asin x), asin(sqrt z) =
+// sqrt z (1 + z R(z)) with a degree-12 polynomial R (Chebyshev interpolant of (asin(sqrt z) / sqrt z - 1) / z on
+// [0, 1/4], relative error 5e-18; coefficients in SCALAR registers, one v_fma_f64 per step) and a correctly rounded
+// sqrt.  <= 1.1 ulp against the correctly rounded value (tests/test_gram_gpu.py::test_acos_fast_accuracy against
+// mpmath).  Inputs outside [-1, 1] and NaN give NaN like acos.
+__device__ __forceinline__ double acos_fast(double x) {
+  const double ax = fabs(x);
+  const bool big = ax >= 0.5;
+  const double z = big ? (1.0 - ax) * 0.5 : x * x;
+  double p = 0.028757851367421566;
+  p = horner_step(p, z, -0.014851887071247204);
+  p = horner_step(p, z, 0.01740087944269402);
+  p = horner_step(p, z, 0.005457506718640358);
+  p = horner_step(p, z, 0.01032281435018578);
+  p = horner_step(p, z, 0.011479177415184906);
+  p = horner_step(p, z, 0.013971212973552933);
+  p = horner_step(p, z, 0.017352392720869973);
+  p = horner_step(p, z, 0.02237217294214989);
+  p = horner_step(p, z, 0.030381944138531247);
+  p = horner_step(p, z, 0.04464285714635543);
+  p = horner_step(p, z, 0.07499999999998433);
+  p = horner_step(p, z, 0.16666666666666669);
+  const double r = z * p;
+  const double s = sqrt(z);                      // NaN for |x| > 1
+  const double t = __builtin_fma(s, r, s);       // asin(sqrt z)
+  const double two_t = t + t;
+  const double res_big = (x > 0.) ? two_t : 3.14159265358979311600e+00 - (two_t - 1.22464679914735317720e-16);
+  const double res_small = 1.57079632679489655800e+00 - (x - (6.12323399573676603587e-17 - x * r));
+  return big ? res_big : res_small;
+}
+
 // The evaluation stack is an 8-wide fp64 vector indexed by the wave-uniform
 // stack pointer: the backend lowers that to VGPR-indexed moves (no scratch,
 // no LDS), which a plain `double st[8]` does not get.
@@ -107,7 +140,7 @@ __device__ __forceinline__ double eval_pair(const DevProgram *__restrict__ Pp, c
     for (int d = 0; d < DIMP; ++d) dot += x.c[d] * y.c[d];
     const double c = dot / (x.norm * y.norm);
     const double eps = 1e-16;  // EPSILON, distance_metrics.hpp:18
-    d_angular = (c > 1. - eps) ? 0. : ((c < -1. + eps) ? M_PI : acos(c));
+    d_angular = (c > 1. - eps) ? 0. : ((c < -1. + eps) ? M_PI : acos_fast(c));
   }
   bool equal = false;
   if (P.uses_equality) {
@@ -282,7 +315,7 @@ __device__ __forceinline__ void eval_sop_n(const SopProgram &P, const Point<DIMP
       for (int d = 0; d < DIMP; ++d) dot += x.c[d] * y.c[d];
       const double c = dot / (x.norm * y.norm);
       const double eps = 1e-16;  // EPSILON, distance_metrics.hpp:18
-      d_angular[p] = (c > 1. - eps) ? 0. : ((c < -1. + eps) ? M_PI : acos(c));
+      d_angular[p] = (c > 1. - eps) ? 0. : ((c < -1. + eps) ? M_PI : acos_fast(c));
     }
     equal[p] = false;
     if (P.uses_equality) {

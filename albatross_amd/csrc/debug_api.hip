@@ -211,6 +211,24 @@ extern "C" AGP_DEBUG_API int agp_debug_exp_neg(agp_context *ctx, const double *t
   return AGP_OK;
 }
 
+// acos_fast (cov_eval.h) on an array: accuracy test against the correctly rounded acos
+__global__ void acos_fast_kernel(const double *t, double *out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = agp::acos_fast(t[i]);
+}
+extern "C" AGP_DEBUG_API int agp_debug_acos_fast(agp_context *ctx, const double *t, int64_t n, double *out) {
+  if (!ctx || !t || !out || n <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  double *d = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&d, sizeof(double) * 2 * (size_t)n));
+  AGP_HIP_CHECK(ctx, hipMemcpy(d, t, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(acos_fast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, d + n, (long long)n);
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  AGP_HIP_CHECK(ctx, hipMemcpy(out, d + n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return AGP_OK;
+}
+
 // ---- launch-chain latency probe ------------------------------------------------------------------------------
 // Synthetic kernels with a chosen static LDS footprint: every workgroup writes a little, then spins `spin` shader
 // clocks.  Used to find out what a dependent launch costs on this part when consecutive kernels of one stream

@@ -370,6 +370,229 @@ static bool sop_enabled() {
   return !(e && e[0] == '0');
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second fast path: sums of AT MOST three terms of fixed kinds,
+//     [ScalingTerm * Constant]  +  [IndependentNoise | Nugget]  +  radial<metric A> [* radial<metric B>]
+// with any of the four radial kernels over any of the three metrics, each term optionally measurement-only - the
+// temperature example's tree (ScalingTerm<Elevation> * Constant + IndependentNoise + Exponential<Angular> *
+// SquaredExponential<Radial>, examples/temperature_example/temperature_example.cc:34-85), or one radial leaf over a
+// non-Euclidean metric.  Same arithmetic as the sum-of-products evaluator (cov_eval.h: eval_sop_n - distances, factor
+// order, one exp per product, the `lhs != 0` short circuit, the order of the sum), but the shape is fixed: no term /
+// factor loop, no scalar loads of the program per pair, and only the point data the tree needs goes through LDS.
+// ---------------------------------------------------------------------------------------------------------------
+struct Pair2Params {
+  int n_rad;                 // radial leaves in the product (1 or 2)
+  int op[2], metric[2];
+  double a[2], b[2];         // sigma^2 and scale / l of each leaf (b = 0: the leaf is 0, radial.hpp:26-28)
+  int rad_meas_only;
+  int has_rank1;             // a term made of ScalingTerm and / or Constant factors
+  int rank1_scaling, rank1_const, rank1_const_first, rank1_col, rank1_meas_only;
+  double rank1_c2;
+  int has_noise, noise_meas_only;
+  double noise_var;
+  int order[3];              // kind of the 1st, 2nd, 3rd term of the sum: 0 radial, 1 rank-1, 2 noise, -1 none
+  int metric_mask;
+};
+
+__device__ __forceinline__ void pair2_leaf(int op, double q, double a, double b, double &v, double &expo) {
+  double coef = a;
+  if (op == AGP_OP_SQUARED_EXPONENTIAL) expo += q * q;
+  else if (op == AGP_OP_EXPONENTIAL) expo += fabs(q);
+  else if (op == AGP_OP_MATERN32) { coef = coef * (1 + q); expo += q; }
+  else { coef = coef * (1 + q + q * q * (1. / 3.)); expo += q; }
+  const double f = (b > 0.) ? coef : 0.;
+  v = (v != 0.) ? v * f : v;
+}
+
+template <int DIMP, bool EUCLID, bool ANGULAR>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_pair2_kernel(Pair2Params pp, FeatView X, FeatView Y, int lower_only,
+                                                                  double *out, long long ld, const double *diag_add,
+                                                                  int *nan_flag) {
+  __shared__ double xs[DIMP][TM], ys[DIMP][TN], xnorm[TM], ynorm[TN], xsc[TM], ysc[TN];
+  __shared__ long long xid[TM], yid[TN];
+  const long long row0 = (long long)blockIdx.x * TM;
+  const long long col0 = (long long)blockIdx.y * TN;
+  if (lower_only && col0 > row0 + TM - 1) return;
+  const bool have_ids = X.ids != nullptr && Y.ids != nullptr;
+  const bool need_norm = (pp.metric_mask & ((1 << AGP_METRIC_RADIAL) | (1 << AGP_METRIC_ANGULAR))) != 0;
+  for (int t = threadIdx.x; t < TM + TN; t += GRAM_THREADS) {
+    const bool isx = t < TM;
+    const FeatView &F = isx ? X : Y;
+    const long long g = isx ? row0 + t : col0 + (t - TM);
+    const bool ok = g < F.n;
+    double nn = 0.;
+#pragma unroll
+    for (int d = 0; d < DIMP; ++d) {
+      const double v = (ok && d < F.dim) ? F.coords[g * F.dim + d] : 0.;
+      nn += v * v;
+      if (isx) xs[d][t] = v; else ys[d][t - TM] = v;
+    }
+    const double nrm = need_norm ? sqrt(nn) : 0.;
+    const double sc = (ok && pp.rank1_scaling && pp.rank1_col < F.nsc) ? F.scales[(long long)pp.rank1_col * scale_stride(F) + g] : 0.;
+    const long long id = (ok && F.ids) ? F.ids[g] : -1;
+    if (isx) { xnorm[t] = nrm; xsc[t] = sc; xid[t] = id; }
+    else { ynorm[t - TM] = nrm; ysc[t - TM] = sc; yid[t - TM] = id; }
+  }
+  __syncthreads();
+  const int lane_row = 2 * (threadIdx.x & 63);
+  const int cgrp = threadIdx.x >> 6;
+  double xa[DIMP], xb[DIMP];
+#pragma unroll
+  for (int d = 0; d < DIMP; ++d) { xa[d] = xs[d][lane_row]; xb[d] = xs[d][lane_row + 1]; }
+  const double na = xnorm[lane_row], nb = xnorm[lane_row + 1];
+  const double sca = xsc[lane_row], scb = xsc[lane_row + 1];
+  const long long ida = xid[lane_row], idb = xid[lane_row + 1];
+  const long long ra = row0 + lane_row, rb = ra + 1;
+  const bool wide = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const bool both_meas = X.meas && Y.meas;
+  const bool rad_on = !pp.rad_meas_only || both_meas;
+  const bool rank1_on = pp.has_rank1 && (!pp.rank1_meas_only || both_meas);
+  const bool noise_on = pp.has_noise && (!pp.noise_meas_only || both_meas);
+  const bool use_radial = (pp.metric_mask & (1 << AGP_METRIC_RADIAL)) != 0;
+  const bool need_eq = pp.has_noise && !have_ids;  // equality of all coordinates by value (noise.hpp:37-43)
+  bool saw_nan = false;
+  for (int jj = 0; jj < TN / 4; ++jj) {
+    const int cslot = cgrp * (TN / 4) + jj;
+    const long long col = col0 + cslot;
+    if (col >= Y.n) break;
+    const double ny = ynorm[cslot];
+    double val[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double *xp = h ? xb : xa;
+      const double nx = h ? nb : na;
+      double d_e = 0., d_r = 0., d_a = 0.;
+      bool eq = true;
+      double ssq = 0., dot = 0.;
+#pragma unroll
+      for (int d = 0; d < DIMP; ++d) {
+        const double yd = ys[d][cslot];
+        if (EUCLID) {
+          const double t = xp[d] - yd;
+          ssq += t * t;
+        }
+        if (ANGULAR) dot += xp[d] * yd;
+        if (need_eq) eq = eq && (xp[d] == yd);
+      }
+      if (EUCLID) d_e = (DIMP == 1) ? fabs(xp[0] - ys[0][cslot]) : sqrt(ssq);
+      if (use_radial) d_r = fabs(nx - ny);
+      if (ANGULAR) {
+        const double c = dot / (nx * ny);
+        const double eps = 1e-16;  // EPSILON, distance_metrics.hpp:18
+        d_a = (c > 1. - eps) ? 0. : ((c < -1. + eps) ? M_PI : acos_fast(c));
+      }
+      if (have_ids) eq = (h ? idb : ida) == yid[cslot];
+      // the terms, each exactly as eval_sop_n forms it
+      double t_rad = 0., t_rank1 = 0., t_noise = 0.;
+      if (rad_on) {
+        double v = 1., expo = 0.;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (i < pp.n_rad) {
+            const double dist = pp.metric[i] == AGP_METRIC_EUCLIDEAN ? d_e : (pp.metric[i] == AGP_METRIC_RADIAL ? d_r : d_a);
+            pair2_leaf(pp.op[i], dist * pp.b[i], pp.a[i], pp.b[i], v, expo);
+          }
+        }
+        t_rad = (v != 0.) ? v * exp_neg(expo) : v;
+      }
+      if (rank1_on) {
+        double v = 1.;
+        const double ff = (h ? scb : sca) * ysc[cslot];
+        if (pp.rank1_const && pp.rank1_const_first) v = v * pp.rank1_c2;
+        if (pp.rank1_scaling) v = (v != 0.) ? v * ff : v;
+        if (pp.rank1_const && !pp.rank1_const_first) v = (v != 0.) ? v * pp.rank1_c2 : v;
+        t_rank1 = v;
+      }
+      if (noise_on) t_noise = eq ? pp.noise_var : 0.;
+      double acc = 0.;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int kind = pp.order[k];
+        // (a measurement-only term that is off is skipped by eval_sop_n: adding its 0 here gives the same sum)
+        if (kind == 0) acc += t_rad;
+        else if (kind == 1) acc += t_rank1;
+        else if (kind == 2) acc += t_noise;
+      }
+      val[h] = acc;
+    }
+    double va = val[0], vb = val[1];
+    if (diag_add) {
+      if (ra == col) va += diag_add[col];
+      if (rb == col) vb += diag_add[col];
+    }
+    saw_nan = saw_nan || (ra < X.n && va != va) || (rb < X.n && vb != vb);
+    double *dst = out + col * ld + ra;
+    if (rb < X.n) {
+      if (wide) *reinterpret_cast<double2 *>(dst) = make_double2(va, vb);
+      else { dst[0] = va; dst[1] = vb; }
+    } else if (ra < X.n) {
+      dst[0] = va;
+    }
+  }
+  if (saw_nan && nan_flag) atomicOr(nan_flag, 1);
+}
+
+// Is the sum-of-products form of the tree one of the shapes above?
+static bool match_pair2(const SopProgram &S, Pair2Params *pp) {
+  std::memset(pp, 0, sizeof(*pp));
+  pp->order[0] = pp->order[1] = pp->order[2] = -1;
+  if (S.n_terms < 1 || S.n_terms > 3) return false;
+  bool have_rad = false;
+  for (int ti = 0; ti < S.n_terms; ++ti) {
+    const SopTerm &T = S.t[ti];
+    const int op0 = T.f[0].packed & 0xff;
+    if (op0 <= AGP_OP_MATERN52) {
+      if (have_rad || T.n_factors > 2) return false;
+      for (int fi = 0; fi < T.n_factors; ++fi) {
+        const SopFactor &F = T.f[fi];
+        const int op = F.packed & 0xff;
+        if (op > AGP_OP_MATERN52) return false;
+        pp->op[fi] = op;
+        pp->metric[fi] = (F.packed >> 8) & 0xff;
+        pp->a[fi] = F.a;
+        pp->b[fi] = F.b;
+      }
+      pp->n_rad = T.n_factors;
+      pp->rad_meas_only = T.measurement_only;
+      have_rad = true;
+      pp->order[ti] = 0;
+    } else if (op0 == AGP_OP_INDEPENDENT_NOISE || op0 == AGP_OP_NUGGET) {
+      if (pp->has_noise || T.n_factors != 1) return false;
+      pp->has_noise = 1;
+      pp->noise_var = T.f[0].a;
+      pp->noise_meas_only = T.measurement_only;
+      pp->order[ti] = 2;
+    } else if (op0 == AGP_OP_SCALING || op0 == AGP_OP_CONSTANT) {
+      if (pp->has_rank1 || T.n_factors > 2) return false;
+      for (int fi = 0; fi < T.n_factors; ++fi) {
+        const SopFactor &F = T.f[fi];
+        const int op = F.packed & 0xff;
+        if (op == AGP_OP_SCALING) {
+          if (pp->rank1_scaling) return false;
+          pp->rank1_scaling = 1;
+          pp->rank1_col = (F.packed >> 16) & 0xff;
+        } else if (op == AGP_OP_CONSTANT) {
+          if (pp->rank1_const) return false;
+          pp->rank1_const = 1;
+          pp->rank1_c2 = F.a;
+          pp->rank1_const_first = fi == 0;
+        } else {
+          return false;
+        }
+      }
+      pp->has_rank1 = 1;
+      pp->rank1_meas_only = T.measurement_only;
+      pp->order[ti] = 1;
+    } else {
+      return false;
+    }
+  }
+  if (!have_rad) return false;
+  pp->metric_mask = 0;
+  for (int i = 0; i < pp->n_rad; ++i) pp->metric_mask |= 1 << pp->metric[i];
+  return true;
+}
+
 template <int DIMP>
 static void launch_gram_t(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y,
                           bool symmetric, bool lower_only, double *out, long long ld,
@@ -407,6 +630,31 @@ void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const Fe
       else if (dim == 2) done = launch_gram_fast_t<2>(s, fp, op, X, Y, lower_only, out, ld, diag_add, nan_flag);
       else done = launch_gram_fast_t<3>(s, fp, op, X, Y, lower_only, out, ld, diag_add, nan_flag);
       if (done) return;
+    }
+  }
+  if (host_program && dim <= 3 && sop_enabled()) {
+    // (every term of these shapes is bitwise symmetric in its arguments too)
+    const char *e = getenv("AGP_GRAM_PAIR2");
+    SopProgram sop;
+    Pair2Params pp;
+    if (!(e && e[0] == '0') && build_sop(*host_program, &sop) && match_pair2(sop, &pp)) {
+      dim3 grid((unsigned)((X.n + TM - 1) / TM), (unsigned)((Y.n + TN - 1) / TN)), block(GRAM_THREADS);
+      const int lo = lower_only ? 1 : 0;
+      const bool eu = (pp.metric_mask & (1 << AGP_METRIC_EUCLIDEAN)) != 0, an = (pp.metric_mask & (1 << AGP_METRIC_ANGULAR)) != 0;
+#define AGP_P2(D, E, A) hipLaunchKernelGGL((gram_pair2_kernel<D, E, A>), grid, block, 0, s, pp, X, Y, lo, out, ld, diag_add, nan_flag)
+#define AGP_P2_DIM(D)                                   \
+  do {                                                  \
+    if (eu && an) AGP_P2(D, true, true);                \
+    else if (eu) AGP_P2(D, true, false);                \
+    else if (an) AGP_P2(D, false, true);                \
+    else AGP_P2(D, false, false);                       \
+  } while (0)
+      if (dim == 1) AGP_P2_DIM(1);
+      else if (dim == 2) AGP_P2_DIM(2);
+      else AGP_P2_DIM(3);
+#undef AGP_P2_DIM
+#undef AGP_P2
+      return;
     }
   }
   if (dim == 1) launch_gram_t<1>(s, P, X, Y, symmetric, lower_only, out, ld, diag_add, nan_flag, host_program);

@@ -1,3 +1,4 @@
-mkdir -p gpurun_out/r3j
-python scripts/time_sharded_rank.py 16384 > gpurun_out/r3j/time_sharded_rank.txt 2>&1; tail -5 gpurun_out/r3j/time_sharded_rank.txt
-(timeout 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r3j/gpu_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r3j/gpu_tests.log); tail -3 gpurun_out/r3j/gpu_tests.log
+mkdir -p gpurun_out/r3k
+timeout 900 python -m pytest tests/test_gram_gpu.py tests/test_variant_gpu.py tests/test_linear_combination_gpu.py tests/test_mixed_precision_gpu.py -m gpu -x -q 2>&1 | tail -5
+python scripts/time_gram_trees.py > gpurun_out/r3k/time_gram_trees.txt 2>&1; cat gpurun_out/r3k/time_gram_trees.txt
+AGP_GRAM_PAIR2=0 python scripts/time_gram_trees.py 2>&1 | sed 's/^/PAIR2=0 /'
