@@ -984,6 +984,16 @@ static long long u1_split_below() {
   return v;
 }
 
+static long long u1_f32_above() {
+  static long long v = -1;
+  if (v < 0) {
+    const char *e = getenv("AGP_U1_F32_ABOVE");
+    v = e ? atoll(e) : 4096;
+    if (v == 0) v = 1LL << 60;  // 0: never
+  }
+  return v;
+}
+
 static long long single_below() {
   static long long v = -1;
   if (v < 0) {
@@ -1046,6 +1056,10 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
       timed_gemm(sc, timers, A + (kend + NB) * lda + (kend + NB), lda, P2, P2, n - kend - NB, next_end - kend - NB, K, false);
       (void)hipEventRecord(ctx->ev_d, sc);
       after_first = ctx->ev_d;
+    } else if (variant == 3 && (n - kend) >= u1_f32_above()) {
+      // mixed precision: U1 on the fp32 MFMA path like the bulk update (products of fp32-rounded panels, fp64
+      // subtraction) while the block column is tall enough for 128 x 128 tiles to fill the chip
+      launch_update_f32(sa, A + kend * lda + kend, lda, P, P, lda, n - kend, next_end - kend, K);
     } else {
       timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
     }

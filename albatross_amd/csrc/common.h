@@ -227,4 +227,6 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
                                BulkTiming *timing = nullptr);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
+void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P, const double *Q, long long ldp, long long M,
+                       long long N, long long K);
 }  // namespace agp

@@ -945,6 +945,23 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
   else hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
 }
 
+// C (M x N, lower tiles: C(0, 0) sits on the matrix diagonal) -= P Q^T with fp32-rounded panels on the fp32 MFMA path
+// (trailing_update_f32_kernel), the result subtracted from the fp64 matrix: the next-block-column update U1 of the
+// mixed-precision factorisation (agp_fit_create_mixed)
+void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P, const double *Q, long long ldp, long long M,
+                       long long N, long long K) {
+  if (M <= 0 || N <= 0 || K <= 0) return;
+  GemmArgs g;
+  g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = Q; g.ldb = ldp;
+  g.M = M; g.N = N; g.K = K; g.tri = 1;
+  g.ntr = (int)((M + GT - 1) / GT);
+  g.ntc = (int)((N + GT - 1) / GT);
+  if (g.ntc > g.ntr) g.ntc = g.ntr;
+  g.remap = 0; g.nsuper = 0; g.nb8 = 0;
+  const long long tiles = count_tiles(g.ntr, g.ntc, 1);
+  if (tiles > 0) hipLaunchKernelGGL(trailing_update_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+}
+
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing) {
   static int variant = -1;
