@@ -12,6 +12,7 @@
 
 namespace agp {
 void read_valu_clock(unsigned long long out[4], bool reset);
+void read_mfma_clock(unsigned long long out[4], bool reset);
 
 __global__ void mfma_tile_kernel(const double *A, const double *B, double *D) {
   const int l = threadIdx.x;
@@ -208,6 +209,14 @@ extern "C" AGP_DEBUG_API int agp_debug_exp_neg(agp_context *ctx, const double *t
   AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   AGP_HIP_CHECK(ctx, hipMemcpy(out, d + n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
   (void)hipFree(d);
+  return AGP_OK;
+}
+
+// {sum of shader-clock cycles, sum of 100 MHz ticks, workgroups} of the trailing_update_kernel launches since the last
+// reset (a library built with -DAGP_CLOCK_PROBE; zeros otherwise)
+extern "C" AGP_DEBUG_API int agp_debug_mfma_kernel_clock(unsigned long long *out, int reset) {
+  if (!out) return AGP_ERR_INVALID_ARGUMENT;
+  agp::read_mfma_clock(out, reset != 0);
   return AGP_OK;
 }
 

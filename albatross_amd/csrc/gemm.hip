@@ -470,9 +470,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_valu_kernel(G
 // The bulk trailing update of the factorisation (C -= P P^T, lower tiles, K =
 // NBO) under its own kernel symbol, so that profiles and bench.py's roofline
 // block isolate exactly these launches.
+// -DAGP_CLOCK_PROBE (scripts/clock_probe.sh, never the product build): every workgroup adds its shader-clock cycles
+// (s_memtime) and 100 MHz ticks (s_memrealtime) to g_mfma_clock - the SCLK the bulk update actually holds
+__device__ unsigned long long g_mfma_clock[4];
+
 __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmArgs g) {
   __shared__ double lds[2 * 2 * GK * GLD];
+#ifdef AGP_CLOCK_PROBE
+  const unsigned long long t_c0 = __builtin_amdgcn_s_memtime(), t_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   gemm_nt_sub_body<false, false>(g, lds);
+#ifdef AGP_CLOCK_PROBE
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_mfma_clock[0], __builtin_amdgcn_s_memtime() - t_c0);
+    atomicAdd(&g_mfma_clock[1], __builtin_amdgcn_s_memrealtime() - t_r0);
+    atomicAdd(&g_mfma_clock[2], 1ull);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -973,6 +987,14 @@ void launch_trailing_update(hipStream_t s, double *C, long long ldc, const doubl
     variant = (e && e[0] == 'd') ? 2 : 0;
   }
   launch_trailing_update_as(variant, s, C, ldc, P, Q, ldp, M, K, timing);
+}
+
+void read_mfma_clock(unsigned long long out[4], bool reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mfma_clock), sizeof(unsigned long long) * 4);
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_clock), z, sizeof(z));
+  }
 }
 
 void read_valu_clock(unsigned long long out[4], bool reset) {
