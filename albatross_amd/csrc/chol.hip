@@ -54,6 +54,11 @@ struct PotrfArgs {
   // the rows below in the same launch; `below` = number of those rows
   double *zpub = nullptr;
   long long below = 0;
+  // fused panel kernel with the PREVIOUS panel's update folded in (panel_fused_kernel<true>): columns k0 - 128 .. k0 - 1
+  // hold the factored previous panel, whose rank-128 update of THIS panel's 128 columns has not been applied yet.
+  // dpub: 36 tiles (the LDS tile layout of the diagonal block) through which the workgroups that update the diagonal
+  // block hand it to the one that factors it (sentinel-filled, see store_pub)
+  double *dpub = nullptr;
 };
 
 constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
@@ -90,6 +95,17 @@ __device__ __forceinline__ double load_pub(const double *p) {
 }
 __device__ __forceinline__ bool is_unpublished(double v) {
   return (unsigned long long)__double_as_longlong(v) == PUB_SENTINEL;
+}
+
+// A consumer never spins for ever: after ~2 s (s_memrealtime, 100 MHz) without the values it waits for it records the
+// failure in flags[2] and carries on with whatever it has read - the host turns that flag into AGP_ERR_HIP instead of
+// the launch hanging the GPU (that can only happen if the producer workgroup died).
+constexpr unsigned long long PUB_TIMEOUT_TICKS = 200000000ull;
+
+__device__ __forceinline__ bool poll_expired(unsigned long long t0, int *flags) {
+  if (__builtin_amdgcn_s_memrealtime() - t0 < PUB_TIMEOUT_TICKS) return false;
+  if ((threadIdx.x & 63) == 0) atomicExch(flags + 2, 1);
+  return true;
 }
 
 __global__ __launch_bounds__(256) void fill_sentinel_kernel(double *p, long long count) {
@@ -309,7 +325,7 @@ __device__ __forceinline__ void micro_syrk_tile2(double *T, int ib0, int kb0, in
 constexpr int POTRF_LDS_DOUBLES = IMG_DOUBLES + 2 * MB * MB + NB;  // tiles | two inverse buffers | y
 
 // PUB: the fused panel kernel - every tile of the image goes out (store_pub) the moment it is final, z_b too
-template <bool PUB>
+template <bool PUB, bool UPD = false>
 __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
   double *Wc = T + IMG_DOUBLES;
   double *ys = Wc + 2 * MB * MB;
@@ -319,7 +335,25 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
   PT(0);
 
   double *Adiag = p.A + p.k0 * p.lda + p.k0;  // element (r, c) of the block at Adiag[c * lda + r]
-  {  // thread (r, c) of every tile; all 36 loads in flight
+  if constexpr (UPD) {
+    // the block arrives UPDATED (D - X X^T, X = the previous panel's rows of this block) from the update workgroups
+    // of the same launch, tile by tile in this very layout: poll until every value has appeared
+    double v[NTILE];
+    unsigned long long t0 = 0;
+    for (int spin = 0;; ++spin) {
+      bool ok = true;
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) v[t] = load_pub(p.dpub + t * (MB * MB) + tid);
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) ok = ok && !is_unpublished(v[t]);
+      if (__all(ok)) break;
+      if (spin == 0) t0 = __builtin_amdgcn_s_memrealtime();
+      else if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) T[t * (MB * MB) + tid] = v[t];
+  } else {  // thread (r, c) of every tile; all 36 loads in flight
     const int r = tid & 15, c = tid >> 4;
     double v[NTILE];
 #pragma unroll
@@ -627,17 +661,6 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
 // Workgroup 0 is dispatched first (workgroups are dispatched in order), so the consumers only ever wait for a
 // workgroup that is already running or will be as soon as a slot of its XCD frees up.
 // ---------------------------------------------------------------------------------------------------------------
-// A consumer never spins for ever: after ~2 s (s_memrealtime, 100 MHz) without the values it waits for it records the
-// failure in flags[2] and carries on with whatever it has read - the host turns that flag into AGP_ERR_HIP instead of
-// the launch hanging the GPU (that can only happen if the producer workgroup died).
-constexpr unsigned long long PUB_TIMEOUT_TICKS = 200000000ull;
-
-__device__ __forceinline__ bool poll_expired(unsigned long long t0, int *flags) {
-  if (__builtin_amdgcn_s_memrealtime() - t0 < PUB_TIMEOUT_TICKS) return false;
-  if ((threadIdx.x & 63) == 0) atomicExch(flags + 2, 1);
-  return true;
-}
-
 template <int NT>
 __device__ __forceinline__ void poll_tiles(const double *img_row, int lane, double (&f)[NMB][4], int *flags) {
   // tiles 0 .. NT - 1 of one image row, as A-operand fragments (f[t][s] = element s * 64 + lane of tile t)
@@ -689,13 +712,108 @@ __device__ __forceinline__ void trsm_fused_step(const PotrfArgs &p, int lane, v4
   }
 }
 
-__device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p) {
+// UPD: one of the 36 micro tiles of the diagonal block per wave: D'(ib, kb) = D(ib, kb) - X_ib X_kb^T with
+// X = the previous panel's rows of this block (128 deep: 32 MFMAs in four chains), published to p.dpub in the LDS tile
+// layout of potrf_diag_body.  Nine workgroups of four waves cover the block; each finishes in ~2 us.
+__device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
+  const int lane = threadIdx.x & 63, ln = lane & 15, lg = lane >> 4;
+  int ib = 0;
+  while ((ib + 1) * (ib + 2) / 2 <= tile) ++ib;
+  const int kb = tile - ib * (ib + 1) / 2;
+  const double *Xd = p.A + (p.k0 - NB) * p.lda + p.k0;  // element (row r of the block, depth k) at Xd[k * lda + r]
+  const double *Dd = p.A + p.k0 * p.lda + p.k0;         // element (r, c) of the block at Dd[c * lda + r]
+  const int ra = kb * MB + ln, rb = ib * MB + ln;
+  const bool oka = ra < p.nbk, okb = rb < p.nbk;
+  v4d acc[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gr = ib * MB + ln, gc = kb * MB + lg + 4 * r;  // D/C layout: register r of lane (ln, lg) = element (row ln, column lg + 4 r)
+    double x;
+    if (gr < p.nbk && gc < p.nbk) x = (gr >= gc) ? Dd[gc * p.lda + gr] : 0.;
+    else x = (gr == gc) ? 1. : 0.;  // identity padding of a partial last block
+    acc[0][r] = x;
+  }
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    double av[16], bv[16];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const long long k = 64 * half + 4 * s2 + lg;
+      av[s2] = oka ? Xd[k * p.lda + ra] : 0.;
+      bv[s2] = okb ? Xd[k * p.lda + rb] : 0.;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) acc[s2 & 3] = mfma16(-av[s2], bv[s2], acc[s2 & 3]);
+  }
+  const v4d out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // the strictly upper part of a diagonal tile stays zero, as the prologue of potrf_diag_body loads it
+    const int gr = ib * MB + ln, gc = kb * MB + lg + 4 * r;
+    store_pub(p.dpub + tile * (MB * MB) + (lg + 4 * r) * MB + ln, (gr >= gc) ? out[r] : 0.);
+  }
+}
+
+template <bool UPD>
+__device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_block, double *Xs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 15, lg = lane >> 4;
-  const long long n0 = ((long long)(blockIdx.x - 1) * 4 + wave) * 16;
-  if (n0 >= p.below) return;  // waves are independent: no barrier below
-  const bool nok = n0 + ln < p.below;
+  const long long n0 = ((long long)(blockIdx.x - first_block) * 4 + wave) * 16;
+  const bool active = n0 < p.below;
+  const bool nok = active && n0 + ln < p.below;
   double *base = p.A + p.k0 * p.lda + (p.k0 + p.nbk) + (n0 + ln);  // X[n][m] at base[m * lda]
+  if constexpr (UPD) {
+    // The previous panel's update of this workgroup's 64 rows x 128 columns, in memory, before they are loaded and
+    // solved: C[jb] -= X_own (16 rows x 128 deep) . X_d[rows of micro column jb]^T; everything it reads is final
+    // (previous launch).  The depth in two passes of 64: X_d (128 rows x 64 deep, 64 KB) goes through LDS once per
+    // workgroup - one coalesced round trip instead of eight latency-bound batches of fragment loads per wave - as
+    // [k][row] with a 144-double pitch (the layout of the update kernels' operand image), X_own stays in registers.
+    // (Holding the eight result tiles in registers across this loop made the kernel spill: memory to memory.)
+    constexpr int XP = NB + 16;
+    const double *Xo = p.A + (p.k0 - NB) * p.lda + (p.k0 + p.nbk) + (n0 + ln);  // own rows: Xo[k * lda]
+    const double *Xd = p.A + (p.k0 - NB) * p.lda + p.k0;                        // rows of the diagonal block
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      double bo[16];
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) bo[s2] = nok ? Xo[(64 * pass + 4 * s2 + lg) * p.lda] : 0.;
+      {
+        double v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const int e = tid + 256 * i, row = e & (NB - 1), k = e >> 7;
+          v[i] = (row < p.nbk) ? Xd[(long long)(64 * pass + k) * p.lda + row] : 0.;
+        }
+        if (pass) __syncthreads();  // the previous pass's readers are done with Xs
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const int e = tid + 256 * i, row = e & (NB - 1), k = e >> 7;
+          Xs[k * XP + row] = v[i];
+        }
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int jb = 0; jb < NMB; ++jb) {
+          v4d acc[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = jb * MB + lg + 4 * r;
+            acc[0][r] = (nok && m < p.nbk) ? base[m * p.lda] : 0.;
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) acc[s2 & 3] = mfma16(-Xs[(4 * s2 + lg) * XP + jb * MB + ln], bo[s2], acc[s2 & 3]);
+          const v4d out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = jb * MB + lg + 4 * r;
+            if (nok && m < p.nbk) base[m * p.lda] = out[r];
+          }
+        }
+      }
+    }
+  }
+  if (!active) return;  // from here on the waves are independent: no barrier below
   v4d Y[NMB];
 #pragma unroll
   for (int jb = 0; jb < NMB; ++jb)
@@ -736,11 +854,22 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p) {
   }
 }
 
+constexpr int UPD_BLOCKS = NTILE / 4;  // 9 workgroups x 4 waves = the 36 micro tiles of the diagonal block
+
+// UPD: the launch also applies the previous panel's update to this panel's columns (no separate update launch, no
+// kernel boundary between "rows updated" and "next diagonal block factored"): workgroups 1 .. 9 update the diagonal
+// block and hand it to workgroup 0 through p.dpub, the workgroups of the rows below update their own rows first.
+template <bool UPD>
 __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ double T[POTRF_LDS_DOUBLES];
-  if (blockIdx.x == 0) potrf_diag_body<true>(p, T);
-  else trsm_fused_body(p);
+  if (blockIdx.x == 0) {
+    potrf_diag_body<true, UPD>(p, T);
+  } else if (UPD && blockIdx.x <= UPD_BLOCKS) {
+    diag_update_body(p, (int)(blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6));
+  } else {
+    trsm_fused_body<UPD>(p, UPD ? 1 + UPD_BLOCKS : 1, T);
+  }
 }
 
 // In the TRANS staging above the image is indexed t = jb(jb+1)/2 + ib with
@@ -789,6 +918,18 @@ static bool panel_fused_enabled() {
   return v == 1;
 }
 
+// Remaining rows at or below which the factorisation advances panel by panel with the UPDATE-AHEAD panel kernel
+// (panel_fused_kernel<true>: the previous panel's update of the next 128 columns inside the panel launch, everything
+// further right on the bulk stream with depth 128); AGP_UPD_BELOW, default 0 = off.  Measured (MI355X, round 3): correct,
+// and no faster - the launch takes 37 us with two row workgroups and 50-60 us with sixty next to the bulk update
+// (the plain fused launch: 35-40 us + a 10-12 us update launch), and one event record / wait pair per PANEL instead of
+// one per four costs ~10 us each time: N = 4096 fit 2.58 against 2.54 ms, N = 16384 33.7 against 33.7 ms.  Read per call
+// (tests switch it in one process).
+static long long upd_below() {
+  const char *e = getenv("AGP_UPD_BELOW");
+  return e ? atoll(e) : 0;
+}
+
 static long long fused_below() {
   static long long v = -1;
   if (v < 0) {
@@ -816,7 +957,19 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
     ctx->zpub_cap = cap;
   }
   const long long b0 = k_begin / NB, b1 = (k_end + NB - 1) / NB;
+  if (upd_below() > 0 && ctx->dpub_cap < b1) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
+    ctx->d_dpub = nullptr;
+    ctx->dpub_cap = 0;
+    const long long cap = (b1 + 31) / 32 * 32;
+    if (hipMalloc(&ctx->d_dpub, sizeof(double) * (size_t)cap * IMG_DOUBLES) == hipSuccess) ctx->dpub_cap = cap;
+    else (void)hipGetLastError();
+  }
   const long long cnt_img = (b1 - b0) * (long long)IMG_DOUBLES, cnt_z = k_end - k_begin;
+  if (ctx->d_dpub && ctx->dpub_cap >= b1)
+    hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_img + 255) / 256)), dim3(256), 0, s,
+                       ctx->d_dpub + b0 * (long long)IMG_DOUBLES, cnt_img);
   hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_img + 255) / 256)), dim3(256), 0, s, invd + b0 * (long long)IMG_DOUBLES, cnt_img);
   hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_z + 255) / 256)), dim3(256), 0, s, ctx->d_zpub + k_begin, cnt_z);
   ctx->zpub_ready_n = k_end;
@@ -827,7 +980,8 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
 // POTRF, panel TRSM (with the fused forward substitution on y) and the update
 // of the remaining columns of the outer block.  Everything on stream s.
 static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *invd,
-                        double *y, long long K0, long long kend, FactorTimers *timers, hipEvent_t after_first = nullptr) {
+                        double *y, long long K0, long long kend, FactorTimers *timers, hipEvent_t after_first = nullptr,
+                        bool upd_prev = false) {
   // AGP_INNER_LEFT=1: left-looking inside the outer block - panel k is brought up to date with the panels
   // [K0, k) of this outer block in ONE product of depth k - K0 just before it is factored, instead of every
   // panel updating all later columns of the outer block with depth 128 (same flop, a third of the C traffic,
@@ -845,7 +999,7 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
   // chip that costs it more than the saved launch (measured: 43.3 -> 41.8 TFLOP/s), so the fused kernel takes over
   // where the panel chain is the critical path (AGP_FUSED_BELOW remaining rows)
   const bool fused = panel_fused_enabled() && ctx->d_zpub && ctx->zpub_ready_n >= kend && ctx->img_ready == invd &&
-                     (n - K0) <= fused_below();
+                     ((n - K0) <= fused_below() || upd_prev);  // (factor_lower asks for upd_prev only when all of this holds)
   for (long long k = K0; k < kend; k += NB) {
     const int nbk = (int)((n - k < NB) ? n - k : NB);
     if (inner_left && k > K0) {
@@ -861,7 +1015,13 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
       pa.flags = ctx->d_flags; pa.scalars = ctx->d_scalars;
       pa.zpub = y ? ctx->d_zpub + k : nullptr;
       pa.below = below > 0 ? below : 0;
-      hipLaunchKernelGGL(panel_fused_kernel, dim3((unsigned)(1 + (pa.below + 63) / 64)), dim3(256), 0, s, pa);
+      if (upd_prev && k == K0) {
+        // the panel before this one (columns K0 - 128 .. K0 - 1) has not been applied to these columns yet
+        pa.dpub = ctx->d_dpub + (k / NB) * (long long)IMG_DOUBLES;
+        hipLaunchKernelGGL(panel_fused_kernel<true>, dim3((unsigned)(1 + UPD_BLOCKS + (pa.below + 63) / 64)), dim3(256), 0, s, pa);
+      } else {
+        hipLaunchKernelGGL(panel_fused_kernel<false>, dim3((unsigned)(1 + (pa.below + 63) / 64)), dim3(256), 0, s, pa);
+      }
       if (below <= 0) continue;
     } else {
     launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars);
@@ -946,6 +1106,7 @@ static void nbo_thresholds(long long *m512, long long *m256) {
 
 static long long pick_nbo(long long remaining, long long override_nbo = 0) {
   if (override_nbo > 0) return override_nbo;
+  if (panel_fused_enabled() && remaining <= upd_below()) return NB;  // update-ahead panel kernel: one panel per step
   long long m512, m256;
   nbo_thresholds(&m512, &m256);
   if (remaining > m512) return 512;
@@ -1038,8 +1199,14 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     // than the ~10 us of event record / wait packets that hand each of them to the second stream and back - so the last
     // outer block spans all remaining columns: U1 covers everything, its panels update the whole trailing triangle
     // right-looking, nothing leaves the chain stream
-    if (nbo_fixed == 0 && n - kend <= single_below()) next_end = n;
     const long long K = kend - K0;
+    // Update-ahead steps (chain-bound tail): the previous panel [K0, kend) is ONE 128-column panel and its update of the
+    // next 128 columns is folded into that panel's own launch - no U1 launch, no kernel boundary between "rows
+    // updated" and "diagonal block factored"; U2 (depth 128) covers everything right of the next panel.
+    const bool upd = nbo_fixed == 0 && K == NB && (n - kend) <= upd_below() && panel_fused_enabled() && ctx->d_dpub &&
+                     ctx->d_zpub && ctx->img_ready == invd && ctx->zpub_ready_n >= n;
+    if (upd) next_end = (kend + NB < n) ? kend + NB : n;
+    else if (nbo_fixed == 0 && n - kend <= single_below()) next_end = n;
     const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
     if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);   // U2(j - 1) done
@@ -1047,7 +1214,9 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     // columns - all the next diagonal block and its panel wait for - stay on the chain; the other columns go to the side
     // stream and are awaited right after the first panel kernel of P(j + 1) (AGP_U1_SPLIT_BELOW remaining rows).
     hipEvent_t after_first = nullptr;
-    if (ctx->stream_side && next_end - kend > NB && (n - kend) <= u1_split_below()) {
+    if (upd) {
+      // nothing here: panel_phase(..., upd_prev = true) below applies it
+    } else if (ctx->stream_side && next_end - kend > NB && (n - kend) <= u1_split_below()) {
       hipStream_t sc = ctx->stream_side;
       (void)hipStreamWaitEvent(sc, ctx->ev_a, 0);
       if (have_u2) (void)hipStreamWaitEvent(sc, ctx->ev_b, 0);
@@ -1077,7 +1246,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     if (sb != sb_prev && have_u2) (void)hipStreamWaitEvent(sb, ctx->ev_b, 0);  // U2(j - 1) ran on the other bulk stream
     sb_prev = sb;
     const bool throttle = next_end < n && (n - kend) <= throttle_below();
-    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first);
+    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd);
     if (next_end < n) {
       if (throttle) {
         while (hipEventQuery(ctx->ev_a) == hipErrorNotReady) {}
@@ -1096,7 +1265,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     } else {
       have_u2 = false;
     }
-    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first);
+    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd);
     K0 = kend;
     kend = next_end;
   }

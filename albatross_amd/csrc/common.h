@@ -96,6 +96,10 @@ struct agp_context {
   // which tile-image buffer has been sentinel-filled for the factorisation in progress
   double *d_zpub = nullptr;
   long long zpub_cap = 0, zpub_ready_n = 0;
+  // ... and the slots through which an UPDATED diagonal block reaches the workgroup that factors it (one tile image
+  // per diagonal block, like invd; only allocated when the update-ahead panel kernel is in use)
+  double *d_dpub = nullptr;
+  long long dpub_cap = 0;  // diagonal blocks
   const double *img_ready = nullptr;
 };
 

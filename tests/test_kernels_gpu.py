@@ -138,3 +138,26 @@ def test_factor_reports_first_bad_pivot(ctx, dbg):
     logdet = C.c_double()
     assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, None, C.byref(logdet), C.byref(bad)) == 0
     assert bad.value == 200
+
+
+@pytest.mark.parametrize("n", [700, 2304])
+def test_update_ahead_panel_kernel(ctx, dbg, n, monkeypatch):
+    """AGP_UPD_BELOW: the panel kernel that also applies the previous panel's update (chol.hip: panel_fused_kernel<true>,
+    an experiment that is off by default) gives the same factor as the default schedule."""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n))
+    A = np.asfortranarray(B @ B.T + n * np.eye(n))
+    y = rng.standard_normal(n)
+    out = {}
+    for mode in ("0", "8192"):
+        monkeypatch.setenv("AGP_UPD_BELOW", mode)
+        Ad, yd = A.copy(order="F"), y.copy()
+        logdet, bad = C.c_double(), C.c_int64()
+        assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
+        assert bad.value == -1
+        out[mode] = (np.tril(Ad), yd, logdet.value)
+    L = np.linalg.cholesky(A)
+    for mode in out:
+        assert np.abs(out[mode][0] - L).max() <= 1e-11 * np.abs(L).max()
+        assert np.abs(out[mode][1] - np.linalg.solve(L, y)).max() <= 1e-10
+    assert abs(out["0"][2] - out["8192"][2]) <= 1e-10 * abs(out["0"][2])
