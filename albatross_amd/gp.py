@@ -326,6 +326,8 @@ def _mean_at(mean_function, cov, features):
 # Fit<GPFit<...>> (gp.hpp:43-77): device factor + information vector
 # ---------------------------------------------------------------------------
 class GPFit:
+    host_composition = False  # the factor, the solves and the predictions all live on the device
+
     def __init__(self, ctx, handle, n, train_features):
         self._ctx = ctx
         self._h = handle
@@ -569,7 +571,12 @@ def negative_log_likelihood(deviation, covariance, context=None):
 
 class BlockSymmetric:
     """linalg/block_symmetric.hpp:46-115: solver of [[A, B], [B^T, C]] from a solver of A,
-    Ai_B = A^-1 B and the factor of the Schur complement S = C - B^T A^-1 B."""
+    Ai_B = A^-1 B and the factor of the Schur complement S = C - B^T A^-1 B.
+
+    `host_composition = True`: the block algebra around the device solves (A.solve, S.solve) is numpy on the host -
+    only solvers that are NOT a device factor end up here (pivoted LDL^T fits, fit_from_prediction); fits on the device
+    factor are updated on the device (agp_fit_update)."""
+    host_composition = True
 
     def __init__(self, A, B, S):
         self.A = A
@@ -596,7 +603,8 @@ class BlockSymmetric:
 class ExplainedCovariance:
     """ExplainedCovariance (covariance_functions/representations.hpp:64-96): S^-1 = A^-1 B A^-1 with the
     outer matrix A held through its factor (the device LL^T) and the inner matrix B kept as it is, because B
-    may be singular."""
+    may be singular.  `host_composition = True`: the product with B between the two device solves is numpy."""
+    host_composition = True
 
     def __init__(self, outer, inner, context=None):
         self.outer_ldlt = outer if isinstance(outer, (DenseFactor, PivotedLDLT)) else DenseFactor(outer, context)
@@ -613,7 +621,10 @@ class ExplainedCovariance:
 
 class UpdatedGPFit:
     """Fit<GPFit<Representation, F>> whose solver is not the plain factor: BlockSymmetric<Solver> from
-    update() (gp.hpp:384-414) or ExplainedCovariance from fit_from_prediction (gp.hpp:139-153)."""
+    update() (gp.hpp:384-414) or ExplainedCovariance from fit_from_prediction (gp.hpp:139-153).
+    `host_composition = True`: predictions go through the generic CovarianceRepresentation form of _predict_impl with
+    numpy between the device Gram / solve calls (FitModel.host_composition tells a caller which kind it holds)."""
+    host_composition = True
 
     def __init__(self, train_features, train_covariance, information):
         self.train_features = train_features
@@ -657,6 +668,12 @@ class FitModel:
 
     def get_model(self):
         return self._model
+
+    @property
+    def host_composition(self):
+        """True when the fit's solver is a host-side composition around device solves (BlockSymmetric /
+        ExplainedCovariance over a solver that is not a device factor) rather than a device factor."""
+        return bool(getattr(self._fit, "host_composition", False))
 
     def predict(self, features):
         return Prediction(self, features)

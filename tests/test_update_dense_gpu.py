@@ -95,6 +95,7 @@ def test_update_equals_full_fit(ctx):
     split = split.update(ab.RegressionDataset(x[second], ab.MarginalDistribution(y[second], var[second])))
     split = split.update(ab.RegressionDataset(x[third], ab.MarginalDistribution(y[third], var[third])))  # nested update
     split_pred = split.predict(xs).joint()
+    assert not split.host_composition  # agp_fit_update: the resident factor grew on the device
     assert np.allclose(split_pred.mean, full_pred.mean, rtol=1e-9, atol=1e-10)
     assert np.linalg.norm(split_pred.covariance - full_pred.covariance) <= 1e-6
     assert np.linalg.norm(split_pred.mean - first_pred.mean) > 1e-3  # and it is not the partial fit
@@ -117,7 +118,11 @@ def test_fit_from_prediction_round_trip(ctx):
     fit_model = model.fit(ab.RegressionDataset(x, y))
     features = np.array([1.3, 4.2, 7.1])
     pred = fit_model.predict(features).joint()
-    again = model.fit_from_prediction(features, pred).predict(features).joint()
+    from_pred = model.fit_from_prediction(features, pred)
+    # a fit whose solver is an ExplainedCovariance is a HOST composition around device solves and says so; a plain fit
+    # (and a device update of one) is not
+    assert from_pred.host_composition and not fit_model.host_composition
+    again = from_pred.predict(features).joint()
     assert np.linalg.norm(again.mean - pred.mean) <= 1e-6
     assert np.linalg.norm(again.covariance - pred.covariance) <= 1e-6
     # ExplainedCovariance::solve = A^-1 B A^-1 (representations.hpp:80-82) against numpy
