@@ -133,6 +133,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->partial_ws) (void)hipFree(ctx->partial_ws);
   if (ctx->ws_A) (void)hipFree(ctx->ws_A);
   if (ctx->pool_A) (void)hipFree(ctx->pool_A);
+  if (ctx->pool_K) (void)hipFree(ctx->pool_K);
   if (ctx->pool_shard) (void)hipFree(ctx->pool_shard);
   if (ctx->pool_sparse) (void)hipFree(ctx->pool_sparse);
   if (ctx->ws_aux) (void)hipFree(ctx->ws_aux);
@@ -668,8 +669,12 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   hipStream_t s = ctx->stream;
   double *yvar_d = nullptr;
   double *Kfull = nullptr, *Wfwd = nullptr, *vec = nullptr;  // mixed precision only
+  size_t Kfull_bytes = 0;
   auto drop_mixed = [&]() {
-    if (Kfull) (void)hipFree(Kfull);
+    if (Kfull) {  // parked for the next mixed fit of the same size, like the factor's own buffer (pool_A)
+      if (!ctx->pool_K) { ctx->pool_K = Kfull; ctx->pool_K_bytes = Kfull_bytes; }
+      else (void)hipFree(Kfull);
+    }
     if (Wfwd) (void)hipFree(Wfwd);
     if (vec) (void)hipFree(vec);
     Kfull = Wfwd = vec = nullptr;
@@ -713,7 +718,15 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   if (mixed) {
     // the exact fp64 covariance (both triangles) for the residuals of the refinement, the targets,
     // and the work vectors r, z, p, q
-    FIT_CHECK(hipMalloc(&Kfull, fit->A_bytes));
+    Kfull_bytes = fit->A_bytes;
+    if (ctx->pool_K && ctx->pool_K_bytes == Kfull_bytes) {
+      Kfull = ctx->pool_K;
+      ctx->pool_K = nullptr;
+      ctx->pool_K_bytes = 0;
+    } else {
+      if (ctx->pool_K) { (void)hipFree(ctx->pool_K); ctx->pool_K = nullptr; ctx->pool_K_bytes = 0; }
+      FIT_CHECK(hipMalloc(&Kfull, Kfull_bytes));
+    }
     FIT_CHECK(hipMalloc(&Wfwd, sizeof(double) * (size_t)nblk * NB * NB));
     FIT_CHECK(hipMalloc(&vec, sizeof(double) * (size_t)n * 5));
     FIT_CHECK(hipMemcpyAsync(vec, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));

@@ -80,6 +80,9 @@ struct agp_context {
   // the next agp_fit_create of the same size takes it instead of hipMalloc)
   double *pool_A = nullptr;
   size_t pool_A_bytes = 0;
+  // ... and one cached exact-covariance buffer of the mixed-precision fit (its CG refinement multiplies with K itself)
+  double *pool_K = nullptr;
+  size_t pool_K_bytes = 0;
   // bulk-update kernel of the next factorisation: -1 = default (fp64 MFMA), 3 = fp32 products
   // (agp_fit_create_mixed sets and resets it around its factor_lower call)
   int update_variant = -1;

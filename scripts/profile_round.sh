@@ -1,21 +1,32 @@
 #!/bin/bash
-# All profile passes of a round, on the GPU box:  bash scripts/profile_round.sh r01
+# All profile passes of a round, on the GPU box:  bash scripts/profile_round.sh r03
 # Writes under gpurun_out/prof_<round>/ ; scripts/pmc_summary.py turns the CSVs into the
 # summaries kept under profiles/<round>/.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 # the repository root, resolved BEFORE the cd below (GRAFT_REPO_ROOT is only set on the gpurun box)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT="$ROOT/gpurun_out/prof_$R"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py"
+FAST="--no-cpu-baseline --no-predict --no-configs"
 python3 "$B" > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$B" --steps 5 --warmup 2 --no-cpu-baseline --no-predict > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o bench -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-predict > /dev/null 2> "$OUT/pmc_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o bench -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-predict > /dev/null 2> "$OUT/pmc_write.err"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o bench -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-predict > /dev/null 2> "$OUT/pmc_mfma.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$B" --steps 5 --warmup 2 $FAST > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o bench -- python3 "$B" --steps 2 --warmup 1 $FAST > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o bench -- python3 "$B" --steps 2 --warmup 1 $FAST > /dev/null 2> "$OUT/pmc_write.err"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o bench -- python3 "$B" --steps 2 --warmup 1 $FAST > /dev/null 2> "$OUT/pmc_mfma.err"
 # keep the merge-back small: the raw traces are large
 find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
-ls -la "$OUT" "$OUT"/*/ | head -40
+cd "$ROOT"
+# the other measurements DESIGN.md quotes
+python3 scripts/time_panel.py > "$OUT/time_panel_fused.txt" 2>&1
+AGP_PANEL_FUSED=0 python3 scripts/time_panel.py > "$OUT/time_panel_two_launches.txt" 2>&1
+bash scripts/sweep_fused.sh > "$OUT/sweep_fused.txt" 2>&1
+python3 scripts/time_gram_trees.py > "$OUT/time_gram_trees.txt" 2>&1
+python3 scripts/time_mixed.py 32768 > "$OUT/time_mixed.txt" 2>&1
+python3 scripts/time_sharded_rank.py 16384 65536 > "$OUT/time_sharded_rank.txt" 2>&1
+python3 scripts/time_sharded_rccl1.py > "$OUT/time_sharded_rccl1.txt" 2>&1
+python3 scripts/time_config2.py 1024 2048 4096 8192 > "$OUT/time_config2.txt" 2>&1
+ls -la "$OUT" "$OUT"/*/ | head -60
 tail -1 "$OUT/bench_n1.json" | cut -c1-300
