@@ -486,7 +486,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
   // serial panel chain: issue ahead of the bulk-update waves that share this CU
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);
   {
     const long long b = blockIdx.y;
     p.A += b * p.batch_A;
@@ -532,7 +532,7 @@ struct TrsmArgs {
 
 template <bool TRANS, bool FUSE_Y>
 __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
-  __builtin_amdgcn_s_setprio(3);  // panel chain (see potrf_diag_kernel)
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);  // panel chain (see potrf_diag_kernel)
   __shared__ double F[NFRAG_TILES * 4 * 64 + NB];
   double *zs = F + NFRAG_TILES * 4 * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -861,7 +861,7 @@ constexpr int UPD_BLOCKS = NTILE / 4;  // 9 workgroups x 4 waves = the 36 micro 
 // block and hand it to workgroup 0 through p.dpub, the workgroups of the rows below update their own rows first.
 template <bool UPD>
 __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);
   __shared__ double T[POTRF_LDS_DOUBLES];
   if (blockIdx.x == 0) {
     potrf_diag_body<true, UPD>(p, T);

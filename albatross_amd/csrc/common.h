@@ -10,6 +10,15 @@
 #include "../../include/albatross_amd.h"
 #include "cov_eval.h"
 
+// Wave priority of the panel-chain kernels (s_setprio) and of the bulk update; compile-time so that
+// scripts/sweep_prio.sh can rebuild the four combinations (measured: see DESIGN.md section 8)
+#ifndef AGP_CHAIN_PRIO
+#define AGP_CHAIN_PRIO 3
+#endif
+#ifndef AGP_BULK_PRIO
+#define AGP_BULK_PRIO 0
+#endif
+
 namespace agp {
 
 // Blocking factors of the LL^T factorisation:

@@ -287,7 +287,7 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g) {
-  __builtin_amdgcn_s_setprio(3);  // everything but the bulk update (its own kernel below)
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);  // everything but the bulk update (its own kernel below)
   g.C += (long long)blockIdx.y * g.batch_C;
   g.A += (long long)blockIdx.y * g.batch_A;
   g.B += (long long)blockIdx.y * g.batch_B;
@@ -475,6 +475,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_valu_kernel(G
 __device__ unsigned long long g_mfma_clock[4];
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmArgs g) {
+#if AGP_BULK_PRIO > 0
+  __builtin_amdgcn_s_setprio(AGP_BULK_PRIO);
+#endif
   __shared__ double lds[2 * 2 * GK * GLD];
 #ifdef AGP_CLOCK_PROBE
   const unsigned long long t_c0 = __builtin_amdgcn_s_memtime(), t_r0 = __builtin_amdgcn_s_memrealtime();
@@ -738,7 +741,7 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
 
 
 __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs g) {
-  __builtin_amdgcn_s_setprio(3);  // panel-chain updates: issue ahead of co-resident bulk-update waves
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);  // panel-chain updates: issue ahead of co-resident bulk-update waves
   g.C += (long long)blockIdx.y * g.batch_C;
   g.A += (long long)blockIdx.y * g.batch_A;
   g.B += (long long)blockIdx.y * g.batch_B;
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs
 // 64 x 64 tiles with a TRANSPOSED second operand (B(j, k) at B[k + j * ldb]): the updates of the multi-RHS
 // substitutions with few right-hand sides, where a 128 x 128 tile would be mostly padding.  Not triangular.
 __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_bk_kernel(GemmArgs g) {
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);
   g.C += (long long)blockIdx.y * g.batch_C;
   g.A += (long long)blockIdx.y * g.batch_A;
   g.B += (long long)blockIdx.y * g.batch_B;
