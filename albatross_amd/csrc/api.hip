@@ -716,7 +716,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   FeatView xm = fit->train.v;
   xm.meas = 1;  // as_measurements(features), gp.hpp:288
   if (mixed) {
-    // the exact fp64 covariance (both triangles) for the residuals of the refinement, the targets,
+    // the exact fp64 covariance (lower triangle: the refinement multiplies with launch_symv_lower) for the residuals, the targets,
     // and the work vectors r, z, p, q
     Kfull_bytes = fit->A_bytes;
     if (ctx->pool_K && ctx->pool_K_bytes == Kfull_bytes) {
@@ -730,7 +730,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     FIT_CHECK(hipMalloc(&Wfwd, sizeof(double) * (size_t)nblk * NB * NB));
     FIT_CHECK(hipMalloc(&vec, sizeof(double) * (size_t)n * 5));
     FIT_CHECK(hipMemcpyAsync(vec, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/false, Kfull, fit->lda, yvar_d, ctx->d_flags,
+    launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, Kfull, fit->lda, yvar_d, ctx->d_flags,
                 &k->prog);
     ctx->update_variant = 3;  // fp32-product bulk updates
     if (const char *e = getenv("AGP_MIXED_NBO")) ctx->nbo_override = atoll(e);  // experiment: fixed outer width
@@ -823,6 +823,9 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
   };
   // the substitutions of every step: through 512-wide inverted diagonal blocks when the size allows (2 x n / 512
   // mat-vec launches per direction instead of n / 128 fused steps: the chains are launch-latency-bound)
+  double *symv_ws = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&symv_ws, sizeof(double) * symv_ws_elems(n)));
+  struct FreeS { double *p; ~FreeS() { if (p) (void)hipFree(p); } } free_s{symv_ws};
   const long long BW = backsolve_width(n);
   double *Wwide = nullptr;
   if (BW) {
@@ -843,7 +846,7 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
   double h[4];
   int st;
   // r = y - K a
-  launch_colvec_dot(s, Kfull, lda, n, n, xa, -1., 1., yv, r);
+  launch_symv_lower(s, Kfull, lda, n, xa, -1., 1., yv, r, symv_ws);
   launch_dot(s, yv, yv, n, dots + 0);
   launch_dot(s, r, r, n, dots + 1);
   if ((st = read_dots(2, h)) != AGP_OK) return st;
@@ -860,7 +863,7 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
     double best = rnorm;
     int stalled = 0;
     while (it < mixed->max_iterations && rnorm > target) {
-      launch_colvec_dot(s, Kfull, lda, n, n, p, 1., 0., nullptr, q);
+      launch_symv_lower(s, Kfull, lda, n, p, 1., 0., nullptr, q, symv_ws);
       launch_dot(s, p, q, n, dots + 0);
       if ((st = read_dots(1, h)) != AGP_OK) return st;
       if (!(h[0] > 0.) || !(rz > 0.)) break;  // breakdown: K or the preconditioner lost definiteness
@@ -880,7 +883,7 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
       launch_axpby(s, n, 1., z, beta, p, p);
     }
     // report the TRUE residual of what is returned (the recurrence drifts)
-    launch_colvec_dot(s, Kfull, lda, n, n, xa, -1., 1., yv, r);
+    launch_symv_lower(s, Kfull, lda, n, xa, -1., 1., yv, r, symv_ws);
     launch_dot(s, r, r, n, dots + 0);
     if ((st = read_dots(1, h)) != AGP_OK) return st;
     rnorm = std::sqrt(h[0]);

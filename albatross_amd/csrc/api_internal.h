@@ -28,6 +28,10 @@ void launch_tall_matvec(hipStream_t s, const double *W, long long ld, long long 
                         double beta, const double *base, double *out);
 void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,
                        double alpha, double beta, const double *base, double *out);
+// out = alpha K p + beta base for a symmetric K given by its LOWER triangle only (reduce.hip); ws: symv_ws_elems(n) doubles
+size_t symv_ws_elems(long long n);
+void launch_symv_lower(hipStream_t s, const double *K, long long ld, long long n, const double *p, double alpha, double beta,
+                       const double *base, double *out, double *ws);
 void launch_axpby(hipStream_t s, long long n, double a, const double *x, double b, const double *y, double *out);
 void launch_loo(hipStream_t s, const double *kinv_diag, const double *y, const double *information, long long n,
                 double *mean, double *variance);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include "common.h"
+#include "api_internal.h"
 #include "mfma_f64.h"
 
 #define AGP_DEBUG_API __attribute__((visibility("default")))
@@ -217,6 +218,25 @@ extern "C" AGP_DEBUG_API int agp_debug_exp_neg(agp_context *ctx, const double *t
 extern "C" AGP_DEBUG_API int agp_debug_mfma_kernel_clock(unsigned long long *out, int reset) {
   if (!out) return AGP_ERR_INVALID_ARGUMENT;
   agp::read_mfma_clock(out, reset != 0);
+  return AGP_OK;
+}
+
+// out = alpha K p + beta base with K symmetric, given by its lower triangle (host arrays): reduce.hip launch_symv_lower
+extern "C" AGP_DEBUG_API int agp_debug_symv_lower(agp_context *ctx, const double *K, int64_t n, int64_t ld, const double *p,
+                                                  double alpha, double beta, const double *base, double *out) {
+  if (!ctx || !K || !p || !out || n <= 0 || ld < n) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  double *dK = nullptr, *dv = nullptr, *ws = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&dK, sizeof(double) * (size_t)ld * (size_t)n));
+  AGP_HIP_CHECK(ctx, hipMalloc(&dv, sizeof(double) * 3 * (size_t)n));
+  AGP_HIP_CHECK(ctx, hipMalloc(&ws, sizeof(double) * symv_ws_elems(n)));
+  AGP_HIP_CHECK(ctx, hipMemcpy(dK, K, sizeof(double) * (size_t)ld * (size_t)n, hipMemcpyHostToDevice));
+  AGP_HIP_CHECK(ctx, hipMemcpy(dv, p, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  if (base) AGP_HIP_CHECK(ctx, hipMemcpy(dv + n, base, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  launch_symv_lower(ctx->stream, dK, ld, n, dv, alpha, beta, base ? dv + n : nullptr, dv + 2 * n, ws);
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  AGP_HIP_CHECK(ctx, hipMemcpy(out, dv + 2 * n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  (void)hipFree(dK); (void)hipFree(dv); (void)hipFree(ws);
   return AGP_OK;
 }
 

@@ -346,6 +346,98 @@ void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m
   hipLaunchKernelGGL(colvec_dot_kernel, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// out = alpha * K p + beta * base for a SYMMETRIC K of which only the lower triangle is stored (column-major, ld): every
+// stored entry is read once and used twice - half the traffic of a product with the full matrix, which is what bounds
+// the K p of the conjugate-gradient steps of the mixed-precision fit (api.hip: refine_information).  Deterministic (no
+// atomics):
+//   symv_lower_kernel   block (strip c of 32 columns, segment s of 4096 rows): for its rows r and columns j <= r
+//                       rowpart[c][r] = sum_j K[r][j] p[j]            (the product with the stored triangle)
+//                       colpart[s][j] = sum_{r > j} K[r][j] p[r]      (the product with its mirror image)
+//   symv_reduce_kernel  out[r] = alpha (sum_{c <= r / 32} rowpart[c][r] + sum_s colpart[s][r]) + beta base[r], fixed order
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SYMV_W = 32;
+constexpr int SYMV_SEG = 4096;
+
+__global__ __launch_bounds__(256) void symv_lower_kernel(const double *__restrict__ K, long long ld, long long n,
+                                                         const double *__restrict__ p, double *__restrict__ rowpart,
+                                                         long long ldp, double *__restrict__ colpart) {
+  const long long j0 = (long long)blockIdx.x * SYMV_W, seg0 = (long long)blockIdx.y * SYMV_SEG;
+  const long long r_begin = seg0 > j0 ? seg0 : j0, r_end = seg0 + SYMV_SEG < n ? seg0 + SYMV_SEG : n;
+  if (r_begin >= r_end) return;  // the segment lies above the strip's diagonal block (symv_reduce_kernel knows which do)
+  __shared__ double pj[SYMV_W];
+  __shared__ double red[4][SYMV_W];
+  const int tid = threadIdx.x;
+  if (tid < SYMV_W) pj[tid] = (j0 + tid < n) ? p[j0 + tid] : 0.;
+  __syncthreads();
+  double colacc[SYMV_W];
+#pragma unroll
+  for (int jj = 0; jj < SYMV_W; ++jj) colacc[jj] = 0.;
+  const double *Kc = K + j0 * ld;
+  for (long long r = r_begin + tid; r < r_end; r += 256) {
+    const double pr = p[r];
+    double racc = 0.;
+    if (r >= j0 + SYMV_W) {  // below the diagonal block: all 32 columns (j < j0 + 32 <= r < n)
+      double v[SYMV_W];
+#pragma unroll
+      for (int jj = 0; jj < SYMV_W; ++jj) v[jj] = Kc[r + jj * ld];
+#pragma unroll
+      for (int jj = 0; jj < SYMV_W; ++jj) {
+        racc += v[jj] * pj[jj];
+        colacc[jj] += v[jj] * pr;
+      }
+    } else {  // a row of the diagonal block: columns j <= r, the diagonal entry counted once
+#pragma unroll
+      for (int jj = 0; jj < SYMV_W; ++jj) {
+        const long long j = j0 + jj;
+        if (j <= r) {
+          const double v = Kc[r + jj * ld];
+          racc += v * pj[jj];
+          if (j < r) colacc[jj] += v * pr;
+        }
+      }
+    }
+    rowpart[(long long)blockIdx.x * ldp + r] = racc;
+  }
+#pragma unroll
+  for (int jj = 0; jj < SYMV_W; ++jj) {
+    double a = colacc[jj];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6][jj] = a;
+  }
+  __syncthreads();
+  if (tid < SYMV_W && j0 + tid < n) colpart[(long long)blockIdx.y * ldp + j0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+__global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ rowpart, const double *__restrict__ colpart,
+                                                          long long ldp, long long n, double alpha, double beta,
+                                                          const double *base, double *out) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  double acc = 0.;
+  const long long cmax = r / SYMV_W;
+  for (long long c = 0; c <= cmax; ++c) acc += rowpart[c * ldp + r];
+  const long long nseg = (n + SYMV_SEG - 1) / SYMV_SEG;
+  for (long long sgm = (cmax * SYMV_W) / SYMV_SEG; sgm < nseg; ++sgm) acc += colpart[sgm * ldp + r];
+  out[r] = alpha * acc + (base ? beta * base[r] : 0.);
+}
+
+// ws: symv_ws_elems(n) doubles of scratch
+size_t symv_ws_elems(long long n) {
+  const long long ldp = (n + 7) / 8 * 8;
+  return (size_t)ldp * (size_t)((n + SYMV_W - 1) / SYMV_W + (n + SYMV_SEG - 1) / SYMV_SEG);
+}
+
+void launch_symv_lower(hipStream_t s, const double *K, long long ld, long long n, const double *p, double alpha, double beta,
+                       const double *base, double *out, double *ws) {
+  if (n <= 0) return;
+  const long long ldp = (n + 7) / 8 * 8, nstrip = (n + SYMV_W - 1) / SYMV_W, nseg = (n + SYMV_SEG - 1) / SYMV_SEG;
+  double *rowpart = ws, *colpart = ws + ldp * nstrip;
+  hipLaunchKernelGGL(symv_lower_kernel, dim3((unsigned)nstrip, (unsigned)nseg), dim3(256), 0, s, K, ld, n, p, rowpart, ldp, colpart);
+  hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rowpart, colpart, ldp, n, alpha, beta, base, out);
+}
+
 // batched: out[b * m + j] = sum_i Q_b[i, j] z_b[i], Q_b = Q + b * stride_Q (m x m, ld), z_b = z + b * stride_z
 __global__ __launch_bounds__(256) void colvec_dot_batched_kernel(const double *__restrict__ Q, long long ld,
                                                                  long long stride_Q, long long m,

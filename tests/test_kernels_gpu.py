@@ -161,3 +161,25 @@ def test_update_ahead_panel_kernel(ctx, dbg, n, monkeypatch):
         assert np.abs(out[mode][0] - L).max() <= 1e-11 * np.abs(L).max()
         assert np.abs(out[mode][1] - np.linalg.solve(L, y)).max() <= 1e-10
     assert abs(out["0"][2] - out["8192"][2]) <= 1e-10 * abs(out["0"][2])
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 500, 4096, 4097, 9000])
+def test_symv_lower(ctx, dbg, n):
+    """launch_symv_lower (the K p of the mixed-precision fit's conjugate gradients): only the lower triangle is read
+    (the upper one holds NaN here), every stored entry used twice; against numpy."""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n))
+    K = B + B.T
+    ld = n + (n % 2) + 2
+    Kd = np.full((ld, n), np.nan, order="F")
+    Kd[:n] = np.tril(K) + np.triu(np.full((n, n), np.nan), 1)
+    p, base = rng.standard_normal(n), rng.standard_normal(n)
+    out = np.empty(n)
+    dbg.agp_debug_symv_lower.restype = C.c_int
+    dbg.agp_debug_symv_lower.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_double, C.c_double,
+                                         C.c_void_p, C.c_void_p]
+    assert dbg.agp_debug_symv_lower(ctx._h, _p(Kd), n, ld, _p(p), -1.0, 0.5, _p(base), _p(out)) == 0
+    want = -(K @ p) + 0.5 * base
+    assert np.abs(out - want).max() <= 1e-12 * max(1., np.abs(K).sum(axis=1).max() * np.abs(p).max())
+    assert dbg.agp_debug_symv_lower(ctx._h, _p(Kd), n, ld, _p(p), 1.0, 0.0, None, _p(out)) == 0
+    assert np.abs(out - K @ p).max() <= 1e-12 * max(1., np.abs(K).sum(axis=1).max() * np.abs(p).max())
