@@ -508,6 +508,8 @@ def run_rank(args):
         ok, why = True, ""
         try:
             resid = sampled_residual(x_h, y_h, sharded_step(True))
+            if os.environ.get("BENCH_TEST_SHARDED_FAILURE") == str(rank):  # test hook: this rank's self-check "fails"
+                resid = 1.0
             self_check = {"rows": 64, "max_rel_residual": resid, "ok": bool(resid < 1e-8),
                           "what": "max_r |(K a)_r - y_r| / max|y| of a sharded fit before the timed region, numpy from the features"}
             if not self_check["ok"]:

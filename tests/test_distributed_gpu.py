@@ -415,3 +415,36 @@ def test_sparse_fit_sharded_through_rccl_group_of_one(ctx):
         assert np.array_equal(a.get_fit().information, b.get_fit().information) and a.get_fit().nll == b.get_fit().nll
     finally:
         comm.close()
+
+
+def _run_bench(extra_env, *args):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SINGLE_DEVICE="1", **extra_env)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n", "2048",
+                        *args], env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the two ranks are child processes; on this one-GPU box they share GPU 0
+    and the collectives are staged over gloo (BENCH_SINGLE_DEVICE test mode - the transport string says so)."""
+    rc, line, err = _run_bench({})
+    assert rc == 0 and line is not None, err[-2000:]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["n_ranks"] == 2
+    assert "callbacks" in line["config"]["transport"] and "not RCCL" in line["config"]["transport"]
+    assert line["self_check"]["ok"] and line["self_check"]["max_rel_residual"] < 1e-8
+    assert "sharded_fallback" not in line
+
+
+def test_bench_falls_back_to_replicas_when_the_sharded_fit_fails_its_check():
+    """one rank's self-check of the sharded fit "fails" (test hook): every rank agrees over gloo to measure independent fits
+    instead, and the line says so - weak scaling, FALLBACK in the parallelism string, the reason recorded."""
+    rc, line, err = _run_bench({"BENCH_TEST_SHARDED_FAILURE": "1"})
+    assert rc == 0 and line is not None, err[-2000:]
+    assert line["scaling"] == "weak" and line["config"]["parallelism"].startswith("FALLBACK")
+    assert "failed" in line["sharded_fallback"] and line["self_check"]["ok"]
+    rc, line, err = _run_bench({"BENCH_TEST_SHARDED_FAILURE": "1"}, "--no-fallback")
+    assert rc != 0 and line is None
