@@ -139,6 +139,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->ws_aux) (void)hipFree(ctx->ws_aux);
   if (ctx->d_zpub) (void)hipFree(ctx->d_zpub);
   if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
+  if (ctx->d_merge_cnt) (void)hipFree(ctx->d_merge_cnt);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);

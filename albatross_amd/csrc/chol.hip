@@ -59,6 +59,11 @@ struct PotrfArgs {
   // dpub: 36 tiles (the LDS tile layout of the diagonal block) through which the workgroups that update the diagonal
   // block hand it to the one that factors it (sentinel-filled, see store_pub)
   double *dpub = nullptr;
+  // merged trailing update (factor_lower): the block column this panel starts is being written by a bulk update that is
+  // STILL RUNNING on another stream; its tiles count themselves in *wait_counter when complete.  The kernel waits for
+  // wait_value of them and then reads the block with device-scope loads.  nullptr: off.
+  const unsigned long long *wait_counter = nullptr;
+  unsigned long long wait_value = 0;
 };
 
 constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
@@ -354,6 +359,18 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) T[t * (MB * MB) + tid] = v[t];
   } else {  // thread (r, c) of every tile; all 36 loads in flight
+    const bool live = p.wait_counter != nullptr;
+    if (live) {
+      if (tid == 0) {
+        unsigned long long t0 = 0;
+        for (int spin = 0; __hip_atomic_load(p.wait_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.wait_value; ++spin) {
+          if (spin == 0) t0 = __builtin_amdgcn_s_memrealtime();
+          else if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      __syncthreads();
+    }
     const int r = tid & 15, c = tid >> 4;
     double v[NTILE];
 #pragma unroll
@@ -362,7 +379,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
       for (int kb = 0; kb <= ib; ++kb) {
         const int gr = ib * MB + r, gc = kb * MB + c;
         double x;
-        if (gr < nbk && gc < nbk) x = (gr >= gc) ? Adiag[gc * p.lda + gr] : 0.;
+        if (gr < nbk && gc < nbk) x = (gr >= gc) ? (live ? load_pub(Adiag + gc * p.lda + gr) : Adiag[gc * p.lda + gr]) : 0.;
         else x = (gr == gc) ? 1. : 0.;  // identity padding of a partial last block
         v[ib * (ib + 1) / 2 + kb] = x;
       }
@@ -878,8 +895,10 @@ __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
 // block ib with the already-solved block jb > ib.
 
 static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, int nbk, double *img,
-                         double *y, int *flags, double *scalars) {
+                         double *y, int *flags, double *scalars, const unsigned long long *wait_counter = nullptr,
+                         unsigned long long wait_value = 0) {
   PotrfArgs p;
+  p.wait_counter = wait_counter; p.wait_value = wait_value;
   p.A = A; p.lda = lda; p.k0 = k0; p.nbk = nbk;
   p.img = img + (k0 / NB) * (long long)IMG_DOUBLES;
   p.y = y ? y + k0 : nullptr;
@@ -890,7 +909,8 @@ static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, 
 // trailing update C -= P P^T (lower tiles) bracketed by a HIP-event pair when
 // the caller collects per-launch timings (bench.py's roofline block)
 static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long lda, const double *P,
-                       const double *Q, long long M, long long N, long long K, bool bulk, int variant = -1) {
+                       const double *Q, long long M, long long N, long long K, bool bulk, int variant = -1,
+                       unsigned long long *done = nullptr, int done_cols = 0) {
   // only the bulk trailing updates' trailing_update_kernel launches (their own kernel symbol) are
   // event-timed: they run on the second stream, where an event gap is off the critical path
   if (!bulk) {
@@ -900,7 +920,8 @@ static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long
   BulkTiming bt;
   const bool timed = timers && timers->ev && timers->used + 2 <= timers->n_ev;
   if (timed) { bt.e0 = timers->ev[timers->used]; bt.e1 = timers->ev[timers->used + 1]; }
-  if (variant >= 0) launch_trailing_update_as(variant, s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
+  if (done) launch_trailing_update_as(0, s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr, done, done_cols);
+  else if (variant >= 0) launch_trailing_update_as(variant, s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
   else launch_trailing_update(s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
   if (timed && bt.flops > 0.) {
     timers->flops[timers->used / 2] = bt.flops;  // algorithmic flop: 2 K per covered C entry on or below the diagonal
@@ -981,7 +1002,8 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
 // of the remaining columns of the outer block.  Everything on stream s.
 static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *invd,
                         double *y, long long K0, long long kend, FactorTimers *timers, hipEvent_t after_first = nullptr,
-                        bool upd_prev = false) {
+                        bool upd_prev = false, const unsigned long long *wait_counter = nullptr,
+                        unsigned long long wait_value = 0) {
   // AGP_INNER_LEFT=1: left-looking inside the outer block - panel k is brought up to date with the panels
   // [K0, k) of this outer block in ONE product of depth k - K0 just before it is factored, instead of every
   // panel updating all later columns of the outer block with depth 128 (same flop, a third of the C traffic,
@@ -999,7 +1021,8 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
   // chip that costs it more than the saved launch (measured: 43.3 -> 41.8 TFLOP/s), so the fused kernel takes over
   // where the panel chain is the critical path (AGP_FUSED_BELOW remaining rows)
   const bool fused = panel_fused_enabled() && ctx->d_zpub && ctx->zpub_ready_n >= kend && ctx->img_ready == invd &&
-                     ((n - K0) <= fused_below() || upd_prev);  // (factor_lower asks for upd_prev only when all of this holds)
+                     ((n - K0) <= fused_below() || upd_prev) &&  // (factor_lower asks for upd_prev only when all of this holds)
+                     !wait_counter;                             // (merged updates: the bulk-bound phase, two launches)
   for (long long k = K0; k < kend; k += NB) {
     const int nbk = (int)((n - k < NB) ? n - k : NB);
     if (inner_left && k > K0) {
@@ -1024,7 +1047,7 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
       }
       if (below <= 0) continue;
     } else {
-    launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars);
+    launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars, k == K0 ? wait_counter : nullptr, wait_value);
     if (below <= 0) continue;
     TrsmArgs t;
     t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
@@ -1155,6 +1178,17 @@ static long long u1_f32_above() {
   return v;
 }
 
+// Remaining rows above which U1 is merged into the bulk update (see factor_lower); AGP_MERGE_ABOVE, default 0 = off.
+// Measured (scripts/sweep_merge.sh, profiles/r03/sweep_merge.txt): with 8704 the bulk kernel runs at 46.5 instead of
+// 43.1 TFLOP/s (0.59 instead of 0.55 of the datasheet peak) - and the fit takes 33.9 instead of 33.7 ms, three runs each:
+// before, U1 rode along on the chain stream at 5 TFLOP/s on top of the bulk update's 43, and 48 TFLOP/s is what the
+// fp64 matrix pipe issues at 2.37 GHz whoever asks.  The bulk-bound phase is AT that ceiling either way.
+constexpr int MERGE_SLOTS = 1024;  // one counter per outer step of a factorisation (N <= 524288 at 512 columns per step)
+static long long merge_above() {
+  const char *e = getenv("AGP_MERGE_ABOVE");
+  return e ? atoll(e) : 0;
+}
+
 static long long single_below() {
   static long long v = -1;
   if (v < 0) {
@@ -1191,6 +1225,15 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   long long kend = K0 + pick_nbo(n, nbo_fixed);
   if (kend > n) kend = n;
   panel_fused_prepare(ctx, sa, invd, 0, n);
+  long long step_index = 0;
+  if (merge_above() > 0 && n > merge_above()) {
+    if (!ctx->d_merge_cnt && hipMalloc(&ctx->d_merge_cnt, sizeof(unsigned long long) * MERGE_SLOTS) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->d_merge_cnt = nullptr;
+    }
+    // (the bulk stream's first launch waits for an event recorded on this stream after this memset)
+    if (ctx->d_merge_cnt) (void)hipMemsetAsync(ctx->d_merge_cnt, 0, sizeof(unsigned long long) * MERGE_SLOTS, sa);
+  }
   panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers);
   while (kend < n) {
     long long next_end = kend + pick_nbo(n - kend, nbo_fixed);
@@ -1209,12 +1252,33 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     else if (nbo_fixed == 0 && n - kend <= single_below()) next_end = n;
     const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
-    if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);   // U2(j - 1) done
     // U1: block column [kend, next_end), all rows below its diagonal.  In the chain-bound phase only its first 128
     // columns - all the next diagonal block and its panel wait for - stay on the chain; the other columns go to the side
     // stream and are awaited right after the first panel kernel of P(j + 1) (AGP_U1_SPLIT_BELOW remaining rows).
     hipEvent_t after_first = nullptr;
-    if (upd) {
+    // Merged trailing update (bulk-bound phase, AGP_MERGE_ABOVE remaining rows): U1 is NOT a launch of its own on the
+    // chain stream - the bulk update on the second stream covers the next block column too, as its FIRST tile columns,
+    // writes them with device-scope stores and counts them; the next panel's POTRF waits for that count inside the
+    // kernel.  The 9 % of the factorisation's flop that U1 carries then run at the bulk kernel's efficiency (128 x 128
+    // tiles, MfmaUtil 0.67) instead of the 64 x 64-tile kernel's (0.40), and nothing but POTRF / TRSM / the inner
+    // updates shares the chip with the bulk update.
+    const long long dcols = (next_end - kend) / NB;
+    const bool merged = !upd && next_end < n && (next_end - kend) % NB == 0 && variant < 0 && nbo_fixed == 0 && ctx->d_merge_cnt &&
+                        merge_above() > 0 && (n - kend) > merge_above() &&
+                        trailing_update_full_tiles(n - kend) >= dcols * ((n - kend + NB - 1) / NB);
+    unsigned long long *mcnt = nullptr, mwait = 0;
+    if (merged) {
+      mcnt = ctx->d_merge_cnt + (step_index % MERGE_SLOTS);
+      const long long ntr = (n - kend + NB - 1) / NB;
+      for (long long bj = 0; bj < dcols; ++bj) mwait += (unsigned long long)(ntr - bj);
+    }
+    ++step_index;
+    // (U2(j - 1) must be done before anything of step j touches the next block column - except in merged mode, where the
+    // bulk stream's own order does that and the chain waits for the counted tiles only)
+    if (have_u2 && !merged) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
+    if (merged) {
+      // nothing on the chain stream
+    } else if (upd) {
       // nothing here: panel_phase(..., upd_prev = true) below applies it
     } else if (ctx->stream_side && next_end - kend > NB && (n - kend) <= u1_split_below()) {
       hipStream_t sc = ctx->stream_side;
@@ -1246,7 +1310,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     if (sb != sb_prev && have_u2) (void)hipStreamWaitEvent(sb, ctx->ev_b, 0);  // U2(j - 1) ran on the other bulk stream
     sb_prev = sb;
     const bool throttle = next_end < n && (n - kend) <= throttle_below();
-    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd);
+    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd, mcnt, mwait);
     if (next_end < n) {
       if (throttle) {
         while (hipEventQuery(ctx->ev_a) == hipErrorNotReady) {}
@@ -1258,14 +1322,19 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
       } else {
         (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       }
-      const double *Q = A + K0 * lda + next_end;
-      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant);
+      if (merged) {
+        const double *Q = A + K0 * lda + kend;  // everything right of block j, the next block column first
+        timed_gemm(sb, timers, A + kend * lda + kend, lda, Q, Q, n - kend, n - kend, K, true, variant, mcnt, (int)dcols);
+      } else {
+        const double *Q = A + K0 * lda + next_end;
+        timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant);
+      }
       (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;
     } else {
       have_u2 = false;
     }
-    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd);
+    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd, mcnt, mwait);
     K0 = kend;
     kend = next_end;
   }

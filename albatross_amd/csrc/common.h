@@ -112,6 +112,8 @@ struct agp_context {
   // per diagonal block, like invd; only allocated when the update-ahead panel kernel is in use)
   double *d_dpub = nullptr;
   long long dpub_cap = 0;  // diagonal blocks
+  // merged trailing updates (factor_lower): one completion counter per outer step
+  unsigned long long *d_merge_cnt = nullptr;
   const double *img_ready = nullptr;
 };
 
@@ -240,7 +242,8 @@ struct BulkTiming {
 };
 void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
                                const double *Q, long long ldp, long long M, long long K,
-                               BulkTiming *timing = nullptr);
+                               BulkTiming *timing = nullptr, unsigned long long *done = nullptr, int done_cols = 0);
+long long trailing_update_full_tiles(long long M);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
 void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P, const double *Q, long long ldp, long long M,

@@ -55,6 +55,12 @@ struct GemmArgs {
   // tile columns up to its own diagonal tile: bj <= gi * st_tpb - st_c0t + bi % st_tpb.  stair == 0: off.
   int stair = 0, st_world = 1, st_rank = 0, st_tpb = 4;
   long long st_lb0 = 0, st_c0t = 0;
+  // merged trailing update (chol.hip: factor_lower): the tiles of the first done_cols tile columns - the NEXT block
+  // column, which the panel chain waits for - are written with device-scope stores and counted in *done when complete,
+  // so that the next panel's POTRF (another launch, another stream) can start on them while this launch is still busy
+  // with everything further right.  done == nullptr: off.
+  unsigned long long *done = nullptr;
+  int done_cols = 0;
 };
 
 // Load this thread's 8 doubles of a 128 x 16 operand chunk.
@@ -185,6 +191,7 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
   int bi, bj;
   if (!tile_of_block(g, bi, bj)) return;
   const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+  const bool counted = g.done != nullptr && bj < g.done_cols;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -279,10 +286,18 @@ __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds)
 #endif
         if (row < g.M && col < g.N) {
           double *c = g.C + row + col * g.ldc;
-          *c = *c + acc[tj][ti][r];
+          const double v = *c + acc[tj][ti][r];
+          if (counted) __hip_atomic_store(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the XCD-private L2
+          else *c = v;
         }
       }
     }
+  if (counted) {
+    // every store of this tile acknowledged, then one count: a reader that sees the full count reads final values
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(g.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR>
@@ -887,10 +902,12 @@ static double lower_entries(long long M, int ntr, long long count) {
 }
 
 void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
-                               const double *Q, long long ldp, long long M, long long K, BulkTiming *timing) {
+                               const double *Q, long long ldp, long long M, long long K, BulkTiming *timing,
+                               unsigned long long *done, int done_cols) {
   if (timing) timing->flops = 0.;
   if (M <= 0 || K <= 0) return;
   GemmArgs g;
+  g.done = done; g.done_cols = done_cols;
   g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = Q; g.ldb = ldp;
   g.M = M; g.N = M; g.K = K; g.tri = 1;
   g.ntr = (int)((M + GT - 1) / GT);
@@ -952,6 +969,7 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
     }
     if (rem > 0) {
       GemmArgs h = g;
+      h.done = nullptr;  // (the counted tiles are the first ones of the launch above)
       h.tile_first = full;
       hipLaunchKernelGGL(trailing_update_tail_kernel, dim3((unsigned)(4 * rem)), dim3(GEMM_THREADS), 0, s, h);
     }
@@ -979,6 +997,20 @@ void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P,
   if (tiles > 0) hipLaunchKernelGGL(trailing_update_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
 }
 
+// number of tiles the first launch (trailing_update_kernel, full rounds) of launch_trailing_update_as(0, ...) covers at size M:
+// a merged update may only count tile columns that lie entirely inside it
+long long trailing_update_full_tiles(long long M) {
+  const int ntr = (int)((M + GT - 1) / GT);
+  const long long tiles = count_tiles(ntr, ntr, 1);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  const long long slots = 2LL * cus;
+  if (tiles < 4 * slots) return 0;
+  const long long full = (tiles / slots) * slots, rem = tiles - full;
+  return (rem * 4 >= 3 * slots) ? tiles : full;
+}
+
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing) {
   static int variant = -1;
@@ -989,7 +1021,7 @@ void launch_trailing_update(hipStream_t s, double *C, long long ldc, const doubl
     const char *e = getenv("AGP_UPDATE_KERNEL");
     variant = (e && e[0] == 'd') ? 2 : 0;
   }
-  launch_trailing_update_as(variant, s, C, ldc, P, Q, ldp, M, K, timing);
+  launch_trailing_update_as(variant, s, C, ldc, P, Q, ldp, M, K, timing, nullptr, 0);
 }
 
 void read_mfma_clock(unsigned long long out[4], bool reset) {

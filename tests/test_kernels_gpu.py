@@ -183,3 +183,28 @@ def test_symv_lower(ctx, dbg, n):
     assert np.abs(out - want).max() <= 1e-12 * max(1., np.abs(K).sum(axis=1).max() * np.abs(p).max())
     assert dbg.agp_debug_symv_lower(ctx._h, _p(Kd), n, ld, _p(p), 1.0, 0.0, None, _p(out)) == 0
     assert np.abs(out - K @ p).max() <= 1e-12 * max(1., np.abs(K).sum(axis=1).max() * np.abs(p).max())
+
+
+def test_merged_trailing_update(ctx, dbg, monkeypatch):
+    """AGP_MERGE_ABOVE: U1 merged into the bulk update, whose first tile columns count themselves complete while the next
+    panel's POTRF waits for that count inside the kernel (chol.hip: factor_lower; an experiment that is off by default):
+    same factor as the default schedule.  Needs >= 8192 trailing rows for the counted tiles to lie in the first launch."""
+    n = 9728
+    rng = np.random.default_rng(7)
+    B = rng.standard_normal((n, 64))
+    A = np.asfortranarray(B @ B.T + 64. * np.eye(n))
+    y = rng.standard_normal(n)
+    out = {}
+    for mode in ("0", "2048"):
+        monkeypatch.setenv("AGP_MERGE_ABOVE", mode)
+        Ad, yd = A.copy(order="F"), y.copy()
+        logdet, bad = C.c_double(), C.c_int64()
+        assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
+        assert bad.value == -1
+        out[mode] = (np.tril(Ad), yd, logdet.value)
+    L0, L1 = out["0"][0], out["2048"][0]
+    assert np.abs(L0 - L1).max() <= 1e-11 * np.abs(L0).max()
+    assert np.abs(out["0"][1] - out["2048"][1]).max() <= 1e-10 * np.abs(out["0"][1]).max()
+    assert abs(out["0"][2] - out["2048"][2]) <= 1e-10 * abs(out["0"][2])
+    rows = rng.integers(0, n, 40)
+    assert np.abs((L1[rows] @ L1.T) - A[rows]).max() <= 1e-11 * np.abs(A).max()
