@@ -827,7 +827,10 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
   double *symv_ws = nullptr;
   AGP_HIP_CHECK(ctx, hipMalloc(&symv_ws, sizeof(double) * symv_ws_elems(n)));
   struct FreeS { double *p; ~FreeS() { if (p) (void)hipFree(p); } } free_s{symv_ws};
-  const long long BW = backsolve_width(n);
+  // (1024-wide inverted blocks here: the eight-odd preconditioner applications share one inversion, and half as many
+  // launch-bound block steps per sweep are worth 5 ms at N = 32768; a single substitution is better off with 512)
+  long long BW = backsolve_width(n);
+  if (BW == 512 && !getenv("AGP_WIDE_BACKSOLVE") && n % 1024 == 0 && n >= 8192) BW = 1024;
   double *Wwide = nullptr;
   if (BW) {
     AGP_HIP_CHECK(ctx, hipMalloc(&Wwide, sizeof(double) * (size_t)(n / BW) * (size_t)BW * (size_t)BW));
