@@ -134,6 +134,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->ws_A) (void)hipFree(ctx->ws_A);
   if (ctx->pool_A) (void)hipFree(ctx->pool_A);
   if (ctx->pool_K) (void)hipFree(ctx->pool_K);
+  if (ctx->pool_aux) (void)hipFree(ctx->pool_aux);
   if (ctx->pool_shard) (void)hipFree(ctx->pool_shard);
   if (ctx->pool_sparse) (void)hipFree(ctx->pool_sparse);
   if (ctx->ws_aux) (void)hipFree(ctx->ws_aux);
@@ -376,8 +377,29 @@ int copy_out_2d(agp_context *ctx, const double *dev, long long ld_dev, long long
 
 // Gram + diag add + LL^T (+ fused forward substitution) on A / y.  On return
 // the stream has been synchronised and ctx->h_flags / h_scalars are valid.
+// finish = false: everything is enqueued, nothing is waited for - the caller goes on enqueueing (the backward
+// substitution of a fit) and calls finish_factor() after its own synchronisation.
+static void finish_factor(agp_context_impl *ctx, const FactorTimers &timers) {
+  if (!ctx->profiling) return;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->stage_ev[0], ctx->stage_ev[1]);
+  ctx->stage_ms[0] = ms;
+  (void)hipEventElapsedTime(&ms, ctx->stage_ev[1], ctx->stage_ev[2]);
+  ctx->stage_ms[1] = ms;
+  double sum = 0., flop = 0.;
+  for (int i = 0; i + 1 < timers.used; i += 2) {
+    (void)hipEventElapsedTime(&ms, timers.ev[i], timers.ev[i + 1]);
+    sum += ms;
+    flop += timers.flops[i / 2];
+  }
+  ctx->stage_ms[3] = sum;
+  ctx->stage_ms[4] = timers.used / 2;
+  ctx->stage_ms[5] = flop;  // flop of the trailing updates (not ms)
+}
+
 static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevProgram *hprog, const FeatView &xm,
-                            double *A, long long lda, double *invd, double *y, const double *yvar) {
+                            double *A, long long lda, double *invd, double *y, const double *yvar, bool finish = true,
+                            FactorTimers *timers_out = nullptr) {
   agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
   const long long n = xm.n;
   hipStream_t s = ctx->stream;
@@ -409,24 +431,11 @@ static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevPr
   if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[2], s));
   AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (timers_out) *timers_out = timers;
+  if (!finish) return AGP_OK;
   AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
   AGP_HIP_CHECK(ctx, hipGetLastError());
-  if (prof) {
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, ctx->stage_ev[0], ctx->stage_ev[1]);
-    ctx->stage_ms[0] = ms;
-    (void)hipEventElapsedTime(&ms, ctx->stage_ev[1], ctx->stage_ev[2]);
-    ctx->stage_ms[1] = ms;
-    double sum = 0., flop = 0.;
-    for (int i = 0; i + 1 < timers.used; i += 2) {
-      (void)hipEventElapsedTime(&ms, timers.ev[i], timers.ev[i + 1]);
-      sum += ms;
-      flop += timers.flops[i / 2];
-    }
-    ctx->stage_ms[3] = sum;
-    ctx->stage_ms[4] = timers.used / 2;
-    ctx->stage_ms[5] = flop;  // flop of the trailing updates (not ms)
-  }
+  finish_factor(ctx, timers);
   return AGP_OK;
 }
 
@@ -549,10 +558,20 @@ void agp_fit_destroy(agp_fit *fit) {
       (void)hipFree(fit->A);
     }
   }
-  if (fit->invd) (void)hipFree(fit->invd);
-  if (fit->winv) (void)hipFree(fit->winv);
-  if (fit->alpha) (void)hipFree(fit->alpha);
-  if (fit->z) (void)hipFree(fit->z);
+  if (fit->aux_base) {
+    agp_context *ctx = fit->ctx;
+    if (ctx && !ctx->pool_aux) {
+      ctx->pool_aux = fit->aux_base;
+      ctx->pool_aux_bytes = fit->aux_bytes;
+    } else {
+      (void)hipFree(fit->aux_base);
+    }
+  } else {
+    if (fit->invd) (void)hipFree(fit->invd);
+    if (fit->winv) (void)hipFree(fit->winv);
+    if (fit->alpha) (void)hipFree(fit->alpha);
+    if (fit->z) (void)hipFree(fit->z);
+  }
   fit->train.release();
   delete fit;
 }
@@ -703,10 +722,21 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   } else {
     FIT_CHECK(hipMalloc(&fit->A, fit->A_bytes));
   }
-  FIT_CHECK(hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * (36 * MB * MB)));
-  FIT_CHECK(hipMalloc(&fit->winv, sizeof(double) * (size_t)nblk * NB * NB));
-  FIT_CHECK(hipMalloc(&fit->alpha, sizeof(double) * (size_t)n));
-  FIT_CHECK(hipMalloc(&fit->z, sizeof(double) * (size_t)n));
+  {
+    const size_t n_invd = (size_t)nblk * (36 * MB * MB), n_winv = (size_t)nblk * NB * NB, n_vec = (size_t)round_up(n, 2);
+    fit->aux_bytes = sizeof(double) * (n_invd + n_winv + 2 * n_vec);
+    if (ctx->pool_aux && ctx->pool_aux_bytes == fit->aux_bytes) {
+      fit->aux_base = ctx->pool_aux;
+      ctx->pool_aux = nullptr;
+      ctx->pool_aux_bytes = 0;
+    } else {
+      FIT_CHECK(hipMalloc(&fit->aux_base, fit->aux_bytes));
+    }
+    fit->invd = fit->aux_base;
+    fit->winv = fit->invd + n_invd;
+    fit->alpha = fit->winv + n_winv;
+    fit->z = fit->alpha + n_vec;
+  }
   const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   FIT_CHECK(hipMemcpyAsync(fit->z, y, sizeof(double) * (size_t)n, kind, s));
   if (y_var) {
@@ -736,19 +766,27 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     ctx->update_variant = 3;  // fp32-product bulk updates
     if (const char *e = getenv("AGP_MIXED_NBO")) ctx->nbo_override = atoll(e);  // experiment: fixed outer width
   }
-  st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d);
+  // The fp64 fit does not wait for the factorisation before it enqueues the backward substitution: one host round trip
+  // (~0.1 ms) less; the status is read after the single synchronisation at the end, and a substitution through a factor
+  // that turns out not to be positive definite was wasted work on garbage, nothing more.  (The flags and the
+  // log-determinant are copied to the host right behind the factorisation, before the substitution touches d_scalars.)
+  const bool deferred = !mixed && !yvar_d;
+  FactorTimers ftimers;
+  st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d, !deferred, &ftimers);
   ctx->update_variant = -1;
   ctx->nbo_override = 0;
   if (yvar_d) { (void)hipFree(yvar_d); yvar_d = nullptr; }
   if (st != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st; }
-  st = status_from_flags(ctx);
-  fit->failed_pivot = ctx->h_flags[1] ? (int64_t)ctx->h_flags[1] - 1 : -1;
-  fit->log_det = 2. * ctx->h_scalars[0];
-  if (st != AGP_OK) {
-    // keep a handle so the caller can query the failed pivot, but no factor
-    drop_mixed();
-    *out = fit;
-    return st;
+  if (!deferred) {
+    st = status_from_flags(ctx);
+    fit->failed_pivot = ctx->h_flags[1] ? (int64_t)ctx->h_flags[1] - 1 : -1;
+    fit->log_det = 2. * ctx->h_scalars[0];
+    if (st != AGP_OK) {
+      // keep a handle so the caller can query the failed pivot, but no factor
+      drop_mixed();
+      *out = fit;
+      return st;
+    }
   }
   // information = L^-T (L^-1 y)
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[3], s));
@@ -777,6 +815,16 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   if (information) FIT_CHECK(hipMemcpyAsync(information, fit->alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   FIT_CHECK(hipStreamSynchronize(s));
   FIT_CHECK(hipGetLastError());
+  if (deferred) {
+    finish_factor(ctx, ftimers);
+    st = status_from_flags(ctx);
+    fit->failed_pivot = ctx->h_flags[1] ? (int64_t)ctx->h_flags[1] - 1 : -1;
+    fit->log_det = 2. * ctx->h_scalars[0];
+    if (st != AGP_OK) {  // keep a handle so the caller can query the failed pivot, but no factor
+      *out = fit;
+      return st;
+    }
+  }
   if (ctx->profiling) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ctx->stage_ev[3], ctx->stage_ev[4]);

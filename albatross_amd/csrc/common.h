@@ -92,6 +92,9 @@ struct agp_context {
   // ... and one cached exact-covariance buffer of the mixed-precision fit (its CG refinement multiplies with K itself)
   double *pool_K = nullptr;
   size_t pool_K_bytes = 0;
+  // ... and one cached block of a fit's small buffers (agp_fit::aux_base)
+  double *pool_aux = nullptr;
+  size_t pool_aux_bytes = 0;
   // bulk-update kernel of the next factorisation: -1 = default (fp64 MFMA), 3 = fp32 products
   // (agp_fit_create_mixed sets and resets it around its factor_lower call)
   int update_variant = -1;
@@ -129,6 +132,11 @@ struct agp_fit {
   double *winv = nullptr;   // (n/NB) inverted NB x NB diagonal blocks
   double *alpha = nullptr;  // information vector K^-1 y
   double *z = nullptr;      // L^-1 y
+  // agp_fit_create makes invd / winv / alpha / z slices of ONE allocation (aux_base, aux_bytes), which agp_fit_destroy
+  // parks in the context like the factor's buffer: four hipMalloc + four hipFree per fit less.  nullptr: the four are
+  // allocations of their own (every other maker of an agp_fit).
+  double *aux_base = nullptr;
+  size_t aux_bytes = 0;
   agp::DeviceFeatures train;
   double log_det = 0.;
   int64_t failed_pivot = -1;
