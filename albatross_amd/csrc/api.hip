@@ -88,6 +88,7 @@ int agp_context_create(int device_id, agp_context **out) {
     // onto its few hardware queues and cost 3.5 ms per N = 16384 fit (33.7 -> 37.2 ms) before it was used at all
     ctx->stream_side = ctx->stream3;
     AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
+    AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_inv, hipEventDisableTiming));
     AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
     // CU mask of the end-phase bulk stream: bit i = CU i, and CU i sits on XCD i % 8 (measured with
     // scripts/probe_cumask.py: dropping the LAST indices keeps the XCDs balanced, dropping i % 32 >= 28 does not).
@@ -151,6 +152,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream3 && ctx->stream3 != ctx->stream2) (void)hipStreamDestroy(ctx->stream3);
   if (ctx->ev_d) (void)hipEventDestroy(ctx->ev_d);
+  if (ctx->ev_inv) (void)hipEventDestroy(ctx->ev_inv);
   if (ctx->stream_masked) (void)hipStreamDestroy(ctx->stream_masked);
   if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
   delete ctx;
@@ -597,8 +599,10 @@ size_t backsolve_ws_elems(long long n) {
   return (size_t)round_up(n, 2) + blocks;
 }
 
+// first_done / ev_done: the inverses of the first `first_done` blocks are already being computed on another stream
+// (factor_lower's early inversion); ev_done completes when they are there.
 void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
-                            double *z, double *ws) {
+                            double *z, double *ws, long long first_done, hipEvent_t ev_done) {
   double *xs = ws, *W = ws + round_up(n, 2);
   const long long BW = backsolve_width(n);
   if (!BW) {
@@ -607,9 +611,15 @@ void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long lo
     return;
   }
   const long long nb = n / BW;
-  launch_set_identity_batched(s, W, BW, BW * BW, BW, nb);
-  forward_solve_mat_batched(s, A, BW * (lda + 1), BW, lda, invd, (BW / NB) * (long long)(36 * MB * MB), W, BW * BW, BW, BW,
-                            /*rhs_lower=*/true, nb);
+  if (first_done < 0 || first_done > nb) first_done = 0;
+  if (first_done < nb) {
+    const long long cnt = nb - first_done;
+    launch_set_identity_batched(s, W + first_done * BW * BW, BW, BW * BW, BW, cnt);
+    forward_solve_mat_batched(s, A + first_done * BW * (lda + 1), BW * (lda + 1), BW, lda,
+                              invd + first_done * (BW / NB) * (long long)(36 * MB * MB), (BW / NB) * (long long)(36 * MB * MB),
+                              W + first_done * BW * BW, BW * BW, BW, BW, /*rhs_lower=*/true, cnt);
+  }
+  if (first_done > 0 && ev_done) (void)hipStreamWaitEvent(s, ev_done, 0);
   for (long long b = nb - 1; b >= 0; --b) {
     const long long k0 = b * BW;
     launch_colvec_dot(s, W + b * BW * BW, BW, BW, BW, z + k0, 1.0, 0.0, nullptr, xs + k0);  // x_B = inv(L_BB)^T z_B
@@ -772,9 +782,22 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   // log-determinant are copied to the host right behind the factorisation, before the substitution touches d_scalars.)
   const bool deferred = !mixed && !yvar_d;
   FactorTimers ftimers;
+  long long bs_done = 0;
+  if (deferred && backsolve_width(n) && !getenv("AGP_NO_EARLY_INVERSION")) {
+    // the inverses of the wide diagonal blocks for the backward substitution: computed by factor_lower on its idle
+    // second stream while the chain-bound tail of the factorisation runs (common.h: bs_W)
+    if (ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * backsolve_ws_elems(n)) == AGP_OK) {
+      ctx->bs_W = ctx->ws_aux + round_up(n, 2);
+      ctx->bs_BW = backsolve_width(n);
+      ctx->bs_done = 0;
+    }
+  }
   st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d, !deferred, &ftimers);
   ctx->update_variant = -1;
   ctx->nbo_override = 0;
+  bs_done = ctx->bs_W ? ctx->bs_done : 0;
+  ctx->bs_W = nullptr;
+  ctx->bs_done = 0;
   if (yvar_d) { (void)hipFree(yvar_d); yvar_d = nullptr; }
   if (st != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st; }
   if (!deferred) {
@@ -800,7 +823,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
     {
       TraceRange tr("agp: backward substitution (information = ldlt.solve(y), gp.hpp:68)");
-      backward_solve_vec_any(s, fit->A, n, fit->lda, fit->invd, fit->alpha, ctx->ws_aux);
+      backward_solve_vec_any(s, fit->A, n, fit->lda, fit->invd, fit->alpha, ctx->ws_aux, bs_done, ctx->ev_inv);
     }
     // the refinement steps of the mixed-precision fit use the 128-row chain on fit->winv
     if (mixed) invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);

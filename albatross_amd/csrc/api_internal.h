@@ -131,5 +131,5 @@ int status_from_flags(const agp_context *ctx);
 extern "C" {  // (defined inside api.hip's extern "C" block)
 size_t backsolve_ws_elems(long long n);
 void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long long lda, const double *invd, double *z,
-                            double *ws);
+                            double *ws, long long first_done = 0, hipEvent_t ev_done = nullptr);
 }

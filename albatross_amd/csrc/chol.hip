@@ -21,6 +21,7 @@
 #include "mfma_f64.h"
 
 namespace agp {
+void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);  // reduce.hip
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const long long b = __double_as_longlong(v);
@@ -1250,6 +1251,22 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
                      ctx->d_zpub && ctx->img_ready == invd && ctx->zpub_ready_n >= n;
     if (upd) next_end = (kend + NB < n) ? kend + NB : n;
     else if (nbo_fixed == 0 && n - kend <= single_below()) next_end = n;
+    if (ctx->bs_W && ctx->bs_done == 0 && next_end == n && ctx->ev_inv && ctx->stream2) {
+      // Last step: everything left of kend is final and the second stream has nothing more to do - it inverts the wide
+      // diagonal blocks the backward substitution of the fit will need (all but the last ones), off the chain.
+      const long long BW = ctx->bs_BW, done = kend / BW;
+      if (done > 0) {
+        hipStream_t si = ctx->stream2;
+        (void)hipEventRecord(ctx->ev_c, sa);  // columns < kend final
+        (void)hipStreamWaitEvent(si, ctx->ev_c, 0);
+        if (have_u2) (void)hipStreamWaitEvent(si, ctx->ev_b, 0);
+        launch_set_identity_batched(si, ctx->bs_W, BW, BW * BW, BW, done);
+        forward_solve_mat_batched(si, A, BW * (lda + 1), BW, lda, invd, (BW / NB) * (long long)IMG_DOUBLES, ctx->bs_W, BW * BW, BW, BW,
+                                  /*rhs_lower=*/true, done);
+        (void)hipEventRecord(ctx->ev_inv, si);
+        ctx->bs_done = done;
+      }
+    }
     const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
     // U1: block column [kend, next_end), all rows below its diagonal.  In the chain-bound phase only its first 128

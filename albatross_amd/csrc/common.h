@@ -117,6 +117,13 @@ struct agp_context {
   long long dpub_cap = 0;  // diagonal blocks
   // merged trailing updates (factor_lower): one completion counter per outer step
   unsigned long long *d_merge_cnt = nullptr;
+  // Early inversion of the wide diagonal blocks for the backward substitution of a fit (api.hip: backward_solve_vec_any):
+  // set by the caller of factor_lower (bs_W = where the inverses go, bs_BW = their width); factor_lower inverts the
+  // blocks that are final when it enters its single-stream tail on the (then idle) second stream, records ev_inv and
+  // reports how many it did in bs_done.  bs_W == nullptr: not requested.
+  double *bs_W = nullptr;
+  long long bs_BW = 0, bs_done = 0;
+  hipEvent_t ev_inv = nullptr;
   const double *img_ready = nullptr;
 };
 
