@@ -139,6 +139,7 @@ EXPORTS = [
     ("agp_sharded_fit_destroy", None, [_P]),
     ("agp_sharded_fit_failed_pivot", C.c_int64, [_P]),
     ("agp_sharded_fit_replicate", C.c_int, [_P, _P, _PP]),
+    ("agp_sharded_predict_marginal", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int]),
     ("agp_sharded_fit_stage", C.c_int, [_P, C.c_int, _D]),
     ("agp_shard_factor_custom", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P, _D, C.POINTER(C.c_int64)]),
     ("agp_last_stage_ms", C.c_int, [_P, C.c_int, _D]),

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and enumerators only; every function goes through the table below
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -743,6 +744,107 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
   *out = f;
 #undef SFIT_CHECK
   return AGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Marginal predictions straight from the SHARDED factor - no replication (SURVEY.md section 8e "Solve: distributed
+// forward substitution"; gp.hpp:87-101).  For factors too large to replicate on every GPU; agp_sharded_fit_replicate +
+// agp_predict_* with the test points split over the ranks remains the faster way while the factor fits (it needs no
+// exchange at all).  Every rank passes the same test points and receives all means and variances.
+//   mean      = K*^T information                      every rank has the whole information vector: no exchange
+//   variance  = k** - colsum(V o V),  V = L^-1 K*     V by block rows: the owner of block row i solves
+//               V_i = L_ii^-1 (K*_i - sum_{j<i} L_ij V_j) on its rows and broadcasts V_i (w x M), every rank subtracts
+//               L_li V_i from its own later rows; the column sums of squares are all-reduced once at the end.
+// Exchange per call: N x M doubles in nb broadcasts + one all-reduce of M doubles.
+// ---------------------------------------------------------------------------------------------------------------
+int agp_sharded_predict_marginal(agp_context *c, const agp_kernel *k, agp_sharded_fit *f, const agp_features *xs, double *mean,
+                                 double *variance, int out_location) {
+  if (!c || !k || !f || !xs || !mean || !variance || f->failed_pivot >= 0 || !f->A) return AGP_ERR_INVALID_ARGUMENT;
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  if (ctx != f->ctx) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st = validate_features(xs);
+  if (st != AGP_OK) return st;
+  if (xs->dim != f->train.v.dim) return AGP_ERR_INVALID_ARGUMENT;
+  const long long m_all = xs->n;
+  if (m_all == 0) return AGP_OK;
+  const ShardPlan &plan = f->plan;
+  const long long n = plan.n, B = plan.B, nb = plan.nb;
+  const int me = plan.rank;
+  HostReducingComm *tr = f->comm ? f->comm->impl : nullptr;
+  if (plan.multi() && !tr) return AGP_ERR_INVALID_ARGUMENT;
+  const DevProgram *dprog = nullptr;
+  if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
+  DeviceFeatures dxs;
+  if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
+  const long long n_loc = plan.multi() ? plan.local_rows(me) : n, nlb = plan.n_local_blocks(me);
+  const long long ldk = round_up(std::max<long long>(n_loc, 2), 2);
+  const long long chunk = std::min<long long>(m_all, 4096), ldc = round_up(chunk, 2);
+  // workspace: K*_loc (n_loc x chunk) | V_i (B x chunk, ld = B) | mean | prior | acc
+  double *ws = nullptr;
+  const size_t ws_elems = (size_t)ldk * (size_t)chunk + (size_t)B * (size_t)chunk + 3 * (size_t)ldc;
+  if (hipMalloc(&ws, sizeof(double) * ws_elems) != hipSuccess) { dxs.release(); ctx->last_error = "hipMalloc (sharded prediction workspace)"; return AGP_ERR_HIP; }
+  double *Kloc = ws, *Vi = Kloc + (size_t)ldk * (size_t)chunk, *mean_d = Vi + (size_t)B * (size_t)chunk, *prior = mean_d + ldc,
+         *acc = prior + ldc;
+  HipShardOps ops(ctx);
+  hipStream_t s = ctx->stream;
+  FeatView train = f->train.v;
+  for (long long o = 0; o < m_all && st == AGP_OK; o += chunk) {
+    const long long m = std::min(chunk, m_all - o);
+    FeatView xv = dxs.v;
+    xv.sstride = scale_stride(dxs.v);
+    xv.n = m;
+    xv.coords = dxs.v.coords + o * dxs.v.dim;
+    xv.ids = dxs.v.ids ? dxs.v.ids + o : nullptr;
+    xv.scales = dxs.v.scales ? dxs.v.scales + o : nullptr;
+    launch_predict_mean(s, dprog, train, xv, f->buf.xfull, mean_d, &k->prog);  // gp.hpp:82-85
+    launch_gram_diagonal(s, dprog, xv, prior);                                 // gp.hpp:339-343
+    if (!plan.multi()) {
+      // one rank: the local matrix is the whole factor (agp_sharded_fit_create's single-GPU path)
+      FeatView all = train;
+      launch_gram(s, dprog, all, xv, false, false, Kloc, ldk, nullptr, nullptr, &k->prog);
+      forward_solve_mat_lookahead(ctx, f->A, n, f->ld, f->buf.img_local, Kloc, m, ldk);
+      launch_coldot(s, Kloc, ldk, Kloc, ldk, n, m, prior, 1.0, prior);  // gp.hpp:97-99
+    } else {
+      // cross covariance of the own row blocks (cov(train_features, features), gp.hpp:337): no exchange
+      for (long long li = 0; li < nlb; ++li) {
+        const long long i = plan.global_block(me, li);
+        FeatView rows = train;
+        rows.sstride = scale_stride(train);
+        rows.coords = train.coords + i * B * train.dim;
+        rows.ids = train.ids ? train.ids + i * B : nullptr;
+        rows.scales = train.scales ? train.scales + i * B : nullptr;
+        rows.n = plan.width(i);
+        launch_gram(s, dprog, rows, xv, false, false, Kloc + li * B, ldk, nullptr, nullptr, &k->prog);
+      }
+      (void)hipMemsetAsync(acc, 0, sizeof(double) * (size_t)m, s);
+      for (long long i = 0; i < nb && st == AGP_OK; ++i) {
+        const int own = plan.owner(i);
+        const long long w = plan.width(i);
+        if (own == me) {
+          const long long li = plan.local_index(i);
+          double *Vrows = Kloc + li * B;  // w x m, ld = ldk
+          forward_solve_mat(s, f->A + li * B + i * B * f->ld, w, f->ld, f->buf.img_local + li * 4 * SHARD_IMG, Vrows, m, ldk);
+          launch_coldot(s, Vrows, ldk, Vrows, ldk, w, m, acc, 1.0, acc);  // acc -= colsum(V_i o V_i)
+          ops.copy2d(QP, Vi, B, Vrows, ldk, w, m);
+        }
+        if (i == nb - 1) break;  // nobody has rows below the last block
+        if ((st = tr->broadcast(ops, QP, Vi, B * m, own)) != AGP_OK) break;
+        const long long li2 = plan.first_local_after(me, i), rows2 = n_loc - li2 * B;
+        if (rows2 > 0)  // K*[own rows of blocks > i] -= L[those rows, block column i] V_i
+          launch_gemm_nt_sub(s, Kloc + li2 * B, ldk, f->A + li2 * B + i * B * f->ld, f->ld, false, Vi, B, true, rows2, m, w, false);
+      }
+      if (st == AGP_OK) st = tr->all_reduce(ops, QP, acc, m, 0);
+      if (st == AGP_OK) launch_axpby(s, m, 1.0, prior, 1.0, acc, prior);  // k** - sum over all ranks
+    }
+    if (st == AGP_OK) st = wait_stream(ctx, s, comm_timeout_seconds());
+    if (st == AGP_OK) st = copy_out(ctx, mean_d, m, mean + o, out_location);
+    if (st == AGP_OK) st = copy_out(ctx, prior, m, variance + o, out_location);
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(ws);
+  dxs.release();
+  return st;
 }
 
 int agp_sharded_fit_replicate(agp_context *c, agp_sharded_fit *f, agp_fit **out) {

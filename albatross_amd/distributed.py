@@ -245,6 +245,18 @@ class ShardedGaussianProcessFit:
         self.ctx._check(self.ctx._lib.agp_sharded_fit_stage(self._h, index, C.byref(v)), "agp_sharded_fit_stage")
         return v.value
 
+    def predict_marginal(self, features):
+        """gp_marginal_prediction (gp.hpp:87-101) straight from the sharded factor, WITHOUT replicating it
+        (agp_sharded_predict_marginal: distributed forward substitution, one broadcast per block row).  Collective:
+        every rank passes the same test features and receives (mean, variance) of all of them.  ZeroMean models."""
+        fs = self.cov.features(features)
+        s = fs.as_struct()
+        mean, var = np.empty(fs.n), np.empty(fs.n)
+        self.ctx._check(self.ctx._lib.agp_sharded_predict_marginal(self.ctx._h, self.ctx.kernel(self.cov), self._h, C.byref(s),
+                                                                   C.c_void_p(mean.ctypes.data), C.c_void_p(var.ctypes.data), capi.HOST),
+                        "agp_sharded_predict_marginal")
+        return mean, var
+
     def replicate(self, model):
         """All-gather the factor: every rank gets an ordinary FitModel of `model` (a GaussianProcessRegression with this
         covariance function) and predicts its own share of the test points."""

@@ -501,6 +501,14 @@ AGP_API int64_t agp_sharded_fit_failed_pivot(const agp_sharded_fit *fit);
  * problem (the factor of gp.hpp:61-69) and predicts ITS share of the test points with agp_predict_* - predictions
  * are independent per test point (gp.hpp:82-113), so sharding M needs no further exchange.  Collective. */
 AGP_API int agp_sharded_fit_replicate(agp_context *ctx, agp_sharded_fit *fit, agp_fit **out);
+/* gp_marginal_prediction (src/models/gp.hpp:87-101) straight from the SHARDED factor, without replicating it: the
+ * distributed forward substitution V = L^-1 K* by block rows (the owner of a block row solves it and broadcasts its
+ * w x M rows of V, every rank updates its own later rows; N x M doubles of broadcasts per call) and one all-reduce of
+ * the M column sums.  For factors too large to hold on every GPU; while it fits, agp_sharded_fit_replicate + the
+ * ordinary agp_predict_* on each rank's share of the test points needs no exchange at all.  Collective: every rank
+ * passes the same test points and receives all M means and variances (at `location`). */
+AGP_API int agp_sharded_predict_marginal(agp_context *ctx, const agp_kernel *k, agp_sharded_fit *fit, const agp_features *xs,
+                                         double *mean, double *variance, int location);
 /* per-stage device time of the last sharded fit on this rank, ms: 0 gram, 1 factor, 2 back substitution,
  * 3 sum of the bulk update launches, 4 their count, 5 their algorithmic flop, 6 host time spent enqueueing the
  * schedule, 7 host time until the device had drained (6 ~ 7: the host is the bottleneck) */

@@ -44,6 +44,33 @@ def test_sharded_fit_one_rank_matches_oracle(ctx, n, block, monkeypatch):
     assert np.abs(res.information - fm.get_fit().information).max() <= 1e-9 * np.abs(ofit.information).max()
 
 
+@pytest.mark.parametrize("n,block,forced", [(900, 128, False), (1700, 256, True), (2048, 512, True), (1300, 512, False)])
+def test_sharded_predict_marginal_without_replication(ctx, n, block, forced, monkeypatch):
+    """agp_sharded_predict_marginal: the distributed forward substitution on one rank - without a transport (the local
+    matrix is the whole factor) and with the multi-rank schedule forced on through an RCCL group of one (every
+    broadcast / all-reduce a real RCCL call) - against the oracle."""
+    monkeypatch.setenv("AGP_SHARD_BLOCK", str(block))
+    comm = None
+    if forced:
+        monkeypatch.setenv("AGP_SHARD_FORCE_COMM", "1")
+        comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id())
+    else:
+        monkeypatch.delenv("AGP_SHARD_FORCE_COMM", raising=False)
+    try:
+        x, y, yvar = problem(n)
+        cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
+        sharded = ShardedGaussianProcessFit(ctx, cov, comm)
+        sharded.fit(x, y, yvar)
+        xs = np.random.default_rng(3).uniform(0., 10., (70, 3))
+        mean, var = sharded.predict_marginal(xs)
+        om, ov = orc.OracleFit(cov, x, y, yvar).predict_marginal(xs)
+        assert np.abs(mean - om).max() <= 1e-8 * np.abs(om).max()
+        assert np.abs(var - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-9
+    finally:
+        if comm is not None:
+            comm.close()
+
+
 @pytest.mark.parametrize("n,block", [(700, 128), (1000, 256), (1500, 512)])
 def test_one_rank_replicate_any_block(ctx, n, block, monkeypatch):
     """agp_sharded_fit_replicate on the one-rank, no-transport path: the tile images are laid out per 128-block by the
@@ -214,6 +241,9 @@ def _worker(rank, world, port, n, block, out):
         xs = np.random.default_rng(3).uniform(0., 10., (64, 3))
         mine = slice(rank * 64 // world, (rank + 1) * 64 // world)  # this rank's share of the test points
         marg = fm.predict(xs[mine]).marginal()
+        dmean, dvar = sharded.predict_marginal(xs)  # all 64 points, from the sharded factor itself (collective)
+        assert np.abs(dmean[mine] - marg.mean).max() <= 1e-9 * np.abs(marg.mean).max()
+        assert np.abs(dvar[mine] - marg.covariance).max() <= 1e-9 * np.abs(marg.covariance).max() + 1e-10
         bad = None
         try:
             xb = np.random.default_rng(99).uniform(0., 10., (n, 3))
