@@ -600,33 +600,51 @@ def run_rank(args):
         sys.stderr.flush()
         os._exit(3)
 
-    # ---- secondary: predict points/sec at M = 4096 against one resident fit ----
+    # ---- secondary: predict points/sec at M = 4096 (per GPU) against one resident fit ----
+    # N = 1: the fit of the timed problem.  N > 1: the test points are the partitioned unit - every rank holds a resident fit
+    # (its own) and predicts its own 4096 points, no collective; `*_pts_per_sec` is the whole-job rate (N x 4096 points /
+    # max-over-ranks time).  Sharded runs add the distributed marginal prediction straight from the sharded factor.
     predict = None
-    if rank == 0 and not args.no_predict and world == 1 and not sharded:
-        m = 4096
-        xs_h, _ = make_dataset(m, 43)
-        xs_d = torch.from_numpy(xs_h).to(f"cuda:{local_rank}")
-        out_d = torch.empty(2 * m, dtype=torch.float64, device=f"cuda:{local_rank}")
-        fx = make_feats(xs_d.data_ptr(), m)
-        h = C.c_void_p()
-        st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
-        assert st == capi.AGP_OK
-        mean_p, var_p = C.c_void_p(out_d.data_ptr()), C.c_void_p(out_d.data_ptr() + 8 * m)
+    if not args.no_predict and (world > 1 or not sharded):
+        try:
+            m = 4096
+            xs_h, _ = make_dataset(m, 43 + 1000 * rank)
+            xs_d = torch.from_numpy(xs_h).to(f"cuda:{local_rank}")
+            out_d = torch.empty(2 * m, dtype=torch.float64, device=f"cuda:{local_rank}")
+            fx = make_feats(xs_d.data_ptr(), m)
+            h = C.c_void_p()
+            st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+            if st != capi.AGP_OK:
+                raise RuntimeError(f"agp_fit_create failed: {lib.agp_status_string(st).decode()}")
+            mean_p, var_p = C.c_void_p(out_d.data_ptr()), C.c_void_p(out_d.data_ptr() + 8 * m)
 
-        def timed(fn, reps):
-            fn()
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(reps):
+            def timed(fn, reps):
                 fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / reps
+                barrier()
+                t = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                barrier()
+                return max_over_ranks(time.perf_counter() - t) / reps
 
-        t_mean = timed(lambda: lib.agp_predict_mean(ctx._h, kh, h, C.byref(fx), mean_p, capi.DEVICE), 5)
-        t_marg = timed(lambda: lib.agp_predict_marginal(ctx._h, kh, h, C.byref(fx), mean_p, var_p, capi.DEVICE), 3)
-        lib.agp_fit_destroy(h)
-        predict = {"m": m, "mean_pts_per_sec": m / t_mean, "marginal_pts_per_sec": m / t_marg,
-                   "mean_ms": 1e3 * t_mean, "marginal_ms": 1e3 * t_marg}
+            t_mean = timed(lambda: lib.agp_predict_mean(ctx._h, kh, h, C.byref(fx), mean_p, capi.DEVICE), 5)
+            t_marg = timed(lambda: lib.agp_predict_marginal(ctx._h, kh, h, C.byref(fx), mean_p, var_p, capi.DEVICE), 3)
+            lib.agp_fit_destroy(h)
+            predict = {"m_per_gpu": m, "m": m * world, "mean_pts_per_sec": world * m / t_mean,
+                       "marginal_pts_per_sec": world * m / t_marg, "mean_ms": 1e3 * t_mean, "marginal_ms": 1e3 * t_marg}
+            if world > 1:
+                predict["scaling"] = "weak"
+                predict["note"] = "test points partitioned over the ranks, each against a resident fit on its GPU; no collective"
+            if world > 1 and sharded:
+                xq, _ = make_dataset(m, 43)  # collective call: the same test points on every rank
+                t_sh = timed(lambda: sfit.predict_marginal(xq), 2)
+                predict["sharded_factor"] = {"m": m, "marginal_pts_per_sec": m / t_sh, "marginal_ms": 1e3 * t_sh,
+                                             "note": "agp_sharded_predict_marginal: the distributed forward substitution "
+                                                     "against the sharded factor (not replicated), host features in and out"}
+        except Exception as exc:  # noqa: BLE001 - see above: peers may be inside a collective
+            sys.stderr.write(f"bench.py rank {rank}: {type(exc).__name__}: {exc}\n")
+            sys.stderr.flush()
+            os._exit(3)
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the per-launch figure
     # comes from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read

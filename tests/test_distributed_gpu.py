@@ -467,6 +467,10 @@ def test_bench_starts_its_own_ranks():
     assert "callbacks" in line["config"]["transport"] and "not RCCL" in line["config"]["transport"]
     assert line["self_check"]["ok"] and line["self_check"]["max_rel_residual"] < 1e-8
     assert "sharded_fallback" not in line
+    # predict pts/sec of the N-GPU job: test points partitioned over the ranks + the distributed marginal prediction
+    pr = line["predict"]
+    assert pr["m"] == 2 * pr["m_per_gpu"] and pr["scaling"] == "weak" and pr["marginal_pts_per_sec"] > 0
+    assert pr["sharded_factor"]["marginal_pts_per_sec"] > 0
 
 
 def test_bench_falls_back_to_replicas_when_the_sharded_fit_fails_its_check():
@@ -476,5 +480,6 @@ def test_bench_falls_back_to_replicas_when_the_sharded_fit_fails_its_check():
     assert rc == 0 and line is not None, err[-2000:]
     assert line["scaling"] == "weak" and line["config"]["parallelism"].startswith("FALLBACK")
     assert "failed" in line["sharded_fallback"] and line["self_check"]["ok"]
+    assert line["predict"]["m"] == 2 * line["predict"]["m_per_gpu"] and "sharded_factor" not in line["predict"]
     rc, line, err = _run_bench({"BENCH_TEST_SHARDED_FAILURE": "1"}, "--no-fallback")
     assert rc != 0 and line is None
