@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "mfma_f64.h"
+#include "gemm_tiles.h"
 
 namespace agp {
 void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);  // reduce.hip
@@ -65,6 +66,11 @@ struct PotrfArgs {
   // wait_value of them and then reads the block with device-scope loads.  nullptr: off.
   const unsigned long long *wait_counter = nullptr;
   unsigned long long wait_value = 0;
+  // panel STEP kernel (panel_fused_kernel<true> in the chain-bound tail, see panel_phase): workgroups trail_first ..
+  // apply the previous panel's rank-128 update to everything RIGHT of this panel (the `below` x `below` lower triangle,
+  // 64 x 64 tiles) while this panel is factored - one launch per panel, no update launch, no second stream.
+  unsigned trail_first = 0xffffffffu;
+  int trail_big = 0;  // 1: 128 x 128 tiles (many rows left: the trailing update is what the launch takes), 0: 64 x 64
 };
 
 constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
@@ -874,13 +880,137 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
 
 constexpr int UPD_BLOCKS = NTILE / 4;  // 9 workgroups x 4 waves = the 36 micro tiles of the diagonal block
 
-// UPD: the launch also applies the previous panel's update to this panel's columns (no separate update launch, no
-// kernel boundary between "rows updated" and "next diagonal block factored"): workgroups 1 .. 9 update the diagonal
-// block and hand it to workgroup 0 through p.dpub, the workgroups of the rows below update their own rows first.
+// One 64 x 64 tile (lower triangle, column-major tile order) of  C[k0 + NB .., k0 + NB ..] -= X X^T,  X = rows k0 + NB ..
+// of the PREVIOUS panel (columns k0 - NB .. k0 - 1, final since the previous launch).  Nothing in this launch reads or
+// writes those tiles, so these workgroups never wait: they fill the chip behind the ~35 us of the panel's POTRF.
+// 64 x 64 tile, depth exactly NB = 128, in TWO passes of 64: each pass brings both operand blocks (64 rows x 64 deep)
+// into LDS with one round of loads per thread - the second pass's loads are in flight while the first one multiplies -
+// instead of the generic body's eight 16-deep chunks (eight load / barrier round trips, which is what a workgroup
+// with only two resident workgroups per CU waits for).  lds: 2 * 64 * TRP doubles.
+constexpr int TRP = ST + 8;  // pitch of one k row (the 16 lanes of a fragment read are consecutive: any pitch is conflict-free)
+
+__device__ __forceinline__ void trail_load_pass(const double *__restrict__ P, long long ld, long long row0, long long nrows,
+                                                int k0, bool vec_ok, double (&r)[16]) {
+  const int t = threadIdx.x, kk = t >> 4, seg = (t & 15) * 4;
+  const long long row = row0 + seg;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double *q = P + row + (long long)(k0 + 16 * c + kk) * ld;
+    if (vec_ok && row0 + ST <= nrows) {
+      const double2 a = *reinterpret_cast<const double2 *>(q);
+      const double2 b = *reinterpret_cast<const double2 *>(q + 2);
+      r[4 * c] = a.x; r[4 * c + 1] = a.y; r[4 * c + 2] = b.x; r[4 * c + 3] = b.y;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[4 * c + e] = (row + e < nrows) ? q[e] : 0.;
+    }
+  }
+}
+
+template <bool NEGATE>
+__device__ __forceinline__ void trail_store_pass(double *__restrict__ Ls, const double (&r)[16]) {
+  const int t = threadIdx.x, kk = t >> 4, seg = (t & 15) * 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double2 *dst = reinterpret_cast<double2 *>(Ls + (16 * c + kk) * TRP + seg);
+    dst[0] = NEGATE ? make_double2(-r[4 * c], -r[4 * c + 1]) : make_double2(r[4 * c], r[4 * c + 1]);
+    dst[1] = NEGATE ? make_double2(-r[4 * c + 2], -r[4 * c + 3]) : make_double2(r[4 * c + 2], r[4 * c + 3]);
+  }
+}
+
+__device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const double *__restrict__ P, long long ld, long long M,
+                                             long long i0, long long j0, double *lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1, ln = lane & 15, lg = lane >> 4;
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(P) & 15) == 0) && ((ld & 1) == 0);
+  double *As = lds, *Bs = lds + 64 * TRP;
+  double ra[16], rb[16];
+  trail_load_pass(P, ld, i0, M, 0, vec_ok, ra);
+  trail_load_pass(P, ld, j0, M, 0, vec_ok, rb);
+  v4d acc[2][2];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const long long row = i0 + 32 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
+        acc[tj][ti][r] = (row < M && col < M) ? Cc[row + col * ld] : 0.;
+      }
+    }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();  // the first pass's readers are done with the buffers
+    trail_store_pass<false>(As, ra);
+    trail_store_pass<true>(Bs, rb);
+    __syncthreads();
+    if (pass == 0) {
+      trail_load_pass(P, ld, i0, M, 64, vec_ok, ra);
+      trail_load_pass(P, ld, j0, M, 64, vec_ok, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int krow = (4 * s + lg) * TRP;
+      double fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = Bs[krow + 32 * wc + 16 * t + ln];
+        fb[t] = As[krow + 32 * wr + 16 * t + ln];
+      }
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
+    }
+  }
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const long long row = i0 + 32 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
+        if (row < M && col < M) Cc[row + col * ld] = acc[tj][ti][r];
+      }
+    }
+}
+
+__device__ __forceinline__ void trail_update_body(const PotrfArgs &p, long long id, double *lds) {
+  const long long t0 = p.k0 + NB;
+  double *Cc = p.A + t0 * p.lda + t0;
+  const double *P = p.A + (p.k0 - NB) * p.lda + t0;
+  const int edge = p.trail_big ? GT : ST;
+  const int ntr = (int)((p.below + edge - 1) / edge);
+  int bj = 0;
+  while (id >= ntr - bj) {
+    id -= ntr - bj;
+    ++bj;
+  }
+  if (p.trail_big) {
+    GemmArgs g;
+    g.C = Cc; g.ldc = p.lda;
+    g.A = g.B = P; g.lda = g.ldb = p.lda;
+    g.M = g.N = p.below; g.K = NB; g.tri = 1;
+    g.remap = 0; g.nsuper = 0; g.nb8 = 0;
+    g.ntr = g.ntc = ntr;
+    gemm_nt_sub_tile<false, false>(g, bj + (int)id, bj, lds);
+  } else {
+    trail_tile64(Cc, P, p.lda, p.below, (long long)(bj + (int)id) * ST, (long long)bj * ST, lds);
+  }
+}
+
 template <bool UPD>
 __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
-  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);
   __shared__ double T[POTRF_LDS_DOUBLES];
+  static_assert(POTRF_LDS_DOUBLES >= 2 * 2 * GK * GLD && POTRF_LDS_DOUBLES >= 2 * 64 * TRP,
+                "the trailing-update workgroups stage their operands in T");
+  if (UPD && blockIdx.x >= p.trail_first) {
+    trail_update_body(p, (long long)(blockIdx.x - p.trail_first), T);
+    return;
+  }
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);
   if (blockIdx.x == 0) {
     potrf_diag_body<true, UPD>(p, T);
   } else if (UPD && blockIdx.x <= UPD_BLOCKS) {
@@ -952,6 +1082,29 @@ static long long upd_below() {
   return e ? atoll(e) : 0;
 }
 
+// Remaining rows at or below which the factorisation runs ONE launch per panel on one stream (panel_phase step_mode);
+// AGP_STEP_BELOW, 0 = off, default 4608 (scripts/sweep_step.sh, profiles/r03/sweep_step.txt: N = 16384 33.3 -> 32.9 ms,
+// N = 8192 6.8 -> 6.5 ms, N = 4096 2.6 -> 2.1 ms, N = 2048 1.04 -> 0.86 ms; 3072 ... 5120 within noise of each other at
+// N = 16384, 5632 and above lose: there the trailing update of one panel takes longer than the two-stream schedule's
+// share of it).  Read per call (tests switch it in one process).
+static long long step_below() {
+  const char *e = getenv("AGP_STEP_BELOW");
+  return e ? atoll(e) : 4608;
+}
+
+// Rows below the panel above which the trailing-update workgroups of a step launch take 128 x 128 tiles instead of
+// 64 x 64 (AGP_STEP_TILE128_ABOVE; default: never).  Measured: with 128 x 128 tiles the launch takes 100-130 us at 4000-4600
+// remaining rows and 60-65 us at 2048-3400, against 57-84 and 45-57 us with 64 x 64 tiles (a 128 x 128 x 128 product is
+// eight load / barrier round trips by two workgroups per CU - latency-bound - and two rounds of them).
+static long long step_tile128_above() {
+  static long long v = -1;
+  if (v < 0) {
+    const char *e = getenv("AGP_STEP_TILE128_ABOVE");
+    v = e ? atoll(e) : (1LL << 60);
+  }
+  return v;
+}
+
 static long long fused_below() {
   static long long v = -1;
   if (v < 0) {
@@ -979,7 +1132,7 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
     ctx->zpub_cap = cap;
   }
   const long long b0 = k_begin / NB, b1 = (k_end + NB - 1) / NB;
-  if (upd_below() > 0 && ctx->dpub_cap < b1) {
+  if ((upd_below() > 0 || step_below() > 0) && ctx->dpub_cap < b1) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
     ctx->d_dpub = nullptr;
@@ -1004,7 +1157,11 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
 static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *invd,
                         double *y, long long K0, long long kend, FactorTimers *timers, hipEvent_t after_first = nullptr,
                         bool upd_prev = false, const unsigned long long *wait_counter = nullptr,
-                        unsigned long long wait_value = 0) {
+                        unsigned long long wait_value = 0, bool step_mode = false) {
+  // step_mode (the chain-bound tail, factor_lower): ONE launch per panel.  The first panel is a plain fused launch;
+  // every later one is the update-ahead kernel - the previous panel's update of this panel's 128 columns on the
+  // critical workgroups - plus trailing workgroups that apply the previous panel to everything further right while
+  // this panel's POTRF runs.  No update launches, nothing leaves stream s.
   // AGP_INNER_LEFT=1: left-looking inside the outer block - panel k is brought up to date with the panels
   // [K0, k) of this outer block in ONE product of depth k - K0 just before it is factored, instead of every
   // panel updating all later columns of the outer block with depth 128 (same flop, a third of the C traffic,
@@ -1017,12 +1174,12 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
     left_above = e ? atoll(e) : 6144;
     if (left_above == 0) left_above = 1LL << 60;  // 0: never
   }
-  const bool inner_left = (n - K0) > left_above;
+  const bool inner_left = !step_mode && (n - K0) > left_above;
   // The consumers of the fused kernel hold their slots for the whole POTRF (~30 us): while the bulk update fills the
   // chip that costs it more than the saved launch (measured: 43.3 -> 41.8 TFLOP/s), so the fused kernel takes over
   // where the panel chain is the critical path (AGP_FUSED_BELOW remaining rows)
   const bool fused = panel_fused_enabled() && ctx->d_zpub && ctx->zpub_ready_n >= kend && ctx->img_ready == invd &&
-                     ((n - K0) <= fused_below() || upd_prev) &&  // (factor_lower asks for upd_prev only when all of this holds)
+                     ((n - K0) <= fused_below() || upd_prev || step_mode) &&  // (factor_lower asks for upd_prev / step_mode only when all of this holds)
                      !wait_counter;                             // (merged updates: the bulk-bound phase, two launches)
   for (long long k = K0; k < kend; k += NB) {
     const int nbk = (int)((n - k < NB) ? n - k : NB);
@@ -1039,10 +1196,17 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
       pa.flags = ctx->d_flags; pa.scalars = ctx->d_scalars;
       pa.zpub = y ? ctx->d_zpub + k : nullptr;
       pa.below = below > 0 ? below : 0;
-      if (upd_prev && k == K0) {
-        // the panel before this one (columns K0 - 128 .. K0 - 1) has not been applied to these columns yet
+      if ((upd_prev && k == K0) || (step_mode && k > K0)) {
+        // the panel before this one (columns k - 128 .. k - 1) has not been applied to these columns yet
         pa.dpub = ctx->d_dpub + (k / NB) * (long long)IMG_DOUBLES;
-        hipLaunchKernelGGL(panel_fused_kernel<true>, dim3((unsigned)(1 + UPD_BLOCKS + (pa.below + 63) / 64)), dim3(256), 0, s, pa);
+        unsigned grid = (unsigned)(1 + UPD_BLOCKS + (pa.below + 63) / 64);
+        if (step_mode && pa.below > 0) {  // ... nor to anything right of them
+          pa.trail_big = pa.below > step_tile128_above() ? 1 : 0;
+          const long long edge = pa.trail_big ? 128 : 64, nt = (pa.below + edge - 1) / edge;
+          pa.trail_first = grid;
+          grid += (unsigned)(nt * (nt + 1) / 2);
+        }
+        hipLaunchKernelGGL(panel_fused_kernel<true>, dim3(grid), dim3(256), 0, s, pa);
       } else {
         hipLaunchKernelGGL(panel_fused_kernel<false>, dim3((unsigned)(1 + (pa.below + 63) / 64)), dim3(256), 0, s, pa);
       }
@@ -1067,7 +1231,7 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
     // outer block may touch them before that has finished
     if (after_first && k == K0) (void)hipStreamWaitEvent(s, after_first, 0);
     const long long width = kend - (k + nbk);
-    if (width > 0 && !inner_left) {
+    if (width > 0 && !inner_left && !(step_mode && fused)) {
       const double *P = A + k * lda + (k + nbk);
       timed_gemm(s, timers, A + (k + nbk) * lda + (k + nbk), lda, P, P, below, width, nbk, false);
     }
@@ -1226,6 +1390,13 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   long long kend = K0 + pick_nbo(n, nbo_fixed);
   if (kend > n) kend = n;
   panel_fused_prepare(ctx, sa, invd, 0, n);
+  // the chain-bound tail as one launch per panel on this stream (panel_phase step_mode) once `remaining` rows are left
+  auto step_ok = [&](long long remaining) {
+    return nbo_fixed == 0 && remaining <= step_below() && panel_fused_enabled() && ctx->d_dpub && ctx->dpub_cap * NB >= n &&
+           ctx->d_zpub && ctx->img_ready == invd && ctx->zpub_ready_n >= n;
+  };
+  const bool step_all = step_ok(n);  // small matrix: every panel
+  if (step_all) kend = n;
   long long step_index = 0;
   if (merge_above() > 0 && n > merge_above()) {
     if (!ctx->d_merge_cnt && hipMalloc(&ctx->d_merge_cnt, sizeof(unsigned long long) * MERGE_SLOTS) != hipSuccess) {
@@ -1235,7 +1406,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     // (the bulk stream's first launch waits for an event recorded on this stream after this memset)
     if (ctx->d_merge_cnt) (void)hipMemsetAsync(ctx->d_merge_cnt, 0, sizeof(unsigned long long) * MERGE_SLOTS, sa);
   }
-  panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers);
+  panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers, nullptr, false, nullptr, 0, step_all);
   while (kend < n) {
     long long next_end = kend + pick_nbo(n - kend, nbo_fixed);
     if (next_end > n) next_end = n;
@@ -1249,8 +1420,9 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     // updated" and "diagonal block factored"; U2 (depth 128) covers everything right of the next panel.
     const bool upd = nbo_fixed == 0 && K == NB && (n - kend) <= upd_below() && panel_fused_enabled() && ctx->d_dpub &&
                      ctx->d_zpub && ctx->img_ready == invd && ctx->zpub_ready_n >= n;
+    const bool step = !upd && step_ok(n - kend);
     if (upd) next_end = (kend + NB < n) ? kend + NB : n;
-    else if (nbo_fixed == 0 && n - kend <= single_below()) next_end = n;
+    else if (step || (nbo_fixed == 0 && n - kend <= single_below())) next_end = n;
     if (ctx->bs_W && ctx->bs_done == 0 && next_end == n && ctx->ev_inv && ctx->stream2) {
       // Last step: everything left of kend is final and the second stream has nothing more to do - it inverts the wide
       // diagonal blocks the backward substitution of the fit will need (all but the last ones), off the chain.
@@ -1310,6 +1482,9 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
       // mixed precision: U1 on the fp32 MFMA path like the bulk update (products of fp32-rounded panels, fp64
       // subtraction) while the block column is tall enough for 128 x 128 tiles to fill the chip
       launch_update_f32(sa, A + kend * lda + kend, lda, P, P, lda, n - kend, next_end - kend, K);
+    } else if (step && n - kend > 1536) {
+      // hand-over to the step tail: the whole trailing matrix, on the chain stream, alone on the chip - the bulk kernel
+      timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, n - kend, K, true, variant);
     } else {
       timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
     }
@@ -1327,7 +1502,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     if (sb != sb_prev && have_u2) (void)hipStreamWaitEvent(sb, ctx->ev_b, 0);  // U2(j - 1) ran on the other bulk stream
     sb_prev = sb;
     const bool throttle = next_end < n && (n - kend) <= throttle_below();
-    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd, mcnt, mwait);
+    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd, mcnt, mwait, step);
     if (next_end < n) {
       if (throttle) {
         while (hipEventQuery(ctx->ev_a) == hipErrorNotReady) {}
@@ -1351,7 +1526,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     } else {
       have_u2 = false;
     }
-    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd, mcnt, mwait);
+    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd, mcnt, mwait, step);
     K0 = kend;
     kend = next_end;
   }

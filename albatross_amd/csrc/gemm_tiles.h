@@ -1,0 +1,386 @@
+// The tile bodies of the update kernels, C -= A B^T on the fp64 MFMA (128 x 128 and 64 x 64 tiles per workgroup), and
+// their argument block: shared by gemm.hip (the update launches) and chol.hip (the trailing-update workgroups of the
+// panel step kernel).
+#pragma once
+#include "common.h"
+#include "mfma_f64.h"
+
+namespace agp {
+
+constexpr int GT = 128;        // C tile edge
+constexpr int GK = 16;         // K chunk
+constexpr int GLD = GT + 16;   // LDS row pitch in doubles
+constexpr int GEMM_THREADS = 256;
+
+struct GemmArgs {
+  double *C;
+  long long ldc;
+  const double *A;  // operand indexed by C row i
+  long long lda;
+  const double *B;  // operand indexed by C col j
+  long long ldb;
+  long long M, N, K;
+  int tri;  // skip tiles strictly above the diagonal of C
+  int ntr, ntc;
+  // XCD-aware order (bulk update only): workgroups b, b+8, b+16, ... share an
+  // XCD (round-robin dispatch); the 64 that run there together are dealt one
+  // 8 x 8 super-tile of C, so they share 8 row strips and 8 column strips of
+  // the panel in that XCD's L2.  nsuper = number of lower super-tiles.
+  int remap, nsuper, nb8;
+  // batched launches (blockIdx.y = batch entry): element offsets per entry; 0 = not batched
+  long long batch_C = 0, batch_A = 0, batch_B = 0;
+  long long tile_first = 0;  // first tile (in column-major tile order) of this launch: split bulk updates
+  // "staircase" launches of the row-block-sharded fit (shard.h): C = the stacked local row blocks of one rank, the row
+  // tile bi belongs to local block st_lb0 + bi / st_tpb = global block gi (snake deal over st_world ranks) and owns the
+  // tile columns up to its own diagonal tile: bj <= gi * st_tpb - st_c0t + bi % st_tpb.  stair == 0: off.
+  int stair = 0, st_world = 1, st_rank = 0, st_tpb = 4;
+  long long st_lb0 = 0, st_c0t = 0;
+  // merged trailing update (chol.hip: factor_lower): the tiles of the first done_cols tile columns - the NEXT block
+  // column, which the panel chain waits for - are written with device-scope stores and counted in *done when complete,
+  // so that the next panel's POTRF (another launch, another stream) can start on them while this launch is still busy
+  // with everything further right.  done == nullptr: off.
+  unsigned long long *done = nullptr;
+  int done_cols = 0;
+};
+
+#ifndef AGP_GEMM_4X4
+#define AGP_GEMM_4X4 0  // 1: 128 x 128 kernels on v_mfma_f64_4x4x4 with DPP-rotated fragments (same speed)
+#endif
+
+// Load this thread's 8 doubles of a 128 x 16 operand chunk.
+//   !KMAJOR: element (row, k) at P[row + k * ld]   (panel stored like the matrix)
+//    KMAJOR: element (row, k) at P[k + row * ld]   (transposed access)
+template <bool KMAJOR>
+__device__ __forceinline__ void load_chunk(const double *__restrict__ P, long long ld, long long row0,
+                                           long long nrows, long long k0, long long K, bool vec_ok,
+                                           double (&r)[8]) {
+  const int t = threadIdx.x;
+  // wave-uniform: interior tile and full chunk -> unguarded 16-B loads
+  const bool fast = vec_ok && (row0 + GT <= nrows) && (k0 + GK <= K);
+  if (!KMAJOR) {
+    const int kk = t >> 4, seg = (t & 15) * 8;
+    const long long row = row0 + seg, k = k0 + kk;
+    const double *p = P + row + k * ld;
+    if (fast) {
+      const double2 a = *reinterpret_cast<const double2 *>(p);
+      const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+      const double2 c = *reinterpret_cast<const double2 *>(p + 4);
+      const double2 d = *reinterpret_cast<const double2 *>(p + 6);
+      r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+      r[4] = c.x; r[5] = c.y; r[6] = d.x; r[7] = d.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r[q] = (k < K && row + q < nrows) ? p[q] : 0.;
+    }
+  } else {
+    const int j = t >> 1, kh = (t & 1) * 8;
+    const long long row = row0 + j, k = k0 + kh;
+    const double *p = P + k + row * ld;
+    if (fast) {
+      const double2 a = *reinterpret_cast<const double2 *>(p);
+      const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+      const double2 c = *reinterpret_cast<const double2 *>(p + 4);
+      const double2 d = *reinterpret_cast<const double2 *>(p + 6);
+      r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+      r[4] = c.x; r[5] = c.y; r[6] = d.x; r[7] = d.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r[q] = (row < nrows && k + q < K) ? p[q] : 0.;
+    }
+  }
+}
+
+template <bool KMAJOR, bool NEGATE>
+__device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const double (&r)[8]) {
+  const int t = threadIdx.x;
+  if (!KMAJOR) {
+    const int kk = t >> 4, seg = (t & 15) * 8;
+    double2 *dst = reinterpret_cast<double2 *>(Ls + kk * GLD + seg);
+    if (NEGATE) {
+      dst[0] = make_double2(-r[0], -r[1]);
+      dst[1] = make_double2(-r[2], -r[3]);
+      dst[2] = make_double2(-r[4], -r[5]);
+      dst[3] = make_double2(-r[6], -r[7]);
+    } else {
+      dst[0] = make_double2(r[0], r[1]);
+      dst[1] = make_double2(r[2], r[3]);
+      dst[2] = make_double2(r[4], r[5]);
+      dst[3] = make_double2(r[6], r[7]);
+    }
+  } else {
+    const int j = t >> 1, kh = (t & 1) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Ls[(kh + q) * GLD + j] = NEGATE ? -r[q] : r[q];
+  }
+}
+
+// One 128 x 128 tile (bi, bj) of C by one workgroup of 256 threads; lds: 2 * 2 * GK * GLD doubles.
+template <bool A_KMAJOR, bool B_KMAJOR>
+__device__ __forceinline__ void gemm_nt_sub_tile(const GemmArgs &g, const int bi, const int bj, double *lds) {
+  const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+  const bool counted = g.done != nullptr && bj < g.done_cols;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ln = lane & 15, lg = lane >> 4;
+
+  const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
+
+  v4d acc[4][4];  // [tj][ti]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = v4zero();
+
+  double ra[8], rb[8];
+  const long long nk = (g.K + GK - 1) / GK;
+  load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
+  load_chunk<B_KMAJOR>(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb);
+  store_chunk<A_KMAJOR, false>(lds, ra);
+  store_chunk<B_KMAJOR, true>(lds + GK * GLD, rb);
+  __syncthreads();
+
+  for (long long kc = 0; kc < nk; ++kc) {
+    const int cur = (int)(kc & 1);
+    const double *As = lds + cur * (2 * GK * GLD);
+    const double *Bs = As + GK * GLD;
+    const bool more = kc + 1 < nk;
+    if (more) {
+      load_chunk<A_KMAJOR>(g.A, g.lda, i0, g.M, (kc + 1) * GK, g.K, a_vec, ra);
+      load_chunk<B_KMAJOR>(g.B, g.ldb, j0, g.N, (kc + 1) * GK, g.K, b_vec, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < GK / 4; ++s) {
+      double fa[4], fb[4];
+      const int krow = (4 * s + lg) * GLD;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = Bs[krow + 64 * wc + 16 * t + ln];  // MFMA A operand: C-column panel (negated)
+        fb[t] = As[krow + 64 * wr + 16 * t + ln];  // MFMA B operand: C-row panel
+      }
+#if AGP_GEMM_4X4
+      // four 4x4x4 products per 16 x 16 tile: block b pairs column group (b + ra) with row group (b + rb),
+      // (ra, rb) = (0,0), (1,0), (0,2), (1,2): all 16 group pairs; the rotated fragments come from DPP
+      double fa1[4], fb2[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa1[t] = rotate_groups<1>(fa[t]);
+        fb2[t] = rotate_groups<2>(fb[t]);
+      }
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          acc[tj][ti][0] = mfma4(fa[tj], fb[ti], acc[tj][ti][0]);
+          acc[tj][ti][1] = mfma4(fa1[tj], fb[ti], acc[tj][ti][1]);
+          acc[tj][ti][2] = mfma4(fa[tj], fb2[ti], acc[tj][ti][2]);
+          acc[tj][ti][3] = mfma4(fa1[tj], fb2[ti], acc[tj][ti][3]);
+        }
+#else
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
+#endif
+    }
+    if (more) {
+      double *An = lds + (cur ^ 1) * (2 * GK * GLD);
+      store_chunk<A_KMAJOR, false>(An, ra);
+      store_chunk<B_KMAJOR, true>(An + GK * GLD, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C += acc (acc already holds -A B^T) ----
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+#if !AGP_GEMM_4X4
+      const long long row = i0 + 64 * wr + 16 * ti + ln;
+#endif
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#if AGP_GEMM_4X4
+        // accumulator r = (ra, rb) = (r & 1, r & 2): lane (ln = 4 lq + lr, lg) holds
+        // C[row 4 ((lq + rb) & 3) + lr][col 4 ((lq + ra) & 3) + lg] of the 16 x 16 tile
+        const int lq = ln >> 2, lr = ln & 3;
+        const long long row = i0 + 64 * wr + 16 * ti + 4 * ((lq + (r & 2)) & 3) + lr;
+        const long long col = j0 + 64 * wc + 16 * tj + 4 * ((lq + (r & 1)) & 3) + lg;
+#else
+        const long long col = j0 + 64 * wc + 16 * tj + lg + 4 * r;
+#endif
+        if (row < g.M && col < g.N) {
+          double *c = g.C + row + col * g.ldc;
+          const double v = *c + acc[tj][ti][r];
+          if (counted) __hip_atomic_store(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the XCD-private L2
+          else *c = v;
+        }
+      }
+    }
+  if (counted) {
+    // every store of this tile acknowledged, then one count: a reader that sees the full count reads final values
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(g.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 64 x 64-tile variant for launches too small to fill the chip with 128 x 128
+// tiles (the next-panel and inner updates of the serial panel chain): four
+// times as many, four times shorter workgroups, 3-4 of them per CU.
+// Panel-major operands only.
+// ---------------------------------------------------------------------------
+constexpr int ST = 64;         // small tile edge
+constexpr int SLD = ST + 16;   // LDS pitch (pitch mod 32 == 16: conflict-free fragment reads)
+
+__device__ __forceinline__ void load_chunk64(const double *__restrict__ P, long long ld, long long row0,
+                                             long long nrows, long long k0, long long K, bool vec_ok,
+                                             double (&r)[4]) {
+  const int t = threadIdx.x;
+  const int kk = t >> 4, seg = (t & 15) * 4;
+  const long long row = row0 + seg, k = k0 + kk;
+  const double *p = P + row + k * ld;
+  const bool fast = vec_ok && (row0 + ST <= nrows) && (k0 + GK <= K);
+  if (fast) {
+    const double2 a = *reinterpret_cast<const double2 *>(p);
+    const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+    r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (k < K && row + q < nrows) ? p[q] : 0.;
+  }
+}
+
+template <bool NEGATE>
+__device__ __forceinline__ void store_chunk64(double *__restrict__ Ls, const double (&r)[4]) {
+  const int t = threadIdx.x;
+  const int kk = t >> 4, seg = (t & 15) * 4;
+  double2 *dst = reinterpret_cast<double2 *>(Ls + kk * SLD + seg);
+  dst[0] = NEGATE ? make_double2(-r[0], -r[1]) : make_double2(r[0], r[1]);
+  dst[1] = NEGATE ? make_double2(-r[2], -r[3]) : make_double2(r[2], r[3]);
+}
+
+// transposed operand storage (element (row, k) at P[k + row * ld]): thread t holds 4 consecutive k of row t >> 2
+__device__ __forceinline__ void load_chunk64_kmajor(const double *__restrict__ P, long long ld, long long row0,
+                                                    long long nrows, long long k0, long long K, bool vec_ok,
+                                                    double (&r)[4]) {
+  const int t = threadIdx.x;
+  const int j = t >> 2, kq = (t & 3) * 4;
+  const long long row = row0 + j, k = k0 + kq;
+  const double *p = P + k + row * ld;
+  if (vec_ok && row < nrows && k + 4 <= K) {
+    const double2 a = *reinterpret_cast<const double2 *>(p);
+    const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+    r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (row < nrows && k + q < K) ? p[q] : 0.;
+  }
+}
+
+template <bool NEGATE>
+__device__ __forceinline__ void store_chunk64_kmajor(double *__restrict__ Ls, const double (&r)[4]) {
+  const int t = threadIdx.x;
+  const int j = t >> 2, kq = (t & 3) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) Ls[(kq + q) * SLD + j] = NEGATE ? -r[q] : r[q];
+}
+
+template <bool B_KMAJOR = false, bool A_KMAJOR = false>
+__device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i0, const long long j0, double *lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ln = lane & 15, lg = lane >> 4;
+  const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
+
+  // These launches sit on the serial panel chain and are latency-bound (a 64 x 64 x K tile is a
+  // few microseconds of MFMA work behind K / 16 global-load round trips), so the operand stream
+  // runs TWO chunks ahead of the MFMAs (two register stages + the two LDS buffers) and the
+  // accumulators start from C, loaded while the first chunks are in flight: no read-modify-write
+  // at the end.
+  double ra[2][4], rb[2][4];
+  const long long nk = (g.K + GK - 1) / GK;
+  if (A_KMAJOR) load_chunk64_kmajor(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra[0]);
+  else load_chunk64(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra[0]);
+  if (B_KMAJOR) load_chunk64_kmajor(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb[0]);
+  else load_chunk64(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb[0]);
+  if (nk > 1) {
+    if (A_KMAJOR) load_chunk64_kmajor(g.A, g.lda, i0, g.M, GK, g.K, a_vec, ra[1]);
+    else load_chunk64(g.A, g.lda, i0, g.M, GK, g.K, a_vec, ra[1]);
+    if (B_KMAJOR) load_chunk64_kmajor(g.B, g.ldb, j0, g.N, GK, g.K, b_vec, rb[1]);
+    else load_chunk64(g.B, g.ldb, j0, g.N, GK, g.K, b_vec, rb[1]);
+  }
+  v4d acc[2][2];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const long long row = i0 + 32 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
+        acc[tj][ti][r] = (row < g.M && col < g.N) ? g.C[row + col * g.ldc] : 0.;
+      }
+    }
+  if (A_KMAJOR) store_chunk64_kmajor<false>(lds, ra[0]);
+  else store_chunk64<false>(lds, ra[0]);
+  if (B_KMAJOR) store_chunk64_kmajor<true>(lds + GK * SLD, rb[0]);
+  else store_chunk64<true>(lds + GK * SLD, rb[0]);
+  __syncthreads();
+  for (long long kc = 0; kc < nk; kc += 2) {
+    // two chunks per trip so that the register stages are compile-time indices
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const long long k = kc + half;
+      if (k >= nk) break;
+      const double *As = lds + half * (2 * GK * SLD);
+      const double *Bs = As + GK * SLD;
+      if (k + 2 < nk) {  // stage `half` was stored to LDS one trip ago: refill it with chunk k + 2
+        if (A_KMAJOR) load_chunk64_kmajor(g.A, g.lda, i0, g.M, (k + 2) * GK, g.K, a_vec, ra[half]);
+        else load_chunk64(g.A, g.lda, i0, g.M, (k + 2) * GK, g.K, a_vec, ra[half]);
+        if (B_KMAJOR) load_chunk64_kmajor(g.B, g.ldb, j0, g.N, (k + 2) * GK, g.K, b_vec, rb[half]);
+        else load_chunk64(g.B, g.ldb, j0, g.N, (k + 2) * GK, g.K, b_vec, rb[half]);
+      }
+#pragma unroll
+      for (int s = 0; s < GK / 4; ++s) {
+        const int krow = (4 * s + lg) * SLD;
+        double fa[2], fb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[t] = Bs[krow + 32 * wc + 16 * t + ln];
+          fb[t] = As[krow + 32 * wr + 16 * t + ln];
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
+      }
+      if (k + 1 < nk) {  // chunk k + 1 (register stage half ^ 1, loaded a trip ago) -> the other LDS buffer
+        double *An = lds + (half ^ 1) * (2 * GK * SLD);
+        if (A_KMAJOR) store_chunk64_kmajor<false>(An, ra[half ^ 1]);
+        else store_chunk64<false>(An, ra[half ^ 1]);
+        if (B_KMAJOR) store_chunk64_kmajor<true>(An + GK * SLD, rb[half ^ 1]);
+        else store_chunk64<true>(An + GK * SLD, rb[half ^ 1]);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const long long row = i0 + 32 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
+        if (row < g.M && col < g.N) g.C[row + col * g.ldc] = acc[tj][ti][r];
+      }
+    }
+}
+
+
+}  // namespace agp

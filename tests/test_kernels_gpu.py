@@ -163,6 +163,32 @@ def test_update_ahead_panel_kernel(ctx, dbg, n, monkeypatch):
     assert abs(out["0"][2] - out["8192"][2]) <= 1e-10 * abs(out["0"][2])
 
 
+@pytest.mark.parametrize("n", [129, 700, 1500, 2304, 3400])
+def test_panel_step_kernel(ctx, dbg, n, monkeypatch):
+    """AGP_STEP_BELOW: the chain-bound tail as ONE launch per panel (chol.hip: panel_phase step_mode - the update-ahead panel
+    kernel plus trailing-update workgroups in the same launch) against the two-launch tail and numpy; sizes with a partial
+    last panel, a partial last 64-row tile, and a tail that starts in the middle of the matrix."""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n))
+    A = np.asfortranarray(B @ B.T + n * np.eye(n))
+    y = rng.standard_normal(n)
+    out = {}
+    monkeypatch.setenv("AGP_STEP_TILE128_ABOVE", "2048")  # (read once per process: the 128 x 128 trailing tiles get covered too)
+    for mode in ("0", "2048", "8192"):  # 8192: every panel a step launch, 128 x 128 trailing tiles while > 2048 rows remain
+        monkeypatch.setenv("AGP_STEP_BELOW", mode)
+        Ad, yd = A.copy(order="F"), y.copy()
+        logdet, bad = C.c_double(), C.c_int64()
+        assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
+        assert bad.value == -1
+        out[mode] = (np.tril(Ad), yd, logdet.value)
+    L = np.linalg.cholesky(A)
+    for mode in out:
+        assert np.abs(out[mode][0] - L).max() <= 1e-11 * np.abs(L).max()
+        assert np.abs(out[mode][1] - np.linalg.solve(L, y)).max() <= 1e-10
+    for mode in ("2048", "8192"):
+        assert abs(out["0"][2] - out[mode][2]) <= 1e-10 * abs(out["0"][2])
+
+
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 500, 4096, 4097, 9000])
 def test_symv_lower(ctx, dbg, n):
     """launch_symv_lower (the K p of the mixed-precision fit's conjugate gradients): only the lower triangle is read
