@@ -304,8 +304,15 @@ __device__ __forceinline__ void micro_syrk_tile(double *T, int ib, int kb, int j
 #ifdef AGP_POTRF_TIMING
 __device__ unsigned long long g_potrf_t[64];
 #define PT(i) do { if (threadIdx.x == 0) g_potrf_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// per step launch (slot = rows below the panel / 128), s_memrealtime ticks (100 MHz): [0] workgroup 0 starts, [1] its
+// prologue is done (the diagonal block has arrived), [2] it ends, [3] the last row workgroup ends, [4] the first
+// trailing-update workgroup starts, [5] the last one ends, [6] the first row workgroup starts
+__device__ unsigned long long g_step_t[64 * 16];
+#define STEP_T(p, j, op) do { if (threadIdx.x == 0) { const int slot_ = (int)((p).below / NB) < 63 ? (int)((p).below / NB) : 63; \
+  op(&g_step_t[slot_ * 16 + (j)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } while (0)
 #else
 #define PT(i)
+#define STEP_T(p, j, op)
 #endif
 
 // two SYRK tiles at once (independent accumulators: the MFMA latencies overlap)
@@ -396,6 +403,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
   if (tid < NB) ys[tid] = (p.y && tid < nbk) ? p.y[tid] : 0.;
   __syncthreads();
   PT(1);
+  if constexpr (PUB) STEP_T(p, 1, atomicMax);
 
   int bad_pivot = 0;
   if (wave == 0) micro_potrf_inv<PUB>(T + tile_off(0, 0), Wc, p.img + tile_off(0, 0), lane, ln, 0, bad_pivot);
@@ -442,6 +450,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
       micro_potrf_inv<PUB>(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB), p.img + tile_off(jb + 1, jb + 1),
                            lane, ln, o + MB, bad_pivot);
       PT(6 + 4 * jb);
+      if constexpr (PUB) { if (jb == NMB - 2) STEP_T(p, 8, atomicMax); }
     } else {
       const int rem = NMB - 1 - jb;
       const int ntile = rem * (rem + 1) / 2;
@@ -478,6 +487,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
     PT(7 + 4 * jb);
   }
   PT(40);
+  if constexpr (PUB) STEP_T(p, 7, atomicMax);
   if constexpr (PUB) {  // z_b first: the workgroups below wait for it, nobody in this launch waits for the write-back of L11
     if (p.zpub && tid < nbk) store_pub(p.zpub + tid, ys[tid]);
   }
@@ -525,6 +535,15 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
 #ifdef AGP_POTRF_TIMING
 void read_potrf_timing(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potrf_t), sizeof(unsigned long long) * 64);
+}
+void read_step_timing(unsigned long long *out, bool reset) {
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_t), sizeof(g_step_t));
+  if (reset) {
+    static unsigned long long init[64 * 16];
+    for (int i = 0; i < 64; ++i)
+      for (int j = 0; j < 16; ++j) init[i * 16 + j] = (j == 4 || j == 6) ? ~0ull : 0ull;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_t), init, sizeof(init));
+  }
 }
 #endif
 
@@ -757,17 +776,17 @@ __device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
     else x = (gr == gc) ? 1. : 0.;  // identity padding of a partial last block
     acc[0][r] = x;
   }
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    double av[16], bv[16];
+  {
+    // the whole depth (32 k-steps x 2 operands) in flight at once: one load round trip on the launch's critical path
+    double av[32], bv[32];
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {
-      const long long k = 64 * half + 4 * s2 + lg;
+    for (int s2 = 0; s2 < 32; ++s2) {
+      const long long k = 4 * s2 + lg;
       av[s2] = oka ? Xd[k * p.lda + ra] : 0.;
       bv[s2] = okb ? Xd[k * p.lda + rb] : 0.;
     }
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) acc[s2 & 3] = mfma16(-av[s2], bv[s2], acc[s2 & 3]);
+    for (int s2 = 0; s2 < 32; ++s2) acc[s2 & 3] = mfma16(-av[s2], bv[s2], acc[s2 & 3]);
   }
   const v4d out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
@@ -847,31 +866,37 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
       Y[jb][r] = (nok && m < p.nbk) ? base[m * p.lda] : 0.;
     }
   trsm_fused_step<0>(p, lane, Y, base, nok, lg);
+  STEP_T(p, 9, atomicMax);
   if (p.y) {
-    // y[n] -= sum_m X[n][m] z[m]: z_b is published when the producer has finished the whole block
+    // y[n] -= sum_m X[n][m] z[m]: z_b is published when the producer has finished the whole block.  All 32 values of this
+    // lane in flight at once and re-read together until none is the sentinel (one element at a time, each poll a
+    // dependent L2 round trip, took 6 us - measured with scripts/diag_step.py - and was the last thing the launch waited for)
+    double z[NMB][4];
+    unsigned long long t0 = 0;
+    for (int spin = 0;; ++spin) {
+      bool ok = true;
+#pragma unroll
+      for (int jb = 0; jb < NMB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = jb * MB + lg + 4 * r;
+          z[jb][r] = (m < p.nbk) ? load_pub(p.zpub + m) : 0.;
+        }
+#pragma unroll
+      for (int jb = 0; jb < NMB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ok = ok && !is_unpublished(z[jb][r]);
+      if (__all(ok)) break;
+      if (spin == 0) t0 = __builtin_amdgcn_s_memrealtime();
+      else if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
     double part = 0.;
 #pragma unroll
     for (int jb = 0; jb < NMB; ++jb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = jb * MB + lg + 4 * r;
-        double z = 0.;
-        if (m < p.nbk) {
-          z = load_pub(p.zpub + m);
-          if (is_unpublished(z)) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (int spin = 1; is_unpublished(z); ++spin) {
-              if ((spin & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 >= PUB_TIMEOUT_TICKS) {
-                atomicExch(p.flags + 2, 1);
-                break;
-              }
-              __builtin_amdgcn_s_sleep(4);
-              z = load_pub(p.zpub + m);
-            }
-          }
-        }
-        part += Y[jb][r] * z;
-      }
+      for (int r = 0; r < 4; ++r) part += Y[jb][r] * z[jb][r];
+    STEP_T(p, 10, atomicMax);
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
     if (lg == 0 && nok) p.y[p.nbk + n0 + ln] -= part;
@@ -1007,16 +1032,22 @@ __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
   static_assert(POTRF_LDS_DOUBLES >= 2 * 2 * GK * GLD && POTRF_LDS_DOUBLES >= 2 * 64 * TRP,
                 "the trailing-update workgroups stage their operands in T");
   if (UPD && blockIdx.x >= p.trail_first) {
+    STEP_T(p, 4, atomicMin);
     trail_update_body(p, (long long)(blockIdx.x - p.trail_first), T);
+    STEP_T(p, 5, atomicMax);
     return;
   }
   __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);
   if (blockIdx.x == 0) {
+    STEP_T(p, 0, atomicMax);
     potrf_diag_body<true, UPD>(p, T);
+    STEP_T(p, 2, atomicMax);
   } else if (UPD && blockIdx.x <= UPD_BLOCKS) {
     diag_update_body(p, (int)(blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6));
   } else {
+    STEP_T(p, 6, atomicMin);
     trsm_fused_body<UPD>(p, UPD ? 1 + UPD_BLOCKS : 1, T);
+    STEP_T(p, 3, atomicMax);
   }
 }
 
