@@ -71,6 +71,15 @@ struct PotrfArgs {
   // 64 x 64 tiles) while this panel is factored - one launch per panel, no update launch, no second stream.
   unsigned trail_first = 0xffffffffu;
   int trail_big = 0;  // 1: 128 x 128 tiles (many rows left: the trailing update is what the launch takes), 0: 64 x 64
+  // workgroup hold_index does nothing but keep its slot until workgroup 0 is done (see panel_phase)
+  unsigned hold_index = 0xffffffffu;
+  // step launches: the previous panel's update of THIS panel's rows below the diagonal block is done by the first
+  // 2 x ceil(below / 64) trailing workgroups (64 x 64 tiles, device-scope stores), which count themselves in
+  // rowcnt[64-row block] when complete; the workgroup that solves those 64 rows waits for rowcnt_expect there and reads
+  // its rows with device-scope loads.  (The counters only grow: every step launch adds two per row block.)
+  // nullptr: the row workgroups update their own rows first (the update-ahead experiment without trailing workgroups).
+  unsigned long long *rowcnt = nullptr;
+  unsigned long long rowcnt_expect = 0;
 };
 
 constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
@@ -308,11 +317,17 @@ __device__ unsigned long long g_potrf_t[64];
 // prologue is done (the diagonal block has arrived), [2] it ends, [3] the last row workgroup ends, [4] the first
 // trailing-update workgroup starts, [5] the last one ends, [6] the first row workgroup starts
 __device__ unsigned long long g_step_t[64 * 16];
+__device__ unsigned long long g_row_t[128 * 8];  // the launch with 1408 rows below: per workgroup (blockIdx) start, pre-update done, TRSM done, end, CU
 #define STEP_T(p, j, op) do { if (threadIdx.x == 0) { const int slot_ = (int)((p).below / NB) < 63 ? (int)((p).below / NB) : 63; \
   op(&g_step_t[slot_ * 16 + (j)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } while (0)
 #else
 #define PT(i)
 #define STEP_T(p, j, op)
+#endif
+#ifdef AGP_POTRF_TIMING
+#define ROW_T(p, j) do { if (threadIdx.x == 0 && (p).below == 1408 && blockIdx.x < 128) g_row_t[blockIdx.x * 8 + (j)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ROW_T(p, j)
 #endif
 
 // two SYRK tiles at once (independent accumulators: the MFMA latencies overlap)
@@ -536,6 +551,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
 void read_potrf_timing(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potrf_t), sizeof(unsigned long long) * 64);
 }
+void read_row_timing(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_t), sizeof(g_row_t)); }
 void read_step_timing(unsigned long long *out, bool reset) {
   if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_t), sizeof(g_step_t));
   if (reset) {
@@ -805,7 +821,24 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
   const bool active = n0 < p.below;
   const bool nok = active && n0 + ln < p.below;
   double *base = p.A + p.k0 * p.lda + (p.k0 + p.nbk) + (n0 + ln);  // X[n][m] at base[m * lda]
-  if constexpr (UPD) {
+  ROW_T(p, 0);
+#ifdef AGP_POTRF_TIMING
+  if (threadIdx.x == 0 && p.below == 1408 && blockIdx.x < 128)
+    g_row_t[blockIdx.x * 8 + 4] = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u) << 8 | (__builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4) & 255u);
+#endif
+  const bool handed = UPD && p.rowcnt != nullptr;  // the rows arrive updated from the first trailing workgroups of this launch
+  if (handed) {
+    if (tid == 0) {
+      const unsigned long long *c = p.rowcnt + (blockIdx.x - first_block);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (int spin = 1; __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.rowcnt_expect; ++spin) {
+        if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (UPD) if (!handed) {
     // The previous panel's update of this workgroup's 64 rows x 128 columns, in memory, before they are loaded and
     // solved: C[jb] -= X_own (16 rows x 128 deep) . X_d[rows of micro column jb]^T; everything it reads is final
     // (previous launch).  The depth in two passes of 64: X_d (128 rows x 64 deep, 64 KB) goes through LDS once per
@@ -835,27 +868,52 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
         }
       }
       __syncthreads();
+      if (pass == 0) ROW_T(p, 5); else ROW_T(p, 7);
       if (active) {
+        // this wave's 16 rows x 128 columns of C in two halves of four micro columns: the 16 values per lane of a half in
+        // flight at once (one micro column at a time - load, 16 MFMAs, store: sixteen dependent round trips - took 26 us
+        // next to the trailing workgroups, measured with scripts/diag_step.py: the TRSM then started when the POTRF was
+        // nearly done; all eight at once spills)
 #pragma unroll
-        for (int jb = 0; jb < NMB; ++jb) {
-          v4d acc[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
+        for (int h = 0; h < 2; ++h) {
+          double cv[4][4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = jb * MB + lg + 4 * r;
-            acc[0][r] = (nok && m < p.nbk) ? base[m * p.lda] : 0.;
-          }
+          for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
-          for (int s2 = 0; s2 < 16; ++s2) acc[s2 & 3] = mfma16(-Xs[(4 * s2 + lg) * XP + jb * MB + ln], bo[s2], acc[s2 & 3]);
-          const v4d out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            for (int r = 0; r < 4; ++r) {
+              const int m = (4 * h + j4) * MB + lg + 4 * r;
+              cv[j4][r] = (nok && m < p.nbk) ? base[m * p.lda] : 0.;
+            }
+          // the 16 A fragments of a micro column are read from LDS in one batch, the next column's while this one multiplies
+          // (one ds_read in front of every MFMA made the 128 MFMAs of a pass take 9 us)
+          double fa[2][16];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = jb * MB + lg + 4 * r;
-            if (nok && m < p.nbk) base[m * p.lda] = out[r];
+          for (int s2 = 0; s2 < 16; ++s2) fa[0][s2] = Xs[(4 * s2 + lg) * XP + (4 * h) * MB + ln];
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4) {
+            const int jb = 4 * h + j4;
+            if (j4 < 3) {
+#pragma unroll
+              for (int s2 = 0; s2 < 16; ++s2) fa[(j4 + 1) & 1][s2] = Xs[(4 * s2 + lg) * XP + (jb + 1) * MB + ln];
+            }
+            v4d acc[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][r] = cv[j4][r];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) acc[s2 & 3] = mfma16(-fa[j4 & 1][s2], bo[s2], acc[s2 & 3]);
+            const v4d out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int m = jb * MB + lg + 4 * r;
+              if (nok && m < p.nbk) base[m * p.lda] = out[r];
+            }
           }
         }
       }
+      if (pass == 0) ROW_T(p, 6);
     }
   }
+  ROW_T(p, 1);
   if (!active) return;  // from here on the waves are independent: no barrier below
   v4d Y[NMB];
 #pragma unroll
@@ -863,10 +921,17 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = jb * MB + lg + 4 * r;
-      Y[jb][r] = (nok && m < p.nbk) ? base[m * p.lda] : 0.;
+      Y[jb][r] = (nok && m < p.nbk) ? (handed ? load_pub(base + m * p.lda) : base[m * p.lda]) : 0.;
     }
   trsm_fused_step<0>(p, lane, Y, base, nok, lg);
+  ROW_T(p, 2);
   STEP_T(p, 9, atomicMax);
+#ifdef AGP_POTRF_TIMING
+  if (lane == 0) {  // who is last: (time << 20 | workgroup << 4 | wave)
+    const int slot_ = (int)(p.below / NB) < 63 ? (int)(p.below / NB) : 63;
+    atomicMax(&g_step_t[slot_ * 16 + 11], (unsigned long long)__builtin_amdgcn_s_memrealtime() << 20 | (unsigned long long)blockIdx.x << 4 | wave);
+  }
+#endif
   if (p.y) {
     // y[n] -= sum_m X[n][m] z[m]: z_b is published when the producer has finished the whole block.  All 32 values of this
     // lane in flight at once and re-read together until none is the sentinel (one element at a time, each poll a
@@ -943,8 +1008,9 @@ __device__ __forceinline__ void trail_store_pass(double *__restrict__ Ls, const 
   }
 }
 
+template <bool PUBLISH = false>
 __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const double *__restrict__ P, long long ld, long long M,
-                                             long long i0, long long j0, double *lds) {
+                                             long long i0, long long j0, double *lds, unsigned long long *done = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1, ln = lane & 15, lg = lane >> 4;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(P) & 15) == 0) && ((ld & 1) == 0);
@@ -997,12 +1063,33 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
-        if (row < M && col < M) Cc[row + col * ld] = acc[tj][ti][r];
+        if (row < M && col < M) {
+          if constexpr (PUBLISH) store_pub(Cc + row + col * ld, acc[tj][ti][r]);
+          else Cc[row + col * ld] = acc[tj][ti][r];
+        }
       }
     }
+  if constexpr (PUBLISH) {
+    // every store of this tile acknowledged, then one count: a reader that sees the count reads final values
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 __device__ __forceinline__ void trail_update_body(const PotrfArgs &p, long long id, double *lds) {
+  if (p.rowcnt) {
+    // the first 2 x nrb workgroups: this panel's own columns, rows below the diagonal block (tile column 0, then 1)
+    const long long nrb = (p.below + ST - 1) / ST;
+    if (id < 2 * nrb) {
+      const long long bj = id / nrb, bi = id % nrb;
+      // origin at (k0, k0): rows of the diagonal block = rows 0 .. 127 of the previous panel's rows from k0 on
+      trail_tile64<true>(p.A + p.k0 * p.lda + p.k0, p.A + (p.k0 - NB) * p.lda + p.k0, p.lda, p.below + NB, (2 + bi) * ST, bj * ST,
+                         lds, p.rowcnt + bi);
+      return;
+    }
+    id -= 2 * nrb;
+  }
   const long long t0 = p.k0 + NB;
   double *Cc = p.A + t0 * p.lda + t0;
   const double *P = p.A + (p.k0 - NB) * p.lda + t0;
@@ -1032,9 +1119,25 @@ __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
   static_assert(POTRF_LDS_DOUBLES >= 2 * 2 * GK * GLD && POTRF_LDS_DOUBLES >= 2 * 64 * TRP,
                 "the trailing-update workgroups stage their operands in T");
   if (UPD && blockIdx.x >= p.trail_first) {
+    if (blockIdx.x == p.hold_index) {
+      // placeholder: idle in the slot next to workgroup 0 until the last tile of the image is out
+      const double *last = p.img + tile_off(NMB - 1, NMB - 1) + MB * MB - 1;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (int spin = 1; is_unpublished(load_pub(last)); ++spin) {
+        if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
+        __builtin_amdgcn_s_sleep(64);
+      }
+      return;
+    }
     STEP_T(p, 4, atomicMin);
-    trail_update_body(p, (long long)(blockIdx.x - p.trail_first), T);
+    ROW_T(p, 0);
+#ifdef AGP_POTRF_TIMING
+    if (threadIdx.x == 0 && p.below == 1408 && blockIdx.x < 128)
+      g_row_t[blockIdx.x * 8 + 4] = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u) << 8 | (__builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4) & 255u);
+#endif
+    trail_update_body(p, (long long)(blockIdx.x - p.trail_first) - (blockIdx.x > p.hold_index ? 1 : 0), T);
     STEP_T(p, 5, atomicMax);
+    ROW_T(p, 3);
     return;
   }
   __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);
@@ -1167,12 +1270,18 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
     ctx->d_dpub = nullptr;
+    ctx->d_rowcnt = nullptr;
     ctx->dpub_cap = 0;
     const long long cap = (b1 + 31) / 32 * 32;
-    if (hipMalloc(&ctx->d_dpub, sizeof(double) * (size_t)cap * IMG_DOUBLES) == hipSuccess) ctx->dpub_cap = cap;
+    // (+ two 64-row counters per diagonal block behind the images: the hand-over of the step launches' row updates)
+    if (hipMalloc(&ctx->d_dpub, sizeof(double) * (size_t)cap * (IMG_DOUBLES + 2)) == hipSuccess) {
+      ctx->dpub_cap = cap;
+      ctx->d_rowcnt = reinterpret_cast<unsigned long long *>(ctx->d_dpub + cap * (long long)IMG_DOUBLES);
+    }
     else (void)hipGetLastError();
   }
   const long long cnt_img = (b1 - b0) * (long long)IMG_DOUBLES, cnt_z = k_end - k_begin;
+  if (ctx->d_dpub && ctx->dpub_cap >= b1) (void)hipMemsetAsync(ctx->d_rowcnt + 2 * b0, 0, sizeof(unsigned long long) * 2 * (size_t)(b1 - b0), s);
   if (ctx->d_dpub && ctx->dpub_cap >= b1)
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_img + 255) / 256)), dim3(256), 0, s,
                        ctx->d_dpub + b0 * (long long)IMG_DOUBLES, cnt_img);
@@ -1235,7 +1344,28 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
           pa.trail_big = pa.below > step_tile128_above() ? 1 : 0;
           const long long edge = pa.trail_big ? 128 : 64, nt = (pa.below + edge - 1) / edge;
           pa.trail_first = grid;
+          if (ctx->d_rowcnt && !pa.trail_big) {
+            pa.rowcnt = ctx->d_rowcnt + (k + NB) / 64;
+            pa.rowcnt_expect = 2ull * (unsigned long long)((k - K0) / NB);
+            grid += (unsigned)(2 * nt);  // (nt = 64-row blocks below)
+          }
           grid += (unsigned)(nt * (nt + 1) / 2);
+          // AGP_STEP_HOLD (default 256, 0 = off): workgroup 256 of the launch is a placeholder.  Workgroups go round-robin over
+          // the 8 XCDs and, inside one, to its 32 CUs in turn: number 256 is the first to get a CU that already has a
+          // workgroup - workgroup 0's (scripts/microbench/hwid_probe.hip, scripts/diag_step.py).  Next to a trailing-update
+          // workgroup the POTRF of workgroup 0 takes 40-47 us instead of 27-30; next to an idle one it does not notice.
+          // If the dispatch order ever differs this costs one idle slot and nothing else.  Measured on whole fits
+          // (scripts/sweep_step2.sh): N = 4096 2.19 -> 1.99 ms, N = 8192 6.38 -> 6.24 ms, N = 16384 32.89 -> 32.80 ms.  (Starting the
+          // trailing workgroups a few microseconds late, so that the critical workgroups' loads go first, gained nothing.)
+          static int hold = -1;
+          if (hold < 0) {
+            const char *e = getenv("AGP_STEP_HOLD");
+            hold = e ? atoi(e) : 256;
+          }
+          if (hold > 0 && (unsigned)hold >= pa.trail_first && (unsigned)hold < grid) {
+            pa.hold_index = (unsigned)hold;
+            grid += 1;
+          }
         }
         hipLaunchKernelGGL(panel_fused_kernel<true>, dim3(grid), dim3(256), 0, s, pa);
       } else {

@@ -30,4 +30,18 @@ for slot in range(63, -1, -1):
     nxt = ""
     if slot > 0 and t[slot - 1][0] > 0:
         nxt = f"{(t[slot - 1][0] - r[0]) / 100.:7.1f}"
-    print(f"{slot * 128:6d}      {f(r[1])} {f(r[2])} |  {f(r[6])} {f(r[3])} |  {f(r[4])} {f(r[5])}   {nxt}   | wg0 last diag tile out {f(r[8])} z out {f(r[7])} | rows: trsm done {f(r[9])} z seen {f(r[10])}")
+    print(f"{slot * 128:6d}      {f(r[1])} {f(r[2])} |  {f(r[6])} {f(r[3])} |  {f(r[4])} {f(r[5])}   {nxt}   | wg0 last diag tile out {f(r[8])} z out {f(r[7])} | rows: trsm done {f(r[9])} z seen {f(r[10])} last: wg {(int(r[11]) >> 4) & 0xffff} wave {int(r[11]) & 15}")
+
+if os.environ.get("ROW_DETAIL"):
+    rt = (C.c_ulonglong * 1024)()
+    lib.agp_debug_row_timing.argtypes = [C.c_void_p]
+    lib.agp_debug_row_timing(rt)
+    rt = np.array(list(rt), dtype=np.uint64).reshape(128, 8).astype(np.int64)
+    base = t[11][0]  # workgroup 0's start of the launch with 1408 rows below
+    print("launch with 1408 rows below: workgroup, CU, start, pre-update done, TRSM done / (trailing) end  [us after wg0's start]")
+    for w in range(128):
+        r = rt[w]
+        if r[0] == 0:
+            continue
+        g = lambda v: f"{(v - base) / 100.:7.1f}" if v > 0 else "      -"
+        print(f"wg {w:3d} cu {int(r[4]):#06x}  {g(r[0])} {g(r[1])} {g(r[2])} {g(r[3])}   pre-update: staged0 {g(r[5])} mfma0 {g(r[6])} staged1 {g(r[7])}")
