@@ -1252,7 +1252,7 @@ static long long fused_below() {
 // Before the fused panel kernels of one factorisation run: sentinel-fill the tile images of the diagonal blocks
 // [k_begin, k_end) and the z slots of those rows (stream-ordered before the first panel launch on `s`).
 // A no-op (and the two-launch path is used) if the fused kernel is off or the z buffer cannot be allocated.
-void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long long k_begin, long long k_end) {
+void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long long k_begin, long long k_end, bool want_step) {
   ctx->img_ready = nullptr;
   if (!panel_fused_enabled() || k_end <= k_begin) return;
   if (ctx->zpub_cap < k_end) {
@@ -1266,7 +1266,7 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
     ctx->zpub_cap = cap;
   }
   const long long b0 = k_begin / NB, b1 = (k_end + NB - 1) / NB;
-  if ((upd_below() > 0 || step_below() > 0) && ctx->dpub_cap < b1) {
+  if ((upd_below() > 0 || (want_step && step_below() > 0)) && ctx->dpub_cap < b1) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
     ctx->d_dpub = nullptr;
@@ -1314,6 +1314,7 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
     left_above = e ? atoll(e) : 6144;
     if (left_above == 0) left_above = 1LL << 60;  // 0: never
   }
+  if (kend != n) step_mode = false;  // (see panel_phase_public)
   const bool inner_left = !step_mode && (n - K0) > left_above;
   // The consumers of the fused kernel hold their slots for the whole POTRF (~30 us): while the bulk update fills the
   // chip that costs it more than the saved launch (measured: 43.3 -> 41.8 TFLOP/s), so the fused kernel takes over
@@ -1401,8 +1402,13 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
 
 void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *img,
                         double *y, long long K0, long long kend) {
-  panel_fused_prepare(ctx, s, img, K0, kend);
-  panel_phase(ctx, s, A, n, lda, img, y, K0, kend, nullptr);
+  // (one block column of a sharded fit, or a probe: the block's own panels as step launches - one launch per panel, no
+  // update launches - while the second image and the counters, which are indexed by the GLOBAL block number, stay small)
+  const bool step = kend == n && kend <= 65536 && kend - K0 <= step_below();  // (a step launch updates ALL columns right of its panel: the block must end the matrix)
+  panel_fused_prepare(ctx, s, img, K0, kend, step);
+  const bool step_ok = step && panel_fused_enabled() && ctx->d_dpub && ctx->dpub_cap * NB >= kend && ctx->d_rowcnt && ctx->d_zpub &&
+                       ctx->img_ready == img && ctx->zpub_ready_n >= kend;
+  panel_phase(ctx, s, A, n, lda, img, y, K0, kend, nullptr, nullptr, false, nullptr, 0, step_ok);
   ctx->img_ready = nullptr;
 }
 
@@ -1550,7 +1556,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   const int variant = ctx->update_variant;
   long long kend = K0 + pick_nbo(n, nbo_fixed);
   if (kend > n) kend = n;
-  panel_fused_prepare(ctx, sa, invd, 0, n);
+  panel_fused_prepare(ctx, sa, invd, 0, n, true);
   // the chain-bound tail as one launch per panel on this stream (panel_phase step_mode) once `remaining` rows are left
   auto step_ok = [&](long long remaining) {
     return nbo_fixed == 0 && remaining <= step_below() && panel_fused_enabled() && ctx->d_dpub && ctx->dpub_cap * NB >= n &&
