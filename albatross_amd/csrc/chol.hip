@@ -317,6 +317,7 @@ __device__ unsigned long long g_potrf_t[64];
 // prologue is done (the diagonal block has arrived), [2] it ends, [3] the last row workgroup ends, [4] the first
 // trailing-update workgroup starts, [5] the last one ends, [6] the first row workgroup starts
 __device__ unsigned long long g_step_t[64 * 16];
+__device__ long long g_row_target = 1408;
 __device__ unsigned long long g_row_t[128 * 8];  // the launch with 1408 rows below: per workgroup (blockIdx) start, pre-update done, TRSM done, end, CU
 #define STEP_T(p, j, op) do { if (threadIdx.x == 0) { const int slot_ = (int)((p).below / NB) < 63 ? (int)((p).below / NB) : 63; \
   op(&g_step_t[slot_ * 16 + (j)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } while (0)
@@ -325,7 +326,7 @@ __device__ unsigned long long g_row_t[128 * 8];  // the launch with 1408 rows be
 #define STEP_T(p, j, op)
 #endif
 #ifdef AGP_POTRF_TIMING
-#define ROW_T(p, j) do { if (threadIdx.x == 0 && (p).below == 1408 && blockIdx.x < 128) g_row_t[blockIdx.x * 8 + (j)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ROW_T(p, j) do { if (threadIdx.x == 0 && (p).below == g_row_target && blockIdx.x < 128) g_row_t[blockIdx.x * 8 + (j)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ROW_T(p, j)
 #endif
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
 void read_potrf_timing(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potrf_t), sizeof(unsigned long long) * 64);
 }
+void set_row_target(long long v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_row_target), &v, sizeof(v)); }
 void read_row_timing(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_t), sizeof(g_row_t)); }
 void read_step_timing(unsigned long long *out, bool reset) {
   if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_t), sizeof(g_step_t));
@@ -776,6 +778,7 @@ __device__ __forceinline__ void trsm_fused_step(const PotrfArgs &p, int lane, v4
 // layout of potrf_diag_body.  Nine workgroups of four waves cover the block; each finishes in ~2 us.
 __device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
   const int lane = threadIdx.x & 63, ln = lane & 15, lg = lane >> 4;
+  ROW_T(p, 0);
   int ib = 0;
   while ((ib + 1) * (ib + 2) / 2 <= tile) ++ib;
   const int kb = tile - ib * (ib + 1) / 2;
@@ -801,9 +804,11 @@ __device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
       av[s2] = oka ? Xd[k * p.lda + ra] : 0.;
       bv[s2] = okb ? Xd[k * p.lda + rb] : 0.;
     }
+    ROW_T(p, 5);
 #pragma unroll
     for (int s2 = 0; s2 < 32; ++s2) acc[s2 & 3] = mfma16(-av[s2], bv[s2], acc[s2 & 3]);
   }
+  ROW_T(p, 1);
   const v4d out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -811,6 +816,7 @@ __device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
     const int gr = ib * MB + ln, gc = kb * MB + lg + 4 * r;
     store_pub(p.dpub + tile * (MB * MB) + (lg + 4 * r) * MB + ln, (gr >= gc) ? out[r] : 0.);
   }
+  ROW_T(p, 2);
 }
 
 template <bool UPD>
@@ -823,7 +829,7 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
   double *base = p.A + p.k0 * p.lda + (p.k0 + p.nbk) + (n0 + ln);  // X[n][m] at base[m * lda]
   ROW_T(p, 0);
 #ifdef AGP_POTRF_TIMING
-  if (threadIdx.x == 0 && p.below == 1408 && blockIdx.x < 128)
+  if (threadIdx.x == 0 && p.below == g_row_target && blockIdx.x < 128)
     g_row_t[blockIdx.x * 8 + 4] = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u) << 8 | (__builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4) & 255u);
 #endif
   const bool handed = UPD && p.rowcnt != nullptr;  // the rows arrive updated from the first trailing workgroups of this launch
@@ -1132,7 +1138,7 @@ __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
     STEP_T(p, 4, atomicMin);
     ROW_T(p, 0);
 #ifdef AGP_POTRF_TIMING
-    if (threadIdx.x == 0 && p.below == 1408 && blockIdx.x < 128)
+    if (threadIdx.x == 0 && p.below == g_row_target && blockIdx.x < 128)
       g_row_t[blockIdx.x * 8 + 4] = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u) << 8 | (__builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4) & 255u);
 #endif
     trail_update_body(p, (long long)(blockIdx.x - p.trail_first) - (blockIdx.x > p.hold_index ? 1 : 0), T);

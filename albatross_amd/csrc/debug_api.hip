@@ -386,7 +386,8 @@ extern "C" AGP_DEBUG_API int agp_debug_panel_chain(agp_context *ctx, int64_t n, 
 #ifdef AGP_POTRF_TIMING
 namespace agp { void read_potrf_timing(unsigned long long *out); }
 extern "C" AGP_DEBUG_API int agp_debug_potrf_timing(unsigned long long *out) { read_potrf_timing(out); return 0; }
-namespace agp { void read_step_timing(unsigned long long *out, bool reset); void read_row_timing(unsigned long long *out); }
+namespace agp { void read_step_timing(unsigned long long *out, bool reset); void read_row_timing(unsigned long long *out); void set_row_target(long long v); }
+extern "C" AGP_DEBUG_API int agp_debug_row_target(long long v) { set_row_target(v); return 0; }
 extern "C" AGP_DEBUG_API int agp_debug_row_timing(unsigned long long *out) { read_row_timing(out); return 0; }
 extern "C" AGP_DEBUG_API int agp_debug_step_timing(unsigned long long *out, int reset) { read_step_timing(out, reset != 0); return 0; }
 #endif

@@ -13,6 +13,10 @@ lib.agp_debug_factor.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C
 lib.agp_debug_step_timing.argtypes = [C.c_void_p, C.c_int]
 rng = np.random.default_rng(0)
 B = rng.standard_normal((n, n)); A = np.asfortranarray(B @ B.T + n * np.eye(n)); y = rng.standard_normal(n)
+target = int(os.environ.get("ROW_DETAIL", "0") or 0)
+if target > 1:
+    lib.agp_debug_row_target.argtypes = [C.c_longlong]
+    lib.agp_debug_row_target(target)
 for rep in range(3):
     lib.agp_debug_step_timing(None, 1)
     Ad = A.copy(order="F"); yd = y.copy(); ld = C.c_double(); bad = C.c_int64()
@@ -37,8 +41,9 @@ if os.environ.get("ROW_DETAIL"):
     lib.agp_debug_row_timing.argtypes = [C.c_void_p]
     lib.agp_debug_row_timing(rt)
     rt = np.array(list(rt), dtype=np.uint64).reshape(128, 8).astype(np.int64)
-    base = t[11][0]  # workgroup 0's start of the launch with 1408 rows below
-    print("launch with 1408 rows below: workgroup, CU, start, pre-update done, TRSM done / (trailing) end  [us after wg0's start]")
+    tr = target if target > 1 else 1408
+    base = t[tr // 128][0]  # workgroup 0's start of that launch
+    print(f"launch with {tr} rows below: workgroup, CU, start, pre-update done, TRSM done / (trailing) end  [us after wg0's start]")
     for w in range(128):
         r = rt[w]
         if r[0] == 0:
