@@ -72,7 +72,7 @@ struct PotrfArgs {
   unsigned trail_first = 0xffffffffu;
   int trail_big = 0;  // 1: 128 x 128 tiles (many rows left: the trailing update is what the launch takes), 0: 64 x 64
   // workgroup hold_index does nothing but keep its slot until workgroup 0 is done (see panel_phase)
-  unsigned hold_index = 0xffffffffu;
+  unsigned hold_index = 0xffffffffu, hold_count = 0;
   // step launches: the previous panel's update of THIS panel's rows below the diagonal block is done by the first
   // 2 x ceil(below / 64) trailing workgroups (64 x 64 tiles, device-scope stores), which count themselves in
   // rowcnt[64-row block] when complete; the workgroup that solves those 64 rows waits for rowcnt_expect there and reads
@@ -80,6 +80,7 @@ struct PotrfArgs {
   // nullptr: the row workgroups update their own rows first (the update-ahead experiment without trailing workgroups).
   unsigned long long *rowcnt = nullptr;
   unsigned long long rowcnt_expect = 0;
+  long long trail_tiles = 0, trail_workers = 1;  // tiles of the launch (row tiles first) / trailing workgroups that share them
 };
 
 constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
@@ -767,7 +768,7 @@ __device__ __forceinline__ void trsm_fused_step(const PotrfArgs &p, int lane, v4
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = JB * MB + lg + 4 * r;
-      if (nok && m < p.nbk) base[m * p.lda] = out[r];
+      if (nok && m < p.nbk) store_pub(base + m * p.lda, out[r]);  // (write-through: read by the next launch, see trail_tile64)
     }
     trsm_fused_step<JB + 1>(p, lane, Y, base, nok, lg);
   }
@@ -1069,10 +1070,10 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
-        if (row < M && col < M) {
-          if constexpr (PUBLISH) store_pub(Cc + row + col * ld, acc[tj][ti][r]);
-          else Cc[row + col * ld] = acc[tj][ti][r];
-        }
+        // device-scope (write-through) stores for every tile: what a step launch writes is read by the NEXT launch, on other
+        // XCDs - left dirty in this XCD's L2 it is written back at the kernel boundary, R^2 / 2 doubles at once, and the
+        // next launch's first loads (the diagonal block's update, on its critical path) queue behind that
+        if (row < M && col < M) store_pub(Cc + row + col * ld, acc[tj][ti][r]);
       }
     }
   if constexpr (PUBLISH) {
@@ -1083,9 +1084,9 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
   }
 }
 
-__device__ __forceinline__ void trail_update_body(const PotrfArgs &p, long long id, double *lds) {
+__device__ __forceinline__ void trail_one_tile(const PotrfArgs &p, long long id, double *lds) {
   if (p.rowcnt) {
-    // the first 2 x nrb workgroups: this panel's own columns, rows below the diagonal block (tile column 0, then 1)
+    // the first 2 x nrb tiles: this panel's own columns, rows below the diagonal block (tile column 0, then 1)
     const long long nrb = (p.below + ST - 1) / ST;
     if (id < 2 * nrb) {
       const long long bj = id / nrb, bi = id % nrb;
@@ -1119,13 +1120,24 @@ __device__ __forceinline__ void trail_update_body(const PotrfArgs &p, long long 
   }
 }
 
+// A trailing workgroup takes the tiles worker, worker + trail_workers, ... : no more workgroups than fit on the chip next
+// to the critical ones.  (One workgroup per tile: at 4000 remaining rows the dispatcher starts and retires 2600 of them
+// during the launch - 20 ns each even when they do nothing - and every start on a CU disturbs what runs there: with
+// empty trailing workgroups the diagonal block reached workgroup 0 after 44 us instead of 6, scripts/diag_step.py.)
+__device__ __forceinline__ void trail_update_body(const PotrfArgs &p, long long worker, double *lds) {
+  for (long long id = worker; id < p.trail_tiles; id += p.trail_workers) {
+    if (id != worker) __syncthreads();  // the previous tile's readers are done with lds
+    trail_one_tile(p, id, lds);
+  }
+}
+
 template <bool UPD>
 __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
   __shared__ double T[POTRF_LDS_DOUBLES];
   static_assert(POTRF_LDS_DOUBLES >= 2 * 2 * GK * GLD && POTRF_LDS_DOUBLES >= 2 * 64 * TRP,
                 "the trailing-update workgroups stage their operands in T");
   if (UPD && blockIdx.x >= p.trail_first) {
-    if (blockIdx.x == p.hold_index) {
+    if (blockIdx.x >= p.hold_index && blockIdx.x < p.hold_index + p.hold_count) {
       // placeholder: idle in the slot next to workgroup 0 until the last tile of the image is out
       const double *last = p.img + tile_off(NMB - 1, NMB - 1) + MB * MB - 1;
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1141,7 +1153,7 @@ __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
     if (threadIdx.x == 0 && p.below == g_row_target && blockIdx.x < 128)
       g_row_t[blockIdx.x * 8 + 4] = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u) << 8 | (__builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4) & 255u);
 #endif
-    trail_update_body(p, (long long)(blockIdx.x - p.trail_first) - (blockIdx.x > p.hold_index ? 1 : 0), T);
+    trail_update_body(p, (long long)(blockIdx.x - p.trail_first) - (blockIdx.x > p.hold_index ? (long long)p.hold_count : 0), T);
     STEP_T(p, 5, atomicMax);
     ROW_T(p, 3);
     return;
@@ -1351,27 +1363,46 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
           pa.trail_big = pa.below > step_tile128_above() ? 1 : 0;
           const long long edge = pa.trail_big ? 128 : 64, nt = (pa.below + edge - 1) / edge;
           pa.trail_first = grid;
+          long long tiles = nt * (nt + 1) / 2;
           if (ctx->d_rowcnt && !pa.trail_big) {
             pa.rowcnt = ctx->d_rowcnt + (k + NB) / 64;
             pa.rowcnt_expect = 2ull * (unsigned long long)((k - K0) / NB);
-            grid += (unsigned)(2 * nt);  // (nt = 64-row blocks below)
+            tiles += 2 * nt;  // (nt = 64-row blocks below)
           }
-          grid += (unsigned)(nt * (nt + 1) / 2);
-          // AGP_STEP_HOLD (default 256, 0 = off): workgroup 256 of the launch is a placeholder.  Workgroups go round-robin over
-          // the 8 XCDs and, inside one, to its 32 CUs in turn: number 256 is the first to get a CU that already has a
-          // workgroup - workgroup 0's (scripts/microbench/hwid_probe.hip, scripts/diag_step.py).  Next to a trailing-update
-          // workgroup the POTRF of workgroup 0 takes 40-47 us instead of 27-30; next to an idle one it does not notice.
-          // If the dispatch order ever differs this costs one idle slot and nothing else.  Measured on whole fits
-          // (scripts/sweep_step2.sh): N = 4096 2.19 -> 1.99 ms, N = 8192 6.38 -> 6.24 ms, N = 16384 32.89 -> 32.80 ms.  (Starting the
-          // trailing workgroups a few microseconds late, so that the critical workgroups' loads go first, gained nothing.)
+          // Workgroups go round-robin over the 8 XCDs and, inside one, to its 32 CUs in turn: the first 256 of a launch get a CU
+          // each, number 256 + i lands next to number i (scripts/microbench/hwid_probe.hip, scripts/diag_step.py).  The critical
+          // workgroups - the factoring one, the nine that update its block, the row workgroups - keep their CUs to themselves:
+          // workgroups 256 .. 256 + (their number) are PLACEHOLDERS that idle until the image is complete (next to a
+          // trailing workgroup the POTRF takes 40-47 us instead of 27-30 and the diagonal block arrives after 10-13 us
+          // instead of 6).  The trailing workgroups take the tiles worker, worker + workers, ...: as many as fit (two per
+          // CU on the CUs left), not one per tile (2600 starts and exits per launch at 4000 remaining rows cost ~10 %).
+          // If the dispatch order ever differs this costs idle slots and nothing else.  AGP_STEP_HOLD=0: no placeholders.
           static int hold = -1;
           if (hold < 0) {
             const char *e = getenv("AGP_STEP_HOLD");
-            hold = e ? atoi(e) : 256;
+            hold = e ? atoi(e) : 1;
           }
-          if (hold > 0 && (unsigned)hold >= pa.trail_first && (unsigned)hold < grid) {
-            pa.hold_index = (unsigned)hold;
-            grid += 1;
+          const long long ncrit = grid;
+          long long workers = tiles;
+          long long nhold = 0;
+          if (ncrit + workers > 256 && hold > 0 && ncrit < 256) {
+            // 1 (default): all critical workgroups while the trailing update is short (it needs the slots when it is what the
+            // launch takes: from ~2900 remaining rows on only the factoring workgroup and the nine that feed it); n > 1: the first n
+            nhold = (hold == 1) ? (tiles <= 1200 ? ncrit : 1 + UPD_BLOCKS) : (hold < ncrit ? hold : ncrit);
+            const long long cap = 512 - ncrit - nhold;
+            if (workers > cap) workers = cap;
+            if (ncrit + workers <= 256) nhold = 0;
+          } else if (workers > 512 - ncrit) {
+            workers = 512 - ncrit;
+          }
+          if (workers < 2 * nt && workers < tiles) workers = (2 * nt < tiles) ? 2 * nt : tiles;
+          pa.trail_tiles = tiles;
+          pa.trail_workers = workers;
+          grid += (unsigned)workers;
+          if (nhold > 0) {
+            pa.hold_index = 256;
+            pa.hold_count = (unsigned)nhold;
+            grid += (unsigned)nhold;
           }
         }
         hipLaunchKernelGGL(panel_fused_kernel<true>, dim3(grid), dim3(256), 0, s, pa);
