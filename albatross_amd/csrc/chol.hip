@@ -1377,11 +1377,10 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
           // instead of 6).  The trailing workgroups take the tiles worker, worker + workers, ...: as many as fit (two per
           // CU on the CUs left), not one per tile (2600 starts and exits per launch at 4000 remaining rows cost ~10 %).
           // If the dispatch order ever differs this costs idle slots and nothing else.  AGP_STEP_HOLD=0: no placeholders.
-          static int hold = -1;
-          if (hold < 0) {
-            const char *e = getenv("AGP_STEP_HOLD");
-            hold = e ? atoi(e) : 1;
-          }
+          int hold = 1;
+          long long slots = 512;  // two workgroups of this kernel per CU (AGP_STEP_SLOTS; both read per call: tests switch them)
+          if (const char *e = getenv("AGP_STEP_HOLD")) hold = atoi(e);
+          if (const char *e = getenv("AGP_STEP_SLOTS")) slots = atoll(e) > 0 ? atoll(e) : 512;
           const long long ncrit = grid;
           long long workers = tiles;
           long long nhold = 0;
@@ -1389,11 +1388,11 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
             // 1 (default): all critical workgroups while the trailing update is short (it needs the slots when it is what the
             // launch takes: from ~2900 remaining rows on only the factoring workgroup and the nine that feed it); n > 1: the first n
             nhold = (hold == 1) ? (tiles <= 1200 ? ncrit : 1 + UPD_BLOCKS) : (hold < ncrit ? hold : ncrit);
-            const long long cap = 512 - ncrit - nhold;
+            const long long cap = slots - ncrit - nhold;
             if (workers > cap) workers = cap;
             if (ncrit + workers <= 256) nhold = 0;
-          } else if (workers > 512 - ncrit) {
-            workers = 512 - ncrit;
+          } else if (workers > slots - ncrit) {
+            workers = slots - ncrit;
           }
           if (workers < 2 * nt && workers < tiles) workers = (2 * nt < tiles) ? 2 * nt : tiles;
           pa.trail_tiles = tiles;

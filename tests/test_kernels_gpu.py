@@ -189,6 +189,27 @@ def test_panel_step_kernel(ctx, dbg, n, monkeypatch):
         assert abs(out["0"][2] - out[mode][2]) <= 1e-10 * abs(out["0"][2])
 
 
+@pytest.mark.parametrize("hold,slots", [("0", "512"), ("1000", "512"), ("1", "96"), ("10", "300")])
+def test_panel_step_kernel_layouts(ctx, dbg, hold, slots, monkeypatch):
+    """The step launches with other workgroup layouts than the default: no placeholder workgroups / one next to every critical
+    workgroup / few slots (every trailing workgroup loops over many tiles; the row tiles still come first)."""
+    n = 3000
+    rng = np.random.default_rng(7)
+    B = rng.standard_normal((n, n))
+    A = np.asfortranarray(B @ B.T + n * np.eye(n))
+    y = rng.standard_normal(n)
+    monkeypatch.setenv("AGP_STEP_BELOW", "8192")
+    monkeypatch.setenv("AGP_STEP_HOLD", hold)
+    monkeypatch.setenv("AGP_STEP_SLOTS", slots)
+    Ad, yd = A.copy(order="F"), y.copy()
+    logdet, bad = C.c_double(), C.c_int64()
+    assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
+    assert bad.value == -1
+    L = np.linalg.cholesky(A)
+    assert np.abs(np.tril(Ad) - L).max() <= 1e-11 * np.abs(L).max()
+    assert np.abs(yd - np.linalg.solve(L, y)).max() <= 1e-10
+
+
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 500, 4096, 4097, 9000])
 def test_symv_lower(ctx, dbg, n):
     """launch_symv_lower (the K p of the mixed-precision fit's conjugate gradients): only the lower triangle is read
