@@ -95,6 +95,7 @@ int agp_context_create(int device_id, agp_context **out) {
     // AGP_MASK_CUS = CUs the bulk stream keeps (multiple of 8; 0 = no masked stream)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
+    ctx->cus = cus;
     int keep = 224;  // scripts/sweep_mask.sh: 224 CUs (28 per XCD) from 8704 remaining rows on is the best pair at N = 16384
     if (const char *e = getenv("AGP_MASK_CUS")) keep = atoi(e);
     keep = keep / 8 * 8;

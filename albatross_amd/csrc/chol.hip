@@ -1440,7 +1440,7 @@ void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n,
                         double *y, long long K0, long long kend) {
   // (one block column of a sharded fit, or a probe: the block's own panels as step launches - one launch per panel, no
   // update launches - while the second image and the counters, which are indexed by the GLOBAL block number, stay small)
-  const bool step = kend == n && kend <= 65536 && kend - K0 <= step_below();  // (a step launch updates ALL columns right of its panel: the block must end the matrix)
+  const bool step = kend == n && kend <= 65536 && kend - K0 <= step_below() && 2LL * ctx->cus >= 10 + (kend - K0) / 64 + 64;  // (a step launch updates ALL columns right of its panel: the block must end the matrix)
   panel_fused_prepare(ctx, s, img, K0, kend, step);
   const bool step_ok = step && panel_fused_enabled() && ctx->d_dpub && ctx->dpub_cap * NB >= kend && ctx->d_rowcnt && ctx->d_zpub &&
                        ctx->img_ready == img && ctx->zpub_ready_n >= kend;
@@ -1594,8 +1594,11 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   if (kend > n) kend = n;
   panel_fused_prepare(ctx, sa, invd, 0, n, true);
   // the chain-bound tail as one launch per panel on this stream (panel_phase step_mode) once `remaining` rows are left
+  // (the row workgroups of a step launch wait for trailing workgroups that are dispatched AFTER them: all critical workgroups -
+  // 10 + one per 64 rows - and some trailing ones must fit on the chip at once, two per CU, or they would wait for their
+  // 2 s time-out; a small partition of the GPU does not use the step launches)
   auto step_ok = [&](long long remaining) {
-    return nbo_fixed == 0 && remaining <= step_below() && panel_fused_enabled() && ctx->d_dpub && ctx->dpub_cap * NB >= n &&
+    return nbo_fixed == 0 && remaining <= step_below() && 2LL * ctx->cus >= 10 + remaining / 64 + 64 && panel_fused_enabled() && ctx->d_dpub && ctx->dpub_cap * NB >= n &&
            ctx->d_zpub && ctx->img_ready == invd && ctx->zpub_ready_n >= n;
   };
   const bool step_all = step_ok(n);  // small matrix: every panel

@@ -115,6 +115,7 @@ struct agp_context {
   // per diagonal block, like invd; only allocated when the update-ahead panel kernel is in use)
   double *d_dpub = nullptr;
   long long dpub_cap = 0;  // diagonal blocks
+  int cus = 256;  // CUs of the device (hipDeviceAttributeMultiprocessorCount)
   unsigned long long *d_rowcnt = nullptr;  // one counter per 64 rows (tail of the d_dpub allocation): hand-over of the step launches' row updates
   // merged trailing updates (factor_lower): one completion counter per outer step
   unsigned long long *d_merge_cnt = nullptr;
