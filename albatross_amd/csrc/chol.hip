@@ -1361,13 +1361,14 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
         unsigned grid = (unsigned)(1 + UPD_BLOCKS + (pa.below + 63) / 64);
         if (step_mode && pa.below > 0) {  // ... nor to anything right of them
           pa.trail_big = pa.below > step_tile128_above() ? 1 : 0;
-          const long long edge = pa.trail_big ? 128 : 64, nt = (pa.below + edge - 1) / edge;
+          const long long edge = pa.trail_big ? 128 : 64, ntb = (pa.below + edge - 1) / edge;  // trailing tiles right of the panel
+          const long long nt = (pa.below + 63) / 64;                                            // 64-row blocks below
           pa.trail_first = grid;
-          long long tiles = nt * (nt + 1) / 2;
-          if (ctx->d_rowcnt && !pa.trail_big) {
+          long long tiles = ntb * (ntb + 1) / 2;
+          if (ctx->d_rowcnt) {
             pa.rowcnt = ctx->d_rowcnt + (k + NB) / 64;
             pa.rowcnt_expect = 2ull * (unsigned long long)((k - K0) / NB);
-            tiles += 2 * nt;  // (nt = 64-row blocks below)
+            tiles += 2 * nt;
           }
           // Workgroups go round-robin over the 8 XCDs and, inside one, to its 32 CUs in turn: the first 256 of a launch get a CU
           // each, number 256 + i lands next to number i (scripts/microbench/hwid_probe.hip, scripts/diag_step.py).  The critical
