@@ -1015,6 +1015,11 @@ __device__ __forceinline__ void trail_store_pass(double *__restrict__ Ls, const 
   }
 }
 
+// Barrier for LDS hand-overs only: waits for this wave's LDS operations, not for its global loads and stores in flight
+// (__syncthreads() drains those too: at every tile boundary the trailing workgroups waited for their C stores to be
+// acknowledged before the next tile's loads could even be issued).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool PUBLISH = false>
 __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const double *__restrict__ P, long long ld, long long M,
                                              long long i0, long long j0, double *lds, unsigned long long *done = nullptr) {
@@ -1039,10 +1044,10 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
     }
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    if (pass) __syncthreads();  // the first pass's readers are done with the buffers
+    if (pass) lds_barrier();  // the first pass's readers are done with the buffers
     trail_store_pass<false>(As, ra);
     trail_store_pass<true>(Bs, rb);
-    __syncthreads();
+    lds_barrier();
     if (pass == 0) {
       trail_load_pass(P, ld, i0, M, 64, vec_ok, ra);
       trail_load_pass(P, ld, j0, M, 64, vec_ok, rb);
@@ -1126,7 +1131,7 @@ __device__ __forceinline__ void trail_one_tile(const PotrfArgs &p, long long id,
 // empty trailing workgroups the diagonal block reached workgroup 0 after 44 us instead of 6, scripts/diag_step.py.)
 __device__ __forceinline__ void trail_update_body(const PotrfArgs &p, long long worker, double *lds) {
   for (long long id = worker; id < p.trail_tiles; id += p.trail_workers) {
-    if (id != worker) __syncthreads();  // the previous tile's readers are done with lds
+    if (id != worker) lds_barrier();  // the previous tile's readers are done with lds
     trail_one_tile(p, id, lds);
   }
 }
