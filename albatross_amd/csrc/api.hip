@@ -89,6 +89,8 @@ int agp_context_create(int device_id, agp_context **out) {
     ctx->stream_side = ctx->stream3;
     AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
     AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_inv, hipEventDisableTiming));
+    AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_step[0], hipEventDisableTiming));
+    AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_step[1], hipEventDisableTiming));
     AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
     // CU mask of the end-phase bulk stream: bit i = CU i, and CU i sits on XCD i % 8 (measured with
     // scripts/probe_cumask.py: dropping the LAST indices keeps the XCDs balanced, dropping i % 32 >= 28 does not).
@@ -154,6 +156,8 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->stream3 && ctx->stream3 != ctx->stream2) (void)hipStreamDestroy(ctx->stream3);
   if (ctx->ev_d) (void)hipEventDestroy(ctx->ev_d);
   if (ctx->ev_inv) (void)hipEventDestroy(ctx->ev_inv);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->ev_step[i]) (void)hipEventDestroy(ctx->ev_step[i]);
   if (ctx->stream_masked) (void)hipStreamDestroy(ctx->stream_masked);
   if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
   delete ctx;

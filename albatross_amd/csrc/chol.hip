@@ -81,6 +81,13 @@ struct PotrfArgs {
   unsigned long long *rowcnt = nullptr;
   unsigned long long rowcnt_expect = 0;
   long long trail_tiles = 0, trail_workers = 1;  // tiles of the launch (row tiles first) / trailing workgroups that share them
+  // split step launches (many rows left): the update of everything RIGHT of this panel by the panel before the previous one
+  // ran as a kernel of its own on the second stream and may still be running; its tiles of THIS panel's columns count
+  // themselves per 64-row block in farcnt (indexed from row k0 on).  The workgroups that read those columns - the nine that
+  // update the diagonal block, the row tiles - wait for far_expect (the first 64 rows of the diagonal block: one less)
+  // and read with device-scope loads.  nullptr: nothing pending.
+  const unsigned long long *farcnt = nullptr;
+  unsigned long long far_expect = 0;
 };
 
 constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
@@ -128,6 +135,15 @@ __device__ __forceinline__ bool poll_expired(unsigned long long t0, int *flags) 
   if (__builtin_amdgcn_s_memrealtime() - t0 < PUB_TIMEOUT_TICKS) return false;
   if ((threadIdx.x & 63) == 0) atomicExch(flags + 2, 1);
   return true;
+}
+
+// every lane polls (wave-uniform address): wait until *c >= need
+__device__ __forceinline__ void wait_count(const unsigned long long *c, unsigned long long need, int *flags) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int spin = 1; __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spin) {
+    if ((spin & 63) == 0 && poll_expired(t0, flags)) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
 }
 
 __global__ __launch_bounds__(256) void fill_sentinel_kernel(double *p, long long count) {
@@ -788,11 +804,13 @@ __device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
   const int ra = kb * MB + ln, rb = ib * MB + ln;
   const bool oka = ra < p.nbk, okb = rb < p.nbk;
   v4d acc[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
+  const bool far = p.farcnt != nullptr;  // the block's last update may still be on its way from the second stream
+  if (far) wait_count(p.farcnt + ib / 4, p.far_expect - (ib < 4 ? 1 : 0), p.flags);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gr = ib * MB + ln, gc = kb * MB + lg + 4 * r;  // D/C layout: register r of lane (ln, lg) = element (row ln, column lg + 4 r)
     double x;
-    if (gr < p.nbk && gc < p.nbk) x = (gr >= gc) ? Dd[gc * p.lda + gr] : 0.;
+    if (gr < p.nbk && gc < p.nbk) x = (gr >= gc) ? (far ? load_pub(Dd + gc * p.lda + gr) : Dd[gc * p.lda + gr]) : 0.;
     else x = (gr == gc) ? 1. : 0.;  // identity padding of a partial last block
     acc[0][r] = x;
   }
@@ -1022,7 +1040,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 template <bool PUBLISH = false>
 __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const double *__restrict__ P, long long ld, long long M,
-                                             long long i0, long long j0, double *lds, unsigned long long *done = nullptr) {
+                                             long long i0, long long j0, double *lds, unsigned long long *done = nullptr,
+                                             const unsigned long long *wait_cnt = nullptr, unsigned long long wait_val = 0,
+                                             int *flags = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1, ln = lane & 15, lg = lane >> 4;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(P) & 15) == 0) && ((ld & 1) == 0);
@@ -1030,6 +1050,7 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
   double ra[16], rb[16];
   trail_load_pass(P, ld, i0, M, 0, vec_ok, ra);
   trail_load_pass(P, ld, j0, M, 0, vec_ok, rb);
+  if (wait_cnt) wait_count(wait_cnt, wait_val, flags);  // (this tile of C is still being written by the far update before this one)
   v4d acc[2][2];
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
@@ -1039,7 +1060,7 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
-        acc[tj][ti][r] = (row < M && col < M) ? Cc[row + col * ld] : 0.;
+        acc[tj][ti][r] = (row < M && col < M) ? (wait_cnt ? load_pub(Cc + row + col * ld) : Cc[row + col * ld]) : 0.;
       }
     }
 #pragma unroll
@@ -1097,7 +1118,7 @@ __device__ __forceinline__ void trail_one_tile(const PotrfArgs &p, long long id,
       const long long bj = id / nrb, bi = id % nrb;
       // origin at (k0, k0): rows of the diagonal block = rows 0 .. 127 of the previous panel's rows from k0 on
       trail_tile64<true>(p.A + p.k0 * p.lda + p.k0, p.A + (p.k0 - NB) * p.lda + p.k0, p.lda, p.below + NB, (2 + bi) * ST, bj * ST,
-                         lds, p.rowcnt + bi);
+                         lds, p.rowcnt + bi, p.farcnt ? p.farcnt + 2 + bi : nullptr, p.far_expect, p.flags);
       return;
     }
     id -= 2 * nrb;
@@ -1262,6 +1283,13 @@ static long long step_tile128_above() {
   return v;
 }
 
+// Rows below the panel above which a step launch leaves the update of everything right of the panel to a kernel of its
+// own on the second stream (AGP_STEP_SPLIT_ABOVE; 0 = never).  Read per call.
+static long long step_split_above() {
+  const char *e = getenv("AGP_STEP_SPLIT_ABOVE");
+  return e ? atoll(e) : 0;
+}
+
 static long long fused_below() {
   static long long v = -1;
   if (v < 0) {
@@ -1294,17 +1322,22 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
     if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
     ctx->d_dpub = nullptr;
     ctx->d_rowcnt = nullptr;
+    ctx->d_farcnt = nullptr;
     ctx->dpub_cap = 0;
     const long long cap = (b1 + 31) / 32 * 32;
     // (+ two 64-row counters per diagonal block behind the images: the hand-over of the step launches' row updates)
-    if (hipMalloc(&ctx->d_dpub, sizeof(double) * (size_t)cap * (IMG_DOUBLES + 2)) == hipSuccess) {
+    if (hipMalloc(&ctx->d_dpub, sizeof(double) * (size_t)cap * (IMG_DOUBLES + 4)) == hipSuccess) {
       ctx->dpub_cap = cap;
       ctx->d_rowcnt = reinterpret_cast<unsigned long long *>(ctx->d_dpub + cap * (long long)IMG_DOUBLES);
+      ctx->d_farcnt = ctx->d_rowcnt + 2 * cap;
     }
     else (void)hipGetLastError();
   }
   const long long cnt_img = (b1 - b0) * (long long)IMG_DOUBLES, cnt_z = k_end - k_begin;
-  if (ctx->d_dpub && ctx->dpub_cap >= b1) (void)hipMemsetAsync(ctx->d_rowcnt + 2 * b0, 0, sizeof(unsigned long long) * 2 * (size_t)(b1 - b0), s);
+  if (ctx->d_dpub && ctx->dpub_cap >= b1) {
+    (void)hipMemsetAsync(ctx->d_rowcnt + 2 * b0, 0, sizeof(unsigned long long) * 2 * (size_t)(b1 - b0), s);
+    (void)hipMemsetAsync(ctx->d_farcnt + 2 * b0, 0, sizeof(unsigned long long) * 2 * (size_t)(b1 - b0), s);
+  }
   if (ctx->d_dpub && ctx->dpub_cap >= b1)
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_img + 255) / 256)), dim3(256), 0, s,
                        ctx->d_dpub + b0 * (long long)IMG_DOUBLES, cnt_img);
@@ -1345,6 +1378,11 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
   const bool fused = panel_fused_enabled() && ctx->d_zpub && ctx->zpub_ready_n >= kend && ctx->img_ready == invd &&
                      ((n - K0) <= fused_below() || upd_prev || step_mode) &&  // (factor_lower asks for upd_prev / step_mode only when all of this holds)
                      !wait_counter;                             // (merged updates: the bulk-bound phase, two launches)
+  // split step launches (step_mode, many rows left): see PotrfArgs::farcnt
+  long long far_launched = 0;   // far updates launched on the second stream so far (every one covers all rows to the end)
+  bool far_pending = false;     // the previous panel's far update is (possibly) still running
+  hipStream_t s_far = ctx->stream_masked ? ctx->stream_masked : ctx->stream2;
+  const long long split_above = step_split_above();
   for (long long k = K0; k < kend; k += NB) {
     const int nbk = (int)((n - k < NB) ? n - k : NB);
     if (inner_left && k > K0) {
@@ -1364,6 +1402,29 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
         // the panel before this one (columns k - 128 .. k - 1) has not been applied to these columns yet
         pa.dpub = ctx->d_dpub + (k / NB) * (long long)IMG_DOUBLES;
         unsigned grid = (unsigned)(1 + UPD_BLOCKS + (pa.below + 63) / 64);
+        const bool split = step_mode && pa.below > split_above && split_above > 0 && ctx->d_farcnt && ctx->d_rowcnt && s_far &&
+                           ctx->ev_step[0] && ctx->ev_step[1];
+        if (far_pending) {
+          // this launch reads columns the previous far update may still be writing: its counted tiles are the hand-over
+          pa.farcnt = ctx->d_farcnt + k / 64;
+          pa.far_expect = 2ull * (unsigned long long)far_launched;
+          if (!split) {
+            // ... and a launch that updates the far columns itself must not overtake it there
+            (void)hipEventRecord(ctx->ev_d, s_far);
+            (void)hipStreamWaitEvent(s, ctx->ev_d, 0);
+            far_pending = false;
+          }
+        }
+        if (split) {
+          // critical workgroups + the row tiles only; everything right of the panel goes to the second stream below
+          const long long nt = (pa.below + 63) / 64;
+          pa.trail_first = grid;
+          pa.rowcnt = ctx->d_rowcnt + (k + NB) / 64;
+          pa.rowcnt_expect = 2ull * (unsigned long long)((k - K0) / NB);
+          pa.trail_tiles = 2 * nt;
+          pa.trail_workers = 2 * nt;
+          grid += (unsigned)(2 * nt);
+        } else
         if (step_mode && pa.below > 0) {  // ... nor to anything right of them
           pa.trail_big = pa.below > step_tile128_above() ? 1 : 0;
           const long long edge = pa.trail_big ? 128 : 64, ntb = (pa.below + edge - 1) / edge;  // trailing tiles right of the panel
@@ -1411,8 +1472,25 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
           }
         }
         hipLaunchKernelGGL(panel_fused_kernel<true>, dim3(grid), dim3(256), 0, s, pa);
+        if (split) {
+          // The far update of this step: everything right of this panel -= (previous panel)(previous panel)^T, as a kernel of
+          // its own (64 x 64 tiles, four workgroups per CU: 37 TFLOP/s where the trailing workgroups inside the launch,
+          // two per CU next to the 79 KB of the factoring workgroup's kind, reach 26).  It needs the PREVIOUS launch
+          // complete - the host waits for that (an unsatisfied hipStreamWaitEvent on the other stream slows the chain, section
+          // 8) while this launch is already queued - and its tiles of the next panel's columns count themselves for the next launch.
+          const int slot = (int)((k / NB) & 1);
+          (void)hipEventRecord(ctx->ev_step[slot], s);
+          while (hipEventQuery(ctx->ev_step[slot ^ 1]) == hipErrorNotReady) {}
+          const long long t0 = k + NB;
+          launch_update64_counted(s_far, A + t0 * lda + t0, lda, A + (k - NB) * lda + t0, lda, pa.below, NB, ctx->d_farcnt + t0 / 64, 2);
+          ++far_launched;
+          far_pending = true;
+        } else if (step_mode) {
+          (void)hipEventRecord(ctx->ev_step[(int)((k / NB) & 1)], s);
+        }
       } else {
         hipLaunchKernelGGL(panel_fused_kernel<false>, dim3((unsigned)(1 + (pa.below + 63) / 64)), dim3(256), 0, s, pa);
+        if (step_mode && ctx->ev_step[0] && ctx->ev_step[1]) (void)hipEventRecord(ctx->ev_step[(int)((k / NB) & 1)], s);
       }
       if (below <= 0) continue;
     } else {

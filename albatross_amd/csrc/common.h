@@ -116,6 +116,8 @@ struct agp_context {
   double *d_dpub = nullptr;
   long long dpub_cap = 0;  // diagonal blocks
   int cus = 256;  // CUs of the device (hipDeviceAttributeMultiprocessorCount)
+  hipEvent_t ev_step[2] = {nullptr, nullptr};  // step launches: "launch k complete" for the host, alternating
+  unsigned long long *d_farcnt = nullptr;  // per 64 rows: tiles of the NEXT panel's columns finished by the far trailing updates (second stream)
   unsigned long long *d_rowcnt = nullptr;  // one counter per 64 rows (tail of the d_dpub allocation): hand-over of the step launches' row updates
   // merged trailing updates (factor_lower): one completion counter per outer step
   unsigned long long *d_merge_cnt = nullptr;
@@ -243,6 +245,8 @@ int mfma_f64_peak(hipStream_t s, int iters, double *tflops);
 namespace agp {
 // C(M x N) -= A(M x K) * B(N x K)^T  (fp64 MFMA).  a_kmajor / b_kmajor select
 // transposed operand storage; tri keeps only tiles on/below C's diagonal.
+void launch_update64_counted(hipStream_t s, double *C, long long ldc, const double *P, long long ldp, long long M, long long K,
+                             unsigned long long *done, int done_cols);
 void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
                         bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
                         long long N, long long K, bool tri);

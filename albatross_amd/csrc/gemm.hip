@@ -517,6 +517,21 @@ void launch_gemm_nt_sub_stair(hipStream_t s, double *C, long long ldc, const dou
   hipLaunchKernelGGL((gemm_nt_sub_kernel<false, false>), dim3((unsigned)((long long)g.ntr * g.ntc)), dim3(GEMM_THREADS), 0, s, g);
 }
 
+// C (M x M, lower 64 x 64 tiles) -= P P^T with the 64-tile kernel whatever the size; the tiles of the first done_cols tile
+// columns are counted per row tile in done[bi] (GemmArgs::done64): the far trailing update of a step launch
+void launch_update64_counted(hipStream_t s, double *C, long long ldc, const double *P, long long ldp, long long M, long long K,
+                             unsigned long long *done, int done_cols) {
+  if (M <= 0 || K <= 0) return;
+  GemmArgs h;
+  h.C = C; h.ldc = ldc; h.A = P; h.lda = ldp; h.B = P; h.ldb = ldp;
+  h.M = M; h.N = M; h.K = K; h.tri = 1;
+  h.remap = 0; h.nsuper = 0; h.nb8 = 0;
+  h.ntr = h.ntc = (int)((M + ST - 1) / ST);
+  h.done64 = done; h.done64_cols = done_cols;
+  const long long t64 = count_tiles(h.ntr, h.ntc, 1);
+  hipLaunchKernelGGL(gemm64_nt_sub_kernel, dim3((unsigned)t64, 1), dim3(GEMM_THREADS), 0, s, h);
+}
+
 void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
                         bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
                         long long N, long long K, bool tri) {

@@ -41,6 +41,11 @@ struct GemmArgs {
   // with everything further right.  done == nullptr: off.
   unsigned long long *done = nullptr;
   int done_cols = 0;
+  // 64 x 64-tile kernel, far trailing update of a step launch (chol.hip: panel_phase): the tiles of the first done64_cols
+  // tile columns - the next panel's columns - are written with device-scope stores and counted per ROW tile in
+  // done64[bi] when complete; the next step launch, on another stream, waits for those counts.  nullptr: off.
+  unsigned long long *done64 = nullptr;
+  int done64_cols = 0;
 };
 
 #ifndef AGP_GEMM_4X4
@@ -369,6 +374,7 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
       __syncthreads();
     }
   }
+  const bool counted = g.done64 != nullptr && j0 < (long long)g.done64_cols * ST;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
@@ -377,9 +383,18 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
-        if (row < g.M && col < g.N) g.C[row + col * g.ldc] = acc[tj][ti][r];
+        if (row < g.M && col < g.N) {
+          if (counted) __hip_atomic_store(g.C + row + col * g.ldc, acc[tj][ti][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else g.C[row + col * g.ldc] = acc[tj][ti][r];
+        }
       }
     }
+  if (counted) {
+    // every store of this tile acknowledged, then one count: a reader that sees the count reads final values
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(g.done64 + i0 / ST, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 

@@ -189,6 +189,27 @@ def test_panel_step_kernel(ctx, dbg, n, monkeypatch):
         assert abs(out["0"][2] - out[mode][2]) <= 1e-10 * abs(out["0"][2])
 
 
+@pytest.mark.parametrize("n,split", [(3000, "1024"), (3400, "2000"), (2100, "256")])
+def test_panel_step_kernel_split(ctx, dbg, n, split, monkeypatch):
+    """AGP_STEP_SPLIT_ABOVE: the step launches with many rows left hand the update of everything right of the panel to a
+    kernel of its own on the second stream; its counted tiles are what the next launch waits for.  Against numpy, with the
+    switch into and out of the split launches inside the matrix."""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n))
+    A = np.asfortranarray(B @ B.T + n * np.eye(n))
+    y = rng.standard_normal(n)
+    monkeypatch.setenv("AGP_STEP_BELOW", "8192")
+    monkeypatch.setenv("AGP_STEP_SPLIT_ABOVE", split)
+    L = np.linalg.cholesky(A)
+    for rep in range(2):  # (the counters are reset per factorisation)
+        Ad, yd = A.copy(order="F"), y.copy()
+        logdet, bad = C.c_double(), C.c_int64()
+        assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
+        assert bad.value == -1
+        assert np.abs(np.tril(Ad) - L).max() <= 1e-11 * np.abs(L).max()
+        assert np.abs(yd - np.linalg.solve(L, y)).max() <= 1e-10
+
+
 @pytest.mark.parametrize("hold,slots", [("0", "512"), ("1000", "512"), ("1", "96"), ("10", "300")])
 def test_panel_step_kernel_layouts(ctx, dbg, hold, slots, monkeypatch):
     """The step launches with other workgroup layouts than the default: no placeholder workgroups / one next to every critical
