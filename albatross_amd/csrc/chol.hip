@@ -1485,12 +1485,13 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
           launch_update64_counted(s_far, A + t0 * lda + t0, lda, A + (k - NB) * lda + t0, lda, pa.below, NB, ctx->d_farcnt + t0 / 64, 2);
           ++far_launched;
           far_pending = true;
-        } else if (step_mode) {
+        } else if (step_mode && split_above > 0 && ctx->ev_step[0] && ctx->ev_step[1]) {
+          // (only when split launches may follow: an event record between two launches costs ~6 us of gap on this stream)
           (void)hipEventRecord(ctx->ev_step[(int)((k / NB) & 1)], s);
         }
       } else {
         hipLaunchKernelGGL(panel_fused_kernel<false>, dim3((unsigned)(1 + (pa.below + 63) / 64)), dim3(256), 0, s, pa);
-        if (step_mode && ctx->ev_step[0] && ctx->ev_step[1]) (void)hipEventRecord(ctx->ev_step[(int)((k / NB) & 1)], s);
+        if (step_mode && split_above > 0 && ctx->ev_step[0] && ctx->ev_step[1]) (void)hipEventRecord(ctx->ev_step[(int)((k / NB) & 1)], s);
       }
       if (below <= 0) continue;
     } else {
