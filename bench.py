@@ -306,6 +306,9 @@ def other_configs(ab, ctx):
     return out
 
 
+FALLBACK_EXIT = 5  # a replicas line was printed in place of the sharded measurement that was asked for
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,6 +326,9 @@ def parse_args(argv=None):
                          "data-path collective (weak scaling).  The other mode is measured too and reported in an auxiliary block.")
     ap.add_argument("--no-fallback", action="store_true",
                     help="N > 1: fail instead of falling back to replicas when the sharded fit cannot run or fails its self-check")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: exit 0 when the replicas fallback was measured instead of the sharded fit (default: the labelled "
+                         f"line is still printed, but the exit code is {FALLBACK_EXIT} - a dead RCCL path is not a green run)")
     ap.add_argument("--fallback-note", default="", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -372,21 +378,27 @@ def launch_ranks(args, argv):
     argv = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--train-points", str(args.n),
             "--multi-gpu", args.multi_gpu]
     for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-predict", args.no_predict), ("--no-configs", args.no_configs),
-                     ("--force-sharded", args.force_sharded), ("--no-fallback", args.no_fallback)):
+                     ("--force-sharded", args.force_sharded), ("--no-fallback", args.no_fallback),
+                     ("--allow-fallback", args.allow_fallback)):
         if on:
             argv.append(flag)
     rc, line = attempt([])
     if rc == 0 and line:
         print(line, flush=True)
         return 0
+    if rc != 0 and line and '"sharded_fallback"' in line:
+        # the ranks agreed on the fallback themselves and left with FALLBACK_EXIT (torch.distributed.run turns that into 1):
+        # the labelled line, a non-zero code
+        print(line, flush=True)
+        return FALLBACK_EXIT
     if args.multi_gpu == "sharded" and not args.no_fallback:
         note = f"the sharded {args.gpus}-rank run exited with code {rc}" + ("" if line else " and printed no result line")
         sys.stderr.write(f"bench.py: {note}; measuring {args.gpus} independent fits (replicas) instead\n")
         argv[argv.index("--multi-gpu") + 1] = "replicas"
         rc2, line2 = attempt(["--fallback-note", note])
-        if rc2 == 0 and line2:
+        if line2 and (rc2 == 0 or '"sharded_fallback"' in line2):
             print(line2, flush=True)
-            return 0
+            return 0 if args.allow_fallback else FALLBACK_EXIT
         return rc2 or 1
     if line:
         print(line, flush=True)
@@ -671,8 +683,9 @@ def run_rank(args):
         fits = args.steps if (sharded or world == 1) else args.steps * world
         achieved = (gemm_flop / 1e12) / (gemm_ms * 1e-3) if gemm_ms > 0 else 0.0  # 0: no launch of that kernel at this size
         if sharded and world > 1:
-            parallelism = (f"ONE fit row-block-sharded (512-row blocks, snake-cyclic) over {world} GPUs: per block column ONE RCCL "
-                           "all-gather carrying the panel rows and the next diagonal block, one block column of look-ahead")
+            parallelism = (f"ONE fit row-block-sharded (512-row blocks, snake-cyclic) over {world} GPUs: per block column one RCCL "
+                           "broadcast of the factored diagonal block + one RCCL all-gather of the panel rows, one block column of "
+                           "look-ahead; back substitution: one all-reduce per 2048-row super-block")
             kernel_name = "agp::gemm_nt_sub_kernel (fp64 MFMA updates of rank 0's own row blocks, K=512)"
         else:
             parallelism = "1 GPU" if world == 1 else f"{world} independent fits, one per GPU, no data-path collective"
@@ -734,7 +747,7 @@ def run_rank(args):
         gloo_barrier()
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(4 if bad_check else 0)
+        os._exit(4 if bad_check else (0 if args.allow_fallback else FALLBACK_EXIT))
     if comm is not None:
         comm.barrier()
         comm.close()

@@ -1,7 +1,7 @@
 """CPU tests (-m "not gpu") of the multi-GPU path: the library's C++ sharded-fit schedule
 (albatross_amd/csrc/shard_sched.hip: row-block-cyclic LL^T with look-ahead, both substitutions) driven through
 `agp_shard_factor_custom` with numpy block operations (tests/dist_cpu_ops.py) and gloo collectives
-(`Communicator.torch_callbacks`), world sizes 1-4, checked against the oracle."""
+(`Communicator.torch_callbacks`), world sizes 1-8, checked against the oracle."""
 import os
 import socket
 import sys
@@ -92,15 +92,27 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,n,block", [(2, 700, 128), (3, 1000, 256), (2, 512, 512), (4, 300, 128), (3, 1300, 128),
-                                           (4, 2100, 128), (2, 1024, 512)])
+                                           (4, 2100, 128), (2, 1024, 512),
+                                           # world = 8, the size of the node the schedule is written for: 33 / 9 block columns,
+                                           # every rank is the root of several broadcasts; (8, 700, 128): fewer blocks than
+                                           # ranks, two ranks own nothing
+                                           (8, 4200, 128), (8, 2100, 256), (8, 700, 128)])
 def test_sharded_schedule_over_gloo(world, n, block):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
         port = _free_port()
         procs = [ctx.Process(target=_worker, args=(r, world, port, n, block, out)) for r in range(world)]
-        for p in procs:
-            p.start()
+        threads = os.environ.get("OMP_NUM_THREADS")
+        os.environ["OMP_NUM_THREADS"] = "1"  # inherited by the ranks: `world` BLAS pools on this machine's few cores crawl
+        try:
+            for p in procs:
+                p.start()
+        finally:
+            if threads is None:
+                os.environ.pop("OMP_NUM_THREADS", None)
+            else:
+                os.environ["OMP_NUM_THREADS"] = threads
         for p in procs:
             p.join(180)
             assert p.exitcode == 0

@@ -265,7 +265,9 @@ def _free_port():
 
 
 # (4, 4200, 128): 33 block columns over 4 ranks in snake order - every rank is the root of several broadcasts (roots != 0)
-@pytest.mark.parametrize("world,n,block", [(2, 1500, 128), (3, 2100, 256), (2, 2048, 512), (4, 4200, 128)])
+# (8, 4200, 128) / (8, 2100, 256): the world size of the node (8 processes sharing this box's one GPU)
+@pytest.mark.parametrize("world,n,block", [(2, 1500, 128), (3, 2100, 256), (2, 2048, 512), (4, 4200, 128), (8, 4200, 128),
+                                           (8, 2100, 256)])
 def test_sharded_fit_two_processes_one_gpu(world, n, block):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
@@ -477,6 +479,9 @@ def test_bench_falls_back_to_replicas_when_the_sharded_fit_fails_its_check():
     """one rank's self-check of the sharded fit "fails" (test hook): every rank agrees over gloo to measure independent fits
     instead, and the line says so - weak scaling, FALLBACK in the parallelism string, the reason recorded."""
     rc, line, err = _run_bench({"BENCH_TEST_SHARDED_FAILURE": "1"})
+    assert rc == 5 and line is not None, err[-2000:]  # the labelled line is printed, but the run is not green
+    assert line["scaling"] == "weak" and line["config"]["parallelism"].startswith("FALLBACK")
+    rc, line, err = _run_bench({"BENCH_TEST_SHARDED_FAILURE": "1"}, "--allow-fallback")
     assert rc == 0 and line is not None, err[-2000:]
     assert line["scaling"] == "weak" and line["config"]["parallelism"].startswith("FALLBACK")
     assert "failed" in line["sharded_fallback"] and line["self_check"]["ok"]
