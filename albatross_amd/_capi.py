@@ -126,6 +126,7 @@ EXPORTS = [
     ("agp_comm_unique_id", C.c_int, [_P]),
     ("agp_comm_create", C.c_int, [_P, C.c_int, C.c_int, _P, _PP]),
     ("agp_comm_create_callbacks", C.c_int, [C.c_int, C.c_int, _P, _PP]),
+    ("agp_comm_create_ipc", C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, _PP]),
     ("agp_comm_destroy", None, [_P]),
     ("agp_comm_size", C.c_int, [_P]),
     ("agp_comm_rank", C.c_int, [_P]),

@@ -145,6 +145,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->d_zpub) (void)hipFree(ctx->d_zpub);
   if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
   if (ctx->d_merge_cnt) (void)hipFree(ctx->d_merge_cnt);
+  if (ctx->shard_flags) (void)hipFree(ctx->shard_flags);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
@@ -159,6 +160,7 @@ void agp_context_destroy(agp_context *c) {
   for (int i = 0; i < 2; ++i)
     if (ctx->ev_step[i]) (void)hipEventDestroy(ctx->ev_step[i]);
   if (ctx->stream_masked) (void)hipStreamDestroy(ctx->stream_masked);
+  if (ctx->stream_comm) (void)hipStreamDestroy(ctx->stream_comm);
   if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
   delete ctx;
 }

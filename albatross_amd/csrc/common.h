@@ -129,6 +129,15 @@ struct agp_context {
   long long bs_BW = 0, bs_done = 0;
   hipEvent_t ev_inv = nullptr;
   const double *img_ready = nullptr;
+  // sharded fit, device-side pacing (shard_hip.hip: HipShardOps): one flag per schedule event + probe flags in device
+  // memory, their sequence numbers (monotonic over the life of the context), and the pacing mode (-1: not decided yet)
+  hipStream_t stream_comm = nullptr;  // queue of the collectives (created by the first sharded call)
+  unsigned long long *shard_flags = nullptr;
+  unsigned long long shard_seq[16] = {};
+  unsigned long long shard_probe_seq = 0;
+  int shard_host_pacing = -1;
+  int shard_hybrid = 0;
+  bool shard_probe_ok = false;
 };
 
 struct agp_fit {

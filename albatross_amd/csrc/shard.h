@@ -17,6 +17,10 @@
 namespace agp {
 
 constexpr long long SHARD_IMG = 36 * 16 * 16;  // tile image of one 128 x 128 diagonal block (chol.hip)
+// Back substitution: SHARD_SUPER consecutive row blocks form a SUPER-BLOCK (2048 rows at 512-row blocks).  Every rank keeps
+// the diagonal super-blocks of L (the broadcast diagonal blocks + the first rows of the gathered panels), solves a
+// super-block redundantly and exchanges ONE all-reduce per super-block instead of one per row block.
+constexpr long long SHARD_SUPER = 4;
 
 struct ShardPlan {
   long long n = 0, B = 512, nb = 0;
@@ -71,6 +75,10 @@ struct ShardPlan {
     }
     return m;
   }
+  // super-blocks of the back substitution
+  long long n_super() const { return (nb + SHARD_SUPER - 1) / SHARD_SUPER; }
+  long long super_end_block(long long sb) const { return (sb + 1) * SHARD_SUPER < nb ? (sb + 1) * SHARD_SUPER : nb; }  // one past its last block
+  long long super_end_row(long long sb) const { return super_end_block(sb) * B < n ? super_end_block(sb) * B : n; }
 };
 
 enum ShardQueue { QP = 0, QB = 1, QC = 2 };  // panel chain (high priority) | bulk updates | collectives
@@ -101,18 +109,25 @@ struct ShardOps {
   virtual void pack_msg(int q, double *msg, long long B, const double *D, long long ld, long long w, const double *img,
                         const double *z);
   virtual void invert_diag(int q, const double *D, long long ld, long long w, const double *img, double *W) = 0;
+  // `count` diagonal blocks of the same width at constant strides (default: one invert_diag each)
+  virtual void invert_diag_batch(int q, const double *D, long long stride_D, long long ld, long long w, const double *img,
+                                 long long stride_img, double *W, long long stride_W, long long count);
   virtual void colvec_dot(int q, const double *W, long long ld, long long m, long long n, const double *v, double alpha,
                           double beta, const double *base, double *out) = 0;
   virtual void axpby(int q, long long n, double a, const double *x, double b, const double *y, double *out) = 0;
   virtual void fill_zero(int q, double *p, long long count) = 0;
+  // record(ev, q): `ev` completes when everything enqueued on q so far has.  wait(q, ev): whatever is enqueued on q
+  // afterwards starts only once the LAST record of `ev` has completed (a no-op if it was never recorded).  How is the
+  // backend's business.  HipShardOps: DEVICE pacing - a one-thread kernel behind the producer stores the record's
+  // sequence number to a flag in device memory, a one-wave kernel in front of the consumer polls it with a bounded
+  // spin: the host enqueues the whole factorisation ahead, no stream ever sits at a hipStreamWaitEvent (on this GPU a
+  // stream blocked there slows the dependent launches of every OTHER stream: 121 instead of 44 us per 128 columns of
+  // the panel chain, scripts/probe_chain.py) and no host thread spins on hipEventQuery in the data path.  Fallback
+  // (HOST pacing, when the queues turn out to share a hardware queue): the round-3 scheme - the panel chain waits with
+  // hipStreamWaitEvent, the collectives and bulk queues are fed by the host once their inputs are ready.
+  // Returns AGP_OK, AGP_ERR_COMM after the transport's timeout (host pacing), AGP_ERR_HIP on a device error.
   virtual void record(int ev, int q) { (void)ev; (void)q; }
-  virtual void wait(int q, int ev) { (void)q; (void)ev; }
-  // The HOST waits until the last record of `ev` has completed.  Used instead of wait(q, ev) where the queue would
-  // otherwise sit at an unsatisfied wait for long: on this GPU a stream blocked in hipStreamWaitEvent slows the
-  // dependent launches of every other stream (121 instead of 44 us per 128 columns of the panel chain, measured with
-  // scripts/probe_chain.py), so the collectives and bulk queues are fed only when their inputs are ready.
-  // AGP_OK, AGP_ERR_COMM after the transport's timeout (a stalled peer or stream), AGP_ERR_HIP on a device error
-  virtual int host_wait(int ev) { (void)ev; return AGP_OK; }
+  virtual int wait(int q, int ev) { (void)q; (void)ev; return AGP_OK; }
   // drain every queue; AGP_OK or an error status
   virtual int sync_all() { return AGP_OK; }
   // {sum of log L_ii over this rank's diagonal blocks, 1 + global index of its first non-positive pivot or 0}
@@ -133,17 +148,29 @@ struct ShardComm {
   virtual int all_reduce(ShardOps &ops, int q, double *buf, long long count, int op) = 0;  // op 0 sum, 1 max
   // a wait of the schedule timed out: the communicator may hold a collective no peer will join - abort, not destroy
   virtual void mark_broken() {}
+  // after the queues have drained: did a device-side wait of the transport give up (AGP_ERR_COMM)?  RCCL and the host
+  // transports report through their return codes and the stream deadlines: AGP_OK.
+  virtual int check_health() { return AGP_OK; }
 };
 
 // scratch of the schedule, carved out of one allocation of shard_work_doubles(plan) doubles
 struct ShardBuffers {
-  double *msg[2] = {nullptr, nullptr};   // [L_kk (B x B, ld = B) | 4 tile images | z_k (B)]
+  // One message slot per block column: [L_kk (w x w, ld = w) | 4 tile images | z_k (B)].  Several ranks: EVERY slot is
+  // kept (77 MB at N = 16384) - after the factorisation each rank holds all diagonal blocks, their images and all of z,
+  // which is what the replicated back substitution needs.  One rank: two slots, used alternately.
+  double *msgs = nullptr;
+  long long msg_stride = 0, msg_slots = 0;
+  double *msg(long long k) const { return msgs + (k % msg_slots) * msg_stride; }
   double *img_local = nullptr;           // tile images of the own diagonal blocks
-  double *W = nullptr;                   // inverses of the own diagonal blocks (B x B each)
+  double *W = nullptr;                   // inverses of the diagonal blocks (B x B each): the own ones (one rank) / all nb
+  // several ranks: per block column k the rows of L below its diagonal block INSIDE its super-block,
+  // ((SHARD_SUPER - 1) B) x B at leading dimension ld_lcol, copied from the gathered panel
+  double *lcol = nullptr;
+  long long ld_lcol = 0;
   double *send = nullptr, *recv = nullptr;
   double *pall[2] = {nullptr, nullptr};
   long long ldp = 0;
-  double *t = nullptr, *xfull = nullptr, *tmp = nullptr, *stat = nullptr;
+  double *t = nullptr, *xfull = nullptr, *tmp = nullptr, *stat = nullptr;  // stat: 2 + 2 * world doubles
 };
 bool shard_force_comm();  // AGP_SHARD_FORCE_COMM=1
 long long shard_msg_doubles(const ShardPlan &plan);

@@ -74,7 +74,7 @@ static RcclApi *rccl_api() {
   return &api;
 }
 
-static double comm_timeout_seconds() {
+double comm_timeout_seconds() {
   static double t = -1.;
   if (t < 0.) {
     const char *e = getenv("AGP_COMM_TIMEOUT_S");
@@ -200,6 +200,56 @@ __global__ __launch_bounds__(256) void shard_pack_msg_kernel(double *__restrict_
   if (i < w) msg[B * B + 4 * SHARD_IMG + i] = z[i];
 }
 
+// ---- device-side pacing (shard.h: ShardOps::record / wait) ----
+// record: ONE thread stores the record's sequence number behind everything enqueued on its stream so far (the kernel
+// boundary before it has made the producers' writes visible device-wide; the store is a device-scope release).
+__global__ void shard_signal_kernel(unsigned long long *flag, unsigned long long value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait: one wave polls the flag until it has reached `need` (sequence numbers only grow) and ends; what follows on its
+// stream starts behind it.  The spin is bounded (s_memrealtime ticks at 100 MHz): a producer that never comes - a dead
+// peer inside a collective - raises *timeout_flag and lets the stream run on, so that the host's own deadline turns the
+// fit into AGP_ERR_COMM instead of a hung GPU.
+__global__ void shard_gate_kernel(const unsigned long long *flag, unsigned long long need, unsigned long long timeout_ticks,
+                                  int *timeout_flag) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(8);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+      if (timeout_flag) atomicExch(timeout_flag, 1);
+      return;
+    }
+  }
+}
+
+// Consecutive records / waits on one stream travel as ONE launch: up to SHARD_MICRO_MAX operations executed in order by one
+// thread (a dependent launch costs 2-5 us on its stream, more next to a bulk update that fills the chip).
+constexpr int SHARD_MICRO_MAX = 6;
+struct ShardMicroOps {
+  unsigned long long *flag[SHARD_MICRO_MAX];
+  unsigned long long value[SHARD_MICRO_MAX];
+  int wait[SHARD_MICRO_MAX];  // 1: spin until *flag >= value, 0: store value
+  int count;
+};
+__global__ void shard_micro_kernel(ShardMicroOps ops, unsigned long long timeout_ticks, int *timeout_flag) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < ops.count; ++i) {
+    if (!ops.wait[i]) {
+      __hip_atomic_store(ops.flag[i], ops.value[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    while (__hip_atomic_load(ops.flag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < ops.value[i]) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+        if (timeout_flag) atomicExch(timeout_flag, 1);
+        return;  // (the stores behind a wait that gave up are not made: their consumers run into their own deadline)
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void shard_add_diag_kernel(double *A, long long ld, long long lrow0, long long gcol0, long long w,
                                                             const double *yvar) {
   const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -228,6 +278,13 @@ struct HipShardOps : ShardOps {
   hipEvent_t ev[EV_COUNT];
   bool ok = true;
   double timeout_s;
+  // DEVICE pacing (default): one flag per event in device memory, sequence numbers that only grow (they live in the
+  // context and continue from fit to fit: nothing to reset).  HOST pacing: HIP events (AGP_SHARD_HOST_PACING=1, or the
+  // probe below found two of the queues sharing a hardware queue).
+  bool device_pacing = true;
+  bool hybrid = false;  // device pacing, but the panel chain waits with hipStreamWaitEvent (no gate kernels on it)
+  unsigned long long *flags = nullptr;  // ctx->shard_flags: [EV_COUNT] events | [EV_COUNT ..] probe
+  unsigned long long timeout_ticks = 0;
   // bulk-update timing (profiling only)
   std::vector<hipEvent_t> tev;
   std::vector<double> tflop;
@@ -236,22 +293,94 @@ struct HipShardOps : ShardOps {
   explicit HipShardOps(agp_context_impl *c) : ctx(c), timeout_s(comm_timeout_seconds()) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    ok = hipStreamCreateWithPriority(&own_comm_stream, hipStreamNonBlocking, hi) == hipSuccess;
-    sq[QP] = ctx->stream; sq[QB] = ctx->stream2; sq[QC] = own_comm_stream;
-    for (auto &e : ev) {
-      e = nullptr;
-      ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    // the collectives' queue: created with the first sharded call of the context and kept (creating and destroying a
+    // stream costs ~0.4 ms per fit); AGP_SHARD_OWN_STREAM=1: one per call, the round-3 behaviour
+    static const bool per_call = [] { const char *e = getenv("AGP_SHARD_OWN_STREAM"); return e && e[0] == '1'; }();
+    if (per_call) {
+      ok = hipStreamCreateWithPriority(&own_comm_stream, hipStreamNonBlocking, hi) == hipSuccess;
+      sq[QC] = own_comm_stream;
+    } else {
+      if (!ctx->stream_comm) ok = hipStreamCreateWithPriority(&ctx->stream_comm, hipStreamNonBlocking, hi) == hipSuccess;
+      sq[QC] = ctx->stream_comm;
     }
+    sq[QP] = ctx->stream; sq[QB] = ctx->stream2;
+    for (auto &e : ev) e = nullptr;
+    timeout_ticks = (unsigned long long)(timeout_s * 1e8);
+    if (ctx->shard_host_pacing < 0) {
+      const char *e = getenv("AGP_SHARD_HOST_PACING");
+      ctx->shard_host_pacing = (e && e[0] == '1') ? 1 : 0;
+      const char *h = getenv("AGP_SHARD_HYBRID_PACING");
+      ctx->shard_hybrid = (h && h[0] == '1') ? 1 : 0;
+    }
+    hybrid = ctx->shard_hybrid == 1;
+    device_pacing = ok && ctx->shard_host_pacing == 0;
+    if (device_pacing) {
+      if (!ctx->shard_flags) {
+        if (hipMalloc(&ctx->shard_flags, sizeof(unsigned long long) * 2 * EV_COUNT) != hipSuccess ||
+            hipMemset(ctx->shard_flags, 0, sizeof(unsigned long long) * 2 * EV_COUNT) != hipSuccess) {
+          (void)hipGetLastError();
+          if (ctx->shard_flags) (void)hipFree(ctx->shard_flags);
+          ctx->shard_flags = nullptr;
+        }
+      }
+      flags = ctx->shard_flags;
+      device_pacing = flags != nullptr;
+    }
+  }
+  // first record / wait of this object: settle the pacing mode (entry points that only borrow the queues never pay for it)
+  bool decided = false;
+  void decide() {
+    if (decided) return;
+    decided = true;
+    if (device_pacing && !(ctx->shard_probe_ok && !own_comm_stream)) {
+      device_pacing = probe_queues();
+      if (!own_comm_stream) {  // the queues are the context's own: the answer holds for its lifetime
+        if (device_pacing) ctx->shard_probe_ok = true;
+        else ctx->shard_host_pacing = 1;
+      }
+    }
+    if (!device_pacing || hybrid)
+      for (auto &e : ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   }
   ~HipShardOps() override {
     for (auto e : ev) if (e) (void)hipEventDestroy(e);
     for (auto e : tev) (void)hipEventDestroy(e);
+    if (ev_switch) (void)hipEventDestroy(ev_switch);
     if (own_comm_stream) (void)hipStreamDestroy(own_comm_stream);
   }
-  void *stream(int q) override { return sq[q]; }
+  // A gate kernel must never sit in FRONT of its producer in a hardware queue: the runtime maps HIP streams onto a few
+  // hardware queues (GPU_MAX_HW_QUEUES) and serialises streams that share one.  One round of gates and signals between
+  // every pair of queues the schedule pairs up, with a short deadline: if any gate runs into it, the queues alias and
+  // this fit is paced by the host.  ~40 us when all is well.
+  bool probe_queues() {
+    unsigned long long *pf = flags + EV_COUNT;
+    int *fail = ctx->d_flags + 3;
+    unsigned long long &seq = ctx->shard_probe_seq;
+    const unsigned long long short_ticks = 25000000ull;  // 250 ms (processes that share the GPU are time-sliced)
+    (void)hipMemsetAsync(fail, 0, sizeof(int), sq[QC]);
+    if (hipStreamSynchronize(sq[QC]) != hipSuccess) return false;
+    const int pairs[4][2] = {{QC, QP}, {QC, QB}, {QP, QC}, {QB, QC}};  // {consumer, producer}
+    for (int i = 0; i < 4; ++i) {
+      ++seq;
+      hipLaunchKernelGGL(shard_gate_kernel, dim3(1), dim3(64), 0, sq[pairs[i][0]], pf + i, seq, short_ticks, fail);
+      hipLaunchKernelGGL(shard_signal_kernel, dim3(1), dim3(1), 0, sq[pairs[i][1]], pf + i, seq);
+    }
+    int h = 1;
+    bool fine = true;
+    for (int q = 0; q < 3; ++q) fine = fine && hipStreamSynchronize(sq[q]) == hipSuccess;
+    fine = fine && hipMemcpy(&h, fail, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && h == 0;
+    if (!fine) {
+      (void)hipGetLastError();
+      (void)hipMemset(fail, 0, sizeof(int));
+    }
+    return fine;
+  }
+  void *stream(int q) override {
+    flush(q); return sq[q]; }
   bool device_memory() const override { return true; }
 
   void factor_diag(int q, double *D, long long ld, long long w, long long pivot_base, double *img, double *zblk) override {
+    flush(q);
     // the panel phase of the single-GPU factorisation on the w x w block alone; the pointers are shifted so that the
     // block sits at row / column `pivot_base` and a non-positive pivot is reported with its GLOBAL index
     panel_phase_public(ctx, sq[q], D - pivot_base * (ld + 1), pivot_base + w, ld, img - (pivot_base / NB) * (long long)SHARD_IMG,
@@ -259,10 +388,12 @@ struct HipShardOps : ShardOps {
   }
   void trsm_rows(int q, double *X, long long ld, long long nrows, long long w, const double *Lkk, const double *img,
                  const double *z, double *yrows) override {
+    flush(q);
     trsm_rows_wide(sq[q], X, ld, nrows, w, Lkk, w, img, z, yrows);
   }
   void gemm(int q, double *C, long long ldc, const double *P, long long ldp, const double *Q, long long ldq, long long M,
             long long N, long long K, bool tri, int bulk) override {
+    flush(q);
     if (M <= 0 || N <= 0 || K <= 0) return;
     hipStream_t s = sq[q];
     const bool timed = bulk && ctx->profiling;
@@ -296,7 +427,28 @@ struct HipShardOps : ShardOps {
       tused += 2;
     }
   }
+  // Chain-bound phase: the bulk update moves to the context's CU-MASKED stream (224 of 256 CUs, api.hip).  A bulk update
+  // that fills every CU holds all VGPRs and LDS: every kernel of the panel chain - and every record / wait launch -
+  // then waits ~50 us for a workgroup of it to retire before it can start (profiles/r04/timeline_sharded_rccl1_dev.txt:
+  // each small kernel 54 us), which is what made the chain 3x slower next to a full-size update.  With 4 CUs per XCD
+  // left free they start at once.  The update is chain-bound once (remaining rows)^2 / world <= 8704^2 (chol.hip:
+  // mask_below is the single-GPU point); the switch happens once per fit, ordered by one event.
+  bool bulk_masked = false;
+  hipEvent_t ev_switch = nullptr;
+  void maybe_switch_bulk_queue(const ShardPlan &plan, long long k) {
+    if (bulk_masked || !ctx->stream_masked) return;
+    const double remaining = (double)(plan.n - (k + 2) * plan.B);
+    if (remaining * remaining > 8704. * 8704. * (double)plan.world) return;
+    flush(QB);
+    if (!ev_switch && hipEventCreateWithFlags(&ev_switch, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+    (void)hipEventRecord(ev_switch, sq[QB]);
+    (void)hipStreamWaitEvent(ctx->stream_masked, ev_switch, 0);
+    sq[QB] = ctx->stream_masked;
+    bulk_masked = true;
+  }
   void update_staircase(int q, double *A, long long ld, const double *Q, long long ldq, const ShardPlan &plan, long long k) override {
+    if (q == QB) maybe_switch_bulk_queue(plan, k);
+    flush(q);
     // ONE launch over all own row blocks >= k + 2: the tiles right of a row block's own diagonal tile exit at once
     const long long B = plan.B, li2 = plan.first_local_after(plan.rank, k + 1);
     const long long M = plan.local_rows(plan.rank) - li2 * B, c0 = (k + 2) * B, N = plan.n - c0, K = plan.width(k);
@@ -326,17 +478,20 @@ struct HipShardOps : ShardOps {
     }
   }
   void copy2d(int q, double *dst, long long ldd, const double *src, long long lds, long long rows, long long cols) override {
+    flush(q);
     if (rows <= 0 || cols <= 0) return;
     const unsigned gy = (unsigned)(cols < 256 ? cols : 256);
     hipLaunchKernelGGL(shard_copy2d_kernel, dim3((unsigned)((rows + 255) / 256), gy), dim3(256), 0, sq[q], dst, ldd, src, lds, rows, cols);
   }
   void pack_msg(int q, double *msg, long long B, const double *D, long long ld, long long w, const double *img,
                 const double *z) override {
+    flush(q);
     const long long count = w * w > 4 * SHARD_IMG ? w * w : 4 * SHARD_IMG;
     hipLaunchKernelGGL(shard_pack_msg_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, sq[q], msg, B, D, ld, w, img, z);
   }
   void gather_panel(int q, double *Pall, long long ldP, const double *recv, long long cnt_rows, long long w, const ShardPlan &plan,
                     long long k) override {
+    flush(q);
     const long long rows = plan.n - (k + 1) * plan.B;
     if (rows <= 0) return;
     const unsigned gy = (unsigned)(w < 128 ? w : 128);
@@ -344,20 +499,30 @@ struct HipShardOps : ShardOps {
                        plan.n, plan.B, plan.world, k);
   }
   void invert_diag(int q, const double *D, long long ld, long long w, const double *img, double *W) override {
+    flush(q);
     launch_set_identity_batched(sq[q], W, w, w * w, w, 1);
     forward_solve_mat_batched(sq[q], D, 0, w, ld, img, 0, W, 0, w, w, /*rhs_lower=*/true, 1);
   }
+  void invert_diag_batch(int q, const double *D, long long stride_D, long long ld, long long w, const double *img,
+                         long long stride_img, double *W, long long stride_W, long long count) override {
+    flush(q);
+    launch_set_identity_batched(sq[q], W, w, stride_W, w, count);
+    forward_solve_mat_batched(sq[q], D, stride_D, w, ld, img, stride_img, W, stride_W, w, w, /*rhs_lower=*/true, count);
+  }
   void colvec_dot(int q, const double *W, long long ld, long long m, long long n, const double *v, double alpha, double beta,
                   const double *base, double *out) override {
+    flush(q);
     launch_colvec_dot(sq[q], W, ld, m, n, v, alpha, beta, base, out);
   }
   void axpby(int q, long long n, double a, const double *x, double b, const double *y, double *out) override {
+    flush(q);
     launch_axpby(sq[q], n, a, x, b, y, out);
   }
   void fill_zero(int q, double *p, long long count) override {
+    flush(q);
     if (count > 0) (void)hipMemsetAsync(p, 0, sizeof(double) * (size_t)count, sq[q]);
   }
-  int host_wait(int e) override {
+  int host_spin(int e) {
     const auto t0 = std::chrono::steady_clock::now();
     long long spins = 0;
     while (true) {
@@ -373,9 +538,54 @@ struct HipShardOps : ShardOps {
       }
     }
   }
-  void record(int e, int q) override { (void)hipEventRecord(ev[e], sq[q]); }
-  void wait(int q, int e) override { (void)hipStreamWaitEvent(sq[q], ev[e], 0); }
+  void record(int e, int q) override {
+    decide();
+    if (device_pacing) {
+      push(q, flags + e, ++ctx->shard_seq[e], 0);
+      recorded[e] = true;
+      record_queue[e] = q;
+      if (hybrid) { flush(q); (void)hipEventRecord(ev[e], sq[q]); }
+    } else {
+      (void)hipEventRecord(ev[e], sq[q]);
+    }
+  }
+  int wait(int q, int e) override {
+    decide();
+    if (device_pacing) {
+      if (hybrid && q == QP) {
+        if (recorded[e]) { flush(q); (void)hipStreamWaitEvent(sq[q], ev[e], 0); }
+        return AGP_OK;
+      }
+      if (recorded[e]) {  // (never recorded by this fit: nothing to wait for, like hipStreamWaitEvent)
+        // the record must be ON its stream before anything can wait for it: a host-synchronous transport (callbacks)
+        // drains the waiting queue before the host returns to flush the producer's
+        if (record_queue[e] != q) flush(record_queue[e]);
+        push(q, flags + e, ctx->shard_seq[e], 1);
+      }
+      return AGP_OK;
+    }
+    // host pacing: the panel chain may sit at a stream wait, the other queues are fed once their inputs are ready
+    if (q == QP) { (void)hipStreamWaitEvent(sq[q], ev[e], 0); return AGP_OK; }
+    return host_spin(e);
+  }
+  bool recorded[EV_COUNT] = {};
+  int record_queue[EV_COUNT] = {};
+  ShardMicroOps pending[3] = {};
+  void push(int q, unsigned long long *flag, unsigned long long value, int is_wait) {
+    ShardMicroOps &m = pending[q];
+    if (m.count == SHARD_MICRO_MAX) flush(q);
+    m.flag[m.count] = flag; m.value[m.count] = value; m.wait[m.count] = is_wait;
+    ++m.count;
+  }
+  // launch the records / waits collected for queue q (before anything else is enqueued on it)
+  void flush(int q) {
+    ShardMicroOps &m = pending[q];
+    if (m.count == 0) return;
+    hipLaunchKernelGGL(shard_micro_kernel, dim3(1), dim3(64), 0, sq[q], m, timeout_ticks, ctx->d_flags + 3);
+    m.count = 0;
+  }
   int sync_all() override {
+    for (int q = 0; q < 3; ++q) flush(q);
     for (int q = 0; q < 3; ++q) {
       const int st = wait_stream(ctx, sq[q], timeout_s);
       if (st != AGP_OK) return st;
@@ -392,13 +602,17 @@ struct HipShardOps : ShardOps {
     out[0] = scal[0];
     out[1] = (double)flags[1];
     handover_timeout = flags[2] != 0;
+    gate_timeout = flags[3] != 0;
   }
+  bool gate_timeout = false;      // a wait of the device-paced schedule ran into the transport's deadline
   bool handover_timeout = false;  // a consumer of the fused panel kernel gave up waiting (chol.hip): the factor is garbage
   int to_host(int q, const double *dev, double *host, long long count) override {
+    flush(q);
     if (hipMemcpyAsync(host, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, sq[q]) != hipSuccess) return AGP_ERR_HIP;
     return wait_stream(ctx, sq[q], timeout_s);
   }
   int from_host(int q, const double *host, double *dev, long long count) override {
+    flush(q);
     if (hipMemcpyAsync(dev, host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, sq[q]) != hipSuccess) return AGP_ERR_HIP;
     return wait_stream(ctx, sq[q], timeout_s);  // pageable source: must be consumed before the caller reuses it
   }
@@ -442,7 +656,8 @@ int comm_all_reduce_device(agp_context *ctx, agp_comm *comm, double *dev, long l
   if (st != AGP_OK) return st;
   // the caller goes on with calls that synchronise the stream without a deadline (factorisations, stage timers): find a
   // collective that a dead peer never joins HERE, where it becomes AGP_ERR_COMM
-  return wait_stream(ctx, ctx->stream, comm_timeout_seconds());
+  const int sw = wait_stream(ctx, ctx->stream, comm_timeout_seconds());
+  return sw != AGP_OK ? sw : comm->impl->check_health();
 }
 
 int comm_wait_stream(agp_context *ctx, hipStream_t s) { return wait_stream(ctx, s, comm_timeout_seconds()); }
@@ -712,6 +927,11 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
       ctx->last_error = "panel kernel: hand-over of a diagonal block timed out";
       st = AGP_ERR_HIP;
     }
+    if (ops.gate_timeout && (st == AGP_OK || st == AGP_ERR_NOT_POSITIVE_DEFINITE)) {
+      ctx->last_error = "sharded schedule: a queue waited for another (or for a collective) past the transport's deadline";
+      st = AGP_ERR_COMM;
+    }
+    f->stage[2] = ops.device_pacing ? (ops.hybrid ? 2. : 1.) : 0.;
     f->stage[6] = res.enqueue_factor_ms + res.enqueue_solve_ms;
     f->stage[7] = res.total_ms;
     if (ctx->profiling) {
@@ -838,6 +1058,7 @@ int agp_sharded_predict_marginal(agp_context *c, const agp_kernel *k, agp_sharde
       if (st == AGP_OK) launch_axpby(s, m, 1.0, prior, 1.0, acc, prior);  // k** - sum over all ranks
     }
     if (st == AGP_OK) st = wait_stream(ctx, s, comm_timeout_seconds());
+    if (st == AGP_OK && tr) st = tr->check_health();
     if (st == AGP_OK) st = copy_out(ctx, mean_d, m, mean + o, out_location);
     if (st == AGP_OK) st = copy_out(ctx, prior, m, variance + o, out_location);
   }
@@ -911,6 +1132,7 @@ int agp_sharded_fit_replicate(agp_context *c, agp_sharded_fit *f, agp_fit **out)
       }
       (void)hipMemcpyAsync(fit->alpha, f->buf.xfull, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
       st = ops.sync_all();
+      if (st == AGP_OK && tr) st = tr->check_health();
     }
   }
   if (stacks && stacks != f->A) (void)hipFree(stacks);

@@ -80,10 +80,8 @@ class Communicator:
         c._ctx = ctx  # the RCCL transport dereferences its context until it is destroyed: keep it alive, and see close()
         return c
 
-    @classmethod
-    def callbacks(cls, world, rank, broadcast, all_gather, all_reduce):
-        """broadcast(buf: ndarray, root), all_gather(send: ndarray, recv: ndarray), all_reduce(buf: ndarray, op: 0 sum |
-        1 max): Python callables working IN PLACE on float64 arrays"""
+    @staticmethod
+    def _callback_struct(world, broadcast, all_gather, all_reduce):
         def view(ptr, count):
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(int(count),))
 
@@ -102,15 +100,21 @@ class Communicator:
         g = capi.ALL_GATHER_FN(guard(lambda user, send, recv, count: all_gather(view(send, count), view(recv, count * world))))
         r = capi.ALL_REDUCE_FN(guard(lambda user, buf, count, op: all_reduce(view(buf, count), int(op))))
         cbs = capi.CommCallbacks(None, b, g, r)
+        return cbs, (b, g, r, cbs)
+
+    @classmethod
+    def callbacks(cls, world, rank, broadcast, all_gather, all_reduce):
+        """broadcast(buf: ndarray, root), all_gather(send: ndarray, recv: ndarray), all_reduce(buf: ndarray, op: 0 sum |
+        1 max): Python callables working IN PLACE on float64 arrays"""
+        cbs, keep = cls._callback_struct(world, broadcast, all_gather, all_reduce)
         h = C.c_void_p()
         st = capi.load().agp_comm_create_callbacks(world, rank, C.byref(cbs), C.byref(h))
         if st != capi.AGP_OK:
             raise RuntimeError(f"agp_comm_create_callbacks failed ({st})")
-        return cls(h, keepalive=(b, g, r, cbs))
+        return cls(h, keepalive=keep)
 
-    @classmethod
-    def torch_callbacks(cls, group=None):
-        """collectives of an initialised torch.distributed process group on CPU tensors (gloo)"""
+    @staticmethod
+    def _torch_collectives(group=None):
         import torch
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -126,16 +130,37 @@ class Communicator:
         def all_reduce(buf, op):
             dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=group)
 
-        return cls.callbacks(world, rank, broadcast, all_gather, all_reduce)
+        return world, rank, broadcast, all_gather, all_reduce
+
+    @classmethod
+    def torch_callbacks(cls, group=None):
+        """collectives of an initialised torch.distributed process group on CPU tensors (gloo)"""
+        return cls.callbacks(*cls._torch_collectives(group))
+
+    @classmethod
+    def ipc(cls, ctx, group=None, mailbox_doubles=0):
+        """agp_comm_create_ipc: the device-asynchronous transport between processes sharing ONE GPU (peer stores through
+        hipIpc mailboxes + stream-ordered flags; csrc/shard_ipc.hip).  The torch group (gloo) only carries the IPC
+        handles and the control plane.  Collective."""
+        world, rank, broadcast, all_gather, all_reduce = cls._torch_collectives(group)
+        cbs, keep = cls._callback_struct(world, broadcast, all_gather, all_reduce)
+        h = C.c_void_p()
+        ctx._check(ctx._lib.agp_comm_create_ipc(ctx._h, world, rank, C.byref(cbs), int(mailbox_doubles), C.byref(h)), "agp_comm_create_ipc")
+        c = cls(h, keepalive=keep)
+        c._ctx = ctx
+        return c
 
     @classmethod
     def from_torch(cls, ctx, group=None, transport="rccl"):
         """One communicator over the ranks of an initialised torch.distributed group.  transport="rccl": the library's
         own RCCL communicator (the unique id is broadcast over the torch group, whatever its backend);
-        "callbacks": the torch group's collectives on host arrays."""
+        "callbacks": the torch group's collectives on host arrays; "ipc": device-asynchronous
+        peer stores between processes on one GPU (tests)."""
         import torch.distributed as dist
         if transport == "callbacks":
             return cls.torch_callbacks(group)
+        if transport == "ipc":
+            return cls.ipc(ctx, group)
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         box = [cls.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=(dist.get_global_rank(group, 0) if group is not None else 0), group=group)

@@ -472,6 +472,16 @@ typedef struct {
   int (*all_reduce)(void *user, double *buf, int64_t count, int op);
 } agp_comm_callbacks;
 AGP_API int agp_comm_create_callbacks(int nranks, int rank, const agp_comm_callbacks *cb, agp_comm **out);
+/* A DEVICE-ASYNCHRONOUS transport between processes that share ONE GPU (csrc/shard_ipc.hip): every collective is a few
+ * kernels on the caller's stream - stores into the peers' mailboxes (hipIpcOpenMemHandle), stream-ordered flags, bounded
+ * spins - and the host returns at once, as with RCCL.  For exercising the asynchronous multi-rank schedule on a one-GPU
+ * box (RCCL refuses two ranks per device; the callback transport is host-synchronous); RCCL remains the transport of
+ * real multi-GPU runs.  `bootstrap`: host collectives (all_gather, all_reduce) that carry the 64-byte IPC handles at
+ * creation and serve agp_comm_all_reduce_host / agp_comm_barrier afterwards; it must outlive the communicator.
+ * mailbox_doubles: capacity of one of the two mailbox slots (0: 8 Mi doubles); larger messages travel in pieces.
+ * nranks <= 16; needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of every rank.  Collective (also the destroy). */
+AGP_API int agp_comm_create_ipc(agp_context *ctx, int nranks, int rank, const agp_comm_callbacks *bootstrap, int64_t mailbox_doubles,
+                                agp_comm **out);
 AGP_API void agp_comm_destroy(agp_comm *comm);
 AGP_API int agp_comm_size(const agp_comm *comm);
 AGP_API int agp_comm_rank(const agp_comm *comm);

@@ -38,3 +38,17 @@ for n in [int(a) for a in (sys.argv[1:] or ["16384"])]:
                 lib.agp_sharded_fit_stage(h, i, C.byref(stage[i]))
             lib.agp_sharded_fit_destroy(h)
         print(f"N={n} world={world} rank={rank}: {1e3*min(times[1:]):.1f} ms per call (gram {stage[0].value:.2f} ms, factor+solve {stage[1].value:.1f} ms; host enqueue {stage[6].value:.1f} of {stage[7].value:.1f} ms)", flush=True)
+
+# a plain single-GPU fit AFTER the sharded calls (the collectives' queue of the context now exists: does it disturb the
+# stream-to-hardware-queue mapping of the plain fit?  DESIGN.md section 8, "a fourth stream")
+os.environ.pop("AGP_SHARD_FAKE_WORLD", None)
+model = ab.gp_from_covariance(cov, context=ctx)
+x, y = make_dataset(16384, 44)
+ds = ab.RegressionDataset(x, y)
+ts = []
+for _ in range(4):
+    t0 = time.perf_counter()
+    fm = model.fit(ds)
+    ts.append(time.perf_counter() - t0)
+    del fm
+print(f"plain agp_fit_create N=16384 afterwards: {1e3 * min(ts[1:]):.1f} ms", flush=True)

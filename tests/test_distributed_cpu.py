@@ -172,5 +172,8 @@ def test_single_rank_through_the_multi_rank_schedule(monkeypatch):
     assert st == capi.AGP_OK
     assert np.abs(info - ofit.information).max() <= 1e-9 * np.abs(ofit.information).max()
     nb = (n + block - 1) // block
-    assert seen["broadcast"] == nb and seen["all_gather"] == nb - 1 and seen["all_reduce"] >= nb + 1
+    nsb = (nb + 3) // 4  # super-blocks of the back substitution (csrc/shard.h: SHARD_SUPER)
+    # per block column one broadcast and (but for the last) one all-gather; the back substitution exchanges ONE all-reduce
+    # per super-block but the last; log-determinant and bad pivot travel in one more all-gather
+    assert seen["broadcast"] == nb and seen["all_gather"] == nb - 1 + 1 and seen["all_reduce"] == nsb - 1
     comm.close()

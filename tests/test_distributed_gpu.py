@@ -222,21 +222,31 @@ def test_sharded_fit_rccl_one_rank_per_gpu(n, block):
         _check_against_oracle(out, world, n, expect_bad=False)
 
 
-def _worker(rank, world, port, n, block, out):
+def _worker(rank, world, port, n, block, out, transport="callbacks", env=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["AGP_SHARD_BLOCK"] = str(block)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.update(env or {})
     import torch
     import torch.distributed as dist
     torch.cuda.init()  # torch's HIP runtime first (tests/conftest.py)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ctx = ab.Context(0)  # every rank on THIS box's one GPU
-        comm = Communicator.from_torch(ctx, transport="callbacks")
+        if transport == "ipc_small":  # 64 Ki doubles per mailbox slot: panels, stacks and tile images travel in pieces
+            comm = Communicator.ipc(ctx, mailbox_doubles=1 << 16)
+        else:
+            comm = Communicator.from_torch(ctx, transport=transport)
         x, y, yvar = problem(n)
         cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
         sharded = ShardedGaussianProcessFit(ctx, cov, comm)
         res = sharded.fit(x, y, yvar)
+        if transport != "callbacks":
+            assert sharded.stage(2) == (0. if (env or {}).get("AGP_SHARD_HOST_PACING") == "1" else 1.)  # the pacing that ran
+            res2 = sharded.fit(x, 2. * y, yvar)  # the flags' sequence numbers carry on from fit to fit
+            assert np.abs(res2.information - 2. * res.information).max() <= 1e-12 * np.abs(res.information).max()
+            res = sharded.fit(x, y, yvar)
         fm = sharded.replicate(ab.gp_from_covariance(cov, context=ctx))
         xs = np.random.default_rng(3).uniform(0., 10., (64, 3))
         mine = slice(rank * 64 // world, (rank + 1) * 64 // world)  # this rank's share of the test points
@@ -279,6 +289,31 @@ def test_sharded_fit_two_processes_one_gpu(world, n, block):
             p.start()
         for p in procs:
             p.join(300)
+            assert p.exitcode == 0
+        _check_against_oracle(out, world, n, expect_bad=True)
+
+
+# The asynchronous schedule with asynchronous collectives on ONE GPU (csrc/shard_ipc.hip): every broadcast / all-gather /
+# all-reduce is a few kernels on the collectives' queue writing into the peers' hipIpc mailboxes - the host never waits
+# between the steps, exactly as over RCCL.  Device pacing (flags + gate kernels, the default) and host pacing.
+@pytest.mark.parametrize("world,n,block,transport,pacing", [
+    (2, 1500, 128, "ipc", "device"), (2, 2048, 512, "ipc", "host"), (3, 2100, 256, "ipc_small", "device"),
+    (4, 4200, 128, "ipc", "device"), (4, 2100, 128, "ipc_small", "host"), (8, 4200, 128, "ipc", "device"),
+    (8, 2100, 256, "ipc_small", "device")])
+def test_sharded_fit_async_transport_processes_one_gpu(world, n, block, transport, pacing):
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    env = {"AGP_COMM_TIMEOUT_S": "60"}
+    if pacing == "host":
+        env["AGP_SHARD_HOST_PACING"] = "1"
+    with mpc.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [mpc.Process(target=_worker, args=(r, world, port, n, block, out, transport, env)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(420)
             assert p.exitcode == 0
         _check_against_oracle(out, world, n, expect_bad=True)
 
