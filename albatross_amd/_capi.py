@@ -135,17 +135,14 @@ EXPORTS = [
     ("agp_shard_local_rows", C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
     ("agp_shard_global_row", C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64]),
     ("agp_shard_owner", C.c_int, [C.c_int64, C.c_int]),
-    ("agp_shard_work_doubles", C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
     ("agp_sharded_fit_create", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, _PP, _P, _D]),
     ("agp_sharded_fit_destroy", None, [_P]),
     ("agp_sharded_fit_failed_pivot", C.c_int64, [_P]),
     ("agp_sharded_fit_replicate", C.c_int, [_P, _P, _PP]),
     ("agp_sharded_predict_marginal", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int]),
     ("agp_sharded_fit_stage", C.c_int, [_P, C.c_int, _D]),
-    ("agp_shard_factor_custom", C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P, _D, C.POINTER(C.c_int64)]),
     ("agp_last_stage_ms", C.c_int, [_P, C.c_int, _D]),
     ("agp_set_profiling", C.c_int, [_P, C.c_int]),
-    ("agp_mfma_f64_peak", C.c_int, [_P, C.c_int, _D]),
 ]
 
 COMM_ID_BYTES = 128
@@ -200,6 +197,14 @@ def load_debug():
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build it with `make -C albatross_amd/csrc`")
         _debug_lib = C.CDLL(path)
+        # the test-only entry points with pointer / 64-bit arguments (csrc/debug_api.hip)
+        _debug_lib.agp_debug_shard_work_doubles.restype = C.c_int64
+        _debug_lib.agp_debug_shard_work_doubles.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int]
+        _debug_lib.agp_debug_shard_factor_custom.restype = C.c_int
+        _debug_lib.agp_debug_shard_factor_custom.argtypes = [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P, _D,
+                                                            C.POINTER(C.c_int64)]
+        _debug_lib.agp_debug_comm_create_null.restype = C.c_int
+        _debug_lib.agp_debug_comm_create_null.argtypes = [C.c_int, C.c_int, _PP]
     return _debug_lib
 
 

@@ -43,6 +43,12 @@ using namespace agp;
 static agp_context_ext *ext_of(agp_context *ctx) { return &static_cast<agp_context_impl *>(ctx)->ext; }
 std::atomic<unsigned long long> g_kernel_uid{1};
 
+namespace agp {
+// the Gram launchers have no context: they follow the switches of the context created last
+static bool g_gram_sop = true;
+bool gram_sop_enabled() { return g_gram_sop; }
+}  // namespace agp
+
 extern "C" {
 
 const char *agp_status_string(int status) {
@@ -65,6 +71,28 @@ int agp_device_count(void) {
   return n;
 }
 
+// the switches of include/albatross_amd.h ("switches"): read here, once per context, and nowhere else
+static agp_context::Tuning read_tuning() {
+  agp_context::Tuning t;
+  auto flag = [](const char *name, bool dflt) {
+    const char *e = getenv(name);
+    return e && e[0] ? e[0] == '1' : dflt;
+  };
+  auto number = [](const char *name, long long dflt) {
+    const char *e = getenv(name);
+    return e && e[0] ? atoll(e) : dflt;
+  };
+  t.panel_fused = flag("AGP_PANEL_FUSED", true);
+  t.step_below = number("AGP_STEP_BELOW", 4608);
+  t.gram_sop = flag("AGP_GRAM_SOP", true);
+  t.sparse_pivoted = flag("AGP_SPARSE_PIVOTED", false);
+  t.predict_chunk = number("AGP_PREDICT_CHUNK", 0);
+  t.shard_block = number("AGP_SHARD_BLOCK", 0);
+  t.shard_force_comm = flag("AGP_SHARD_FORCE_COMM", false);
+  t.shard_host_pacing = flag("AGP_SHARD_HOST_PACING", false);
+  return t;
+}
+
 int agp_context_create(int device_id, agp_context **out) {
   if (!out) return AGP_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -74,6 +102,8 @@ int agp_context_create(int device_id, agp_context **out) {
   agp_context_impl *ctx = new (std::nothrow) agp_context_impl();
   if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
   ctx->device = device_id;
+  ctx->tune = read_tuning();
+  agp::g_gram_sop = ctx->tune.gram_sop;
   AGP_HIP_CHECK(ctx, hipSetDevice(device_id));
   {
     // main / panel stream at the highest priority: its short kernels must not
@@ -82,15 +112,10 @@ int agp_context_create(int device_id, agp_context **out) {
     AGP_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi));
     AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo));
-    if (getenv("AGP_NO_STREAM3")) ctx->stream3 = ctx->stream2;  // experiment: one stream fewer for the runtime to map
-    else AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo));
-    // the side chain of the factorisation shares stream3: a FOURTH stream of its own changed how the runtime maps streams
-    // onto its few hardware queues and cost 3.5 ms per N = 16384 fit (33.7 -> 37.2 ms) before it was used at all
-    ctx->stream_side = ctx->stream3;
-    AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
+    // (no further streams in the context: one more high-priority stream changed how the runtime maps streams onto its few
+    // hardware queues and cost 3.5 ms per N = 16384 fit before it was used at all)
+    AGP_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo));
     AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_inv, hipEventDisableTiming));
-    AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_step[0], hipEventDisableTiming));
-    AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_step[1], hipEventDisableTiming));
     AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
     // CU mask of the end-phase bulk stream: bit i = CU i, and CU i sits on XCD i % 8 (measured with
     // scripts/probe_cumask.py: dropping the LAST indices keeps the XCDs balanced, dropping i % 32 >= 28 does not).
@@ -98,9 +123,8 @@ int agp_context_create(int device_id, agp_context **out) {
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
     ctx->cus = cus;
-    int keep = 224;  // scripts/sweep_mask.sh: 224 CUs (28 per XCD) from 8704 remaining rows on is the best pair at N = 16384
-    if (const char *e = getenv("AGP_MASK_CUS")) keep = atoi(e);
-    keep = keep / 8 * 8;
+    // 224 of 256 CUs (28 per XCD) from 8704 remaining rows on is the best pair at N = 16384 (profiles/r02/sweep_mask.txt)
+    const int keep = cus / 8 * 7 / 8 * 8;
     if (keep > 0 && keep < cus) {
       uint32_t mask[16] = {0};
       for (int i = 0; i < keep && i < 512; ++i) mask[i / 32] |= 1u << (i % 32);
@@ -144,7 +168,6 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->ws_aux) (void)hipFree(ctx->ws_aux);
   if (ctx->d_zpub) (void)hipFree(ctx->d_zpub);
   if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
-  if (ctx->d_merge_cnt) (void)hipFree(ctx->d_merge_cnt);
   if (ctx->shard_flags) (void)hipFree(ctx->shard_flags);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -154,11 +177,8 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-  if (ctx->stream3 && ctx->stream3 != ctx->stream2) (void)hipStreamDestroy(ctx->stream3);
-  if (ctx->ev_d) (void)hipEventDestroy(ctx->ev_d);
+  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
   if (ctx->ev_inv) (void)hipEventDestroy(ctx->ev_inv);
-  for (int i = 0; i < 2; ++i)
-    if (ctx->ev_step[i]) (void)hipEventDestroy(ctx->ev_step[i]);
   if (ctx->stream_masked) (void)hipStreamDestroy(ctx->stream_masked);
   if (ctx->stream_comm) (void)hipStreamDestroy(ctx->stream_comm);
   if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
@@ -185,11 +205,6 @@ int agp_last_stage_ms(const agp_context *c, int stage, double *ms) {
   return AGP_OK;
 }
 
-int agp_mfma_f64_peak(agp_context *ctx, int iters, double *tflops) {
-  if (!ctx || !tflops || iters <= 0) return AGP_ERR_INVALID_ARGUMENT;
-  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  return mfma_f64_peak(ctx->stream, iters, tflops);
-}
 
 // ---- covariance function ---------------------------------------------------
 int agp_kernel_create(const agp_kernel_node *postfix, int n_nodes, agp_kernel **out) {
@@ -591,13 +606,8 @@ void agp_fit_destroy(agp_fit *fit) {
 // four fused launches per 128 rows: the chain is launch-latency-bound (AGP_WIDE_BACKSOLVE=0: off, =<width>: other
 // block width).  Otherwise the 128-row chain on 128 x 128 inverses.  ws: backsolve_ws_elems(n) doubles of scratch.
 long long backsolve_width(long long n) {
-  static int wide = -1;
-  if (wide < 0) {
-    const char *e = getenv("AGP_WIDE_BACKSOLVE");
-    wide = e ? atoi(e) : 1;
-  }
-  const long long BW = wide > 1 ? wide : 512;
-  return (wide && n >= 4 * BW && n % BW == 0) ? BW : 0;
+  constexpr long long BW = 512;
+  return (n >= 4 * BW && n % BW == 0) ? BW : 0;
 }
 
 size_t backsolve_ws_elems(long long n) {
@@ -781,7 +791,6 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, Kfull, fit->lda, yvar_d, ctx->d_flags,
                 &k->prog);
     ctx->update_variant = 3;  // fp32-product bulk updates
-    if (const char *e = getenv("AGP_MIXED_NBO")) ctx->nbo_override = atoll(e);  // experiment: fixed outer width
   }
   // The fp64 fit does not wait for the factorisation before it enqueues the backward substitution: one host round trip
   // (~0.1 ms) less; the status is read after the single synchronisation at the end, and a substitution through a factor
@@ -790,7 +799,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   const bool deferred = !mixed && !yvar_d;
   FactorTimers ftimers;
   long long bs_done = 0;
-  if (deferred && backsolve_width(n) && !getenv("AGP_NO_EARLY_INVERSION")) {
+  if (deferred && backsolve_width(n)) {
     // the inverses of the wide diagonal blocks for the backward substitution: computed by factor_lower on its idle
     // second stream while the chain-bound tail of the factorisation runs (common.h: bs_W)
     if (ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * backsolve_ws_elems(n)) == AGP_OK) {
@@ -806,7 +815,13 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   ctx->bs_W = nullptr;
   ctx->bs_done = 0;
   if (yvar_d) { (void)hipFree(yvar_d); yvar_d = nullptr; }
-  if (st != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st; }
+  if (st != AGP_OK) {
+    // (the early inversion may still be writing ws_aux on the second stream: whatever uses it next is ordered behind it)
+    if (bs_done > 0) (void)hipStreamWaitEvent(s, ctx->ev_inv, 0);
+    drop_mixed();
+    agp_fit_destroy(fit);
+    return st;
+  }
   if (!deferred) {
     st = status_from_flags(ctx);
     fit->failed_pivot = ctx->h_flags[1] ? (int64_t)ctx->h_flags[1] - 1 : -1;
@@ -842,7 +857,9 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     if (st3 != AGP_OK) { agp_fit_destroy(fit); return st3; }
   }
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[4], s));
-  if (information) FIT_CHECK(hipMemcpyAsync(information, fit->alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+  // (deferred status: the caller's buffer is written only once the factor is known to be good - a NaN, a non-positive
+  // pivot or a timed-out hand-over leaves it untouched)
+  if (information && !deferred) FIT_CHECK(hipMemcpyAsync(information, fit->alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   FIT_CHECK(hipStreamSynchronize(s));
   FIT_CHECK(hipGetLastError());
   if (deferred) {
@@ -854,6 +871,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
       *out = fit;
       return st;
     }
+    if (information) FIT_CHECK(hipMemcpy(information, fit->alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
   }
   if (ctx->profiling) {
     float ms = 0.f;
@@ -866,9 +884,24 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   return AGP_OK;
 }
 
+// A hand-over of the step launches that timed out (flags[2]: fewer workgroup slots than the launch layout assumed - a CU
+// mask, a partition - so that waiters sat in front of their producers) is not the caller's problem: the fit is repeated
+// once on the two-launch schedule, which waits for nothing inside a launch, and the context stays on it.
+static int fit_create_retrying(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y, const double *y_var,
+                               agp_fit **out, double *information, double *log_det, MixedRequest *mixed) {
+  int st = fit_create_impl(c, k, x, y, y_var, out, information, log_det, mixed);
+  if (st == AGP_ERR_HIP && c && c->h_flags && c->h_flags[2] && (c->tune.step_below > 0 || c->tune.panel_fused)) {
+    if (out && *out) { agp_fit_destroy(*out); *out = nullptr; }
+    c->tune.step_below = 0;
+    c->tune.panel_fused = false;
+    st = fit_create_impl(c, k, x, y, y_var, out, information, log_det, mixed);
+  }
+  return st;
+}
+
 int agp_fit_create(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y,
                    const double *y_var, agp_fit **out, double *information, double *log_det) {
-  return fit_create_impl(c, k, x, y, y_var, out, information, log_det, nullptr);
+  return fit_create_retrying(c, k, x, y, y_var, out, information, log_det, nullptr);
 }
 
 int agp_fit_create_mixed(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y,
@@ -878,7 +911,7 @@ int agp_fit_create_mixed(agp_context *c, const agp_kernel *k, const agp_features
   MixedRequest m;
   m.max_iterations = max_iterations;
   m.tolerance = tolerance;
-  const int st = fit_create_impl(c, k, x, y, y_var, out, information, log_det, &m);
+  const int st = fit_create_retrying(c, k, x, y, y_var, out, information, log_det, &m);
   if (iterations) *iterations = m.iterations;
   if (residual) *residual = m.residual;
   return st;
@@ -908,7 +941,7 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
   // (1024-wide inverted blocks here: the eight-odd preconditioner applications share one inversion, and half as many
   // launch-bound block steps per sweep are worth 5 ms at N = 32768; a single substitution is better off with 512)
   long long BW = backsolve_width(n);
-  if (BW == 512 && !getenv("AGP_WIDE_BACKSOLVE") && n % 1024 == 0 && n >= 8192) BW = 1024;
+  if (BW == 512 && n % 1024 == 0 && n >= 8192) BW = 1024;
   double *Wwide = nullptr;
   if (BW) {
     AGP_HIP_CHECK(ctx, hipMalloc(&Wwide, sizeof(double) * (size_t)(n / BW) * (size_t)BW * (size_t)BW));
@@ -1376,10 +1409,8 @@ static FeatView feature_range(const FeatView &v, long long o, long long cnt) {
 // Test points per pass of a marginal prediction: the n x m block L^-1 K* is the only large buffer, and nothing couples
 // the columns of a marginal prediction, so m is cut into passes that keep it at 2 GiB (AGP_PREDICT_CHUNK=<points>
 // overrides; a joint prediction needs all columns at once).
-static long long marginal_chunk(long long rows) {
-  const char *e = getenv("AGP_PREDICT_CHUNK");  // read per call: the tests switch it within one process
-  const long long forced = e ? atoll(e) : 0;
-  if (forced > 0) return forced;
+static long long marginal_chunk(const agp_context *ctx, long long rows) {
+  if (ctx->tune.predict_chunk > 0) return ctx->tune.predict_chunk;
   const long long c = (1LL << 28) / (rows > 0 ? rows : 1);
   return c < 1024 ? 1024 : (c > (1LL << 20) ? (1LL << 20) : c);  // (a million points: the Gram kernels' grids stay in range)
 }
@@ -1399,7 +1430,7 @@ static int predict_common(agp_context *ctx, const agp_kernel *k, const agp_fit *
   if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
   TraceRange tr_predict(joint ? "agp: predict joint (gp.hpp:103-113)" : "agp: predict marginal (gp.hpp:87-101)");
   const long long ldv = round_up(n, 2);
-  const long long chunk = joint ? m_all : std::min(m_all, marginal_chunk(ldv));
+  const long long chunk = joint ? m_all : std::min(m_all, marginal_chunk(ctx, ldv));
   // workspace: V (n x chunk) | mean (chunk) | prior (chunk, or m x m for a joint prediction)
   const long long ldc = round_up(chunk, 2);
   const size_t v_elems = (size_t)ldv * (size_t)chunk;

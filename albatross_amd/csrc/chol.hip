@@ -20,6 +20,7 @@
 #include "common.h"
 #include "mfma_f64.h"
 #include "gemm_tiles.h"
+#include "trsm_kernel.h"
 
 namespace agp {
 void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);  // reduce.hip
@@ -61,49 +62,21 @@ struct PotrfArgs {
   // dpub: 36 tiles (the LDS tile layout of the diagonal block) through which the workgroups that update the diagonal
   // block hand it to the one that factors it (sentinel-filled, see store_pub)
   double *dpub = nullptr;
-  // merged trailing update (factor_lower): the block column this panel starts is being written by a bulk update that is
-  // STILL RUNNING on another stream; its tiles count themselves in *wait_counter when complete.  The kernel waits for
-  // wait_value of them and then reads the block with device-scope loads.  nullptr: off.
-  const unsigned long long *wait_counter = nullptr;
-  unsigned long long wait_value = 0;
   // panel STEP kernel (panel_fused_kernel<true> in the chain-bound tail, see panel_phase): workgroups trail_first ..
   // apply the previous panel's rank-128 update to everything RIGHT of this panel (the `below` x `below` lower triangle,
   // 64 x 64 tiles) while this panel is factored - one launch per panel, no update launch, no second stream.
   unsigned trail_first = 0xffffffffu;
-  int trail_big = 0;  // 1: 128 x 128 tiles (many rows left: the trailing update is what the launch takes), 0: 64 x 64
   // workgroup hold_index does nothing but keep its slot until workgroup 0 is done (see panel_phase)
   unsigned hold_index = 0xffffffffu, hold_count = 0;
   // step launches: the previous panel's update of THIS panel's rows below the diagonal block is done by the first
   // 2 x ceil(below / 64) trailing workgroups (64 x 64 tiles, device-scope stores), which count themselves in
   // rowcnt[64-row block] when complete; the workgroup that solves those 64 rows waits for rowcnt_expect there and reads
   // its rows with device-scope loads.  (The counters only grow: every step launch adds two per row block.)
-  // nullptr: the row workgroups update their own rows first (the update-ahead experiment without trailing workgroups).
   unsigned long long *rowcnt = nullptr;
   unsigned long long rowcnt_expect = 0;
   long long trail_tiles = 0, trail_workers = 1;  // tiles of the launch (row tiles first) / trailing workgroups that share them
-  // split step launches (many rows left): the update of everything RIGHT of this panel by the panel before the previous one
-  // ran as a kernel of its own on the second stream and may still be running; its tiles of THIS panel's columns count
-  // themselves per 64-row block in farcnt (indexed from row k0 on).  The workgroups that read those columns - the nine that
-  // update the diagonal block, the row tiles - wait for far_expect (the first 64 rows of the diagonal block: one less)
-  // and read with device-scope loads.  nullptr: nothing pending.
-  const unsigned long long *farcnt = nullptr;
-  unsigned long long far_expect = 0;
 };
 
-constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
-constexpr int IMG_DOUBLES = NTILE * MB * MB;  // 9216 doubles = 72 KiB per diagonal block
-
-// LDS image: only the 36 lower micro tiles, each column-major 16x16
-// (tile (ib, kb), ib >= kb, at index ib(ib+1)/2 + kb).  An MFMA operand
-// fragment of a tile (element [k*16 + m], k = (lane >> 4) + 4 s, m = lane & 15)
-// is 64 consecutive doubles per k-step: conflict-free ds_read_b64.
-//
-// The kernel also emits the "tile image" of the factored block to global
-// memory: the same 36 tiles with the off-diagonal ones NEGATED and the diagonal
-// ones replaced by their INVERSES.  That image is exactly the set of MFMA
-// A-operand fragments the substitution kernels need, so they stage it with a
-// straight coalesced copy.
-__device__ __forceinline__ int tile_off(int ib, int kb) { return (ib * (ib + 1) / 2 + kb) * (MB * MB); }
 
 // ---- hand-over of the factored diagonal block INSIDE one launch (panel_fused_kernel) ----------------------------
 // The workgroup that factors the 128 x 128 diagonal block emits its tile image tile by tile while it runs; the
@@ -135,15 +108,6 @@ __device__ __forceinline__ bool poll_expired(unsigned long long t0, int *flags) 
   if (__builtin_amdgcn_s_memrealtime() - t0 < PUB_TIMEOUT_TICKS) return false;
   if ((threadIdx.x & 63) == 0) atomicExch(flags + 2, 1);
   return true;
-}
-
-// every lane polls (wave-uniform address): wait until *c >= need
-__device__ __forceinline__ void wait_count(const unsigned long long *c, unsigned long long need, int *flags) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  for (int spin = 1; __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spin) {
-    if ((spin & 63) == 0 && poll_expired(t0, flags)) break;
-    __builtin_amdgcn_s_sleep(4);
-  }
 }
 
 __global__ __launch_bounds__(256) void fill_sentinel_kernel(double *p, long long count) {
@@ -327,27 +291,6 @@ __device__ __forceinline__ void micro_syrk_tile(double *T, int ib, int kb, int j
   for (int r = 0; r < 4; ++r) Cc[(lg + 4 * r) * MB + ln] = acc0[r] + acc1[r];
 }
 
-#ifdef AGP_POTRF_TIMING
-__device__ unsigned long long g_potrf_t[64];
-#define PT(i) do { if (threadIdx.x == 0) g_potrf_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
-// per step launch (slot = rows below the panel / 128), s_memrealtime ticks (100 MHz): [0] workgroup 0 starts, [1] its
-// prologue is done (the diagonal block has arrived), [2] it ends, [3] the last row workgroup ends, [4] the first
-// trailing-update workgroup starts, [5] the last one ends, [6] the first row workgroup starts
-__device__ unsigned long long g_step_t[64 * 16];
-__device__ long long g_row_target = 1408;
-__device__ unsigned long long g_row_t[128 * 8];  // the launch with 1408 rows below: per workgroup (blockIdx) start, pre-update done, TRSM done, end, CU
-#define STEP_T(p, j, op) do { if (threadIdx.x == 0) { const int slot_ = (int)((p).below / NB) < 63 ? (int)((p).below / NB) : 63; \
-  op(&g_step_t[slot_ * 16 + (j)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } while (0)
-#else
-#define PT(i)
-#define STEP_T(p, j, op)
-#endif
-#ifdef AGP_POTRF_TIMING
-#define ROW_T(p, j) do { if (threadIdx.x == 0 && (p).below == g_row_target && blockIdx.x < 128) g_row_t[blockIdx.x * 8 + (j)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ROW_T(p, j)
-#endif
-
 // two SYRK tiles at once (independent accumulators: the MFMA latencies overlap)
 __device__ __forceinline__ void micro_syrk_tile2(double *T, int ib0, int kb0, int ib1, int kb1, int jb, int ln, int lg) {
   double *C0 = T + tile_off(ib0, kb0), *C1 = T + tile_off(ib1, kb1);
@@ -384,7 +327,6 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 15, lg = lane >> 4;
   const int nbk = p.nbk;
-  PT(0);
 
   double *Adiag = p.A + p.k0 * p.lda + p.k0;  // element (r, c) of the block at Adiag[c * lda + r]
   if constexpr (UPD) {
@@ -406,18 +348,6 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) T[t * (MB * MB) + tid] = v[t];
   } else {  // thread (r, c) of every tile; all 36 loads in flight
-    const bool live = p.wait_counter != nullptr;
-    if (live) {
-      if (tid == 0) {
-        unsigned long long t0 = 0;
-        for (int spin = 0; __hip_atomic_load(p.wait_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.wait_value; ++spin) {
-          if (spin == 0) t0 = __builtin_amdgcn_s_memrealtime();
-          else if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
-          __builtin_amdgcn_s_sleep(8);
-        }
-      }
-      __syncthreads();
-    }
     const int r = tid & 15, c = tid >> 4;
     double v[NTILE];
 #pragma unroll
@@ -426,7 +356,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
       for (int kb = 0; kb <= ib; ++kb) {
         const int gr = ib * MB + r, gc = kb * MB + c;
         double x;
-        if (gr < nbk && gc < nbk) x = (gr >= gc) ? (live ? load_pub(Adiag + gc * p.lda + gr) : Adiag[gc * p.lda + gr]) : 0.;
+        if (gr < nbk && gc < nbk) x = (gr >= gc) ? Adiag[gc * p.lda + gr] : 0.;
         else x = (gr == gc) ? 1. : 0.;  // identity padding of a partial last block
         v[ib * (ib + 1) / 2 + kb] = x;
       }
@@ -435,14 +365,10 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
   }
   if (tid < NB) ys[tid] = (p.y && tid < nbk) ? p.y[tid] : 0.;
   __syncthreads();
-  PT(1);
-  if constexpr (PUB) STEP_T(p, 1, atomicMax);
 
   int bad_pivot = 0;
   if (wave == 0) micro_potrf_inv<PUB>(T + tile_off(0, 0), Wc, p.img + tile_off(0, 0), lane, ln, 0, bad_pivot);
-  PT(2);
   __syncthreads();
-  PT(3);
 
 #pragma unroll 1
   for (int jb = 0; jb < NMB; ++jb) {
@@ -472,18 +398,14 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
       if (lane < MB) ys[o + ln] = zz;
     }
     __syncthreads();
-    PT(4 + 4 * jb);
     if (jb == NMB - 1) break;
 
     // ---- stage B: wave 0 updates the NEXT diagonal tile and factors it right
     // away (look-ahead) while waves 1-3 run the remaining SYRK tiles + y update
     if (wave == 0) {
       micro_syrk_tile(T, jb + 1, jb + 1, jb, ln, lg);
-      PT(5 + 4 * jb);
       micro_potrf_inv<PUB>(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB), p.img + tile_off(jb + 1, jb + 1),
                            lane, ln, o + MB, bad_pivot);
-      PT(6 + 4 * jb);
-      if constexpr (PUB) { if (jb == NMB - 2) STEP_T(p, 8, atomicMax); }
     } else {
       const int rem = NMB - 1 - jb;
       const int ntile = rem * (rem + 1) / 2;
@@ -517,10 +439,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
       }
     }
     __syncthreads();
-    PT(7 + 4 * jb);
   }
-  PT(40);
-  if constexpr (PUB) STEP_T(p, 7, atomicMax);
   if constexpr (PUB) {  // z_b first: the workgroups below wait for it, nobody in this launch waits for the write-back of L11
     if (p.zpub && tid < nbk) store_pub(p.zpub + tid, ys[tid]);
   }
@@ -548,7 +467,6 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
     p.scalars[0] += (ys[0] + ys[1]) + (ys[2] + ys[3]);
     if (bad_pivot && p.flags[1] == 0) p.flags[1] = (int)(p.k0 + bad_pivot);
   }
-  PT(41);
 }
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
@@ -563,168 +481,6 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
   }
   __shared__ double T[POTRF_LDS_DOUBLES];
   potrf_diag_body<false>(p, T);
-}
-
-#ifdef AGP_POTRF_TIMING
-void read_potrf_timing(unsigned long long *out) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potrf_t), sizeof(unsigned long long) * 64);
-}
-void set_row_target(long long v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_row_target), &v, sizeof(v)); }
-void read_row_timing(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_t), sizeof(g_row_t)); }
-void read_step_timing(unsigned long long *out, bool reset) {
-  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_t), sizeof(g_step_t));
-  if (reset) {
-    static unsigned long long init[64 * 16];
-    for (int i = 0; i < 64; ++i)
-      for (int j = 0; j < 16; ++j) init[i * 16 + j] = (j == 4 || j == 6) ? ~0ull : 0ull;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_t), init, sizeof(init));
-  }
-}
-#endif
-
-// ---------------------------------------------------------------------------
-// Substitution against one NB x NB diagonal block over its micro blocks.
-//   Y (NB x 16 per wave, held as 8 C/D tiles) <- L11^-1 Y        (TRANS = false)
-//   Y                                         <- L11^-T Y        (TRANS = true)
-// Element (m, n) of Y lives at base[m * stride_m + n * stride_n]:
-//   panel TRSM  X <- X L11^-T : Y = X^T, stride_m = lda, stride_n = 1
-//   left  TRSM  V <- L11^-1 V : Y = V,   stride_m = 1,   stride_n = ldv
-// LDS holds the 36 lower 16x16 tiles of L11 as ready-made MFMA A-operand
-// fragments (negated off-diagonal tiles, inverted diagonal tiles).
-// ---------------------------------------------------------------------------
-constexpr int NFRAG_TILES = NTILE;
-
-struct TrsmArgs {
-  const double *img;  // tile image of the diagonal block (written by potrf_diag_kernel)
-  int nbk;
-  double *Y;  // element (0, 0) of the block to be solved
-  long long stride_m, stride_n;
-  long long ncols;  // number of n (panel rows / V columns)
-  const double *z;  // z_b (nbk) or nullptr          (FUSE_Y only)
-  double *yrest;    // y entries matching n = 0..ncols (FUSE_Y only)
-  // batched launches (blockIdx.y = diagonal block index): element strides
-  long long batch_img, batch_Y;
-  long long n_total;  // matrix size, to derive nbk per batch entry (0: use nbk)
-  long long batch_z = 0;  // FUSE_Y: offset of z / yrest per batch entry
-};
-
-template <bool TRANS, bool FUSE_Y>
-__global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
-  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);  // panel chain (see potrf_diag_kernel)
-  __shared__ double F[NFRAG_TILES * 4 * 64 + NB];
-  double *zs = F + NFRAG_TILES * 4 * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ln = lane & 15, lg = lane >> 4;
-  if (blockIdx.y > 0 || p.n_total > 0) {
-    const long long b = blockIdx.y;
-    p.img += b * p.batch_img;
-    p.Y += b * p.batch_Y;
-    if (FUSE_Y) {
-      p.z += b * p.batch_z;
-      p.yrest += b * p.batch_z;
-    }
-    if (p.n_total > 0) {
-      const long long left = p.n_total - b * NB;
-      p.nbk = (int)(left < NB ? left : NB);
-    }
-  }
-
-  // ---- stage the fragment image of L11 ----
-  // Image element [tile * 256 + k * 16 + m] is the A-operand value T[m][k] of
-  // the forward solve; the transposed solve needs T^T of every tile.
-  if (!TRANS) {
-#pragma unroll
-    for (int it = 0; it < IMG_DOUBLES / 2 / 256; ++it) {
-      const int e = 2 * (tid + 256 * it);
-      *reinterpret_cast<double2 *>(F + e) = *reinterpret_cast<const double2 *>(p.img + e);
-    }
-  } else {
-#pragma unroll 4
-    for (int e = tid; e < IMG_DOUBLES; e += 256) {
-      const int m = e & 15, k = (e >> 4) & 15, t = e >> 8;
-      F[e] = p.img[t * 256 + m * 16 + k];
-    }
-  }
-  if (FUSE_Y && tid < NB) zs[tid] = (tid < p.nbk) ? p.z[tid] : 0.;
-  __syncthreads();
-
-  const long long n0 = ((long long)blockIdx.x * 4 + wave) * 16;
-  if (n0 >= p.ncols) return;
-  const bool nok = n0 + ln < p.ncols;
-  double *base = p.Y + (n0 + ln) * p.stride_n;
-
-  v4d Y[NMB];
-  // all 8 input tiles are requested up front: one HBM round trip, not eight
-#pragma unroll
-  for (int jb = 0; jb < NMB; ++jb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = jb * MB + lg + 4 * r;
-      Y[jb][r] = (nok && m < p.nbk) ? base[m * p.stride_m] : 0.;
-    }
-  if (!TRANS) {
-#pragma unroll
-    for (int jb = 0; jb < NMB; ++jb) {
-      // four independent accumulation chains (one per k-step) instead of one
-      // chain of 4 jb dependent MFMAs: the dependent-issue latency of the f64
-      // MFMA (~190 cycles) is what this kernel is bound by
-      v4d pa[4] = {Y[jb], v4zero(), v4zero(), v4zero()};
-#pragma unroll
-      for (int ib = 0; ib < jb; ++ib) {
-        const double *f = F + (jb * (jb + 1) / 2 + ib) * 256 + lane;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) pa[s] = mfma16(f[s * 64], Y[ib][s], pa[s]);
-      }
-      const v4d acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
-      v4d po[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
-      const double *f = F + (jb * (jb + 1) / 2 + jb) * 256 + lane;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) po[s] = mfma16(f[s * 64], acc[s], po[s]);
-      const v4d out = (po[0] + po[1]) + (po[2] + po[3]);
-      Y[jb] = out;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = jb * MB + lg + 4 * r;
-        if (nok && m < p.nbk) base[m * p.stride_m] = out[r];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int jb = NMB - 1; jb >= 0; --jb) {
-      v4d pa[4] = {Y[jb], v4zero(), v4zero(), v4zero()};
-#pragma unroll
-      for (int ib = NMB - 1; ib > jb; --ib) {
-        // image tile index of the stored pair (row block ib, col block jb)
-        const double *f = F + (ib * (ib + 1) / 2 + jb) * 256 + lane;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) pa[s] = mfma16(f[s * 64], Y[ib][s], pa[s]);
-      }
-      const v4d acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
-      v4d po[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
-      const double *f = F + (jb * (jb + 1) / 2 + jb) * 256 + lane;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) po[s] = mfma16(f[s * 64], acc[s], po[s]);
-      const v4d out = (po[0] + po[1]) + (po[2] + po[3]);
-      Y[jb] = out;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = jb * MB + lg + 4 * r;
-        if (nok && m < p.nbk) base[m * p.stride_m] = out[r];
-      }
-    }
-  }
-
-  if (FUSE_Y) {
-    // y[n] -= sum_m X[n][m] z[m]   (forward substitution carried by the panel)
-    double part = 0.;
-#pragma unroll
-    for (int jb = 0; jb < NMB; ++jb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part += Y[jb][r] * zs[jb * MB + lg + 4 * r];
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
-    if (lg == 0 && nok) p.yrest[n0 + ln] -= part;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -795,7 +551,6 @@ __device__ __forceinline__ void trsm_fused_step(const PotrfArgs &p, int lane, v4
 // layout of potrf_diag_body.  Nine workgroups of four waves cover the block; each finishes in ~2 us.
 __device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
   const int lane = threadIdx.x & 63, ln = lane & 15, lg = lane >> 4;
-  ROW_T(p, 0);
   int ib = 0;
   while ((ib + 1) * (ib + 2) / 2 <= tile) ++ib;
   const int kb = tile - ib * (ib + 1) / 2;
@@ -804,13 +559,11 @@ __device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
   const int ra = kb * MB + ln, rb = ib * MB + ln;
   const bool oka = ra < p.nbk, okb = rb < p.nbk;
   v4d acc[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
-  const bool far = p.farcnt != nullptr;  // the block's last update may still be on its way from the second stream
-  if (far) wait_count(p.farcnt + ib / 4, p.far_expect - (ib < 4 ? 1 : 0), p.flags);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gr = ib * MB + ln, gc = kb * MB + lg + 4 * r;  // D/C layout: register r of lane (ln, lg) = element (row ln, column lg + 4 r)
     double x;
-    if (gr < p.nbk && gc < p.nbk) x = (gr >= gc) ? (far ? load_pub(Dd + gc * p.lda + gr) : Dd[gc * p.lda + gr]) : 0.;
+    if (gr < p.nbk && gc < p.nbk) x = (gr >= gc) ? Dd[gc * p.lda + gr] : 0.;
     else x = (gr == gc) ? 1. : 0.;  // identity padding of a partial last block
     acc[0][r] = x;
   }
@@ -823,11 +576,9 @@ __device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
       av[s2] = oka ? Xd[k * p.lda + ra] : 0.;
       bv[s2] = okb ? Xd[k * p.lda + rb] : 0.;
     }
-    ROW_T(p, 5);
 #pragma unroll
     for (int s2 = 0; s2 < 32; ++s2) acc[s2 & 3] = mfma16(-av[s2], bv[s2], acc[s2 & 3]);
   }
-  ROW_T(p, 1);
   const v4d out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -835,22 +586,16 @@ __device__ __forceinline__ void diag_update_body(const PotrfArgs &p, int tile) {
     const int gr = ib * MB + ln, gc = kb * MB + lg + 4 * r;
     store_pub(p.dpub + tile * (MB * MB) + (lg + 4 * r) * MB + ln, (gr >= gc) ? out[r] : 0.);
   }
-  ROW_T(p, 2);
 }
 
 template <bool UPD>
-__device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_block, double *Xs) {
+__device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_block) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 15, lg = lane >> 4;
   const long long n0 = ((long long)(blockIdx.x - first_block) * 4 + wave) * 16;
   const bool active = n0 < p.below;
   const bool nok = active && n0 + ln < p.below;
   double *base = p.A + p.k0 * p.lda + (p.k0 + p.nbk) + (n0 + ln);  // X[n][m] at base[m * lda]
-  ROW_T(p, 0);
-#ifdef AGP_POTRF_TIMING
-  if (threadIdx.x == 0 && p.below == g_row_target && blockIdx.x < 128)
-    g_row_t[blockIdx.x * 8 + 4] = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u) << 8 | (__builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4) & 255u);
-#endif
   const bool handed = UPD && p.rowcnt != nullptr;  // the rows arrive updated from the first trailing workgroups of this launch
   if (handed) {
     if (tid == 0) {
@@ -863,82 +608,6 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
     }
     __syncthreads();
   }
-  if constexpr (UPD) if (!handed) {
-    // The previous panel's update of this workgroup's 64 rows x 128 columns, in memory, before they are loaded and
-    // solved: C[jb] -= X_own (16 rows x 128 deep) . X_d[rows of micro column jb]^T; everything it reads is final
-    // (previous launch).  The depth in two passes of 64: X_d (128 rows x 64 deep, 64 KB) goes through LDS once per
-    // workgroup - one coalesced round trip instead of eight latency-bound batches of fragment loads per wave - as
-    // [k][row] with a 144-double pitch (the layout of the update kernels' operand image), X_own stays in registers.
-    // (Holding the eight result tiles in registers across this loop made the kernel spill: memory to memory.)
-    constexpr int XP = NB + 16;
-    const double *Xo = p.A + (p.k0 - NB) * p.lda + (p.k0 + p.nbk) + (n0 + ln);  // own rows: Xo[k * lda]
-    const double *Xd = p.A + (p.k0 - NB) * p.lda + p.k0;                        // rows of the diagonal block
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      double bo[16];
-#pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) bo[s2] = nok ? Xo[(64 * pass + 4 * s2 + lg) * p.lda] : 0.;
-      {
-        double v[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-          const int e = tid + 256 * i, row = e & (NB - 1), k = e >> 7;
-          v[i] = (row < p.nbk) ? Xd[(long long)(64 * pass + k) * p.lda + row] : 0.;
-        }
-        if (pass) __syncthreads();  // the previous pass's readers are done with Xs
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-          const int e = tid + 256 * i, row = e & (NB - 1), k = e >> 7;
-          Xs[k * XP + row] = v[i];
-        }
-      }
-      __syncthreads();
-      if (pass == 0) ROW_T(p, 5); else ROW_T(p, 7);
-      if (active) {
-        // this wave's 16 rows x 128 columns of C in two halves of four micro columns: the 16 values per lane of a half in
-        // flight at once (one micro column at a time - load, 16 MFMAs, store: sixteen dependent round trips - took 26 us
-        // next to the trailing workgroups, measured with scripts/diag_step.py: the TRSM then started when the POTRF was
-        // nearly done; all eight at once spills)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          double cv[4][4];
-#pragma unroll
-          for (int j4 = 0; j4 < 4; ++j4)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int m = (4 * h + j4) * MB + lg + 4 * r;
-              cv[j4][r] = (nok && m < p.nbk) ? base[m * p.lda] : 0.;
-            }
-          // the 16 A fragments of a micro column are read from LDS in one batch, the next column's while this one multiplies
-          // (one ds_read in front of every MFMA made the 128 MFMAs of a pass take 9 us)
-          double fa[2][16];
-#pragma unroll
-          for (int s2 = 0; s2 < 16; ++s2) fa[0][s2] = Xs[(4 * s2 + lg) * XP + (4 * h) * MB + ln];
-#pragma unroll
-          for (int j4 = 0; j4 < 4; ++j4) {
-            const int jb = 4 * h + j4;
-            if (j4 < 3) {
-#pragma unroll
-              for (int s2 = 0; s2 < 16; ++s2) fa[(j4 + 1) & 1][s2] = Xs[(4 * s2 + lg) * XP + (jb + 1) * MB + ln];
-            }
-            v4d acc[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[0][r] = cv[j4][r];
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) acc[s2 & 3] = mfma16(-fa[j4 & 1][s2], bo[s2], acc[s2 & 3]);
-            const v4d out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int m = jb * MB + lg + 4 * r;
-              if (nok && m < p.nbk) base[m * p.lda] = out[r];
-            }
-          }
-        }
-      }
-      if (pass == 0) ROW_T(p, 6);
-    }
-  }
-  ROW_T(p, 1);
   if (!active) return;  // from here on the waves are independent: no barrier below
   v4d Y[NMB];
 #pragma unroll
@@ -949,14 +618,6 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
       Y[jb][r] = (nok && m < p.nbk) ? (handed ? load_pub(base + m * p.lda) : base[m * p.lda]) : 0.;
     }
   trsm_fused_step<0>(p, lane, Y, base, nok, lg);
-  ROW_T(p, 2);
-  STEP_T(p, 9, atomicMax);
-#ifdef AGP_POTRF_TIMING
-  if (lane == 0) {  // who is last: (time << 20 | workgroup << 4 | wave)
-    const int slot_ = (int)(p.below / NB) < 63 ? (int)(p.below / NB) : 63;
-    atomicMax(&g_step_t[slot_ * 16 + 11], (unsigned long long)__builtin_amdgcn_s_memrealtime() << 20 | (unsigned long long)blockIdx.x << 4 | wave);
-  }
-#endif
   if (p.y) {
     // y[n] -= sum_m X[n][m] z[m]: z_b is published when the producer has finished the whole block.  All 32 values of this
     // lane in flight at once and re-read together until none is the sentinel (one element at a time, each poll a
@@ -986,7 +647,6 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
     for (int jb = 0; jb < NMB; ++jb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) part += Y[jb][r] * z[jb][r];
-    STEP_T(p, 10, atomicMax);
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
     if (lg == 0 && nok) p.y[p.nbk + n0 + ln] -= part;
@@ -1040,9 +700,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 template <bool PUBLISH = false>
 __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const double *__restrict__ P, long long ld, long long M,
-                                             long long i0, long long j0, double *lds, unsigned long long *done = nullptr,
-                                             const unsigned long long *wait_cnt = nullptr, unsigned long long wait_val = 0,
-                                             int *flags = nullptr) {
+                                             long long i0, long long j0, double *lds, unsigned long long *done = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1, ln = lane & 15, lg = lane >> 4;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(P) & 15) == 0) && ((ld & 1) == 0);
@@ -1050,7 +708,6 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
   double ra[16], rb[16];
   trail_load_pass(P, ld, i0, M, 0, vec_ok, ra);
   trail_load_pass(P, ld, j0, M, 0, vec_ok, rb);
-  if (wait_cnt) wait_count(wait_cnt, wait_val, flags);  // (this tile of C is still being written by the far update before this one)
   v4d acc[2][2];
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
@@ -1060,7 +717,7 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
-        acc[tj][ti][r] = (row < M && col < M) ? (wait_cnt ? load_pub(Cc + row + col * ld) : Cc[row + col * ld]) : 0.;
+        acc[tj][ti][r] = (row < M && col < M) ? Cc[row + col * ld] : 0.;
       }
     }
 #pragma unroll
@@ -1104,9 +761,11 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
     }
   if constexpr (PUBLISH) {
     // every store of this tile acknowledged, then one count: a reader that sees the count reads final values
+    // (the tile's stores are write-through already; the RELEASE on the count is what orders them before it in the
+    // language's memory model too, not only on this hardware)
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1118,7 +777,7 @@ __device__ __forceinline__ void trail_one_tile(const PotrfArgs &p, long long id,
       const long long bj = id / nrb, bi = id % nrb;
       // origin at (k0, k0): rows of the diagonal block = rows 0 .. 127 of the previous panel's rows from k0 on
       trail_tile64<true>(p.A + p.k0 * p.lda + p.k0, p.A + (p.k0 - NB) * p.lda + p.k0, p.lda, p.below + NB, (2 + bi) * ST, bj * ST,
-                         lds, p.rowcnt + bi, p.farcnt ? p.farcnt + 2 + bi : nullptr, p.far_expect, p.flags);
+                         lds, p.rowcnt + bi);
       return;
     }
     id -= 2 * nrb;
@@ -1126,24 +785,13 @@ __device__ __forceinline__ void trail_one_tile(const PotrfArgs &p, long long id,
   const long long t0 = p.k0 + NB;
   double *Cc = p.A + t0 * p.lda + t0;
   const double *P = p.A + (p.k0 - NB) * p.lda + t0;
-  const int edge = p.trail_big ? GT : ST;
-  const int ntr = (int)((p.below + edge - 1) / edge);
+  const int ntr = (int)((p.below + ST - 1) / ST);
   int bj = 0;
   while (id >= ntr - bj) {
     id -= ntr - bj;
     ++bj;
   }
-  if (p.trail_big) {
-    GemmArgs g;
-    g.C = Cc; g.ldc = p.lda;
-    g.A = g.B = P; g.lda = g.ldb = p.lda;
-    g.M = g.N = p.below; g.K = NB; g.tri = 1;
-    g.remap = 0; g.nsuper = 0; g.nb8 = 0;
-    g.ntr = g.ntc = ntr;
-    gemm_nt_sub_tile<false, false>(g, bj + (int)id, bj, lds);
-  } else {
-    trail_tile64(Cc, P, p.lda, p.below, (long long)(bj + (int)id) * ST, (long long)bj * ST, lds);
-  }
+  trail_tile64(Cc, P, p.lda, p.below, (long long)(bj + (int)id) * ST, (long long)bj * ST, lds);
 }
 
 // A trailing workgroup takes the tiles worker, worker + trail_workers, ... : no more workgroups than fit on the chip next
@@ -1160,8 +808,7 @@ __device__ __forceinline__ void trail_update_body(const PotrfArgs &p, long long 
 template <bool UPD>
 __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
   __shared__ double T[POTRF_LDS_DOUBLES];
-  static_assert(POTRF_LDS_DOUBLES >= 2 * 2 * GK * GLD && POTRF_LDS_DOUBLES >= 2 * 64 * TRP,
-                "the trailing-update workgroups stage their operands in T");
+  static_assert(POTRF_LDS_DOUBLES >= 2 * 64 * TRP, "the trailing-update workgroups stage their operands in T");
   if (UPD && blockIdx.x >= p.trail_first) {
     if (blockIdx.x >= p.hold_index && blockIdx.x < p.hold_index + p.hold_count) {
       // placeholder: idle in the slot next to workgroup 0 until the last tile of the image is out
@@ -1173,28 +820,16 @@ __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
       }
       return;
     }
-    STEP_T(p, 4, atomicMin);
-    ROW_T(p, 0);
-#ifdef AGP_POTRF_TIMING
-    if (threadIdx.x == 0 && p.below == g_row_target && blockIdx.x < 128)
-      g_row_t[blockIdx.x * 8 + 4] = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u) << 8 | (__builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4) & 255u);
-#endif
     trail_update_body(p, (long long)(blockIdx.x - p.trail_first) - (blockIdx.x > p.hold_index ? (long long)p.hold_count : 0), T);
-    STEP_T(p, 5, atomicMax);
-    ROW_T(p, 3);
     return;
   }
   __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);
   if (blockIdx.x == 0) {
-    STEP_T(p, 0, atomicMax);
     potrf_diag_body<true, UPD>(p, T);
-    STEP_T(p, 2, atomicMax);
   } else if (UPD && blockIdx.x <= UPD_BLOCKS) {
     diag_update_body(p, (int)(blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6));
   } else {
-    STEP_T(p, 6, atomicMin);
-    trsm_fused_body<UPD>(p, UPD ? 1 + UPD_BLOCKS : 1, T);
-    STEP_T(p, 3, atomicMax);
+    trsm_fused_body<UPD>(p, UPD ? 1 + UPD_BLOCKS : 1);
   }
 }
 
@@ -1204,10 +839,8 @@ __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
 // block ib with the already-solved block jb > ib.
 
 static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, int nbk, double *img,
-                         double *y, int *flags, double *scalars, const unsigned long long *wait_counter = nullptr,
-                         unsigned long long wait_value = 0) {
+                         double *y, int *flags, double *scalars) {
   PotrfArgs p;
-  p.wait_counter = wait_counter; p.wait_value = wait_value;
   p.A = A; p.lda = lda; p.k0 = k0; p.nbk = nbk;
   p.img = img + (k0 / NB) * (long long)IMG_DOUBLES;
   p.y = y ? y + k0 : nullptr;
@@ -1218,8 +851,7 @@ static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, 
 // trailing update C -= P P^T (lower tiles) bracketed by a HIP-event pair when
 // the caller collects per-launch timings (bench.py's roofline block)
 static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long lda, const double *P,
-                       const double *Q, long long M, long long N, long long K, bool bulk, int variant = -1,
-                       unsigned long long *done = nullptr, int done_cols = 0) {
+                       const double *Q, long long M, long long N, long long K, bool bulk, int variant = -1) {
   // only the bulk trailing updates' trailing_update_kernel launches (their own kernel symbol) are
   // event-timed: they run on the second stream, where an event gap is off the critical path
   if (!bulk) {
@@ -1229,8 +861,7 @@ static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long
   BulkTiming bt;
   const bool timed = timers && timers->ev && timers->used + 2 <= timers->n_ev;
   if (timed) { bt.e0 = timers->ev[timers->used]; bt.e1 = timers->ev[timers->used + 1]; }
-  if (done) launch_trailing_update_as(0, s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr, done, done_cols);
-  else if (variant >= 0) launch_trailing_update_as(variant, s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
+  if (variant >= 0) launch_trailing_update_as(variant, s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
   else launch_trailing_update(s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
   if (timed && bt.flops > 0.) {
     timers->flops[timers->used / 2] = bt.flops;  // algorithmic flop: 2 K per covered C entry on or below the diagonal
@@ -1238,66 +869,37 @@ static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long
   }
 }
 
-// AGP_PANEL_FUSED=0 switches the fused panel kernel off (POTRF and TRSM as two launches, the round-2 path)
-static bool panel_fused_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("AGP_PANEL_FUSED");
-    v = (e && e[0] == '0') ? 0 : 1;
+// ---- the schedule's switch points (measured on one MI355X; DESIGN.md sections 3 and 8 hold the sweeps) ------------
+// The two switches a caller can set - AGP_PANEL_FUSED=0 (POTRF and TRSM as two launches) and AGP_STEP_BELOW=<rows> (0: no
+// step launches) - are read ONCE, at agp_context_create, into ctx->tune (api.hip); everything else is a constant.
+constexpr long long FUSED_BELOW = 4608;     // remaining rows at or below which POTRF + TRSM are one fused launch (2048 .. 4608 best)
+constexpr long long INNER_LEFT_ABOVE = 6144;  // left-looking inside an outer block while more rows than this remain
+constexpr long long NBO_512_ABOVE = 2048, NBO_256_ABOVE = 1024;  // outer block width 512 / 256 / 128 by remaining rows
+constexpr long long THROTTLE_BELOW = 8192;  // bulk updates handed to their stream by the host once their panel is done
+constexpr long long U1_F32_ABOVE = 4096;    // mixed precision: U1 on the fp32 MFMA path while the block column is this tall
+constexpr long long SINGLE_BELOW = 1536;    // the very end on one stream (when the step launches are off)
+constexpr long long MASK_BELOW = 8704;      // bulk updates on the CU-masked stream from here on
+
+// Workgroup slots of panel_fused_kernel<true> on this device: occupancy x CUs, asked of the runtime once per context.
+static long long step_slots(agp_context *ctx) {
+  if (ctx->step_slots <= 0) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, panel_fused_kernel<true>, 256, 0) != hipSuccess || per_cu <= 0) {
+      (void)hipGetLastError();
+      per_cu = 1;
+    }
+    ctx->step_slots = (long long)per_cu * ctx->cus;
   }
-  return v == 1;
+  return ctx->step_slots;
 }
 
-// Remaining rows at or below which the factorisation advances panel by panel with the UPDATE-AHEAD panel kernel
-// (panel_fused_kernel<true>: the previous panel's update of the next 128 columns inside the panel launch, everything
-// further right on the bulk stream with depth 128); AGP_UPD_BELOW, default 0 = off.  Measured (MI355X, round 3): correct,
-// and no faster - the launch takes 37 us with two row workgroups and 50-60 us with sixty next to the bulk update
-// (the plain fused launch: 35-40 us + a 10-12 us update launch), and one event record / wait pair per PANEL instead of
-// one per four costs ~10 us each time: N = 4096 fit 2.58 against 2.54 ms, N = 16384 33.7 against 33.7 ms.  Read per call
-// (tests switch it in one process).
-static long long upd_below() {
-  const char *e = getenv("AGP_UPD_BELOW");
-  return e ? atoll(e) : 0;
-}
-
-// Remaining rows at or below which the factorisation runs ONE launch per panel on one stream (panel_phase step_mode);
-// AGP_STEP_BELOW, 0 = off, default 4608 (scripts/sweep_step.sh, profiles/r03/sweep_step.txt: N = 16384 33.3 -> 32.9 ms,
-// N = 8192 6.8 -> 6.5 ms, N = 4096 2.6 -> 2.1 ms, N = 2048 1.04 -> 0.86 ms; 3072 ... 5120 within noise of each other at
-// N = 16384, 5632 and above lose: there the trailing update of one panel takes longer than the two-stream schedule's
-// share of it).  Read per call (tests switch it in one process).
-static long long step_below() {
-  const char *e = getenv("AGP_STEP_BELOW");
-  return e ? atoll(e) : 4608;
-}
-
-// Rows below the panel above which the trailing-update workgroups of a step launch take 128 x 128 tiles instead of
-// 64 x 64 (AGP_STEP_TILE128_ABOVE; default: never).  Measured: with 128 x 128 tiles the launch takes 100-130 us at 4000-4600
-// remaining rows and 60-65 us at 2048-3400, against 57-84 and 45-57 us with 64 x 64 tiles (a 128 x 128 x 128 product is
-// eight load / barrier round trips by two workgroups per CU - latency-bound - and two rounds of them).
-static long long step_tile128_above() {
-  static long long v = -1;
-  if (v < 0) {
-    const char *e = getenv("AGP_STEP_TILE128_ABOVE");
-    v = e ? atoll(e) : (1LL << 60);
-  }
-  return v;
-}
-
-// Rows below the panel above which a step launch leaves the update of everything right of the panel to a kernel of its
-// own on the second stream (AGP_STEP_SPLIT_ABOVE; 0 = never).  Read per call.
-static long long step_split_above() {
-  const char *e = getenv("AGP_STEP_SPLIT_ABOVE");
-  return e ? atoll(e) : 0;
-}
-
-static long long fused_below() {
-  static long long v = -1;
-  if (v < 0) {
-    const char *e = getenv("AGP_FUSED_BELOW");
-    v = e ? atoll(e) : 4608;  // scripts/sweep_fused.sh: 2048 .. 4608 best, 8704 and above lose to the two-launch path
-    if (v == 0) v = 1LL << 60;  // 0: always
-  }
-  return v;
+// May `rows` remaining rows be factored with step launches?  The row workgroups of a step launch wait for trailing
+// workgroups that are dispatched AFTER them: all critical workgroups (10 + one per 64 rows) and at least 64 trailing ones
+// must be resident at once, or the waiters would sit out their 2 s time-out.  Fewer slots than that (a small partition,
+// a CU mask): the two-launch schedule.  Should the hand-over time out all the same (flags[2]), agp_fit_create repeats
+// the fit without step launches (api.hip).
+static bool step_fits(agp_context *ctx, long long rows) {
+  return ctx->tune.step_below > 0 && rows <= ctx->tune.step_below && step_slots(ctx) >= 10 + rows / 64 + 64;
 }
 
 // Before the fused panel kernels of one factorisation run: sentinel-fill the tile images of the diagonal blocks
@@ -1305,7 +907,7 @@ static long long fused_below() {
 // A no-op (and the two-launch path is used) if the fused kernel is off or the z buffer cannot be allocated.
 void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long long k_begin, long long k_end, bool want_step) {
   ctx->img_ready = nullptr;
-  if (!panel_fused_enabled() || k_end <= k_begin) return;
+  if (!ctx->tune.panel_fused || k_end <= k_begin) return;
   if (ctx->zpub_cap < k_end) {
     // grow; the old buffer may still be read by kernels in flight on this context's streams: drain them first
     (void)hipStreamSynchronize(ctx->stream);
@@ -1317,30 +919,26 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
     ctx->zpub_cap = cap;
   }
   const long long b0 = k_begin / NB, b1 = (k_end + NB - 1) / NB;
-  if ((upd_below() > 0 || (want_step && step_below() > 0)) && ctx->dpub_cap < b1) {
+  if (want_step && ctx->tune.step_below > 0 && ctx->dpub_cap < b1) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
     ctx->d_dpub = nullptr;
     ctx->d_rowcnt = nullptr;
-    ctx->d_farcnt = nullptr;
     ctx->dpub_cap = 0;
     const long long cap = (b1 + 31) / 32 * 32;
     // (+ two 64-row counters per diagonal block behind the images: the hand-over of the step launches' row updates)
-    if (hipMalloc(&ctx->d_dpub, sizeof(double) * (size_t)cap * (IMG_DOUBLES + 4)) == hipSuccess) {
+    if (hipMalloc(&ctx->d_dpub, sizeof(double) * (size_t)cap * (IMG_DOUBLES + 2)) == hipSuccess) {
       ctx->dpub_cap = cap;
       ctx->d_rowcnt = reinterpret_cast<unsigned long long *>(ctx->d_dpub + cap * (long long)IMG_DOUBLES);
-      ctx->d_farcnt = ctx->d_rowcnt + 2 * cap;
     }
     else (void)hipGetLastError();
   }
   const long long cnt_img = (b1 - b0) * (long long)IMG_DOUBLES, cnt_z = k_end - k_begin;
   if (ctx->d_dpub && ctx->dpub_cap >= b1) {
     (void)hipMemsetAsync(ctx->d_rowcnt + 2 * b0, 0, sizeof(unsigned long long) * 2 * (size_t)(b1 - b0), s);
-    (void)hipMemsetAsync(ctx->d_farcnt + 2 * b0, 0, sizeof(unsigned long long) * 2 * (size_t)(b1 - b0), s);
-  }
-  if (ctx->d_dpub && ctx->dpub_cap >= b1)
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_img + 255) / 256)), dim3(256), 0, s,
                        ctx->d_dpub + b0 * (long long)IMG_DOUBLES, cnt_img);
+  }
   hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_img + 255) / 256)), dim3(256), 0, s, invd + b0 * (long long)IMG_DOUBLES, cnt_img);
   hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_z + 255) / 256)), dim3(256), 0, s, ctx->d_zpub + k_begin, cnt_z);
   ctx->zpub_ready_n = k_end;
@@ -1351,38 +949,22 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
 // POTRF, panel TRSM (with the fused forward substitution on y) and the update
 // of the remaining columns of the outer block.  Everything on stream s.
 static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *invd,
-                        double *y, long long K0, long long kend, FactorTimers *timers, hipEvent_t after_first = nullptr,
-                        bool upd_prev = false, const unsigned long long *wait_counter = nullptr,
-                        unsigned long long wait_value = 0, bool step_mode = false) {
+                        double *y, long long K0, long long kend, FactorTimers *timers, bool step_mode = false) {
   // step_mode (the chain-bound tail, factor_lower): ONE launch per panel.  The first panel is a plain fused launch;
-  // every later one is the update-ahead kernel - the previous panel's update of this panel's 128 columns on the
+  // every later one is panel_fused_kernel<true> - the previous panel's update of this panel's 128 columns on the
   // critical workgroups - plus trailing workgroups that apply the previous panel to everything further right while
   // this panel's POTRF runs.  No update launches, nothing leaves stream s.
-  // AGP_INNER_LEFT=1: left-looking inside the outer block - panel k is brought up to date with the panels
-  // [K0, k) of this outer block in ONE product of depth k - K0 just before it is factored, instead of every
-  // panel updating all later columns of the outer block with depth 128 (same flop, a third of the C traffic,
-  // and the update on the serial chain is 128 columns wide instead of up to 384).
-  // Measured (N = 16384): 35.2 -> 35.0 ms; at N <= 8192, where the chain is the critical path, the deeper
-  // product on the chain costs 1-3 %, so it is used only while more than AGP_INNER_LEFT (default 6144) rows remain.
-  static long long left_above = -1;
-  if (left_above < 0) {
-    const char *e = getenv("AGP_INNER_LEFT");
-    left_above = e ? atoll(e) : 6144;
-    if (left_above == 0) left_above = 1LL << 60;  // 0: never
-  }
-  if (kend != n) step_mode = false;  // (see panel_phase_public)
-  const bool inner_left = !step_mode && (n - K0) > left_above;
+  // Otherwise, while more than INNER_LEFT_ABOVE rows remain: left-looking inside the outer block - panel k is brought
+  // up to date with the panels [K0, k) of this outer block in ONE product of depth k - K0 just before it is factored,
+  // instead of every panel updating all later columns of the outer block with depth 128 (same flop, a third of the C
+  // traffic: 35.2 -> 35.0 ms at N = 16384; where the chain is the critical path the deeper product costs 1-3 %).
+  if (kend != n) step_mode = false;  // (a step launch updates ALL columns right of its panel)
+  const bool inner_left = !step_mode && (n - K0) > INNER_LEFT_ABOVE;
   // The consumers of the fused kernel hold their slots for the whole POTRF (~30 us): while the bulk update fills the
   // chip that costs it more than the saved launch (measured: 43.3 -> 41.8 TFLOP/s), so the fused kernel takes over
-  // where the panel chain is the critical path (AGP_FUSED_BELOW remaining rows)
-  const bool fused = panel_fused_enabled() && ctx->d_zpub && ctx->zpub_ready_n >= kend && ctx->img_ready == invd &&
-                     ((n - K0) <= fused_below() || upd_prev || step_mode) &&  // (factor_lower asks for upd_prev / step_mode only when all of this holds)
-                     !wait_counter;                             // (merged updates: the bulk-bound phase, two launches)
-  // split step launches (step_mode, many rows left): see PotrfArgs::farcnt
-  long long far_launched = 0;   // far updates launched on the second stream so far (every one covers all rows to the end)
-  bool far_pending = false;     // the previous panel's far update is (possibly) still running
-  hipStream_t s_far = ctx->stream_masked ? ctx->stream_masked : ctx->stream2;
-  const long long split_above = step_split_above();
+  // where the panel chain is the critical path
+  const bool fused = ctx->tune.panel_fused && ctx->d_zpub && ctx->zpub_ready_n >= kend && ctx->img_ready == invd &&
+                     ((n - K0) <= FUSED_BELOW || step_mode);
   for (long long k = K0; k < kend; k += NB) {
     const int nbk = (int)((n - k < NB) ? n - k : NB);
     if (inner_left && k > K0) {
@@ -1398,121 +980,70 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
       pa.flags = ctx->d_flags; pa.scalars = ctx->d_scalars;
       pa.zpub = y ? ctx->d_zpub + k : nullptr;
       pa.below = below > 0 ? below : 0;
-      if ((upd_prev && k == K0) || (step_mode && k > K0)) {
-        // the panel before this one (columns k - 128 .. k - 1) has not been applied to these columns yet
+      if (step_mode && k > K0) {
+        // the panel before this one (columns k - 128 .. k - 1) has not been applied to these columns - nor to anything
+        // right of them - yet
         pa.dpub = ctx->d_dpub + (k / NB) * (long long)IMG_DOUBLES;
         unsigned grid = (unsigned)(1 + UPD_BLOCKS + (pa.below + 63) / 64);
-        const bool split = step_mode && pa.below > split_above && split_above > 0 && ctx->d_farcnt && ctx->d_rowcnt && s_far &&
-                           ctx->ev_step[0] && ctx->ev_step[1];
-        if (far_pending) {
-          // this launch reads columns the previous far update may still be writing: its counted tiles are the hand-over
-          pa.farcnt = ctx->d_farcnt + k / 64;
-          pa.far_expect = 2ull * (unsigned long long)far_launched;
-          if (!split) {
-            // ... and a launch that updates the far columns itself must not overtake it there
-            (void)hipEventRecord(ctx->ev_d, s_far);
-            (void)hipStreamWaitEvent(s, ctx->ev_d, 0);
-            far_pending = false;
-          }
-        }
-        if (split) {
-          // critical workgroups + the row tiles only; everything right of the panel goes to the second stream below
-          const long long nt = (pa.below + 63) / 64;
+        if (pa.below > 0) {
+          const long long nt = (pa.below + 63) / 64;  // 64-row blocks below = tile rows of the trailing triangle
           pa.trail_first = grid;
           pa.rowcnt = ctx->d_rowcnt + (k + NB) / 64;
           pa.rowcnt_expect = 2ull * (unsigned long long)((k - K0) / NB);
-          pa.trail_tiles = 2 * nt;
-          pa.trail_workers = 2 * nt;
-          grid += (unsigned)(2 * nt);
-        } else
-        if (step_mode && pa.below > 0) {  // ... nor to anything right of them
-          pa.trail_big = pa.below > step_tile128_above() ? 1 : 0;
-          const long long edge = pa.trail_big ? 128 : 64, ntb = (pa.below + edge - 1) / edge;  // trailing tiles right of the panel
-          const long long nt = (pa.below + 63) / 64;                                            // 64-row blocks below
-          pa.trail_first = grid;
-          long long tiles = ntb * (ntb + 1) / 2;
-          if (ctx->d_rowcnt) {
-            pa.rowcnt = ctx->d_rowcnt + (k + NB) / 64;
-            pa.rowcnt_expect = 2ull * (unsigned long long)((k - K0) / NB);
-            tiles += 2 * nt;
-          }
-          // Workgroups go round-robin over the 8 XCDs and, inside one, to its 32 CUs in turn: the first 256 of a launch get a CU
-          // each, number 256 + i lands next to number i (scripts/microbench/hwid_probe.hip, scripts/diag_step.py).  The critical
-          // workgroups - the factoring one, the nine that update its block, the row workgroups - keep their CUs to themselves:
-          // workgroups 256 .. 256 + (their number) are PLACEHOLDERS that idle until the image is complete (next to a
+          const long long tiles = nt * (nt + 1) / 2 + 2 * nt;
+          // Workgroups go round-robin over the XCDs and, inside one, to its CUs in turn: the first `cus` of a launch get a
+          // CU each, number cus + i lands next to number i (scripts/microbench/hwid_probe.hip).  The critical workgroups -
+          // the factoring one, the nine that update its block, the row workgroups - keep their CUs to themselves:
+          // workgroups cus .. cus + (their number) are PLACEHOLDERS that idle until the image is complete (next to a
           // trailing workgroup the POTRF takes 40-47 us instead of 27-30 and the diagonal block arrives after 10-13 us
-          // instead of 6).  The trailing workgroups take the tiles worker, worker + workers, ...: as many as fit (two per
-          // CU on the CUs left), not one per tile (2600 starts and exits per launch at 4000 remaining rows cost ~10 %).
-          // If the dispatch order ever differs this costs idle slots and nothing else.  AGP_STEP_HOLD=0: no placeholders.
-          int hold = 1;
-          long long slots = 512;  // two workgroups of this kernel per CU (AGP_STEP_SLOTS; both read per call: tests switch them)
-          if (const char *e = getenv("AGP_STEP_HOLD")) hold = atoi(e);
-          if (const char *e = getenv("AGP_STEP_SLOTS")) slots = atoll(e) > 0 ? atoll(e) : 512;
-          const long long ncrit = grid;
-          long long workers = tiles;
-          long long nhold = 0;
-          if (ncrit + workers > 256 && hold > 0 && ncrit < 256) {
-            // 1 (default): all critical workgroups while the trailing update is short (it needs the slots when it is what the
-            // launch takes: from ~2900 remaining rows on only the factoring workgroup and the nine that feed it); n > 1: the first n
-            nhold = (hold == 1) ? (tiles <= 1200 ? ncrit : 1 + UPD_BLOCKS) : (hold < ncrit ? hold : ncrit);
+          // instead of 6).  The trailing workgroups take the tiles worker, worker + workers, ...: as many as fit on the
+          // CUs left, not one per tile (2600 starts and exits per launch at 4000 remaining rows cost ~10 %).  If the
+          // dispatch order ever differs this costs idle slots and nothing else.
+          const long long slots = step_slots(ctx), first_round = ctx->cus, ncrit = grid;
+          long long workers = tiles, nhold = 0;
+          if (ncrit + workers > first_round && ncrit < first_round) {
+            // all critical workgroups while the trailing update is short; from ~2900 remaining rows on it is what the
+            // launch takes and needs the slots: only the factoring workgroup and the nine that feed it
+            nhold = tiles <= 1200 ? ncrit : 1 + UPD_BLOCKS;
             const long long cap = slots - ncrit - nhold;
             if (workers > cap) workers = cap;
-            if (ncrit + workers <= 256) nhold = 0;
+            if (ncrit + workers <= first_round) nhold = 0;
           } else if (workers > slots - ncrit) {
             workers = slots - ncrit;
           }
-          if (workers < 2 * nt && workers < tiles) workers = (2 * nt < tiles) ? 2 * nt : tiles;
+          // (the row tiles come first in the tile order and every one needs a workgroup of its own up front: the row
+          // workgroups wait for them)
+          if (workers < 2 * nt) workers = 2 * nt < tiles ? 2 * nt : tiles;
           pa.trail_tiles = tiles;
           pa.trail_workers = workers;
           grid += (unsigned)workers;
           if (nhold > 0) {
-            pa.hold_index = 256;
+            pa.hold_index = (unsigned)first_round;
             pa.hold_count = (unsigned)nhold;
             grid += (unsigned)nhold;
           }
         }
         hipLaunchKernelGGL(panel_fused_kernel<true>, dim3(grid), dim3(256), 0, s, pa);
-        if (split) {
-          // The far update of this step: everything right of this panel -= (previous panel)(previous panel)^T, as a kernel of
-          // its own (64 x 64 tiles, four workgroups per CU: 37 TFLOP/s where the trailing workgroups inside the launch,
-          // two per CU next to the 79 KB of the factoring workgroup's kind, reach 26).  It needs the PREVIOUS launch
-          // complete - the host waits for that (an unsatisfied hipStreamWaitEvent on the other stream slows the chain, section
-          // 8) while this launch is already queued - and its tiles of the next panel's columns count themselves for the next launch.
-          const int slot = (int)((k / NB) & 1);
-          (void)hipEventRecord(ctx->ev_step[slot], s);
-          while (hipEventQuery(ctx->ev_step[slot ^ 1]) == hipErrorNotReady) {}
-          const long long t0 = k + NB;
-          launch_update64_counted(s_far, A + t0 * lda + t0, lda, A + (k - NB) * lda + t0, lda, pa.below, NB, ctx->d_farcnt + t0 / 64, 2);
-          ++far_launched;
-          far_pending = true;
-        } else if (step_mode && split_above > 0 && ctx->ev_step[0] && ctx->ev_step[1]) {
-          // (only when split launches may follow: an event record between two launches costs ~6 us of gap on this stream)
-          (void)hipEventRecord(ctx->ev_step[(int)((k / NB) & 1)], s);
-        }
       } else {
         hipLaunchKernelGGL(panel_fused_kernel<false>, dim3((unsigned)(1 + (pa.below + 63) / 64)), dim3(256), 0, s, pa);
-        if (step_mode && split_above > 0 && ctx->ev_step[0] && ctx->ev_step[1]) (void)hipEventRecord(ctx->ev_step[(int)((k / NB) & 1)], s);
       }
       if (below <= 0) continue;
     } else {
-    launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars, k == K0 ? wait_counter : nullptr, wait_value);
-    if (below <= 0) continue;
-    TrsmArgs t;
-    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
-    t.nbk = nbk;
-    t.Y = A + k * lda + (k + nbk);
-    t.stride_m = lda; t.stride_n = 1;
-    t.ncols = below;
-    t.z = y ? y + k : nullptr;
-    t.yrest = y ? y + k + nbk : nullptr;
-    t.batch_img = t.batch_Y = 0; t.n_total = 0;
-    const unsigned grid = (unsigned)((below + 63) / 64);
-    if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
-    else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
+      launch_potrf(s, A, lda, k, nbk, invd, y, ctx->d_flags, ctx->d_scalars);
+      if (below <= 0) continue;
+      TrsmArgs t;
+      t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+      t.nbk = nbk;
+      t.Y = A + k * lda + (k + nbk);
+      t.stride_m = lda; t.stride_n = 1;
+      t.ncols = below;
+      t.z = y ? y + k : nullptr;
+      t.yrest = y ? y + k + nbk : nullptr;
+      t.batch_img = t.batch_Y = 0; t.n_total = 0;
+      const unsigned grid = (unsigned)((below + 63) / 64);
+      if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), dim3(grid), dim3(256), 0, s, t);
+      else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(grid), dim3(256), 0, s, t);
     }
-    // the columns right of the first panel receive the rest of U1 on the side stream (factor_lower): nothing of this
-    // outer block may touch them before that has finished
-    if (after_first && k == K0) (void)hipStreamWaitEvent(s, after_first, 0);
     const long long width = kend - (k + nbk);
     if (width > 0 && !inner_left && !(step_mode && fused)) {
       const double *P = A + k * lda + (k + nbk);
@@ -1521,15 +1052,18 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
   }
 }
 
+static bool step_ready(agp_context *ctx, const double *invd, long long kend) {
+  return ctx->tune.panel_fused && ctx->d_dpub && ctx->dpub_cap * NB >= kend && ctx->d_rowcnt && ctx->d_zpub &&
+         ctx->img_ready == invd && ctx->zpub_ready_n >= kend;
+}
+
 void panel_phase_public(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *img,
                         double *y, long long K0, long long kend) {
   // (one block column of a sharded fit, or a probe: the block's own panels as step launches - one launch per panel, no
   // update launches - while the second image and the counters, which are indexed by the GLOBAL block number, stay small)
-  const bool step = kend == n && kend <= 65536 && kend - K0 <= step_below() && 2LL * ctx->cus >= 10 + (kend - K0) / 64 + 64;  // (a step launch updates ALL columns right of its panel: the block must end the matrix)
+  const bool step = kend == n && kend <= 65536 && step_fits(ctx, kend - K0);
   panel_fused_prepare(ctx, s, img, K0, kend, step);
-  const bool step_ok = step && panel_fused_enabled() && ctx->d_dpub && ctx->dpub_cap * NB >= kend && ctx->d_rowcnt && ctx->d_zpub &&
-                       ctx->img_ready == img && ctx->zpub_ready_n >= kend;
-  panel_phase(ctx, s, A, n, lda, img, y, K0, kend, nullptr, nullptr, false, nullptr, 0, step_ok);
+  panel_phase(ctx, s, A, n, lda, img, y, K0, kend, nullptr, step && step_ready(ctx, img, kend));
   ctx->img_ready = nullptr;
 }
 
@@ -1565,100 +1099,12 @@ void trsm_rows_wide(hipStream_t s, double *X, long long ld, long long nrows, lon
 // Outer block width as a function of the remaining (trailing) size.  Wide blocks (K = 512) keep
 // the bulk update's C traffic off the HBM roofline and its MFMA efficiency up; narrow blocks
 // shorten the serial panel chain per step.  With the current panel kernels the choice barely
-// matters at N = 16384 (scripts/sweep_nbo.sh: 27.3-27.8 fits/s for every split at or below
-// 4096); 512 is kept until 2048 rows remain.  AGP_NBO_SWITCH="m512,m256" overrides (remaining
-// size above which 512 / 256 is used).
-static void nbo_thresholds(long long *m512, long long *m256) {
-  static long long t512 = -1, t256 = -1;
-  if (t512 < 0) {
-    t512 = 2048; t256 = 1024;
-    if (const char *e = getenv("AGP_NBO_SWITCH")) {
-      long long a = 0, b = 0;
-      if (sscanf(e, "%lld,%lld", &a, &b) == 2) { t512 = a; t256 = b; }
-    }
-  }
-  *m512 = t512; *m256 = t256;
-}
-
+// matters at N = 16384 (scripts/sweep_nbo.sh: every split at or below 4096 within 1 %).
 static long long pick_nbo(long long remaining, long long override_nbo = 0) {
   if (override_nbo > 0) return override_nbo;
-  if (panel_fused_enabled() && remaining <= upd_below()) return NB;  // update-ahead panel kernel: one panel per step
-  long long m512, m256;
-  nbo_thresholds(&m512, &m256);
-  if (remaining > m512) return 512;
-  if (remaining > m256) return 256;
+  if (remaining > NBO_512_ABOVE) return 512;
+  if (remaining > NBO_256_ABOVE) return 256;
   return NB;
-}
-
-// Remaining size below which the bulk update U2(j) is held back until U1(j) has finished
-// (AGP_U1_FIRST; default 0 = never: measured no gain on MI355X).
-static long long u1_first_below() {
-  static long long v = -1;
-  if (v < 0) {
-    const char *e = getenv("AGP_U1_FIRST");
-    v = e ? atoll(e) : 0;
-  }
-  return v;
-}
-
-// Remaining size at or below which U2 launches are held back on the HOST until their panel has finished
-// (AGP_THROTTLE_BELOW, 0 = never; see factor_lower)
-static long long throttle_below() {
-  static long long v = -1;
-  if (v < 0) {
-    const char *e = getenv("AGP_THROTTLE_BELOW");
-    v = e ? atoll(e) : 8192;
-  }
-  return v;
-}
-
-static long long u1_split_below() {
-  static long long v = -1;
-  if (v < 0) {
-    const char *e = getenv("AGP_U1_SPLIT_BELOW");
-    v = e ? atoll(e) : 0;  // off: measured 33.8-34.0 against 33.75 ms (the event packets cost what the overlap gains)
-  }
-  return v;
-}
-
-static long long u1_f32_above() {
-  static long long v = -1;
-  if (v < 0) {
-    const char *e = getenv("AGP_U1_F32_ABOVE");
-    v = e ? atoll(e) : 4096;
-    if (v == 0) v = 1LL << 60;  // 0: never
-  }
-  return v;
-}
-
-// Remaining rows above which U1 is merged into the bulk update (see factor_lower); AGP_MERGE_ABOVE, default 0 = off.
-// Measured (scripts/sweep_merge.sh, profiles/r03/sweep_merge.txt): with 8704 the bulk kernel runs at 46.5 instead of
-// 43.1 TFLOP/s (0.59 instead of 0.55 of the datasheet peak) - and the fit takes 33.9 instead of 33.7 ms, three runs each:
-// before, U1 rode along on the chain stream at 5 TFLOP/s on top of the bulk update's 43, and 48 TFLOP/s is what the
-// fp64 matrix pipe issues at 2.37 GHz whoever asks.  The bulk-bound phase is AT that ceiling either way.
-constexpr int MERGE_SLOTS = 1024;  // one counter per outer step of a factorisation (N <= 524288 at 512 columns per step)
-static long long merge_above() {
-  const char *e = getenv("AGP_MERGE_ABOVE");
-  return e ? atoll(e) : 0;
-}
-
-static long long single_below() {
-  static long long v = -1;
-  if (v < 0) {
-    const char *e = getenv("AGP_SINGLE_BELOW");
-    v = e ? atoll(e) : 1536;
-  }
-  return v;
-}
-
-// Remaining size at or below which the bulk updates run on the CU-masked stream (AGP_MASK_BELOW, 0 = never)
-static long long mask_below() {
-  static long long v = -1;
-  if (v < 0) {
-    const char *e = getenv("AGP_MASK_BELOW");
-    v = e ? atoll(e) : 8704;
-  }
-  return v;
 }
 
 // Right-looking LL^T with one outer block of look-ahead on two streams:
@@ -1678,42 +1124,21 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   long long kend = K0 + pick_nbo(n, nbo_fixed);
   if (kend > n) kend = n;
   panel_fused_prepare(ctx, sa, invd, 0, n, true);
-  // the chain-bound tail as one launch per panel on this stream (panel_phase step_mode) once `remaining` rows are left
-  // (the row workgroups of a step launch wait for trailing workgroups that are dispatched AFTER them: all critical workgroups -
-  // 10 + one per 64 rows - and some trailing ones must fit on the chip at once, two per CU, or they would wait for their
-  // 2 s time-out; a small partition of the GPU does not use the step launches)
-  auto step_ok = [&](long long remaining) {
-    return nbo_fixed == 0 && remaining <= step_below() && 2LL * ctx->cus >= 10 + remaining / 64 + 64 && panel_fused_enabled() && ctx->d_dpub && ctx->dpub_cap * NB >= n &&
-           ctx->d_zpub && ctx->img_ready == invd && ctx->zpub_ready_n >= n;
-  };
+  // the chain-bound tail as one launch per panel on this stream (panel_phase step_mode) once few enough rows are left
+  auto step_ok = [&](long long remaining) { return nbo_fixed == 0 && step_fits(ctx, remaining) && step_ready(ctx, invd, n); };
   const bool step_all = step_ok(n);  // small matrix: every panel
   if (step_all) kend = n;
-  long long step_index = 0;
-  if (merge_above() > 0 && n > merge_above()) {
-    if (!ctx->d_merge_cnt && hipMalloc(&ctx->d_merge_cnt, sizeof(unsigned long long) * MERGE_SLOTS) != hipSuccess) {
-      (void)hipGetLastError();
-      ctx->d_merge_cnt = nullptr;
-    }
-    // (the bulk stream's first launch waits for an event recorded on this stream after this memset)
-    if (ctx->d_merge_cnt) (void)hipMemsetAsync(ctx->d_merge_cnt, 0, sizeof(unsigned long long) * MERGE_SLOTS, sa);
-  }
-  panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers, nullptr, false, nullptr, 0, step_all);
+  panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers, step_all);
   while (kend < n) {
     long long next_end = kend + pick_nbo(n - kend, nbo_fixed);
     if (next_end > n) next_end = n;
-    // The very end runs on ONE stream: with <= AGP_SINGLE_BELOW rows left the bulk updates are 10-20 us launches, less
-    // than the ~10 us of event record / wait packets that hand each of them to the second stream and back - so the last
-    // outer block spans all remaining columns: U1 covers everything, its panels update the whole trailing triangle
-    // right-looking, nothing leaves the chain stream
+    // The very end runs on ONE stream: the last outer block spans all remaining columns - as step launches (U1 below
+    // becomes the hand-over update of the whole trailing matrix), or, where those are off, with <= SINGLE_BELOW rows left:
+    // there the bulk updates are 10-20 us launches, less than the ~10 us of event record / wait packets that hand each
+    // of them to the second stream and back
     const long long K = kend - K0;
-    // Update-ahead steps (chain-bound tail): the previous panel [K0, kend) is ONE 128-column panel and its update of the
-    // next 128 columns is folded into that panel's own launch - no U1 launch, no kernel boundary between "rows
-    // updated" and "diagonal block factored"; U2 (depth 128) covers everything right of the next panel.
-    const bool upd = nbo_fixed == 0 && K == NB && (n - kend) <= upd_below() && panel_fused_enabled() && ctx->d_dpub &&
-                     ctx->d_zpub && ctx->img_ready == invd && ctx->zpub_ready_n >= n;
-    const bool step = !upd && step_ok(n - kend);
-    if (upd) next_end = (kend + NB < n) ? kend + NB : n;
-    else if (step || (nbo_fixed == 0 && n - kend <= single_below())) next_end = n;
+    const bool step = step_ok(n - kend);
+    if (step || (nbo_fixed == 0 && n - kend <= SINGLE_BELOW)) next_end = n;
     if (ctx->bs_W && ctx->bs_done == 0 && next_end == n && ctx->ev_inv && ctx->stream2) {
       // Last step: everything left of kend is final and the second stream has nothing more to do - it inverts the wide
       // diagonal blocks the backward substitution of the fit will need (all but the last ones), off the chain.
@@ -1732,44 +1157,10 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     }
     const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
-    // U1: block column [kend, next_end), all rows below its diagonal.  In the chain-bound phase only its first 128
-    // columns - all the next diagonal block and its panel wait for - stay on the chain; the other columns go to the side
-    // stream and are awaited right after the first panel kernel of P(j + 1) (AGP_U1_SPLIT_BELOW remaining rows).
-    hipEvent_t after_first = nullptr;
-    // Merged trailing update (bulk-bound phase, AGP_MERGE_ABOVE remaining rows): U1 is NOT a launch of its own on the
-    // chain stream - the bulk update on the second stream covers the next block column too, as its FIRST tile columns,
-    // writes them with device-scope stores and counts them; the next panel's POTRF waits for that count inside the
-    // kernel.  The 9 % of the factorisation's flop that U1 carries then run at the bulk kernel's efficiency (128 x 128
-    // tiles, MfmaUtil 0.67) instead of the 64 x 64-tile kernel's (0.40), and nothing but POTRF / TRSM / the inner
-    // updates shares the chip with the bulk update.
-    const long long dcols = (next_end - kend) / NB;
-    const bool merged = !upd && next_end < n && (next_end - kend) % NB == 0 && variant < 0 && nbo_fixed == 0 && ctx->d_merge_cnt &&
-                        merge_above() > 0 && (n - kend) > merge_above() &&
-                        trailing_update_full_tiles(n - kend) >= dcols * ((n - kend + NB - 1) / NB);
-    unsigned long long *mcnt = nullptr, mwait = 0;
-    if (merged) {
-      mcnt = ctx->d_merge_cnt + (step_index % MERGE_SLOTS);
-      const long long ntr = (n - kend + NB - 1) / NB;
-      for (long long bj = 0; bj < dcols; ++bj) mwait += (unsigned long long)(ntr - bj);
-    }
-    ++step_index;
-    // (U2(j - 1) must be done before anything of step j touches the next block column - except in merged mode, where the
-    // bulk stream's own order does that and the chain waits for the counted tiles only)
-    if (have_u2 && !merged) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
-    if (merged) {
-      // nothing on the chain stream
-    } else if (upd) {
-      // nothing here: panel_phase(..., upd_prev = true) below applies it
-    } else if (ctx->stream_side && next_end - kend > NB && (n - kend) <= u1_split_below()) {
-      hipStream_t sc = ctx->stream_side;
-      (void)hipStreamWaitEvent(sc, ctx->ev_a, 0);
-      if (have_u2) (void)hipStreamWaitEvent(sc, ctx->ev_b, 0);
-      timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, NB, K, false);
-      const double *P2 = P + NB;  // rows kend + NB .. of the panel
-      timed_gemm(sc, timers, A + (kend + NB) * lda + (kend + NB), lda, P2, P2, n - kend - NB, next_end - kend - NB, K, false);
-      (void)hipEventRecord(ctx->ev_d, sc);
-      after_first = ctx->ev_d;
-    } else if (variant == 3 && (n - kend) >= u1_f32_above()) {
+    // U2(j - 1) must be done before anything of step j touches the next block column
+    if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
+    // U1: block column [kend, next_end), all rows below its diagonal
+    if (variant == 3 && (n - kend) >= U1_F32_ABOVE) {
       // mixed precision: U1 on the fp32 MFMA path like the bulk update (products of fp32-rounded panels, fp64
       // subtraction) while the block column is tall enough for 128 x 128 tiles to fill the chip
       launch_update_f32(sa, A + kend * lda + kend, lda, P, P, lda, n - kend, next_end - kend, K);
@@ -1789,128 +1180,30 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     // kernel takes all 160 KB of LDS) keeps the panel kernels - 75-79 KB of LDS per workgroup - out until its grid has
     // drained: POTRF took 400-500 us instead of 30 (profiles/r02), panel chain and bulk update ran one after the
     // other.  With a few CUs per XCD left free the two overlap.
-    sb = (ctx->stream_masked && (n - kend) <= mask_below()) ? ctx->stream_masked : ctx->stream2;
+    sb = (ctx->stream_masked && (n - kend) <= MASK_BELOW) ? ctx->stream_masked : ctx->stream2;
     if (sb != sb_prev && have_u2) (void)hipStreamWaitEvent(sb, ctx->ev_b, 0);  // U2(j - 1) ran on the other bulk stream
     sb_prev = sb;
-    const bool throttle = next_end < n && (n - kend) <= throttle_below();
-    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd, mcnt, mwait, step);
+    const bool throttle = next_end < n && (n - kend) <= THROTTLE_BELOW;
+    if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, step);
     if (next_end < n) {
       if (throttle) {
         while (hipEventQuery(ctx->ev_a) == hipErrorNotReady) {}
-      } else if (n - kend <= u1_first_below()) {
-        // late phase: the panel chain is the critical path.  Let U1 have the chip to itself
-        // (tens of microseconds) instead of sharing it with the bulk update it is launched with.
-        (void)hipEventRecord(ctx->ev_c, sa);
-        (void)hipStreamWaitEvent(sb, ctx->ev_c, 0);
       } else {
         (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       }
-      if (merged) {
-        const double *Q = A + K0 * lda + kend;  // everything right of block j, the next block column first
-        timed_gemm(sb, timers, A + kend * lda + kend, lda, Q, Q, n - kend, n - kend, K, true, variant, mcnt, (int)dcols);
-      } else {
-        const double *Q = A + K0 * lda + next_end;
-        timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant);
-      }
+      const double *Q = A + K0 * lda + next_end;
+      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant);
       (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;
     } else {
       have_u2 = false;
     }
-    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, after_first, upd, mcnt, mwait, step);
+    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, step);
     K0 = kend;
     kend = next_end;
   }
   // the panel stream ran last (its final panel depends on every update)
   ctx->img_ready = nullptr;
-}
-
-// ---------------------------------------------------------------------------
-// multi-RHS triangular solves (K4): B <- L^-1 B and B <- L^-T B
-// ---------------------------------------------------------------------------
-void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
-                       double *B, long long m, long long ldb, bool rhs_lower) {
-  // rhs_lower: column j of B is zero above row j (e.g. the identity): block row
-  // k then only has work in its first k + nbk columns (N^3/3 instead of N^3 flop)
-  if (m <= 0) return;
-  for (long long K0 = 0; K0 < n; K0 += NBO) {
-    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
-    for (long long k = K0; k < kend; k += NB) {
-      const int nbk = (int)((n - k < NB) ? n - k : NB);
-      TrsmArgs t;
-      t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
-      t.nbk = nbk;
-      t.Y = B + k;
-      t.stride_m = 1; t.stride_n = ldb;
-      const long long m_act = (rhs_lower && k + nbk < m) ? k + nbk : m;
-      t.ncols = m_act;
-      t.z = nullptr; t.yrest = nullptr;
-      t.batch_img = t.batch_Y = 0; t.n_total = 0;
-      hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m_act + 63) / 64)), dim3(256), 0, s, t);
-      const long long rows = kend - (k + nbk);
-      if (rows > 0)  // B[k+nbk : kend] -= L[k+nbk : kend, k : k+nbk] B[k : k+nbk]
-        launch_gemm_nt_sub(s, B + k + nbk, ldb, A + k * lda + (k + nbk), lda, false, B + k, ldb, true, rows, m_act,
-                           nbk, false);
-    }
-    if (kend < n) {  // B[kend :] -= L[kend :, K0 : kend] B[K0 : kend]
-      const long long m_act = (rhs_lower && kend < m) ? kend : m;
-      launch_gemm_nt_sub(s, B + kend, ldb, A + K0 * lda + kend, lda, false, B + K0, ldb, true, n - kend, m_act,
-                         kend - K0, false);
-    }
-  }
-}
-
-// The same substitution with one outer block of look-ahead on the context's two streams (like
-// factor_lower): the solve of block rows j + 1 (small, latency-bound launches) runs on the main
-// stream while the update of everything below with block j's solution (the MFMA-bound bulk) runs on
-// the second one.  Returns with the main stream ordered after all work.
-void forward_solve_mat_lookahead(agp_context *ctx, const double *A, long long n, long long lda, const double *invd,
-                                 double *B, long long m, long long ldb, bool rhs_lower) {
-  if (m <= 0) return;
-  hipStream_t sa = ctx->stream, sb = ctx->stream2;
-  if (n <= 2 * NBO || !sb || m < 64) {  // too small for the second stream to pay for its events
-    forward_solve_mat(sa, A, n, lda, invd, B, m, ldb, rhs_lower);
-    return;
-  }
-  bool have_u2 = false;
-  for (long long K0 = 0; K0 < n; K0 += NBO) {
-    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
-    for (long long k = K0; k < kend; k += NB) {
-      const int nbk = (int)((n - k < NB) ? n - k : NB);
-      TrsmArgs t;
-      t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
-      t.nbk = nbk;
-      t.Y = B + k;
-      t.stride_m = 1; t.stride_n = ldb;
-      const long long m_act = (rhs_lower && k + nbk < m) ? k + nbk : m;
-      t.ncols = m_act;
-      t.z = nullptr; t.yrest = nullptr;
-      t.batch_img = t.batch_Y = 0; t.n_total = 0;
-      hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m_act + 63) / 64)), dim3(256), 0, sa, t);
-      const long long rows = kend - (k + nbk);
-      if (rows > 0)
-        launch_gemm_nt_sub(sa, B + k + nbk, ldb, A + k * lda + (k + nbk), lda, false, B + k, ldb, true, rows, m_act,
-                           nbk, false);
-    }
-    if (kend >= n) break;
-    const long long next_end = (kend + NBO < n) ? kend + NBO : n;
-    const long long m_act = (rhs_lower && kend < m) ? kend : m;
-    (void)hipEventRecord(ctx->ev_a, sa);                      // block j solved
-    if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);  // U2(j - 1) done: it wrote the rows U1(j) writes
-    // U1(j): the next block's rows
-    launch_gemm_nt_sub(sa, B + kend, ldb, A + K0 * lda + kend, lda, false, B + K0, ldb, true, next_end - kend, m_act,
-                       kend - K0, false);
-    if (next_end < n) {
-      (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
-      launch_gemm_nt_sub(sb, B + next_end, ldb, A + K0 * lda + next_end, lda, false, B + K0, ldb, true, n - next_end,
-                         m_act, kend - K0, false);
-      (void)hipEventRecord(ctx->ev_b, sb);
-      have_u2 = true;
-    } else {
-      have_u2 = false;
-    }
-  }
-  if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
 }
 
 // `count` independent n x n factorisations in lock step (blockIdx.y = problem): the blocks of a sparse
@@ -1948,329 +1241,6 @@ void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long lon
     launch_gemm_nt_sub_batched(s, A + (k + nbk) * lda + (k + nbk), lda, stride_A, P, lda, false, stride_A, P, lda, false,
                                stride_A, below, below, nbk, true, count);
   }
-}
-
-// B_b (n x m, ldb) <- L_b^-1 B_b for `count` problems (B_b = B + b * stride_B); rhs_lower as in forward_solve_mat
-void forward_solve_mat_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
-                               const double *invd, long long stride_invd, double *B, long long stride_B, long long m,
-                               long long ldb, bool rhs_lower, long long count) {
-  if (m <= 0 || count <= 0) return;
-  for (long long k = 0; k < n; k += NB) {
-    const int nbk = (int)((n - k < NB) ? n - k : NB);
-    const long long m_act = (rhs_lower && k + nbk < m) ? k + nbk : m;
-    TrsmArgs t;
-    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
-    t.nbk = nbk;
-    t.Y = B + k;
-    t.stride_m = 1; t.stride_n = ldb;
-    t.ncols = m_act;
-    t.z = nullptr; t.yrest = nullptr;
-    t.batch_img = stride_invd; t.batch_Y = stride_B; t.n_total = 0;
-    hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m_act + 63) / 64), (unsigned)count), dim3(256), 0,
-                       s, t);
-    const long long rows = n - (k + nbk);
-    if (rows > 0)  // B[k + nbk :] -= L[k + nbk :, k : k + nbk] B[k : k + nbk]
-      launch_gemm_nt_sub_batched(s, B + k + nbk, ldb, stride_B, A + k * lda + (k + nbk), lda, false, stride_A, B + k, ldb,
-                                 true, stride_B, rows, m_act, nbk, false, count);
-  }
-}
-
-// X_b (nrows x n, ldx) <- X_b L_b^-T for `count` problems: X_b = X + b * stride_X, L_b = A + b * stride_A
-void right_solve_lt_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
-                            const double *invd, long long stride_invd, double *X, long long stride_X, long long nrows,
-                            long long ldx, long long count) {
-  if (nrows <= 0 || count <= 0) return;
-  for (long long k = 0; k < n; k += NB) {
-    const int nbk = (int)((n - k < NB) ? n - k : NB);
-    TrsmArgs t;
-    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
-    t.nbk = nbk;
-    t.Y = X + k * ldx;
-    t.stride_m = ldx; t.stride_n = 1;
-    t.ncols = nrows;
-    t.z = nullptr; t.yrest = nullptr;
-    t.batch_img = stride_invd; t.batch_Y = stride_X; t.n_total = 0;
-    hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((nrows + 63) / 64), (unsigned)count), dim3(256), 0,
-                       s, t);
-    const long long rest = n - (k + nbk);
-    if (rest > 0)
-      launch_gemm_nt_sub_batched(s, X + (k + nbk) * ldx, ldx, stride_X, X + k * ldx, ldx, false, stride_X,
-                                 A + k * lda + (k + nbk), lda, false, stride_A, nrows, rest, nbk, false, count);
-  }
-}
-
-// X (nrows x n, ldx) <- X L^-T : the panel TRSM of the factorisation applied to a free-standing
-// matrix (sparse GP: K_uf[:, group] L_A^-T = (A^-1/2 K_fu)^T, models/sparse_gp.hpp:347-349).
-void right_solve_lt(hipStream_t s, const double *A, long long n, long long lda, const double *invd, double *X,
-                    long long nrows, long long ldx) {
-  if (nrows <= 0) return;
-  for (long long k = 0; k < n; k += NB) {
-    const int nbk = (int)((n - k < NB) ? n - k : NB);
-    TrsmArgs t;
-    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
-    t.nbk = nbk;
-    t.Y = X + k * ldx;           // Y = X[:, k : k + nbk]^T : element (m, n) at Y[m * ldx + n]
-    t.stride_m = ldx; t.stride_n = 1;
-    t.ncols = nrows;
-    t.z = nullptr; t.yrest = nullptr;
-    t.batch_img = t.batch_Y = 0; t.n_total = 0;
-    hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((nrows + 63) / 64)), dim3(256), 0, s, t);
-    const long long rest = n - (k + nbk);
-    if (rest > 0)  // X[:, k + nbk :] -= X[:, k : k + nbk] L[k + nbk :, k : k + nbk]^T
-      launch_gemm_nt_sub(s, X + (k + nbk) * ldx, ldx, X + k * ldx, ldx, false, A + k * lda + (k + nbk), lda, false,
-                         nrows, rest, nbk, false);
-  }
-}
-
-void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
-                        double *B, long long m, long long ldb) {
-  if (m <= 0 || n <= 0) return;
-  const long long nblk = (n + NB - 1) / NB;
-  for (long long b = nblk - 1; b >= 0; --b) {
-    const long long k = b * NB;
-    const int nbk = (int)((n - k < NB) ? n - k : NB);
-    TrsmArgs t;
-    t.img = invd + b * (long long)IMG_DOUBLES;
-    t.nbk = nbk;
-    t.Y = B + k;
-    t.stride_m = 1; t.stride_n = ldb;
-    t.ncols = m;
-    t.z = nullptr; t.yrest = nullptr;
-    t.batch_img = t.batch_Y = 0; t.n_total = 0;
-    hipLaunchKernelGGL((trsm_micro_kernel<true, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, t);
-    if (k > 0)  // B[0 : k] -= L[k : k+nbk, 0 : k]^T B[k : k+nbk]
-      launch_gemm_nt_sub(s, B, ldb, A + k, lda, true, B + k, ldb, true, k, m, nbk, false);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// one right-hand side: x = L^-T z  (second half of K^-1 y, gp.hpp:68)
-//
-// Right-looking over NB blocks from the bottom.  The diagonal blocks are
-// inverted beforehand by ONE batched launch (all blocks in parallel, off the
-// serial chain), so a step is two short kernels:
-//   x_b = inv(L_bb)^T z_b                      (128 x 128 mat-vec, one workgroup)
-//   z[0:k] -= L[k:k+nb, 0:k]^T x_b             (one wave per 8 columns, coalesced
-//                                               1-KiB column segments)
-// Bandwidth: L is read exactly once (8 N^2 / 2 bytes).  (Tried: two blocks per launch with the
-// three 128 x 128 mat-vecs recomputed in every workgroup - 44 us per launch instead of 2 x 11.)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void set_identity_blocks_kernel(double *W, long long count) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
-  const int within = (int)(i & (NB * NB - 1));
-  W[i] = ((within >> 7) == (within & (NB - 1))) ? 1. : 0.;
-}
-
-// Winv[b] = inv(L_bb)^T as a column-major NB x NB array (i.e. inv(L_bb) row-major), for every diagonal block.
-void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
-                        double *Winv) {
-  const long long nblk = (n + NB - 1) / NB;
-  const long long count = nblk * NB * NB;
-  hipLaunchKernelGGL(set_identity_blocks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, Winv, count);
-  TrsmArgs t;
-  (void)A; (void)lda;
-  t.img = invd; t.nbk = NB;
-  // element (m, n) of inv(L_bb) goes to Winv[m * NB + n]: the blocks are stored TRANSPOSED
-  // (row-major), so that the mat-vec x = inv(L_bb)^T z reads them coalesced
-  t.Y = Winv; t.stride_m = NB; t.stride_n = 1; t.ncols = NB;
-  t.z = nullptr; t.yrest = nullptr;
-  t.batch_img = IMG_DOUBLES; t.batch_Y = NB * NB; t.n_total = n;
-  hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
-}
-
-// Wfwd[b] = inv(L_bb) column-major (element (m, n) at [n * NB + m]): what the FORWARD vector
-// substitution reads coalesced.
-void invert_diag_blocks_forward(hipStream_t s, long long n, const double *invd, double *Wfwd) {
-  const long long nblk = (n + NB - 1) / NB;
-  const long long count = nblk * NB * NB;
-  hipLaunchKernelGGL(set_identity_blocks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, Wfwd, count);
-  TrsmArgs t;
-  t.img = invd; t.nbk = NB;
-  t.Y = Wfwd; t.stride_m = 1; t.stride_n = NB; t.ncols = NB;
-  t.z = nullptr; t.yrest = nullptr;
-  t.batch_img = IMG_DOUBLES; t.batch_Y = NB * NB; t.n_total = n;
-  hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
-}
-
-// One step of the right-looking FORWARD substitution on a vector, ONE launch:
-//   x_b = inv(L_bb) z_b                         (recomputed by every workgroup, as in back_step_kernel)
-//   z[i] -= sum_c L[i][k0 + c] x_b[c]           for this workgroup's 64 rows i >= k0 + nbk
-// (wave w sums columns 32 w .. 32 w + 31, lane = row: coalesced 512-B column segments)
-__global__ __launch_bounds__(256) void fwd_step_kernel(const double *__restrict__ A, long long lda, long long k0,
-                                                       int nbk, long long n, const double *__restrict__ Wfwd,
-                                                       double *__restrict__ z, double *__restrict__ x_out) {
-  __shared__ double xs[NB], part[NB], zs[NB], red[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < NB) zs[tid] = (tid < nbk) ? z[k0 + tid] : 0.;
-  __syncthreads();
-  {
-    // x[c] = sum_r inv(L)[c][r] z[r];  Wfwd holds inv(L)[c][r] at [r * NB + c]
-    const int c = tid & (NB - 1), half = tid >> 7;
-    double acc = 0.;
-#pragma unroll 8
-    for (int r = half * 64; r < half * 64 + 64; ++r) acc += Wfwd[r * NB + c] * zs[r];
-    if (half == 1) part[c] = acc;
-    __syncthreads();
-    if (half == 0) {
-      const double v = (c < nbk) ? acc + part[c] : 0.;
-      xs[c] = v;
-      if (blockIdx.x == 0 && c < nbk) x_out[k0 + c] = v;
-    }
-    __syncthreads();
-  }
-  const long long i = k0 + nbk + (long long)blockIdx.x * 64 + lane;
-  double acc = 0.;
-  if (i < n) {
-    const double *p = A + (k0 + 32 * wave) * lda + i;
-#pragma unroll 8
-    for (int c = 0; c < 32; ++c)
-      if (32 * wave + c < nbk) acc += p[(long long)c * lda] * xs[32 * wave + c];
-  }
-  red[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0 && i < n) z[i] -= (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-}
-
-// z <- L^-1 z for one vector (the fused substitution of the factorisation covers the fit's own y; this
-// one serves the refinement steps of the mixed-precision fit).  xstage: n doubles.
-void forward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Wfwd, double *z,
-                       double *xstage) {
-  const long long nblk = (n + NB - 1) / NB;
-  for (long long b = 0; b < nblk; ++b) {
-    const long long k = b * NB;
-    const int nbk = (int)((n - k < NB) ? n - k : NB);
-    const long long below = n - k - nbk;
-    const unsigned grid = (unsigned)(below > 0 ? (below + 63) / 64 : 1);
-    hipLaunchKernelGGL(fwd_step_kernel, dim3(grid), dim3(256), 0, s, A, lda, k, nbk, n,
-                       Wfwd + b * (long long)(NB * NB), z, xstage);
-  }
-  (void)hipMemcpyAsync(z, xstage, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
-}
-
-// One step of the right-looking back substitution, ONE launch:
-//   x_b = inv(L_bb)^T z_b            (every workgroup recomputes this 128 x 128 mat-vec from the
-//                                     L2-resident transposed inverse: 128 KB, coalesced rows)
-//   z[c] -= sum_r L[k0 + r][c] x_b[r]  for this workgroup's 32 columns c < k0
-// Workgroup 0 also publishes x_b into `x_out` (z_b itself stays untouched: other workgroups may
-// still be reading it).
-__global__ __launch_bounds__(256) void back_step_kernel(const double *__restrict__ A, long long lda, long long k0,
-                                                        int nbk, const double *__restrict__ WinvT,
-                                                        double *__restrict__ z, double *__restrict__ x_out) {
-  __shared__ double xs[NB], part[NB], zs[NB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < NB) zs[tid] = (tid < nbk) ? z[k0 + tid] : 0.;
-  __syncthreads();
-  {
-    // x[c] = sum_r inv(L)[r][c] z[r];  WinvT holds inv(L)[r][c] at [r * NB + c]
-    const int c = tid & (NB - 1), half = tid >> 7;
-    double acc = 0.;
-#pragma unroll 8
-    for (int r = half * 64; r < half * 64 + 64; ++r) acc += WinvT[r * NB + c] * zs[r];
-    if (half == 1) part[c] = acc;
-    __syncthreads();
-    if (half == 0) {
-      const double v = (c < nbk) ? acc + part[c] : 0.;
-      xs[c] = v;
-      if (blockIdx.x == 0 && c < nbk) x_out[k0 + c] = v;
-    }
-    __syncthreads();
-  }
-  const long long c0 = ((long long)blockIdx.x * 4 + wave) * 8;
-  if (c0 >= k0) return;
-  const int r = 2 * lane;
-  const double x0 = xs[r], x1 = xs[r + 1];
-  const bool vec = ((lda & 1) == 0) && ((k0 & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  double acc[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const long long c = c0 + q;
-    double a0 = 0., a1 = 0.;
-    if (c < k0) {
-      const double *p = A + c * lda + k0 + r;
-      if (vec && r + 1 < nbk) {
-        const double2 v = *reinterpret_cast<const double2 *>(p);
-        a0 = v.x; a1 = v.y;
-      } else {
-        a0 = r < nbk ? p[0] : 0.;
-        a1 = r + 1 < nbk ? p[1] : 0.;
-      }
-    }
-    acc[q] = a0 * x0 + a1 * x1;
-  }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (c0 + q < k0) z[c0 + q] -= acc[q];
-  }
-}
-
-// z[c] -= sum_r L[k0 + r][c] x[r]  for c < ncols ; r < nbk.   8 columns per wave.
-__global__ __launch_bounds__(256) void back_update_kernel(const double *__restrict__ A, long long lda,
-                                                          long long k0, int nbk, long long ncols,
-                                                          const double *__restrict__ x, double *__restrict__ z) {
-  // rows k0 .. k0 + nbk of A, columns 0 .. ncols
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long c0 = ((long long)blockIdx.x * 4 + wave) * 8;
-  if (c0 >= ncols) return;
-  const int r = 2 * lane;
-  const double x0 = r < nbk ? x[r] : 0., x1 = r + 1 < nbk ? x[r + 1] : 0.;
-  const bool vec = ((lda & 1) == 0) && ((k0 & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  double acc[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const long long c = c0 + q;
-    double a0 = 0., a1 = 0.;
-    if (c < ncols) {
-      const double *p = A + c * lda + k0 + r;
-      if (vec && r + 1 < nbk) {
-        const double2 v = *reinterpret_cast<const double2 *>(p);
-        a0 = v.x; a1 = v.y;
-      } else {
-        a0 = r < nbk ? p[0] : 0.;
-        a1 = r + 1 < nbk ? p[1] : 0.;
-      }
-    }
-    acc[q] = a0 * x0 + a1 * x1;
-  }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (c0 + q < ncols) z[c0 + q] -= acc[q];
-  }
-}
-
-void launch_back_update(hipStream_t s, const double *A, long long lda, long long k0, int nbk, long long ncols,
-                        const double *x, double *z) {
-  if (ncols <= 0 || nbk <= 0) return;
-  hipLaunchKernelGGL(back_update_kernel, dim3((unsigned)((ncols + 31) / 32)), dim3(256), 0, s, A, lda, k0, nbk,
-                     ncols, x, z);
-}
-
-void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Winv,
-                        double *z, double *xstage) {
-  // z is consumed; the solution is produced in `xstage` (n doubles) block by block and copied
-  // back at the end: x of block b may not overwrite z_b while other workgroups of the same
-  // launch still read z_b
-  const long long nblk = (n + NB - 1) / NB;
-  for (long long b = nblk - 1; b >= 0; --b) {
-    const long long k = b * NB;
-    const int nbk = (int)((n - k < NB) ? n - k : NB);
-    const unsigned grid = (unsigned)(k > 0 ? (k + 31) / 32 : 1);
-    hipLaunchKernelGGL(back_step_kernel, dim3(grid), dim3(256), 0, s, A, lda, k, nbk,
-                       Winv + b * (long long)(NB * NB), z, xstage);
-  }
-  (void)hipMemcpyAsync(z, xstage, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }
 
 }  // namespace agp

@@ -10,14 +10,9 @@
 #include "../../include/albatross_amd.h"
 #include "cov_eval.h"
 
-// Wave priority of the panel-chain kernels (s_setprio) and of the bulk update; compile-time so that
-// scripts/sweep_prio.sh can rebuild the four combinations (measured: see DESIGN.md section 8)
-#ifndef AGP_CHAIN_PRIO
+// Wave priority of the panel-chain kernels (s_setprio); the bulk update stays at 0 (the four combinations were measured:
+// DESIGN.md section 8, profiles/r03/sweep_prio.txt)
 #define AGP_CHAIN_PRIO 3
-#endif
-#ifndef AGP_BULK_PRIO
-#define AGP_BULK_PRIO 0
-#endif
 
 namespace agp {
 
@@ -63,14 +58,11 @@ struct agp_context {
   int device = 0;
   hipStream_t stream = nullptr;   // main chain
   hipStream_t stream2 = nullptr;  // look-ahead / side chain
-  hipStream_t stream3 = nullptr;  // second bulk stream (hybrid MFMA + VALU experiment)
+  hipStream_t stream3 = nullptr;  // host-side control-plane collectives of the RCCL transport (shard_hip.hip)
   // bulk stream restricted to a CU mask (hipExtStreamCreateWithCUMask): in the chain-bound end phase of the
   // factorisation the bulk updates run here and leave a few CUs per XCD to the panel chain (chol.hip: factor_lower)
   hipStream_t stream_masked = nullptr;
   hipEvent_t ev_c = nullptr;
-  // side chain of the factorisation (high priority): the part of U1 the next diagonal block does not wait for
-  hipStream_t stream_side = nullptr;
-  hipEvent_t ev_d = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   std::vector<hipEvent_t> ev_pool;
   std::string last_error;
@@ -116,11 +108,20 @@ struct agp_context {
   double *d_dpub = nullptr;
   long long dpub_cap = 0;  // diagonal blocks
   int cus = 256;  // CUs of the device (hipDeviceAttributeMultiprocessorCount)
-  hipEvent_t ev_step[2] = {nullptr, nullptr};  // step launches: "launch k complete" for the host, alternating
-  unsigned long long *d_farcnt = nullptr;  // per 64 rows: tiles of the NEXT panel's columns finished by the far trailing updates (second stream)
+  long long step_slots = 0;  // workgroups of the panel step kernel the device holds at once (chol.hip: step_slots)
+  // The switches a caller can set through the environment, read ONCE at agp_context_create (api.hip: read_tuning; the
+  // table is in include/albatross_amd.h).  Everything else about the schedule is a constant of the library.
+  struct Tuning {
+    bool panel_fused = true;       // AGP_PANEL_FUSED=0: POTRF and panel TRSM as two launches
+    long long step_below = 4608;   // AGP_STEP_BELOW: remaining rows at or below which every panel is ONE step launch (0: off)
+    bool gram_sop = true;          // AGP_GRAM_SOP=0: covariance trees through the stack interpreter only
+    bool sparse_pivoted = false;   // AGP_SPARSE_PIVOTED=1: the sparse GP's literal (pivoted LDL^T + QR) path always
+    long long predict_chunk = 0;   // AGP_PREDICT_CHUNK: test points per slice of the marginal / joint predictions (0: by memory)
+    long long shard_block = 0;     // AGP_SHARD_BLOCK: 128 / 256 / 512 rows per row block of the sharded fit (0: 512)
+    bool shard_force_comm = false; // AGP_SHARD_FORCE_COMM=1: ONE rank runs the multi-rank schedule through its transport
+    bool shard_host_pacing = false;  // AGP_SHARD_HOST_PACING=1: the sharded schedule is paced by the host (round-3 scheme)
+  } tune;
   unsigned long long *d_rowcnt = nullptr;  // one counter per 64 rows (tail of the d_dpub allocation): hand-over of the step launches' row updates
-  // merged trailing updates (factor_lower): one completion counter per outer step
-  unsigned long long *d_merge_cnt = nullptr;
   // Early inversion of the wide diagonal blocks for the backward substitution of a fit (api.hip: backward_solve_vec_any):
   // set by the caller of factor_lower (bs_W = where the inverses go, bs_BW = their width); factor_lower inverts the
   // blocks that are final when it enters its single-stream tail on the (then idle) second stream, records ev_inv and
@@ -136,7 +137,6 @@ struct agp_context {
   unsigned long long shard_seq[16] = {};
   unsigned long long shard_probe_seq = 0;
   int shard_host_pacing = -1;
-  int shard_hybrid = 0;
   bool shard_probe_ok = false;
 };
 
@@ -247,15 +247,11 @@ void launch_gemv_t(hipStream_t s, const double *A, long long lda, long long n, l
                    const double *x, double *y);
 void launch_dot(hipStream_t s, const double *a, const double *b, long long n, double *out);
 
-int mfma_f64_peak(hipStream_t s, int iters, double *tflops);
-
 }  // namespace agp
 
 namespace agp {
 // C(M x N) -= A(M x K) * B(N x K)^T  (fp64 MFMA).  a_kmajor / b_kmajor select
 // transposed operand storage; tri keeps only tiles on/below C's diagonal.
-void launch_update64_counted(hipStream_t s, double *C, long long ldc, const double *P, long long ldp, long long M, long long K,
-                             unsigned long long *done, int done_cols);
 void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
                         bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
                         long long N, long long K, bool tri);
@@ -272,8 +268,7 @@ struct BulkTiming {
 };
 void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
                                const double *Q, long long ldp, long long M, long long K,
-                               BulkTiming *timing = nullptr, unsigned long long *done = nullptr, int done_cols = 0);
-long long trailing_update_full_tiles(long long M);
+                               BulkTiming *timing = nullptr);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
 void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P, const double *Q, long long ldp, long long M,

@@ -8,12 +8,14 @@
 #include "common.h"
 #include "api_internal.h"
 #include "mfma_f64.h"
+#include "shard_internal.h"
+#include <cstdlib>
+#include <cstring>
+#include <new>
 
 #define AGP_DEBUG_API __attribute__((visibility("default")))
 
 namespace agp {
-void read_valu_clock(unsigned long long out[4], bool reset);
-void read_mfma_clock(unsigned long long out[4], bool reset);
 
 __global__ void mfma_tile_kernel(const double *A, const double *B, double *D) {
   const int l = threadIdx.x;
@@ -215,13 +217,6 @@ extern "C" AGP_DEBUG_API int agp_debug_exp_neg(agp_context *ctx, const double *t
 
 // {sum of shader-clock cycles, sum of 100 MHz ticks, workgroups} of the trailing_update_kernel launches since the last
 // reset (a library built with -DAGP_CLOCK_PROBE; zeros otherwise)
-extern "C" AGP_DEBUG_API int agp_debug_mfma_kernel_clock(unsigned long long *out, int reset) {
-  if (!out) return AGP_ERR_INVALID_ARGUMENT;
-  agp::read_mfma_clock(out, reset != 0);
-  return AGP_OK;
-}
-
-// out = alpha K p + beta base with K symmetric, given by its lower triangle (host arrays): reduce.hip launch_symv_lower
 extern "C" AGP_DEBUG_API int agp_debug_symv_lower(agp_context *ctx, const double *K, int64_t n, int64_t ld, const double *p,
                                                   double alpha, double beta, const double *base, double *out) {
   if (!ctx || !K || !p || !out || n <= 0 || ld < n) return AGP_ERR_INVALID_ARGUMENT;
@@ -382,15 +377,6 @@ extern "C" AGP_DEBUG_API int agp_debug_panel_chain(agp_context *ctx, int64_t n, 
   }
   return AGP_OK;
 }
-
-#ifdef AGP_POTRF_TIMING
-namespace agp { void read_potrf_timing(unsigned long long *out); }
-extern "C" AGP_DEBUG_API int agp_debug_potrf_timing(unsigned long long *out) { read_potrf_timing(out); return 0; }
-namespace agp { void read_step_timing(unsigned long long *out, bool reset); void read_row_timing(unsigned long long *out); void set_row_target(long long v); }
-extern "C" AGP_DEBUG_API int agp_debug_row_target(long long v) { set_row_target(v); return 0; }
-extern "C" AGP_DEBUG_API int agp_debug_row_timing(unsigned long long *out) { read_row_timing(out); return 0; }
-extern "C" AGP_DEBUG_API int agp_debug_step_timing(unsigned long long *out, int reset) { read_step_timing(out, reset != 0); return 0; }
-#endif
 
 extern "C" {
 
@@ -723,12 +709,6 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
   float ms = 0.f;
   AGP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
   *ms_out = (double)ms / reps;
-  {
-    unsigned long long c[4];
-    read_valu_clock(c, true);
-    if (c[2]) fprintf(stderr, "  [dpp kernel] main loop per workgroup: %.0f cycles, clock %.3f GHz, %.1f cycles per k-step (K=%lld)\n",
-                      (double)c[0] / c[2], (double)c[0] / ((double)c[1] * 10.0), (double)c[0] / c[2] / (double)K, (long long)K);
-  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(dC); (void)hipFree(dP);
   return st;
@@ -764,6 +744,81 @@ AGP_DEBUG_API int agp_debug_factor(agp_context *ctx, double *A, int64_t n, int64
   if (bad_pivot) *bad_pivot = flags[1] ? flags[1] - 1 : -1;
   (void)hipFree(dA); (void)hipFree(dI);
   if (dy) (void)hipFree(dy);
+  return AGP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Test / measurement instrumentation that used to sit in the product library's ABI
+// ---------------------------------------------------------------------------------------------------------------
+namespace agp {
+// ---- bare MFMA issue loop: measured fp64 matrix peak of this device ----------
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double *sink, int iters, double a0, double b0) {
+  v4d acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = v4zero();
+  double a = a0 + threadIdx.x * 1e-9, b = b0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = mfma16(a, b, acc[i]);
+  }
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456) sink[0] = s;  // keep the loop live
+}
+
+static int mfma_f64_peak(hipStream_t s, int iters, double *tflops) {
+  double *sink = nullptr;
+  if (hipMalloc(&sink, 8) != hipSuccess) return AGP_ERR_HIP;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int blocks = 256 * 2;  // 2 workgroups of 4 waves per CU: 2 waves per SIMD
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, sink, 16, 1.0, 2.0);
+  (void)hipEventRecord(e0, s);
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, sink, iters, 1.0, 2.0);
+  (void)hipEventRecord(e1, s);
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double flop = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+  *tflops = flop / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  return e == hipSuccess ? AGP_OK : AGP_ERR_HIP;
+}
+
+// A transport that moves nothing: times ONE rank's share of a G-rank sharded fit on a box with one GPU - same kernels,
+// same shapes, same launch chain; the peers' data is whatever the buffers hold, so the numerical result is
+// meaningless (scripts/time_sharded_rank.py).
+struct NullComm : HostReducingComm {
+  int broadcast(ShardOps &, int, double *, long long, int) override { return AGP_OK; }
+  int all_gather(ShardOps &, int, const double *, double *, long long) override { return AGP_OK; }
+  int all_reduce(ShardOps &, int, double *, long long, int) override { return AGP_OK; }
+  int all_reduce_host(double *, long long, int) override { return AGP_OK; }
+};
+}  // namespace agp
+
+extern "C" {
+
+AGP_DEBUG_API int agp_debug_mfma_f64_peak(agp_context *ctx, int iters, double *tflops) {
+  if (!ctx || !tflops || iters <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return mfma_f64_peak(ctx->stream, iters, tflops);
+}
+
+AGP_DEBUG_API int agp_debug_comm_create_null(int nranks, int rank, agp_comm **out) {
+  if (!out || nranks < 1 || rank < 0 || rank >= nranks) return AGP_ERR_INVALID_ARGUMENT;
+  NullComm *c = new (std::nothrow) NullComm();
+  agp_comm *h = new (std::nothrow) agp_comm();
+  if (!c || !h) { delete c; delete h; return AGP_ERR_INVALID_ARGUMENT; }
+  c->world = nranks;
+  c->rank = rank;
+  h->impl = c;
+  *out = h;
   return AGP_OK;
 }
 

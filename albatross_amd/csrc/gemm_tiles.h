@@ -22,11 +22,7 @@ struct GemmArgs {
   long long M, N, K;
   int tri;  // skip tiles strictly above the diagonal of C
   int ntr, ntc;
-  // XCD-aware order (bulk update only): workgroups b, b+8, b+16, ... share an
-  // XCD (round-robin dispatch); the 64 that run there together are dealt one
-  // 8 x 8 super-tile of C, so they share 8 row strips and 8 column strips of
-  // the panel in that XCD's L2.  nsuper = number of lower super-tiles.
-  int remap, nsuper, nb8;
+  int a_kmajor = 0;  // gemm64_nt_sub_bk_kernel only: the A operand is stored transposed too
   // batched launches (blockIdx.y = batch entry): element offsets per entry; 0 = not batched
   long long batch_C = 0, batch_A = 0, batch_B = 0;
   long long tile_first = 0;  // first tile (in column-major tile order) of this launch: split bulk updates
@@ -35,22 +31,8 @@ struct GemmArgs {
   // tile columns up to its own diagonal tile: bj <= gi * st_tpb - st_c0t + bi % st_tpb.  stair == 0: off.
   int stair = 0, st_world = 1, st_rank = 0, st_tpb = 4;
   long long st_lb0 = 0, st_c0t = 0;
-  // merged trailing update (chol.hip: factor_lower): the tiles of the first done_cols tile columns - the NEXT block
-  // column, which the panel chain waits for - are written with device-scope stores and counted in *done when complete,
-  // so that the next panel's POTRF (another launch, another stream) can start on them while this launch is still busy
-  // with everything further right.  done == nullptr: off.
-  unsigned long long *done = nullptr;
-  int done_cols = 0;
-  // 64 x 64-tile kernel, far trailing update of a step launch (chol.hip: panel_phase): the tiles of the first done64_cols
-  // tile columns - the next panel's columns - are written with device-scope stores and counted per ROW tile in
-  // done64[bi] when complete; the next step launch, on another stream, waits for those counts.  nullptr: off.
-  unsigned long long *done64 = nullptr;
-  int done64_cols = 0;
 };
 
-#ifndef AGP_GEMM_4X4
-#define AGP_GEMM_4X4 0  // 1: 128 x 128 kernels on v_mfma_f64_4x4x4 with DPP-rotated fragments (same speed)
-#endif
 
 // Load this thread's 8 doubles of a 128 x 16 operand chunk.
 //   !KMAJOR: element (row, k) at P[row + k * ld]   (panel stored like the matrix)
@@ -123,7 +105,6 @@ __device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const doubl
 template <bool A_KMAJOR, bool B_KMAJOR>
 __device__ __forceinline__ void gemm_nt_sub_tile(const GemmArgs &g, const int bi, const int bj, double *lds) {
   const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
-  const bool counted = g.done != nullptr && bj < g.done_cols;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -164,30 +145,10 @@ __device__ __forceinline__ void gemm_nt_sub_tile(const GemmArgs &g, const int bi
         fa[t] = Bs[krow + 64 * wc + 16 * t + ln];  // MFMA A operand: C-column panel (negated)
         fb[t] = As[krow + 64 * wr + 16 * t + ln];  // MFMA B operand: C-row panel
       }
-#if AGP_GEMM_4X4
-      // four 4x4x4 products per 16 x 16 tile: block b pairs column group (b + ra) with row group (b + rb),
-      // (ra, rb) = (0,0), (1,0), (0,2), (1,2): all 16 group pairs; the rotated fragments come from DPP
-      double fa1[4], fb2[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fa1[t] = rotate_groups<1>(fa[t]);
-        fb2[t] = rotate_groups<2>(fb[t]);
-      }
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          acc[tj][ti][0] = mfma4(fa[tj], fb[ti], acc[tj][ti][0]);
-          acc[tj][ti][1] = mfma4(fa1[tj], fb[ti], acc[tj][ti][1]);
-          acc[tj][ti][2] = mfma4(fa[tj], fb2[ti], acc[tj][ti][2]);
-          acc[tj][ti][3] = mfma4(fa1[tj], fb2[ti], acc[tj][ti][3]);
-        }
-#else
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
-#endif
     }
     if (more) {
       double *An = lds + (cur ^ 1) * (2 * GK * GLD);
@@ -202,34 +163,16 @@ __device__ __forceinline__ void gemm_nt_sub_tile(const GemmArgs &g, const int bi
   for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
-#if !AGP_GEMM_4X4
       const long long row = i0 + 64 * wr + 16 * ti + ln;
-#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#if AGP_GEMM_4X4
-        // accumulator r = (ra, rb) = (r & 1, r & 2): lane (ln = 4 lq + lr, lg) holds
-        // C[row 4 ((lq + rb) & 3) + lr][col 4 ((lq + ra) & 3) + lg] of the 16 x 16 tile
-        const int lq = ln >> 2, lr = ln & 3;
-        const long long row = i0 + 64 * wr + 16 * ti + 4 * ((lq + (r & 2)) & 3) + lr;
-        const long long col = j0 + 64 * wc + 16 * tj + 4 * ((lq + (r & 1)) & 3) + lg;
-#else
         const long long col = j0 + 64 * wc + 16 * tj + lg + 4 * r;
-#endif
         if (row < g.M && col < g.N) {
           double *c = g.C + row + col * g.ldc;
-          const double v = *c + acc[tj][ti][r];
-          if (counted) __hip_atomic_store(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the XCD-private L2
-          else *c = v;
+          *c = *c + acc[tj][ti][r];
         }
       }
     }
-  if (counted) {
-    // every store of this tile acknowledged, then one count: a reader that sees the full count reads final values
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(g.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -374,7 +317,6 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
       __syncthreads();
     }
   }
-  const bool counted = g.done64 != nullptr && j0 < (long long)g.done64_cols * ST;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
@@ -383,18 +325,9 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long col = j0 + 32 * wc + 16 * tj + lg + 4 * r;
-        if (row < g.M && col < g.N) {
-          if (counted) __hip_atomic_store(g.C + row + col * g.ldc, acc[tj][ti][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else g.C[row + col * g.ldc] = acc[tj][ti][r];
-        }
+        if (row < g.M && col < g.N) g.C[row + col * g.ldc] = acc[tj][ti][r];
       }
     }
-  if (counted) {
-    // every store of this tile acknowledged, then one count: a reader that sees the count reads final values
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(g.done64 + i0 / ST, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 

@@ -364,11 +364,8 @@ static bool build_sop(const DevProgram &H, SopProgram *out) {
   return true;
 }
 
-static bool sop_enabled() {
-  // read per call (a getenv is nothing next to a launch): the parity tests switch evaluators in one process
-  const char *e = getenv("AGP_GRAM_SOP");  // 0: always the postfix interpreter
-  return !(e && e[0] == '0');
-}
+bool gram_sop_enabled();  // api.hip: AGP_GRAM_SOP of the context created last (0: always the postfix interpreter)
+static bool sop_enabled() { return gram_sop_enabled(); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Second fast path: sums of AT MOST three terms of fixed kinds,
@@ -619,12 +616,7 @@ void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const Fe
     // needs no special handling)
     FastParams fp;
     int op = 0;
-    static int fast_on = -1;
-    if (fast_on < 0) {
-      const char *e = getenv("AGP_GRAM_FAST");
-      fast_on = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (fast_on && match_fast(*host_program, &fp, &op)) {
+    if (sop_enabled() && match_fast(*host_program, &fp, &op)) {
       bool done = false;
       if (dim == 1) done = launch_gram_fast_t<1>(s, fp, op, X, Y, lower_only, out, ld, diag_add, nan_flag);
       else if (dim == 2) done = launch_gram_fast_t<2>(s, fp, op, X, Y, lower_only, out, ld, diag_add, nan_flag);
@@ -634,10 +626,9 @@ void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const Fe
   }
   if (host_program && dim <= 3 && sop_enabled()) {
     // (every term of these shapes is bitwise symmetric in its arguments too)
-    const char *e = getenv("AGP_GRAM_PAIR2");
     SopProgram sop;
     Pair2Params pp;
-    if (!(e && e[0] == '0') && build_sop(*host_program, &sop) && match_pair2(sop, &pp)) {
+    if (build_sop(*host_program, &sop) && match_pair2(sop, &pp)) {
       dim3 grid((unsigned)((X.n + TM - 1) / TM), (unsigned)((Y.n + TN - 1) / TN)), block(GRAM_THREADS);
       const int lo = lower_only ? 1 : 0;
       const bool eu = (pp.metric_mask & (1 << AGP_METRIC_EUCLIDEAN)) != 0, an = (pp.metric_mask & (1 << AGP_METRIC_ANGULAR)) != 0;
@@ -821,8 +812,7 @@ void launch_predict_mean(hipStream_t s, const DevProgram *P, const FeatView &X, 
   if (host_program && X.dim <= 3 && X.dim == XS.dim) {
     FastParams fp;
     int op = 0;
-    const char *e = getenv("AGP_GRAM_FAST");
-    if (!(e && e[0] == '0') && match_fast(*host_program, &fp, &op)) {
+    if (sop_enabled() && match_fast(*host_program, &fp, &op)) {
       bool done = false;
       if (X.dim == 1) done = launch_predict_mean_fast_t<1>(s, fp, op, X, XS, alpha, mean);
       else if (X.dim == 2) done = launch_predict_mean_fast_t<2>(s, fp, op, X, XS, alpha, mean);

@@ -88,9 +88,8 @@ int agp_ldlt_create(agp_context *ctx, const double *K, int64_t n, int64_t ld, in
   double *dotacc = scratch + n + 4, *Tpanel = dotacc + n;
   const int init_info[2] = {0, 1};
   hipError_t e = hipMemcpyAsync(info, init_info, sizeof(init_info), hipMemcpyHostToDevice, s);
-  static const bool blocked_ok = !(getenv("AGP_LDLT_BLOCKED") && getenv("AGP_LDLT_BLOCKED")[0] == '0');
   double *Ap = nullptr;
-  if (e == hipSuccess && blocked_ok && n >= 64) {
+  if (e == hipSuccess && n >= 64) {
     // permute once (Ap = P A P^T), then the blocked factorisation: same arithmetic, ~n / 32 * 3 launches
     e = hipMalloc(&Ap, sizeof(double) * (size_t)f->lda * (size_t)n);
     if (e == hipSuccess) {

@@ -25,33 +25,8 @@ __device__ __forceinline__ v4d mfma16(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 products D_b = A_b * B_b + C_b in one instruction
-// (lane maps measured with scripts/probe_mfma44.py; cbsz / abid have no effect on the f64 shapes):
-//     A operand : lane l holds A_b[i = l & 3][k = l >> 4],  b = (l >> 2) & 3
-//     B operand : lane l holds B_b[k = l >> 4][j = l & 3],  b = (l >> 2) & 3
-//     C/D       : lane l holds D_b[i = l >> 4][j = l & 3],  b = (l >> 2) & 3
-// It issues at 76 TFLOP/s chip-wide on MI355X where the 16x16x4 shape saturates at 47
-// (scripts/diag_mfma_shapes.py), so the GEMM kernels build their 16 x 16 tiles from FOUR of these:
-// call `rot` pairs B block b (4 values of the operand indexed by l & 15) with A block (b + rot) & 3, i.e.
-// the A fragment is read from LDS four times with its 4-element groups rotated.  A 16 x 16 x 4 product
-// D[m][n] (m: A index, n: B index) then lives in four accumulators:
-//     acc[rot], lane l  =  D[m = 4 (((l >> 2) + rot) & 3) + (l >> 4)][n = l & 15]
-__device__ __forceinline__ double mfma4(double a, double b, double c) {
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-
-// x of lane (row r, position p of 16) <- x of lane (r, (p + 4 groups) mod 16): the 4-element groups of a fragment
-// rotated inside each 16-lane row by DPP row_ror, without another LDS read.
-template <int GROUPS>
-__device__ __forceinline__ double rotate_groups(double x) {
-  // row_ror:n moves lane i's value to lane (i + n) mod 16, i.e. lane p receives lane (p - n) mod 16;
-  // receiving from (p + 4 GROUPS) therefore is a right rotation by 16 - 4 GROUPS
-  constexpr int ctrl = 0x120 + ((16 - 4 * GROUPS) & 15);
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), ctrl, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), ctrl, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
+// (The other fp64 shape, v_mfma_f64_4x4x4_4b_f64, issues faster in a bare loop but an update kernel built on it runs
+// at the same speed at a lower clock: DESIGN.md section 8; scripts/microbench/ keeps the probes.)
 __device__ __forceinline__ v4d v4zero() {
   v4d z = {0., 0., 0., 0.};
   return z;

@@ -172,7 +172,6 @@ struct ShardBuffers {
   long long ldp = 0;
   double *t = nullptr, *xfull = nullptr, *tmp = nullptr, *stat = nullptr;  // stat: 2 + 2 * world doubles
 };
-bool shard_force_comm();  // AGP_SHARD_FORCE_COMM=1
 long long shard_msg_doubles(const ShardPlan &plan);
 long long shard_work_doubles(const ShardPlan &plan);
 void shard_carve(const ShardPlan &plan, double *work, ShardBuffers *out);

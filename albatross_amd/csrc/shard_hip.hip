@@ -152,16 +152,6 @@ struct RcclComm : HostReducingComm {
   }
 };
 
-// A transport that moves nothing (debug: AGP_SHARD_FAKE_WORLD="G,r" times ONE rank's share of a G-rank fit on a box
-// with one GPU - same kernels, same shapes, same launch chain; the peers' data is whatever the buffers hold, so the
-// numerical result is meaningless and the entry point says so by returning AGP_ERR_UNSUPPORTED after timing).
-struct NullComm : HostReducingComm {
-  int broadcast(ShardOps &, int, double *, long long, int) override { return AGP_OK; }
-  int all_gather(ShardOps &, int, const double *, double *, long long) override { return AGP_OK; }
-  int all_reduce(ShardOps &, int, double *, long long, int) override { return AGP_OK; }
-  int all_reduce_host(double *, long long, int) override { return AGP_OK; }
-};
-
 // ---------------------------------------------------------------------------------------------------------------
 // kernels of the HIP backend that the single-GPU path does not have
 // ---------------------------------------------------------------------------------------------------------------
@@ -274,7 +264,6 @@ __global__ __launch_bounds__(256) void shard_unstack_kernel(double *__restrict__
 struct HipShardOps : ShardOps {
   agp_context_impl *ctx;
   hipStream_t sq[3];
-  hipStream_t own_comm_stream = nullptr;
   hipEvent_t ev[EV_COUNT];
   bool ok = true;
   double timeout_s;
@@ -282,7 +271,6 @@ struct HipShardOps : ShardOps {
   // context and continue from fit to fit: nothing to reset).  HOST pacing: HIP events (AGP_SHARD_HOST_PACING=1, or the
   // probe below found two of the queues sharing a hardware queue).
   bool device_pacing = true;
-  bool hybrid = false;  // device pacing, but the panel chain waits with hipStreamWaitEvent (no gate kernels on it)
   unsigned long long *flags = nullptr;  // ctx->shard_flags: [EV_COUNT] events | [EV_COUNT ..] probe
   unsigned long long timeout_ticks = 0;
   // bulk-update timing (profiling only)
@@ -294,25 +282,13 @@ struct HipShardOps : ShardOps {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     // the collectives' queue: created with the first sharded call of the context and kept (creating and destroying a
-    // stream costs ~0.4 ms per fit); AGP_SHARD_OWN_STREAM=1: one per call, the round-3 behaviour
-    static const bool per_call = [] { const char *e = getenv("AGP_SHARD_OWN_STREAM"); return e && e[0] == '1'; }();
-    if (per_call) {
-      ok = hipStreamCreateWithPriority(&own_comm_stream, hipStreamNonBlocking, hi) == hipSuccess;
-      sq[QC] = own_comm_stream;
-    } else {
-      if (!ctx->stream_comm) ok = hipStreamCreateWithPriority(&ctx->stream_comm, hipStreamNonBlocking, hi) == hipSuccess;
-      sq[QC] = ctx->stream_comm;
-    }
+    // stream costs ~0.4 ms per fit, sometimes tens of ms; a plain fit afterwards is as fast as before: profiles/r04)
+    if (!ctx->stream_comm) ok = hipStreamCreateWithPriority(&ctx->stream_comm, hipStreamNonBlocking, hi) == hipSuccess;
+    sq[QC] = ctx->stream_comm;
     sq[QP] = ctx->stream; sq[QB] = ctx->stream2;
     for (auto &e : ev) e = nullptr;
     timeout_ticks = (unsigned long long)(timeout_s * 1e8);
-    if (ctx->shard_host_pacing < 0) {
-      const char *e = getenv("AGP_SHARD_HOST_PACING");
-      ctx->shard_host_pacing = (e && e[0] == '1') ? 1 : 0;
-      const char *h = getenv("AGP_SHARD_HYBRID_PACING");
-      ctx->shard_hybrid = (h && h[0] == '1') ? 1 : 0;
-    }
-    hybrid = ctx->shard_hybrid == 1;
+    if (ctx->shard_host_pacing < 0) ctx->shard_host_pacing = ctx->tune.shard_host_pacing ? 1 : 0;
     device_pacing = ok && ctx->shard_host_pacing == 0;
     if (device_pacing) {
       if (!ctx->shard_flags) {
@@ -332,21 +308,18 @@ struct HipShardOps : ShardOps {
   void decide() {
     if (decided) return;
     decided = true;
-    if (device_pacing && !(ctx->shard_probe_ok && !own_comm_stream)) {
+    if (device_pacing && !ctx->shard_probe_ok) {  // the queues are the context's own: the answer holds for its lifetime
       device_pacing = probe_queues();
-      if (!own_comm_stream) {  // the queues are the context's own: the answer holds for its lifetime
-        if (device_pacing) ctx->shard_probe_ok = true;
-        else ctx->shard_host_pacing = 1;
-      }
+      if (device_pacing) ctx->shard_probe_ok = true;
+      else ctx->shard_host_pacing = 1;
     }
-    if (!device_pacing || hybrid)
+    if (!device_pacing)
       for (auto &e : ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   }
   ~HipShardOps() override {
     for (auto e : ev) if (e) (void)hipEventDestroy(e);
     for (auto e : tev) (void)hipEventDestroy(e);
     if (ev_switch) (void)hipEventDestroy(ev_switch);
-    if (own_comm_stream) (void)hipStreamDestroy(own_comm_stream);
   }
   // A gate kernel must never sit in FRONT of its producer in a hardware queue: the runtime maps HIP streams onto a few
   // hardware queues (GPU_MAX_HW_QUEUES) and serialises streams that share one.  One round of gates and signals between
@@ -544,7 +517,6 @@ struct HipShardOps : ShardOps {
       push(q, flags + e, ++ctx->shard_seq[e], 0);
       recorded[e] = true;
       record_queue[e] = q;
-      if (hybrid) { flush(q); (void)hipEventRecord(ev[e], sq[q]); }
     } else {
       (void)hipEventRecord(ev[e], sq[q]);
     }
@@ -552,10 +524,6 @@ struct HipShardOps : ShardOps {
   int wait(int q, int e) override {
     decide();
     if (device_pacing) {
-      if (hybrid && q == QP) {
-        if (recorded[e]) { flush(q); (void)hipStreamWaitEvent(sq[q], ev[e], 0); }
-        return AGP_OK;
-      }
       if (recorded[e]) {  // (never recorded by this fit: nothing to wait for, like hipStreamWaitEvent)
         // the record must be ON its stream before anything can wait for it: a host-synchronous transport (callbacks)
         // drains the waiting queue before the host returns to flush the producer's
@@ -759,18 +727,6 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
   const long long n = x->n;
   if (n <= 0) return AGP_ERR_INVALID_ARGUMENT;
   HostReducingComm *tr = comm ? comm->impl : nullptr;
-  NullComm fake;
-  bool faked = false;
-  if (!tr) {
-    if (const char *e = getenv("AGP_SHARD_FAKE_WORLD")) {
-      int g = 0, r = 0;
-      if (sscanf(e, "%d,%d", &g, &r) == 2 && g > 1 && r >= 0 && r < g) {
-        fake.world = g; fake.rank = r;
-        tr = &fake;
-        faked = true;
-      }
-    }
-  }
   const int world = tr ? tr->world : 1, rank = tr ? tr->rank : 0;
   const DevProgram *dprog = nullptr;
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
@@ -780,12 +736,12 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
   f->ctx = ctx;
   f->comm = comm;
   long long block = NBO;
-  if (const char *e = getenv("AGP_SHARD_BLOCK")) {  // tests: many row blocks at small n (128 / 256 / 512)
-    const long long b = atoll(e);
+  {  // AGP_SHARD_BLOCK (tests: many row blocks at small n)
+    const long long b = ctx->tune.shard_block;
     if (b == 128 || b == 256 || b == 512) block = b;
   }
   f->plan = ShardPlan(n, block, world, rank);
-  f->plan.force_comm = tr && shard_force_comm();
+  f->plan.force_comm = tr && ctx->tune.shard_force_comm;
   const ShardPlan &plan = f->plan;
   const long long nlb = plan.n_local_blocks(rank), B = plan.B;
   f->ld = factor_ld(plan.max_local_blocks() * B);  // the same on every rank (agp_sharded_fit_replicate gathers the stacks)
@@ -931,7 +887,7 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
       ctx->last_error = "sharded schedule: a queue waited for another (or for a collective) past the transport's deadline";
       st = AGP_ERR_COMM;
     }
-    f->stage[2] = ops.device_pacing ? (ops.hybrid ? 2. : 1.) : 0.;
+    f->stage[2] = ops.device_pacing ? 1. : 0.;
     f->stage[6] = res.enqueue_factor_ms + res.enqueue_solve_ms;
     f->stage[7] = res.total_ms;
     if (ctx->profiling) {
@@ -952,11 +908,6 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
   f->stage[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
   f->log_det = res.log_det;
   f->failed_pivot = res.bad_pivot;
-  if (faked) {  // timing-only run: keep the handle for agp_sharded_fit_stage, report that the numbers mean nothing
-    f->comm = nullptr;
-    *out = f;
-    return AGP_ERR_UNSUPPORTED;
-  }
   if (st == AGP_ERR_NOT_POSITIVE_DEFINITE) { *out = f; return st; }  // the handle reports the pivot
   if (st != AGP_OK) { agp_sharded_fit_destroy(f); return st; }
   if (information) SFIT_CHECK(hipMemcpy(information, f->buf.xfull, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));

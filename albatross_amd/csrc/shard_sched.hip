@@ -19,11 +19,6 @@ namespace agp {
 
 static long long round_even(long long x) { return (x + 1) / 2 * 2; }
 
-bool shard_force_comm() {
-  const char *e = getenv("AGP_SHARD_FORCE_COMM");
-  return e && e[0] == '1';
-}
-
 long long shard_msg_doubles(const ShardPlan &p) { return p.B * p.B + 4 * SHARD_IMG + round_even(p.B); }
 
 static long long pall_ld(const ShardPlan &p) {
@@ -335,42 +330,6 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
 // ---------------------------------------------------------------------------------------------------------------
 // callback backends
 // ---------------------------------------------------------------------------------------------------------------
-struct CallbackShardOps : ShardOps {
-  agp_shard_ops_callbacks cb;
-  double logsum = 0.;
-  long long bad = 0;
-  explicit CallbackShardOps(const agp_shard_ops_callbacks &c) : cb(c) {}
-  void factor_diag(int, double *D, long long ld, long long w, long long pivot_base, double *img, double *zblk) override {
-    double ls = 0.;
-    const long long b = cb.factor_diag(cb.user, D, ld, w, img, zblk, &ls);
-    logsum += ls;
-    if (b > 0 && bad == 0) bad = pivot_base + b;
-  }
-  void trsm_rows(int, double *X, long long ld, long long nrows, long long w, const double *Lkk, const double *img,
-                 const double *z, double *yrows) override {
-    cb.trsm_rows(cb.user, X, ld, nrows, w, Lkk, img, z, yrows);
-  }
-  void gemm(int, double *C, long long ldc, const double *P, long long ldp, const double *Q, long long ldq, long long M,
-            long long N, long long K, bool tri, int) override {
-    cb.gemm(cb.user, C, ldc, P, ldp, Q, ldq, M, N, K, tri ? 1 : 0);
-  }
-  void copy2d(int, double *dst, long long ldd, const double *src, long long lds, long long rows, long long cols) override {
-    cb.copy2d(cb.user, dst, ldd, src, lds, rows, cols);
-  }
-  void invert_diag(int, const double *D, long long ld, long long w, const double *img, double *W) override {
-    cb.invert_diag(cb.user, D, ld, w, img, W);
-  }
-  void colvec_dot(int, const double *W, long long ld, long long m, long long n, const double *v, double alpha, double beta,
-                  const double *base, double *out) override {
-    cb.colvec_dot(cb.user, W, ld, m, n, v, alpha, beta, base, out);
-  }
-  void axpby(int, long long n, double a, const double *x, double b, const double *y, double *out) override {
-    cb.axpby(cb.user, n, a, x, b, y, out);
-  }
-  void fill_zero(int, double *p, long long count) override { cb.fill_zero(cb.user, p, count); }
-  void status(double out[2]) override { out[0] = logsum; out[1] = (double)bad; }
-};
-
 int CallbackComm::staged(ShardOps &ops, int q, double *buf, long long count, int kind, int arg, const double *send,
                          long long send_count) {
   // host transport: device data is staged through host memory around the caller's collective
@@ -461,35 +420,6 @@ int64_t agp_shard_global_row(int64_t n, int64_t block, int nranks, int rank, int
 int agp_shard_owner(int64_t block_index, int nranks) {
   if (block_index < 0 || nranks < 1) return -1;
   return ShardPlan::owner_of(block_index, nranks);
-}
-
-int64_t agp_shard_work_doubles(int64_t n, int64_t block, int nranks, int rank) {
-  if (n <= 0 || block <= 0 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
-  ShardPlan p(n, block, nranks, rank);
-  p.force_comm = shard_force_comm();
-  return shard_work_doubles(p);
-}
-
-int agp_shard_factor_custom(const agp_shard_ops_callbacks *ops, agp_comm *comm, int64_t n, int64_t block, double *A,
-                            int64_t ld, double *y, double *work, double *information, double *log_det,
-                            int64_t *bad_pivot) {
-  if (!ops || !A || !y || !work || n <= 0 || block <= 0 || block % 128 != 0) return AGP_ERR_INVALID_ARGUMENT;
-  if (!ops->factor_diag || !ops->trsm_rows || !ops->gemm || !ops->copy2d || !ops->invert_diag || !ops->colvec_dot ||
-      !ops->axpby || !ops->fill_zero)
-    return AGP_ERR_INVALID_ARGUMENT;
-  const int world = comm && comm->impl ? comm->impl->world : 1, rank = comm && comm->impl ? comm->impl->rank : 0;
-  ShardPlan plan(n, block, world, rank);
-  plan.force_comm = comm && comm->impl && shard_force_comm();
-  if (ld < plan.local_rows(rank)) return AGP_ERR_INVALID_ARGUMENT;
-  CallbackShardOps cops(*ops);
-  ShardBuffers buf;
-  shard_carve(plan, work, &buf);
-  ShardResult res;
-  const int st = shard_factor_solve(cops, comm ? comm->impl : nullptr, plan, A, ld, y, buf, &res);
-  if (log_det) *log_det = res.log_det;
-  if (bad_pivot) *bad_pivot = res.bad_pivot;
-  if (st == AGP_OK && information) std::memcpy(information, buf.xfull, sizeof(double) * (size_t)n);
-  return st;
 }
 
 }  // extern "C"

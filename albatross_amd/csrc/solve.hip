@@ -1,0 +1,426 @@
+// solve.hip — K4: the substitutions against a factor held as L (lower triangle) + the tile images of its diagonal blocks:
+// multi-RHS forward / backward / right solves on the MFMA (trsm_micro_kernel + update launches), their batched forms,
+// the explicit inverses of the diagonal blocks, and the one-vector substitution chains.
+//
+// Replaces LDLT::solve (include/albatross/src/eigen/serializable_ldlt.hpp, used at models/gp.hpp:68,96,111) and
+// matrixL().solveInPlace (serializable_ldlt.hpp:105,160).
+#include "common.h"
+#include "mfma_f64.h"
+#include "gemm_tiles.h"
+#include "trsm_kernel.h"
+
+namespace agp {
+void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);  // reduce.hip
+
+// ---------------------------------------------------------------------------
+// multi-RHS triangular solves (K4): B <- L^-1 B and B <- L^-T B
+// ---------------------------------------------------------------------------
+void forward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                       double *B, long long m, long long ldb, bool rhs_lower) {
+  // rhs_lower: column j of B is zero above row j (e.g. the identity): block row
+  // k then only has work in its first k + nbk columns (N^3/3 instead of N^3 flop)
+  if (m <= 0) return;
+  for (long long K0 = 0; K0 < n; K0 += NBO) {
+    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
+    for (long long k = K0; k < kend; k += NB) {
+      const int nbk = (int)((n - k < NB) ? n - k : NB);
+      TrsmArgs t;
+      t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+      t.nbk = nbk;
+      t.Y = B + k;
+      t.stride_m = 1; t.stride_n = ldb;
+      const long long m_act = (rhs_lower && k + nbk < m) ? k + nbk : m;
+      t.ncols = m_act;
+      t.z = nullptr; t.yrest = nullptr;
+      t.batch_img = t.batch_Y = 0; t.n_total = 0;
+      hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m_act + 63) / 64)), dim3(256), 0, s, t);
+      const long long rows = kend - (k + nbk);
+      if (rows > 0)  // B[k+nbk : kend] -= L[k+nbk : kend, k : k+nbk] B[k : k+nbk]
+        launch_gemm_nt_sub(s, B + k + nbk, ldb, A + k * lda + (k + nbk), lda, false, B + k, ldb, true, rows, m_act,
+                           nbk, false);
+    }
+    if (kend < n) {  // B[kend :] -= L[kend :, K0 : kend] B[K0 : kend]
+      const long long m_act = (rhs_lower && kend < m) ? kend : m;
+      launch_gemm_nt_sub(s, B + kend, ldb, A + K0 * lda + kend, lda, false, B + K0, ldb, true, n - kend, m_act,
+                         kend - K0, false);
+    }
+  }
+}
+
+// The same substitution with one outer block of look-ahead on the context's two streams (like
+// factor_lower): the solve of block rows j + 1 (small, latency-bound launches) runs on the main
+// stream while the update of everything below with block j's solution (the MFMA-bound bulk) runs on
+// the second one.  Returns with the main stream ordered after all work.
+void forward_solve_mat_lookahead(agp_context *ctx, const double *A, long long n, long long lda, const double *invd,
+                                 double *B, long long m, long long ldb, bool rhs_lower) {
+  if (m <= 0) return;
+  hipStream_t sa = ctx->stream, sb = ctx->stream2;
+  if (n <= 2 * NBO || !sb || m < 64) {  // too small for the second stream to pay for its events
+    forward_solve_mat(sa, A, n, lda, invd, B, m, ldb, rhs_lower);
+    return;
+  }
+  bool have_u2 = false;
+  for (long long K0 = 0; K0 < n; K0 += NBO) {
+    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
+    for (long long k = K0; k < kend; k += NB) {
+      const int nbk = (int)((n - k < NB) ? n - k : NB);
+      TrsmArgs t;
+      t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+      t.nbk = nbk;
+      t.Y = B + k;
+      t.stride_m = 1; t.stride_n = ldb;
+      const long long m_act = (rhs_lower && k + nbk < m) ? k + nbk : m;
+      t.ncols = m_act;
+      t.z = nullptr; t.yrest = nullptr;
+      t.batch_img = t.batch_Y = 0; t.n_total = 0;
+      hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m_act + 63) / 64)), dim3(256), 0, sa, t);
+      const long long rows = kend - (k + nbk);
+      if (rows > 0)
+        launch_gemm_nt_sub(sa, B + k + nbk, ldb, A + k * lda + (k + nbk), lda, false, B + k, ldb, true, rows, m_act,
+                           nbk, false);
+    }
+    if (kend >= n) break;
+    const long long next_end = (kend + NBO < n) ? kend + NBO : n;
+    const long long m_act = (rhs_lower && kend < m) ? kend : m;
+    (void)hipEventRecord(ctx->ev_a, sa);                      // block j solved
+    if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);  // U2(j - 1) done: it wrote the rows U1(j) writes
+    // U1(j): the next block's rows
+    launch_gemm_nt_sub(sa, B + kend, ldb, A + K0 * lda + kend, lda, false, B + K0, ldb, true, next_end - kend, m_act,
+                       kend - K0, false);
+    if (next_end < n) {
+      (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
+      launch_gemm_nt_sub(sb, B + next_end, ldb, A + K0 * lda + next_end, lda, false, B + K0, ldb, true, n - next_end,
+                         m_act, kend - K0, false);
+      (void)hipEventRecord(ctx->ev_b, sb);
+      have_u2 = true;
+    } else {
+      have_u2 = false;
+    }
+  }
+  if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
+}
+
+// B_b (n x m, ldb) <- L_b^-1 B_b for `count` problems (B_b = B + b * stride_B); rhs_lower as in forward_solve_mat
+void forward_solve_mat_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
+                               const double *invd, long long stride_invd, double *B, long long stride_B, long long m,
+                               long long ldb, bool rhs_lower, long long count) {
+  if (m <= 0 || count <= 0) return;
+  for (long long k = 0; k < n; k += NB) {
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    const long long m_act = (rhs_lower && k + nbk < m) ? k + nbk : m;
+    TrsmArgs t;
+    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+    t.nbk = nbk;
+    t.Y = B + k;
+    t.stride_m = 1; t.stride_n = ldb;
+    t.ncols = m_act;
+    t.z = nullptr; t.yrest = nullptr;
+    t.batch_img = stride_invd; t.batch_Y = stride_B; t.n_total = 0;
+    hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((m_act + 63) / 64), (unsigned)count), dim3(256), 0,
+                       s, t);
+    const long long rows = n - (k + nbk);
+    if (rows > 0)  // B[k + nbk :] -= L[k + nbk :, k : k + nbk] B[k : k + nbk]
+      launch_gemm_nt_sub_batched(s, B + k + nbk, ldb, stride_B, A + k * lda + (k + nbk), lda, false, stride_A, B + k, ldb,
+                                 true, stride_B, rows, m_act, nbk, false, count);
+  }
+}
+
+// X_b (nrows x n, ldx) <- X_b L_b^-T for `count` problems: X_b = X + b * stride_X, L_b = A + b * stride_A
+void right_solve_lt_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
+                            const double *invd, long long stride_invd, double *X, long long stride_X, long long nrows,
+                            long long ldx, long long count) {
+  if (nrows <= 0 || count <= 0) return;
+  for (long long k = 0; k < n; k += NB) {
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    TrsmArgs t;
+    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+    t.nbk = nbk;
+    t.Y = X + k * ldx;
+    t.stride_m = ldx; t.stride_n = 1;
+    t.ncols = nrows;
+    t.z = nullptr; t.yrest = nullptr;
+    t.batch_img = stride_invd; t.batch_Y = stride_X; t.n_total = 0;
+    hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((nrows + 63) / 64), (unsigned)count), dim3(256), 0,
+                       s, t);
+    const long long rest = n - (k + nbk);
+    if (rest > 0)
+      launch_gemm_nt_sub_batched(s, X + (k + nbk) * ldx, ldx, stride_X, X + k * ldx, ldx, false, stride_X,
+                                 A + k * lda + (k + nbk), lda, false, stride_A, nrows, rest, nbk, false, count);
+  }
+}
+
+// X (nrows x n, ldx) <- X L^-T : the panel TRSM of the factorisation applied to a free-standing
+// matrix (sparse GP: K_uf[:, group] L_A^-T = (A^-1/2 K_fu)^T, models/sparse_gp.hpp:347-349).
+void right_solve_lt(hipStream_t s, const double *A, long long n, long long lda, const double *invd, double *X,
+                    long long nrows, long long ldx) {
+  if (nrows <= 0) return;
+  for (long long k = 0; k < n; k += NB) {
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    TrsmArgs t;
+    t.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+    t.nbk = nbk;
+    t.Y = X + k * ldx;           // Y = X[:, k : k + nbk]^T : element (m, n) at Y[m * ldx + n]
+    t.stride_m = ldx; t.stride_n = 1;
+    t.ncols = nrows;
+    t.z = nullptr; t.yrest = nullptr;
+    t.batch_img = t.batch_Y = 0; t.n_total = 0;
+    hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3((unsigned)((nrows + 63) / 64)), dim3(256), 0, s, t);
+    const long long rest = n - (k + nbk);
+    if (rest > 0)  // X[:, k + nbk :] -= X[:, k : k + nbk] L[k + nbk :, k : k + nbk]^T
+      launch_gemm_nt_sub(s, X + (k + nbk) * ldx, ldx, X + k * ldx, ldx, false, A + k * lda + (k + nbk), lda, false,
+                         nrows, rest, nbk, false);
+  }
+}
+
+void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                        double *B, long long m, long long ldb) {
+  if (m <= 0 || n <= 0) return;
+  const long long nblk = (n + NB - 1) / NB;
+  for (long long b = nblk - 1; b >= 0; --b) {
+    const long long k = b * NB;
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    TrsmArgs t;
+    t.img = invd + b * (long long)IMG_DOUBLES;
+    t.nbk = nbk;
+    t.Y = B + k;
+    t.stride_m = 1; t.stride_n = ldb;
+    t.ncols = m;
+    t.z = nullptr; t.yrest = nullptr;
+    t.batch_img = t.batch_Y = 0; t.n_total = 0;
+    hipLaunchKernelGGL((trsm_micro_kernel<true, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, t);
+    if (k > 0)  // B[0 : k] -= L[k : k+nbk, 0 : k]^T B[k : k+nbk]
+      launch_gemm_nt_sub(s, B, ldb, A + k, lda, true, B + k, ldb, true, k, m, nbk, false);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// one right-hand side: x = L^-T z  (second half of K^-1 y, gp.hpp:68)
+//
+// Right-looking over NB blocks from the bottom.  The diagonal blocks are
+// inverted beforehand by ONE batched launch (all blocks in parallel, off the
+// serial chain), so a step is two short kernels:
+//   x_b = inv(L_bb)^T z_b                      (128 x 128 mat-vec, one workgroup)
+//   z[0:k] -= L[k:k+nb, 0:k]^T x_b             (one wave per 8 columns, coalesced
+//                                               1-KiB column segments)
+// Bandwidth: L is read exactly once (8 N^2 / 2 bytes).  (Tried: two blocks per launch with the
+// three 128 x 128 mat-vecs recomputed in every workgroup - 44 us per launch instead of 2 x 11.)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void set_identity_blocks_kernel(double *W, long long count) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const int within = (int)(i & (NB * NB - 1));
+  W[i] = ((within >> 7) == (within & (NB - 1))) ? 1. : 0.;
+}
+
+// Winv[b] = inv(L_bb)^T as a column-major NB x NB array (i.e. inv(L_bb) row-major), for every diagonal block.
+void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
+                        double *Winv) {
+  const long long nblk = (n + NB - 1) / NB;
+  const long long count = nblk * NB * NB;
+  hipLaunchKernelGGL(set_identity_blocks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, Winv, count);
+  TrsmArgs t;
+  (void)A; (void)lda;
+  t.img = invd; t.nbk = NB;
+  // element (m, n) of inv(L_bb) goes to Winv[m * NB + n]: the blocks are stored TRANSPOSED
+  // (row-major), so that the mat-vec x = inv(L_bb)^T z reads them coalesced
+  t.Y = Winv; t.stride_m = NB; t.stride_n = 1; t.ncols = NB;
+  t.z = nullptr; t.yrest = nullptr;
+  t.batch_img = IMG_DOUBLES; t.batch_Y = NB * NB; t.n_total = n;
+  hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
+}
+
+// Wfwd[b] = inv(L_bb) column-major (element (m, n) at [n * NB + m]): what the FORWARD vector
+// substitution reads coalesced.
+void invert_diag_blocks_forward(hipStream_t s, long long n, const double *invd, double *Wfwd) {
+  const long long nblk = (n + NB - 1) / NB;
+  const long long count = nblk * NB * NB;
+  hipLaunchKernelGGL(set_identity_blocks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, Wfwd, count);
+  TrsmArgs t;
+  t.img = invd; t.nbk = NB;
+  t.Y = Wfwd; t.stride_m = 1; t.stride_n = NB; t.ncols = NB;
+  t.z = nullptr; t.yrest = nullptr;
+  t.batch_img = IMG_DOUBLES; t.batch_Y = NB * NB; t.n_total = n;
+  hipLaunchKernelGGL((trsm_micro_kernel<false, false>), dim3(2, (unsigned)nblk), dim3(256), 0, s, t);
+}
+
+// One step of the right-looking FORWARD substitution on a vector, ONE launch:
+//   x_b = inv(L_bb) z_b                         (recomputed by every workgroup, as in back_step_kernel)
+//   z[i] -= sum_c L[i][k0 + c] x_b[c]           for this workgroup's 64 rows i >= k0 + nbk
+// (wave w sums columns 32 w .. 32 w + 31, lane = row: coalesced 512-B column segments)
+__global__ __launch_bounds__(256) void fwd_step_kernel(const double *__restrict__ A, long long lda, long long k0,
+                                                       int nbk, long long n, const double *__restrict__ Wfwd,
+                                                       double *__restrict__ z, double *__restrict__ x_out) {
+  __shared__ double xs[NB], part[NB], zs[NB], red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < NB) zs[tid] = (tid < nbk) ? z[k0 + tid] : 0.;
+  __syncthreads();
+  {
+    // x[c] = sum_r inv(L)[c][r] z[r];  Wfwd holds inv(L)[c][r] at [r * NB + c]
+    const int c = tid & (NB - 1), half = tid >> 7;
+    double acc = 0.;
+#pragma unroll 8
+    for (int r = half * 64; r < half * 64 + 64; ++r) acc += Wfwd[r * NB + c] * zs[r];
+    if (half == 1) part[c] = acc;
+    __syncthreads();
+    if (half == 0) {
+      const double v = (c < nbk) ? acc + part[c] : 0.;
+      xs[c] = v;
+      if (blockIdx.x == 0 && c < nbk) x_out[k0 + c] = v;
+    }
+    __syncthreads();
+  }
+  const long long i = k0 + nbk + (long long)blockIdx.x * 64 + lane;
+  double acc = 0.;
+  if (i < n) {
+    const double *p = A + (k0 + 32 * wave) * lda + i;
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c)
+      if (32 * wave + c < nbk) acc += p[(long long)c * lda] * xs[32 * wave + c];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && i < n) z[i] -= (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// z <- L^-1 z for one vector (the fused substitution of the factorisation covers the fit's own y; this
+// one serves the refinement steps of the mixed-precision fit).  xstage: n doubles.
+void forward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Wfwd, double *z,
+                       double *xstage) {
+  const long long nblk = (n + NB - 1) / NB;
+  for (long long b = 0; b < nblk; ++b) {
+    const long long k = b * NB;
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    const long long below = n - k - nbk;
+    const unsigned grid = (unsigned)(below > 0 ? (below + 63) / 64 : 1);
+    hipLaunchKernelGGL(fwd_step_kernel, dim3(grid), dim3(256), 0, s, A, lda, k, nbk, n,
+                       Wfwd + b * (long long)(NB * NB), z, xstage);
+  }
+  (void)hipMemcpyAsync(z, xstage, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+}
+
+// One step of the right-looking back substitution, ONE launch:
+//   x_b = inv(L_bb)^T z_b            (every workgroup recomputes this 128 x 128 mat-vec from the
+//                                     L2-resident transposed inverse: 128 KB, coalesced rows)
+//   z[c] -= sum_r L[k0 + r][c] x_b[r]  for this workgroup's 32 columns c < k0
+// Workgroup 0 also publishes x_b into `x_out` (z_b itself stays untouched: other workgroups may
+// still be reading it).
+__global__ __launch_bounds__(256) void back_step_kernel(const double *__restrict__ A, long long lda, long long k0,
+                                                        int nbk, const double *__restrict__ WinvT,
+                                                        double *__restrict__ z, double *__restrict__ x_out) {
+  __shared__ double xs[NB], part[NB], zs[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < NB) zs[tid] = (tid < nbk) ? z[k0 + tid] : 0.;
+  __syncthreads();
+  {
+    // x[c] = sum_r inv(L)[r][c] z[r];  WinvT holds inv(L)[r][c] at [r * NB + c]
+    const int c = tid & (NB - 1), half = tid >> 7;
+    double acc = 0.;
+#pragma unroll 8
+    for (int r = half * 64; r < half * 64 + 64; ++r) acc += WinvT[r * NB + c] * zs[r];
+    if (half == 1) part[c] = acc;
+    __syncthreads();
+    if (half == 0) {
+      const double v = (c < nbk) ? acc + part[c] : 0.;
+      xs[c] = v;
+      if (blockIdx.x == 0 && c < nbk) x_out[k0 + c] = v;
+    }
+    __syncthreads();
+  }
+  const long long c0 = ((long long)blockIdx.x * 4 + wave) * 8;
+  if (c0 >= k0) return;
+  const int r = 2 * lane;
+  const double x0 = xs[r], x1 = xs[r + 1];
+  const bool vec = ((lda & 1) == 0) && ((k0 & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  double acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const long long c = c0 + q;
+    double a0 = 0., a1 = 0.;
+    if (c < k0) {
+      const double *p = A + c * lda + k0 + r;
+      if (vec && r + 1 < nbk) {
+        const double2 v = *reinterpret_cast<const double2 *>(p);
+        a0 = v.x; a1 = v.y;
+      } else {
+        a0 = r < nbk ? p[0] : 0.;
+        a1 = r + 1 < nbk ? p[1] : 0.;
+      }
+    }
+    acc[q] = a0 * x0 + a1 * x1;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (c0 + q < k0) z[c0 + q] -= acc[q];
+  }
+}
+
+// z[c] -= sum_r L[k0 + r][c] x[r]  for c < ncols ; r < nbk.   8 columns per wave.
+__global__ __launch_bounds__(256) void back_update_kernel(const double *__restrict__ A, long long lda,
+                                                          long long k0, int nbk, long long ncols,
+                                                          const double *__restrict__ x, double *__restrict__ z) {
+  // rows k0 .. k0 + nbk of A, columns 0 .. ncols
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long c0 = ((long long)blockIdx.x * 4 + wave) * 8;
+  if (c0 >= ncols) return;
+  const int r = 2 * lane;
+  const double x0 = r < nbk ? x[r] : 0., x1 = r + 1 < nbk ? x[r + 1] : 0.;
+  const bool vec = ((lda & 1) == 0) && ((k0 & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  double acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const long long c = c0 + q;
+    double a0 = 0., a1 = 0.;
+    if (c < ncols) {
+      const double *p = A + c * lda + k0 + r;
+      if (vec && r + 1 < nbk) {
+        const double2 v = *reinterpret_cast<const double2 *>(p);
+        a0 = v.x; a1 = v.y;
+      } else {
+        a0 = r < nbk ? p[0] : 0.;
+        a1 = r + 1 < nbk ? p[1] : 0.;
+      }
+    }
+    acc[q] = a0 * x0 + a1 * x1;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (c0 + q < ncols) z[c0 + q] -= acc[q];
+  }
+}
+
+void launch_back_update(hipStream_t s, const double *A, long long lda, long long k0, int nbk, long long ncols,
+                        const double *x, double *z) {
+  if (ncols <= 0 || nbk <= 0) return;
+  hipLaunchKernelGGL(back_update_kernel, dim3((unsigned)((ncols + 31) / 32)), dim3(256), 0, s, A, lda, k0, nbk,
+                     ncols, x, z);
+}
+
+void backward_solve_vec(hipStream_t s, const double *A, long long n, long long lda, const double *Winv,
+                        double *z, double *xstage) {
+  // z is consumed; the solution is produced in `xstage` (n doubles) block by block and copied
+  // back at the end: x of block b may not overwrite z_b while other workgroups of the same
+  // launch still read z_b
+  const long long nblk = (n + NB - 1) / NB;
+  for (long long b = nblk - 1; b >= 0; --b) {
+    const long long k = b * NB;
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    const unsigned grid = (unsigned)(k > 0 ? (k + 31) / 32 : 1);
+    hipLaunchKernelGGL(back_step_kernel, dim3(grid), dim3(256), 0, s, A, lda, k, nbk,
+                       Winv + b * (long long)(NB * NB), z, xstage);
+  }
+  (void)hipMemcpyAsync(z, xstage, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+}
+
+}  // namespace agp

@@ -85,7 +85,7 @@ struct StageTimer {
   hipStream_t s;
   bool on;
   std::chrono::steady_clock::time_point last;
-  explicit StageTimer(hipStream_t st) : s(st), on(getenv("AGP_SPARSE_TIMING") != nullptr), last(std::chrono::steady_clock::now()) {}
+  explicit StageTimer(hipStream_t st, bool enabled) : s(st), on(enabled), last(std::chrono::steady_clock::now()) {}
   void operator()(const char *name) {
     if (!on) return;
     (void)hipStreamSynchronize(s);
@@ -290,12 +290,7 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
   } else {
     // few or very uneven groups: one block at a time, T host threads on T helper contexts (own streams)
     agp_context_impl *ci = static_cast<agp_context_impl *>(ctx);
-    static int want_threads = -1;
-    if (want_threads < 0) {
-      const char *e = getenv("AGP_SPARSE_THREADS");
-      want_threads = e ? atoi(e) : 4;  // measured: 4 threads 590 ms, 16: 650 ms, 32: 740 ms at 512 blocks of 512
-      if (want_threads < 1) want_threads = 1;
-    }
+    constexpr int want_threads = 4;  // measured: 4 threads 590 ms, 16: 650 ms, 32: 740 ms at 512 blocks of 512
     const int T = (int)std::min<long long>(want_threads, n_groups);
     while ((int)ci->helpers.size() < T) {
       agp_context *h = nullptr;
@@ -573,7 +568,7 @@ static int sparse_fit_create_pivoted(agp_context *ctx, const agp_kernel *k, cons
   const DevProgram *dprog = nullptr;
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
   hipStream_t s = ctx->stream;
-  StageTimer stage(s);
+  StageTimer stage(s, ctx->profiling);
   std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
   if (!f) return AGP_ERR_INVALID_ARGUMENT;
   f->ctx = ctx; f->m = m; f->inducing_nugget = inducing_nugget;
@@ -685,7 +680,7 @@ static int sparse_fit_create_fast(agp_context *ctx, agp_comm *comm, const agp_ke
   }
   const long long n = x->n, m = u->n;
   hipStream_t s = ctx->stream;
-  StageTimer stage(s);
+  StageTimer stage(s, ctx->profiling);
   std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
   SparseScratch w;
   const long long ldm = factor_ld(m);
@@ -741,9 +736,8 @@ static int sparse_fit_create_impl(agp_context *ctx, agp_comm *comm, const agp_ke
                                   const int64_t *offsets, const double *y, const double *y_var, const agp_features *u,
                                   double measurement_nugget, double inducing_nugget, agp_sparse_fit **out,
                                   double *information, double *nll_out) {
-  const char *force = getenv("AGP_SPARSE_PIVOTED");
   int st = AGP_ERR_NOT_POSITIVE_DEFINITE;
-  if (comm || !(force && force[0] == '1'))
+  if (comm || !ctx->tune.sparse_pivoted)
     st = sparse_fit_create_fast(ctx, comm, k, x, n_groups, offsets, y, y_var, u, measurement_nugget, inducing_nugget, out,
                                 information, nll_out);
   if (st == AGP_ERR_NOT_POSITIVE_DEFINITE && !comm)
@@ -836,7 +830,7 @@ int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *k, const agp_spars
   const DevProgram *dprog = nullptr;
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
   hipStream_t s = ctx->stream;
-  StageTimer stage(s);
+  StageTimer stage(s, ctx->profiling);
   std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
   if (!f) return AGP_ERR_INVALID_ARGUMENT;
   f->ctx = ctx; f->m = m;
@@ -995,8 +989,7 @@ static int sparse_predict_common(agp_context *ctx, const agp_kernel *k, const ag
   // (AGP_PREDICT_CHUNK=<points> overrides); a joint prediction needs all of them at once
   long long chunk = M_all;
   if (mode != 2) {
-    const char *e = getenv("AGP_PREDICT_CHUNK");
-    const long long forced = e ? atoll(e) : 0;
+    const long long forced = ctx->tune.predict_chunk;
     const long long c = forced > 0 ? forced : std::min<long long>(1LL << 20, std::max<long long>(1024, (1LL << 28) / ldq));
     chunk = std::min(M_all, c);
   }

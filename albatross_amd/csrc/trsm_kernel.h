@@ -1,0 +1,169 @@
+// trsm_kernel.h — the tile image of a factored 128 x 128 diagonal block and the MFMA substitution kernel against it
+// (trsm_micro_kernel): shared by chol.hip (panel TRSM of the factorisation) and solve.hip (multi-RHS substitutions).
+#pragma once
+#include "common.h"
+#include "mfma_f64.h"
+
+namespace agp {
+
+constexpr int NTILE = NMB * (NMB + 1) / 2;   // 36 lower 16x16 tiles
+constexpr int IMG_DOUBLES = NTILE * MB * MB;  // 9216 doubles = 72 KiB per diagonal block
+
+// LDS image: only the 36 lower micro tiles, each column-major 16x16
+// (tile (ib, kb), ib >= kb, at index ib(ib+1)/2 + kb).  An MFMA operand
+// fragment of a tile (element [k*16 + m], k = (lane >> 4) + 4 s, m = lane & 15)
+// is 64 consecutive doubles per k-step: conflict-free ds_read_b64.
+//
+// The kernel also emits the "tile image" of the factored block to global
+// memory: the same 36 tiles with the off-diagonal ones NEGATED and the diagonal
+// ones replaced by their INVERSES.  That image is exactly the set of MFMA
+// A-operand fragments the substitution kernels need, so they stage it with a
+// straight coalesced copy.
+__device__ __forceinline__ int tile_off(int ib, int kb) { return (ib * (ib + 1) / 2 + kb) * (MB * MB); }
+
+// ---------------------------------------------------------------------------
+// Substitution against one NB x NB diagonal block over its micro blocks.
+//   Y (NB x 16 per wave, held as 8 C/D tiles) <- L11^-1 Y        (TRANS = false)
+//   Y                                         <- L11^-T Y        (TRANS = true)
+// Element (m, n) of Y lives at base[m * stride_m + n * stride_n]:
+//   panel TRSM  X <- X L11^-T : Y = X^T, stride_m = lda, stride_n = 1
+//   left  TRSM  V <- L11^-1 V : Y = V,   stride_m = 1,   stride_n = ldv
+// LDS holds the 36 lower 16x16 tiles of L11 as ready-made MFMA A-operand
+// fragments (negated off-diagonal tiles, inverted diagonal tiles).
+// ---------------------------------------------------------------------------
+constexpr int NFRAG_TILES = NTILE;
+
+struct TrsmArgs {
+  const double *img;  // tile image of the diagonal block (written by potrf_diag_kernel)
+  int nbk;
+  double *Y;  // element (0, 0) of the block to be solved
+  long long stride_m, stride_n;
+  long long ncols;  // number of n (panel rows / V columns)
+  const double *z;  // z_b (nbk) or nullptr          (FUSE_Y only)
+  double *yrest;    // y entries matching n = 0..ncols (FUSE_Y only)
+  // batched launches (blockIdx.y = diagonal block index): element strides
+  long long batch_img, batch_Y;
+  long long n_total;  // matrix size, to derive nbk per batch entry (0: use nbk)
+  long long batch_z = 0;  // FUSE_Y: offset of z / yrest per batch entry
+};
+
+template <bool TRANS, bool FUSE_Y>
+__global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);  // panel chain (see potrf_diag_kernel)
+  __shared__ double F[NFRAG_TILES * 4 * 64 + NB];
+  double *zs = F + NFRAG_TILES * 4 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, lg = lane >> 4;
+  if (blockIdx.y > 0 || p.n_total > 0) {
+    const long long b = blockIdx.y;
+    p.img += b * p.batch_img;
+    p.Y += b * p.batch_Y;
+    if (FUSE_Y) {
+      p.z += b * p.batch_z;
+      p.yrest += b * p.batch_z;
+    }
+    if (p.n_total > 0) {
+      const long long left = p.n_total - b * NB;
+      p.nbk = (int)(left < NB ? left : NB);
+    }
+  }
+
+  // ---- stage the fragment image of L11 ----
+  // Image element [tile * 256 + k * 16 + m] is the A-operand value T[m][k] of
+  // the forward solve; the transposed solve needs T^T of every tile.
+  if (!TRANS) {
+#pragma unroll
+    for (int it = 0; it < IMG_DOUBLES / 2 / 256; ++it) {
+      const int e = 2 * (tid + 256 * it);
+      *reinterpret_cast<double2 *>(F + e) = *reinterpret_cast<const double2 *>(p.img + e);
+    }
+  } else {
+#pragma unroll 4
+    for (int e = tid; e < IMG_DOUBLES; e += 256) {
+      const int m = e & 15, k = (e >> 4) & 15, t = e >> 8;
+      F[e] = p.img[t * 256 + m * 16 + k];
+    }
+  }
+  if (FUSE_Y && tid < NB) zs[tid] = (tid < p.nbk) ? p.z[tid] : 0.;
+  __syncthreads();
+
+  const long long n0 = ((long long)blockIdx.x * 4 + wave) * 16;
+  if (n0 >= p.ncols) return;
+  const bool nok = n0 + ln < p.ncols;
+  double *base = p.Y + (n0 + ln) * p.stride_n;
+
+  v4d Y[NMB];
+  // all 8 input tiles are requested up front: one HBM round trip, not eight
+#pragma unroll
+  for (int jb = 0; jb < NMB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = jb * MB + lg + 4 * r;
+      Y[jb][r] = (nok && m < p.nbk) ? base[m * p.stride_m] : 0.;
+    }
+  if (!TRANS) {
+#pragma unroll
+    for (int jb = 0; jb < NMB; ++jb) {
+      // four independent accumulation chains (one per k-step) instead of one
+      // chain of 4 jb dependent MFMAs: the dependent-issue latency of the f64
+      // MFMA (~190 cycles) is what this kernel is bound by
+      v4d pa[4] = {Y[jb], v4zero(), v4zero(), v4zero()};
+#pragma unroll
+      for (int ib = 0; ib < jb; ++ib) {
+        const double *f = F + (jb * (jb + 1) / 2 + ib) * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pa[s] = mfma16(f[s * 64], Y[ib][s], pa[s]);
+      }
+      const v4d acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+      v4d po[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
+      const double *f = F + (jb * (jb + 1) / 2 + jb) * 256 + lane;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) po[s] = mfma16(f[s * 64], acc[s], po[s]);
+      const v4d out = (po[0] + po[1]) + (po[2] + po[3]);
+      Y[jb] = out;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = jb * MB + lg + 4 * r;
+        if (nok && m < p.nbk) base[m * p.stride_m] = out[r];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int jb = NMB - 1; jb >= 0; --jb) {
+      v4d pa[4] = {Y[jb], v4zero(), v4zero(), v4zero()};
+#pragma unroll
+      for (int ib = NMB - 1; ib > jb; --ib) {
+        // image tile index of the stored pair (row block ib, col block jb)
+        const double *f = F + (ib * (ib + 1) / 2 + jb) * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pa[s] = mfma16(f[s * 64], Y[ib][s], pa[s]);
+      }
+      const v4d acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+      v4d po[4] = {v4zero(), v4zero(), v4zero(), v4zero()};
+      const double *f = F + (jb * (jb + 1) / 2 + jb) * 256 + lane;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) po[s] = mfma16(f[s * 64], acc[s], po[s]);
+      const v4d out = (po[0] + po[1]) + (po[2] + po[3]);
+      Y[jb] = out;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = jb * MB + lg + 4 * r;
+        if (nok && m < p.nbk) base[m * p.stride_m] = out[r];
+      }
+    }
+  }
+
+  if (FUSE_Y) {
+    // y[n] -= sum_m X[n][m] z[m]   (forward substitution carried by the panel)
+    double part = 0.;
+#pragma unroll
+    for (int jb = 0; jb < NMB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part += Y[jb][r] * zs[jb * MB + lg + 4 * r];
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (lg == 0 && nok) p.yrest[n0 + ln] -= part;
+  }
+}
+
+}  // namespace agp

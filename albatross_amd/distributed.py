@@ -48,8 +48,6 @@ class ShardLayout:
             return np.zeros(0, dtype=np.int64)
         return np.concatenate([np.arange(b * self.block, b * self.block + self.width(b), dtype=np.int64) for b in blocks])
 
-    def work_doubles(self, rank):
-        return self._lib.agp_shard_work_doubles(self.n, self.block, self.world, rank)
 
 
 class Communicator:

@@ -114,12 +114,6 @@ class Context:
         self._check(self._lib.agp_last_stage_ms(self._h, stage, C.byref(v)), "last_stage_ms")
         return v.value
 
-    def mfma_f64_peak(self, iters=20000):
-        v = C.c_double()
-        self._check(self._lib.agp_mfma_f64_peak(self._h, iters, C.byref(v)), "mfma_f64_peak")
-        return v.value
-
-    # --- Gram ------------------------------------------------------------------
     def gram(self, cov, xs, ys=None):
         """compute_covariance_matrix (callers.hpp:38-166) on the device."""
         if has_linear_combinations(xs) or (ys is not None and has_linear_combinations(ys)):

@@ -2,7 +2,7 @@
 // a machine WITHOUT a GPU (examples/Makefile: `make asan`).  Two parts:
 //
 //  1. the sharded-fit schedule (albatross_amd/csrc/shard_sched.hip is plain C++: compiled INTO this binary with the
-//     sanitizers on) driven through agp_shard_factor_custom with naive block operations, one rank and - through
+//     sanitizers on) driven through agp_debug_shard_factor_custom (csrc/shard_custom.hip) with naive block operations, one rank and - through
 //     in-process "collectives" - the forced multi-rank path; checked against a naive dense solve;
 //  2. the header-only host layer (include/albatross_amd/albatross.hpp): covariance-function programs, parameter
 //     handling, feature flattening (Measurement<>, scale columns), grouping - everything that runs before the
@@ -15,6 +15,13 @@
 #include <vector>
 
 #include "albatross_amd/albatross.hpp"
+#include "shard_internal.h"  // agp_shard_ops_callbacks (csrc/, test-only)
+
+extern "C" {
+int64_t agp_debug_shard_work_doubles(int64_t n, int64_t block, int nranks, int rank);
+int agp_debug_shard_factor_custom(const agp_shard_ops_callbacks *ops, agp_comm *comm, int64_t n, int64_t block, double *A, int64_t ld,
+                                  double *y, double *work, double *information, double *log_det, int64_t *bad_pivot);
+}
 
 using namespace albatross;
 
@@ -135,7 +142,7 @@ void schedule_under_sanitizers(bool force_comm) {
   const std::int64_t n_loc = agp_shard_local_rows(n, block, 1, 0);
   require(n_loc == n, "one rank owns every row");
   const std::int64_t ld = n_loc + 1;
-  std::vector<double> A((size_t)ld * n, std::nan("")), yl(y), work((size_t)agp_shard_work_doubles(n, block, 1, 0), std::nan("")), info(n);
+  std::vector<double> A((size_t)ld * n, std::nan("")), yl(y), work((size_t)agp_debug_shard_work_doubles(n, block, 1, 0), std::nan("")), info(n);
   for (std::int64_t l = 0; l < n_loc; ++l) {
     const std::int64_t g = agp_shard_global_row(n, block, 1, 0, l);
     const std::int64_t end = std::min<std::int64_t>(n, (g / block + 1) * block);
@@ -144,8 +151,8 @@ void schedule_under_sanitizers(bool force_comm) {
   agp_shard_ops_callbacks ops{nullptr, cb_factor_diag, cb_trsm_rows, cb_gemm, cb_copy2d, cb_invert_diag, cb_colvec_dot, cb_axpby, cb_fill_zero};
   double logdet = 0.;
   std::int64_t bad = -1;
-  const int st = agp_shard_factor_custom(&ops, comm, n, block, A.data(), ld, yl.data(), work.data(), info.data(), &logdet, &bad);
-  require(st == AGP_OK && bad == -1, "agp_shard_factor_custom");
+  const int st = agp_debug_shard_factor_custom(&ops, comm, n, block, A.data(), ld, yl.data(), work.data(), info.data(), &logdet, &bad);
+  require(st == AGP_OK && bad == -1, "agp_debug_shard_factor_custom");
   double worst = 0., scale = 0.;
   for (std::int64_t i = 0; i < n; ++i) { worst = std::fmax(worst, std::fabs(info[i] - ref[i])); scale = std::fmax(scale, std::fabs(ref[i])); }
   require(worst <= 1e-9 * scale, "sharded schedule == dense solve");

@@ -453,8 +453,9 @@ AGP_API int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_f
  *              carries 1/G of the panel at the same time)                    (RCCL all-gather)
  *   every rank C[own rows, cols > k] -= X_own P^T                            (fp64 MFMA update kernels)
  * with one block column of look-ahead: the owner of block k + 1 updates and factors its diagonal block while the
- * panel of step k is still being gathered and applied.  information = L^-T z follows block by block with one
- * small all-reduce per block.  Every rank receives the full information vector and log-determinant.
+ * panel of step k is still being gathered and applied.  information = L^-T z follows super-block by super-block (four
+ * row blocks: every rank keeps the diagonal super-blocks and solves them redundantly) with ONE small all-reduce per
+ * super-block.  Every rank receives the full information vector and log-determinant.
  *
  * agp_comm wraps the transport: RCCL (librccl of the ROCm installation, loaded at first use), or - for tests and
  * for boxes where RCCL cannot be used (it refuses two ranks on one device) - collectives supplied by the caller. */
@@ -494,8 +495,6 @@ AGP_API int64_t agp_shard_local_rows(int64_t n, int64_t block, int nranks, int r
 /* global row of local row l of `rank` (l < agp_shard_local_rows) */
 AGP_API int64_t agp_shard_global_row(int64_t n, int64_t block, int nranks, int rank, int64_t l);
 AGP_API int agp_shard_owner(int64_t block_index, int nranks);
-/* doubles of scratch agp_shard_factor_custom needs */
-AGP_API int64_t agp_shard_work_doubles(int64_t n, int64_t block, int nranks, int rank);
 
 typedef struct agp_sharded_fit agp_sharded_fit;
 /* One fit over all ranks of `comm`; collective.  Every rank passes the SAME full dataset (x, y, y_var as in
@@ -524,39 +523,6 @@ AGP_API int agp_sharded_predict_marginal(agp_context *ctx, const agp_kernel *k, 
  * schedule, 7 host time until the device had drained (6 ~ 7: the host is the bottleneck) */
 AGP_API int agp_sharded_fit_stage(const agp_sharded_fit *fit, int stage, double *value);
 
-/* The same schedule (factorisation + both substitutions) on a rank-local matrix the CALLER built, with the block
- * arithmetic supplied through callbacks instead of the HIP kernels: test instrumentation - tests/ drives the
- * library's C++ schedule with numpy block operations and gloo collectives on CPU-only machines, world size > 1.
- * All matrices column-major; pointers are whatever the callbacks understand (host memory in the tests).
- *   A      local stacked rows (agp_shard_local_rows x n, leading dimension ld), lower staircase filled
- *   y      the targets of the local rows (agp_shard_local_rows doubles), overwritten
- *   work   agp_shard_work_doubles doubles of scratch in the same memory space */
-typedef struct {
-  void *user;
-  /* LL^T of the w x w block D (ld) in place, z <- L^-1 z on the w entries at zblk; img: scratch the other callbacks
-   * get back (4 * 9216 doubles); returns 0, or 1 + index of the first non-positive pivot */
-  int64_t (*factor_diag)(void *user, double *D, int64_t ld, int64_t w, double *img, double *zblk, double *logsum);
-  /* X (nrows x w, ld) <- X L^-T with L the w x w lower triangle at Lkk (leading dimension w);
-   * yrows[r] -= sum_c X[r][c] z[c] */
-  void (*trsm_rows)(void *user, double *X, int64_t ld, int64_t nrows, int64_t w, const double *Lkk,
-                    const double *img, const double *z, double *yrows);
-  /* C (M x N, ldc) -= P (M x K, ldp) Q (N x K, ldq)^T; tri: only entries on / below the diagonal of C are needed */
-  void (*gemm)(void *user, double *C, int64_t ldc, const double *P, int64_t ldp, const double *Q, int64_t ldq,
-               int64_t M, int64_t N, int64_t K, int tri);
-  void (*copy2d)(void *user, double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int64_t cols);
-  /* W (w x w, ld = w) <- inv(L) of the factored diagonal block D */
-  void (*invert_diag)(void *user, const double *D, int64_t ld, int64_t w, const double *img, double *W);
-  /* out[c] = alpha sum_r W[r][c] v[r] + beta base[c],  r < m, c < n (base may be NULL when beta == 0) */
-  void (*colvec_dot)(void *user, const double *W, int64_t ld, int64_t m, int64_t n, const double *v, double alpha,
-                     double beta, const double *base, double *out);
-  /* out = a x + b y */
-  void (*axpby)(void *user, int64_t n, double a, const double *x, double b, const double *y, double *out);
-  void (*fill_zero)(void *user, double *p, int64_t count);
-} agp_shard_ops_callbacks;
-AGP_API int agp_shard_factor_custom(const agp_shard_ops_callbacks *ops, agp_comm *comm, int64_t n, int64_t block, double *A,
-                            int64_t ld, double *y, double *work, double *information, double *log_det,
-                            int64_t *bad_pivot);
-
 /* ---- instrumentation (bench.py) ----------------------------------------- */
 /* Per-stage device time of the LAST fit / nll on this context, measured with
  * HIP events on the stream the kernels were launched on.  Stages:
@@ -566,9 +532,25 @@ AGP_API int agp_last_stage_ms(const agp_context *ctx, int stage, double *ms);
 /* enable (1) / disable (0) per-stage event timing (default off: events add
  * host overhead to the launch chain). */
 AGP_API int agp_set_profiling(agp_context *ctx, int enabled);
-/* Bare v_mfma_f64_16x16x4_f64 issue loop: measured fp64 MFMA TFLOP/s of this
- * device (used as a cross-check of the roofline denominator). */
-AGP_API int agp_mfma_f64_peak(agp_context *ctx, int iters, double *tflops);
+
+/* ---- switches ------------------------------------------------------------
+ * The library reads the following environment variables, ONCE per context, in agp_context_create (csrc/api.hip:
+ * read_tuning); a later change of the environment does not affect an existing context.  Nothing else is switchable:
+ * the schedule's other parameters are constants (csrc/chol.hip).
+ *   AGP_PANEL_FUSED=0        POTRF and panel TRSM as two launches instead of the fused panel kernel
+ *   AGP_STEP_BELOW=<rows>    remaining rows at or below which every panel is ONE step launch (default 4608; 0: off)
+ *   AGP_GRAM_SOP=0           covariance trees through the stack interpreter only (parity tests run both evaluators)
+ *   AGP_SPARSE_PIVOTED=1     the sparse GP always takes the literal (pivoted LDL^T + column-pivoted QR) path
+ *   AGP_PREDICT_CHUNK=<m>    test points per slice of marginal predictions (default: by memory, 2 GiB per slice)
+ *   AGP_SHARD_BLOCK=<b>      128 / 256 / 512 rows per row block of the sharded fit (default 512; tests)
+ *   AGP_SHARD_FORCE_COMM=1   ONE rank runs the multi-rank schedule through its transport (RCCL group of one; tests)
+ *   AGP_SHARD_HOST_PACING=1  the sharded schedule is paced by the host instead of device-side flags
+ * and, process-wide, at first use:
+ *   AGP_COMM_TIMEOUT_S=<s>   deadline of every wait that may hold a collective (default 120)
+ *   AGP_RCCL_LIB=<path>      librccl to dlopen (default: the ROCm installation's)
+ *   AGP_ROCTX=1              roctx ranges around the stages (rocprofv3 --marker-trace)
+ * Test-only entry points (kernel probes, the schedule over caller-supplied block arithmetic, a transport that moves
+ * nothing) are `agp_debug_*` in libalbatross_amd_debug.so and are not part of this interface. */
 
 #ifdef __cplusplus
 }

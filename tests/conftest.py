@@ -37,6 +37,22 @@ def ctx():
     c.close()
 
 
+@pytest.fixture
+def make_ctx():
+    """Contexts created INSIDE a test, after it has set the switches the library reads once per context
+    (include/albatross_amd.h, "switches": AGP_STEP_BELOW, AGP_GRAM_SOP, AGP_SHARD_BLOCK, ...)."""
+    import albatross_amd as ab
+    made = []
+
+    def make():
+        c = ab.Context(0)
+        made.append(c)
+        return c
+    yield make
+    for c in made:
+        c.close()
+
+
 def synthetic_3d(n, seed):
     """SURVEY.md section 8d configs 2/3, exactly as pinned there and as bench.py times them: X ~ U[0,10]^3 from libstdc++'s
     mt19937(seed) + uniform_real_distribution (bench.mt19937_uniform reproduces it bit for bit, checked against the

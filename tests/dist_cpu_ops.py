@@ -1,4 +1,4 @@
-"""TEST-ONLY numpy implementation of the block arithmetic (`agp_shard_ops_callbacks`, include/albatross_amd.h) that the
+"""TEST-ONLY numpy implementation of the block arithmetic (`agp_shard_ops_callbacks`, csrc/shard_internal.h) that the
 library's C++ sharded-fit schedule (albatross_amd/csrc/shard_sched.hip) is written against, so that the schedule -
 ownership, broadcasts, all-gathers, look-ahead, both substitutions - runs on CPU-only machines over gloo with world
 sizes > 1.  The product uses HipShardOps (the HIP kernels) instead; nothing under albatross_amd/ imports this file."""
@@ -91,7 +91,7 @@ def sharded_factor_numpy(K_lower_full, y, block, comm):
     used).  comm: albatross_amd.distributed.Communicator or None.  Returns (status, information, log_det, bad_pivot,
     ops.calls)."""
     from albatross_amd.distributed import ShardLayout
-    lib = capi.load()
+    lib = capi.load_debug()  # the schedule over caller-supplied block arithmetic is a TEST entry point (csrc/debug_api.hip)
     n = K_lower_full.shape[0]
     world = 1 if comm is None else comm.world
     rank = 0 if comm is None else comm.rank
@@ -106,11 +106,11 @@ def sharded_factor_numpy(K_lower_full, y, block, comm):
         A[l, :g + 1] = K_lower_full[g, :g + 1]
         A[l, g + 1:end] = K_lower_full[g + 1:end, g]  # the upper part of the diagonal block may be touched (symmetric)
     yl = np.ascontiguousarray(y[rows], dtype=np.float64) if n_loc else np.zeros(1)
-    work = np.full(lay.work_doubles(rank), np.nan)
+    work = np.full(lib.agp_debug_shard_work_doubles(n, block, world, rank), np.nan)
     info = np.full(n, np.nan)
     logdet, bad = C.c_double(), C.c_int64(-1)
     ops = NumpyShardOps()
-    st = lib.agp_shard_factor_custom(C.byref(ops.struct), None if comm is None else comm._h, n, block,
+    st = lib.agp_debug_shard_factor_custom(C.byref(ops.struct), None if comm is None else comm._h, n, block,
                                      C.c_void_p(A.ctypes.data), ld, C.c_void_p(yl.ctypes.data), C.c_void_p(work.ctypes.data),
                                      C.c_void_p(info.ctypes.data), C.byref(logdet), C.byref(bad))
     return st, info, logdet.value, bad.value, ops.calls

@@ -1,6 +1,6 @@
 """CPU tests (-m "not gpu") of the multi-GPU path: the library's C++ sharded-fit schedule
 (albatross_amd/csrc/shard_sched.hip: row-block-cyclic LL^T with look-ahead, both substitutions) driven through
-`agp_shard_factor_custom` with numpy block operations (tests/dist_cpu_ops.py) and gloo collectives
+`agp_debug_shard_factor_custom` (libalbatross_amd_debug.so) with numpy block operations (tests/dist_cpu_ops.py) and gloo collectives
 (`Communicator.torch_callbacks`), world sizes 1-8, checked against the oracle."""
 import os
 import socket

@@ -31,8 +31,9 @@ def problem(n, dim=3):
 
 
 @pytest.mark.parametrize("n,block", [(100, 128), (700, 128), (1500, 512), (2048, 512), (1000, 256), (3000, 512)])
-def test_sharded_fit_one_rank_matches_oracle(ctx, n, block, monkeypatch):
+def test_sharded_fit_one_rank_matches_oracle(make_ctx, n, block, monkeypatch):
     monkeypatch.setenv("AGP_SHARD_BLOCK", str(block))
+    ctx = make_ctx()  # (the switches are read when the context is created)
     x, y, yvar = problem(n)
     cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
     res = ShardedGaussianProcessFit(ctx, cov).fit(x, y, yvar)
@@ -45,7 +46,7 @@ def test_sharded_fit_one_rank_matches_oracle(ctx, n, block, monkeypatch):
 
 
 @pytest.mark.parametrize("n,block,forced", [(900, 128, False), (1700, 256, True), (2048, 512, True), (1300, 512, False)])
-def test_sharded_predict_marginal_without_replication(ctx, n, block, forced, monkeypatch):
+def test_sharded_predict_marginal_without_replication(make_ctx, n, block, forced, monkeypatch):
     """agp_sharded_predict_marginal: the distributed forward substitution on one rank - without a transport (the local
     matrix is the whole factor) and with the multi-rank schedule forced on through an RCCL group of one (every
     broadcast / all-reduce a real RCCL call) - against the oracle."""
@@ -53,9 +54,11 @@ def test_sharded_predict_marginal_without_replication(ctx, n, block, forced, mon
     comm = None
     if forced:
         monkeypatch.setenv("AGP_SHARD_FORCE_COMM", "1")
-        comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id())
     else:
         monkeypatch.delenv("AGP_SHARD_FORCE_COMM", raising=False)
+    ctx = make_ctx()  # (the switches are read when the context is created)
+    if forced:
+        comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id())
     try:
         x, y, yvar = problem(n)
         cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
@@ -72,11 +75,12 @@ def test_sharded_predict_marginal_without_replication(ctx, n, block, forced, mon
 
 
 @pytest.mark.parametrize("n,block", [(700, 128), (1000, 256), (1500, 512)])
-def test_one_rank_replicate_any_block(ctx, n, block, monkeypatch):
+def test_one_rank_replicate_any_block(make_ctx, n, block, monkeypatch):
     """agp_sharded_fit_replicate on the one-rank, no-transport path: the tile images are laid out per 128-block by the
     single-GPU factorisation whatever AGP_SHARD_BLOCK says (it used to read them with the 512-block stride)."""
     monkeypatch.setenv("AGP_SHARD_BLOCK", str(block))
     monkeypatch.delenv("AGP_SHARD_FORCE_COMM", raising=False)
+    ctx = make_ctx()
     x, y, yvar = problem(n)
     cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
     sharded = ShardedGaussianProcessFit(ctx, cov)
@@ -104,8 +108,9 @@ def test_sharded_fit_config3_size_one_rank(ctx):
     assert abs(res.log_determinant - fm.get_fit().log_determinant) <= 1e-9 * abs(res.log_determinant)
 
 
-def test_sharded_fit_errors(ctx, monkeypatch):
+def test_sharded_fit_errors(make_ctx, monkeypatch):
     monkeypatch.setenv("AGP_SHARD_BLOCK", "128")
+    ctx = make_ctx()
     x, y, yvar = problem(600)
     with pytest.raises(ab.NotPositiveDefiniteError, match="pivot 5"):
         ShardedGaussianProcessFit(ctx, ab.SquaredExponential(1., 1.)).fit(x, y)
@@ -120,11 +125,12 @@ def test_sharded_fit_errors(ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("n,block", [(900, 256), (1700, 128), (2048, 512)])
-def test_sharded_fit_through_rccl_group_of_one(ctx, n, block, monkeypatch):
+def test_sharded_fit_through_rccl_group_of_one(make_ctx, n, block, monkeypatch):
     """RCCL itself (the ROCm installation's librccl, bound by the library at run time): communicator of size one, the
     multi-rank schedule forced on, so that ncclBroadcast / ncclAllGather / ncclAllReduce run on the library's streams"""
     monkeypatch.setenv("AGP_SHARD_BLOCK", str(block))
     monkeypatch.setenv("AGP_SHARD_FORCE_COMM", "1")
+    ctx = make_ctx()
     comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id())
     try:
         assert comm.world == 1 and comm.rank == 0
@@ -152,13 +158,14 @@ def test_sharded_fit_through_rccl_group_of_one(ctx, n, block, monkeypatch):
         comm.close()
 
 
-def test_sharded_fit_config3_size_through_rccl(ctx, monkeypatch):
+def test_sharded_fit_config3_size_through_rccl(make_ctx, monkeypatch):
     """The multi-rank schedule at BASELINE config 3's size (N = 16384, 512-row blocks, 32 block columns) with every
     broadcast / all-gather / all-reduce a real RCCL call (communicator of size one): same answer as agp_fit_create on
     the dataset bench.py times."""
     from bench import make_dataset
     monkeypatch.setenv("AGP_SHARD_FORCE_COMM", "1")
     monkeypatch.delenv("AGP_SHARD_BLOCK", raising=False)
+    ctx = make_ctx()
     comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id())
     try:
         x, y = make_dataset(16384, 44)

@@ -441,7 +441,7 @@ def test_single_point_prediction_uses_the_vector_chain(ctx):
     assert abs(pj.covariance[0, 0] - ov[0]) <= 1e-8 * abs(ov[0])
 
 
-def test_marginal_prediction_in_slices_matches_one_pass(ctx, monkeypatch):
+def test_marginal_prediction_in_slices_matches_one_pass(make_ctx, monkeypatch):
     """Marginal predictions pass over the test points in slices that bound the n x M workspace (2 GiB by default;
     AGP_PREDICT_CHUNK forces the slice): same numbers as one pass, for the dense and the sparse model, with a scaling
     term in the covariance (the sub-views keep the stride of the scale columns)."""
@@ -460,14 +460,15 @@ def test_marginal_prediction_in_slices_matches_one_pass(ctx, monkeypatch):
             return 1. + 0.1 * np.asarray(c)[:, 0]
 
     cov = ab.ScalingTerm(Ramp()) * ab.Constant(0.7) + ab.Matern52(1.5, 1.2) + ab.measurement_only(ab.IndependentNoise(0.2))
-    model = ab.gp_from_covariance(cov, context=ctx)
-    fm = model.fit(ab.RegressionDataset(x, y))
-    sparse = ab.sparse_gp_from_covariance(cov, lambda f: int(f[0] // 1.0), ab.FixedInducingPoints(x[:60]), "s", context=ctx)
-    sparse.set_param("inducing_nugget", 1e-6)
-    sfm = sparse.fit(ab.RegressionDataset(x, y))
     results = []
     for chunk in ("0", "1000"):  # one pass; three slices, the last one partial
         monkeypatch.setenv("AGP_PREDICT_CHUNK", chunk)
+        ctx = make_ctx()  # (the switch is read when the context is created)
+        model = ab.gp_from_covariance(cov, context=ctx)
+        fm = model.fit(ab.RegressionDataset(x, y))
+        sparse = ab.sparse_gp_from_covariance(cov, lambda f: int(f[0] // 1.0), ab.FixedInducingPoints(x[:60]), "s", context=ctx)
+        sparse.set_param("inducing_nugget", 1e-6)
+        sfm = sparse.fit(ab.RegressionDataset(x, y))
         dense = fm.predict_with_measurement_noise(xs).marginal()
         sm = sfm.predict_with_measurement_noise(xs).marginal()
         results.append((dense.mean, dense.covariance, sm.mean, sm.covariance))

@@ -175,11 +175,12 @@ def _random_tree(rng, depth, dim):
 
 @pytest.mark.parametrize("evaluator", ["sop", "interpreter"])
 @pytest.mark.parametrize("seed", range(24))
-def test_random_covariance_trees_match_oracle(ctx, seed, evaluator, monkeypatch):
+def test_random_covariance_trees_match_oracle(make_ctx, seed, evaluator, monkeypatch):
     """Parity sweep of both generic evaluators (sum-of-products where the tree expands to few products, the
     postfix interpreter otherwise or when AGP_GRAM_SOP=0): random sums / products / measurement-only wrappers of
     every leaf, symmetric and cross Gram, plain and Measurement<> features, with repeated points (equality terms)."""
     monkeypatch.setenv("AGP_GRAM_SOP", "1" if evaluator == "sop" else "0")
+    ctx = make_ctx()  # (the switch is read when the context is created)
     rng = np.random.default_rng(1000 + seed)
     dim = int(rng.integers(1, 4))
     cov = _random_tree(rng, 3, dim)

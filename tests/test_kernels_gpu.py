@@ -43,8 +43,11 @@ def test_mfma_f64_lane_map(ctx, dbg):
     assert np.array_equal(D, A @ B)
 
 
-def test_mfma_peak_is_sane(ctx):
-    tf = ctx.mfma_f64_peak(4000)
+def test_mfma_peak_is_sane(ctx, dbg):
+    out = C.c_double()
+    dbg.agp_debug_mfma_f64_peak.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    assert dbg.agp_debug_mfma_f64_peak(ctx._h, 4000, C.byref(out)) == 0
+    tf = out.value
     print(f"measured fp64 MFMA issue-loop rate: {tf:.1f} TFLOP/s")
     assert 20. < tf < 400.
 
@@ -140,42 +143,21 @@ def test_factor_reports_first_bad_pivot(ctx, dbg):
     assert bad.value == 200
 
 
-@pytest.mark.parametrize("n", [700, 2304])
-def test_update_ahead_panel_kernel(ctx, dbg, n, monkeypatch):
-    """AGP_UPD_BELOW: the panel kernel that also applies the previous panel's update (chol.hip: panel_fused_kernel<true>,
-    an experiment that is off by default) gives the same factor as the default schedule."""
-    rng = np.random.default_rng(n)
-    B = rng.standard_normal((n, n))
-    A = np.asfortranarray(B @ B.T + n * np.eye(n))
-    y = rng.standard_normal(n)
-    out = {}
-    for mode in ("0", "8192"):
-        monkeypatch.setenv("AGP_UPD_BELOW", mode)
-        Ad, yd = A.copy(order="F"), y.copy()
-        logdet, bad = C.c_double(), C.c_int64()
-        assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
-        assert bad.value == -1
-        out[mode] = (np.tril(Ad), yd, logdet.value)
-    L = np.linalg.cholesky(A)
-    for mode in out:
-        assert np.abs(out[mode][0] - L).max() <= 1e-11 * np.abs(L).max()
-        assert np.abs(out[mode][1] - np.linalg.solve(L, y)).max() <= 1e-10
-    assert abs(out["0"][2] - out["8192"][2]) <= 1e-10 * abs(out["0"][2])
-
-
 @pytest.mark.parametrize("n", [129, 700, 1500, 2304, 3400])
-def test_panel_step_kernel(ctx, dbg, n, monkeypatch):
+def test_panel_step_kernel(make_ctx, dbg, n, monkeypatch):
     """AGP_STEP_BELOW: the chain-bound tail as ONE launch per panel (chol.hip: panel_phase step_mode - the update-ahead panel
-    kernel plus trailing-update workgroups in the same launch) against the two-launch tail and numpy; sizes with a partial
-    last panel, a partial last 64-row tile, and a tail that starts in the middle of the matrix."""
+    kernel plus trailing-update workgroups in the same launch) against the two-launch tail (AGP_STEP_BELOW=0, and with
+    AGP_PANEL_FUSED=0 the round-2 POTRF / TRSM launches) and numpy; sizes with a partial last panel, a partial last
+    64-row tile, and a tail that starts in the middle of the matrix.  The switches are read per context."""
     rng = np.random.default_rng(n)
     B = rng.standard_normal((n, n))
     A = np.asfortranarray(B @ B.T + n * np.eye(n))
     y = rng.standard_normal(n)
     out = {}
-    monkeypatch.setenv("AGP_STEP_TILE128_ABOVE", "2048")  # (read once per process: the 128 x 128 trailing tiles get covered too)
-    for mode in ("0", "2048", "8192"):  # 8192: every panel a step launch, 128 x 128 trailing tiles while > 2048 rows remain
-        monkeypatch.setenv("AGP_STEP_BELOW", mode)
+    for mode in ("0", "2048", "8192", "unfused"):  # 8192: every panel a step launch
+        monkeypatch.setenv("AGP_STEP_BELOW", "0" if mode == "unfused" else mode)
+        monkeypatch.setenv("AGP_PANEL_FUSED", "0" if mode == "unfused" else "1")
+        ctx = make_ctx()
         Ad, yd = A.copy(order="F"), y.copy()
         logdet, bad = C.c_double(), C.c_int64()
         assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
@@ -185,50 +167,8 @@ def test_panel_step_kernel(ctx, dbg, n, monkeypatch):
     for mode in out:
         assert np.abs(out[mode][0] - L).max() <= 1e-11 * np.abs(L).max()
         assert np.abs(out[mode][1] - np.linalg.solve(L, y)).max() <= 1e-10
-    for mode in ("2048", "8192"):
+    for mode in ("2048", "8192", "unfused"):
         assert abs(out["0"][2] - out[mode][2]) <= 1e-10 * abs(out["0"][2])
-
-
-@pytest.mark.parametrize("n,split", [(3000, "1024"), (3400, "2000"), (2100, "256")])
-def test_panel_step_kernel_split(ctx, dbg, n, split, monkeypatch):
-    """AGP_STEP_SPLIT_ABOVE: the step launches with many rows left hand the update of everything right of the panel to a
-    kernel of its own on the second stream; its counted tiles are what the next launch waits for.  Against numpy, with the
-    switch into and out of the split launches inside the matrix."""
-    rng = np.random.default_rng(n)
-    B = rng.standard_normal((n, n))
-    A = np.asfortranarray(B @ B.T + n * np.eye(n))
-    y = rng.standard_normal(n)
-    monkeypatch.setenv("AGP_STEP_BELOW", "8192")
-    monkeypatch.setenv("AGP_STEP_SPLIT_ABOVE", split)
-    L = np.linalg.cholesky(A)
-    for rep in range(2):  # (the counters are reset per factorisation)
-        Ad, yd = A.copy(order="F"), y.copy()
-        logdet, bad = C.c_double(), C.c_int64()
-        assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
-        assert bad.value == -1
-        assert np.abs(np.tril(Ad) - L).max() <= 1e-11 * np.abs(L).max()
-        assert np.abs(yd - np.linalg.solve(L, y)).max() <= 1e-10
-
-
-@pytest.mark.parametrize("hold,slots", [("0", "512"), ("1000", "512"), ("1", "96"), ("10", "300")])
-def test_panel_step_kernel_layouts(ctx, dbg, hold, slots, monkeypatch):
-    """The step launches with other workgroup layouts than the default: no placeholder workgroups / one next to every critical
-    workgroup / few slots (every trailing workgroup loops over many tiles; the row tiles still come first)."""
-    n = 3000
-    rng = np.random.default_rng(7)
-    B = rng.standard_normal((n, n))
-    A = np.asfortranarray(B @ B.T + n * np.eye(n))
-    y = rng.standard_normal(n)
-    monkeypatch.setenv("AGP_STEP_BELOW", "8192")
-    monkeypatch.setenv("AGP_STEP_HOLD", hold)
-    monkeypatch.setenv("AGP_STEP_SLOTS", slots)
-    Ad, yd = A.copy(order="F"), y.copy()
-    logdet, bad = C.c_double(), C.c_int64()
-    assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
-    assert bad.value == -1
-    L = np.linalg.cholesky(A)
-    assert np.abs(np.tril(Ad) - L).max() <= 1e-11 * np.abs(L).max()
-    assert np.abs(yd - np.linalg.solve(L, y)).max() <= 1e-10
 
 
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 500, 4096, 4097, 9000])
@@ -252,27 +192,3 @@ def test_symv_lower(ctx, dbg, n):
     assert dbg.agp_debug_symv_lower(ctx._h, _p(Kd), n, ld, _p(p), 1.0, 0.0, None, _p(out)) == 0
     assert np.abs(out - K @ p).max() <= 1e-12 * max(1., np.abs(K).sum(axis=1).max() * np.abs(p).max())
 
-
-def test_merged_trailing_update(ctx, dbg, monkeypatch):
-    """AGP_MERGE_ABOVE: U1 merged into the bulk update, whose first tile columns count themselves complete while the next
-    panel's POTRF waits for that count inside the kernel (chol.hip: factor_lower; an experiment that is off by default):
-    same factor as the default schedule.  Needs >= 8192 trailing rows for the counted tiles to lie in the first launch."""
-    n = 9728
-    rng = np.random.default_rng(7)
-    B = rng.standard_normal((n, 64))
-    A = np.asfortranarray(B @ B.T + 64. * np.eye(n))
-    y = rng.standard_normal(n)
-    out = {}
-    for mode in ("0", "2048"):
-        monkeypatch.setenv("AGP_MERGE_ABOVE", mode)
-        Ad, yd = A.copy(order="F"), y.copy()
-        logdet, bad = C.c_double(), C.c_int64()
-        assert dbg.agp_debug_factor(ctx._h, _p(Ad), n, n, _p(yd), C.byref(logdet), C.byref(bad)) == 0
-        assert bad.value == -1
-        out[mode] = (np.tril(Ad), yd, logdet.value)
-    L0, L1 = out["0"][0], out["2048"][0]
-    assert np.abs(L0 - L1).max() <= 1e-11 * np.abs(L0).max()
-    assert np.abs(out["0"][1] - out["2048"][1]).max() <= 1e-10 * np.abs(out["0"][1]).max()
-    assert abs(out["0"][2] - out["2048"][2]) <= 1e-10 * abs(out["0"][2])
-    rows = rng.integers(0, n, 40)
-    assert np.abs((L1[rows] @ L1.T) - A[rows]).max() <= 1e-11 * np.abs(A).max()

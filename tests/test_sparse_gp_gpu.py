@@ -371,11 +371,12 @@ def test_rebase_well_conditioned_matches_oracle(ctx):
 
 
 @pytest.mark.parametrize("n,m,width", [(60, 7, 5.0), (400, 40, 2.5)])
-def test_pivoted_fit_matches_oracle(ctx, monkeypatch, n, m, width):
+def test_pivoted_fit_matches_oracle(make_ctx, monkeypatch, n, m, width):
     """The reference's own algorithm on the device (pivoted L D L^T of K_uu, column-pivoted QR of B: the path that takes
     over where LL^T / CholeskyQR2 reject the matrices), forced on a well-conditioned problem: fit, likelihood, rank,
     predictions and an update against the oracle."""
     monkeypatch.setenv("AGP_SPARSE_PIVOTED", "1")
+    ctx = make_ctx()  # (the switch is read when the context is created)
     rng = np.random.default_rng(n)
     x = rng.uniform(0., 20., n)
     y = np.sin(x) + 0.3 * x + 0.1 * rng.standard_normal(n)
