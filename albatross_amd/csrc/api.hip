@@ -90,6 +90,7 @@ static agp_context::Tuning read_tuning() {
   t.shard_block = number("AGP_SHARD_BLOCK", 0);
   t.shard_force_comm = flag("AGP_SHARD_FORCE_COMM", false);
   t.shard_host_pacing = flag("AGP_SHARD_HOST_PACING", false);
+  if (const char *e = getenv("AGP_SHARD_MASK_GFLOP")) t.shard_mask_gflop = atof(e);
   return t;
 }
 

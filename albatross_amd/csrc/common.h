@@ -120,6 +120,7 @@ struct agp_context {
     long long shard_block = 0;     // AGP_SHARD_BLOCK: 128 / 256 / 512 rows per row block of the sharded fit (0: 512)
     bool shard_force_comm = false; // AGP_SHARD_FORCE_COMM=1: ONE rank runs the multi-rank schedule through its transport
     bool shard_host_pacing = false;  // AGP_SHARD_HOST_PACING=1: the sharded schedule is paced by the host (round-3 scheme)
+    double shard_mask_gflop = 40.;   // AGP_SHARD_MASK_GFLOP: bulk update per step below which a sharded fit is chain-bound
   } tune;
   unsigned long long *d_rowcnt = nullptr;  // one counter per 64 rows (tail of the d_dpub allocation): hand-over of the step launches' row updates
   // Early inversion of the wide diagonal blocks for the backward substitution of a fit (api.hip: backward_solve_vec_any):

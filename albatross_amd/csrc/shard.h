@@ -128,6 +128,10 @@ struct ShardOps {
   // Returns AGP_OK, AGP_ERR_COMM after the transport's timeout (host pacing), AGP_ERR_HIP on a device error.
   virtual void record(int ev, int q) { (void)ev; (void)q; }
   virtual int wait(int q, int ev) { (void)q; (void)ev; return AGP_OK; }
+  // hooks of the schedule: before the first step (the plan is known) and at the top of every block column k, before
+  // anything of that step is enqueued.  A backend may change how it paces or where it runs its bulk updates there.
+  virtual void begin(const ShardPlan &plan) { (void)plan; }
+  virtual int step_begin(long long k) { (void)k; return AGP_OK; }
   // drain every queue; AGP_OK or an error status
   virtual int sync_all() { return AGP_OK; }
   // {sum of log L_ii over this rank's diagonal blocks, 1 + global index of its first non-positive pivot or 0}

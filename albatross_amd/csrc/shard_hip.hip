@@ -308,18 +308,18 @@ struct HipShardOps : ShardOps {
   void decide() {
     if (decided) return;
     decided = true;
-    if (device_pacing && !ctx->shard_probe_ok) {  // the queues are the context's own: the answer holds for its lifetime
-      device_pacing = probe_queues();
-      if (device_pacing) ctx->shard_probe_ok = true;
-      else ctx->shard_host_pacing = 1;
+    if ((device_pacing || allow_device) && !ctx->shard_probe_ok) {  // the queues are the context's own: the answer holds for its lifetime
+      const bool fine = probe_queues();
+      if (fine) ctx->shard_probe_ok = true;
+      else { ctx->shard_host_pacing = 1; device_pacing = allow_device = false; }
     }
     if (!device_pacing)
-      for (auto &e : ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+      for (auto &e : ev)
+        if (!e) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   }
   ~HipShardOps() override {
     for (auto e : ev) if (e) (void)hipEventDestroy(e);
     for (auto e : tev) (void)hipEventDestroy(e);
-    if (ev_switch) (void)hipEventDestroy(ev_switch);
   }
   // A gate kernel must never sit in FRONT of its producer in a hardware queue: the runtime maps HIP streams onto a few
   // hardware queues (GPU_MAX_HW_QUEUES) and serialises streams that share one.  One round of gates and signals between
@@ -400,27 +400,62 @@ struct HipShardOps : ShardOps {
       tused += 2;
     }
   }
-  // Chain-bound phase: the bulk update moves to the context's CU-MASKED stream (224 of 256 CUs, api.hip).  A bulk update
-  // that fills every CU holds all VGPRs and LDS: every kernel of the panel chain - and every record / wait launch -
-  // then waits ~50 us for a workgroup of it to retire before it can start (profiles/r04/timeline_sharded_rccl1_dev.txt:
-  // each small kernel 54 us), which is what made the chain 3x slower next to a full-size update.  With 4 CUs per XCD
-  // left free they start at once.  The update is chain-bound once (remaining rows)^2 / world <= 8704^2 (chol.hip:
-  // mask_below is the single-GPU point); the switch happens once per fit, ordered by one event.
+  // Two regimes of a sharded fit, told apart by the flop of this rank's bulk update U2(k) of a step:
+  //  * BULK-BOUND (U2 is longer than the step's panel chain): U2 on the ordinary bulk stream, all 256 CUs, and the schedule
+  //    paced by the HOST.  A bulk update that fills every CU holds all VGPRs and LDS: every launch next to it - the
+  //    one-thread record / wait kernels of the device pacing too - waits ~50 us for one of its workgroups to retire
+  //    (profiles/r04/timeline_sharded_rccl1_dev.txt: each small kernel 54 us), and the chain is hidden behind U2 anyway.
+  //  * CHAIN-BOUND (from step `switch_step` on): U2 on the context's CU-MASKED stream (224 of 256 CUs, api.hip), so that
+  //    the panel chain's launches start at once on the 4 free CUs per XCD, and DEVICE pacing - no host in the loop.
+  // The switch happens once per fit, at the top of a step, behind ONE drain of the three queues (so no wait ever
+  // refers to a record of the other mechanism).  Threshold: 40 GFLOP of U2 per step (AGP_SHARD_MASK_GFLOP), from
+  // scripts/sweep_shard_regime.sh on one rank's share (profiles/r04/sweep_shard_regime*.txt): N = 16384, 8 ranks: 9.5 ms
+  // against 10.8 (host, unmasked throughout) and 9.6 (device, masked throughout); N = 65536: 258 against 260 and 279.
+  // ONE rank running the multi-rank schedule (AGP_SHARD_FORCE_COMM, a test mode: every step an owner step next to a
+  // full-size bulk update) stays with the host: 41.5 ms against 45-60.
+  bool allow_device = false;   // device pacing is permitted (switch + probe) - used from switch_step on
+  long long switch_step = 0;   // first block column of the chain-bound regime
   bool bulk_masked = false;
-  hipEvent_t ev_switch = nullptr;
-  void maybe_switch_bulk_queue(const ShardPlan &plan, long long k) {
+  void begin(const ShardPlan &plan) override {
+    allow_device = device_pacing;
+    switch_step = 0;
+    if (!ctx->stream_masked) {  // no masked stream: one regime (device pacing everywhere if permitted)
+      switch_step = 0;
+    } else {
+      const double limit_gflop = plan.world > 1 ? ctx->tune.shard_mask_gflop : 0.;
+      const long long B = plan.B, nlb = plan.n_local_blocks(plan.rank);
+      for (long long k = 0; k + 2 < plan.nb; ++k) {
+        double entries = 0.;
+        for (long long li = plan.first_local_after(plan.rank, k + 1); li < nlb; ++li) {
+          const long long i = plan.global_block(plan.rank, li);
+          entries += (double)plan.width(i) * (double)((i + 1) * B - (k + 2) * B);
+        }
+        if (2. * (double)plan.width(k) * entries <= limit_gflop * 1e9) break;
+        switch_step = k + 1;
+      }
+    }
+    if (switch_step > 0) device_pacing = false;  // host pacing until the switch
+    decided = false;
+    decide();
+    if (switch_step == 0) to_masked_bulk();
+  }
+  void to_masked_bulk() {
     if (bulk_masked || !ctx->stream_masked) return;
-    const double remaining = (double)(plan.n - (k + 2) * plan.B);
-    if (remaining * remaining > 8704. * 8704. * (double)plan.world) return;
-    flush(QB);
-    if (!ev_switch && hipEventCreateWithFlags(&ev_switch, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
-    (void)hipEventRecord(ev_switch, sq[QB]);
-    (void)hipStreamWaitEvent(ctx->stream_masked, ev_switch, 0);
-    sq[QB] = ctx->stream_masked;
+    sq[QB] = ctx->stream_masked;  // (nothing of this fit is on the unmasked stream, or the queues have just been drained)
     bulk_masked = true;
   }
+  int step_begin(long long k) override {
+    if (k != switch_step || k == 0) return AGP_OK;
+    const int st = sync_all();  // drain: every record so far has completed
+    if (st != AGP_OK) return st;
+    to_masked_bulk();
+    if (allow_device && !device_pacing) {
+      device_pacing = true;
+      for (auto &r : recorded) r = false;  // (waits for records of the host-paced steps are satisfied by the drain)
+    }
+    return AGP_OK;
+  }
   void update_staircase(int q, double *A, long long ld, const double *Q, long long ldq, const ShardPlan &plan, long long k) override {
-    if (q == QB) maybe_switch_bulk_queue(plan, k);
     flush(q);
     // ONE launch over all own row blocks >= k + 2: the tiles right of a row block's own diagonal tile exit at once
     const long long B = plan.B, li2 = plan.first_local_after(plan.rank, k + 1);
@@ -887,7 +922,7 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
       ctx->last_error = "sharded schedule: a queue waited for another (or for a collective) past the transport's deadline";
       st = AGP_ERR_COMM;
     }
-    f->stage[2] = ops.device_pacing ? 1. : 0.;
+    f->stage[2] = ops.device_pacing ? 1. : 0.;  // the pacing the fit ENDED with
     f->stage[6] = res.enqueue_factor_ms + res.enqueue_solve_ms;
     f->stage[7] = res.total_ms;
     if (ctx->profiling) {

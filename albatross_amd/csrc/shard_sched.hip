@@ -139,8 +139,10 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
   auto ms_since = [&](std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
   };
+  ops.begin(plan);
   if (plan.owner(0) == me) factor_and_pack(0);
   for (long long k = 0; k < nb && st == AGP_OK; ++k) {
+    if ((st = ops.step_begin(k)) != AGP_OK) break;
     const int o = plan.owner(k), slot = (int)(k & 1);
     const long long w = plan.width(k);
     if (multi) {

@@ -545,6 +545,8 @@ AGP_API int agp_set_profiling(agp_context *ctx, int enabled);
  *   AGP_SHARD_BLOCK=<b>      128 / 256 / 512 rows per row block of the sharded fit (default 512; tests)
  *   AGP_SHARD_FORCE_COMM=1   ONE rank runs the multi-rank schedule through its transport (RCCL group of one; tests)
  *   AGP_SHARD_HOST_PACING=1  the sharded schedule is paced by the host instead of device-side flags
+ *   AGP_SHARD_MASK_GFLOP=<g> flop of a rank's bulk update per step (default 40e9) below which a sharded fit counts as
+ *                            chain-bound: bulk updates on the CU-masked stream + device-side pacing from there on
  * and, process-wide, at first use:
  *   AGP_COMM_TIMEOUT_S=<s>   deadline of every wait that may hold a collective (default 120)
  *   AGP_RCCL_LIB=<path>      librccl to dlopen (default: the ROCm installation's)

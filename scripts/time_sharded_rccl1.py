@@ -12,17 +12,16 @@ import albatross_amd as ab
 from albatross_amd.distributed import Communicator, ShardedGaussianProcessFit
 from bench import make_dataset
 
-ctx = ab.Context(0)
 cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
 for n in [int(a) for a in (sys.argv[1:] or ["16384"])]:
     x, y = make_dataset(n, 44)
     for forced in (False, True):
         if forced:
             os.environ["AGP_SHARD_FORCE_COMM"] = "1"
-            comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id())
         else:
             os.environ.pop("AGP_SHARD_FORCE_COMM", None)
-            comm = None
+        ctx = ab.Context(0)  # (the switches are read when the context is created)
+        comm = Communicator.rccl(ctx, 1, 0, Communicator.unique_id()) if forced else None
         s = ShardedGaussianProcessFit(ctx, cov, comm)
         ts = []
         for _ in range(4):
@@ -33,3 +32,5 @@ for n in [int(a) for a in (sys.argv[1:] or ["16384"])]:
               f"{1e3 * min(ts[1:]):7.1f} ms per fit (host enqueue {s.stage(6):.1f} of {s.stage(7):.1f} ms)", flush=True)
         if comm is not None:
             comm.close()
+        del s
+        ctx.close()
