@@ -13,7 +13,7 @@ from .covariance import (AngularDistance, Constant, CovarianceFunction, Euclidea
 from .gp import (AlbatrossAmdError, BlockSymmetric, ExplainedCovariance, PivotedLDLT, Context, CrossValidation, CrossValidationPrediction, DenseFactor,
                  LeaveOneOutGrouper, group_indexer, root_mean_square_error, UpdatedGPFit, negative_log_likelihood, FitModel, GaussianProcessRegression, GPFit, JointDistribution,
                  LinearMean, MeanFunction, SumOfMeanFunctions, ProductOfMeanFunctions, MarginalDistribution, NanInputError, NotPositiveDefiniteError, Prediction,
-                 RegressionDataset, ZeroMean, default_context, gp_from_covariance, gp_from_covariance_and_mean)
+                 RegressionDataset, ZeroMean, default_context, fit_batch, gp_from_covariance, gp_from_covariance_and_mean)
 
 from .sparse_gp import (FixedInducingPoints, SparseFitModel, SparseGaussianProcessRegression, SparseGPFit,
                         UniformlySpacedInducingPoints, rebase_inducing_points, sparse_gp_from_covariance,

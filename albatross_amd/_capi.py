@@ -90,6 +90,7 @@ EXPORTS = [
     ("agp_fit_download_information", C.c_int, [_P, _P, _P]),
     ("agp_nll", C.c_int, [_P, _P, C.POINTER(Features), _P, _P, _D]),
     ("agp_nll_batch", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int64, _P, _P]),
+    ("agp_fit_create_batch", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, _P, _P]),
     ("agp_solve", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int]),
     ("agp_factor_create", C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _PP]),
     ("agp_nll_dense", C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _D]),

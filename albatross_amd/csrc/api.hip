@@ -166,6 +166,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->pool_aux) (void)hipFree(ctx->pool_aux);
   if (ctx->pool_shard) (void)hipFree(ctx->pool_shard);
   if (ctx->pool_sparse) (void)hipFree(ctx->pool_sparse);
+  if (ctx->pool_batch) (void)hipFree(ctx->pool_batch);
   if (ctx->ws_aux) (void)hipFree(ctx->ws_aux);
   if (ctx->d_zpub) (void)hipFree(ctx->d_zpub);
   if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
@@ -572,6 +573,17 @@ int agp_gram_combined(agp_context *ctx, const agp_kernel *k, const agp_features 
 void agp_fit_destroy(agp_fit *fit) {
   if (!fit) return;
   (void)hipSetDevice(fit->device);
+  if (fit->slab) {
+    if (--fit->slab->refs == 0) {
+      agp_context *ctx = fit->ctx;
+      if (ctx && !ctx->pool_batch) { ctx->pool_batch = fit->slab->base; ctx->pool_batch_bytes = fit->slab->bytes; }  // (like pool_A)
+      else (void)hipFree(fit->slab->base);
+      delete fit->slab;
+    }
+    fit->train.release();
+    delete fit;
+    return;
+  }
   if (fit->A) {
     agp_context *ctx = fit->ctx;
     if (ctx && !ctx->pool_A) {
@@ -1174,6 +1186,152 @@ int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, c
   }
   for (auto &d : dxs) d.release();
   return st;
+}
+
+// B independent fits of one shape in lock step: the Fit<GPFit> constructor (models/gp.hpp:61-69) for `count` datasets /
+// parameter vectors at once.  Where the reference's users live - N of a few hundred to a few thousand
+// (benchmarks/bench_predict.cc:20-40, the tuner loop tune/tune.hpp:276-290) - ONE fit is bound by the latency of its
+// 128 serial pivots per panel (27-30 us per POTRF, config 2: 0.14 of the MFMA peak); a batch shares that latency and
+// fills the chip with the trailing updates of all problems (factor_lower_batched).
+int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *kernels, const agp_features *const *features,
+                         const double *y, int64_t ldy, const double *y_var, int64_t ldv, agp_fit **out, double *information,
+                         int64_t ldi, double *log_det, int *status) {
+  if (!c || count <= 0 || !kernels || !features || !y || !out || !status) return AGP_ERR_INVALID_ARGUMENT;
+  agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  for (int b = 0; b < count; ++b) { out[b] = nullptr; status[b] = AGP_ERR_INVALID_ARGUMENT; }
+  const long long n = features[0] ? features[0]->n : 0;
+  if (n <= 0 || (ldy != 0 && ldy < n) || (y_var && ldv != 0 && ldv < n) || (information && ldi < n)) return AGP_ERR_INVALID_ARGUMENT;
+  int st = AGP_OK;
+  for (int b = 0; b < count; ++b) {
+    if (!kernels[b] || !features[b] || features[b]->n != n || features[b]->location != features[0]->location)
+      return AGP_ERR_INVALID_ARGUMENT;
+    if ((st = validate_features(features[b])) != AGP_OK) return st;
+  }
+  const long long lda = factor_ld(n), nblk = (n + NB - 1) / NB, np2 = round_up(n, 2), cp2 = round_up(count, 2);
+  const long long stride_A = lda * n, stride_I = nblk * (36 * MB * MB);
+  hipStream_t s = ctx->stream;
+  // one allocation: [A slabs | tile images | information | z | logsum | flags (4 ints each) | y_var (scratch) | features]
+  size_t feat_elems = 0;  // per problem: coordinates, equality ids, scale columns (8-byte units)
+  for (int b = 0; b < count; ++b)
+    feat_elems += (size_t)n * ((size_t)features[b]->dim + (features[b]->eq_id ? 1 : 0) + (size_t)features[b]->n_scale_columns);
+  const size_t head_elems = (size_t)count * ((size_t)stride_A + (size_t)stride_I + 2 * (size_t)np2) + (size_t)cp2 + 2 * (size_t)cp2 +
+                            (y_var ? (size_t)count * (size_t)np2 : 0);
+  const size_t elems = head_elems + feat_elems;
+  double *base = nullptr;
+  if (ctx->pool_batch && ctx->pool_batch_bytes == sizeof(double) * elems) {
+    base = ctx->pool_batch;
+    ctx->pool_batch = nullptr;
+    ctx->pool_batch_bytes = 0;
+  } else {
+    if (ctx->pool_batch) { (void)hipFree(ctx->pool_batch); ctx->pool_batch = nullptr; ctx->pool_batch_bytes = 0; }
+    AGP_HIP_CHECK(ctx, hipMalloc(&base, sizeof(double) * elems));
+  }
+  double *A = base, *invd = A + (size_t)count * (size_t)stride_A, *alpha = invd + (size_t)count * (size_t)stride_I;
+  double *z = alpha + (size_t)count * (size_t)np2, *logsum = z + (size_t)count * (size_t)np2;
+  int *flags = reinterpret_cast<int *>(logsum + cp2);
+  double *yvar_d = y_var ? logsum + 3 * cp2 : nullptr;
+  std::vector<agp_fit *> fits((size_t)count, nullptr);
+  auto fail = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    for (auto *f : fits)
+      if (f) { f->train.release(); delete f; }
+    (void)hipFree(base);
+    return code;
+  };
+#define BATCH_CHECK(expr)                                                     \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);    \
+      return fail(AGP_ERR_HIP);                                               \
+    }                                                                         \
+  } while (0)
+  const int loc = features[0]->location;
+  const hipMemcpyKind kind = loc == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  for (int b = 0; b < count; ++b) {
+    BATCH_CHECK(hipMemcpyAsync(z + (size_t)b * (size_t)np2, y + (size_t)b * (size_t)ldy, sizeof(double) * (size_t)n, kind, s));
+    if (y_var) BATCH_CHECK(hipMemcpyAsync(yvar_d + (size_t)b * (size_t)np2, y_var + (size_t)b * (size_t)ldv, sizeof(double) * (size_t)n, kind, s));
+  }
+  // train_features = features (gp.hpp:63): a copy per fit, inside the batch's allocation (no allocation per problem)
+  double *fcur = base + head_elems;
+  for (int b = 0; b < count; ++b) {
+    agp_fit *fit = new (std::nothrow) agp_fit();
+    if (!fit) return fail(AGP_ERR_INVALID_ARGUMENT);
+    fits[(size_t)b] = fit;
+    const agp_features *f = features[b];
+    FeatView v;
+    v.n = n; v.dim = f->dim; v.nsc = f->n_scale_columns; v.meas = 0;
+    v.coords = fcur; v.ids = nullptr; v.scales = nullptr;
+    BATCH_CHECK(hipMemcpyAsync(fcur, f->coords, sizeof(double) * (size_t)n * (size_t)f->dim, kind, s));
+    fcur += (size_t)n * (size_t)f->dim;
+    if (f->eq_id) {
+      v.ids = reinterpret_cast<const long long *>(fcur);
+      BATCH_CHECK(hipMemcpyAsync(fcur, f->eq_id, sizeof(long long) * (size_t)n, kind, s));
+      fcur += n;
+    }
+    if (f->n_scale_columns > 0) {
+      v.scales = fcur;
+      BATCH_CHECK(hipMemcpyAsync(fcur, f->scales, sizeof(double) * (size_t)n * (size_t)f->n_scale_columns, kind, s));
+      fcur += (size_t)n * (size_t)f->n_scale_columns;
+    }
+    fit->train.v = v;  // (not owned: DeviceFeatures::release has nothing to free)
+  }
+  if (loc == AGP_HOST) BATCH_CHECK(hipStreamSynchronize(s));
+  BATCH_CHECK(hipMemsetAsync(logsum, 0, sizeof(double) * 3 * (size_t)cp2, s));  // log sums and flags
+  for (int b = 0; b < count; ++b) {
+    const DevProgram *dprog = nullptr;
+    if ((st = device_program(ctx, kernels[b], &dprog)) != AGP_OK) return fail(st);
+    agp_fit *fit = fits[(size_t)b];
+    FeatView xm = fit->train.v;
+    xm.meas = 1;  // as_measurements(features), gp.hpp:288
+    launch_gram(s, dprog, xm, xm, true, true, A + (size_t)b * (size_t)stride_A, lda, y_var ? yvar_d + (size_t)b * (size_t)np2 : nullptr,
+                flags + 4 * b, &kernels[b]->prog);
+  }
+  // (two streams once the trailing updates of the batch are long enough to hide the panel chain behind)
+  if ((double)count * (double)n * (double)n >= 6e7 && n > 2 * NBO)
+    factor_lower_batched_lookahead(ctx, A, stride_A, n, lda, invd, stride_I, z, np2, count, flags, logsum, 4);
+  else
+    factor_lower_batched(s, A, stride_A, n, lda, invd, stride_I, z, np2, count, flags, logsum, 4);
+  BATCH_CHECK(hipMemcpyAsync(alpha, z, sizeof(double) * (size_t)count * (size_t)np2, hipMemcpyDeviceToDevice, s));
+  backward_solve_vec_batched(s, A, stride_A, n, lda, invd, stride_I, alpha, np2, count);  // information = L^-T (L^-1 y), gp.hpp:68
+  std::vector<double> h_log((size_t)cp2);
+  std::vector<int> h_flags(4 * (size_t)count);
+  BATCH_CHECK(hipMemcpyAsync(h_log.data(), logsum, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+  BATCH_CHECK(hipMemcpyAsync(h_flags.data(), flags, sizeof(int) * 4 * (size_t)count, hipMemcpyDeviceToHost, s));
+  BATCH_CHECK(hipStreamSynchronize(s));
+  BATCH_CHECK(hipGetLastError());
+  agp_fit_slab *slab = new (std::nothrow) agp_fit_slab();
+  if (!slab) return fail(AGP_ERR_INVALID_ARGUMENT);
+  slab->base = base;
+  slab->bytes = sizeof(double) * elems;
+  slab->refs = count;
+  for (int b = 0; b < count; ++b) {
+    agp_fit *fit = fits[(size_t)b];
+    fit->ctx = ctx;
+    fit->slab = slab;
+    fit->device = ctx->device;
+    fit->n = n;
+    fit->lda = lda;
+    fit->A_bytes = sizeof(double) * (size_t)stride_A;
+    fit->A = A + (size_t)b * (size_t)stride_A;
+    fit->invd = invd + (size_t)b * (size_t)stride_I;
+    fit->alpha = alpha + (size_t)b * (size_t)np2;
+    fit->z = z + (size_t)b * (size_t)np2;
+    const int *fl = &h_flags[4 * (size_t)b];
+    fit->failed_pivot = fl[1] ? (int64_t)fl[1] - 1 : -1;
+    fit->log_det = 2. * h_log[(size_t)b];
+    status[b] = fl[0] ? AGP_ERR_NAN_INPUT : (fl[1] ? AGP_ERR_NOT_POSITIVE_DEFINITE : AGP_OK);  // gp.hpp:66, then the factor
+    if (log_det) log_det[b] = fit->log_det;
+    out[b] = fit;
+  }
+  if (information)  // only the good fits' vectors: a failed one leaves its column untouched
+    for (int b = 0; b < count; ++b)
+      if (status[b] == AGP_OK)
+        AGP_HIP_CHECK(ctx, hipMemcpy(information + (size_t)b * (size_t)ldi, alpha + (size_t)b * (size_t)np2, sizeof(double) * (size_t)n,
+                                     hipMemcpyDeviceToHost));
+#undef BATCH_CHECK
+  return AGP_OK;
 }
 
 // ---- solve -----------------------------------------------------------------

@@ -28,6 +28,9 @@ void launch_tall_matvec(hipStream_t s, const double *W, long long ld, long long 
                         double beta, const double *base, double *out);
 void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,
                        double alpha, double beta, const double *base, double *out);
+void launch_colvec_dot_strided(hipStream_t s, const double *W, long long ld, long long stride_W, long long m, long long n,
+                               const double *v, long long stride_v, double alpha, double beta, const double *base, double *out,
+                               long long count);
 // out = alpha K p + beta base for a symmetric K given by its LOWER triangle only (reduce.hip); ws: symv_ws_elems(n) doubles
 size_t symv_ws_elems(long long n);
 void launch_symv_lower(hipStream_t s, const double *K, long long ld, long long n, const double *p, double alpha, double beta,

@@ -52,7 +52,7 @@ struct PotrfArgs {
   int *flags;
   double *scalars;
   // batched launches (blockIdx.y = batch entry): element offsets per entry; all 0 = not batched
-  long long batch_A = 0, batch_img = 0, batch_y = 0, batch_scalars = 0;
+  long long batch_A = 0, batch_img = 0, batch_y = 0, batch_scalars = 0, batch_flags = 0;
   // fused panel kernel only: z of this block is also PUBLISHED here (device-scope stores) for the workgroups that solve
   // the rows below in the same launch; `below` = number of those rows
   double *zpub = nullptr;
@@ -478,6 +478,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
     p.img += b * p.batch_img;
     if (p.y) p.y += b * p.batch_y;
     p.scalars += b * p.batch_scalars;
+    p.flags += b * p.batch_flags;
   }
   __shared__ double T[POTRF_LDS_DOUBLES];
   potrf_diag_body<false>(p, T);
@@ -1206,41 +1207,118 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   ctx->img_ready = nullptr;
 }
 
-// `count` independent n x n factorisations in lock step (blockIdx.y = problem): the blocks of a sparse
-// GP's A.  Problem b lives at A + b * stride_A (leading dimension lda), its tile images at
-// invd + b * stride_invd, its right-hand side (optional, fused forward substitution) at y + b * stride_y;
-// logsum[b] receives sum log L_ii.  No look-ahead: every step is three launches for all problems.
+// `count` independent n x n factorisations in lock step (blockIdx.y = problem): the blocks of a sparse GP's A, the
+// parameter vectors of agp_nll_batch, the fits of agp_fit_create_batch.  Problem b lives at A + b * stride_A (leading
+// dimension lda), its tile images at invd + b * stride_invd, its right-hand side (optional, fused forward
+// substitution) at y + b * stride_y; logsum[b] receives sum log L_ii; its flags at flags + b * stride_flags (0: shared).
+// The blocking of factor_lower without its streams: outer blocks of 512 columns whose panels are left-looking (one
+// product of depth <= 384 brings a panel up to date), then ONE trailing update of depth 512 for all problems - with a
+// handful of problems that launch fills the chip, and the 27-30 us of a POTRF are shared by all of them.
 void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long long n, long long lda, double *invd,
                           long long stride_invd, double *y, long long stride_y, long long count, int *flags,
-                          double *logsum) {
+                          double *logsum, long long stride_flags) {
   if (count <= 0 || n <= 0) return;
-  for (long long k = 0; k < n; k += NB) {
-    const int nbk = (int)((n - k < NB) ? n - k : NB);
-    PotrfArgs p;
-    p.A = A; p.lda = lda; p.k0 = k; p.nbk = nbk;
-    p.img = invd + (k / NB) * (long long)IMG_DOUBLES;
-    p.y = y ? y + k : nullptr;
-    p.flags = flags; p.scalars = logsum;
-    p.batch_A = stride_A; p.batch_img = stride_invd; p.batch_y = stride_y; p.batch_scalars = 1;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)count), dim3(256), 0, s, p);
-    const long long below = n - (k + nbk);
-    if (below <= 0) continue;
-    TrsmArgs t;
-    t.img = p.img;
-    t.nbk = nbk;
-    t.Y = A + k * lda + (k + nbk);
-    t.stride_m = lda; t.stride_n = 1;
-    t.ncols = below;
-    t.z = y ? y + k : nullptr;
-    t.yrest = y ? y + k + nbk : nullptr;
-    t.batch_img = stride_invd; t.batch_Y = stride_A; t.n_total = 0; t.batch_z = stride_y;
-    const dim3 grid((unsigned)((below + 63) / 64), (unsigned)count);
-    if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), grid, dim3(256), 0, s, t);
-    else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), grid, dim3(256), 0, s, t);
-    const double *P = A + k * lda + (k + nbk);
-    launch_gemm_nt_sub_batched(s, A + (k + nbk) * lda + (k + nbk), lda, stride_A, P, lda, false, stride_A, P, lda, false,
-                               stride_A, below, below, nbk, true, count);
+  for (long long K0 = 0; K0 < n; K0 += NBO) {
+    const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
+    for (long long k = K0; k < kend; k += NB) {
+      const int nbk = (int)((n - k < NB) ? n - k : NB);
+      if (k > K0) {  // columns [k, k + nbk), rows k.. -= (rows k.. of the panels [K0, k)) (rows k..k+nbk of them)^T
+        const double *P = A + K0 * lda + k;
+        launch_gemm_nt_sub_batched(s, A + k * lda + k, lda, stride_A, P, lda, false, stride_A, P, lda, false, stride_A, n - k, nbk,
+                                   k - K0, true, count);
+      }
+      PotrfArgs p;
+      p.A = A; p.lda = lda; p.k0 = k; p.nbk = nbk;
+      p.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+      p.y = y ? y + k : nullptr;
+      p.flags = flags; p.scalars = logsum;
+      p.batch_A = stride_A; p.batch_img = stride_invd; p.batch_y = stride_y; p.batch_scalars = 1; p.batch_flags = stride_flags;
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)count), dim3(256), 0, s, p);
+      const long long below = n - (k + nbk);
+      if (below <= 0) continue;
+      TrsmArgs t;
+      t.img = p.img;
+      t.nbk = nbk;
+      t.Y = A + k * lda + (k + nbk);
+      t.stride_m = lda; t.stride_n = 1;
+      t.ncols = below;
+      t.z = y ? y + k : nullptr;
+      t.yrest = y ? y + k + nbk : nullptr;
+      t.batch_img = stride_invd; t.batch_Y = stride_A; t.n_total = 0; t.batch_z = stride_y;
+      const dim3 grid((unsigned)((below + 63) / 64), (unsigned)count);
+      if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), grid, dim3(256), 0, s, t);
+      else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), grid, dim3(256), 0, s, t);
+    }
+    const long long rest = n - kend;
+    if (rest > 0) {  // everything right of the outer block -= (its rows below) (its rows below)^T, depth kend - K0
+      const double *P = A + K0 * lda + kend;
+      launch_gemm_nt_sub_batched(s, A + kend * lda + kend, lda, stride_A, P, lda, false, stride_A, P, lda, false, stride_A, rest, rest,
+                                 kend - K0, true, count);
+    }
   }
 }
-
+// The same with the two-stream look-ahead of factor_lower (without its end-game): the panels of outer block j + 1 run on
+// the context's chain stream while the trailing update of everything right of it (depth 512, all problems: the launch
+// that fills the chip) runs on the bulk stream.  For batches whose updates are long enough to hide the chain behind.
+void factor_lower_batched_lookahead(agp_context *ctx, double *A, long long stride_A, long long n, long long lda, double *invd,
+                                    long long stride_invd, double *y, long long stride_y, long long count, int *flags,
+                                    double *logsum, long long stride_flags) {
+  if (count <= 0 || n <= 0) return;
+  hipStream_t sa = ctx->stream, sb = ctx->stream2;
+  bool have_u2 = false;
+  auto panels = [&](long long K0, long long kend) {
+    for (long long k = K0; k < kend; k += NB) {
+      const int nbk = (int)((n - k < NB) ? n - k : NB);
+      if (k > K0) {
+        const double *P = A + K0 * lda + k;
+        launch_gemm_nt_sub_batched(sa, A + k * lda + k, lda, stride_A, P, lda, false, stride_A, P, lda, false, stride_A, n - k, nbk,
+                                   k - K0, true, count);
+      }
+      PotrfArgs p;
+      p.A = A; p.lda = lda; p.k0 = k; p.nbk = nbk;
+      p.img = invd + (k / NB) * (long long)IMG_DOUBLES;
+      p.y = y ? y + k : nullptr;
+      p.flags = flags; p.scalars = logsum;
+      p.batch_A = stride_A; p.batch_img = stride_invd; p.batch_y = stride_y; p.batch_scalars = 1; p.batch_flags = stride_flags;
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)count), dim3(256), 0, sa, p);
+      const long long below = n - (k + nbk);
+      if (below <= 0) continue;
+      TrsmArgs t;
+      t.img = p.img;
+      t.nbk = nbk;
+      t.Y = A + k * lda + (k + nbk);
+      t.stride_m = lda; t.stride_n = 1;
+      t.ncols = below;
+      t.z = y ? y + k : nullptr;
+      t.yrest = y ? y + k + nbk : nullptr;
+      t.batch_img = stride_invd; t.batch_Y = stride_A; t.n_total = 0; t.batch_z = stride_y;
+      const dim3 grid((unsigned)((below + 63) / 64), (unsigned)count);
+      if (y) hipLaunchKernelGGL((trsm_micro_kernel<false, true>), grid, dim3(256), 0, sa, t);
+      else hipLaunchKernelGGL((trsm_micro_kernel<false, false>), grid, dim3(256), 0, sa, t);
+    }
+  };
+  long long K0 = 0, kend = NBO < n ? NBO : n;
+  panels(K0, kend);
+  while (kend < n) {
+    const long long next_end = (kend + NBO < n) ? kend + NBO : n, K = kend - K0;
+    (void)hipEventRecord(ctx->ev_a, sa);                        // P(j) done
+    if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);    // U2(j - 1) wrote the next block column too
+    const double *P = A + K0 * lda + kend;                      // panel rows kend.., columns K0 .. kend
+    launch_gemm_nt_sub_batched(sa, A + kend * lda + kend, lda, stride_A, P, lda, false, stride_A, P, lda, false, stride_A, n - kend,
+                               next_end - kend, K, true, count);  // U1: the next block column
+    if (next_end < n) {
+      (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
+      const double *Q = A + K0 * lda + next_end;
+      launch_gemm_nt_sub_batched(sb, A + next_end * lda + next_end, lda, stride_A, Q, lda, false, stride_A, Q, lda, false, stride_A,
+                                 n - next_end, n - next_end, K, true, count);  // U2: everything right of it
+      (void)hipEventRecord(ctx->ev_b, sb);
+      have_u2 = true;
+    } else {
+      have_u2 = false;
+    }
+    panels(kend, next_end);
+    K0 = kend;
+    kend = next_end;
+  }
+}
 }  // namespace agp

@@ -98,6 +98,9 @@ struct agp_context {
   // re-fits the same shapes, and hipMalloc / hipFree of several GB per call costs more than some of the stages
   double *pool_sparse = nullptr;
   size_t pool_sparse_bytes = 0;
+  // ... and one cached slab of agp_fit_create_batch (released by the last fit of a batch)
+  double *pool_batch = nullptr;
+  size_t pool_batch_bytes = 0;
   // fused panel kernel (chol.hip: panel_fused_kernel): the slots through which a diagonal block's z_b reaches the
   // workgroups solving the rows below in the same launch (one per matrix row, sentinel-filled per factorisation), and
   // which tile-image buffer has been sentinel-filled for the factorisation in progress
@@ -141,8 +144,17 @@ struct agp_context {
   bool shard_probe_ok = false;
 };
 
+// agp_fit_create_batch: the fits of one batch are slices of ONE device allocation (the batched kernels need constant
+// strides between the problems); it goes when the last of them is destroyed
+struct agp_fit_slab {
+  double *base = nullptr;
+  size_t bytes = 0;
+  int refs = 0;
+};
+
 struct agp_fit {
   agp_context *ctx = nullptr;  // owner; a fit must not outlive its context
+  agp_fit_slab *slab = nullptr;  // non-null: A / invd / alpha / z are slices of slab->base (winv: not kept)
   size_t A_bytes = 0;
   int device = 0;
   int64_t n = 0;
@@ -219,7 +231,13 @@ void forward_solve_mat(hipStream_t s, const double *A, long long n, long long ld
 // B (n x m, ldb) <- L^-T B
 void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long long n, long long lda, double *invd,
                           long long stride_invd, double *y, long long stride_y, long long count, int *flags,
-                          double *logsum);
+                          double *logsum, long long stride_flags = 0);
+void factor_lower_batched_lookahead(agp_context *ctx, double *A, long long stride_A, long long n, long long lda, double *invd,
+                                    long long stride_invd, double *y, long long stride_y, long long count, int *flags,
+                                    double *logsum, long long stride_flags = 0);
+// z_b <- L_b^-T z_b for `count` problems, one vector each (solve.hip)
+void backward_solve_vec_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
+                                const double *invd, long long stride_invd, double *z, long long stride_z, long long count);
 void forward_solve_mat_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
                                const double *invd, long long stride_invd, double *B, long long stride_B, long long m,
                                long long ldb, bool rhs_lower, long long count);

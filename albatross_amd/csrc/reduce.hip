@@ -325,11 +325,17 @@ void launch_tall_matvec(hipStream_t s, const double *W, long long ld, long long 
 }
 
 // out[j] = alpha * sum_i W[i, j] v[i] + beta * base[j]   (one workgroup per column)
+// (blockIdx.y = batch entry; the strides are 0 for a single problem)
 __global__ __launch_bounds__(256) void colvec_dot_kernel(const double *__restrict__ W, long long ld, long long m,
                                                          const double *__restrict__ v, double alpha, double beta,
-                                                         const double *base, double *out) {
+                                                         const double *base, double *out, long long stride_W,
+                                                         long long stride_v) {
   __shared__ double red[4];
   const long long j = blockIdx.x;
+  W += (long long)blockIdx.y * stride_W;
+  v += (long long)blockIdx.y * stride_v;
+  if (base) base += (long long)blockIdx.y * stride_v;
+  out += (long long)blockIdx.y * stride_v;
   const double *w = W + j * ld;
   double acc = 0.;
   for (long long i = threadIdx.x; i < m; i += 256) acc += w[i] * v[i];
@@ -343,7 +349,16 @@ __global__ __launch_bounds__(256) void colvec_dot_kernel(const double *__restric
 void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,
                        double alpha, double beta, const double *base, double *out) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(colvec_dot_kernel, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out);
+  hipLaunchKernelGGL(colvec_dot_kernel, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out, 0LL, 0LL);
+}
+
+// the same for `count` problems: W_b = W + b * stride_W; v, base and out are slices of vectors stride_v apart
+void launch_colvec_dot_strided(hipStream_t s, const double *W, long long ld, long long stride_W, long long m, long long n,
+                               const double *v, long long stride_v, double alpha, double beta, const double *base, double *out,
+                               long long count) {
+  if (n <= 0 || count <= 0) return;
+  hipLaunchKernelGGL(colvec_dot_kernel, dim3((unsigned)n, (unsigned)count), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out,
+                     stride_W, stride_v);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -11,6 +11,9 @@
 
 namespace agp {
 void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);  // reduce.hip
+void launch_colvec_dot_strided(hipStream_t s, const double *W, long long ld, long long stride_W, long long m, long long n,
+                               const double *v, long long stride_v, double alpha, double beta, const double *base, double *out,
+                               long long count);  // reduce.hip
 
 // ---------------------------------------------------------------------------
 // multi-RHS triangular solves (K4): B <- L^-1 B and B <- L^-T B
@@ -421,6 +424,30 @@ void backward_solve_vec(hipStream_t s, const double *A, long long n, long long l
                        Winv + b * (long long)(NB * NB), z, xstage);
   }
   (void)hipMemcpyAsync(z, xstage, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+}
+
+// z_b <- L_b^-T z_b for `count` problems with ONE right-hand side each (the information vectors of
+// agp_fit_create_batch): per 128 rows from the bottom one MFMA substitution against the tile image (blockIdx.y =
+// problem) and one batched column-dot launch for the rows above.
+void backward_solve_vec_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
+                                const double *invd, long long stride_invd, double *z, long long stride_z, long long count) {
+  if (n <= 0 || count <= 0) return;
+  const long long nblk = (n + NB - 1) / NB;
+  for (long long b = nblk - 1; b >= 0; --b) {
+    const long long k = b * NB;
+    const int nbk = (int)((n - k < NB) ? n - k : NB);
+    TrsmArgs t;
+    t.img = invd + b * (long long)IMG_DOUBLES;
+    t.nbk = nbk;
+    t.Y = z + k;
+    t.stride_m = 1; t.stride_n = 1;
+    t.ncols = 1;
+    t.z = nullptr; t.yrest = nullptr;
+    t.batch_img = stride_invd; t.batch_Y = stride_z; t.n_total = 0;
+    hipLaunchKernelGGL((trsm_micro_kernel<true, false>), dim3(1, (unsigned)count), dim3(256), 0, s, t);
+    if (k > 0)  // z[0 : k] -= L[k : k + nbk, 0 : k]^T x
+      launch_colvec_dot_strided(s, A + k, lda, stride_A, nbk, k, z + k, stride_z, -1.0, 1.0, z, z, count);
+  }
 }
 
 }  // namespace agp

@@ -1107,6 +1107,53 @@ def root_mean_square_error(prediction, truth):
     return float(np.sqrt(np.mean(d * d)))
 
 
+def fit_batch(models, datasets):
+    """`models[b].fit(datasets[b])` for several problems of ONE size in lock step (agp_fit_create_batch): the regime of the
+    reference's own workloads (benchmarks/bench_predict.cc: N = 512; one fit per tuner step), where a single fit is bound by the
+    latency of its serial pivots - a batch shares it.  models: GaussianProcessRegression objects on one context (one model
+    may appear several times); datasets: as many RegressionDatasets with the same number of points.  Returns the FitModels;
+    raises like `fit` for the first problem whose covariance has NaN or is not positive definite."""
+    if len(models) != len(datasets) or not models:
+        raise ValueError("fit_batch: as many datasets as models, at least one")
+    ctx = models[0]._ctx()
+    count = len(models)
+    fsets, structs, ys, yvs = [], [], [], []
+    for m, ds in zip(models, datasets):
+        if m.precision != "fp64" or has_linear_combinations(ds.features) or m._ctx() is not ctx:
+            raise ValueError("fit_batch: fp64 models on one context, plain features")
+        fs = m.covariance_function_.features(_values_of(ds.features))
+        y, yv = m._targets(fs, ds.targets)
+        fsets.append(fs)
+        structs.append(fs.as_struct())
+        ys.append(y)
+        yvs.append(yv)
+    n = fsets[0].n
+    if any(fs.n != n for fs in fsets):
+        raise ValueError("fit_batch: every dataset must have the same number of points")
+    Y = np.asfortranarray(np.stack(ys, axis=1))
+    have_var = any(v is not None for v in yvs)
+    V = np.asfortranarray(np.stack([np.zeros(n) if v is None else v for v in yvs], axis=1)) if have_var else None
+    handles = []
+    out = (C.c_void_p * count)()
+    status = (C.c_int * count)()
+    try:
+        for m in models:  # private handles: the context's small kernel cache may evict while the batch is assembled
+            handles.append(ctx.private_kernel(m.covariance_function_))
+        kernels = (C.c_void_p * count)(*handles)
+        fptrs = (C.c_void_p * count)(*[C.addressof(st) for st in structs])
+        ctx._check(ctx._lib.agp_fit_create_batch(ctx._h, count, kernels, fptrs, _ptr(Y), n, _ptr(V) if have_var else None, n, out, None,
+                                                 0, None, status), "agp_fit_create_batch")
+    finally:
+        for kh in handles:
+            ctx._lib.agp_kernel_destroy(kh)
+    fits = [GPFit(ctx, C.c_void_p(out[b]), n, datasets[b].features) for b in range(count)]
+    for b in range(count):
+        if status[b] != capi.AGP_OK:
+            pivot = ctx._lib.agp_fit_failed_pivot(fits[b]._h)
+            ctx._check(status[b], f"agp_fit_create_batch: problem {b} (pivot {pivot})")
+    return [FitModel(m, f) for m, f in zip(models, fits)]
+
+
 def gp_from_covariance(covariance_function, model_name="gaussian_process_regression", context=None):
     """gp.hpp:507-521"""
     return GaussianProcessRegression(covariance_function, None, model_name, context)

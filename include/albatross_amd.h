@@ -234,6 +234,22 @@ AGP_API int agp_nll_batch(agp_context *ctx, int count, const agp_kernel *const *
                   const agp_features *const *features, const double *y, int64_t ldy, const double *y_var,
                   double *out);
 
+/* `count` INDEPENDENT fits of one shape in lock step: the Fit<GPFit> constructor (src/models/gp.hpp:61-69) for several
+ * datasets / parameter vectors of n points each at once - the regime of the reference's own workloads
+ * (benchmarks/bench_predict.cc:20-40: N = 512; the tuner, tune/tune.hpp:276-290), where one fit alone is bound by the
+ * latency of its serial pivots.  The batch shares that latency and fills the GPU with the updates of all problems.
+ *   kernels[b], features[b]   covariance function and features of problem b (all n equal, all at one location)
+ *   y, ldy                    targets, n x count column-major at that location (ldy = 0: one vector shared by all)
+ *   y_var, ldv                target variances likewise, or NULL
+ *   out[b]                    an ordinary agp_fit per problem (agp_predict_*, agp_solve, agp_fit_destroy as usual); the fits of
+ *                             a batch share one device allocation, released with the last of them
+ *   information, ldi          n x count (host) or NULL; log_det[b] (host) or NULL
+ *   status[b]                 AGP_OK / AGP_ERR_NAN_INPUT / AGP_ERR_NOT_POSITIVE_DEFINITE per problem (out[b] then reports
+ *                             the pivot like agp_fit_create); the return value is about the call as a whole */
+AGP_API int agp_fit_create_batch(agp_context *ctx, int count, const agp_kernel *const *kernels, const agp_features *const *features,
+                                 const double *y, int64_t ldy, const double *y_var, int64_t ldv, agp_fit **out, double *information,
+                                 int64_t ldi, double *log_det, int *status);
+
 /* ---- solve (CovarianceRepresentation::solve, gp.hpp:42-45,68,96,111) ----- */
 /* out = K^-1 rhs; rhs/out column-major n x nrhs (ld = n), at `location`. */
 AGP_API int agp_solve(agp_context *ctx, const agp_fit *fit, const double *rhs,
