@@ -750,9 +750,6 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
       return AGP_ERR_HIP;                                                                \
     }                                                                                    \
   } while (0)
-  // train_features = features (un-wrapped; gp.hpp:63,293): always an owned copy
-  if ((st = to_device(ctx, x, true, &fit->train)) != AGP_OK) { agp_fit_destroy(fit); return st; }
-  fit->train.v.meas = 0;
   fit->ctx = ctx;
   fit->A_bytes = sizeof(double) * (size_t)fit->lda * (size_t)n;
   if (ctx->pool_A && ctx->pool_A_bytes == fit->A_bytes) {
@@ -764,7 +761,10 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   }
   {
     const size_t n_invd = (size_t)nblk * (36 * MB * MB), n_winv = (size_t)nblk * NB * NB, n_vec = (size_t)round_up(n, 2);
-    fit->aux_bytes = sizeof(double) * (n_invd + n_winv + 2 * n_vec);
+    // (+ train_features = features, un-wrapped; gp.hpp:63,293: always a copy, inside this pooled block - a hipMalloc and a
+    // hipFree per fit are ~0.1 ms of a 2 ms fit)
+    const size_t n_feat = (size_t)n * ((size_t)x->dim + (x->eq_id ? 1 : 0) + (size_t)x->n_scale_columns);
+    fit->aux_bytes = sizeof(double) * (n_invd + n_winv + 2 * n_vec + n_feat);
     if (ctx->pool_aux && ctx->pool_aux_bytes == fit->aux_bytes) {
       fit->aux_base = ctx->pool_aux;
       ctx->pool_aux = nullptr;
@@ -778,6 +778,24 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     fit->z = fit->alpha + n_vec;
   }
   const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  {
+    double *fcur = fit->z + round_up(n, 2);
+    FeatView v;
+    v.n = n; v.dim = x->dim; v.nsc = x->n_scale_columns; v.meas = 0;
+    v.coords = fcur; v.ids = nullptr; v.scales = nullptr;
+    FIT_CHECK(hipMemcpyAsync(fcur, x->coords, sizeof(double) * (size_t)n * (size_t)x->dim, kind, s));
+    fcur += (size_t)n * (size_t)x->dim;
+    if (x->eq_id) {
+      v.ids = reinterpret_cast<const long long *>(fcur);
+      FIT_CHECK(hipMemcpyAsync(fcur, x->eq_id, sizeof(long long) * (size_t)n, kind, s));
+      fcur += n;
+    }
+    if (x->n_scale_columns > 0) {
+      v.scales = fcur;
+      FIT_CHECK(hipMemcpyAsync(fcur, x->scales, sizeof(double) * (size_t)n * (size_t)x->n_scale_columns, kind, s));
+    }
+    fit->train.v = v;  // (a view into aux_base: DeviceFeatures::release has nothing to free)
+  }
   FIT_CHECK(hipMemcpyAsync(fit->z, y, sizeof(double) * (size_t)n, kind, s));
   if (y_var) {
     FIT_CHECK(hipMalloc(&yvar_d, sizeof(double) * (size_t)n));
@@ -1544,11 +1562,16 @@ int agp_predict_mean(agp_context *ctx, const agp_kernel *k, const agp_fit *fit, 
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
   DeviceFeatures dxs;
   if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
-  st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)m);
-  if (st == AGP_OK) {
-    // cross_cov = cov(train_features, features); mean = cross_cov^T information  (gp.hpp:361-363)
-    launch_predict_mean(ctx->stream, dprog, fit->train.v, dxs.v, fit->alpha, ctx->ws_aux, &k->prog);
-    st = copy_out(ctx, ctx->ws_aux, m, mean, out_location);
+  // cross_cov = cov(train_features, features); mean = cross_cov^T information  (gp.hpp:361-363)
+  if (out_location == AGP_DEVICE) {  // straight into the caller's buffer: no staging copy
+    launch_predict_mean(ctx->stream, dprog, fit->train.v, dxs.v, fit->alpha, mean, &k->prog);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->last_error = "agp_predict_mean: stream"; st = AGP_ERR_HIP; }
+  } else {
+    st = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)m);
+    if (st == AGP_OK) {
+      launch_predict_mean(ctx->stream, dprog, fit->train.v, dxs.v, fit->alpha, ctx->ws_aux, &k->prog);
+      st = copy_out(ctx, ctx->ws_aux, m, mean, out_location);
+    }
   }
   dxs.release();
   return st;

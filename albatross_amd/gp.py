@@ -346,8 +346,17 @@ class GPFit:
             self._information = out
         return self._information
 
+    # a mixed-precision factor (agp_fit_create_mixed): its log-determinant carries the fp32 rounding of the bulk products -
+    # measured 1.3e-5 relative at N = 32768 on BASELINE config 4's covariance, outside the 1e-6 N bar of the fp64 path
+    mixed_precision = False
+    accept_mixed_log_determinant = False
+
     @property
     def log_determinant(self):
+        if self.mixed_precision and not self.accept_mixed_log_determinant:
+            raise AlbatrossAmdError(capi.AGP_ERR_UNSUPPORTED,
+                                    "log_determinant of a mixed-precision factor is good to ~1e-5 relative only: use "
+                                    "model.log_likelihood (always fp64) or set fit.accept_mixed_log_determinant = True")
         v = C.c_double()
         self._ctx._check(self._ctx._lib.agp_fit_log_determinant(self._h, C.byref(v)), "log_determinant")
         return v.value
@@ -474,6 +483,7 @@ class DenseFactor:
     solve = GPFit.solve
     inverse_diagonal = GPFit.inverse_diagonal
     factor = GPFit.factor
+    mixed_precision = False  # (always an fp64 factor)
     log_determinant = GPFit.log_determinant
 
 
@@ -874,7 +884,9 @@ class GaussianProcessRegression:
             if st == capi.AGP_ERR_NOT_POSITIVE_DEFINITE and self.pivoted_fallback:
                 return self._fit_pivoted(dataset, fs, y, yv)
             ctx._check(st, f"agp_fit_create (pivot {pivot})")
-        return FitModel(self, GPFit(ctx, h, fs.n, dataset.features))
+        fit = GPFit(ctx, h, fs.n, dataset.features)
+        fit.mixed_precision = self.precision == "mixed"
+        return FitModel(self, fit)
 
     pivoted_fallback = True
     # 'fp64' (the reference's arithmetic) or 'mixed' (fp32 MFMA products in the bulk updates of the factorisation,

@@ -63,6 +63,7 @@ def test_config4_n32768_mixed(ctx):
     assert res <= 2e-12 and 1 <= its <= 50, (its, res)
     assert rel(amx, a64) <= 1e-8                                   # the stated bar for the information vector
     # log|K| keeps the fp32 rounding of the bulk products: 1.4e-5 relative measured on this kernel at this size
+    fmx.get_fit().accept_mixed_log_determinant = True  # (opt-in: measured 1.3e-5 relative here)
     assert abs(fmx.get_fit().log_determinant - ld64) <= 5e-5 * abs(ld64)
 
     # (3) size-independent property: both information vectors solve K a = y, with K rebuilt independently of the

@@ -68,6 +68,9 @@ def test_mixed_fit_matches_oracle(ctx, n):
     pred = fm.predict(xs).marginal()
     assert rel(pred.mean, om) <= 1e-8
     assert np.abs(pred.covariance - ov).max() <= 1e-4 * np.abs(ov).max()
+    with pytest.raises(ab.AlbatrossAmdError, match="mixed-precision factor"):  # opt-in: the fp32 rounding is in it
+        fm.get_fit().log_determinant
+    fm.get_fit().accept_mixed_log_determinant = True
     assert abs(fm.get_fit().log_determinant - ofit.log_determinant) <= 1e-5 * abs(ofit.log_determinant)
 
 
@@ -88,6 +91,7 @@ def test_mixed_fit_config4_kernel(ctx):
     ofit = orc.OracleFit(cov, train, y)
     assert rel(f64.get_fit().information, ofit.information) <= 1e-8
     assert rel(fmx.get_fit().information, ofit.information) <= 1e-8
+    fmx.get_fit().accept_mixed_log_determinant = True
     assert abs(fmx.get_fit().log_determinant - ofit.log_determinant) <= 1e-5 * abs(ofit.log_determinant)
 
 
@@ -107,6 +111,7 @@ def test_mixed_fit_large_property(ctx):
     assert res <= 1e-12 and 1 <= its <= 30, (its, res)
     f64 = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
     assert rel(a, f64.get_fit().information) <= 1e-8
+    fmx.get_fit().accept_mixed_log_determinant = True
     assert abs(fmx.get_fit().log_determinant - f64.get_fit().log_determinant) <= 1e-5 * abs(f64.get_fit().log_determinant)
 
 
