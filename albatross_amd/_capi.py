@@ -141,6 +141,7 @@ EXPORTS = [
     ("agp_sharded_fit_failed_pivot", C.c_int64, [_P]),
     ("agp_sharded_fit_replicate", C.c_int, [_P, _P, _PP]),
     ("agp_sharded_predict_marginal", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int]),
+    ("agp_sharded_predict_joint", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int]),
     ("agp_sharded_fit_stage", C.c_int, [_P, C.c_int, _D]),
     ("agp_last_stage_ms", C.c_int, [_P, C.c_int, _D]),
     ("agp_set_profiling", C.c_int, [_P, C.c_int]),

@@ -963,8 +963,8 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
 //               L_li V_i from its own later rows; the column sums of squares are all-reduced once at the end.
 // Exchange per call: N x M doubles in nb broadcasts + one all-reduce of M doubles.
 // ---------------------------------------------------------------------------------------------------------------
-int agp_sharded_predict_marginal(agp_context *c, const agp_kernel *k, agp_sharded_fit *f, const agp_features *xs, double *mean,
-                                 double *variance, int out_location) {
+static int sharded_predict(agp_context *c, const agp_kernel *k, agp_sharded_fit *f, const agp_features *xs, double *mean,
+                           double *variance, bool joint, int out_location) {
   if (!c || !k || !f || !xs || !mean || !variance || f->failed_pivot >= 0 || !f->A) return AGP_ERR_INVALID_ARGUMENT;
   agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
   if (ctx != f->ctx) return AGP_ERR_INVALID_ARGUMENT;
@@ -985,13 +985,15 @@ int agp_sharded_predict_marginal(agp_context *c, const agp_kernel *k, agp_sharde
   if ((st = to_device(ctx, xs, false, &dxs)) != AGP_OK) return st;
   const long long n_loc = plan.multi() ? plan.local_rows(me) : n, nlb = plan.n_local_blocks(me);
   const long long ldk = round_up(std::max<long long>(n_loc, 2), 2);
-  const long long chunk = std::min<long long>(m_all, 4096), ldc = round_up(chunk, 2);
-  // workspace: K*_loc (n_loc x chunk) | V_i (B x chunk, ld = B) | mean | prior | acc
+  // (a joint prediction needs all test points at once: its m x m covariance couples them)
+  const long long chunk = joint ? m_all : std::min<long long>(m_all, 4096), ldc = round_up(chunk, 2);
+  // workspace: K*_loc (n_loc x chunk) | V_i (B x chunk, ld = B) | mean | prior | acc  (joint: prior and acc are m x m)
   double *ws = nullptr;
-  const size_t ws_elems = (size_t)ldk * (size_t)chunk + (size_t)B * (size_t)chunk + 3 * (size_t)ldc;
+  const size_t sq = joint ? (size_t)ldc * (size_t)chunk : (size_t)ldc;
+  const size_t ws_elems = (size_t)ldk * (size_t)chunk + (size_t)B * (size_t)chunk + (size_t)ldc + 2 * sq;
   if (hipMalloc(&ws, sizeof(double) * ws_elems) != hipSuccess) { dxs.release(); ctx->last_error = "hipMalloc (sharded prediction workspace)"; return AGP_ERR_HIP; }
   double *Kloc = ws, *Vi = Kloc + (size_t)ldk * (size_t)chunk, *mean_d = Vi + (size_t)B * (size_t)chunk, *prior = mean_d + ldc,
-         *acc = prior + ldc;
+         *acc = prior + sq;
   HipShardOps ops(ctx);
   hipStream_t s = ctx->stream;
   FeatView train = f->train.v;
@@ -1004,13 +1006,19 @@ int agp_sharded_predict_marginal(agp_context *c, const agp_kernel *k, agp_sharde
     xv.ids = dxs.v.ids ? dxs.v.ids + o : nullptr;
     xv.scales = dxs.v.scales ? dxs.v.scales + o : nullptr;
     launch_predict_mean(s, dprog, train, xv, f->buf.xfull, mean_d, &k->prog);  // gp.hpp:82-85
-    launch_gram_diagonal(s, dprog, xv, prior);                                 // gp.hpp:339-343
+    if (joint) launch_gram(s, dprog, xv, xv, true, false, prior, ldc, nullptr, nullptr, &k->prog);  // prior_cov, gp.hpp:317
+    else launch_gram_diagonal(s, dprog, xv, prior);                            // gp.hpp:339-343
     if (!plan.multi()) {
       // one rank: the local matrix is the whole factor (agp_sharded_fit_create's single-GPU path)
       FeatView all = train;
       launch_gram(s, dprog, all, xv, false, false, Kloc, ldk, nullptr, nullptr, &k->prog);
       forward_solve_mat_lookahead(ctx, f->A, n, f->ld, f->buf.img_local, Kloc, m, ldk);
-      launch_coldot(s, Kloc, ldk, Kloc, ldk, n, m, prior, 1.0, prior);  // gp.hpp:97-99
+      if (joint) {  // gp.hpp:111: K** - V^T V (lower tiles, then mirrored)
+        launch_gemm_nt_sub(s, prior, ldc, Kloc, ldk, true, Kloc, ldk, true, m, m, n, true);
+        launch_symmetrize(s, prior, ldc, m);
+      } else {
+        launch_coldot(s, Kloc, ldk, Kloc, ldk, n, m, prior, 1.0, prior);  // gp.hpp:97-99
+      }
     } else {
       // cross covariance of the own row blocks (cov(train_features, features), gp.hpp:337): no exchange
       for (long long li = 0; li < nlb; ++li) {
@@ -1023,7 +1031,7 @@ int agp_sharded_predict_marginal(agp_context *c, const agp_kernel *k, agp_sharde
         rows.n = plan.width(i);
         launch_gram(s, dprog, rows, xv, false, false, Kloc + li * B, ldk, nullptr, nullptr, &k->prog);
       }
-      (void)hipMemsetAsync(acc, 0, sizeof(double) * (size_t)m, s);
+      (void)hipMemsetAsync(acc, 0, sizeof(double) * (joint ? (size_t)ldc * (size_t)m : (size_t)m), s);
       for (long long i = 0; i < nb && st == AGP_OK; ++i) {
         const int own = plan.owner(i);
         const long long w = plan.width(i);
@@ -1031,7 +1039,7 @@ int agp_sharded_predict_marginal(agp_context *c, const agp_kernel *k, agp_sharde
           const long long li = plan.local_index(i);
           double *Vrows = Kloc + li * B;  // w x m, ld = ldk
           forward_solve_mat(s, f->A + li * B + i * B * f->ld, w, f->ld, f->buf.img_local + li * 4 * SHARD_IMG, Vrows, m, ldk);
-          launch_coldot(s, Vrows, ldk, Vrows, ldk, w, m, acc, 1.0, acc);  // acc -= colsum(V_i o V_i)
+          if (!joint) launch_coldot(s, Vrows, ldk, Vrows, ldk, w, m, acc, 1.0, acc);  // acc -= colsum(V_i o V_i)
           ops.copy2d(QP, Vi, B, Vrows, ldk, w, m);
         }
         if (i == nb - 1) break;  // nobody has rows below the last block
@@ -1040,18 +1048,42 @@ int agp_sharded_predict_marginal(agp_context *c, const agp_kernel *k, agp_sharde
         if (rows2 > 0)  // K*[own rows of blocks > i] -= L[those rows, block column i] V_i
           launch_gemm_nt_sub(s, Kloc + li2 * B, ldk, f->A + li2 * B + i * B * f->ld, f->ld, false, Vi, B, true, rows2, m, w, false);
       }
-      if (st == AGP_OK) st = tr->all_reduce(ops, QP, acc, m, 0);
-      if (st == AGP_OK) launch_axpby(s, m, 1.0, prior, 1.0, acc, prior);  // k** - sum over all ranks
+      if (joint) {
+        // every rank's rows of V = L^-1 K* now stand in K*_loc: acc = - V_own^T V_own (lower tiles, one MFMA product over
+        // the stacked own rows), summed over the ranks by ONE all-reduce of m x m doubles
+        if (st == AGP_OK && n_loc > 0) launch_gemm_nt_sub(s, acc, ldc, Kloc, ldk, true, Kloc, ldk, true, m, m, n_loc, true);
+        if (st == AGP_OK) st = tr->all_reduce(ops, QP, acc, ldc * m, 0);
+        if (st == AGP_OK) {
+          launch_axpby(s, ldc * m, 1.0, prior, 1.0, acc, prior);  // K** - sum over all ranks (gp.hpp:111)
+          launch_symmetrize(s, prior, ldc, m);
+        }
+      } else {
+        if (st == AGP_OK) st = tr->all_reduce(ops, QP, acc, m, 0);
+        if (st == AGP_OK) launch_axpby(s, m, 1.0, prior, 1.0, acc, prior);  // k** - sum over all ranks
+      }
     }
     if (st == AGP_OK) st = wait_stream(ctx, s, comm_timeout_seconds());
     if (st == AGP_OK && tr) st = tr->check_health();
     if (st == AGP_OK) st = copy_out(ctx, mean_d, m, mean + o, out_location);
-    if (st == AGP_OK) st = copy_out(ctx, prior, m, variance + o, out_location);
+    if (st == AGP_OK) st = joint ? copy_out_2d(ctx, prior, ldc, m, m, variance, m, out_location) : copy_out(ctx, prior, m, variance + o, out_location);
   }
   (void)hipStreamSynchronize(s);
   (void)hipFree(ws);
   dxs.release();
   return st;
+}
+
+int agp_sharded_predict_marginal(agp_context *c, const agp_kernel *k, agp_sharded_fit *f, const agp_features *xs, double *mean,
+                                 double *variance, int out_location) {
+  return sharded_predict(c, k, f, xs, mean, variance, false, out_location);
+}
+
+// gp_joint_prediction (gp.hpp:103-113) from the SHARDED factor: the distributed forward substitution of the marginal
+// prediction, then K** - V^T V with every rank contributing the product of its own rows of V and ONE all-reduce of the
+// m x m result.  For factors too large to replicate; all m test points at once (the rank-local block of V is n_loc x m).
+int agp_sharded_predict_joint(agp_context *c, const agp_kernel *k, agp_sharded_fit *f, const agp_features *xs, double *mean,
+                              double *covariance, int out_location) {
+  return sharded_predict(c, k, f, xs, mean, covariance, true, out_location);
 }
 
 int agp_sharded_fit_replicate(agp_context *c, agp_sharded_fit *f, agp_fit **out) {

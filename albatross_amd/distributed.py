@@ -280,6 +280,18 @@ class ShardedGaussianProcessFit:
                         "agp_sharded_predict_marginal")
         return mean, var
 
+    def predict_joint(self, features):
+        """gp_joint_prediction (gp.hpp:103-113) from the sharded factor, not replicated (agp_sharded_predict_joint): every
+        rank multiplies its own rows of V = L^-1 K*, one all-reduce of the m x m product.  Collective: every rank passes the
+        same test features and receives (mean, covariance)."""
+        fs = self.cov.features(features)
+        s = fs.as_struct()
+        mean, cov = np.empty(fs.n), np.empty((fs.n, fs.n), order="F")
+        self.ctx._check(self.ctx._lib.agp_sharded_predict_joint(self.ctx._h, self.ctx.kernel(self.cov), self._h, C.byref(s),
+                                                                C.c_void_p(mean.ctypes.data), C.c_void_p(cov.ctypes.data), capi.HOST),
+                        "agp_sharded_predict_joint")
+        return mean, cov
+
     def replicate(self, model):
         """All-gather the factor: every rank gets an ordinary FitModel of `model` (a GaussianProcessRegression with this
         covariance function) and predicts its own share of the test points."""

@@ -537,6 +537,11 @@ AGP_API int agp_sharded_fit_replicate(agp_context *ctx, agp_sharded_fit *fit, ag
  * passes the same test points and receives all M means and variances (at `location`). */
 AGP_API int agp_sharded_predict_marginal(agp_context *ctx, const agp_kernel *k, agp_sharded_fit *fit, const agp_features *xs,
                                          double *mean, double *variance, int location);
+/* gp_joint_prediction (src/models/gp.hpp:103-113) from the sharded factor, likewise without replicating it: the same
+ * distributed forward substitution, then cov = K** - V^T V where every rank multiplies its own rows of V = L^-1 K* and ONE
+ * all-reduce of m x m doubles sums the products.  cov: m x m column-major, ld = m, on every rank.  Collective. */
+AGP_API int agp_sharded_predict_joint(agp_context *ctx, const agp_kernel *k, agp_sharded_fit *fit, const agp_features *xs,
+                                      double *mean, double *covariance, int location);
 /* per-stage device time of the last sharded fit on this rank, ms: 0 gram, 1 factor, 2 back substitution,
  * 3 sum of the bulk update launches, 4 their count, 5 their algorithmic flop, 6 host time spent enqueueing the
  * schedule, 7 host time until the device had drained (6 ~ 7: the host is the bottleneck) */

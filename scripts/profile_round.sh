@@ -3,7 +3,7 @@
 # Writes under gpurun_out/prof_<round>/ ; scripts/pmc_summary.py turns the CSVs into the
 # summaries kept under profiles/<round>/.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 # the repository root, resolved BEFORE the cd below (GRAFT_REPO_ROOT is only set on the gpurun box)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT="$ROOT/gpurun_out/prof_$R"
@@ -21,12 +21,13 @@ find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
 cd "$ROOT"
 # the other measurements DESIGN.md quotes
 python3 scripts/time_panel.py > "$OUT/time_panel_fused.txt" 2>&1
-AGP_PANEL_FUSED=0 python3 scripts/time_panel.py > "$OUT/time_panel_two_launches.txt" 2>&1
-bash scripts/sweep_fused.sh > "$OUT/sweep_fused.txt" 2>&1
 python3 scripts/time_gram_trees.py > "$OUT/time_gram_trees.txt" 2>&1
 python3 scripts/time_mixed.py 32768 > "$OUT/time_mixed.txt" 2>&1
 python3 scripts/time_sharded_rank.py 16384 65536 > "$OUT/time_sharded_rank.txt" 2>&1
+AGP_SHARD_HOST_PACING=1 python3 scripts/time_sharded_rank.py 16384 > "$OUT/time_sharded_rank_hostpaced.txt" 2>&1
 python3 scripts/time_sharded_rccl1.py > "$OUT/time_sharded_rccl1.txt" 2>&1
 python3 scripts/time_config2.py 1024 2048 4096 8192 > "$OUT/time_config2.txt" 2>&1
+python3 scripts/time_fit_batch.py > "$OUT/time_fit_batch.txt" 2>&1
+python3 scripts/fit_vs_n.py > "$OUT/fit_vs_n.txt" 2>&1
 ls -la "$OUT" "$OUT"/*/ | head -60
 tail -1 "$OUT/bench_n1.json" | cut -c1-300

@@ -66,9 +66,15 @@ def test_sharded_predict_marginal_without_replication(make_ctx, n, block, forced
         sharded.fit(x, y, yvar)
         xs = np.random.default_rng(3).uniform(0., 10., (70, 3))
         mean, var = sharded.predict_marginal(xs)
-        om, ov = orc.OracleFit(cov, x, y, yvar).predict_marginal(xs)
+        ofit = orc.OracleFit(cov, x, y, yvar)
+        om, ov = ofit.predict_marginal(xs)
         assert np.abs(mean - om).max() <= 1e-8 * np.abs(om).max()
         assert np.abs(var - ov).max() <= 1e-8 * np.abs(ov).max() + 1e-9
+        # the joint prediction from the same distributed substitution (gp.hpp:103-113)
+        jm, jc = sharded.predict_joint(xs)
+        ojm, ojc = ofit.predict_joint(xs)
+        assert np.abs(jm - ojm).max() <= 1e-8 * np.abs(ojm).max()
+        assert np.abs(jc - ojc).max() <= 1e-8 * np.abs(ojc).max() + 1e-9 and np.array_equal(jc, jc.T)
     finally:
         if comm is not None:
             comm.close()
@@ -261,6 +267,13 @@ def _worker(rank, world, port, n, block, out, transport="callbacks", env=None):
         dmean, dvar = sharded.predict_marginal(xs)  # all 64 points, from the sharded factor itself (collective)
         assert np.abs(dmean[mine] - marg.mean).max() <= 1e-9 * np.abs(marg.mean).max()
         assert np.abs(dvar[mine] - marg.covariance).max() <= 1e-9 * np.abs(marg.covariance).max() + 1e-10
+        # ... and the joint prediction (every rank its own rows of V, one all-reduce of the 64 x 64 product) against the
+        # replicated factor's
+        jmean, jcov = sharded.predict_joint(xs)
+        rj = fm.predict(xs).joint()
+        assert np.abs(jmean - rj.mean).max() <= 1e-9 * np.abs(rj.mean).max()
+        assert np.abs(jcov - rj.covariance).max() <= 1e-9 * np.abs(rj.covariance).max() + 1e-10
+        assert np.abs(np.diag(jcov) - dvar).max() <= 1e-9 * np.abs(dvar).max() + 1e-10
         bad = None
         try:
             xb = np.random.default_rng(99).uniform(0., 10., (n, 3))
