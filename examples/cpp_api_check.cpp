@@ -86,6 +86,28 @@ int main() {
     std::printf("sharded_prediction_diff,%.17g\n", dp);
     std::printf("sharded_logdet_diff,%.17g\n", std::fabs(sfm.get_fit().log_determinant - fm.get_fit().log_determinant));
   }
+  // several datasets of one size in lock step (agp_fit_create_batch): the same numbers as one fit at a time
+  {
+    std::vector<RegressionDataset<P3>> batch;
+    for (int b = 0; b < 3; ++b) {
+      Vector yb(n);
+      for (int i = 0; i < n; ++i) yb[i] = y[i] * (1. + 0.5 * b);
+      batch.emplace_back(x, yb);
+    }
+    const auto fms = model.fit_batch(batch);
+    double di = 0., dp = 0., dl = 0.;
+    for (int b = 0; b < 3; ++b) {
+      const auto one = model.fit(batch[b]);
+      for (int i = 0; i < n; ++i) di = std::fmax(di, std::fabs(fms[b].get_fit().information[i] - one.get_fit().information[i]));
+      const auto pb = fms[b].predict(xs).marginal(), po = one.predict(xs).marginal();
+      for (int i = 0; i < ms; ++i) dp = std::fmax(dp, std::fmax(std::fabs(pb.mean[i] - po.mean[i]), std::fabs(pb.covariance[i] - po.covariance[i])));
+      dl = std::fmax(dl, std::fabs(fms[b].get_fit().log_determinant - one.get_fit().log_determinant));
+    }
+    std::printf("batch_count,%d\n", (int)fms.size());
+    std::printf("batch_information_diff,%.17g\n", di);
+    std::printf("batch_prediction_diff,%.17g\n", dp);
+    std::printf("batch_logdet_diff,%.17g\n", dl);
+  }
   // CovarianceRepresentation::solve round trip: K (K^-1 e_0) = e_0
   Matrix rhs(n, 1);
   rhs(0, 0) = 1.;

@@ -1465,6 +1465,67 @@ class GaussianProcessRegression {
     return FitModel<GaussianProcessRegression, FeatureType>(*this, std::move(fit));
   }
 
+  // `fit` for SEVERAL datasets of one size in lock step (agp_fit_create_batch): the regime of the reference's own workloads
+  // (benchmarks/bench_predict.cc:20-40: N = 512; one fit per tuner step), where a single fit is bound by the latency of its
+  // serial pivots - a batch shares it.  Every dataset is fitted with THIS model (its current parameters); throws like `fit`
+  // for the first dataset whose covariance has NaN or is not positive definite.
+  template <typename FeatureType>
+  std::vector<FitModel<GaussianProcessRegression, FeatureType>> fit_batch(const std::vector<RegressionDataset<FeatureType>> &datasets) const {
+    std::vector<FitModel<GaussianProcessRegression, FeatureType>> out;
+    if (datasets.empty()) return out;
+    if (mixed_precision.enabled) throw std::invalid_argument("fit_batch: fp64 models only");
+    const std::size_t count = datasets.size(), n = datasets[0].features.size();
+    auto ctx = detail::default_context();
+    detail::KernelHolder k(covariance_function_.program());
+    std::vector<detail::Flat> flats;
+    flats.reserve(count);
+    Vector y(n * count);
+    bool have_var = false;
+    for (const auto &d : datasets) have_var = have_var || !d.targets.covariance.empty();
+    Vector yv(have_var ? n * count : 0, 0.);
+    for (std::size_t b = 0; b < count; ++b) {
+      const auto &d = datasets[b];
+      if (d.features.size() != n || d.targets.size() != n) throw std::invalid_argument("fit_batch: every dataset must have the same number of points");
+      if (!d.targets.covariance.empty() && d.targets.covariance.size() != n)
+        throw std::invalid_argument("target covariance must be diagonal (one variance per target)");
+      flats.push_back(detail::flatten(covariance_function_, d.features));
+      for (std::size_t i = 0; i < n; ++i) {
+        double v = d.targets.mean[i];  // mean_function_.remove_from, gp.hpp:291-292
+        if (!std::is_same<MeanFunc, ZeroMean>::value) v -= mean_function_._call_impl(detail::unwrap<FeatureType>::get(d.features[i]));
+        y[b * n + i] = v;
+        if (have_var && !d.targets.covariance.empty()) yv[b * n + i] = d.targets.covariance[i];
+      }
+    }
+    std::vector<const agp_kernel *> kernels(count, k.k);
+    std::vector<const agp_features *> views(count);
+    for (std::size_t b = 0; b < count; ++b) views[b] = &flats[b].view;
+    std::vector<agp_fit *> handles(count, nullptr);
+    std::vector<int> status(count, AGP_OK);
+    std::vector<double> info(n * count), logdet(count);
+    const int st = agp_fit_create_batch(ctx->ctx, (int)count, kernels.data(), views.data(), y.data(), (std::int64_t)n,
+                                        have_var ? yv.data() : nullptr, (std::int64_t)n, handles.data(), info.data(), (std::int64_t)n,
+                                        logdet.data(), status.data());
+    detail::check(st, ctx->ctx, "agp_fit_create_batch");
+    std::vector<std::shared_ptr<agp_fit>> owned;
+    for (agp_fit *h : handles) owned.emplace_back(h, [ctx](agp_fit *p) { agp_fit_destroy(p); });
+    for (std::size_t b = 0; b < count; ++b)
+      if (status[b] != AGP_OK) {
+        std::string what = "agp_fit_create_batch: problem " + std::to_string(b);
+        if (status[b] == AGP_ERR_NOT_POSITIVE_DEFINITE) what += " (pivot " + std::to_string((long long)agp_fit_failed_pivot(handles[b])) + ")";
+        detail::check(status[b], ctx->ctx, what.c_str());
+      }
+    for (std::size_t b = 0; b < count; ++b) {
+      GPFit<FeatureType> fit;
+      fit.train_features = datasets[b].features;
+      fit.information.assign(info.begin() + (std::ptrdiff_t)(b * n), info.begin() + (std::ptrdiff_t)((b + 1) * n));
+      fit.log_determinant = logdet[b];
+      fit.context = ctx;
+      fit.handle = owned[b];
+      out.emplace_back(*this, std::move(fit));
+    }
+    return out;
+  }
+
   // The same fit over the GPUs of a communicator: every rank passes the SAME dataset, the Gram matrix and its LL^T are
   // sharded row-block-wise (agp_sharded_fit_create), then the factor is replicated (agp_sharded_fit_replicate) so that
   // every rank holds an ordinary FitModel and predicts its own share of the test points - predictions are independent

@@ -159,6 +159,9 @@ def test_cpp_api_matches_oracle():
     assert int(one["sharded_ranks"]) == 1
     assert float(one["sharded_information_diff"]) < 1e-10 and float(one["sharded_prediction_diff"]) < 1e-10
     assert float(one["sharded_logdet_diff"]) < 1e-9
+    # GaussianProcessRegression::fit_batch: three datasets in lock step (agp_fit_create_batch) == one fit at a time
+    assert int(one["batch_count"]) == 3 and float(one["batch_information_diff"]) < 1e-9
+    assert float(one["batch_prediction_diff"]) < 1e-10 and float(one["batch_logdet_diff"]) < 1e-9
     assert int(one["nll_batch_count"]) == 7 and float(one["nll_batch_diff"]) < 1e-8  # agp_nll_batch == agp_nll
     # sparse GP through the C++ surface: close to the direct GP (test_sparse_gp.cc:115-133 thresholds) and
     # equal to the oracle's QR-based restatement
