@@ -13,6 +13,10 @@
 #include <thread>
 
 #include "api_internal.h"
+#include <deque>
+#include <mutex>
+#include <tuple>
+#include <unordered_map>
 #include "trace.h"
 
 namespace agp {
@@ -42,6 +46,91 @@ using namespace agp;
 
 static agp_context_ext *ext_of(agp_context *ctx) { return &static_cast<agp_context_impl *>(ctx)->ext; }
 std::atomic<unsigned long long> g_kernel_uid{1};
+
+namespace agp {
+namespace {
+constexpr size_t DEV_CACHE_BYTES = 8ull << 30;
+struct DevCache {
+  std::mutex mu;
+  std::unordered_map<void *, std::pair<int, size_t>> live;   // blocks handed out: device, size
+  std::deque<std::tuple<int, size_t, void *>> parked;        // oldest first
+  size_t held = 0;
+};
+DevCache &dev_cache() {
+  static DevCache c;
+  return c;
+}
+}  // namespace
+
+hipError_t dev_malloc_bytes(void **p, size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DevCache &c = dev_cache();
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (auto it = c.parked.begin(); it != c.parked.end(); ++it)
+      if (std::get<0>(*it) == dev && std::get<1>(*it) == bytes) {
+        *p = std::get<2>(*it);
+        c.held -= bytes;
+        c.parked.erase(it);
+        c.live[*p] = {dev, bytes};
+        return hipSuccess;
+      }
+  }
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.live[*p] = {dev, bytes};
+  } else {
+    dev_cache_trim();  // out of memory with blocks parked: give them back and try once more
+    const hipError_t e2 = hipMalloc(p, bytes);
+    if (e2 == hipSuccess) {
+      std::lock_guard<std::mutex> lock(c.mu);
+      c.live[*p] = {dev, bytes};
+    }
+    return e2;
+  }
+  return e;
+}
+
+hipError_t dev_free(void *p) {
+  if (!p) return hipSuccess;
+  DevCache &c = dev_cache();
+  std::pair<int, size_t> info{-1, 0};
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto it = c.live.find(p);
+    if (it != c.live.end()) { info = it->second; c.live.erase(it); }
+  }
+  if (info.first < 0 || info.second > DEV_CACHE_BYTES / 4) return hipFree(p);
+  (void)hipDeviceSynchronize();  // what hipFree implies: nothing in flight uses the block any more
+  std::vector<void *> evict;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.parked.emplace_back(info.first, info.second, p);
+    c.held += info.second;
+    while (c.held > DEV_CACHE_BYTES || c.parked.size() > 96) {
+      evict.push_back(std::get<2>(c.parked.front()));
+      c.held -= std::get<1>(c.parked.front());
+      c.parked.pop_front();
+    }
+  }
+  for (void *q : evict) (void)hipFree(q);
+  return hipSuccess;
+}
+
+void dev_cache_trim() {
+  DevCache &c = dev_cache();
+  std::vector<void *> all;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (auto &t : c.parked) all.push_back(std::get<2>(t));
+    c.parked.clear();
+    c.held = 0;
+  }
+  for (void *q : all) (void)hipFree(q);
+}
+}  // namespace agp
 
 namespace agp {
 // the Gram launchers have no context: they follow the switches of the context created last
@@ -185,6 +274,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->stream_comm) (void)hipStreamDestroy(ctx->stream_comm);
   if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
   delete ctx;
+  agp::dev_cache_trim();  // (the parked blocks of dev_free: a process that closes its contexts gives its device memory back)
 }
 
 int agp_context_synchronize(agp_context *ctx) {
@@ -592,7 +682,7 @@ void agp_fit_destroy(agp_fit *fit) {
       ctx->pool_A = fit->A;
       ctx->pool_A_bytes = fit->A_bytes;
     } else {
-      (void)hipFree(fit->A);
+      (void)dev_free(fit->A);
     }
   }
   if (fit->aux_base) {
@@ -604,10 +694,10 @@ void agp_fit_destroy(agp_fit *fit) {
       (void)hipFree(fit->aux_base);
     }
   } else {
-    if (fit->invd) (void)hipFree(fit->invd);
-    if (fit->winv) (void)hipFree(fit->winv);
-    if (fit->alpha) (void)hipFree(fit->alpha);
-    if (fit->z) (void)hipFree(fit->z);
+    if (fit->invd) (void)dev_free(fit->invd);
+    if (fit->winv) (void)dev_free(fit->winv);
+    if (fit->alpha) (void)dev_free(fit->alpha);
+    if (fit->z) (void)dev_free(fit->z);
   }
   fit->train.release();
   delete fit;
@@ -1427,9 +1517,9 @@ static int factor_dense(agp_context *c, const double *K, long long n, long long 
     ctx->pool_A = nullptr;
     ctx->pool_A_bytes = 0;
   } else {
-    AGP_HIP_CHECK(ctx, hipMalloc(&fit->A, fit->A_bytes));
+    AGP_HIP_CHECK(ctx, dev_malloc(&fit->A, fit->A_bytes));
   }
-  AGP_HIP_CHECK(ctx, hipMalloc(&fit->invd, sizeof(double) * (size_t)nblk * (36 * MB * MB)));
+  AGP_HIP_CHECK(ctx, dev_malloc(&fit->invd, sizeof(double) * (size_t)nblk * (36 * MB * MB)));
   const double *src = K;  // device-resident source of the triangle
   if (location == AGP_HOST) {
     // a pitched copy from pageable host memory degenerates into one small copy per

@@ -9,6 +9,16 @@
 #include "common.h"
 
 namespace agp {
+// Device allocations of the entry points that build several medium-sized objects per call (sparse GP fits, dense factors,
+// cross validation): a hipMalloc / hipFree of tens of MB is 1-6 ms on this runtime, a sparse fit did ~40 of them (20 ms in
+// its first stage alone).  dev_free parks the block (after the device-wide synchronisation hipFree implies) and
+// dev_malloc hands out a parked block of exactly the requested size; at most DEV_CACHE_BYTES are kept, the oldest
+// blocks go first; agp_context_destroy empties the cache.  Pointers that did not come from dev_malloc are hipFree'd.
+hipError_t dev_malloc_bytes(void **p, size_t bytes);
+template <class T>
+inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_bytes(reinterpret_cast<void **>(p), bytes); }
+hipError_t dev_free(void *p);
+void dev_cache_trim();
 void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n);
 void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n);
 void launch_set_identity(hipStream_t s, double *B, long long ld, long long n);

@@ -64,8 +64,8 @@ struct SparseScratch {
   double *slabs = nullptr, *pads = nullptr;
   long long slab_count = 0;
   ~SparseScratch() {
-    (void)hipFree(M0); (void)hipFree(T); (void)hipFree(vecs);
-    (void)hipFree(partial); (void)hipFree(Ag); (void)hipFree(Pimg);
+    (void)dev_free(M0); (void)dev_free(T); (void)dev_free(vecs);
+    (void)dev_free(partial); (void)dev_free(Ag); (void)dev_free(Pimg);
     for (agp_fit *b : blocks) agp_fit_destroy(b);
     dx.release();
   }
@@ -160,7 +160,7 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
   xm.meas = 1;  // as_measurements(out_of_order_features), sparse_gp.hpp:649-650
   const long long ldk = round_up(m, 2), np2 = round_up(n, 2);
   // vectors: dvar (n) | yw (n) | t (n)
-  SPX_HIP(hipMalloc(&w.vecs, sizeof(double) * (size_t)(3 * np2)));
+  SPX_HIP(dev_malloc(&w.vecs, sizeof(double) * (size_t)(3 * np2)));
   double *dvar = w.vecs, *yw = dvar + np2, *tvec = yw + np2;
   const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   SPX_HIP(hipMemcpyAsync(yw, y, sizeof(double) * (size_t)n, kind, s));
@@ -214,8 +214,8 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
     // is what the per-block path below is bound by (the HIP launch path is serial per process).
     const long long sb = smax, lda_b = factor_ld(sb), nblk_b = (sb + NB - 1) / NB;
     const long long stride_A = lda_b * sb, stride_I = nblk_b * (36 * MB * MB);
-    SPX_HIP(hipMalloc(&w.Ag, sizeof(double) * (size_t)stride_A * (size_t)n_groups));
-    SPX_HIP(hipMalloc(&w.Pimg, sizeof(double) * ((size_t)stride_I + 1) * (size_t)n_groups));
+    SPX_HIP(dev_malloc(&w.Ag, sizeof(double) * (size_t)stride_A * (size_t)n_groups));
+    SPX_HIP(dev_malloc(&w.Pimg, sizeof(double) * ((size_t)stride_I + 1) * (size_t)n_groups));
     double *logsum = w.Pimg + (size_t)stride_I * (size_t)n_groups;
     SPX_HIP(hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)n_groups, s));
     SPX_HIP(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
@@ -244,7 +244,7 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
     const long long stride_A = lda_b * sb, stride_I = nblk_b * (36 * MB * MB), padded = sb * G;
     double *Ppad = nullptr, *Kpad = nullptr, *ypad = nullptr;
     long long *off_d = nullptr;
-    auto free_pads = [&]() { (void)hipFree(ypad); (void)hipFree(off_d); };
+    auto free_pads = [&]() { (void)dev_free(ypad); (void)dev_free(off_d); };
 #define SPX_HIP2(expr)                                                                   \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
@@ -254,13 +254,13 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
       return AGP_ERR_HIP;                                                                \
     }                                                                                    \
   } while (0)
-    SPX_HIP2(hipMalloc(&off_d, sizeof(long long) * (size_t)(G + 1)));
+    SPX_HIP2(dev_malloc(&off_d, sizeof(long long) * (size_t)(G + 1)));
     SPX_HIP2(hipMemcpyAsync(off_d, offsets, sizeof(long long) * (size_t)(G + 1), hipMemcpyHostToDevice, s));
     Ppad = w.pads;  // in the pool (sized above)
     Kpad = Ppad + (size_t)ldk * (size_t)padded;
-    SPX_HIP2(hipMalloc(&ypad, sizeof(double) * (size_t)round_up(padded, 2)));
-    SPX_HIP2(hipMalloc(&w.Ag, sizeof(double) * (size_t)stride_A * (size_t)G));
-    SPX_HIP2(hipMalloc(&w.Pimg, sizeof(double) * ((size_t)stride_I + 1) * (size_t)G));
+    SPX_HIP2(dev_malloc(&ypad, sizeof(double) * (size_t)round_up(padded, 2)));
+    SPX_HIP2(dev_malloc(&w.Ag, sizeof(double) * (size_t)stride_A * (size_t)G));
+    SPX_HIP2(dev_malloc(&w.Pimg, sizeof(double) * ((size_t)stride_I + 1) * (size_t)G));
     double *logsum = w.Pimg + (size_t)stride_I * (size_t)G;
     SPX_HIP2(hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)G, s));
     SPX_HIP2(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
@@ -309,7 +309,7 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
       const DevProgram *hprog = nullptr;
       if ((stt = device_program(h, k, &hprog)) != AGP_OK) return;
       double *Ag = nullptr;
-      if (hipMalloc(&Ag, sizeof(double) * (size_t)lda_g * (size_t)smax) != hipSuccess) { stt = AGP_ERR_HIP; return; }
+      if (dev_malloc(&Ag, sizeof(double) * (size_t)lda_g * (size_t)smax) != hipSuccess) { stt = AGP_ERR_HIP; return; }
       hipStream_t hs = h->stream;
       for (int64_t g = t; g < n_groups && stt == AGP_OK; g += T) {
         const long long o = offsets[g], sg = offsets[g + 1] - o;
@@ -325,7 +325,7 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
       }
       if (hipStreamSynchronize(hs) != hipSuccess && stt == AGP_OK) stt = AGP_ERR_HIP;
       if (stt != AGP_OK) errors[(size_t)t] = h->last_error;
-      (void)hipFree(Ag);
+      (void)dev_free(Ag);
     };
     std::vector<std::thread> pool;
     for (int t = 1; t < T; ++t) pool.emplace_back(worker, t);
@@ -361,7 +361,7 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
   hipStream_t s = ctx->stream;
   int st = AGP_OK;
   // M = T T^T + W W^T   (the W part summed over the ranks)
-  SPX_HIP(hipMalloc(&w.M0, sizeof(double) * (size_t)ldm * (size_t)m));
+  SPX_HIP(dev_malloc(&w.M0, sizeof(double) * (size_t)ldm * (size_t)m));
   SPX_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
   if (n > 0) syrk_over_observations(s, w, w.M0, ldm, W, ldk, m, n);
   if ((st = comm_all_reduce_device(ctx, comm, w.M0, ldm * m, 0)) != AGP_OK) return st;
@@ -397,11 +397,11 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
   };
   // vectors: b | v | r | dv | tt (m each) | t (n) ; partial sums of the mat-vecs
   double *mv = nullptr;
-  SPX_HIP(hipMalloc(&mv, sizeof(double) * (size_t)(5 * mp2 + np2)));
-  std::unique_ptr<double, void (*)(double *)> mv_guard(mv, [](double *p) { (void)hipFree(p); });
+  SPX_HIP(dev_malloc(&mv, sizeof(double) * (size_t)(5 * mp2 + np2)));
+  std::unique_ptr<double, void (*)(double *)> mv_guard(mv, [](double *p) { (void)dev_free(p); });
   double *bvec = mv, *vvec = bvec + mp2, *rvec = vvec + mp2, *dv = rvec + mp2, *tt = dv + mp2, *tvec = tt + mp2;
   const long long cols = std::max(n, m), chunks = (cols + 1023) / 1024;
-  SPX_HIP(hipMalloc(&w.partial, sizeof(double) * (size_t)chunks * (size_t)m));
+  SPX_HIP(dev_malloc(&w.partial, sizeof(double) * (size_t)chunks * (size_t)m));
   // b = T y_t + W y_w   (B^T y_aug: :370-372 for a fit, :344-350 for an update)
   if (n > 0) launch_matvec(s, W, ldk, m, n, yw, w.partial, 1.0, 0.0, nullptr, bvec);
   else launch_axpby(s, m, 0.0, nullptr, 0.0, nullptr, bvec);
@@ -425,7 +425,7 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
     if ((st = sigma_solve(dv)) != AGP_OK) return st;
     launch_axpby(s, m, 1.0, vvec, 1.0, dv, vvec);
   }
-  SPX_HIP(hipMalloc(&f->v, sizeof(double) * (size_t)m));
+  SPX_HIP(dev_malloc(&f->v, sizeof(double) * (size_t)m));
   SPX_HIP(hipMemcpyAsync(f->v, vvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
   if (bq) {  // y_b = R^-T P^T B^T y_aug = L2^-1 L1^-1 b  (:590)
     forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, bvec, 1, m);
@@ -434,12 +434,12 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
   }
   stage("information + refinement");
   // L_acc = L1 L2 (for update): C = 0 - L1z (L2z^T)^T, negated
-  SPX_HIP(hipMalloc(&f->Lacc, sizeof(double) * (size_t)ldm * (size_t)m));
+  SPX_HIP(dev_malloc(&f->Lacc, sizeof(double) * (size_t)ldm * (size_t)m));
   {
     double *L1z = w.M0;  // m x ldm scratch, no longer needed
     double *L2z = nullptr;
-    SPX_HIP(hipMalloc(&L2z, sizeof(double) * (size_t)ldm * (size_t)m));
-    std::unique_ptr<double, void (*)(double *)> g2(L2z, [](double *p) { (void)hipFree(p); });
+    SPX_HIP(dev_malloc(&L2z, sizeof(double) * (size_t)ldm * (size_t)m));
+    std::unique_ptr<double, void (*)(double *)> g2(L2z, [](double *p) { (void)dev_free(p); });
     SPX_HIP(hipMemcpy2DAsync(L1z, sizeof(double) * (size_t)ldm, f->sigma->A, sizeof(double) * (size_t)f->sigma->lda,
                              sizeof(double) * (size_t)m, (size_t)m, hipMemcpyDeviceToDevice, s));
     SPX_HIP(hipMemcpy2DAsync(L2z, sizeof(double) * (size_t)ldm, f->sigma2->A, sizeof(double) * (size_t)f->sigma2->lda,
@@ -466,12 +466,12 @@ void agp_sparse_fit_destroy(agp_sparse_fit *f) {
   f->kuu.reset();
   if (f->sigma) agp_fit_destroy(f->sigma);
   if (f->sigma2) agp_fit_destroy(f->sigma2);
-  if (f->Lacc) (void)hipFree(f->Lacc);
-  if (f->v) (void)hipFree(f->v);
+  if (f->Lacc) (void)dev_free(f->Lacc);
+  if (f->v) (void)dev_free(f->v);
   f->kz.reset();
   f->kp.reset();
-  if (f->R) (void)hipFree(f->R);
-  if (f->perm) (void)hipFree(f->perm);
+  if (f->R) (void)dev_free(f->R);
+  if (f->perm) (void)dev_free(f->perm);
   delete f;
 }
 
@@ -505,11 +505,11 @@ static int factor_kuu(agp_context *ctx, const agp_kernel *k, const DevProgram *d
   const long long m = uv.n, ldm = factor_ld(m);
   hipStream_t s = ctx->stream;
   double *nug = nullptr, *T = nullptr;
-  SPX_HIP(hipMalloc(&nug, sizeof(double) * (size_t)round_up(m, 2)));
-  std::unique_ptr<double, void (*)(double *)> nug_guard(nug, [](double *p) { (void)hipFree(p); });
+  SPX_HIP(dev_malloc(&nug, sizeof(double) * (size_t)round_up(m, 2)));
+  std::unique_ptr<double, void (*)(double *)> nug_guard(nug, [](double *p) { (void)dev_free(p); });
   launch_axpby(s, m, 0.0, nullptr, nugget, nullptr, nug);
-  SPX_HIP(hipMalloc(&T, sizeof(double) * (size_t)ldm * (size_t)m));
-  std::unique_ptr<double, void (*)(double *)> t_guard(T, [](double *p) { (void)hipFree(p); });
+  SPX_HIP(dev_malloc(&T, sizeof(double) * (size_t)ldm * (size_t)m));
+  std::unique_ptr<double, void (*)(double *)> t_guard(T, [](double *p) { (void)dev_free(p); });
   launch_gram(s, dprog, uv, uv, true, true, T, ldm, nug, nullptr, &k->prog);
   agp_fit *kuu = nullptr;
   const int st = agp_factor_create(ctx, T, m, ldm, 0, AGP_DEVICE, &kuu);
@@ -537,8 +537,8 @@ static int factor_kuu_pivoted(agp_context *ctx, const agp_kernel *k, const DevPr
   const long long m = uv.n, ldq = round_up(m, 2);
   hipStream_t s = ctx->stream;
   double *K = nullptr;
-  SPX_HIP(hipMalloc(&K, sizeof(double) * (size_t)ldq * (size_t)m));
-  std::unique_ptr<double, void (*)(double *)> guard(K, [](double *p) { (void)hipFree(p); });
+  SPX_HIP(dev_malloc(&K, sizeof(double) * (size_t)ldq * (size_t)m));
+  std::unique_ptr<double, void (*)(double *)> guard(K, [](double *p) { (void)dev_free(p); });
   launch_gram(s, dprog, uv, uv, true, false, K, ldq, nullptr, nullptr, &k->prog);
   hipLaunchKernelGGL(add_to_diagonal_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, K, ldq, m, nugget);
   agp_ldlt *kz = nullptr;
@@ -577,7 +577,7 @@ static int sparse_fit_create_pivoted(agp_context *ctx, const agp_kernel *k, cons
   if ((st = to_device(ctx, u, true, f->u.get())) != AGP_OK) return st;
   if ((st = factor_kuu_pivoted(ctx, k, dprog, f->u->v, inducing_nugget, &f->kz)) != AGP_OK) return st;
   f->kp = f->kz;
-  SPX_HIP(hipMalloc(&w.T, sizeof(double) * (size_t)ldm * (size_t)m));
+  SPX_HIP(dev_malloc(&w.T, sizeof(double) * (size_t)ldm * (size_t)m));
   SPX_HIP(hipMemsetAsync(w.T, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
   hipLaunchKernelGGL(ldlt_root_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, s, f->kz->A, f->kz->lda,
                      f->kz->q_dev, m, w.T, ldm);
@@ -591,8 +591,8 @@ static int sparse_fit_create_pivoted(agp_context *ctx, const agp_kernel *k, cons
   // negative log likelihood (:524-596): log|K| = log|A| + 2 log|R| - log|K_uu|; q = y^T A^-1 y - y_b^T y_b, y_b = R^-T P^T K_uf A^-1 y
   const long long chunks = (std::max(n, m) + 1023) / 1024;
   double *vb = nullptr;
-  SPX_HIP(hipMalloc(&vb, sizeof(double) * ((size_t)chunks * (size_t)m + (size_t)3 * (size_t)ldk)));
-  std::unique_ptr<double, void (*)(double *)> vb_guard(vb, [](double *p) { (void)hipFree(p); });
+  SPX_HIP(dev_malloc(&vb, sizeof(double) * ((size_t)chunks * (size_t)m + (size_t)3 * (size_t)ldk)));
+  std::unique_ptr<double, void (*)(double *)> vb_guard(vb, [](double *p) { (void)dev_free(p); });
   double *partial = vb, *bvec = vb + (size_t)chunks * (size_t)m, *yb = bvec + ldk, *rdiag = yb + ldk;
   launch_matvec(s, w.Kuf, ldk, m, n, yw, partial, 1.0, 0.0, nullptr, bvec);
   qr_sqrt_solve(s, f->R, ldk, f->perm, m, bvec, ldk, yb, ldk, 1);
@@ -694,6 +694,7 @@ static int sparse_fit_create_fast(agp_context *ctx, agp_comm *comm, const agp_ke
     f->ctx = ctx; f->m = m; f->inducing_nugget = inducing_nugget;
     f->u = std::shared_ptr<DeviceFeatures>(new DeviceFeatures(), [](DeviceFeatures *d) { d->release(); delete d; });
     if ((e = to_device(ctx, u, true, f->u.get())) != AGP_OK) return e;
+
     // K_uu + inducing_nugget I  (:674-679) -> LL^T ; T = L_u with explicit zeros above the diagonal
     if ((e = factor_kuu(ctx, k, dprog, f->u->v, inducing_nugget, &f->kuu, &w.T)) != AGP_OK) return e;
     SPX_HIP(hipMemcpy2DAsync(w.T, sizeof(double) * (size_t)ldm, f->kuu->A, sizeof(double) * (size_t)f->kuu->lda,
@@ -773,10 +774,10 @@ static int sparse_pivoted_from_rows(agp_context *ctx, agp_sparse_fit *f, const d
   const long long extra = (yt || yw) ? 1 : 0;
   hipStream_t s = ctx->stream;
   double *B = nullptr, *aux = nullptr;
-  SPX_HIP(hipMalloc(&B, sizeof(double) * (size_t)ldb * (size_t)(m + extra)));
-  std::unique_ptr<double, void (*)(double *)> b_guard(B, [](double *p) { (void)hipFree(p); });
-  SPX_HIP(hipMalloc(&aux, sizeof(double) * (size_t)(2 * ldr + 8)));  // tau | norms | state
-  std::unique_ptr<double, void (*)(double *)> a_guard(aux, [](double *p) { (void)hipFree(p); });
+  SPX_HIP(dev_malloc(&B, sizeof(double) * (size_t)ldb * (size_t)(m + extra)));
+  std::unique_ptr<double, void (*)(double *)> b_guard(B, [](double *p) { (void)dev_free(p); });
+  SPX_HIP(dev_malloc(&aux, sizeof(double) * (size_t)(2 * ldr + 8)));  // tau | norms | state
+  std::unique_ptr<double, void (*)(double *)> a_guard(aux, [](double *p) { (void)dev_free(p); });
   double *tau = aux, *norms = aux + ldr, *state = norms + ldr;
   SPX_HIP(hipMemsetAsync(B, 0, sizeof(double) * (size_t)ldb * (size_t)(m + extra), s));
   long long r0 = 0;
@@ -792,7 +793,7 @@ static int sparse_pivoted_from_rows(agp_context *ctx, agp_sparse_fit *f, const d
                        ldb, r0);
     if (yw) SPX_HIP(hipMemcpyAsync(B + (size_t)ldb * (size_t)m + r0, yw, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
   }
-  if (!f->perm) SPX_HIP(hipMalloc(&f->perm, sizeof(long long) * (size_t)m));
+  if (!f->perm) SPX_HIP(dev_malloc(&f->perm, sizeof(long long) * (size_t)m));
   colpiv_qr(s, B, ldb, rows, m, extra, tau, f->perm, norms, state);
   double hstate[4] = {0., 0., 0., 0.};
   SPX_HIP(hipMemcpyAsync(hstate, state, sizeof(hstate), hipMemcpyDeviceToHost, s));
@@ -800,14 +801,14 @@ static int sparse_pivoted_from_rows(agp_context *ctx, agp_sparse_fit *f, const d
   SPX_HIP(hipGetLastError());
   f->rank = (long long)hstate[3];
   const long long nonzero_pivots = (long long)hstate[2];
-  if (!f->R) SPX_HIP(hipMalloc(&f->R, sizeof(double) * (size_t)ldr * (size_t)m));
+  if (!f->R) SPX_HIP(dev_malloc(&f->R, sizeof(double) * (size_t)ldr * (size_t)m));
   qr_extract_r(s, B, ldb, m, f->R, ldr, 0.0);
   if (extra) {
-    if (!f->v) SPX_HIP(hipMalloc(&f->v, sizeof(double) * (size_t)m));
+    if (!f->v) SPX_HIP(dev_malloc(&f->v, sizeof(double) * (size_t)m));
     qr_back_solve(s, f->R, ldr, f->perm, m, nonzero_pivots, B + (size_t)ldb * (size_t)m, f->v);  // the last column is Q^T y_aug
   }
   if (inflate && f->rank < m) qr_extract_r(s, B, ldb, m, f->R, ldr, 1e-10);
-  if (!f->Lacc) SPX_HIP(hipMalloc(&f->Lacc, sizeof(double) * (size_t)ldm * (size_t)m));
+  if (!f->Lacc) SPX_HIP(dev_malloc(&f->Lacc, sizeof(double) * (size_t)ldm * (size_t)m));
   qr_root(s, f->R, ldr, f->perm, m, f->Lacc, ldm);
   SPX_HIP(hipStreamSynchronize(s));
   SPX_HIP(hipGetLastError());
@@ -854,8 +855,8 @@ int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *k, const agp_spars
     return st;
   const long long ldm = factor_ld(m);
   double *yt = nullptr;
-  SPX_HIP(hipMalloc(&yt, sizeof(double) * (size_t)round_up(m, 2)));
-  std::unique_ptr<double, void (*)(double *)> yt_guard(yt, [](double *p) { (void)hipFree(p); });
+  SPX_HIP(dev_malloc(&yt, sizeof(double) * (size_t)round_up(m, 2)));
+  std::unique_ptr<double, void (*)(double *)> yt_guard(yt, [](double *p) { (void)dev_free(p); });
   launch_colvec_dot(s, old->Lacc, ldm, m, m, old->v, 1.0, 0.0, nullptr, yt);  // y_t = L_acc^T v_old  (:344-347)
   if (old->R) {
     // pivoted form: the reference's own algorithm (:336-371) - column-pivoted QR of B = [R_old P_old^T; A^-1/2 K_fu]
@@ -907,8 +908,8 @@ int agp_sparse_fit_from_prediction(agp_context *ctx, const agp_kernel *k, const 
   if ((st = to_device(ctx, z, true, f->u.get())) != AGP_OK) return st;
   // buffers: K_zz | C (later B_z) | W (m x m each, ld ldq) | mean, scratch (2 ldq)
   double *buf = nullptr;
-  SPX_HIP(hipMalloc(&buf, sizeof(double) * ((size_t)3 * (size_t)ldq * (size_t)m + (size_t)2 * (size_t)ldq)));
-  std::unique_ptr<double, void (*)(double *)> guard(buf, [](double *p) { (void)hipFree(p); });
+  SPX_HIP(dev_malloc(&buf, sizeof(double) * ((size_t)3 * (size_t)ldq * (size_t)m + (size_t)2 * (size_t)ldq)));
+  std::unique_ptr<double, void (*)(double *)> guard(buf, [](double *p) { (void)dev_free(p); });
   double *Kzz = buf, *C = Kzz + (size_t)ldq * (size_t)m, *Bz = C + (size_t)ldq * (size_t)m, *mv = Bz + (size_t)ldq * (size_t)m,
          *mw = mv + ldq;
   launch_gram(s, dprog, f->u->v, f->u->v, true, false, Kzz, ldq, nullptr, nullptr, &k->prog);  // K_zz, both triangles (:416-417)
@@ -924,7 +925,7 @@ int agp_sparse_fit_from_prediction(agp_context *ctx, const agp_kernel *k, const 
                            (size_t)m, kind, s));
   if (location == AGP_HOST) SPX_HIP(hipStreamSynchronize(s));
   ldlt_solve(s, f->kz->A, f->kz->lda, m, f->kz->q_dev, mw, mv, ldq, 1);                        // information (:426)
-  SPX_HIP(hipMalloc(&f->v, sizeof(double) * (size_t)m));
+  SPX_HIP(dev_malloc(&f->v, sizeof(double) * (size_t)m));
   SPX_HIP(hipMemcpyAsync(f->v, mv, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
   {
     // DEFAULT_NUGGET on the diagonal of the predictive covariance (:20, 423-425)
