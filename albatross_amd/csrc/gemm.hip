@@ -175,6 +175,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs
   g.A += (long long)blockIdx.y * g.batch_A;
   g.B += (long long)blockIdx.y * g.batch_B;
   __shared__ double lds[2 * 2 * GK * SLD];
+  if (g.stair) {  // (see GemmArgs::stair; st_tpb and st_c0t are in 64-tile units here)
+    const long long sid = blockIdx.x;
+    const int sbi = (int)(sid % g.ntr), sbj = (int)(sid / g.ntr);
+    const long long lb = g.st_lb0 + sbi / g.st_tpb;
+    const long long gi = lb * g.st_world + ((lb & 1) ? g.st_world - 1 - g.st_rank : g.st_rank);
+    if (sbj > gi * g.st_tpb - g.st_c0t + (sbi % g.st_tpb)) return;
+    gemm64_body(g, (long long)sbi * ST, (long long)sbj * ST, lds);
+    return;
+  }
   int bj = 0;
   long long id = blockIdx.x;
   while (true) {
@@ -186,6 +195,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm64_nt_sub_kernel(GemmArgs
   }
   const int bi = (g.tri ? bj : 0) + (int)id;
   gemm64_body(g, (long long)bi * ST, (long long)bj * ST, lds);
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 6) void gemm32_nt_sub_kernel(GemmArgs g) {
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);
+  g.C += (long long)blockIdx.y * g.batch_C;
+  g.A += (long long)blockIdx.y * g.batch_A;
+  g.B += (long long)blockIdx.y * g.batch_B;
+  __shared__ double lds[2 * 2 * GK * TLD];
+  int bj = 0;
+  long long id = blockIdx.x;
+  while (true) {
+    const int cnt = g.tri ? (g.ntr - bj) : g.ntr;
+    if (id < cnt) break;
+    id -= cnt;
+    ++bj;
+  }
+  const int bi = (g.tri ? bj : 0) + (int)id;
+  gemm32_body(g, (long long)bi * TT, (long long)bj * TT, lds);
 }
 
 // 64 x 64 tiles with a TRANSPOSED second operand (B(j, k) at B[k + j * ldb]): the updates of the multi-RHS
@@ -263,6 +290,16 @@ void launch_gemm_nt_sub_batched(hipStream_t s, double *C, long long ldc, long lo
     h.ntc = (int)((N + ST - 1) / ST);
     if (tri && h.ntc > h.ntr) h.ntc = h.ntr;
     const long long t64 = count_tiles(h.ntr, h.ntc, h.tri);
+    if (t64 * count < 256 && K >= 256) {
+      // fewer 64-tiles than CUs and a deep product: every wave would carry K / 4 x 4 MFMAs one behind the other on a
+      // mostly idle chip - 32 x 32 tiles (1536 x 512 x 512: 58 -> 2x us next to a bulk update)
+      h.ntr = (int)((M + TT - 1) / TT);
+      h.ntc = (int)((N + TT - 1) / TT);
+      if (tri && h.ntc > h.ntr) h.ntc = h.ntr;
+      const long long t32 = count_tiles(h.ntr, h.ntc, h.tri);
+      hipLaunchKernelGGL(gemm32_nt_sub_kernel, dim3((unsigned)t32, (unsigned)count), dim3(GEMM_THREADS), 0, s, h);
+      return;
+    }
     hipLaunchKernelGGL(gemm64_nt_sub_kernel, dim3((unsigned)t64, (unsigned)count), dim3(GEMM_THREADS), 0, s, h);
     return;
   }
@@ -286,6 +323,23 @@ void launch_gemm_nt_sub_stair(hipStream_t s, double *C, long long ldc, const dou
   g.ntc = (int)((N + GT - 1) / GT);
   g.stair = 1; g.st_world = world; g.st_rank = rank; g.st_tpb = (int)(block / GT);
   g.st_lb0 = lb0; g.st_c0t = c0 / GT;
+  // Few rounds of 128 x 128 tiles (a rank's share of a sharded fit: 12 tile rows): the last round is mostly idle slots -
+  // 64 x 64 tiles balance the CUs better (the single-GPU bulk update makes the same switch below four rounds)
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    slots = 2 * cus;
+  }
+  if ((long long)g.ntr * g.ntc / 2 < 4LL * slots) {
+    g.ntr = (int)((M + ST - 1) / ST);
+    g.ntc = (int)((N + ST - 1) / ST);
+    g.st_tpb = (int)(block / ST);
+    g.st_c0t = c0 / ST;
+    hipLaunchKernelGGL(gemm64_nt_sub_kernel, dim3((unsigned)((long long)g.ntr * g.ntc)), dim3(GEMM_THREADS), 0, s, g);
+    return;
+  }
   hipLaunchKernelGGL((gemm_nt_sub_kernel<false, false>), dim3((unsigned)((long long)g.ntr * g.ntc)), dim3(GEMM_THREADS), 0, s, g);
 }
 

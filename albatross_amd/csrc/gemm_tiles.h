@@ -331,4 +331,93 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
 }
 
 
+// ---------------------------------------------------------------------------
+// 32 x 32-tile variant for the SMALLEST launches of the panel chain - the next-block-column update of a sharded fit's
+// rank (1536 x 512 x 512), the update of a 512 x 512 diagonal block - where even 64 x 64 tiles leave most of the chip
+// idle and every wave carries 512 MFMAs one behind the other: four times as many workgroups, a 16 x 16 tile (two
+// accumulators over alternating k-steps) per wave.  Panel-major operands only.
+// ---------------------------------------------------------------------------
+constexpr int TT = 32;          // tiny tile edge
+constexpr int TLD = TT + 16;    // LDS pitch (pitch mod 32 == 16: conflict-free fragment reads)
+
+__device__ __forceinline__ void load_chunk32(const double *__restrict__ P, long long ld, long long row0, long long nrows,
+                                             long long k0, long long K, bool vec_ok, double (&r)[2]) {
+  const int t = threadIdx.x;
+  const int kk = t >> 4, seg = (t & 15) * 2;
+  const long long row = row0 + seg, k = k0 + kk;
+  const double *p = P + row + k * ld;
+  if (vec_ok && row0 + TT <= nrows && k0 + GK <= K) {
+    const double2 a = *reinterpret_cast<const double2 *>(p);
+    r[0] = a.x; r[1] = a.y;
+  } else {
+    r[0] = (k < K && row < nrows) ? p[0] : 0.;
+    r[1] = (k < K && row + 1 < nrows) ? p[1] : 0.;
+  }
+}
+
+template <bool NEGATE>
+__device__ __forceinline__ void store_chunk32(double *__restrict__ Ls, const double (&r)[2]) {
+  const int t = threadIdx.x;
+  const int kk = t >> 4, seg = (t & 15) * 2;
+  *reinterpret_cast<double2 *>(Ls + kk * TLD + seg) = NEGATE ? make_double2(-r[0], -r[1]) : make_double2(r[0], r[1]);
+}
+
+// lds: 2 * 2 * GK * TLD doubles
+__device__ __forceinline__ void gemm32_body(const GemmArgs &g, const long long i0, const long long j0, double *lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ln = lane & 15, lg = lane >> 4;
+  const bool a_vec = (((reinterpret_cast<uintptr_t>(g.A)) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_vec = (((reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) && ((g.ldb & 1) == 0);
+  // (the operand stream runs two chunks ahead of the MFMAs, the accumulator starts from C: see gemm64_body)
+  double ra[2][2], rb[2][2];
+  const long long nk = (g.K + GK - 1) / GK;
+  load_chunk32(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra[0]);
+  load_chunk32(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb[0]);
+  if (nk > 1) {
+    load_chunk32(g.A, g.lda, i0, g.M, GK, g.K, a_vec, ra[1]);
+    load_chunk32(g.B, g.ldb, j0, g.N, GK, g.K, b_vec, rb[1]);
+  }
+  v4d acc0, acc1 = v4zero();
+  const long long row = i0 + 16 * wr + ln;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long col = j0 + 16 * wc + lg + 4 * r;
+    acc0[r] = (row < g.M && col < g.N) ? g.C[row + col * g.ldc] : 0.;
+  }
+  store_chunk32<false>(lds, ra[0]);
+  store_chunk32<true>(lds + GK * TLD, rb[0]);
+  __syncthreads();
+  for (long long kc = 0; kc < nk; kc += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const long long k = kc + half;
+      if (k >= nk) break;
+      const double *As = lds + half * (2 * GK * TLD);
+      const double *Bs = As + GK * TLD;
+      if (k + 2 < nk) {
+        load_chunk32(g.A, g.lda, i0, g.M, (k + 2) * GK, g.K, a_vec, ra[half]);
+        load_chunk32(g.B, g.ldb, j0, g.N, (k + 2) * GK, g.K, b_vec, rb[half]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < GK / 4; s2 += 2) {
+        const int k0r = (4 * s2 + lg) * TLD, k1r = (4 * (s2 + 1) + lg) * TLD;
+        acc0 = mfma16(Bs[k0r + 16 * wc + ln], As[k0r + 16 * wr + ln], acc0);
+        acc1 = mfma16(Bs[k1r + 16 * wc + ln], As[k1r + 16 * wr + ln], acc1);
+      }
+      if (k + 1 < nk) {
+        double *An = lds + (half ^ 1) * (2 * GK * TLD);
+        store_chunk32<false>(An, ra[half ^ 1]);
+        store_chunk32<true>(An + GK * TLD, rb[half ^ 1]);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long col = j0 + 16 * wc + lg + 4 * r;
+    if (row < g.M && col < g.N) g.C[row + col * g.ldc] = acc0[r] + acc1[r];
+  }
+}
+
 }  // namespace agp

@@ -56,6 +56,8 @@ def test_mfma_peak_is_sane(ctx, dbg):
     (128, 128, 16, 0, 0, 0), (256, 128, 128, 0, 0, 0), (384, 384, 512, 1, 0, 0),
     (200, 130, 70, 0, 0, 0), (333, 333, 129, 1, 0, 0), (257, 100, 128, 0, 0, 1),
     (140, 90, 50, 0, 1, 1), (300, 64, 128, 0, 1, 0), (130, 130, 1000, 1, 1, 1),
+    # few 64-tiles and K >= 256: the 32 x 32-tile kernel (the sharded fit's next-block-column and diagonal-block updates)
+    (1536, 512, 512, 0, 0, 0), (512, 512, 512, 1, 0, 0), (100, 70, 300, 0, 0, 0), (333, 333, 257, 1, 0, 0), (33, 31, 256, 0, 0, 0),
     # >= 512 tiles of 128 x 128: the large-tile kernel (smaller launches use 64 x 64 tiles)
     (4500, 4500, 48, 1, 0, 0), (3000, 2900, 40, 0, 0, 0), (70, 70, 300, 1, 0, 0),
     # skinny second dimension with a transposed second operand: the 64 x 64-tile kernel with the k-major loader
