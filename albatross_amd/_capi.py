@@ -124,6 +124,14 @@ EXPORTS = [
     ("agp_gram_combined", C.c_int, [_P, _P, C.POINTER(Features), C.c_int64, _P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P,
                            C.c_int64, C.c_int]),
     ("agp_fit_update", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, _P, _PP, _P, _D]),
+    ("agp_solver_from_fit", C.c_int, [_P, _P, _PP]),
+    ("agp_solver_from_ldlt", C.c_int, [_P, _P, _PP]),
+    ("agp_solver_block_symmetric", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _PP]),
+    ("agp_solver_explained", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _PP]),
+    ("agp_solver_rows", C.c_int64, [_P]),
+    ("agp_solver_solve", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int]),
+    ("agp_solver_predict", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, C.POINTER(Features), _P, _P, C.c_int, C.c_int]),
+    ("agp_solver_destroy", None, [_P]),
     ("agp_comm_unique_id", C.c_int, [_P]),
     ("agp_comm_create", C.c_int, [_P, C.c_int, C.c_int, _P, _PP]),
     ("agp_comm_create_callbacks", C.c_int, [C.c_int, C.c_int, _P, _PP]),

@@ -57,8 +57,9 @@ struct DevCache {
   size_t held = 0;
 };
 DevCache &dev_cache() {
-  static DevCache c;
-  return c;
+  // never destroyed: contexts held in a host program's statics are closed after this library's statics would be gone
+  static DevCache *c = new DevCache();
+  return *c;
 }
 }  // namespace
 
@@ -748,16 +749,8 @@ void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long lo
   (void)hipMemcpyAsync(z, xs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }
 
-// ---- one right-hand side through explicitly inverted BW x BW diagonal blocks (n a multiple of BW) ----------------
-// W[b] = inv(L_BB), column-major BW x BW: one batched triangular solve against the identity for all blocks.
-static void invert_wide_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd, long long BW,
-                               double *W) {
-  const long long nb = n / BW;
-  launch_set_identity_batched(s, W, BW, BW * BW, BW, nb);
-  forward_solve_mat_batched(s, A, BW * (lda + 1), BW, lda, invd, (BW / NB) * (long long)(36 * MB * MB), W, BW * BW, BW, BW,
-                            /*rhs_lower=*/true, nb);
-}
-
+// ---- one right-hand side through explicitly inverted BW x BW diagonal blocks (n a multiple of BW): invert_wide_blocks
+// (solve.hip) ----------------
 // z <- L^-1 z, right-looking: x_B = W_B z_B (in place), z[below] -= L[below, B] x_B: two mat-vec launches per BW rows
 // instead of one fused launch per 128 (the chain is launch-latency-bound).  partial: n doubles of scratch.
 static void forward_solve_vec_wide(hipStream_t s, const double *A, long long n, long long lda, const double *W, long long BW,

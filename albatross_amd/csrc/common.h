@@ -254,6 +254,12 @@ void forward_solve_mat_lookahead(agp_context *ctx, const double *A, long long n,
                                  double *B, long long m, long long ldb, bool rhs_lower = false);
 void backward_solve_mat(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
                         double *B, long long m, long long ldb);
+// X = L^-1 B OUT OF PLACE for a right-hand side much wider than L (the sparse GP's m x n matrices): see solve.hip
+constexpr long long WIDE_BW = 512;
+bool forward_solve_wide_ok(long long n, long long ncols);
+void invert_wide_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd, long long BW, double *W);
+void forward_solve_wide(hipStream_t s, const double *A, long long n, long long lda, const double *Winv, const double *B,
+                        long long ldb, double *X, long long ldx, long long ncols);
 
 // out[j] = sum_i A[i,j] * B[i,j]   (column-wise dot of two n x m matrices)
 void launch_coldot(hipStream_t s, const double *A, long long lda, const double *B, long long ldb,
@@ -274,6 +280,8 @@ namespace agp {
 void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,
                         bool a_kmajor, const double *B, long long ldb, bool b_kmajor, long long M,
                         long long N, long long K, bool tri);
+void launch_gemm_nt_ext(hipStream_t s, double *C, long long ldc, const double *Cin, long long ldcin, const double *A, long long lda,
+                        const double *B, long long ldb, long long M, long long N, long long K);
 void launch_gemm_nt_sub_stair(hipStream_t s, double *C, long long ldc, const double *A, long long lda, const double *B,
                               long long ldb, long long M, long long N, long long K, int world, int rank, long long lb0,
                               long long block, long long c0);

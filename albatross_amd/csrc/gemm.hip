@@ -68,6 +68,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g
   gemm_nt_sub_body<A_KMAJOR, B_KMAJOR>(g, lds);
 }
 
+// C = Cin - A B^T or C = A B^T (GemmArgs::Cin / assign): the products of the out-of-place substitution against a very
+// wide right-hand side (forward_solve_wide, solve.hip).  B always k-major (the right-hand side's own rows).
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ext_kernel(GemmArgs g) {
+  __shared__ double lds[2 * 2 * GK * GLD];
+  const int bi = (int)(blockIdx.x % g.ntr), bj = (int)(blockIdx.x / g.ntr);
+  gemm_nt_sub_tile<false, true, true>(g, bi, bj, lds);
+}
+
 // The bulk trailing update of the factorisation (C -= P P^T, lower tiles, K =
 // NBO) under its own kernel symbol, so that profiles and bench.py's roofline
 // block isolate exactly these launches.
@@ -341,6 +349,20 @@ void launch_gemm_nt_sub_stair(hipStream_t s, double *C, long long ldc, const dou
     return;
   }
   hipLaunchKernelGGL((gemm_nt_sub_kernel<false, false>), dim3((unsigned)((long long)g.ntr * g.ntc)), dim3(GEMM_THREADS), 0, s, g);
+}
+
+// C (M x N, ldc) = Cin (ldcin) - A B^T, or C = A B^T if Cin == nullptr;  A (M x K): element (i, k) at A[i + k lda],
+// B (N x K): element (j, k) at B[k + j ldb]
+void launch_gemm_nt_ext(hipStream_t s, double *C, long long ldc, const double *Cin, long long ldcin, const double *A, long long lda,
+                        const double *B, long long ldb, long long M, long long N, long long K) {
+  if (M <= 0 || N <= 0 || K <= 0) return;
+  GemmArgs g;
+  g.C = C; g.ldc = ldc; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
+  g.M = M; g.N = N; g.K = K; g.tri = 0;
+  g.ntr = (int)((M + GT - 1) / GT);
+  g.ntc = (int)((N + GT - 1) / GT);
+  g.Cin = Cin; g.ldcin = ldcin; g.assign = Cin ? 0 : 1;
+  hipLaunchKernelGGL(gemm_nt_ext_kernel, dim3((unsigned)((long long)g.ntr * g.ntc)), dim3(GEMM_THREADS), 0, s, g);
 }
 
 void launch_gemm_nt_sub(hipStream_t s, double *C, long long ldc, const double *A, long long lda,

@@ -31,6 +31,11 @@ struct GemmArgs {
   // tile columns up to its own diagonal tile: bj <= gi * st_tpb - st_c0t + bi % st_tpb.  stair == 0: off.
   int stair = 0, st_world = 1, st_rank = 0, st_tpb = 4;
   long long st_lb0 = 0, st_c0t = 0;
+  // gemm_nt_ext_kernel only: C = Cin - A B^T (Cin may be another matrix, leading dimension ldcin), or - assign != 0 -
+  // C = + A B^T without reading C
+  const double *Cin = nullptr;
+  long long ldcin = 0;
+  int assign = 0;
 };
 
 
@@ -102,7 +107,7 @@ __device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const doubl
 }
 
 // One 128 x 128 tile (bi, bj) of C by one workgroup of 256 threads; lds: 2 * 2 * GK * GLD doubles.
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <bool A_KMAJOR, bool B_KMAJOR, bool EXT = false>
 __device__ __forceinline__ void gemm_nt_sub_tile(const GemmArgs &g, const int bi, const int bj, double *lds) {
   const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
 
@@ -169,7 +174,12 @@ __device__ __forceinline__ void gemm_nt_sub_tile(const GemmArgs &g, const int bi
         const long long col = j0 + 64 * wc + 16 * tj + lg + 4 * r;
         if (row < g.M && col < g.N) {
           double *c = g.C + row + col * g.ldc;
-          *c = *c + acc[tj][ti][r];
+          if (EXT) {
+            if (g.assign) *c = -acc[tj][ti][r];
+            else *c = g.Cin[row + col * g.ldcin] + acc[tj][ti][r];
+          } else {
+            *c = *c + acc[tj][ti][r];
+          }
         }
       }
     }

@@ -450,4 +450,38 @@ void backward_solve_vec_batched(hipStream_t s, const double *A, long long stride
   }
 }
 
+// ---- X = L^-1 B out of place for a right-hand side MUCH wider than L (the sparse GP's m x n matrices K_uf and W, n in the
+// hundred thousands) --------------------------------------------------------------------------------------------------
+// forward_solve_mat walks such a right-hand side 16 times per 2048 rows with K = 128 products; here the 512 x 512
+// diagonal blocks are inverted explicitly (Winv, invert_wide_blocks) and a block row is two steps:
+//   X_i = B_i - L[i, 0:i] X[0:i]      one product of depth 512 i over all columns (B is read once, nothing is copied)
+//   X_i = inv(L_ii) X_i               four products of depth <= 512 with the inverse's 128-row tile rows, bottom-up in
+//                                     place (tile row r reads rows <= r of the same column strip before it stores)
+// n a multiple of 512.  B and X may not overlap.
+void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);  // reduce.hip
+
+bool forward_solve_wide_ok(long long n, long long ncols) { return n >= 2 * WIDE_BW && n % WIDE_BW == 0 && ncols >= 8 * n; }
+
+void invert_wide_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd, long long BW, double *W) {
+  const long long nb = n / BW;
+  launch_set_identity_batched(s, W, BW, BW * BW, BW, nb);
+  forward_solve_mat_batched(s, A, BW * (lda + 1), BW, lda, invd, (BW / NB) * (long long)IMG_DOUBLES, W, BW * BW, BW, BW,
+                            /*rhs_lower=*/true, nb);
+}
+
+void forward_solve_wide(hipStream_t s, const double *A, long long n, long long lda, const double *Winv, const double *B,
+                        long long ldb, double *X, long long ldx, long long ncols) {
+  constexpr long long BW = WIDE_BW;
+  if (ncols <= 0) return;
+  for (long long i = 0; i < n / BW; ++i) {
+    const long long k0 = i * BW;
+    const double *Wi = Winv + i * BW * BW;
+    if (i > 0) launch_gemm_nt_ext(s, X + k0, ldx, B + k0, ldb, A + k0, lda, X, ldx, BW, ncols, k0);
+    const double *src = i > 0 ? X + k0 : B;
+    const long long lds = i > 0 ? ldx : ldb;
+    for (long long r = BW / NB - 1; r >= 0; --r)
+      launch_gemm_nt_ext(s, X + k0 + r * NB, ldx, nullptr, 0, Wi + r * NB, BW, src, lds, NB, ncols, (r + 1) * NB);
+  }
+}
+
 }  // namespace agp

@@ -57,7 +57,7 @@ namespace {
 
 struct SparseScratch {
   double *Kuf = nullptr, *Pbuf = nullptr, *M0 = nullptr, *T = nullptr, *vecs = nullptr, *partial = nullptr,
-         *Ag = nullptr, *Pimg = nullptr, *Q1T = nullptr;
+         *Ag = nullptr, *Pimg = nullptr, *Q1T = nullptr, *Winv = nullptr;
   std::vector<agp_fit *> blocks;
   DeviceFeatures dx;
   // Kuf, Pbuf / Q1T (one region: P is dead before Q1^T is formed) and the split-K slabs live in ctx->pool_sparse
@@ -65,7 +65,7 @@ struct SparseScratch {
   long long slab_count = 0;
   ~SparseScratch() {
     (void)dev_free(M0); (void)dev_free(T); (void)dev_free(vecs);
-    (void)dev_free(partial); (void)dev_free(Ag); (void)dev_free(Pimg);
+    (void)dev_free(partial); (void)dev_free(Ag); (void)dev_free(Pimg); (void)dev_free(Winv);
     for (agp_fit *b : blocks) agp_fit_destroy(b);
     dx.release();
   }
@@ -197,6 +197,11 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
   launch_gram(s, dprog, uv, xm, false, false, w.Kuf, ldk, nullptr, nullptr, &k->prog);
   if (kp) {  // P = K_uu_ldlt.sqrt_solve(K_uf) with the pivoted L D L^T (:680-685)
     ldlt_sqrt_solve(s, kp->A, kp->lda, m, kp->q_dev, w.Pbuf, w.Kuf, ldk, n);
+  } else if (forward_solve_wide_ok(m, n)) {
+    // many more observations than inducing points: out of place through the inverted 512 x 512 diagonal blocks
+    if (!w.Winv) SPX_HIP(dev_malloc(&w.Winv, sizeof(double) * (size_t)m * (size_t)WIDE_BW));
+    invert_wide_blocks(s, kuu->A, m, kuu->lda, kuu->invd, WIDE_BW, w.Winv);
+    forward_solve_wide(s, kuu->A, m, kuu->lda, w.Winv, w.Kuf, ldk, w.Pbuf, ldk, n);
   } else {
     SPX_HIP(hipMemcpyAsync(w.Pbuf, w.Kuf, sizeof(double) * (size_t)ldk * (size_t)n, hipMemcpyDeviceToDevice, s));
     forward_solve_mat(s, kuu->A, m, kuu->lda, kuu->invd, w.Pbuf, n, ldk);
@@ -373,10 +378,17 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
   // CholeskyQR2: Q1^T = L1^-1 [T | W]  (m x (m + n)), G = Q1^T Q1 = L2 L2^T
   SPX_HIP(hipMemcpy2DAsync(w.Q1T, sizeof(double) * (size_t)ldk, T, sizeof(double) * (size_t)ldt, sizeof(double) * (size_t)m,
                            (size_t)m, hipMemcpyDeviceToDevice, s));
-  if (n > 0)
-    SPX_HIP(hipMemcpyAsync(w.Q1T + (size_t)ldk * (size_t)m, W, sizeof(double) * (size_t)ldk * (size_t)n,
-                           hipMemcpyDeviceToDevice, s));
-  forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, w.Q1T, n + m, ldk);
+  if (n > 0 && forward_solve_wide_ok(m, n)) {  // the W columns out of place (no copy), the T columns in place
+    if (!w.Winv) SPX_HIP(dev_malloc(&w.Winv, sizeof(double) * (size_t)m * (size_t)WIDE_BW));
+    invert_wide_blocks(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, WIDE_BW, w.Winv);
+    forward_solve_wide(s, f->sigma->A, m, f->sigma->lda, w.Winv, W, ldk, w.Q1T + (size_t)ldk * (size_t)m, ldk, n);
+    forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, w.Q1T, m, ldk, /*rhs_lower=*/true);
+  } else {
+    if (n > 0)
+      SPX_HIP(hipMemcpyAsync(w.Q1T + (size_t)ldk * (size_t)m, W, sizeof(double) * (size_t)ldk * (size_t)n,
+                             hipMemcpyDeviceToDevice, s));
+    forward_solve_mat(s, f->sigma->A, m, f->sigma->lda, f->sigma->invd, w.Q1T, n + m, ldk);
+  }
   SPX_HIP(hipMemsetAsync(w.M0, 0, sizeof(double) * (size_t)ldm * (size_t)m, s));
   if (n > 0)  // the W columns of Q1 (summed over the ranks), then the T columns
     syrk_over_observations(s, w, w.M0, ldm, w.Q1T + (size_t)ldk * (size_t)m, ldk, m, n);

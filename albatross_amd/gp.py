@@ -319,8 +319,40 @@ def _mean_at(mean_function, cov, features):
 # ---------------------------------------------------------------------------
 # Fit<GPFit<...>> (gp.hpp:43-77): device factor + information vector
 # ---------------------------------------------------------------------------
-class GPFit:
+class _DeviceSolver:
+    """A CovarianceRepresentation that lives on the device as an `agp_solver` (include/albatross_amd.h): the handle is made on
+    first use and goes with the object.  Subclasses provide `_make_solver()`."""
+    _sv = None
+
+    def _solver(self):
+        if self._sv is None:
+            self._sv = self._make_solver()
+        return self._sv
+
+    def _drop_solver(self):
+        try:
+            if getattr(self, "_sv", None) and self._ctx._h:
+                self._ctx._lib.agp_solver_destroy(self._sv)
+        except Exception:
+            pass
+        self._sv = None
+
+    def _solve_through_handle(self, rhs):
+        rhs = np.asarray(rhs, dtype=np.float64)
+        r2 = np.asfortranarray(rhs.reshape(rhs.shape[0], -1))
+        out = np.empty_like(r2, order="F")
+        self._ctx._check(self._ctx._lib.agp_solver_solve(self._ctx._h, self._solver(), _ptr(r2), r2.shape[1], _ptr(out), capi.HOST),
+                         "agp_solver_solve")
+        return out.reshape(rhs.shape, order="F")
+
+
+class GPFit(_DeviceSolver):
     host_composition = False  # the factor, the solves and the predictions all live on the device
+
+    def _make_solver(self):
+        h = C.c_void_p()
+        self._ctx._check(self._ctx._lib.agp_solver_from_fit(self._ctx._h, self._h, C.byref(h)), "agp_solver_from_fit")
+        return h
 
     def __init__(self, ctx, handle, n, train_features):
         self._ctx = ctx
@@ -330,6 +362,7 @@ class GPFit:
         self._information = None
 
     def __del__(self):
+        self._drop_solver()
         try:
             if getattr(self, "_h", None) and self._ctx._h:
                 self._ctx._lib.agp_fit_destroy(self._h)
@@ -445,9 +478,10 @@ class GPFit:
         return L
 
 
-class DenseFactor:
+class DenseFactor(_DeviceSolver):
     """`Eigen::SerializableLDLT(const MatrixXd &)` (eigen/serializable_ldlt.hpp:27): the
     device LL^T of a dense symmetric positive-definite matrix (lower triangle read)."""
+    _make_solver = GPFit._make_solver
 
     def __init__(self, matrix, context=None):
         self._ctx = context or default_context()
@@ -470,6 +504,7 @@ class DenseFactor:
         self._h = h
 
     def __del__(self):
+        self._drop_solver()
         try:
             if getattr(self, "_h", None) and self._ctx._h:
                 self._ctx._lib.agp_fit_destroy(self._h)
@@ -487,7 +522,7 @@ class DenseFactor:
     log_determinant = GPFit.log_determinant
 
 
-class PivotedLDLT:
+class PivotedLDLT(_DeviceSolver):
     """Eigen::LDLT<MatrixXd, Lower> as SerializableLDLT wraps it (eigen/serializable_ldlt.hpp:27): the
     diagonally pivoted P A P^T = L D L^T on the device, for symmetric matrices that are only semi-definite
     (the un-pivoted DenseFactor rejects those).  Same operation order as the reference's unblocked
@@ -508,7 +543,13 @@ class PivotedLDLT:
         self._h = h
         self.success = bool(ok.value)  # info() == Eigen::Success
 
+    def _make_solver(self):
+        h = C.c_void_p()
+        self._ctx._check(self._ctx._lib.agp_solver_from_ldlt(self._ctx._h, self._h, C.byref(h)), "agp_solver_from_ldlt")
+        return h
+
     def __del__(self):
+        self._drop_solver()
         try:
             if getattr(self, "_h", None) and self._ctx._h:
                 self._ctx._lib.agp_ldlt_destroy(self._h)
@@ -573,68 +614,79 @@ def negative_log_likelihood(deviation, covariance, context=None):
     return out.value
 
 
-class BlockSymmetric:
-    """linalg/block_symmetric.hpp:46-115: solver of [[A, B], [B^T, C]] from a solver of A,
-    Ai_B = A^-1 B and the factor of the Schur complement S = C - B^T A^-1 B.
-
-    `host_composition = True`: the block algebra around the device solves (A.solve, S.solve) is numpy on the host -
-    only solvers that are NOT a device factor end up here (pivoted LDL^T fits, fit_from_prediction); fits on the device
-    factor are updated on the device (agp_fit_update)."""
-    host_composition = True
+class BlockSymmetric(_DeviceSolver):
+    """linalg/block_symmetric.hpp:46-115: solver of [[A, B], [B^T, C]] from a solver of A, Ai_B = A^-1 B and the factor of
+    the Schur complement S = C - B^T A^-1 B - ON THE DEVICE (agp_solver_block_symmetric): Ai_B is computed and kept in HBM,
+    a solve is device solves + MFMA products.  Only solvers that are not a plain device factor end up here (pivoted
+    LDL^T fits, fit_from_prediction); fits on the device factor are updated by agp_fit_update."""
+    host_composition = False
 
     def __init__(self, A, B, S):
-        self.A = A
-        self.Ai_B = A.solve(np.asfortranarray(B, dtype=np.float64))  # block_symmetric.hpp:51
-        self.S = S
+        self._ctx = A._ctx
+        self.A, self.S = A, S  # (kept alive: the device object borrows their solvers)
+        self._B = np.asfortranarray(B, dtype=np.float64)
+        if self._B.shape != (A.rows(), S.rows()):
+            raise ValueError("BlockSymmetric: B must be rows(A) x rows(S)")
+
+    def _make_solver(self):
+        h = C.c_void_p()
+        self._ctx._check(self._ctx._lib.agp_solver_block_symmetric(self._ctx._h, self.A._solver(), _ptr(self._B), self._B.shape[0], capi.HOST,
+                                                                   self.S._solver(), C.byref(h)), "agp_solver_block_symmetric")
+        return h
+
+    def __del__(self):
+        self._drop_solver()
 
     def rows(self):
         return self.A.rows() + self.S.rows()
 
     def solve(self, rhs):  # block_symmetric.hpp:75-98
-        rhs = np.asarray(rhs, dtype=np.float64)
-        r2 = rhs.reshape(rhs.shape[0], -1)
-        na = self.A.rows()
-        rhs_a, rhs_b = r2[:na], r2[na:]
-        Bt_Ai_rhs = self.Ai_B.T @ rhs_a
-        Si_Bt_Ai_rhs = self.S.solve(Bt_Ai_rhs)
-        Si_rhs_b = self.S.solve(np.ascontiguousarray(rhs_b))
-        out = np.empty_like(r2)
-        out[:na] = self.A.solve(np.ascontiguousarray(rhs_a)) + self.Ai_B @ (Si_Bt_Ai_rhs - Si_rhs_b)
-        out[na:] = Si_rhs_b - Si_Bt_Ai_rhs
-        return out.reshape(rhs.shape)
+        return self._solve_through_handle(rhs)
 
 
-class ExplainedCovariance:
-    """ExplainedCovariance (covariance_functions/representations.hpp:64-96): S^-1 = A^-1 B A^-1 with the
-    outer matrix A held through its factor (the device LL^T) and the inner matrix B kept as it is, because B
-    may be singular.  `host_composition = True`: the product with B between the two device solves is numpy."""
-    host_composition = True
+class ExplainedCovariance(_DeviceSolver):
+    """ExplainedCovariance (covariance_functions/representations.hpp:64-96): S^-1 = A^-1 B A^-1 with the outer matrix A
+    held through its factor and the inner matrix B kept as it is, because B may be singular - on the device
+    (agp_solver_explained): the product with B between the two solves is an MFMA product in HBM."""
+    host_composition = False
 
     def __init__(self, outer, inner, context=None):
         self.outer_ldlt = outer if isinstance(outer, (DenseFactor, PivotedLDLT)) else DenseFactor(outer, context)
-        self.inner = np.asarray(inner, dtype=np.float64)
+        self._ctx = self.outer_ldlt._ctx
+        self.inner = np.asfortranarray(inner, dtype=np.float64)
+
+    def _make_solver(self):
+        h = C.c_void_p()
+        self._ctx._check(self._ctx._lib.agp_solver_explained(self._ctx._h, self.outer_ldlt._solver(), _ptr(self.inner), self.inner.shape[0],
+                                                             capi.HOST, C.byref(h)), "agp_solver_explained")
+        return h
+
+    def __del__(self):
+        self._drop_solver()
 
     def rows(self):
         return self.inner.shape[0]
 
     def solve(self, rhs):  # representations.hpp:80-82
-        rhs = np.asarray(rhs, dtype=np.float64)
-        r2 = rhs.reshape(rhs.shape[0], -1)
-        return self.outer_ldlt.solve(self.inner @ self.outer_ldlt.solve(np.ascontiguousarray(r2))).reshape(rhs.shape)
+        return self._solve_through_handle(rhs)
 
 
 class UpdatedGPFit:
-    """Fit<GPFit<Representation, F>> whose solver is not the plain factor: BlockSymmetric<Solver> from
-    update() (gp.hpp:384-414) or ExplainedCovariance from fit_from_prediction (gp.hpp:139-153).
-    `host_composition = True`: predictions go through the generic CovarianceRepresentation form of _predict_impl with
-    numpy between the device Gram / solve calls (FitModel.host_composition tells a caller which kind it holds)."""
-    host_composition = True
+    """Fit<GPFit<Representation, F>> whose solver is not the plain LL^T factor: a pivoted L D L^T (semi-definite covariances),
+    BlockSymmetric<Solver> from update() (gp.hpp:384-414) or ExplainedCovariance from fit_from_prediction (gp.hpp:139-153).
+    The solver is a device object (`agp_solver`) and predictions go through agp_solver_predict - the generic
+    CovarianceRepresentation form of _predict_impl (gp.hpp:305-366) in HBM.  `host_composition` is True only for fits over
+    LinearCombination features, whose Gram matrices are contracted on the host by design."""
 
     def __init__(self, train_features, train_covariance, information):
         self.train_features = train_features
         self.train_covariance = train_covariance
         self.information = information
         self.n = information.shape[0]
+
+    @property
+    def host_composition(self):
+        return has_linear_combinations(self.train_features)
 
     def rows(self):
         return self.n
@@ -704,9 +756,11 @@ class FitModel:
         S_ldlt = DenseFactor(S, ctx)                                          # gp.hpp:393
         old_feats = _values_of(self._fit.train_features)
         cross = ctx.gram(m.covariance_function_, old_feats, feats)            # gp.hpp:395-396
-        new_cov = BlockSymmetric(self._fit, cross, S_ldlt)                    # gp.hpp:398-399
+        solver_a = self._fit.train_covariance if isinstance(self._fit, UpdatedGPFit) else self._fit
+        new_cov = BlockSymmetric(solver_a, cross, S_ldlt)                     # gp.hpp:398-399
         Si_delta = S_ldlt.solve(delta)
-        info = np.concatenate([self._fit.information - new_cov.Ai_B @ Si_delta, Si_delta])  # gp.hpp:403-407
+        # information - Ai_B Si_delta = information - A^-1 (B Si_delta)   (gp.hpp:403-407; Ai_B itself stays on the device)
+        info = np.concatenate([self._fit.information - solver_a.solve(cross @ Si_delta), Si_delta])
         new_feats = np.concatenate([np.asarray(old_feats, dtype=np.float64).reshape(self._fit.rows(), -1),
                                     np.asarray(feats, dtype=np.float64).reshape(len(delta), -1)])
         return FitModel(m, UpdatedGPFit(new_feats, new_cov, info))
@@ -736,31 +790,35 @@ class FitModel:
 
     # --- _predict_impl (gp.hpp:305-366) ------------------------------------------
     def _host_predict(self, features, want):
-        """_predict_impl written against a generic CovarianceRepresentation (gp.hpp:305-366):
-        used for fits whose solver is a BlockSymmetric; Gram and solves still run on the device."""
+        """_predict_impl written against a generic CovarianceRepresentation (gp.hpp:305-366), for fits whose solver is not the
+        plain LL^T factor: agp_solver_predict - cross covariance, solve, explained covariance all in HBM.  (LinearCombination
+        features: their Gram matrices are contracted on the host by design, so the composition is too.)"""
         m, ctx = self._model, self._model._ctx()
         cov = m.covariance_function_
-        if has_linear_combinations(features) or has_linear_combinations(self._fit.train_features):
-            cross = ctx.gram(cov, self._fit.train_features, features)
-            mean = cross.T @ self._fit.information + _mean_at(m.mean_function_, cov, features)
+        if not (has_linear_combinations(features) or has_linear_combinations(self._fit.train_features)):
+            fs = cov.features(features)
+            ftr = cov.features(self._fit.train_features)
+            s_xs, s_tr = fs.as_struct(), ftr.as_struct()
+            info = np.ascontiguousarray(self._fit.information, dtype=np.float64)
+            mode = {"mean": 0, "marginal": 1, "joint": 2}[want]
+            mean = np.empty(fs.n)
+            second = None if mode == 0 else (np.empty(fs.n) if mode == 1 else np.empty((fs.n, fs.n), order="F"))
+            ctx._check(ctx._lib.agp_solver_predict(ctx._h, ctx.kernel(cov), self._fit.train_covariance._solver(), C.byref(s_tr), _ptr(info),
+                                                   C.byref(s_xs), _ptr(mean), None if second is None else _ptr(second), mode, capi.HOST),
+                       "agp_solver_predict")
+            mean = mean + m.mean_function_(fs.coords)  # mean_function_.add_to, gp.hpp:364
             if want == "mean":
                 return mean
-            explained = self._fit.solve(cross)
-            prior = ctx.gram(cov, features)
-            if want == "marginal":
-                return MarginalDistribution(mean, np.diag(prior) - np.einsum("ij,ij->j", explained, cross))
-            return JointDistribution(mean, prior - cross.T @ explained)
-        fs = cov.features(features)
-        cross = ctx.gram(cov, self._fit.train_features, fs)
-        mean = cross.T @ self._fit.information + m.mean_function_(fs.coords)
+            return MarginalDistribution(mean, second) if want == "marginal" else JointDistribution(mean, second)
+        cross = ctx.gram(cov, self._fit.train_features, features)
+        mean = cross.T @ self._fit.information + _mean_at(m.mean_function_, cov, features)
         if want == "mean":
             return mean
         explained = self._fit.solve(cross)
+        prior = ctx.gram(cov, features)
         if want == "marginal":
-            prior = np.array([ctx.gram(cov, FeatureSet(fs.coords[i:i + 1], None if fs.scales is None else list(fs.scales[i:i + 1].T),
-                                                       None, fs.is_measurement))[0, 0] for i in range(fs.n)])
-            return MarginalDistribution(mean, prior - np.einsum("ij,ij->j", explained, cross))
-        return JointDistribution(mean, ctx.gram(cov, fs) - cross.T @ explained)
+            return MarginalDistribution(mean, np.diag(prior) - np.einsum("ij,ij->j", explained, cross))
+        return JointDistribution(mean, prior - cross.T @ explained)
 
     def _xs(self, features):
         fs = self._model.covariance_function_.features(features)

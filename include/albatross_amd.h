@@ -456,6 +456,34 @@ AGP_API int agp_predict_joint(agp_context *ctx, const agp_kernel *k, const agp_f
                       const agp_features *xs, double *mean, double *cov,
                       int out_location);
 
+/* ---- CovarianceRepresentation compositions on the device ----------------------------------------------------------
+ * The solvers a fit can hold besides its own factor (src/models/gp.hpp:42-45 asks for `solve` and `rows`), and the generic
+ * form of _predict_impl over any of them - everything stays in HBM, a solve is device solves + MFMA products:
+ *   agp_solver_from_fit / _from_ldlt   the LL^T factor / the pivoted L D L^T as a solver (borrowed: the fit outlives it)
+ *   agp_solver_block_symmetric         BlockSymmetric<Solver> (src/linalg/block_symmetric.hpp:46-133): solver of
+ *                                      [[A, B], [B^T, C]] from a solver of A, B (rows(A) x rows(S), ldb, at `location`) and the
+ *                                      solver S of the Schur complement C - B^T A^-1 B; Ai_B = A.solve(B) is kept on the device
+ *   agp_solver_explained               ExplainedCovariance (src/covariance_functions/representations.hpp:64-96):
+ *                                      S^-1 = outer^-1 inner outer^-1, inner n x n (ld, at `location`)
+ *   agp_solver_solve                   rhs / out n x nrhs column-major (ld = n) at `location`
+ *   agp_solver_predict                 gp.hpp:305-366 over a generic representation: mode 0 mean, 1 marginal (variance m),
+ *                                      2 joint (covariance m x m, ld = m); train = the fit's training features as the
+ *                                      covariance function sees them, information n doubles; all at `location`
+ * Sub-solvers are borrowed and must outlive the composition. */
+typedef struct agp_solver agp_solver;
+AGP_API int agp_solver_from_fit(agp_context *ctx, const agp_fit *fit, agp_solver **out);
+AGP_API int agp_solver_from_ldlt(agp_context *ctx, const agp_ldlt *ldlt, agp_solver **out);
+AGP_API int agp_solver_block_symmetric(agp_context *ctx, const agp_solver *A, const double *B, int64_t ldb, int location,
+                                       const agp_solver *S, agp_solver **out);
+AGP_API int agp_solver_explained(agp_context *ctx, const agp_solver *outer, const double *inner, int64_t ld, int location,
+                                 agp_solver **out);
+AGP_API int64_t agp_solver_rows(const agp_solver *solver);
+AGP_API int agp_solver_solve(agp_context *ctx, const agp_solver *solver, const double *rhs, int64_t nrhs, double *out, int location);
+AGP_API int agp_solver_predict(agp_context *ctx, const agp_kernel *k, const agp_solver *solver, const agp_features *train,
+                               const double *information, const agp_features *xs, double *mean, double *var_or_cov, int mode,
+                               int location);
+AGP_API void agp_solver_destroy(agp_solver *solver);
+
 /* ---- multi-GPU: ONE fit sharded over the GPUs of a node ---------------------------------------
  * The work of the Fit<GPFit> constructor (include/albatross/src/models/gp.hpp:61-69: covariance +
  * diag(targets.covariance), SerializableLDLT, information = ldlt.solve(y)) and of _fit_impl's Gram

@@ -917,6 +917,14 @@ class SerializableLDLT {
                   "agp_fit_inverse_diagonal");
     return out;
   }
+  // this factor as a device-side CovarianceRepresentation (agp_solver): what the compositions below are built from
+  std::shared_ptr<agp_solver> device_solver() const {
+    agp_solver *sv = nullptr;
+    detail::check(agp_solver_from_fit(context_->ctx, handle_.get(), &sv), context_->ctx, "agp_solver_from_fit");
+    auto keep = handle_;
+    return std::shared_ptr<agp_solver>(sv, [keep](agp_solver *p) { agp_solver_destroy(p); });
+  }
+  const std::shared_ptr<detail::ContextHolder> &context() const { return context_; }
 
  private:
   std::shared_ptr<detail::ContextHolder> context_;
@@ -975,6 +983,13 @@ class PivotedLDLT {
     for (double d : vectorD()) s += std::log(d);
     return s;
   }
+  std::shared_ptr<agp_solver> device_solver() const {
+    agp_solver *sv = nullptr;
+    detail::check(agp_solver_from_ldlt(context_->ctx, handle_.get(), &sv), context_->ctx, "agp_solver_from_ldlt");
+    auto keep = handle_;
+    return std::shared_ptr<agp_solver>(sv, [keep](agp_solver *p) { agp_solver_destroy(p); });
+  }
+  const std::shared_ptr<detail::ContextHolder> &context() const { return context_; }
 
  private:
   std::shared_ptr<detail::ContextHolder> context_;
@@ -993,39 +1008,40 @@ inline double negative_log_likelihood(const Vector &deviation, const Matrix &cov
   return out;
 }
 
-// linalg/block_symmetric.hpp:46-115
+namespace detail {
+// solve / predict through a device-side CovarianceRepresentation (agp_solver_*, include/albatross_amd.h)
+inline Matrix solver_solve(const std::shared_ptr<ContextHolder> &ctx, const agp_solver *sv, const Matrix &rhs) {
+  Matrix out(rhs.rows(), rhs.cols());
+  if (rhs.cols() > 0 && rhs.rows() > 0)
+    check(agp_solver_solve(ctx->ctx, sv, rhs.data.data(), rhs.cols(), out.data.data(), AGP_HOST), ctx->ctx, "agp_solver_solve");
+  return out;
+}
+}  // namespace detail
+
+// linalg/block_symmetric.hpp:46-115 - on the device (agp_solver_block_symmetric): Ai_B = A.solve(B) is computed and kept in
+// HBM, a solve is device solves + MFMA products; nothing of the block algebra runs on the host.
 template <typename Solver>
 struct BlockSymmetric {
   BlockSymmetric() = default;
-  BlockSymmetric(const Solver &A_, const Matrix &B_, const SerializableLDLT &S_) : A(A_), Ai_B(A_.solve(B_)), S(S_) {}
-  std::int64_t rows() const { return A.rows() + S.rows(); }
-  Matrix solve(const Matrix &rhs) const {  // block_symmetric.hpp:75-98
-    const std::int64_t na = A.rows(), ns = S.rows(), k = rhs.cols();
-    Matrix rhs_a(na, k), rhs_b(ns, k), Bt_Ai_rhs(ns, k);
-    for (std::int64_t c = 0; c < k; ++c) {
-      for (std::int64_t i = 0; i < na; ++i) rhs_a(i, c) = rhs(i, c);
-      for (std::int64_t i = 0; i < ns; ++i) rhs_b(i, c) = rhs(na + i, c);
-      for (std::int64_t j = 0; j < ns; ++j) {
-        double s = 0.;
-        for (std::int64_t i = 0; i < na; ++i) s += Ai_B(i, j) * rhs(i, c);
-        Bt_Ai_rhs(j, c) = s;
-      }
-    }
-    const Matrix Si_Bt_Ai_rhs = S.solve(Bt_Ai_rhs), Si_rhs_b = S.solve(rhs_b), Ai_rhs_a = A.solve(rhs_a);
-    Matrix out(na + ns, k);
-    for (std::int64_t c = 0; c < k; ++c) {
-      for (std::int64_t i = 0; i < na; ++i) {
-        double s = Ai_rhs_a(i, c);
-        for (std::int64_t j = 0; j < ns; ++j) s += Ai_B(i, j) * (Si_Bt_Ai_rhs(j, c) - Si_rhs_b(j, c));
-        out(i, c) = s;
-      }
-      for (std::int64_t j = 0; j < ns; ++j) out(na + j, c) = Si_rhs_b(j, c) - Si_Bt_Ai_rhs(j, c);
-    }
-    return out;
+  BlockSymmetric(const Solver &A_, const Matrix &B_, const SerializableLDLT &S_) : A(A_), S(S_), context_(S_.context()) {
+    sub_a_ = A.device_solver();
+    sub_s_ = S.device_solver();
+    agp_solver *sv = nullptr;
+    detail::check(agp_solver_block_symmetric(context_->ctx, sub_a_.get(), B_.data.data(), B_.rows(), AGP_HOST, sub_s_.get(), &sv),
+                  context_->ctx, "agp_solver_block_symmetric");
+    auto ka = sub_a_, ks = sub_s_;
+    handle_ = std::shared_ptr<agp_solver>(sv, [ka, ks](agp_solver *p) { agp_solver_destroy(p); });
   }
+  std::int64_t rows() const { return A.rows() + S.rows(); }
+  Matrix solve(const Matrix &rhs) const { return detail::solver_solve(context_, handle_.get(), rhs); }  // block_symmetric.hpp:75-98
+  std::shared_ptr<agp_solver> device_solver() const { return handle_; }
+  const std::shared_ptr<detail::ContextHolder> &context() const { return context_; }
   Solver A;
-  Matrix Ai_B;
   SerializableLDLT S;
+
+ private:
+  std::shared_ptr<detail::ContextHolder> context_;
+  std::shared_ptr<agp_solver> sub_a_, sub_s_, handle_;
 };
 
 template <typename ModelType, typename FeatureType> class FitModel;
@@ -1124,23 +1140,18 @@ class UpdatedFitModel {
   std::int64_t rows() const { return train_covariance.rows(); }
   Matrix solve(const Matrix &rhs) const { return train_covariance.solve(rhs); }
 
+  // _predict_impl over a generic CovarianceRepresentation (gp.hpp:305-366), in HBM: agp_solver_predict
   JointDistribution predict_joint(const std::vector<FeatureType> &xs) const {
-    const Matrix cross = model_.get_covariance()(train_features, xs);
-    const Matrix explained = train_covariance.solve(cross);
     JointDistribution out;
-    out.mean = mean_of(cross, xs);
-    out.covariance = model_.get_covariance()(xs);
-    const std::int64_t n = cross.rows(), m = cross.cols();
-    for (std::int64_t a = 0; a < m; ++a)
-      for (std::int64_t b = 0; b < m; ++b) {
-        double s = 0.;
-        for (std::int64_t i = 0; i < n; ++i) s += cross(i, a) * explained(i, b);
-        out.covariance(a, b) -= s;
-      }
+    out.mean.assign(xs.size(), 0.);
+    out.covariance = Matrix(static_cast<std::int64_t>(xs.size()), static_cast<std::int64_t>(xs.size()));
+    device_predict(xs, &out.mean, out.covariance.data.data(), 2);
     return out;
   }
   Vector predict_mean(const std::vector<FeatureType> &xs) const {
-    return mean_of(model_.get_covariance()(train_features, xs), xs);
+    Vector mean(xs.size(), 0.);
+    device_predict(xs, &mean, nullptr, 0);
+    return mean;
   }
 
   // a further update nests the solvers, exactly like the reference's types do
@@ -1163,12 +1174,16 @@ class UpdatedFitModel {
     const Matrix cross = model.get_covariance()(old_features, d.features);          // gp.hpp:395-396
     BlockSymmetric<S2> new_cov(solver, cross, S_ldlt);                              // gp.hpp:398-399
     const Vector Si_delta = S_ldlt.solve(delta);
-    Vector info(n + m);
-    for (std::size_t i = 0; i < n; ++i) {                                           // gp.hpp:403-407
-      double s = old_information[i];
-      for (std::size_t j = 0; j < m; ++j) s -= new_cov.Ai_B(static_cast<std::int64_t>(i), static_cast<std::int64_t>(j)) * Si_delta[j];
-      info[i] = s;
+    // information - Ai_B Si_delta = information - A^-1 (B Si_delta)   (gp.hpp:403-407; Ai_B itself stays on the device)
+    Matrix b_si(static_cast<std::int64_t>(n), 1);
+    for (std::size_t i = 0; i < n; ++i) {
+      double t = 0.;
+      for (std::size_t j = 0; j < m; ++j) t += cross(static_cast<std::int64_t>(i), static_cast<std::int64_t>(j)) * Si_delta[j];
+      b_si(static_cast<std::int64_t>(i), 0) = t;
     }
+    const Matrix ai_b_si = solver.solve(b_si);
+    Vector info(n + m);
+    for (std::size_t i = 0; i < n; ++i) info[i] = old_information[i] - ai_b_si(static_cast<std::int64_t>(i), 0);
     for (std::size_t j = 0; j < m; ++j) info[n + j] = Si_delta[j];
     std::vector<F2> feats = old_features;
     feats.insert(feats.end(), d.features.begin(), d.features.end());
@@ -1181,15 +1196,16 @@ class UpdatedFitModel {
 
  private:
   template <typename P>
-  Vector mean_of(const Matrix &cross, const std::vector<P> &xs) const {
-    Vector mean(xs.size(), 0.);
-    for (std::int64_t j = 0; j < cross.cols(); ++j) {
-      double s = 0.;
-      for (std::int64_t i = 0; i < cross.rows(); ++i) s += cross(i, j) * information[static_cast<std::size_t>(i)];
-      mean[static_cast<std::size_t>(j)] = s;
-    }
-    model_.add_mean(xs, &mean);
-    return mean;
+  void device_predict(const std::vector<P> &xs, Vector *mean, double *second, int mode) const {
+    if (xs.empty()) return;
+    const auto &ctx = train_covariance.context();
+    detail::KernelHolder k(model_.get_covariance().program());
+    detail::Flat ftr = detail::flatten(model_.get_covariance(), train_features);
+    detail::Flat fxs = detail::flatten(model_.get_covariance(), xs);
+    detail::check(agp_solver_predict(ctx->ctx, k.k, train_covariance.device_solver().get(), &ftr.view, information.data(), &fxs.view,
+                                     mean->data(), second, mode, AGP_HOST),
+                  ctx->ctx, "agp_solver_predict");
+    model_.add_mean(xs, mean);
   }
   ModelType model_;
 };
@@ -1197,22 +1213,27 @@ class UpdatedFitModel {
 // covariance_functions/representations.hpp:64-96: S^-1 = A^-1 B A^-1, A through its factor, B kept as it is
 struct ExplainedCovariance {
   ExplainedCovariance() = default;
-  ExplainedCovariance(const SerializableLDLT &outer_ldlt_, const Matrix &inner_) : outer_ldlt(outer_ldlt_), inner(inner_) {}
-  ExplainedCovariance(const Matrix &outer, const Matrix &inner_) : outer_ldlt(outer), inner(inner_) {}
+  ExplainedCovariance(const SerializableLDLT &outer_ldlt_, const Matrix &inner_) : outer_ldlt(outer_ldlt_), inner(inner_) { make(); }
+  ExplainedCovariance(const Matrix &outer, const Matrix &inner_) : outer_ldlt(outer), inner(inner_) { make(); }
   std::int64_t rows() const { return inner.rows(); }
   std::int64_t cols() const { return inner.cols(); }
-  Matrix solve(const Matrix &rhs) const {  // :80-82
-    const Matrix t = outer_ldlt.solve(rhs);
-    Matrix bt(inner.rows(), t.cols());
-    for (std::int64_t j = 0; j < t.cols(); ++j)
-      for (std::int64_t k = 0; k < inner.cols(); ++k) {
-        const double tk = t(k, j);
-        for (std::int64_t i = 0; i < inner.rows(); ++i) bt(i, j) += inner(i, k) * tk;
-      }
-    return outer_ldlt.solve(bt);
-  }
+  // :80-82 - outer^-1 (inner (outer^-1 rhs)), the product with the inner matrix on the MFMA between the two device solves
+  Matrix solve(const Matrix &rhs) const { return detail::solver_solve(outer_ldlt.context(), handle_.get(), rhs); }
+  std::shared_ptr<agp_solver> device_solver() const { return handle_; }
+  const std::shared_ptr<detail::ContextHolder> &context() const { return outer_ldlt.context(); }
   SerializableLDLT outer_ldlt;
   Matrix inner;
+
+ private:
+  void make() {
+    sub_ = outer_ldlt.device_solver();
+    agp_solver *sv = nullptr;
+    detail::check(agp_solver_explained(outer_ldlt.context()->ctx, sub_.get(), inner.data.data(), inner.rows(), AGP_HOST, &sv),
+                  outer_ldlt.context()->ctx, "agp_solver_explained");
+    auto keep = sub_;
+    handle_ = std::shared_ptr<agp_solver>(sv, [keep](agp_solver *p) { agp_solver_destroy(p); });
+  }
+  std::shared_ptr<agp_solver> sub_, handle_;
 };
 
 // FitModel over a Fit<GPFit<Representation, F>> whose solver is any CovarianceRepresentation

@@ -89,6 +89,32 @@ def test_uniform_groups_batched_path_matches_oracle(ctx, n, gs, m):
     assert np.abs(j.covariance - oj).max() <= 1e-8 * np.abs(oj).max()
 
 
+def test_wide_substitution_path_matches_oracle(ctx):
+    """Many more observations than inducing points (n >= 8 m, m a multiple of 512): P = L_u^-1 K_uf and Q1 = L1^-1 W go
+    through the out-of-place substitution on explicitly inverted 512 x 512 diagonal blocks (forward_solve_wide,
+    csrc/solve.hip) instead of the in-place 128-row chain."""
+    n, m, gs = 8192, 1024, 256
+    rng = np.random.default_rng(1)
+    x = np.sort(rng.uniform(0., n / 16., n))
+    y = np.sin(x) + 0.1 * rng.standard_normal(n)
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.measurement_only(ab.IndependentNoise(0.1))
+    u = np.linspace(x.min(), x.max(), m)
+    rank = {float(v): i for i, v in enumerate(x)}
+    grouper = lambda f: rank[float(f)] // gs
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "sparse", context=ctx)
+    model.set_param("inducing_nugget", 1e-6)
+    fm = model.fit(ab.RegressionDataset(x, y))
+    ofit = orc.OracleSparseFit(cov, x, np.arange(n) // gs, y, None, u, 1e-8, 1e-6)
+    v = ofit.information
+    assert np.abs(fm.get_fit().information - v).max() <= 1e-7 * np.abs(v).max()
+    assert abs(fm.get_fit().nll - ofit.nll) <= 1e-8 * n
+    xs = np.linspace(x.min() + 0.3, x.max() - 0.3, 50)
+    om, ov, oj = ofit.predict(xs, xs_meas=True, joint=True)
+    j = fm.predict_with_measurement_noise(xs).joint()
+    assert np.abs(j.mean - om).max() <= 1e-8 * max(1., np.abs(om).max())
+    assert np.abs(j.covariance - oj).max() <= 1e-8 * np.abs(oj).max()
+
+
 @pytest.mark.parametrize("length_scale,sparse_thr,really_sparse_thr", [(1000., 1e-2, 0.5), (100., 1e-2, 0.5),
                                                                         (10., 5e-2, 100.)])
 def test_sanity_against_direct_gp(ctx, length_scale, sparse_thr, really_sparse_thr):

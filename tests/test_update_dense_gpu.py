@@ -77,6 +77,54 @@ def test_block_symmetric_matches_dense(ctx):
     assert np.abs(bs.solve(rhs) - want).max() <= 1e-10 * np.abs(want).max()
 
 
+def test_device_compositions_nest_and_predict(ctx):
+    """agp_solver_* (include/albatross_amd.h): BlockSymmetric over a BlockSymmetric over a pivoted L D L^T, ExplainedCovariance
+    over a pivoted factor - solves against numpy - and the generic _predict_impl (agp_solver_predict, gp.hpp:305-366) of a fit
+    that was updated twice on a pivoted factor against the oracle's full fit."""
+    n, m1, m2 = 120, 30, 17
+    M = spd(n + m1 + m2, 9)
+    A, B1, C1 = M[:n, :n], M[:n, n:n + m1], M[n:n + m1, n:n + m1]
+    fa = ab.PivotedLDLT(A, ctx)
+    S1 = C1 - B1.T @ np.linalg.solve(A, B1)
+    bs1 = ab.BlockSymmetric(fa, B1, ab.DenseFactor(S1, ctx))
+    M1 = M[:n + m1, :n + m1]
+    B2, C2 = M[:n + m1, n + m1:], M[n + m1:, n + m1:]
+    S2 = C2 - B2.T @ np.linalg.solve(M1, B2)
+    bs2 = ab.BlockSymmetric(bs1, B2, ab.PivotedLDLT(S2, ctx))
+    rhs = np.random.default_rng(1).standard_normal((n + m1 + m2, 5))
+    want = np.linalg.solve(M, rhs)
+    assert bs2.rows() == n + m1 + m2 and not bs2.host_composition
+    assert np.abs(bs2.solve(rhs) - want).max() <= 1e-9 * np.abs(want).max()
+    assert np.abs(bs2.solve(rhs[:, 0]) - want[:, 0]).max() <= 1e-9 * np.abs(want).max()
+    inner = spd(n, 4) - np.eye(n)
+    ec = ab.ExplainedCovariance(fa, inner, ctx)
+    want = np.linalg.solve(A, inner @ np.linalg.solve(A, rhs[:n]))
+    assert np.abs(ec.solve(rhs[:n]) - want).max() <= 1e-9 * np.abs(want).max()
+    # a model fitted through the pivoted factor, updated twice (BlockSymmetric on the device), predicted generically
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0., 10., (260, 2))
+    y = np.sin(x).sum(axis=1) + 0.05 * rng.standard_normal(260)
+    var = np.full(260, 0.1)
+    xs = rng.uniform(0., 10., (40, 2))
+    cov = ab.SquaredExponential(1.5, 1.0) + ab.Constant(2.0)
+    model = ab.gp_from_covariance(cov, context=ctx)
+    first, second, third = slice(0, 150), slice(150, 210), slice(210, 260)
+    fm = model._fit_pivoted(ab.RegressionDataset(x[first], ab.MarginalDistribution(y[first], var[first])),
+                            cov.features(x[first]), y[first].copy(), var[first])
+    fm = fm.update(ab.RegressionDataset(x[second], ab.MarginalDistribution(y[second], var[second])))
+    fm = fm.update(ab.RegressionDataset(x[third], ab.MarginalDistribution(y[third], var[third])))
+    assert isinstance(fm.get_fit().train_covariance, ab.BlockSymmetric) and not fm.host_composition
+    ofit = orc.OracleFit(cov, x, y, var)
+    om, ov = ofit.predict_marginal(xs)
+    ojm, ojc = ofit.predict_joint(xs)
+    assert np.abs(fm.predict(xs).mean() - om).max() <= 1e-8 * np.abs(om).max()
+    marg = fm.predict(xs).marginal()
+    assert np.abs(marg.covariance - ov).max() <= 1e-7 * np.abs(ov).max() + 1e-9
+    joint = fm.predict(xs).joint()
+    assert np.abs(joint.covariance - ojc).max() <= 1e-7 * np.abs(ojc).max() + 1e-9
+    assert np.abs(fm.get_fit().information - ofit.information).max() <= 1e-7 * np.abs(ofit.information).max()
+
+
 def test_update_equals_full_fit(ctx):
     # tests/test_gp.cc:182-219: a partial fit followed by update == a full fit
     rng = np.random.default_rng(3)
@@ -119,9 +167,9 @@ def test_fit_from_prediction_round_trip(ctx):
     features = np.array([1.3, 4.2, 7.1])
     pred = fit_model.predict(features).joint()
     from_pred = model.fit_from_prediction(features, pred)
-    # a fit whose solver is an ExplainedCovariance is a HOST composition around device solves and says so; a plain fit
-    # (and a device update of one) is not
-    assert from_pred.host_composition and not fit_model.host_composition
+    # a fit whose solver is an ExplainedCovariance lives on the device too (agp_solver_explained / agp_solver_predict): no
+    # host arithmetic between the solves
+    assert not from_pred.host_composition and not fit_model.host_composition
     again = from_pred.predict(features).joint()
     assert np.linalg.norm(again.mean - pred.mean) <= 1e-6
     assert np.linalg.norm(again.covariance - pred.covariance) <= 1e-6
