@@ -54,7 +54,8 @@ template <bool A_KMAJOR, bool B_KMAJOR>
 __device__ __forceinline__ void gemm_nt_sub_body(const GemmArgs &g, double *lds) {
   int bi, bj;
   if (!tile_of_block(g, bi, bj)) return;
-  gemm_nt_sub_tile<A_KMAJOR, B_KMAJOR>(g, bi, bj, lds);
+  if (tile_takes_cpf(g, bi, bj)) gemm_nt_sub_tile_cpf<A_KMAJOR, B_KMAJOR>(g, bi, bj, lds);
+  else gemm_nt_sub_tile<A_KMAJOR, B_KMAJOR>(g, bi, bj, lds);
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR>
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_sub_kernel(GemmArgs g
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ext_kernel(GemmArgs g) {
   __shared__ double lds[2 * 2 * GK * GLD];
   const int bi = (int)(blockIdx.x % g.ntr), bj = (int)(blockIdx.x / g.ntr);
-  gemm_nt_sub_tile<false, true, true>(g, bi, bj, lds);
+  if (tile_takes_cpf(g, bi, bj)) gemm_nt_sub_tile_cpf<false, true, true>(g, bi, bj, lds);
+  else gemm_nt_sub_tile<false, true, true>(g, bi, bj, lds);
 }
 
 // The bulk trailing update of the factorisation (C -= P P^T, lower tiles, K =
@@ -81,7 +83,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ext_kernel(GemmArgs g
 // block isolate exactly these launches.
 __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmArgs g) {
   __shared__ double lds[2 * 2 * GK * GLD];
-  gemm_nt_sub_body<false, false>(g, lds);
+  int bi, bj;
+  if (!tile_of_block(g, bi, bj)) return;
+  if (tile_takes_cpf(g, bi, bj)) gemm_nt_sub_tile_cpf<false, false>(g, bi, bj, lds);
+  else gemm_nt_sub_tile<false, false>(g, bi, bj, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -124,6 +129,79 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_f32_kernel(Ge
 
   double ra[8], rb[8];
   const long long nk = (g.K + GK - 1) / GK;
+  if (tile_takes_cpf(g, bi, bj)) {
+    // interior tile, deep product: C (fp64, 64 values per lane) comes in during the K loop in eight parts and the
+    // epilogue only adds and stores (gemm_nt_sub_tile_cpf; here the fp32 accumulators leave room for all of C) - at the
+    // fp32 MFMA's rate the K loop of a tile is 4x shorter and the read-modify-write behind it weighed 4x as much
+    const long long nq = nk / 8;
+    load_chunk_interior<false>(g.A, g.lda, i0, 0, ra);
+    load_chunk_interior<false>(g.B, g.ldb, j0, 0, rb);
+    store_chunk_f32<false>(lds, ra);
+    store_chunk_f32<true>(lds + GK * GLD, rb);
+    __syncthreads();
+    double *const cbase = g.C + (i0 + 64 * wr + ln) + (j0 + 64 * wc + 4 * lg) * g.ldc;
+    constexpr int NPRE = 7;  // parts of C fetched during the loop (all eight would need 4 more registers than a wave has)
+    double cpre[4][4][4];  // [tj][ti][r]
+    long long kc = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const long long k_end = (p == 7) ? nk : (p + 1) * nq;
+      bool first = true;
+      for (; kc < k_end; ++kc) {
+        const int cur = (int)(kc & 1);
+        const float *As = lds + cur * (2 * GK * GLD);
+        const float *Bs = As + GK * GLD;
+        const bool more = kc + 1 < nk;
+        if (more) {
+          load_chunk_interior<false>(g.A, g.lda, i0, (kc + 1) * GK, ra);
+          load_chunk_interior<false>(g.B, g.ldb, j0, (kc + 1) * GK, rb);
+        }
+        if (first && p < NPRE) {
+          first = false;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              cpre[p >> 1][2 * (p & 1) + t][r] = cbase[16 * (2 * (p & 1) + t) + (long long)(16 * (p >> 1) + r) * g.ldc];
+        }
+#pragma unroll
+        for (int s = 0; s < GK / 4; ++s) {
+          float fa[4], fb[4];
+          const int krow = (4 * s + lg) * GLD;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            fa[t] = Bs[krow + 64 * wc + 16 * t + ln];
+            fb[t] = As[krow + 64 * wr + 16 * t + ln];
+          }
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+              acc[tj][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[tj], fb[ti], acc[tj][ti], 0, 0, 0);
+        }
+        if (more) {
+          float *An = lds + (cur ^ 1) * (2 * GK * GLD);
+          store_chunk_f32<false>(An, ra);
+          store_chunk_f32<true>(An + GK * GLD, rb);
+        }
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int p = NPRE; p < 8; ++p)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cpre[p >> 1][2 * (p & 1) + t][r] = cbase[16 * (2 * (p & 1) + t) + (long long)(16 * (p >> 1) + r) * g.ldc];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cbase[16 * ti + (long long)(16 * tj + r) * g.ldc] = cpre[tj][ti][r] + (double)acc[tj][ti][r];
+    return;
+  }
   load_chunk<false>(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
   load_chunk<false>(g.B, g.ldb, j0, g.N, 0, g.K, b_vec, rb);
   store_chunk_f32<false>(lds, ra);

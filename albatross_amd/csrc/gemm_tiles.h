@@ -82,6 +82,20 @@ __device__ __forceinline__ void load_chunk(const double *__restrict__ P, long lo
   }
 }
 
+// the same for an interior tile, a full chunk and 16-B aligned operands: no guards
+template <bool KMAJOR>
+__device__ __forceinline__ void load_chunk_interior(const double *__restrict__ P, long long ld, long long row0, long long k0,
+                                                    double (&r)[8]) {
+  const int t = threadIdx.x;
+  const double *p = KMAJOR ? P + (k0 + (t & 1) * 8) + (row0 + (t >> 1)) * ld : P + (row0 + (t & 15) * 8) + (k0 + (t >> 4)) * ld;
+  const double2 a = *reinterpret_cast<const double2 *>(p);
+  const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+  const double2 c = *reinterpret_cast<const double2 *>(p + 4);
+  const double2 d = *reinterpret_cast<const double2 *>(p + 6);
+  r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+  r[4] = c.x; r[5] = c.y; r[6] = d.x; r[7] = d.y;
+}
+
 template <bool KMAJOR, bool NEGATE>
 __device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const double (&r)[8]) {
   const int t = threadIdx.x;
@@ -183,6 +197,103 @@ __device__ __forceinline__ void gemm_nt_sub_tile(const GemmArgs &g, const int bi
         }
       }
     }
+}
+
+// The same tile for INTERIOR tiles of products at least 8 chunks deep, without the read-modify-write of C behind the K loop.
+// gemm_nt_sub_tile reads, adds and writes C after its loop - where every workgroup of a round does it at the same
+// moment: a burst of 2 x 128 KB per workgroup that the matrix pipe waits for (45 us per round of 512 tiles against
+// 131 us of MFMA work at K = 512: the rate of the bulk update was a function of K, 47.6 TFLOP/s at 512, 60 at 2048;
+// profiles/r04/bulk_update_vs_k.txt).  Here C is added into the accumulators in EIGHT parts while the loop runs: part p
+// (accumulators acc[p >> 1][2 (p & 1) + 0 / 1], 8 values per lane) is loaded at the first chunk of the p-th eighth of
+// the K loop and added after its last chunk, an eighth of the loop later - nothing waits for it -, and the epilogue only
+// stores.  EXT: C = Cin - A B^T / C = A B^T as in gemm_nt_sub_tile.
+template <bool A_KMAJOR, bool B_KMAJOR, bool EXT = false>
+__device__ __forceinline__ void gemm_nt_sub_tile_cpf(const GemmArgs &g, const int bi, const int bj, double *lds) {
+  const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ln = lane & 15, lg = lane >> 4;
+
+  v4d acc[4][4];  // [tj][ti]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = v4zero();
+
+  double ra[8], rb[8];
+  const long long nk = g.K / GK, nq = nk / 8;
+  load_chunk_interior<A_KMAJOR>(g.A, g.lda, i0, 0, ra);
+  load_chunk_interior<B_KMAJOR>(g.B, g.ldb, j0, 0, rb);
+  store_chunk<A_KMAJOR, false>(lds, ra);
+  store_chunk<B_KMAJOR, true>(lds + GK * GLD, rb);
+  __syncthreads();
+
+  const long long coff = (i0 + 64 * wr + ln) + (j0 + 64 * wc + lg) * g.ldc;
+  double *const cbase = g.C + coff;
+  const bool add_c = !EXT || !g.assign;
+  const double *const cin = (EXT && add_c) ? g.Cin + (i0 + 64 * wr + ln) + (j0 + 64 * wc + lg) * g.ldcin : cbase;
+  const long long ldcin = (EXT && add_c) ? g.ldcin : g.ldc;
+  long long kc = 0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    v4d ct[2];
+    const long long k_end = (p == 7) ? nk : (p + 1) * nq;
+    bool first = add_c;
+    for (; kc < k_end; ++kc) {
+      const int cur = (int)(kc & 1);
+      const double *As = lds + cur * (2 * GK * GLD);
+      const double *Bs = As + GK * GLD;
+      const bool more = kc + 1 < nk;
+      if (more) {
+        load_chunk_interior<A_KMAJOR>(g.A, g.lda, i0, (kc + 1) * GK, ra);
+        load_chunk_interior<B_KMAJOR>(g.B, g.ldb, j0, (kc + 1) * GK, rb);
+      }
+      if (first) {  // part p of C: columns 16 (p >> 1) + lg + 4 r of this wave's 64, rows 16 (2 (p & 1) + t) + ln
+        first = false;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ct[t][r] = cin[16 * (2 * (p & 1) + t) + (long long)(16 * (p >> 1) + 4 * r) * ldcin];
+      }
+#pragma unroll
+      for (int s = 0; s < GK / 4; ++s) {
+        double fa[4], fb[4];
+        const int krow = (4 * s + lg) * GLD;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          fa[t] = Bs[krow + 64 * wc + 16 * t + ln];
+          fb[t] = As[krow + 64 * wr + 16 * t + ln];
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
+      }
+      if (more) {
+        double *An = lds + (cur ^ 1) * (2 * GK * GLD);
+        store_chunk<A_KMAJOR, false>(An, ra);
+        store_chunk<B_KMAJOR, true>(An + GK * GLD, rb);
+      }
+      __syncthreads();
+    }
+    if (add_c) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[p >> 1][2 * (p & 1) + t] += ct[t];
+    }
+  }
+  const double sgn = add_c ? 1. : -1.;  // (the accumulators hold -A B^T)
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cbase[16 * ti + (long long)(16 * tj + 4 * r) * g.ldc] = sgn * acc[tj][ti][r];
+}
+
+// interior tile of a product deep enough for the eight parts?
+__device__ __forceinline__ bool tile_takes_cpf(const GemmArgs &g, const int bi, const int bj) {
+  const bool aligned = ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) == 0 && ((g.lda | g.ldb) & 1) == 0;
+  return aligned && g.K >= 8 * GK && g.K % GK == 0 && (long long)(bi + 1) * GT <= g.M && (long long)(bj + 1) * GT <= g.N;
 }
 
 // ---------------------------------------------------------------------------

@@ -5,7 +5,10 @@ import numpy as np
 import albatross_amd as ab
 
 ctx = ab.Context(0)
-for n, m, gs in ((32768, 1024, 512), (262144, 2048, 512), (262144, 2048, -512)):
+CASES = ((32768, 1024, 512), (262144, 2048, 512), (262144, 2048, -512))
+if len(sys.argv) > 1:  # e.g. `time_sparse.py 1`: config 5 only (for a kernel trace)
+    CASES = tuple(CASES[int(a)] for a in sys.argv[1:])
+for n, m, gs in CASES:
     rng = np.random.default_rng(n)
     x = np.sort(rng.uniform(0., n / 16., n))              # 1-D, ~16 points per unit length
     y = np.sin(x) + 0.1 * np.cos(10. * x) + 0.1 * rng.standard_normal(n)
