@@ -488,9 +488,10 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
     slots = 2 * cus;
   }
   long long full, rem;
-  if (tiles < 4LL * slots) {
-    // fewer than four rounds of large tiles: 64 x 64 workgroups throughout balance the CUs better
-    // (scripts/time_tail_split.py: M = 4096, K = 512: 0.196 ms instead of 0.272)
+  if (tiles < 2LL * slots) {
+    // fewer than two rounds of large tiles: 64 x 64 workgroups throughout balance the CUs better (M = 4096, K = 512:
+    // 0.196 ms instead of 0.272; with the store-only epilogue of the large tiles two rounds are enough: M = 6144 448 -> 424 us,
+    // M = 7680 707 -> 670 us)
     full = 0; rem = tiles;
   } else {
     full = (tiles / slots) * slots;

@@ -829,10 +829,10 @@ def run_rank(args):
                 "launches_per_fit": gemm_launches / args.steps,
                 "avg_launch_ms": gemm_ms / max(gemm_launches, 1.0),
                 "flop_per_fit": gemm_flop / args.steps,
-                # context, not the contract's `peak`: what back-to-back independent v_mfma_f64_16x16x4_f64 sustain on this
-                # part (profiles/r01/microbench_fp64.txt: one instruction per ~100 cycles and SIMD at full clock; r02
-                # mfma_rates.txt on random operands: 39-40) and what this kernel does alone at M = 15872 (48.4)
-                "measured_pipe_ceiling_tflops": 48.0,
+                # context, not the contract's `peak`: the K-proportional part of this kernel's time per round of tiles
+                # (0.256 us per k and 512 tiles: profiles/r04/bulk_update_vs_k.txt) - what the loop would do with no
+                # per-tile fixed cost; alone at M = 15872, K = 512 the kernel does 52
+                "k_loop_rate_tflops": 65.0,
             },
             "stages_ms_per_fit": {"gram": gram_ms / args.steps, "factor": factor_ms / args.steps,
                                   "backward_solve": solve_ms / args.steps,

@@ -167,6 +167,39 @@ def test_ldlt_pivoting_handles_semidefinite():
     assert info != 0  # un-pivoted LL^T reports the failed pivot instead
 
 
+def test_ldlt_pivot_order_is_a_function_of_the_diagonal():
+    """Eigen 3.3's LDLT (the reference's BlockDiagonalLDLT of the sparse GP's A blocks, linalg/block_diagonal.hpp:24-313,
+    models/sparse_gp.hpp:688-697) searches its pivot on the trailing diagonal BEFORE that diagonal has seen the updates of
+    the columns already eliminated (the factorisation is left-looking: only A_kk is updated at step k).  The transposition
+    sequence is therefore known from diag(A) alone, and for a positive definite block L D^1/2 is the LL^T factor of the
+    pre-permuted block - which is why the device factors the A blocks in lock step by LL^T (csrc/sparse_api.hip): the
+    products W W^T, W y_w, y_w^T y_w it feeds are invariant under a permutation inside a group, and where a pivot is not
+    positive sqrt_solve (serializable_ldlt.hpp:99-109) has no finite value in the reference either."""
+    rng = np.random.default_rng(21)
+    for n in (5, 64, 200):
+        G = rng.standard_normal((n, n))
+        A = G @ G.T + np.diag(rng.uniform(0.1, 50., n))
+        packed, tr, ok = orc.ldlt(A)
+        assert ok
+        d = np.abs(np.diag(A)).copy()
+        perm = np.arange(n)
+        for k in range(n):  # the search of the factorisation, on the diagonal alone
+            big = k + int(np.argmax(d[k:]))
+            assert tr[k] == big
+            d[[k, big]] = d[[big, k]]
+            perm[[k, big]] = perm[[big, k]]
+        Lunit = np.tril(packed, -1) + np.eye(n)
+        D = np.diag(packed).copy()
+        assert np.all(D > 0.)
+        Lc, info = orc.llt(A[np.ix_(perm, perm)])
+        assert info == 0
+        assert np.abs(Lunit * np.sqrt(D)[None, :] - np.tril(Lc)).max() <= 1e-12 * np.abs(Lc).max()
+        B = rng.standard_normal((n, 4))
+        want = orc.ldlt_sqrt_solve(packed, tr, B)  # D^-1/2 L^-1 P B
+        got = np.linalg.solve(np.tril(Lc), B[perm])
+        assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+
+
 def test_oracle_nan_input_is_reported():
     cov = ab.SquaredExponential(1., 1.)
     x = np.array([0., np.nan, 2.])
