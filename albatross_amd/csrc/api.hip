@@ -215,7 +215,7 @@ int agp_context_create(int device_id, agp_context **out) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
     ctx->cus = cus;
     // 224 of 256 CUs (28 per XCD) from 8704 remaining rows on is the best pair at N = 16384 (profiles/r02/sweep_mask.txt)
-    const int keep = getenv("AGP_X_KEEP") ? atoi(getenv("AGP_X_KEEP")) : cus / 8 * 7 / 8 * 8;
+    const int keep = cus / 8 * 7 / 8 * 8;
     if (keep > 0 && keep < cus) {
       uint32_t mask[16] = {0};
       for (int i = 0; i < keep && i < 512; ++i) mask[i / 32] |= 1u << (i % 32);

@@ -873,13 +873,13 @@ static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long
 // ---- the schedule's switch points (measured on one MI355X; DESIGN.md sections 3 and 8 hold the sweeps) ------------
 // The two switches a caller can set - AGP_PANEL_FUSED=0 (POTRF and TRSM as two launches) and AGP_STEP_BELOW=<rows> (0: no
 // step launches) - are read ONCE, at agp_context_create, into ctx->tune (api.hip); everything else is a constant.
-static long long FUSED_BELOW = getenv("AGP_X_FUSED") ? atoll(getenv("AGP_X_FUSED")) : 4608;     // remaining rows at or below which POTRF + TRSM are one fused launch (2048 .. 4608 best)
-static long long INNER_LEFT_ABOVE = getenv("AGP_X_INNER") ? atoll(getenv("AGP_X_INNER")) : 6144;  // left-looking inside an outer block while more rows than this remain
+constexpr long long FUSED_BELOW = 4608;     // remaining rows at or below which POTRF + TRSM are one fused launch (2048 .. 4608 best)
+constexpr long long INNER_LEFT_ABOVE = 6144;  // left-looking inside an outer block while more rows than this remain
 constexpr long long NBO_512_ABOVE = 2048, NBO_256_ABOVE = 1024;  // outer block width 512 / 256 / 128 by remaining rows
-static long long THROTTLE_BELOW = getenv("AGP_X_THROTTLE") ? atoll(getenv("AGP_X_THROTTLE")) : 8192;  // bulk updates handed to their stream by the host once their panel is done
+constexpr long long THROTTLE_BELOW = 8192;  // bulk updates handed to their stream by the host once their panel is done
 constexpr long long U1_F32_ABOVE = 4096;    // mixed precision: U1 on the fp32 MFMA path while the block column is this tall
 constexpr long long SINGLE_BELOW = 1536;    // the very end on one stream (when the step launches are off)
-static long long MASK_BELOW = getenv("AGP_X_MASK") ? atoll(getenv("AGP_X_MASK")) : 8704;      // bulk updates on the CU-masked stream from here on
+constexpr long long MASK_BELOW = 8704;      // bulk updates on the CU-masked stream from here on
 
 // Workgroup slots of panel_fused_kernel<true> on this device: occupancy x CUs, asked of the runtime once per context.
 static long long step_slots(agp_context *ctx) {
