@@ -92,7 +92,8 @@ if tot_active:
         out["trailing_update_largest_launch"] = {"duration_ms": best[0] / 1e6, "mfma_util": best[1] / (best[2] / 8 * 1024),
                                                  "mfma_mops_f64": best[3]}
     out["note"] = ("counter runs serialise kernels (no overlap with the panel stream); each v_mfma_f64_16x16x4_f64 holds the pipe 64 "
-                   "cycles but at most one issues per ~100 cycles per SIMD, so ~0.65-0.68 is the utilisation ceiling of this instruction")
+                   "cycles; the K loop of the kernel alone is at ~0.9 (65 TFLOP/s: profiles/r04/bulk_update_vs_k.txt), the rest is the "
+                   "fixed cost per tile (rounds 1-3 read their 0.67 as the ceiling of the instruction: it was the C read-modify-write)")
     json.dump(out, open(os.path.join(dst, "pmc_mfma_util.json"), "w"), indent=1)
 
 # ---- stats + bench lines -------------------------------------------------------
