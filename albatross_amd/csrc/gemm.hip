@@ -81,10 +81,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ext_kernel(GemmArgs g
 // The bulk trailing update of the factorisation (C -= P P^T, lower tiles, K =
 // NBO) under its own kernel symbol, so that profiles and bench.py's roofline
 // block isolate exactly these launches.
+// The tiles that would form a partial LAST round of 128 x 128 workgroups go FIRST, as four 64 x 64 workgroups each
+// (small_first / small_count): the launch ends with full rounds, and no second launch (round 3: trailing_update_tail_kernel
+// behind this one - 50-100 us per update during which a fraction of the chip worked) is needed for them.
 __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmArgs g) {
   __shared__ double lds[2 * 2 * GK * GLD];
-  int bi, bj;
-  if (!tile_of_block(g, bi, bj)) return;
+  const bool small = (long long)blockIdx.x < 4LL * g.small_count;
+  long long id = small ? (long long)(blockIdx.x >> 2) + g.small_first : (long long)blockIdx.x - 4LL * g.small_count + g.tile_first;
+  int bj = 0;
+  while (true) {
+    const int cnt = g.ntr - bj;
+    if (id < cnt) break;
+    id -= cnt;
+    ++bj;
+  }
+  const int bi = bj + (int)id;
+  if (small) {
+    const int q = blockIdx.x & 3, qi = q & 1, qj = q >> 1;
+    if (bi == bj && qj > qi) return;  // upper quadrant of a diagonal tile
+    gemm64_body(g, (long long)bi * GT + qi * ST, (long long)bj * GT + qj * ST, lds);
+    return;
+  }
   if (tile_takes_cpf(g, bi, bj)) gemm_nt_sub_tile_cpf<false, false>(g, bi, bj, lds);
   else gemm_nt_sub_tile<false, false>(g, bi, bj, lds);
 }
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_f32_kernel(Ge
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              cpre[p >> 1][2 * (p & 1) + t][r] = cbase[16 * (2 * (p & 1) + t) + (long long)(16 * (p >> 1) + r) * g.ldc];
+              cpre[p >> 1][2 * (p & 1) + t][r] = __builtin_nontemporal_load(&cbase[16 * (2 * (p & 1) + t) + (long long)(16 * (p >> 1) + r) * g.ldc]);
         }
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_f32_kernel(Ge
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cbase[16 * ti + (long long)(16 * tj + r) * g.ldc] = cpre[tj][ti][r] + (double)acc[tj][ti][r];
+        for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(cpre[tj][ti][r] + (double)acc[tj][ti][r], &cbase[16 * ti + (long long)(16 * tj + r) * g.ldc]);
     return;
   }
   load_chunk<false>(g.A, g.lda, i0, g.M, 0, g.K, a_vec, ra);
@@ -500,11 +517,14 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
   }
   if (full > 0) {
     if (timing && timing->e0) (void)hipEventRecord(timing->e0, s);
-    hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)full), dim3(GEMM_THREADS), 0, s, g);
+    g.small_first = full;
+    g.small_count = (int)rem;
+    hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)(full + 4 * rem)), dim3(GEMM_THREADS), 0, s, g);
     if (timing && timing->e1) {
       (void)hipEventRecord(timing->e1, s);
-      timing->flops = 2. * (double)K * lower_entries(M, g.ntr, full);
+      timing->flops = 2. * (double)K * lower_entries(M, g.ntr, tiles);
     }
+    return;
   }
   if (rem > 0) {
     GemmArgs h = g;

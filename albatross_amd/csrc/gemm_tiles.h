@@ -36,6 +36,10 @@ struct GemmArgs {
   const double *Cin = nullptr;
   long long ldcin = 0;
   int assign = 0;
+  // trailing_update_kernel only: its first 4 * small_count workgroups compute the 128-tiles small_first .. (column-major
+  // lower-tile order) as 64 x 64 quadrants, the others the tiles 0 .. small_first - 1 whole
+  long long small_first = 0;
+  int small_count = 0;
 };
 
 
@@ -253,7 +257,7 @@ __device__ __forceinline__ void gemm_nt_sub_tile_cpf(const GemmArgs &g, const in
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ct[t][r] = cin[16 * (2 * (p & 1) + t) + (long long)(16 * (p >> 1) + 4 * r) * ldcin];
+          for (int r = 0; r < 4; ++r) ct[t][r] = __builtin_nontemporal_load(&cin[16 * (2 * (p & 1) + t) + (long long)(16 * (p >> 1) + 4 * r) * ldcin]);
       }
 #pragma unroll
       for (int s = 0; s < GK / 4; ++s) {
@@ -287,7 +291,7 @@ __device__ __forceinline__ void gemm_nt_sub_tile_cpf(const GemmArgs &g, const in
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cbase[16 * ti + (long long)(16 * tj + 4 * r) * g.ldc] = sgn * acc[tj][ti][r];
+      for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(sgn * acc[tj][ti][r], &cbase[16 * ti + (long long)(16 * tj + 4 * r) * g.ldc]);
 }
 
 // interior tile of a product deep enough for the eight parts?
