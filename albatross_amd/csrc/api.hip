@@ -253,6 +253,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->ws_A) (void)hipFree(ctx->ws_A);
   if (ctx->pool_A) (void)hipFree(ctx->pool_A);
   if (ctx->pool_K) (void)hipFree(ctx->pool_K);
+  if (ctx->p32) (void)hipFree(ctx->p32);
   if (ctx->pool_aux) (void)hipFree(ctx->pool_aux);
   if (ctx->pool_shard) (void)hipFree(ctx->pool_shard);
   if (ctx->pool_sparse) (void)hipFree(ctx->pool_sparse);
@@ -905,6 +906,15 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, Kfull, fit->lda, yvar_d, ctx->d_flags,
                 &k->prog);
     ctx->update_variant = 3;  // fp32-product bulk updates
+    {  // two fp32 panel copies of (n rows + padding) x 512 (chol.hip, factor_lower); kept in the context
+      const size_t want = sizeof(float) * 2 * ((size_t)n + 16) * 512;
+      if (ctx->p32_bytes < want) {
+        if (ctx->p32) (void)hipFree(ctx->p32);
+        ctx->p32 = nullptr; ctx->p32_bytes = 0;
+        if (hipMalloc(&ctx->p32, want) == hipSuccess) ctx->p32_bytes = want;
+        else (void)hipGetLastError();  // (the kernels round the operands themselves then)
+      }
+    }
   }
   // The fp64 fit does not wait for the factorisation before it enqueues the backward substitution: one host round trip
   // (~0.1 ms) less; the status is read after the single synchronisation at the end, and a substitution through a factor

@@ -852,7 +852,8 @@ static void launch_potrf(hipStream_t s, double *A, long long lda, long long k0, 
 // trailing update C -= P P^T (lower tiles) bracketed by a HIP-event pair when
 // the caller collects per-launch timings (bench.py's roofline block)
 static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long lda, const double *P,
-                       const double *Q, long long M, long long N, long long K, bool bulk, int variant = -1) {
+                       const double *Q, long long M, long long N, long long K, bool bulk, int variant = -1,
+                       const float *P32 = nullptr, long long ld32 = 0) {
   // only the bulk trailing updates' trailing_update_kernel launches (their own kernel symbol) are
   // event-timed: they run on the second stream, where an event gap is off the critical path
   if (!bulk) {
@@ -862,7 +863,7 @@ static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long
   BulkTiming bt;
   const bool timed = timers && timers->ev && timers->used + 2 <= timers->n_ev;
   if (timed) { bt.e0 = timers->ev[timers->used]; bt.e1 = timers->ev[timers->used + 1]; }
-  if (variant >= 0) launch_trailing_update_as(variant, s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
+  if (variant >= 0) launch_trailing_update_as(variant, s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr, P32, P32, ld32);
   else launch_trailing_update(s, C, lda, P, Q, lda, M, K, timed ? &bt : nullptr);
   if (timed && bt.flops > 0.) {
     timers->flops[timers->used / 2] = bt.flops;  // algorithmic flop: 2 K per covered C entry on or below the diagonal
@@ -1118,7 +1119,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
                   FactorTimers *timers) {
   hipStream_t sa = ctx->stream, sb = ctx->stream2;
   hipStream_t sb_prev = sb;
-  bool have_u2 = false;
+  bool have_u2 = false, p32_flip = false;
   long long K0 = 0;
   const long long nbo_fixed = ctx->nbo_override;
   const int variant = ctx->update_variant;
@@ -1157,6 +1158,22 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
       }
     }
     const double *P = A + K0 * lda + kend;  // panel rows kend.., columns K0..kend
+    // mixed precision: ONE fp32 copy of the panel for all the tiles of U1 and of the bulk update (two alternating
+    // buffers: the bulk update of step j still reads its copy while step j + 1 makes the next one; the copy of step
+    // j + 2 is written after U2(j) has been waited for below).  Without it every tile rounds the fp64 operands itself
+    // while it stages them - twice the operand traffic of the fp32 kernel, which is what it waits for.
+    const float *P32 = nullptr;
+    long long ld32 = 0;
+    if (variant == 3 && ctx->p32 && (n - kend) >= U1_F32_ABOVE) {
+      ld32 = (n - kend + 7) / 8 * 8;
+      if (ld32 % 512 == 0) ld32 += 8;
+      if (sizeof(float) * (size_t)ld32 * (size_t)K * 2 <= ctx->p32_bytes) {
+        float *dst = ctx->p32 + (size_t)(p32_flip ? 1 : 0) * (ctx->p32_bytes / sizeof(float) / 2);
+        p32_flip = !p32_flip;
+        launch_convert_panel_f32(sa, P, lda, n - kend, K, dst, ld32);
+        P32 = dst;
+      }
+    }
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
     // U2(j - 1) must be done before anything of step j touches the next block column
     if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
@@ -1164,7 +1181,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     if (variant == 3 && (n - kend) >= U1_F32_ABOVE) {
       // mixed precision: U1 on the fp32 MFMA path like the bulk update (products of fp32-rounded panels, fp64
       // subtraction) while the block column is tall enough for 128 x 128 tiles to fill the chip
-      launch_update_f32(sa, A + kend * lda + kend, lda, P, P, lda, n - kend, next_end - kend, K);
+      launch_update_f32(sa, A + kend * lda + kend, lda, P, P, lda, n - kend, next_end - kend, K, P32, P32, ld32);
     } else if (step && n - kend > 1536) {
       // hand-over to the step tail: the whole trailing matrix, on the chain stream, alone on the chip - the bulk kernel
       timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, n - kend, K, true, variant);
@@ -1193,7 +1210,8 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
         (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       }
       const double *Q = A + K0 * lda + next_end;
-      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant);
+      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant,
+                 P32 ? P32 + (next_end - kend) : nullptr, ld32);
       (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;
     } else {

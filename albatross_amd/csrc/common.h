@@ -84,6 +84,9 @@ struct agp_context {
   // ... and one cached exact-covariance buffer of the mixed-precision fit (its CG refinement multiplies with K itself)
   double *pool_K = nullptr;
   size_t pool_K_bytes = 0;
+  // mixed-precision fits: two alternating fp32 copies of the current panel (rows x 512 each)
+  float *p32 = nullptr;
+  size_t p32_bytes = 0;
   // ... and one cached block of a fit's small buffers (agp_fit::aux_base)
   double *pool_aux = nullptr;
   size_t pool_aux_bytes = 0;
@@ -295,9 +298,12 @@ struct BulkTiming {
 };
 void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
                                const double *Q, long long ldp, long long M, long long K,
-                               BulkTiming *timing = nullptr);
+                               BulkTiming *timing = nullptr, const float *P32 = nullptr, const float *Q32 = nullptr,
+                               long long ld32 = 0);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
 void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P, const double *Q, long long ldp, long long M,
-                       long long N, long long K);
+                       long long N, long long K, const float *P32 = nullptr, const float *Q32 = nullptr, long long ld32 = 0);
+// P32 (rows x K, ld32) = (float) P: the fp32 copy of one outer step's panel for the fp32-product kernels
+void launch_convert_panel_f32(hipStream_t s, const double *P, long long ldp, long long rows, long long K, float *P32, long long ld32);
 }  // namespace agp

@@ -700,9 +700,16 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
   AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
   AGP_HIP_CHECK(ctx, hipEventCreate(&e1));
   int st = AGP_OK;
+  float *dP32 = nullptr;  // variant 4: the fp32-product kernel on an fp32 copy of the panel
+  const long long ld32 = (M + 7) / 8 * 8 + 8;
+  if (variant == 4) {
+    AGP_HIP_CHECK(ctx, hipMalloc(&dP32, sizeof(float) * (size_t)ld32 * (size_t)K));
+    launch_convert_panel_f32(ctx->stream, dP, ld, M, K, dP32, ld32);
+  }
   for (int r = -2; r < reps && st == AGP_OK; ++r) {
     if (r == 0) AGP_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
-    launch_trailing_update_as(variant, ctx->stream, dC, ld, dP, dP, ld, M, K);
+    if (variant == 4) launch_trailing_update_as(3, ctx->stream, dC, ld, dP, dP, ld, M, K, nullptr, dP32, dP32, ld32);
+    else launch_trailing_update_as(variant, ctx->stream, dC, ld, dP, dP, ld, M, K);
   }
   AGP_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
   AGP_HIP_CHECK(ctx, hipEventSynchronize(e1));
@@ -711,6 +718,7 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
   *ms_out = (double)ms / reps;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(dC); (void)hipFree(dP);
+  if (dP32) (void)hipFree(dP32);
   return st;
 }
 

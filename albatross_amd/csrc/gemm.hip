@@ -127,6 +127,45 @@ __device__ __forceinline__ void store_chunk_f32(float *__restrict__ Ls, const do
   dst[1] = make_float4(sg * (float)r[4], sg * (float)r[5], sg * (float)r[6], sg * (float)r[7]);
 }
 
+// chunk (128 rows x 16 k) of an fp32 panel copy: thread t -> k = t >> 4, rows (t & 15) * 8 .. + 7
+__device__ __forceinline__ void load_chunk_p32(const float *__restrict__ P, long long ld, long long row0, long long k0, float4 &r0,
+                                               float4 &r1) {
+  const int t = threadIdx.x;
+  const float *p = P + (row0 + (t & 15) * 8) + (k0 + (t >> 4)) * ld;
+  r0 = *reinterpret_cast<const float4 *>(p);
+  r1 = *reinterpret_cast<const float4 *>(p + 4);
+}
+template <bool NEGATE>
+__device__ __forceinline__ void store_chunk_p32(float *__restrict__ Ls, const float4 r0, const float4 r1) {
+  const int t = threadIdx.x;
+  float4 *dst = reinterpret_cast<float4 *>(Ls + (t >> 4) * GLD + (t & 15) * 8);
+  if (NEGATE) {
+    dst[0] = make_float4(-r0.x, -r0.y, -r0.z, -r0.w);
+    dst[1] = make_float4(-r1.x, -r1.y, -r1.z, -r1.w);
+  } else {
+    dst[0] = r0;
+    dst[1] = r1;
+  }
+}
+
+// P32 (rows x K, ld32) = (float) P (rows x K, ldp): the panel of one outer step, once, for all the tiles that read it
+__global__ __launch_bounds__(256) void convert_panel_f32_kernel(const double *__restrict__ P, long long ldp, long long rows, float *__restrict__ P32,
+                                                                long long ld32) {
+  const long long r = ((long long)blockIdx.x * 256 + threadIdx.x) * 2, k = blockIdx.y;
+  if (r + 1 < rows) {
+    const double2 v = *reinterpret_cast<const double2 *>(P + r + k * ldp);
+    *reinterpret_cast<float2 *>(P32 + r + k * ld32) = make_float2((float)v.x, (float)v.y);
+  } else if (r < rows) {
+    P32[r + k * ld32] = (float)P[r + k * ldp];
+  }
+}
+
+void launch_convert_panel_f32(hipStream_t s, const double *P, long long ldp, long long rows, long long K, float *P32, long long ld32) {
+  if (rows <= 0 || K <= 0) return;
+  hipLaunchKernelGGL(convert_panel_f32_kernel, dim3((unsigned)((rows + 511) / 512), (unsigned)K), dim3(256), 0, s, P, ldp, rows, P32, ld32);
+}
+
+template <bool P32>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_f32_kernel(GemmArgs g) {
   __shared__ float lds[2 * 2 * GK * GLD];
   int bi, bj;
@@ -151,13 +190,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_f32_kernel(Ge
     // epilogue only adds and stores (gemm_nt_sub_tile_cpf; here the fp32 accumulators leave room for all of C) - at the
     // fp32 MFMA's rate the K loop of a tile is 4x shorter and the read-modify-write behind it weighed 4x as much
     const long long nq = nk / 8;
-    load_chunk_interior<false>(g.A, g.lda, i0, 0, ra);
-    load_chunk_interior<false>(g.B, g.ldb, j0, 0, rb);
-    store_chunk_f32<false>(lds, ra);
-    store_chunk_f32<true>(lds + GK * GLD, rb);
+    constexpr bool p32 = P32;
+    float4 a32_0 = {}, a32_1 = {}, b32_0 = {}, b32_1 = {};
+    if constexpr (p32) {
+      load_chunk_p32(g.A32, g.ld32, i0, 0, a32_0, a32_1);
+      load_chunk_p32(g.B32, g.ld32, j0, 0, b32_0, b32_1);
+      store_chunk_p32<false>(lds, a32_0, a32_1);
+      store_chunk_p32<true>(lds + GK * GLD, b32_0, b32_1);
+    } else {
+      load_chunk_interior<false>(g.A, g.lda, i0, 0, ra);
+      load_chunk_interior<false>(g.B, g.ldb, j0, 0, rb);
+      store_chunk_f32<false>(lds, ra);
+      store_chunk_f32<true>(lds + GK * GLD, rb);
+    }
     __syncthreads();
     double *const cbase = g.C + (i0 + 64 * wr + ln) + (j0 + 64 * wc + 4 * lg) * g.ldc;
-    constexpr int NPRE = 7;  // parts of C fetched during the loop (all eight would need 4 more registers than a wave has)
+    constexpr int NPRE = 7;  // parts of C fetched during the loop (all eight: 4 more registers than a wave has with fp64 staging; no gain with fp32 staging)
     double cpre[4][4][4];  // [tj][ti][r]
     long long kc = 0;
 #pragma unroll
@@ -170,8 +218,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_f32_kernel(Ge
         const float *Bs = As + GK * GLD;
         const bool more = kc + 1 < nk;
         if (more) {
-          load_chunk_interior<false>(g.A, g.lda, i0, (kc + 1) * GK, ra);
-          load_chunk_interior<false>(g.B, g.ldb, j0, (kc + 1) * GK, rb);
+          if constexpr (p32) {
+            load_chunk_p32(g.A32, g.ld32, i0, (kc + 1) * GK, a32_0, a32_1);
+            load_chunk_p32(g.B32, g.ld32, j0, (kc + 1) * GK, b32_0, b32_1);
+          } else {
+            load_chunk_interior<false>(g.A, g.lda, i0, (kc + 1) * GK, ra);
+            load_chunk_interior<false>(g.B, g.ldb, j0, (kc + 1) * GK, rb);
+          }
         }
         if (first && p < NPRE) {
           first = false;
@@ -198,8 +251,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_f32_kernel(Ge
         }
         if (more) {
           float *An = lds + (cur ^ 1) * (2 * GK * GLD);
-          store_chunk_f32<false>(An, ra);
-          store_chunk_f32<true>(An + GK * GLD, rb);
+          if constexpr (p32) {
+            store_chunk_p32<false>(An, a32_0, a32_1);
+            store_chunk_p32<true>(An + GK * GLD, b32_0, b32_1);
+          } else {
+            store_chunk_f32<false>(An, ra);
+            store_chunk_f32<true>(An + GK * GLD, rb);
+          }
         }
         __syncthreads();
       }
@@ -481,17 +539,20 @@ static double lower_entries(long long M, int ntr, long long count) {
 
 // variant 0: fp64 MFMA kernel, 3: fp32-product MFMA kernel (mixed precision)
 void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
-                               const double *Q, long long ldp, long long M, long long K, BulkTiming *timing) {
+                               const double *Q, long long ldp, long long M, long long K, BulkTiming *timing, const float *P32,
+                               const float *Q32, long long ld32) {
   if (timing) timing->flops = 0.;
   if (M <= 0 || K <= 0) return;
   GemmArgs g;
   g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = Q; g.ldb = ldp;
+  g.A32 = P32; g.B32 = Q32; g.ld32 = ld32;
   g.M = M; g.N = M; g.K = K; g.tri = 1;
   g.ntr = (int)((M + GT - 1) / GT);
   g.ntc = g.ntr;
   const long long tiles = count_tiles(g.ntr, g.ntc, 1);
   if (variant == 3) {
-    hipLaunchKernelGGL(trailing_update_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+    if (g.A32) hipLaunchKernelGGL(trailing_update_f32_kernel<true>, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+    else hipLaunchKernelGGL(trailing_update_f32_kernel<false>, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
     return;
   }
   // Tail split: a launch of T tiles runs floor(T / slots) full rounds of 128 x 128 workgroups (slots = 2 per
@@ -537,16 +598,19 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
 // (trailing_update_f32_kernel), the result subtracted from the fp64 matrix: the next-block-column update U1 of the
 // mixed-precision factorisation (agp_fit_create_mixed)
 void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P, const double *Q, long long ldp, long long M,
-                       long long N, long long K) {
+                       long long N, long long K, const float *P32, const float *Q32, long long ld32) {
   if (M <= 0 || N <= 0 || K <= 0) return;
   GemmArgs g;
   g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = Q; g.ldb = ldp;
+  g.A32 = P32; g.B32 = Q32; g.ld32 = ld32;
   g.M = M; g.N = N; g.K = K; g.tri = 1;
   g.ntr = (int)((M + GT - 1) / GT);
   g.ntc = (int)((N + GT - 1) / GT);
   if (g.ntc > g.ntr) g.ntc = g.ntr;
   const long long tiles = count_tiles(g.ntr, g.ntc, 1);
-  if (tiles > 0) hipLaunchKernelGGL(trailing_update_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+  if (tiles <= 0) return;
+  if (g.A32) hipLaunchKernelGGL(trailing_update_f32_kernel<true>, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+  else hipLaunchKernelGGL(trailing_update_f32_kernel<false>, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
 }
 
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,

@@ -40,6 +40,10 @@ struct GemmArgs {
   // lower-tile order) as 64 x 64 quadrants, the others the tiles 0 .. small_first - 1 whole
   long long small_first = 0;
   int small_count = 0;
+  // trailing_update_f32_kernel only: fp32 copies of the two operands (element (row, k) at X32[row + k * ld32]; made once per
+  // panel by launch_convert_panel_f32) - nullptr: the kernel rounds the fp64 operands itself while it stages them
+  const float *A32 = nullptr, *B32 = nullptr;
+  long long ld32 = 0;
 };
 
 
