@@ -254,6 +254,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->pool_A) (void)hipFree(ctx->pool_A);
   if (ctx->pool_K) (void)hipFree(ctx->pool_K);
   if (ctx->p32) (void)hipFree(ctx->p32);
+  if (ctx->pool_L32) (void)hipFree(ctx->pool_L32);
   if (ctx->pool_aux) (void)hipFree(ctx->pool_aux);
   if (ctx->pool_shard) (void)hipFree(ctx->pool_shard);
   if (ctx->pool_sparse) (void)hipFree(ctx->pool_sparse);
@@ -754,26 +755,30 @@ void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long lo
 // (solve.hip) ----------------
 // z <- L^-1 z, right-looking: x_B = W_B z_B (in place), z[below] -= L[below, B] x_B: two mat-vec launches per BW rows
 // instead of one fused launch per 128 (the chain is launch-latency-bound).  partial: n doubles of scratch.
+// A32 (optional): an fp32 copy of the factor's lower triangle (same leading dimension) for the products with the rows
+// below / the columns left of a diagonal block - half the bytes of sweeps that are bound by them; for a PRECONDITIONER
 static void forward_solve_vec_wide(hipStream_t s, const double *A, long long n, long long lda, const double *W, long long BW,
-                                   double *z, double *partial) {
+                                   double *z, double *partial, const float *A32 = nullptr) {
   const long long nb = n / BW;
   for (long long b = 0; b < nb; ++b) {
     const long long k0 = b * BW, below = n - k0 - BW;
     // (x_B goes through `partial` first: the kernel may not overwrite z_B while other workgroups still read it)
     launch_tall_matvec(s, W + b * BW * BW, BW, BW, BW, z + k0, 1.0, 0.0, nullptr, partial);
     (void)hipMemcpyAsync(z + k0, partial, sizeof(double) * (size_t)BW, hipMemcpyDeviceToDevice, s);
-    if (below > 0) launch_tall_matvec(s, A + k0 * lda + k0 + BW, lda, below, BW, z + k0, -1.0, 1.0, z + k0 + BW, z + k0 + BW);
+    if (below > 0 && A32) launch_tall_matvec_f32(s, A32 + k0 * lda + k0 + BW, lda, below, BW, z + k0, -1.0, 1.0, z + k0 + BW, z + k0 + BW);
+    else if (below > 0) launch_tall_matvec(s, A + k0 * lda + k0 + BW, lda, below, BW, z + k0, -1.0, 1.0, z + k0 + BW, z + k0 + BW);
   }
 }
 
 // z <- L^-T z with the same inverses (the loop of backward_solve_vec_any); xs: n doubles of scratch
 static void backward_solve_vec_wide(hipStream_t s, const double *A, long long n, long long lda, const double *W, long long BW,
-                                    double *z, double *xs) {
+                                    double *z, double *xs, const float *A32 = nullptr) {
   const long long nb = n / BW;
   for (long long b = nb - 1; b >= 0; --b) {
     const long long k0 = b * BW;
     launch_colvec_dot(s, W + b * BW * BW, BW, BW, BW, z + k0, 1.0, 0.0, nullptr, xs + k0);
-    if (k0 > 0) launch_colvec_dot(s, A + k0, lda, BW, k0, xs + k0, -1.0, 1.0, z, z);
+    if (k0 > 0 && A32) launch_colvec_dot_f32(s, A32 + k0, lda, BW, k0, xs + k0, -1.0, 1.0, z, z);
+    else if (k0 > 0) launch_colvec_dot(s, A + k0, lda, BW, k0, xs + k0, -1.0, 1.0, z, z);
   }
   (void)hipMemcpyAsync(z, xs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }
@@ -1072,11 +1077,25 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
     invert_wide_blocks(s, fit->A, n, lda, fit->invd, BW, Wwide);
   }
   struct FreeW { double *p; ~FreeW() { if (p) (void)hipFree(p); } } free_w{Wwide};
+  // The preconditioner M = L L^T is applied eight-odd times and each application streams L twice; it does not have to
+  // be exact - L itself comes from fp32-rounded products -, so the sweeps read an fp32 COPY of L's off-diagonal blocks
+  // (the inverted diagonal blocks stay fp64): half the bytes, kept in the context between fits.
+  float *L32 = nullptr;
+  if (BW) {
+    const size_t want = sizeof(float) * (size_t)lda * (size_t)n;
+    if (ctx->pool_L32 && ctx->pool_L32_bytes != want) { (void)hipFree(ctx->pool_L32); ctx->pool_L32 = nullptr; ctx->pool_L32_bytes = 0; }
+    if (!ctx->pool_L32) {
+      if (hipMalloc(&ctx->pool_L32, want) == hipSuccess) ctx->pool_L32_bytes = want;
+      else { (void)hipGetLastError(); ctx->pool_L32 = nullptr; }
+    }
+    L32 = ctx->pool_L32;
+    if (L32) launch_convert_lower_f32(s, fit->A, lda, n, L32);
+  }
   auto precondition = [&](const double *in, double *outv) {
     (void)hipMemcpyAsync(outv, in, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
     if (BW) {
-      forward_solve_vec_wide(s, fit->A, n, lda, Wwide, BW, outv, ctx->ws_aux);
-      backward_solve_vec_wide(s, fit->A, n, lda, Wwide, BW, outv, ctx->ws_aux);
+      forward_solve_vec_wide(s, fit->A, n, lda, Wwide, BW, outv, ctx->ws_aux, L32);
+      backward_solve_vec_wide(s, fit->A, n, lda, Wwide, BW, outv, ctx->ws_aux, L32);
     } else {
       forward_solve_vec(s, fit->A, n, lda, Wfwd, outv, ctx->ws_aux);
       backward_solve_vec(s, fit->A, n, lda, fit->winv, outv, ctx->ws_aux);

@@ -36,6 +36,11 @@ void launch_contract_combinations(hipStream_t s, const double *K, long long ldk,
                                   const long long *yoff, const double *yc, long long nb, bool symmetric, double *out, long long ldo);
 void launch_tall_matvec(hipStream_t s, const double *W, long long ld, long long rows, long long ncols, const double *x, double alpha,
                         double beta, const double *base, double *out);
+void launch_tall_matvec_f32(hipStream_t s, const float *W, long long ld, long long rows, long long ncols, const double *x, double alpha,
+                            double beta, const double *base, double *out);
+void launch_colvec_dot_f32(hipStream_t s, const float *W, long long ld, long long m, long long n, const double *v,
+                           double alpha, double beta, const double *base, double *out);
+void launch_convert_lower_f32(hipStream_t s, const double *L, long long ld, long long n, float *L32);
 void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,
                        double alpha, double beta, const double *base, double *out);
 void launch_colvec_dot_strided(hipStream_t s, const double *W, long long ld, long long stride_W, long long m, long long n,

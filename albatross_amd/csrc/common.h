@@ -87,6 +87,9 @@ struct agp_context {
   // mixed-precision fits: two alternating fp32 copies of the current panel (rows x 512 each)
   float *p32 = nullptr;
   size_t p32_bytes = 0;
+  // ... and the fp32 copy of the factor that preconditions their refinement
+  float *pool_L32 = nullptr;
+  size_t pool_L32_bytes = 0;
   // ... and one cached block of a fit's small buffers (agp_fit::aux_base)
   double *pool_aux = nullptr;
   size_t pool_aux_bytes = 0;

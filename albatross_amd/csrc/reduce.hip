@@ -289,7 +289,8 @@ void launch_contract_combinations(hipStream_t s, const double *K, long long ldk,
 // owns 64 rows (lane = row: every load is a 512-B segment of one column), its 4 waves split the columns and keep 8
 // loads in flight each; fixed-order reduction through LDS.  The right-looking vector substitutions are sequences of
 // such products (rows below x 512).
-__global__ __launch_bounds__(256) void tall_matvec_kernel(const double *__restrict__ W, long long ld, long long rows, int ncols,
+template <typename T>  // T: the matrix's element type (double; float: the fp32 copy of a factor as a preconditioner)
+__global__ __launch_bounds__(256) void tall_matvec_kernel(const T *__restrict__ W, long long ld, long long rows, int ncols,
                                                           const double *__restrict__ x, double alpha, double beta,
                                                           const double *base, double *out) {
   __shared__ double xs[2048], red[4][64];
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void tall_matvec_kernel(const double *__restri
   const int per = (ncols + 3) / 4, c0 = wave * per, c1 = (c0 + per < ncols) ? c0 + per : ncols;
   double acc = 0.;
   if (i < rows) {
-    const double *p = W + i + (long long)c0 * ld;
+    const T *p = W + i + (long long)c0 * ld;
     int c = c0;
     for (; c + 8 <= c1; c += 8, p += 8 * ld) {
       const double v0 = p[0], v1 = p[ld], v2 = p[2 * ld], v3 = p[3 * ld], v4 = p[4 * ld], v5 = p[5 * ld], v6 = p[6 * ld], v7 = p[7 * ld];
@@ -320,13 +321,20 @@ __global__ __launch_bounds__(256) void tall_matvec_kernel(const double *__restri
 void launch_tall_matvec(hipStream_t s, const double *W, long long ld, long long rows, long long ncols, const double *x, double alpha,
                         double beta, const double *base, double *out) {
   if (rows <= 0 || ncols <= 0 || ncols > 2048) return;
-  hipLaunchKernelGGL(tall_matvec_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, W, ld, rows, (int)ncols, x, alpha, beta,
+  hipLaunchKernelGGL(tall_matvec_kernel<double>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, W, ld, rows, (int)ncols, x, alpha, beta,
+                     base, out);
+}
+void launch_tall_matvec_f32(hipStream_t s, const float *W, long long ld, long long rows, long long ncols, const double *x, double alpha,
+                            double beta, const double *base, double *out) {
+  if (rows <= 0 || ncols <= 0 || ncols > 2048) return;
+  hipLaunchKernelGGL(tall_matvec_kernel<float>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, W, ld, rows, (int)ncols, x, alpha, beta,
                      base, out);
 }
 
 // out[j] = alpha * sum_i W[i, j] v[i] + beta * base[j]   (one workgroup per column)
 // (blockIdx.y = batch entry; the strides are 0 for a single problem)
-__global__ __launch_bounds__(256) void colvec_dot_kernel(const double *__restrict__ W, long long ld, long long m,
+template <typename T>
+__global__ __launch_bounds__(256) void colvec_dot_kernel(const T *__restrict__ W, long long ld, long long m,
                                                          const double *__restrict__ v, double alpha, double beta,
                                                          const double *base, double *out, long long stride_W,
                                                          long long stride_v) {
@@ -336,9 +344,9 @@ __global__ __launch_bounds__(256) void colvec_dot_kernel(const double *__restric
   v += (long long)blockIdx.y * stride_v;
   if (base) base += (long long)blockIdx.y * stride_v;
   out += (long long)blockIdx.y * stride_v;
-  const double *w = W + j * ld;
+  const T *w = W + j * ld;
   double acc = 0.;
-  for (long long i = threadIdx.x; i < m; i += 256) acc += w[i] * v[i];
+  for (long long i = threadIdx.x; i < m; i += 256) acc += (double)w[i] * v[i];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -349,7 +357,34 @@ __global__ __launch_bounds__(256) void colvec_dot_kernel(const double *__restric
 void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m, long long n, const double *v,
                        double alpha, double beta, const double *base, double *out) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(colvec_dot_kernel, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out, 0LL, 0LL);
+  hipLaunchKernelGGL(colvec_dot_kernel<double>, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out, 0LL, 0LL);
+}
+void launch_colvec_dot_f32(hipStream_t s, const float *W, long long ld, long long m, long long n, const double *v,
+                           double alpha, double beta, const double *base, double *out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(colvec_dot_kernel<float>, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out, 0LL, 0LL);
+}
+
+// L32 (lower triangle incl. diagonal, ld) = (float) L: the fp32 copy of a factor that preconditions the refinement of a
+// mixed-precision fit (api.hip: refine_information)
+__global__ __launch_bounds__(256) void convert_lower_f32_kernel(const double *__restrict__ L, long long ld, long long n, float *__restrict__ L32) {
+  const long long j = blockIdx.y;
+  const long long i = j / 2 * 2 + ((long long)blockIdx.x * 256 + threadIdx.x) * 2;  // pairs from the even row at or above the diagonal
+  if (i + 1 < n) {
+    const double2 v = *reinterpret_cast<const double2 *>(L + i + j * ld);
+    *reinterpret_cast<float2 *>(L32 + i + j * ld) = make_float2((float)v.x, (float)v.y);
+  } else if (i < n) {
+    L32[i + j * ld] = (float)L[i + j * ld];
+  }
+}
+void launch_convert_lower_f32(hipStream_t s, const double *L, long long ld, long long n, float *L32) {
+  if (n <= 0) return;
+  // (one launch per 2048 columns keeps the idle blocks above the diagonal few)
+  for (long long j0 = 0; j0 < n; j0 += 2048) {
+    const long long cols = (n - j0 < 2048) ? n - j0 : 2048, rows = n - j0 / 2 * 2;
+    hipLaunchKernelGGL(convert_lower_f32_kernel, dim3((unsigned)((rows + 511) / 512), (unsigned)cols), dim3(256), 0, s, L + j0 * ld + j0 / 2 * 2,
+                       ld, n - j0 / 2 * 2, L32 + j0 * ld + j0 / 2 * 2);
+  }
 }
 
 // the same for `count` problems: W_b = W + b * stride_W; v, base and out are slices of vectors stride_v apart
@@ -357,7 +392,7 @@ void launch_colvec_dot_strided(hipStream_t s, const double *W, long long ld, lon
                                const double *v, long long stride_v, double alpha, double beta, const double *base, double *out,
                                long long count) {
   if (n <= 0 || count <= 0) return;
-  hipLaunchKernelGGL(colvec_dot_kernel, dim3((unsigned)n, (unsigned)count), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out,
+  hipLaunchKernelGGL(colvec_dot_kernel<double>, dim3((unsigned)n, (unsigned)count), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out,
                      stride_W, stride_v);
 }
 
