@@ -620,11 +620,20 @@ AGP_DEBUG_API int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t
   AGP_HIP_CHECK(ctx, hipMemcpy(dC, C, cb, hipMemcpyHostToDevice));
   AGP_HIP_CHECK(ctx, hipMemcpy(dP, P, pb, hipMemcpyHostToDevice));
   int st = AGP_OK;
-  launch_trailing_update_as(variant, ctx->stream, dC, ldc, dP, dP, ldp, M, K);
+  float *dP32 = nullptr;
+  if (variant == 13) {  // the fp32-product kernel (3) reading an fp32 copy of the panel, as the mixed fit runs it
+    const long long ld32 = (M + 7) / 8 * 8 + 8;
+    AGP_HIP_CHECK(ctx, hipMalloc(&dP32, sizeof(float) * (size_t)ld32 * (size_t)K));
+    launch_convert_panel_f32(ctx->stream, dP, ldp, M, K, dP32, ld32);
+    launch_trailing_update_as(3, ctx->stream, dC, ldc, dP, dP, ldp, M, K, nullptr, dP32, dP32, ld32);
+  } else {
+    launch_trailing_update_as(variant, ctx->stream, dC, ldc, dP, dP, ldp, M, K);
+  }
   AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   AGP_HIP_CHECK(ctx, hipGetLastError());
   AGP_HIP_CHECK(ctx, hipMemcpy(C, dC, cb, hipMemcpyDeviceToHost));
   (void)hipFree(dC); (void)hipFree(dP);
+  if (dP32) (void)hipFree(dP32);
   return st;
 }
 

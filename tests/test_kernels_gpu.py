@@ -89,6 +89,42 @@ def test_gemm_nt_sub(ctx, dbg, M, N, K, tri, akm, bkm):
     assert np.array_equal(Cd[M:], np.zeros((ldc - M, N)))  # padding rows untouched
 
 
+@pytest.mark.parametrize("M,N,K,tri,akm,bkm", [
+    # >= 512 tiles of 128 x 128 AND at least 8 chunks of K: the interior tiles add C into their accumulators during the K
+    # loop and only store behind it (gemm_nt_sub_tile_cpf), the edge tiles keep the read-modify-write epilogue; every
+    # operand layout; K = 136 is not a whole number of chunks and keeps all tiles on the old path
+    (3000, 2900, 160, 0, 0, 0), (3000, 2900, 160, 0, 0, 1), (3000, 2900, 160, 0, 1, 0), (3000, 2900, 160, 0, 1, 1),
+    (4500, 4500, 144, 1, 0, 0), (4480, 4480, 256, 1, 1, 1), (3000, 2900, 136, 0, 0, 1),
+])
+def test_gemm_nt_sub_prefetching_tiles(ctx, dbg, M, N, K, tri, akm, bkm):
+    test_gemm_nt_sub(ctx, dbg, M, N, K, tri, akm, bkm)
+
+
+@pytest.mark.parametrize("variant", [0, 3, 13])
+@pytest.mark.parametrize("M,K", [(5900, 128), (6016, 512)])
+def test_trailing_update_large_tiles(ctx, dbg, M, K, variant):
+    """Bulk updates of more than two rounds of 128 x 128 tiles: full rounds of prefetching tiles, the tiles of the partial
+    round as 64 x 64 quadrants at the head of the same launch, ragged edge tiles (M = 5900) on the old path.  Variant 0:
+    fp64 MFMA; 3: fp32 products of operands rounded while staged; 13: fp32 products of an fp32 copy of the panel
+    (launch_convert_panel_f32) - the two must agree bit for bit."""
+    rng = np.random.default_rng(M + K)
+    ldc, ldp = M + 8, M + 10
+    Cm = np.asfortranarray(rng.standard_normal((ldc, M)))
+    P = np.asfortranarray(rng.standard_normal((ldp, K)))
+    want = Cm[:M] - P[:M] @ P[:M].T
+    got = Cm.copy(order="F")
+    assert dbg.agp_debug_trailing_update(ctx._h, _p(got), ldc, _p(P), ldp, M, K, variant) == 0
+    low = np.tril_indices(M)
+    scale = np.abs(P[:M]).sum(axis=1).max() ** 2
+    tol = 1e-14 if variant == 0 else 2e-7
+    assert np.abs(got[:M][low] - want[low]).max() <= tol * scale
+    assert np.array_equal(got[M:], Cm[M:])  # padding rows untouched
+    if variant == 13:
+        ref = Cm.copy(order="F")
+        assert dbg.agp_debug_trailing_update(ctx._h, _p(ref), ldc, _p(P), ldp, M, K, 3) == 0
+        assert np.array_equal(ref[:M][low], got[:M][low])
+
+
 @pytest.mark.parametrize("variant", [0, 2, 4, 5])
 @pytest.mark.parametrize("M,K", [(256, 16), (640, 128), (1000, 256), (1418, 512), (130, 32), (4300, 64)])
 def test_trailing_update_variants(ctx, dbg, M, K, variant):
