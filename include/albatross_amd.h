@@ -197,7 +197,10 @@ AGP_API int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_feat
  * absolute, i.e. outside the 1e-6 N bar of the fp64 path) and variances 1e-4
  * relative - use agp_nll / an fp64 fit where the likelihood or the variances
  * matter.  The reference has no reduced-precision path; this one exists for
- * problems where one fp64 factorisation is too slow (N >= 32768). */
+ * problems where one fp64 factorisation is too slow (N >= 32768).  Device memory
+ * next to the factor (kept in the context between mixed fits): the exact
+ * covariance (8 N^2 B), an fp32 copy of the factor for the preconditioner
+ * (4 N^2 B) and two fp32 panel copies (2 x 2 KB x N). */
 AGP_API int agp_fit_create_mixed(agp_context *ctx, const agp_kernel *k, const agp_features *x,
                          const double *y, const double *y_var, int max_iterations,
                          double tolerance, agp_fit **out, double *information,
