@@ -309,7 +309,10 @@ struct HipShardOps : ShardOps {
     if (decided) return;
     decided = true;
     if ((device_pacing || allow_device) && !ctx->shard_probe_ok) {  // the queues are the context's own: the answer holds for its lifetime
-      const bool fine = probe_queues();
+      // (processes that share one GPU are time-sliced: a healthy gate can miss the short deadline while its producer's
+      // process is not running - one more round with a long deadline before the queues are declared aliased; on a GPU of
+      // its own the first round passes in ~40 us)
+      const bool fine = probe_queues(25000000ull) || probe_queues(200000000ull);
       if (fine) ctx->shard_probe_ok = true;
       else { ctx->shard_host_pacing = 1; device_pacing = allow_device = false; }
     }
@@ -325,11 +328,10 @@ struct HipShardOps : ShardOps {
   // hardware queues (GPU_MAX_HW_QUEUES) and serialises streams that share one.  One round of gates and signals between
   // every pair of queues the schedule pairs up, with a short deadline: if any gate runs into it, the queues alias and
   // this fit is paced by the host.  ~40 us when all is well.
-  bool probe_queues() {
+  bool probe_queues(const unsigned long long short_ticks /* 100 MHz: 25000000 = 250 ms */) {
     unsigned long long *pf = flags + EV_COUNT;
     int *fail = ctx->d_flags + 3;
     unsigned long long &seq = ctx->shard_probe_seq;
-    const unsigned long long short_ticks = 25000000ull;  // 250 ms (processes that share the GPU are time-sliced)
     (void)hipMemsetAsync(fail, 0, sizeof(int), sq[QC]);
     if (hipStreamSynchronize(sq[QC]) != hipSuccess) return false;
     const int pairs[4][2] = {{QC, QP}, {QC, QB}, {QP, QC}, {QB, QC}};  // {consumer, producer}
