@@ -107,11 +107,21 @@ struct StageTimer {
 // C (m x m, lower tiles) -= W W^T for W m x n with n >> m: 136 tiles of 128 x 128 at m = 2048 would leave most of the
 // chip idle behind one very long K loop, so the columns are cut into `slab_count` equal slices that run as one batched
 // launch into separate m x m slabs, summed in a fixed order afterwards (deterministic; no atomics).
+// The slice count is the one (up to 32, slices of at least 4096 columns) whose tiles fill whole rounds of the chip's 512
+// workgroup slots best: 6 slices of the 136 tiles at m = 2048 were 1.6 rounds (49 TFLOP/s), 15 are 3.98.
 static long long syrk_slabs(long long m, long long n) {
   const long long tr = (m + 127) / 128, tiles = tr * (tr + 1) / 2;
-  long long s = (768 + tiles - 1) / tiles;
-  while (s > 1 && n / s < 4096) --s;
-  return s < 1 ? 1 : (s > 32 ? 32 : s);
+  constexpr long long slots = 512;
+  long long best = 1;
+  double best_fill = 0.;
+  for (long long s = 1; s <= 32; ++s) {
+    if (s > 1 && n / s < 4096) break;
+    const long long t = tiles * s, rounds = (t + slots - 1) / slots;
+    // (a launch of less than one round is as long as one tile: prefer more slices until a round is full)
+    const double fill = (double)t / (double)(rounds * slots) * (rounds >= 2 ? 1. : 0.5);
+    if (fill > best_fill + 1e-9) { best_fill = fill; best = s; }
+  }
+  return best;
 }
 
 __global__ __launch_bounds__(256) void sum_slabs_kernel(double *C, const double *__restrict__ slabs, long long elems, long long count) {
