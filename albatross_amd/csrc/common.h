@@ -201,6 +201,8 @@ struct agp_fit {
 namespace agp {
 
 // ---- launchers implemented in the .hip files ----
+bool launch_gram_blocks(hipStream_t s, const DevProgram *host_program, const FeatView &X, long long rows, long long count,
+                        double *out, long long ld, long long stride, const double *diag_add, int *nan_flag);
 void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y,
                  bool symmetric, bool lower_only, double *out, long long ld,
                  const double *diag_add, int *nan_flag, const DevProgram *host_program = nullptr);

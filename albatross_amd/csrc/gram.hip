@@ -179,9 +179,18 @@ __device__ __forceinline__ double radial_fast(double s2, const FastParams &fp) {
 template <int DIMP, int OP>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_fast_kernel(FastParams fp, FeatView X, FeatView Y, int lower_only,
                                                                  double *out, long long ld, const double *diag_add,
-                                                                 int *nan_flag) {
+                                                                 int *nan_flag, long long blk_rows, long long blk_stride) {
   __shared__ double xs[DIMP][TM], ys[DIMP][TN];
   __shared__ long long xid[TM], yid[TN];
+  if (blk_rows > 0) {  // blockIdx.z = one diagonal block of a block-diagonal Gram matrix (launch_gram_blocks)
+    const long long z = blockIdx.z;
+    X.coords += z * blk_rows * X.dim; Y.coords += z * blk_rows * Y.dim;
+    if (X.ids) X.ids += z * blk_rows;
+    if (Y.ids) Y.ids += z * blk_rows;
+    X.n = Y.n = blk_rows;
+    out += z * blk_stride;
+    if (diag_add) diag_add += z * blk_rows;
+  }
   const long long row0 = (long long)blockIdx.x * TM;
   const long long col0 = (long long)blockIdx.y * TN;
   if (lower_only && col0 > row0 + TM - 1) return;
@@ -280,21 +289,23 @@ static bool match_fast(const DevProgram &H, FastParams *fp, int *op) {
 
 template <int DIMP>
 static bool launch_gram_fast_t(hipStream_t s, const FastParams &fp, int op, const FeatView &X, const FeatView &Y,
-                               bool lower_only, double *out, long long ld, const double *diag_add, int *nan_flag) {
-  dim3 grid((unsigned)((X.n + TM - 1) / TM), (unsigned)((Y.n + TN - 1) / TN)), block(GRAM_THREADS);
+                               bool lower_only, double *out, long long ld, const double *diag_add, int *nan_flag,
+                               long long blk_rows = 0, long long blk_stride = 0, long long blk_count = 1) {
+  const long long xn = blk_rows > 0 ? blk_rows : X.n, yn = blk_rows > 0 ? blk_rows : Y.n;
+  dim3 grid((unsigned)((xn + TM - 1) / TM), (unsigned)((yn + TN - 1) / TN), (unsigned)blk_count), block(GRAM_THREADS);
   const int lo = lower_only ? 1 : 0;
   switch (op) {
   case AGP_OP_SQUARED_EXPONENTIAL:
-    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_SQUARED_EXPONENTIAL>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag);
+    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_SQUARED_EXPONENTIAL>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag, blk_rows, blk_stride);
     return true;
   case AGP_OP_EXPONENTIAL:
-    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_EXPONENTIAL>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag);
+    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_EXPONENTIAL>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag, blk_rows, blk_stride);
     return true;
   case AGP_OP_MATERN32:
-    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_MATERN32>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag);
+    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_MATERN32>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag, blk_rows, blk_stride);
     return true;
   case AGP_OP_MATERN52:
-    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_MATERN52>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag);
+    hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_MATERN52>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag, blk_rows, blk_stride);
     return true;
   default: return false;
   }
@@ -604,6 +615,21 @@ static void launch_gram_t(hipStream_t s, const DevProgram *P, const FeatView &X,
   std::memset(&sop, 0, sizeof(sop));
   hipLaunchKernelGGL((gram_kernel<DIMP, false>), grid, dim3(GRAM_THREADS), 0, s, P, sop, X, Y, symmetric ? 1 : 0,
                      lower_only ? 1 : 0, out, ld, diag_add, nan_flag);
+}
+
+// `count` diagonal blocks of `rows` consecutive features each - block g = the symmetric Gram matrix of features
+// [g rows, (g + 1) rows), lower tiles, written to out + g * stride (leading dimension ld), diag_add likewise - in ONE launch
+// (the A blocks of a sparse fit with equal groups: 512 launches of a few microseconds each were host-bound).  Only for the
+// radial fast-path shapes; returns false otherwise (the caller launches block by block).
+bool launch_gram_blocks(hipStream_t s, const DevProgram *host_program, const FeatView &X, long long rows, long long count,
+                        double *out, long long ld, long long stride, const double *diag_add, int *nan_flag) {
+  if (!host_program || X.dim > 3 || rows <= 0 || count <= 0 || count > 65535 || !sop_enabled()) return false;
+  FastParams fp;
+  int op = 0;
+  if (!match_fast(*host_program, &fp, &op)) return false;
+  if (X.dim == 1) return launch_gram_fast_t<1>(s, fp, op, X, X, true, out, ld, diag_add, nan_flag, rows, stride, count);
+  if (X.dim == 2) return launch_gram_fast_t<2>(s, fp, op, X, X, true, out, ld, diag_add, nan_flag, rows, stride, count);
+  return launch_gram_fast_t<3>(s, fp, op, X, X, true, out, ld, diag_add, nan_flag, rows, stride, count);
 }
 
 void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y, bool symmetric,

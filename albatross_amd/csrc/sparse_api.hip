@@ -234,10 +234,12 @@ int sparse_observations(agp_context *ctx, const agp_kernel *k, const DevProgram 
     double *logsum = w.Pimg + (size_t)stride_I * (size_t)n_groups;
     SPX_HIP(hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)n_groups, s));
     SPX_HIP(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
-    for (int64_t g = 0; g < n_groups; ++g) {
-      const FeatView xg = feature_rows(xm, g * sb, sb);
-      launch_gram(s, dprog, xg, xg, true, true, w.Ag + g * stride_A, lda_b, dvar + g * sb, ctx->d_flags, &k->prog);
-    }
+    // K_gg + target variance, all groups: one launch for the radial fast-path kernels, else one per group
+    if (!launch_gram_blocks(s, &k->prog, xm, sb, n_groups, w.Ag, lda_b, stride_A, dvar, ctx->d_flags))
+      for (int64_t g = 0; g < n_groups; ++g) {
+        const FeatView xg = feature_rows(xm, g * sb, sb);
+        launch_gram(s, dprog, xg, xg, true, true, w.Ag + g * stride_A, lda_b, dvar + g * sb, ctx->d_flags, &k->prog);
+      }
     // A_g -= P_g^T P_g, all groups
     launch_gemm_nt_sub_batched(s, w.Ag, lda_b, stride_A, w.Pbuf, ldk, true, sb * ldk, w.Pbuf, ldk, true, sb * ldk, sb, sb, m,
                                true, n_groups);
