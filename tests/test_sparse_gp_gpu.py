@@ -89,6 +89,35 @@ def test_uniform_groups_batched_path_matches_oracle(ctx, n, gs, m):
     assert np.abs(j.covariance - oj).max() <= 1e-8 * np.abs(oj).max()
 
 
+@pytest.mark.parametrize("dim,cov_name", [(2, "matern52"), (3, "se"), (3, "matern32")])
+def test_uniform_groups_gram_blocks_in_one_launch(ctx, dim, cov_name):
+    """Equal groups + a radial fast-path kernel: the K_gg blocks of all groups come from ONE launch (launch_gram_blocks,
+    csrc/gram.hip, blockIdx.z = group) - 2-D / 3-D features, target variances, measurement-only noise."""
+    n, gs, m = 768, 128, 48
+    rng = np.random.default_rng(dim * 10 + len(cov_name))
+    x = rng.uniform(0., 12., (n, dim))
+    x = x[np.argsort(x[:, 0])]
+    y = np.sin(x[:, 0]) + 0.1 * x.sum(axis=1) + 0.1 * rng.standard_normal(n)
+    yvar = rng.uniform(0.01, 0.04, n)
+    radial = {"matern52": ab.Matern52(3.0, 1.5), "se": ab.SquaredExponential(2.5, 1.5), "matern32": ab.Matern32(3.0, 1.2)}[cov_name]
+    cov = radial + ab.measurement_only(ab.IndependentNoise(0.2))
+    u = rng.uniform(0., 12., (m, dim))
+    index = {tuple(v): i for i, v in enumerate(x)}
+    grouper = lambda f: index[tuple(np.atleast_1d(f))] // gs
+    model = ab.sparse_gp_from_covariance(cov, grouper, ab.FixedInducingPoints(u), "sparse", context=ctx)
+    model.set_param("inducing_nugget", 1e-6)
+    fm = model.fit(ab.RegressionDataset(x, ab.MarginalDistribution(y, yvar)))
+    ofit = orc.OracleSparseFit(cov, x, np.arange(n) // gs, y, yvar, u, 1e-8, 1e-6)
+    v = ofit.information
+    assert np.abs(fm.get_fit().information - v).max() <= 1e-7 * np.abs(v).max()
+    assert abs(fm.get_fit().nll - ofit.nll) <= 1e-8 * n
+    xs = rng.uniform(0., 12., (30, dim))
+    om, ov, oj = ofit.predict(xs, xs_meas=True, joint=True)
+    j = fm.predict_with_measurement_noise(xs).joint()
+    assert np.abs(j.mean - om).max() <= 1e-8 * max(1., np.abs(om).max())
+    assert np.abs(j.covariance - oj).max() <= 1e-8 * np.abs(oj).max()
+
+
 def test_wide_substitution_path_matches_oracle(ctx):
     """Many more observations than inducing points (n >= 8 m, m a multiple of 512): P = L_u^-1 K_uf and Q1 = L1^-1 W go
     through the out-of-place substitution on explicitly inverted 512 x 512 diagonal blocks (forward_solve_wide,
