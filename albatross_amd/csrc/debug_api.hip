@@ -700,6 +700,9 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
   std::vector<double> h((size_t)ld * (size_t)K);
   unsigned long long x = 88172645463325252ull;
   for (auto &v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+  // (AGP_DEBUG_ZERO_OPERANDS=1: how much of the kernel's time depends on the DATA - at K = 512 the update is 11 % faster on
+  // zeros, at K = 2048 not at all: power, with the memory traffic as the swing term; profiles/r04/bulk_update_vs_k.txt)
+  if (getenv("AGP_DEBUG_ZERO_OPERANDS")) std::fill(h.begin(), h.end(), 0.);
   AGP_HIP_CHECK(ctx, hipMemcpy(dP, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
   for (long long c = 0; c < M; c += K) {
     const long long w = (M - c < K) ? M - c : K;
