@@ -40,6 +40,9 @@ struct GemmArgs {
   // lower-tile order) as 64 x 64 quadrants, the others the tiles 0 .. small_first - 1 whole
   long long small_first = 0;
   int small_count = 0;
+  // ... and, when set, the whole tiles in the order of this table (entry = bi << 16 | bj, -1: no tile): workgroup i runs on
+  // XCD i % 8, and the table gives every XCD compact 8 x 8 blocks of tiles (launch_trailing_update_as)
+  const int *order = nullptr;
   // trailing_update_f32_kernel only: fp32 copies of the two operands (element (row, k) at X32[row + k * ld32]; made once per
   // panel by launch_convert_panel_f32) - nullptr: the kernel rounds the fp64 operands itself while it stages them
   const float *A32 = nullptr, *B32 = nullptr;
