@@ -702,11 +702,15 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
   for (auto &v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
   // (AGP_DEBUG_ZERO_OPERANDS=1: how much of the kernel's time depends on the DATA - at K = 512 the update is 11 % faster on
   // zeros, at K = 2048 not at all: power, with the memory traffic as the swing term; profiles/r04/bulk_update_vs_k.txt)
-  if (getenv("AGP_DEBUG_ZERO_OPERANDS")) std::fill(h.begin(), h.end(), 0.);
-  AGP_HIP_CHECK(ctx, hipMemcpy(dP, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+  // (=1: panel and C zero, =2: the panel only, =3: C only)
+  const int zero_mode = getenv("AGP_DEBUG_ZERO_OPERANDS") ? atoi(getenv("AGP_DEBUG_ZERO_OPERANDS")) : 0;
+  std::vector<double> hz;
+  if (zero_mode) hz.assign(h.size(), 0.);
+  AGP_HIP_CHECK(ctx, hipMemcpy(dP, (zero_mode == 1 || zero_mode == 2) ? hz.data() : h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
   for (long long c = 0; c < M; c += K) {
     const long long w = (M - c < K) ? M - c : K;
-    AGP_HIP_CHECK(ctx, hipMemcpy(dC + c * ld, h.data(), sizeof(double) * (size_t)ld * (size_t)w, hipMemcpyHostToDevice));
+    AGP_HIP_CHECK(ctx, hipMemcpy(dC + c * ld, (zero_mode == 1 || zero_mode == 3) ? hz.data() : h.data(), sizeof(double) * (size_t)ld * (size_t)w,
+                            hipMemcpyHostToDevice));
   }
   hipEvent_t e0, e1;
   AGP_HIP_CHECK(ctx, hipEventCreate(&e0));
