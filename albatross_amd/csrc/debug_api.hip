@@ -703,9 +703,12 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
   // (AGP_DEBUG_ZERO_OPERANDS=1: how much of the kernel's time depends on the DATA - at K = 512 the update is 11 % faster on
   // zeros, at K = 2048 not at all: power, with the memory traffic as the swing term; profiles/r04/bulk_update_vs_k.txt)
   // (=1: panel and C zero, =2: the panel only, =3: C only)
-  const int zero_mode = getenv("AGP_DEBUG_ZERO_OPERANDS") ? atoi(getenv("AGP_DEBUG_ZERO_OPERANDS")) : 0;
+  int zero_mode = getenv("AGP_DEBUG_ZERO_OPERANDS") ? atoi(getenv("AGP_DEBUG_ZERO_OPERANDS")) : 0;
   std::vector<double> hz;
   if (zero_mode) hz.assign(h.size(), 0.);
+  if (zero_mode == 4) { zero_mode = 2; hz.assign(h.size(), 0.3); }                                         // constant panel
+  if (zero_mode == 5) { zero_mode = 2; for (size_t i = 0; i < h.size(); ++i) hz[i] = h[i] < 0. ? -0.3 : 0.3; }  // random signs only
+  if (zero_mode == 6) { zero_mode = 2; for (size_t i = 0; i < h.size(); ++i) hz[i] = (i % 7 == 0) ? h[i] : 0.; }  // 1 in 7 entries non-zero
   AGP_HIP_CHECK(ctx, hipMemcpy(dP, (zero_mode == 1 || zero_mode == 2) ? hz.data() : h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
   for (long long c = 0; c < M; c += K) {
     const long long w = (M - c < K) ? M - c : K;
