@@ -181,7 +181,12 @@ template <bool P32>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_f32_kernel(GemmArgs g) {
   __shared__ float lds[2 * 2 * GK * GLD];
   int bi, bj;
-  if (!tile_of_block(g, bi, bj)) return;
+  if (g.order) {  // XCD-aware order (launch_trailing_update_as)
+    const int packed = g.order[blockIdx.x];
+    if (packed < 0) return;
+    bi = packed >> 16;
+    bj = packed & 0xffff;
+  } else if (!tile_of_block(g, bi, bj)) return;
   const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -625,8 +630,13 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
   g.ntc = g.ntr;
   const long long tiles = count_tiles(g.ntr, g.ntc, 1);
   if (variant == 3) {
-    if (g.A32) hipLaunchKernelGGL(trailing_update_f32_kernel<true>, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
-    else hipLaunchKernelGGL(trailing_update_f32_kernel<false>, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, s, g);
+    long long wgs = tiles;
+    if (tiles >= 1024) {  // (the same XCD-aware order as the fp64 kernel's whole tiles; all tiles are whole here)
+      const XcdOrder o = xcd_order(g.ntr, tiles);
+      if (o.dev) { g.order = o.dev; wgs = o.len; }
+    }
+    if (g.A32) hipLaunchKernelGGL(trailing_update_f32_kernel<true>, dim3((unsigned)wgs), dim3(GEMM_THREADS), 0, s, g);
+    else hipLaunchKernelGGL(trailing_update_f32_kernel<false>, dim3((unsigned)wgs), dim3(GEMM_THREADS), 0, s, g);
     return;
   }
   // Tail split: a launch of T tiles runs floor(T / slots) full rounds of 128 x 128 workgroups (slots = 2 per
