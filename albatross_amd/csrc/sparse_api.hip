@@ -421,7 +421,7 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
   };
   // vectors: b | v | r | dv | tt (m each) | t (n) ; partial sums of the mat-vecs
   double *mv = nullptr;
-  SPX_HIP(dev_malloc(&mv, sizeof(double) * (size_t)(5 * mp2 + np2)));
+  SPX_HIP(dev_malloc(&mv, sizeof(double) * (size_t)(5 * mp2 + np2 + 2)));
   std::unique_ptr<double, void (*)(double *)> mv_guard(mv, [](double *p) { (void)dev_free(p); });
   double *bvec = mv, *vvec = bvec + mp2, *rvec = vvec + mp2, *dv = rvec + mp2, *tt = dv + mp2, *tvec = tt + mp2;
   const long long cols = std::max(n, m), chunks = (cols + 1023) / 1024;
@@ -448,6 +448,16 @@ int sparse_sigma(agp_context *ctx, agp_sparse_fit *f, const double *T, long long
     SPX_HIP(hipMemcpyAsync(dv, rvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
     if ((st = sigma_solve(dv)) != AGP_OK) return st;
     launch_axpby(s, m, 1.0, vvec, 1.0, dv, vvec);
+    if (it == 0) {
+      // a first correction below 1e-10 |v| leaves nothing for a second one (corrections shrink by the same factor again):
+      // one small read-back instead of two more passes over W (every rank holds the same v and takes the same branch)
+      double *nrm = tvec + np2, h[2] = {1., 0.};
+      launch_dot(s, dv, dv, m, nrm);
+      launch_dot(s, vvec, vvec, m, nrm + 1);
+      SPX_HIP(hipMemcpyAsync(h, nrm, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+      SPX_HIP(hipStreamSynchronize(s));
+      if (h[0] <= 1e-20 * h[1]) break;
+    }
   }
   SPX_HIP(dev_malloc(&f->v, sizeof(double) * (size_t)m));
   SPX_HIP(hipMemcpyAsync(f->v, vvec, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, s));
