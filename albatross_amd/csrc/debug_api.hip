@@ -741,6 +741,33 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
   return st;
 }
 
+// X (n x ncols, ld n) = L^-1 B for L = the LL^T factor of the host matrix K (n x n, lower triangle, ld n) through
+// forward_solve_wide (solve.hip): out of place, explicitly inverted 512 x 512 diagonal blocks.  n a multiple of 512.
+AGP_DEBUG_API int agp_debug_forward_solve_wide(agp_context *ctx, const double *K, int64_t n, const double *B, int64_t ncols, double *X) {
+  if (!ctx || !K || !B || !X || n < 1024 || n % 512 != 0 || ncols <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  agp_fit *f = nullptr;
+  int st = agp_factor_create(ctx, K, n, n, 0, AGP_HOST, &f);
+  if (st != AGP_OK) return st;
+  const long long ldb = n + 2;  // (a right-hand side whose leading dimension is not the matrix's)
+  double *dB = nullptr, *dX = nullptr, *dW = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&dB, sizeof(double) * (size_t)ldb * (size_t)ncols));
+  AGP_HIP_CHECK(ctx, hipMalloc(&dX, sizeof(double) * (size_t)ldb * (size_t)ncols));
+  AGP_HIP_CHECK(ctx, hipMalloc(&dW, sizeof(double) * (size_t)n * 512));
+  AGP_HIP_CHECK(ctx, hipMemcpy2D(dB, sizeof(double) * (size_t)ldb, B, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n, (size_t)ncols,
+                                 hipMemcpyHostToDevice));
+  AGP_HIP_CHECK(ctx, hipMemset(dX, 0, sizeof(double) * (size_t)ldb * (size_t)ncols));
+  invert_wide_blocks(ctx->stream, f->A, n, f->lda, f->invd, WIDE_BW, dW);
+  forward_solve_wide(ctx->stream, f->A, n, f->lda, dW, dB, ldb, dX, ldb, ncols);
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  AGP_HIP_CHECK(ctx, hipGetLastError());
+  AGP_HIP_CHECK(ctx, hipMemcpy2D(X, sizeof(double) * (size_t)n, dX, sizeof(double) * (size_t)ldb, sizeof(double) * (size_t)n, (size_t)ncols,
+                                 hipMemcpyDeviceToHost));
+  (void)hipFree(dB); (void)hipFree(dX); (void)hipFree(dW);
+  agp_fit_destroy(f);
+  return AGP_OK;
+}
+
 // In-place LL^T of the lower triangle of a host matrix; y (optional) -> L^-1 y.
 AGP_DEBUG_API int agp_debug_factor(agp_context *ctx, double *A, int64_t n, int64_t lda, double *y, double *log_det,
                      int64_t *bad_pivot) {

@@ -143,6 +143,26 @@ def test_trailing_update_variants(ctx, dbg, M, K, variant):
     assert np.array_equal(got[M:], Cm[M:])  # padding rows untouched
 
 
+@pytest.mark.parametrize("n,ncols", [(1024, 8192), (1536, 12289), (1024, 9000)])
+def test_forward_solve_wide(ctx, dbg, n, ncols):
+    """X = L^-1 B out of place for a right-hand side much wider than L (csrc/solve.hip: forward_solve_wide - inverted 512 x 512
+    diagonal blocks, one deep product per block row, in-place triangular products bottom-up): the sparse GP's m x n solves.
+    Ragged column counts exercise the edge tiles of the out-of-place kernel."""
+    import ctypes as C
+    from scipy.linalg import solve_triangular
+    rng = np.random.default_rng(n + ncols)
+    G = rng.standard_normal((n, n))
+    K = np.asfortranarray(G @ G.T / n + np.eye(n))
+    B = np.asfortranarray(rng.standard_normal((n, ncols)))
+    X = np.zeros((n, ncols), order="F")
+    fn = dbg.agp_debug_forward_solve_wide
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    assert fn(ctx._h, _p(K), n, _p(B), ncols, _p(X)) == 0
+    want = solve_triangular(np.linalg.cholesky(K), B, lower=True)
+    assert np.abs(X - want).max() <= 1e-11 * np.abs(want).max()
+
+
 @pytest.mark.parametrize("n", [16, 100, 128, 129, 300, 512, 640, 1000, 1537])
 def test_factor_matches_oracle_llt(ctx, dbg, n):
     rng = np.random.default_rng(n)
