@@ -120,6 +120,19 @@ hipError_t dev_free(void *p) {
   return hipSuccess;
 }
 
+// hipFree of a block that MAY have come from dev_malloc (a factor parked in a context pool, a buffer handed from one
+// owner to another): the `live` entry goes with it - a stale entry would later match an unrelated hipMalloc that
+// happens to return the same address, and dev_free would park that block under the old (larger) size.
+hipError_t dev_release(void *p) {
+  if (!p) return hipSuccess;
+  DevCache &c = dev_cache();
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.live.erase(p);
+  }
+  return hipFree(p);
+}
+
 void dev_cache_trim() {
   DevCache &c = dev_cache();
   std::vector<void *> all;
@@ -250,15 +263,15 @@ void agp_context_destroy(agp_context *c) {
   for (auto e : ctx->stage_ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->partial_ws) (void)hipFree(ctx->partial_ws);
-  if (ctx->ws_A) (void)hipFree(ctx->ws_A);
-  if (ctx->pool_A) (void)hipFree(ctx->pool_A);
-  if (ctx->pool_K) (void)hipFree(ctx->pool_K);
+  if (ctx->ws_A) (void)agp::dev_release(ctx->ws_A);
+  if (ctx->pool_A) (void)agp::dev_release(ctx->pool_A);
+  if (ctx->pool_K) (void)agp::dev_release(ctx->pool_K);
   if (ctx->p32) (void)hipFree(ctx->p32);
   if (ctx->pool_L32) (void)hipFree(ctx->pool_L32);
-  if (ctx->pool_aux) (void)hipFree(ctx->pool_aux);
-  if (ctx->pool_shard) (void)hipFree(ctx->pool_shard);
-  if (ctx->pool_sparse) (void)hipFree(ctx->pool_sparse);
-  if (ctx->pool_batch) (void)hipFree(ctx->pool_batch);
+  if (ctx->pool_aux) (void)agp::dev_release(ctx->pool_aux);
+  if (ctx->pool_shard) (void)agp::dev_release(ctx->pool_shard);
+  if (ctx->pool_sparse) (void)agp::dev_release(ctx->pool_sparse);
+  if (ctx->pool_batch) (void)agp::dev_release(ctx->pool_batch);
   if (ctx->ws_aux) (void)hipFree(ctx->ws_aux);
   if (ctx->d_zpub) (void)hipFree(ctx->d_zpub);
   if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
@@ -670,7 +683,7 @@ void agp_fit_destroy(agp_fit *fit) {
     if (--fit->slab->refs == 0) {
       agp_context *ctx = fit->ctx;
       if (ctx && !ctx->pool_batch) { ctx->pool_batch = fit->slab->base; ctx->pool_batch_bytes = fit->slab->bytes; }  // (like pool_A)
-      else (void)hipFree(fit->slab->base);
+      else (void)dev_release(fit->slab->base);
       delete fit->slab;
     }
     fit->train.release();
@@ -694,7 +707,7 @@ void agp_fit_destroy(agp_fit *fit) {
       ctx->pool_aux = fit->aux_base;
       ctx->pool_aux_bytes = fit->aux_bytes;
     } else {
-      (void)hipFree(fit->aux_base);
+      (void)dev_release(fit->aux_base);
     }
   } else {
     if (fit->invd) (void)dev_free(fit->invd);
@@ -902,7 +915,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
       ctx->pool_K = nullptr;
       ctx->pool_K_bytes = 0;
     } else {
-      if (ctx->pool_K) { (void)hipFree(ctx->pool_K); ctx->pool_K = nullptr; ctx->pool_K_bytes = 0; }
+      if (ctx->pool_K) { (void)dev_release(ctx->pool_K); ctx->pool_K = nullptr; ctx->pool_K_bytes = 0; }
       FIT_CHECK(hipMalloc(&Kfull, Kfull_bytes));
     }
     FIT_CHECK(hipMalloc(&Wfwd, sizeof(double) * (size_t)nblk * NB * NB));
@@ -1354,7 +1367,7 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
     ctx->pool_batch = nullptr;
     ctx->pool_batch_bytes = 0;
   } else {
-    if (ctx->pool_batch) { (void)hipFree(ctx->pool_batch); ctx->pool_batch = nullptr; ctx->pool_batch_bytes = 0; }
+    if (ctx->pool_batch) { (void)dev_release(ctx->pool_batch); ctx->pool_batch = nullptr; ctx->pool_batch_bytes = 0; }
     AGP_HIP_CHECK(ctx, hipMalloc(&base, sizeof(double) * elems));
   }
   double *A = base, *invd = A + (size_t)count * (size_t)stride_A, *alpha = invd + (size_t)count * (size_t)stride_I;

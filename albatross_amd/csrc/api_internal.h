@@ -14,10 +14,14 @@ namespace agp {
 // its first stage alone).  dev_free parks the block (after the device-wide synchronisation hipFree implies) and
 // dev_malloc hands out a parked block of exactly the requested size; at most DEV_CACHE_BYTES are kept, the oldest
 // blocks go first; agp_context_destroy empties the cache.  Pointers that did not come from dev_malloc are hipFree'd.
+// A block that leaves through any other door (a context pool that is closed, a hand-over between owners) goes through
+// dev_release, so that the table of live blocks never holds an address the runtime may hand out again.
 hipError_t dev_malloc_bytes(void **p, size_t bytes);
 template <class T>
 inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_bytes(reinterpret_cast<void **>(p), bytes); }
 hipError_t dev_free(void *p);
+// plain hipFree of a block that may have come from dev_malloc (forgets it first; never parks)
+hipError_t dev_release(void *p);
 void dev_cache_trim();
 void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n);
 void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n);

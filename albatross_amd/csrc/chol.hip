@@ -606,6 +606,10 @@ __device__ __forceinline__ void trsm_fused_body(const PotrfArgs &p, int first_bl
         if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
         __builtin_amdgcn_s_sleep(8);
       }
+      // pairs with the RELEASE of trail_tile64<true>'s count: the rows read below are ordered behind the count in the
+      // memory model too (on this hardware they already are - every hand-over load is device-scope, sc1, and cannot
+      // hit a stale line of the XCD-private L2 -, so the poll itself stays RELAXED and the fence costs one s_waitcnt)
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
   }

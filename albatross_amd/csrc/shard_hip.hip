@@ -735,11 +735,11 @@ void agp_sharded_fit_destroy(agp_sharded_fit *f) {
   // on the context's streams, and so is whatever uses them next)
   if (f->A) {
     if (f->ctx && !f->ctx->pool_A) { f->ctx->pool_A = f->A; f->ctx->pool_A_bytes = f->A_bytes; }
-    else (void)hipFree(f->A);
+    else (void)dev_release(f->A);  // (may have come from a dense factor's dev_malloc through pool_A)
   }
   if (f->work) {
     if (f->ctx && !f->ctx->pool_shard) { f->ctx->pool_shard = f->work; f->ctx->pool_shard_bytes = f->work_bytes; }
-    else (void)hipFree(f->work);
+    else (void)dev_release(f->work);
   }
   f->train.release();
   delete f;

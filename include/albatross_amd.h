@@ -36,8 +36,9 @@ typedef enum {
   /* the assembled covariance holds a NaN: ALBATROSS_ASSERT(!cov.hasNaN()),
    * include/albatross/src/models/gp.hpp:66 */
   AGP_ERR_NAN_INPUT = 2,
-  /* un-pivoted LL^T met a pivot <= 0 (the reference's pivoted LDL^T tolerates
-   * semi-definite input; callers fall back to their CPU path on this code) */
+  /* un-pivoted LL^T met a pivot <= 0.  The reference's pivoted LDL^T tolerates semi-definite input: callers
+   * that want that behaviour go on to the DEVICE implementation of that algorithm, agp_ldlt_* below (the
+   * host mirrors do: gp.py `pivoted_fallback`, albatross.hpp `fit_pivoted`).  There is no CPU path. */
   AGP_ERR_NOT_POSITIVE_DEFINITE = 3,
   AGP_ERR_HIP = 4,
   AGP_ERR_COMM = 5,

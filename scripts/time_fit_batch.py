@@ -12,5 +12,6 @@ import albatross_amd as ab
 from bench import fit_batch_rates
 
 ctx = ab.Context(0)
-for row in fit_batch_rates(ab, ctx, sizes=[int(a) for a in sys.argv[1:]] or None):
+batches = tuple(int(b) for b in os.environ.get('FIT_BATCHES', '1,8,32').split(','))
+for row in fit_batch_rates(ab, ctx, sizes=[int(a) for a in sys.argv[1:]] or None, batches=batches):
     print(row, flush=True)
