@@ -18,6 +18,7 @@
 #include <tuple>
 #include <unordered_map>
 #include "trace.h"
+#include "pub.h"
 
 namespace agp {
 
@@ -188,6 +189,7 @@ static agp_context::Tuning read_tuning() {
   t.panel_fused = flag("AGP_PANEL_FUSED", true);
   t.step_below = number("AGP_STEP_BELOW", 4608);
   t.gram_sop = flag("AGP_GRAM_SOP", true);
+  t.backsub_coop = flag("AGP_BACKSUB_COOP", true);
   t.sparse_pivoted = flag("AGP_SPARSE_PIVOTED", false);
   t.predict_chunk = number("AGP_PREDICT_CHUNK", 0);
   t.shard_block = number("AGP_SHARD_BLOCK", 0);
@@ -240,10 +242,11 @@ int agp_context_create(int device_id, agp_context **out) {
   }
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
-  AGP_HIP_CHECK(ctx, hipMalloc(&ctx->d_flags, 4 * sizeof(int)));
-  AGP_HIP_CHECK(ctx, hipMalloc(&ctx->d_scalars, 4 * sizeof(double)));
-  AGP_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_flags, 4 * sizeof(int)));
-  AGP_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_scalars, 4 * sizeof(double)));
+  // flags and scalars of a factorisation: ONE block on either side ([4 ints | 4 doubles]) so that one 48-byte copy brings both back
+  AGP_HIP_CHECK(ctx, hipMalloc(&ctx->d_flags, 4 * sizeof(int) + 4 * sizeof(double)));
+  ctx->d_scalars = reinterpret_cast<double *>(ctx->d_flags + 4);
+  AGP_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_flags, 4 * sizeof(int) + 4 * sizeof(double)));
+  ctx->h_scalars = reinterpret_cast<double *>(ctx->h_flags + 4);
   for (auto &e : ctx->stage_ev) AGP_HIP_CHECK(ctx, hipEventCreate(&e));
   for (auto &sl : ctx->ext.slots) AGP_HIP_CHECK(ctx, hipMalloc(&sl.dev, sizeof(DevProgram)));
   *out = ctx;
@@ -276,10 +279,8 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->d_zpub) (void)hipFree(ctx->d_zpub);
   if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
   if (ctx->shard_flags) (void)hipFree(ctx->shard_flags);
-  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
-  if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+  if (ctx->d_flags) (void)hipFree(ctx->d_flags);  // (d_scalars / h_scalars are the tails of these blocks)
   if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
-  if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -529,14 +530,25 @@ static void finish_factor(agp_context_impl *ctx, const FactorTimers &timers) {
   ctx->stage_ms[5] = flop;  // flop of the trailing updates (not ms)
 }
 
+static constexpr long long BACKSUB_COOP_MAX_N = 1280;
+static constexpr size_t STATUS_BYTES = 4 * sizeof(int) + 4 * sizeof(double);
+
+// pre (optional): fills and copies the caller wants made BEFORE the Gram matrix is built, in the same launch as the
+// zeroing of the flags and the sentinel fills of the panel kernels (pub.h: a fit of a few hundred points used to
+// spend ten launches on these)
 static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevProgram *hprog, const FeatView &xm,
                             double *A, long long lda, double *invd, double *y, const double *yvar, bool finish = true,
-                            FactorTimers *timers_out = nullptr) {
+                            FactorTimers *timers_out = nullptr, PrepArgs *pre = nullptr) {
   agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
   const long long n = xm.n;
   hipStream_t s = ctx->stream;
-  AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
-  AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 4 * sizeof(double), s));
+  {
+    PrepArgs local;
+    PrepArgs *prep = pre ? pre : &local;
+    prep->fill(ctx->d_flags, 0ull, (long long)(STATUS_BYTES / 8));
+    if (prep->n + 4 <= PREP_MAX) ctx->prep_external = panel_fused_plan(ctx, invd, 0, n, true, prep);
+    launch_prep(s, *prep);
+  }
   const bool prof = ctx->profiling;
   if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[0], s));
   // as_measurements(features) -> covariance_function_(measurement_features)   gp.hpp:288-290
@@ -560,9 +572,9 @@ static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevPr
     timers.n_ev = (int)want;
   }
   factor_lower(ctx, A, n, lda, invd, y, prof ? &timers : nullptr);
+  ctx->prep_external = false;
   if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[2], s));
-  AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-  AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, STATUS_BYTES, hipMemcpyDeviceToHost, s));
   if (timers_out) *timers_out = timers;
   if (!finish) return AGP_OK;
   AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
@@ -880,30 +892,42 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     fit->z = fit->alpha + n_vec;
   }
   const hipMemcpyKind kind = x->location == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  // device-resident inputs: the copies of the training features and targets travel in the ONE preparation launch of
+  // build_and_factor (pub.h: PrepArgs) instead of a copy kernel each; host inputs are uploads and stay what they were
+  PrepArgs pre;
+  const bool dev_in = x->location != AGP_HOST;
+  auto stage = [&](void *dst, const void *src, long long words) -> hipError_t {
+    if (dev_in) { pre.copy(dst, src, words); return hipSuccess; }
+    return hipMemcpyAsync(dst, src, sizeof(double) * (size_t)words, kind, s);
+  };
   {
     double *fcur = fit->z + round_up(n, 2);
     FeatView v;
     v.n = n; v.dim = x->dim; v.nsc = x->n_scale_columns; v.meas = 0;
     v.coords = fcur; v.ids = nullptr; v.scales = nullptr;
-    FIT_CHECK(hipMemcpyAsync(fcur, x->coords, sizeof(double) * (size_t)n * (size_t)x->dim, kind, s));
+    FIT_CHECK(stage(fcur, x->coords, n * (long long)x->dim));
     fcur += (size_t)n * (size_t)x->dim;
     if (x->eq_id) {
       v.ids = reinterpret_cast<const long long *>(fcur);
-      FIT_CHECK(hipMemcpyAsync(fcur, x->eq_id, sizeof(long long) * (size_t)n, kind, s));
+      FIT_CHECK(stage(fcur, x->eq_id, n));
       fcur += n;
     }
     if (x->n_scale_columns > 0) {
       v.scales = fcur;
-      FIT_CHECK(hipMemcpyAsync(fcur, x->scales, sizeof(double) * (size_t)n * (size_t)x->n_scale_columns, kind, s));
+      FIT_CHECK(stage(fcur, x->scales, n * (long long)x->n_scale_columns));
     }
     fit->train.v = v;  // (a view into aux_base: DeviceFeatures::release has nothing to free)
   }
-  FIT_CHECK(hipMemcpyAsync(fit->z, y, sizeof(double) * (size_t)n, kind, s));
+  FIT_CHECK(stage(fit->z, y, n));
   if (y_var) {
     FIT_CHECK(hipMalloc(&yvar_d, sizeof(double) * (size_t)n));
-    FIT_CHECK(hipMemcpyAsync(yvar_d, y_var, sizeof(double) * (size_t)n, kind, s));
+    FIT_CHECK(stage(yvar_d, y_var, n));
   }
   if (x->location == AGP_HOST) FIT_CHECK(hipStreamSynchronize(s));
+  if (mixed && pre.n > 0) {  // (the mixed fit reads the staged inputs before build_and_factor: its exact covariance, the copy of y)
+    launch_prep(s, pre);
+    pre = PrepArgs();
+  }
   FeatView xm = fit->train.v;
   xm.meas = 1;  // as_measurements(features), gp.hpp:288
   if (mixed) {
@@ -939,9 +963,16 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   // that turns out not to be positive definite was wasted work on garbage, nothing more.  (The flags and the
   // log-determinant are copied to the host right behind the factorisation, before the substitution touches d_scalars.)
   const bool deferred = !mixed && !yvar_d;
+  // information = L^-T z in ONE launch (solve.hip: backsub_coop_kernel) for the fp64 fit: its output vector is the
+  // hand-over buffer and is sentinel-filled by the preparation launch.  (The refinement of a mixed fit needs the
+  // inverted diagonal blocks anyway and keeps the launch-per-block substitution.)
+  // Measured (profiles/r05): one hand-over + substitution per 128-column block is ~9 us - 37 us at N = 512 against 45 us
+  // for the launch chain, 286 us at N = 4096 against 190 us through the 512-wide inverted blocks: small fits only.
+  const bool coop = !mixed && ctx->tune.backsub_coop && n <= BACKSUB_COOP_MAX_N;
+  if (coop) pre.sentinel(fit->alpha, n);
   FactorTimers ftimers;
   long long bs_done = 0;
-  if (deferred && backsolve_width(n)) {
+  if (!coop && deferred && backsolve_width(n)) {
     // the inverses of the wide diagonal blocks for the backward substitution: computed by factor_lower on its idle
     // second stream while the chain-bound tail of the factorisation runs (common.h: bs_W)
     if (ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * backsolve_ws_elems(n)) == AGP_OK) {
@@ -950,7 +981,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
       ctx->bs_done = 0;
     }
   }
-  st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d, !deferred, &ftimers);
+  st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d, !deferred, &ftimers, &pre);
   ctx->update_variant = -1;
   ctx->nbo_override = 0;
   bs_done = ctx->bs_W ? ctx->bs_done : 0;
@@ -977,12 +1008,17 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   }
   // information = L^-T (L^-1 y)
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[3], s));
-  FIT_CHECK(hipMemcpyAsync(fit->alpha, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-  {
-    const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)round_up(n, 2));
-    if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
-  }
-  {
+  if (coop) {
+    TraceRange tr("agp: backward substitution (information = ldlt.solve(y), gp.hpp:68)");
+    backward_solve_coop(s, fit->A, n, fit->lda, fit->invd, fit->z, fit->alpha, ctx->d_flags);
+    // (the hand-over flag of the substitution: the 48-byte status copy left before it ran)
+    FIT_CHECK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  } else {
+    FIT_CHECK(hipMemcpyAsync(fit->alpha, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    {
+      const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)round_up(n, 2));
+      if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
+    }
     const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * backsolve_ws_elems(n));
     if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
     {
@@ -1014,6 +1050,10 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
       return st;
     }
     if (information) FIT_CHECK(hipMemcpy(information, fit->alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  } else if (coop && ctx->h_flags[2]) {  // the one-launch substitution gave up on a hand-over (its producer died)
+    ctx->last_error = "back substitution: hand-over timed out";
+    agp_fit_destroy(fit);
+    return AGP_ERR_HIP;
   }
   if (ctx->profiling) {
     float ms = 0.f;
@@ -1299,9 +1339,10 @@ int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, c
   std::vector<DeviceFeatures> dxs((size_t)count);
   const agp_features *last = nullptr;
   int last_b = -1;
+  std::vector<FeatView> views((size_t)count);
+  std::vector<const DevProgram *> hprogs((size_t)count);
+  std::vector<double *> outs((size_t)count);
   for (int b = 0; b < count && st == AGP_OK; ++b) {
-    const DevProgram *dprog = nullptr;
-    if ((st = device_program(ctx, kernels[b], &dprog)) != AGP_OK) break;
     // parameter vectors usually share one feature array: upload it once
     const bool same = last && features[b]->coords == last->coords && features[b]->scales == last->scales &&
                       features[b]->eq_id == last->eq_id;
@@ -1310,9 +1351,25 @@ int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, c
       last = features[b];
       last_b = b;
     }
-    FeatView xm = dxs[(size_t)(same ? last_b : b)].v;
-    xm.meas = 1;  // as_measurements(features), gp.hpp:288
-    launch_gram(s, dprog, xm, xm, true, true, A + (size_t)b * (size_t)stride_A, lda, y_var ? yvar_d : nullptr, nullptr,
+    views[(size_t)b] = dxs[(size_t)(same ? last_b : b)].v;
+    views[(size_t)b].meas = 1;  // as_measurements(features), gp.hpp:288
+    hprogs[(size_t)b] = &kernels[b]->prog;
+    outs[(size_t)b] = A + (size_t)b * (size_t)stride_A;
+  }
+  bool gram_done = false;
+  if (st == AGP_OK && count > 1) {  // all Gram matrices in ONE launch when the trees share a fast path (gram.hip)
+    std::vector<const double *> diag((size_t)count, y_var ? yvar_d : nullptr);
+    void *table = nullptr;
+    if (dev_malloc(&table, gram_batch_table_bytes(count)) == hipSuccess) {
+      gram_done = launch_gram_batch(s, count, hprogs.data(), views.data(), outs.data(), lda, y_var ? diag.data() : nullptr, nullptr, table);
+      if (gram_done) (void)hipStreamSynchronize(s);  // (the table is read by the launch)
+      (void)dev_free(table);
+    } else (void)hipGetLastError();
+  }
+  for (int b = 0; b < count && st == AGP_OK && !gram_done; ++b) {
+    const DevProgram *dprog = nullptr;
+    if ((st = device_program(ctx, kernels[b], &dprog)) != AGP_OK) break;
+    launch_gram(s, dprog, views[(size_t)b], views[(size_t)b], true, true, outs[(size_t)b], lda, y_var ? yvar_d : nullptr, nullptr,
                 &kernels[b]->prog);
   }
   if (st == AGP_OK) {
@@ -1392,11 +1449,29 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
   } while (0)
   const int loc = features[0]->location;
   const hipMemcpyKind kind = loc == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-  for (int b = 0; b < count; ++b) {
-    BATCH_CHECK(hipMemcpyAsync(z + (size_t)b * (size_t)np2, y + (size_t)b * (size_t)ldy, sizeof(double) * (size_t)n, kind, s));
-    if (y_var) BATCH_CHECK(hipMemcpyAsync(yvar_d + (size_t)b * (size_t)np2, y_var + (size_t)b * (size_t)ldv, sizeof(double) * (size_t)n, kind, s));
+  // targets (and their variances): constant strides on both sides - one pitched copy each
+  BATCH_CHECK(hipMemcpy2DAsync(z, sizeof(double) * (size_t)np2, y, sizeof(double) * (size_t)(ldy ? ldy : n), sizeof(double) * (size_t)n,
+                               (size_t)(ldy ? count : 1), kind, s));
+  if (!ldy)
+    for (int b = 1; b < count; ++b)  // (one target vector shared by all problems)
+      BATCH_CHECK(hipMemcpyAsync(z + (size_t)b * (size_t)np2, y, sizeof(double) * (size_t)n, kind, s));
+  if (y_var) {
+    BATCH_CHECK(hipMemcpy2DAsync(yvar_d, sizeof(double) * (size_t)np2, y_var, sizeof(double) * (size_t)(ldv ? ldv : n), sizeof(double) * (size_t)n,
+                                 (size_t)(ldv ? count : 1), kind, s));
+    if (!ldv)
+      for (int b = 1; b < count; ++b)
+        BATCH_CHECK(hipMemcpyAsync(yvar_d + (size_t)b * (size_t)np2, y_var, sizeof(double) * (size_t)n, kind, s));
   }
-  // train_features = features (gp.hpp:63): a copy per fit, inside the batch's allocation (no allocation per problem)
+  // train_features = features (gp.hpp:63): a copy per fit, inside the batch's allocation (no allocation per problem).
+  // Device-resident inputs: ONE table-driven copy launch for all problems (pub.h: CopyItem) instead of a copy kernel per array
+  std::vector<CopyItem> copies;
+  long long copy_max = 0;
+  auto stage = [&](double *dst, const void *src, long long words) -> hipError_t {
+    if (loc == AGP_HOST) return hipMemcpyAsync(dst, src, sizeof(double) * (size_t)words, kind, s);
+    copies.push_back(CopyItem{reinterpret_cast<unsigned long long *>(dst), static_cast<const unsigned long long *>(src), words});
+    if (words > copy_max) copy_max = words;
+    return hipSuccess;
+  };
   double *fcur = base + head_elems;
   for (int b = 0; b < count; ++b) {
     agp_fit *fit = new (std::nothrow) agp_fit();
@@ -1406,30 +1481,62 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
     FeatView v;
     v.n = n; v.dim = f->dim; v.nsc = f->n_scale_columns; v.meas = 0;
     v.coords = fcur; v.ids = nullptr; v.scales = nullptr;
-    BATCH_CHECK(hipMemcpyAsync(fcur, f->coords, sizeof(double) * (size_t)n * (size_t)f->dim, kind, s));
+    BATCH_CHECK(stage(fcur, f->coords, n * (long long)f->dim));
     fcur += (size_t)n * (size_t)f->dim;
     if (f->eq_id) {
       v.ids = reinterpret_cast<const long long *>(fcur);
-      BATCH_CHECK(hipMemcpyAsync(fcur, f->eq_id, sizeof(long long) * (size_t)n, kind, s));
+      BATCH_CHECK(stage(fcur, f->eq_id, n));
       fcur += n;
     }
     if (f->n_scale_columns > 0) {
       v.scales = fcur;
-      BATCH_CHECK(hipMemcpyAsync(fcur, f->scales, sizeof(double) * (size_t)n * (size_t)f->n_scale_columns, kind, s));
+      BATCH_CHECK(stage(fcur, f->scales, n * (long long)f->n_scale_columns));
       fcur += (size_t)n * (size_t)f->n_scale_columns;
     }
     fit->train.v = v;  // (not owned: DeviceFeatures::release has nothing to free)
   }
+  // device scratch behind the features: the copy table and the Gram table of the batched launches
+  void *tables = nullptr;
+  const size_t copy_bytes = (sizeof(CopyItem) * copies.size() + 15) / 16 * 16;
+  const size_t table_bytes = copy_bytes + gram_batch_table_bytes(count);
+  if (dev_malloc(&tables, table_bytes) != hipSuccess) { (void)hipGetLastError(); tables = nullptr; }
+  struct FreeTables { void *p; ~FreeTables() { if (p) (void)dev_free(p); } } free_tables{tables};
+  if (!copies.empty()) {
+    if (tables) {
+      BATCH_CHECK(hipMemcpyAsync(tables, copies.data(), sizeof(CopyItem) * copies.size(), hipMemcpyHostToDevice, s));
+      BATCH_CHECK(hipStreamSynchronize(s));  // (pageable source)
+      launch_copy_table(s, static_cast<const CopyItem *>(tables), (long long)copies.size(), copy_max);
+    } else {
+      for (const CopyItem &c : copies) BATCH_CHECK(hipMemcpyAsync(c.dst, c.src, sizeof(double) * (size_t)c.words, kind, s));
+    }
+  }
   if (loc == AGP_HOST) BATCH_CHECK(hipStreamSynchronize(s));
   BATCH_CHECK(hipMemsetAsync(logsum, 0, sizeof(double) * 3 * (size_t)cp2, s));  // log sums and flags
-  for (int b = 0; b < count; ++b) {
-    const DevProgram *dprog = nullptr;
-    if ((st = device_program(ctx, kernels[b], &dprog)) != AGP_OK) return fail(st);
-    agp_fit *fit = fits[(size_t)b];
-    FeatView xm = fit->train.v;
-    xm.meas = 1;  // as_measurements(features), gp.hpp:288
-    launch_gram(s, dprog, xm, xm, true, true, A + (size_t)b * (size_t)stride_A, lda, y_var ? yvar_d + (size_t)b * (size_t)np2 : nullptr,
-                flags + 4 * b, &kernels[b]->prog);
+  {
+    std::vector<FeatView> views((size_t)count);
+    std::vector<const DevProgram *> hprogs((size_t)count);
+    std::vector<double *> outs((size_t)count);
+    std::vector<const double *> diag((size_t)count, nullptr);
+    std::vector<int *> nanf((size_t)count);
+    for (int b = 0; b < count; ++b) {
+      views[(size_t)b] = fits[(size_t)b]->train.v;
+      views[(size_t)b].meas = 1;  // as_measurements(features), gp.hpp:288
+      hprogs[(size_t)b] = &kernels[b]->prog;
+      outs[(size_t)b] = A + (size_t)b * (size_t)stride_A;
+      if (y_var) diag[(size_t)b] = yvar_d + (size_t)b * (size_t)np2;
+      nanf[(size_t)b] = flags + 4 * b;
+    }
+    bool gram_done = false;
+    if (tables && count > 1) {  // all Gram matrices in ONE launch when the trees share a fast path (gram.hip)
+      gram_done = launch_gram_batch(s, count, hprogs.data(), views.data(), outs.data(), lda, y_var ? diag.data() : nullptr, nanf.data(),
+                                    static_cast<char *>(tables) + copy_bytes);
+    }
+    for (int b = 0; b < count && !gram_done; ++b) {
+      const DevProgram *dprog = nullptr;
+      if ((st = device_program(ctx, kernels[b], &dprog)) != AGP_OK) return fail(st);
+      launch_gram(s, dprog, views[(size_t)b], views[(size_t)b], true, true, outs[(size_t)b], lda, diag[(size_t)b], nanf[(size_t)b],
+                  &kernels[b]->prog);
+    }
   }
   // (two streams once the trailing updates of the batch are long enough to hide the panel chain behind)
   if ((double)count * (double)n * (double)n >= 6e7 && n > 2 * NBO)

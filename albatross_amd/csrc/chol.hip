@@ -21,6 +21,7 @@
 #include "mfma_f64.h"
 #include "gemm_tiles.h"
 #include "trsm_kernel.h"
+#include "pub.h"
 
 namespace agp {
 void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);  // reduce.hip
@@ -77,43 +78,6 @@ struct PotrfArgs {
   long long trail_tiles = 0, trail_workers = 1;  // tiles of the launch (row tiles first) / trailing workgroups that share them
 };
 
-
-// ---- hand-over of the factored diagonal block INSIDE one launch (panel_fused_kernel) ----------------------------
-// The workgroup that factors the 128 x 128 diagonal block emits its tile image tile by tile while it runs; the
-// workgroups that solve the rows below consume those tiles as they appear.  No flags: the image (and the slot of
-// z_b) is filled with a sentinel bit pattern before the launch, the producer writes every value ONCE with a
-// device-scope store (global_store ... sc1: written through to the memory side, past the XCD-private L2), and a
-// consumer re-reads a fragment with device-scope loads (sc1) until none of its values is the sentinel.  8-byte
-// accesses are single-copy atomic, so a value is either the sentinel or final.  The producer never waits for an
-// acknowledgement - nothing is added to the serial pivot chain - and a consumer waits for exactly the values it is
-// about to multiply.  The sentinel is a NaN payload no arithmetic produces (hardware NaNs are 0x7FF8000000000000).
-constexpr unsigned long long PUB_SENTINEL = 0xFFF8A5A5DEADBEEFull;
-
-__device__ __forceinline__ void store_pub(double *p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_pub(const double *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool is_unpublished(double v) {
-  return (unsigned long long)__double_as_longlong(v) == PUB_SENTINEL;
-}
-
-// A consumer never spins for ever: after ~2 s (s_memrealtime, 100 MHz) without the values it waits for it records the
-// failure in flags[2] and carries on with whatever it has read - the host turns that flag into AGP_ERR_HIP instead of
-// the launch hanging the GPU (that can only happen if the producer workgroup died).
-constexpr unsigned long long PUB_TIMEOUT_TICKS = 200000000ull;
-
-__device__ __forceinline__ bool poll_expired(unsigned long long t0, int *flags) {
-  if (__builtin_amdgcn_s_memrealtime() - t0 < PUB_TIMEOUT_TICKS) return false;
-  if ((threadIdx.x & 63) == 0) atomicExch(flags + 2, 1);
-  return true;
-}
-
-__global__ __launch_bounds__(256) void fill_sentinel_kernel(double *p, long long count) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < count) p[i] = __longlong_as_double((long long)PUB_SENTINEL);
-}
 
 // DPP row broadcast on fp64 (gfx90a+ "DPP64": row_newbcast only): every lane reads lane J of its
 // own 16-lane row.  One VALU instruction, no SGPR round trip (v_readlane x2 + use).  The leading
@@ -317,7 +281,7 @@ __device__ __forceinline__ void micro_syrk_tile2(double *T, int ib0, int kb0, in
   }
 }
 
-constexpr int POTRF_LDS_DOUBLES = IMG_DOUBLES + 2 * MB * MB + NB;  // tiles | two inverse buffers | y
+constexpr int POTRF_LDS_DOUBLES = IMG_DOUBLES + 2 * MB * MB + NB + 2;  // tiles | two inverse buffers | y | hand-shake counter
 
 // PUB: the fused panel kernel - every tile of the image goes out (store_pub) the moment it is final, z_b too
 template <bool PUB, bool UPD = false>
@@ -364,78 +328,105 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
     for (int t = 0; t < NTILE; ++t) T[t * (MB * MB) + c * MB + r] = v[t];
   }
   if (tid < NB) ys[tid] = (p.y && tid < nbk) ? p.y[tid] : 0.;
+  if (tid == 0) *reinterpret_cast<int *>(ys + NB) = 0;
   __syncthreads();
 
   int bad_pivot = 0;
   if (wave == 0) micro_potrf_inv<PUB>(T + tile_off(0, 0), Wc, p.img + tile_off(0, 0), lane, ln, 0, bad_pivot);
   __syncthreads();
 
+  // Round 5: ONE barrier per micro step, and wave 0 carries nothing but the serial chain.  After the barrier of step jb
+  // (W_jb and L_jb,jb in LDS, every tile up to date with the steps before jb):
+  //   wave 0       X(jb+1, jb) = A(jb+1, jb) W^T, kept in registers -> D(jb+1, jb+1) -= X X^T straight from those
+  //                registers (a finished C/D tile IS the next product's operand, mfma_f64.h) -> POTRF16 + INV16 of it
+  //   waves 1 - 3  the other tiles of column jb (MFMA TRSM), z_jb; then - after a hand-shake through an LDS counter
+  //                that wave 0 only signals, never waits for - the SYRK of every trailing tile but wave 0's, the y update
+  // Rounds 1-4 ran the TRSM stage on all four waves, a barrier, then the SYRK stage: two barriers per step, and wave 0
+  // waited at the first one for the slowest TRSM wave (two tiles) before it could touch the next diagonal tile.
+  int *hs = reinterpret_cast<int *>(ys + NB);  // (the hand-shake counter: zeroed in the prologue, only grows)
 #pragma unroll 1
   for (int jb = 0; jb < NMB; ++jb) {
     const int o = jb * MB;
     const double *W = Wc + (jb & 1) * (MB * MB);
-    // ---- stage A: micro TRSM of the tiles below, X <- X W^T, one tile per wave ----
-    for (int ib = jb + 1 + wave; ib < NMB; ib += 4) {
+    auto trsm_tile = [&](int ib, v4d &x) {  // X <- X W^T for tile (ib, jb): final element (ln, lg + 4 r) of L in x[r]
       double *X = T + tile_off(ib, jb);
       v4d acc0 = v4zero(), acc1 = v4zero();
       acc0 = mfma16(W[(0 + lg) * MB + ln], X[(0 + lg) * MB + ln], acc0);
       acc1 = mfma16(W[(4 + lg) * MB + ln], X[(4 + lg) * MB + ln], acc1);
       acc0 = mfma16(W[(8 + lg) * MB + ln], X[(8 + lg) * MB + ln], acc0);
       acc1 = mfma16(W[(12 + lg) * MB + ln], X[(12 + lg) * MB + ln], acc1);
+      x = acc0 + acc1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double x = acc0[r] + acc1[r];  // final: element (ln, lg + 4 r) of tile (ib, jb) of L (the image holds -L)
-        X[(lg + 4 * r) * MB + ln] = x;
-        if constexpr (PUB) store_pub(p.img + tile_off(ib, jb) + (lg + 4 * r) * MB + ln, -x);
-        else p.img[tile_off(ib, jb) + (lg + 4 * r) * MB + ln] = -x;
+        X[(lg + 4 * r) * MB + ln] = x[r];
+        if constexpr (PUB) store_pub(p.img + tile_off(ib, jb) + (lg + 4 * r) * MB + ln, -x[r]);  // (the image holds -L)
+        else p.img[tile_off(ib, jb) + (lg + 4 * r) * MB + ln] = -x[r];
       }
-    }
-    // z_jb = W y_jb  (wave 3; reads precede the write in program order)
-    if (wave == 3) {
-      double zz = 0.;
-#pragma unroll
-      for (int c = 0; c < MB; ++c) zz += W[c * MB + ln] * ys[o + c];
-      if (lane < MB) ys[o + ln] = zz;
-    }
-    __syncthreads();
-    if (jb == NMB - 1) break;
-
-    // ---- stage B: wave 0 updates the NEXT diagonal tile and factors it right
-    // away (look-ahead) while waves 1-3 run the remaining SYRK tiles + y update
+    };
     if (wave == 0) {
-      micro_syrk_tile(T, jb + 1, jb + 1, jb, ln, lg);
-      micro_potrf_inv<PUB>(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB), p.img + tile_off(jb + 1, jb + 1),
-                           lane, ln, o + MB, bad_pivot);
-    } else {
-      const int rem = NMB - 1 - jb;
-      const int ntile = rem * (rem + 1) / 2;
-      auto tile_of = [&](int tix, int &ib, int &kb) {
-        int left = tix;
-        kb = 0;
-        while (left >= rem - kb) { left -= rem - kb; ++kb; }
-        ib = jb + 1 + kb + left;
-        kb = jb + 1 + kb;
-      };
-      // tix 0 is the diagonal tile done by wave 0; two tiles per trip: four independent MFMA chains
-      int tix = wave;
-      for (; tix + 3 < ntile; tix += 6) {
-        int i0, k0, i1, k1;
-        tile_of(tix, i0, k0);
-        tile_of(tix + 3, i1, k1);
-        micro_syrk_tile2(T, i0, k0, i1, k1, jb, ln, lg);
-      }
-      if (tix < ntile) {
-        int i0, k0;
-        tile_of(tix, i0, k0);
-        micro_syrk_tile(T, i0, k0, jb, ln, lg);
-      }
-      const int row = o + MB + (tid - 64);
-      if (row < NB) {
-        const double *Xr = T + tile_off(row >> 4, jb) + (row & 15);
-        double s = ys[row];
+      if (jb + 1 < NMB) {
+        v4d x;
+        trsm_tile(jb + 1, x);
+        if (lane == 0) __hip_atomic_fetch_add(hs, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // X(jb + 1, jb) is in LDS
+        double *Cc = T + tile_off(jb + 1, jb + 1);
+        v4d c0, c1 = v4zero();
 #pragma unroll
-        for (int k = 0; k < MB; ++k) s -= Xr[k * MB] * ys[o + k];
-        ys[row] = s;
+        for (int r = 0; r < 4; ++r) c0[r] = Cc[(lg + 4 * r) * MB + ln];
+        c0 = mfma16(-x[0], x[0], c0);
+        c1 = mfma16(-x[1], x[1], c1);
+        c0 = mfma16(-x[2], x[2], c0);
+        c1 = mfma16(-x[3], x[3], c1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cc[(lg + 4 * r) * MB + ln] = c0[r] + c1[r];
+        micro_potrf_inv<PUB>(Cc, Wc + ((jb + 1) & 1) * (MB * MB), p.img + tile_off(jb + 1, jb + 1), lane, ln, o + MB, bad_pivot);
+      }
+    } else {
+      for (int ib = jb + 1 + wave; ib < NMB; ib += 3) {  // (wave 1 starts at jb + 2)
+        v4d x;
+        trsm_tile(ib, x);
+      }
+      // z_jb = W y_jb  (wave 3; reads precede the write in program order)
+      if (wave == 3) {
+        double zz = 0.;
+#pragma unroll
+        for (int c = 0; c < MB; ++c) zz += W[c * MB + ln] * ys[o + c];
+        if (lane < MB) ys[o + ln] = zz;
+      }
+      if (jb + 1 < NMB) {
+        // all of column jb (and z_jb) in LDS?  Three of these waves + wave 0 per step.
+        if (lane == 0) __hip_atomic_fetch_add(hs, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int want = 4 * (jb + 1);
+        while (__hip_atomic_load(hs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+        const int rem = NMB - 1 - jb;
+        const int ntile = rem * (rem + 1) / 2;
+        auto tile_of = [&](int tix, int &ib, int &kb) {
+          int left = tix;
+          kb = 0;
+          while (left >= rem - kb) { left -= rem - kb; ++kb; }
+          ib = jb + 1 + kb + left;
+          kb = jb + 1 + kb;
+        };
+        // tix 0 is the diagonal tile done by wave 0; two tiles per trip: four independent MFMA chains
+        int tix = wave;
+        for (; tix + 3 < ntile; tix += 6) {
+          int i0, k0, i1, k1;
+          tile_of(tix, i0, k0);
+          tile_of(tix + 3, i1, k1);
+          micro_syrk_tile2(T, i0, k0, i1, k1, jb, ln, lg);
+        }
+        if (tix < ntile) {
+          int i0, k0;
+          tile_of(tix, i0, k0);
+          micro_syrk_tile(T, i0, k0, jb, ln, lg);
+        }
+        const int row = o + MB + (tid - 64);
+        if (row < NB) {
+          const double *Xr = T + tile_off(row >> 4, jb) + (row & 15);
+          double s = ys[row];
+#pragma unroll
+          for (int k = 0; k < MB; ++k) s -= Xr[k * MB] * ys[o + k];
+          ys[row] = s;
+        }
       }
     }
     __syncthreads();
@@ -703,9 +694,13 @@ __device__ __forceinline__ void trail_store_pass(double *__restrict__ Ls, const 
 // acknowledged before the next tile's loads could even be issued).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool PUBLISH = false>
+// K: depth of the product (a multiple of 64; the panel P is K columns wide) - passes of 64 through LDS, the next pass's
+// loads in flight while this one multiplies.  WT: write-through stores (see below); false: plain stores.
+
+template <bool PUBLISH = false, bool WT = true>
 __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const double *__restrict__ P, long long ld, long long M,
-                                             long long i0, long long j0, double *lds, unsigned long long *done = nullptr) {
+                                             long long i0, long long j0, double *lds, unsigned long long *done = nullptr,
+                                             int K = NB) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1, ln = lane & 15, lg = lane >> 4;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(P) & 15) == 0) && ((ld & 1) == 0);
@@ -725,15 +720,16 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
         acc[tj][ti][r] = (row < M && col < M) ? Cc[row + col * ld] : 0.;
       }
     }
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass) lds_barrier();  // the first pass's readers are done with the buffers
+  const int npass = K / 64;
+#pragma unroll 2
+  for (int pass = 0; pass < npass; ++pass) {
+    if (pass) lds_barrier();  // the previous pass's readers are done with the buffers
     trail_store_pass<false>(As, ra);
     trail_store_pass<true>(Bs, rb);
     lds_barrier();
-    if (pass == 0) {
-      trail_load_pass(P, ld, i0, M, 64, vec_ok, ra);
-      trail_load_pass(P, ld, j0, M, 64, vec_ok, rb);
+    if (pass + 1 < npass) {
+      trail_load_pass(P, ld, i0, M, 64 * (pass + 1), vec_ok, ra);
+      trail_load_pass(P, ld, j0, M, 64 * (pass + 1), vec_ok, rb);
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -761,7 +757,10 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
         // device-scope (write-through) stores for every tile: what a step launch writes is read by the NEXT launch, on other
         // XCDs - left dirty in this XCD's L2 it is written back at the kernel boundary, R^2 / 2 doubles at once, and the
         // next launch's first loads (the diagonal block's update, on its critical path) queue behind that
-        if (row < M && col < M) store_pub(Cc + row + col * ld, acc[tj][ti][r]);
+        if (row < M && col < M) {
+          if (WT) store_pub(Cc + row + col * ld, acc[tj][ti][r]);
+          else Cc[row + col * ld] = acc[tj][ti][r];
+        }
       }
     }
   if constexpr (PUBLISH) {
@@ -908,12 +907,48 @@ static bool step_fits(agp_context *ctx, long long rows) {
   return ctx->tune.step_below > 0 && rows <= ctx->tune.step_below && step_slots(ctx) >= 10 + rows / 64 + 64;
 }
 
-// Before the fused panel kernels of one factorisation run: sentinel-fill the tile images of the diagonal blocks
-// [k_begin, k_end) and the z slots of those rows (stream-ordered before the first panel launch on `s`).
-// A no-op (and the two-launch path is used) if the fused kernel is off or the z buffer cannot be allocated.
-void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long long k_begin, long long k_end, bool want_step) {
+__global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
+  int e = 0;
+  while (e + 1 < a.n && (long long)blockIdx.x >= a.first_block[e + 1]) ++e;
+  const long long i0 = ((long long)blockIdx.x - a.first_block[e]) * 1024 + threadIdx.x;
+  unsigned long long *d = a.dst[e];
+  const unsigned long long *sr = a.src[e];
+  const unsigned long long pat = a.pattern[e];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = i0 + 256 * u;
+    if (i < a.count[e]) d[i] = sr ? sr[i] : pat;
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_table_kernel(const CopyItem *__restrict__ table) {
+  const CopyItem it = table[blockIdx.y];
+  const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = i0 + 256 * u;
+    if (i < it.words) it.dst[i] = it.src[i];
+  }
+}
+
+void launch_copy_table(hipStream_t s, const CopyItem *table_dev, long long count, long long max_words) {
+  if (count <= 0 || max_words <= 0) return;
+  hipLaunchKernelGGL(copy_table_kernel, dim3((unsigned)((max_words + 1023) / 1024), (unsigned)count), dim3(256), 0, s, table_dev);
+}
+
+void launch_prep(hipStream_t s, const PrepArgs &a) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)a.first_block[a.n]), dim3(256), 0, s, a);
+}
+
+// Before the fused panel kernels of one factorisation run: the tile images of the diagonal blocks [k_begin, k_end) and
+// the z slots of those rows are sentinel-filled (and, for step launches, the second image and the row counters).
+// panel_fused_plan makes sure the buffers exist and APPENDS the fills to `prep`, which the caller launches (stream-ordered
+// before the first panel launch) together with whatever else it has to fill or copy; panel_fused_prepare is plan + launch.
+// Not planned (and the two-launch path is used) if the fused kernel is off or a buffer cannot be allocated.
+bool panel_fused_plan(agp_context *ctx, double *invd, long long k_begin, long long k_end, bool want_step, PrepArgs *prep) {
   ctx->img_ready = nullptr;
-  if (!ctx->tune.panel_fused || k_end <= k_begin) return;
+  if (!ctx->tune.panel_fused || k_end <= k_begin) return false;
   if (ctx->zpub_cap < k_end) {
     // grow; the old buffer may still be read by kernels in flight on this context's streams: drain them first
     (void)hipStreamSynchronize(ctx->stream);
@@ -921,7 +956,7 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
     ctx->d_zpub = nullptr;
     ctx->zpub_cap = 0;
     const long long cap = (k_end + 4095) / 4096 * 4096;
-    if (hipMalloc(&ctx->d_zpub, sizeof(double) * (size_t)cap) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipMalloc(&ctx->d_zpub, sizeof(double) * (size_t)cap) != hipSuccess) { (void)hipGetLastError(); return false; }
     ctx->zpub_cap = cap;
   }
   const long long b0 = k_begin / NB, b1 = (k_end + NB - 1) / NB;
@@ -941,14 +976,19 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
   }
   const long long cnt_img = (b1 - b0) * (long long)IMG_DOUBLES, cnt_z = k_end - k_begin;
   if (ctx->d_dpub && ctx->dpub_cap >= b1) {
-    (void)hipMemsetAsync(ctx->d_rowcnt + 2 * b0, 0, sizeof(unsigned long long) * 2 * (size_t)(b1 - b0), s);
-    hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_img + 255) / 256)), dim3(256), 0, s,
-                       ctx->d_dpub + b0 * (long long)IMG_DOUBLES, cnt_img);
+    prep->fill(ctx->d_rowcnt + 2 * b0, 0ull, 2 * (b1 - b0));
+    prep->sentinel(ctx->d_dpub + b0 * (long long)IMG_DOUBLES, cnt_img);
   }
-  hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_img + 255) / 256)), dim3(256), 0, s, invd + b0 * (long long)IMG_DOUBLES, cnt_img);
-  hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)((cnt_z + 255) / 256)), dim3(256), 0, s, ctx->d_zpub + k_begin, cnt_z);
+  prep->sentinel(invd + b0 * (long long)IMG_DOUBLES, cnt_img);
+  prep->sentinel(ctx->d_zpub + k_begin, cnt_z);
   ctx->zpub_ready_n = k_end;
   ctx->img_ready = invd;
+  return true;
+}
+
+void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long long k_begin, long long k_end, bool want_step) {
+  PrepArgs prep;
+  if (panel_fused_plan(ctx, invd, k_begin, k_end, want_step, &prep)) launch_prep(s, prep);
 }
 
 // Panel phase of one outer block [K0, kend): for every NB-wide diagonal block
@@ -1129,7 +1169,9 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   const int variant = ctx->update_variant;
   long long kend = K0 + pick_nbo(n, nbo_fixed);
   if (kend > n) kend = n;
-  panel_fused_prepare(ctx, sa, invd, 0, n, true);
+  // (agp_fit_create has already planned and launched the fills together with its own: prep_external)
+  if (!(ctx->prep_external && ctx->img_ready == invd && ctx->zpub_ready_n >= n)) panel_fused_prepare(ctx, sa, invd, 0, n, true);
+  ctx->prep_external = false;
   // the chain-bound tail as one launch per panel on this stream (panel_phase step_mode) once few enough rows are left
   auto step_ok = [&](long long remaining) { return nbo_fixed == 0 && step_fits(ctx, remaining) && step_ready(ctx, invd, n); };
   const bool step_all = step_ok(n);  // small matrix: every panel

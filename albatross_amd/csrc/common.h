@@ -124,6 +124,7 @@ struct agp_context {
     bool panel_fused = true;       // AGP_PANEL_FUSED=0: POTRF and panel TRSM as two launches
     long long step_below = 4608;   // AGP_STEP_BELOW: remaining rows at or below which every panel is ONE step launch (0: off)
     bool gram_sop = true;          // AGP_GRAM_SOP=0: covariance trees through the stack interpreter only
+    bool backsub_coop = true;      // AGP_BACKSUB_COOP=0: the fit's back substitution as a launch per block (rounds 1-4) instead of ONE launch
     bool sparse_pivoted = false;   // AGP_SPARSE_PIVOTED=1: the sparse GP's literal (pivoted LDL^T + QR) path always
     long long predict_chunk = 0;   // AGP_PREDICT_CHUNK: test points per slice of the marginal / joint predictions (0: by memory)
     long long shard_block = 0;     // AGP_SHARD_BLOCK: 128 / 256 / 512 rows per row block of the sharded fit (0: 512)
@@ -140,6 +141,7 @@ struct agp_context {
   long long bs_BW = 0, bs_done = 0;
   hipEvent_t ev_inv = nullptr;
   const double *img_ready = nullptr;
+  bool prep_external = false;  // the caller of factor_lower has made the fills of panel_fused_plan itself (api.hip: fit_create_impl)
   // sharded fit, device-side pacing (shard_hip.hip: HipShardOps): one flag per schedule event + probe flags in device
   // memory, their sequence numbers (monotonic over the life of the context), and the pacing mode (-1: not decided yet)
   hipStream_t stream_comm = nullptr;  // queue of the collectives (created by the first sharded call)
@@ -206,6 +208,11 @@ bool launch_gram_blocks(hipStream_t s, const DevProgram *host_program, const Fea
 void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y,
                  bool symmetric, bool lower_only, double *out, long long ld,
                  const double *diag_add, int *nan_flag, const DevProgram *host_program = nullptr);
+// `count` symmetric lower-only Gram matrices in ONE launch when every problem takes the same fast path (gram.hip); false:
+// not applicable, nothing launched.  table_dev: gram_batch_table_bytes(count) bytes of device scratch.
+size_t gram_batch_table_bytes(long long count);
+bool launch_gram_batch(hipStream_t s, long long count, const DevProgram *const *host_programs, const FeatView *Xs, double *const *outs,
+                       long long ld, const double *const *diag_adds, int *const *nan_flags, void *table_dev);
 void launch_gram_diagonal(hipStream_t s, const DevProgram *P, const FeatView &X, double *out);
 // mean_j = sum_i k(x_i, xs_j) alpha_i without materialising the cross Gram
 void launch_predict_mean(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &XS,
@@ -223,6 +230,8 @@ struct FactorTimers {
 };
 void factor_lower(agp_context *ctx, double *A, long long n, long long lda, double *invd, double *y,
                   FactorTimers *timers);
+struct PrepArgs;  // pub.h
+bool panel_fused_plan(agp_context *ctx, double *invd, long long k_begin, long long k_end, bool want_step, PrepArgs *prep);
 
 // Winv[b] = inv(L_bb) for every NB x NB diagonal block (batched, one launch)
 void invert_diag_blocks(hipStream_t s, const double *A, long long n, long long lda, const double *invd,
@@ -246,6 +255,11 @@ void factor_lower_batched_lookahead(agp_context *ctx, double *A, long long strid
 // z_b <- L_b^-T z_b for `count` problems, one vector each (solve.hip)
 void backward_solve_vec_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
                                 const double *invd, long long stride_invd, double *z, long long stride_z, long long count);
+// x = L^-T z in ONE launch (solve.hip: backsub_coop_kernel); x must be sentinel-filled (launch_fill_sentinel / PrepArgs)
+void backward_solve_coop(hipStream_t s, const double *A, long long n, long long lda, const double *invd, const double *z,
+                         double *x, int *flags, long long count = 1, long long stride_A = 0, long long stride_invd = 0,
+                         long long stride_z = 0, long long stride_x = 0, long long stride_flags = 0);
+void launch_fill_sentinel(hipStream_t s, double *p, long long count);
 void forward_solve_mat_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
                                const double *invd, long long stride_invd, double *B, long long stride_B, long long m,
                                long long ldb, bool rhs_lower, long long count);

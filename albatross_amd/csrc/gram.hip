@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include "common.h"
 
 namespace agp {
@@ -177,9 +178,8 @@ __device__ __forceinline__ double radial_fast(double s2, const FastParams &fp) {
 }
 
 template <int DIMP, int OP>
-__global__ __launch_bounds__(GRAM_THREADS) void gram_fast_kernel(FastParams fp, FeatView X, FeatView Y, int lower_only,
-                                                                 double *out, long long ld, const double *diag_add,
-                                                                 int *nan_flag, long long blk_rows, long long blk_stride) {
+__device__ __forceinline__ void gram_fast_body(const FastParams &fp, FeatView X, FeatView Y, int lower_only, double *out, long long ld,
+                                               const double *diag_add, int *nan_flag, long long blk_rows, long long blk_stride) {
   __shared__ double xs[DIMP][TM], ys[DIMP][TN];
   __shared__ long long xid[TM], yid[TN];
   if (blk_rows > 0) {  // blockIdx.z = one diagonal block of a block-diagonal Gram matrix (launch_gram_blocks)
@@ -260,6 +260,31 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_fast_kernel(FastParams fp, 
     }
   }
   if (saw_nan && nan_flag) atomicOr(nan_flag, 1);
+}
+
+template <int DIMP, int OP>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_fast_kernel(FastParams fp, FeatView X, FeatView Y, int lower_only,
+                                                                 double *out, long long ld, const double *diag_add,
+                                                                 int *nan_flag, long long blk_rows, long long blk_stride) {
+  gram_fast_body<DIMP, OP>(fp, X, Y, lower_only, out, ld, diag_add, nan_flag, blk_rows, blk_stride);
+}
+
+// `count` symmetric Gram matrices of one SHAPE (same fast-path operator, same DIMP) but their own parameters and
+// features in ONE launch: blockIdx.z = problem, described by a table in device memory (agp_fit_create_batch and
+// agp_nll_batch built them with one launch per problem: 256 launches are 1.2 ms of host enqueue time).
+struct GramBatchItem {
+  FastParams fp;
+  FeatView X;
+  double *out;
+  const double *diag_add;
+  int *nan_flag;
+};
+
+template <int DIMP, int OP>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_fast_batch_kernel(const GramBatchItem *__restrict__ items, int lower_only, long long ld) {
+  const GramBatchItem it = items[blockIdx.z];
+  if ((long long)blockIdx.x * TM >= it.X.n || (long long)blockIdx.y * TN >= it.X.n) return;
+  gram_fast_body<DIMP, OP>(it.fp, it.X, it.X, lower_only, it.out, ld, it.diag_add, it.nan_flag, 0, 0);
 }
 
 // Does the program have one of the fast-path shapes?
@@ -630,6 +655,53 @@ bool launch_gram_blocks(hipStream_t s, const DevProgram *host_program, const Fea
   if (X.dim == 1) return launch_gram_fast_t<1>(s, fp, op, X, X, true, out, ld, diag_add, nan_flag, rows, stride, count);
   if (X.dim == 2) return launch_gram_fast_t<2>(s, fp, op, X, X, true, out, ld, diag_add, nan_flag, rows, stride, count);
   return launch_gram_fast_t<3>(s, fp, op, X, X, true, out, ld, diag_add, nan_flag, rows, stride, count);
+}
+
+size_t gram_batch_table_bytes(long long count) { return sizeof(GramBatchItem) * (size_t)(count > 0 ? count : 0); }
+
+// Symmetric (lower-only) Gram matrices of `count` problems in one launch when all of them take the same fast path
+// (radial<Euclidean> [+ noise], dim <= 3, same operator): false = not applicable, nothing launched.
+// table_dev: gram_batch_table_bytes(count) bytes of device scratch the launch reads (must stay valid until it has run).
+bool launch_gram_batch(hipStream_t s, long long count, const DevProgram *const *host_programs, const FeatView *Xs, double *const *outs,
+                       long long ld, const double *const *diag_adds, int *const *nan_flags, void *table_dev) {
+  if (count <= 0 || count > 65535 || !table_dev || !sop_enabled()) return false;
+  std::vector<GramBatchItem> items((size_t)count);
+  int op0 = 0, dim0 = 0;
+  long long nmax = 0;
+  for (long long b = 0; b < count; ++b) {
+    GramBatchItem &it = items[(size_t)b];
+    int op = 0;
+    if (!host_programs[b] || Xs[b].dim > 3 || !match_fast(*host_programs[b], &it.fp, &op)) return false;
+    if (b == 0) { op0 = op; dim0 = Xs[b].dim; }
+    else if (op != op0 || Xs[b].dim != dim0) return false;
+    it.X = Xs[b];
+    it.out = outs[b];
+    it.diag_add = diag_adds ? diag_adds[b] : nullptr;
+    it.nan_flag = nan_flags ? nan_flags[b] : nullptr;
+    if (Xs[b].n > nmax) nmax = Xs[b].n;
+  }
+  if (nmax <= 0) return true;
+  if (hipMemcpyAsync(table_dev, items.data(), sizeof(GramBatchItem) * (size_t)count, hipMemcpyHostToDevice, s) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  (void)hipStreamSynchronize(s);  // (pageable source: the vector goes out of scope)
+  dim3 grid((unsigned)((nmax + TM - 1) / TM), (unsigned)((nmax + TN - 1) / TN), (unsigned)count), block(GRAM_THREADS);
+  auto *tab = static_cast<const GramBatchItem *>(table_dev);
+#define AGP_GB(D, O) hipLaunchKernelGGL((gram_fast_batch_kernel<D, O>), grid, block, 0, s, tab, 1, ld)
+#define AGP_GB_DIM(D)                                                        \
+  switch (op0) {                                                             \
+  case AGP_OP_SQUARED_EXPONENTIAL: AGP_GB(D, AGP_OP_SQUARED_EXPONENTIAL); break; \
+  case AGP_OP_EXPONENTIAL: AGP_GB(D, AGP_OP_EXPONENTIAL); break;             \
+  case AGP_OP_MATERN32: AGP_GB(D, AGP_OP_MATERN32); break;                   \
+  default: AGP_GB(D, AGP_OP_MATERN52); break;                                \
+  }
+  if (dim0 == 1) { AGP_GB_DIM(1) }
+  else if (dim0 == 2) { AGP_GB_DIM(2) }
+  else { AGP_GB_DIM(3) }
+#undef AGP_GB_DIM
+#undef AGP_GB
+  return true;
 }
 
 void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &Y, bool symmetric,

@@ -8,6 +8,7 @@
 #include "mfma_f64.h"
 #include "gemm_tiles.h"
 #include "trsm_kernel.h"
+#include "pub.h"
 
 namespace agp {
 void launch_set_identity_batched(hipStream_t s, double *B, long long ld, long long stride, long long m, long long count);  // reduce.hip
@@ -448,6 +449,118 @@ void backward_solve_vec_batched(hipStream_t s, const double *A, long long stride
     if (k > 0)  // z[0 : k] -= L[k : k + nbk, 0 : k]^T x
       launch_colvec_dot_strided(s, A + k, lda, stride_A, nbk, k, z + k, stride_z, -1.0, 1.0, z, z, count);
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// x = L^-T z for ONE vector in ONE launch (round 5).
+// The launch-per-block chains above cost a launch (4-8 us of stream time) per 128 or 512 rows - 45 us at N = 512,
+// 190 us at N = 4096 (of which 108 us to invert the wide diagonal blocks), 0.6 ms at N = 16384 - for a computation
+// whose serial part is a 128 x 128 substitution per block.  Here workgroup b owns the 128-column block column b:
+//   acc_b = sum_{j > b} L[block row j, block column b]^T x_j   accumulated block row by block row as the x_j appear
+//   x_b   = L_bb^-T (z_b - acc_b)                              micro-block substitution against the tile image in LDS
+// and PUBLISHES x_b in the output vector itself: `x` is sentinel-filled before the launch, written with device-scope
+// stores and polled with device-scope loads (pub.h) - no flags, no atomics.  Every workgroup but the one that owns
+// block row j is AHEAD of its next dependency (it consumes x_j while the owner of block j - 1 is still substituting),
+// so the chain per block is: one hand-over (~1 us), 32 FMAs per lane, one butterfly reduction, the substitution.
+// Liveness does not need co-residency: blockIdx.x = 0 is the LAST block, workgroups are dispatched in order, and a
+// workgroup only ever waits for blocks dispatched before it.  blockIdx.y = problem of a batch.
+// Layout of the work inside a workgroup (512 threads): wave w owns the columns 16 w .. 16 w + 15 of the block column,
+// lane l the rows l and l + 64 of the current block row - coalesced 512-B column segments, 32 values in flight per lane,
+// requested right after the previous block row has been consumed (the next x is ~3 us away).
+// ---------------------------------------------------------------------------------------------------------------
+struct BackCoopArgs {
+  const double *A;
+  long long lda, n;
+  const double *img;  // tile images of the diagonal blocks (IMG_DOUBLES each)
+  const double *z;    // right-hand side
+  double *x;          // solution (sentinel-filled by the caller)
+  int *flags;         // flags[2]: a hand-over timed out
+  long long batch_A = 0, batch_img = 0, batch_z = 0, batch_x = 0, batch_flags = 0;
+};
+
+__global__ __launch_bounds__(512) void backsub_coop_kernel(BackCoopArgs p) {
+  __shared__ double F[IMG_DOUBLES];
+  __shared__ double ts[NB];
+  {
+    const long long pb = blockIdx.y;
+    p.A += pb * p.batch_A; p.img += pb * p.batch_img; p.z += pb * p.batch_z; p.x += pb * p.batch_x; p.flags += pb * p.batch_flags;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long nb = (p.n + NB - 1) / NB;
+  const long long b = nb - 1 - (long long)blockIdx.x;
+  const long long k0 = b * NB;
+  const int nbk = (int)((p.n - k0 < NB) ? p.n - k0 : NB);
+  // the image of this block: needed only at the very end, requested first
+  {
+    const double *src = p.img + b * (long long)IMG_DOUBLES;
+#pragma unroll
+    for (int it = 0; it < IMG_DOUBLES / 2 / 512; ++it) {
+      const int e = 2 * (tid + 512 * it);
+      *reinterpret_cast<double2 *>(F + e) = *reinterpret_cast<const double2 *>(src + e);
+    }
+  }
+  double acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.;
+  const long long c0 = k0 + 16 * wave;  // first column of this wave
+  double a0[16], a1[16];
+  auto load_rows = [&](long long j) {
+    const long long r0 = j * NB + lane, r1 = r0 + 64;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long long c = c0 + q;
+      const double *col = p.A + c * p.lda;
+      a0[q] = (c < p.n && r0 < p.n) ? col[r0] : 0.;
+      a1[q] = (c < p.n && r1 < p.n) ? col[r1] : 0.;
+    }
+  };
+  if (nb - 1 > b) load_rows(nb - 1);
+  for (long long j = nb - 1; j > b; --j) {
+    const long long r0 = j * NB + lane, r1 = r0 + 64;
+    double x0 = 0., x1 = 0.;
+    {
+      unsigned long long t0 = 0;
+      for (int spin = 0;; ++spin) {
+        x0 = (r0 < p.n) ? load_pub(p.x + r0) : 0.;
+        x1 = (r1 < p.n) ? load_pub(p.x + r1) : 0.;
+        if (__all(!is_unpublished(x0) && !is_unpublished(x1))) break;
+        if (spin == 0) t0 = __builtin_amdgcn_s_memrealtime();
+        else if ((spin & 63) == 0 && poll_expired(t0, p.flags)) { x0 = x1 = 0.; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] += a0[q] * x0 + a1[q] * x1;
+    if (j - 1 > b) load_rows(j - 1);
+  }
+  const double sum = colsum16(acc);  // (trsm_kernel.h)
+  if (lane < 16) {
+    const int c = 16 * wave + colsum16_index(lane);
+    ts[c] = (c < nbk) ? p.z[k0 + c] - sum : 0.;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // x_b = L_bb^-T t by micro blocks (trsm_kernel.h), every value published the moment it is final
+  micro_backsub_wave(F, ts, [&](int c, double v) { if (c < nbk) store_pub(p.x + k0 + c, v); });
+}
+
+// x (n, sentinel-filled by the caller: PrepArgs::sentinel / launch_fill_sentinel) = L^-T z; count problems (strides 0 for one)
+void backward_solve_coop(hipStream_t s, const double *A, long long n, long long lda, const double *invd, const double *z,
+                         double *x, int *flags, long long count, long long stride_A, long long stride_invd, long long stride_z,
+                         long long stride_x, long long stride_flags) {
+  if (n <= 0 || count <= 0) return;
+  BackCoopArgs p;
+  p.A = A; p.lda = lda; p.n = n; p.img = invd; p.z = z; p.x = x; p.flags = flags;
+  p.batch_A = stride_A; p.batch_img = stride_invd; p.batch_z = stride_z; p.batch_x = stride_x; p.batch_flags = stride_flags;
+  const long long nb = (n + NB - 1) / NB;
+  hipLaunchKernelGGL(backsub_coop_kernel, dim3((unsigned)nb, (unsigned)count), dim3(512), 0, s, p);
+}
+
+void launch_fill_sentinel(hipStream_t s, double *p, long long count) {
+  PrepArgs a;
+  a.sentinel(p, count);
+  launch_prep(s, a);
 }
 
 // ---- X = L^-1 B out of place for a right-hand side MUCH wider than L (the sparse GP's m x n matrices K_uf and W, n in the

@@ -47,30 +47,12 @@ struct TrsmArgs {
   long long batch_z = 0;  // FUSE_Y: offset of z / yrest per batch entry
 };
 
+// the fragment image of L11 into LDS (F: NFRAG_TILES * 256 doubles, zs: NB doubles); all 256 threads
+// Image element [tile * 256 + k * 16 + m] is the A-operand value T[m][k] of
+// the forward solve; the transposed solve needs T^T of every tile.
 template <bool TRANS, bool FUSE_Y>
-__global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
-  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);  // panel chain (see potrf_diag_kernel)
-  __shared__ double F[NFRAG_TILES * 4 * 64 + NB];
-  double *zs = F + NFRAG_TILES * 4 * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ln = lane & 15, lg = lane >> 4;
-  if (blockIdx.y > 0 || p.n_total > 0) {
-    const long long b = blockIdx.y;
-    p.img += b * p.batch_img;
-    p.Y += b * p.batch_Y;
-    if (FUSE_Y) {
-      p.z += b * p.batch_z;
-      p.yrest += b * p.batch_z;
-    }
-    if (p.n_total > 0) {
-      const long long left = p.n_total - b * NB;
-      p.nbk = (int)(left < NB ? left : NB);
-    }
-  }
-
-  // ---- stage the fragment image of L11 ----
-  // Image element [tile * 256 + k * 16 + m] is the A-operand value T[m][k] of
-  // the forward solve; the transposed solve needs T^T of every tile.
+__device__ __forceinline__ void trsm_micro_stage(const TrsmArgs &p, double *F, double *zs) {
+  const int tid = threadIdx.x;
   if (!TRANS) {
 #pragma unroll
     for (int it = 0; it < IMG_DOUBLES / 2 / 256; ++it) {
@@ -85,9 +67,13 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
     }
   }
   if (FUSE_Y && tid < NB) zs[tid] = (tid < p.nbk) ? p.z[tid] : 0.;
-  __syncthreads();
+}
 
-  const long long n0 = ((long long)blockIdx.x * 4 + wave) * 16;
+// one wave: the 16 columns n0 .. n0 + 15 of Y against the staged image (no barrier inside)
+template <bool TRANS, bool FUSE_Y>
+__device__ __forceinline__ void trsm_micro_solve(const TrsmArgs &p, const double *F, const double *zs, const long long n0) {
+  const int lane = threadIdx.x & 63;
+  const int ln = lane & 15, lg = lane >> 4;
   if (n0 >= p.ncols) return;
   const bool nok = n0 + ln < p.ncols;
   double *base = p.Y + (n0 + ln) * p.stride_n;
@@ -164,6 +150,93 @@ __global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
     part += __shfl_xor(part, 32, 64);
     if (lg == 0 && nok) p.yrest[n0 + ln] -= part;
   }
+}
+
+
+// x = L_bb^-T t for ONE vector by micro blocks, bottom-up, right-looking: one wave, values in registers.
+// lane = (k = lane >> 2, mq = lane & 3): element k of every micro block, replicated over the four mq lanes, which
+// split the sums over m.  Image tile (ib, kb) holds -L[16 ib + m][16 kb + k] at [k * 16 + m], the diagonal tile
+// inv(L_ii)[m][k] at the same place: both substitution steps are out[k] += sum_m tile[k * 16 + m] in[m].
+// F: the image in LDS (as stored), ts: t (NB doubles, LDS).  emit(index, value) receives x[16 jb + k] once, from the
+// mq == 0 lanes, as soon as it is final (bottom micro block first).
+template <class Emit>
+__device__ __forceinline__ void micro_backsub_wave(const double *F, const double *ts, Emit emit) {
+  const int lane = threadIdx.x & 63;
+  const int k = lane >> 2, mq = lane & 3;
+  double t[NMB];
+#pragma unroll
+  for (int jb = 0; jb < NMB; ++jb) t[jb] = ts[jb * MB + k];
+#pragma unroll
+  for (int jb = NMB - 1; jb >= 0; --jb) {
+    const double *D = F + tile_off(jb, jb) + k * MB + 4 * mq;
+    double part = 0.;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) part += D[u] * __shfl(t[jb], (4 * mq + u) << 2, 64);
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    const double xk = part;  // x[16 jb + k]
+    if (mq == 0) emit(jb * MB + k, xk);
+    if (jb == 0) break;
+    double xm[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xm[u] = __shfl(xk, (4 * mq + u) << 2, 64);
+#pragma unroll
+    for (int kb = 0; kb < jb; ++kb) {
+      const double *T = F + tile_off(jb, kb) + k * MB + 4 * mq;
+      double q = T[0] * xm[0] + T[1] * xm[1] + T[2] * xm[2] + T[3] * xm[3];
+      q += __shfl_xor(q, 1, 64);
+      q += __shfl_xor(q, 2, 64);
+      t[kb] += q;
+    }
+  }
+}
+
+// 16 per-lane partial sums (one per column) -> their totals over the 64 lanes: a butterfly that halves the live values
+// at every step (15 exchanges instead of 16 x 6), then the four 16-lane groups.  On return lanes 0 .. 15 hold the
+// total of column colsum16_index(lane).
+__device__ __forceinline__ double colsum16(double (&acc)[16]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int bit = 0; bit < 4; ++bit) {
+    const int half = 8 >> bit;
+    const bool up = (lane >> bit) & 1;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const double keep = up ? acc[i + half] : acc[i];
+      const double send = up ? acc[i] : acc[i + half];
+      acc[i] = keep + __shfl_xor(send, 1 << bit, 64);
+    }
+  }
+  double sum = acc[0];
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  return sum;
+}
+__device__ __forceinline__ int colsum16_index(int lane) {
+  return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+}
+
+template <bool TRANS, bool FUSE_Y>
+__global__ __launch_bounds__(256, 2) void trsm_micro_kernel(TrsmArgs p) {
+  __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO);  // panel chain (see potrf_diag_kernel)
+  __shared__ double F[NFRAG_TILES * 4 * 64 + NB];
+  double *zs = F + NFRAG_TILES * 4 * 64;
+  if (blockIdx.y > 0 || p.n_total > 0) {
+    const long long b = blockIdx.y;
+    p.img += b * p.batch_img;
+    p.Y += b * p.batch_Y;
+    if (FUSE_Y) {
+      p.z += b * p.batch_z;
+      p.yrest += b * p.batch_z;
+    }
+    if (p.n_total > 0) {
+      const long long left = p.n_total - b * NB;
+      p.nbk = (int)(left < NB ? left : NB);
+    }
+  }
+  trsm_micro_stage<TRANS, FUSE_Y>(p, F, zs);
+  __syncthreads();
+  trsm_micro_solve<TRANS, FUSE_Y>(p, F, zs, ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16);
 }
 
 }  // namespace agp

@@ -57,53 +57,93 @@ def make_dataset(n, seed):
     return x, y
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _oracle_cflags():
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "Makefile")) as f:
+            for line in f:
+                if line.startswith("CFLAGS"):
+                    return line.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seconds_budget=30.0):
-    """Oracle ("port") timed on host cores: albatross-faithful default = serial
-    Gram + single-threaded unblocked pivoted LDL^T.  Bounded sample, scaled to
-    fits/sec at N = 16384 by the N^3 law of the factorisation."""
+    """Oracle ("port") timed on host cores: albatross-faithful default = serial Gram + single-threaded unblocked pivoted
+    LDL^T (core/model.hpp:20; Eigen 3.3's LDLT has no blocked or parallel path).  BASELINE.md section 2 / SURVEY 8d: the
+    fit is timed at N in {1024, 2048, 4096, 6144} (about 16 s of CPU work), t(N) = a N^3 + b N^2 is fitted by least
+    squares and evaluated at N = 16384; the record carries the samples, the coefficients and the largest relative
+    residual of the fit, the host's CPU model, its core count and the oracle's compiler flags.  (The extrapolation is
+    conservative for the CPU: at 16384 the unblocked factor works on a 2 GiB matrix, out of every cache.)"""
     import albatross_amd as ab
     from oracle import oracle_py as orc
     cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
-    n = 1024
-    best = None
-    while True:
+    sizes, samples, spent = (1024, 2048, 4096, 6144), [], 0.0
+    for n in sizes:
+        if samples:  # the next size costs (n / n_prev)^3 of the previous one: stop before the budget is blown
+            n_prev, t_prev = samples[-1][0], samples[-1][2]
+            if spent + t_prev * (n / n_prev) ** 3 * 1.3 > seconds_budget:
+                break
         x, y = make_dataset(n, 44)
+        t0 = time.perf_counter()
+        _ = orc.gram(cov, x, x_meas=True, y_meas=True)
+        t_gram = time.perf_counter() - t0
+        del _
         t0 = time.perf_counter()
         fit = orc.OracleFit(cov, x, y)
         _ = fit.information
         dt = time.perf_counter() - t0
         del fit
-        best = (n, dt)
-        # next size costs ~8x (more once the matrix leaves the caches: x12); stop when it would blow the budget
-        if dt * 12.0 > seconds_budget or n >= 8192:
-            break
-        n *= 2
-    # one more sample at 1.5x the size when that still fits: the sample should be 10-30 s of CPU work
-    if best[1] * 3.375 * 1.5 <= seconds_budget and best[0] < 8192:
-        n = best[0] * 3 // 2
-        x, y = make_dataset(n, 44)
-        t0 = time.perf_counter()
-        fit = orc.OracleFit(cov, x, y)
-        _ = fit.information
-        best = (n, time.perf_counter() - t0)
-        del fit
-    n, dt = best
-    scaled = dt * (N_TRAIN / n) ** 3
+        samples.append((n, t_gram, dt))
+        spent += dt + t_gram
+    ns = np.array([s[0] for s in samples], dtype=np.float64)
+    ts = np.array([s[2] for s in samples])
+    if len(samples) >= 2:
+        M = np.stack([ns ** 3, ns ** 2], axis=1)
+        # relative least squares (every sample counts alike, not only the largest)
+        coef, *_ = np.linalg.lstsq(M / ts[:, None], np.ones_like(ts), rcond=None)
+        if coef[0] <= 0. or coef[1] < 0.:  # (no physical N^2 term: the pure cubic law, relative least squares)
+            a = float(np.sum(ns ** 3 / ts) / np.sum((ns ** 3 / ts) ** 2))
+            coef = np.array([a, 0.])
+        resid = float(np.abs((M @ coef) / ts - 1.).max())
+    else:
+        coef, resid = np.array([ts[-1] / ns[-1] ** 3, 0.]), 0.
+    scaled = float(coef[0] * N_TRAIN ** 3 + coef[1] * N_TRAIN ** 2)
+    cores_host = os.cpu_count() or 1
     out = {"value": 1.0 / scaled, "unit": "fits/sec", "cores": 1, "kind": "port",
-           "sample": f"one oracle fit (serial Gram + unblocked pivoted LDLT) at N={n}: {dt:.2f} s; "
-                     f"scaled by (16384/{n})^3 to N=16384"}
+           "sample": "oracle fits (serial Gram + unblocked pivoted LDLT, 1 thread) at N = "
+                     + ", ".join(f"{n}: {dt:.2f} s" for n, _, dt in samples)
+                     + f"; t(N) = {coef[0]:.3e} N^3 + {coef[1]:.3e} N^2 (relative least squares, max residual {100 * resid:.1f} %)"
+                     f" evaluated at N = {N_TRAIN}: {scaled:.0f} s",
+           "samples": [{"n": int(n), "gram_s": tg, "fit_s": dt} for n, tg, dt in samples],
+           "cubic_fit": {"a_n3": float(coef[0]), "b_n2": float(coef[1]), "max_rel_residual": resid},
+           "cpu_model": _cpu_model(), "nproc": cores_host, "compiler_flags": "gcc " + _oracle_cflags()}
     # BASELINE.md section 2, B2 "albatross-faithful, pooled": the Gram over all host cores (callers.hpp:134-166), the
-    # factor unchanged (Eigen's LDLT has no parallel path) - the same fit once more with the pooled Gram
+    # factor unchanged (Eigen's LDLT has no parallel path): only the Gram's share of the fit changes
     try:
-        cores = os.cpu_count() or 1
-        xg, yg = make_dataset(n, 44)
+        n, t_gram, dt = samples[-1]
+        xg, _y = make_dataset(n, 44)
         t0 = time.perf_counter()
-        fit = orc.OracleFit(cov, xg, yg, threads=cores)
-        _ = fit.information
-        t_pooled = time.perf_counter() - t0
-        del fit
-        out["pooled_gram"] = {"value": 1.0 / (t_pooled * (N_TRAIN / n) ** 3), "unit": "fits/sec", "cores": cores,
-                              "sample": f"the same oracle fit at N={n} with the Gram pooled over {cores} threads: {t_pooled:.2f} s"}
+        _ = orc.gram(cov, xg, x_meas=True, y_meas=True, threads=cores_host)
+        t_pool = time.perf_counter() - t0
+        del _
+        # Gram ~ N^2, factor ~ N^3: scale the two shares separately
+        gram_16k = t_gram * (N_TRAIN / n) ** 2
+        pooled_16k = scaled - gram_16k + t_pool * (N_TRAIN / n) ** 2
+        out["pooled_gram"] = {"value": 1.0 / pooled_16k, "unit": "fits/sec", "cores": cores_host,
+                              "sample": f"Gram at N={n}: serial {t_gram:.2f} s, pooled over {cores_host} threads {t_pool:.2f} s; "
+                                        f"the fit's Gram share (x (16384/{n})^2) exchanged, the single-threaded factor unchanged"}
     except Exception as exc:  # noqa: BLE001 - context only
         out["pooled_gram"] = {"error": f"{type(exc).__name__}: {exc}"}
     # For context (SURVEY.md 8d, "strong CPU"): the same fit with a blocked, multi-threaded LAPACK Cholesky (scipy) and a
@@ -213,7 +253,7 @@ def _device_features(torch, capi, x_d, n):
     return f
 
 
-def fit_batch_rates(ab, ctx, sizes=None, batches=(1, 8, 32)):
+def fit_batch_rates(ab, ctx, sizes=None, batches=(1, 8, 32, 256)):
     """Small / medium N, where the reference's own workloads live (benchmarks/bench_predict.cc:20-40: N = 512; the tuner loop):
     fits per second of agp_fit_create_batch - B independent fits of one shape in lock step, inputs resident in HBM - with the
     aggregate fraction of the fp64 MFMA peak.  B = 1 is agp_fit_create.  Config 2's covariance (Matern-5/2 + noise)."""
@@ -225,6 +265,8 @@ def fit_batch_rates(ab, ctx, sizes=None, batches=(1, 8, 32)):
     rows = []
     for n in (sizes or (512, 1024, 2048, 4096)):
         for B in batches:
+            if B > 1 and B * n * n * 8 > 6e9:  # (the slab of a batch: a few GB are plenty to fill the chip)
+                continue
             xs_d, feats = [], []
             ys = np.empty((n, B), order="F")
             for b in range(B):
@@ -250,17 +292,35 @@ def fit_batch_rates(ab, ctx, sizes=None, batches=(1, 8, 32)):
                     assert st == capi.AGP_OK and all(s == capi.AGP_OK for s in status), (st, list(status))
                     for b in range(B):
                         lib.agp_fit_destroy(C.c_void_p(out[b]))
-            step()
-            step()
-            reps = max(3, min(40, int(0.25 / (2e-4 * B * (n / 512.) ** 2))))
-            t = 1e9
+            # warm the clock: short kernels after an idle gap run at whatever the GPU had dropped to - at least 50 ms of the
+            # same work back to back before anything is timed (two driver runs of this table used to differ by 2x at N = 512)
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.05:
+                step()
+            reps = max(5, min(60, int(0.25 / (2e-4 * B * (n / 512.) ** 2))))
+            ts = []
             for _ in range(reps):
                 t0 = time.perf_counter()
                 step()
-                t = min(t, time.perf_counter() - t0)
+                ts.append(time.perf_counter() - t0)
+            t = min(ts)
             flop = B * n ** 3 / 3.
-            rows.append({"n": n, "batch": B, "ms_per_batch": 1e3 * t, "fits_per_sec": B / t,
-                         "frac_of_mfma_peak": flop / t / 1e12 / MFMA_F64_PEAK_TFLOPS, "tflops": flop / t / 1e12})
+            row = {"n": n, "batch": B, "ms_per_batch": 1e3 * t, "ms_median": 1e3 * sorted(ts)[len(ts) // 2], "reps": reps,
+                   "fits_per_sec": B / t, "frac_of_mfma_peak": flop / t / 1e12 / MFMA_F64_PEAK_TFLOPS, "tflops": flop / t / 1e12}
+            if B == 1:
+                # the GPU's own span of one fit (HIP events of the library's stage timers: Gram + factor + back substitution),
+                # next to the wall time of the call
+                lib.agp_set_profiling(ctx._h, 1)
+                step()
+                step()
+                span = 0.
+                for stage in (0, 1, 2):
+                    ms = C.c_double()
+                    lib.agp_last_stage_ms(ctx._h, stage, C.byref(ms))
+                    span += ms.value
+                lib.agp_set_profiling(ctx._h, 0)
+                row["gpu_span_ms"] = span
+            rows.append(row)
             del xs_d, y_d
     return rows
 
@@ -773,7 +833,7 @@ def run_rank(args):
     # correction applied) of the single-GPU run; null if absent or not applicable.
     traffic = traffic_src = None
     if world == 1 and not sharded and n == N_TRAIN:
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
                     traffic = json.load(fh)["traffic_bytes_per_launch"]
@@ -824,15 +884,19 @@ def run_rank(args):
                 "bound": "mfma", "kernel": kernel_name,
                 "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F64_PEAK_TFLOPS,
+                # NOT measured by this run (counters cannot be read from inside the benchmark process): the constant of the
+                # committed rocprofv3 --pmc passes of the same command, named in traffic_source; null when there is none
                 "traffic": traffic,
-                "traffic_unit": f"bytes per launch (rocprofv3 PMC passes, {traffic_src})" if traffic_src else None,
+                "traffic_unit": "bytes per launch" if traffic_src else None,
+                "traffic_source": f"constant from {traffic_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read "
+                                  "correction), not measured in this run" if traffic_src else None,
                 "launches_per_fit": gemm_launches / args.steps,
                 "avg_launch_ms": gemm_ms / max(gemm_launches, 1.0),
                 "flop_per_fit": gemm_flop / args.steps,
-                # context, not the contract's `peak`: the K-proportional part of this kernel's time per round of tiles
-                # (0.256 us per k and 512 tiles: profiles/r04/bulk_update_vs_k.txt) - what the loop would do with no
-                # per-tile fixed cost; alone at M = 15872, K = 512 the kernel does 52
-                "k_loop_rate_tflops": 65.0,
+                # context, not the contract's `peak` and not measured in this run: the K-proportional part of this kernel's
+                # time per round of tiles (0.256 us per k and 512 tiles) - what the loop would do with no per-tile fixed
+                # cost; alone at M = 15872, K = 512 the kernel does 52
+                "context": {"k_loop_rate_tflops": 65.0, "source": "constant from profiles/r04/bulk_update_vs_k.txt, not measured in this run"},
             },
             "stages_ms_per_fit": {"gram": gram_ms / args.steps, "factor": factor_ms / args.steps,
                                   "backward_solve": solve_ms / args.steps,

@@ -15,4 +15,4 @@ for n in 512 4096; do
 done
 find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
 cd "$ROOT"
-tail -20 "$OUT/time_fit_batch.txt" "$OUT/fit_resident.txt"
+tail -n 20 "$OUT/time_fit_batch.txt" "$OUT/fit_resident.txt"
