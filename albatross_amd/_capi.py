@@ -131,6 +131,9 @@ EXPORTS = [
     ("agp_solver_rows", C.c_int64, [_P]),
     ("agp_solver_solve", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int]),
     ("agp_solver_predict", C.c_int, [_P, _P, _P, C.POINTER(Features), _P, C.POINTER(Features), _P, _P, C.c_int, C.c_int]),
+    ("agp_solver_update_information", C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
+    ("agp_solver_predict_combined", C.c_int, [_P, _P, _P, C.POINTER(Features), C.c_int64, _P, _P, _P, C.POINTER(Features), C.c_int64, _P, _P,
+                                              _P, _P, C.c_int, C.c_int]),
     ("agp_solver_destroy", None, [_P]),
     ("agp_comm_unique_id", C.c_int, [_P]),
     ("agp_comm_create", C.c_int, [_P, C.c_int, C.c_int, _P, _PP]),

@@ -281,7 +281,7 @@ __device__ __forceinline__ void micro_syrk_tile2(double *T, int ib0, int kb0, in
   }
 }
 
-constexpr int POTRF_LDS_DOUBLES = IMG_DOUBLES + 2 * MB * MB + NB + 2;  // tiles | two inverse buffers | y | hand-shake counter
+constexpr int POTRF_LDS_DOUBLES = IMG_DOUBLES + 2 * MB * MB + NB;  // tiles | two inverse buffers | y
 
 // PUB: the fused panel kernel - every tile of the image goes out (store_pub) the moment it is final, z_b too
 template <bool PUB, bool UPD = false>
@@ -328,105 +328,78 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
     for (int t = 0; t < NTILE; ++t) T[t * (MB * MB) + c * MB + r] = v[t];
   }
   if (tid < NB) ys[tid] = (p.y && tid < nbk) ? p.y[tid] : 0.;
-  if (tid == 0) *reinterpret_cast<int *>(ys + NB) = 0;
   __syncthreads();
 
   int bad_pivot = 0;
   if (wave == 0) micro_potrf_inv<PUB>(T + tile_off(0, 0), Wc, p.img + tile_off(0, 0), lane, ln, 0, bad_pivot);
   __syncthreads();
 
-  // Round 5: ONE barrier per micro step, and wave 0 carries nothing but the serial chain.  After the barrier of step jb
-  // (W_jb and L_jb,jb in LDS, every tile up to date with the steps before jb):
-  //   wave 0       X(jb+1, jb) = A(jb+1, jb) W^T, kept in registers -> D(jb+1, jb+1) -= X X^T straight from those
-  //                registers (a finished C/D tile IS the next product's operand, mfma_f64.h) -> POTRF16 + INV16 of it
-  //   waves 1 - 3  the other tiles of column jb (MFMA TRSM), z_jb; then - after a hand-shake through an LDS counter
-  //                that wave 0 only signals, never waits for - the SYRK of every trailing tile but wave 0's, the y update
-  // Rounds 1-4 ran the TRSM stage on all four waves, a barrier, then the SYRK stage: two barriers per step, and wave 0
-  // waited at the first one for the slowest TRSM wave (two tiles) before it could touch the next diagonal tile.
-  int *hs = reinterpret_cast<int *>(ys + NB);  // (the hand-shake counter: zeroed in the prologue, only grows)
 #pragma unroll 1
   for (int jb = 0; jb < NMB; ++jb) {
     const int o = jb * MB;
     const double *W = Wc + (jb & 1) * (MB * MB);
-    auto trsm_tile = [&](int ib, v4d &x) {  // X <- X W^T for tile (ib, jb): final element (ln, lg + 4 r) of L in x[r]
+    // ---- stage A: micro TRSM of the tiles below, X <- X W^T, one tile per wave ----
+    for (int ib = jb + 1 + wave; ib < NMB; ib += 4) {
       double *X = T + tile_off(ib, jb);
       v4d acc0 = v4zero(), acc1 = v4zero();
       acc0 = mfma16(W[(0 + lg) * MB + ln], X[(0 + lg) * MB + ln], acc0);
       acc1 = mfma16(W[(4 + lg) * MB + ln], X[(4 + lg) * MB + ln], acc1);
       acc0 = mfma16(W[(8 + lg) * MB + ln], X[(8 + lg) * MB + ln], acc0);
       acc1 = mfma16(W[(12 + lg) * MB + ln], X[(12 + lg) * MB + ln], acc1);
-      x = acc0 + acc1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        X[(lg + 4 * r) * MB + ln] = x[r];
-        if constexpr (PUB) store_pub(p.img + tile_off(ib, jb) + (lg + 4 * r) * MB + ln, -x[r]);  // (the image holds -L)
-        else p.img[tile_off(ib, jb) + (lg + 4 * r) * MB + ln] = -x[r];
+        const double x = acc0[r] + acc1[r];  // final: element (ln, lg + 4 r) of tile (ib, jb) of L (the image holds -L)
+        X[(lg + 4 * r) * MB + ln] = x;
+        if constexpr (PUB) store_pub(p.img + tile_off(ib, jb) + (lg + 4 * r) * MB + ln, -x);
+        else p.img[tile_off(ib, jb) + (lg + 4 * r) * MB + ln] = -x;
       }
-    };
+    }
+    // z_jb = W y_jb  (wave 3; reads precede the write in program order)
+    if (wave == 3) {
+      double zz = 0.;
+#pragma unroll
+      for (int c = 0; c < MB; ++c) zz += W[c * MB + ln] * ys[o + c];
+      if (lane < MB) ys[o + ln] = zz;
+    }
+    __syncthreads();
+    if (jb == NMB - 1) break;
+
+    // ---- stage B: wave 0 updates the NEXT diagonal tile and factors it right
+    // away (look-ahead) while waves 1-3 run the remaining SYRK tiles + y update
     if (wave == 0) {
-      if (jb + 1 < NMB) {
-        v4d x;
-        trsm_tile(jb + 1, x);
-        if (lane == 0) __hip_atomic_fetch_add(hs, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // X(jb + 1, jb) is in LDS
-        double *Cc = T + tile_off(jb + 1, jb + 1);
-        v4d c0, c1 = v4zero();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c0[r] = Cc[(lg + 4 * r) * MB + ln];
-        c0 = mfma16(-x[0], x[0], c0);
-        c1 = mfma16(-x[1], x[1], c1);
-        c0 = mfma16(-x[2], x[2], c0);
-        c1 = mfma16(-x[3], x[3], c1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Cc[(lg + 4 * r) * MB + ln] = c0[r] + c1[r];
-        micro_potrf_inv<PUB>(Cc, Wc + ((jb + 1) & 1) * (MB * MB), p.img + tile_off(jb + 1, jb + 1), lane, ln, o + MB, bad_pivot);
-      }
+      micro_syrk_tile(T, jb + 1, jb + 1, jb, ln, lg);
+      micro_potrf_inv<PUB>(T + tile_off(jb + 1, jb + 1), Wc + ((jb + 1) & 1) * (MB * MB), p.img + tile_off(jb + 1, jb + 1),
+                           lane, ln, o + MB, bad_pivot);
     } else {
-      for (int ib = jb + 1 + wave; ib < NMB; ib += 3) {  // (wave 1 starts at jb + 2)
-        v4d x;
-        trsm_tile(ib, x);
+      const int rem = NMB - 1 - jb;
+      const int ntile = rem * (rem + 1) / 2;
+      auto tile_of = [&](int tix, int &ib, int &kb) {
+        int left = tix;
+        kb = 0;
+        while (left >= rem - kb) { left -= rem - kb; ++kb; }
+        ib = jb + 1 + kb + left;
+        kb = jb + 1 + kb;
+      };
+      // tix 0 is the diagonal tile done by wave 0; two tiles per trip: four independent MFMA chains
+      int tix = wave;
+      for (; tix + 3 < ntile; tix += 6) {
+        int i0, k0, i1, k1;
+        tile_of(tix, i0, k0);
+        tile_of(tix + 3, i1, k1);
+        micro_syrk_tile2(T, i0, k0, i1, k1, jb, ln, lg);
       }
-      // z_jb = W y_jb  (wave 3; reads precede the write in program order)
-      if (wave == 3) {
-        double zz = 0.;
-#pragma unroll
-        for (int c = 0; c < MB; ++c) zz += W[c * MB + ln] * ys[o + c];
-        if (lane < MB) ys[o + ln] = zz;
+      if (tix < ntile) {
+        int i0, k0;
+        tile_of(tix, i0, k0);
+        micro_syrk_tile(T, i0, k0, jb, ln, lg);
       }
-      if (jb + 1 < NMB) {
-        // all of column jb (and z_jb) in LDS?  Three of these waves + wave 0 per step.
-        if (lane == 0) __hip_atomic_fetch_add(hs, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int want = 4 * (jb + 1);
-        while (__hip_atomic_load(hs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
-        const int rem = NMB - 1 - jb;
-        const int ntile = rem * (rem + 1) / 2;
-        auto tile_of = [&](int tix, int &ib, int &kb) {
-          int left = tix;
-          kb = 0;
-          while (left >= rem - kb) { left -= rem - kb; ++kb; }
-          ib = jb + 1 + kb + left;
-          kb = jb + 1 + kb;
-        };
-        // tix 0 is the diagonal tile done by wave 0; two tiles per trip: four independent MFMA chains
-        int tix = wave;
-        for (; tix + 3 < ntile; tix += 6) {
-          int i0, k0, i1, k1;
-          tile_of(tix, i0, k0);
-          tile_of(tix + 3, i1, k1);
-          micro_syrk_tile2(T, i0, k0, i1, k1, jb, ln, lg);
-        }
-        if (tix < ntile) {
-          int i0, k0;
-          tile_of(tix, i0, k0);
-          micro_syrk_tile(T, i0, k0, jb, ln, lg);
-        }
-        const int row = o + MB + (tid - 64);
-        if (row < NB) {
-          const double *Xr = T + tile_off(row >> 4, jb) + (row & 15);
-          double s = ys[row];
+      const int row = o + MB + (tid - 64);
+      if (row < NB) {
+        const double *Xr = T + tile_off(row >> 4, jb) + (row & 15);
+        double s = ys[row];
 #pragma unroll
-          for (int k = 0; k < MB; ++k) s -= Xr[k * MB] * ys[o + k];
-          ys[row] = s;
-        }
+        for (int k = 0; k < MB; ++k) s -= Xr[k * MB] * ys[o + k];
+        ys[row] = s;
       }
     }
     __syncthreads();
@@ -721,7 +694,6 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
       }
     }
   const int npass = K / 64;
-#pragma unroll 2
   for (int pass = 0; pass < npass; ++pass) {
     if (pass) lds_barrier();  // the previous pass's readers are done with the buffers
     trail_store_pass<false>(As, ra);

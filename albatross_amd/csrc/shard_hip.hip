@@ -334,12 +334,22 @@ struct HipShardOps : ShardOps {
     unsigned long long &seq = ctx->shard_probe_seq;
     (void)hipMemsetAsync(fail, 0, sizeof(int), sq[QC]);
     if (hipStreamSynchronize(sq[QC]) != hipSuccess) return false;
-    const int pairs[4][2] = {{QC, QP}, {QC, QB}, {QP, QC}, {QB, QC}};  // {consumer, producer}
-    for (int i = 0; i < 4; ++i) {
-      ++seq;
-      hipLaunchKernelGGL(shard_gate_kernel, dim3(1), dim3(64), 0, sq[pairs[i][0]], pf + i, seq, short_ticks, fail);
-      hipLaunchKernelGGL(shard_signal_kernel, dim3(1), dim3(1), 0, sq[pairs[i][1]], pf + i, seq);
-    }
+    // every {consumer, producer} pair the schedule uses - the panel chain also gates on records of the bulk queue (the
+    // previous step's U2) and, on one rank, the bulk queue on the chain - and the same pairs against the CU-MASKED stream,
+    // which becomes the bulk queue in the chain-bound regime (to_masked_bulk): the answer is cached for the context's
+    // lifetime, so it has to cover every stream a fit may put behind `QB`
+    hipStream_t qs[4] = {sq[QC], sq[QP], sq[QB], (ctx->stream_masked && ctx->stream_masked != sq[QB]) ? ctx->stream_masked : nullptr};
+    int slot = 0;
+    for (int c = 0; c < 4; ++c)
+      for (int pr = 0; pr < 4; ++pr) {
+        if (c == pr || !qs[c] || !qs[pr]) continue;
+        if (c >= 2 && pr >= 2) continue;  // (the two bulk streams never wait for each other inside a regime)
+        ++seq;
+        hipLaunchKernelGGL(shard_gate_kernel, dim3(1), dim3(64), 0, qs[c], pf + slot, seq, short_ticks, fail);
+        hipLaunchKernelGGL(shard_signal_kernel, dim3(1), dim3(1), 0, qs[pr], pf + slot, seq);
+        ++slot;
+      }
+    if (qs[3] && hipStreamSynchronize(qs[3]) != hipSuccess) { (void)hipGetLastError(); return false; }
     int h = 1;
     bool fine = true;
     for (int q = 0; q < 3; ++q) fine = fine && hipStreamSynchronize(sq[q]) == hipSuccess;
@@ -923,6 +933,10 @@ int agp_sharded_fit_create(agp_context *c, agp_comm *comm, const agp_kernel *k, 
     if (ops.gate_timeout && (st == AGP_OK || st == AGP_ERR_NOT_POSITIVE_DEFINITE)) {
       ctx->last_error = "sharded schedule: a queue waited for another (or for a collective) past the transport's deadline";
       st = AGP_ERR_COMM;
+    }
+    if (ops.gate_timeout) {  // whatever the reason: the next fit of this context is paced by the host, which waits for nothing on the device
+      ctx->shard_host_pacing = 1;
+      ctx->shard_probe_ok = false;
     }
     f->stage[2] = ops.device_pacing ? 1. : 0.;  // the pacing the fit ENDED with
     f->stage[6] = res.enqueue_factor_ms + res.enqueue_solve_ms;

@@ -238,4 +238,71 @@ int agp_solver_predict(agp_context *ctx, const agp_kernel *k, const agp_solver *
   return copy_out(ctx, prior.p, m * m, var_or_cov, location);
 }
 
+// FitModel::update on a generic representation (gp.hpp:403-407): the information vector of the conditioned fit,
+//   [ information - Ai_B Si_delta ; Si_delta ],
+// with the Ai_B = A^-1 B the BlockSymmetric solver already holds in HBM (block_symmetric.hpp:51): one mat-vec on the device.
+// information: na doubles, si_delta: nb doubles, out: na + nb doubles, all at `location`.
+int agp_solver_update_information(agp_context *ctx, const agp_solver *bs, const double *information, const double *si_delta, double *out,
+                                  int location) {
+  if (!ctx || !bs || bs->kind != 2 || !bs->AiB || !information || !si_delta || !out) return AGP_ERR_INVALID_ARGUMENT;
+  if (bs->ctx != ctx) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const long long na = bs->na, nb = bs->nb;
+  DevBuf v;
+  if (v.get((size_t)(2 * na + nb)) != hipSuccess) { ctx->last_error = "agp_solver_update_information: allocation"; return AGP_ERR_HIP; }
+  double *info = v.p, *res = v.p + na;  // res: na + nb
+  int st = vector_to_device(ctx, information, na, location, info);
+  if (st == AGP_OK) st = vector_to_device(ctx, si_delta, nb, location, res + na);
+  if (st != AGP_OK) return st;
+  // res[0 : na] = information - Ai_B (na x nb, ld = na) Si_delta
+  launch_tall_matvec(ctx->stream, bs->AiB, na, na, nb, res + na, -1.0, 1.0, info, res);
+  return copy_out(ctx, res, na + nb, out, location);
+}
+
+// _predict_impl over a generic representation (gp.hpp:305-366) for LinearCombination<X> features on either side
+// (covariance_functions/callers.hpp:321-396): as agp_solver_predict, with every covariance matrix the contracted one
+// of agp_gram_combined - train / xs hold the EXPANDED points, combination a of a side = its expanded points
+// offsets[a] .. offsets[a + 1) with coefficients[..] (host arrays; offsets == NULL: plain features on that side).
+// The solver's size must equal the number of training combinations.  Everything stays in HBM.
+int agp_solver_predict_combined(agp_context *ctx, const agp_kernel *k, const agp_solver *sv, const agp_features *train, int64_t n_train,
+                                const int64_t *train_offsets, const double *train_coefficients, const double *information,
+                                const agp_features *xs, int64_t n_xs, const int64_t *xs_offsets, const double *xs_coefficients,
+                                double *mean, double *var_or_cov, int mode, int location) {
+  if (!ctx || !k || !sv || !train || !information || !xs || !mean || mode < 0 || mode > 2 || (mode > 0 && !var_or_cov))
+    return AGP_ERR_INVALID_ARGUMENT;
+  if (sv->ctx != ctx || xs->dim != train->dim) return AGP_ERR_INVALID_ARGUMENT;
+  int st = validate_features(train);
+  if (st != AGP_OK || (st = validate_features(xs)) != AGP_OK) return st;
+  const long long n = train_offsets ? n_train : train->n, m = xs_offsets ? n_xs : xs->n;
+  if (n != sv->n) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m == 0) return AGP_OK;
+  hipStream_t s = ctx->stream;
+  DevBuf cross, expl, info, mean_d, prior, pdiag;
+  if (cross.get((size_t)n * m) != hipSuccess || info.get((size_t)n) != hipSuccess || mean_d.get((size_t)m) != hipSuccess ||
+      (mode > 0 && expl.get((size_t)n * m) != hipSuccess) || (mode > 0 && prior.get((size_t)m * m) != hipSuccess) ||
+      (mode == 1 && pdiag.get((size_t)m) != hipSuccess)) {
+    ctx->last_error = "agp_solver_predict_combined: allocation";
+    return AGP_ERR_HIP;
+  }
+  if ((st = vector_to_device(ctx, information, n, location, info.p)) != AGP_OK) return st;
+  // cross_cov = cov(train_features, features) through LinearCombinationCaller; mean = cross_cov^T information
+  if ((st = agp_gram_combined(ctx, k, train, n_train, train_offsets, train_coefficients, xs, n_xs, xs_offsets, xs_coefficients, cross.p, n,
+                              AGP_DEVICE)) != AGP_OK) return st;
+  launch_colvec_dot(s, cross.p, n, n, m, info.p, 1.0, 0.0, nullptr, mean_d.p);
+  if ((st = copy_out(ctx, mean_d.p, m, mean, location)) != AGP_OK) return st;
+  if (mode == 0) return AGP_OK;
+  if ((st = solve_dev(ctx, sv, cross.p, m, expl.p)) != AGP_OK) return st;  // train_covariance.solve(cross_cov), gp.hpp:96,111
+  if ((st = agp_gram_combined(ctx, k, xs, n_xs, xs_offsets, xs_coefficients, nullptr, 0, nullptr, nullptr, prior.p, m, AGP_DEVICE)) != AGP_OK)
+    return st;                                                              // prior_cov, gp.hpp:317,339-343
+  if (mode == 1) {
+    SOL_HIP(hipMemcpy2DAsync(pdiag.p, sizeof(double), prior.p, sizeof(double) * (size_t)(m + 1), sizeof(double), (size_t)m,
+                             hipMemcpyDeviceToDevice, s));                  // its diagonal
+    launch_coldot(s, expl.p, n, cross.p, n, n, m, pdiag.p, 1.0, pdiag.p);   // prior - colsum(explained o cross), gp.hpp:97-99
+    return copy_out(ctx, pdiag.p, m, var_or_cov, location);
+  }
+  launch_gemm_nt_sub(s, prior.p, m, cross.p, n, true, expl.p, n, true, m, m, n, false);  // - cross^T explained, gp.hpp:111
+  return copy_out(ctx, prior.p, m * m, var_or_cov, location);
+}
+
 }  // extern "C"

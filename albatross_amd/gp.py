@@ -347,7 +347,6 @@ class _DeviceSolver:
 
 
 class GPFit(_DeviceSolver):
-    host_composition = False  # the factor, the solves and the predictions all live on the device
 
     def _make_solver(self):
         h = C.c_void_p()
@@ -619,7 +618,6 @@ class BlockSymmetric(_DeviceSolver):
     the Schur complement S = C - B^T A^-1 B - ON THE DEVICE (agp_solver_block_symmetric): Ai_B is computed and kept in HBM,
     a solve is device solves + MFMA products.  Only solvers that are not a plain device factor end up here (pivoted
     LDL^T fits, fit_from_prediction); fits on the device factor are updated by agp_fit_update."""
-    host_composition = False
 
     def __init__(self, A, B, S):
         self._ctx = A._ctx
@@ -643,12 +641,21 @@ class BlockSymmetric(_DeviceSolver):
     def solve(self, rhs):  # block_symmetric.hpp:75-98
         return self._solve_through_handle(rhs)
 
+    def update_information(self, information, si_delta):
+        """gp.hpp:403-407: [information - Ai_B Si_delta ; Si_delta] from the Ai_B this solver holds in HBM
+        (agp_solver_update_information: one mat-vec on the device)."""
+        info = np.ascontiguousarray(information, dtype=np.float64)
+        sd = np.ascontiguousarray(si_delta, dtype=np.float64)
+        out = np.empty(info.shape[0] + sd.shape[0])
+        self._ctx._check(self._ctx._lib.agp_solver_update_information(self._ctx._h, self._solver(), _ptr(info), _ptr(sd), _ptr(out), capi.HOST),
+                         "agp_solver_update_information")
+        return out
+
 
 class ExplainedCovariance(_DeviceSolver):
     """ExplainedCovariance (covariance_functions/representations.hpp:64-96): S^-1 = A^-1 B A^-1 with the outer matrix A
     held through its factor and the inner matrix B kept as it is, because B may be singular - on the device
     (agp_solver_explained): the product with B between the two solves is an MFMA product in HBM."""
-    host_composition = False
 
     def __init__(self, outer, inner, context=None):
         self.outer_ldlt = outer if isinstance(outer, (DenseFactor, PivotedLDLT)) else DenseFactor(outer, context)
@@ -675,18 +682,14 @@ class UpdatedGPFit:
     """Fit<GPFit<Representation, F>> whose solver is not the plain LL^T factor: a pivoted L D L^T (semi-definite covariances),
     BlockSymmetric<Solver> from update() (gp.hpp:384-414) or ExplainedCovariance from fit_from_prediction (gp.hpp:139-153).
     The solver is a device object (`agp_solver`) and predictions go through agp_solver_predict - the generic
-    CovarianceRepresentation form of _predict_impl (gp.hpp:305-366) in HBM.  `host_composition` is True only for fits over
-    LinearCombination features, whose Gram matrices are contracted on the host by design."""
+    CovarianceRepresentation form of _predict_impl (gp.hpp:305-366) in HBM - agp_solver_predict_combined when either side holds
+    LinearCombination features (their covariance matrices are built and contracted on the device too)."""
 
     def __init__(self, train_features, train_covariance, information):
         self.train_features = train_features
         self.train_covariance = train_covariance
         self.information = information
         self.n = information.shape[0]
-
-    @property
-    def host_composition(self):
-        return has_linear_combinations(self.train_features)
 
     def rows(self):
         return self.n
@@ -725,12 +728,6 @@ class FitModel:
     def get_model(self):
         return self._model
 
-    @property
-    def host_composition(self):
-        """True when the fit's solver is a host-side composition around device solves (BlockSymmetric /
-        ExplainedCovariance over a solver that is not a device factor) rather than a device factor."""
-        return bool(getattr(self._fit, "host_composition", False))
-
     def predict(self, features):
         return Prediction(self, features)
 
@@ -759,8 +756,7 @@ class FitModel:
         solver_a = self._fit.train_covariance if isinstance(self._fit, UpdatedGPFit) else self._fit
         new_cov = BlockSymmetric(solver_a, cross, S_ldlt)                     # gp.hpp:398-399
         Si_delta = S_ldlt.solve(delta)
-        # information - Ai_B Si_delta = information - A^-1 (B Si_delta)   (gp.hpp:403-407; Ai_B itself stays on the device)
-        info = np.concatenate([self._fit.information - solver_a.solve(cross @ Si_delta), Si_delta])
+        info = new_cov.update_information(self._fit.information, Si_delta)   # gp.hpp:403-407, on the device
         new_feats = np.concatenate([np.asarray(old_feats, dtype=np.float64).reshape(self._fit.rows(), -1),
                                     np.asarray(feats, dtype=np.float64).reshape(len(delta), -1)])
         return FitModel(m, UpdatedGPFit(new_feats, new_cov, info))
@@ -791,8 +787,7 @@ class FitModel:
     # --- _predict_impl (gp.hpp:305-366) ------------------------------------------
     def _host_predict(self, features, want):
         """_predict_impl written against a generic CovarianceRepresentation (gp.hpp:305-366), for fits whose solver is not the
-        plain LL^T factor: agp_solver_predict - cross covariance, solve, explained covariance all in HBM.  (LinearCombination
-        features: their Gram matrices are contracted on the host by design, so the composition is too.)"""
+        plain LL^T factor: agp_solver_predict - cross covariance, solve, explained covariance all in HBM."""
         m, ctx = self._model, self._model._ctx()
         cov = m.covariance_function_
         if not (has_linear_combinations(features) or has_linear_combinations(self._fit.train_features)):
@@ -810,15 +805,30 @@ class FitModel:
             if want == "mean":
                 return mean
             return MarginalDistribution(mean, second) if want == "marginal" else JointDistribution(mean, second)
-        cross = ctx.gram(cov, self._fit.train_features, features)
-        mean = cross.T @ self._fit.information + _mean_at(m.mean_function_, cov, features)
+        # LinearCombination features on either side (callers.hpp:321-396): the same composition with the contracted covariance
+        # matrices of agp_gram_combined, all of it in HBM (agp_solver_predict_combined)
+        def side(f):
+            if has_linear_combinations(f):
+                ex, off, co = expand_with_offsets(f)
+                return cov.features(ex), len(off) - 1, off, co
+            fs_ = cov.features(f)
+            return fs_, fs_.n, None, None
+        ftr, ntr, troff, trco = side(self._fit.train_features)
+        fxs, nxs, xoff, xco = side(features)
+        s_tr, s_xs = ftr.as_struct(), fxs.as_struct()
+        solver = self._fit.train_covariance._solver() if isinstance(self._fit, UpdatedGPFit) else self._fit._solver()
+        info = np.ascontiguousarray(self._fit.information, dtype=np.float64)
+        mode = {"mean": 0, "marginal": 1, "joint": 2}[want]
+        mean = np.empty(nxs)
+        second = None if mode == 0 else (np.empty(nxs) if mode == 1 else np.empty((nxs, nxs), order="F"))
+        ctx._check(ctx._lib.agp_solver_predict_combined(
+            ctx._h, ctx.kernel(cov), solver, C.byref(s_tr), ntr, None if troff is None else _ptr(troff), None if trco is None else _ptr(trco),
+            _ptr(info), C.byref(s_xs), nxs, None if xoff is None else _ptr(xoff), None if xco is None else _ptr(xco), _ptr(mean),
+            None if second is None else _ptr(second), mode, capi.HOST), "agp_solver_predict_combined")
+        mean = mean + _mean_at(m.mean_function_, cov, features)  # mean_function_.add_to, gp.hpp:364
         if want == "mean":
             return mean
-        explained = self._fit.solve(cross)
-        prior = ctx.gram(cov, features)
-        if want == "marginal":
-            return MarginalDistribution(mean, np.diag(prior) - np.einsum("ij,ij->j", explained, cross))
-        return JointDistribution(mean, prior - cross.T @ explained)
+        return MarginalDistribution(mean, second) if want == "marginal" else JointDistribution(mean, second)
 
     def _xs(self, features):
         fs = self._model.covariance_function_.features(features)

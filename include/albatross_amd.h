@@ -486,6 +486,19 @@ AGP_API int agp_solver_solve(agp_context *ctx, const agp_solver *solver, const d
 AGP_API int agp_solver_predict(agp_context *ctx, const agp_kernel *k, const agp_solver *solver, const agp_features *train,
                                const double *information, const agp_features *xs, double *mean, double *var_or_cov, int mode,
                                int location);
+/* FitModel::update on a generic representation (src/models/gp.hpp:403-407): the information vector of the conditioned fit,
+ * [information - Ai_B Si_delta ; Si_delta], from the Ai_B a BlockSymmetric solver holds in HBM (block_symmetric.hpp:51).
+ * information: rows(A) doubles, si_delta: rows(S) doubles, out: rows(A) + rows(S) doubles, all at `location`. */
+AGP_API int agp_solver_update_information(agp_context *ctx, const agp_solver *block_symmetric, const double *information,
+                                          const double *si_delta, double *out, int location);
+/* agp_solver_predict for LinearCombination<X> features on either side (covariance_functions/callers.hpp:321-396): train / xs
+ * hold the EXPANDED points, combination a of a side = its expanded points offsets[a] .. offsets[a + 1) with
+ * coefficients[..] (host arrays as in agp_gram_combined; offsets == NULL: plain features on that side).  The solver's
+ * size is the number of training combinations.  Covariances, contraction, solve and products all run on the device. */
+AGP_API int agp_solver_predict_combined(agp_context *ctx, const agp_kernel *k, const agp_solver *solver, const agp_features *train,
+                                        int64_t n_train, const int64_t *train_offsets, const double *train_coefficients,
+                                        const double *information, const agp_features *xs, int64_t n_xs, const int64_t *xs_offsets,
+                                        const double *xs_coefficients, double *mean, double *var_or_cov, int mode, int location);
 AGP_API void agp_solver_destroy(agp_solver *solver);
 
 /* ---- multi-GPU: ONE fit sharded over the GPUs of a node ---------------------------------------

