@@ -190,6 +190,7 @@ static agp_context::Tuning read_tuning() {
   t.step_below = number("AGP_STEP_BELOW", 4608);
   t.gram_sop = flag("AGP_GRAM_SOP", true);
   t.backsub_coop = flag("AGP_BACKSUB_COOP", true);
+  t.mixed_bf16 = flag("AGP_MIXED_BF16", true);
   t.sparse_pivoted = flag("AGP_SPARSE_PIVOTED", false);
   t.predict_chunk = number("AGP_PREDICT_CHUNK", 0);
   t.shard_block = number("AGP_SHARD_BLOCK", 0);
@@ -760,6 +761,23 @@ void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long lo
   }
   const long long nb = n / BW;
   if (first_done < 0 || first_done > nb) first_done = 0;
+  if (first_done == nb - 1 && nb >= 2) {
+    // all inverses but the LAST block's are on their way (factor_lower's early inversion): inverting one more block is the
+    // same seven-launch chain as inverting all of them (~100 us) - the last BW rows go through the one-launch substitution
+    // instead (solve.hip: backsub_coop_kernel on the trailing BW x BW triangle, ~9 us per 128 rows), then its update
+    const long long k0 = (nb - 1) * BW;
+    launch_fill_sentinel(s, xs + k0, BW);
+    backward_solve_coop(s, A + k0 * (lda + 1), BW, lda, invd + (k0 / NB) * (long long)(36 * MB * MB), z + k0, xs + k0, nullptr);
+    launch_colvec_dot(s, A + k0, lda, BW, k0, xs + k0, -1.0, 1.0, z, z);  // z[0:k0] -= L[B, 0:k0]^T x_B
+    if (ev_done) (void)hipStreamWaitEvent(s, ev_done, 0);
+    for (long long b = nb - 2; b >= 0; --b) {
+      const long long c0 = b * BW;
+      launch_colvec_dot(s, W + b * BW * BW, BW, BW, BW, z + c0, 1.0, 0.0, nullptr, xs + c0);
+      if (c0 > 0) launch_colvec_dot(s, A + c0, lda, BW, c0, xs + c0, -1.0, 1.0, z, z);
+    }
+    (void)hipMemcpyAsync(z, xs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+    return;
+  }
   if (first_done < nb) {
     const long long cnt = nb - first_done;
     launch_set_identity_batched(s, W + first_done * BW * BW, BW, BW * BW, BW, cnt);
@@ -947,9 +965,11 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     FIT_CHECK(hipMemcpyAsync(vec, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, Kfull, fit->lda, yvar_d, ctx->d_flags,
                 &k->prog);
-    ctx->update_variant = 3;  // fp32-product bulk updates
-    {  // two fp32 panel copies of (n rows + padding) x 512 (chol.hip, factor_lower); kept in the context
-      const size_t want = sizeof(float) * 2 * ((size_t)n + 16) * 512;
+    // fp32-accurate products of the bulk updates: on the BF16 pipe from three bf16 planes per panel (gemm_bf16x3.hip), or
+    // - AGP_MIXED_BF16=0 - on the fp32 MFMA as in rounds 1-4
+    ctx->update_variant = ctx->tune.mixed_bf16 ? 4 : 3;
+    {  // two panel copies of (n rows + padding) x 512 (chol.hip, factor_lower): fp32, or three bf16 planes; kept in the context
+      const size_t want = ctx->tune.mixed_bf16 ? 2 * bf16x3_bytes(n, 512) : sizeof(float) * 2 * ((size_t)n + 16) * 512;
       if (ctx->p32_bytes < want) {
         if (ctx->p32) (void)hipFree(ctx->p32);
         ctx->p32 = nullptr; ctx->p32_bytes = 0;

@@ -967,7 +967,8 @@ void panel_fused_prepare(agp_context *ctx, hipStream_t s, double *invd, long lon
 // POTRF, panel TRSM (with the fused forward substitution on y) and the update
 // of the remaining columns of the outer block.  Everything on stream s.
 static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n, long long lda, double *invd,
-                        double *y, long long K0, long long kend, FactorTimers *timers, bool step_mode = false) {
+                        double *y, long long K0, long long kend, FactorTimers *timers, bool step_mode = false,
+                        long long mark_after = -1, hipEvent_t mark_event = nullptr) {
   // step_mode (the chain-bound tail, factor_lower): ONE launch per panel.  The first panel is a plain fused launch;
   // every later one is panel_fused_kernel<true> - the previous panel's update of this panel's 128 columns on the
   // critical workgroups - plus trailing workgroups that apply the previous panel to everything further right while
@@ -985,6 +986,7 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
                      ((n - K0) <= FUSED_BELOW || step_mode);
   for (long long k = K0; k < kend; k += NB) {
     const int nbk = (int)((n - k < NB) ? n - k : NB);
+    if (mark_event && k == mark_after + NB) (void)hipEventRecord(mark_event, s);  // everything up to panel mark_after is enqueued
     if (inner_left && k > K0) {
       const double *P = A + K0 * lda + k;  // rows k.., columns K0..k
       timed_gemm(s, timers, A + k * lda + k, lda, P, P, n - k, nbk, k - K0, false);
@@ -1148,7 +1150,24 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   auto step_ok = [&](long long remaining) { return nbo_fixed == 0 && step_fits(ctx, remaining) && step_ready(ctx, invd, n); };
   const bool step_all = step_ok(n);  // small matrix: every panel
   if (step_all) kend = n;
-  panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers, step_all);
+  // A fit that is ALL step launches (n <= 4608) never reaches the two-stream tail below, where the wide diagonal blocks
+  // of the back substitution get inverted on the idle second stream: here the host marks the panel after which all but
+  // the last wide block are final, and - the stream must not sit at a hipStreamWaitEvent next to the chain (section 8) -
+  // hands the inversion to the second stream itself once that mark has passed; the last four panels run meanwhile.
+  const bool early_inv = step_all && ctx->bs_W && ctx->bs_done == 0 && ctx->ev_inv && ctx->stream2 && ctx->bs_BW > 0 &&
+                         n % ctx->bs_BW == 0 && n / ctx->bs_BW >= 2;
+  panel_phase(ctx, sa, A, n, lda, invd, y, K0, kend, timers, step_all, early_inv ? (n / ctx->bs_BW - 1) * ctx->bs_BW - NB : -1,
+              early_inv ? ctx->ev_c : nullptr);
+  if (early_inv) {
+    const long long BW = ctx->bs_BW, done = n / BW - 1;
+    while (hipEventQuery(ctx->ev_c) == hipErrorNotReady) {}
+    hipStream_t si = ctx->stream2;
+    launch_set_identity_batched(si, ctx->bs_W, BW, BW * BW, BW, done);
+    forward_solve_mat_batched(si, A, BW * (lda + 1), BW, lda, invd, (BW / NB) * (long long)IMG_DOUBLES, ctx->bs_W, BW * BW, BW, BW,
+                              /*rhs_lower=*/true, done);
+    (void)hipEventRecord(ctx->ev_inv, si);
+    ctx->bs_done = done;
+  }
   while (kend < n) {
     long long next_end = kend + pick_nbo(n - kend, nbo_fixed);
     if (next_end > n) next_end = n;
@@ -1182,6 +1201,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     // while it stages them - twice the operand traffic of the fp32 kernel, which is what it waits for.
     const float *P32 = nullptr;
     long long ld32 = 0;
+    const unsigned short *P16 = nullptr;  // variant 4: the panel as three bf16 planes (gemm_bf16x3.hip), same two alternating buffers
     if (variant == 3 && ctx->p32 && (n - kend) >= U1_F32_ABOVE) {
       ld32 = (n - kend + 7) / 8 * 8;
       if (ld32 % 512 == 0) ld32 += 8;
@@ -1191,18 +1211,26 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
         launch_convert_panel_f32(sa, P, lda, n - kend, K, dst, ld32);
         P32 = dst;
       }
+    } else if (variant == 4 && ctx->p32 && (n - kend) >= U1_F32_ABOVE && K % 32 == 0 && 2 * bf16x3_bytes(n - kend, K) <= ctx->p32_bytes) {
+      unsigned short *dst = reinterpret_cast<unsigned short *>(ctx->p32) + (size_t)(p32_flip ? 1 : 0) * (ctx->p32_bytes / sizeof(unsigned short) / 2);
+      p32_flip = !p32_flip;
+      launch_convert_panel_bf16x3(sa, P, lda, n - kend, K, dst);
+      P16 = dst;
     }
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
     // U2(j - 1) must be done before anything of step j touches the next block column
     if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
     // U1: block column [kend, next_end), all rows below its diagonal
-    if (variant == 3 && (n - kend) >= U1_F32_ABOVE) {
+    if (P16) {
+      // mixed precision, bf16 x 3: U1 and the bulk update from the planes of this step's panel
+      launch_update_bf16x3(sa, A + kend * lda + kend, lda, P16, n - kend, 0, 0, n - kend, next_end - kend, K);
+    } else if ((variant == 3 || variant == 4) && (n - kend) >= U1_F32_ABOVE) {
       // mixed precision: U1 on the fp32 MFMA path like the bulk update (products of fp32-rounded panels, fp64
       // subtraction) while the block column is tall enough for 128 x 128 tiles to fill the chip
       launch_update_f32(sa, A + kend * lda + kend, lda, P, P, lda, n - kend, next_end - kend, K, P32, P32, ld32);
     } else if (step && n - kend > 1536) {
       // hand-over to the step tail: the whole trailing matrix, on the chain stream, alone on the chip - the bulk kernel
-      timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, n - kend, K, true, variant);
+      timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, n - kend, K, true, variant == 4 ? 3 : variant);
     } else {
       timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
     }
@@ -1228,7 +1256,15 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
         (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       }
       const double *Q = A + K0 * lda + next_end;
-      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant,
+      if (P16) {
+        const long long M2 = n - next_end;
+        const int ntr = (int)((M2 + 127) / 128);
+        const long long tiles = (long long)ntr * (ntr + 1) / 2;
+        long long olen = 0;
+        const int *order = tiles >= 1024 ? bulk_tile_order(ntr, tiles, &olen) : nullptr;
+        launch_update_bf16x3(sb, A + next_end * lda + next_end, lda, P16, n - kend, next_end - kend, next_end - kend, M2, M2, K, order, olen);
+      } else
+      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant == 4 ? 3 : variant,
                  P32 ? P32 + (next_end - kend) : nullptr, ld32);
       (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;

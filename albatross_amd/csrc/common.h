@@ -93,7 +93,7 @@ struct agp_context {
   // ... and one cached block of a fit's small buffers (agp_fit::aux_base)
   double *pool_aux = nullptr;
   size_t pool_aux_bytes = 0;
-  // bulk-update kernel of the next factorisation: -1 = default (fp64 MFMA), 3 = fp32 products
+  // bulk-update kernel of the next factorisation: -1 = default (fp64 MFMA), 3 = fp32 products, 4 = bf16 x 3 products (fp32 accuracy on the BF16 pipe)
   // (agp_fit_create_mixed sets and resets it around its factor_lower call)
   int update_variant = -1;
   long long nbo_override = 0;  // outer block width of the next factorisation (0 = default schedule)
@@ -124,6 +124,7 @@ struct agp_context {
     bool panel_fused = true;       // AGP_PANEL_FUSED=0: POTRF and panel TRSM as two launches
     long long step_below = 4608;   // AGP_STEP_BELOW: remaining rows at or below which every panel is ONE step launch (0: off)
     bool gram_sop = true;          // AGP_GRAM_SOP=0: covariance trees through the stack interpreter only
+    bool mixed_bf16 = true;        // AGP_MIXED_BF16=0: the mixed-precision fit's products on the fp32 MFMA (rounds 1-4) instead of bf16 x 3
     bool backsub_coop = true;      // AGP_BACKSUB_COOP=0: the fit's back substitution as a launch per block (rounds 1-4) instead of ONE launch
     bool sparse_pivoted = false;   // AGP_SPARSE_PIVOTED=1: the sparse GP's literal (pivoted LDL^T + QR) path always
     long long predict_chunk = 0;   // AGP_PREDICT_CHUNK: test points per slice of the marginal / joint predictions (0: by memory)
@@ -323,6 +324,14 @@ void launch_trailing_update(hipStream_t s, double *C, long long ldc, const doubl
                             long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
 void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P, const double *Q, long long ldp, long long M,
                        long long N, long long K, const float *P32 = nullptr, const float *Q32 = nullptr, long long ld32 = 0);
+// The bf16 x 3 path of the mixed-precision factorisation (gemm_bf16x3.hip): the panel of one outer step as three bf16
+// planes (hi + mid + lo = the value to fp32 accuracy), and C -= P[row_a ..] P[row_b ..]^T from them on the BF16 pipe
+size_t bf16x3_bytes(long long rows, long long K);
+void launch_convert_panel_bf16x3(hipStream_t s, const double *P, long long ldp, long long rows, long long K, unsigned short *planes);
+void launch_update_bf16x3(hipStream_t s, double *C, long long ldc, const unsigned short *planes, long long panel_rows, long long row_a,
+                          long long row_b, long long M, long long N, long long K, const int *order = nullptr, long long order_len = 0);
+// the XCD-aware order of the `tiles` first lower 128 x 128 tiles of a grid with ntr tile rows (gemm.hip; cached): nullptr = none
+const int *bulk_tile_order(int ntr, long long tiles, long long *len);
 // P32 (rows x K, ld32) = (float) P: the fp32 copy of one outer step's panel for the fp32-product kernels
 void launch_convert_panel_f32(hipStream_t s, const double *P, long long ldp, long long rows, long long K, float *P32, long long ld32);
 }  // namespace agp

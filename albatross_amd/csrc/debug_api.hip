@@ -626,6 +626,17 @@ AGP_DEBUG_API int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t
     AGP_HIP_CHECK(ctx, hipMalloc(&dP32, sizeof(float) * (size_t)ld32 * (size_t)K));
     launch_convert_panel_f32(ctx->stream, dP, ldp, M, K, dP32, ld32);
     launch_trailing_update_as(3, ctx->stream, dC, ldc, dP, dP, ldp, M, K, nullptr, dP32, dP32, ld32);
+  } else if (variant == 14) {  // the bf16 x 3 kernel on the three bf16 planes of the panel, as the mixed fit runs it (gemm_bf16x3.hip)
+    unsigned short *planes = nullptr;
+    AGP_HIP_CHECK(ctx, hipMalloc(&planes, bf16x3_bytes(M, K)));
+    launch_convert_panel_bf16x3(ctx->stream, dP, ldp, M, K, planes);
+    const int ntr = (int)((M + 127) / 128);
+    const long long tiles = (long long)ntr * (ntr + 1) / 2;
+    long long olen = 0;
+    const int *order = tiles >= 1024 ? bulk_tile_order(ntr, tiles, &olen) : nullptr;
+    launch_update_bf16x3(ctx->stream, dC, ldc, planes, M, 0, 0, M, M, K, order, olen);
+    AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(planes);
   } else {
     launch_trailing_update_as(variant, ctx->stream, dC, ldc, dP, dP, ldp, M, K);
   }
@@ -725,9 +736,20 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
     AGP_HIP_CHECK(ctx, hipMalloc(&dP32, sizeof(float) * (size_t)ld32 * (size_t)K));
     launch_convert_panel_f32(ctx->stream, dP, ld, M, K, dP32, ld32);
   }
+  unsigned short *planes = nullptr;  // variant 5: the bf16 x 3 kernel on the panel's planes
+  const int ntr5 = (int)((M + 127) / 128);
+  long long olen = 0;
+  const int *order = nullptr;
+  if (variant == 5) {
+    AGP_HIP_CHECK(ctx, hipMalloc(&planes, bf16x3_bytes(M, K)));
+    launch_convert_panel_bf16x3(ctx->stream, dP, ld, M, K, planes);
+    const long long tiles = (long long)ntr5 * (ntr5 + 1) / 2;
+    if (tiles >= 1024) order = bulk_tile_order(ntr5, tiles, &olen);
+  }
   for (int r = -2; r < reps && st == AGP_OK; ++r) {
     if (r == 0) AGP_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
     if (variant == 4) launch_trailing_update_as(3, ctx->stream, dC, ld, dP, dP, ld, M, K, nullptr, dP32, dP32, ld32);
+    else if (variant == 5) launch_update_bf16x3(ctx->stream, dC, ld, planes, M, 0, 0, M, M, K, order, olen);
     else launch_trailing_update_as(variant, ctx->stream, dC, ld, dP, dP, ld, M, K);
   }
   AGP_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
@@ -738,6 +760,7 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(dC); (void)hipFree(dP);
   if (dP32) (void)hipFree(dP32);
+  if (planes) (void)hipFree(planes);
   return st;
 }
 

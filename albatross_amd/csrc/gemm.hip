@@ -616,6 +616,12 @@ static XcdOrder xcd_order(int ntr, long long full) {
   return o;
 }
 
+const int *bulk_tile_order(int ntr, long long tiles, long long *len) {
+  const XcdOrder o = xcd_order(ntr, tiles);
+  *len = o.dev ? o.len : 0;
+  return o.dev;
+}
+
 // variant 0: fp64 MFMA kernel, 3: fp32-product MFMA kernel (mixed precision)
 void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long ldc, const double *P,
                                const double *Q, long long ldp, long long M, long long K, BulkTiming *timing, const float *P32,

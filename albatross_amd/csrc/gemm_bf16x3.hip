@@ -1,0 +1,260 @@
+// gemm_bf16x3.hip - the bulk trailing update of the MIXED-precision factorisation on the BF16 matrix pipe (round 5).
+//
+// BASELINE config 4 ("fp32 ... MFMA f32 Gram + mixed-precision Cholesky",
+// examples/temperature_example/temperature_example.cc:34-85 at N = 32768): agp_fit_create_mixed keeps the matrix, the
+// panel chain and every accumulation between outer steps in fp64 and forms the K <= 512 products of one outer step at
+// fp32 accuracy.  Rounds 1-4 did that with v_mfma_f32_16x16x4_f32 (157 TFLOP/s peak, 103 reached).
+// gfx950 has no faster fp32 matrix instruction, but its BF16 pipe is 16x that rate, and an fp32 number IS three
+// bf16 numbers: x = hi + mid + lo with 8 significant bits each (24 = the fp32 significand).  A product of two such
+// numbers to fp32 accuracy needs the six partial products whose weight is above 2^-24,
+//     a b ~ hi hi + (hi mid + mid hi) + (hi lo + lo hi + mid mid),
+// all accumulated in the fp32 accumulators of v_mfma_f32_16x16x32_bf16: six instructions of 16 cycles for a
+// 16 x 16 x 32 block = 171 flop per clock and SIMD, 419 TFLOP/s of fp32-equivalent peak against 157.
+//
+//   convert_panel_bf16x3   the fp64 panel of one outer step -> three bf16 planes, ONCE for all the tiles that read it
+//                          (hi = rn(x), mid = rn(x - hi), lo = rn(x - hi - mid); |x - hi - mid - lo| <= 2^-25 |x|),
+//                          laid out [plane][k / 32][row][k % 32]: the 128 rows x 32 k of a tile's chunk are 8 KB
+//                          contiguous per plane
+//   trailing_update_bf16x3_kernel   128 x 128 tile of C per workgroup, 64 x 64 per wave (16 accumulators), K in chunks
+//                          of 32 through LDS (double buffered, row pitch 80 B: the 16 rows a 16-lane group reads with
+//                          ds_read_b128 fall on 16 different 16-B bank slots), C (fp64) fetched during the loop and
+//                          written once: C -= (double)(fp32 sum of the step's products) - the same contract as
+//                          trailing_update_f32_kernel (gemm.hip), whose place it takes.
+#include "common.h"
+#include "gemm_tiles.h"
+
+namespace agp {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;                 // k per chunk = one v_mfma_f32_16x16x32_bf16
+constexpr int BPITCH = 40;             // LDS row pitch in bf16 (80 B)
+constexpr int BPLANE = GT * BPITCH;    // one plane of one operand of one stage, in bf16
+
+__device__ __forceinline__ unsigned short bf16_rn(float f) {
+  unsigned int u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs: the panel of a factorisation)
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_val(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// planes: 3 x [K / 32][rows_pad][32] bf16; thread = (row, chunk)
+__global__ __launch_bounds__(256) void convert_panel_bf16x3_kernel(const double *__restrict__ P, long long ldp, long long rows, long long rows_pad,
+                                                                   unsigned short *__restrict__ planes, long long plane_stride) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long c = blockIdx.y;
+  if (row >= rows_pad) return;
+  unsigned short *dst = planes + c * rows_pad * BK + row * BK;
+#pragma unroll
+  for (int q = 0; q < BK / 8; ++q) {
+    unsigned short h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double x = row < rows ? P[row + (c * BK + 8 * q + j) * ldp] : 0.;
+      h[j] = bf16_rn((float)x);
+      const double r1 = x - (double)bf16_val(h[j]);
+      m[j] = bf16_rn((float)r1);
+      const double r2 = r1 - (double)bf16_val(m[j]);
+      l[j] = bf16_rn((float)r2);
+    }
+    auto pack = [](const unsigned short (&v)[8]) {
+      uint4 o;
+      o.x = v[0] | ((unsigned int)v[1] << 16); o.y = v[2] | ((unsigned int)v[3] << 16);
+      o.z = v[4] | ((unsigned int)v[5] << 16); o.w = v[6] | ((unsigned int)v[7] << 16);
+      return o;
+    };
+    *reinterpret_cast<uint4 *>(dst + 8 * q) = pack(h);
+    *reinterpret_cast<uint4 *>(dst + plane_stride + 8 * q) = pack(m);
+    *reinterpret_cast<uint4 *>(dst + 2 * plane_stride + 8 * q) = pack(l);
+  }
+}
+
+long long bf16x3_rows_pad(long long rows) { return (rows + GT - 1) / GT * GT + GT; }  // (+ one tile of zero rows: a tile may start anywhere below `rows`)
+size_t bf16x3_bytes(long long rows, long long K) { return sizeof(unsigned short) * 3 * (size_t)bf16x3_rows_pad(rows) * (size_t)((K + BK - 1) / BK * BK); }
+
+void launch_convert_panel_bf16x3(hipStream_t s, const double *P, long long ldp, long long rows, long long K, unsigned short *planes) {
+  if (rows <= 0 || K <= 0 || K % BK) return;
+  const long long rows_pad = bf16x3_rows_pad(rows);
+  hipLaunchKernelGGL(convert_panel_bf16x3_kernel, dim3((unsigned)((rows_pad + 255) / 256), (unsigned)(K / BK)), dim3(256), 0, s, P, ldp, rows,
+                     rows_pad, planes, rows_pad * K);
+}
+
+struct Bf16Args {
+  double *C;
+  long long ldc;
+  const unsigned short *planes;  // of the panel both operands come from
+  long long rows_pad, plane_stride;
+  long long row_a, row_b;        // panel row of C's row 0 / of C's column 0
+  long long M, N, K;
+  int ntr, ntc;
+  const int *order;              // XCD-aware tile order (gemm.hip: xcd_order) or nullptr
+};
+
+// tile (bi, bj) of the lower-triangular grid in column-major order (as gemm.hip's tile_of_block with tri = 1)
+__device__ __forceinline__ bool bf16_tile_of_block(const Bf16Args &g, int &bi, int &bj) {
+  long long id = blockIdx.x;
+  bj = 0;
+  while (bj < g.ntc && id >= g.ntr - bj) { id -= g.ntr - bj; ++bj; }
+  if (bj >= g.ntc) return false;
+  bi = bj + (int)id;
+  return true;
+}
+
+// staging of one K chunk: piece q (16 B) of a plane tile = row q >> 2, k group q & 3; a thread moves pieces tid and tid + 256
+// of the three planes of both operands.  (Twelve named registers, not an array: the compiler left an array of them in scratch.)
+struct BfStage {
+  uint4 a00, a01, a10, a11, a20, a21, b00, b01, b10, b11, b20, b21;
+};
+__device__ __forceinline__ void bf_load_stage(BfStage &st, const unsigned short *__restrict__ srcA, const unsigned short *__restrict__ srcB,
+                                              long long plane_stride, long long chunk_off, int tid) {
+  const long long o0 = chunk_off + (long long)tid * 8, o1 = o0 + 256 * 8;
+#define AGP_BF_LD(P, H, O) \
+  st.a##P##H = *reinterpret_cast<const uint4 *>(srcA + P * plane_stride + O); \
+  st.b##P##H = *reinterpret_cast<const uint4 *>(srcB + P * plane_stride + O)
+  AGP_BF_LD(0, 0, o0); AGP_BF_LD(0, 1, o1);
+  AGP_BF_LD(1, 0, o0); AGP_BF_LD(1, 1, o1);
+  AGP_BF_LD(2, 0, o0); AGP_BF_LD(2, 1, o1);
+#undef AGP_BF_LD
+}
+__device__ __forceinline__ void bf_store_stage(const BfStage &st, unsigned short *__restrict__ base, int tid) {
+  const int q1 = tid + 256;
+  const int d0 = (tid >> 2) * BPITCH + (tid & 3) * 8, d1 = (q1 >> 2) * BPITCH + (q1 & 3) * 8;
+#define AGP_BF_ST(P, H, D) \
+  *reinterpret_cast<uint4 *>(base + P * BPLANE + D) = st.a##P##H; \
+  *reinterpret_cast<uint4 *>(base + (3 + P) * BPLANE + D) = st.b##P##H
+  AGP_BF_ST(0, 0, d0); AGP_BF_ST(0, 1, d1);
+  AGP_BF_ST(1, 0, d0); AGP_BF_ST(1, 1, d1);
+  AGP_BF_ST(2, 0, d0); AGP_BF_ST(2, 1, d1);
+#undef AGP_BF_ST
+}
+
+__global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args g) {
+  __shared__ unsigned short lds[2 * 6 * BPLANE];  // [stage][operand A: hi mid lo | operand B: hi mid lo][128 rows][40]
+  int bi, bj;
+  if (g.order) {
+    const int packed = g.order[blockIdx.x];
+    if (packed < 0) return;
+    bi = packed >> 16;
+    bj = packed & 0xffff;
+  } else if (!bf16_tile_of_block(g, bi, bj)) return;
+  const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ln = lane & 15, lg = lane >> 4;
+
+  const unsigned short *srcA = g.planes + (g.row_a + i0) * BK, *srcB = g.planes + (g.row_b + j0) * BK;
+  const long long chunk_stride = g.rows_pad * BK;
+  BfStage st;
+
+  v4f32 acc[4][4];  // [tj][ti]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = v4f32{0.f, 0.f, 0.f, 0.f};
+
+  const long long nk = g.K / BK;
+  bf_load_stage(st, srcA, srcB, g.plane_stride, 0, tid);
+  bf_store_stage(st, lds, tid);
+  __syncthreads();
+
+  // C of this wave's 64 x 64 quadrant, fetched while the loop runs (register r of accumulator (tj, ti): row
+  // 16 ti + ln of the quadrant, column 16 tj + 4 lg + r - the C/D map of every non-f64 MFMA)
+  const bool interior = i0 + GT <= g.M && j0 + GT <= g.N;
+  double *const cbase = g.C + (i0 + 64 * wr + ln) + (j0 + 64 * wc + 4 * lg) * g.ldc;
+  double cpre[4][4][4];
+  const bool prefetch_c = interior && nk >= 16;
+  const long long nq = nk / 16;
+  long long kc = 0;
+  // (sixteen sections so that the part of C a section fetches is a compile-time index: one accumulator tile each)
+#pragma unroll
+  for (int part = 0; part < 16; ++part) {
+    const long long k_end = (part == 15 || !prefetch_c) ? nk : (part + 1) * nq;
+    bool first = prefetch_c;
+    for (; kc < k_end; ++kc) {
+      const int cur = (int)(kc & 1);
+      const unsigned short *S = lds + cur * (6 * BPLANE);
+      const bool more = kc + 1 < nk;
+      bf_load_stage(st, srcA, srcB, g.plane_stride, (more ? kc + 1 : kc) * chunk_stride, tid);
+      if (first) {
+        first = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cpre[part >> 2][part & 3][r] = __builtin_nontemporal_load(&cbase[16 * (part & 3) + (long long)(16 * (part >> 2) + r) * g.ldc]);
+      }
+      // fragments: A operand = the C-COLUMN panel (rows j0 ..), B operand = the C-ROW panel (rows i0 ..), as in gemm_tiles.h
+      v8bf fa[3][4], fb[3][4];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          fa[p][t] = *reinterpret_cast<const v8bf *>(S + (3 + p) * BPLANE + (64 * wc + 16 * t + ln) * BPITCH + 8 * lg);
+          fb[p][t] = *reinterpret_cast<const v8bf *>(S + p * BPLANE + (64 * wr + 16 * t + ln) * BPITCH + 8 * lg);
+        }
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          v4f32 a = acc[tj][ti];
+          // smallest terms first
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][tj], fb[0][ti], a, 0, 0, 0);  // lo hi
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][tj], fb[2][ti], a, 0, 0, 0);  // hi lo
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][tj], fb[1][ti], a, 0, 0, 0);  // mid mid
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][tj], fb[0][ti], a, 0, 0, 0);  // mid hi
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][tj], fb[1][ti], a, 0, 0, 0);  // hi mid
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][tj], fb[0][ti], a, 0, 0, 0);  // hi hi
+          acc[tj][ti] = a;
+        }
+      if (more) bf_store_stage(st, lds + (cur ^ 1) * (6 * BPLANE), tid);
+      __syncthreads();
+    }
+  }
+  if (prefetch_c) {
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_nontemporal_store(cpre[tj][ti][r] - (double)acc[tj][ti][r], &cbase[16 * ti + (long long)(16 * tj + r) * g.ldc]);
+    return;
+  }
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const long long row = i0 + 64 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 64 * wc + 16 * tj + 4 * lg + r;
+        if (row < g.M && col < g.N) {
+          double *c = g.C + row + col * g.ldc;
+          *c = *c - (double)acc[tj][ti][r];
+        }
+      }
+    }
+}
+
+// C (M x N, lower tiles, C(0, 0) on the matrix diagonal) -= P[row_a ..] P[row_b ..]^T from the bf16 planes of ONE panel
+// (launch_convert_panel_bf16x3).  order / order_len: the XCD-aware tile order of gemm.hip (nullptr: column-major tiles).
+void launch_update_bf16x3(hipStream_t s, double *C, long long ldc, const unsigned short *planes, long long panel_rows, long long row_a,
+                          long long row_b, long long M, long long N, long long K, const int *order, long long order_len) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % BK) return;
+  Bf16Args g;
+  g.C = C; g.ldc = ldc; g.planes = planes;
+  g.rows_pad = bf16x3_rows_pad(panel_rows);
+  g.plane_stride = g.rows_pad * K;
+  g.row_a = row_a; g.row_b = row_b;
+  g.M = M; g.N = N; g.K = K;
+  g.ntr = (int)((M + GT - 1) / GT);
+  g.ntc = (int)((N + GT - 1) / GT);
+  if (g.ntc > g.ntr) g.ntc = g.ntr;
+  g.order = order;
+  long long tiles = 0;
+  for (int bj = 0; bj < g.ntc; ++bj) tiles += g.ntr - bj;
+  const long long wgs = order ? order_len : tiles;
+  if (wgs <= 0) return;
+  hipLaunchKernelGGL(trailing_update_bf16x3_kernel, dim3((unsigned)wgs), dim3(256), 0, s, g);
+}
+
+}  // namespace agp

@@ -33,7 +33,7 @@ constexpr unsigned long long PUB_TIMEOUT_TICKS = 200000000ull;
 
 __device__ __forceinline__ bool poll_expired(unsigned long long t0, int *flags) {
   if (__builtin_amdgcn_s_memrealtime() - t0 < PUB_TIMEOUT_TICKS) return false;
-  if ((threadIdx.x & 63) == 0) atomicExch(flags + 2, 1);
+  if (flags && (threadIdx.x & 63) == 0) atomicExch(flags + 2, 1);
   return true;
 }
 

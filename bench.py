@@ -828,6 +828,36 @@ def run_rank(args):
             sys.stderr.flush()
             os._exit(3)
 
+    # ---- auxiliary (N > 1, sharded), LAST thing that touches the communicator: the same sharded fit at N = 65536, where the
+    # 8-rank schedule is COMPUTE-bound (one rank's share 227-250 ms against 1.67 s on one GPU; at N = 16384 it is bound by
+    # the owner chain) - the first real scaling curve should show both regimes.  Outside `value`.  A failure here must not
+    # cost the headline line: it is recorded, the line goes out, and the ranks leave without running destructors.
+    aux_big, aux_broken = None, False
+    if world > 1 and sharded and not args.no_configs and n == N_TRAIN:
+        try:
+            nb = 65536
+            xb, yb = make_dataset(nb, 45)
+            xb_d, yb_d = torch.from_numpy(xb).to(f"cuda:{local_rank}"), torch.from_numpy(yb).to(f"cuda:{local_rank}")
+            fb = make_feats(xb_d.data_ptr(), nb)
+            torch.cuda.synchronize()
+            big = ShardedGaussianProcessFit(ctx, cov, comm)
+            res = big.fit(None, None, features_struct=fb, device_targets=yb_d.data_ptr())  # warm-up + self-check
+            resid_b = sampled_residual(xb, yb, res.information)
+            barrier()
+            tb = time.perf_counter()
+            big.fit(None, None, features_struct=fb, device_targets=yb_d.data_ptr())
+            barrier()
+            tb = max_over_ranks(time.perf_counter() - tb)
+            aux_big = {"n": nb, "ms_per_fit": 1e3 * tb, "fits_per_sec": 1.0 / tb, "scaling": "strong",
+                       "tflops": nb ** 3 / 3. / tb / 1e12, "max_rel_residual": resid_b,
+                       "one_gpu_reference_ms": 1670.,
+                       "one_gpu_reference_source": "constant from profiles/r04/fit_vs_n.txt, not measured in this run",
+                       "note": "ONE fit of N = 65536 row-block-sharded over all ranks (compute-bound regime)"}
+            del big, xb_d, yb_d
+        except Exception as exc:  # noqa: BLE001
+            aux_big = {"error": f"{type(exc).__name__}: {exc}"}
+            aux_broken = True
+
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the per-launch figure
     # comes from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read
     # correction applied) of the single-GPU run; null if absent or not applicable.
@@ -910,12 +940,18 @@ def run_rank(args):
             out["predict"] = predict
         if aux is not None:
             out.update(aux)
+        if aux_big is not None:
+            out["n65536_sharded"] = aux_big
         if configs is not None:
             out["configs"] = configs
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     bad_check = self_check is not None and not self_check["ok"]
+    if aux_broken:  # the communicator may be mid-collective on a peer: no destructors
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(4 if bad_check else 0)
     if fell_back:
         # the abandoned communicator must not run its destructors (peers may sit in a collective of it)
         gloo_barrier()

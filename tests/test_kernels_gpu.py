@@ -100,13 +100,15 @@ def test_gemm_nt_sub_prefetching_tiles(ctx, dbg, M, N, K, tri, akm, bkm):
     test_gemm_nt_sub(ctx, dbg, M, N, K, tri, akm, bkm)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 13])
-@pytest.mark.parametrize("M,K", [(5900, 128), (6016, 512)])
+@pytest.mark.parametrize("variant", [0, 3, 13, 14])
+@pytest.mark.parametrize("M,K", [(5900, 128), (6016, 512), (700, 512), (1418, 96)])
 def test_trailing_update_large_tiles(ctx, dbg, M, K, variant):
     """Bulk updates of more than two rounds of 128 x 128 tiles: full rounds of prefetching tiles, the tiles of the partial
     round as 64 x 64 quadrants at the head of the same launch, ragged edge tiles (M = 5900) on the old path.  Variant 0:
     fp64 MFMA; 3: fp32 products of operands rounded while staged; 13: fp32 products of an fp32 copy of the panel
-    (launch_convert_panel_f32) - the two must agree bit for bit."""
+    (launch_convert_panel_f32) - the two must agree bit for bit; 14 (round 5): fp32-accurate products on the BF16 pipe from
+    three bf16 planes of the panel (gemm_bf16x3.hip: hi + mid + lo, six partial products) - the same 2e-7 bar as the fp32
+    kernel (measured: both ~3e-8 of the scale), interior tiles with C prefetched and ragged / shallow ones without."""
     rng = np.random.default_rng(M + K)
     ldc, ldp = M + 8, M + 10
     Cm = np.asfortranarray(rng.standard_normal((ldc, M)))
