@@ -191,6 +191,7 @@ static agp_context::Tuning read_tuning() {
   t.gram_sop = flag("AGP_GRAM_SOP", true);
   t.backsub_coop = flag("AGP_BACKSUB_COOP", true);
   t.mixed_bf16 = flag("AGP_MIXED_BF16", true);
+  t.sweep_coop = flag("AGP_SWEEP_COOP", true);
   t.sparse_pivoted = flag("AGP_SPARSE_PIVOTED", false);
   t.predict_chunk = number("AGP_PREDICT_CHUNK", 0);
   t.shard_block = number("AGP_SHARD_BLOCK", 0);
@@ -272,6 +273,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->pool_K) (void)agp::dev_release(ctx->pool_K);
   if (ctx->p32) (void)hipFree(ctx->p32);
   if (ctx->pool_L32) (void)hipFree(ctx->pool_L32);
+  if (ctx->pool_L32T) (void)hipFree(ctx->pool_L32T);
   if (ctx->pool_aux) (void)agp::dev_release(ctx->pool_aux);
   if (ctx->pool_shard) (void)agp::dev_release(ctx->pool_shard);
   if (ctx->pool_sparse) (void)agp::dev_release(ctx->pool_sparse);
@@ -961,7 +963,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
       FIT_CHECK(hipMalloc(&Kfull, Kfull_bytes));
     }
     FIT_CHECK(hipMalloc(&Wfwd, sizeof(double) * (size_t)nblk * NB * NB));
-    FIT_CHECK(hipMalloc(&vec, sizeof(double) * (size_t)n * 5));
+    FIT_CHECK(hipMalloc(&vec, sizeof(double) * (size_t)n * 7));  // y, r, z, p, q of the refinement + two scratch vectors of its sweeps
     FIT_CHECK(hipMemcpyAsync(vec, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, Kfull, fit->lda, yvar_d, ctx->d_flags,
                 &k->prog);
@@ -1164,7 +1166,34 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
     L32 = ctx->pool_L32;
     if (L32) launch_convert_lower_f32(s, fit->A, lda, n, L32);
   }
+  // ... and both sweeps as ONE launch each (solve.hip: sweep_coop_kernel) when the transposed copies fit: the backward
+  // sweep runs the same kernel on L^T (fp32) and the transposed inverses.  vec[5 n .. 7 n) : the intermediate and t.
+  float *L32T = nullptr;
+  double *WT = nullptr;
+  if (BW && L32 && ctx->tune.sweep_coop && n % 64 == 0 && BW <= 1024) {
+    const size_t want = sizeof(float) * (size_t)lda * (size_t)n;
+    if (ctx->pool_L32T && ctx->pool_L32T_bytes != want) { (void)hipFree(ctx->pool_L32T); ctx->pool_L32T = nullptr; ctx->pool_L32T_bytes = 0; }
+    if (!ctx->pool_L32T) {
+      if (hipMalloc(&ctx->pool_L32T, want) == hipSuccess) ctx->pool_L32T_bytes = want;
+      else { (void)hipGetLastError(); ctx->pool_L32T = nullptr; }
+    }
+    L32T = ctx->pool_L32T;
+    const size_t wbytes = sizeof(double) * (size_t)(n / BW) * (size_t)BW * (size_t)BW;
+    if (L32T && hipMalloc(&WT, wbytes) != hipSuccess) { (void)hipGetLastError(); WT = nullptr; L32T = nullptr; }
+    if (L32T) {
+      launch_transpose_tri_f32(s, L32, lda, L32T, lda, n);
+      (void)hipMemsetAsync(WT, 0, wbytes, s);
+      launch_transpose_tri_blocks(s, Wwide, WT, BW, n / BW);
+    }
+  }
+  struct FreeWT { double *p; ~FreeWT() { if (p) (void)hipFree(p); } } free_wt{WT};
   auto precondition = [&](const double *in, double *outv) {
+    if (L32T) {
+      double *ytmp = vec + 5 * n, *ttmp = vec + 6 * n;
+      launch_sweep_coop(s, L32, lda, n, Wwide, BW, in, ytmp, ttmp, ctx->d_flags, false);
+      launch_sweep_coop(s, L32T, lda, n, WT, BW, ytmp, outv, ttmp, ctx->d_flags, true);
+      return;
+    }
     (void)hipMemcpyAsync(outv, in, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
     if (BW) {
       forward_solve_vec_wide(s, fit->A, n, lda, Wwide, BW, outv, ctx->ws_aux, L32);
