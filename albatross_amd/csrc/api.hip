@@ -175,6 +175,7 @@ int agp_device_count(void) {
   return n;
 }
 
+static constexpr long long BACKSUB_COOP_MAX_N = 1280;
 // the switches of include/albatross_amd.h ("switches"): read here, once per context, and nowhere else
 static agp_context::Tuning read_tuning() {
   agp_context::Tuning t;
@@ -190,8 +191,8 @@ static agp_context::Tuning read_tuning() {
   t.step_below = number("AGP_STEP_BELOW", 4608);
   t.gram_sop = flag("AGP_GRAM_SOP", true);
   t.backsub_coop = flag("AGP_BACKSUB_COOP", true);
+  t.backsub_coop_max = number("AGP_BACKSUB_COOP_MAX", BACKSUB_COOP_MAX_N);
   t.mixed_bf16 = flag("AGP_MIXED_BF16", true);
-  t.sweep_coop = flag("AGP_SWEEP_COOP", true);
   t.sparse_pivoted = flag("AGP_SPARSE_PIVOTED", false);
   t.predict_chunk = number("AGP_PREDICT_CHUNK", 0);
   t.shard_block = number("AGP_SHARD_BLOCK", 0);
@@ -273,7 +274,6 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->pool_K) (void)agp::dev_release(ctx->pool_K);
   if (ctx->p32) (void)hipFree(ctx->p32);
   if (ctx->pool_L32) (void)hipFree(ctx->pool_L32);
-  if (ctx->pool_L32T) (void)hipFree(ctx->pool_L32T);
   if (ctx->pool_aux) (void)agp::dev_release(ctx->pool_aux);
   if (ctx->pool_shard) (void)agp::dev_release(ctx->pool_shard);
   if (ctx->pool_sparse) (void)agp::dev_release(ctx->pool_sparse);
@@ -533,7 +533,6 @@ static void finish_factor(agp_context_impl *ctx, const FactorTimers &timers) {
   ctx->stage_ms[5] = flop;  // flop of the trailing updates (not ms)
 }
 
-static constexpr long long BACKSUB_COOP_MAX_N = 1280;
 static constexpr size_t STATUS_BYTES = 4 * sizeof(int) + 4 * sizeof(double);
 
 // pre (optional): fills and copies the caller wants made BEFORE the Gram matrix is built, in the same launch as the
@@ -768,8 +767,14 @@ void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long lo
     // same seven-launch chain as inverting all of them (~100 us) - the last BW rows go through the one-launch substitution
     // instead (solve.hip: backsub_coop_kernel on the trailing BW x BW triangle, ~9 us per 128 rows), then its update
     const long long k0 = (nb - 1) * BW;
-    launch_fill_sentinel(s, xs + k0, BW);
-    backward_solve_coop(s, A + k0 * (lda + 1), BW, lda, invd + (k0 / NB) * (long long)(36 * MB * MB), z + k0, xs + k0, nullptr);
+    // (its per-block flags: the first words of xs, which the loop below overwrites only after this launch)
+    unsigned long long *done = reinterpret_cast<unsigned long long *>(xs);
+    {
+      PrepArgs prep;
+      prep.fill(done, 0ull, backsub_done_words(BW, 1));
+      launch_prep(s, prep);
+    }
+    backward_solve_coop(s, A + k0 * (lda + 1), BW, lda, invd + (k0 / NB) * (long long)(36 * MB * MB), z + k0, xs + k0, nullptr, done);
     launch_colvec_dot(s, A + k0, lda, BW, k0, xs + k0, -1.0, 1.0, z, z);  // z[0:k0] -= L[B, 0:k0]^T x_B
     if (ev_done) (void)hipStreamWaitEvent(s, ev_done, 0);
     for (long long b = nb - 2; b >= 0; --b) {
@@ -963,7 +968,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
       FIT_CHECK(hipMalloc(&Kfull, Kfull_bytes));
     }
     FIT_CHECK(hipMalloc(&Wfwd, sizeof(double) * (size_t)nblk * NB * NB));
-    FIT_CHECK(hipMalloc(&vec, sizeof(double) * (size_t)n * 7));  // y, r, z, p, q of the refinement + two scratch vectors of its sweeps
+    FIT_CHECK(hipMalloc(&vec, sizeof(double) * (size_t)n * 5));
     FIT_CHECK(hipMemcpyAsync(vec, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, Kfull, fit->lda, yvar_d, ctx->d_flags,
                 &k->prog);
@@ -990,8 +995,8 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   // inverted diagonal blocks anyway and keeps the launch-per-block substitution.)
   // Measured (profiles/r05): one hand-over + substitution per 128-column block is ~9 us - 37 us at N = 512 against 45 us
   // for the launch chain, 286 us at N = 4096 against 190 us through the 512-wide inverted blocks: small fits only.
-  const bool coop = !mixed && ctx->tune.backsub_coop && n <= BACKSUB_COOP_MAX_N;
-  if (coop) pre.sentinel(fit->alpha, n);
+  const bool coop = !mixed && ctx->tune.backsub_coop && n <= ctx->tune.backsub_coop_max;
+  if (coop) pre.fill(fit->winv, 0ull, backsub_done_words(n, 1));  // (its per-block flags live in the unused block-inverse buffer)
   FactorTimers ftimers;
   long long bs_done = 0;
   if (!coop && deferred && backsolve_width(n)) {
@@ -1032,7 +1037,7 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[3], s));
   if (coop) {
     TraceRange tr("agp: backward substitution (information = ldlt.solve(y), gp.hpp:68)");
-    backward_solve_coop(s, fit->A, n, fit->lda, fit->invd, fit->z, fit->alpha, ctx->d_flags);
+    backward_solve_coop(s, fit->A, n, fit->lda, fit->invd, fit->z, fit->alpha, ctx->d_flags, reinterpret_cast<unsigned long long *>(fit->winv));
     // (the hand-over flag of the substitution: the 48-byte status copy left before it ran)
     FIT_CHECK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   } else {
@@ -1166,34 +1171,7 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
     L32 = ctx->pool_L32;
     if (L32) launch_convert_lower_f32(s, fit->A, lda, n, L32);
   }
-  // ... and both sweeps as ONE launch each (solve.hip: sweep_coop_kernel) when the transposed copies fit: the backward
-  // sweep runs the same kernel on L^T (fp32) and the transposed inverses.  vec[5 n .. 7 n) : the intermediate and t.
-  float *L32T = nullptr;
-  double *WT = nullptr;
-  if (BW && L32 && ctx->tune.sweep_coop && n % 64 == 0 && BW <= 1024) {
-    const size_t want = sizeof(float) * (size_t)lda * (size_t)n;
-    if (ctx->pool_L32T && ctx->pool_L32T_bytes != want) { (void)hipFree(ctx->pool_L32T); ctx->pool_L32T = nullptr; ctx->pool_L32T_bytes = 0; }
-    if (!ctx->pool_L32T) {
-      if (hipMalloc(&ctx->pool_L32T, want) == hipSuccess) ctx->pool_L32T_bytes = want;
-      else { (void)hipGetLastError(); ctx->pool_L32T = nullptr; }
-    }
-    L32T = ctx->pool_L32T;
-    const size_t wbytes = sizeof(double) * (size_t)(n / BW) * (size_t)BW * (size_t)BW;
-    if (L32T && hipMalloc(&WT, wbytes) != hipSuccess) { (void)hipGetLastError(); WT = nullptr; L32T = nullptr; }
-    if (L32T) {
-      launch_transpose_tri_f32(s, L32, lda, L32T, lda, n);
-      (void)hipMemsetAsync(WT, 0, wbytes, s);
-      launch_transpose_tri_blocks(s, Wwide, WT, BW, n / BW);
-    }
-  }
-  struct FreeWT { double *p; ~FreeWT() { if (p) (void)hipFree(p); } } free_wt{WT};
   auto precondition = [&](const double *in, double *outv) {
-    if (L32T) {
-      double *ytmp = vec + 5 * n, *ttmp = vec + 6 * n;
-      launch_sweep_coop(s, L32, lda, n, Wwide, BW, in, ytmp, ttmp, ctx->d_flags, false);
-      launch_sweep_coop(s, L32T, lda, n, WT, BW, ytmp, outv, ttmp, ctx->d_flags, true);
-      return;
-    }
     (void)hipMemcpyAsync(outv, in, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
     if (BW) {
       forward_solve_vec_wide(s, fit->A, n, lda, Wwide, BW, outv, ctx->ws_aux, L32);

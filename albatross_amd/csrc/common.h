@@ -90,8 +90,6 @@ struct agp_context {
   // ... and the fp32 copy of the factor that preconditions their refinement
   float *pool_L32 = nullptr;
   size_t pool_L32_bytes = 0;
-  float *pool_L32T = nullptr;  // ... and its transpose (the backward sweep of the one-launch preconditioner, solve.hip: sweep_coop_kernel)
-  size_t pool_L32T_bytes = 0;
   // ... and one cached block of a fit's small buffers (agp_fit::aux_base)
   double *pool_aux = nullptr;
   size_t pool_aux_bytes = 0;
@@ -126,8 +124,8 @@ struct agp_context {
     bool panel_fused = true;       // AGP_PANEL_FUSED=0: POTRF and panel TRSM as two launches
     long long step_below = 4608;   // AGP_STEP_BELOW: remaining rows at or below which every panel is ONE step launch (0: off)
     bool gram_sop = true;          // AGP_GRAM_SOP=0: covariance trees through the stack interpreter only
-    bool sweep_coop = true;        // AGP_SWEEP_COOP=0: the mixed fit's preconditioner sweeps as a launch chain per block (rounds 2-4)
     bool mixed_bf16 = true;        // AGP_MIXED_BF16=0: the mixed-precision fit's products on the fp32 MFMA (rounds 1-4) instead of bf16 x 3
+    long long backsub_coop_max = 1280;  // AGP_BACKSUB_COOP_MAX: largest n whose fit uses it (measurement switch)
     bool backsub_coop = true;      // AGP_BACKSUB_COOP=0: the fit's back substitution as a launch per block (rounds 1-4) instead of ONE launch
     bool sparse_pivoted = false;   // AGP_SPARSE_PIVOTED=1: the sparse GP's literal (pivoted LDL^T + QR) path always
     long long predict_chunk = 0;   // AGP_PREDICT_CHUNK: test points per slice of the marginal / joint predictions (0: by memory)
@@ -259,16 +257,12 @@ void factor_lower_batched_lookahead(agp_context *ctx, double *A, long long strid
 // z_b <- L_b^-T z_b for `count` problems, one vector each (solve.hip)
 void backward_solve_vec_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
                                 const double *invd, long long stride_invd, double *z, long long stride_z, long long count);
-// x = L^-T z in ONE launch (solve.hip: backsub_coop_kernel); x must be sentinel-filled (launch_fill_sentinel / PrepArgs)
+// x = L^-T z in ONE launch (solve.hip: backsub_coop_kernel); done: backsub_done_words(n, count) ZEROED words (PrepArgs::fill)
+long long backsub_done_words(long long n, long long count);
 void backward_solve_coop(hipStream_t s, const double *A, long long n, long long lda, const double *invd, const double *z,
-                         double *x, int *flags, long long count = 1, long long stride_A = 0, long long stride_invd = 0,
-                         long long stride_z = 0, long long stride_x = 0, long long stride_flags = 0);
+                         double *x, int *flags, unsigned long long *done, long long count = 1, long long stride_A = 0,
+                         long long stride_invd = 0, long long stride_z = 0, long long stride_x = 0, long long stride_flags = 0);
 void launch_fill_sentinel(hipStream_t s, double *p, long long count);
-// one triangular sweep of the mixed fit's preconditioner in ONE launch (solve.hip: sweep_coop_kernel)
-void launch_sweep_coop(hipStream_t s, const float *M, long long ld, long long n, const double *W, long long BW, const double *z, double *x,
-                       double *t, int *flags, bool backward);
-void launch_transpose_tri_f32(hipStream_t s, const float *src, long long lds_, float *dst, long long ldd, long long n);
-void launch_transpose_tri_blocks(hipStream_t s, const double *src, double *dst, long long BW, long long count);
 void forward_solve_mat_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
                                const double *invd, long long stride_invd, double *B, long long stride_B, long long m,
                                long long ldb, bool rhs_lower, long long count);

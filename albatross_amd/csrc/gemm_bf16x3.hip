@@ -102,32 +102,28 @@ __device__ __forceinline__ bool bf16_tile_of_block(const Bf16Args &g, int &bi, i
 }
 
 // staging of one K chunk: piece q (16 B) of a plane tile = row q >> 2, k group q & 3; a thread moves pieces tid and tid + 256
-// of the three planes of both operands.  (Twelve named registers, not an array: the compiler left an array of them in scratch.)
-struct BfStage {
-  uint4 a00, a01, a10, a11, a20, a21, b00, b01, b10, b11, b20, b21;
-};
-__device__ __forceinline__ void bf_load_stage(BfStage &st, const unsigned short *__restrict__ srcA, const unsigned short *__restrict__ srcB,
-                                              long long plane_stride, long long chunk_off, int tid) {
-  const long long o0 = chunk_off + (long long)tid * 8, o1 = o0 + 256 * 8;
-#define AGP_BF_LD(P, H, O) \
-  st.a##P##H = *reinterpret_cast<const uint4 *>(srcA + P * plane_stride + O); \
-  st.b##P##H = *reinterpret_cast<const uint4 *>(srcB + P * plane_stride + O)
-  AGP_BF_LD(0, 0, o0); AGP_BF_LD(0, 1, o1);
-  AGP_BF_LD(1, 0, o0); AGP_BF_LD(1, 1, o1);
-  AGP_BF_LD(2, 0, o0); AGP_BF_LD(2, 1, o1);
-#undef AGP_BF_LD
-}
-__device__ __forceinline__ void bf_store_stage(const BfStage &st, unsigned short *__restrict__ base, int tid) {
-  const int q1 = tid + 256;
-  const int d0 = (tid >> 2) * BPITCH + (tid & 3) * 8, d1 = (q1 >> 2) * BPITCH + (q1 & 3) * 8;
-#define AGP_BF_ST(P, H, D) \
-  *reinterpret_cast<uint4 *>(base + P * BPLANE + D) = st.a##P##H; \
-  *reinterpret_cast<uint4 *>(base + (3 + P) * BPLANE + D) = st.b##P##H
-  AGP_BF_ST(0, 0, d0); AGP_BF_ST(0, 1, d1);
-  AGP_BF_ST(1, 0, d0); AGP_BF_ST(1, 1, d1);
-  AGP_BF_ST(2, 0, d0); AGP_BF_ST(2, 1, d1);
-#undef AGP_BF_ST
-}
+// of the three planes of both operands - twelve NAMED registers and macros: an array or a struct of them passed to helper
+// functions stayed in scratch once the loads were pinned in front of the MFMAs
+#define AGP_BF_LOAD(OFF)                                                                                   \
+  do {                                                                                                     \
+    const long long o0_ = (OFF) + (long long)tid * 8, o1_ = o0_ + 256 * 8;                                 \
+    sa00 = *reinterpret_cast<const uint4 *>(srcA + o0_);                    sa01 = *reinterpret_cast<const uint4 *>(srcA + o1_);                    \
+    sb00 = *reinterpret_cast<const uint4 *>(srcB + o0_);                    sb01 = *reinterpret_cast<const uint4 *>(srcB + o1_);                    \
+    sa10 = *reinterpret_cast<const uint4 *>(srcA + g.plane_stride + o0_);     sa11 = *reinterpret_cast<const uint4 *>(srcA + g.plane_stride + o1_);     \
+    sb10 = *reinterpret_cast<const uint4 *>(srcB + g.plane_stride + o0_);     sb11 = *reinterpret_cast<const uint4 *>(srcB + g.plane_stride + o1_);     \
+    sa20 = *reinterpret_cast<const uint4 *>(srcA + 2 * g.plane_stride + o0_); sa21 = *reinterpret_cast<const uint4 *>(srcA + 2 * g.plane_stride + o1_); \
+    sb20 = *reinterpret_cast<const uint4 *>(srcB + 2 * g.plane_stride + o0_); sb21 = *reinterpret_cast<const uint4 *>(srcB + 2 * g.plane_stride + o1_); \
+  } while (0)
+#define AGP_BF_STORE(BASE)                                                                                 \
+  do {                                                                                                     \
+    unsigned short *b_ = (BASE);                                                                           \
+    *reinterpret_cast<uint4 *>(b_ + 0 * BPLANE + d0) = sa00; *reinterpret_cast<uint4 *>(b_ + 0 * BPLANE + d1) = sa01; \
+    *reinterpret_cast<uint4 *>(b_ + 1 * BPLANE + d0) = sa10; *reinterpret_cast<uint4 *>(b_ + 1 * BPLANE + d1) = sa11; \
+    *reinterpret_cast<uint4 *>(b_ + 2 * BPLANE + d0) = sa20; *reinterpret_cast<uint4 *>(b_ + 2 * BPLANE + d1) = sa21; \
+    *reinterpret_cast<uint4 *>(b_ + 3 * BPLANE + d0) = sb00; *reinterpret_cast<uint4 *>(b_ + 3 * BPLANE + d1) = sb01; \
+    *reinterpret_cast<uint4 *>(b_ + 4 * BPLANE + d0) = sb10; *reinterpret_cast<uint4 *>(b_ + 4 * BPLANE + d1) = sb11; \
+    *reinterpret_cast<uint4 *>(b_ + 5 * BPLANE + d0) = sb20; *reinterpret_cast<uint4 *>(b_ + 5 * BPLANE + d1) = sb21; \
+  } while (0)
 
 __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args g) {
   __shared__ unsigned short lds[2 * 6 * BPLANE];  // [stage][operand A: hi mid lo | operand B: hi mid lo][128 rows][40]
@@ -145,7 +141,8 @@ __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args
 
   const unsigned short *srcA = g.planes + (g.row_a + i0) * BK, *srcB = g.planes + (g.row_b + j0) * BK;
   const long long chunk_stride = g.rows_pad * BK;
-  BfStage st;
+  uint4 sa00, sa01, sa10, sa11, sa20, sa21, sb00, sb01, sb10, sb11, sb20, sb21;
+  const int d0 = (tid >> 2) * BPITCH + (tid & 3) * 8, d1 = ((tid + 256) >> 2) * BPITCH + (tid & 3) * 8;
 
   v4f32 acc[4][4];  // [tj][ti]
 #pragma unroll
@@ -154,8 +151,8 @@ __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args
     for (int b = 0; b < 4; ++b) acc[a][b] = v4f32{0.f, 0.f, 0.f, 0.f};
 
   const long long nk = g.K / BK;
-  bf_load_stage(st, srcA, srcB, g.plane_stride, 0, tid);
-  bf_store_stage(st, lds, tid);
+  AGP_BF_LOAD(0);
+  AGP_BF_STORE(lds);
   __syncthreads();
 
   // C of this wave's 64 x 64 quadrant, fetched while the loop runs (register r of accumulator (tj, ti): row
@@ -163,6 +160,8 @@ __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args
   const bool interior = i0 + GT <= g.M && j0 + GT <= g.N;
   double *const cbase = g.C + (i0 + 64 * wr + ln) + (j0 + 64 * wc + 4 * lg) * g.ldc;
   double cpre[4][4][4];
+  double cnew[4] = {0., 0., 0., 0.};
+  bool fresh = false;
   const bool prefetch_c = interior && nk >= 16;
   const long long nq = nk / 16;
   long long kc = 0;
@@ -175,12 +174,14 @@ __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args
       const int cur = (int)(kc & 1);
       const unsigned short *S = lds + cur * (6 * BPLANE);
       const bool more = kc + 1 < nk;
-      bf_load_stage(st, srcA, srcB, g.plane_stride, (more ? kc + 1 : kc) * chunk_stride, tid);
+      // (pinning these loads in front of the MFMAs with a scheduling barrier, and parking C in accumulation registers to make
+      // room for that, were measured: 97-99 / 115-116 TFLOP/s at M = 15872 / 30720 in all four combinations - not the bound)
+      AGP_BF_LOAD((more ? kc + 1 : kc) * chunk_stride);
       if (first) {
         first = false;
+        fresh = true;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cpre[part >> 2][part & 3][r] = __builtin_nontemporal_load(&cbase[16 * (part & 3) + (long long)(16 * (part >> 2) + r) * g.ldc]);
+        for (int r = 0; r < 4; ++r) cnew[r] = __builtin_nontemporal_load(&cbase[16 * (part & 3) + (long long)(16 * (part >> 2) + r) * g.ldc]);
       }
       // fragments: A operand = the C-COLUMN panel (rows j0 ..), B operand = the C-ROW panel (rows i0 ..), as in gemm_tiles.h
       v8bf fa[3][4], fb[3][4];
@@ -205,7 +206,14 @@ __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][tj], fb[0][ti], a, 0, 0, 0);  // hi hi
           acc[tj][ti] = a;
         }
-      if (more) bf_store_stage(st, lds + (cur ^ 1) * (6 * BPLANE), tid);
+      if (fresh) {  // the part of C requested at the top of this chunk has arrived behind its MFMAs: park it
+        fresh = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cpre[part >> 2][part & 3][r] = cnew[r];
+        }
+      }
+      if (more) AGP_BF_STORE(lds + (cur ^ 1) * (6 * BPLANE));
       __syncthreads();
     }
   }
@@ -215,8 +223,10 @@ __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          __builtin_nontemporal_store(cpre[tj][ti][r] - (double)acc[tj][ti][r], &cbase[16 * ti + (long long)(16 * tj + r) * g.ldc]);
+        for (int r = 0; r < 4; ++r) {
+          const double cv = cpre[tj][ti][r];
+          __builtin_nontemporal_store(cv - (double)acc[tj][ti][r], &cbase[16 * ti + (long long)(16 * tj + r) * g.ldc]);
+        }
     return;
   }
 #pragma unroll
@@ -234,6 +244,9 @@ __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args
       }
     }
 }
+
+#undef AGP_BF_LOAD
+#undef AGP_BF_STORE
 
 // C (M x N, lower tiles, C(0, 0) on the matrix diagonal) -= P[row_a ..] P[row_b ..]^T from the bf16 planes of ONE panel
 // (launch_convert_panel_bf16x3).  order / order_len: the XCD-aware tile order of gemm.hip (nullptr: column-major tiles).

@@ -474,9 +474,10 @@ struct BackCoopArgs {
   long long lda, n;
   const double *img;  // tile images of the diagonal blocks (IMG_DOUBLES each)
   const double *z;    // right-hand side
-  double *x;          // solution (sentinel-filled by the caller)
+  double *x;          // solution
   int *flags;         // flags[2]: a hand-over timed out
-  long long batch_A = 0, batch_img = 0, batch_z = 0, batch_x = 0, batch_flags = 0;
+  unsigned long long *done;  // one word per block (zeroed by the caller): set when the block's x is in memory
+  long long batch_A = 0, batch_img = 0, batch_z = 0, batch_x = 0, batch_flags = 0, batch_done = 0;
 };
 
 __global__ __launch_bounds__(512) void backsub_coop_kernel(BackCoopArgs p) {
@@ -484,7 +485,9 @@ __global__ __launch_bounds__(512) void backsub_coop_kernel(BackCoopArgs p) {
   __shared__ double ts[NB];
   {
     const long long pb = blockIdx.y;
-    p.A += pb * p.batch_A; p.img += pb * p.batch_img; p.z += pb * p.batch_z; p.x += pb * p.batch_x; p.flags += pb * p.batch_flags;
+    p.A += pb * p.batch_A; p.img += pb * p.batch_img; p.z += pb * p.batch_z; p.x += pb * p.batch_x;
+    if (p.flags) p.flags += pb * p.batch_flags;
+    p.done += pb * p.batch_done;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long nb = (p.n + NB - 1) / NB;
@@ -518,18 +521,16 @@ __global__ __launch_bounds__(512) void backsub_coop_kernel(BackCoopArgs p) {
   if (nb - 1 > b) load_rows(nb - 1);
   for (long long j = nb - 1; j > b; --j) {
     const long long r0 = j * NB + lane, r1 = r0 + 64;
-    double x0 = 0., x1 = 0.;
-    {
-      unsigned long long t0 = 0;
-      for (int spin = 0;; ++spin) {
-        x0 = (r0 < p.n) ? load_pub(p.x + r0) : 0.;
-        x1 = (r1 < p.n) ? load_pub(p.x + r1) : 0.;
-        if (__all(!is_unpublished(x0) && !is_unpublished(x1))) break;
-        if (spin == 0) t0 = __builtin_amdgcn_s_memrealtime();
-        else if ((spin & 63) == 0 && poll_expired(t0, p.flags)) { x0 = x1 = 0.; break; }
-        __builtin_amdgcn_s_sleep(2);
+    // ONE lane per wave polls the block's flag (every lane polling the values themselves is 131 k threads hammering the
+    // memory side: that polling was what the hand-over cost), then every lane reads its two values once
+    if (lane == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (int spin = 1; __hip_atomic_load(p.done + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin) {
+        if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
+        __builtin_amdgcn_s_sleep(4);
       }
     }
+    const double x0 = (r0 < p.n) ? load_pub(p.x + r0) : 0., x1 = (r1 < p.n) ? load_pub(p.x + r1) : 0.;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] += a0[q] * x0 + a1[q] * x1;
     if (j - 1 > b) load_rows(j - 1);
@@ -543,14 +544,17 @@ __global__ __launch_bounds__(512) void backsub_coop_kernel(BackCoopArgs p) {
   if (wave != 0) return;
   // x_b = L_bb^-T t by micro blocks (trsm_kernel.h), every value published the moment it is final
   micro_backsub_wave(F, ts, [&](int c, double v) { if (c < nbk) store_pub(p.x + k0 + c, v); });
+  if (lane == 0) __hip_atomic_store(p.done + b, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // (behind the wave's stores)
 }
 
-// x (n, sentinel-filled by the caller: PrepArgs::sentinel / launch_fill_sentinel) = L^-T z; count problems (strides 0 for one)
+// x = L^-T z; count problems (strides 0 for one).  done: one zeroed word per 128-row block and problem (backsub_done_words)
+long long backsub_done_words(long long n, long long count) { return (n + NB - 1) / NB * (count > 0 ? count : 1); }
 void backward_solve_coop(hipStream_t s, const double *A, long long n, long long lda, const double *invd, const double *z,
-                         double *x, int *flags, long long count, long long stride_A, long long stride_invd, long long stride_z,
-                         long long stride_x, long long stride_flags) {
+                         double *x, int *flags, unsigned long long *done, long long count, long long stride_A, long long stride_invd,
+                         long long stride_z, long long stride_x, long long stride_flags) {
   if (n <= 0 || count <= 0) return;
   BackCoopArgs p;
+  p.done = done; p.batch_done = (n + NB - 1) / NB;
   p.A = A; p.lda = lda; p.n = n; p.img = invd; p.z = z; p.x = x; p.flags = flags;
   p.batch_A = stride_A; p.batch_img = stride_invd; p.batch_z = stride_z; p.batch_x = stride_x; p.batch_flags = stride_flags;
   const long long nb = (n + NB - 1) / NB;
@@ -563,162 +567,6 @@ void launch_fill_sentinel(hipStream_t s, double *p, long long count) {
   launch_prep(s, a);
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// One triangular sweep of the mixed fit's PRECONDITIONER in ONE launch (round 5): z -> L^-1 z (forward) or L^-T z
-// (backward) through explicitly inverted BW x BW diagonal blocks (invert_wide_blocks) and the fp32 copy of the factor.
-// Rounds 2-4 walked the blocks with launches - 3 per block forward, 2 backward, 160 launches per application at
-// N = 32768 - and were bound by them: 3 ms per application where the fp32 factor streams in 2 x 0.5 ms.
-// Here a workgroup owns a strip of 64 rows of the triangular system and consumes the solution block by block as it is
-// PUBLISHED (sentinel-filled vectors, device-scope stores and loads, pub.h):
-//   acc  = sum over the blocks c before its own:  M[strip, block c] x_c        (the fp32 matrix, 256 KB per block, streamed)
-//   t    = z - acc                      published; the diagonal block needs the t of the strips before this one
-//   x    = W_b[strip, :] t_b            published
-// `M` is addressed as a LOWER triangle whatever the direction: the backward sweep runs on TRANSPOSED copies (the upper
-// triangle of L^T stored as given, launch_transpose_tri) with the strips in descending order - same kernel, `backward`
-// flips the index maps.  Liveness: blockIdx.x = 0 is the strip whose solution comes first, and a workgroup only waits
-// for strips dispatched before it.  Thread layout: lane = (rg = lane & 15: rows 4 rg .. 4 rg + 3 of the strip,
-// cg = lane >> 4 + 4 wave: every 16th column) - float4 / 2 x double2 loads of 4 consecutive rows.
-// ---------------------------------------------------------------------------------------------------------------
-struct SweepArgs {
-  const float *M;     // fp32 factor: forward L (lower), backward L^T (upper), leading dimension ld
-  long long ld, n, BW;
-  const double *W;    // inverted diagonal blocks, BW x BW each, column-major: forward inv(L_bb), backward inv(L_bb)^T
-  const double *z;    // right-hand side
-  double *x, *t;      // solution / intermediate, both sentinel-filled by the caller
-  int *flags;
-  int backward;
-};
-
-template <bool BACK>
-__device__ __forceinline__ void sweep_body(const SweepArgs &p) {
-  __shared__ double xs[1024];
-  __shared__ double red[16][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rg = lane & 15, cg = (lane >> 4) + 4 * wave;
-  const long long nstrips = p.n / 64, spb = p.BW / 64, nb = p.n / p.BW;
-  const long long s = BACK ? nstrips - 1 - (long long)blockIdx.x : (long long)blockIdx.x;
-  const long long r0 = 64 * s, b = r0 / p.BW, q = s - b * spb;  // strip q of block b
-  // wait for `count` values of v starting at `first` (a multiple of 4 per thread), into xs[0 .. count)
-  auto fetch = [&](const double *v, long long first, int count) {
-    unsigned long long t0 = 0;
-    for (int i = 4 * tid; i < count; i += 1024) {
-      double a[4];
-      for (int spin = 0;; ++spin) {
-        bool ok = true;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = load_pub(v + first + i + u); ok = ok && !is_unpublished(a[u]); }
-        if (ok) break;
-        if (spin == 0) t0 = __builtin_amdgcn_s_memrealtime();
-        else if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) xs[i + u] = a[u];
-    }
-  };
-  double acc[4] = {0., 0., 0., 0.};
-  const float *Mrow = p.M + r0 + 4 * rg;
-  for (long long k = 0; k < (BACK ? nb - 1 - b : b); ++k) {
-    const long long c = BACK ? nb - 1 - k : k;
-    fetch(p.x, c * p.BW, (int)p.BW);
-    __syncthreads();
-    const float *Mc = Mrow + (c * p.BW + cg) * p.ld;
-#pragma unroll 8
-    for (int jj = 0; jj < (int)(p.BW / 16); ++jj) {
-      const float4 v = *reinterpret_cast<const float4 *>(Mc + (long long)(16 * jj) * p.ld);
-      const double xj = xs[16 * jj + cg];
-      acc[0] += (double)v.x * xj; acc[1] += (double)v.y * xj; acc[2] += (double)v.z * xj; acc[3] += (double)v.w * xj;
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) red[cg][4 * rg + u] = acc[u];
-  __syncthreads();
-  if (tid < 64) {
-    double sum = 0.;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) sum += red[g][tid];
-    store_pub(p.t + r0 + tid, p.z[r0 + tid] - sum);
-  }
-  // x[strip] = W_b[strip rows, needed columns] t_b: the lower triangle of the block (forward: columns up to this strip's
-  // last row; backward, on the transposed block: columns from this strip's first row on)
-  const long long j_lo = BACK ? q * 64 : 0, j_hi = BACK ? p.BW : (q + 1) * 64;
-  __syncthreads();
-  fetch(p.t, b * p.BW + j_lo, (int)(j_hi - j_lo));
-  __syncthreads();
-  double ax[4] = {0., 0., 0., 0.};
-  const double *Wr = p.W + b * p.BW * p.BW + (q * 64 + 4 * rg);
-#pragma unroll 4
-  for (long long j = j_lo + cg; j < j_hi; j += 16) {
-    const double2 v0 = *reinterpret_cast<const double2 *>(Wr + j * p.BW);
-    const double2 v1 = *reinterpret_cast<const double2 *>(Wr + j * p.BW + 2);
-    const double tj = xs[j - j_lo];
-    ax[0] += v0.x * tj; ax[1] += v0.y * tj; ax[2] += v1.x * tj; ax[3] += v1.y * tj;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 4; ++u) red[cg][4 * rg + u] = ax[u];
-  __syncthreads();
-  if (tid < 64) {
-    double sum = 0.;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) sum += red[g][tid];
-    store_pub(p.x + r0 + tid, sum);
-  }
-}
-
-__global__ __launch_bounds__(256) void sweep_coop_kernel(SweepArgs p) {
-  if (p.backward) sweep_body<true>(p);
-  else sweep_body<false>(p);
-}
-
-// x = L^-1 z (backward = 0: M = the fp32 lower factor, W = the inverted diagonal blocks) or x = L^-T z (backward = 1: M and W
-// the TRANSPOSED copies).  n a multiple of BW, BW a multiple of 64 and <= 1024.  x and t are filled with sentinels here.
-void launch_sweep_coop(hipStream_t s, const float *M, long long ld, long long n, const double *W, long long BW, const double *z, double *x,
-                       double *t, int *flags, bool backward) {
-  PrepArgs prep;
-  prep.sentinel(x, n);
-  prep.sentinel(t, n);
-  launch_prep(s, prep);
-  SweepArgs a;
-  a.M = M; a.ld = ld; a.n = n; a.BW = BW; a.W = W; a.z = z; a.x = x; a.t = t; a.flags = flags; a.backward = backward ? 1 : 0;
-  hipLaunchKernelGGL(sweep_coop_kernel, dim3((unsigned)(n / 64)), dim3(256), 0, s, a);
-}
-
-// dst (upper triangle, ldd) = the transpose of src's lower triangle (lds): dst[i + j ldd] = src[j + i lds] for j >= i.
-// 32 x 32 tiles through LDS; the other triangle of dst is left alone.
-template <class T>
-__global__ __launch_bounds__(256) void transpose_tri_kernel(const T *__restrict__ src, long long lds_, T *__restrict__ dst, long long ldd, long long n,
-                                                            long long batch_src, long long batch_dst) {
-  __shared__ T tile[32][33];
-  src += (long long)blockIdx.z * batch_src;
-  dst += (long long)blockIdx.z * batch_dst;
-  const long long bi = blockIdx.x, bj = blockIdx.y;  // source tile rows bi, cols bj (bi >= bj)
-  if (bi < bj) return;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const long long r = bi * 32 + tx, c = bj * 32 + ty + 8 * k;
-    tile[ty + 8 * k][tx] = (r < n && c < n && r >= c) ? src[r + c * lds_] : (T)0;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    // destination element (i, j) = (source col, source row): i = bj * 32 + tx, j = bi * 32 + ty + 8 k
-    const long long i = bj * 32 + tx, j = bi * 32 + ty + 8 * k;
-    if (i < n && j < n && j >= i) dst[i + j * ldd] = tile[tx][ty + 8 * k];
-  }
-}
-
-void launch_transpose_tri_f32(hipStream_t s, const float *src, long long lds_, float *dst, long long ldd, long long n) {
-  const unsigned nt = (unsigned)((n + 31) / 32);
-  hipLaunchKernelGGL(transpose_tri_kernel<float>, dim3(nt, nt, 1), dim3(256), 0, s, src, lds_, dst, ldd, n, 0LL, 0LL);
-}
-void launch_transpose_tri_blocks(hipStream_t s, const double *src, double *dst, long long BW, long long count) {
-  const unsigned nt = (unsigned)((BW + 31) / 32);
-  hipLaunchKernelGGL(transpose_tri_kernel<double>, dim3(nt, nt, (unsigned)count), dim3(256), 0, s, src, BW, dst, BW, BW, BW * BW, BW * BW);
-}
 
 // ---- X = L^-1 B out of place for a right-hand side MUCH wider than L (the sparse GP's m x n matrices K_uf and W, n in the
 // hundred thousands) --------------------------------------------------------------------------------------------------

@@ -610,7 +610,6 @@ AGP_API int agp_set_profiling(agp_context *ctx, int enabled);
  *   AGP_STEP_BELOW=<rows>    remaining rows at or below which every panel is ONE step launch (default 4608; 0: off)
  *   AGP_GRAM_SOP=0           covariance trees through the stack interpreter only (parity tests run both evaluators)
  *   AGP_MIXED_BF16=0         agp_fit_create_mixed forms its fp32-accurate products on the fp32 MFMA instead of bf16 x 3
- *   AGP_SWEEP_COOP=0         the mixed fit's preconditioner sweeps as launch chains per block instead of ONE launch each
  *   AGP_BACKSUB_COOP=0       the fit's back substitution as one launch per block (rounds 1-4) instead of ONE launch
  *   AGP_SPARSE_PIVOTED=1     the sparse GP always takes the literal (pivoted LDL^T + column-pivoted QR) path
  *   AGP_PREDICT_CHUNK=<m>    test points per slice of marginal predictions (default: by memory, 2 GiB per slice)

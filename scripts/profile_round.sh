@@ -3,7 +3,7 @@
 # Writes under gpurun_out/prof_<round>/ ; scripts/pmc_summary.py turns the CSVs into the
 # summaries kept under profiles/<round>/.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 # the repository root, resolved BEFORE the cd below (GRAFT_REPO_ROOT is only set on the gpurun box)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT="$ROOT/gpurun_out/prof_$R"
@@ -29,5 +29,8 @@ python3 scripts/time_sharded_rccl1.py > "$OUT/time_sharded_rccl1.txt" 2>&1
 python3 scripts/time_config2.py 1024 2048 4096 8192 > "$OUT/time_config2.txt" 2>&1
 python3 scripts/time_fit_batch.py > "$OUT/time_fit_batch.txt" 2>&1
 python3 scripts/fit_vs_n.py > "$OUT/fit_vs_n.txt" 2>&1
+python3 scripts/time_bf16x3.py 15872 30720 > "$OUT/time_bf16x3.txt" 2>&1
+FIT_BATCHES=1,8,32,256 python3 scripts/time_fit_batch.py 512 1024 > "$OUT/time_fit_batch_256.txt" 2>&1
+for n in 512 1024 2048 4096; do TRACE_N=$n python3 scripts/trace_config2_api.py; done > "$OUT/fit_resident.txt" 2>&1
 ls -la "$OUT" "$OUT"/*/ | head -60
 tail -1 "$OUT/bench_n1.json" | cut -c1-300
