@@ -696,6 +696,11 @@ void agp_fit_destroy(agp_fit *fit) {
   if (fit->slab) {
     if (--fit->slab->refs == 0) {
       agp_context *ctx = fit->ctx;
+      if (ctx && ctx->pool_batch && ctx->pool_batch_bytes != fit->slab->bytes) {  // (the most recent size wins the slot, as pool_A)
+        (void)dev_release(ctx->pool_batch);
+        ctx->pool_batch = nullptr;
+        ctx->pool_batch_bytes = 0;
+      }
       if (ctx && !ctx->pool_batch) { ctx->pool_batch = fit->slab->base; ctx->pool_batch_bytes = fit->slab->bytes; }  // (like pool_A)
       else (void)dev_release(fit->slab->base);
       delete fit->slab;
@@ -706,6 +711,14 @@ void agp_fit_destroy(agp_fit *fit) {
   }
   if (fit->A) {
     agp_context *ctx = fit->ctx;
+    // (the most recent size wins the slot: a buffer of another size parked there - the headline's 2 GiB factor, say, in a
+    // process that goes on to fit 512 points - would cost every later fit a hipMalloc and a hipFree: +0.2 ms per N = 512
+    // fit, the "0.21 vs 0.41 ms" of the round-4 review)
+    if (ctx && ctx->pool_A && ctx->pool_A_bytes != fit->A_bytes) {
+      (void)dev_release(ctx->pool_A);
+      ctx->pool_A = nullptr;
+      ctx->pool_A_bytes = 0;
+    }
     if (ctx && !ctx->pool_A) {
       // kernels reading the factor were enqueued on the context's streams; the
       // next user of the buffer is enqueued on the same streams, after them
@@ -717,6 +730,11 @@ void agp_fit_destroy(agp_fit *fit) {
   }
   if (fit->aux_base) {
     agp_context *ctx = fit->ctx;
+    if (ctx && ctx->pool_aux && ctx->pool_aux_bytes != fit->aux_bytes) {
+      (void)dev_release(ctx->pool_aux);
+      ctx->pool_aux = nullptr;
+      ctx->pool_aux_bytes = 0;
+    }
     if (ctx && !ctx->pool_aux) {
       ctx->pool_aux = fit->aux_base;
       ctx->pool_aux_bytes = fit->aux_bytes;

@@ -141,31 +141,46 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
   };
   ops.begin(plan);
   if (plan.owner(0) == me) factor_and_pack(0);
+  // the message of block column b from its owner to everybody, on the collectives queue (the owner's pack is awaited there)
+  auto broadcast_msg = [&](long long b) -> int {
+    if (plan.owner(b) == me) {
+      const int stw = ops.wait(QC, EV_MSG);
+      if (stw != AGP_OK) return stw;
+    }
+    const int stb = comm->broadcast(ops, QC, buf.msg(b), msg_count, plan.owner(b));
+    if (stb != AGP_OK) return stb;
+    ops.record(EV_BCAST, QC);
+    return AGP_OK;
+  };
+  if (multi && nb > 0 && (st = broadcast_msg(0)) != AGP_OK) { comm->mark_broken(); (void)ops.sync_all(); return st; }
   for (long long k = 0; k < nb && st == AGP_OK; ++k) {
     if ((st = ops.step_begin(k)) != AGP_OK) break;
-    const int o = plan.owner(k), slot = (int)(k & 1);
+    const int slot = (int)(k & 1);
     const long long w = plan.width(k);
-    if (multi) {
-      if (o == me && (st = ops.wait(QC, EV_MSG)) != AGP_OK) break;
-      st = comm->broadcast(ops, QC, buf.msg(k), msg_count, o);
-      if (st != AGP_OK) break;
-      ops.record(EV_BCAST, QC);
-      if ((st = ops.wait(QP, EV_BCAST)) != AGP_OK) break;
-    }
+    // (the broadcast of message k was enqueued in step k - 1, AHEAD of that step's all-gather - see below)
+    if (multi && (st = ops.wait(QP, EV_BCAST)) != AGP_OK) break;
     if (k == nb - 1) break;
     const long long li0 = plan.first_local_after(me, k);
     const long long nrows = n_loc - li0 * B > 0 ? n_loc - li0 * B : 0;
-    if (nrows > 0)
-      ops.trsm_rows(QP, Aat(li0 * B, k * B), ld, nrows, w, msg_L(k), msg_img(k), msg_z(k), y + li0 * B);
     const long long w1 = plan.width(k + 1);
     const int o1 = plan.owner(k + 1);
+    // Round 5: the OWNER of block k + 1 solves only ITS BLOCK ROW k + 1 first (its first row block behind k), brings
+    // D_{k+1} up to date, factors it and packs the message - and the broadcast of that message goes onto the collectives
+    // queue AHEAD of this step's all-gather.  The chain that a different rank carries every step is then
+    //   broadcast(k) -> 512 rows of panel solve -> D_{k+1} update -> 4 POTRF steps -> pack -> broadcast(k + 1)
+    // instead of  broadcast(k) -> ALL the owner's rows -> ... -> pack -> all-gather(k) -> broadcast(k + 1): the owner's
+    // other rows, the all-gather and U1 / U2 of the step run beside it.
+    const bool own_next = multi && o1 == me && nrows > 0;
+    const long long head = own_next ? (w1 < nrows ? w1 : nrows) : 0;  // rows solved ahead of the look-ahead (block row k + 1)
+    if (nrows > 0 && !own_next)
+      ops.trsm_rows(QP, Aat(li0 * B, k * B), ld, nrows, w, msg_L(k), msg_img(k), msg_z(k), y + li0 * B);
+    if (head > 0)
+      ops.trsm_rows(QP, Aat(li0 * B, k * B), ld, head, w, msg_L(k), msg_img(k), msg_z(k), y + li0 * B);
     const double *Q;
     long long ldq;
     const int ev_u2_prev = ((k - 1) & 1) ? EV_U2_B : EV_U2_A, ev_u2_cur = (k & 1) ? EV_U2_B : EV_U2_A;
     if (multi) {
       const long long cnt_rows = plan.max_blocks_after(k) * B;
-      if (nrows > 0) ops.copy2d(QP, buf.send, cnt_rows, Aat(li0 * B, k * B), ld, nrows, w);
-      ops.record(EV_PACK, QP);
       // look-ahead: the owner of block k + 1 has everything D_{k+1} still needs in its own panel rows
       // (U2(k - 1) wrote D_{k+1} and the columns U1(k) is about to update)
       if (k >= 1 && (st = ops.wait(QP, ev_u2_prev)) != AGP_OK) break;
@@ -175,6 +190,11 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
         ops.gemm(QP, Aat(li1 * B, (k + 1) * B), ld, X1, ld, X1, ld, w1, w1, w, true, 0);
         factor_and_pack(k + 1);
       }
+      if ((st = broadcast_msg(k + 1)) != AGP_OK) break;
+      if (own_next && nrows > head)  // the owner's remaining rows, off its chain
+        ops.trsm_rows(QP, Aat(li0 * B + head, k * B), ld, nrows - head, w, msg_L(k), msg_img(k), msg_z(k), y + li0 * B + head);
+      if (nrows > 0) ops.copy2d(QP, buf.send, cnt_rows, Aat(li0 * B, k * B), ld, nrows, w);
+      ops.record(EV_PACK, QP);
       if ((st = ops.wait(QC, EV_PACK)) != AGP_OK) break;
       if ((st = ops.wait(QC, ev_u2_cur)) != AGP_OK) break;  // U2(k - 2) read pall[slot]
       st = comm->all_gather(ops, QC, buf.send, buf.recv, cnt_rows * w);
