@@ -132,6 +132,11 @@ struct ShardOps {
   // anything of that step is enqueued.  A backend may change how it paces or where it runs its bulk updates there.
   virtual void begin(const ShardPlan &plan) { (void)plan; }
   virtual int step_begin(long long k) { (void)k; return AGP_OK; }
+  // Is step k CHAIN-bound - the owner chain, not this rank's bulk update, decides when the step ends?  Then the owner of
+  // block k + 1 solves its own block row first and its broadcast goes ahead of the step's all-gather (shard_sched.hip).
+  // The answer must be the same on every rank (it orders the collectives).  Default: alternate, so that a backend
+  // without a notion of regimes (the CPU test backend) exercises both orders.
+  virtual bool owner_first(long long k) { return (k & 1) != 0; }
   // drain every queue; AGP_OK or an error status
   virtual int sync_all() { return AGP_OK; }
   // {sum of log L_ii over this rank's diagonal blocks, 1 + global index of its first non-positive pivot or 0}

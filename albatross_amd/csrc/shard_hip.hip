@@ -427,6 +427,7 @@ struct HipShardOps : ShardOps {
   // full-size bulk update) stays with the host: 41.5 ms against 45-60.
   bool allow_device = false;   // device pacing is permitted (switch + probe) - used from switch_step on
   long long switch_step = 0;   // first block column of the chain-bound regime
+  long long order_switch = 0;  // first block column from which the bulk update of EVERY rank is below the threshold (owner_first)
   bool bulk_masked = false;
   void begin(const ShardPlan &plan) override {
     allow_device = device_pacing;
@@ -446,6 +447,27 @@ struct HipShardOps : ShardOps {
         switch_step = k + 1;
       }
     }
+    // ... and the step from which EVERY rank's bulk update is that small: the order of the collectives of a step
+    // (owner_first) has to be the same on all ranks, so it cannot follow this rank's own regime switch
+    order_switch = 0;
+    if (ctx->stream_masked || plan.world > 1) {
+      const double limit_gflop = plan.world > 1 ? ctx->tune.shard_mask_gflop : 0.;
+      const long long Bq = plan.B;
+      for (long long k = 0; k + 2 < plan.nb; ++k) {
+        double worst = 0.;
+        for (int r = 0; r < plan.world; ++r) {
+          double entries = 0.;
+          const long long nl = plan.n_local_blocks(r);
+          for (long long li = plan.first_local_after(r, k + 1); li < nl; ++li) {
+            const long long i = plan.global_block(r, li);
+            entries += (double)plan.width(i) * (double)((i + 1) * Bq - (k + 2) * Bq);
+          }
+          if (entries > worst) worst = entries;
+        }
+        if (2. * (double)plan.width(k) * worst <= limit_gflop * 1e9) break;
+        order_switch = k + 1;
+      }
+    }
     if (switch_step > 0) device_pacing = false;  // host pacing until the switch
     decided = false;
     decide();
@@ -456,6 +478,8 @@ struct HipShardOps : ShardOps {
     sq[QB] = ctx->stream_masked;  // (nothing of this fit is on the unmasked stream, or the queues have just been drained)
     bulk_masked = true;
   }
+  // chain-bound from switch_step on (begin): the same on every rank - the plan and the threshold are
+  bool owner_first(long long k) override { return k >= order_switch; }
   int step_begin(long long k) override {
     if (k != switch_step || k == 0) return AGP_OK;
     const int st = sync_all();  // drain: every record so far has completed

@@ -170,7 +170,8 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
     //   broadcast(k) -> 512 rows of panel solve -> D_{k+1} update -> 4 POTRF steps -> pack -> broadcast(k + 1)
     // instead of  broadcast(k) -> ALL the owner's rows -> ... -> pack -> all-gather(k) -> broadcast(k + 1): the owner's
     // other rows, the all-gather and U1 / U2 of the step run beside it.
-    const bool own_next = multi && o1 == me && nrows > 0;
+    const bool chain_step = multi && ops.owner_first(k);
+    const bool own_next = chain_step && o1 == me && nrows > 0;
     const long long head = own_next ? (w1 < nrows ? w1 : nrows) : 0;  // rows solved ahead of the look-ahead (block row k + 1)
     if (nrows > 0 && !own_next)
       ops.trsm_rows(QP, Aat(li0 * B, k * B), ld, nrows, w, msg_L(k), msg_img(k), msg_z(k), y + li0 * B);
@@ -181,6 +182,10 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
     const int ev_u2_prev = ((k - 1) & 1) ? EV_U2_B : EV_U2_A, ev_u2_cur = (k & 1) ? EV_U2_B : EV_U2_A;
     if (multi) {
       const long long cnt_rows = plan.max_blocks_after(k) * B;
+      if (!chain_step) {  // bulk-bound step: this rank's panel rows go to the all-gather BEFORE the look-ahead, as in rounds 3-4
+        if (nrows > 0) ops.copy2d(QP, buf.send, cnt_rows, Aat(li0 * B, k * B), ld, nrows, w);
+        ops.record(EV_PACK, QP);
+      }
       // look-ahead: the owner of block k + 1 has everything D_{k+1} still needs in its own panel rows
       // (U2(k - 1) wrote D_{k+1} and the columns U1(k) is about to update)
       if (k >= 1 && (st = ops.wait(QP, ev_u2_prev)) != AGP_OK) break;
@@ -190,17 +195,20 @@ int shard_factor_solve(ShardOps &ops, ShardComm *comm, const ShardPlan &plan, do
         ops.gemm(QP, Aat(li1 * B, (k + 1) * B), ld, X1, ld, X1, ld, w1, w1, w, true, 0);
         factor_and_pack(k + 1);
       }
-      if ((st = broadcast_msg(k + 1)) != AGP_OK) break;
+      if (chain_step && (st = broadcast_msg(k + 1)) != AGP_OK) break;
       if (own_next && nrows > head)  // the owner's remaining rows, off its chain
         ops.trsm_rows(QP, Aat(li0 * B + head, k * B), ld, nrows - head, w, msg_L(k), msg_img(k), msg_z(k), y + li0 * B + head);
-      if (nrows > 0) ops.copy2d(QP, buf.send, cnt_rows, Aat(li0 * B, k * B), ld, nrows, w);
-      ops.record(EV_PACK, QP);
+      if (chain_step) {
+        if (nrows > 0) ops.copy2d(QP, buf.send, cnt_rows, Aat(li0 * B, k * B), ld, nrows, w);
+        ops.record(EV_PACK, QP);
+      }
       if ((st = ops.wait(QC, EV_PACK)) != AGP_OK) break;
       if ((st = ops.wait(QC, ev_u2_cur)) != AGP_OK) break;  // U2(k - 2) read pall[slot]
       st = comm->all_gather(ops, QC, buf.send, buf.recv, cnt_rows * w);
       if (st != AGP_OK) break;
       ops.gather_panel(QC, buf.pall[slot], buf.ldp, buf.recv, cnt_rows, w, plan, k);
       ops.record(EV_GATHER, QC);
+      if (!chain_step && (st = broadcast_msg(k + 1)) != AGP_OK) break;  // (bulk-bound step: behind the all-gather, as before)
       if ((st = ops.wait(QP, EV_GATHER)) != AGP_OK) break;
       Q = buf.pall[slot];
       ldq = buf.ldp;

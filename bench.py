@@ -728,12 +728,18 @@ def run_rank(args):
     step = sharded_step if sharded else replica_step
 
     def barrier():
+        tb0 = time.perf_counter()
         torch.cuda.synchronize()
+        tb1 = time.perf_counter()
         if comm is not None:
             comm.barrier()
         else:
             gloo_barrier()
+        tb2 = time.perf_counter()
         torch.cuda.synchronize()
+        if os.environ.get("BENCH_DEBUG_STEPS"):
+            sys.stderr.write(f"bench.py rank {rank}: barrier: sync {1e3 * (tb1 - tb0):.3f} ms, ranks {1e3 * (tb2 - tb1):.3f} ms, "
+                             f"sync {1e3 * (time.perf_counter() - tb2):.3f} ms\n")
 
     def max_over_ranks(v):
         if comm is not None:
@@ -750,10 +756,17 @@ def run_rank(args):
             step()
         gemm_ms = gemm_flop = gemm_launches = 0.0
         gram_ms = factor_ms = solve_ms = 0.0
-        barrier()
+        # On most boxes of the pool ONE torch.cuda.synchronize() early in the life of the process takes 40-60 ms (two HIP
+        # runtimes in one process - torch's and the library's; the GPU is idle, every step has returned) - at the closing
+        # barrier of a 10-step run that is 10 % of `value` (profiles/r05/README.md).  It happens once: let it happen here.
+        for _ in range(3):
+            barrier()
         t0 = time.perf_counter()
+        step_walls = []
         for _ in range(args.steps):
+            ts0 = time.perf_counter()
             step()  # returns after its streams have drained
+            step_walls.append(time.perf_counter() - ts0)
             if sharded:
                 gram_ms += sfit.stage(0)
                 factor_ms += sfit.stage(1)
@@ -767,8 +780,12 @@ def run_rank(args):
                 gemm_ms += ctx.stage_ms(3)
                 gemm_launches += ctx.stage_ms(4)
                 gemm_flop += ctx.stage_ms(5)
+        t_loop = time.perf_counter() - t0
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        if os.environ.get("BENCH_DEBUG_STEPS"):
+            sys.stderr.write(f"bench.py rank {rank}: per-step wall ms {[round(1e3 * v, 2) for v in step_walls]}, loop {1e3 * t_loop:.2f} ms, "
+                             f"with closing barrier {1e3 * elapsed:.2f} ms\n")
 
         if not sharded:  # self-check of the replica path: one more fit of the timed problem, outside the timed region
             resid = sampled_residual(x_h, y_h, replica_step(True))
@@ -845,7 +862,7 @@ def run_rank(args):
     # the owner chain) - the first real scaling curve should show both regimes.  Outside `value`.  A failure here must not
     # cost the headline line: it is recorded, the line goes out, and the ranks leave without running destructors.
     aux_big, aux_broken = None, False
-    if world > 1 and sharded and not args.no_configs and n == N_TRAIN:
+    if world > 1 and sharded and not single_device and not args.no_configs and n == N_TRAIN:
         try:
             nb = 65536
             xb, yb = make_dataset(nb, 45)
@@ -912,6 +929,10 @@ def run_rank(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            # the same K steps without the closing barrier (sum of the per-step wall times; every step returns after its
+            # streams have drained) and what that barrier cost: see the note at the opening barrier
+            "ms_per_step_loop_only": 1e3 * sum(step_walls) / args.steps,
+            "closing_barrier_ms": 1e3 * (elapsed - t_loop),
             "higher_is_better": True,
             "scaling": "strong" if (sharded and world > 1) else "weak",
             "vs_baseline": None,

@@ -104,7 +104,7 @@ std::vector<Measurement<X>> as_measurements(const std::vector<X> &features) {
 // functions and models below accept std::vector<LinearCombination<X>> wherever they accept std::vector<X>:
 // LinearCombinationCaller (covariance_functions/callers.hpp:321-396) applies the double sum at the top of the
 // caller chain, so the Gram matrix of the EXPANDED points is built on the device and contracted with the
-// coefficients on the host.  (The reference mixes plain and combined features through variant<X, LinearCombination<X>>;
+// coefficients there too (agp_gram_combined; predictions: agp_solver_predict_combined).  (The reference mixes plain and combined features through variant<X, LinearCombination<X>>;
 // here a plain feature in such a vector is the combination of itself: LinearCombination<X>({x}).)
 template <typename X>
 struct LinearCombination {
@@ -1174,17 +1174,11 @@ class UpdatedFitModel {
     const Matrix cross = model.get_covariance()(old_features, d.features);          // gp.hpp:395-396
     BlockSymmetric<S2> new_cov(solver, cross, S_ldlt);                              // gp.hpp:398-399
     const Vector Si_delta = S_ldlt.solve(delta);
-    // information - Ai_B Si_delta = information - A^-1 (B Si_delta)   (gp.hpp:403-407; Ai_B itself stays on the device)
-    Matrix b_si(static_cast<std::int64_t>(n), 1);
-    for (std::size_t i = 0; i < n; ++i) {
-      double t = 0.;
-      for (std::size_t j = 0; j < m; ++j) t += cross(static_cast<std::int64_t>(i), static_cast<std::int64_t>(j)) * Si_delta[j];
-      b_si(static_cast<std::int64_t>(i), 0) = t;
-    }
-    const Matrix ai_b_si = solver.solve(b_si);
+    // [information - Ai_B Si_delta ; Si_delta] (gp.hpp:403-407) from the Ai_B the new solver holds in HBM: one mat-vec on the device
     Vector info(n + m);
-    for (std::size_t i = 0; i < n; ++i) info[i] = old_information[i] - ai_b_si(static_cast<std::int64_t>(i), 0);
-    for (std::size_t j = 0; j < m; ++j) info[n + j] = Si_delta[j];
+    detail::check(agp_solver_update_information(new_cov.context()->ctx, new_cov.device_solver().get(), old_information.data(), Si_delta.data(),
+                                                info.data(), AGP_HOST),
+                  new_cov.context()->ctx, "agp_solver_update_information");
     std::vector<F2> feats = old_features;
     feats.insert(feats.end(), d.features.begin(), d.features.end());
     return UpdatedFitModel<M2, F2, S2>(model, std::move(feats), std::move(new_cov), std::move(info));
@@ -1244,21 +1238,20 @@ class RepresentationFitModel {
   RepresentationFitModel(const ModelType &model, std::vector<FeatureType> features, Representation cov, Vector info)
       : train_features(std::move(features)), train_covariance(std::move(cov)), information(std::move(info)), model_(model) {}
 
+  // _predict_impl over a generic CovarianceRepresentation (gp.hpp:305-366) in HBM: agp_solver_predict, or - LinearCombination
+  // features on either side (callers.hpp:321-396) - agp_solver_predict_combined
   template <typename P>
-  Vector predict_mean(const std::vector<P> &xs) const { return mean_of(model_.get_covariance()(train_features, xs), xs); }
+  Vector predict_mean(const std::vector<P> &xs) const {
+    Vector mean(xs.size(), 0.);
+    device_predict(xs, &mean, nullptr, 0);
+    return mean;
+  }
   template <typename P>
   JointDistribution predict_joint(const std::vector<P> &xs) const {
-    const Matrix cross = model_.get_covariance()(train_features, xs);
-    const Matrix explained = train_covariance.solve(cross);
     JointDistribution out;
-    out.mean = mean_of(cross, xs);
-    out.covariance = model_.get_covariance()(xs);
-    for (std::int64_t a = 0; a < cross.cols(); ++a)
-      for (std::int64_t b = 0; b < cross.cols(); ++b) {
-        double s = 0.;
-        for (std::int64_t i = 0; i < cross.rows(); ++i) s += cross(i, a) * explained(i, b);
-        out.covariance(a, b) -= s;
-      }
+    out.mean.assign(xs.size(), 0.);
+    out.covariance = Matrix(static_cast<std::int64_t>(xs.size()), static_cast<std::int64_t>(xs.size()));
+    device_predict(xs, &out.mean, out.covariance.data.data(), 2);
     return out;
   }
 
@@ -1267,16 +1260,51 @@ class RepresentationFitModel {
   Vector information;
 
  private:
-  template <typename P>
-  Vector mean_of(const Matrix &cross, const std::vector<P> &xs) const {
-    Vector mean(xs.size(), 0.);
-    for (std::int64_t j = 0; j < cross.cols(); ++j) {
-      double s = 0.;
-      for (std::int64_t i = 0; i < cross.rows(); ++i) s += cross(i, j) * information[static_cast<std::size_t>(i)];
-      mean[static_cast<std::size_t>(j)] = s;
+  // one side of a prediction: the (expanded) points, and - for LinearCombination features - offsets and coefficients
+  template <typename F>
+  struct Side {
+    detail::Flat flat;
+    std::vector<std::int64_t> offsets;
+    std::vector<double> coefficients;
+    std::int64_t count = 0;
+    bool combined = false;
+  };
+  template <typename F>
+  Side<F> side_of(const std::vector<F> &features) const {
+    Side<F> sd;
+    if constexpr (detail::expansion<F>::expands) {
+      const detail::Expanded<F> ex(features);
+      sd.flat = detail::flatten(model_.get_covariance(), ex.points);
+      sd.offsets = ex.offsets();
+      sd.coefficients = ex.coefficient;
+      sd.count = static_cast<std::int64_t>(ex.n);
+      sd.combined = true;
+    } else {
+      sd.flat = detail::flatten(model_.get_covariance(), features);
+      sd.count = sd.flat.view.n;
     }
-    model_.add_mean(xs, &mean);
-    return mean;
+    return sd;
+  }
+  template <typename P>
+  void device_predict(const std::vector<P> &xs, Vector *mean, double *second, int mode) const {
+    if (xs.empty()) return;
+    auto ctx = detail::default_context();
+    detail::KernelHolder k(model_.get_covariance().program());
+    const auto tr = side_of(train_features);
+    const auto te = side_of(xs);
+    auto solver = train_covariance.device_solver();
+    if (tr.combined || te.combined) {
+      detail::check(agp_solver_predict_combined(ctx->ctx, k.k, solver.get(), &tr.flat.view, tr.count, tr.combined ? tr.offsets.data() : nullptr,
+                                                tr.combined ? tr.coefficients.data() : nullptr, information.data(), &te.flat.view, te.count,
+                                                te.combined ? te.offsets.data() : nullptr, te.combined ? te.coefficients.data() : nullptr,
+                                                mean->data(), second, mode, AGP_HOST),
+                    ctx->ctx, "agp_solver_predict_combined");
+    } else {
+      detail::check(agp_solver_predict(ctx->ctx, k.k, solver.get(), &tr.flat.view, information.data(), &te.flat.view, mean->data(), second, mode,
+                                       AGP_HOST),
+                    ctx->ctx, "agp_solver_predict");
+    }
+    model_.add_mean(xs, mean);
   }
   ModelType model_;
 };
