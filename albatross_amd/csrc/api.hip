@@ -1596,6 +1596,14 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
   BATCH_CHECK(hipMemcpyAsync(h_flags.data(), flags, sizeof(int) * 4 * (size_t)count, hipMemcpyDeviceToHost, s));
   BATCH_CHECK(hipStreamSynchronize(s));
   BATCH_CHECK(hipGetLastError());
+  // the information vectors of the good fits go to the caller BEFORE any handle is published: a failed copy must not leave
+  // the caller with an error code AND live handles (a failed problem leaves its column untouched)
+  if (information)
+    for (int b = 0; b < count; ++b) {
+      const int *fl = &h_flags[4 * (size_t)b];
+      if (!fl[0] && !fl[1])
+        BATCH_CHECK(hipMemcpy(information + (size_t)b * (size_t)ldi, alpha + (size_t)b * (size_t)np2, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    }
   agp_fit_slab *slab = new (std::nothrow) agp_fit_slab();
   if (!slab) return fail(AGP_ERR_INVALID_ARGUMENT);
   slab->base = base;
@@ -1620,11 +1628,6 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
     if (log_det) log_det[b] = fit->log_det;
     out[b] = fit;
   }
-  if (information)  // only the good fits' vectors: a failed one leaves its column untouched
-    for (int b = 0; b < count; ++b)
-      if (status[b] == AGP_OK)
-        AGP_HIP_CHECK(ctx, hipMemcpy(information + (size_t)b * (size_t)ldi, alpha + (size_t)b * (size_t)np2, sizeof(double) * (size_t)n,
-                                     hipMemcpyDeviceToHost));
 #undef BATCH_CHECK
   return AGP_OK;
 }

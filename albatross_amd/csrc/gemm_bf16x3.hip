@@ -20,6 +20,13 @@
 //                          ds_read_b128 fall on 16 different 16-B bank slots), C (fp64) fetched during the loop and
 //                          written once: C -= (double)(fp32 sum of the step's products) - the same contract as
 //                          trailing_update_f32_kernel (gemm.hip), whose place it takes.
+//
+// Measured (profiles/r05/time_bf16x3.txt, N = 32768 trailing shapes): 97-99 TFLOP/s of fp32-equivalent work at
+// M = 8192 and 115-118 at M = 30720, against 87-89 / 105-107 for the fp32 kernel on the same shapes.  What bounds it
+// is the operand stream, not the matrix pipe: a 128 x 128 tile reads 2 x 128 rows x 512 k x 6 B = 768 KB of planes
+// for 16.8 MFLOP (22 flop/B), so 115 TFLOP/s is 5.3 TB/s out of L2 / Infinity Cache - the same fabric limit the fp32
+// kernel meets at 4 B per element - and the LDS pipe is ~75 % busy (24 ds_read_b128 + 12 ds_write_b128 per wave and
+// chunk).  A larger tile (256 x 128: 33 flop/B) is the next step and needs k chunks of 16 to fit LDS twice.
 #include "common.h"
 #include "gemm_tiles.h"
 

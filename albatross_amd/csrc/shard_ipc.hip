@@ -70,7 +70,14 @@ __global__ __launch_bounds__(256) void ipc_push_kernel(IpcPeers P, const double 
   if (seq > 2 && (int)threadIdx.x < P.world && (int)threadIdx.x != P.me)
     if (!ipc_spin(P.acks[P.me] + threadIdx.x, seq - 2, ticks, err)) ok = 0;
   __syncthreads();
-  if (!ok) return;
+  if (!ok) {
+    // a peer never acknowledged: this rank pushes nothing - and says so in EVERY peer's error word (it sits behind the flag
+    // and acknowledgement arrays of a region), so that the peers, which will pull stale mailbox contents, report
+    // AGP_ERR_COMM too instead of returning wrong numbers with AGP_OK
+    if (blockIdx.x == 0 && (int)threadIdx.x < P.world)
+      (void)__hip_atomic_exchange(reinterpret_cast<int *>(P.flags[threadIdx.x] + 2 * IPC_MAX_WORLD), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   const long long stride = (long long)gridDim.x * 256;
   for (int p = 0; p < P.world; ++p) {
     if (root >= 0 && p == P.me) continue;  // the root keeps its own copy
@@ -82,7 +89,8 @@ __global__ __launch_bounds__(256) void ipc_push_kernel(IpcPeers P, const double 
 __global__ void ipc_signal_kernel(IpcPeers P, unsigned long long seq, unsigned long long ticks, int *err) {
   const int p = (int)threadIdx.x;
   if (p >= P.world) return;
-  __hip_atomic_store(P.flags[p] + P.me, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (a maximum, not a store: sequence numbers only grow, whatever the order in which two streams' collectives get here)
+  (void)__hip_atomic_fetch_max(P.flags[p] + P.me, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   (void)ipc_spin(P.flags[P.me] + p, seq, ticks, err);
 }
 
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(256) void ipc_pull_kernel(IpcPeers P, double *__res
 
 __global__ void ipc_ack_kernel(IpcPeers P, unsigned long long seq) {
   const int p = (int)threadIdx.x;
-  if (p < P.world) __hip_atomic_store(P.acks[p] + P.me, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (p < P.world) (void)__hip_atomic_fetch_max(P.acks[p] + P.me, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct IpcComm : HostReducingComm {
@@ -129,11 +137,11 @@ struct IpcComm : HostReducingComm {
     if (ctx) (void)hipSetDevice(ctx->device);
     // nobody may still push into (or read flags of) a region that is about to go: host barrier first - unless a peer is
     // known to be gone
-    if (!broken && world > 1 && boot.all_reduce) {
+    (void)hipDeviceSynchronize();  // this rank's own queued pushes / acknowledgements first ...
+    if (!broken && world > 1 && boot.all_reduce) {  // ... then everybody's: after the barrier no kernel of any rank touches a region
       double token = 0.;
       (void)boot.all_reduce(boot.user, &token, 1, 0);
     }
-    (void)hipDeviceSynchronize();
     for (int p = 0; p < world; ++p)
       if (opened[p]) (void)hipIpcCloseMemHandle(opened[p]);
     if (region) (void)hipFree(region);

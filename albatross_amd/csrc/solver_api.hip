@@ -147,7 +147,7 @@ void agp_solver_destroy(agp_solver *s) {
 
 int agp_solver_block_symmetric(agp_context *ctx, const agp_solver *A, const double *B, int64_t ldb, int location, const agp_solver *S,
                                agp_solver **out) {
-  if (!ctx || !A || !B || !S || !out || ldb < A->n) return AGP_ERR_INVALID_ARGUMENT;
+  if (!ctx || !A || !B || !S || !out || ldb < A->n || A->ctx != ctx || S->ctx != ctx) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long na = A->n, nb = S->n;
   agp_solver *s = new (std::nothrow) agp_solver();
@@ -167,7 +167,7 @@ int agp_solver_block_symmetric(agp_context *ctx, const agp_solver *A, const doub
 }
 
 int agp_solver_explained(agp_context *ctx, const agp_solver *outer, const double *inner, int64_t ld, int location, agp_solver **out) {
-  if (!ctx || !outer || !inner || !out || ld < outer->n) return AGP_ERR_INVALID_ARGUMENT;
+  if (!ctx || !outer || !inner || !out || ld < outer->n || outer->ctx != ctx) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long n = outer->n;
   agp_solver *s = new (std::nothrow) agp_solver();
@@ -185,7 +185,7 @@ int agp_solver_explained(agp_context *ctx, const agp_solver *outer, const double
 }
 
 int agp_solver_solve(agp_context *ctx, const agp_solver *sv, const double *rhs, int64_t nrhs, double *out, int location) {
-  if (!ctx || !sv || !rhs || !out || nrhs < 0) return AGP_ERR_INVALID_ARGUMENT;
+  if (!ctx || !sv || !rhs || !out || nrhs < 0 || sv->ctx != ctx) return AGP_ERR_INVALID_ARGUMENT;
   if (nrhs == 0 || sv->n == 0) return AGP_OK;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (location == AGP_DEVICE) return solve_dev(ctx, sv, rhs, nrhs, out);
@@ -204,6 +204,11 @@ int agp_solver_predict(agp_context *ctx, const agp_kernel *k, const agp_solver *
                        const agp_features *xs, double *mean, double *var_or_cov, int mode, int location) {
   if (!ctx || !k || !sv || !train || !information || !xs || !mean || mode < 0 || mode > 2 || (mode > 0 && !var_or_cov))
     return AGP_ERR_INVALID_ARGUMENT;
+  if (sv->ctx != ctx) return AGP_ERR_INVALID_ARGUMENT;  // a solver lives in the context (and on the device) that made it
+  {
+    int stv = validate_features(train);
+    if (stv != AGP_OK || (stv = validate_features(xs)) != AGP_OK) return stv;
+  }
   if (train->n != sv->n || xs->dim != train->dim) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const long long n = sv->n, m = xs->n;

@@ -252,7 +252,11 @@ AGP_API int agp_nll_batch(agp_context *ctx, int count, const agp_kernel *const *
  *                             a batch share one device allocation, released with the last of them
  *   information, ldi          n x count (host) or NULL; log_det[b] (host) or NULL
  *   status[b]                 AGP_OK / AGP_ERR_NAN_INPUT / AGP_ERR_NOT_POSITIVE_DEFINITE per problem (out[b] then reports
- *                             the pivot like agp_fit_create); the return value is about the call as a whole */
+ *                             the pivot like agp_fit_create); the return value is about the call as a whole: when it is not
+ *                             AGP_OK no handle has been published (every out[b] is NULL) and nothing is left to destroy
+ * y and y_var live where features[0] lives (host or device); `information` and `log_det` are HOST arrays whatever the
+ * location, and a failed problem leaves its column of `information` untouched.  No pivoted fall-back is applied to a
+ * problem that is not positive definite (agp_fit_create's callers go on to agp_ldlt_*; a batch reports and moves on). */
 AGP_API int agp_fit_create_batch(agp_context *ctx, int count, const agp_kernel *const *kernels, const agp_features *const *features,
                                  const double *y, int64_t ldy, const double *y_var, int64_t ldv, agp_fit **out, double *information,
                                  int64_t ldi, double *log_det, int *status);
