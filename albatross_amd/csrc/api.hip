@@ -175,7 +175,7 @@ int agp_device_count(void) {
   return n;
 }
 
-static constexpr long long BACKSUB_COOP_MAX_N = 1280;
+static constexpr long long BACKSUB_COOP_MAX_N = 2047;
 // the switches of include/albatross_amd.h ("switches"): read here, once per context, and nowhere else
 static agp_context::Tuning read_tuning() {
   agp_context::Tuning t;
@@ -250,6 +250,7 @@ int agp_context_create(int device_id, agp_context **out) {
   ctx->d_scalars = reinterpret_cast<double *>(ctx->d_flags + 4);
   AGP_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_flags, 4 * sizeof(int) + 4 * sizeof(double)));
   ctx->h_scalars = reinterpret_cast<double *>(ctx->h_flags + 4);
+  if (hipHostGetDevicePointer(&ctx->h_status_dev, ctx->h_flags, 0) != hipSuccess) { (void)hipGetLastError(); ctx->h_status_dev = nullptr; }
   for (auto &e : ctx->stage_ev) AGP_HIP_CHECK(ctx, hipEventCreate(&e));
   for (auto &sl : ctx->ext.slots) AGP_HIP_CHECK(ctx, hipMalloc(&sl.dev, sizeof(DevProgram)));
   *out = ctx;
@@ -540,7 +541,7 @@ static constexpr size_t STATUS_BYTES = 4 * sizeof(int) + 4 * sizeof(double);
 // spend ten launches on these)
 static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevProgram *hprog, const FeatView &xm,
                             double *A, long long lda, double *invd, double *y, const double *yvar, bool finish = true,
-                            FactorTimers *timers_out = nullptr, PrepArgs *pre = nullptr) {
+                            FactorTimers *timers_out = nullptr, PrepArgs *pre = nullptr, bool copy_status = true) {
   agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
   const long long n = xm.n;
   hipStream_t s = ctx->stream;
@@ -576,7 +577,8 @@ static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevPr
   factor_lower(ctx, A, n, lda, invd, y, prof ? &timers : nullptr);
   ctx->prep_external = false;
   if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[2], s));
-  AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, STATUS_BYTES, hipMemcpyDeviceToHost, s));
+  // (copy_status false: the caller's next launch forwards the status block itself - backsub_coop_kernel)
+  if (copy_status || finish) AGP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, STATUS_BYTES, hipMemcpyDeviceToHost, s));
   if (timers_out) *timers_out = timers;
   if (!finish) return AGP_OK;
   AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
@@ -785,14 +787,13 @@ void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long lo
     // same seven-launch chain as inverting all of them (~100 us) - the last BW rows go through the one-launch substitution
     // instead (solve.hip: backsub_coop_kernel on the trailing BW x BW triangle, ~9 us per 128 rows), then its update
     const long long k0 = (nb - 1) * BW;
-    // (its per-block flags: the first words of xs, which the loop below overwrites only after this launch)
-    unsigned long long *done = reinterpret_cast<unsigned long long *>(xs);
+    // (BW / 128 <= BACKSUB_DIRECT_BLOCKS blocks: the sentinel-filled output is its own hand-over buffer)
     {
       PrepArgs prep;
-      prep.fill(done, 0ull, backsub_done_words(BW, 1));
+      prep.sentinel(xs + k0, BW);
       launch_prep(s, prep);
     }
-    backward_solve_coop(s, A + k0 * (lda + 1), BW, lda, invd + (k0 / NB) * (long long)(36 * MB * MB), z + k0, xs + k0, nullptr, done);
+    backward_solve_coop(s, A + k0 * (lda + 1), BW, lda, invd + (k0 / NB) * (long long)(36 * MB * MB), z + k0, xs + k0, nullptr, nullptr);
     launch_colvec_dot(s, A + k0, lda, BW, k0, xs + k0, -1.0, 1.0, z, z);  // z[0:k0] -= L[B, 0:k0]^T x_B
     if (ev_done) (void)hipStreamWaitEvent(s, ev_done, 0);
     for (long long b = nb - 2; b >= 0; --b) {
@@ -1014,7 +1015,11 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   // Measured (profiles/r05): one hand-over + substitution per 128-column block is ~9 us - 37 us at N = 512 against 45 us
   // for the launch chain, 286 us at N = 4096 against 190 us through the 512-wide inverted blocks: small fits only.
   const bool coop = !mixed && ctx->tune.backsub_coop && n <= ctx->tune.backsub_coop_max;
-  if (coop) pre.fill(fit->winv, 0ull, backsub_done_words(n, 1));  // (its per-block flags live in the unused block-inverse buffer)
+  // (hand-over: the sentinel-filled output itself up to BACKSUB_DIRECT_BLOCKS blocks, per-block flags in the unused
+  // block-inverse buffer beyond)
+  const bool coop_direct = coop && (n + NB - 1) / NB <= BACKSUB_DIRECT_BLOCKS;
+  if (coop && coop_direct) pre.sentinel(fit->alpha, n);
+  else if (coop) pre.fill(fit->winv, 0ull, backsub_done_words(n, 1));
   FactorTimers ftimers;
   long long bs_done = 0;
   if (!coop && deferred && backsolve_width(n)) {
@@ -1026,7 +1031,11 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
       ctx->bs_done = 0;
     }
   }
-  st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d, !deferred, &ftimers, &pre);
+  // (a deferred fit with the one-launch substitution: that launch's last workgroup writes the status block into the
+  // pinned mirror - no copy launch behind the factorisation, none behind the substitution)
+  const bool status_in_kernel = coop && deferred && ctx->h_status_dev != nullptr;
+  st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d, !deferred, &ftimers, &pre,
+                        !status_in_kernel);
   ctx->update_variant = -1;
   ctx->nbo_override = 0;
   bs_done = ctx->bs_W ? ctx->bs_done : 0;
@@ -1055,9 +1064,11 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   if (ctx->profiling) FIT_CHECK(hipEventRecord(ctx->stage_ev[3], s));
   if (coop) {
     TraceRange tr("agp: backward substitution (information = ldlt.solve(y), gp.hpp:68)");
-    backward_solve_coop(s, fit->A, n, fit->lda, fit->invd, fit->z, fit->alpha, ctx->d_flags, reinterpret_cast<unsigned long long *>(fit->winv));
+    backward_solve_coop(s, fit->A, n, fit->lda, fit->invd, fit->z, fit->alpha, ctx->d_flags,
+                        coop_direct ? nullptr : reinterpret_cast<unsigned long long *>(fit->winv), 1, 0, 0, 0, 0, 0,
+                        status_in_kernel ? ctx->d_flags : nullptr, ctx->h_status_dev, (int)(STATUS_BYTES / 8));
     // (the hand-over flag of the substitution: the 48-byte status copy left before it ran)
-    FIT_CHECK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (!status_in_kernel) FIT_CHECK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   } else {
     FIT_CHECK(hipMemcpyAsync(fit->alpha, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     {
@@ -1556,7 +1567,15 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
     }
   }
   if (loc == AGP_HOST) BATCH_CHECK(hipStreamSynchronize(s));
-  BATCH_CHECK(hipMemsetAsync(logsum, 0, sizeof(double) * 3 * (size_t)cp2, s));  // log sums and flags
+  // information = L^-T z of every problem in ONE launch (solve.hip: backsub_coop_kernel, blockIdx.y = problem) for sizes
+  // of few 128-row blocks: its output vectors are the hand-over buffers and enter sentinel-filled
+  const bool coop = ctx->tune.backsub_coop && n <= ctx->tune.backsub_coop_max && (n + NB - 1) / NB <= BACKSUB_DIRECT_BLOCKS;
+  {
+    PrepArgs prep;
+    prep.fill(logsum, 0ull, 3 * cp2);  // log sums and flags
+    if (coop) prep.sentinel(alpha, count * np2);
+    launch_prep(s, prep);
+  }
   {
     std::vector<FeatView> views((size_t)count);
     std::vector<const DevProgram *> hprogs((size_t)count);
@@ -1588,14 +1607,24 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
     factor_lower_batched_lookahead(ctx, A, stride_A, n, lda, invd, stride_I, z, np2, count, flags, logsum, 4);
   else
     factor_lower_batched(s, A, stride_A, n, lda, invd, stride_I, z, np2, count, flags, logsum, 4);
-  BATCH_CHECK(hipMemcpyAsync(alpha, z, sizeof(double) * (size_t)count * (size_t)np2, hipMemcpyDeviceToDevice, s));
-  backward_solve_vec_batched(s, A, stride_A, n, lda, invd, stride_I, alpha, np2, count);  // information = L^-T (L^-1 y), gp.hpp:68
+  // information = L^-T (L^-1 y), gp.hpp:68
+  if (coop) {
+    backward_solve_coop(s, A, n, lda, invd, z, alpha, flags, nullptr, count, stride_A, stride_I, np2, np2, 4);
+  } else {
+    BATCH_CHECK(hipMemcpyAsync(alpha, z, sizeof(double) * (size_t)count * (size_t)np2, hipMemcpyDeviceToDevice, s));
+    backward_solve_vec_batched(s, A, stride_A, n, lda, invd, stride_I, alpha, np2, count);
+  }
   std::vector<double> h_log((size_t)cp2);
   std::vector<int> h_flags(4 * (size_t)count);
   BATCH_CHECK(hipMemcpyAsync(h_log.data(), logsum, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
   BATCH_CHECK(hipMemcpyAsync(h_flags.data(), flags, sizeof(int) * 4 * (size_t)count, hipMemcpyDeviceToHost, s));
   BATCH_CHECK(hipStreamSynchronize(s));
   BATCH_CHECK(hipGetLastError());
+  for (int b = 0; b < count; ++b)
+    if (h_flags[4 * (size_t)b + 2]) {  // a hand-over of the one-launch substitution timed out (its producer died)
+      ctx->last_error = "batched back substitution: hand-over timed out";
+      return fail(AGP_ERR_HIP);
+    }
   // the information vectors of the good fits go to the caller BEFORE any handle is published: a failed copy must not leave
   // the caller with an error code AND live handles (a failed problem leaves its column untouched)
   if (information)

@@ -70,6 +70,7 @@ struct agp_context {
   int *h_flags = nullptr;  // pinned mirror
   double *d_scalars = nullptr;  // [0] sum log L_ii, [1] z^T z
   double *h_scalars = nullptr;  // pinned mirror
+  void *h_status_dev = nullptr;  // h_flags (the whole status block) as the device addresses it, or nullptr
   bool profiling = false;
   double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // reusable factor workspace (agp_nll re-uses it between tuner steps)
@@ -125,7 +126,7 @@ struct agp_context {
     long long step_below = 4608;   // AGP_STEP_BELOW: remaining rows at or below which every panel is ONE step launch (0: off)
     bool gram_sop = true;          // AGP_GRAM_SOP=0: covariance trees through the stack interpreter only
     bool mixed_bf16 = true;        // AGP_MIXED_BF16=0: the mixed-precision fit's products on the fp32 MFMA (rounds 1-4) instead of bf16 x 3
-    long long backsub_coop_max = 1280;  // AGP_BACKSUB_COOP_MAX: largest n whose fit uses it (measurement switch)
+    long long backsub_coop_max = 2047;  // AGP_BACKSUB_COOP_MAX: largest n whose fit uses it (measurement switch)
     bool backsub_coop = true;      // AGP_BACKSUB_COOP=0: the fit's back substitution as a launch per block (rounds 1-4) instead of ONE launch
     bool sparse_pivoted = false;   // AGP_SPARSE_PIVOTED=1: the sparse GP's literal (pivoted LDL^T + QR) path always
     long long predict_chunk = 0;   // AGP_PREDICT_CHUNK: test points per slice of the marginal / joint predictions (0: by memory)
@@ -257,11 +258,14 @@ void factor_lower_batched_lookahead(agp_context *ctx, double *A, long long strid
 // z_b <- L_b^-T z_b for `count` problems, one vector each (solve.hip)
 void backward_solve_vec_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
                                 const double *invd, long long stride_invd, double *z, long long stride_z, long long count);
-// x = L^-T z in ONE launch (solve.hip: backsub_coop_kernel); done: backsub_done_words(n, count) ZEROED words (PrepArgs::fill)
+// x = L^-T z in ONE launch (solve.hip: backsub_coop_kernel); done: backsub_done_words(n, count) ZEROED words (PrepArgs::fill),
+// or nullptr with x SENTINEL-filled (PrepArgs::sentinel) for at most BACKSUB_DIRECT_BLOCKS 128-row blocks
+constexpr long long BACKSUB_DIRECT_BLOCKS = 16;
 long long backsub_done_words(long long n, long long count);
 void backward_solve_coop(hipStream_t s, const double *A, long long n, long long lda, const double *invd, const double *z,
                          double *x, int *flags, unsigned long long *done, long long count = 1, long long stride_A = 0,
-                         long long stride_invd = 0, long long stride_z = 0, long long stride_x = 0, long long stride_flags = 0);
+                         long long stride_invd = 0, long long stride_z = 0, long long stride_x = 0, long long stride_flags = 0,
+                         const void *status_src = nullptr, void *status_dst = nullptr, int status_words = 0);
 void launch_fill_sentinel(hipStream_t s, double *p, long long count);
 void forward_solve_mat_batched(hipStream_t s, const double *A, long long stride_A, long long n, long long lda,
                                const double *invd, long long stride_invd, double *B, long long stride_B, long long m,

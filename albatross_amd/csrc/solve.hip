@@ -476,8 +476,14 @@ struct BackCoopArgs {
   const double *z;    // right-hand side
   double *x;          // solution
   int *flags;         // flags[2]: a hand-over timed out
-  unsigned long long *done;  // one word per block (zeroed by the caller): set when the block's x is in memory
+  unsigned long long *done;  // one word per block (zeroed by the caller): set when the block's x is in memory;
+                             // nullptr: x itself is the hand-over (SENTINEL-filled by the caller, polled per value)
   long long batch_A = 0, batch_img = 0, batch_z = 0, batch_x = 0, batch_flags = 0, batch_done = 0;
+  // the fit's status block (flags + scalars, device memory) and its pinned host mirror as the device sees it: the
+  // workgroup that finishes LAST (block 0) forwards it - the two 4-5 us copy launches behind a small fit
+  const unsigned long long *status_src = nullptr;
+  unsigned long long *status_dst = nullptr;
+  int status_words = 0;
 };
 
 __global__ __launch_bounds__(512) void backsub_coop_kernel(BackCoopArgs p) {
@@ -521,16 +527,32 @@ __global__ __launch_bounds__(512) void backsub_coop_kernel(BackCoopArgs p) {
   if (nb - 1 > b) load_rows(nb - 1);
   for (long long j = nb - 1; j > b; --j) {
     const long long r0 = j * NB + lane, r1 = r0 + 64;
-    // ONE lane per wave polls the block's flag (every lane polling the values themselves is 131 k threads hammering the
-    // memory side: that polling was what the hand-over cost), then every lane reads its two values once
-    if (lane == 0) {
+    double x0 = 0., x1 = 0.;
+    if (p.done) {
+      // many blocks: ONE lane per wave polls the block's flag (every lane polling the values themselves is 131 k threads
+      // hammering the memory side at N = 4096), then every lane reads its two values once
+      if (lane == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (int spin = 1; __hip_atomic_load(p.done + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin) {
+          if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      if (r0 < p.n) x0 = load_pub(p.x + r0);
+      if (r1 < p.n) x1 = load_pub(p.x + r1);
+    } else {
+      // few blocks (<= BACKSUB_DIRECT_BLOCKS x 512 threads): the values themselves are the hand-over - x enters
+      // sentinel-filled and every lane polls its own two: ONE memory-side trip per block instead of flag, then values
+      const bool h0 = r0 < p.n, h1 = r1 < p.n;
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      for (int spin = 1; __hip_atomic_load(p.done + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin) {
+      for (int spin = 1;; ++spin) {
+        if (h0) x0 = load_pub(p.x + r0);
+        if (h1) x1 = load_pub(p.x + r1);
+        if (!((h0 && is_unpublished(x0)) || (h1 && is_unpublished(x1)))) break;
         if ((spin & 63) == 0 && poll_expired(t0, p.flags)) break;
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(2);
       }
     }
-    const double x0 = (r0 < p.n) ? load_pub(p.x + r0) : 0., x1 = (r1 < p.n) ? load_pub(p.x + r1) : 0.;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] += a0[q] * x0 + a1[q] * x1;
     if (j - 1 > b) load_rows(j - 1);
@@ -544,16 +566,25 @@ __global__ __launch_bounds__(512) void backsub_coop_kernel(BackCoopArgs p) {
   if (wave != 0) return;
   // x_b = L_bb^-T t by micro blocks (trsm_kernel.h), every value published the moment it is final
   micro_backsub_wave(F, ts, [&](int c, double v) { if (c < nbk) store_pub(p.x + k0 + c, v); });
-  if (lane == 0) __hip_atomic_store(p.done + b, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // (behind the wave's stores)
+  if (p.done && lane == 0) __hip_atomic_store(p.done + b, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // (behind the wave's stores)
+  // block 0 consumed every other block's x: whatever those raised in the status block is in memory by now
+  if (b == 0 && p.status_dst && lane < p.status_words)
+    p.status_dst[lane] = __hip_atomic_load(p.status_src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // x = L^-T z; count problems (strides 0 for one).  done: one zeroed word per 128-row block and problem (backsub_done_words)
 long long backsub_done_words(long long n, long long count) { return (n + NB - 1) / NB * (count > 0 ? count : 1); }
 void backward_solve_coop(hipStream_t s, const double *A, long long n, long long lda, const double *invd, const double *z,
                          double *x, int *flags, unsigned long long *done, long long count, long long stride_A, long long stride_invd,
-                         long long stride_z, long long stride_x, long long stride_flags) {
+                         long long stride_z, long long stride_x, long long stride_flags, const void *status_src, void *status_dst,
+                         int status_words) {
   if (n <= 0 || count <= 0) return;
   BackCoopArgs p;
+  if (count == 1 && status_src && status_dst && status_words > 0 && status_words <= 64) {
+    p.status_src = static_cast<const unsigned long long *>(status_src);
+    p.status_dst = static_cast<unsigned long long *>(status_dst);
+    p.status_words = status_words;
+  }
   p.done = done; p.batch_done = (n + NB - 1) / NB;
   p.A = A; p.lda = lda; p.n = n; p.img = invd; p.z = z; p.x = x; p.flags = flags;
   p.batch_A = stride_A; p.batch_img = stride_invd; p.batch_z = stride_z; p.batch_x = stride_x; p.batch_flags = stride_flags;

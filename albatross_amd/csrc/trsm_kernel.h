@@ -153,6 +153,25 @@ __device__ __forceinline__ void trsm_micro_solve(const TrsmArgs &p, const double
 }
 
 
+// Exchanges inside a row of 16 lanes on the DPP path (no LDS crossbar trip: __shfl_xor is a ds_bpermute, ~100 cycles of
+// latency on a dependent chain): lane <-> lane ^ 1, ^ 2 by quad permutation, ^ 4 and ^ 8 by the mirrors
+// (i ^ 7 then i ^ 3, i ^ 15 then i ^ 7).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int MASK>
+__device__ __forceinline__ double row_xor(double v) {
+  static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8, "inside a row of 16 lanes");
+  if (MASK == 1) return dpp_move<0xB1>(v);                   // quad_perm [1, 0, 3, 2]
+  if (MASK == 2) return dpp_move<0x4E>(v);                   // quad_perm [2, 3, 0, 1]
+  if (MASK == 4) return dpp_move<0x1B>(dpp_move<0x141>(v));  // row_half_mirror, quad_perm [3, 2, 1, 0]
+  return dpp_move<0x141>(dpp_move<0x140>(v));                // row_mirror, row_half_mirror
+}
+
 // x = L_bb^-T t for ONE vector by micro blocks, bottom-up, right-looking: one wave, values in registers.
 // lane = (k = lane >> 2, mq = lane & 3): element k of every micro block, replicated over the four mq lanes, which
 // split the sums over m.  Image tile (ib, kb) holds -L[16 ib + m][16 kb + k] at [k * 16 + m], the diagonal tile
@@ -172,8 +191,8 @@ __device__ __forceinline__ void micro_backsub_wave(const double *F, const double
     double part = 0.;
 #pragma unroll
     for (int u = 0; u < 4; ++u) part += D[u] * __shfl(t[jb], (4 * mq + u) << 2, 64);
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
+    part += row_xor<1>(part);
+    part += row_xor<2>(part);
     const double xk = part;  // x[16 jb + k]
     if (mq == 0) emit(jb * MB + k, xk);
     if (jb == 0) break;
@@ -184,8 +203,8 @@ __device__ __forceinline__ void micro_backsub_wave(const double *F, const double
     for (int kb = 0; kb < jb; ++kb) {
       const double *T = F + tile_off(jb, kb) + k * MB + 4 * mq;
       double q = T[0] * xm[0] + T[1] * xm[1] + T[2] * xm[2] + T[3] * xm[3];
-      q += __shfl_xor(q, 1, 64);
-      q += __shfl_xor(q, 2, 64);
+      q += row_xor<1>(q);
+      q += row_xor<2>(q);
       t[kb] += q;
     }
   }
@@ -196,17 +215,21 @@ __device__ __forceinline__ void micro_backsub_wave(const double *F, const double
 // total of column colsum16_index(lane).
 __device__ __forceinline__ double colsum16(double (&acc)[16]) {
   const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int bit = 0; bit < 4; ++bit) {
-    const int half = 8 >> bit;
-    const bool up = (lane >> bit) & 1;
-#pragma unroll
-    for (int i = 0; i < half; ++i) {
-      const double keep = up ? acc[i + half] : acc[i];
-      const double send = up ? acc[i] : acc[i + half];
-      acc[i] = keep + __shfl_xor(send, 1 << bit, 64);
-    }
+#define AGP_COLSUM_STEP(BIT)                                                  \
+  {                                                                           \
+    constexpr int half = 8 >> BIT;                                            \
+    const bool up = (lane >> BIT) & 1;                                        \
+    _Pragma("unroll") for (int i = 0; i < half; ++i) {                        \
+      const double keep = up ? acc[i + half] : acc[i];                        \
+      const double send = up ? acc[i] : acc[i + half];                        \
+      acc[i] = keep + row_xor<(1 << BIT)>(send);                              \
+    }                                                                         \
   }
+  AGP_COLSUM_STEP(0)
+  AGP_COLSUM_STEP(1)
+  AGP_COLSUM_STEP(2)
+  AGP_COLSUM_STEP(3)
+#undef AGP_COLSUM_STEP
   double sum = acc[0];
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
