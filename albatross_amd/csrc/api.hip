@@ -839,6 +839,30 @@ static void forward_solve_vec_wide(hipStream_t s, const double *A, long long n, 
   }
 }
 
+// x = L^-T z_in OUT of place (the fit: z = L^-1 y stays, the information vector is written where it lives).  With the
+// early inversion under way this is the loop above without its two copy launches: the first update reads z_in and
+// writes the work vector (ws[0:n]), every x_B goes straight into x.
+void backward_solve_vec_from(hipStream_t s, const double *A, long long n, long long lda, const double *invd, const double *z_in,
+                             double *x, double *ws, long long first_done, hipEvent_t ev_done) {
+  const long long BW = backsolve_width(n), nb = BW ? n / BW : 0;
+  if (BW && nb >= 2 && first_done == nb - 1) {
+    double *work = ws, *W = ws + round_up(n, 2);
+    const long long k0 = (nb - 1) * BW;
+    launch_fill_sentinel(s, x + k0, BW);
+    backward_solve_coop(s, A + k0 * (lda + 1), BW, lda, invd + (k0 / NB) * (long long)(36 * MB * MB), z_in + k0, x + k0, nullptr, nullptr);
+    launch_colvec_dot(s, A + k0, lda, BW, k0, x + k0, -1.0, 1.0, z_in, work);  // work[0:k0] = z[0:k0] - L[B, 0:k0]^T x_B
+    if (ev_done) (void)hipStreamWaitEvent(s, ev_done, 0);
+    for (long long b = nb - 2; b >= 0; --b) {
+      const long long c0 = b * BW;
+      launch_colvec_dot(s, W + b * BW * BW, BW, BW, BW, work + c0, 1.0, 0.0, nullptr, x + c0);
+      if (c0 > 0) launch_colvec_dot(s, A + c0, lda, BW, c0, x + c0, -1.0, 1.0, work, work);
+    }
+    return;
+  }
+  (void)hipMemcpyAsync(x, z_in, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+  backward_solve_vec_any(s, A, n, lda, invd, x, ws, first_done, ev_done);
+}
+
 // z <- L^-T z with the same inverses (the loop of backward_solve_vec_any); xs: n doubles of scratch
 static void backward_solve_vec_wide(hipStream_t s, const double *A, long long n, long long lda, const double *W, long long BW,
                                     double *z, double *xs, const float *A32 = nullptr) {
@@ -1070,16 +1094,11 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     // (the hand-over flag of the substitution: the 48-byte status copy left before it ran)
     if (!status_in_kernel) FIT_CHECK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   } else {
-    FIT_CHECK(hipMemcpyAsync(fit->alpha, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    {
-      const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * (size_t)round_up(n, 2));
-      if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
-    }
     const int st2 = ensure_ws(ctx, &ctx->ws_aux, &ctx->ws_aux_bytes, sizeof(double) * backsolve_ws_elems(n));
     if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
     {
       TraceRange tr("agp: backward substitution (information = ldlt.solve(y), gp.hpp:68)");
-      backward_solve_vec_any(s, fit->A, n, fit->lda, fit->invd, fit->alpha, ctx->ws_aux, bs_done, ctx->ev_inv);
+      backward_solve_vec_from(s, fit->A, n, fit->lda, fit->invd, fit->z, fit->alpha, ctx->ws_aux, bs_done, ctx->ev_inv);
     }
     // the refinement steps of the mixed-precision fit use the 128-row chain on fit->winv
     if (mixed) invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);

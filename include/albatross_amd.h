@@ -615,6 +615,7 @@ AGP_API int agp_set_profiling(agp_context *ctx, int enabled);
  *   AGP_GRAM_SOP=0           covariance trees through the stack interpreter only (parity tests run both evaluators)
  *   AGP_MIXED_BF16=0         agp_fit_create_mixed forms its fp32-accurate products on the fp32 MFMA instead of bf16 x 3
  *   AGP_BACKSUB_COOP=0       the fit's back substitution as one launch per block (rounds 1-4) instead of ONE launch
+ *   AGP_BACKSUB_COOP_MAX=<n> largest fit that uses the one-launch back substitution (default 2047)
  *   AGP_SPARSE_PIVOTED=1     the sparse GP always takes the literal (pivoted LDL^T + column-pivoted QR) path
  *   AGP_PREDICT_CHUNK=<m>    test points per slice of marginal predictions (default: by memory, 2 GiB per slice)
  *   AGP_SHARD_BLOCK=<b>      128 / 256 / 512 rows per row block of the sharded fit (default 512; tests)
