@@ -193,6 +193,7 @@ static agp_context::Tuning read_tuning() {
   t.backsub_coop = flag("AGP_BACKSUB_COOP", true);
   t.backsub_coop_max = number("AGP_BACKSUB_COOP_MAX", BACKSUB_COOP_MAX_N);
   t.mixed_bf16 = flag("AGP_MIXED_BF16", true);
+  set_bf16x3_kernel((int)number("AGP_BF16X3_KERNEL", 2), (int)number("AGP_BF16X3_LDS_PAD", 8192));
   t.sparse_pivoted = flag("AGP_SPARSE_PIVOTED", false);
   t.predict_chunk = number("AGP_PREDICT_CHUNK", 0);
   t.shard_block = number("AGP_SHARD_BLOCK", 0);
@@ -273,6 +274,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->ws_A) (void)agp::dev_release(ctx->ws_A);
   if (ctx->pool_A) (void)agp::dev_release(ctx->pool_A);
   if (ctx->pool_K) (void)agp::dev_release(ctx->pool_K);
+  if (ctx->ws_refine) (void)hipFree(ctx->ws_refine);
   if (ctx->p32) (void)hipFree(ctx->p32);
   if (ctx->pool_L32) (void)hipFree(ctx->pool_L32);
   if (ctx->pool_aux) (void)agp::dev_release(ctx->pool_aux);
@@ -1192,19 +1194,21 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
   };
   // the substitutions of every step: through 512-wide inverted diagonal blocks when the size allows (2 x n / 512
   // mat-vec launches per direction instead of n / 128 fused steps: the chains are launch-latency-bound)
-  double *symv_ws = nullptr;
-  AGP_HIP_CHECK(ctx, hipMalloc(&symv_ws, sizeof(double) * symv_ws_elems(n)));
-  struct FreeS { double *p; ~FreeS() { if (p) (void)hipFree(p); } } free_s{symv_ws};
   // (1024-wide inverted blocks here: the eight-odd preconditioner applications share one inversion, and half as many
   // launch-bound block steps per sweep are worth 5 ms at N = 32768; a single substitution is better off with 512)
   long long BW = backsolve_width(n);
   if (BW == 512 && n % 1024 == 0 && n >= 8192) BW = 1024;
-  double *Wwide = nullptr;
-  if (BW) {
-    AGP_HIP_CHECK(ctx, hipMalloc(&Wwide, sizeof(double) * (size_t)(n / BW) * (size_t)BW * (size_t)BW));
-    invert_wide_blocks(s, fit->A, n, lda, fit->invd, BW, Wwide);
+  // the mat-vec's workspace and the inverted blocks (268 MB at N = 32768): kept in the context between mixed fits - a
+  // hipMalloc + hipFree pair of that size per fit was 2-3 ms of a 120 ms fit
+  const size_t symv_elems = (symv_ws_elems(n) + 1) / 2 * 2;
+  const size_t wide_elems = BW ? (size_t)(n / BW) * (size_t)BW * (size_t)BW : 0;
+  {
+    const int st_ws = ensure_ws(ctx, &ctx->ws_refine, &ctx->ws_refine_bytes, sizeof(double) * (symv_elems + wide_elems));
+    if (st_ws != AGP_OK) return st_ws;
   }
-  struct FreeW { double *p; ~FreeW() { if (p) (void)hipFree(p); } } free_w{Wwide};
+  double *symv_ws = ctx->ws_refine;
+  double *Wwide = BW ? ctx->ws_refine + symv_elems : nullptr;
+  if (BW) invert_wide_blocks(s, fit->A, n, lda, fit->invd, BW, Wwide);
   // The preconditioner M = L L^T is applied eight-odd times and each application streams L twice; it does not have to
   // be exact - L itself comes from fp32-rounded products -, so the sweeps read an fp32 COPY of L's off-diagonal blocks
   // (the inverted diagonal blocks stay fp64): half the bytes, kept in the context between fits.

@@ -78,6 +78,8 @@ struct agp_context {
   size_t ws_A_bytes = 0;
   double *ws_aux = nullptr;
   size_t ws_aux_bytes = 0;
+  double *ws_refine = nullptr;  // scratch of the mixed fit's refinement (api.hip: refine_information), kept between fits
+  size_t ws_refine_bytes = 0;
   // one cached factor allocation (agp_fit_destroy parks its N x N buffer here;
   // the next agp_fit_create of the same size takes it instead of hipMalloc)
   double *pool_A = nullptr;
@@ -334,6 +336,7 @@ void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P,
 // planes (hi + mid + lo = the value to fp32 accuracy), and C -= P[row_a ..] P[row_b ..]^T from them on the BF16 pipe
 size_t bf16x3_bytes(long long rows, long long K);
 void launch_convert_panel_bf16x3(hipStream_t s, const double *P, long long ldp, long long rows, long long K, unsigned short *planes);
+void set_bf16x3_kernel(int choice, int lds_pad);  // 1: one workgroup per CU (first version), 2: two per CU (AGP_BF16X3_KERNEL)
 void launch_update_bf16x3(hipStream_t s, double *C, long long ldc, const unsigned short *planes, long long panel_rows, long long row_a,
                           long long row_b, long long M, long long N, long long K, const int *order = nullptr, long long order_len = 0);
 // the XCD-aware order of the `tiles` first lower 128 x 128 tiles of a grid with ntr tile rows (gemm.hip; cached): nullptr = none

@@ -132,11 +132,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <bool NEGATE>
 __device__ __forceinline__ void store_chunk_f32(float *__restrict__ Ls, const double (&r)[8]) {
   const int t = threadIdx.x;
-  const int kk = t >> 4, seg = (t & 15) * 8;
-  float4 *dst = reinterpret_cast<float4 *>(Ls + kk * GLD + seg);
+  // (r: row pairs 2 (t & 15) + 32 j of k-row t >> 4, as load_chunk delivers them)
+  const int kk = t >> 4, seg = (t & 15) * 2;
+  float2 *dst = reinterpret_cast<float2 *>(Ls + kk * GLD + seg);
   const float sg = NEGATE ? -1.f : 1.f;
-  dst[0] = make_float4(sg * (float)r[0], sg * (float)r[1], sg * (float)r[2], sg * (float)r[3]);
-  dst[1] = make_float4(sg * (float)r[4], sg * (float)r[5], sg * (float)r[6], sg * (float)r[7]);
+  dst[0] = make_float2(sg * (float)r[0], sg * (float)r[1]);
+  dst[16] = make_float2(sg * (float)r[2], sg * (float)r[3]);
+  dst[32] = make_float2(sg * (float)r[4], sg * (float)r[5]);
+  dst[48] = make_float2(sg * (float)r[6], sg * (float)r[7]);
 }
 
 // chunk (128 rows x 16 k) of an fp32 panel copy: thread t -> k = t >> 4, rows (t & 15) * 8 .. + 7

@@ -38,6 +38,15 @@ typedef float v4f32 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;                 // k per chunk = one v_mfma_f32_16x16x32_bf16
 constexpr int BPITCH = 40;             // LDS row pitch in bf16 (80 B)
 constexpr int BPLANE = GT * BPITCH;    // one plane of one operand of one stage, in bf16
+// The 80-B pitch is NOT conflict-free: ds_read_b128 is served in four NON-contiguous groups of 16 lanes (lanes {0-3,
+// 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS), in which rows 4-11 read k group lg + 1 while rows 0-3 / 12-15 read lg, and
+// three pairs of them share a 16-B slot (PMC: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE).  No pitch repairs that -
+// a row's four pieces must be PERMUTED: unpadded 64-B rows, piece kg of row r at slot kg ^ ((-(r >> 2)) & 3).  Every
+// group then covers the sixteen slots of the 256-B bank row once, and the eight lanes of a ds_write_b128 group (two
+// whole rows) cover 128 contiguous bytes.
+constexpr int SPITCH = 32;             // swizzled layout: row pitch in bf16 (64 B, no padding)
+constexpr int SPLANE = GT * SPITCH;
+__device__ __forceinline__ int sw_piece(int kg, int row) { return kg ^ ((4 - ((row >> 2) & 3)) & 3); }
 
 __device__ __forceinline__ unsigned short bf16_rn(float f) {
   unsigned int u = __float_as_uint(f);
@@ -121,16 +130,17 @@ __device__ __forceinline__ bool bf16_tile_of_block(const Bf16Args &g, int &bi, i
     sa20 = *reinterpret_cast<const uint4 *>(srcA + 2 * g.plane_stride + o0_); sa21 = *reinterpret_cast<const uint4 *>(srcA + 2 * g.plane_stride + o1_); \
     sb20 = *reinterpret_cast<const uint4 *>(srcB + 2 * g.plane_stride + o0_); sb21 = *reinterpret_cast<const uint4 *>(srcB + 2 * g.plane_stride + o1_); \
   } while (0)
-#define AGP_BF_STORE(BASE)                                                                                 \
+#define AGP_BF_STORE_P(BASE, PL)                                                                            \
   do {                                                                                                     \
     unsigned short *b_ = (BASE);                                                                           \
-    *reinterpret_cast<uint4 *>(b_ + 0 * BPLANE + d0) = sa00; *reinterpret_cast<uint4 *>(b_ + 0 * BPLANE + d1) = sa01; \
-    *reinterpret_cast<uint4 *>(b_ + 1 * BPLANE + d0) = sa10; *reinterpret_cast<uint4 *>(b_ + 1 * BPLANE + d1) = sa11; \
-    *reinterpret_cast<uint4 *>(b_ + 2 * BPLANE + d0) = sa20; *reinterpret_cast<uint4 *>(b_ + 2 * BPLANE + d1) = sa21; \
-    *reinterpret_cast<uint4 *>(b_ + 3 * BPLANE + d0) = sb00; *reinterpret_cast<uint4 *>(b_ + 3 * BPLANE + d1) = sb01; \
-    *reinterpret_cast<uint4 *>(b_ + 4 * BPLANE + d0) = sb10; *reinterpret_cast<uint4 *>(b_ + 4 * BPLANE + d1) = sb11; \
-    *reinterpret_cast<uint4 *>(b_ + 5 * BPLANE + d0) = sb20; *reinterpret_cast<uint4 *>(b_ + 5 * BPLANE + d1) = sb21; \
+    *reinterpret_cast<uint4 *>(b_ + 0 * (PL) + d0) = sa00; *reinterpret_cast<uint4 *>(b_ + 0 * (PL) + d1) = sa01; \
+    *reinterpret_cast<uint4 *>(b_ + 1 * (PL) + d0) = sa10; *reinterpret_cast<uint4 *>(b_ + 1 * (PL) + d1) = sa11; \
+    *reinterpret_cast<uint4 *>(b_ + 2 * (PL) + d0) = sa20; *reinterpret_cast<uint4 *>(b_ + 2 * (PL) + d1) = sa21; \
+    *reinterpret_cast<uint4 *>(b_ + 3 * (PL) + d0) = sb00; *reinterpret_cast<uint4 *>(b_ + 3 * (PL) + d1) = sb01; \
+    *reinterpret_cast<uint4 *>(b_ + 4 * (PL) + d0) = sb10; *reinterpret_cast<uint4 *>(b_ + 4 * (PL) + d1) = sb11; \
+    *reinterpret_cast<uint4 *>(b_ + 5 * (PL) + d0) = sb20; *reinterpret_cast<uint4 *>(b_ + 5 * (PL) + d1) = sb21; \
   } while (0)
+#define AGP_BF_STORE(BASE) AGP_BF_STORE_P(BASE, BPLANE)
 
 __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args g) {
   __shared__ unsigned short lds[2 * 6 * BPLANE];  // [stage][operand A: hi mid lo | operand B: hi mid lo][128 rows][40]
@@ -252,8 +262,110 @@ __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args
     }
 }
 
+// ---- the same tile with TWO workgroups per CU ------------------------------------------------------------------
+// The kernel above keeps one workgroup per CU (two LDS stages, 122 KB; 128 registers of prefetched C): ONE wave per
+// SIMD, so every wait of that wave - the fragment reads in front of the MFMAs, the staging stores behind the global
+// loads, the barrier - is a hole in the matrix pipe (PMC: the MFMA pipe is busy 28 % of the time).  Here a workgroup has
+// ONE stage (61 KB) and no prefetched C (<= 256 registers): two workgroups share a CU and one's MFMAs run in the
+// other's holes; C is read and written in the epilogue, behind the other workgroup's loop.
+__global__ __launch_bounds__(256, 2) void trailing_update_bf16x3_pair_kernel(Bf16Args g) {
+  __shared__ unsigned short lds[6 * SPLANE];  // [operand A: hi mid lo | operand B: hi mid lo][128 rows][32], 16-B pieces swizzled
+  int bi, bj;
+  if (g.order) {
+    const int packed = g.order[blockIdx.x];
+    if (packed < 0) return;
+    bi = packed >> 16;
+    bj = packed & 0xffff;
+  } else if (!bf16_tile_of_block(g, bi, bj)) return;
+  const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ln = lane & 15, lg = lane >> 4;
+
+  const unsigned short *srcA = g.planes + (g.row_a + i0) * BK, *srcB = g.planes + (g.row_b + j0) * BK;
+  const long long chunk_stride = g.rows_pad * BK;
+  uint4 sa00, sa01, sa10, sa11, sa20, sa21, sb00, sb01, sb10, sb11, sb20, sb21;
+  const int d0 = (tid >> 2) * SPITCH + sw_piece(tid & 3, tid >> 2) * 8, d1 = d0 + 64 * SPITCH;  // (row + 64: the same swizzle)
+
+  v4f32 acc[4][4];  // [tj][ti]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = v4f32{0.f, 0.f, 0.f, 0.f};
+
+  const long long nk = g.K / BK;
+  AGP_BF_LOAD(0);
+  for (long long kc = 0; kc < nk; ++kc) {
+    if (kc > 0) __syncthreads();  // every wave has read chunk kc - 1 out of the stage
+    AGP_BF_STORE_P(lds, SPLANE);
+    __syncthreads();
+    AGP_BF_LOAD((kc + 1 < nk ? kc + 1 : kc) * chunk_stride);  // (unconditional: a guarded load kept the staging registers in scratch)
+    v8bf fa[3][4], fb[3][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[p][t] = *reinterpret_cast<const v8bf *>(lds + (3 + p) * SPLANE + (64 * wc + 16 * t + ln) * SPITCH + 8 * sw_piece(lg, ln));
+        fb[p][t] = *reinterpret_cast<const v8bf *>(lds + p * SPLANE + (64 * wr + 16 * t + ln) * SPITCH + 8 * sw_piece(lg, ln));
+      }
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        v4f32 a = acc[tj][ti];
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][tj], fb[0][ti], a, 0, 0, 0);  // lo hi (smallest terms first)
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][tj], fb[2][ti], a, 0, 0, 0);  // hi lo
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][tj], fb[1][ti], a, 0, 0, 0);  // mid mid
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][tj], fb[0][ti], a, 0, 0, 0);  // mid hi
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][tj], fb[1][ti], a, 0, 0, 0);  // hi mid
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][tj], fb[0][ti], a, 0, 0, 0);  // hi hi
+        acc[tj][ti] = a;
+      }
+  }
+  // C -= acc (register r of accumulator (tj, ti): row 16 ti + ln of the quadrant, column 16 tj + 4 lg + r)
+  if (i0 + GT <= g.M && j0 + GT <= g.N) {
+    double *const cbase = g.C + (i0 + 64 * wr + ln) + (j0 + 64 * wc + 4 * lg) * g.ldc;
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+      double cv[4][4];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[ti][r] = __builtin_nontemporal_load(&cbase[16 * ti + (long long)(16 * tj + r) * g.ldc]);
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_nontemporal_store(cv[ti][r] - (double)acc[tj][ti][r], &cbase[16 * ti + (long long)(16 * tj + r) * g.ldc]);
+    }
+    return;
+  }
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const long long row = i0 + 64 * wr + 16 * ti + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long col = j0 + 64 * wc + 16 * tj + 4 * lg + r;
+        if (row < g.M && col < g.N) {
+          double *c = g.C + row + col * g.ldc;
+          *c = *c - (double)acc[tj][ti][r];
+        }
+      }
+    }
+}
+
 #undef AGP_BF_LOAD
 #undef AGP_BF_STORE
+#undef AGP_BF_STORE_P
+
+// AGP_BF16X3_KERNEL (api.hip): 1 = one workgroup per CU with prefetched C, otherwise two workgroups per CU
+static int bf16x3_kernel_choice = 2;
+// AGP_BF16X3_LDS_PAD: extra dynamic LDS per workgroup (bytes): 0 = three workgroups per CU (3 x 48 KB), >= 6 KB = two.
+// Three are the faster KERNEL (+2 %) and the slower FIT (126.8 against 123.0 ms at N = 32768, same box): the panel
+// kernels of the chain stream need LDS next to the bulk update.
+static int bf16x3_lds_pad = 8192;
 
 // C (M x N, lower tiles, C(0, 0) on the matrix diagonal) -= P[row_a ..] P[row_b ..]^T from the bf16 planes of ONE panel
 // (launch_convert_panel_bf16x3).  order / order_len: the XCD-aware tile order of gemm.hip (nullptr: column-major tiles).
@@ -274,7 +386,10 @@ void launch_update_bf16x3(hipStream_t s, double *C, long long ldc, const unsigne
   for (int bj = 0; bj < g.ntc; ++bj) tiles += g.ntr - bj;
   const long long wgs = order ? order_len : tiles;
   if (wgs <= 0) return;
-  hipLaunchKernelGGL(trailing_update_bf16x3_kernel, dim3((unsigned)wgs), dim3(256), 0, s, g);
+  if (bf16x3_kernel_choice == 1) hipLaunchKernelGGL(trailing_update_bf16x3_kernel, dim3((unsigned)wgs), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(trailing_update_bf16x3_pair_kernel, dim3((unsigned)wgs), dim3(256), (size_t)bf16x3_lds_pad, s, g);
 }
+
+void set_bf16x3_kernel(int choice, int lds_pad) { bf16x3_kernel_choice = choice; bf16x3_lds_pad = lds_pad; }
 
 }  // namespace agp

@@ -61,19 +61,25 @@ __device__ __forceinline__ void load_chunk(const double *__restrict__ P, long lo
   // wave-uniform: interior tile and full chunk -> unguarded 16-B loads
   const bool fast = vec_ok && (row0 + GT <= nrows) && (k0 + GK <= K);
   if (!KMAJOR) {
-    const int kk = t >> 4, seg = (t & 15) * 8;
+    // thread t: row pairs 2 (t & 15) + 32 j (j = 0 .. 3) of k-row t >> 4 - the sixteen lanes of a k-row move 256
+    // contiguous bytes per instruction, and so do their ds_write_b128 (store_chunk): eight lanes = 128 B = every bank
+    // once (a lane's own 64 contiguous bytes put lanes l and l + 2 on the same banks: 4-way)
+    const int kk = t >> 4, seg = (t & 15) * 2;
     const long long row = row0 + seg, k = k0 + kk;
     const double *p = P + row + k * ld;
     if (fast) {
       const double2 a = *reinterpret_cast<const double2 *>(p);
-      const double2 b = *reinterpret_cast<const double2 *>(p + 2);
-      const double2 c = *reinterpret_cast<const double2 *>(p + 4);
-      const double2 d = *reinterpret_cast<const double2 *>(p + 6);
+      const double2 b = *reinterpret_cast<const double2 *>(p + 32);
+      const double2 c = *reinterpret_cast<const double2 *>(p + 64);
+      const double2 d = *reinterpret_cast<const double2 *>(p + 96);
       r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
       r[4] = c.x; r[5] = c.y; r[6] = d.x; r[7] = d.y;
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) r[q] = (k < K && row + q < nrows) ? p[q] : 0.;
+      for (int q = 0; q < 8; ++q) {
+        const int off = 32 * (q >> 1) + (q & 1);
+        r[q] = (k < K && row + off < nrows) ? p[off] : 0.;
+      }
     }
   } else {
     const int j = t >> 1, kh = (t & 1) * 8;
@@ -98,11 +104,12 @@ template <bool KMAJOR>
 __device__ __forceinline__ void load_chunk_interior(const double *__restrict__ P, long long ld, long long row0, long long k0,
                                                     double (&r)[8]) {
   const int t = threadIdx.x;
-  const double *p = KMAJOR ? P + (k0 + (t & 1) * 8) + (row0 + (t >> 1)) * ld : P + (row0 + (t & 15) * 8) + (k0 + (t >> 4)) * ld;
+  const double *p = KMAJOR ? P + (k0 + (t & 1) * 8) + (row0 + (t >> 1)) * ld : P + (row0 + (t & 15) * 2) + (k0 + (t >> 4)) * ld;
+  constexpr int step = KMAJOR ? 2 : 32;  // (!KMAJOR: row pairs 2 (t & 15) + 32 j, see load_chunk)
   const double2 a = *reinterpret_cast<const double2 *>(p);
-  const double2 b = *reinterpret_cast<const double2 *>(p + 2);
-  const double2 c = *reinterpret_cast<const double2 *>(p + 4);
-  const double2 d = *reinterpret_cast<const double2 *>(p + 6);
+  const double2 b = *reinterpret_cast<const double2 *>(p + step);
+  const double2 c = *reinterpret_cast<const double2 *>(p + 2 * step);
+  const double2 d = *reinterpret_cast<const double2 *>(p + 3 * step);
   r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
   r[4] = c.x; r[5] = c.y; r[6] = d.x; r[7] = d.y;
 }
@@ -111,18 +118,18 @@ template <bool KMAJOR, bool NEGATE>
 __device__ __forceinline__ void store_chunk(double *__restrict__ Ls, const double (&r)[8]) {
   const int t = threadIdx.x;
   if (!KMAJOR) {
-    const int kk = t >> 4, seg = (t & 15) * 8;
-    double2 *dst = reinterpret_cast<double2 *>(Ls + kk * GLD + seg);
+    const int kk = t >> 4, seg = (t & 15) * 2;
+    double2 *dst = reinterpret_cast<double2 *>(Ls + kk * GLD + seg);  // (double2 index 16 j = row pair + 32 j)
     if (NEGATE) {
       dst[0] = make_double2(-r[0], -r[1]);
-      dst[1] = make_double2(-r[2], -r[3]);
-      dst[2] = make_double2(-r[4], -r[5]);
-      dst[3] = make_double2(-r[6], -r[7]);
+      dst[16] = make_double2(-r[2], -r[3]);
+      dst[32] = make_double2(-r[4], -r[5]);
+      dst[48] = make_double2(-r[6], -r[7]);
     } else {
       dst[0] = make_double2(r[0], r[1]);
-      dst[1] = make_double2(r[2], r[3]);
-      dst[2] = make_double2(r[4], r[5]);
-      dst[3] = make_double2(r[6], r[7]);
+      dst[16] = make_double2(r[2], r[3]);
+      dst[32] = make_double2(r[4], r[5]);
+      dst[48] = make_double2(r[6], r[7]);
     }
   } else {
     const int j = t >> 1, kh = (t & 1) * 8;
@@ -320,27 +327,31 @@ __device__ __forceinline__ void load_chunk64(const double *__restrict__ P, long 
                                              long long nrows, long long k0, long long K, bool vec_ok,
                                              double (&r)[4]) {
   const int t = threadIdx.x;
-  const int kk = t >> 4, seg = (t & 15) * 4;
+  // (row pairs 2 (t & 15) and 2 (t & 15) + 32: contiguous across lanes, as load_chunk)
+  const int kk = t >> 4, seg = (t & 15) * 2;
   const long long row = row0 + seg, k = k0 + kk;
   const double *p = P + row + k * ld;
   const bool fast = vec_ok && (row0 + ST <= nrows) && (k0 + GK <= K);
   if (fast) {
     const double2 a = *reinterpret_cast<const double2 *>(p);
-    const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+    const double2 b = *reinterpret_cast<const double2 *>(p + 32);
     r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
   } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = (k < K && row + q < nrows) ? p[q] : 0.;
+    for (int q = 0; q < 4; ++q) {
+      const int off = 32 * (q >> 1) + (q & 1);
+      r[q] = (k < K && row + off < nrows) ? p[off] : 0.;
+    }
   }
 }
 
 template <bool NEGATE>
 __device__ __forceinline__ void store_chunk64(double *__restrict__ Ls, const double (&r)[4]) {
   const int t = threadIdx.x;
-  const int kk = t >> 4, seg = (t & 15) * 4;
+  const int kk = t >> 4, seg = (t & 15) * 2;
   double2 *dst = reinterpret_cast<double2 *>(Ls + kk * SLD + seg);
   dst[0] = NEGATE ? make_double2(-r[0], -r[1]) : make_double2(r[0], r[1]);
-  dst[1] = NEGATE ? make_double2(-r[2], -r[3]) : make_double2(r[2], r[3]);
+  dst[16] = NEGATE ? make_double2(-r[2], -r[3]) : make_double2(r[2], r[3]);
 }
 
 // transposed operand storage (element (row, k) at P[k + row * ld]): thread t holds 4 consecutive k of row t >> 2
