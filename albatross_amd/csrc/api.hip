@@ -193,6 +193,7 @@ static agp_context::Tuning read_tuning() {
   t.backsub_coop = flag("AGP_BACKSUB_COOP", true);
   t.backsub_coop_max = number("AGP_BACKSUB_COOP_MAX", BACKSUB_COOP_MAX_N);
   t.mixed_bf16 = flag("AGP_MIXED_BF16", true);
+  t.mixed_nbo = number("AGP_MIXED_NBO", 512);
   set_bf16x3_kernel((int)number("AGP_BF16X3_KERNEL", 2), (int)number("AGP_BF16X3_LDS_PAD", 8192));
   t.sparse_pivoted = flag("AGP_SPARSE_PIVOTED", false);
   t.predict_chunk = number("AGP_PREDICT_CHUNK", 0);
@@ -543,7 +544,8 @@ static constexpr size_t STATUS_BYTES = 4 * sizeof(int) + 4 * sizeof(double);
 // spend ten launches on these)
 static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevProgram *hprog, const FeatView &xm,
                             double *A, long long lda, double *invd, double *y, const double *yvar, bool finish = true,
-                            FactorTimers *timers_out = nullptr, PrepArgs *pre = nullptr, bool copy_status = true) {
+                            FactorTimers *timers_out = nullptr, PrepArgs *pre = nullptr, bool copy_status = true,
+                            const double *gram_copy = nullptr) {
   agp_context_impl *ctx = static_cast<agp_context_impl *>(c);
   const long long n = xm.n;
   hipStream_t s = ctx->stream;
@@ -559,7 +561,9 @@ static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevPr
   // as_measurements(features) -> covariance_function_(measurement_features)   gp.hpp:288-290
   {
     TraceRange tr("agp: gram (compute_covariance_matrix, callers.hpp:107-166)");
-    launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, A, lda, yvar, ctx->d_flags, hprog);
+    // (gram_copy: the caller holds this very matrix - same leading dimension, measurement variances included - already)
+    if (gram_copy) launch_copy_lower(s, gram_copy, lda, n, A, ctx->d_flags);
+    else launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, A, lda, yvar, ctx->d_flags, hprog);
   }
   if (prof) AGP_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[1], s));
   TraceRange tr_factor("agp: factor LL^T + forward substitution (SerializableLDLT, serializable_ldlt.hpp:27)");
@@ -1020,8 +1024,10 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     // fp32-accurate products of the bulk updates: on the BF16 pipe from three bf16 planes per panel (gemm_bf16x3.hip), or
     // - AGP_MIXED_BF16=0 - on the fp32 MFMA as in rounds 1-4
     ctx->update_variant = ctx->tune.mixed_bf16 ? 4 : 3;
+    ctx->nbo_wide = (ctx->tune.mixed_bf16 && ctx->tune.mixed_nbo > 512 && ctx->tune.mixed_nbo % 128 == 0) ? ctx->tune.mixed_nbo : 0;
     {  // two panel copies of (n rows + padding) x 512 (chol.hip, factor_lower): fp32, or three bf16 planes; kept in the context
-      const size_t want = ctx->tune.mixed_bf16 ? 2 * bf16x3_bytes(n, 512) : sizeof(float) * 2 * ((size_t)n + 16) * 512;
+      const size_t want = ctx->tune.mixed_bf16 ? 2 * bf16x3_bytes(n, ctx->nbo_wide > 512 ? ctx->nbo_wide : 512)
+                                               : sizeof(float) * 2 * ((size_t)n + 16) * 512;
       if (ctx->p32_bytes < want) {
         if (ctx->p32) (void)hipFree(ctx->p32);
         ctx->p32 = nullptr; ctx->p32_bytes = 0;
@@ -1061,9 +1067,10 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
   // pinned mirror - no copy launch behind the factorisation, none behind the substitution)
   const bool status_in_kernel = coop && deferred && ctx->h_status_dev != nullptr;
   st = build_and_factor(ctx, dprog, &k->prog, xm, fit->A, fit->lda, fit->invd, fit->z, yvar_d, !deferred, &ftimers, &pre,
-                        !status_in_kernel);
+                        !status_in_kernel, mixed ? Kfull : nullptr);
   ctx->update_variant = -1;
   ctx->nbo_override = 0;
+  ctx->nbo_wide = 0;
   bs_done = ctx->bs_W ? ctx->bs_done : 0;
   ctx->bs_W = nullptr;
   ctx->bs_done = 0;
@@ -1202,13 +1209,21 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
   // hipMalloc + hipFree pair of that size per fit was 2-3 ms of a 120 ms fit
   const size_t symv_elems = (symv_ws_elems(n) + 1) / 2 * 2;
   const size_t wide_elems = BW ? (size_t)(n / BW) * (size_t)BW * (size_t)BW : 0;
+  const size_t np2 = (size_t)round_up(n, 2);
   {
-    const int st_ws = ensure_ws(ctx, &ctx->ws_refine, &ctx->ws_refine_bytes, sizeof(double) * (symv_elems + wide_elems));
+    const int st_ws = ensure_ws(ctx, &ctx->ws_refine, &ctx->ws_refine_bytes, sizeof(double) * (symv_elems + 2 * wide_elems + 2 * np2));
     if (st_ws != AGP_OK) return st_ws;
   }
   double *symv_ws = ctx->ws_refine;
   double *Wwide = BW ? ctx->ws_refine + symv_elems : nullptr;
-  if (BW) invert_wide_blocks(s, fit->A, n, lda, fit->invd, BW, Wwide);
+  // ... and their transposes: the forward sweep applies inv(L_BB) as a column-wise product with the transposed copy
+  // (one workgroup per output, like the backward sweep) instead of a row-wise one on BW / 64 workgroups
+  double *WwideT = BW ? Wwide + wide_elems : nullptr;
+  double *t1 = ctx->ws_refine + symv_elems + 2 * wide_elems, *t2 = t1 + np2;  // the sweeps' work vectors
+  if (BW) {
+    invert_wide_blocks(s, fit->A, n, lda, fit->invd, BW, Wwide);
+    launch_transpose_blocks(s, Wwide, WwideT, BW, n / BW);
+  }
   // The preconditioner M = L L^T is applied eight-odd times and each application streams L twice; it does not have to
   // be exact - L itself comes from fp32-rounded products -, so the sweeps read an fp32 COPY of L's off-diagonal blocks
   // (the inverted diagonal blocks stay fp64): half the bytes, kept in the context between fits.
@@ -1224,6 +1239,23 @@ static int refine_information(agp_context_impl *ctx, agp_fit *fit, const double 
     if (L32) launch_convert_lower_f32(s, fit->A, lda, n, L32);
   }
   auto precondition = [&](const double *in, double *outv) {
+    if (BW && L32) {
+      // both sweeps out of place - no staging copy per block, none at the end: t1 = in is consumed by the forward sweep
+      // (x_B into t2, the rows below updated in t1), t2 by the backward sweep (x_B into outv, the rows above updated in t2)
+      const long long nbw = n / BW;
+      (void)hipMemcpyAsync(t1, in, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
+      for (long long b = 0; b < nbw; ++b) {
+        const long long k0 = b * BW, below = n - k0 - BW;
+        launch_colvec_dot(s, WwideT + b * BW * BW, BW, BW, BW, t1 + k0, 1.0, 0.0, nullptr, t2 + k0);  // x_B = inv(L_BB) z_B
+        if (below > 0) launch_tall_matvec_f32(s, L32 + k0 * lda + k0 + BW, lda, below, BW, t2 + k0, -1.0, 1.0, t1 + k0 + BW, t1 + k0 + BW);
+      }
+      for (long long b = nbw - 1; b >= 0; --b) {
+        const long long k0 = b * BW;
+        launch_colvec_dot(s, Wwide + b * BW * BW, BW, BW, BW, t2 + k0, 1.0, 0.0, nullptr, outv + k0);  // x_B = inv(L_BB)^T z_B
+        if (k0 > 0) launch_colvec_dot_f32(s, L32 + k0, lda, BW, k0, outv + k0, -1.0, 1.0, t2, t2);
+      }
+      return;
+    }
     (void)hipMemcpyAsync(outv, in, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
     if (BW) {
       forward_solve_vec_wide(s, fit->A, n, lda, Wwide, BW, outv, ctx->ws_aux, L32);

@@ -24,6 +24,8 @@ hipError_t dev_free(void *p);
 hipError_t dev_release(void *p);
 void dev_cache_trim();
 void launch_symmetrize(hipStream_t s, double *A, long long ld, long long n);
+void launch_transpose_blocks(hipStream_t s, const double *src, double *dst, long long m, long long count);  // reduce.hip
+void launch_copy_lower(hipStream_t s, const double *src, long long ld, long long n, double *dst, int *nan_flag);  // reduce.hip
 void launch_zero_upper(hipStream_t s, double *A, long long ld, long long n);
 void launch_set_identity(hipStream_t s, double *B, long long ld, long long n);
 void launch_nan_scan_lower(hipStream_t s, const double *A, long long ld, long long n, int *flag);

@@ -852,6 +852,7 @@ static void timed_gemm(hipStream_t s, FactorTimers *timers, double *C, long long
 constexpr long long FUSED_BELOW = 4608;     // remaining rows at or below which POTRF + TRSM are one fused launch (2048 .. 4608 best)
 constexpr long long INNER_LEFT_ABOVE = 6144;  // left-looking inside an outer block while more rows than this remain
 constexpr long long NBO_512_ABOVE = 2048, NBO_256_ABOVE = 1024;  // outer block width 512 / 256 / 128 by remaining rows
+constexpr long long NBO_WIDE_ABOVE = 8192;  // ... and ctx->nbo_wide (mixed precision) above this
 constexpr long long THROTTLE_BELOW = 8192;  // bulk updates handed to their stream by the host once their panel is done
 constexpr long long U1_F32_ABOVE = 4096;    // mixed precision: U1 on the fp32 MFMA path while the block column is this tall
 constexpr long long SINGLE_BELOW = 1536;    // the very end on one stream (when the step launches are off)
@@ -1120,8 +1121,11 @@ void trsm_rows_wide(hipStream_t s, double *X, long long ld, long long nrows, lon
 // the bulk update's C traffic off the HBM roofline and its MFMA efficiency up; narrow blocks
 // shorten the serial panel chain per step.  With the current panel kernels the choice barely
 // matters at N = 16384 (scripts/sweep_nbo.sh: every split at or below 4096 within 1 %).
-static long long pick_nbo(long long remaining, long long override_nbo = 0) {
+static long long pick_nbo(long long remaining, long long override_nbo = 0, long long wide = 0) {
   if (override_nbo > 0) return override_nbo;
+  // (mixed precision, bf16 x 3: at 150 TFLOP/s the fp64 C read-modify-write of a K = 512 update is 2.3 TB/s next to
+  // 2.6 TB/s of operand strips beyond the L2 - a deeper outer block halves the former while many rows remain)
+  if (wide > 512 && remaining > NBO_WIDE_ABOVE) return wide;
   if (remaining > NBO_512_ABOVE) return 512;
   if (remaining > NBO_256_ABOVE) return 256;
   return NB;
@@ -1141,7 +1145,8 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   long long K0 = 0;
   const long long nbo_fixed = ctx->nbo_override;
   const int variant = ctx->update_variant;
-  long long kend = K0 + pick_nbo(n, nbo_fixed);
+  const long long nbo_wide = (variant == 4) ? ctx->nbo_wide : 0;
+  long long kend = K0 + pick_nbo(n, nbo_fixed, nbo_wide);
   if (kend > n) kend = n;
   // (agp_fit_create has already planned and launched the fills together with its own: prep_external)
   if (!(ctx->prep_external && ctx->img_ready == invd && ctx->zpub_ready_n >= n)) panel_fused_prepare(ctx, sa, invd, 0, n, true);
@@ -1169,7 +1174,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     ctx->bs_done = done;
   }
   while (kend < n) {
-    long long next_end = kend + pick_nbo(n - kend, nbo_fixed);
+    long long next_end = kend + pick_nbo(n - kend, nbo_fixed, nbo_wide);
     if (next_end > n) next_end = n;
     // The very end runs on ONE stream: the last outer block spans all remaining columns - as step launches (U1 below
     // becomes the hand-over update of the whole trailing matrix), or, where those are off, with <= SINGLE_BELOW rows left:

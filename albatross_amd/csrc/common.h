@@ -100,6 +100,7 @@ struct agp_context {
   // (agp_fit_create_mixed sets and resets it around its factor_lower call)
   int update_variant = -1;
   long long nbo_override = 0;  // outer block width of the next factorisation (0 = default schedule)
+  long long nbo_wide = 0;      // mixed precision (bf16 x 3): outer block width while many rows remain (0 / 512 = default schedule)
   // scratch of the sharded fit (agp_sharded_fit_destroy parks it here, like pool_A)
   double *pool_shard = nullptr;
   size_t pool_shard_bytes = 0;
@@ -127,6 +128,7 @@ struct agp_context {
     bool panel_fused = true;       // AGP_PANEL_FUSED=0: POTRF and panel TRSM as two launches
     long long step_below = 4608;   // AGP_STEP_BELOW: remaining rows at or below which every panel is ONE step launch (0: off)
     bool gram_sop = true;          // AGP_GRAM_SOP=0: covariance trees through the stack interpreter only
+    long long mixed_nbo = 512;     // AGP_MIXED_NBO: outer block width of the bf16 x 3 factorisation while > 8192 rows remain
     bool mixed_bf16 = true;        // AGP_MIXED_BF16=0: the mixed-precision fit's products on the fp32 MFMA (rounds 1-4) instead of bf16 x 3
     long long backsub_coop_max = 2047;  // AGP_BACKSUB_COOP_MAX: largest n whose fit uses it (measurement switch)
     bool backsub_coop = true;      // AGP_BACKSUB_COOP=0: the fit's back substitution as a launch per block (rounds 1-4) instead of ONE launch

@@ -15,18 +15,27 @@
 //                          (hi = rn(x), mid = rn(x - hi), lo = rn(x - hi - mid); |x - hi - mid - lo| <= 2^-25 |x|),
 //                          laid out [plane][k / 32][row][k % 32]: the 128 rows x 32 k of a tile's chunk are 8 KB
 //                          contiguous per plane
-//   trailing_update_bf16x3_kernel   128 x 128 tile of C per workgroup, 64 x 64 per wave (16 accumulators), K in chunks
-//                          of 32 through LDS (double buffered, row pitch 80 B: the 16 rows a 16-lane group reads with
-//                          ds_read_b128 fall on 16 different 16-B bank slots), C (fp64) fetched during the loop and
-//                          written once: C -= (double)(fp32 sum of the step's products) - the same contract as
+//   trailing_update_bf16x3_pair_kernel   128 x 128 tile of C per workgroup, 64 x 64 per wave (16 accumulators), K in
+//                          chunks of 32 through ONE LDS stage (unpadded 64-B rows, the four 16-B pieces of a row
+//                          permuted so that every ds_read_b128 lane group covers the 256-B bank row once), two
+//                          workgroups per CU; C (fp64) read and written in the epilogue:
+//                          C -= (double)(fp32 sum of the step's products) - the same contract as
 //                          trailing_update_f32_kernel (gemm.hip), whose place it takes.
+//   trailing_update_bf16x3_kernel        the first version (one workgroup per CU, two stages at an 80-B pitch, C
+//                          prefetched during the loop), kept behind AGP_BF16X3_KERNEL=1 for comparison.
 //
-// Measured (profiles/r05/time_bf16x3.txt, N = 32768 trailing shapes): 97-99 TFLOP/s of fp32-equivalent work at
-// M = 8192 and 115-118 at M = 30720, against 87-89 / 105-107 for the fp32 kernel on the same shapes.  What bounds it
-// is the operand stream, not the matrix pipe: a 128 x 128 tile reads 2 x 128 rows x 512 k x 6 B = 768 KB of planes
-// for 16.8 MFLOP (22 flop/B), so 115 TFLOP/s is 5.3 TB/s out of L2 / Infinity Cache - the same fabric limit the fp32
-// kernel meets at 4 B per element - and the LDS pipe is ~75 % busy (24 ds_read_b128 + 12 ds_write_b128 per wave and
-// chunk).  A larger tile (256 x 128: 33 flop/B) is the next step and needs k chunks of 16 to fit LDS twice.
+// Measured (profiles/r05/time_bf16x3.txt, pmc_bulk_kernels_sq_counters.txt; N = 32768 trailing shapes, fp32-equivalent
+// TFLOP/s at M = 8192 / 15872 / 30720; fp32 kernel: 87-89 / - / 105-107):
+//   first version    one workgroup per CU, two LDS stages at an 80-B pitch, C prefetched into 128 registers:
+//                    97-99 / 98 / 115-118.  PMC: the MFMA pipe busy 30 % of the time, the (single) wave per SIMD at an
+//                    s_waitcnt 52 % of its cycles - 9 % of them for LDS, the rest for the global loads of the next
+//                    chunk -, and HALF of the LDS cycles bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+//   pair kernel      one stage, no prefetched C, 163 registers: two workgroups per CU, one's MFMAs in the other's
+//                    waits: 124-128 / 118 / 141.
+//   + swizzled LDS   conflict-free reads AND writes (below), 48 KB per workgroup: 144-146 / 125-127 / 150.
+// In the fit the bulk stream runs it back to back at 142 TFLOP/s (80 of the factorisation's 87 ms at N = 32768): what
+// is left is the memory system - 768 KB of planes per tile, 37 % of them past the L2, plus 256 KB of fp64 C read and
+// written: ~4.9 TB/s beyond the L2 at 150 TFLOP/s.
 #include "common.h"
 #include "gemm_tiles.h"
 

@@ -303,6 +303,20 @@ __global__ __launch_bounds__(256) void tall_matvec_kernel(const T *__restrict__ 
   if (i < rows) {
     const T *p = W + i + (long long)c0 * ld;
     int c = c0;
+    // (sixteen loads in flight per lane: a wave's 256 columns were 32 dependent round trips with eight - 25 us per launch
+    // at 2.7 TB/s in the preconditioner sweeps of the mixed fit)
+    for (; c + 16 <= c1; c += 16, p += 16 * ld) {
+      T w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = p[u * ld];
+      double lo = 0., hi = 0.;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        lo += (double)w[u] * xs[c + u];
+        hi += (double)w[8 + u] * xs[c + 8 + u];
+      }
+      acc += lo + hi;
+    }
     for (; c + 8 <= c1; c += 8, p += 8 * ld) {
       const double v0 = p[0], v1 = p[ld], v2 = p[2 * ld], v3 = p[3 * ld], v4 = p[4 * ld], v5 = p[5 * ld], v6 = p[6 * ld], v7 = p[7 * ld];
       acc += ((v0 * xs[c] + v1 * xs[c + 1]) + (v2 * xs[c + 2] + v3 * xs[c + 3])) +
@@ -359,10 +373,51 @@ void launch_colvec_dot(hipStream_t s, const double *W, long long ld, long long m
   if (n <= 0) return;
   hipLaunchKernelGGL(colvec_dot_kernel<double>, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out, 0LL, 0LL);
 }
+// The same with EIGHT columns per workgroup (a wave owns two, sixteen matrix loads in flight per lane, no barrier): one
+// column of a 1024-row fp32 block is 4 KB - a workgroup per column spent its time starting and ending (27 us per launch
+// at 2.5 TB/s in the backward sweep of the mixed fit's preconditioner).  Summation order differs from colvec_dot_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void colvec_dot8_kernel(const T *__restrict__ W, long long ld, long long m, long long n,
+                                                          const double *__restrict__ v, double alpha, double beta,
+                                                          const double *base, double *out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long j0 = (long long)blockIdx.x * 8 + 2 * wave;
+  if (j0 >= n) return;
+  const bool two = j0 + 1 < n;
+  const T *w0 = W + j0 * ld, *w1 = two ? w0 + ld : w0;
+  double a0 = 0., a1 = 0.;
+  for (long long i0 = lane; i0 < m; i0 += 512) {
+    double x[8];
+    T p[8], q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long i = i0 + 64 * u;
+      const bool ok = i < m;
+      x[u] = ok ? v[i] : 0.;
+      p[u] = ok ? w0[i] : (T)0;
+      q[u] = ok ? w1[i] : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0 += (double)p[u] * x[u];
+      a1 += (double)q[u] * x[u];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_down(a0, off, 64);
+    a1 += __shfl_down(a1, off, 64);
+  }
+  if (lane == 0) {
+    out[j0] = alpha * a0 + (base ? beta * base[j0] : 0.);
+    if (two) out[j0 + 1] = alpha * a1 + (base ? beta * base[j0 + 1] : 0.);
+  }
+}
+
 void launch_colvec_dot_f32(hipStream_t s, const float *W, long long ld, long long m, long long n, const double *v,
                            double alpha, double beta, const double *base, double *out) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(colvec_dot_kernel<float>, dim3((unsigned)n), dim3(256), 0, s, W, ld, m, v, alpha, beta, base, out, 0LL, 0LL);
+  hipLaunchKernelGGL(colvec_dot8_kernel<float>, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, s, W, ld, m, n, v, alpha, beta, base, out);
 }
 
 // L32 (lower triangle incl. diagonal, ld) = (float) L: the fp32 copy of a factor that preconditions the refinement of a
@@ -385,6 +440,60 @@ void launch_convert_lower_f32(hipStream_t s, const double *L, long long ld, long
     hipLaunchKernelGGL(convert_lower_f32_kernel, dim3((unsigned)((rows + 511) / 512), (unsigned)cols), dim3(256), 0, s, L + j0 * ld + j0 / 2 * 2,
                        ld, n - j0 / 2 * 2, L32 + j0 * ld + j0 / 2 * 2);
   }
+}
+
+// dst (lower triangle incl. diagonal, ld) = src: the factor's working copy of a covariance matrix that is kept as well (the
+// mixed-precision fit: api.hip) - a copy is 2 x 8 B per entry, evaluating the covariance function a second time was
+// 3.6 ms at N = 32768 for the temperature example's tree.  A NaN among the copied entries raises *nan_flag like the
+// Gram kernels do (the flags are zeroed between the Gram launch and this copy).
+__global__ __launch_bounds__(256) void copy_lower_kernel(const double *__restrict__ src, long long ld, long long n, double *__restrict__ dst,
+                                                        int *__restrict__ nan_flag) {
+  const long long j = blockIdx.y;
+  const long long i = j / 2 * 2 + ((long long)blockIdx.x * 256 + threadIdx.x) * 2;  // pairs from the even row at or above the diagonal
+  bool bad = false;
+  if (i + 1 < n) {
+    const double2 v = *reinterpret_cast<const double2 *>(src + i + j * ld);
+    *reinterpret_cast<double2 *>(dst + i + j * ld) = v;
+    bad = (i >= j && v.x != v.x) || v.y != v.y;
+  } else if (i < n) {
+    const double v = src[i + j * ld];
+    dst[i + j * ld] = v;
+    bad = v != v;
+  }
+  if (bad && nan_flag) atomicOr(nan_flag, 1);
+}
+void launch_copy_lower(hipStream_t s, const double *src, long long ld, long long n, double *dst, int *nan_flag) {
+  if (n <= 0) return;
+  for (long long j0 = 0; j0 < n; j0 += 2048) {
+    const long long cols = (n - j0 < 2048) ? n - j0 : 2048, rows = n - j0 / 2 * 2;
+    hipLaunchKernelGGL(copy_lower_kernel, dim3((unsigned)((rows + 511) / 512), (unsigned)cols), dim3(256), 0, s, src + j0 * ld + j0 / 2 * 2, ld,
+                       n - j0 / 2 * 2, dst + j0 * ld + j0 / 2 * 2, nan_flag);
+  }
+}
+
+// dst_b = src_b^T for `count` contiguous m x m blocks (leading dimension m): the transposed copies of the wide inverted
+// diagonal blocks, so that BOTH sweeps of the mixed fit's preconditioner apply them with the one-workgroup-per-output
+// colvec_dot (a 1024 x 1024 row-wise product on 16 workgroups took 21 us, the column-wise one on 1024 takes 8)
+__global__ __launch_bounds__(256) void transpose_blocks_kernel(const double *__restrict__ src, double *__restrict__ dst, long long m) {
+  __shared__ double tile[32][33];
+  const double *S = src + (long long)blockIdx.z * m * m;
+  double *D = dst + (long long)blockIdx.z * m * m;
+  const long long bi = blockIdx.x, bj = blockIdx.y;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const long long row = bi * 32 + tx, col = bj * 32 + r;
+    tile[r][tx] = (row < m && col < m) ? S[col * m + row] : 0.;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const long long row = bj * 32 + tx, col = bi * 32 + r;  // D[row, col] = S[col, row]
+    if (row < m && col < m) D[col * m + row] = tile[tx][r];
+  }
+}
+void launch_transpose_blocks(hipStream_t s, const double *src, double *dst, long long m, long long count) {
+  if (m <= 0 || count <= 0) return;
+  const unsigned nb = (unsigned)((m + 31) / 32);
+  hipLaunchKernelGGL(transpose_blocks_kernel, dim3(nb, nb, (unsigned)count), dim3(256), 0, s, src, dst, m);
 }
 
 // the same for `count` problems: W_b = W + b * stride_W; v, base and out are slices of vectors stride_v apart
@@ -460,17 +569,29 @@ __global__ __launch_bounds__(256) void symv_lower_kernel(const double *__restric
   if (tid < SYMV_W && j0 + tid < n) colpart[(long long)blockIdx.y * ldp + j0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
-__global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ rowpart, const double *__restrict__ colpart,
-                                                          long long ldp, long long n, double alpha, double beta,
-                                                          const double *base, double *out) {
-  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (r >= n) return;
+// (256 rows per block, four threads per row: thread group g sums the strips c = g, g + 4, ... - one thread per row walked
+// up to n / 32 strided loads alone and the launch took 0.37 ms at N = 32768, a third of the product itself)
+__global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restrict__ rowpart, const double *__restrict__ colpart,
+                                                           long long ldp, long long n, double alpha, double beta,
+                                                           const double *base, double *out) {
+  __shared__ double part[3][256];
+  const int lane = threadIdx.x & 255, g = threadIdx.x >> 8;
+  const long long r = (long long)blockIdx.x * 256 + lane;
   double acc = 0.;
-  const long long cmax = r / SYMV_W;
-  for (long long c = 0; c <= cmax; ++c) acc += rowpart[c * ldp + r];
-  const long long nseg = (n + SYMV_SEG - 1) / SYMV_SEG;
-  for (long long sgm = (cmax * SYMV_W) / SYMV_SEG; sgm < nseg; ++sgm) acc += colpart[sgm * ldp + r];
-  out[r] = alpha * acc + (base ? beta * base[r] : 0.);
+  if (r < n) {
+    const long long cmax = r / SYMV_W;
+    for (long long c = g; c <= cmax; c += 4) acc += rowpart[c * ldp + r];
+    if (g == 0) {
+      const long long nseg = (n + SYMV_SEG - 1) / SYMV_SEG;
+      for (long long sgm = (cmax * SYMV_W) / SYMV_SEG; sgm < nseg; ++sgm) acc += colpart[sgm * ldp + r];
+    }
+  }
+  if (g > 0) part[g - 1][lane] = acc;
+  __syncthreads();
+  if (g == 0 && r < n) {
+    acc = (acc + part[0][lane]) + (part[1][lane] + part[2][lane]);  // fixed order
+    out[r] = alpha * acc + (base ? beta * base[r] : 0.);
+  }
 }
 
 // ws: symv_ws_elems(n) doubles of scratch
@@ -485,7 +606,7 @@ void launch_symv_lower(hipStream_t s, const double *K, long long ld, long long n
   const long long ldp = (n + 7) / 8 * 8, nstrip = (n + SYMV_W - 1) / SYMV_W, nseg = (n + SYMV_SEG - 1) / SYMV_SEG;
   double *rowpart = ws, *colpart = ws + ldp * nstrip;
   hipLaunchKernelGGL(symv_lower_kernel, dim3((unsigned)nstrip, (unsigned)nseg), dim3(256), 0, s, K, ld, n, p, rowpart, ldp, colpart);
-  hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rowpart, colpart, ldp, n, alpha, beta, base, out);
+  hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(1024), 0, s, rowpart, colpart, ldp, n, alpha, beta, base, out);
 }
 
 // batched: out[b * m + j] = sum_i Q_b[i, j] z_b[i], Q_b = Q + b * stride_Q (m x m, ld), z_b = z + b * stride_z
