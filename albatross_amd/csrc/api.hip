@@ -194,6 +194,7 @@ static agp_context::Tuning read_tuning() {
   t.backsub_coop_max = number("AGP_BACKSUB_COOP_MAX", BACKSUB_COOP_MAX_N);
   t.mixed_bf16 = flag("AGP_MIXED_BF16", true);
   t.mixed_nbo = number("AGP_MIXED_NBO", 512);
+  t.fp64_nbo = number("AGP_FP64_NBO", 0);
   set_bf16x3_kernel((int)number("AGP_BF16X3_KERNEL", 2), (int)number("AGP_BF16X3_LDS_PAD", 8192));
   t.sparse_pivoted = flag("AGP_SPARSE_PIVOTED", false);
   t.predict_chunk = number("AGP_PREDICT_CHUNK", 0);

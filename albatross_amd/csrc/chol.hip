@@ -631,34 +631,47 @@ constexpr int UPD_BLOCKS = NTILE / 4;  // 9 workgroups x 4 waves = the 36 micro 
 // into LDS with one round of loads per thread - the second pass's loads are in flight while the first one multiplies -
 // instead of the generic body's eight 16-deep chunks (eight load / barrier round trips, which is what a workgroup
 // with only two resident workgroups per CU waits for).  lds: 2 * 64 * TRP doubles.
-constexpr int TRP = ST + 8;  // pitch of one k row (the 16 lanes of a fragment read are consecutive: any pitch is conflict-free)
+// LDS image of one 64-deep pass: [64 k rows][64] doubles, NO padding; element (k row, col) at col ^ ((k row & 1) << 4).
+// A ds_read_b64 is served in two groups of 32 lanes = two k rows x 16 consecutive columns: with a 512-byte pitch both
+// rows would sit on the same half of the 256-byte bank row - the swap of the two 16-column halves in odd k rows puts
+// them on opposite halves.  (The first version padded the pitch to 72 on the belief that any pitch is conflict-free for
+// 16 consecutive lanes: 25 % of the step launches' LDS cycles were bank conflicts, profiles/r05/pmc_lds_n4096.txt.)
+// Staging: thread t moves the row pairs 2 (t & 15) and 2 (t & 15) + 32 of k row t >> 4 (+ 16 c): sixteen lanes = 256
+// contiguous bytes in memory, eight lanes of a ds_write_b128 = 128 contiguous bytes in LDS.
+constexpr int TRP = ST;
+__device__ __forceinline__ int trail_col(int krow, int col) { return col ^ ((krow & 1) << 4); }
 
 __device__ __forceinline__ void trail_load_pass(const double *__restrict__ P, long long ld, long long row0, long long nrows,
                                                 int k0, bool vec_ok, double (&r)[16]) {
-  const int t = threadIdx.x, kk = t >> 4, seg = (t & 15) * 4;
+  const int t = threadIdx.x, kk = t >> 4, seg = (t & 15) * 2;
   const long long row = row0 + seg;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const double *q = P + row + (long long)(k0 + 16 * c + kk) * ld;
     if (vec_ok && row0 + ST <= nrows) {
       const double2 a = *reinterpret_cast<const double2 *>(q);
-      const double2 b = *reinterpret_cast<const double2 *>(q + 2);
+      const double2 b = *reinterpret_cast<const double2 *>(q + 32);
       r[4 * c] = a.x; r[4 * c + 1] = a.y; r[4 * c + 2] = b.x; r[4 * c + 3] = b.y;
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[4 * c + e] = (row + e < nrows) ? q[e] : 0.;
+      for (int e = 0; e < 4; ++e) {
+        const int off = 32 * (e >> 1) + (e & 1);
+        r[4 * c + e] = (row + off < nrows) ? q[off] : 0.;
+      }
     }
   }
 }
 
 template <bool NEGATE>
 __device__ __forceinline__ void trail_store_pass(double *__restrict__ Ls, const double (&r)[16]) {
-  const int t = threadIdx.x, kk = t >> 4, seg = (t & 15) * 4;
+  const int t = threadIdx.x, kk = t >> 4, seg = (t & 15) * 2;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    double2 *dst = reinterpret_cast<double2 *>(Ls + (16 * c + kk) * TRP + seg);
-    dst[0] = NEGATE ? make_double2(-r[4 * c], -r[4 * c + 1]) : make_double2(r[4 * c], r[4 * c + 1]);
-    dst[1] = NEGATE ? make_double2(-r[4 * c + 2], -r[4 * c + 3]) : make_double2(r[4 * c + 2], r[4 * c + 3]);
+    const int krow = 16 * c + kk;
+    double *row = Ls + krow * TRP;
+    double2 *d0 = reinterpret_cast<double2 *>(row + trail_col(krow, seg)), *d1 = reinterpret_cast<double2 *>(row + trail_col(krow, seg + 32));
+    *d0 = NEGATE ? make_double2(-r[4 * c], -r[4 * c + 1]) : make_double2(r[4 * c], r[4 * c + 1]);
+    *d1 = NEGATE ? make_double2(-r[4 * c + 2], -r[4 * c + 3]) : make_double2(r[4 * c + 2], r[4 * c + 3]);
   }
 }
 
@@ -705,12 +718,12 @@ __device__ __forceinline__ void trail_tile64(double *__restrict__ Cc, const doub
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int krow = (4 * s + lg) * TRP;
+      const int krow = (4 * s + lg) * TRP, swz = (lg & 1) << 4;  // (k row 4 s + lg: odd with lg)
       double fa[2], fb[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        fa[t] = Bs[krow + 32 * wc + 16 * t + ln];
-        fb[t] = As[krow + 32 * wr + 16 * t + ln];
+        fa[t] = Bs[krow + ((32 * wc + 16 * t + ln) ^ swz)];
+        fb[t] = As[krow + ((32 * wr + 16 * t + ln) ^ swz)];
       }
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
@@ -1145,7 +1158,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   long long K0 = 0;
   const long long nbo_fixed = ctx->nbo_override;
   const int variant = ctx->update_variant;
-  const long long nbo_wide = (variant == 4) ? ctx->nbo_wide : 0;
+  const long long nbo_wide = (variant == 4) ? ctx->nbo_wide : ctx->tune.fp64_nbo;  // (fp64: AGP_FP64_NBO, measurement switch)
   long long kend = K0 + pick_nbo(n, nbo_fixed, nbo_wide);
   if (kend > n) kend = n;
   // (agp_fit_create has already planned and launched the fills together with its own: prep_external)

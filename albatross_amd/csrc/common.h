@@ -128,6 +128,7 @@ struct agp_context {
     bool panel_fused = true;       // AGP_PANEL_FUSED=0: POTRF and panel TRSM as two launches
     long long step_below = 4608;   // AGP_STEP_BELOW: remaining rows at or below which every panel is ONE step launch (0: off)
     bool gram_sop = true;          // AGP_GRAM_SOP=0: covariance trees through the stack interpreter only
+    long long fp64_nbo = 0;        // AGP_FP64_NBO: outer block width of the fp64 factorisation while > 8192 rows remain (0: 512)
     long long mixed_nbo = 512;     // AGP_MIXED_NBO: outer block width of the bf16 x 3 factorisation while > 8192 rows remain
     bool mixed_bf16 = true;        // AGP_MIXED_BF16=0: the mixed-precision fit's products on the fp32 MFMA (rounds 1-4) instead of bf16 x 3
     long long backsub_coop_max = 2047;  // AGP_BACKSUB_COOP_MAX: largest n whose fit uses it (measurement switch)

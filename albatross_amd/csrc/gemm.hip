@@ -452,7 +452,7 @@ void launch_gemm_nt_sub_batched(hipStream_t s, double *C, long long ldc, long lo
   const long long tiles = count_tiles(g.ntr, g.ntc, g.tri);
   if (tiles <= 0) return;
   // fewer 128-tiles than workgroup slots (2 per CU): use 64 x 64 tiles instead (128 ... 512: flat, profiles/r03)
-  constexpr int small_limit = 512;
+  static const int small_limit = [] { const char *e = getenv("AGP_GEMM_SMALL_LIMIT"); return e && e[0] ? atoi(e) : 512; }();
   if (b_kmajor && !tri && tiles * count < small_limit) {
     // launches that cannot fill the chip with 128 x 128 tiles (few right-hand sides, or the inner updates of a
     // substitution with few rows): 64 x 64 tiles with the transposed-operand loader(s).  N = 16384, predict

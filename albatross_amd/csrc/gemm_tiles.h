@@ -282,15 +282,18 @@ __device__ __forceinline__ void gemm_nt_sub_tile_cpf(const GemmArgs &g, const in
           fa[t] = Bs[krow + 64 * wc + 16 * t + ln];
           fb[t] = As[krow + 64 * wr + 16 * t + ln];
         }
+        if (s == GK / 4 - 1 && more) {
+          // the next chunk into the OTHER stage in front of the last sixteen MFMAs (nobody reads that stage before the
+          // barrier below; its loads were issued three k steps ago): the stores used to follow the last MFMA - eight
+          // ds_write_b128 and their vmcnt waits with an idle matrix pipe, once per chunk
+          double *An = lds + (cur ^ 1) * (2 * GK * GLD);
+          store_chunk<A_KMAJOR, false>(An, ra);
+          store_chunk<B_KMAJOR, true>(An + GK * GLD, rb);
+        }
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
           for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
-      }
-      if (more) {
-        double *An = lds + (cur ^ 1) * (2 * GK * GLD);
-        store_chunk<A_KMAJOR, false>(An, ra);
-        store_chunk<B_KMAJOR, true>(An + GK * GLD, rb);
       }
       __syncthreads();
     }
@@ -450,6 +453,8 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs &g, const long long i
 #pragma unroll
           for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
       }
+      // (the stores IN FRONT of the MFMAs - their data has been in registers for a trip - measured 1 % slower at
+      // N = 8192 / 16384: behind the MFMAs they overlap with the tail of the matrix pipe)
       if (k + 1 < nk) {  // chunk k + 1 (register stage half ^ 1, loaded a trip ago) -> the other LDS buffer
         double *An = lds + (half ^ 1) * (2 * GK * SLD);
         if (A_KMAJOR) store_chunk64_kmajor<false>(An, ra[half ^ 1]);

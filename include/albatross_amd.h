@@ -614,6 +614,11 @@ AGP_API int agp_set_profiling(agp_context *ctx, int enabled);
  *   AGP_STEP_BELOW=<rows>    remaining rows at or below which every panel is ONE step launch (default 4608; 0: off)
  *   AGP_GRAM_SOP=0           covariance trees through the stack interpreter only (parity tests run both evaluators)
  *   AGP_MIXED_BF16=0         agp_fit_create_mixed forms its fp32-accurate products on the fp32 MFMA instead of bf16 x 3
+ *   AGP_BF16X3_KERNEL=1      ... with the first bf16 x 3 tile kernel (one workgroup per CU) instead of the pair kernel
+ *   AGP_BF16X3_LDS_PAD=<b>   extra LDS bytes per workgroup of the pair kernel (default 8192: two per CU; 0: three)
+ *   AGP_MIXED_NBO=<w>        outer block width of the mixed factorisation while > 8192 rows remain (default 512)
+ *   AGP_FP64_NBO=<w>         the same for the fp64 factorisation (default 0 = 512)
+ *   AGP_GEMM_SMALL_LIMIT=<t> 64 x 64 instead of 128 x 128 tiles for products of fewer than t 128-tiles (default 512)
  *   AGP_BACKSUB_COOP=0       the fit's back substitution as one launch per block (rounds 1-4) instead of ONE launch
  *   AGP_BACKSUB_COOP_MAX=<n> largest fit that uses the one-launch back substitution (default 2047)
  *   AGP_SPARSE_PIVOTED=1     the sparse GP always takes the literal (pivoted LDL^T + column-pivoted QR) path
