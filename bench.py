@@ -293,17 +293,22 @@ def fit_batch_rates(ab, ctx, sizes=None, batches=(1, 8, 32, 256)):
             out = (C.c_void_p * B)()
             status = (C.c_int * B)()
 
+            # (the ctypes arguments are built ONCE: at N = 512 a fit is 0.17 ms and building them per call - byref, c_void_p,
+            # tensor.data_ptr() - was 10-15 us of the harness, not of the library)
+            h = C.c_void_p()
+            h_ref, f0_ref, y_ptr, ctx_h = C.byref(h), C.byref(feats[0]), C.c_void_p(y_d.data_ptr()), ctx._h
+            fit_create, fit_create_batch, fit_destroy = lib.agp_fit_create, lib.agp_fit_create_batch, lib.agp_fit_destroy
+
             def step():
                 if B == 1:
-                    h = C.c_void_p()
-                    st = lib.agp_fit_create(ctx._h, kh, C.byref(feats[0]), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+                    st = fit_create(ctx_h, kh, f0_ref, y_ptr, None, h_ref, None, None)
                     assert st == capi.AGP_OK, st
-                    lib.agp_fit_destroy(h)
+                    fit_destroy(h)
                 else:
-                    st = lib.agp_fit_create_batch(ctx._h, B, kernels, fptrs, C.c_void_p(y_d.data_ptr()), n, None, 0, out, None, 0, None, status)
+                    st = fit_create_batch(ctx_h, B, kernels, fptrs, y_ptr, n, None, 0, out, None, 0, None, status)
                     assert st == capi.AGP_OK and all(s == capi.AGP_OK for s in status), (st, list(status))
                     for b in range(B):
-                        lib.agp_fit_destroy(C.c_void_p(out[b]))
+                        fit_destroy(C.c_void_p(out[b]))
             # warm the clock: short kernels after an idle gap run at whatever the GPU had dropped to - at least 50 ms of the
             # same work back to back before anything is timed (two driver runs of this table used to differ by 2x at N = 512)
             t_w = time.perf_counter()
