@@ -1289,7 +1289,24 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     } else {
       have_u2 = false;
     }
-    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, step);
+    // The step tail of a large fit, like the all-step fit above: the wide diagonal blocks that become final INSIDE the tail
+    // (all but the last one) are inverted on the idle second stream under the tail's last four panels - the back
+    // substitution of the fit used to invert them behind the factorisation (~0.15 ms of a 29 ms fit at N = 16384).
+    const long long bw = ctx->bs_BW;
+    const bool tail_inv = !throttle && step && next_end == n && ctx->bs_W && bw > 0 && ctx->ev_inv && ctx->stream2 && n % bw == 0 &&
+                          ctx->bs_done > 0 && ctx->bs_done == kend / bw && n / bw - 1 > ctx->bs_done && (n / bw - 1) * bw - NB >= kend;
+    if (!throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, step, tail_inv ? (n / bw - 1) * bw - NB : -1,
+                               tail_inv ? ctx->ev_c : nullptr);
+    if (tail_inv) {
+      const long long first = ctx->bs_done, last = n / bw - 1, cnt = last - first;
+      while (hipEventQuery(ctx->ev_c) == hipErrorNotReady) {}
+      hipStream_t si = ctx->stream2;
+      launch_set_identity_batched(si, ctx->bs_W + first * bw * bw, bw, bw * bw, bw, cnt);
+      forward_solve_mat_batched(si, A + first * bw * (lda + 1), bw * (lda + 1), bw, lda, invd + first * (bw / NB) * (long long)IMG_DOUBLES,
+                                (bw / NB) * (long long)IMG_DOUBLES, ctx->bs_W + first * bw * bw, bw * bw, bw, bw, /*rhs_lower=*/true, cnt);
+      (void)hipEventRecord(ctx->ev_inv, si);
+      ctx->bs_done = last;
+    }
     K0 = kend;
     kend = next_end;
   }

@@ -446,7 +446,15 @@ def other_configs(ab, ctx):
                 fit.accept_mixed_log_determinant = True  # (reported as log_det_rel_err_vs_fp64)
                 info, ld = fit.information.copy(), fit.log_determinant
                 del fm, fit
-            res[prec] = (t, info, ld, model.refinement_, [ctx.stage_ms(i) for i in range(3)])
+            refinement = model.refinement_
+            ctx.set_profiling(True)  # (one more fit for the stage split: the event records are kept out of the timed fits)
+            try:
+                fm = model.fit(ds)
+                stages_ms = [ctx.stage_ms(i) for i in range(3)]
+                del fm
+            finally:
+                ctx.set_profiling(False)
+            res[prec] = (t, info, ld, refinement, stages_ms)
         flop = n ** 3 / 3.
         t64, a64, ld64, _, _ = res["fp64"]
         tmx, amx, ldm, (its, rel_res), stages = res["mixed"]
@@ -788,6 +796,9 @@ def run_rank(args):
         t_loop = time.perf_counter() - t0
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        # (the stage events are for the headline's live roofline only: left on, every later measurement of this process - the
+        # first row of the small-N table - paid five event records per fit, 20 us at N = 512)
+        ctx.set_profiling(False)
         if os.environ.get("BENCH_DEBUG_STEPS"):
             sys.stderr.write(f"bench.py rank {rank}: per-step wall ms {[round(1e3 * v, 2) for v in step_walls]}, loop {1e3 * t_loop:.2f} ms, "
                              f"with closing barrier {1e3 * elapsed:.2f} ms\n")
