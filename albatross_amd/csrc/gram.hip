@@ -883,40 +883,58 @@ __global__ __launch_bounds__(64 * PM_WAVES) void predict_mean_fast_kernel(FastPa
   if (lane == 0) mean[j] = acc;
 }
 
-// The same for MANY test points (M >= 1024): a workgroup of 256 threads owns PM_TJ test points - their coordinates are
+// The same for MANY test points (M >= 1024): a workgroup of 256 threads owns TJ test points - their coordinates are
 // wave-uniform, i.e. scalar registers - and every thread walks the training points tid, tid + 256, ... loading each one
-// (and its information entry) ONCE for PM_TJ kernel evaluations; PM_TJ independent exp_neg chains per iteration fill
+// (and its information entry) ONCE for TJ kernel evaluations; TJ independent exp_neg chains per iteration fill
 // the latency of one another.  One shuffle reduction per test point at the end.  (The one-wave-per-test-point kernel
 // above loads three coordinates and one information entry per single evaluation: 0.145 ms for M = 4096 at N = 16384,
 // a quarter of the VALU roofline.)  Deterministic; the summation order differs from the kernel above (both hold the
 // 1e-8 parity bar with orders of magnitude to spare).
-constexpr int PM_TJ = 4;
-template <int DIMP, int OP>
+// TJ = 4 test points per workgroup, 8 from 16384 test points on (half the training loads per evaluation; below that the
+// launch has too few workgroups for it: 0.185 against 0.166 ms at M = 4096).  The next training point's coordinates are
+// requested before the current one is evaluated.
+template <int DIMP, int OP, int TJ>
 __global__ __launch_bounds__(256) void predict_mean_tiled_kernel(FastParams fp, FeatView X, FeatView XS, const double *alpha,
                                                                 double *mean) {
-  const long long j0 = (long long)blockIdx.x * PM_TJ;
-  double y[PM_TJ][DIMP];
-  long long yid[PM_TJ];
+  const long long j0 = (long long)blockIdx.x * TJ;
+  double y[TJ][DIMP];
+  long long yid[TJ];
   const bool have_ids = X.ids != nullptr && XS.ids != nullptr;
 #pragma unroll
-  for (int t = 0; t < PM_TJ; ++t) {
+  for (int t = 0; t < TJ; ++t) {
     const long long j = j0 + t < XS.n ? j0 + t : XS.n - 1;  // (a partial last tile repeats the last point; not stored)
 #pragma unroll
     for (int d = 0; d < DIMP; ++d) y[t][d] = XS.coords[j * XS.dim + d];
     yid[t] = have_ids ? XS.ids[j] : -1;
   }
   const bool noise_on = fp.has_noise && (!fp.noise_meas_only || (X.meas && XS.meas));
-  double acc[PM_TJ];
+  double acc[TJ];
 #pragma unroll
-  for (int t = 0; t < PM_TJ; ++t) acc[t] = 0.;
+  for (int t = 0; t < TJ; ++t) acc[t] = 0.;
+  double xn[DIMP], an = 0.;
+  long long idn = 0;
+  {
+    const long long i = threadIdx.x < X.n ? threadIdx.x : X.n - 1;
+#pragma unroll
+    for (int d = 0; d < DIMP; ++d) xn[d] = X.coords[i * DIMP + d];
+    an = alpha[i];
+    idn = have_ids ? X.ids[i] : 0;
+  }
   for (long long i = threadIdx.x; i < X.n; i += 256) {
     double x[DIMP];
 #pragma unroll
-    for (int d = 0; d < DIMP; ++d) x[d] = X.coords[i * DIMP + d];
-    const double a = alpha[i];
-    const long long xid = have_ids ? X.ids[i] : 0;
+    for (int d = 0; d < DIMP; ++d) x[d] = xn[d];
+    const double a = an;
+    const long long xid = idn;
+    {
+      const long long in = i + 256 < X.n ? i + 256 : i;  // (the last trip re-reads its own point)
 #pragma unroll
-    for (int t = 0; t < PM_TJ; ++t) {
+      for (int d = 0; d < DIMP; ++d) xn[d] = X.coords[in * DIMP + d];
+      an = alpha[in];
+      idn = have_ids ? X.ids[in] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
       bool eq = true;
       double sq = 0.;
 #pragma unroll
@@ -931,40 +949,48 @@ __global__ __launch_bounds__(256) void predict_mean_tiled_kernel(FastParams fp, 
       acc[t] += v * a;
     }
   }
-  __shared__ double red[4][PM_TJ];
+  __shared__ double red[4][TJ];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int t = 0; t < PM_TJ; ++t) {
+  for (int t = 0; t < TJ; ++t) {
     double r = acc[t];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
     if (lane == 0) red[wave][t] = r;
   }
   __syncthreads();
-  if (threadIdx.x < PM_TJ && j0 + threadIdx.x < XS.n)
+  if (threadIdx.x < TJ && j0 + threadIdx.x < XS.n)
     mean[j0 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <int DIMP, int TJ>
+static bool launch_predict_mean_tiled_t(hipStream_t s, const FastParams &fp, int op, const FeatView &X, const FeatView &XS,
+                                        const double *alpha, double *mean) {
+  dim3 tgrid((unsigned)((XS.n + TJ - 1) / TJ)), tblock(256);
+  switch (op) {
+  case AGP_OP_SQUARED_EXPONENTIAL:
+    hipLaunchKernelGGL((predict_mean_tiled_kernel<DIMP, AGP_OP_SQUARED_EXPONENTIAL, TJ>), tgrid, tblock, 0, s, fp, X, XS, alpha, mean);
+    return true;
+  case AGP_OP_EXPONENTIAL:
+    hipLaunchKernelGGL((predict_mean_tiled_kernel<DIMP, AGP_OP_EXPONENTIAL, TJ>), tgrid, tblock, 0, s, fp, X, XS, alpha, mean);
+    return true;
+  case AGP_OP_MATERN32:
+    hipLaunchKernelGGL((predict_mean_tiled_kernel<DIMP, AGP_OP_MATERN32, TJ>), tgrid, tblock, 0, s, fp, X, XS, alpha, mean);
+    return true;
+  case AGP_OP_MATERN52:
+    hipLaunchKernelGGL((predict_mean_tiled_kernel<DIMP, AGP_OP_MATERN52, TJ>), tgrid, tblock, 0, s, fp, X, XS, alpha, mean);
+    return true;
+  default: return false;
+  }
 }
 
 template <int DIMP>
 static bool launch_predict_mean_fast_t(hipStream_t s, const FastParams &fp, int op, const FeatView &X,
                                        const FeatView &XS, const double *alpha, double *mean) {
-  if (XS.n >= 1024 && XS.dim == DIMP) {  // enough test points for 256 workgroups of PM_TJ
-    dim3 tgrid((unsigned)((XS.n + PM_TJ - 1) / PM_TJ)), tblock(256);
-    switch (op) {
-    case AGP_OP_SQUARED_EXPONENTIAL:
-      hipLaunchKernelGGL((predict_mean_tiled_kernel<DIMP, AGP_OP_SQUARED_EXPONENTIAL>), tgrid, tblock, 0, s, fp, X, XS, alpha, mean);
-      return true;
-    case AGP_OP_EXPONENTIAL:
-      hipLaunchKernelGGL((predict_mean_tiled_kernel<DIMP, AGP_OP_EXPONENTIAL>), tgrid, tblock, 0, s, fp, X, XS, alpha, mean);
-      return true;
-    case AGP_OP_MATERN32:
-      hipLaunchKernelGGL((predict_mean_tiled_kernel<DIMP, AGP_OP_MATERN32>), tgrid, tblock, 0, s, fp, X, XS, alpha, mean);
-      return true;
-    case AGP_OP_MATERN52:
-      hipLaunchKernelGGL((predict_mean_tiled_kernel<DIMP, AGP_OP_MATERN52>), tgrid, tblock, 0, s, fp, X, XS, alpha, mean);
-      return true;
-    default: break;
-    }
+  if (XS.n >= 1024 && XS.dim == DIMP) {  // enough test points for 256 workgroups of four (16384: of eight)
+    const bool done = XS.n >= 16384 ? launch_predict_mean_tiled_t<DIMP, 8>(s, fp, op, X, XS, alpha, mean)
+                                    : launch_predict_mean_tiled_t<DIMP, 4>(s, fp, op, X, XS, alpha, mean);
+    if (done) return true;
   }
   dim3 grid((unsigned)((XS.n + PM_WAVES - 1) / PM_WAVES)), block(64 * PM_WAVES);
   switch (op) {
