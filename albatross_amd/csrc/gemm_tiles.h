@@ -182,15 +182,15 @@ __device__ __forceinline__ void gemm_nt_sub_tile(const GemmArgs &g, const int bi
         fa[t] = Bs[krow + 64 * wc + 16 * t + ln];  // MFMA A operand: C-column panel (negated)
         fb[t] = As[krow + 64 * wr + 16 * t + ln];  // MFMA B operand: C-row panel
       }
+      if (s == GK / 4 - 1 && more) {  // (the next chunk's LDS stores in front of the last k step's MFMAs: see gemm_nt_sub_tile_cpf)
+        double *An = lds + (cur ^ 1) * (2 * GK * GLD);
+        store_chunk<A_KMAJOR, false>(An, ra);
+        store_chunk<B_KMAJOR, true>(An + GK * GLD, rb);
+      }
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = mfma16(fa[tj], fb[ti], acc[tj][ti]);
-    }
-    if (more) {
-      double *An = lds + (cur ^ 1) * (2 * GK * GLD);
-      store_chunk<A_KMAJOR, false>(An, ra);
-      store_chunk<B_KMAJOR, true>(An + GK * GLD, rb);
     }
     __syncthreads();
   }
