@@ -115,6 +115,36 @@ def test_mixed_fit_large_property(ctx):
     assert abs(fmx.get_fit().log_determinant - f64.get_fit().log_determinant) <= 1e-5 * abs(f64.get_fit().log_determinant)
 
 
+@pytest.mark.parametrize("n", [3072, 4608])
+def test_mixed_fit_wide_sweeps_property(ctx, n):
+    """Multiples of 512 below 8192: the preconditioner sweeps run through 512-wide inverted blocks and their transposed
+    copies, out of place (api.hip: refine_information); the factor's working matrix is a lower-triangle COPY of the kept
+    covariance.  Property: K a = y against an independently built Gram matrix, and agreement with the all-fp64 fit."""
+    x, y = synthetic_3d(n, 7 + n)
+    cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.05)
+    mm = ab.gp_from_covariance(cov, context=ctx)
+    mm.precision = "mixed"
+    fmx = mm.fit(ab.RegressionDataset(x, y))
+    its, res = mm.refinement_
+    a = fmx.get_fit().information
+    K = ctx.gram(cov, ab.Measurement(x))
+    assert np.linalg.norm(K @ a - y) <= 1e-11 * np.linalg.norm(y)
+    assert res <= 1e-12 and its <= 30, (its, res)
+    f64 = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
+    assert rel(a, f64.get_fit().information) <= 1e-8
+
+
+def test_mixed_fit_reports_nan_input(ctx):
+    """gp.hpp:66 (ALBATROSS_ASSERT(!cov.hasNaN())) on the mixed path: the NaN is seen by the lower-triangle copy that
+    feeds the factorisation (reduce.hip: copy_lower_kernel), not by a second evaluation of the covariance."""
+    x, y = synthetic_3d(2048, 9)
+    x[100, 1] = np.nan
+    model = ab.gp_from_covariance(ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1), context=ctx)
+    model.precision = "mixed"
+    with pytest.raises(ab.NanInputError):
+        model.fit(ab.RegressionDataset(x, y))
+
+
 def test_mixed_fit_reports_failures(ctx):
     x, y = synthetic_3d(300, 3)
     x[17] = x[3]  # duplicate point and no noise: singular
