@@ -35,7 +35,8 @@
 //   + swizzled LDS   conflict-free reads AND writes (below), 48 KB per workgroup: 144-146 / 125-127 / 150.
 // In the fit the bulk stream runs it back to back at 142 TFLOP/s (80 of the factorisation's 87 ms at N = 32768): what
 // is left is the memory system - 768 KB of planes per tile, 37 % of them past the L2, plus 256 KB of fp64 C read and
-// written: ~4.9 TB/s beyond the L2 at 150 TFLOP/s.
+// written: ~4.9 TB/s beyond the L2 at 150 TFLOP/s.  (A second register stage - the loads of chunk k + 2 in flight while
+// chunk k is multiplied, 212 registers - measured 141 against 144.5 TFLOP/s on one box: it is throughput, not latency.)
 #include "common.h"
 #include "gemm_tiles.h"
 
