@@ -77,3 +77,23 @@ def test_repeated_fits_are_bitwise_identical(ctx, n, reps):
             first = got
         else:
             assert np.array_equal(got[0], first[0]) and got[1] == first[1]
+
+
+@pytest.mark.parametrize("n,reps", [(129, 300), (512, 300), (1280, 150), (1920, 100), (2047, 100)])
+def test_repeated_small_fits_are_bitwise_identical(ctx, n, reps):
+    """The polling kernels of a small fit - the step launches' hand-overs and the one-launch back substitution, whose
+    workgroups wait for each other's values inside ONE launch - must neither time out nor depend on timing: every repeat
+    of the same fit reproduces the information vector bit for bit (scripts/stress_small_fits.py runs thousands)."""
+    x, y = synthetic_3d(n, 77 + n)
+    model = ab.gp_from_covariance(ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1), context=ctx)
+    ds = ab.RegressionDataset(x, y)
+    first = None
+    for i in range(reps):
+        fm = model.fit(ds)
+        if i % 10 == 0:
+            got = (fm.get_fit().information.copy(), fm.get_fit().log_determinant)
+            if first is None:
+                first = got
+            else:
+                assert np.array_equal(got[0], first[0]) and got[1] == first[1], (n, i)
+        del fm
