@@ -498,6 +498,35 @@ def other_configs(ab, ctx):
         del fm
     except Exception as exc:  # noqa: BLE001
         out["config5"] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # ---- config 3's problem at larger N (one GPU, features and targets resident in HBM): the sizes at which the sharded fit
+    #      of `--gpus N` has work to share (its N = 65536 block), and how far the factorisation gets from the tile's fixed costs ----
+    try:
+        import torch
+        from albatross_amd import _capi as capi
+        rows = []
+        cov3 = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+        kh3 = ctx.kernel(cov3)
+        for n in (32768, 65536):
+            x, y = make_dataset(n, 44)
+            x_d, y_d = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+            feats = _device_features(torch, capi, x_d, n)
+            torch.cuda.synchronize()
+
+            def fit_large():
+                h = C.c_void_p()
+                st = ctx._lib.agp_fit_create(ctx._h, kh3, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+                assert st == capi.AGP_OK, st
+                ctx._lib.agp_fit_destroy(h)
+            t = best(fit_large, 2)  # (one untimed fit pays for the allocation, best of two timed ones)
+            flop = n ** 3 / 3.
+            rows.append({"n": n, "fit_ms": 1e3 * t, "fits_per_sec": 1. / t, "tflops_overall": flop / t / 1e12,
+                         "frac_of_mfma_peak": flop / t / 1e12 / MFMA_F64_PEAK_TFLOPS})
+            del x_d, y_d
+        out["config3_large_n"] = {"workload": "config 3's problem (3-D SE(1,1) + noise(0.1), mt19937(44)) at N = 32768 / 65536, fp64 dense fit, "
+                                              "inputs resident in HBM, one GPU; n^3/3 flop over the whole fit", "rows": rows}
+    except Exception as exc:  # noqa: BLE001
+        out["config3_large_n"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 
