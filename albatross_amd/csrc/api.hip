@@ -789,28 +789,7 @@ void backward_solve_vec_any(hipStream_t s, const double *A, long long n, long lo
   }
   const long long nb = n / BW;
   if (first_done < 0 || first_done > nb) first_done = 0;
-  if (first_done == nb - 1 && nb >= 2) {
-    // all inverses but the LAST block's are on their way (factor_lower's early inversion): inverting one more block is the
-    // same seven-launch chain as inverting all of them (~100 us) - the last BW rows go through the one-launch substitution
-    // instead (solve.hip: backsub_coop_kernel on the trailing BW x BW triangle, ~9 us per 128 rows), then its update
-    const long long k0 = (nb - 1) * BW;
-    // (BW / 128 <= BACKSUB_DIRECT_BLOCKS blocks: the sentinel-filled output is its own hand-over buffer)
-    {
-      PrepArgs prep;
-      prep.sentinel(xs + k0, BW);
-      launch_prep(s, prep);
-    }
-    backward_solve_coop(s, A + k0 * (lda + 1), BW, lda, invd + (k0 / NB) * (long long)(36 * MB * MB), z + k0, xs + k0, nullptr, nullptr);
-    launch_colvec_dot(s, A + k0, lda, BW, k0, xs + k0, -1.0, 1.0, z, z);  // z[0:k0] -= L[B, 0:k0]^T x_B
-    if (ev_done) (void)hipStreamWaitEvent(s, ev_done, 0);
-    for (long long b = nb - 2; b >= 0; --b) {
-      const long long c0 = b * BW;
-      launch_colvec_dot(s, W + b * BW * BW, BW, BW, BW, z + c0, 1.0, 0.0, nullptr, xs + c0);
-      if (c0 > 0) launch_colvec_dot(s, A + c0, lda, BW, c0, xs + c0, -1.0, 1.0, z, z);
-    }
-    (void)hipMemcpyAsync(z, xs, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s);
-    return;
-  }
+  // (first_done == nb - 1 - every inverse but the last block's under way - is backward_solve_vec_from's fast path below)
   if (first_done < nb) {
     const long long cnt = nb - first_done;
     launch_set_identity_batched(s, W + first_done * BW * BW, BW, BW * BW, BW, cnt);
