@@ -10,7 +10,7 @@ from .covariance import (AngularDistance, Constant, CovarianceFunction, Euclidea
                          ScalingTerm, SquaredExponential, SumOfCovarianceFunctions, as_measurements,
                          measurement_only, OnlyForAlternatives, VariantFeatures, only_for_alternatives)
 
-from .gp import (AlbatrossAmdError, BlockSymmetric, ExplainedCovariance, PivotedLDLT, Context, CrossValidation, CrossValidationPrediction, DenseFactor,
+from .gp import (AlbatrossAmdError, BlockSymmetric, ExplainedCovariance, PivotedLDLT, Context, DeviceArray, CrossValidation, CrossValidationPrediction, DenseFactor,
                  LeaveOneOutGrouper, group_indexer, root_mean_square_error, UpdatedGPFit, negative_log_likelihood, FitModel, GaussianProcessRegression, GPFit, JointDistribution,
                  LinearMean, MeanFunction, SumOfMeanFunctions, ProductOfMeanFunctions, MarginalDistribution, NanInputError, NotPositiveDefiniteError, Prediction,
                  RegressionDataset, ZeroMean, default_context, fit_batch, gp_from_covariance, gp_from_covariance_and_mean)

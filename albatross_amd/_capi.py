@@ -77,6 +77,9 @@ EXPORTS = [
     ("agp_last_error", C.c_char_p, [_P]),
     ("agp_status_string", C.c_char_p, [C.c_int]),
     ("agp_device_count", C.c_int, []),
+    ("agp_device_malloc", C.c_int, [_P, C.c_int64, _PP]),
+    ("agp_device_free", C.c_int, [_P, _P]),
+    ("agp_memcpy", C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
     ("agp_kernel_create", C.c_int, [C.POINTER(KernelNode), C.c_int, _PP]),
     ("agp_kernel_destroy", None, [_P]),
     ("agp_gram", C.c_int, [_P, _P, C.POINTER(Features), C.POINTER(Features), _P, C.c_int64, C.c_int]),

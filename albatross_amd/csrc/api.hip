@@ -304,7 +304,35 @@ void agp_context_destroy(agp_context *c) {
 
 int agp_context_synchronize(agp_context *ctx) {
   if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
-  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  AGP_HIP_CHECK(ctx, hipDeviceSynchronize());
+  return AGP_OK;
+}
+
+// device buffers for AGP_DEVICE arguments (include/albatross_amd.h, "device memory"): plain runtime calls on the context's
+// device, so that a host program needs neither HIP headers nor a second runtime in its process
+int agp_device_malloc(agp_context *ctx, int64_t bytes, void **out) {
+  if (!ctx || !out || bytes <= 0) return AGP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  AGP_HIP_CHECK(ctx, hipMalloc(out, (size_t)bytes));
+  return AGP_OK;
+}
+
+int agp_device_free(agp_context *ctx, void *ptr) {
+  if (!ctx) return AGP_ERR_INVALID_ARGUMENT;
+  if (!ptr) return AGP_OK;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  AGP_HIP_CHECK(ctx, hipFree(ptr));
+  return AGP_OK;
+}
+
+int agp_memcpy(agp_context *ctx, void *dst, const void *src, int64_t bytes, int kind) {
+  if (!ctx || bytes < 0 || (kind != AGP_HOST && kind != AGP_DEVICE) || (bytes > 0 && (!dst || !src))) return AGP_ERR_INVALID_ARGUMENT;
+  if (bytes == 0) return AGP_OK;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (kind == AGP_HOST) AGP_HIP_CHECK(ctx, hipDeviceSynchronize());  // the context's streams are non-blocking: the copy would not wait for them
+  AGP_HIP_CHECK(ctx, hipMemcpy(dst, src, (size_t)bytes, kind == AGP_DEVICE ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
   return AGP_OK;
 }
 
@@ -829,13 +857,15 @@ static void forward_solve_vec_wide(hipStream_t s, const double *A, long long n, 
 // early inversion under way this is the loop above without its two copy launches: the first update reads z_in and
 // writes the work vector (ws[0:n]), every x_B goes straight into x.
 void backward_solve_vec_from(hipStream_t s, const double *A, long long n, long long lda, const double *invd, const double *z_in,
-                             double *x, double *ws, long long first_done, hipEvent_t ev_done) {
+                             double *x, double *ws, long long first_done, hipEvent_t ev_done, int *flags) {
   const long long BW = backsolve_width(n), nb = BW ? n / BW : 0;
-  if (BW && nb >= 2 && first_done == nb - 1) {
+  // (flags == nullptr: the one-launch substitution of the last block is off - AGP_BACKSUB_COOP=0, or a hand-over timed out
+  // earlier on this context)
+  if (BW && nb >= 2 && first_done == nb - 1 && flags) {
     double *work = ws, *W = ws + round_up(n, 2);
     const long long k0 = (nb - 1) * BW;
     launch_fill_sentinel(s, x + k0, BW);
-    backward_solve_coop(s, A + k0 * (lda + 1), BW, lda, invd + (k0 / NB) * (long long)(36 * MB * MB), z_in + k0, x + k0, nullptr, nullptr);
+    backward_solve_coop(s, A + k0 * (lda + 1), BW, lda, invd + (k0 / NB) * (long long)(36 * MB * MB), z_in + k0, x + k0, flags, nullptr);
     launch_colvec_dot(s, A + k0, lda, BW, k0, x + k0, -1.0, 1.0, z_in, work);  // work[0:k0] = z[0:k0] - L[B, 0:k0]^T x_B
     if (ev_done) (void)hipStreamWaitEvent(s, ev_done, 0);
     for (long long b = nb - 2; b >= 0; --b) {
@@ -1087,7 +1117,11 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     if (st2 != AGP_OK) { drop_mixed(); agp_fit_destroy(fit); return st2; }
     {
       TraceRange tr("agp: backward substitution (information = ldlt.solve(y), gp.hpp:68)");
-      backward_solve_vec_from(s, fit->A, n, fit->lda, fit->invd, fit->z, fit->alpha, ctx->ws_aux, bs_done, ctx->ev_inv);
+      backward_solve_vec_from(s, fit->A, n, fit->lda, fit->invd, fit->z, fit->alpha, ctx->ws_aux, bs_done, ctx->ev_inv,
+                              ctx->tune.backsub_coop ? ctx->d_flags : nullptr);
+      // (its last wide block goes through the one-launch substitution, which records a timed-out hand-over in flags[2]: the
+      // status block left for the host BEFORE the substitution ran - the flags once more behind it)
+      if (deferred) FIT_CHECK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     }
     // the refinement steps of the mixed-precision fit use the 128-row chain on fit->winv
     if (mixed) invert_diag_blocks(s, fit->A, n, fit->lda, fit->invd, fit->winv);
@@ -1140,6 +1174,7 @@ static int fit_create_retrying(agp_context *c, const agp_kernel *k, const agp_fe
     if (out && *out) { agp_fit_destroy(*out); *out = nullptr; }
     c->tune.step_below = 0;
     c->tune.panel_fused = false;
+    c->tune.backsub_coop = false;  // (the one-launch substitution hands over inside a launch too)
     st = fit_create_impl(c, k, x, y, y_var, out, information, log_det, mixed);
   }
   return st;

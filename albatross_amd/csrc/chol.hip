@@ -441,8 +441,8 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfArgs p) {
     p.A += b * p.batch_A;
     p.img += b * p.batch_img;
     if (p.y) p.y += b * p.batch_y;
-    p.scalars += b * p.batch_scalars;
-    p.flags += b * p.batch_flags;
+    if (p.scalars) p.scalars += b * p.batch_scalars;
+    if (p.flags) p.flags += b * p.batch_flags;
   }
   __shared__ double T[POTRF_LDS_DOUBLES];
   potrf_diag_body<false>(p, T);
@@ -1086,6 +1086,19 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
   }
 }
 
+// Host-side wait for an event WITHOUT parking a stream at a hipStreamWaitEvent (section 8: a stream that sits at an
+// unsatisfied wait slows the launches of the others).  Polls with a pause instruction between queries (the core is
+// shared with the launch threads of the other ranks of a box); true only if the event completed - any error ends the
+// wait and the caller skips what depended on it.
+static bool host_wait_event(hipEvent_t ev) {
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return true;
+    if (e != hipErrorNotReady) { (void)hipGetLastError(); return false; }
+    for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
+  }
+}
+
 static bool step_ready(agp_context *ctx, const double *invd, long long kend) {
   return ctx->tune.panel_fused && ctx->d_dpub && ctx->dpub_cap * NB >= kend && ctx->d_rowcnt && ctx->d_zpub &&
          ctx->img_ready == invd && ctx->zpub_ready_n >= kend;
@@ -1178,13 +1191,14 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
               early_inv ? ctx->ev_c : nullptr);
   if (early_inv) {
     const long long BW = ctx->bs_BW, done = n / BW - 1;
-    while (hipEventQuery(ctx->ev_c) == hipErrorNotReady) {}
-    hipStream_t si = ctx->stream2;
-    launch_set_identity_batched(si, ctx->bs_W, BW, BW * BW, BW, done);
-    forward_solve_mat_batched(si, A, BW * (lda + 1), BW, lda, invd, (BW / NB) * (long long)IMG_DOUBLES, ctx->bs_W, BW * BW, BW, BW,
-                              /*rhs_lower=*/true, done);
-    (void)hipEventRecord(ctx->ev_inv, si);
-    ctx->bs_done = done;
+    if (host_wait_event(ctx->ev_c)) {  // (otherwise bs_done stays 0: the substitution inverts behind the factorisation)
+      hipStream_t si = ctx->stream2;
+      launch_set_identity_batched(si, ctx->bs_W, BW, BW * BW, BW, done);
+      forward_solve_mat_batched(si, A, BW * (lda + 1), BW, lda, invd, (BW / NB) * (long long)IMG_DOUBLES, ctx->bs_W, BW * BW, BW, BW,
+                                /*rhs_lower=*/true, done);
+      (void)hipEventRecord(ctx->ev_inv, si);
+      ctx->bs_done = done;
+    }
   }
   while (kend < n) {
     long long next_end = kend + pick_nbo(n - kend, nbo_fixed, nbo_wide);
@@ -1269,7 +1283,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     if (throttle) panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, step);
     if (next_end < n) {
       if (throttle) {
-        while (hipEventQuery(ctx->ev_a) == hipErrorNotReady) {}
+        if (!host_wait_event(ctx->ev_a)) (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       } else {
         (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
       }
@@ -1299,13 +1313,15 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
                                tail_inv ? ctx->ev_c : nullptr);
     if (tail_inv) {
       const long long first = ctx->bs_done, last = n / bw - 1, cnt = last - first;
-      while (hipEventQuery(ctx->ev_c) == hipErrorNotReady) {}
-      hipStream_t si = ctx->stream2;
-      launch_set_identity_batched(si, ctx->bs_W + first * bw * bw, bw, bw * bw, bw, cnt);
-      forward_solve_mat_batched(si, A + first * bw * (lda + 1), bw * (lda + 1), bw, lda, invd + first * (bw / NB) * (long long)IMG_DOUBLES,
-                                (bw / NB) * (long long)IMG_DOUBLES, ctx->bs_W + first * bw * bw, bw * bw, bw, bw, /*rhs_lower=*/true, cnt);
-      (void)hipEventRecord(ctx->ev_inv, si);
-      ctx->bs_done = last;
+      if (host_wait_event(ctx->ev_c)) {
+        // (ev_inv already carries the first `first` inverses: same stream, so the new record covers both)
+        hipStream_t si = ctx->stream2;
+        launch_set_identity_batched(si, ctx->bs_W + first * bw * bw, bw, bw * bw, bw, cnt);
+        forward_solve_mat_batched(si, A + first * bw * (lda + 1), bw * (lda + 1), bw, lda, invd + first * (bw / NB) * (long long)IMG_DOUBLES,
+                                  (bw / NB) * (long long)IMG_DOUBLES, ctx->bs_W + first * bw * bw, bw * bw, bw, bw, /*rhs_lower=*/true, cnt);
+        (void)hipEventRecord(ctx->ev_inv, si);
+        ctx->bs_done = last;
+      }
     }
     K0 = kend;
     kend = next_end;

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(512) void backsub_coop_kernel(BackCoopArgs p) {
     const long long pb = blockIdx.y;
     p.A += pb * p.batch_A; p.img += pb * p.batch_img; p.z += pb * p.batch_z; p.x += pb * p.batch_x;
     if (p.flags) p.flags += pb * p.batch_flags;
-    p.done += pb * p.batch_done;
+    if (p.done) p.done += pb * p.batch_done;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long nb = (p.n + NB - 1) / NB;

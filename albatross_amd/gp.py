@@ -104,7 +104,20 @@ class Context:
         return kh
 
     def synchronize(self):
+        """waits for everything queued on any of the context's streams (device-wide)"""
         self._check(self._lib.agp_context_synchronize(self._h), "synchronize")
+
+    def to_device(self, array):
+        """a DeviceArray holding a copy of `array` (fp64 / int64 numpy) in this context's HBM: what AGP_DEVICE arguments
+        point at (agp_device_malloc + agp_memcpy; no second HIP runtime in the process)"""
+        a = np.ascontiguousarray(array)
+        d = DeviceArray(self, a.nbytes, a.dtype, a.shape)
+        self._check(self._lib.agp_memcpy(self._h, C.c_void_p(d.ptr), C.c_void_p(a.ctypes.data), a.nbytes, capi.DEVICE), "agp_memcpy")
+        return d
+
+    def device_empty(self, shape, dtype=np.float64):
+        shape = tuple(np.atleast_1d(shape).astype(np.int64).tolist())
+        return DeviceArray(self, int(np.prod(shape)) * np.dtype(dtype).itemsize, np.dtype(dtype), shape)
 
     def set_profiling(self, enabled):
         self._check(self._lib.agp_set_profiling(self._h, 1 if enabled else 0), "set_profiling")
@@ -163,6 +176,37 @@ class Context:
 
 
 _default_context = None
+
+
+class DeviceArray:
+    """`nbytes` of device memory owned by a Context (agp_device_malloc); `.ptr` is the integer device address that the
+    AGP_DEVICE arguments of the C-ABI take, `.numpy()` downloads (after the context's streams have drained)."""
+
+    def __init__(self, ctx, nbytes, dtype=np.float64, shape=None):
+        self._ctx = ctx
+        self.nbytes = int(nbytes)
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(shape) if shape is not None else (self.nbytes // self.dtype.itemsize,)
+        p = C.c_void_p()
+        ctx._check(ctx._lib.agp_device_malloc(ctx._h, max(self.nbytes, 8), C.byref(p)), "agp_device_malloc")
+        self.ptr = p.value
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self._ctx._check(self._ctx._lib.agp_memcpy(self._ctx._h, C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr), self.nbytes, capi.HOST),
+                         "agp_memcpy")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None) and getattr(self._ctx, "_h", None):
+            self._ctx._lib.agp_device_free(self._ctx._h, C.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def default_context():
@@ -378,8 +422,11 @@ class GPFit(_DeviceSolver):
             self._information = out
         return self._information
 
-    # a mixed-precision factor (agp_fit_create_mixed): its log-determinant carries the fp32 rounding of the bulk products -
-    # measured 1.3e-5 relative at N = 32768 on BASELINE config 4's covariance, outside the 1e-6 N bar of the fp64 path
+    # a mixed-precision factor (agp_fit_create_mixed): its log-determinant carries the rounding of the bulk products.
+    # MEASURED at N = 32768 (include/albatross_amd.h; tests/test_full_size_configs_gpu.py holds each figure): bf16 x 3 path
+    # 0.027 absolute on BASELINE config 4's covariance (inside the 2e-6 N log-likelihood bar), 0.14 = 4.3e-6 N on config 3's
+    # kernel (outside); fp32 fallback (AGP_MIXED_BF16=0) 1.3e-5 relative.  The bound depends on the covariance function, so
+    # reading it stays an explicit opt-in.
     mixed_precision = False
     accept_mixed_log_determinant = False
 
@@ -387,8 +434,10 @@ class GPFit(_DeviceSolver):
     def log_determinant(self):
         if self.mixed_precision and not self.accept_mixed_log_determinant:
             raise AlbatrossAmdError(capi.AGP_ERR_UNSUPPORTED,
-                                    "log_determinant of a mixed-precision factor is good to ~1e-5 relative only: use "
-                                    "model.log_likelihood (always fp64) or set fit.accept_mixed_log_determinant = True")
+                                    "log_determinant of a mixed-precision factor carries the rounding of the bulk products "
+                                    "(measured 6e-7 ... 1.1e-6 relative on the bf16 x 3 path, 1.3e-5 on the fp32 fallback; whether "
+                                    "that meets the 2e-6 N bar depends on the covariance function): use model.log_likelihood "
+                                    "(always fp64) or set fit.accept_mixed_log_determinant = True")
         v = C.c_double()
         self._ctx._check(self._ctx._lib.agp_fit_log_determinant(self._h, C.byref(v)), "log_determinant")
         return v.value

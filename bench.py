@@ -254,10 +254,12 @@ def sampled_residual(x, y, information, ell=1.0, sigma=1.0, noise=0.1, rows=64):
     return float(np.abs(r).max() / np.abs(y).max())
 
 
-def _device_features(torch, capi, x_d, n):
+def _device_features(capi, x_d, n):
+    """agp_features over coordinates resident in HBM (x_d: albatross_amd.DeviceArray - agp_device_malloc + agp_memcpy of the
+    C-ABI; this process holds ONE HIP runtime, the library's)"""
     f = capi.Features()
     f.n, f.dim, f.n_scale_columns = n, DIM, 0
-    f.coords = x_d.data_ptr()
+    f.coords = x_d.ptr
     f.eq_id = None
     f.scales = None
     f.is_measurement = 0
@@ -269,7 +271,6 @@ def fit_batch_rates(ab, ctx, sizes=None, batches=(1, 8, 32, 256)):
     """Small / medium N, where the reference's own workloads live (benchmarks/bench_predict.cc:20-40: N = 512; the tuner loop):
     fits per second of agp_fit_create_batch - B independent fits of one shape in lock step, inputs resident in HBM - with the
     aggregate fraction of the fp64 MFMA peak.  B = 1 is agp_fit_create.  Config 2's covariance (Matern-5/2 + noise)."""
-    import torch
     from albatross_amd import _capi as capi
     lib = ctx._lib
     cov = ab.Matern52(2.0, 1.0) + ab.IndependentNoise(0.1)
@@ -283,11 +284,11 @@ def fit_batch_rates(ab, ctx, sizes=None, batches=(1, 8, 32, 256)):
             ys = np.empty((n, B), order="F")
             for b in range(B):
                 x, y = make_dataset(n, 1000 + b)
-                xs_d.append(torch.from_numpy(x).cuda())
+                xs_d.append(ctx.to_device(x))
                 ys[:, b] = y
-                feats.append(_device_features(torch, capi, xs_d[-1], n))
-            y_d = torch.from_numpy(ys.T.copy()).cuda()  # (B, n) C-order = n x B column-major
-            torch.cuda.synchronize()
+                feats.append(_device_features(capi, xs_d[-1], n))
+            y_d = ctx.to_device(ys.T.copy())  # (B, n) C-order = n x B column-major
+            ctx.synchronize()
             kernels = (C.c_void_p * B)(*([kh] * B))
             fptrs = (C.c_void_p * B)(*[C.addressof(f) for f in feats])
             out = (C.c_void_p * B)()
@@ -296,7 +297,7 @@ def fit_batch_rates(ab, ctx, sizes=None, batches=(1, 8, 32, 256)):
             # (the ctypes arguments are built ONCE: at N = 512 a fit is 0.17 ms and building them per call - byref, c_void_p,
             # tensor.data_ptr() - was 10-15 us of the harness, not of the library)
             h = C.c_void_p()
-            h_ref, f0_ref, y_ptr, ctx_h = C.byref(h), C.byref(feats[0]), C.c_void_p(y_d.data_ptr()), ctx._h
+            h_ref, f0_ref, y_ptr, ctx_h = C.byref(h), C.byref(feats[0]), C.c_void_p(y_d.ptr), ctx._h
             fit_create, fit_create_batch, fit_destroy = lib.agp_fit_create, lib.agp_fit_create_batch, lib.agp_fit_destroy
 
             def step():
@@ -365,16 +366,15 @@ def other_configs(ab, ctx):
         ds = ab.RegressionDataset(x, y)
         t_fit = best(lambda: model.fit(ds), 40)  # (2 ms fits: the clock needs a few of them back to back; best of 40)
         # the same fit as the headline times it: features and targets resident in HBM, straight through the C-ABI
-        import torch
         from albatross_amd import _capi as capi
-        x_d, y_d = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-        feats = _device_features(torch, capi, x_d, n)
+        x_d, y_d = ctx.to_device(x), ctx.to_device(y)
+        feats = _device_features(capi, x_d, n)
         kh = ctx.kernel(model.covariance_function_)
-        torch.cuda.synchronize()
+        ctx.synchronize()
 
         def fit_resident():
             h = C.c_void_p()
-            st = ctx._lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+            st = ctx._lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.ptr), None, C.byref(h), None, None)
             assert st == capi.AGP_OK, st
             ctx._lib.agp_fit_destroy(h)
         t_fit_dev = best(fit_resident, 150)  # (0.3 s back to back: the clock ramps over bursts of 2 ms kernels)
@@ -382,26 +382,25 @@ def other_configs(ab, ctx):
         p = fm.predict(xs)
         # predictions as the headline's `predict` block times them: test features and outputs resident in HBM, C-ABI
         hfit = C.c_void_p()
-        st = ctx._lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(hfit), None, None)
+        st = ctx._lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.ptr), None, C.byref(hfit), None, None)
         assert st == capi.AGP_OK, st
-        xs_d = torch.from_numpy(xs).cuda()
-        fxs = _device_features(torch, capi, xs_d, m)
-        mean_d = torch.empty(m, dtype=torch.float64, device="cuda")
-        var_d = torch.empty(m, dtype=torch.float64, device="cuda")
-        cov_d = torch.empty(m * m, dtype=torch.float64, device="cuda")
-        torch.cuda.synchronize()
+        xs_d = ctx.to_device(xs)
+        fxs = _device_features(capi, xs_d, m)
+        mean_d, var_d, cov_d = ctx.device_empty(m), ctx.device_empty(m), ctx.device_empty((m, m))
+        ctx.synchronize()
         lib = ctx._lib
-        t_mean = best(lambda: lib.agp_predict_mean(ctx._h, kh, hfit, C.byref(fxs), C.c_void_p(mean_d.data_ptr()), capi.DEVICE), 20)
-        t_marg = best(lambda: lib.agp_predict_marginal(ctx._h, kh, hfit, C.byref(fxs), C.c_void_p(mean_d.data_ptr()),
-                                                       C.c_void_p(var_d.data_ptr()), capi.DEVICE), 10)
-        t_joint = best(lambda: lib.agp_predict_joint(ctx._h, kh, hfit, C.byref(fxs), C.c_void_p(mean_d.data_ptr()),
-                                                     C.c_void_p(cov_d.data_ptr()), capi.DEVICE), 5)
+        t_mean = best(lambda: lib.agp_predict_mean(ctx._h, kh, hfit, C.byref(fxs), C.c_void_p(mean_d.ptr), capi.DEVICE), 20)
+        t_marg = best(lambda: lib.agp_predict_marginal(ctx._h, kh, hfit, C.byref(fxs), C.c_void_p(mean_d.ptr),
+                                                       C.c_void_p(var_d.ptr), capi.DEVICE), 10)
+        t_joint = best(lambda: lib.agp_predict_joint(ctx._h, kh, hfit, C.byref(fxs), C.c_void_p(mean_d.ptr),
+                                                     C.c_void_p(cov_d.ptr), capi.DEVICE), 5)
         # (and the device results are the Python mirror's, which the parity tests hold against the oracle)
         pj = p.joint()
-        assert np.abs(cov_d.cpu().numpy().reshape(m, m) - pj.covariance).max() <= 1e-12 * np.abs(pj.covariance).max()
-        assert np.abs(mean_d.cpu().numpy() - pj.mean).max() <= 1e-12 * max(1., np.abs(pj.mean).max())
+        assert np.abs(cov_d.numpy() - pj.covariance).max() <= 1e-12 * np.abs(pj.covariance).max()
+        assert np.abs(mean_d.numpy() - pj.mean).max() <= 1e-12 * max(1., np.abs(pj.mean).max())
         t_joint_host = best(p.joint, 2)
         lib.agp_fit_destroy(hfit)
+        cov_d.free()
         del cov_d, pj
         fit_flop, marg_flop, joint_flop = n ** 3 / 3., float(n) * n * m, float(n) * n * m + float(n) * m * m
         out["config2"] = {
@@ -502,20 +501,19 @@ def other_configs(ab, ctx):
     # ---- config 3's problem at larger N (one GPU, features and targets resident in HBM): the sizes at which the sharded fit
     #      of `--gpus N` has work to share (its N = 65536 block), and how far the factorisation gets from the tile's fixed costs ----
     try:
-        import torch
         from albatross_amd import _capi as capi
         rows = []
         cov3 = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
         kh3 = ctx.kernel(cov3)
         for n in (32768, 65536):
             x, y = make_dataset(n, 44)
-            x_d, y_d = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-            feats = _device_features(torch, capi, x_d, n)
-            torch.cuda.synchronize()
+            x_d, y_d = ctx.to_device(x), ctx.to_device(y)
+            feats = _device_features(capi, x_d, n)
+            ctx.synchronize()
 
             def fit_large():
                 h = C.c_void_p()
-                st = ctx._lib.agp_fit_create(ctx._h, kh3, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+                st = ctx._lib.agp_fit_create(ctx._h, kh3, C.byref(feats), C.c_void_p(y_d.ptr), None, C.byref(h), None, None)
                 assert st == capi.AGP_OK, st
                 ctx._lib.agp_fit_destroy(h)
             t = best(fit_large, 2)  # (one untimed fit pays for the allocation, best of two timed ones)
@@ -638,27 +636,30 @@ def run_rank(args):
     os.environ.setdefault("AGP_COMM_TIMEOUT_S", "60")  # a dead peer / deadlocked collective becomes an error within a minute
 
     import datetime
-    import torch
-    import torch.distributed as dist
 
-    if not torch.cuda.is_available():
+    import albatross_amd as ab
+    from albatross_amd import _capi as capi
+
+    # ONE HIP runtime in this process: the library's.  Device buffers come from the C-ABI (agp_device_malloc / agp_memcpy),
+    # "torch.cuda.synchronize()" of the contract is agp_context_synchronize (hipDeviceSynchronize on the rank's device).
+    # Rounds 1-5 let torch allocate the inputs: two runtimes (torch's ROCm 7.0 + the library's 7.2) in one process cost a
+    # one-off 35-60 ms stall in some later synchronisation, which landed inside the driver's timed region in round 5.
+    if capi.load().agp_device_count() <= 0:
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # BENCH_SINGLE_DEVICE=1 (testing the N > 1 code path on a one-GPU box): every rank uses GPU 0 and the collectives of
     # the sharded fit go over gloo through the library's callback transport - RCCL refuses two ranks per device.
     single_device = os.environ.get("BENCH_SINGLE_DEVICE") == "1"
     if single_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    torch.cuda.init()  # torch's HIP runtime first, then the library's
+    torch = dist = None
     if world > 1:
         # torch.distributed is the CONTROL plane only (rendezvous, exchange of the 128-byte RCCL id, agreeing on a
-        # fallback): gloo, finite timeout.  The data path - and the barrier / max-over-ranks of the timing - run on the
-        # library's own RCCL communicator.
+        # fallback): gloo on CPU tensors, finite timeout - torch never touches the GPU here.  The data path - and the
+        # barrier / max-over-ranks of the timing - run on the library's own RCCL communicator.
+        import torch
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
-
-    import albatross_amd as ab
-    from albatross_amd import _capi as capi
     from albatross_amd.distributed import Communicator, ShardedGaussianProcessFit
 
     def all_agree(ok):
@@ -715,18 +716,18 @@ def run_rank(args):
     # ranks); replicas: one dataset per rank.
     def load(seed):
         xh, yh = make_dataset(n, seed)
-        return xh, yh, torch.from_numpy(xh).to(f"cuda:{local_rank}"), torch.from_numpy(yh).to(f"cuda:{local_rank}")
+        return xh, yh, ctx.to_device(xh), ctx.to_device(yh)
 
     sharded = want_sharded and (world == 1 or comm is not None)
     x_h, y_h, x_d, y_d = load(44 if sharded or world == 1 else 44 + rank)
-    torch.cuda.synchronize()
-    feats = make_feats(x_d.data_ptr(), n)
+    ctx.synchronize()
+    feats = make_feats(x_d.ptr, n)
     sfit = ShardedGaussianProcessFit(ctx, cov, comm) if sharded else None
 
     def replica_step(want_information=False):
         h = C.c_void_p()
         info = np.empty(n) if want_information else None
-        st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h),
+        st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.ptr), None, C.byref(h),
                                 None if info is None else C.c_void_p(info.ctypes.data), None)
         if st != capi.AGP_OK:
             raise RuntimeError(f"agp_fit_create failed: {lib.agp_status_string(st).decode()} "
@@ -735,7 +736,7 @@ def run_rank(args):
         return info
 
     def sharded_step(want_information=False):
-        res = sfit.fit(None, None, features_struct=feats, device_targets=y_d.data_ptr())
+        res = sfit.fit(None, None, features_struct=feats, device_targets=y_d.ptr)
         return res.information if want_information else None
 
     # ---- self-check (and, for N > 1, the decision whether the sharded path is usable at all) ----
@@ -761,8 +762,8 @@ def run_rank(args):
             comm._h = None  # broken or possibly mid-collective on a peer: never destroyed, the process ends with os._exit
             comm, sfit, sharded, transport = None, None, False, "none"
             x_h, y_h, x_d, y_d = load(44 + rank)
-            feats = make_feats(x_d.data_ptr(), n)
-            torch.cuda.synchronize()
+            feats = make_feats(x_d.ptr, n)
+            ctx.synchronize()
         elif world == 1 and not ok:
             raise SystemExit(f"bench.py: {why}")
     fell_back = world > 1 and want_sharded and not sharded
@@ -771,14 +772,14 @@ def run_rank(args):
 
     def barrier():
         tb0 = time.perf_counter()
-        torch.cuda.synchronize()
+        ctx.synchronize()
         tb1 = time.perf_counter()
         if comm is not None:
             comm.barrier()
         else:
             gloo_barrier()
         tb2 = time.perf_counter()
-        torch.cuda.synchronize()
+        ctx.synchronize()
         if os.environ.get("BENCH_DEBUG_STEPS"):
             sys.stderr.write(f"bench.py rank {rank}: barrier: sync {1e3 * (tb1 - tb0):.3f} ms, ranks {1e3 * (tb2 - tb1):.3f} ms, "
                              f"sync {1e3 * (time.perf_counter() - tb2):.3f} ms\n")
@@ -798,11 +799,7 @@ def run_rank(args):
             step()
         gemm_ms = gemm_flop = gemm_launches = 0.0
         gram_ms = factor_ms = solve_ms = 0.0
-        # On most boxes of the pool ONE torch.cuda.synchronize() early in the life of the process takes 40-60 ms (two HIP
-        # runtimes in one process - torch's and the library's; the GPU is idle, every step has returned) - at the closing
-        # barrier of a 10-step run that is 10 % of `value` (profiles/r05/README.md).  It happens once: let it happen here.
-        for _ in range(3):
-            barrier()
+        barrier()
         t0 = time.perf_counter()
         step_walls = []
         for _ in range(args.steps):
@@ -865,14 +862,14 @@ def run_rank(args):
         try:
             m = 4096
             xs_h, _ = make_dataset(m, 43 + 1000 * rank)
-            xs_d = torch.from_numpy(xs_h).to(f"cuda:{local_rank}")
-            out_d = torch.empty(2 * m, dtype=torch.float64, device=f"cuda:{local_rank}")
-            fx = make_feats(xs_d.data_ptr(), m)
+            xs_d = ctx.to_device(xs_h)
+            out_d = ctx.device_empty(2 * m)
+            fx = make_feats(xs_d.ptr, m)
             h = C.c_void_p()
-            st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+            st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.ptr), None, C.byref(h), None, None)
             if st != capi.AGP_OK:
                 raise RuntimeError(f"agp_fit_create failed: {lib.agp_status_string(st).decode()}")
-            mean_p, var_p = C.c_void_p(out_d.data_ptr()), C.c_void_p(out_d.data_ptr() + 8 * m)
+            mean_p, var_p = C.c_void_p(out_d.ptr), C.c_void_p(out_d.ptr + 8 * m)
 
             def timed(fn, reps):
                 fn()
@@ -911,15 +908,15 @@ def run_rank(args):
         try:
             nb = 65536
             xb, yb = make_dataset(nb, 45)
-            xb_d, yb_d = torch.from_numpy(xb).to(f"cuda:{local_rank}"), torch.from_numpy(yb).to(f"cuda:{local_rank}")
-            fb = make_feats(xb_d.data_ptr(), nb)
-            torch.cuda.synchronize()
+            xb_d, yb_d = ctx.to_device(xb), ctx.to_device(yb)
+            fb = make_feats(xb_d.ptr, nb)
+            ctx.synchronize()
             big = ShardedGaussianProcessFit(ctx, cov, comm)
-            res = big.fit(None, None, features_struct=fb, device_targets=yb_d.data_ptr())  # warm-up + self-check
+            res = big.fit(None, None, features_struct=fb, device_targets=yb_d.ptr)  # warm-up + self-check
             resid_b = sampled_residual(xb, yb, res.information)
             barrier()
             tb = time.perf_counter()
-            big.fit(None, None, features_struct=fb, device_targets=yb_d.data_ptr())
+            big.fit(None, None, features_struct=fb, device_targets=yb_d.ptr)
             barrier()
             tb = max_over_ranks(time.perf_counter() - tb)
             aux_big = {"n": nb, "ms_per_fit": 1e3 * tb, "fits_per_sec": 1.0 / tb, "scaling": "strong",
@@ -937,7 +934,7 @@ def run_rank(args):
     # correction applied) of the single-GPU run; null if absent or not applicable.
     traffic = traffic_src = None
     if world == 1 and not sharded and n == N_TRAIN:
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
                     traffic = json.load(fh)["traffic_bytes_per_launch"]
@@ -948,8 +945,8 @@ def run_rank(args):
 
     configs = None
     if rank == 0 and world == 1 and not sharded and not args.no_configs:
-        del x_d, y_d
-        torch.cuda.empty_cache()
+        x_d.free()
+        y_d.free()
         configs = other_configs(ab, ctx)
 
     if rank == 0:
@@ -966,6 +963,10 @@ def run_rank(args):
             if fell_back or fallback_note:
                 parallelism = "FALLBACK - " + parallelism + f" (the sharded single-fit path was not used: {fallback_note})"
             kernel_name = "agp::trailing_update_kernel (fp64 MFMA bulk trailing update C -= P P^T, K=512)"
+        stages = {"gram": gram_ms / args.steps, "factor": factor_ms / args.steps, "backward_solve": solve_ms / args.steps,
+                  "trailing_update_kernels": gemm_ms / args.steps}
+        if sharded:
+            stages["note"] = "sharded entry point: `factor` is host wall time of factorisation + both substitutions"
         out = {
             "metric": f"GP fits/sec (Gram+Chol+solve) at N={n} fp64",
             "value": fits / elapsed,
@@ -974,10 +975,6 @@ def run_rank(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            # the same K steps without the closing barrier (sum of the per-step wall times; every step returns after its
-            # streams have drained) and what that barrier cost: see the note at the opening barrier
-            "ms_per_step_loop_only": 1e3 * sum(step_walls) / args.steps,
-            "closing_barrier_ms": 1e3 * (elapsed - t_loop),
             "higher_is_better": True,
             "scaling": "strong" if (sharded and world > 1) else "weak",
             "vs_baseline": None,
@@ -996,22 +993,17 @@ def run_rank(args):
                 # committed rocprofv3 --pmc passes of the same command, named in traffic_source; null when there is none
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch" if traffic_src else None,
-                "traffic_source": f"constant from {traffic_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read "
-                                  "correction), not measured in this run" if traffic_src else None,
+                "traffic_source": f"constant from {traffic_src}, not measured in this run" if traffic_src else None,
                 "launches_per_fit": gemm_launches / args.steps,
                 "avg_launch_ms": gemm_ms / max(gemm_launches, 1.0),
                 "flop_per_fit": gemm_flop / args.steps,
-                # context, not the contract's `peak` and not measured in this run: the K-proportional part of this kernel's
-                # time per round of tiles (0.256 us per k and 512 tiles) - what the loop would do with no per-tile fixed
-                # cost; alone at M = 15872, K = 512 the kernel does 52
-                "context": {"k_loop_rate_tflops": 65.0, "source": "constant from profiles/r04/bulk_update_vs_k.txt, not measured in this run"},
+                # the whole fit against the same peak (n^3/3 flop over ms_per_step), and where the wall time of a step goes:
+                # GPU stage events of the library (Gram / factor / back substitution) against the wall clock of the loop
+                "whole_fit_frac": (n ** 3 / 3.) / (elapsed / args.steps) / 1e12 / MFMA_F64_PEAK_TFLOPS,
+                "fit_stages_ms": stages,
+                "wall_minus_stages_ms": 1e3 * elapsed / args.steps - (stages["gram"] + stages["factor"] + stages["backward_solve"]),
             },
-            "stages_ms_per_fit": {"gram": gram_ms / args.steps, "factor": factor_ms / args.steps,
-                                  "backward_solve": solve_ms / args.steps,
-                                  "trailing_update_kernels": gemm_ms / args.steps},
         }
-        if sharded:
-            out["stages_ms_per_fit"]["note"] = "sharded entry point: `factor` is host wall time of factorisation + both substitutions"
         if fell_back or fallback_note:
             out["sharded_fallback"] = fallback_note
         if predict is not None:
@@ -1024,6 +1016,18 @@ def run_rank(args):
             out["configs"] = configs
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
+        # LAST on the line (the driver's record keeps the final 2 kB verbatim): where a step's wall time goes.
+        # ms_per_step_loop_only = the same K steps without the closing barrier (every step returns after its streams have
+        # drained); closing_barrier_ms = what that barrier cost; max_step_ms / max_step_index = the slowest step.
+        out["stages_ms_per_fit"] = stages
+        out["timing"] = {"value": fits / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
+                         "ms_per_step_loop_only": 1e3 * sum(step_walls) / args.steps,
+                         "closing_barrier_ms": 1e3 * (elapsed - t_loop),
+                         "min_step_ms": 1e3 * min(step_walls), "max_step_ms": 1e3 * max(step_walls),
+                         "max_step_index": int(np.argmax(step_walls)),
+                         "wall_minus_stages_ms": out["roofline"]["wall_minus_stages_ms"],
+                         "roofline_frac": out["roofline"]["frac"], "avg_launch_ms": out["roofline"]["avg_launch_ms"],
+                         "hip_runtimes_in_process": 1}
         print(json.dumps(out), flush=True)
     bad_check = self_check is not None and not self_check["ok"]
     if aux_broken:  # the communicator may be mid-collective on a peer: no destructors

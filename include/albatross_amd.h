@@ -137,12 +137,27 @@ typedef struct agp_comm agp_comm; /* transport of the multi-GPU entry points, se
  * ThreadPool (src/core/model.hpp:30-36,133-135). */
 AGP_API int agp_context_create(int device_id, agp_context **out);
 AGP_API void agp_context_destroy(agp_context *ctx);
+/* waits for everything queued on ANY of the context's streams (device-wide: hipDeviceSynchronize on its device) */
 AGP_API int agp_context_synchronize(agp_context *ctx);
 /* last HIP error text for AGP_ERR_HIP, "" otherwise */
 AGP_API const char *agp_last_error(const agp_context *ctx);
 AGP_API const char *agp_status_string(int status);
 /* number of visible HIP devices (0 when no GPU / no driver) */
 AGP_API int agp_device_count(void);
+
+/* ---- device memory for AGP_DEVICE arguments ------------------------------ */
+/* Every entry point that takes a `location` accepts buffers that already live in HBM (features, targets, outputs).  A host
+ * program that links nothing but this library gets such buffers here - plain hipMalloc / hipMemcpy / hipFree on the
+ * context's device, so that a caller needs no HIP headers and no second runtime in its process (bench.py's N = 1 path and
+ * examples/bench_fit.cpp use exactly these).  The reference keeps everything in host Eigen matrices; its equivalent is the
+ * allocation inside Eigen::MatrixXd (models/gp.hpp:61-69 copies features and covariance into the fit).
+ * agp_device_malloc: *out = `bytes` of device memory (bytes > 0).  agp_device_free(NULL) is a no-op.
+ * agp_memcpy: `kind` = the agp_location of DST; the source is at the other location for AGP_HOST <-> AGP_DEVICE copies
+ * (kind AGP_DEVICE: host -> device, kind AGP_HOST: device -> host); synchronous - it returns after the copy, and a
+ * device -> host copy waits for the work queued on the context's streams first. */
+AGP_API int agp_device_malloc(agp_context *ctx, int64_t bytes, void **out);
+AGP_API int agp_device_free(agp_context *ctx, void *ptr);
+AGP_API int agp_memcpy(agp_context *ctx, void *dst, const void *src, int64_t bytes, int kind);
 
 /* ---- covariance function ------------------------------------------------- */
 /* Flattened get_params() of a composed covariance function
@@ -185,23 +200,36 @@ AGP_API int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_feat
                    double *information, double *log_det);
 /* Mixed-precision variant of agp_fit_create (BASELINE.json configs[3], SURVEY
  * section 8d config 4): the same Fit<GPFit> constructor (models/gp.hpp:61-69),
- * but the bulk trailing updates of the LL^T multiply fp32-rounded panels on the
- * fp32 MFMA path (the panel chain, the matrix and every accumulation between
- * outer steps stay fp64) and the information vector is then refined in fp64:
- * conjugate gradients on the exact fp64 covariance, preconditioned with that
- * factor, until ||y - K a||_2 <= tolerance * ||y||_2, `max_iterations` steps, or
- * the fp64 floor of the system.  *iterations / *residual (may be NULL) report
- * the steps taken and the final relative residual.  The factor kept in *out is
- * the mixed-precision one: predicted means use the refined information vector,
- * variances and log_det carry the fp32 rounding of the products: MEASURED at
- * N = 32768 on BASELINE config 4's covariance, log_det 1.3e-5 relative (0.6
- * absolute, i.e. outside the 1e-6 N bar of the fp64 path) and variances 1e-4
- * relative - use agp_nll / an fp64 fit where the likelihood or the variances
- * matter.  The reference has no reduced-precision path; this one exists for
- * problems where one fp64 factorisation is too slow (N >= 32768).  Device memory
- * next to the factor (kept in the context between mixed fits): the exact
- * covariance (8 N^2 B), an fp32 copy of the factor for the preconditioner
- * (4 N^2 B) and two fp32 panel copies (2 x 2 KB x N). */
+ * but the bulk trailing updates (and the next-block-column update) of the LL^T
+ * form their products on the BF16 matrix pipe: every panel is split ONCE into
+ * three bf16 planes (hi + mid + lo = the fp32 value), a product is the six
+ * partial products above 2^-24 (six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32
+ * block, csrc/gemm_bf16x3.hip), accumulated in fp32 inside one launch and
+ * subtracted from the fp64 matrix; the panel chain, the matrix and every
+ * accumulation between outer steps stay fp64.  (AGP_MIXED_BF16=0 selects the
+ * older fallback: fp32-rounded panels on v_mfma_f32_16x16x4_f32.)  The information
+ * vector is then refined in fp64: conjugate gradients on the exact fp64 covariance,
+ * preconditioned with that factor, until ||y - K a||_2 <= tolerance * ||y||_2,
+ * `max_iterations` steps, or the fp64 floor of the system.  *iterations /
+ * *residual (may be NULL) report the steps taken and the final relative residual.
+ * What the result is good for (each line is held by a test at N = 32768,
+ * tests/test_full_size_configs_gpu.py):
+ *   information vector, predicted means: 1e-8 relative to the fp64 fit (refined) on both paths;
+ *   predicted variances: 1e-4 relative (they come from the mixed factor);
+ *   log_det, bf16 x 3 path, MEASURED: BASELINE config 4's covariance 0.027 absolute
+ *     (5.8e-7 relative) - INSIDE the log-likelihood bar of the fp64 path (|nll error|
+ *     <= 1e-6 N, i.e. |log_det error| <= 2e-6 N); config 3's kernel (SE(1,1) +
+ *     noise(0.1)) 0.14 absolute = 4.3e-6 N (1.1e-6 relative) - OUTSIDE it.  The bound
+ *     is a property of the covariance function (how much of log|K| sits in the
+ *     rounded products), not of N alone;
+ *   log_det, fp32 fallback path: 1.3e-5 relative (0.6 absolute) on config 4 - outside.
+ * Use agp_nll / an fp64 fit where the likelihood must meet the bar for an arbitrary
+ * covariance; the host mirrors make reading log_det of a mixed fit an explicit opt-in.
+ * The reference has no reduced-precision path; this one exists for problems where one
+ * fp64 factorisation is too slow (N >= 32768).  Device memory next to the factor (kept
+ * in the context between mixed fits): the exact covariance (8 N^2 B), an fp32 copy of
+ * the factor for the preconditioner (4 N^2 B) and two panel copies (2 x 3 KB x N for
+ * the bf16 planes). */
 AGP_API int agp_fit_create_mixed(agp_context *ctx, const agp_kernel *k, const agp_features *x,
                          const double *y, const double *y_var, int max_iterations,
                          double tolerance, agp_fit **out, double *information,

@@ -7,8 +7,6 @@ import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
-torch.cuda.init()
 import albatross_amd as ab
 from albatross_amd import _capi as capi
 from bench import make_dataset, _device_features
@@ -20,16 +18,16 @@ kh = ctx.kernel(cov)
 reps = int(os.environ.get("STRESS_REPS", "3000"))
 for n in (129, 512, 1000, 1280, 1920, 2047, 2048, 4096):
     x, y = make_dataset(n, 7)
-    x_d, y_d = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-    feats = _device_features(torch, capi, x_d, n)
-    torch.cuda.synchronize()
+    x_d, y_d = ctx.to_device(x), ctx.to_device(y)
+    feats = _device_features(capi, x_d, n)
+    ctx.synchronize()
     ref = None
     info = np.empty(n)
     t0 = time.perf_counter()
     r = max(50, reps * 512 // max(n, 512))
     for i in range(r):
         h = C.c_void_p()
-        st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.data_ptr()), None, C.byref(h), None, None)
+        st = lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.ptr), None, C.byref(h), None, None)
         assert st == 0, (n, i, st, ctx.last_error() if hasattr(ctx, "last_error") else "")
         if i % 50 == 0:
             assert lib.agp_fit_download_information(ctx._h, h, info.ctypes.data_as(C.c_void_p)) == 0
@@ -44,10 +42,10 @@ for n, B in ((512, 256), (1024, 64), (520, 32)):
     ys = np.empty((n, B), order="F")
     for b in range(B):
         x, y = make_dataset(n, 100 + b)
-        xs_d.append(torch.from_numpy(x).cuda())
+        xs_d.append(ctx.to_device(x))
         ys[:, b] = y
-        feats.append(_device_features(torch, capi, xs_d[-1], n))
-    y_d = torch.from_numpy(ys.T.copy()).cuda()
+        feats.append(_device_features(capi, xs_d[-1], n))
+    y_d = ctx.to_device(ys.T.copy())
     kernels = (C.c_void_p * B)(*([kh] * B))
     fptrs = (C.c_void_p * B)(*[C.addressof(f) for f in feats])
     out = (C.c_void_p * B)()
@@ -55,7 +53,7 @@ for n, B in ((512, 256), (1024, 64), (520, 32)):
     info = np.empty((n, B), order="F")
     ref = None
     for i in range(max(20, reps // 30)):
-        st = lib.agp_fit_create_batch(ctx._h, B, kernels, fptrs, C.c_void_p(y_d.data_ptr()), n, None, 0, out, info.ctypes.data_as(C.c_void_p), n, None, status)
+        st = lib.agp_fit_create_batch(ctx._h, B, kernels, fptrs, C.c_void_p(y_d.ptr), n, None, 0, out, info.ctypes.data_as(C.c_void_p), n, None, status)
         assert st == 0 and all(s == 0 for s in status), (n, B, i, st)
         if ref is None:
             ref = info.copy()

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import albatross_amd as ab
-from conftest import synthetic_stations, temperature_covariance
+from conftest import synthetic_3d, synthetic_stations, temperature_covariance
 from oracle import oracle_py as orc
 
 pytestmark = pytest.mark.gpu
@@ -62,9 +62,12 @@ def test_config4_n32768_mixed(ctx):
     # this system (cond ~ 2e6, n = 32768): a few 1e-13 above
     assert res <= 2e-12 and 1 <= its <= 50, (its, res)
     assert rel(amx, a64) <= 1e-8                                   # the stated bar for the information vector
-    # log|K| keeps the fp32 rounding of the bulk products: 1.4e-5 relative measured on this kernel at this size
-    fmx.get_fit().accept_mixed_log_determinant = True  # (opt-in: measured 1.3e-5 relative here)
-    assert abs(fmx.get_fit().log_determinant - ld64) <= 5e-5 * abs(ld64)
+    # log|K| of the mixed factor: the bulk products are bf16 x 3 (fp32-accurate products, fp32 accumulation inside a launch,
+    # fp64 between launches) - MEASURED 0.027 absolute = 5.8e-7 relative on this kernel at this size (profiles/r05/time_mixed.txt),
+    # inside the log-likelihood bar of BASELINE.md (|nll error| <= 1e-6 N, i.e. |log_det error| <= 2e-6 N = 0.066).  The fp32-MFMA
+    # fallback (AGP_MIXED_BF16=0) is held to its own measured 1.3e-5 relative by the next test.
+    fmx.get_fit().accept_mixed_log_determinant = True  # (opt-in: the bound is per covariance function, include/albatross_amd.h)
+    assert abs(fmx.get_fit().log_determinant - ld64) <= 2e-6 * n, abs(fmx.get_fit().log_determinant - ld64)
 
     # (3) size-independent property: both information vectors solve K a = y, with K rebuilt independently of the
     # fit in row blocks (measurement-wrapped features, as_measurements, gp.hpp:288-290)
@@ -87,6 +90,47 @@ def test_config4_n32768_mixed(ctx):
     assert rel(pmx.mean, p64.mean) <= 1e-8
     assert np.abs(pmx.covariance - p64.covariance).max() <= 1e-4 * np.abs(p64.covariance).max()
     assert np.all(p64.covariance > 0.)
+
+
+def test_config4_n32768_mixed_log_determinant_bounds(make_ctx, monkeypatch):
+    """What the mixed factor's log|K| is good for, pinned per path and per covariance function at N = 32768 (round 5 measured
+    it, no test held it): bf16 x 3 products on config 3's kernel (SE(1,1) + noise(0.1)): 0.14 absolute = 4.3e-6 N - OUTSIDE the
+    2e-6 N bar, asserted at 8e-6 N; the fp32-MFMA fallback (AGP_MIXED_BF16=0) on config 4's covariance: 1.3e-5 relative,
+    asserted at 5e-5.  The information vector meets 1e-8 on both (the refinement is fp64)."""
+    n = 32768
+    # --- config 3's kernel, default (bf16 x 3) path
+    ctx = make_ctx()
+    x, y = synthetic_3d(n, 44)
+    cov3 = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+    ds = ab.RegressionDataset(x, y)
+    f64 = ab.gp_from_covariance(cov3, context=ctx).fit(ds)
+    ld64, a64 = f64.get_fit().log_determinant, np.array(f64.get_fit().information)
+    del f64
+    mm = ab.gp_from_covariance(cov3, context=ctx)
+    mm.precision = "mixed"
+    fit = mm.fit(ds).get_fit()
+    fit.accept_mixed_log_determinant = True
+    assert abs(fit.log_determinant - ld64) <= 8e-6 * n, abs(fit.log_determinant - ld64)
+    assert rel(fit.information, a64) <= 1e-8
+    del fit
+    ctx.close()
+    # --- config 4's covariance on the fp32-MFMA fallback path
+    monkeypatch.setenv("AGP_MIXED_BF16", "0")
+    ctx = make_ctx()
+    ecef, h, temp = synthetic_stations(n, 11)
+    cov, scale = temperature_covariance(ab)
+    ds = ab.RegressionDataset(ab.FeatureSet(ecef, [scale(h)]), temp - temp.mean())
+    f64 = ab.gp_from_covariance(cov, context=ctx).fit(ds)
+    ld64, a64 = f64.get_fit().log_determinant, np.array(f64.get_fit().information)
+    del f64
+    mm = ab.gp_from_covariance(cov, context=ctx)
+    mm.precision = "mixed"
+    fit = mm.fit(ds).get_fit()
+    fit.accept_mixed_log_determinant = True
+    err = abs(fit.log_determinant - ld64)
+    assert err <= 5e-5 * abs(ld64), err / abs(ld64)
+    assert err > 2e-6 * n, "the fp32 fallback is expected OUTSIDE the bar: if it is inside now, tighten include/albatross_amd.h"
+    assert rel(fit.information, a64) <= 1e-8
 
 
 def _pitc_problem(n, m, seed):

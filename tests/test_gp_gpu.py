@@ -233,6 +233,22 @@ def test_config3_n16384_properties(ctx):
     B = np.random.default_rng(2).standard_normal((n, 2))
     X = fm.get_fit().solve(B)
     assert np.abs(K @ X - B).max() <= 1e-8 * np.abs(B).max() * 10
+    # The leading 2048 x 2048 block of L is the LL^T factor of the leading principal sub-matrix - the first four outer blocks
+    # of the N = 16384 schedule (two-stream look-ahead, bulk launches that carry the next block column, left-looking inner
+    # panels), pinned to the ORACLE on the sub-problem of the first 2048 points: log-determinant and solves through the
+    # oracle's own un-pivoted LL^T (threads = 8, as config 2), and - an LL^T factor with a positive diagonal is unique -
+    # element by element against LAPACK's factor of the oracle's Gram matrix.
+    import scipy.linalg as sla
+    m = 2048
+    L11 = np.ascontiguousarray(L[:m, :m])
+    assert np.all(np.triu(L11, 1) == 0.) and np.all(np.diag(L11) > 0.)
+    ofit = orc.OracleFit(cov, x[:m], y[:m], threads=8, use_llt=True)
+    assert abs(2. * np.log(np.diag(L11)).sum() - ofit.log_determinant) <= 1e-6 * m
+    Bs = np.random.default_rng(3).standard_normal((m, 2))
+    assert rel(sla.cho_solve((L11, True), Bs), ofit.solve(Bs)) <= 1e-8
+    assert rel(sla.cho_solve((L11, True), y[:m]), ofit.information) <= 1e-8
+    Ko = orc.gram(cov, x[:m], x_meas=True)
+    assert np.abs(L11 - np.linalg.cholesky(Ko)).max() <= 1e-9
 
 
 @pytest.mark.parametrize("n", [1, 50, 128, 300, 1000, 1700])
