@@ -219,7 +219,8 @@ AGP_API int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_feat
  *   log_det, bf16 x 3 path, MEASURED: BASELINE config 4's covariance 0.027 absolute
  *     (5.8e-7 relative) - INSIDE the log-likelihood bar of the fp64 path (|nll error|
  *     <= 1e-6 N, i.e. |log_det error| <= 2e-6 N); config 3's kernel (SE(1,1) +
- *     noise(0.1)) 0.14 absolute = 4.3e-6 N (1.1e-6 relative) - OUTSIDE it.  The bound
+ *     noise(0.1)) 0.14 absolute = 4.3e-6 N (1.1e-6 relative) and Matern-5/2(2,1) +
+ *     noise(0.1) at N = 5300 0.026 = 4.9e-6 N - OUTSIDE it.  The bound
  *     is a property of the covariance function (how much of log|K| sits in the
  *     rounded products), not of N alone;
  *   log_det, fp32 fallback path: 1.3e-5 relative (0.6 absolute) on config 4 - outside.
