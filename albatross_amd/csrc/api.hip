@@ -202,6 +202,7 @@ static agp_context::Tuning read_tuning() {
   t.shard_force_comm = flag("AGP_SHARD_FORCE_COMM", false);
   t.shard_host_pacing = flag("AGP_SHARD_HOST_PACING", false);
   if (const char *e = getenv("AGP_SHARD_MASK_GFLOP")) t.shard_mask_gflop = atof(e);
+  t.merge_above = number("AGP_MERGE_ABOVE", 8704);
   return t;
 }
 
@@ -249,6 +250,7 @@ int agp_context_create(int device_id, agp_context **out) {
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   AGP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
   // flags and scalars of a factorisation: ONE block on either side ([4 ints | 4 doubles]) so that one 48-byte copy brings both back
+  AGP_HIP_CHECK(ctx, hipMalloc(&ctx->d_headcnt, sizeof(unsigned long long) * agp_context::HEADCNT_WORDS));
   AGP_HIP_CHECK(ctx, hipMalloc(&ctx->d_flags, 4 * sizeof(int) + 4 * sizeof(double)));
   ctx->d_scalars = reinterpret_cast<double *>(ctx->d_flags + 4);
   AGP_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_flags, 4 * sizeof(int) + 4 * sizeof(double)));
@@ -287,6 +289,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->d_zpub) (void)hipFree(ctx->d_zpub);
   if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
   if (ctx->shard_flags) (void)hipFree(ctx->shard_flags);
+  if (ctx->d_headcnt) (void)hipFree(ctx->d_headcnt);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);  // (d_scalars / h_scalars are the tails of these blocks)
   if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
   if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
@@ -582,7 +585,7 @@ static int build_and_factor(agp_context *c, const DevProgram *dprog, const DevPr
     PrepArgs local;
     PrepArgs *prep = pre ? pre : &local;
     prep->fill(ctx->d_flags, 0ull, (long long)(STATUS_BYTES / 8));
-    if (prep->n + 4 <= PREP_MAX) ctx->prep_external = panel_fused_plan(ctx, invd, 0, n, true, prep);
+    if (prep->n + 5 <= PREP_MAX) ctx->prep_external = panel_fused_plan(ctx, invd, 0, n, true, prep);
     launch_prep(s, *prep);
   }
   const bool prof = ctx->profiling;
@@ -1170,11 +1173,12 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
 static int fit_create_retrying(agp_context *c, const agp_kernel *k, const agp_features *x, const double *y, const double *y_var,
                                agp_fit **out, double *information, double *log_det, MixedRequest *mixed) {
   int st = fit_create_impl(c, k, x, y, y_var, out, information, log_det, mixed);
-  if (st == AGP_ERR_HIP && c && c->h_flags && c->h_flags[2] && (c->tune.step_below > 0 || c->tune.panel_fused)) {
+  if (st == AGP_ERR_HIP && c && c->h_flags && c->h_flags[2] && (c->tune.step_below > 0 || c->tune.panel_fused || c->tune.merge_above > 0)) {
     if (out && *out) { agp_fit_destroy(*out); *out = nullptr; }
     c->tune.step_below = 0;
     c->tune.panel_fused = false;
     c->tune.backsub_coop = false;  // (the one-launch substitution hands over inside a launch too)
+    c->tune.merge_above = 0;       // (... and the gate of a merged bulk update waits for another stream's launch)
     st = fit_create_impl(c, k, x, y, y_var, out, information, log_det, mixed);
   }
   return st;

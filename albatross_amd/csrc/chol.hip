@@ -967,6 +967,12 @@ bool panel_fused_plan(agp_context *ctx, double *invd, long long k_begin, long lo
   }
   prep->sentinel(invd + b0 * (long long)IMG_DOUBLES, cnt_img);
   prep->sentinel(ctx->d_zpub + k_begin, cnt_z);
+  // (the counters of the merged bulk updates: factor_lower of a whole matrix large enough to have any)
+  ctx->headcnt_ready = false;
+  if (want_step && k_begin == 0 && ctx->d_headcnt && ctx->tune.merge_above > 0 && k_end > ctx->tune.merge_above && !prep->full()) {
+    prep->fill(ctx->d_headcnt, 0ull, agp_context::HEADCNT_WORDS);
+    ctx->headcnt_ready = true;
+  }
   ctx->zpub_ready_n = k_end;
   ctx->img_ready = invd;
   return true;
@@ -1086,6 +1092,26 @@ static void panel_phase(agp_context *ctx, hipStream_t s, double *A, long long n,
   }
 }
 
+// The gate of a merged bulk update (factor_lower): ONE wave on the chain stream waits until the tiles of the next block
+// column - the first workgroups of the bulk launch that runs on the other stream - have all counted themselves.  The
+// kernels behind it on the stream (the next panel phase) then start while the rest of the bulk launch is still running;
+// their start is the ACQUIRE that pairs with the tiles' RELEASE.  The wave holds no LDS and four registers; it gives up
+// after 2 s like every hand-over of this library (flags[2] -> AGP_ERR_HIP, and the fit is repeated without merged launches).
+__global__ __launch_bounds__(64) void head_gate_kernel(const unsigned long long *done, unsigned long long expect, int *flags) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int spin = 1; __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect; ++spin) {
+      if ((spin & 63) == 0 && poll_expired(t0, flags)) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+}
+
+void launch_head_gate(hipStream_t s, const unsigned long long *done, unsigned long long expect, int *flags) {
+  hipLaunchKernelGGL(head_gate_kernel, dim3(1), dim3(64), 0, s, done, expect, flags);
+}
+
 // Host-side wait for an event WITHOUT parking a stream at a hipStreamWaitEvent (section 8: a stream that sits at an
 // unsatisfied wait slows the launches of the others).  Polls with a pause instruction between queries (the core is
 // shared with the launch threads of the other ranks of a box); true only if the event completed - any error ends the
@@ -1168,7 +1194,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   hipStream_t sa = ctx->stream, sb = ctx->stream2;
   hipStream_t sb_prev = sb;
   bool have_u2 = false, p32_flip = false;
-  long long K0 = 0;
+  long long K0 = 0, step_index = 0;
   const long long nbo_fixed = ctx->nbo_override;
   const int variant = ctx->update_variant;
   const long long nbo_wide = (variant == 4) ? ctx->nbo_wide : ctx->tune.fp64_nbo;  // (fp64: AGP_FP64_NBO, measurement switch)
@@ -1250,6 +1276,40 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
       P16 = dst;
     }
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
+    // Bulk-bound phase, fp64: U1(j) and U2(j) are ONE launch on the bulk stream - the whole trailing matrix, the tiles of
+    // the next block column FIRST (at the bulk kernel's efficiency: as a launch of its own on the chain stream U1 ran
+    // 64 x 64 tiles at MfmaUtil 0.38 next to the bulk update, waited for U2(j - 1) through an event, and sat on the
+    // critical path of P(j + 1)) and counted; the chain stream carries a one-wave gate kernel in U1's place, which lets
+    // P(j + 1) start when the count is complete, ~one tile time into the launch.  The chain stream never waits for ev_b here:
+    // the launch is stream-ordered behind U2(j - 1), and its head is what P(j + 1) needs.
+    const bool merged = variant <= 0 && nbo_fixed == 0 && !step && next_end < n && ctx->headcnt_ready && ctx->tune.merge_above > 0 &&
+                        (n - kend) > ctx->tune.merge_above && step_index < agp_context::HEADCNT_WORDS && (next_end - kend) % NB == 0;
+    if (merged) {
+      sb = (ctx->stream_masked && (n - kend) <= MASK_BELOW) ? ctx->stream_masked : ctx->stream2;
+      if (sb != sb_prev && have_u2) (void)hipStreamWaitEvent(sb, ctx->ev_b, 0);
+      sb_prev = sb;
+      (void)hipStreamWaitEvent(sb, ctx->ev_a, 0);
+      BulkTiming bt;
+      const bool timed = timers && timers->ev && timers->used + 2 <= timers->n_ev;
+      if (timed) { bt.e0 = timers->ev[timers->used]; bt.e1 = timers->ev[timers->used + 1]; }
+      long long head_tiles = 0;
+      unsigned long long *cnt = ctx->d_headcnt + step_index;
+      launch_trailing_update_merged(sb, A + kend * lda + kend, lda, P, lda, n - kend, K, (int)((next_end - kend) / NB), cnt, &head_tiles,
+                                    timed ? &bt : nullptr);
+      if (timed && bt.flops > 0.) {
+        timers->flops[timers->used / 2] = bt.flops;
+        timers->used += 2;
+      }
+      (void)hipEventRecord(ctx->ev_b, sb);
+      have_u2 = true;
+      launch_head_gate(sa, cnt, (unsigned long long)head_tiles, ctx->d_flags);
+      panel_phase(ctx, sa, A, n, lda, invd, y, kend, next_end, timers, false);
+      K0 = kend;
+      kend = next_end;
+      ++step_index;
+      continue;
+    }
+    ++step_index;
     // U2(j - 1) must be done before anything of step j touches the next block column
     if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
     // U1: block column [kend, next_end), all rows below its diagonal
@@ -1328,6 +1388,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   }
   // the panel stream ran last (its final panel depends on every update)
   ctx->img_ready = nullptr;
+  ctx->headcnt_ready = false;
 }
 
 // `count` independent n x n factorisations in lock step (blockIdx.y = problem): the blocks of a sparse GP's A, the

@@ -139,8 +139,14 @@ struct agp_context {
     bool shard_force_comm = false; // AGP_SHARD_FORCE_COMM=1: ONE rank runs the multi-rank schedule through its transport
     bool shard_host_pacing = false;  // AGP_SHARD_HOST_PACING=1: the sharded schedule is paced by the host (round-3 scheme)
     double shard_mask_gflop = 40.;   // AGP_SHARD_MASK_GFLOP: bulk update per step below which a sharded fit is chain-bound
+    long long merge_above = 8704;  // AGP_MERGE_ABOVE: trailing rows above which the next-block-column update rides in the bulk launch (0: never)
   } tune;
   unsigned long long *d_rowcnt = nullptr;  // one counter per 64 rows (tail of the d_dpub allocation): hand-over of the step launches' row updates
+  // merged bulk updates (chol.hip: factor_lower): one counter per outer step - the tiles of the next block column count
+  // themselves, the chain stream's gate kernel waits for all of them; zeroed by panel_fused_plan (headcnt_ready)
+  static constexpr long long HEADCNT_WORDS = 256;
+  unsigned long long *d_headcnt = nullptr;
+  bool headcnt_ready = false;
   // Early inversion of the wide diagonal blocks for the backward substitution of a fit (api.hip: backward_solve_vec_any):
   // set by the caller of factor_lower (bs_W = where the inverses go, bs_BW = their width); factor_lower inverts the
   // blocks that are final when it enters its single-stream tail on the (then idle) second stream, records ev_inv and
@@ -333,6 +339,10 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
                                long long ld32 = 0);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
+void launch_head_gate(hipStream_t s, const unsigned long long *done, unsigned long long expect, int *flags);  // chol.hip
+// the whole trailing matrix of an outer step in ONE launch, the next block column's tiles first and counted (gemm.hip)
+void launch_trailing_update_merged(hipStream_t s, double *C, long long ldc, const double *P, long long ldp, long long M, long long K,
+                                   int head_cols, unsigned long long *head_done, long long *head_tiles, BulkTiming *timing = nullptr);
 void launch_update_f32(hipStream_t s, double *C, long long ldc, const double *P, const double *Q, long long ldp, long long M,
                        long long N, long long K, const float *P32 = nullptr, const float *Q32 = nullptr, long long ld32 = 0);
 // The bf16 x 3 path of the mixed-precision factorisation (gemm_bf16x3.hip): the panel of one outer step as three bf16

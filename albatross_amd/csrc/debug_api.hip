@@ -637,6 +637,22 @@ AGP_DEBUG_API int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t
     launch_update_bf16x3(ctx->stream, dC, ldc, planes, M, 0, 0, M, M, K, order, olen);
     AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(planes);
+  } else if (variant >= 20 && variant < 30) {
+    // the MERGED update of factor_lower with head_cols = variant - 20: the launch on the bulk stream, the gate kernel on
+    // the chain stream (it must end - the head counted itself completely - although the launch it waits for is on another
+    // stream), and the count it left must be exactly the number of head tiles
+    unsigned long long *cnt = ctx->d_headcnt + 7, seen = ~0ull;
+    AGP_HIP_CHECK(ctx, hipMemset(cnt, 0, sizeof(unsigned long long)));
+    AGP_HIP_CHECK(ctx, hipMemset(ctx->d_flags, 0, 4 * sizeof(int)));
+    long long head_tiles = 0;
+    launch_trailing_update_merged(ctx->stream2, dC, ldc, dP, ldp, M, K, variant - 20, cnt, &head_tiles);
+    launch_head_gate(ctx->stream, cnt, (unsigned long long)head_tiles, ctx->d_flags);
+    AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
+    int flags[4] = {0, 0, 0, 0};
+    AGP_HIP_CHECK(ctx, hipMemcpy(&seen, cnt, sizeof(seen), hipMemcpyDeviceToHost));
+    AGP_HIP_CHECK(ctx, hipMemcpy(flags, ctx->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+    if (seen != (unsigned long long)head_tiles || flags[2] != 0 || head_tiles <= 0) st = AGP_ERR_HIP;
   } else {
     launch_trailing_update_as(variant, ctx->stream, dC, ldc, dP, dP, ldp, M, K);
   }

@@ -89,33 +89,57 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ext_kernel(GemmArgs g
 // The tiles that would form a partial LAST round of 128 x 128 workgroups go FIRST, as four 64 x 64 workgroups each
 // (small_first / small_count): the launch ends with full rounds, and no second launch (round 3: trailing_update_tail_kernel
 // behind this one - 50-100 us per update during which a fraction of the chip worked) is needed for them.
+// Merged update (GemmArgs::head_cols): the tiles of the next block column come before everything else and are counted.
 __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmArgs g) {
   __shared__ double lds[2 * 2 * GK * GLD];
-  const bool small = (long long)blockIdx.x < 4LL * g.small_count;
-  long long id = small ? (long long)(blockIdx.x >> 2) + g.small_first : (long long)blockIdx.x - 4LL * g.small_count + g.tile_first;
+  long long wg = blockIdx.x;
+  const bool head = wg < g.head_count;
   int bi, bj = 0;
-  if (!small && g.order) {
-    const int packed = g.order[id];
-    if (packed < 0) return;
-    bi = packed >> 16;
-    bj = packed & 0xffff;
-  } else {
-    while (true) {
-      const int cnt = g.ntr - bj;
-      if (id < cnt) break;
-      id -= cnt;
+  if (head) {
+    const int nth = g.ntr + g.head_cols;  // tile rows of the whole trailing matrix
+    long long id = wg;
+    while (id >= nth - bj) {
+      id -= nth - bj;
       ++bj;
     }
     bi = bj + (int)id;
-  }
-  if (small) {
-    const int q = blockIdx.x & 3, qi = q & 1, qj = q >> 1;
-    if (bi == bj && qj > qi) return;  // upper quadrant of a diagonal tile
-    gemm64_body(g, (long long)bi * GT + qi * ST, (long long)bj * GT + qj * ST, lds);
-    return;
+  } else {
+    wg -= g.head_count;
+    const bool small = wg < 4LL * g.small_count;
+    long long id = small ? (wg >> 2) + g.small_first : wg - 4LL * g.small_count + g.tile_first;
+    if (!small && g.order) {
+      const int packed = g.order[id];
+      if (packed < 0) return;
+      bi = packed >> 16;
+      bj = packed & 0xffff;
+    } else {
+      while (true) {
+        const int cnt = g.ntr - bj;
+        if (id < cnt) break;
+        id -= cnt;
+        ++bj;
+      }
+      bi = bj + (int)id;
+    }
+    // (the sub-triangle right of the head, in the frame of the whole trailing matrix)
+    bi += g.head_cols;
+    bj += g.head_cols;
+    if (small) {
+      const int q = (int)(wg & 3), qi = q & 1, qj = q >> 1;
+      if (bi == bj && qj > qi) return;  // upper quadrant of a diagonal tile
+      gemm64_body(g, (long long)bi * GT + qi * ST, (long long)bj * GT + qj * ST, lds);
+      return;
+    }
   }
   if (tile_takes_cpf(g, bi, bj)) gemm_nt_sub_tile_cpf<false, false>(g, bi, bj, lds);
   else gemm_nt_sub_tile<false, false>(g, bi, bj, lds);
+  if (head) {
+    // every store of the tile acknowledged, then one count: the RELEASE writes this XCD's L2 back, and the kernels that
+    // read the tile start behind the gate kernel that saw the count (their start is the matching ACQUIRE)
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(g.head_done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -429,6 +453,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void trailing_update_tail_kernel(G
   gemm64_body(g, (long long)bi * GT + qi * ST, (long long)bj * GT + qj * ST, lds);
 }
 
+static void launch_trailing_update_planned(int variant, hipStream_t s, GemmArgs &g, BulkTiming *timing);
 static long long count_tiles(int ntr, int ntc, int tri) {
   long long total = 0;
   for (int bj = 0; bj < ntc; ++bj) total += tri ? (ntr - bj > 0 ? ntr - bj : 0) : ntr;
@@ -637,6 +662,32 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
   g.M = M; g.N = M; g.K = K; g.tri = 1;
   g.ntr = (int)((M + GT - 1) / GT);
   g.ntc = g.ntr;
+  launch_trailing_update_planned(variant, s, g, timing);
+}
+
+// fp64 only: C (M x M lower, the WHOLE trailing matrix of an outer step) -= P P^T in one launch whose first workgroups are
+// the 128 x 128 tiles of the first head_cols tile columns (GemmArgs::head_cols); *head_tiles = how many *head_done will count
+void launch_trailing_update_merged(hipStream_t s, double *C, long long ldc, const double *P, long long ldp, long long M, long long K,
+                                   int head_cols, unsigned long long *head_done, long long *head_tiles, BulkTiming *timing) {
+  if (timing) timing->flops = 0.;
+  *head_tiles = 0;
+  if (M <= 0 || K <= 0) return;
+  GemmArgs g;
+  g.C = C; g.ldc = ldc; g.A = P; g.lda = ldp; g.B = P; g.ldb = ldp;
+  g.M = M; g.N = M; g.K = K; g.tri = 1;
+  const int nth = (int)((M + GT - 1) / GT);
+  if (head_cols > nth) head_cols = nth;
+  g.head_cols = head_cols;
+  g.head_done = head_done;
+  for (int c = 0; c < head_cols; ++c) g.head_count += nth - c;
+  g.ntr = nth - head_cols;  // the sub-triangle right of the head
+  g.ntc = g.ntr;
+  *head_tiles = g.head_count;
+  launch_trailing_update_planned(0, s, g, timing);
+}
+
+static void launch_trailing_update_planned(int variant, hipStream_t s, GemmArgs &g, BulkTiming *timing) {
+  const long long M = g.M, K = g.K;
   const long long tiles = count_tiles(g.ntr, g.ntc, 1);
   if (variant == 3) {
     long long wgs = tiles;
@@ -659,6 +710,30 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
     slots = 2 * cus;
   }
   long long full, rem;
+  if (g.head_cols > 0) {
+    // merged update: the head's tiles are the first round(s); behind them whole rounds of large tiles, the remainder as
+    // 64 x 64 quadrants right after the head (the launch still ends with full rounds)
+    if (tiles < 2LL * slots) { full = 0; rem = tiles; }
+    else {
+      full = (tiles / slots) * slots;
+      rem = tiles - full;
+      if (rem * 4 >= 3LL * slots) { full = tiles; rem = 0; }
+    }
+    if (timing && timing->e0) (void)hipEventRecord(timing->e0, s);
+    g.small_first = full;
+    g.small_count = (int)rem;
+    long long big = full;
+    if (full > 0) {
+      const XcdOrder o = xcd_order(g.ntr, full);
+      if (o.dev) { g.order = o.dev; big = o.len; }
+    }
+    hipLaunchKernelGGL(trailing_update_kernel, dim3((unsigned)(g.head_count + big + 4 * rem)), dim3(GEMM_THREADS), 0, s, g);
+    if (timing && timing->e1) {
+      (void)hipEventRecord(timing->e1, s);
+      timing->flops = 2. * (double)K * lower_entries(M, g.ntr + g.head_cols, (long long)(g.ntr + g.head_cols) * (g.ntr + g.head_cols + 1) / 2);
+    }
+    return;
+  }
   if (tiles < 2LL * slots) {
     // fewer than two rounds of large tiles: 64 x 64 workgroups throughout balance the CUs better (M = 4096, K = 512:
     // 0.196 ms instead of 0.272; with the store-only epilogue of the large tiles two rounds are enough: M = 6144 448 -> 424 us,

@@ -47,6 +47,15 @@ struct GemmArgs {
   // panel by launch_convert_panel_f32) - nullptr: the kernel rounds the fp64 operands itself while it stages them
   const float *A32 = nullptr, *B32 = nullptr;
   long long ld32 = 0;
+  // trailing_update_kernel only, the MERGED update of factor_lower (chol.hip): C is the whole trailing matrix of an outer
+  // step and its first head_cols tile columns - the NEXT block column, which the panel chain needs first - are the first
+  // head_count workgroups of the launch (column by column, top to bottom, 128 x 128 tiles); each counts itself in *head_done
+  // (RELEASE, device scope) when its tile is in memory, and the chain stream's gate kernel lets the next panel phase start
+  // at head_count - while the rest of the launch (tiles with bj >= head_cols; ntr / small_* / order describe THAT
+  // sub-triangle, in its own frame) is still running.  head_cols == 0: off.
+  int head_cols = 0;
+  long long head_count = 0;
+  unsigned long long *head_done = nullptr;
 };
 
 

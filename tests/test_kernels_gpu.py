@@ -127,6 +127,28 @@ def test_trailing_update_large_tiles(ctx, dbg, M, K, variant):
         assert np.array_equal(ref[:M][low], got[:M][low])
 
 
+@pytest.mark.parametrize("head_cols", [1, 4, 8])
+@pytest.mark.parametrize("M,K", [(9216, 512), (6016, 512), (5900, 128), (1418, 512), (700, 96), (384, 512)])
+def test_trailing_update_merged(ctx, dbg, M, K, head_cols):
+    """The merged update of factor_lower (round 6; csrc/gemm.hip: GemmArgs::head_cols): the whole trailing matrix in one
+    launch on the bulk stream whose first workgroups are the 128 x 128 tiles of the next block column (head_cols tile columns),
+    each counting itself when its tile is in memory; the gate kernel on the chain stream ends at the full count.  Same
+    tile bodies as the plain bulk launch: within 1e-14 of the scale everywhere; the debug entry point also checks the
+    count and that no hand-over timed out.  Sizes: full rounds + remainder quadrants behind the head (9216, 6016), ragged
+    last tile row (5900, 1418, 700), a head wider than the matrix (384: 3 tile columns)."""
+    rng = np.random.default_rng(M + K + head_cols)
+    ldc, ldp = M + 8, M + 10
+    Cm = np.asfortranarray(rng.standard_normal((ldc, M)))
+    P = np.asfortranarray(rng.standard_normal((ldp, K)))
+    want = Cm[:M] - P[:M] @ P[:M].T
+    got = Cm.copy(order="F")
+    assert dbg.agp_debug_trailing_update(ctx._h, _p(got), ldc, _p(P), ldp, M, K, 20 + head_cols) == 0
+    low = np.tril_indices(M)
+    scale = np.abs(P[:M]).sum(axis=1).max() ** 2
+    assert np.abs(got[:M][low] - want[low]).max() <= 1e-14 * scale
+    assert np.array_equal(got[M:], Cm[M:])  # padding rows untouched
+
+
 @pytest.mark.parametrize("variant", [0, 2, 4, 5])
 @pytest.mark.parametrize("M,K", [(256, 16), (640, 128), (1000, 256), (1418, 512), (130, 32), (4300, 64)])
 def test_trailing_update_variants(ctx, dbg, M, K, variant):
