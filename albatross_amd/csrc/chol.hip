@@ -283,6 +283,31 @@ __device__ __forceinline__ void micro_syrk_tile2(double *T, int ib0, int kb0, in
 
 constexpr int POTRF_LDS_DOUBLES = IMG_DOUBLES + 2 * MB * MB + NB;  // tiles | two inverse buffers | y
 
+// Cycle probe of the factoring workgroup (a -DAGP_POTRF_TIMING build only: scripts/build_probe_libs.sh makes one,
+// scripts/probe_potrf.py reads it through agp_debug_potrf_probe).  Slots [wave][stamp]: 0 = entry, 1 = block loaded and the
+// first micro tile factored, then per micro step jb = 0 .. 6 two stamps: 2 + 2 jb = this wave's own work of stage B done,
+// 3 + 2 jb = behind the barrier that ends the step; the last launch on the device wins.
+// Round 6 used it to time a TWO-wave version (POTRF16 chain on wave 0, INV16 + the exact diagonal on wave 3, columns
+// handed over through LDS - the split round 5 proposed because ~28 instructions per column at one fp64 issue per 8 cycles
+// looked issue-bound): the chain ALONE takes 280-312 cycles per column against 275 with everything on one wave - it is
+// bound by the latency of its nine dependent fp64 operations, the other terms already sit in their shadows -, the inverse
+// lands ~1.1 k cycles behind it and the SYRK loses a wave: N = 512 0.191 instead of 0.165 ms, N = 4096 1.58 instead of
+// 1.41 (profiles/r06/ab_potrf_two_waves.txt, potrf_probe_two_waves.txt).  Not kept; the code is in the git history.
+// The same probe on the one-wave body: micro steps 0 and 1 of a block wait for the SYRK waves (27 / 20 tiles over three
+// waves, ~1.1 k ticks per tile), the other five for wave 0 (5.5 k ticks each); four SYRK tiles per trip instead of two
+// (eight MFMA chains, 48 reads in flight) changed neither (10.4 k ticks for step 0 both ways) and cost 32 registers.
+#ifdef AGP_POTRF_TIMING
+__device__ unsigned long long g_potrf_probe[4 * 32];
+#define AGP_PROBE(slot)                                                                             \
+  do {                                                                                              \
+    if ((threadIdx.x & 63) == 0) g_potrf_probe[(threadIdx.x >> 6) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+void read_potrf_probe(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potrf_probe), sizeof(unsigned long long) * 4 * 32); }
+#else
+#define AGP_PROBE(slot) do { } while (0)
+void read_potrf_probe(unsigned long long *out) { for (int i = 0; i < 4 * 32; ++i) out[i] = 0; }
+#endif
+
 // PUB: the fused panel kernel - every tile of the image goes out (store_pub) the moment it is final, z_b too
 template <bool PUB, bool UPD = false>
 __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
@@ -291,6 +316,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 15, lg = lane >> 4;
   const int nbk = p.nbk;
+  AGP_PROBE(0);
 
   double *Adiag = p.A + p.k0 * p.lda + p.k0;  // element (r, c) of the block at Adiag[c * lda + r]
   if constexpr (UPD) {
@@ -333,6 +359,7 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
   int bad_pivot = 0;
   if (wave == 0) micro_potrf_inv<PUB>(T + tile_off(0, 0), Wc, p.img + tile_off(0, 0), lane, ln, 0, bad_pivot);
   __syncthreads();
+  AGP_PROBE(1);
 
 #pragma unroll 1
   for (int jb = 0; jb < NMB; ++jb) {
@@ -402,7 +429,9 @@ __device__ __forceinline__ void potrf_diag_body(PotrfArgs &p, double *T) {
         ys[row] = s;
       }
     }
+    AGP_PROBE(2 + 2 * jb);
     __syncthreads();
+    AGP_PROBE(3 + 2 * jb);
   }
   if constexpr (PUB) {  // z_b first: the workgroups below wait for it, nobody in this launch waits for the write-back of L11
     if (p.zpub && tid < nbk) store_pub(p.zpub + tid, ys[tid]);

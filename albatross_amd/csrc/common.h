@@ -339,6 +339,7 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
                                long long ld32 = 0);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
+void read_potrf_probe(unsigned long long *out);  // chol.hip: 4 x 32 cycle stamps of a -DAGP_POTRF_TIMING build (zeros otherwise)
 void launch_head_gate(hipStream_t s, const unsigned long long *done, unsigned long long expect, int *flags);  // chol.hip
 // the whole trailing matrix of an outer step in ONE launch, the next block column's tiles first and counted (gemm.hip)
 void launch_trailing_update_merged(hipStream_t s, double *C, long long ldc, const double *P, long long ldp, long long M, long long K,

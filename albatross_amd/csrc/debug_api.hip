@@ -897,6 +897,15 @@ struct NullComm : HostReducingComm {
 
 extern "C" {
 
+// the cycle stamps the factoring workgroup of the LAST potrf / panel launch left (a -DAGP_POTRF_TIMING build; zeros otherwise)
+AGP_DEBUG_API int agp_debug_potrf_probe(agp_context *ctx, unsigned long long *out) {
+  if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  AGP_HIP_CHECK(ctx, hipDeviceSynchronize());
+  read_potrf_probe(out);
+  return AGP_OK;
+}
+
 AGP_DEBUG_API int agp_debug_mfma_f64_peak(agp_context *ctx, int iters, double *tflops) {
   if (!ctx || !tflops || iters <= 0) return AGP_ERR_INVALID_ARGUMENT;
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
