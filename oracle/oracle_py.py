@@ -44,6 +44,8 @@ def lib():
         L.orc_ldlt_logdet.argtypes = [V, I64, I64]
         L.orc_llt.restype = I64
         L.orc_llt.argtypes = [V, I64, I64]
+        L.orc_llt_blocked.restype = I64
+        L.orc_llt_blocked.argtypes = [V, I64, I64, C.c_int]
         L.orc_llt_solve.argtypes = [V, I64, I64, V, I64, I64]
         L.orc_llt_logdet.restype = C.c_double
         L.orc_llt_logdet.argtypes = [V, I64, I64]
@@ -167,6 +169,17 @@ def llt(A):
     n = A.shape[0]
     info = lib().orc_llt(_ptr(A), n, n)
     return A, int(info)
+
+
+def llt_blocked(A, threads):
+    """strong_llt.c: the blocked, pthread-parallel LL^T of bench.py's `strong_cpu` context row (NOT the reference's
+    algorithm); the lower triangle of the result is the factor, the upper one is scratch."""
+    A = np.array(A, dtype=np.float64, order="F")
+    n = A.shape[0]
+    info = lib().orc_llt_blocked(_ptr(A), n, n, int(threads))
+    if info:
+        raise FloatingPointError(f"pivot {info - 1} is not positive")
+    return A
 
 
 def llt_solve(L, B):

@@ -3,7 +3,7 @@
 # Writes under gpurun_out/prof_<round>/ ; scripts/pmc_summary.py turns the CSVs into the
 # summaries kept under profiles/<round>/.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 # the repository root, resolved BEFORE the cd below (GRAFT_REPO_ROOT is only set on the gpurun box)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT="$ROOT/gpurun_out/prof_$R"

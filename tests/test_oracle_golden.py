@@ -490,3 +490,23 @@ def test_oracle_update_equals_full_fit():
     fullm = orc.OracleFit(covm, x, y, var)
     updm = orc.OracleFit(covm, x[:50], y[:50], var[:50]).update(x[50:], y[50:], var[50:])
     assert np.abs(updm.information - fullm.information).max() > 1e-3 * np.abs(fullm.information).max()
+
+
+@pytest.mark.parametrize("n,threads", [(1, 1), (37, 2), (300, 3), (777, 8)])
+def test_strong_cpu_llt_matches_the_oracle_llt(n, threads):
+    """oracle/strong_llt.c (bench.py's `strong_cpu` context row: blocked, pthread-parallel LL^T with an AVX2 / AVX-512
+    micro-kernel, own code) against the oracle's plain left-looking LL^T and numpy's: same factor to rounding, a
+    non-positive pivot reported at the same index."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, n + 3))
+    A = X @ X.T / n + 2. * np.eye(n)
+    Lb = np.tril(orc.llt_blocked(A, threads))
+    Lo, info = orc.llt(A)
+    assert info == 0
+    assert np.abs(Lb - np.tril(Lo)).max() <= 1e-13 * np.abs(Lo).max()
+    assert np.abs(Lb - np.linalg.cholesky(A)).max() <= 1e-13 * np.abs(Lo).max()
+    if n >= 37:
+        A[20, 20] = -1.
+        with pytest.raises(FloatingPointError, match="pivot 20 "):
+            orc.llt_blocked(A, threads)
+        assert orc.llt(A)[1] == 21
