@@ -935,18 +935,25 @@ __global__ __launch_bounds__(256) void predict_mean_tiled_kernel(FastParams fp, 
     }
 #pragma unroll
     for (int t = 0; t < TJ; ++t) {
-      bool eq = true;
       double sq = 0.;
 #pragma unroll
       for (int d = 0; d < DIMP; ++d) {
         const double dd = x[d] - y[t][d];
         sq += dd * dd;
-        eq = eq && (x[d] == y[t][d]);
       }
-      if (have_ids) eq = xid == yid[t];
-      double v = radial_fast<OP>(sq, fp);
-      if (fp.has_noise) v = v + ((noise_on && eq) ? fp.noise_var : 0.);
+      const double v = radial_fast<OP>(sq, fp);
       acc[t] += v * a;
+      // the noise term (noise.hpp:37-43: sigma^2 iff x == y) only where a training point IS the test point: equal
+      // coordinates give sq == 0 exactly, so the per-coordinate comparison (three v_cmp_f64 + the selects, a sixth of the
+      // instructions of an evaluation) runs only in a wave that holds such a pair
+      if (noise_on && __any(have_ids ? (xid == yid[t]) : (sq == 0.))) {
+        bool eq = true;
+#pragma unroll
+        for (int d = 0; d < DIMP; ++d) eq = eq && (x[d] == y[t][d]);
+        if (have_ids) eq = xid == yid[t];
+        // ((v + noise) a as before: the sum is formed before the product, like lhs + rhs of the reference's SumOfCovarianceFunctions)
+        if (eq) acc[t] += (v + fp.noise_var) * a - v * a;
+      }
     }
   }
   __shared__ double red[4][TJ];
@@ -988,6 +995,7 @@ template <int DIMP>
 static bool launch_predict_mean_fast_t(hipStream_t s, const FastParams &fp, int op, const FeatView &X,
                                        const FeatView &XS, const double *alpha, double *mean) {
   if (XS.n >= 1024 && XS.dim == DIMP) {  // enough test points for 256 workgroups of four (16384: of eight)
+    // (TJ = 2 below 8192 test points - twice the workgroups - measured in round 6: +6 % at M = 2048, 0 at 4096, -4 % at 8192)
     const bool done = XS.n >= 16384 ? launch_predict_mean_tiled_t<DIMP, 8>(s, fp, op, X, XS, alpha, mean)
                                     : launch_predict_mean_tiled_t<DIMP, 4>(s, fp, op, X, XS, alpha, mean);
     if (done) return true;

@@ -448,6 +448,56 @@ def other_configs(ab, ctx):
     except Exception as exc:  # noqa: BLE001
         out["small_n_batched"] = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # ---- the reference's OWN benchmark (benchmarks/bench_predict.cc:20-85, bench_utils.h:25-85): N = 512 1-D training
+    #      points x ~ U[0, 10] from mt19937(seed), y = sin x + 0.1 cos 10 x, bench_covariance = SE(1, 1) + IndependentNoise(0.1);
+    #      BM_gp_fit (seed 31), BM_gp_predict_joint (32 / 33), _marginal (34 / 35), _mean (36 / 37) at 512 test points.
+    #      Through the drop-in surface with HOST inputs, as the reference's benchmark calls it (model.fit(dataset),
+    #      fit_model.predict(features).joint()); B = 32: thirty-two such fits per call (ab.fit_batch).  `cpu_port_ms`: the
+    #      oracle (the reference's algorithm restated, one thread) on the same inputs, best of three.
+    try:
+        from oracle import oracle_py as orc
+        nt = 512
+        covb = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+
+        def bench_ds(seed):
+            xf = mt19937_uniform(seed, nt)
+            return xf, np.sin(xf) + 0.1 * np.cos(10. * xf)
+        model = ab.gp_from_covariance(covb, context=ctx)
+        x31, y31 = bench_ds(31)
+        ds31 = ab.RegressionDataset(x31, y31)
+        t_fit = best(lambda: model.fit(ds31), 300)
+        dsets = [ab.RegressionDataset(*bench_ds(1000 + b)) for b in range(32)]
+        t_fit32 = best(lambda: ab.fit_batch([model] * 32, dsets), 30)
+        rb = {"workload": "benchmarks/bench_predict.cc: N = 512 1-D, bench_covariance SE(1,1)+IndependentNoise(0.1), 512 test points; "
+                          "host inputs through the Python mirror of the reference's call surface",
+              "fit_ms": 1e3 * t_fit, "fit_batch32_ms": 1e3 * t_fit32, "fits_per_sec_single": 1. / t_fit, "fits_per_sec_batch32": 32. / t_fit32}
+        tcpu = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            orc.OracleFit(covb, x31, y31).information
+            tcpu = min(tcpu, time.perf_counter() - t0)
+        rb["fit_cpu_port_ms"] = 1e3 * tcpu
+        for name, s_tr, s_te in (("joint", 32, 33), ("marginal", 34, 35), ("mean", 36, 37)):
+            xtr, ytr = bench_ds(s_tr)
+            xte = mt19937_uniform(s_te, nt)
+            fm = model.fit(ab.RegressionDataset(xtr, ytr))
+            pred = {"joint": lambda: fm.predict(xte).joint(), "marginal": lambda: fm.predict(xte).marginal(),
+                    "mean": lambda: fm.predict(xte).mean()}[name]
+            rb[f"predict_{name}_ms"] = 1e3 * best(pred, 100)
+            ofit = orc.OracleFit(covb, xtr, ytr)
+            ocall = {"joint": lambda: ofit.predict_joint(xte), "marginal": lambda: ofit.predict_marginal(xte),
+                     "mean": lambda: ofit.predict_mean(xte)}[name]
+            tcpu = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ocall()
+                tcpu = min(tcpu, time.perf_counter() - t0)
+            rb[f"predict_{name}_cpu_port_ms"] = 1e3 * tcpu
+            del fm
+        out["reference_bench"] = rb
+    except Exception as exc:  # noqa: BLE001
+        out["reference_bench"] = {"error": f"{type(exc).__name__}: {exc}"}
+
     # ---- config 4: temperature-example kernel, N = 32768, fp64 vs mixed precision ----
     try:
         n = 32768
