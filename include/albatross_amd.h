@@ -148,8 +148,8 @@ AGP_API int agp_device_count(void);
 /* ---- device memory for AGP_DEVICE arguments ------------------------------ */
 /* Every entry point that takes a `location` accepts buffers that already live in HBM (features, targets, outputs).  A host
  * program that links nothing but this library gets such buffers here - plain hipMalloc / hipMemcpy / hipFree on the
- * context's device, so that a caller needs no HIP headers and no second runtime in its process (bench.py's N = 1 path and
- * examples/bench_fit.cpp use exactly these).  The reference keeps everything in host Eigen matrices; its equivalent is the
+ * context's device, so that a caller needs no HIP headers and no second runtime in its process (bench.py allocates its
+ * inputs and outputs with exactly these).  The reference keeps everything in host Eigen matrices; its equivalent is the
  * allocation inside Eigen::MatrixXd (models/gp.hpp:61-69 copies features and covariance into the fit).
  * agp_device_malloc: *out = `bytes` of device memory (bytes > 0).  agp_device_free(NULL) is a no-op.
  * agp_memcpy: `kind` = the agp_location of DST; the source is at the other location for AGP_HOST <-> AGP_DEVICE copies
@@ -641,6 +641,9 @@ AGP_API int agp_set_profiling(agp_context *ctx, int enabled);
  * the schedule's other parameters are constants (csrc/chol.hip).
  *   AGP_PANEL_FUSED=0        POTRF and panel TRSM as two launches instead of the fused panel kernel
  *   AGP_STEP_BELOW=<rows>    remaining rows at or below which every panel is ONE step launch (default 4608; 0: off)
+ *   AGP_MERGE_ABOVE=<rows>   trailing rows above which the update of the NEXT block column rides in the bulk launch (its
+ *                            tiles first, counted; a one-wave gate kernel on the panel stream) instead of being a launch
+ *                            of its own behind an event (default 8704; 0: the round-5 schedule)
  *   AGP_GRAM_SOP=0           covariance trees through the stack interpreter only (parity tests run both evaluators)
  *   AGP_MIXED_BF16=0         agp_fit_create_mixed forms its fp32-accurate products on the fp32 MFMA instead of bf16 x 3
  *   AGP_BF16X3_KERNEL=1      ... with the first bf16 x 3 tile kernel (one workgroup per CU) instead of the pair kernel
