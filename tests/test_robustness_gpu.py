@@ -97,3 +97,61 @@ def test_repeated_small_fits_are_bitwise_identical(ctx, n, reps):
             else:
                 assert np.array_equal(got[0], first[0]) and got[1] == first[1], (n, i)
         del fm
+
+
+def test_merged_bulk_launches_on_several_contexts_at_once(ctx):
+    """The merged bulk launches of large fits (round 6, csrc/chol.hip: factor_lower - the next block column's tiles ride at
+    the head of the bulk launch, a one-wave gate kernel on the panel stream waits for their count) make one stream of a
+    context wait for a LAUNCH ON ANOTHER STREAM of the same context.  Three contexts on three host threads put twelve and
+    more streams on the runtime's few hardware queues: every fit must still be the fit (bit-identical to the one computed
+    alone, same as AGP_MERGE_ABOVE=0 to rounding) - should two streams of one context ever share a hardware queue, the gate's
+    deadline turns the fit into an error and agp_fit_create repeats it without merged launches instead of hanging."""
+    import threading
+    n = 10240  # (merged launches while more than 8704 trailing rows remain: the first two outer steps)
+    x, y = synthetic_3d(n, 91)
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+    ds = ab.RegressionDataset(x, y)
+    want = np.array(ab.gp_from_covariance(cov, context=ctx).fit(ds).get_fit().information)
+    K = ctx.gram(cov, ab.Measurement(x))
+    assert np.abs(K @ want - y).max() <= 1e-9 * np.abs(K).sum(axis=1).max() * np.abs(want).max()
+    del K
+    results, errors = {}, []
+
+    def work(tag):
+        try:
+            c = ab.Context(0)
+            for _ in range(3):
+                results[tag] = np.array(ab.gp_from_covariance(cov, context=c).fit(ds).get_fit().information)
+            c.close()
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for i in range(3):
+        assert np.array_equal(results[i], want)
+
+
+def test_merged_bulk_launches_match_the_separate_update(make_ctx, monkeypatch):
+    """AGP_MERGE_ABOVE=0 (U1 as a launch of its own on the panel stream, as in rounds 1-5) against the default: the same
+    factorisation to rounding (the 64 x 64 tiles of the separate launch start their accumulators from C, the 128 x 128 head
+    tiles add C in eight parts), both against the residual of the normal equations."""
+    n = 12288
+    x, y = synthetic_3d(n, 92)
+    cov = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+    ds = ab.RegressionDataset(x, y)
+    c1 = make_ctx()
+    a1 = np.array(ab.gp_from_covariance(cov, context=c1).fit(ds).get_fit().information)
+    ld1 = ab.gp_from_covariance(cov, context=c1).fit(ds).get_fit().log_determinant
+    monkeypatch.setenv("AGP_MERGE_ABOVE", "0")
+    c0 = make_ctx()
+    f0 = ab.gp_from_covariance(cov, context=c0).fit(ds).get_fit()
+    a0, ld0 = np.array(f0.information), f0.log_determinant
+    assert np.abs(a1 - a0).max() <= 1e-9 * np.abs(a0).max()
+    assert abs(ld1 - ld0) <= 1e-9 * abs(ld0)
+    K = c1.gram(cov, ab.Measurement(x))
+    for a in (a0, a1):
+        assert np.abs(K @ a - y).max() <= 1e-9 * np.abs(K).sum(axis=1).max() * np.abs(a).max()
