@@ -149,7 +149,8 @@ def cpu_baseline(seconds_budget=60.0):
     coef, resid = rel_fit(ns[big], ts[big]) if big.sum() >= 1 else (coef_all, resid_all)
     scaled = float(coef[0] * N_TRAIN ** 3 + coef[1] * N_TRAIN ** 2)
     scaled_all = float(coef_all[0] * N_TRAIN ** 3 + coef_all[1] * N_TRAIN ** 2)
-    cores_host = os.cpu_count() or 1
+    _usable, _quota = _cpu_quota_cores()
+    cores_host = int(max(1, min(_usable, _quota if _quota else _usable)))  # (threads beyond the cgroup quota only add contention)
     out = {"value": 1.0 / scaled, "unit": "fits/sec", "cores": 1, "kind": "port",
            "sample": "oracle fits (serial Gram + unblocked pivoted LDLT, 1 thread) at N = "
                      + ", ".join(f"{n}: {dt:.2f} s" for n, _, dt in samples)
@@ -161,7 +162,7 @@ def cpu_baseline(seconds_budget=60.0):
            "cubic_fit_all_samples": {"a_n3": float(coef_all[0]), "b_n2": float(coef_all[1]), "max_rel_residual": resid_all,
                                      "fits_per_sec_at_16384": 1.0 / scaled_all},
            "range_fits_per_sec": sorted([1.0 / scaled, 1.0 / scaled_all]),
-           "cpu_model": _cpu_model(), "nproc": cores_host, "compiler_flags": "gcc " + _oracle_cflags()}
+           "cpu_model": _cpu_model(), "nproc": os.cpu_count() or 1, "usable_cores": cores_host, "compiler_flags": "gcc " + _oracle_cflags()}
     # BASELINE.md section 2, B2 "albatross-faithful, pooled": the Gram over all host cores (callers.hpp:134-166), the
     # factor unchanged (Eigen's LDLT has no parallel path): only the Gram's share of the fit changes
     try:
@@ -179,9 +180,9 @@ def cpu_baseline(seconds_budget=60.0):
                                         f"the fit's Gram share (x (16384/{n})^2) exchanged, the single-threaded factor unchanged"}
     except Exception as exc:  # noqa: BLE001 - context only
         out["pooled_gram"] = {"error": f"{type(exc).__name__}: {exc}"}
-    # For context ("strong CPU"): the same fit by a competent multi-core CPU implementation - the oracle's
-    # pooled Gram (callers.hpp:134-166) over the usable cores + oracle/strong_llt.c (own code: blocked, pthread-parallel
-    # LL^T, AVX2 / AVX-512 micro-kernel) + the oracle's substitutions.  NOT the reference's algorithm (albatross factors
+    # For context ("strong CPU"): the same fit by a competent multi-core CPU implementation - oracle/strong_llt.c
+    # (own code: a threaded SE Gram of the lower triangle, a blocked pthread-parallel LL^T with an AVX2 / AVX-512
+    # micro-kernel) + the oracle's substitutions.  NOT the reference's algorithm (albatross factors
     # with Eigen's unblocked single-threaded LDL^T), so it is reported beside `value`, with the GFLOP/s it achieved and the
     # cores it was allowed (rounds 1-5 used scipy's LAPACK here and measured 49 GFLOP/s: its BLAS pool does not scale
     # inside the box's container, whose cgroup grants 16 of the 256 visible hardware threads).
@@ -190,11 +191,15 @@ def cpu_baseline(seconds_budget=60.0):
         threads = int(max(1, min(usable, quota if quota else usable)))
         L = orc.lib()
         L.orc_llt_blocked_isa.restype = C.c_int
+        L.orc_strong_gram_se.restype = None
+        L.orc_strong_gram_se.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_int]
 
         def strong_fit(m):
             xs, ys = make_dataset(m, 44)
             t0 = time.perf_counter()
-            K = orc.gram(cov, xs, x_meas=True, threads=threads)
+            K = np.empty((m, m), order="F")  # (lower triangle only: all the factorisation and the substitutions read)
+            L.orc_strong_gram_se(C.c_void_p(xs.ctypes.data), m, DIM, C.c_double(1.0), C.c_double(1.0), C.c_double(0.1),
+                                 C.c_void_p(K.ctypes.data), m, threads)
             t_gram = time.perf_counter() - t0
             t0 = time.perf_counter()
             info = L.orc_llt_blocked(C.c_void_p(K.ctypes.data), m, m, threads)
@@ -222,7 +227,7 @@ def cpu_baseline(seconds_budget=60.0):
         out["strong_cpu"] = {"value": 1.0 / total, "unit": "fits/sec", "cores": threads,
                              "factor_gflops": gflops, "factor_gflops_n8192": gflops8, "vector_bits": int(L.orc_llt_blocked_isa()),
                              "usable_hardware_threads": usable, "cgroup_cpu_quota": quota, "self_check_residual": r,
-                             "sample": f"pooled oracle Gram {tg:.2f} s + blocked pthread LL^T (oracle/strong_llt.c) {tc:.2f} s = "
+                             "sample": f"threaded SE Gram (lower triangle, oracle/strong_llt.c) {tg:.2f} s + blocked pthread LL^T (oracle/strong_llt.c) {tc:.2f} s = "
                                        f"{gflops:.0f} GFLOP/s + substitutions {ts_:.2f} s {how}; {threads} threads "
                                        f"({usable} hardware threads visible, cgroup CPU quota {quota})",
                              # a competent dpotrf on >= 32 unrestricted cores does >= 0.5 TFLOP/s: below that this row does not

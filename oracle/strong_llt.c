@@ -320,3 +320,51 @@ ORC_API int64_t orc_llt_blocked(double *A, int64_t n, int64_t ld, int threads) {
   free(s.ws); free(s.packA); free(s.packB); free(pa); free(pool.tid);
   return bad;
 }
+
+/* ---- the Gram matrix of the strong-CPU row: SquaredExponential(l, sigma) + IndependentNoise on row-major n x dim points,
+ * LOWER triangle only (all orc_llt_blocked and the substitutions read), columns dealt cyclically to the threads - the CPU
+ * counterpart of the library's fast path (csrc/gram.hip: gram_fast_kernel), not the reference's generic caller chain ---- */
+typedef struct {
+  const double *x;
+  int64_t n, ld;
+  int dim, threads;
+  double inv_l2, sigma2, noise_var;
+  double *K;
+} gram_job_t;
+typedef struct { gram_job_t *g; int id; } gram_arg_t;
+
+static void *gram_se_worker(void *v) {
+  gram_arg_t *a = (gram_arg_t *)v;
+  const gram_job_t *g = a->g;
+  for (int64_t j = a->id; j < g->n; j += g->threads) {
+    const double *xj = g->x + j * g->dim;
+    double *col = g->K + j * g->ld;
+    for (int64_t i = j; i < g->n; ++i) {
+      const double *xi = g->x + i * g->dim;
+      double d2 = 0.;
+      for (int d = 0; d < g->dim; ++d) {
+        const double t = xi[d] - xj[d];
+        d2 += t * t;
+      }
+      col[i] = g->sigma2 * exp(-d2 * g->inv_l2);
+    }
+    col[j] += g->noise_var;
+  }
+  return NULL;
+}
+
+ORC_API void orc_strong_gram_se(const double *x, int64_t n, int dim, double length_scale, double sigma, double noise_sigma, double *K,
+                                int64_t ld, int threads) {
+  if (threads < 1) threads = 1;
+  gram_job_t g = {x, n, ld, dim, threads, 1. / (length_scale * length_scale), sigma * sigma, noise_sigma * noise_sigma, K};
+  pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+  gram_arg_t *args = (gram_arg_t *)malloc(sizeof(gram_arg_t) * (size_t)threads);
+  for (int t = 0; t < threads; ++t) {
+    args[t].g = &g;
+    args[t].id = t;
+    pthread_create(&tid[t], NULL, gram_se_worker, &args[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+  free(args);
+  free(tid);
+}
