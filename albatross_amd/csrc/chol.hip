@@ -963,6 +963,7 @@ void launch_prep(hipStream_t s, const PrepArgs &a) {
 // Not planned (and the two-launch path is used) if the fused kernel is off or a buffer cannot be allocated.
 bool panel_fused_plan(agp_context *ctx, double *invd, long long k_begin, long long k_end, bool want_step, PrepArgs *prep) {
   ctx->img_ready = nullptr;
+  ctx->headcnt_ready = false;  // (set below, only together with the fill that zeroes the counters)
   if (!ctx->tune.panel_fused || k_end <= k_begin) return false;
   if (ctx->zpub_cap < k_end) {
     // grow; the old buffer may still be read by kernels in flight on this context's streams: drain them first
@@ -997,7 +998,6 @@ bool panel_fused_plan(agp_context *ctx, double *invd, long long k_begin, long lo
   prep->sentinel(invd + b0 * (long long)IMG_DOUBLES, cnt_img);
   prep->sentinel(ctx->d_zpub + k_begin, cnt_z);
   // (the counters of the merged bulk updates: factor_lower of a whole matrix large enough to have any)
-  ctx->headcnt_ready = false;
   if (want_step && k_begin == 0 && ctx->d_headcnt && ctx->tune.merge_above > 0 && k_end > ctx->tune.merge_above && !prep->full()) {
     prep->fill(ctx->d_headcnt, 0ull, agp_context::HEADCNT_WORDS);
     ctx->headcnt_ready = true;
