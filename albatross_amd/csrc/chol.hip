@@ -296,6 +296,9 @@ constexpr int POTRF_LDS_DOUBLES = IMG_DOUBLES + 2 * MB * MB + NB;  // tiles | tw
 // The same probe on the one-wave body: micro steps 0 and 1 of a block wait for the SYRK waves (27 / 20 tiles over three
 // waves, ~1.1 k ticks per tile), the other five for wave 0 (5.5 k ticks each); four SYRK tiles per trip instead of two
 // (eight MFMA chains, 48 reads in flight) changed neither (10.4 k ticks for step 0 both ways) and cost 32 registers.
+// One dependent operation less per column by folding the pivot's broadcast into `v_rsq_f64_dpp ... row_newbcast` is not
+// available: the instruction assembles for gfx950 and returns garbage (scripts/microbench/rsq_dpp_probe.hip) - DPP on
+// 64-bit operands works for v_mov_b64 and v_fmac_f64 here, not for the transcendental.
 #ifdef AGP_POTRF_TIMING
 __device__ unsigned long long g_potrf_probe[4 * 32];
 #define AGP_PROBE(slot)                                                                             \
