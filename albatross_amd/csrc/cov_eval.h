@@ -70,6 +70,47 @@ __device__ __forceinline__ double exp_neg(double t) {
   return __builtin_ldexp(p, (int)kf);
 }
 
+// NT independent exp_neg in lock step: the Horner steps of the NT arguments are issued round-robin (volatile asm keeps the
+// source order), so that a wave covers the latency of one dependent v_fma_f64 with the steps of the others instead of
+// waiting - the compiler's scheduler leaves NT separate exp_neg calls one behind the other.  Same operations per
+// argument as exp_neg: bit-identical values.
+__device__ __forceinline__ double horner_step_ordered(double p, double r, double c) {
+  double o;
+  asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
+  return o;
+}
+
+template <int NT>
+__device__ __forceinline__ void exp_neg_n(const double (&tin)[NT], double (&out)[NT]) {
+  double kf[NT], r[NT], p[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const double t = (tin[i] > 1100.) ? 1100. : tin[i];
+    kf[i] = __builtin_rint(t * -1.4426950408889634074);
+    r[i] = __builtin_fma(kf[i], -6.93147180369123816490e-01, -t);
+    r[i] = __builtin_fma(kf[i], -1.90821492927058770002e-10, r[i]);
+    p[i] = 1.6059043836821613e-10;  // 1/13!
+  }
+#define AGP_EXPN_STEP(C)                                                \
+  _Pragma("unroll") for (int i = 0; i < NT; ++i) p[i] = horner_step_ordered(p[i], r[i], C);
+  AGP_EXPN_STEP(2.0876756987868100e-09)  // 1/12!
+  AGP_EXPN_STEP(2.5052108385441720e-08)
+  AGP_EXPN_STEP(2.7557319223985888e-07)
+  AGP_EXPN_STEP(2.7557319223985893e-06)
+  AGP_EXPN_STEP(2.4801587301587302e-05)
+  AGP_EXPN_STEP(1.9841269841269841e-04)
+  AGP_EXPN_STEP(1.3888888888888889e-03)
+  AGP_EXPN_STEP(8.3333333333333332e-03)
+  AGP_EXPN_STEP(4.1666666666666664e-02)
+  AGP_EXPN_STEP(1.6666666666666666e-01)
+  AGP_EXPN_STEP(0.5)
+  AGP_EXPN_STEP(1.0)
+  AGP_EXPN_STEP(1.0)
+#undef AGP_EXPN_STEP
+#pragma unroll
+  for (int i = 0; i < NT; ++i) out[i] = __builtin_ldexp(p[i], (int)kf[i]);
+}
+
 // acos(x) for the angular metric (distance_metrics.hpp:64-90).  The library acos is 93 VALU instructions, 26 of them
 // v_mov of literals; this one is ~45: branch-free argument reduction to z in [0, 1/4] (|x| >= 1/2: z = (1 - |x|) / 2,
 // exact by Sterbenz, acos = 2 asin(sqrt z) or pi - that; |x| < 1/2: z = x^2, acos = pi/2 - asin x), asin(sqrt z) =

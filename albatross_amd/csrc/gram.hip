@@ -177,6 +177,34 @@ __device__ __forceinline__ double radial_fast(double s2, const FastParams &fp) {
   }
 }
 
+// NT values at once, without the test of the length scale's sign (radial.hpp: 0 if l <= 0; the caller handles it) and
+// with the exponentials in lock step (cov_eval.h: exp_neg_n).  Per value the operations of radial_fast.
+template <int OP, int NT>
+__device__ __forceinline__ void radial_fast_n(const double (&s2)[NT], const FastParams &fp, double (&v)[NT]) {
+  double arg[NT], pre[NT], e[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    if (OP == AGP_OP_SQUARED_EXPONENTIAL) {
+      arg[i] = s2[i] * fp.inv_l2;
+      pre[i] = fp.sigma2;
+    } else if (OP == AGP_OP_EXPONENTIAL) {
+      arg[i] = sqrt(s2[i]) * fp.cq;
+      pre[i] = fp.sigma2;
+    } else if (OP == AGP_OP_MATERN32) {
+      const double q = sqrt(s2[i]) * fp.cq;
+      arg[i] = q;
+      pre[i] = fp.sigma2 * (1 + q);
+    } else {
+      const double q = sqrt(s2[i]) * fp.cq;
+      arg[i] = q;
+      pre[i] = fp.sigma2 * (1 + q + q * q * (1. / 3.));
+    }
+  }
+  exp_neg_n<NT>(arg, e);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) v[i] = pre[i] * e[i];
+}
+
 template <int DIMP, int OP>
 __device__ __forceinline__ void gram_fast_body(const FastParams &fp, FeatView X, FeatView Y, int lower_only, double *out, long long ld,
                                                const double *diag_add, int *nan_flag, long long blk_rows, long long blk_stride) {
@@ -933,28 +961,44 @@ __global__ __launch_bounds__(256) void predict_mean_tiled_kernel(FastParams fp, 
       an = alpha[in];
       idn = have_ids ? X.ids[in] : 0;
     }
+    // All TJ evaluations in ONE basic block: the exp_neg chains (13 dependent v_fma_f64 each) interleave, and a wave hides
+    // its own latencies instead of leaning on the other three of its SIMD.  (Round 5's loop body branched per evaluation -
+    // on the length scale's sign and, since round 6, on the noise term - which kept the chains one behind the other: the
+    // kernel sat at 60 % of the fp64 issue rate.)  Same operations per evaluation: bit-identical results.
+    double sq[TJ], c[TJ];
 #pragma unroll
     for (int t = 0; t < TJ; ++t) {
-      double sq = 0.;
+      sq[t] = 0.;
 #pragma unroll
       for (int d = 0; d < DIMP; ++d) {
         const double dd = x[d] - y[t][d];
-        sq += dd * dd;
-      }
-      const double v = radial_fast<OP>(sq, fp);
-      acc[t] += v * a;
-      // the noise term (noise.hpp:37-43: sigma^2 iff x == y) only where a training point IS the test point: equal
-      // coordinates give sq == 0 exactly, so the per-coordinate comparison (three v_cmp_f64 + the selects, a sixth of the
-      // instructions of an evaluation) runs only in a wave that holds such a pair
-      if (noise_on && __any(have_ids ? (xid == yid[t]) : (sq == 0.))) {
-        bool eq = true;
-#pragma unroll
-        for (int d = 0; d < DIMP; ++d) eq = eq && (x[d] == y[t][d]);
-        if (have_ids) eq = xid == yid[t];
-        // ((v + noise) a as before: the sum is formed before the product, like lhs + rhs of the reference's SumOfCovarianceFunctions)
-        if (eq) acc[t] += (v + fp.noise_var) * a - v * a;
+        sq[t] += dd * dd;
       }
     }
+    double v[TJ];
+    radial_fast_n<OP, TJ>(sq, fp, v);  // (the launcher sends a non-positive length scale to the other kernel)
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) c[t] = v[t] * a;
+    // the noise term (noise.hpp:37-43: sigma^2 iff x == y) only where a training point IS a test point: equal coordinates
+    // give sq == 0 exactly, so the per-coordinate comparison (three v_cmp_f64 + the selects, a sixth of the instructions of
+    // an evaluation) runs only in a wave that holds such a pair
+    if (noise_on) {
+      bool maybe = false;
+#pragma unroll
+      for (int t = 0; t < TJ; ++t) maybe = maybe || (have_ids ? (xid == yid[t]) : (sq[t] == 0.));
+      if (__any(maybe)) {
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) {
+          bool eq = true;
+#pragma unroll
+          for (int d = 0; d < DIMP; ++d) eq = eq && (x[d] == y[t][d]);
+          if (have_ids) eq = xid == yid[t];
+          if (eq) c[t] = (v[t] + fp.noise_var) * a;  // (lhs + rhs first, like the reference's SumOfCovarianceFunctions: the value round 5 computed)
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) acc[t] += c[t];
   }
   __shared__ double red[4][TJ];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -994,7 +1038,8 @@ static bool launch_predict_mean_tiled_t(hipStream_t s, const FastParams &fp, int
 template <int DIMP>
 static bool launch_predict_mean_fast_t(hipStream_t s, const FastParams &fp, int op, const FeatView &X,
                                        const FeatView &XS, const double *alpha, double *mean) {
-  if (XS.n >= 1024 && XS.dim == DIMP) {  // enough test points for 256 workgroups of four (16384: of eight)
+  // (radial.hpp: the covariance is 0 for a non-positive length scale - the tiled kernel has no test for it in its loop)
+  if (XS.n >= 1024 && XS.dim == DIMP && fp.length_scale > 0.) {  // enough test points for 256 workgroups of four (16384: of eight)
     // (TJ = 2 below 8192 test points - twice the workgroups - measured in round 6: +6 % at M = 2048, 0 at 4096, -4 % at 8192)
     const bool done = XS.n >= 16384 ? launch_predict_mean_tiled_t<DIMP, 8>(s, fp, op, X, XS, alpha, mean)
                                     : launch_predict_mean_tiled_t<DIMP, 4>(s, fp, op, X, XS, alpha, mean);

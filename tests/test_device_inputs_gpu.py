@@ -129,7 +129,8 @@ def test_two_contexts_are_independent(ctx):
     for t in ts:
         t.join()
     for i in range(3):
-        assert np.array_equal(results[i], want)
+        assert np.array_equal(results[i], want), (i, [float(np.abs(results[j] - want).max()) for j in range(3)],
+                                                  [int((results[j] != want).sum()) for j in range(3)])
 
 
 def test_bench_json_contract():
