@@ -290,6 +290,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->d_dpub) (void)hipFree(ctx->d_dpub);
   if (ctx->shard_flags) (void)hipFree(ctx->shard_flags);
   if (ctx->d_headcnt) (void)hipFree(ctx->d_headcnt);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);  // (d_scalars / h_scalars are the tails of these blocks)
   if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
   if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
@@ -1523,6 +1524,21 @@ int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, c
 // (benchmarks/bench_predict.cc:20-40, the tuner loop tune/tune.hpp:276-290) - ONE fit is bound by the latency of its
 // 128 serial pivots per panel (27-30 us per POTRF, config 2: 0.14 of the MFMA peak); a batch shares that latency and
 // fills the chip with the trailing updates of all problems (factor_lower_batched).
+// `bytes` of the context's pinned staging area (common.h: h_stage), grown on demand; nullptr if it cannot be had (the
+// callers then stage through pageable memory and synchronise once).  The previous contents are dead: every user ends its
+// call with a synchronisation of the stream that read them.
+static void *host_stage(agp_context *ctx, size_t bytes) {
+  if (ctx->h_stage_bytes < bytes) {
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    ctx->h_stage_bytes = 0;
+    const size_t want = (bytes + 65535) / 65536 * 65536;
+    if (hipHostMalloc(&ctx->h_stage, want) != hipSuccess) { (void)hipGetLastError(); ctx->h_stage = nullptr; return nullptr; }
+    ctx->h_stage_bytes = want;
+  }
+  return ctx->h_stage;
+}
+
 int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *kernels, const agp_features *const *features,
                          const double *y, int64_t ldy, const double *y_var, int64_t ldv, agp_fit **out, double *information,
                          int64_t ldi, double *log_det, int *status) {
@@ -1631,10 +1647,15 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
   const size_t table_bytes = copy_bytes + gram_batch_table_bytes(count);
   if (dev_malloc(&tables, table_bytes) != hipSuccess) { (void)hipGetLastError(); tables = nullptr; }
   struct FreeTables { void *p; ~FreeTables() { if (p) (void)dev_free(p); } } free_tables{tables};
+  // (both tables are built in the context's pinned staging area: no synchronisation between the uploads and the launches
+  // that read them - the two mid-call synchronisations of round 5 were ~4 % of a batch of 256 fits of N = 512)
+  char *pinned = tables ? static_cast<char *>(host_stage(ctx, table_bytes)) : nullptr;
   if (!copies.empty()) {
     if (tables) {
-      BATCH_CHECK(hipMemcpyAsync(tables, copies.data(), sizeof(CopyItem) * copies.size(), hipMemcpyHostToDevice, s));
-      BATCH_CHECK(hipStreamSynchronize(s));  // (pageable source)
+      const void *src = copies.data();
+      if (pinned) { std::memcpy(pinned, copies.data(), sizeof(CopyItem) * copies.size()); src = pinned; }
+      BATCH_CHECK(hipMemcpyAsync(tables, src, sizeof(CopyItem) * copies.size(), hipMemcpyHostToDevice, s));
+      if (!pinned) BATCH_CHECK(hipStreamSynchronize(s));  // (pageable source)
       launch_copy_table(s, static_cast<const CopyItem *>(tables), (long long)copies.size(), copy_max);
     } else {
       for (const CopyItem &c : copies) BATCH_CHECK(hipMemcpyAsync(c.dst, c.src, sizeof(double) * (size_t)c.words, kind, s));
@@ -1667,7 +1688,7 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
     bool gram_done = false;
     if (tables && count > 1) {  // all Gram matrices in ONE launch when the trees share a fast path (gram.hip)
       gram_done = launch_gram_batch(s, count, hprogs.data(), views.data(), outs.data(), lda, y_var ? diag.data() : nullptr, nanf.data(),
-                                    static_cast<char *>(tables) + copy_bytes);
+                                    static_cast<char *>(tables) + copy_bytes, pinned ? pinned + copy_bytes : nullptr);
     }
     for (int b = 0; b < count && !gram_done; ++b) {
       const DevProgram *dprog = nullptr;

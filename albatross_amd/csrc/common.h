@@ -144,6 +144,11 @@ struct agp_context {
   unsigned long long *d_rowcnt = nullptr;  // one counter per 64 rows (tail of the d_dpub allocation): hand-over of the step launches' row updates
   // merged bulk updates (chol.hip: factor_lower): one counter per outer step - the tiles of the next block column count
   // themselves, the chain stream's gate kernel waits for all of them; zeroed by panel_fused_plan (headcnt_ready)
+  // pinned host memory for the small tables a batched entry point uploads (descriptors of its problems): a copy from
+  // pinned memory is really asynchronous, so the call needs no synchronisation between building a table and the launch
+  // that reads it (api.hip: host_stage; valid until the call's final synchronisation)
+  void *h_stage = nullptr;
+  size_t h_stage_bytes = 0;
   static constexpr long long HEADCNT_WORDS = 256;
   unsigned long long *d_headcnt = nullptr;
   bool headcnt_ready = false;
@@ -225,8 +230,10 @@ void launch_gram(hipStream_t s, const DevProgram *P, const FeatView &X, const Fe
 // `count` symmetric lower-only Gram matrices in ONE launch when every problem takes the same fast path (gram.hip); false:
 // not applicable, nothing launched.  table_dev: gram_batch_table_bytes(count) bytes of device scratch.
 size_t gram_batch_table_bytes(long long count);
+// host_stage (optional): gram_batch_table_bytes(count) bytes of PINNED host memory that stay untouched until the launch has
+// run - the table is built there and uploaded without a synchronisation; nullptr: pageable staging + one stream synchronisation
 bool launch_gram_batch(hipStream_t s, long long count, const DevProgram *const *host_programs, const FeatView *Xs, double *const *outs,
-                       long long ld, const double *const *diag_adds, int *const *nan_flags, void *table_dev);
+                       long long ld, const double *const *diag_adds, int *const *nan_flags, void *table_dev, void *host_stage = nullptr);
 void launch_gram_diagonal(hipStream_t s, const DevProgram *P, const FeatView &X, double *out);
 // mean_j = sum_i k(x_i, xs_j) alpha_i without materialising the cross Gram
 void launch_predict_mean(hipStream_t s, const DevProgram *P, const FeatView &X, const FeatView &XS,

@@ -691,9 +691,14 @@ size_t gram_batch_table_bytes(long long count) { return sizeof(GramBatchItem) * 
 // (radial<Euclidean> [+ noise], dim <= 3, same operator): false = not applicable, nothing launched.
 // table_dev: gram_batch_table_bytes(count) bytes of device scratch the launch reads (must stay valid until it has run).
 bool launch_gram_batch(hipStream_t s, long long count, const DevProgram *const *host_programs, const FeatView *Xs, double *const *outs,
-                       long long ld, const double *const *diag_adds, int *const *nan_flags, void *table_dev) {
+                       long long ld, const double *const *diag_adds, int *const *nan_flags, void *table_dev, void *host_stage) {
   if (count <= 0 || count > 65535 || !table_dev || !sop_enabled()) return false;
-  std::vector<GramBatchItem> items((size_t)count);
+  std::vector<GramBatchItem> pageable;
+  GramBatchItem *items = static_cast<GramBatchItem *>(host_stage);
+  if (!items) {
+    pageable.resize((size_t)count);
+    items = pageable.data();
+  }
   int op0 = 0, dim0 = 0;
   long long nmax = 0;
   for (long long b = 0; b < count; ++b) {
@@ -709,11 +714,11 @@ bool launch_gram_batch(hipStream_t s, long long count, const DevProgram *const *
     if (Xs[b].n > nmax) nmax = Xs[b].n;
   }
   if (nmax <= 0) return true;
-  if (hipMemcpyAsync(table_dev, items.data(), sizeof(GramBatchItem) * (size_t)count, hipMemcpyHostToDevice, s) != hipSuccess) {
+  if (hipMemcpyAsync(table_dev, items, sizeof(GramBatchItem) * (size_t)count, hipMemcpyHostToDevice, s) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  (void)hipStreamSynchronize(s);  // (pageable source: the vector goes out of scope)
+  if (!host_stage) (void)hipStreamSynchronize(s);  // (pageable source: the vector goes out of scope; a pinned stage outlives the launch)
   dim3 grid((unsigned)((nmax + TM - 1) / TM), (unsigned)((nmax + TN - 1) / TN), (unsigned)count), block(GRAM_THREADS);
   auto *tab = static_cast<const GramBatchItem *>(table_dev);
 #define AGP_GB(D, O) hipLaunchKernelGGL((gram_fast_batch_kernel<D, O>), grid, block, 0, s, tab, 1, ld)

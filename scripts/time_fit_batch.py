@@ -6,8 +6,6 @@ import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
-torch.cuda.init()
 import albatross_amd as ab
 from bench import fit_batch_rates
 
