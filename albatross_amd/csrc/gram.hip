@@ -247,44 +247,85 @@ __device__ __forceinline__ void gram_fast_body(const FastParams &fp, FeatView X,
   const bool wide = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   const bool noise_on = fp.has_noise && (!fp.noise_meas_only || (X.meas && Y.meas));
   bool saw_nan = false;
-  for (int jj = 0; jj < TN / 4; ++jj) {
+  const bool dead = fp.length_scale <= 0.;  // radial.hpp: the covariance is 0 for a non-positive length scale (wave-uniform)
+  // Two columns (four entries) per trip: their exponentials run in lock step (cov_eval.h: exp_neg_n) - round 5's loop made
+  // two separate calls per trip, which the compiler left one behind the other -, and the noise term's equality test
+  // (noise.hpp:37-43) runs only in a wave that holds an equal pair: equal coordinates give a squared distance of exactly 0.
+  // Same operations per entry as before: bit-identical matrices.
+  for (int jj = 0; jj < TN / 4; jj += 2) {
     const int cslot = cgrp * (TN / 4) + jj;
     const long long col = col0 + cslot;
     if (col >= Y.n) break;
-    bool ea = true, eb = true;
-    double sa = 0., sb = 0.;
+    const bool two = col + 1 < Y.n;  // (TN / 4 is even: the second column is this wave group's too)
+    double s2[4] = {0., 0., 0., 0.};  // (row a, col 0), (row b, col 0), (row a, col 1), (row b, col 1)
+    double yv[2][DIMP];
 #pragma unroll
     for (int d = 0; d < DIMP; ++d) {
-      const double yd = ys[d][cslot];
-      const double ta = xa[d] - yd, tb = xb[d] - yd;
-      sa += ta * ta;
-      sb += tb * tb;
-      ea = ea && (xa[d] == yd);
-      eb = eb && (xb[d] == yd);
+      yv[0][d] = ys[d][cslot];
+      yv[1][d] = ys[d][cslot + 1];
     }
-    if (have_ids) {
-      ea = ida == yid[cslot];
-      eb = idb == yid[cslot];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int d = 0; d < DIMP; ++d) {
+        const double ta = xa[d] - yv[c][d], tb = xb[d] - yv[c][d];
+        s2[2 * c] += ta * ta;
+        s2[2 * c + 1] += tb * tb;
+      }
+    double v[4];
+    if (dead) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = 0.;
+    } else {
+      radial_fast_n<OP, 4>(s2, fp, v);
     }
-    double va = radial_fast<OP>(sa, fp);
-    double vb = radial_fast<OP>(sb, fp);
     if (fp.has_noise) {  // lhs + rhs with rhs = noise (0 when not measurements / not equal)
-      va = va + ((noise_on && ea) ? fp.noise_var : 0.);
-      vb = vb + ((noise_on && eb) ? fp.noise_var : 0.);
+      bool e[4] = {false, false, false, false};
+      bool maybe = false;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const long long yi = yid[cslot + c];
+        maybe = maybe || (have_ids ? (ida == yi || idb == yi) : (s2[2 * c] == 0. || s2[2 * c + 1] == 0.));
+      }
+      if (noise_on && __any(maybe)) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          bool ea = true, eb = true;
+#pragma unroll
+          for (int d = 0; d < DIMP; ++d) {
+            ea = ea && (xa[d] == yv[c][d]);
+            eb = eb && (xb[d] == yv[c][d]);
+          }
+          if (have_ids) {
+            ea = ida == yid[cslot + c];
+            eb = idb == yid[cslot + c];
+          }
+          e[2 * c] = ea;
+          e[2 * c + 1] = eb;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = v[q] + (e[q] ? fp.noise_var : 0.);
     }
-    if (diag_add) {
-      if (ra == col) va += diag_add[col];
-      if (rb == col) vb += diag_add[col];
-    }
-    // only entries that are stored count (padding rows of an edge tile are zero
-    // vectors: the angular metric makes NaN out of them)
-    saw_nan = saw_nan || (ra < X.n && va != va) || (rb < X.n && vb != vb);
-    double *dst = out + col * ld + ra;
-    if (rb < X.n) {
-      if (wide) *reinterpret_cast<double2 *>(dst) = make_double2(va, vb);
-      else { dst[0] = va; dst[1] = vb; }
-    } else if (ra < X.n) {
-      dst[0] = va;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c == 1 && !two) break;
+      const long long cc = col + c;
+      double va = v[2 * c], vb = v[2 * c + 1];
+      if (diag_add) {
+        if (ra == cc) va += diag_add[cc];
+        if (rb == cc) vb += diag_add[cc];
+      }
+      // only entries that are stored count (padding rows of an edge tile are zero
+      // vectors: the angular metric makes NaN out of them)
+      saw_nan = saw_nan || (ra < X.n && va != va) || (rb < X.n && vb != vb);
+      double *dst = out + cc * ld + ra;
+      if (rb < X.n) {
+        if (wide) *reinterpret_cast<double2 *>(dst) = make_double2(va, vb);  // (non-temporal stores measured in round 6: no difference)
+        else { dst[0] = va; dst[1] = vb; }
+      } else if (ra < X.n) {
+        dst[0] = va;
+      }
     }
   }
   if (saw_nan && nan_flag) atomicOr(nan_flag, 1);

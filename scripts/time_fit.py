@@ -38,8 +38,12 @@ for n in [int(a) for a in sys.argv[1:]] or [16384]:
     fit()
     st = [ctx.stage_ms(i) for i in range(6)]
     ctx.set_profiling(False)
+    info = np.empty(n)
+    hh = C.c_void_p()
+    assert lib.agp_fit_create(ctx._h, kh, C.byref(feats), C.c_void_p(y_d.ptr), None, C.byref(hh), C.c_void_p(info.ctypes.data), None) == 0
+    lib.agp_fit_destroy(hh)
     ts.sort()
     print(f"N={n}: best {1e3 * ts[0]:.3f} ms, median {1e3 * ts[len(ts) // 2]:.3f} ms ({reps} fits); stages gram {st[0]:.3f} factor {st[1]:.3f} "
-          f"backsub {st[2]:.3f}; bulk launches {st[4]:.0f} x {st[3] / max(st[4], 1):.4f} ms = {st[5] / max(st[3], 1e-9) / 1e9:.2f} TFLOP/s", flush=True)
+          f"backsub {st[2]:.3f}; sum(information) {float(info.sum()):.15e}; bulk launches {st[4]:.0f} x {st[3] / max(st[4], 1):.4f} ms = {st[5] / max(st[3], 1e-9) / 1e9:.2f} TFLOP/s", flush=True)
     x_d.free()
     y_d.free()
