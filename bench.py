@@ -79,6 +79,15 @@ def _oracle_cflags():
     return "unknown"
 
 
+def _hip_runtimes_loaded():
+    """distinct libamdhip64 shared objects mapped into this process (1 = the library's own; torch.cuda would add its wheel's)"""
+    try:
+        with open("/proc/self/maps") as f:
+            return len({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    except OSError:
+        return -1
+
+
 def _cpu_quota_cores():
     """cores this process may use: the smaller of its affinity mask and its cgroup CPU quota (the boxes of the pool show
     256 hardware threads and a quota of 16: `cpu.max` = "1600000 100000")"""
@@ -1104,7 +1113,7 @@ def run_rank(args):
                          "max_step_index": int(np.argmax(step_walls)),
                          "wall_minus_stages_ms": out["roofline"]["wall_minus_stages_ms"],
                          "roofline_frac": out["roofline"]["frac"], "avg_launch_ms": out["roofline"]["avg_launch_ms"],
-                         "hip_runtimes_in_process": 1}
+                         "hip_runtimes_in_process": _hip_runtimes_loaded()}
         cb = out.get("cpu_baseline") or {}
         if cb.get("value"):
             lo, hi = cb.get("range_fits_per_sec", [cb["value"], cb["value"]])
