@@ -1644,12 +1644,18 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
   // device scratch behind the features: the copy table and the Gram table of the batched launches
   void *tables = nullptr;
   const size_t copy_bytes = (sizeof(CopyItem) * copies.size() + 15) / 16 * 16;
-  const size_t table_bytes = copy_bytes + gram_batch_table_bytes(count);
+  const size_t gram_bytes = (gram_batch_table_bytes(count) + 15) / 16 * 16;
+  // (fused panel launches for batches whose workgroups fit on the chip at once: they publish z through a slab of their own)
+  const bool lookahead = (double)count * (double)n * (double)n >= 6e7 && n > 2 * NBO;
+  const bool fused_panels = !lookahead && batched_fused_fits(ctx, n, count);
+  const size_t zpub_bytes = fused_panels ? sizeof(double) * (size_t)count * (size_t)np2 : 0;
+  const size_t table_bytes = copy_bytes + gram_bytes + zpub_bytes;
   if (dev_malloc(&tables, table_bytes) != hipSuccess) { (void)hipGetLastError(); tables = nullptr; }
   struct FreeTables { void *p; ~FreeTables() { if (p) (void)dev_free(p); } } free_tables{tables};
   // (both tables are built in the context's pinned staging area: no synchronisation between the uploads and the launches
   // that read them - the two mid-call synchronisations of round 5 were ~4 % of a batch of 256 fits of N = 512)
-  char *pinned = tables ? static_cast<char *>(host_stage(ctx, table_bytes)) : nullptr;
+  char *pinned = tables ? static_cast<char *>(host_stage(ctx, copy_bytes + gram_bytes)) : nullptr;
+  double *zpub = (tables && fused_panels) ? reinterpret_cast<double *>(static_cast<char *>(tables) + copy_bytes + gram_bytes) : nullptr;
   if (!copies.empty()) {
     if (tables) {
       const void *src = copies.data();
@@ -1669,6 +1675,10 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
     PrepArgs prep;
     prep.fill(logsum, 0ull, 3 * cp2);  // log sums and flags
     if (coop) prep.sentinel(alpha, count * np2);
+    if (zpub) {  // the hand-over buffers of the fused panel launches: every tile image and every z slot of the batch
+      prep.sentinel(invd, count * stride_I);
+      prep.sentinel(zpub, count * np2);
+    }
     launch_prep(s, prep);
   }
   {
@@ -1698,10 +1708,10 @@ int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *ker
     }
   }
   // (two streams once the trailing updates of the batch are long enough to hide the panel chain behind)
-  if ((double)count * (double)n * (double)n >= 6e7 && n > 2 * NBO)
+  if (lookahead)
     factor_lower_batched_lookahead(ctx, A, stride_A, n, lda, invd, stride_I, z, np2, count, flags, logsum, 4);
   else
-    factor_lower_batched(s, A, stride_A, n, lda, invd, stride_I, z, np2, count, flags, logsum, 4);
+    factor_lower_batched(s, A, stride_A, n, lda, invd, stride_I, z, np2, count, flags, logsum, 4, zpub, np2);
   // information = L^-T (L^-1 y), gp.hpp:68
   if (coop) {
     backward_solve_coop(s, A, n, lda, invd, z, alpha, flags, nullptr, count, stride_A, stride_I, np2, np2, 4);

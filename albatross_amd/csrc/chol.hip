@@ -53,7 +53,7 @@ struct PotrfArgs {
   int *flags;
   double *scalars;
   // batched launches (blockIdx.y = batch entry): element offsets per entry; all 0 = not batched
-  long long batch_A = 0, batch_img = 0, batch_y = 0, batch_scalars = 0, batch_flags = 0;
+  long long batch_A = 0, batch_img = 0, batch_y = 0, batch_scalars = 0, batch_flags = 0, batch_zpub = 0;
   // fused panel kernel only: z of this block is also PUBLISHED here (device-scope stores) for the workgroups that solve
   // the rows below in the same launch; `below` = number of those rows
   double *zpub = nullptr;
@@ -830,6 +830,15 @@ template <bool UPD>
 __global__ __launch_bounds__(256, 2) void panel_fused_kernel(PotrfArgs p) {
   __shared__ double T[POTRF_LDS_DOUBLES];
   static_assert(POTRF_LDS_DOUBLES >= 2 * 64 * TRP, "the trailing-update workgroups stage their operands in T");
+  if (!UPD && blockIdx.y > 0) {  // batched fused panels (factor_lower_batched): blockIdx.y = problem
+    const long long b = blockIdx.y;
+    p.A += b * p.batch_A;
+    p.img += b * p.batch_img;
+    if (p.y) p.y += b * p.batch_y;
+    if (p.zpub) p.zpub += b * p.batch_zpub;
+    if (p.scalars) p.scalars += b * p.batch_scalars;
+    if (p.flags) p.flags += b * p.batch_flags;
+  }
   if (UPD && blockIdx.x >= p.trail_first) {
     if (blockIdx.x >= p.hold_index && blockIdx.x < p.hold_index + p.hold_count) {
       // placeholder: idle in the slot next to workgroup 0 until the last tile of the image is out
@@ -1430,10 +1439,21 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
 // The blocking of factor_lower without its streams: outer blocks of 512 columns whose panels are left-looking (one
 // product of depth <= 384 brings a panel up to date), then ONE trailing update of depth 512 for all problems - with a
 // handful of problems that launch fills the chip, and the 27-30 us of a POTRF are shared by all of them.
+// zpub (optional, with y): count x stride_zpub doubles; together with the tile images it must enter SENTINEL-filled - then
+// every panel is ONE fused launch (panel_fused_kernel<false>, blockIdx.y = problem: the rows below are solved as the image
+// appears) instead of POTRF -> TRSM.  For batches whose workgroups fit on the chip at once (batched_fused_fits): the row
+// workgroups hold their slots for the whole POTRF.
+bool batched_fused_fits(agp_context *ctx, long long n, long long count) {
+  if (!ctx->tune.panel_fused || n <= NB) return false;
+  const long long per_problem = 1 + (n - NB + 63) / 64;
+  return count * per_problem <= step_slots(ctx);
+}
+
 void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long long n, long long lda, double *invd,
                           long long stride_invd, double *y, long long stride_y, long long count, int *flags,
-                          double *logsum, long long stride_flags) {
+                          double *logsum, long long stride_flags, double *zpub, long long stride_zpub) {
   if (count <= 0 || n <= 0) return;
+  const bool fused = zpub != nullptr && y != nullptr;
   for (long long K0 = 0; K0 < n; K0 += NBO) {
     const long long kend = (K0 + NBO < n) ? K0 + NBO : n;
     for (long long k = K0; k < kend; k += NB) {
@@ -1449,8 +1469,15 @@ void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long lon
       p.y = y ? y + k : nullptr;
       p.flags = flags; p.scalars = logsum;
       p.batch_A = stride_A; p.batch_img = stride_invd; p.batch_y = stride_y; p.batch_scalars = 1; p.batch_flags = stride_flags;
-      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)count), dim3(256), 0, s, p);
       const long long below = n - (k + nbk);
+      if (fused) {
+        p.zpub = zpub + k;
+        p.batch_zpub = stride_zpub;
+        p.below = below > 0 ? below : 0;
+        hipLaunchKernelGGL(panel_fused_kernel<false>, dim3((unsigned)(1 + (p.below + 63) / 64), (unsigned)count), dim3(256), 0, s, p);
+        continue;
+      }
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)count), dim3(256), 0, s, p);
       if (below <= 0) continue;
       TrsmArgs t;
       t.img = p.img;

@@ -269,7 +269,9 @@ void forward_solve_mat(hipStream_t s, const double *A, long long n, long long ld
 // B (n x m, ldb) <- L^-T B
 void factor_lower_batched(hipStream_t s, double *A, long long stride_A, long long n, long long lda, double *invd,
                           long long stride_invd, double *y, long long stride_y, long long count, int *flags,
-                          double *logsum, long long stride_flags = 0);
+                          double *logsum, long long stride_flags = 0, double *zpub = nullptr, long long stride_zpub = 0);
+// may a batch of `count` n x n problems use the fused panel launches of factor_lower_batched (zpub != nullptr)?
+bool batched_fused_fits(agp_context *ctx, long long n, long long count);
 void factor_lower_batched_lookahead(agp_context *ctx, double *A, long long stride_A, long long n, long long lda, double *invd,
                                     long long stride_invd, double *y, long long stride_y, long long count, int *flags,
                                     double *logsum, long long stride_flags = 0);
