@@ -1429,6 +1429,21 @@ int agp_nll(agp_context *c, const agp_kernel *k, const agp_features *x, const do
   return st;
 }
 
+// `bytes` of the context's pinned staging area (common.h: h_stage), grown on demand; nullptr if it cannot be had (the
+// callers then stage through pageable memory and synchronise once).  The previous contents are dead: every user ends its
+// call with a synchronisation of the stream that read them.
+static void *host_stage(agp_context *ctx, size_t bytes) {
+  if (ctx->h_stage_bytes < bytes) {
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    ctx->h_stage_bytes = 0;
+    const size_t want = (bytes + 65535) / 65536 * 65536;
+    if (hipHostMalloc(&ctx->h_stage, want) != hipSuccess) { (void)hipGetLastError(); ctx->h_stage = nullptr; return nullptr; }
+    ctx->h_stage_bytes = want;
+  }
+  return ctx->h_stage;
+}
+
 // ---- tuner objective batching ---------------------------------------------------------
 // The negative log likelihoods of `count` parameter vectors of one model on one dataset, in lock step:
 // what compute_gradient (tune/finite_difference.hpp:20-94) and the ModelTuner objective
@@ -1452,12 +1467,16 @@ int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, c
   const long long lda = factor_ld(n), nblk = (n + NB - 1) / NB, np2 = round_up(n, 2);
   const long long stride_A = lda * n, stride_I = nblk * (36 * MB * MB);
   hipStream_t s = ctx->stream;
-  // workspace: [A slabs | tile images | y slabs | yvar | logsum | quad]
+  // workspace: [A slabs | tile images | y slabs | yvar | logsum | quad | z slots of the fused panel launches | Gram table]
+  const bool fused_panels = batched_fused_fits(ctx, n, count);
+  const size_t table_elems = (gram_batch_table_bytes(count) + 7) / 8;
   const size_t elems = (size_t)count * ((size_t)stride_A + (size_t)stride_I + (size_t)np2) + (size_t)np2 +
-                       2 * (size_t)round_up(count, 2);
+                       2 * (size_t)round_up(count, 2) + (fused_panels ? (size_t)count * (size_t)np2 : 0) + table_elems;
   if ((st = ensure_ws(ctx, &ctx->ws_A, &ctx->ws_A_bytes, sizeof(double) * elems)) != AGP_OK) return st;
   double *A = ctx->ws_A, *invd = A + (size_t)count * (size_t)stride_A, *ys = invd + (size_t)count * (size_t)stride_I;
   double *yvar_d = ys + (size_t)count * (size_t)np2, *logsum = yvar_d + np2, *quad = logsum + round_up(count, 2);
+  double *zpub = fused_panels ? quad + round_up(count, 2) : nullptr;
+  void *table = quad + round_up(count, 2) + (fused_panels ? (size_t)count * (size_t)np2 : 0);
   const int loc = features[0]->location;
   const hipMemcpyKind kind = loc == AGP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   for (int b = 0; b < count; ++b)
@@ -1465,8 +1484,16 @@ int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, c
                                       kind, s));
   if (y_var) AGP_HIP_CHECK(ctx, hipMemcpyAsync(yvar_d, y_var, sizeof(double) * (size_t)n, kind, s));
   if (loc == AGP_HOST) AGP_HIP_CHECK(ctx, hipStreamSynchronize(s));
-  AGP_HIP_CHECK(ctx, hipMemsetAsync(logsum, 0, sizeof(double) * (size_t)round_up(count, 2), s));
-  AGP_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int), s));
+  {  // one preparation launch: log sums and flags zeroed, the hand-over buffers of the fused panel launches sentinel-filled
+    PrepArgs prep;
+    prep.fill(logsum, 0ull, round_up(count, 2));
+    prep.fill(ctx->d_flags, 0ull, 2);
+    if (zpub) {
+      prep.sentinel(invd, count * stride_I);
+      prep.sentinel(zpub, count * np2);
+    }
+    launch_prep(s, prep);
+  }
   std::vector<DeviceFeatures> dxs((size_t)count);
   const agp_features *last = nullptr;
   int last_b = -1;
@@ -1490,12 +1517,10 @@ int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, c
   bool gram_done = false;
   if (st == AGP_OK && count > 1) {  // all Gram matrices in ONE launch when the trees share a fast path (gram.hip)
     std::vector<const double *> diag((size_t)count, y_var ? yvar_d : nullptr);
-    void *table = nullptr;
-    if (dev_malloc(&table, gram_batch_table_bytes(count)) == hipSuccess) {
-      gram_done = launch_gram_batch(s, count, hprogs.data(), views.data(), outs.data(), lda, y_var ? diag.data() : nullptr, nullptr, table);
-      if (gram_done) (void)hipStreamSynchronize(s);  // (the table is read by the launch)
-      (void)dev_free(table);
-    } else (void)hipGetLastError();
+    // (the descriptor table lives in the workspace and is uploaded from the context's pinned staging area: no allocation,
+    // no synchronisation between the upload and the launch)
+    gram_done = launch_gram_batch(s, count, hprogs.data(), views.data(), outs.data(), lda, y_var ? diag.data() : nullptr, nullptr, table,
+                                  host_stage(ctx, gram_batch_table_bytes(count)));
   }
   for (int b = 0; b < count && st == AGP_OK && !gram_done; ++b) {
     const DevProgram *dprog = nullptr;
@@ -1504,7 +1529,7 @@ int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, c
                 &kernels[b]->prog);
   }
   if (st == AGP_OK) {
-    factor_lower_batched(s, A, stride_A, n, lda, invd, stride_I, ys, np2, count, ctx->d_flags, logsum);
+    factor_lower_batched(s, A, stride_A, n, lda, invd, stride_I, ys, np2, count, ctx->d_flags, logsum, 0, zpub, np2);
     launch_coldot(s, ys, np2, ys, np2, n, count, quad, -1.0, nullptr);  // z_b^T z_b, z_b = L_b^-1 y_b
     std::vector<double> h(2 * (size_t)round_up(count, 2));
     hipError_t e = hipMemcpyAsync(h.data(), logsum, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s);
@@ -1524,21 +1549,6 @@ int agp_nll_batch(agp_context *c, int count, const agp_kernel *const *kernels, c
 // (benchmarks/bench_predict.cc:20-40, the tuner loop tune/tune.hpp:276-290) - ONE fit is bound by the latency of its
 // 128 serial pivots per panel (27-30 us per POTRF, config 2: 0.14 of the MFMA peak); a batch shares that latency and
 // fills the chip with the trailing updates of all problems (factor_lower_batched).
-// `bytes` of the context's pinned staging area (common.h: h_stage), grown on demand; nullptr if it cannot be had (the
-// callers then stage through pageable memory and synchronise once).  The previous contents are dead: every user ends its
-// call with a synchronisation of the stream that read them.
-static void *host_stage(agp_context *ctx, size_t bytes) {
-  if (ctx->h_stage_bytes < bytes) {
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    ctx->h_stage = nullptr;
-    ctx->h_stage_bytes = 0;
-    const size_t want = (bytes + 65535) / 65536 * 65536;
-    if (hipHostMalloc(&ctx->h_stage, want) != hipSuccess) { (void)hipGetLastError(); ctx->h_stage = nullptr; return nullptr; }
-    ctx->h_stage_bytes = want;
-  }
-  return ctx->h_stage;
-}
-
 int agp_fit_create_batch(agp_context *c, int count, const agp_kernel *const *kernels, const agp_features *const *features,
                          const double *y, int64_t ldy, const double *y_var, int64_t ldv, agp_fit **out, double *information,
                          int64_t ldi, double *log_det, int *status) {
