@@ -207,7 +207,8 @@ __device__ __forceinline__ void radial_fast_n(const double (&s2)[NT], const Fast
 
 template <int DIMP, int OP>
 __device__ __forceinline__ void gram_fast_body(const FastParams &fp, FeatView X, FeatView Y, int lower_only, double *out, long long ld,
-                                               const double *diag_add, int *nan_flag, long long blk_rows, long long blk_stride) {
+                                               const double *diag_add, int *nan_flag, long long blk_rows, long long blk_stride,
+                                               long long tile_r = -1, long long tile_c = -1) {
   __shared__ double xs[DIMP][TM], ys[DIMP][TN];
   __shared__ long long xid[TM], yid[TN];
   if (blk_rows > 0) {  // blockIdx.z = one diagonal block of a block-diagonal Gram matrix (launch_gram_blocks)
@@ -219,8 +220,8 @@ __device__ __forceinline__ void gram_fast_body(const FastParams &fp, FeatView X,
     out += z * blk_stride;
     if (diag_add) diag_add += z * blk_rows;
   }
-  const long long row0 = (long long)blockIdx.x * TM;
-  const long long col0 = (long long)blockIdx.y * TN;
+  const long long row0 = (tile_r >= 0 ? tile_r : (long long)blockIdx.x) * TM;
+  const long long col0 = (tile_c >= 0 ? tile_c : (long long)blockIdx.y) * TN;
   if (lower_only && col0 > row0 + TM - 1) return;
   const bool have_ids = X.ids != nullptr && Y.ids != nullptr;
   for (int t = threadIdx.x; t < TM + TN; t += GRAM_THREADS) {
@@ -352,8 +353,14 @@ struct GramBatchItem {
 template <int DIMP, int OP>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_fast_batch_kernel(const GramBatchItem *__restrict__ items, int lower_only, long long ld) {
   const GramBatchItem it = items[blockIdx.z];
-  if ((long long)blockIdx.x * TM >= it.X.n || (long long)blockIdx.y * TN >= it.X.n) return;
-  gram_fast_body<DIMP, OP>(it.fp, it.X, it.X, lower_only, it.out, ld, it.diag_add, it.nan_flag, 0, 0);
+  // blockIdx.x = index of a tile ON OR BELOW the diagonal, row tile by row tile (row tile r holds the column tiles
+  // 0 .. (r + 1) TM / TN - 1): the launch has no workgroups for the upper triangle - at N = 512 a batch of 256 problems
+  // started 16384 workgroups of which 6144 returned at once, and the dispatcher's ~20 ns per workgroup showed in the launch
+  constexpr long long PER = TM / TN;
+  long long r = 0, left = blockIdx.x;
+  while (left >= (r + 1) * PER) { left -= (r + 1) * PER; ++r; }
+  if (r * TM >= it.X.n || left * TN >= it.X.n) return;
+  gram_fast_body<DIMP, OP>(it.fp, it.X, it.X, lower_only, it.out, ld, it.diag_add, it.nan_flag, 0, 0, r, left);
 }
 
 // Does the program have one of the fast-path shapes?
@@ -760,7 +767,8 @@ bool launch_gram_batch(hipStream_t s, long long count, const DevProgram *const *
     return false;
   }
   if (!host_stage) (void)hipStreamSynchronize(s);  // (pageable source: the vector goes out of scope; a pinned stage outlives the launch)
-  dim3 grid((unsigned)((nmax + TM - 1) / TM), (unsigned)((nmax + TN - 1) / TN), (unsigned)count), block(GRAM_THREADS);
+  const long long rt = (nmax + TM - 1) / TM;  // row tiles; the lower tiles of row tile r: (r + 1) TM / TN
+  dim3 grid((unsigned)(rt * (rt + 1) / 2 * (TM / TN)), 1u, (unsigned)count), block(GRAM_THREADS);
   auto *tab = static_cast<const GramBatchItem *>(table_dev);
 #define AGP_GB(D, O) hipLaunchKernelGGL((gram_fast_batch_kernel<D, O>), grid, block, 0, s, tab, 1, ld)
 #define AGP_GB_DIM(D)                                                        \
