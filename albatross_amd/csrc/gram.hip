@@ -339,6 +339,23 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_fast_kernel(FastParams fp, 
   gram_fast_body<DIMP, OP>(fp, X, Y, lower_only, out, ld, diag_add, nan_flag, blk_rows, blk_stride);
 }
 
+// The lower triangle of ONE symmetric Gram matrix with workgroups for the tiles on or below the diagonal only (blockIdx.x =
+// index of such a tile, row tile by row tile as in gram_fast_batch_kernel below): at N = 16384 the rectangular grid starts
+// 65536 workgroups of which 32256 return at once.
+template <int DIMP, int OP>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_fast_tri_kernel(FastParams fp, FeatView X, double *out, long long ld,
+                                                                     const double *diag_add, int *nan_flag) {
+  constexpr long long PER = TM / TN;
+  const long long idx = blockIdx.x;
+  // tiles before row tile r: PER r (r + 1) / 2
+  long long r = (long long)((sqrt(1. + 8. * (double)idx / (double)PER) - 1.) * 0.5);
+  while (r > 0 && PER * r * (r + 1) / 2 > idx) --r;
+  while (PER * (r + 1) * (r + 2) / 2 <= idx) ++r;
+  const long long c = idx - PER * r * (r + 1) / 2;
+  if (c * TN >= X.n) return;
+  gram_fast_body<DIMP, OP>(fp, X, X, 1, out, ld, diag_add, nan_flag, 0, 0, r, c);
+}
+
 // `count` symmetric Gram matrices of one SHAPE (same fast-path operator, same DIMP) but their own parameters and
 // features in ONE launch: blockIdx.z = problem, described by a table in device memory (agp_fit_create_batch and
 // agp_nll_batch built them with one launch per problem: 256 launches are 1.2 ms of host enqueue time).
@@ -395,6 +412,25 @@ static bool launch_gram_fast_t(hipStream_t s, const FastParams &fp, int op, cons
   const long long xn = blk_rows > 0 ? blk_rows : X.n, yn = blk_rows > 0 ? blk_rows : Y.n;
   dim3 grid((unsigned)((xn + TM - 1) / TM), (unsigned)((yn + TN - 1) / TN), (unsigned)blk_count), block(GRAM_THREADS);
   const int lo = lower_only ? 1 : 0;
+  if (lower_only && blk_rows == 0 && blk_count == 1 && X.coords == Y.coords && X.ids == Y.ids && X.n == Y.n && X.meas == Y.meas) {
+    const long long rt = (X.n + TM - 1) / TM;
+    dim3 tri((unsigned)(rt * (rt + 1) / 2 * (TM / TN)));
+    switch (op) {
+    case AGP_OP_SQUARED_EXPONENTIAL:
+      hipLaunchKernelGGL((gram_fast_tri_kernel<DIMP, AGP_OP_SQUARED_EXPONENTIAL>), tri, block, 0, s, fp, X, out, ld, diag_add, nan_flag);
+      return true;
+    case AGP_OP_EXPONENTIAL:
+      hipLaunchKernelGGL((gram_fast_tri_kernel<DIMP, AGP_OP_EXPONENTIAL>), tri, block, 0, s, fp, X, out, ld, diag_add, nan_flag);
+      return true;
+    case AGP_OP_MATERN32:
+      hipLaunchKernelGGL((gram_fast_tri_kernel<DIMP, AGP_OP_MATERN32>), tri, block, 0, s, fp, X, out, ld, diag_add, nan_flag);
+      return true;
+    case AGP_OP_MATERN52:
+      hipLaunchKernelGGL((gram_fast_tri_kernel<DIMP, AGP_OP_MATERN52>), tri, block, 0, s, fp, X, out, ld, diag_add, nan_flag);
+      return true;
+    default: return false;
+    }
+  }
   switch (op) {
   case AGP_OP_SQUARED_EXPONENTIAL:
     hipLaunchKernelGGL((gram_fast_kernel<DIMP, AGP_OP_SQUARED_EXPONENTIAL>), grid, block, 0, s, fp, X, Y, lo, out, ld, diag_add, nan_flag, blk_rows, blk_stride);
