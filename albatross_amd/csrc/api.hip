@@ -193,6 +193,8 @@ static agp_context::Tuning read_tuning() {
   t.backsub_coop = flag("AGP_BACKSUB_COOP", true);
   t.backsub_coop_max = number("AGP_BACKSUB_COOP_MAX", BACKSUB_COOP_MAX_N);
   t.mixed_bf16 = flag("AGP_MIXED_BF16", true);
+  t.mixed_f16 = flag("AGP_MIXED_F16", true);
+  set_f16x2_kernel((int)number("AGP_F16X2_LDS_PAD", 8192), (int)number("AGP_F16X2_TERMS", 4));
   t.mixed_nbo = number("AGP_MIXED_NBO", 512);
   t.fp64_nbo = number("AGP_FP64_NBO", 0);
   set_bf16x3_kernel((int)number("AGP_BF16X3_KERNEL", 2), (int)number("AGP_BF16X3_LDS_PAD", 8192));
@@ -280,6 +282,7 @@ void agp_context_destroy(agp_context *c) {
   if (ctx->pool_K) (void)agp::dev_release(ctx->pool_K);
   if (ctx->ws_refine) (void)hipFree(ctx->ws_refine);
   if (ctx->p32) (void)hipFree(ctx->p32);
+  if (ctx->f16_scales) (void)hipFree(ctx->f16_scales);
   if (ctx->pool_L32) (void)hipFree(ctx->pool_L32);
   if (ctx->pool_aux) (void)agp::dev_release(ctx->pool_aux);
   if (ctx->pool_shard) (void)agp::dev_release(ctx->pool_shard);
@@ -1035,13 +1038,24 @@ static int fit_create_impl(agp_context *c, const agp_kernel *k, const agp_featur
     FIT_CHECK(hipMemcpyAsync(vec, fit->z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     launch_gram(s, dprog, xm, xm, /*symmetric=*/true, /*lower_only=*/true, Kfull, fit->lda, yvar_d, ctx->d_flags,
                 &k->prog);
-    // fp32-accurate products of the bulk updates: on the BF16 pipe from three bf16 planes per panel (gemm_bf16x3.hip), or
+    // fp32-accurate products of the bulk updates: on the 16-bit matrix pipe from split planes of the panel, or
     // - AGP_MIXED_BF16=0 - on the fp32 MFMA as in rounds 1-4
-    ctx->update_variant = ctx->tune.mixed_bf16 ? 4 : 3;
-    ctx->nbo_wide = (ctx->tune.mixed_bf16 && ctx->tune.mixed_nbo > 512 && ctx->tune.mixed_nbo % 128 == 0) ? ctx->tune.mixed_nbo : 0;
-    {  // two panel copies of (n rows + padding) x 512 (chol.hip, factor_lower): fp32, or three bf16 planes; kept in the context
-      const size_t want = ctx->tune.mixed_bf16 ? 2 * bf16x3_bytes(n, ctx->nbo_wide > 512 ? ctx->nbo_wide : 512)
-                                               : sizeof(float) * 2 * ((size_t)n + 16) * 512;
+    // default (round 6): from two fp16 planes of power-of-two-scaled rows (gemm_f16x2.hip); AGP_MIXED_F16=0: three bf16 planes
+    const bool planes16 = ctx->tune.mixed_bf16;
+    const bool f16 = planes16 && ctx->tune.mixed_f16;
+    ctx->update_variant = f16 ? 5 : (planes16 ? 4 : 3);
+    ctx->nbo_wide = (planes16 && ctx->tune.mixed_nbo > 512 && ctx->tune.mixed_nbo % 128 == 0) ? ctx->tune.mixed_nbo : 0;
+    if (f16 && ctx->f16_scales_n < n) {
+      if (ctx->f16_scales) (void)hipFree(ctx->f16_scales);
+      ctx->f16_scales = nullptr; ctx->f16_scales_n = 0;
+      const long long cap = round_up(n, 2);
+      if (hipMalloc(&ctx->f16_scales, sizeof(double) * 2 * (size_t)cap) == hipSuccess) ctx->f16_scales_n = cap;
+      else (void)hipGetLastError();  // (factor_lower falls back to the bf16 planes)
+    }
+    {  // two panel copies of (n rows + padding) x 512 (chol.hip, factor_lower): fp32, or three bf16 planes (two fp16 planes fit in the
+       // same space: the fall-back from fp16 to bf16 planes needs no second allocation); kept in the context
+      const size_t want = planes16 ? 2 * bf16x3_bytes(n, ctx->nbo_wide > 512 ? ctx->nbo_wide : 512)
+                                   : sizeof(float) * 2 * ((size_t)n + 16) * 512;
       if (ctx->p32_bytes < want) {
         if (ctx->p32) (void)hipFree(ctx->p32);
         ctx->p32 = nullptr; ctx->p32_bytes = 0;

@@ -283,7 +283,7 @@ __device__ __forceinline__ void micro_syrk_tile2(double *T, int ib0, int kb0, in
 
 constexpr int POTRF_LDS_DOUBLES = IMG_DOUBLES + 2 * MB * MB + NB;  // tiles | two inverse buffers | y
 
-// Cycle probe of the factoring workgroup (a -DAGP_POTRF_TIMING build only: scripts/build_probe_libs.sh makes one,
+// Cycle probe of the factoring workgroup (a -DAGP_POTRF_TIMING build only: scripts/build_variant.sh probe -DAGP_POTRF_TIMING makes one,
 // scripts/probe_potrf.py reads it through agp_debug_potrf_probe).  Slots [wave][stamp]: 0 = entry, 1 = block loaded and the
 // first micro tile factored, then per micro step jb = 0 .. 6 two stamps: 2 + 2 jb = this wave's own work of stage B done,
 // 3 + 2 jb = behind the barrier that ends the step; the last launch on the device wins.
@@ -1237,8 +1237,19 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
   bool have_u2 = false, p32_flip = false;
   long long K0 = 0, step_index = 0;
   const long long nbo_fixed = ctx->nbo_override;
-  const int variant = ctx->update_variant;
-  const long long nbo_wide = (variant == 4) ? ctx->nbo_wide : ctx->tune.fp64_nbo;  // (fp64: AGP_FP64_NBO, measurement switch)
+  int variant = ctx->update_variant;
+  // variant 5 (fp16 x 2 products, gemm_f16x2.hip): power-of-two row scales from the diagonal, BEFORE the first panel overwrites it
+  const double *rs16 = nullptr, *irs16 = nullptr;
+  if (variant == 5) {
+    if (ctx->f16_scales && ctx->f16_scales_n >= n) {
+      launch_f16x2_row_scales(sa, A, lda, n, ctx->f16_scales, ctx->f16_scales + ctx->f16_scales_n);
+      rs16 = ctx->f16_scales;
+      irs16 = ctx->f16_scales + ctx->f16_scales_n;
+    } else {
+      variant = 4;
+    }
+  }
+  const long long nbo_wide = (variant == 4 || variant == 5) ? ctx->nbo_wide : ctx->tune.fp64_nbo;  // (fp64: AGP_FP64_NBO, measurement switch)
   long long kend = K0 + pick_nbo(n, nbo_fixed, nbo_wide);
   if (kend > n) kend = n;
   // (agp_fit_create has already planned and launched the fills together with its own: prep_external)
@@ -1315,6 +1326,11 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
       p32_flip = !p32_flip;
       launch_convert_panel_bf16x3(sa, P, lda, n - kend, K, dst);
       P16 = dst;
+    } else if (variant == 5 && ctx->p32 && (n - kend) >= U1_F32_ABOVE && K % 32 == 0 && 2 * f16x2_bytes(n - kend, K) <= ctx->p32_bytes) {
+      unsigned short *dst = reinterpret_cast<unsigned short *>(ctx->p32) + (size_t)(p32_flip ? 1 : 0) * (ctx->p32_bytes / sizeof(unsigned short) / 2);
+      p32_flip = !p32_flip;
+      launch_convert_panel_f16x2(sa, P, lda, n - kend, K, rs16 + kend, dst);
+      P16 = dst;
     }
     (void)hipEventRecord(ctx->ev_a, sa);                       // P(j) done
     // Bulk-bound phase, fp64: U1(j) and U2(j) are ONE launch on the bulk stream - the whole trailing matrix, the tiles of
@@ -1354,16 +1370,19 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
     // U2(j - 1) must be done before anything of step j touches the next block column
     if (have_u2) (void)hipStreamWaitEvent(sa, ctx->ev_b, 0);
     // U1: block column [kend, next_end), all rows below its diagonal
-    if (P16) {
+    if (P16 && variant == 5) {
+      // mixed precision, fp16 x 2: U1 and the bulk update from the planes of this step's panel
+      launch_update_f16x2(sa, A + kend * lda + kend, lda, P16, n - kend, 0, 0, irs16 + kend, n - kend, next_end - kend, K);
+    } else if (P16) {
       // mixed precision, bf16 x 3: U1 and the bulk update from the planes of this step's panel
       launch_update_bf16x3(sa, A + kend * lda + kend, lda, P16, n - kend, 0, 0, n - kend, next_end - kend, K);
-    } else if ((variant == 3 || variant == 4) && (n - kend) >= U1_F32_ABOVE) {
+    } else if ((variant == 3 || variant == 4 || variant == 5) && (n - kend) >= U1_F32_ABOVE) {
       // mixed precision: U1 on the fp32 MFMA path like the bulk update (products of fp32-rounded panels, fp64
       // subtraction) while the block column is tall enough for 128 x 128 tiles to fill the chip
       launch_update_f32(sa, A + kend * lda + kend, lda, P, P, lda, n - kend, next_end - kend, K, P32, P32, ld32);
     } else if (step && n - kend > 1536) {
       // hand-over to the step tail: the whole trailing matrix, on the chain stream, alone on the chip - the bulk kernel
-      timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, n - kend, K, true, variant == 4 ? 3 : variant);
+      timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, n - kend, K, true, variant >= 4 ? 3 : variant);
     } else {
       timed_gemm(sa, timers, A + kend * lda + kend, lda, P, P, n - kend, next_end - kend, K, false);
     }
@@ -1395,9 +1414,13 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
         const long long tiles = (long long)ntr * (ntr + 1) / 2;
         long long olen = 0;
         const int *order = tiles >= 1024 ? bulk_tile_order(ntr, tiles, &olen) : nullptr;
-        launch_update_bf16x3(sb, A + next_end * lda + next_end, lda, P16, n - kend, next_end - kend, next_end - kend, M2, M2, K, order, olen);
+        if (variant == 5)
+          launch_update_f16x2(sb, A + next_end * lda + next_end, lda, P16, n - kend, next_end - kend, next_end - kend, irs16 + kend, M2, M2, K,
+                              order, olen);
+        else
+          launch_update_bf16x3(sb, A + next_end * lda + next_end, lda, P16, n - kend, next_end - kend, next_end - kend, M2, M2, K, order, olen);
       } else
-      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant == 4 ? 3 : variant,
+      timed_gemm(sb, timers, A + next_end * lda + next_end, lda, Q, Q, n - next_end, n - next_end, K, true, variant >= 4 ? 3 : variant,
                  P32 ? P32 + (next_end - kend) : nullptr, ld32);
       (void)hipEventRecord(ctx->ev_b, sb);
       have_u2 = true;

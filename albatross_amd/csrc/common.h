@@ -90,13 +90,15 @@ struct agp_context {
   // mixed-precision fits: two alternating fp32 copies of the current panel (rows x 512 each)
   float *p32 = nullptr;
   size_t p32_bytes = 0;
+  double *f16_scales = nullptr;  // fp16 x 2 products (gemm_f16x2.hip): row scales r and 1 / r, f16_scales_n doubles each
+  long long f16_scales_n = 0;
   // ... and the fp32 copy of the factor that preconditions their refinement
   float *pool_L32 = nullptr;
   size_t pool_L32_bytes = 0;
   // ... and one cached block of a fit's small buffers (agp_fit::aux_base)
   double *pool_aux = nullptr;
   size_t pool_aux_bytes = 0;
-  // bulk-update kernel of the next factorisation: -1 = default (fp64 MFMA), 3 = fp32 products, 4 = bf16 x 3 products (fp32 accuracy on the BF16 pipe)
+  // bulk-update kernel of the next factorisation: -1 = default (fp64 MFMA), 3 = fp32 products, 4 = bf16 x 3 products (fp32 accuracy on the BF16 pipe), 5 = fp16 x 2 products of scaled rows
   // (agp_fit_create_mixed sets and resets it around its factor_lower call)
   int update_variant = -1;
   long long nbo_override = 0;  // outer block width of the next factorisation (0 = default schedule)
@@ -130,6 +132,7 @@ struct agp_context {
     bool gram_sop = true;          // AGP_GRAM_SOP=0: covariance trees through the stack interpreter only
     long long fp64_nbo = 0;        // AGP_FP64_NBO: outer block width of the fp64 factorisation while > 8192 rows remain (0: 512)
     long long mixed_nbo = 512;     // AGP_MIXED_NBO: outer block width of the bf16 x 3 factorisation while > 8192 rows remain
+    bool mixed_f16 = true;         // AGP_MIXED_F16=0: the mixed-precision fit's products from three bf16 planes (round 5) instead of two fp16 planes
     bool mixed_bf16 = true;        // AGP_MIXED_BF16=0: the mixed-precision fit's products on the fp32 MFMA (rounds 1-4) instead of bf16 x 3
     long long backsub_coop_max = 2047;  // AGP_BACKSUB_COOP_MAX: largest n whose fit uses it (measurement switch)
     bool backsub_coop = true;      // AGP_BACKSUB_COOP=0: the fit's back substitution as a launch per block (rounds 1-4) instead of ONE launch
@@ -348,6 +351,7 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
                                long long ld32 = 0);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
+void read_bf16_probe(unsigned long long *out);   // gemm_bf16x3.hip: 8 words of a -DAGP_BF16_STAMPS build (zeros otherwise)
 void read_potrf_probe(unsigned long long *out);  // chol.hip: 4 x 32 cycle stamps of a -DAGP_POTRF_TIMING build (zeros otherwise)
 void launch_head_gate(hipStream_t s, const unsigned long long *done, unsigned long long expect, int *flags);  // chol.hip
 // the whole trailing matrix of an outer step in ONE launch, the next block column's tiles first and counted (gemm.hip)
@@ -362,6 +366,17 @@ void launch_convert_panel_bf16x3(hipStream_t s, const double *P, long long ldp, 
 void set_bf16x3_kernel(int choice, int lds_pad);  // 1: one workgroup per CU (first version), 2: two per CU (AGP_BF16X3_KERNEL)
 void launch_update_bf16x3(hipStream_t s, double *C, long long ldc, const unsigned short *planes, long long panel_rows, long long row_a,
                           long long row_b, long long M, long long N, long long K, const int *order = nullptr, long long order_len = 0);
+// The fp16 x 2 path (gemm_f16x2.hip): power-of-two row scales from the diagonal (rs, irs = 1 / rs: n doubles each), the
+// panel of one outer step as two fp16 planes of the scaled rows, and C -= P[row_a ..] P[row_b ..]^T from them (three
+// v_mfma_f32_16x16x32_f16 per block; irs belongs to the panel's row 0)
+size_t f16x2_bytes(long long rows, long long K);
+void launch_f16x2_row_scales(hipStream_t s, const double *A, long long lda, long long n, double *rs, double *irs);
+void launch_convert_panel_f16x2(hipStream_t s, const double *P, long long ldp, long long rows, long long K, const double *rs,
+                                unsigned short *planes);
+void set_f16x2_kernel(int lds_pad, int terms);  // AGP_F16X2_LDS_PAD, AGP_F16X2_TERMS (3, or 4: with h2 h2)
+void launch_update_f16x2(hipStream_t s, double *C, long long ldc, const unsigned short *planes, long long panel_rows, long long row_a,
+                         long long row_b, const double *irs, long long M, long long N, long long K, const int *order = nullptr,
+                         long long order_len = 0);
 // the XCD-aware order of the `tiles` first lower 128 x 128 tiles of a grid with ntr tile rows (gemm.hip; cached): nullptr = none
 const int *bulk_tile_order(int ntr, long long tiles, long long *len);
 // P32 (rows x K, ld32) = (float) P: the fp32 copy of one outer step's panel for the fp32-product kernels

@@ -606,6 +606,25 @@ AGP_DEBUG_API int agp_debug_mfma_shape(agp_context *ctx, int mode, int nacc, int
   return AGP_OK;
 }
 
+// fp16 x 2 planes of a host panel (gemm_f16x2.hip) with the row scales of a matrix whose diagonal is the squared row norm of
+// the panel - the bound a Cholesky factor's rows obey; *scales_out = [r | 1 / r] (M doubles each), *planes_out the planes
+static int make_f16x2_planes(agp_context *ctx, const double *hP, long long ldp, const double *dP, long long M, long long K,
+                             double **scales_out, unsigned short **planes_out) {
+  std::vector<double> diag((size_t)M, 0.);
+  for (long long k = 0; k < K; ++k)
+    for (long long i = 0; i < M; ++i) diag[(size_t)i] += hP[i + k * ldp] * hP[i + k * ldp];
+  double *d_diag = nullptr;
+  AGP_HIP_CHECK(ctx, hipMalloc(&d_diag, sizeof(double) * (size_t)M));
+  AGP_HIP_CHECK(ctx, hipMalloc(scales_out, sizeof(double) * 2 * (size_t)M));
+  AGP_HIP_CHECK(ctx, hipMalloc(planes_out, f16x2_bytes(M, K)));
+  AGP_HIP_CHECK(ctx, hipMemcpy(d_diag, diag.data(), sizeof(double) * (size_t)M, hipMemcpyHostToDevice));
+  launch_f16x2_row_scales(ctx->stream, d_diag, 0, M, *scales_out, *scales_out + M);
+  launch_convert_panel_f16x2(ctx->stream, dP, ldp, M, K, *scales_out, *planes_out);
+  AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_diag);
+  return AGP_OK;
+}
+
 // Bulk trailing update C (M x M, lower tiles) -= P P^T on host data.  variant 0: MFMA kernel,
 // 2: DPP-broadcast VALU kernel.
 AGP_DEBUG_API int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t ldc, const double *P, int64_t ldp, int64_t M,
@@ -637,6 +656,18 @@ AGP_DEBUG_API int agp_debug_trailing_update(agp_context *ctx, double *C, int64_t
     launch_update_bf16x3(ctx->stream, dC, ldc, planes, M, 0, 0, M, M, K, order, olen);
     AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(planes);
+  } else if (variant == 15) {  // the fp16 x 2 kernel on the two fp16 planes of the row-scaled panel, as the mixed fit runs it (gemm_f16x2.hip)
+    unsigned short *planes = nullptr;
+    double *scales = nullptr;
+    const int stp = make_f16x2_planes(ctx, P, ldp, dP, M, K, &scales, &planes);
+    if (stp != AGP_OK) return stp;
+    const int ntr = (int)((M + 127) / 128);
+    const long long tiles = (long long)ntr * (ntr + 1) / 2;
+    long long olen = 0;
+    const int *order = tiles >= 1024 ? bulk_tile_order(ntr, tiles, &olen) : nullptr;
+    launch_update_f16x2(ctx->stream, dC, ldc, planes, M, 0, 0, scales + M, M, M, K, order, olen);
+    AGP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(planes); (void)hipFree(scales);
   } else if (variant >= 20 && variant < 30) {
     // the MERGED update of factor_lower with head_cols = variant - 20: the launch on the bulk stream, the gate kernel on
     // the chain stream (it must end - the head counted itself completely - although the launch it waits for is on another
@@ -762,10 +793,18 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
     const long long tiles = (long long)ntr5 * (ntr5 + 1) / 2;
     if (tiles >= 1024) order = bulk_tile_order(ntr5, tiles, &olen);
   }
+  double *scales = nullptr;  // variant 6: the fp16 x 2 kernel on the row-scaled panel's planes
+  if (variant == 6) {
+    const int stp = make_f16x2_planes(ctx, (zero_mode == 1 || zero_mode == 2) ? hz.data() : h.data(), ld, dP, M, K, &scales, &planes);
+    if (stp != AGP_OK) return stp;
+    const long long tiles = (long long)ntr5 * (ntr5 + 1) / 2;
+    if (tiles >= 1024) order = bulk_tile_order(ntr5, tiles, &olen);
+  }
   for (int r = -2; r < reps && st == AGP_OK; ++r) {
     if (r == 0) AGP_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
     if (variant == 4) launch_trailing_update_as(3, ctx->stream, dC, ld, dP, dP, ld, M, K, nullptr, dP32, dP32, ld32);
     else if (variant == 5) launch_update_bf16x3(ctx->stream, dC, ld, planes, M, 0, 0, M, M, K, order, olen);
+    else if (variant == 6) launch_update_f16x2(ctx->stream, dC, ld, planes, M, 0, 0, scales + M, M, M, K, order, olen);
     else launch_trailing_update_as(variant, ctx->stream, dC, ld, dP, dP, ld, M, K);
   }
   AGP_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
@@ -777,6 +816,7 @@ AGP_DEBUG_API int agp_debug_time_trailing_update(agp_context *ctx, int64_t M, in
   (void)hipFree(dC); (void)hipFree(dP);
   if (dP32) (void)hipFree(dP32);
   if (planes) (void)hipFree(planes);
+  if (scales) (void)hipFree(scales);
   return st;
 }
 
@@ -903,6 +943,15 @@ AGP_DEBUG_API int agp_debug_potrf_probe(agp_context *ctx, unsigned long long *ou
   AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   AGP_HIP_CHECK(ctx, hipDeviceSynchronize());
   read_potrf_probe(out);
+  return AGP_OK;
+}
+
+// the phase cycle sums one workgroup of the LAST bf16 x 3 bulk launch left (a -DAGP_BF16_STAMPS build; zeros otherwise)
+AGP_DEBUG_API int agp_debug_bf16_probe(agp_context *ctx, unsigned long long *out) {
+  if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  AGP_HIP_CHECK(ctx, hipDeviceSynchronize());
+  read_bf16_probe(out);
   return AGP_OK;
 }
 

@@ -272,6 +272,26 @@ __global__ __launch_bounds__(256, 1) void trailing_update_bf16x3_kernel(Bf16Args
     }
 }
 
+// Cycle probe of the pair kernel (a -DAGP_BF16_STAMPS build only: scripts/build_variant.sh bf16_stamps -DAGP_BF16_STAMPS;
+// read through agp_debug_bf16_probe by scripts/probe_bf16x3.py).  Wave 0 of the workgroup in the middle of the grid sums,
+// over its K chunks, the shader cycles (s_memtime) of the four phases of a chunk - [0] barrier "stage free", [1] wait for
+// the global loads + the twelve LDS stores, [2] barrier "stage full", [3] fragment reads + 96 MFMAs (+ the issue of the next
+// chunk's loads) - and leaves [4] = cycles and [5] = 100 MHz ticks (s_memrealtime) of the whole loop, [6] = chunks, [7] = cycles of the epilogue (C read, subtract, write): the clock
+// the chip held is 100 MHz x [4] / [5].  Every stamp sits where the kernel waits for lgkmcnt(0) anyway.
+#ifdef AGP_BF16_STAMPS
+__device__ unsigned long long g_bf16_probe[8];
+#define AGP_BF_STAMP(var)                              \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    var = __builtin_amdgcn_s_memtime();                \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  } while (0)
+void read_bf16_probe(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_probe), sizeof(unsigned long long) * 8); }
+#else
+#define AGP_BF_STAMP(var) do { } while (0)
+void read_bf16_probe(unsigned long long *out) { for (int i = 0; i < 8; ++i) out[i] = 0; }
+#endif
+
 // ---- the same tile with TWO workgroups per CU ------------------------------------------------------------------
 // The kernel above keeps one workgroup per CU (two LDS stages, 122 KB; 128 registers of prefetched C): ONE wave per
 // SIMD, so every wait of that wave - the fragment reads in front of the MFMAs, the staging stores behind the global
@@ -305,11 +325,29 @@ __global__ __launch_bounds__(256, 2) void trailing_update_bf16x3_pair_kernel(Bf1
 
   const long long nk = g.K / BK;
   AGP_BF_LOAD(0);
+#ifdef AGP_BF16_STAMPS
+  unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0;
+  const unsigned long long loop_c0 = __builtin_amdgcn_s_memtime(), loop_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (long long kc = 0; kc < nk; ++kc) {
+    AGP_BF_STAMP(ta);
     if (kc > 0) __syncthreads();  // every wave has read chunk kc - 1 out of the stage
+    AGP_BF_STAMP(tb);
     AGP_BF_STORE_P(lds, SPLANE);
+#ifdef AGP_BF16_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);  // (the barrier below waits for the stores anyway)
+#endif
+    AGP_BF_STAMP(tc);
     __syncthreads();
+    AGP_BF_STAMP(td);
+#ifdef AGP_DIAG_BF16_NOMEM  // diagnostic build: every chunk re-reads chunk 0 (L2 hits) - the ceiling without the memory side
+    AGP_BF_LOAD((kc + 1 < nk ? 1 : 0) * chunk_stride);
+#else
     AGP_BF_LOAD((kc + 1 < nk ? kc + 1 : kc) * chunk_stride);  // (unconditional: a guarded load kept the staging registers in scratch)
+#endif
+#ifdef AGP_BF16_EARLY_LOADS
+    __builtin_amdgcn_sched_barrier(0);  // the loads of the next chunk stay in front of this chunk's MFMAs
+#endif
     v8bf fa[3][4], fb[3][4];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -331,23 +369,48 @@ __global__ __launch_bounds__(256, 2) void trailing_update_bf16x3_pair_kernel(Bf1
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][tj], fb[0][ti], a, 0, 0, 0);  // hi hi
         acc[tj][ti] = a;
       }
+#ifdef AGP_BF16_STAMPS
+    AGP_BF_STAMP(te);
+    ph0 += tb - ta; ph1 += tc - tb; ph2 += td - tc; ph3 += te - td;
+#endif
   }
+#ifdef AGP_BF16_STAMPS
+  if (blockIdx.x == gridDim.x / 2 && tid == 0) {
+    g_bf16_probe[0] = ph0; g_bf16_probe[1] = ph1; g_bf16_probe[2] = ph2; g_bf16_probe[3] = ph3;
+    g_bf16_probe[4] = __builtin_amdgcn_s_memtime() - loop_c0;
+    g_bf16_probe[5] = __builtin_amdgcn_s_memrealtime() - loop_r0;
+    g_bf16_probe[6] = (unsigned long long)nk;
+  }
+  const unsigned long long epi_c0 = __builtin_amdgcn_s_memtime();
+#endif
   // C -= acc (register r of accumulator (tj, ti): row 16 ti + ln of the quadrant, column 16 tj + 4 lg + r)
   if (i0 + GT <= g.M && j0 + GT <= g.N) {
     double *const cbase = g.C + (i0 + 64 * wr + ln) + (j0 + 64 * wc + 4 * lg) * g.ldc;
+#ifndef AGP_BF16_EPI
+#define AGP_BF16_EPI 1
+#endif
+    constexpr int EPI = AGP_BF16_EPI;  // accumulator columns (of four) whose C is in flight at a time
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj) {
-      double cv[4][4];
+    for (int t0 = 0; t0 < 4; t0 += EPI) {
+      double cv[EPI][4][4];
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
+      for (int e = 0; e < EPI; ++e)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cv[ti][r] = __builtin_nontemporal_load(&cbase[16 * ti + (long long)(16 * tj + r) * g.ldc]);
+        for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
+          for (int r = 0; r < 4; ++r) cv[e][ti][r] = __builtin_nontemporal_load(&cbase[16 * ti + (long long)(16 * (t0 + e) + r) * g.ldc]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          __builtin_nontemporal_store(cv[ti][r] - (double)acc[tj][ti][r], &cbase[16 * ti + (long long)(16 * tj + r) * g.ldc]);
+      for (int e = 0; e < EPI; ++e)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __builtin_nontemporal_store(cv[e][ti][r] - (double)acc[t0 + e][ti][r], &cbase[16 * ti + (long long)(16 * (t0 + e) + r) * g.ldc]);
     }
+#ifdef AGP_BF16_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) g_bf16_probe[7] = __builtin_amdgcn_s_memtime() - epi_c0;  // [7] = epilogue cycles
+#endif
     return;
   }
 #pragma unroll

@@ -602,7 +602,7 @@ static int sparse_fit_create_pivoted(agp_context *ctx, const agp_kernel *k, cons
   const DevProgram *dprog = nullptr;
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
   hipStream_t s = ctx->stream;
-  StageTimer stage(s, false);  // (development aid: prints the stage times of one fit)
+  StageTimer stage(s, getenv("AGP_SPARSE_TIMING") != nullptr);  // (development aid: prints the stage times of one fit)
   std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
   if (!f) return AGP_ERR_INVALID_ARGUMENT;
   f->ctx = ctx; f->m = m; f->inducing_nugget = inducing_nugget;
@@ -714,7 +714,7 @@ static int sparse_fit_create_fast(agp_context *ctx, agp_comm *comm, const agp_ke
   }
   const long long n = x->n, m = u->n;
   hipStream_t s = ctx->stream;
-  StageTimer stage(s, false);  // (development aid: prints the stage times of one fit)
+  StageTimer stage(s, getenv("AGP_SPARSE_TIMING") != nullptr);  // (development aid: prints the stage times of one fit)
   std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
   SparseScratch w;
   const long long ldm = factor_ld(m);
@@ -865,7 +865,7 @@ int agp_sparse_fit_update(agp_context *ctx, const agp_kernel *k, const agp_spars
   const DevProgram *dprog = nullptr;
   if ((st = device_program(ctx, k, &dprog)) != AGP_OK) return st;
   hipStream_t s = ctx->stream;
-  StageTimer stage(s, false);  // (development aid: prints the stage times of one fit)
+  StageTimer stage(s, getenv("AGP_SPARSE_TIMING") != nullptr);  // (development aid: prints the stage times of one fit)
   std::unique_ptr<agp_sparse_fit, void (*)(agp_sparse_fit *)> f(new (std::nothrow) agp_sparse_fit(), agp_sparse_fit_destroy);
   if (!f) return AGP_ERR_INVALID_ARGUMENT;
   f->ctx = ctx; f->m = m;

@@ -423,10 +423,10 @@ class GPFit(_DeviceSolver):
         return self._information
 
     # a mixed-precision factor (agp_fit_create_mixed): its log-determinant carries the rounding of the bulk products.
-    # MEASURED at N = 32768 (include/albatross_amd.h; tests/test_full_size_configs_gpu.py holds each figure): bf16 x 3 path
-    # 0.027 absolute on BASELINE config 4's covariance (inside the 2e-6 N log-likelihood bar), 0.14 = 4.3e-6 N on config 3's
-    # kernel (outside); fp32 fallback (AGP_MIXED_BF16=0) 1.3e-5 relative.  The bound depends on the covariance function, so
-    # reading it stays an explicit opt-in.
+    # MEASURED (include/albatross_amd.h; tests/test_full_size_configs_gpu.py holds each figure): default fp16 x 2 path 0.5e-6 N
+    # on BASELINE config 4's covariance at N = 32768, 1.9e-6 N on config 3's kernel - inside the 2e-6 N log-likelihood bar,
+    # the latter just; bf16 x 3 (AGP_MIXED_F16=0) 0.8e-6 N / 4.3e-6 N; fp32 fallback (AGP_MIXED_BF16=0) 1.3e-5 relative.
+    # The bound depends on the covariance function and is not proven for an arbitrary one, so reading it stays an explicit opt-in.
     mixed_precision = False
     accept_mixed_log_determinant = False
 
@@ -435,8 +435,8 @@ class GPFit(_DeviceSolver):
         if self.mixed_precision and not self.accept_mixed_log_determinant:
             raise AlbatrossAmdError(capi.AGP_ERR_UNSUPPORTED,
                                     "log_determinant of a mixed-precision factor carries the rounding of the bulk products "
-                                    "(measured 6e-7 ... 1.1e-6 relative on the bf16 x 3 path, 1.3e-5 on the fp32 fallback; whether "
-                                    "that meets the 2e-6 N bar depends on the covariance function): use model.log_likelihood "
+                                    "(measured 0.5e-6 N ... 1.9e-6 N on the default fp16 x 2 path, up to 4.9e-6 N on bf16 x 3, 1.9e-5 N on the fp32 "
+                                    "fallback; whether that meets the 2e-6 N bar depends on the covariance function): use model.log_likelihood "
                                     "(always fp64) or set fit.accept_mixed_log_determinant = True")
         v = C.c_double()
         self._ctx._check(self._ctx._lib.agp_fit_log_determinant(self._h, C.byref(v)), "log_determinant")

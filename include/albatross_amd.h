@@ -201,36 +201,41 @@ AGP_API int agp_fit_create(agp_context *ctx, const agp_kernel *k, const agp_feat
 /* Mixed-precision variant of agp_fit_create (BASELINE.json configs[3], SURVEY
  * section 8d config 4): the same Fit<GPFit> constructor (models/gp.hpp:61-69),
  * but the bulk trailing updates (and the next-block-column update) of the LL^T
- * form their products on the BF16 matrix pipe: every panel is split ONCE into
- * three bf16 planes (hi + mid + lo = the fp32 value), a product is the six
- * partial products above 2^-24 (six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32
- * block, csrc/gemm_bf16x3.hip), accumulated in fp32 inside one launch and
- * subtracted from the fp64 matrix; the panel chain, the matrix and every
- * accumulation between outer steps stay fp64.  (AGP_MIXED_BF16=0 selects the
- * older fallback: fp32-rounded panels on v_mfma_f32_16x16x4_f32.)  The information
+ * form their products on the 16-bit matrix pipe: every row is scaled by a power
+ * of two taken from the diagonal (|L[i, k]| <= sqrt(A[i, i])), every panel is split
+ * ONCE into two fp16 planes (h1 + h2 = the scaled value to 22 bits), a product is
+ * the four partial products (four v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block,
+ * each exact in fp32; csrc/gemm_f16x2.hip), accumulated in fp32 inside one launch,
+ * un-scaled exactly and subtracted from the fp64 matrix; the panel chain, the matrix
+ * and every accumulation between outer steps stay fp64.  (AGP_MIXED_F16=0 selects
+ * round 5's path, three bf16 planes and six products per block,
+ * csrc/gemm_bf16x3.hip; AGP_MIXED_BF16=0 the oldest fallback: fp32-rounded panels on
+ * v_mfma_f32_16x16x4_f32.)  The information
  * vector is then refined in fp64: conjugate gradients on the exact fp64 covariance,
  * preconditioned with that factor, until ||y - K a||_2 <= tolerance * ||y||_2,
  * `max_iterations` steps, or the fp64 floor of the system.  *iterations /
  * *residual (may be NULL) report the steps taken and the final relative residual.
- * What the result is good for (each line is held by a test at N = 32768,
- * tests/test_full_size_configs_gpu.py):
- *   information vector, predicted means: 1e-8 relative to the fp64 fit (refined) on both paths;
+ * What the result is good for (tests/test_full_size_configs_gpu.py and
+ * tests/test_mixed_precision_gpu.py hold each line; all figures MEASURED,
+ * profiles/r06/mixed_log_determinant_by_path.txt):
+ *   information vector, predicted means: 1e-8 relative to the fp64 fit (refined) on every path;
  *   predicted variances: 1e-4 relative (they come from the mixed factor);
- *   log_det, bf16 x 3 path, MEASURED: BASELINE config 4's covariance 0.027 absolute
- *     (5.8e-7 relative) - INSIDE the log-likelihood bar of the fp64 path (|nll error|
- *     <= 1e-6 N, i.e. |log_det error| <= 2e-6 N); config 3's kernel (SE(1,1) +
- *     noise(0.1)) 0.14 absolute = 4.3e-6 N (1.1e-6 relative) and Matern-5/2(2,1) +
- *     noise(0.1) at N = 5300 0.026 = 4.9e-6 N - OUTSIDE it.  The bound
- *     is a property of the covariance function (how much of log|K| sits in the
- *     rounded products), not of N alone;
+ *   log_det, default path: BASELINE config 4's covariance at N = 32768 0.017 absolute
+ *     = 0.5e-6 N; config 3's kernel (SE(1,1) + noise(0.1)) 0.062 = 1.9e-6 N at N = 32768
+ *     and 1.4e-6 N at N = 8192; Matern-5/2(2,1) + noise(0.1) at N = 5300 1.9e-6 N - all
+ *     INSIDE the log-likelihood bar of the fp64 path (|nll error| <= 1e-6 N, i.e.
+ *     |log_det error| <= 2e-6 N), the last three AT it: the bound is a property of the
+ *     covariance function (how much of log|K| sits in the fp32 accumulation), not of N
+ *     alone, and is not proven for an arbitrary one;
+ *   log_det, bf16 x 3 path: 0.8e-6 N on config 4, 4.3e-6 N / 4.9e-6 N on the other two - outside;
  *   log_det, fp32 fallback path: 1.3e-5 relative (0.6 absolute) on config 4 - outside.
  * Use agp_nll / an fp64 fit where the likelihood must meet the bar for an arbitrary
  * covariance; the host mirrors make reading log_det of a mixed fit an explicit opt-in.
  * The reference has no reduced-precision path; this one exists for problems where one
  * fp64 factorisation is too slow (N >= 32768).  Device memory next to the factor (kept
  * in the context between mixed fits): the exact covariance (8 N^2 B), an fp32 copy of
- * the factor for the preconditioner (4 N^2 B) and two panel copies (2 x 3 KB x N for
- * the bf16 planes). */
+ * the factor for the preconditioner (4 N^2 B), two panel copies (2 x 3 KB x N: room
+ * for the bf16 planes; the fp16 planes take 2 x 2 KB x N of it) and 16 N B of row scales. */
 AGP_API int agp_fit_create_mixed(agp_context *ctx, const agp_kernel *k, const agp_features *x,
                          const double *y, const double *y_var, int max_iterations,
                          double tolerance, agp_fit **out, double *information,
@@ -645,7 +650,10 @@ AGP_API int agp_set_profiling(agp_context *ctx, int enabled);
  *                            tiles first, counted; a one-wave gate kernel on the panel stream) instead of being a launch
  *                            of its own behind an event (default 8704; 0: the round-5 schedule)
  *   AGP_GRAM_SOP=0           covariance trees through the stack interpreter only (parity tests run both evaluators)
- *   AGP_MIXED_BF16=0         agp_fit_create_mixed forms its fp32-accurate products on the fp32 MFMA instead of bf16 x 3
+ *   AGP_MIXED_F16=0          agp_fit_create_mixed forms its products from three bf16 planes (round 5) instead of two fp16 planes
+ *   AGP_F16X2_TERMS=3        ... from two fp16 planes WITHOUT the h2 h2 product (3 % faster, log_det outside the bar: gemm_f16x2.hip)
+ *   AGP_F16X2_LDS_PAD=<b>    extra LDS bytes per workgroup of the fp16 x 2 kernel (default 8192: two per CU; 0: three)
+ *   AGP_MIXED_BF16=0         agp_fit_create_mixed forms its fp32-accurate products on the fp32 MFMA instead of the 16-bit planes
  *   AGP_BF16X3_KERNEL=1      ... with the first bf16 x 3 tile kernel (one workgroup per CU) instead of the pair kernel
  *   AGP_BF16X3_LDS_PAD=<b>   extra LDS bytes per workgroup of the pair kernel (default 8192: two per CU; 0: three)
  *   AGP_MIXED_NBO=<w>        outer block width of the mixed factorisation while > 8192 rows remain (default 512)

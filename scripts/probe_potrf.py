@@ -1,5 +1,5 @@
 """Cycle stamps of the factoring workgroup of the last panel launch (a -DAGP_POTRF_TIMING build of the two libraries, see
-scripts/build_probe_libs.sh): per micro step of the 128 x 128 POTRF, when each wave finished its own work and when the
+scripts/build_variant.sh probe -DAGP_POTRF_TIMING): per micro step of the 128 x 128 POTRF, when each wave finished its own work and when the
 barrier released them.  Wave 0: SYRK of the next diagonal tile + POTRF16 + INV16, waves 1-3: SYRK + y."""
 import ctypes as C
 import os

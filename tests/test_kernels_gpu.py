@@ -100,7 +100,7 @@ def test_gemm_nt_sub_prefetching_tiles(ctx, dbg, M, N, K, tri, akm, bkm):
     test_gemm_nt_sub(ctx, dbg, M, N, K, tri, akm, bkm)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 13, 14])
+@pytest.mark.parametrize("variant", [0, 3, 13, 14, 15])
 @pytest.mark.parametrize("M,K", [(5900, 128), (6016, 512), (700, 512), (1418, 96)])
 def test_trailing_update_large_tiles(ctx, dbg, M, K, variant):
     """Bulk updates of more than two rounds of 128 x 128 tiles: full rounds of prefetching tiles, the tiles of the partial
@@ -108,7 +108,9 @@ def test_trailing_update_large_tiles(ctx, dbg, M, K, variant):
     fp64 MFMA; 3: fp32 products of operands rounded while staged; 13: fp32 products of an fp32 copy of the panel
     (launch_convert_panel_f32) - the two must agree bit for bit; 14 (round 5): fp32-accurate products on the BF16 pipe from
     three bf16 planes of the panel (gemm_bf16x3.hip: hi + mid + lo, six partial products) - the same 2e-7 bar as the fp32
-    kernel (measured: both ~3e-8 of the scale), interior tiles with C prefetched and ragged / shallow ones without."""
+    kernel (measured: both ~3e-8 of the scale), interior tiles with C prefetched and ragged / shallow ones without; 15
+    (round 6): products from two fp16 planes of power-of-two-scaled rows (gemm_f16x2.hip: h1 + h2, three partial products,
+    scales from the rows' squared norms - the bound a Cholesky factor's rows obey), same bar."""
     rng = np.random.default_rng(M + K)
     ldc, ldp = M + 8, M + 10
     Cm = np.asfortranarray(rng.standard_normal((ldc, M)))
@@ -125,6 +127,29 @@ def test_trailing_update_large_tiles(ctx, dbg, M, K, variant):
         ref = Cm.copy(order="F")
         assert dbg.agp_debug_trailing_update(ctx._h, _p(ref), ldc, _p(P), ldp, M, K, 3) == 0
         assert np.array_equal(ref[:M][low], got[:M][low])
+
+
+@pytest.mark.parametrize("variant", [14, 15])
+def test_trailing_update_split_planes_badly_scaled_rows(ctx, dbg, variant):
+    """Rows of the panel between 1e-9 and 1e+9 times each other (a covariance matrix whose diagonal spans 36 orders of
+    magnitude): the error of every entry stays below 2e-7 of ITS OWN row and column scale, sum_k |P[i, k]| sum_k |P[j, k]|.
+    bf16 x 3 (14) has fp32's exponent range; fp16 x 2 (15) gets there through the power-of-two row scales - without them
+    the large rows would overflow fp16 and the small ones vanish."""
+    M, K = 1418, 256
+    rng = np.random.default_rng(variant)
+    ldc, ldp = M + 8, M + 10
+    rowscale = 10. ** rng.uniform(-9., 9., size=ldp)
+    P = np.asfortranarray(rng.standard_normal((ldp, K)) * rowscale[:, None])
+    # (entries of very different size inside a row too: every fourth column 1e-5 of the others)
+    P[:, ::4] *= 1e-5
+    Cm = np.asfortranarray(rng.standard_normal((ldc, M)) * np.outer(np.r_[rowscale[:M], np.ones(ldc - M)], rowscale[:M]))
+    want = Cm[:M] - P[:M] @ P[:M].T
+    got = Cm.copy(order="F")
+    assert dbg.agp_debug_trailing_update(ctx._h, _p(got), ldc, _p(P), ldp, M, K, variant) == 0
+    rs = np.abs(P[:M]).sum(axis=1)
+    rel = np.abs(got[:M] - want) / np.outer(rs, rs)
+    assert rel[np.tril_indices(M)].max() <= 2e-7
+    assert np.array_equal(got[M:], Cm[M:])
 
 
 @pytest.mark.parametrize("head_cols", [1, 4, 8])

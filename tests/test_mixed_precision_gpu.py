@@ -3,10 +3,11 @@ products in the bulk trailing updates, fp64 panel chain and accumulation, fp64 c
 information vector) against the oracle and against the all-fp64 fit.
 
 Stated tolerances: information vector and predicted means 1e-8 relative (the same as the fp64 path: the refinement
-runs to a 1e-12 relative residual); predictive variances 1e-4 relative; log-determinant on the default bf16 x 3 path:
-1e-5 N absolute here (measured: 4.9e-6 N on Matern-5/2 + noise at N = 5300, 4.3e-6 N on config 3's SE(1,1) + noise(0.1) at
-N = 32768 - both OUTSIDE the 2e-6 N log-likelihood bar of the fp64 path; only BASELINE config 4's covariance at its own size
-meets that bar, 0.8e-6 N, and tests/test_full_size_configs_gpu.py holds it there: include/albatross_amd.h, agp_fit_create_mixed)."""
+runs to a 1e-12 relative residual); predictive variances 1e-4 relative; log-determinant on the default path (fp16 x 2
+planes of scaled rows, four products: csrc/gemm_f16x2.hip): 4e-6 N absolute here (measured, profiles/r06/
+mixed_log_determinant_by_path.txt: 1.9e-6 N on Matern-5/2 + noise at N = 5300, 1.4e-6 N on config 3's SE(1,1) + noise(0.1) at
+N = 8192 - inside the 2e-6 N log-likelihood bar of the fp64 path, but close to it; BASELINE config 4's covariance at its own
+size: 0.5e-6 N, and tests/test_full_size_configs_gpu.py holds it and the other paths: include/albatross_amd.h, agp_fit_create_mixed)."""
 import ctypes as C
 
 import numpy as np
@@ -73,7 +74,7 @@ def test_mixed_fit_matches_oracle(ctx, n):
     with pytest.raises(ab.AlbatrossAmdError, match="mixed-precision factor"):  # opt-in: the fp32 rounding is in it
         fm.get_fit().log_determinant
     fm.get_fit().accept_mixed_log_determinant = True
-    assert abs(fm.get_fit().log_determinant - ofit.log_determinant) <= 1e-5 * n  # (measured 4.9e-6 n at n = 5300 on the Matern kernel: OUTSIDE the 2e-6 n bar of the fp64 path)
+    assert abs(fm.get_fit().log_determinant - ofit.log_determinant) <= 4e-6 * n  # (measured 1.9e-6 n at n = 5300 on the Matern kernel: at the 2e-6 n bar of the fp64 path)
 
 
 def test_mixed_fit_config4_kernel(ctx):
@@ -94,7 +95,7 @@ def test_mixed_fit_config4_kernel(ctx):
     assert rel(f64.get_fit().information, ofit.information) <= 1e-8
     assert rel(fmx.get_fit().information, ofit.information) <= 1e-8
     fmx.get_fit().accept_mixed_log_determinant = True
-    assert abs(fmx.get_fit().log_determinant - ofit.log_determinant) <= 1e-5 * n
+    assert abs(fmx.get_fit().log_determinant - ofit.log_determinant) <= 4e-6 * n
 
 
 def test_mixed_fit_large_property(ctx):
@@ -114,7 +115,7 @@ def test_mixed_fit_large_property(ctx):
     f64 = ab.gp_from_covariance(cov, context=ctx).fit(ab.RegressionDataset(x, y))
     assert rel(a, f64.get_fit().information) <= 1e-8
     fmx.get_fit().accept_mixed_log_determinant = True
-    assert abs(fmx.get_fit().log_determinant - f64.get_fit().log_determinant) <= 1e-5 * n  # (config 3's kernel)
+    assert abs(fmx.get_fit().log_determinant - f64.get_fit().log_determinant) <= 4e-6 * n  # (config 3's kernel: measured 1.4e-6 n)
 
 
 @pytest.mark.parametrize("n", [3072, 4608])
