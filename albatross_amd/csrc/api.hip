@@ -194,7 +194,7 @@ static agp_context::Tuning read_tuning() {
   t.backsub_coop_max = number("AGP_BACKSUB_COOP_MAX", BACKSUB_COOP_MAX_N);
   t.mixed_bf16 = flag("AGP_MIXED_BF16", true);
   t.mixed_f16 = flag("AGP_MIXED_F16", true);
-  set_f16x2_kernel((int)number("AGP_F16X2_LDS_PAD", 8192), (int)number("AGP_F16X2_TERMS", 4));
+  set_f16x2_kernel((int)number("AGP_F16X2_LDS_PAD", 8192), (int)number("AGP_F16X2_TERMS", 4), (int)number("AGP_F16X2_CHUNK", 32));
   t.mixed_nbo = number("AGP_MIXED_NBO", 512);
   t.fp64_nbo = number("AGP_FP64_NBO", 0);
   set_bf16x3_kernel((int)number("AGP_BF16X3_KERNEL", 2), (int)number("AGP_BF16X3_LDS_PAD", 8192));

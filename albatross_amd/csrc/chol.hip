@@ -1326,7 +1326,7 @@ void factor_lower(agp_context *ctx, double *A, long long n, long long lda, doubl
       p32_flip = !p32_flip;
       launch_convert_panel_bf16x3(sa, P, lda, n - kend, K, dst);
       P16 = dst;
-    } else if (variant == 5 && ctx->p32 && (n - kend) >= U1_F32_ABOVE && K % 32 == 0 && 2 * f16x2_bytes(n - kend, K) <= ctx->p32_bytes) {
+    } else if (variant == 5 && ctx->p32 && (n - kend) >= U1_F32_ABOVE && f16x2_depth_ok(K) && 2 * f16x2_bytes(n - kend, K) <= ctx->p32_bytes) {
       unsigned short *dst = reinterpret_cast<unsigned short *>(ctx->p32) + (size_t)(p32_flip ? 1 : 0) * (ctx->p32_bytes / sizeof(unsigned short) / 2);
       p32_flip = !p32_flip;
       launch_convert_panel_f16x2(sa, P, lda, n - kend, K, rs16 + kend, dst);

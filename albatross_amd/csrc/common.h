@@ -373,7 +373,8 @@ size_t f16x2_bytes(long long rows, long long K);
 void launch_f16x2_row_scales(hipStream_t s, const double *A, long long lda, long long n, double *rs, double *irs);
 void launch_convert_panel_f16x2(hipStream_t s, const double *P, long long ldp, long long rows, long long K, const double *rs,
                                 unsigned short *planes);
-void set_f16x2_kernel(int lds_pad, int terms);  // AGP_F16X2_LDS_PAD, AGP_F16X2_TERMS (3, or 4: with h2 h2)
+void set_f16x2_kernel(int lds_pad, int terms, int chunk);  // AGP_F16X2_LDS_PAD, AGP_F16X2_TERMS (3, or 4: with h2 h2), AGP_F16X2_CHUNK (32 / 64)
+bool f16x2_depth_ok(long long K);  // K a whole number of the kernel's K chunks
 void launch_update_f16x2(hipStream_t s, double *C, long long ldc, const unsigned short *planes, long long panel_rows, long long row_a,
                          long long row_b, const double *irs, long long M, long long N, long long K, const int *order = nullptr,
                          long long order_len = 0);
