@@ -351,6 +351,7 @@ void launch_trailing_update_as(int variant, hipStream_t s, double *C, long long 
                                long long ld32 = 0);
 void launch_trailing_update(hipStream_t s, double *C, long long ldc, const double *P, const double *Q,
                             long long ldp, long long M, long long K, BulkTiming *timing = nullptr);
+void read_bulk_probe(unsigned long long *out);   // gemm.hip: cycles and 100 MHz ticks of one tile of a -DAGP_BULK_STAMPS build (zeros otherwise)
 void read_bf16_probe(unsigned long long *out);   // gemm_bf16x3.hip: 8 words of a -DAGP_BF16_STAMPS build (zeros otherwise)
 void read_potrf_probe(unsigned long long *out);  // chol.hip: 4 x 32 cycle stamps of a -DAGP_POTRF_TIMING build (zeros otherwise)
 void launch_head_gate(hipStream_t s, const unsigned long long *done, unsigned long long expect, int *flags);  // chol.hip

@@ -946,6 +946,15 @@ AGP_DEBUG_API int agp_debug_potrf_probe(agp_context *ctx, unsigned long long *ou
   return AGP_OK;
 }
 
+// cycles and 100 MHz ticks of one tile of the LAST fp64 bulk launch (a -DAGP_BULK_STAMPS build; zeros otherwise)
+AGP_DEBUG_API int agp_debug_bulk_probe(agp_context *ctx, unsigned long long *out) {
+  if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;
+  AGP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  AGP_HIP_CHECK(ctx, hipDeviceSynchronize());
+  read_bulk_probe(out);
+  return AGP_OK;
+}
+
 // the phase cycle sums one workgroup of the LAST bf16 x 3 bulk launch left (a -DAGP_BF16_STAMPS build; zeros otherwise)
 AGP_DEBUG_API int agp_debug_bf16_probe(agp_context *ctx, unsigned long long *out) {
   if (!ctx || !out) return AGP_ERR_INVALID_ARGUMENT;

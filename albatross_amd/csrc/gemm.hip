@@ -90,8 +90,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_ext_kernel(GemmArgs g
 // (small_first / small_count): the launch ends with full rounds, and no second launch (round 3: trailing_update_tail_kernel
 // behind this one - 50-100 us per update during which a fraction of the chip worked) is needed for them.
 // Merged update (GemmArgs::head_cols): the tiles of the next block column come before everything else and are counted.
+// -DAGP_BULK_STAMPS (scripts/build_variant.sh bulk_stamps -DAGP_BULK_STAMPS; scripts/probe_bulk_clock.py): the workgroup in the
+// middle of the grid leaves the shader cycles (s_memtime) and the 100 MHz ticks (s_memrealtime) of its whole tile: the clock
+// the chip holds under the fp64 bulk update = 100 MHz x cycles / ticks.
+#ifdef AGP_BULK_STAMPS
+__device__ unsigned long long g_bulk_probe[4];
+void read_bulk_probe(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bulk_probe), sizeof(unsigned long long) * 4); }
+#else
+void read_bulk_probe(unsigned long long *out) { for (int i = 0; i < 4; ++i) out[i] = 0; }
+#endif
+
 __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmArgs g) {
   __shared__ double lds[2 * 2 * GK * GLD];
+#ifdef AGP_BULK_STAMPS
+  const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   long long wg = blockIdx.x;
   const bool head = wg < g.head_count;
   int bi, bj = 0;
@@ -133,6 +146,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void trailing_update_kernel(GemmAr
   }
   if (tile_takes_cpf(g, bi, bj)) gemm_nt_sub_tile_cpf<false, false>(g, bi, bj, lds);
   else gemm_nt_sub_tile<false, false>(g, bi, bj, lds);
+#ifdef AGP_BULK_STAMPS
+  if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    g_bulk_probe[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
+    g_bulk_probe[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+  }
+#endif
   if (head) {
     // every store of the tile acknowledged, then one count: the RELEASE writes this XCD's L2 back, and the kernels that
     // read the tile start behind the gate kernel that saw the count (their start is the matching ACQUIRE)
