@@ -551,7 +551,12 @@ def other_configs(ab, ctx):
             "mixed_stages_ms": {"gram": stages[0], "factor": stages[1], "refinement_and_solve": stages[2]},
             "cg_steps": int(its), "cg_relative_residual": float(rel_res),
             "information_rel_err_vs_fp64": float(np.abs(amx - a64).max() / np.abs(a64).max()),
-            "log_det_rel_err_vs_fp64": float(abs(ldm - ld64) / abs(ld64))}
+            "log_det_rel_err_vs_fp64": float(abs(ldm - ld64) / abs(ld64)),
+            "log_det_abs_err_over_n": float(abs(ldm - ld64) / n),
+            "mixed_products": ("fp32 MFMA (AGP_MIXED_BF16=0)" if os.environ.get("AGP_MIXED_BF16", "1") == "0" else
+                               "bf16 x 3, six products per block (AGP_MIXED_F16=0)" if os.environ.get("AGP_MIXED_F16", "1") == "0" else
+                               "fp16 x 2 planes of power-of-two-scaled rows, four exact products per block, fp32 accumulation "
+                               "inside a launch (csrc/gemm_f16x2.hip)")}
     except Exception as exc:  # noqa: BLE001
         out["config4"] = {"error": f"{type(exc).__name__}: {exc}"}
 
