@@ -23,7 +23,10 @@
 //
 //   convert_panel_f16x2    fp64 panel of one outer step -> two fp16 planes [plane][k / 32][row][k % 32] (as the bf16 planes)
 //   trailing_update_f16x2_kernel   128 x 128 tile of C per workgroup, 64 x 64 per wave (16 accumulators), K in chunks of 32
-//                          through one LDS stage (unpadded 64-B rows, 16-B pieces swizzled as in gemm_bf16x3.hip), 32 KB of LDS
+//                          through one LDS stage (unpadded 64-B rows, 16-B pieces swizzled as in gemm_bf16x3.hip), 32 KB of LDS;
+//                          the fp64 C of the tile comes in one accumulator column (16 doubles per lane) at a time, the first
+//                          requested in front of the last chunk's matrix instructions, each next one before the previous is
+//                          stored (+1 % on the kernel, -1 % on the fit against two columns loaded and stored in turn)
 #include "common.h"
 #include "gemm_tiles.h"
 
@@ -185,8 +188,32 @@ __global__ __launch_bounds__(256, 2) void trailing_update_f16x2_kernel(F16Args g
     for (int b = 0; b < 4; ++b) acc[a][b] = v4f32{0.f, 0.f, 0.f, 0.f};
 
   const long long nk = g.K / CH;
+#define AGP_H_COMPUTE()                                                                                                                  \
+  do {                                                                                                                                   \
+    _Pragma("unroll") for (int t = 0; t < CH / MK; ++t) { /* the matrix instruction's k steps inside the stage */                         \
+      v8h fa[2][4], fb[2][4];                                                                                                            \
+      _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                                  \
+          fa[p][q] = *reinterpret_cast<const v8h *>(lds + p * PLANE + (64 * wc + 16 * q + ln) * CH + 8 * sw_piece<CH>(4 * t + lg, ln));  \
+          fb[p][q] = *reinterpret_cast<const v8h *>(lds + (2 + p) * PLANE + (64 * wr + 16 * q + ln) * CH + 8 * sw_piece<CH>(4 * t + lg, ln)); \
+        }                                                                                                                                \
+      _Pragma("unroll") for (int tj = 0; tj < 4; ++tj)                                                                                   \
+        _Pragma("unroll") for (int ti = 0; ti < 4; ++ti) {                                                                               \
+          v4f32 a = acc[tj][ti];                                                                                                         \
+          if (TERMS == 4) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][tj], fb[1][ti], a, 0, 0, 0); /* h2 h2 */                       \
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][tj], fb[0][ti], a, 0, 0, 0); /* h2 h1 (smallest terms first) */               \
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][tj], fb[1][ti], a, 0, 0, 0); /* h1 h2 */                                      \
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][tj], fb[0][ti], a, 0, 0, 0); /* h1 h1 */                                      \
+          acc[tj][ti] = a;                                                                                                               \
+        }                                                                                                                                \
+    }                                                                                                                                    \
+  } while (0)
+  // C of this wave's quadrant (register r of accumulator (tj, ti): row 16 ti + ln of the quadrant, column 16 tj + 4 lg + r)
+  const long long rbase = i0 + 64 * wr + ln, cbase_col = j0 + 64 * wc + 4 * lg;
+  const bool interior = i0 + GT <= g.M && j0 + GT <= g.N;
+  double *const cbase = g.C + rbase + cbase_col * g.ldc;
   AGP_H_LOAD(0);
-  for (long long kc = 0; kc < nk; ++kc) {
+  for (long long kc = 0; kc + 1 < nk; ++kc) {
     if (kc > 0) __syncthreads();  // every wave has read chunk kc - 1 out of the stage
 #if defined(AGP_DIAG_F16_NOSTORE)  // diagnostic builds (wrong results): which part of the loop the time is in
     if (kc == 0) AGP_H_STORE();
@@ -197,64 +224,60 @@ __global__ __launch_bounds__(256, 2) void trailing_update_f16x2_kernel(F16Args g
 #if defined(AGP_DIAG_F16_NOLOAD) || defined(AGP_DIAG_F16_NOSTORE)
     asm volatile("" ::: "memory");
 #else
-    AGP_H_LOAD((kc + 1 < nk ? kc + 1 : kc) * chunk_stride);  // (unconditional: a guarded load kept the staging registers in scratch)
+    AGP_H_LOAD((kc + 1) * chunk_stride);
 #endif
-#pragma unroll
-    for (int t = 0; t < CH / MK; ++t) {  // the matrix instruction's k steps inside the stage
-      v8h fa[2][4], fb[2][4];
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          fa[p][q] = *reinterpret_cast<const v8h *>(lds + p * PLANE + (64 * wc + 16 * q + ln) * CH + 8 * sw_piece<CH>(4 * t + lg, ln));
-          fb[p][q] = *reinterpret_cast<const v8h *>(lds + (2 + p) * PLANE + (64 * wr + 16 * q + ln) * CH + 8 * sw_piece<CH>(4 * t + lg, ln));
-        }
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          v4f32 a = acc[tj][ti];
-          if (TERMS == 4) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][tj], fb[1][ti], a, 0, 0, 0);  // h2 h2
-          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][tj], fb[0][ti], a, 0, 0, 0);  // h2 h1 (smallest terms first)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][tj], fb[1][ti], a, 0, 0, 0);  // h1 h2
-          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][tj], fb[0][ti], a, 0, 0, 0);  // h1 h1
-          acc[tj][ti] = a;
-        }
-    }
+    AGP_H_COMPUTE();
   }
+  // the last chunk: nothing left to load for the loop - the first batch of C (one accumulator column: 16 doubles) is requested in
+  // front of its matrix instructions instead, and the epilogue below keeps one batch in flight behind the one it stores
+  if (nk > 1) __syncthreads();
+#if defined(AGP_DIAG_F16_NOSTORE)
+  if (nk == 1) AGP_H_STORE();
+#else
+  AGP_H_STORE();
+#endif
+  __syncthreads();
+  double cv0[4][4], cv1[4][4];
+  if (interior) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv0[ti][r] = __builtin_nontemporal_load(&cbase[16 * ti + (long long)r * g.ldc]);
+  }
+  AGP_H_COMPUTE();
+#undef AGP_H_COMPUTE
 #undef AGP_H_LOAD
 #undef AGP_H_STORE
 #undef AGP_H_LOAD1
 #undef AGP_H_STORE1
-  // C -= acc / (r_row r_col) (register r of accumulator (tj, ti): row 16 ti + ln of the quadrant, column 16 tj + 4 lg + r)
-  const long long rbase = i0 + 64 * wr + ln, cbase_col = j0 + 64 * wc + 4 * lg;
+  // C -= acc / (r_row r_col)
   double ir_row[4];
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) ir_row[ti] = (rbase + 16 * ti < g.M) ? g.irs_a[rbase + 16 * ti] : 0.;
-  if (i0 + GT <= g.M && j0 + GT <= g.N) {
-    double *const cbase = g.C + rbase + cbase_col * g.ldc;
-#pragma unroll
-    for (int t0 = 0; t0 < 4; t0 += 2) {  // the C of two accumulator columns in flight at a time
-      double cv[2][4][4], ic[2][4];
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ic[e][r] = g.irs_b[cbase_col + 16 * (t0 + e) + r];
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cv[e][ti][r] = __builtin_nontemporal_load(&cbase[16 * ti + (long long)(16 * (t0 + e) + r) * g.ldc]);
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            __builtin_nontemporal_store(cv[e][ti][r] - (double)acc[t0 + e][ti][r] * (ir_row[ti] * ic[e][r]),
-                                        &cbase[16 * ti + (long long)(16 * (t0 + e) + r) * g.ldc]);
-    }
+  if (interior) {
+    // software pipeline over the four accumulator columns: column tj + 1 is requested before column tj is stored
+#define AGP_H_EPI_LOAD(DST, TJ)                                                                                          \
+  _Pragma("unroll") for (int ti = 0; ti < 4; ++ti)                                                                       \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                        \
+      DST[ti][r] = __builtin_nontemporal_load(&cbase[16 * ti + (long long)(16 * (TJ) + r) * g.ldc])
+#define AGP_H_EPI_STORE(SRC, TJ)                                                                                         \
+  do {                                                                                                                   \
+    double ic_[4];                                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) ic_[r] = g.irs_b[cbase_col + 16 * (TJ) + r];                           \
+    _Pragma("unroll") for (int ti = 0; ti < 4; ++ti)                                                                     \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                      \
+        __builtin_nontemporal_store(SRC[ti][r] - (double)acc[TJ][ti][r] * (ir_row[ti] * ic_[r]),                         \
+                                    &cbase[16 * ti + (long long)(16 * (TJ) + r) * g.ldc]);                               \
+  } while (0)
+    AGP_H_EPI_LOAD(cv1, 1);
+    AGP_H_EPI_STORE(cv0, 0);
+    AGP_H_EPI_LOAD(cv0, 2);
+    AGP_H_EPI_STORE(cv1, 1);
+    AGP_H_EPI_LOAD(cv1, 3);
+    AGP_H_EPI_STORE(cv0, 2);
+    AGP_H_EPI_STORE(cv1, 3);
+#undef AGP_H_EPI_LOAD
+#undef AGP_H_EPI_STORE
     return;
   }
 #pragma unroll

@@ -10,6 +10,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 B=/tmp/agp_variant_build_$NAME
 rm -rf "$B" && mkdir -p "$B/albatross_amd" "$B/include" && cp -r "$ROOT/albatross_amd/csrc" "$B/albatross_amd/" && cp "$ROOT/include/albatross_amd.h" "$B/include/"
 rm -rf "$B/albatross_amd/csrc/build"
-make -s -j8 -C "$B/albatross_amd/csrc" HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-result $*"
+# (EXTRA, not HIPFLAGS: a HIPFLAGS given on the command line would switch off the per-file -ffp-contract=off of gram.o / ldlt.o)
+make -s -j8 -C "$B/albatross_amd/csrc" EXTRA="$*"
 mkdir -p "$ROOT/scripts/variants/$NAME" && cp "$B/albatross_amd/"libalbatross_amd*.so "$ROOT/scripts/variants/$NAME/"
 rm -rf "$B"
