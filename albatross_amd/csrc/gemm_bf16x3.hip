@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void trailing_update_bf16x3_pair_kernel(Bf1
 #else
     AGP_BF_LOAD((kc + 1 < nk ? kc + 1 : kc) * chunk_stride);  // (unconditional: a guarded load kept the staging registers in scratch)
 #endif
-#ifdef AGP_BF16_EARLY_LOADS
+#ifdef AGP_BF16_EARLY_LOADS  // (measured, round 6: 198 registers, the waiting phase 1790 -> 1000 cycles, the matrix phase longer by as much)
     __builtin_amdgcn_sched_barrier(0);  // the loads of the next chunk stay in front of this chunk's MFMAs
 #endif
     v8bf fa[3][4], fb[3][4];
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void trailing_update_bf16x3_pair_kernel(Bf1
   if (i0 + GT <= g.M && j0 + GT <= g.N) {
     double *const cbase = g.C + (i0 + 64 * wr + ln) + (j0 + 64 * wc + 4 * lg) * g.ldc;
 #ifndef AGP_BF16_EPI
-#define AGP_BF16_EPI 1
+#define AGP_BF16_EPI 2  // (1: 163 registers, the epilogue 22 % longer and the kernel 1 % slower; 4: spills)
 #endif
     constexpr int EPI = AGP_BF16_EPI;  // accumulator columns (of four) whose C is in flight at a time
 #pragma unroll
