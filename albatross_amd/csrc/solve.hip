@@ -63,6 +63,9 @@ void forward_solve_mat_lookahead(agp_context *ctx, const double *A, long long n,
     forward_solve_mat(sa, A, n, lda, invd, B, m, ldb, rhs_lower);
     return;
   }
+  // (AGP_SOLVE_NBO: measurement switch - outer block width of this substitution, a multiple of 128)
+  static const long long nbo_env = [] { const char *e = getenv("AGP_SOLVE_NBO"); const long long v = e && e[0] ? atoll(e) : 0; return (v >= 128 && v % 128 == 0) ? v : (long long)NBO; }();
+  const long long NBO = nbo_env;
   bool have_u2 = false;
   for (long long K0 = 0; K0 < n; K0 += NBO) {
     const long long kend = (K0 + NBO < n) ? K0 + NBO : n;

@@ -657,6 +657,8 @@ AGP_API int agp_set_profiling(agp_context *ctx, int enabled);
  *   AGP_BF16X3_KERNEL=1      ... with the first bf16 x 3 tile kernel (one workgroup per CU) instead of the pair kernel
  *   AGP_BF16X3_LDS_PAD=<b>   extra LDS bytes per workgroup of the pair kernel (default 8192: two per CU; 0: three)
  *   AGP_MIXED_NBO=<w>        outer block width of the mixed factorisation while > 8192 rows remain (default 512)
+ *   AGP_SOLVE_NBO=<w>        outer block width of the forward substitution with many right-hand sides (predictions; default 512;
+ *                            measured flat from 256 to 1024: profiles/r06/time_predict_marginal_nbo.txt)
  *   AGP_FP64_NBO=<w>         the same for the fp64 factorisation (default 0 = 512)
  *   AGP_GEMM_SMALL_LIMIT=<t> 64 x 64 instead of 128 x 128 tiles for products of fewer than t 128-tiles (default 512)
  *   AGP_BACKSUB_COOP=0       the fit's back substitution as one launch per block (rounds 1-4) instead of ONE launch
