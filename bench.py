@@ -32,6 +32,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# A context of the library has four HIP streams, and the HIP runtime multiplexes the streams of a process onto
+# GPU_MAX_HW_QUEUES (default 4) hardware queues: with a second or third context in the process (configs.fits_in_flight)
+# streams share queues and one fit's panel chain sits behind another's bulk update - measured: two fits in flight 37.0
+# fits/s with 8 queues, 35.1 with the default once a third context merely exists; one fit at a time: the same either way
+# (profiles/r06/time_fits_in_flight.txt).  Read by the runtime when it initialises, so it is set before the library loads.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_TRAIN = 16384
 DIM = 3
@@ -616,6 +622,73 @@ def other_configs(ab, ctx):
                                               "inputs resident in HBM, one GPU; n^3/3 flop over the whole fit", "rows": rows}
     except Exception as exc:  # noqa: BLE001
         out["config3_large_n"] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # ---- independent fits in flight: T host threads, each with a context of its own, issue fits of the headline problem
+    # (and of config 2's size) concurrently on this GPU - the chain-bound tail and the substitution of one fit run beside the
+    # bulk phase of another.  The headline `value` stays ONE fit at a time (a fit's latency is its reciprocal); this is the
+    # throughput a caller with several independent datasets or parameter vectors gets (the tuner's P + 1 objective evaluations,
+    # tune/finite_difference.hpp:20-94, at sizes beyond agp_nll_batch's lock-step launches).  Thread i starts i / T of a fit
+    # late (started together the fits run in lock step and gain nothing).  Which hardware queue the runtime gives a context's
+    # streams differs from context to context and the result with it (34.5 or 37.5 fits/s at T = 2, profiles/r06/
+    # time_fits_in_flight.txt): three attempts with fresh contexts, all reported, the best one quoted.
+    try:
+        import threading
+        cov3 = ab.SquaredExponential(1.0, 1.0) + ab.IndependentNoise(0.1)
+        rows = []
+
+        def attempt(n, x, y, threads, fits):
+            ctxs = [ab.Context(ctx.device_id) for _ in range(threads)]
+            try:
+                state = []
+                for c in ctxs:
+                    x_d, y_d = c.to_device(x), c.to_device(y)
+                    state.append((c, c.kernel(cov3), _device_features(capi, x_d, n), y_d, x_d))
+                gate = threading.Barrier(threads)
+                took, failed = [0.] * threads, []
+
+                def run(i):
+                    c, kh_i, feats_i, y_i, _ = state[i]
+
+                    def one():
+                        h = C.c_void_p()
+                        st = c._lib.agp_fit_create(c._h, kh_i, C.byref(feats_i), C.c_void_p(y_i.ptr), None, C.byref(h), None, None)
+                        if st != capi.AGP_OK:
+                            failed.append(st)
+                        c._lib.agp_fit_destroy(h)
+                    for _ in range(2):
+                        one()
+                    t0 = time.perf_counter()
+                    one()
+                    single = time.perf_counter() - t0
+                    gate.wait()
+                    t0 = time.perf_counter()
+                    time.sleep(i * single / threads)
+                    for _ in range(fits):
+                        one()
+                    took[i] = time.perf_counter() - t0
+                th = [threading.Thread(target=run, args=(i,)) for i in range(threads)]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+                if failed:
+                    raise RuntimeError(f"agp_fit_create returned {failed[0]}")
+                del state
+                return threads * fits / max(took)
+            finally:
+                for c in ctxs:
+                    c.close()
+
+        for n, fits in ((N_TRAIN, 10), (4096, 40)):
+            x, y = make_dataset(n, 44)
+            for threads in (1, 2):
+                rates = [attempt(n, x, y, threads, fits) for _ in range(1 if threads == 1 else 3)]
+                rows.append({"n": n, "threads": threads, "fits_per_sec": max(rates), "attempts_fits_per_sec": rates})
+        out["fits_in_flight"] = {"workload": "independent fp64 fits of config 3's problem (and of its N = 4096 sub-problem), inputs "
+                                             "resident in HBM, one context and one host thread per fit in flight, one GPU; "
+                                             "fits_per_sec = the best attempt", "rows": rows}
+    except Exception as exc:  # noqa: BLE001
+        out["fits_in_flight"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 
