@@ -219,8 +219,11 @@ inline int &default_device() {
   return device;
 }
 
+// One context per HOST THREAD: contexts are independent and thread-safe against each other (a context itself serves one
+// thread at a time), so threads that fit independent datasets run concurrently on the GPU - one fit's chain-bound tail beside
+// another's bulk phase (bench.py configs.fits_in_flight).  Objects keep the context they were made with alive.
 inline std::shared_ptr<ContextHolder> default_context() {
-  static std::shared_ptr<ContextHolder> c = std::make_shared<ContextHolder>(default_device());
+  static thread_local std::shared_ptr<ContextHolder> c = std::make_shared<ContextHolder>(default_device());
   return c;
 }
 
