@@ -32,12 +32,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# A context of the library has four HIP streams, and the HIP runtime multiplexes the streams of a process onto
-# GPU_MAX_HW_QUEUES (default 4) hardware queues: with a second or third context in the process (configs.fits_in_flight)
-# streams share queues and one fit's panel chain sits behind another's bulk update - measured: two fits in flight 37.0
-# fits/s with 8 queues, 35.1 with the default once a third context merely exists; one fit at a time: the same either way
-# (profiles/r06/time_fits_in_flight.txt).  Read by the runtime when it initialises, so it is set before the library loads.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_TRAIN = 16384
 DIM = 3
