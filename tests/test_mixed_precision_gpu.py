@@ -1,6 +1,7 @@
-"""BASELINE.json configs[3] / SURVEY.md section 8d config 4: the mixed-precision fit (agp_fit_create_mixed: fp32 MFMA
-products in the bulk trailing updates, fp64 panel chain and accumulation, fp64 conjugate-gradient refinement of the
-information vector) against the oracle and against the all-fp64 fit.
+"""BASELINE.json configs[3] / SURVEY.md section 8d config 4: the mixed-precision fit (agp_fit_create_mixed: the products of
+the bulk trailing updates from split 16-bit planes with fp32 accumulation inside a launch - or, AGP_MIXED_BF16=0, on the fp32
+MFMA -, fp64 panel chain and accumulation between launches, fp64 conjugate-gradient refinement of the information vector)
+against the oracle and against the all-fp64 fit.
 
 Stated tolerances: information vector and predicted means 1e-8 relative (the same as the fp64 path: the refinement
 runs to a 1e-12 relative residual); predictive variances 1e-4 relative; log-determinant on the default path (fp16 x 2
